@@ -1,0 +1,614 @@
+"""CPU oracle for the QuIP# inference hot path (numpy restatement).
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is part of the product:
+only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import it, and only as the checker.  The product path
+(``quip_for_all_amd``) never imports this module and fails loudly when its HIP
+extension is missing.
+
+Parity pin: every table / function below is checked against the reference's own
+Python (imported in the authoring container by ``tests/golden/make_golden.py``)
+through the fixtures committed under ``tests/golden/``; see
+``tests/test_oracle_golden.py``.  The CUDA kernels of the reference cannot be
+built here (nvcc / PTX), so the kernel-side statements are pinned through the
+identities listed in SURVEY.md section 4 (decode identity, path identity, FHT
+identity).
+
+Each function cites the reference ``file:line`` (relative to the reference
+checkout) whose behaviour it restates.
+"""
+from __future__ import annotations
+
+import itertools
+import math
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+# --------------------------------------------------------------------------
+# E8P12 tables
+# --------------------------------------------------------------------------
+
+# Position p of an 8-group reads byte _E8P_BYTE_OF_POS[p] of the packed abs
+# entry (codebook/e8p12.py:86 ``shuffle_map``; origin_order.cu:846-856 store
+# order of the half2 pairs).
+E8P_BYTE_OF_POS = (0, 2, 1, 3, 4, 6, 5, 7)
+
+# The 29 norm-12 points appended after the 227 |D8^| points
+# (codebook/e8p12.py:28-60); entries are 2*value, i.e. 3 -> 3/2, 1 -> 1/2.
+_NORM12_TWICE = (
+    "31113333 13113333 11313333 11133333 33313311 33313131 33311331 33313113 "
+    "33311313 33311133 33133311 33133131 33131331 33133113 33131313 33131133 "
+    "31333311 31333131 31331331 31333113 31331313 13331133 13333311 13333131 "
+    "13331331 13333113 13331313 11331333 33113331"
+).split()
+
+
+def e8p_abs_rows() -> np.ndarray:
+    """(256, 8) float64 rows of the E8P12 abs codebook *before* column
+    permutation / packing (codebook/e8p12.py:64-71).
+
+    |D8^| = abs values of the points of (Z+1/2)^8 with even coordinate sum and
+    squared norm <= 10.  A sign flip of one half-integer coordinate changes the
+    coordinate sum by an odd integer, so every abs pattern with norm <= 10 is
+    reachable; the set is therefore all patterns over {1/2,3/2,5/2,7/2}^8 with
+    squared norm <= 10, in lexicographic order (``torch.unique(dim=0)`` sorts).
+    """
+    vals = (0.5, 1.5, 2.5, 3.5)
+    rows = [p for p in itertools.product(vals, repeat=8)
+            if sum(v * v for v in p) <= 10.0]
+    rows.sort()
+    d8abs = np.asarray(rows, dtype=np.float64)
+    n12 = np.asarray([[int(ch) / 2.0 for ch in s] for s in _NORM12_TWICE],
+                     dtype=np.float64)
+    out = np.concatenate([d8abs, n12], axis=0)
+    assert out.shape == (256, 8), out.shape
+    return out
+
+
+def e8p_grid_packed_abs() -> np.ndarray:
+    """int64[256] ``grid_packed_abs`` (codebook/e8p12.py:63-79).
+
+    Columns are permuted by [0,2,1,3,4,6,5,7]; column 7 is negated where the
+    row sum is odd; values are multiplied by 4 and packed little-endian, one
+    int8 per byte.
+    """
+    cba = e8p_abs_rows()[:, list(E8P_BYTE_OF_POS)].copy()
+    odd = (cba.sum(axis=1) % 2.0) != 0.0
+    cba[odd, 7] *= -1.0
+    b = (cba * 4.0).astype(np.int64)  # may be negative in column 7
+    acc = b[:, 0].copy()
+    for i in range(1, 8):
+        # python-int semantics of the reference: OR of sign-extended shifted
+        # values; replicate with int64 arithmetic (wraps identically).
+        acc = acc | (b[:, i] << np.int64(8 * i))
+    return acc.astype(np.int64)
+
+
+def _popcount8(a: np.ndarray) -> np.ndarray:
+    a = a.astype(np.uint8)
+    a = (a & 0x55) + ((a >> 1) & 0x55)
+    a = (a & 0x33) + ((a >> 2) & 0x33)
+    return ((a & 0x0F) + (a >> 4)).astype(np.uint8)
+
+
+def e8p_decode_i8(codes: np.ndarray, grid_packed_abs: Optional[np.ndarray] = None
+                  ) -> np.ndarray:
+    """Decode uint16 E8P12 codes to int8 ``4*w`` with shape codes.shape+(8,).
+
+    Restates ``get_full_grid`` (codebook/e8p12.py:82-103), which SURVEY 4.1
+    shows equal to the kernel's ``decode8weights`` + unpack + store order
+    (origin_order.cu:211-231, 837-857):
+
+        par = popcount(sign) & 1 ; sv = sign ^ par
+        w[p] = (bit(sv, 7-b) ? -P.byte[b] : P.byte[b]) / 4 + (par ? -1/4 : +1/4)
+        with b = [0,2,1,3,4,6,5,7][p]
+    """
+    if grid_packed_abs is None:
+        grid_packed_abs = e8p_grid_packed_abs()
+    c = np.asarray(codes).astype(np.uint16)
+    sign = (c & 0xFF).astype(np.uint8)
+    absi = (c >> 8).astype(np.intp)
+    par = (_popcount8(sign) & 1).astype(np.uint8)
+    sv = sign ^ par
+    table = np.ascontiguousarray(grid_packed_abs).view(np.int8).reshape(256, 8)
+    pbytes = table[absi]  # (..., 8) int8, byte index
+    out = np.empty(c.shape + (8,), dtype=np.int16)
+    for p, b in enumerate(E8P_BYTE_OF_POS):
+        v = pbytes[..., b].astype(np.int16)
+        neg = ((sv >> (7 - b)) & 1).astype(bool)
+        out[..., p] = np.where(neg, -v, v)
+    out += np.where(par.astype(bool), -1, 1).astype(np.int16)[..., None]
+    return out.astype(np.int8)
+
+
+def e8p_full_grid_i8() -> np.ndarray:
+    """int8[65536, 8] = 4 * full E8P12 grid, row c = decode of code c."""
+    return e8p_decode_i8(np.arange(1 << 16, dtype=np.uint32).astype(np.uint16))
+
+
+# --------------------------------------------------------------------------
+# E8P12RVQ3B residual table (1-bit E8)
+# --------------------------------------------------------------------------
+
+def e81b_grid() -> np.ndarray:
+    """float64[256, 8] residual codebook (codebook/e8p12_rvq3.py:16-50).
+
+    E8 points with squared norm <= 2 in ``torch.cartesian_prod`` enumeration
+    order (first coordinate slowest, values ascending): integer points first
+    (the zero vector and the 112 roots with two +-1 entries), then the 128
+    half-integer roots with an even number of minus signs; followed by 15
+    literal +-2 e_i rows (-2 e_7 is deliberately absent).
+    """
+    ints = [p for p in itertools.product((-1, 0, 1), repeat=8)
+            if sum(v * v for v in p) <= 2 and sum(p) % 2 == 0]
+    halves = [p for p in itertools.product((-0.5, 0.5), repeat=8)
+              if sum(p) % 2 == 0]
+    ints.sort()
+    halves.sort()
+    rows = [list(map(float, p)) for p in ints] + [list(p) for p in halves]
+    for sgn in (2.0, -2.0):
+        for i in range(8):
+            if sgn < 0 and i == 7:
+                continue
+            r = [0.0] * 8
+            r[i] = sgn
+            rows.append(r)
+    out = np.asarray(rows, dtype=np.float64)
+    assert out.shape == (256, 8), out.shape
+    return out
+
+
+E81B_COL_OF_NIBBLE = (0, 2, 4, 6, 1, 3, 5, 7)
+
+
+def e81b_grid_packed(grid: Optional[np.ndarray] = None) -> np.ndarray:
+    """int32[256]: nibble i = int4(2 * grid[:, [0,2,4,6,1,3,5,7][i]])
+    (codebook/e8p12_rvq3.py:53-62)."""
+    if grid is None:
+        grid = e81b_grid()
+    v = (grid[:, list(E81B_COL_OF_NIBBLE)] * 2.0).astype(np.int64) & 0xF
+    acc = np.zeros(256, dtype=np.int64)
+    for i in range(8):
+        acc |= v[:, i] << (4 * i)
+    return acc.astype(np.uint32).view(np.int32)
+
+
+def e81b_decode_twice(resid_idx: np.ndarray, packed: Optional[np.ndarray] = None
+                      ) -> np.ndarray:
+    """int8 ``2*value`` of the residual rows, shape idx.shape+(8,), restating
+    the kernel's unpack (origin_order.cu:908-922): positions (0,1)=(nib0,nib4),
+    (2,3)=(nib1,nib5), (4,5)=(nib2,nib6), (6,7)=(nib3,nib7); nibble is int4."""
+    if packed is None:
+        packed = e81b_grid_packed()
+    w = packed.view(np.uint32)[np.asarray(resid_idx).astype(np.intp)]
+    out = np.empty(w.shape + (8,), dtype=np.int8)
+    nib_of_pos = (0, 4, 1, 5, 2, 6, 3, 7)
+    for p, nb in enumerate(nib_of_pos):
+        n = ((w >> np.uint32(4 * nb)) & np.uint32(0xF)).astype(np.int16)
+        out[..., p] = np.where(n >= 8, n - 16, n).astype(np.int8)
+    return out
+
+
+# --------------------------------------------------------------------------
+# D4 and HI tables
+# --------------------------------------------------------------------------
+
+def d4_grid() -> np.ndarray:
+    """float64[256, 4] D4 codebook (codebook/d4.py:26-96)."""
+    def signs(i3, x):
+        x = list(x)
+        if i3 & 0x20:
+            x[2] = -x[2]
+        if i3 & 0x40:
+            x[1] = -x[1]
+        if sum(x) % 2 != 0:
+            x[3] = -x[3]
+        if i3 & 0x80:
+            x = [-v for v in x]
+        return x
+
+    def base(lo):
+        h, o, t = 0.5, 1.5, 2.5
+        if lo == 0:
+            return [h] * 4
+        if lo == 1:
+            return [o] * 4
+        if lo < 8:
+            j = lo >> 1
+            x = [h] * 4 if (lo & 1) else [o] * 4
+            x[0] = x[j] = o if (lo & 1) else h
+            return x
+        if lo < 12:
+            x = [h] * 4
+            x[lo & 3] = o
+            return x
+        if lo < 16:
+            x = [o] * 4
+            x[lo & 3] = h
+            return x
+        if lo < 20:
+            x = [h] * 4
+            x[lo & 3] = t
+            return x
+        r = lo - 20
+        i4, i3 = r & 3, r >> 2
+        x = [h] * 4
+        x[i4] = o
+        if i3 >= i4:
+            i3 += 1
+        x[i3] = t
+        return x
+
+    return np.asarray([signs(c & 0xE0, base(c & 31)) for c in range(256)],
+                      dtype=np.float64)
+
+
+HI_COL_OF_NIBBLE = (0, 2, 4, 6, 1, 3, 5, 7)
+
+
+def hi_pack(idx: np.ndarray) -> np.ndarray:
+    """Pack 4-bit indices (rows, cols) -> int32 (rows, cols/8)
+    (codebook/hi.py:41-50): nibble i holds column [0,2,4,6,1,3,5,7][i]."""
+    idx = np.asarray(idx).astype(np.int64)
+    acc = np.zeros((idx.shape[0], idx.shape[1] // 8), dtype=np.int64)
+    for i, col in enumerate(HI_COL_OF_NIBBLE):
+        acc += idx[:, col::8] << (4 * i)
+    return acc.astype(np.uint32).view(np.int32)
+
+
+def hi_decode_twice(codes: np.ndarray) -> np.ndarray:
+    """int8 ``2*w`` for HI codes, shape codes.shape+(8,): w = nibble - 7.5
+    (origin_order.cu:1028-1051)."""
+    w = np.asarray(codes).view(np.uint32) if np.asarray(codes).dtype == np.int32 \
+        else np.asarray(codes).astype(np.uint32)
+    out = np.empty(w.shape + (8,), dtype=np.int8)
+    nib_of_pos = (0, 4, 1, 5, 2, 6, 3, 7)
+    for p, nb in enumerate(nib_of_pos):
+        n = ((w >> np.uint32(4 * nb)) & np.uint32(0xF)).astype(np.int16)
+        out[..., p] = (2 * n - 15).astype(np.int8)
+    return out
+
+
+# --------------------------------------------------------------------------
+# dense weight reconstruction ("decompress_*_origorder")
+# --------------------------------------------------------------------------
+
+def _f16(a):
+    return np.asarray(a, dtype=np.float16)
+
+
+def _fma_f16(scale: float, resid: np.ndarray, main: np.ndarray) -> np.ndarray:
+    """fp16 fused multiply-add with one rounding: fp16(scale_h*resid + main),
+    restating ``__hfma2(scale2, resid, main)`` with
+    ``scale2 = __float2half2_rn(scale)`` (origin_order.cu:330-331, 378-380).
+    All operands are fp16-exact; the product and sum are exact in float64
+    (11-bit x 6-bit significands), so rounding float64 -> fp16 once is the fma.
+    """
+    s = np.float64(np.float16(scale))
+    return (s * resid.astype(np.float64) + main.astype(np.float64)).astype(np.float16)
+
+
+def decompress_e8p(qidxs: np.ndarray, grid_packed_abs=None) -> np.ndarray:
+    """fp16 (rows, cols*8) dense weights (origin_order.cu:837-885)."""
+    q = np.ascontiguousarray(qidxs).view(np.uint16)
+    w = e8p_decode_i8(q, grid_packed_abs).astype(np.float32) / 4.0
+    return w.reshape(q.shape[0], -1).astype(np.float16)
+
+
+def decompress_e8prvq4(qidxs: np.ndarray, scale: float, grid_packed_abs=None
+                       ) -> np.ndarray:
+    """fp16 (rows, cols*8): E8P(hi16) (+) fp16(scale)*E8P(lo16), one fp16 fma
+    (origin_order.cu:956-995; code = (main << 16) + resid,
+    codebook/e8p12_rvq4.py:37-46)."""
+    q = np.ascontiguousarray(qidxs).view(np.uint32)
+    main = e8p_decode_i8((q >> 16).astype(np.uint16), grid_packed_abs)
+    res = e8p_decode_i8((q & 0xFFFF).astype(np.uint16), grid_packed_abs)
+    w = _fma_f16(scale, res.astype(np.float64) / 4.0, main.astype(np.float64) / 4.0)
+    return w.reshape(q.shape[0], -1)
+
+
+def rvq3_split(qidxs: np.ndarray):
+    """View an (rows, cols) int32 RVQ3 tensor as its 3-byte codes: returns
+    (main uint16, resid uint8), each (rows, cols*4/3)
+    (codebook/e8p12_rvq3.py:102-107; origin_order.cu:895-897: byte0 = residual
+    index, byte1 = sign byte, byte2 = abs index)."""
+    b = np.ascontiguousarray(qidxs).view(np.uint8).reshape(qidxs.shape[0], -1, 3)
+    resid = b[..., 0]
+    main = b[..., 1].astype(np.uint16) | (b[..., 2].astype(np.uint16) << 8)
+    return main, resid
+
+
+def rvq3_pack(idx24: np.ndarray) -> np.ndarray:
+    """Pack int32 indices ``(main << 8) + resid`` (rows, cols) into the
+    byte-stream int32 tensor (rows, cols*3/4) (codebook/e8p12_rvq3.py:102-107).
+    """
+    a = np.ascontiguousarray(idx24.astype(np.int32)).view(np.uint8)
+    a = a.reshape(idx24.shape[0], idx24.shape[1], 4)[..., :3]
+    return np.ascontiguousarray(a.reshape(idx24.shape[0], -1)).view(np.int32)
+
+
+def decompress_e8prvq3(qidxs: np.ndarray, scale: float, grid_packed_abs=None,
+                       e81b_packed=None) -> np.ndarray:
+    """fp16 (rows, cols*32/3) (origin_order.cu:887-923)."""
+    main, resid = rvq3_split(qidxs)
+    m = e8p_decode_i8(main, grid_packed_abs).astype(np.float64) / 4.0
+    r = e81b_decode_twice(resid, e81b_packed).astype(np.float64) / 2.0
+    return _fma_f16(scale, r, m).reshape(qidxs.shape[0], -1)
+
+
+def decompress_d4(qidxs: np.ndarray, grid=None) -> np.ndarray:
+    """fp16 (rows, cols*4) (origin_order.cu:794-805)."""
+    if grid is None:
+        grid = d4_grid()
+    q = np.ascontiguousarray(qidxs).view(np.uint8)
+    return _f16(np.asarray(grid)[q.astype(np.intp)]).reshape(q.shape[0], -1)
+
+
+def decompress_hi(qidxs: np.ndarray) -> np.ndarray:
+    """fp16 (rows, cols*8) (origin_order.cu:1028-1051)."""
+    w = hi_decode_twice(np.ascontiguousarray(qidxs)).astype(np.float32) / 2.0
+    return w.reshape(qidxs.shape[0], -1).astype(np.float16)
+
+
+def decompress(codebook: str, qidxs, scale: float = 0.0) -> np.ndarray:
+    if codebook == "E8P12":
+        return decompress_e8p(qidxs)
+    if codebook == "E8P12RVQ4B":
+        return decompress_e8prvq4(qidxs, scale)
+    if codebook == "E8P12RVQ3B":
+        return decompress_e8prvq3(qidxs, scale)
+    if codebook == "D4":
+        return decompress_d4(qidxs)
+    if codebook == "HI":
+        return decompress_hi(qidxs)
+    raise KeyError(codebook)
+
+
+# --------------------------------------------------------------------------
+# Hadamard side
+# --------------------------------------------------------------------------
+
+def split_pow2(n: int):
+    """n = 2**e * base, base odd (quant.py:17-23)."""
+    e = 0
+    while n % 2 == 0:
+        n //= 2
+        e += 1
+    return e, n
+
+
+def fwht(a: np.ndarray) -> np.ndarray:
+    """Unnormalised Sylvester-ordered Walsh-Hadamard transform over the last
+    axis (length a power of two).  Same transform as the pairwise butterfly of
+    quant.py:51-60 and as ``fast_hadamard_transform`` (register_lib.py:18-20):
+    out[m] = sum_j (-1)^popcount(m & j) a[j]."""
+    a = np.array(a, dtype=np.float64, copy=True)
+    n = a.shape[-1]
+    assert n & (n - 1) == 0
+    h = 1
+    while h < n:
+        v = a.reshape(a.shape[:-1] + (n // (2 * h), 2, h))
+        lo = v[..., 0, :] + v[..., 1, :]
+        hi = v[..., 0, :] - v[..., 1, :]
+        v[..., 0, :] = lo
+        v[..., 1, :] = hi
+        h *= 2
+    return a
+
+
+def matmul_hadU(x: np.ndarray, hadK: Optional[np.ndarray], K: int, n: int,
+                scale: Optional[float] = None, transpose: bool = False
+                ) -> np.ndarray:
+    """float64 restatement of ``matmul_hadU_cuda`` (quant.py:72-84) ==
+    ``matmul_hadU`` (quant.py:42-65): zero-pad to n, view (..., K, n/K), WHT on
+    the last axis, left-multiply by hadK (hadK.T if transpose), scale by
+    (scale or 1)/sqrt(n/K)."""
+    x = np.asarray(x, dtype=np.float64)
+    if x.shape[-1] != n:
+        pad = [(0, 0)] * (x.ndim - 1) + [(0, n - x.shape[-1])]
+        x = np.pad(x, pad)
+    s = (1.0 if scale is None else float(scale)) / math.sqrt(n // K)
+    if K == 1:
+        return fwht(x) * s
+    v = fwht(x.reshape(x.shape[:-1] + (K, n // K))) * s
+    hk = np.asarray(hadK, dtype=np.float64)
+    if transpose:
+        hk = hk.T
+    return np.einsum("ij,...jk->...ik", hk, v).reshape(x.shape)
+
+
+# --------------------------------------------------------------------------
+# QuantLinear forward
+# --------------------------------------------------------------------------
+
+CODEBOOK_INFO = {
+    # id: (codesz, idx numpy dtype, packed-cols per 8 weights numerator/denominator)
+    "E8P12": dict(codesz=8, idx_dtype=np.int16),
+    "E8P12RVQ3B": dict(codesz=8, idx_dtype=np.int32),
+    "E8P12RVQ4B": dict(codesz=8, idx_dtype=np.int32),
+    "D4": dict(codesz=4, idx_dtype=np.uint8),
+    "HI": dict(codesz=1, idx_dtype=np.int32),
+}
+
+
+def qidx_cols(codebook: str, q_in: int) -> int:
+    """Number of Qidxs columns for a padded input width (qlinear.py:52-57)."""
+    if codebook in ("E8P12", "E8P12RVQ4B", "HI"):
+        return q_in // 8
+    if codebook == "E8P12RVQ3B":
+        return q_in * 3 // 32
+    if codebook == "D4":
+        return q_in // 4
+    raise KeyError(codebook)
+
+
+@dataclass
+class QLinearParams:
+    """State of one ``QuantLinear`` (qlinear.py:10-84) as numpy arrays."""
+    codebook: str
+    in_features: int
+    out_features: int
+    Qidxs: np.ndarray
+    SU: Optional[np.ndarray]          # fp16 (in,) or None (merge_suv)
+    SV: Optional[np.ndarray]          # fp16 (out,) or None
+    Wscale: np.ndarray                # fp32 scalar, or fp16 (q_out,) per-channel
+    wscale_float: float = 1.0         # quantizer.py:836-837
+    had_left: Optional[np.ndarray] = None   # (K_left, K_left) fp16
+    had_right: Optional[np.ndarray] = None
+    K_left: int = 1
+    K_right: int = 1
+    q_in: int = 0
+    q_out: int = 0
+    bias: Optional[np.ndarray] = None
+    per_channel: bool = False
+    resid_scale: float = 0.0          # opt_resid_scale for the RVQ codebooks
+    extra: dict = field(default_factory=dict)
+
+
+def qlinear_dense_weight(p: QLinearParams) -> np.ndarray:
+    """Exact decoded W-hat (q_out, q_in) as float64."""
+    return decompress(p.codebook, p.Qidxs, p.resid_scale).astype(np.float64)
+
+
+def qlinear_forward(p: QLinearParams, x: np.ndarray, mode: str = "exact",
+                    What: Optional[np.ndarray] = None) -> np.ndarray:
+    """``QuantLinear.forward`` eval branch (qlinear.py:87-92, 98-115).
+
+    mode="exact":  float64 evaluation of SURVEY Appendix B with the exact
+                   decoded weights, no intermediate rounding; returned float64.
+    mode="staged": every intermediate the reference materialises as an fp16
+                   tensor is rounded to fp16 at the same point (x*SU, FHT out,
+                   [hadK matmul out], mm out, Wscale mul, FHT out, SV mul,
+                   bias add); returned fp16.  This is what the reference's
+                   op-by-op pipeline computes up to accumulation order.
+    """
+    staged = mode == "staged"
+    r16 = (lambda a: a.astype(np.float16).astype(np.float64)) if staged else (lambda a: a)
+    xin = np.asarray(x)
+    lead = xin.shape[:-1]
+    v = xin.reshape(-1, xin.shape[-1]).astype(np.float64)
+    if p.SU is not None:
+        v = r16(v * p.SU.astype(np.float64))
+    hl = None if p.had_left is None else p.had_left.astype(np.float64)
+    hr = None if p.had_right is None else p.had_right.astype(np.float64)
+    if staged and p.K_left > 1:
+        # reference: hadamard op returns fp16, then fp16 matmul (quant.py:81-84)
+        s = p.wscale_float / math.sqrt(p.q_in // p.K_left)
+        vv = np.pad(v, [(0, 0), (0, p.q_in - v.shape[-1])])
+        t = r16(fwht(vv.reshape(-1, p.K_left, p.q_in // p.K_left)) * s)
+        v = r16(np.einsum("ij,bjk->bik", hl.T, t).reshape(-1, p.q_in))
+    else:
+        v = r16(matmul_hadU(v, hl, p.K_left, p.q_in, p.wscale_float, transpose=True))
+    if What is None:
+        What = qlinear_dense_weight(p)
+    z = r16(v @ What.T)
+    if p.per_channel:
+        z = r16(z * p.Wscale.astype(np.float64))
+    if staged and p.K_right > 1:
+        s = 1.0 / math.sqrt(p.q_out // p.K_right)
+        t = r16(fwht(z.reshape(-1, p.K_right, p.q_out // p.K_right)) * s)
+        z = r16(np.einsum("ij,bjk->bik", hr, t).reshape(-1, p.q_out))
+    else:
+        z = r16(matmul_hadU(z, hr, p.K_right, p.q_out))
+    y = z[:, :p.out_features]
+    if p.SV is not None:
+        y = r16(y * p.SV.astype(np.float64))
+    if p.bias is not None:
+        y = r16(y + p.bias.astype(np.float64))
+    y = y.reshape(lead + (p.out_features,))
+    return y.astype(np.float16) if staged else y
+
+
+def parity_bound(p: QLinearParams, x: np.ndarray, What: Optional[np.ndarray] = None,
+                 stages: int = 6) -> np.ndarray:
+    """Elementwise absolute tolerance for comparing any fp16 implementation of
+    ``QuantLinear.forward`` (the reference's staged fp16 pipeline or a fused HIP
+    pipeline that keeps fp32 between stages) with ``qlinear_forward(...,
+    "exact")``.
+
+    Each fp16 materialisation perturbs a vector by <= 2^-11 relative per
+    element; both Hadamard stages are orthogonal (norm preserving) and the mm
+    has operator norm ||What||_2, so a perturbation of relative size eps at any
+    stage reaches an output element with magnitude <= eps * row_rms-scaled
+    norm.  We bound per output row with the 2-norm of the exact output vector:
+        tol = stages * 2^-11 * (|y| + ||y||_2 / sqrt(out)) * |SV|max-normalised
+    plus fp32 accumulation slack.  Deliberately loose by a small constant; the
+    op-level tests (mm, decompress, hadamard) use much tighter bounds.
+    """
+    y = qlinear_forward(p, x, "exact", What)
+    y2 = y.reshape(-1, p.out_features)
+    rms = np.sqrt((y2 ** 2).mean(axis=1, keepdims=True))
+    tol = stages * 2.0 ** -11 * (np.abs(y2) + 4.0 * rms) + 1e-6
+    return tol.reshape(y.shape)
+
+
+# --------------------------------------------------------------------------
+# seeded synthetic layers (shared by tests, smoke, bench)
+# --------------------------------------------------------------------------
+
+def random_orthogonal(k: int, rng: np.random.Generator) -> np.ndarray:
+    """Random SO(k) matrix (stand-in for scipy special_ortho_group,
+    quant.py:30-32), seeded."""
+    a = rng.standard_normal((k, k))
+    q, r = np.linalg.qr(a)
+    q = q * np.sign(np.diag(r))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    return q
+
+
+def make_layer(codebook: str, in_features: int, out_features: int, seed: int = 0,
+               bias: bool = False, per_channel: bool = False,
+               resid_scale: Optional[float] = None, unit_suv: bool = False
+               ) -> QLinearParams:
+    """Random-init ``QuantLinear`` state with ``use_rand=True`` semantics
+    (qlinear.py:29-30, quant.py:26-32): every code is valid, so uniform random
+    codes are a legal checkpoint."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    e_l, b_l = split_pow2(in_features)
+    e_r, b_r = split_pow2(out_features)
+    K_l, K_r = b_l, b_r
+    q_in, q_out = in_features, out_features
+    cols = qidx_cols(codebook, q_in)
+    if codebook == "E8P12":
+        Q = rng.integers(0, 1 << 16, (q_out, cols), dtype=np.uint16).view(np.int16)
+    elif codebook == "E8P12RVQ4B":
+        Q = rng.integers(0, 1 << 32, (q_out, cols), dtype=np.uint32).view(np.int32)
+    elif codebook == "E8P12RVQ3B":
+        Q = rng.integers(0, 1 << 32, (q_out, cols), dtype=np.uint32).view(np.int32)
+    elif codebook == "D4":
+        Q = rng.integers(0, 256, (q_out, cols), dtype=np.uint8)
+    elif codebook == "HI":
+        Q = rng.integers(0, 1 << 32, (q_out, cols), dtype=np.uint32).view(np.int32)
+    else:
+        raise KeyError(codebook)
+    if unit_suv:
+        SU = np.ones(in_features, np.float16)
+        SV = np.ones(out_features, np.float16)
+    else:
+        SU = (rng.integers(0, 2, in_features) * 2 - 1).astype(np.float16)
+        SV = (rng.integers(0, 2, out_features) * 2 - 1).astype(np.float16)
+        # fine-tuned checkpoints carry non-+-1 SU/SV: perturb mildly
+        SU = (SU * (1 + 0.05 * rng.standard_normal(in_features))).astype(np.float16)
+        SV = (SV * (1 + 0.05 * rng.standard_normal(out_features))).astype(np.float16)
+    # random-init analogue of w.rms/opt_scale (quip.py:146-150): keep |y|~|x|
+    wrms = {"E8P12": 1.03, "E8P12RVQ3B": 1.2, "E8P12RVQ4B": 1.2, "D4": 1.21,
+            "HI": 4.6}[codebook]
+    wscale = 1.0 / (wrms * math.sqrt(in_features))
+    hl = None if K_l == 1 else random_orthogonal(K_l, rng).astype(np.float16)
+    hr = None if K_r == 1 else random_orthogonal(K_r, rng).astype(np.float16)
+    if resid_scale is None:
+        resid_scale = {"E8P12RVQ3B": 1 / 2.04, "E8P12RVQ4B": 1 / 3.45}.get(codebook, 0.0)
+    if per_channel:
+        Wscale = (1 + 0.1 * rng.standard_normal(q_out)).astype(np.float16)
+    else:
+        Wscale = np.float32(wscale)
+    b = (0.1 * rng.standard_normal(out_features)).astype(np.float16) if bias else None
+    return QLinearParams(codebook=codebook, in_features=in_features,
+                         out_features=out_features, Qidxs=Q, SU=SU, SV=SV,
+                         Wscale=Wscale, wscale_float=float(wscale), had_left=hl,
+                         had_right=hr, K_left=K_l, K_right=K_r, q_in=q_in,
+                         q_out=q_out, bias=b, per_channel=per_channel,
+                         resid_scale=float(resid_scale))
