@@ -1,0 +1,127 @@
+/*
+ * quip_mi355.h -- C ABI of the MI355X-native QuIP# inference hot path.
+ *
+ * This is the drop-in boundary: one `extern "C"` entry point per native function
+ * the reference binds for this path.  The reference's native boundary is the
+ * pybind11 module `quiptools_cuda` (quip_cuda/quiptools_wrapper.cpp:87-100) plus
+ * the third-party `fast_hadamard_transform_cuda.fast_hadamard_transform`
+ * (register_lib.py:5,18-20); its Python operator boundary is the `quip_lib`
+ * torch.library namespace (register_lib.py:8-192).
+ *
+ * Contract (differs from the reference where the reference had none):
+ *   - plain pointers + sizes, no torch / ATen types; every pointer is a DEVICE
+ *     pointer to a contiguous row-major buffer owned by the caller;
+ *   - the library allocates nothing and keeps no state: safe under hipGraph
+ *     capture and torch.compile; re-entrant; callable with or without the GIL;
+ *   - `stream` is a hipStream_t (NULL = the legacy default stream); every call
+ *     is asynchronous and stream ordered, no host synchronisation;
+ *   - returns 0 on success or a negative QUIP_ERR_* code; never aborts
+ *     (the reference only had `assert`s, compiled out in release builds:
+ *     origin_order.cu:816-822, 868-874).
+ *
+ * Shapes use the reference's names: x is (m, k) fp16, Qidxs is (n, k/codesz/packsz)
+ * in the codebook's index dtype, the product is (m, n) fp16 with
+ * y[i, j] = sum_t x[i, t] * W[j, t], W = decode(Qidxs) (n, k), fp32 accumulation,
+ * round-to-nearest fp16 store (origin_order.cu:388-555).
+ */
+#ifndef QUIP_MI355_H_
+#define QUIP_MI355_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QUIP_ABI_VERSION 1
+
+typedef void* quip_stream_t; /* hipStream_t */
+
+enum {
+  QUIP_OK = 0,
+  QUIP_ERR_NULL_POINTER = -1,
+  QUIP_ERR_BAD_SHAPE = -2,   /* dimension not supported by the packed format   */
+  QUIP_ERR_MISALIGNED = -3,  /* pointer not aligned for vector access (16 B)    */
+  QUIP_ERR_LAUNCH = -4,      /* HIP launch error; see hipGetLastError           */
+  QUIP_ERR_UNSUPPORTED = -5  /* valid request this build cannot serve           */
+};
+
+int quip_abi_version(void);
+const char* quip_strerror(int code);
+
+/* Number of compute units of the current device (used by callers to size
+ * rotating buffers); <0 on error. */
+int quip_device_cu_count(void);
+
+/* ---- quip_lib::hadamard ----------------------------------------------------
+ * y[r, :] = scale * H_n x[r, :], H_n the Sylvester-ordered +-1 Walsh-Hadamard
+ * matrix, n a power of two (<= 32768).  fp16 in / fp16 out, fp32 inside.
+ * Replaces fast_hadamard_transform_cuda.fast_hadamard_transform
+ * (register_lib.py:18-20; call sites quant.py:78,82).  x and y may alias. */
+int quip_hadamard_f16(const void* x, void* y, int64_t rows, int32_t n, float scale,
+                      quip_stream_t stream);
+
+/* ---- quip_lib::*_mm_origorder ---------------------------------------------
+ * Replace quiptools_cuda.{e8p,e8prvq3,e8prvq4,d4,hi}_mm_origorder
+ * (quiptools_wrapper.cpp:88-92; origin_order.cu:557-788).  The reference
+ * allocates and returns C; here the caller passes y (m, n) fp16.
+ * Requirements: k % 8 == 0 (E8P*, HI), k % 32 == 0 (E8P12RVQ3B), k % 4 == 0 (D4);
+ * m >= 1 (any m is accepted; the codebook modules call this for m < 32). */
+int quip_e8p_mm_origorder(const void* x, const void* qidxs /* int16 (n, k/8) */,
+                          const void* grid_packed_abs /* int64[256] */, void* y,
+                          int32_t m, int32_t n, int32_t k, quip_stream_t stream);
+int quip_e8prvq3_mm_origorder(const void* x, const void* qidxs /* int32 (n, k*3/32) */,
+                              const void* grid_packed_abs /* int64[256] */,
+                              const void* e81b_grid_packed /* int32[256] */, float scale,
+                              void* y, int32_t m, int32_t n, int32_t k,
+                              quip_stream_t stream);
+int quip_e8prvq4_mm_origorder(const void* x, const void* qidxs /* int32 (n, k/8) */,
+                              const void* grid_packed_abs, float scale, void* y,
+                              int32_t m, int32_t n, int32_t k, quip_stream_t stream);
+int quip_d4_mm_origorder(const void* x, const void* qidxs /* uint8 (n, k/4) */,
+                         const void* grid_f16 /* fp16[256*4] */, void* y, int32_t m,
+                         int32_t n, int32_t k, quip_stream_t stream);
+int quip_hi_mm_origorder(const void* x, const void* qidxs /* int32 (n, k/8) */, void* y,
+                         int32_t m, int32_t n, int32_t k, quip_stream_t stream);
+
+/* ---- quip_lib::decompress_*_origorder -------------------------------------
+ * Replace quiptools_cuda.decompress_{e8p,e8prvq3,e8prvq4,d4,hi}_origorder
+ * (quiptools_wrapper.cpp:93-97; origin_order.cu:794-1074): dense fp16
+ * W (rows, cols_out) written into caller-allocated `w`, `cols_out` = number of
+ * weights per row (k). */
+int quip_decompress_e8p_origorder(const void* qidxs, const void* grid_packed_abs, void* w,
+                                  int64_t rows, int32_t k, quip_stream_t stream);
+int quip_decompress_e8prvq3_origorder(const void* qidxs, const void* grid_packed_abs,
+                                      const void* e81b_grid_packed, float scale, void* w,
+                                      int64_t rows, int32_t k, quip_stream_t stream);
+int quip_decompress_e8prvq4_origorder(const void* qidxs, const void* grid_packed_abs,
+                                      float scale, void* w, int64_t rows, int32_t k,
+                                      quip_stream_t stream);
+int quip_decompress_d4_origorder(const void* qidxs, const void* grid_f16, void* w,
+                                 int64_t rows, int32_t k, quip_stream_t stream);
+int quip_decompress_hi_origorder(const void* qidxs, void* w, int64_t rows, int32_t k,
+                                 quip_stream_t stream);
+
+/* ---- fused pieces of QuantLinear.forward (qlinear.py:87-115) ----------------
+ * Input side:  xh = wscale * U_{q_in}(had_left^T) (SU (.) x)      (qlinear.py:90-100,
+ *              quant.py:72-88 with transpose=True)
+ * Output side: y  = SV (.) U_{q_out}(had_right)(Wscale_vec (.) z)[:out] + bias
+ *                                                                   (qlinear.py:106-114)
+ * with U_n(hadK) = (hadK (x) H_{n/K}) / sqrt(n/K) acting on the row-major
+ * (K, n/K) view (quant.py:81-84).  All vectors fp16; had is (K, K) fp16 row
+ * major or NULL when K == 1; su / sv / wscale_vec / bias may be NULL.
+ * `features` = unpadded width (in_features / out_features), n = padded width
+ * (q_in / q_out), n == K * 2^e.  `transpose` selects hadK^T (input side). */
+int quip_had_transform_f16(const void* x, void* y, int64_t rows, int32_t in_features,
+                           int32_t out_features, int32_t n, int32_t K,
+                           const void* had /* (K,K) fp16 or NULL */, int32_t transpose,
+                           const void* pre_scale /* fp16[in_features] or NULL  */,
+                           const void* pre_scale2 /* fp16[n] or NULL (Wscale)   */,
+                           const void* post_scale /* fp16[out_features] or NULL */,
+                           const void* bias /* fp16[out_features] or NULL */,
+                           float scale, quip_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUIP_MI355_H_ */

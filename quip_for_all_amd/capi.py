@@ -1,0 +1,71 @@
+"""ctypes binding of libquip_mi355.so (include/quip_mi355.h).  This module is the
+only place that touches the native library; it never falls back to a CPU path:
+a missing library or symbol raises."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libquip_mi355.so")
+
+_c = ctypes
+_P, _I32, _I64, _F = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_float
+
+# name -> argtypes ; every entry of include/quip_mi355.h
+SIGNATURES = {
+    "quip_abi_version": [],
+    "quip_device_cu_count": [],
+    "quip_hadamard_f16": [_P, _P, _I64, _I32, _F, _P],
+    "quip_had_transform_f16": [_P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _P, _P, _P, _F, _P],
+    "quip_e8p_mm_origorder": [_P, _P, _P, _P, _I32, _I32, _I32, _P],
+    "quip_e8prvq3_mm_origorder": [_P, _P, _P, _P, _F, _P, _I32, _I32, _I32, _P],
+    "quip_e8prvq4_mm_origorder": [_P, _P, _P, _F, _P, _I32, _I32, _I32, _P],
+    "quip_d4_mm_origorder": [_P, _P, _P, _P, _I32, _I32, _I32, _P],
+    "quip_hi_mm_origorder": [_P, _P, _P, _I32, _I32, _I32, _P],
+    "quip_decompress_e8p_origorder": [_P, _P, _P, _I64, _I32, _P],
+    "quip_decompress_e8prvq3_origorder": [_P, _P, _P, _F, _P, _I64, _I32, _P],
+    "quip_decompress_e8prvq4_origorder": [_P, _P, _F, _P, _I64, _I32, _P],
+    "quip_decompress_d4_origorder": [_P, _P, _P, _I64, _I32, _P],
+    "quip_decompress_hi_origorder": [_P, _P, _I64, _I32, _P],
+}
+# not part of the public header: tuning hook used by the micro-benchmarks only
+_INTERNAL = {
+    "quip_e8p_gemv_tuned": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P],
+}
+
+_lib = None
+
+
+class QuipNativeError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise QuipNativeError(
+                f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, args in list(SIGNATURES.items()) + list(_INTERNAL.items()):
+            fn = getattr(L, name)  # AttributeError if the symbol is not exported
+            fn.argtypes = args
+            fn.restype = _c.c_int
+        L.quip_strerror.argtypes = [_c.c_int]
+        L.quip_strerror.restype = _c.c_char_p
+        _lib = L
+    return _lib
+
+
+def check_symbols():
+    L = lib()
+    missing = [n for n in list(SIGNATURES) + ["quip_strerror"] if not hasattr(L, n)]
+    if missing:
+        raise QuipNativeError(f"libquip_mi355.so lacks symbols: {missing}")
+    return sorted(SIGNATURES) + ["quip_strerror"]
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().quip_strerror(code).decode()
+        raise QuipNativeError(f"{what} failed: {msg} ({code})")

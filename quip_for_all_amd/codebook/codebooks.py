@@ -1,0 +1,158 @@
+"""Codebook modules: tables as (non-persistent) buffers + the M-threshold
+dispatch of the reference's forward() (e8p12.py:139-156, e8p12_rvq3.py:109-129,
+e8p12_rvq4.py:50-67, d4.py:128-139, hi.py:52-63).  Quantise-time methods
+(round / quantize) are out of scope of this build."""
+from fractions import Fraction
+
+import torch
+from torch import nn
+
+from . import tables
+
+
+class _Codebook(nn.Module):
+    mm_threshold = 32  # fused mm kernel for M < threshold, else decompress + dense GEMM
+
+    def quantize(self, X, return_idx=True):
+        raise NotImplementedError("quantise-time codebook search is outside the inference hot path")
+
+    def maybe_pack_idxs(self, idxs):
+        return idxs
+
+    def forward(self, input, Qidxs):
+        if input.size(0) < self.mm_threshold:
+            return self.mm(input, Qidxs)
+        W = self.decompress_weight(Qidxs)
+        return input @ W.T
+
+
+class E8P12_codebook(_Codebook):
+    def __init__(self, inference=False, **kwargs):
+        super().__init__()
+        self.id = "E8P12"
+        self.opt_scale = 1.03
+        self.codesz = 8
+        self.idx_dtype = torch.int16
+        self.packsz = 1
+        self.pack_out = False
+        self.version = 1
+        self.register_buffer("grid_packed_abs", torch.from_numpy(tables.e8p_grid_packed_abs().copy()),
+                             persistent=False)
+        if not inference:
+            g = torch.from_numpy(tables.e8p_full_grid().copy())
+            self.register_buffer("grid", g, persistent=False)
+            self.register_buffer("grid_norm", g.norm(dim=-1) ** 2, persistent=False)
+
+    def decompress_weight(self, Qidxs):
+        return torch.ops.quip_lib.decompress_e8p_origorder(Qidxs, self.grid_packed_abs)
+
+    def mm(self, input, Qidxs):
+        return torch.ops.quip_lib.e8p_mm_origorder(input, Qidxs, self.grid_packed_abs)
+
+
+class E8P12RVQ4B_codebook(_Codebook):
+    def __init__(self, inference=False, opt_resid_scale=None, **kwargs):
+        super().__init__()
+        self.id = "E8P12RVQ4B"
+        self.opt_scale = 1.03
+        self.codesz = 8
+        self.idx_dtype = torch.int32
+        self.packsz = 1
+        self.pack_out = False
+        self.version = 0
+        # NB the reference's quantizer passes its default -1 straight through
+        # (quantizer.py:69,126-127): only None selects 1/3.45 (e8p12_rvq4.py:23).
+        self.opt_resid_scale = 1 / 3.45 if opt_resid_scale is None else opt_resid_scale
+        self.register_buffer("grid_packed_abs", torch.from_numpy(tables.e8p_grid_packed_abs().copy()),
+                             persistent=False)
+
+    def decompress_weight(self, Qidxs):
+        return torch.ops.quip_lib.decompress_e8prvq4_origorder(Qidxs, self.grid_packed_abs,
+                                                               self.opt_resid_scale)
+
+    def mm(self, input, Qidxs):
+        return torch.ops.quip_lib.e8prvq4_mm_origorder(input, Qidxs, self.grid_packed_abs,
+                                                       self.opt_resid_scale)
+
+
+class E8P12RVQ3B_codebook(_Codebook):
+    def __init__(self, inference=False, opt_resid_scale=None, **kwargs):
+        super().__init__()
+        self.id = "E8P12RVQ3B"
+        self.opt_scale = 0.98
+        self.codesz = 8
+        self.idx_dtype = torch.int32
+        self.packsz = Fraction(4, 3)
+        self.pack_out = False
+        self.version = 0
+        self.opt_resid_scale = 1 / 2.04 if opt_resid_scale is None else opt_resid_scale
+        self.register_buffer("grid_packed_abs", torch.from_numpy(tables.e8p_grid_packed_abs().copy()),
+                             persistent=False)
+        self.register_buffer("e81b_grid", torch.from_numpy(tables.e81b_grid().copy()), persistent=False)
+        self.register_buffer("e81b_grid_packed", torch.from_numpy(tables.e81b_grid_packed().copy()),
+                             persistent=False)
+
+    def maybe_pack_idxs(self, idxs):
+        """keep the low 3 bytes of every int32 index (e8p12_rvq3.py:102-107)"""
+        b = idxs.contiguous().view(torch.int8).view(idxs.shape[0], idxs.shape[1], -1)
+        return b[..., :3].reshape(idxs.shape[0], -1).view(torch.int32)
+
+    def decompress_weight(self, Qidxs):
+        return torch.ops.quip_lib.decompress_e8prvq3_origorder(
+            Qidxs, self.grid_packed_abs, self.e81b_grid_packed, self.opt_resid_scale)
+
+    def mm(self, input, Qidxs):
+        return torch.ops.quip_lib.e8prvq3_mm_origorder(
+            input, Qidxs, self.grid_packed_abs, self.e81b_grid_packed, self.opt_resid_scale)
+
+
+class D4_codebook(_Codebook):
+    mm_threshold = 24  # d4.py:134
+
+    def __init__(self, inference=False, **kwargs):
+        super().__init__()
+        self.id = "D4"
+        self.codesz = 4
+        self.opt_scale = 1.21
+        self.idx_dtype = torch.uint8
+        self.packsz = 1
+        self.pack_out = False
+        self.version = 0
+        # the kernels need fp16 entries (8-byte rows); keep the buffer in fp16 so that
+        # per-layer copies are valid whatever the caller casts
+        self.register_buffer("grid", torch.from_numpy(tables.d4_grid().copy()).half(), persistent=False)
+
+    def decompress_weight(self, Qidxs):
+        return torch.ops.quip_lib.decompress_d4_origorder(Qidxs, self.grid)
+
+    def mm(self, input, Qidxs):
+        return torch.ops.quip_lib.d4_mm_origorder(input, Qidxs, self.grid)
+
+
+class HI4B1C_codebook(_Codebook):
+    def __init__(self, inference=False, **kwargs):
+        super().__init__()
+        self.id = "HI"
+        self.opt_scale = 2.97
+        self.codesz = 1
+        self.idx_dtype = torch.int32
+        self.packsz = 8
+        self.pack_out = False
+        self.version = 0
+        if not inference:
+            g = (torch.arange(-8, 8) + 0.5).unsqueeze(-1)
+            self.register_buffer("grid", g, persistent=False)
+            self.register_buffer("grid_norm", (g @ g.T).diag(), persistent=False)
+
+    def maybe_pack_idxs(self, idxs):
+        """nibble i <- column [0,2,4,6,1,3,5,7][i] of each 8-group (hi.py:41-50)"""
+        out = torch.zeros(idxs.shape[0], idxs.shape[1] // 8, dtype=idxs.dtype, device=idxs.device)
+        for i, col in enumerate(tables.HI_NIBBLE_COLS):
+            out = out + (idxs[:, col::8] << (4 * i))
+        return out
+
+    def decompress_weight(self, Qidxs):
+        return torch.ops.quip_lib.decompress_hi_origorder(Qidxs)
+
+    def mm(self, input, Qidxs):
+        return torch.ops.quip_lib.hi_mm_origorder(input, Qidxs)

@@ -1,0 +1,168 @@
+// extern "C" entry points of libquip_mi355.so (see include/quip_mi355.h).
+// Argument validation lives here; the reference validated nothing
+// (origin_order.cu:557-788 have no dtype / shape / contiguity checks).
+#include "quip_internal.h"
+
+namespace quip {
+
+int device_cu_count() {
+  static int cached[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+  if (cached[dev] == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    cached[dev] = v;
+  }
+  return cached[dev];
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static int mm_common(CodebookId cb, const void* x, const void* q, const CodebookArgs& a, void* y,
+                     int m, int n, int k, int kdiv, hipStream_t s) {
+  if (!x || !q || !y) return QUIP_ERR_NULL_POINTER;
+  if (m < 0 || n < 0 || k <= 0 || k % kdiv != 0 || k % 8 != 0) return QUIP_ERR_BAD_SHAPE;
+  if (m == 0 || n == 0) return QUIP_OK;
+  if (!aligned16(x)) return QUIP_ERR_MISALIGNED;
+  return generic_mm_launch(cb, x, q, a, y, m, n, k, s);
+}
+
+}  // namespace quip
+
+using namespace quip;
+
+extern "C" {
+
+int quip_abi_version(void) { return QUIP_ABI_VERSION; }
+
+const char* quip_strerror(int code) {
+  switch (code) {
+    case QUIP_OK: return "ok";
+    case QUIP_ERR_NULL_POINTER: return "null pointer argument";
+    case QUIP_ERR_BAD_SHAPE: return "shape not supported by the packed format";
+    case QUIP_ERR_MISALIGNED: return "pointer not 16-byte aligned";
+    case QUIP_ERR_LAUNCH: return "HIP kernel launch failed";
+    case QUIP_ERR_UNSUPPORTED: return "request not supported by this build";
+    default: return "unknown quip error";
+  }
+}
+
+int quip_device_cu_count(void) { return device_cu_count(); }
+
+int quip_hadamard_f16(const void* x, void* y, int64_t rows, int32_t n, float scale,
+                      quip_stream_t stream) {
+  if (!x || !y) return QUIP_ERR_NULL_POINTER;
+  return had_transform_launch(x, y, rows, n, n, n, 1, nullptr, 0, nullptr, nullptr, nullptr,
+                              nullptr, scale, (hipStream_t)stream);
+}
+
+int quip_had_transform_f16(const void* x, void* y, int64_t rows, int32_t in_features,
+                           int32_t out_features, int32_t n, int32_t K, const void* had,
+                           int32_t transpose, const void* pre_scale, const void* pre_scale2,
+                           const void* post_scale, const void* bias, float scale,
+                           quip_stream_t stream) {
+  if (!x || !y) return QUIP_ERR_NULL_POINTER;
+  return had_transform_launch(x, y, rows, in_features, out_features, n, K, had, transpose,
+                              pre_scale, pre_scale2, post_scale, bias, scale, (hipStream_t)stream);
+}
+
+int quip_e8p_mm_origorder(const void* x, const void* qidxs, const void* grid, void* y, int32_t m,
+                          int32_t n, int32_t k, quip_stream_t stream) {
+  if (!grid) return QUIP_ERR_NULL_POINTER;
+  if (x && qidxs && y && m == 1 && n > 0 && e8p_gemv_m1_supported(n, k) && aligned16(x) &&
+      aligned16(qidxs))
+    return e8p_gemv_m1_launch(x, qidxs, grid, y, n, k, GemvTune{}, (hipStream_t)stream);
+  CodebookArgs a;
+  a.grid = grid;
+  return mm_common(kE8P, x, qidxs, a, y, m, n, k, 8, (hipStream_t)stream);
+}
+
+int quip_e8p_gemv_tuned(const void* x, const void* qidxs, const void* grid, void* y, int32_t n,
+                        int32_t k, int32_t rep, int32_t rows, int32_t blocks, int32_t waves_g,
+                        quip_stream_t stream) {
+  if (!x || !qidxs || !grid || !y) return QUIP_ERR_NULL_POINTER;
+  GemvTune t;
+  t.rep = rep; t.rows = rows; t.blocks = blocks; t.waves_g = waves_g;
+  return e8p_gemv_m1_launch(x, qidxs, grid, y, n, k, t, (hipStream_t)stream);
+}
+
+int quip_e8prvq3_mm_origorder(const void* x, const void* qidxs, const void* grid,
+                              const void* grid2, float scale, void* y, int32_t m, int32_t n,
+                              int32_t k, quip_stream_t stream) {
+  if (!grid || !grid2) return QUIP_ERR_NULL_POINTER;
+  CodebookArgs a;
+  a.grid = grid; a.grid2 = grid2; a.scale = scale;
+  return mm_common(kE8PRVQ3, x, qidxs, a, y, m, n, k, 32, (hipStream_t)stream);
+}
+
+int quip_e8prvq4_mm_origorder(const void* x, const void* qidxs, const void* grid, float scale,
+                              void* y, int32_t m, int32_t n, int32_t k, quip_stream_t stream) {
+  if (!grid) return QUIP_ERR_NULL_POINTER;
+  CodebookArgs a;
+  a.grid = grid; a.scale = scale;
+  return mm_common(kE8PRVQ4, x, qidxs, a, y, m, n, k, 8, (hipStream_t)stream);
+}
+
+int quip_d4_mm_origorder(const void* x, const void* qidxs, const void* grid_f16, void* y,
+                         int32_t m, int32_t n, int32_t k, quip_stream_t stream) {
+  if (!grid_f16) return QUIP_ERR_NULL_POINTER;
+  CodebookArgs a;
+  a.grid = grid_f16;
+  return mm_common(kD4, x, qidxs, a, y, m, n, k, 8, (hipStream_t)stream);
+}
+
+int quip_hi_mm_origorder(const void* x, const void* qidxs, void* y, int32_t m, int32_t n,
+                         int32_t k, quip_stream_t stream) {
+  return mm_common(kHI, x, qidxs, CodebookArgs{}, y, m, n, k, 8, (hipStream_t)stream);
+}
+
+static int dec_common(CodebookId cb, const void* q, const CodebookArgs& a, void* w, int64_t rows,
+                      int32_t k, int kdiv, hipStream_t s) {
+  if (!q || !w) return QUIP_ERR_NULL_POINTER;
+  if (rows < 0 || k <= 0 || k % kdiv != 0 || k % 8 != 0) return QUIP_ERR_BAD_SHAPE;
+  if (rows == 0) return QUIP_OK;
+  if (!aligned16(w)) return QUIP_ERR_MISALIGNED;
+  return decompress_launch(cb, q, a, w, rows, k, s);
+}
+
+int quip_decompress_e8p_origorder(const void* qidxs, const void* grid, void* w, int64_t rows,
+                                  int32_t k, quip_stream_t stream) {
+  if (!grid) return QUIP_ERR_NULL_POINTER;
+  CodebookArgs a;
+  a.grid = grid;
+  return dec_common(kE8P, qidxs, a, w, rows, k, 8, (hipStream_t)stream);
+}
+
+int quip_decompress_e8prvq3_origorder(const void* qidxs, const void* grid, const void* grid2,
+                                      float scale, void* w, int64_t rows, int32_t k,
+                                      quip_stream_t stream) {
+  if (!grid || !grid2) return QUIP_ERR_NULL_POINTER;
+  CodebookArgs a;
+  a.grid = grid; a.grid2 = grid2; a.scale = scale;
+  return dec_common(kE8PRVQ3, qidxs, a, w, rows, k, 32, (hipStream_t)stream);
+}
+
+int quip_decompress_e8prvq4_origorder(const void* qidxs, const void* grid, float scale, void* w,
+                                      int64_t rows, int32_t k, quip_stream_t stream) {
+  if (!grid) return QUIP_ERR_NULL_POINTER;
+  CodebookArgs a;
+  a.grid = grid; a.scale = scale;
+  return dec_common(kE8PRVQ4, qidxs, a, w, rows, k, 8, (hipStream_t)stream);
+}
+
+int quip_decompress_d4_origorder(const void* qidxs, const void* grid_f16, void* w, int64_t rows,
+                                 int32_t k, quip_stream_t stream) {
+  if (!grid_f16) return QUIP_ERR_NULL_POINTER;
+  CodebookArgs a;
+  a.grid = grid_f16;
+  return dec_common(kD4, qidxs, a, w, rows, k, 8, (hipStream_t)stream);
+}
+
+int quip_decompress_hi_origorder(const void* qidxs, void* w, int64_t rows, int32_t k,
+                                 quip_stream_t stream) {
+  return dec_common(kHI, qidxs, CodebookArgs{}, w, rows, k, 8, (hipStream_t)stream);
+}
+
+}  // extern "C"

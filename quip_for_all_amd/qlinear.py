@@ -1,0 +1,180 @@
+"""QuantLinear with the reference's constructor, buffers, state-dict keys and
+forward contract (qlinear.py:8-159); the eval forward runs on the HIP kernels:
+
+    xh  = wscale * U_in(had_left^T)(SU (.) x)          1 launch  (quip_lib::had_transform)
+    z   = decode(Qidxs) @ xh                           1 launch  (codebook mm / decompress+GEMM)
+    y   = SV (.) U_out(had_right)(Wscale (.) z)[:out] + bias   1 launch
+
+instead of the reference's >= 5 launches (mul, pad, FHT, [hadK.T.contiguous, matmul],
+mm, [mul], FHT, [matmul], slice, mul, add).  Intermediates stay fp16 between the
+three launches exactly where the reference materialises fp16 tensors; inside a
+launch the arithmetic is fp32.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .quant import get_hadK, matmul_hadU_cuda
+
+
+class QuantLinear(nn.Module):
+
+    def __init__(self, in_features, out_features, codebook, bias=True, use_rand=True,
+                 per_channel=False, weight_dtype=torch.float16):
+        super().__init__()
+        # peft looks for infeatures / outfeatures (qlinear.py:20-23)
+        self.in_features = self.infeatures = in_features
+        self.out_features = self.outfeatures = out_features
+        self.codebook = codebook
+        self.use_rand = use_rand
+        self.per_channel = per_channel
+        self.weight_dtype = weight_dtype
+
+        had_left, self.K_left, self.q_in_features = get_hadK(in_features, use_rand)
+        had_right, self.K_right, self.q_out_features = get_hadK(out_features, use_rand)
+        if had_left is not None:
+            self.register_buffer("had_left", had_left.to(weight_dtype), persistent=use_rand)
+        else:
+            self.had_left = None
+        if had_right is not None:
+            self.register_buffer("had_right", had_right.to(weight_dtype), persistent=use_rand)
+        else:
+            self.had_right = None
+
+        if codebook.pack_out:
+            qshape = (self.q_out_features // codebook.packsz, self.q_in_features // codebook.codesz)
+        else:
+            qshape = (self.q_out_features,
+                      int(self.q_in_features // (codebook.codesz * codebook.packsz)))
+        self.register_buffer("Qidxs", torch.zeros(*qshape, dtype=codebook.idx_dtype))
+        self.SU = nn.Parameter(torch.ones(in_features, dtype=weight_dtype), requires_grad=True)
+        self.SV = nn.Parameter(torch.ones(out_features, dtype=weight_dtype), requires_grad=True)
+        if per_channel:
+            self.register_buffer("Wscale", torch.ones(self.q_out_features, dtype=weight_dtype))
+        else:
+            self.register_buffer("Wscale", torch.ones((), dtype=torch.float))
+        self.wscale_float = 1.0
+        # HF probes `.weight` for device / dtype: keep the reference's 0-dim stand-in
+        self.register_buffer("weight", torch.zeros((), dtype=weight_dtype))
+        if bias:
+            self.register_buffer("bias", torch.zeros(out_features, dtype=weight_dtype))
+        else:
+            self.bias = None
+
+    # ------------------------------------------------------------------ forward
+    def _had(self, name):
+        h = getattr(self, name)
+        if h is not None and (h.dtype != torch.float16 or not h.is_contiguous()):
+            h = h.to(torch.float16).contiguous()
+        return h
+
+    @staticmethod
+    def _vec(v):
+        if v is None:
+            return None
+        v = v.detach() if isinstance(v, nn.Parameter) else v
+        return v if v.dtype == torch.float16 else v.to(torch.float16)
+
+    def forward(self, input):
+        if self.training:
+            return self._forward_dense(input)
+        x = input.reshape(-1, input.shape[-1])
+        x_dtype = x.dtype
+        if x_dtype != torch.float16:
+            x = x.to(torch.float16)
+        L_in = self.q_in_features // self.K_left
+        xh = torch.ops.quip_lib.had_transform(
+            x, self.q_in_features, self.q_in_features, self.K_left, self._had("had_left"), True,
+            self._vec(self.SU), None, None, None, self.wscale_float / math.sqrt(L_in))
+        z = self.codebook(xh, self.Qidxs)
+        L_out = self.q_out_features // self.K_right
+        y = torch.ops.quip_lib.had_transform(
+            z, self.out_features, self.q_out_features, self.K_right, self._had("had_right"), False,
+            None, self._vec(self.Wscale) if self.per_channel else None, self._vec(self.SV),
+            self._vec(self.bias), 1.0 / math.sqrt(L_out))
+        if x_dtype != torch.float16:
+            y = y.to(x_dtype)
+        return y.view(*input.shape[:-1], self.out_features)
+
+    def _forward_dense(self, input):
+        """training-mode branch: x @ calc_weight() (qlinear.py:93-97)."""
+        x = input.reshape(-1, input.shape[-1])
+        if self.SU is not None:
+            x = x * self.SU
+        if x.shape[-1] != self.q_in_features:
+            x = torch.nn.functional.pad(x, (0, self.q_in_features - x.shape[-1]))
+        W = self.W if hasattr(self, "W") else self.calc_weight(cache=False).to(x.dtype)
+        out = (x @ W)[..., :self.out_features]
+        if self.SV is not None:
+            out = out * self.SV
+        out = out.view(*input.shape[:-1], out.shape[-1])
+        return out + self.bias if self.bias is not None else out
+
+    @torch.no_grad()
+    def calc_weight(self, cache=True):
+        """dense (q_in, q_out) weight = U_R(U_L(decode)^T) (qlinear.py:144-159)."""
+        weight = self.codebook.decompress_weight(self.Qidxs)
+        wscale_float = self.Wscale.mean().float().item()
+        t = matmul_hadU_cuda(weight, self.had_left, self.K_left, self.q_in_features, wscale_float)
+        W = matmul_hadU_cuda(t.T.contiguous(), self.had_right, self.K_right,
+                             self.q_out_features).to(self.weight_dtype)
+        if self.per_channel:
+            W = W * self.Wscale / self.Wscale.mean()
+        if cache:
+            self.register_buffer("W", W, persistent=False)
+        return W
+
+    def pack(self, linear, attr):
+        """fill the buffers from a quantiser result dict (qlinear.py:117-142)."""
+        scaleWH, SU, SV = attr["scaleWH"], attr.get("SU"), attr.get("SV")
+        if attr["merge_su"] and scaleWH is None:
+            self.SU = None
+        else:
+            su = scaleWH if attr["merge_su"] else (SU if scaleWH is None else SU * scaleWH)
+            self.SU.data.copy_(su)
+        if attr["merge_sv"]:
+            self.SV = None
+        else:
+            self.SV.data.copy_(SV)
+        self.Qidxs.copy_(attr["Qidxs"])
+        self.Wscale.copy_(attr["w_scale"].squeeze() if self.per_channel else attr["w_scale"])
+        for name, key in (("had_left", "left_hadK"), ("had_right", "right_hadK")):
+            if attr[key] is not None:
+                getattr(self, name).copy_(attr[key])
+        if linear.bias is not None:
+            self.bias.copy_(linear.bias / SV if attr["merge_sv"] else linear.bias)
+
+    # ------------------------------------------------------------------ test / bench helper
+    @classmethod
+    def from_oracle_params(cls, P):
+        """Build a layer from a plain-attribute parameter record (numpy arrays named as
+        the state-dict keys); used by tests, smoke() and bench to share seeded inputs."""
+        from .codebook import codebook_id
+        kw = {}
+        if P.codebook.startswith("E8P12RVQ"):
+            kw["opt_resid_scale"] = P.resid_scale
+        cb = codebook_id[P.codebook](inference=True, **kw)
+        # use_rand=True draws random had matrices only to size the buffers; overwritten below
+        layer = cls(P.in_features, P.out_features, cb, bias=P.bias is not None, use_rand=True,
+                    per_channel=P.per_channel)
+        with torch.no_grad():
+            layer.Qidxs.copy_(torch.from_numpy(P.Qidxs))
+            if P.SU is None:
+                layer.SU = None
+            else:
+                layer.SU.copy_(torch.from_numpy(P.SU))
+            if P.SV is None:
+                layer.SV = None
+            else:
+                layer.SV.copy_(torch.from_numpy(P.SV))
+            import numpy as np
+            layer.Wscale.copy_(torch.from_numpy(np.asarray(P.Wscale)))
+            if P.had_left is not None:
+                layer.had_left.copy_(torch.from_numpy(P.had_left))
+            if P.had_right is not None:
+                layer.had_right.copy_(torch.from_numpy(P.had_right))
+            if P.bias is not None:
+                layer.bias.copy_(torch.from_numpy(P.bias))
+        layer.wscale_float = float(P.wscale_float)
+        return layer

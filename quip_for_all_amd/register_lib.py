@@ -1,0 +1,232 @@
+"""`quip_lib` operator boundary: same op names and schemas as the reference's
+register_lib.py:8-192, implemented by the C-ABI library (capi.py) on the
+caller's current HIP stream.  Only a CUDA(=HIP) implementation and a fake
+(meta) implementation are registered -- like the reference there is no CPU
+kernel, and there is deliberately no CPU fallback."""
+import math
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import capi
+
+try:
+    _lib = torch.library.Library("quip_lib", "DEF")
+except RuntimeError:  # namespace already defined in this process
+    _lib = torch.library.Library("quip_lib", "FRAGMENT")
+
+_SCHEMAS = {
+    "hadamard": "(Tensor x, float scale) -> Tensor",
+    "e8p_mm_origorder": "(Tensor x, Tensor Qidxs, Tensor grid) -> Tensor",
+    "e8prvq3_mm_origorder": "(Tensor x, Tensor Qidxs, Tensor grid, Tensor grid2, float scale) -> Tensor",
+    "e8prvq4_mm_origorder": "(Tensor x, Tensor Qidxs, Tensor grid, float scale) -> Tensor",
+    "d4_mm_origorder": "(Tensor x, Tensor Qidxs, Tensor grid) -> Tensor",
+    "hi_mm_origorder": "(Tensor x, Tensor Qidxs) -> Tensor",
+    "decompress_e8p_origorder": "(Tensor Qidxs, Tensor grid) -> Tensor",
+    "decompress_e8prvq3_origorder": "(Tensor Qidxs, Tensor grid, Tensor grid2, float scale) -> Tensor",
+    "decompress_e8prvq4_origorder": "(Tensor Qidxs, Tensor grid, float scale) -> Tensor",
+    "decompress_d4_origorder": "(Tensor Qidxs, Tensor grid) -> Tensor",
+    "decompress_hi_origorder": "(Tensor Qidxs) -> Tensor",
+    # fused Hadamard side of QuantLinear.forward (no reference counterpart: it
+    # replaces the x*SU / pad / hadamard / hadK@ / *SV / +bias op sequence)
+    "had_transform": "(Tensor x, int out_features, int n, int K, Tensor? had, bool transpose, "
+                     "Tensor? pre, Tensor? pre2, Tensor? post, Tensor? bias, float scale) -> Tensor",
+}
+for _name, _schema in _SCHEMAS.items():
+    try:
+        _lib.define(_name + _schema)
+    except RuntimeError:
+        pass  # already defined (e.g. the reference's register_lib was imported first)
+
+
+def _stream(t: Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _need(cond, msg):
+    if not cond:
+        raise ValueError("quip_lib: " + msg)
+
+
+def _chk_x(x: Tensor):
+    _need(x.dim() == 2, "x must be 2-D (M, in)")
+    _need(x.dtype == torch.float16, f"x must be float16, got {x.dtype}")
+    return x.contiguous()
+
+
+def _chk_q(q: Tensor, dtype):
+    _need(q.dim() == 2, "Qidxs must be 2-D")
+    _need(q.dtype == dtype, f"Qidxs must be {dtype}, got {q.dtype}")
+    return q.contiguous()
+
+
+# ---- hadamard ---------------------------------------------------------------------
+def _hadamard_cuda(x: Tensor, scale: float) -> Tensor:
+    _need(x.dtype == torch.float16, f"hadamard: float16 only in this build, got {x.dtype}")
+    n = x.shape[-1]
+    _need(n & (n - 1) == 0 and 0 < n <= 32768, f"hadamard length {n} must be a power of two <= 32768")
+    xc = x.contiguous()
+    y = torch.empty_like(xc)
+    rows = xc.numel() // n
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().quip_hadamard_f16(xc.data_ptr(), y.data_ptr(), rows, n, float(scale),
+                                                _stream(x)), "quip_hadamard_f16")
+    return y
+
+
+def _had_transform_cuda(x, out_features, n, K, had, transpose, pre, pre2, post, bias, scale):
+    xc = _chk_x(x)
+    for t in (had, pre, pre2, post, bias):
+        _need(t is None or (t.dtype == torch.float16 and t.is_contiguous() and t.device == x.device),
+              "had_transform: vectors must be contiguous float16 on x's device")
+    y = torch.empty((xc.shape[0], out_features), dtype=torch.float16, device=x.device)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().quip_had_transform_f16(
+            xc.data_ptr(), y.data_ptr(), xc.shape[0], xc.shape[1], out_features, n, K, _ptr(had),
+            int(bool(transpose)), _ptr(pre), _ptr(pre2), _ptr(post), _ptr(bias), float(scale),
+            _stream(x)), "quip_had_transform_f16")
+    return y
+
+
+# ---- mm ops -------------------------------------------------------------------------
+def _mm(fn_name, x, Q, qdtype, k_per_col_num, k_per_col_den, extra):
+    xc = _chk_x(x)
+    Qc = _chk_q(Q, qdtype)
+    k = xc.shape[1]
+    _need(Qc.shape[1] * k_per_col_num == k * k_per_col_den,
+          f"{fn_name}: x has {k} columns but Qidxs {tuple(Q.shape)} encodes {Qc.shape[1] * k_per_col_num // k_per_col_den}")
+    _need(Qc.device == x.device, "Qidxs and x must be on the same device")
+    y = torch.empty((xc.shape[0], Qc.shape[0]), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        fn = getattr(capi.lib(), fn_name)
+        capi.check(fn(xc.data_ptr(), Qc.data_ptr(), *extra(), y.data_ptr(), xc.shape[0], Qc.shape[0],
+                      k, _stream(x)), fn_name)
+    return y
+
+
+def _grid_i64(grid: Tensor, x: Tensor):
+    _need(grid.dtype == torch.int64 and grid.numel() == 256, "grid_packed_abs must be int64[256]")
+    _need(grid.device == x.device, "grid and x must be on the same device")
+    return grid.contiguous()
+
+
+def _e8p_mm_cuda(x, Qidxs, grid):
+    g = _grid_i64(grid, x)
+    return _mm("quip_e8p_mm_origorder", x, Qidxs, torch.int16, 8, 1, lambda: (g.data_ptr(),))
+
+
+def _e8prvq3_mm_cuda(x, Qidxs, grid, grid2, scale):
+    g = _grid_i64(grid, x)
+    _need(grid2.dtype == torch.int32 and grid2.numel() == 256, "e81b_grid_packed must be int32[256]")
+    g2 = grid2.contiguous()
+    return _mm("quip_e8prvq3_mm_origorder", x, Qidxs, torch.int32, 32, 3,
+               lambda: (g.data_ptr(), g2.data_ptr(), float(scale)))
+
+
+def _e8prvq4_mm_cuda(x, Qidxs, grid, scale):
+    g = _grid_i64(grid, x)
+    return _mm("quip_e8prvq4_mm_origorder", x, Qidxs, torch.int32, 8, 1,
+               lambda: (g.data_ptr(), float(scale)))
+
+
+def _d4_grid_f16(grid: Tensor):
+    # the reference kernel reinterprets `grid` as uint64[256], i.e. it silently
+    # requires fp16 (origin_order.cu:794-805); cast explicitly here.
+    _need(grid.numel() == 1024, "D4 grid must be (256, 4)")
+    return grid.to(torch.float16).contiguous()
+
+
+def _d4_mm_cuda(x, Qidxs, grid):
+    g = _d4_grid_f16(grid)
+    return _mm("quip_d4_mm_origorder", x, Qidxs, torch.uint8, 4, 1, lambda: (g.data_ptr(),))
+
+
+def _hi_mm_cuda(x, Qidxs):
+    return _mm("quip_hi_mm_origorder", x, Qidxs, torch.int32, 8, 1, lambda: ())
+
+
+# ---- decompress ops --------------------------------------------------------------------
+def _dec(fn_name, Q, qdtype, k, extra):
+    Qc = _chk_q(Q, qdtype)
+    w = torch.empty((Qc.shape[0], k), dtype=torch.float16, device=Q.device)
+    with torch.cuda.device(Q.device):
+        fn = getattr(capi.lib(), fn_name)
+        capi.check(fn(Qc.data_ptr(), *extra(), w.data_ptr(), Qc.shape[0], k, _stream(Q)), fn_name)
+    return w
+
+
+def _dec_e8p_cuda(Qidxs, grid):
+    g = _grid_i64(grid, Qidxs)
+    return _dec("quip_decompress_e8p_origorder", Qidxs, torch.int16, Qidxs.shape[1] * 8,
+                lambda: (g.data_ptr(),))
+
+
+def _dec_e8prvq3_cuda(Qidxs, grid, grid2, scale):
+    g = _grid_i64(grid, Qidxs)
+    g2 = grid2.contiguous()
+    _need(g2.dtype == torch.int32 and g2.numel() == 256, "e81b_grid_packed must be int32[256]")
+    return _dec("quip_decompress_e8prvq3_origorder", Qidxs, torch.int32, Qidxs.shape[1] * 32 // 3,
+                lambda: (g.data_ptr(), g2.data_ptr(), float(scale)))
+
+
+def _dec_e8prvq4_cuda(Qidxs, grid, scale):
+    g = _grid_i64(grid, Qidxs)
+    return _dec("quip_decompress_e8prvq4_origorder", Qidxs, torch.int32, Qidxs.shape[1] * 8,
+                lambda: (g.data_ptr(), float(scale)))
+
+
+def _dec_d4_cuda(Qidxs, grid):
+    g = _d4_grid_f16(grid)
+    return _dec("quip_decompress_d4_origorder", Qidxs, torch.uint8, Qidxs.shape[1] * 4,
+                lambda: (g.data_ptr(),))
+
+
+def _dec_hi_cuda(Qidxs):
+    return _dec("quip_decompress_hi_origorder", Qidxs, torch.int32, Qidxs.shape[1] * 8, lambda: ())
+
+
+_IMPLS = {
+    "hadamard": _hadamard_cuda,
+    "had_transform": _had_transform_cuda,
+    "e8p_mm_origorder": _e8p_mm_cuda,
+    "e8prvq3_mm_origorder": _e8prvq3_mm_cuda,
+    "e8prvq4_mm_origorder": _e8prvq4_mm_cuda,
+    "d4_mm_origorder": _d4_mm_cuda,
+    "hi_mm_origorder": _hi_mm_cuda,
+    "decompress_e8p_origorder": _dec_e8p_cuda,
+    "decompress_e8prvq3_origorder": _dec_e8prvq3_cuda,
+    "decompress_e8prvq4_origorder": _dec_e8prvq4_cuda,
+    "decompress_d4_origorder": _dec_d4_cuda,
+    "decompress_hi_origorder": _dec_hi_cuda,
+}
+for _name, _fn in _IMPLS.items():
+    _lib.impl(_name, _fn, "CUDA")
+
+
+# ---- fake (meta) implementations: shapes only, for torch.compile / export -----------------
+def _fake_mm(x, Qidxs, *a):
+    return x.new_empty((x.shape[0], Qidxs.shape[0]))
+
+
+def _reg_fake(name, fn):
+    torch.library.register_fake("quip_lib::" + name, fn, lib=_lib)
+
+
+_reg_fake("hadamard", lambda x, scale: torch.empty_like(x, memory_format=torch.contiguous_format))
+_reg_fake("had_transform", lambda x, out_features, n, K, had, transpose, pre, pre2, post, bias, scale:
+          x.new_empty((x.shape[0], out_features)))
+for _n in ("e8p_mm_origorder", "e8prvq3_mm_origorder", "e8prvq4_mm_origorder", "d4_mm_origorder",
+           "hi_mm_origorder"):
+    _reg_fake(_n, _fake_mm)
+_reg_fake("decompress_e8p_origorder", lambda Q, g: Q.new_empty((Q.shape[0], Q.shape[1] * 8), dtype=torch.float16))
+_reg_fake("decompress_e8prvq3_origorder",
+          lambda Q, g, g2, s: Q.new_empty((Q.shape[0], Q.shape[1] * 32 // 3), dtype=torch.float16))
+_reg_fake("decompress_e8prvq4_origorder",
+          lambda Q, g, s: Q.new_empty((Q.shape[0], Q.shape[1] * 8), dtype=torch.float16))
+_reg_fake("decompress_d4_origorder", lambda Q, g: Q.new_empty((Q.shape[0], Q.shape[1] * 4), dtype=torch.float16))
+_reg_fake("decompress_hi_origorder", lambda Q: Q.new_empty((Q.shape[0], Q.shape[1] * 8), dtype=torch.float16))
