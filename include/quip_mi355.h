@@ -27,6 +27,7 @@
 #ifndef QUIP_MI355_H_
 #define QUIP_MI355_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -70,6 +71,23 @@ int quip_hadamard_f16(const void* x, void* y, int64_t rows, int32_t n, float sca
 int quip_e8p_mm_origorder(const void* x, const void* qidxs /* int16 (n, k/8) */,
                           const void* grid_packed_abs /* int64[256] */, void* y,
                           int32_t m, int32_t n, int32_t k, quip_stream_t stream);
+/* Workspace variant of the E8P12 product.  At m == 1 (bs=1 decode) the fast path first
+ * rewrites x as block fixed point int8 digit planes (one tiny launch) and then runs the
+ * integer-domain decode GEMV; the planes live in caller-provided scratch so that the library
+ * still allocates nothing.  quip_e8p_mm_origorder() without workspace stays valid (it converts
+ * x inside every workgroup: self-contained but slower).  Other m: workspace unused. */
+size_t quip_e8p_mm_workspace_bytes(int32_t m, int32_t n, int32_t k);
+int quip_e8p_mm_origorder_ws(const void* x, const void* qidxs, const void* grid_packed_abs, void* y,
+                             int32_t m, int32_t n, int32_t k, void* workspace,
+                             size_t workspace_bytes, quip_stream_t stream);
+/* The two halves of the above, for callers that produce the planes themselves (the fused
+ * Hadamard kernel does): planes buffer = quip_e8p_planes_bytes(k) bytes, 16-byte aligned;
+ * layout documented in csrc/e8p_gemv_i8.hip.  k % 64 == 0. */
+size_t quip_e8p_planes_bytes(int32_t k);
+int quip_e8p_x_to_planes(const void* x /* fp16[k] */, void* planes, int32_t k, quip_stream_t stream);
+int quip_e8p_gemv_planes(const void* planes, const void* qidxs, const void* grid_packed_abs,
+                         void* y /* fp16[n] */, int32_t n, int32_t k, quip_stream_t stream);
+
 int quip_e8prvq3_mm_origorder(const void* x, const void* qidxs /* int32 (n, k*3/32) */,
                               const void* grid_packed_abs /* int64[256] */,
                               const void* e81b_grid_packed /* int32[256] */, float scale,
@@ -120,6 +138,15 @@ int quip_had_transform_f16(const void* x, void* y, int64_t rows, int32_t in_feat
                            const void* post_scale /* fp16[out_features] or NULL */,
                            const void* bias /* fp16[out_features] or NULL */,
                            float scale, quip_stream_t stream);
+
+/* Input side for the bs=1 decode path: the same transform as quip_had_transform_f16 (one row,
+ * no output slice / post scale), written directly as the digit planes quip_e8p_gemv_planes()
+ * consumes (quip_e8p_planes_bytes(n) bytes).  Removes the fp16 round trip of xh and the
+ * separate x -> planes launch: QuantLinear.forward at bs=1 is had_transform_planes ->
+ * e8p_gemv_planes -> had_transform_f16, three launches. */
+int quip_had_transform_planes(const void* x, void* planes, int32_t in_features, int32_t n, int32_t K,
+                              const void* had, int32_t transpose, const void* pre_scale, float scale,
+                              quip_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,13 @@ SIGNATURES = {
     "quip_device_cu_count": [],
     "quip_hadamard_f16": [_P, _P, _I64, _I32, _F, _P],
     "quip_had_transform_f16": [_P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _P, _P, _P, _F, _P],
+    "quip_had_transform_planes": [_P, _P, _I32, _I32, _I32, _P, _I32, _P, _F, _P],
     "quip_e8p_mm_origorder": [_P, _P, _P, _P, _I32, _I32, _I32, _P],
+    "quip_e8p_mm_workspace_bytes": [_I32, _I32, _I32],
+    "quip_e8p_mm_origorder_ws": [_P, _P, _P, _P, _I32, _I32, _I32, _P, _c.c_size_t, _P],
+    "quip_e8p_planes_bytes": [_I32],
+    "quip_e8p_x_to_planes": [_P, _P, _I32, _P],
+    "quip_e8p_gemv_planes": [_P, _P, _P, _P, _I32, _I32, _P],
     "quip_e8prvq3_mm_origorder": [_P, _P, _P, _P, _F, _P, _I32, _I32, _I32, _P],
     "quip_e8prvq4_mm_origorder": [_P, _P, _P, _F, _P, _I32, _I32, _I32, _P],
     "quip_d4_mm_origorder": [_P, _P, _P, _P, _I32, _I32, _I32, _P],
@@ -29,7 +35,8 @@ SIGNATURES = {
 }
 # not part of the public header: tuning hook used by the micro-benchmarks only
 _INTERNAL = {
-    "quip_e8p_gemv_tuned": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P],
+    "quip_e8p_x_to_planes_laneorder": [_P, _P, _I32, _P],
+    "quip_e8p_gemv_tuned": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P],
 }
 
 _lib = None
@@ -50,7 +57,7 @@ def lib():
         for name, args in list(SIGNATURES.items()) + list(_INTERNAL.items()):
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
             fn.argtypes = args
-            fn.restype = _c.c_int
+            fn.restype = _c.c_size_t if name.endswith("_bytes") else _c.c_int
         L.quip_strerror.argtypes = [_c.c_int]
         L.quip_strerror.restype = _c.c_char_p
         _lib = L

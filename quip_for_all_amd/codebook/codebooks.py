@@ -49,6 +49,15 @@ class E8P12_codebook(_Codebook):
     def mm(self, input, Qidxs):
         return torch.ops.quip_lib.e8p_mm_origorder(input, Qidxs, self.grid_packed_abs)
 
+    @staticmethod
+    def planes_supported(q_out, q_in):
+        """shapes the matrix-core bs=1 GEMV takes (csrc/e8p_gemv_mfma.hip)"""
+        return q_in % 128 == 0 and 128 <= q_in <= 28672 and q_out >= 1
+
+    def mm_planes(self, planes, Qidxs):
+        """bs=1 product with x given as int8 digit planes (quip_lib::had_transform_planes)"""
+        return torch.ops.quip_lib.e8p_gemv_planes(planes, Qidxs, self.grid_packed_abs)
+
 
 class E8P12RVQ4B_codebook(_Codebook):
     def __init__(self, inference=False, opt_resid_scale=None, **kwargs):

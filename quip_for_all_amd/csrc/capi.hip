@@ -68,24 +68,81 @@ int quip_had_transform_f16(const void* x, void* y, int64_t rows, int32_t in_feat
                               pre_scale, pre_scale2, post_scale, bias, scale, (hipStream_t)stream);
 }
 
+int quip_had_transform_planes(const void* x, void* planes, int32_t in_features, int32_t n, int32_t K,
+                              const void* had, int32_t transpose, const void* pre_scale, float scale,
+                              quip_stream_t stream) {
+  if (!x || !planes) return QUIP_ERR_NULL_POINTER;
+  if (!aligned16(planes)) return QUIP_ERR_MISALIGNED;
+  return had_transform_planes_launch(x, planes, in_features, n, K, had, transpose, pre_scale, scale,
+                                     (hipStream_t)stream);
+}
+
 int quip_e8p_mm_origorder(const void* x, const void* qidxs, const void* grid, void* y, int32_t m,
                           int32_t n, int32_t k, quip_stream_t stream) {
   if (!grid) return QUIP_ERR_NULL_POINTER;
-  if (x && qidxs && y && m == 1 && n > 0 && e8p_gemv_m1_supported(n, k) && aligned16(x) &&
+  if (x && qidxs && y && m == 1 && n > 0 && e8p_gemv_i8_supported(n, k) && aligned16(x) &&
       aligned16(qidxs))
-    return e8p_gemv_m1_launch(x, qidxs, grid, y, n, k, GemvTune{}, (hipStream_t)stream);
+    return e8p_gemv_i8_launch(x, 1, qidxs, grid, y, n, k, GemvTune{}, (hipStream_t)stream);
   CodebookArgs a;
   a.grid = grid;
   return mm_common(kE8P, x, qidxs, a, y, m, n, k, 8, (hipStream_t)stream);
 }
 
+static inline bool aligned64(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 63u) == 0; }
+
+size_t quip_e8p_planes_bytes(int32_t k) { return k > 0 ? e8p_gemv_mfma_planes_bytes(k) : 0; }
+
+size_t quip_e8p_mm_workspace_bytes(int32_t m, int32_t n, int32_t k) {
+  return (m == 1 && e8p_gemv_mfma_supported(n, k)) ? e8p_gemv_mfma_planes_bytes(k) : 0;
+}
+
+int quip_e8p_x_to_planes(const void* x, void* planes, int32_t k, quip_stream_t stream) {
+  if (!x || !planes) return QUIP_ERR_NULL_POINTER;
+  if (!aligned16(x) || !aligned16(planes)) return QUIP_ERR_MISALIGNED;
+  return x_to_planes_linear_launch(x, planes, k, (hipStream_t)stream);
+}
+
+int quip_e8p_gemv_planes(const void* planes, const void* qidxs, const void* grid, void* y, int32_t n,
+                         int32_t k, quip_stream_t stream) {
+  if (!planes || !qidxs || !grid || !y) return QUIP_ERR_NULL_POINTER;
+  if (n < 0) return QUIP_ERR_BAD_SHAPE;
+  if (n == 0) return QUIP_OK;
+  if (!aligned16(planes) || !aligned16(qidxs) || !aligned64(grid)) return QUIP_ERR_MISALIGNED;
+  return e8p_gemv_mfma_launch(planes, qidxs, grid, y, n, k, GemvTune{}, (hipStream_t)stream);
+}
+
+int quip_e8p_mm_origorder_ws(const void* x, const void* qidxs, const void* grid, void* y, int32_t m,
+                             int32_t n, int32_t k, void* workspace, size_t workspace_bytes,
+                             quip_stream_t stream) {
+  if (x && qidxs && grid && y && workspace && m == 1 && n > 0 && e8p_gemv_mfma_supported(n, k) &&
+      aligned16(x) && aligned16(qidxs) && aligned16(workspace) && aligned64(grid) &&
+      workspace_bytes >= e8p_gemv_mfma_planes_bytes(k)) {
+    const int rc = x_to_planes_linear_launch(x, workspace, k, (hipStream_t)stream);
+    if (rc != QUIP_OK) return rc;
+    return e8p_gemv_mfma_launch(workspace, qidxs, grid, y, n, k, GemvTune{}, (hipStream_t)stream);
+  }
+  return quip_e8p_mm_origorder(x, qidxs, grid, y, m, n, k, stream);
+}
+
+int quip_e8p_x_to_planes_laneorder(const void* x, void* planes, int32_t k, quip_stream_t stream) {
+  if (!x || !planes) return QUIP_ERR_NULL_POINTER;
+  return x_to_planes_launch(x, planes, k, (hipStream_t)stream);
+}
+
 int quip_e8p_gemv_tuned(const void* x, const void* qidxs, const void* grid, void* y, int32_t n,
-                        int32_t k, int32_t rep, int32_t rows, int32_t blocks, int32_t waves_g,
+                        int32_t k, int32_t kernel, int32_t rep, int32_t rows, int32_t blocks,
+                        int32_t waves_g, int32_t max_waves, int32_t digits, void* dbg,
                         quip_stream_t stream) {
   if (!x || !qidxs || !grid || !y) return QUIP_ERR_NULL_POINTER;
   GemvTune t;
   t.rep = rep; t.rows = rows; t.blocks = blocks; t.waves_g = waves_g;
-  return e8p_gemv_m1_launch(x, qidxs, grid, y, n, k, t, (hipStream_t)stream);
+  t.max_waves = max_waves; t.digits = digits; t.dbg = dbg;
+  if (kernel == 2) return stream_probe_launch(qidxs, y, n, k, t, (hipStream_t)stream);
+  if (kernel == 5) return pattern_probe_launch(qidxs, y, n, k, t, (hipStream_t)stream);
+  if (kernel == 4) return e8p_gemv_mfma_launch(x, qidxs, grid, y, n, k, t, (hipStream_t)stream);
+  // kernel 4: matrix-core GEMV on linear digit planes; kernel 0: VALU integer GEMV on lane-ordered
+  // digit planes; kernel 3: the same converting fp16 x itself
+  return e8p_gemv_i8_launch(x, kernel == 3 ? 1 : 0, qidxs, grid, y, n, k, t, (hipStream_t)stream);
 }
 
 int quip_e8prvq3_mm_origorder(const void* x, const void* qidxs, const void* grid,

@@ -1,0 +1,557 @@
+// E8P12 decode GEMV for gfx950, integer-domain variant (the default bs=1 path).
+//
+//   y[n] = sum_k W[n,k] x[k],  W = decode(Qidxs (n, k/8) int16)
+//
+// Replaces the M=1 use of tinygemm_m16n8k16_chunk_kernel<.., BLayout_E8, ..>
+// (origin_order.cu:388-555, 604-648).  Same decode statement as the reference's
+// decode8weights (origin_order.cu:211-253): with P = grid_packed_abs[code >> 8],
+//     4*w (8 x int8) = ((P ^ 0xFC-where-negated) | 0x01..) - parity * 0x02..
+// Two facts turn this into two table lookups and two XORs per code:
+//   (a) "| 1" commutes with the sign XOR (bit 0 is untouched by 0xFC), so it is
+//       folded into the abs table:   T1[abs]  = P | 0x0101010101010101
+//   (b) every byte of (P ^ neg) | 1 is one of 3,7,11,15,-1,-5,-9,-13: bit 1 is
+//       always set, so "- 2" == "^ 2" and the parity shift folds into the sign
+//       table:                        T2[sign] = negmask(sign ^ par) ^ (par ? 0x02.. : 0)
+//   =>  4*w = T1[code >> 8] ^ T2[code & 255]      (bytes in natural position order)
+// The products are then taken in integers with v_dot4c_i32_i8.  x (fp16) is
+// converted once per workgroup to block fixed point, X = rint(x * 2^sh) with
+// |X| < 2^22 (sh from the largest |x|), and split into three balanced int8 digit
+// planes X = h*65536 + m*256 + l.  Every x element within 2^-11 of the largest
+// magnitude is represented exactly, smaller ones to 2^-22 of it; the accumulation
+// itself is exact (int32, no overflow: 64 terms * 15 * 128 per lane-row), so the
+// result does not depend on summation order.  Error vs exact fp64:
+//     <= 2^-23 * max|x| * sum_k|w_k|  (x rounding)  + 3 fp32 roundings of the row total
+// i.e. the same class as the reference's fp32 tensor-core accumulation.
+//
+// Work decomposition (wave64): a packed row is K/4 bytes = J slices of 1 KiB, one
+// wave-wide global_load_dwordx4 each (lane = 8 codes = 64 weights).  Wave (g, j)
+// of a workgroup walks rows g, g+G, ... of the workgroup's row block and always
+// reads slice j, so its 64 x values never change: the three digit planes live in
+// 48 VGPRs for the whole kernel.  Per code: 2 v_perm_b32 (LDS addresses),
+// 2 ds_read_b64, 2 v_xor, 6 v_dot4c = 10 VALU ops per 8 weights.
+//
+// LDS tables: REP = 32 stores each 8-byte entry 32 times, filling its own 256-byte
+// bank row; lane l reads copy (l & 31), so the two 32-lane halves of a ds_read_b64
+// never bank-conflict whatever the codes are (128 KiB for both tables; the fill
+// overlaps the first HBM round trip of the weight loads issued before it).
+// REP = 1 keeps compact 2 KiB tables for launches too small to amortise the fill.
+#include "quip_device.hip.h"
+#include "quip_internal.h"
+
+namespace quip {
+
+namespace {
+
+constexpr int kMaxPartials = 4096;  // floats of LDS for per-row slice partials
+
+template <int REP>
+struct Lds {
+  static constexpr int kT1 = 0;
+  static constexpr int kT2 = (REP == 32) ? 0x10000 : 0x800;
+  static constexpr int kPart = (REP == 32) ? 0x20000 : 0x1000;
+  static constexpr int kEnd = kPart + kMaxPartials * 4;
+  // staging (aliases the tables, used before they are filled): 16 floats of
+  // per-wave maxima, then the three digit planes
+  static constexpr int kStageMax = (REP == 32) ? 0 : kEnd;
+  static constexpr int kStagePlanes = kStageMax + 64;
+  static int bytes(int K) {
+    const int slices = K >> 6, S = slices | 1;
+    const int stage_end = kStagePlanes + 3 * 8 * S * 8;
+    return stage_end > kEnd ? stage_end : kEnd;
+  }
+};
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) u32x2* lds_u2_ptr;
+// LDS read by absolute byte address: the kernel has no static __shared__, so the
+// dynamic segment starts at LDS address 0 and v_perm-built offsets are absolute.
+__device__ __forceinline__ uint2 lds_read8(uint32_t addr) {
+  const u32x2 v = *reinterpret_cast<lds_u2_ptr>((uintptr_t)addr);
+  return make_uint2(v.x, v.y);
+}
+
+__device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int acc) {
+  return __builtin_amdgcn_sdot4((int)a, (int)b, acc, false);
+}
+
+template <int REP, bool HIGH>
+__device__ __forceinline__ void code_addr(uint32_t d, uint32_t lane_c, uint32_t& a1, uint32_t& a2) {
+  if constexpr (REP == 32) {
+    // address = table_base | idx << 8 | (lane & 31) << 3 with one v_perm_b32 each:
+    // result bytes {3,2,1,0} <- {0, lane_c.b2 (0x01 = T2 base) or 0, d.byte(idx), lane_c.b0}
+    a1 = __builtin_amdgcn_perm(d, lane_c, HIGH ? 0x0c0c0700u : 0x0c0c0500u);
+    a2 = __builtin_amdgcn_perm(d, lane_c, HIGH ? 0x0c020600u : 0x0c020400u);
+  } else {
+    a1 = HIGH ? ((d >> 21) & 0x7f8u) : ((d >> 5) & 0x7f8u);
+    a2 = (HIGH ? ((d >> 13) & 0x7f8u) : ((d << 3) & 0x7f8u)) | Lds<1>::kT2;
+  }
+}
+
+struct Acc3 { int h, m, l; };
+
+template <int NDIG>
+__device__ __forceinline__ void code_mac(uint2 t1, uint2 t2, const uint2 (&xd)[3], Acc3& a) {
+  const uint32_t w0 = t1.x ^ t2.x, w1 = t1.y ^ t2.y;  // 4*w, positions 0-3 / 4-7
+  a.h = dot4(w1, xd[0].y, dot4(w0, xd[0].x, a.h));
+  a.m = dot4(w1, xd[1].y, dot4(w0, xd[1].x, a.m));
+  if constexpr (NDIG == 3) a.l = dot4(w1, xd[2].y, dot4(w0, xd[2].x, a.l));
+}
+
+// one packed row slice (8 codes of this lane) against the lane's x digits
+template <int REP, int NDIG>
+__device__ __forceinline__ float row_dot(const uint4& q, const uint2 (&xd)[8][3], uint32_t lane_c) {
+  uint32_t a1[8], a2[8];
+  code_addr<REP, false>(q.x, lane_c, a1[0], a2[0]);
+  code_addr<REP, true>(q.x, lane_c, a1[1], a2[1]);
+  code_addr<REP, false>(q.y, lane_c, a1[2], a2[2]);
+  code_addr<REP, true>(q.y, lane_c, a1[3], a2[3]);
+  code_addr<REP, false>(q.z, lane_c, a1[4], a2[4]);
+  code_addr<REP, true>(q.z, lane_c, a1[5], a2[5]);
+  code_addr<REP, false>(q.w, lane_c, a1[6], a2[6]);
+  code_addr<REP, true>(q.w, lane_c, a1[7], a2[7]);
+  uint2 t1[8], t2[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { t1[c] = lds_read8(a1[c]); t2[c] = lds_read8(a2[c]); }
+  Acc3 a{0, 0, 0};
+#pragma unroll
+  for (int c = 0; c < 8; ++c) code_mac<NDIG>(t1[c], t2[c], xd[c], a);
+  float f = __builtin_fmaf((float)a.h, 65536.f, 256.f * (float)a.m);
+  if constexpr (NDIG == 3) f += (float)a.l;
+  return f;
+}
+
+// Compact sign table (pure function of the sign byte), built at compile time.
+struct T2Image {
+  uint2 v[256];
+  constexpr T2Image() : v{} {
+    for (int s = 0; s < 256; ++s) {
+      int par = 0;
+      for (int b = 0; b < 8; ++b) par ^= (s >> b) & 1;
+      const int sv = s ^ par;
+      uint32_t lo = 0, hi = 0;
+      for (int p = 0; p < 4; ++p) {
+        lo |= (((sv >> (7 - e8p_byte_of_pos(p))) & 1) ? 0xfcu : 0u) << (8 * p);
+        hi |= (((sv >> (7 - e8p_byte_of_pos(p + 4))) & 1) ? 0xfcu : 0u) << (8 * p);
+      }
+      const uint32_t sh = par ? 0x02020202u : 0u;
+      v[s].x = lo ^ sh;
+      v[s].y = hi ^ sh;
+    }
+  }
+};
+__device__ const T2Image kT2Image{};
+
+// T1 entry from grid_packed_abs[e] with two v_perm_b32: natural position order
+// (bytes 0,2,1,3 / 4,6,5,7 of the packed word), each byte OR 1.
+__device__ __forceinline__ uint2 t1_entry_fast(uint2 packed) {
+  return make_uint2(__builtin_amdgcn_perm(0u, packed.x, 0x03010200u) | 0x01010101u,
+                    __builtin_amdgcn_perm(0u, packed.y, 0x03010200u) | 0x01010101u);
+}
+
+// Fill both LDS tables.  REP == 32: entry e is wave-uniform, so grid[e] and the T2
+// image come through scalar (SMEM) loads, which do not queue behind the in-order
+// VMEM weight loads already in flight; lanes 0-31 write the 32 copies of T1[e],
+// lanes 32-63 those of T2[e] (one conflict-free 512-byte ds_write_b64 per entry).
+template <int REP>
+__device__ __forceinline__ void fill_tables(char* smem, const uint64_t* __restrict__ grid, int tid,
+                                            int nthreads) {
+  using L = Lds<REP>;
+  if constexpr (REP == 32) {
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = __builtin_amdgcn_readfirstlane(nthreads >> 6);
+    const bool hi = lane >= 32;
+    char* base = smem + (hi ? L::kT2 : L::kT1) + (lane & 31) * 8;
+    const uint2* g2 = reinterpret_cast<const uint2*>(grid);
+#pragma unroll 4
+    for (int e = wave; e < 256; e += nwaves) {
+      const uint2 a = g2[e];             // uniform address -> s_load_dwordx2
+      const uint2 b = kT2Image.v[e];     // constant address space -> s_load_dwordx2
+      const uint2 t1 = t1_entry_fast(a);
+      *reinterpret_cast<uint2*>(base + e * 256) = hi ? b : t1;
+    }
+  } else {
+    const uint2* g2 = reinterpret_cast<const uint2*>(grid);
+    for (int e = tid; e < 256; e += nthreads) {
+      reinterpret_cast<uint2*>(smem + L::kT1)[e] = t1_entry_fast(g2[e]);
+      reinterpret_cast<uint2*>(smem + L::kT2)[e] = kT2Image.v[e];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// x -> block fixed point digit planes (see header comment).  Layout of `planes`
+// (uint2 units): [(c * 3 + d) * slices + lp], c = code slot 0..7 inside a lane's
+// 16-byte weight piece, d = digit plane (0 = h, 1 = m, 2 = l), lp = piece index in
+// the packed row; i.e. exactly the order in which GEMV lane lp consumes them, so its
+// 24 loads are coalesced 8-byte reads.  One workgroup; k % 64 == 0.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void x_digits(const uint4& v, float scale, uint32_t (&dg)[3][2]) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) dg[d][0] = dg[d][1] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const f16x2 h2 = as_f16x2(w[i >> 1]);
+    const int X = (int)__builtin_rintf((float)((i & 1) ? h2.y : h2.x) * scale);
+    const int l = (X << 24) >> 24;
+    const int X1 = (X - l) >> 8;
+    const int m = (X1 << 24) >> 24;
+    const int h = (X1 - m) >> 8;
+    const int sft = 8 * (i & 3);
+    dg[0][i >> 2] |= (uint32_t)(h & 0xff) << sft;
+    dg[1][i >> 2] |= (uint32_t)(m & 0xff) << sft;
+    dg[2][i >> 2] |= (uint32_t)(l & 0xff) << sft;
+  }
+}
+
+__global__ __launch_bounds__(1024) void x_to_planes_kernel(const f16* __restrict__ x,
+                                                           uint2* __restrict__ planes,
+                                                           int* __restrict__ sh_out, int K) {
+  __shared__ uint32_t smax[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  const uint4* xg = reinterpret_cast<const uint4*>(x);
+  const int pieces = K >> 3, slices = K >> 6;
+  uint32_t mx = 0;  // fp16 magnitudes order like their bit patterns
+  for (int p = tid; p < pieces; p += nthreads) {
+    const uint4 v = xg[p];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mx = max(mx, max(w[i] & 0x7fffu, (w[i] >> 16) & 0x7fffu));
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+  if (lane == 0) smax[wave] = mx;
+  __syncthreads();
+  mx = 0;
+  for (int w = 0; w < (nthreads >> 6); ++w) mx = max(mx, smax[w]);
+  // exponent of the largest magnitude; X = rint(x * 2^sh) then satisfies |X| < 2^22
+  const int ebits = (int)(mx >> 10);
+  const int sh = 21 - ((ebits ? ebits : 1) - 15);
+  const float scale = as_f32((uint32_t)(sh + 127) << 23);
+  if (tid == 0) *sh_out = sh;
+  for (int p = tid; p < pieces; p += nthreads) {
+    uint32_t dg[3][2];
+    x_digits(xg[p], scale, dg);
+    const int c = p & 7, lp = p >> 3;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) planes[(c * 3 + d) * slices + lp] = make_uint2(dg[d][0], dg[d][1]);
+  }
+}
+
+// XMODE 0: x given as digit planes + shift (fast path, produced by x_to_planes or by
+//          the fused Hadamard kernel); XMODE 1: x given as fp16, converted in the
+//          prologue by every workgroup (self-contained fallback, slower).
+template <int REP, int ROWS, int NDIG, int MAXT, int XMODE>
+__global__ __launch_bounds__(MAXT) void e8p_gemv_i8_kernel(
+    const uint4* __restrict__ W, const void* __restrict__ xsrc, const int* __restrict__ sh_ptr,
+    f16* __restrict__ y, const uint64_t* __restrict__ grid, int N, int K, int J, int G,
+    int rows_per_block, uint64_t* __restrict__ dbg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using L = Lds<REP>;
+  // optional phase timestamps (micro-benchmark only): 8 x s_memtime per workgroup
+#define QUIP_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+  QUIP_STAMP(0);
+  const int tid = threadIdx.x;
+  const int nthreads = blockDim.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = wave % J, g = wave / J;
+  const int slices = K >> 6;   // 16-byte pieces per packed row (64 weights each)
+  const int lp = j * 64 + lane;
+  const bool active = lp < slices;
+  const int row0 = blockIdx.x * rows_per_block;
+  const int row_end = min(N, row0 + rows_per_block);
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  const uint4* Wl = W + (active ? lp : 0);  // inactive lanes: valid address, x digits = 0
+
+  // VMEM loads return in issue order, so the prologue issues them in the order they are
+  // needed: REP == 1 table sources, x digits (L2 hits), then the first (TLB-cold, HBM)
+  // weight loads, whose latency covers the table fill.
+  uint2 xd[8][3];
+  int sh;
+  uint4 q[ROWS];
+  int r = row0 + g;
+  if constexpr (XMODE == 0) {
+    // (0) this lane's x digits: 24 coalesced 8-byte loads
+    // (inactive lanes read lane 0's entry and mask it: no exec-mask branches)
+    const uint2* planes = reinterpret_cast<const uint2*>(xsrc) + (active ? lp : 0);
+    const uint32_t keep = active ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        if (d < NDIG) {
+          const uint2 v = planes[(c * 3 + d) * slices];
+          xd[c][d] = make_uint2(v.x & keep, v.y & keep);
+        } else {
+          xd[c][d] = make_uint2(0, 0);
+        }
+      }
+    sh = *sh_ptr;  // scalar load
+  }
+  if constexpr (REP == 1) fill_tables<REP>(smem, grid, tid, nthreads);
+  // (1) first weight loads
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) {
+    const int ri = r + i * G;
+    q[i] = zero4;
+    if (ri < row_end) q[i] = ld_nt_u4(Wl + (size_t)ri * slices);
+  }
+  QUIP_STAMP(1);
+
+  if constexpr (XMODE == 0) {
+    QUIP_STAMP(2);
+    QUIP_STAMP(3);
+  } else {
+    const int S = slices | 1;    // odd stride of the staging planes (bank spread)
+    const int nwaves = nthreads >> 6;
+    const uint4* xg = reinterpret_cast<const uint4*>(xsrc);
+    const int pieces = K >> 3;
+    uint32_t mx = 0;
+    for (int p = tid; p < pieces; p += nthreads) {
+      const uint4 v = xg[p];
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mx = max(mx, max(w[i] & 0x7fffu, (w[i] >> 16) & 0x7fffu));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+    uint32_t* smax = reinterpret_cast<uint32_t*>(smem + L::kStageMax);
+    if (lane == 0) smax[wave] = mx;
+    __syncthreads();
+    mx = 0;
+    for (int w = 0; w < nwaves; ++w) mx = max(mx, smax[w]);
+    const int ebits = (int)(mx >> 10);
+    sh = 21 - ((ebits ? ebits : 1) - 15);
+    const float scale = as_f32((uint32_t)(sh + 127) << 23);
+    QUIP_STAMP(2);
+    uint2* planes = reinterpret_cast<uint2*>(smem + L::kStagePlanes);
+    for (int p = tid; p < pieces; p += nthreads) {
+      uint32_t dg[3][2];
+      x_digits(xg[p], scale, dg);
+      const int idx = (p & 7) * S + (p >> 3);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) planes[d * 8 * S + idx] = make_uint2(dg[d][0], dg[d][1]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        xd[c][d] = active ? planes[d * 8 * S + c * S + lp] : make_uint2(0, 0);
+    __syncthreads();  // staging aliases the tables / partials
+    QUIP_STAMP(3);
+  }
+
+  // (2) decode tables
+  if constexpr (REP != 1) fill_tables<REP>(smem, grid, tid, nthreads);
+  __syncthreads();
+  QUIP_STAMP(4);
+
+  // lane constant of the v_perm address builder: byte0 = copy * 8, byte2 = 0x01 (T2 at 0x10000)
+  const uint32_t lane_c = (REP == 32) ? (((uint32_t)(lane & 31) << 3) | 0x00010000u) : 0u;
+  float* part = reinterpret_cast<float*>(smem + L::kPart);
+
+  // (3) stream the rows: ROWS rotating load slots per wave; the steady-state loop has
+  //     no conditional loads (hipcc drains vmcnt(0) at exec-mask joins otherwise).
+  for (; r + (2 * ROWS - 1) * G < row_end; r += ROWS * G) {
+    float acc[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      const uint4 qi = q[i];
+      q[i] = ld_nt_u4(Wl + (size_t)(r + (ROWS + i) * G) * slices);
+      acc[i] = row_dot<REP, NDIG>(qi, xd, lane_c);
+      // Pin the row here: the opaque use keeps the dot products from being sunk down to
+      // the reductions below (which would keep every row's table reads live, ~32 VGPRs
+      // per row), the sched_barrier keeps the next row's LDS reads from moving up.
+      asm volatile("" : "+v"(acc[i]) : : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      const float tot = wave_sum_to_lane63(acc[i]);
+      if (lane == 63) part[(r + i * G - row0) * J + j] = tot;
+    }
+  }
+  for (; r < row_end; r += ROWS * G) {
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      const uint4 qi = q[i];
+      const int ri = r + i * G;
+      const int rn = ri + ROWS * G;
+      if (rn < row_end) q[i] = ld_nt_u4(Wl + (size_t)rn * slices);
+      if (ri < row_end) {
+        const float tot = wave_sum_to_lane63(row_dot<REP, NDIG>(qi, xd, lane_c));
+        if (lane == 63) part[(ri - row0) * J + j] = tot;
+      }
+    }
+  }
+  QUIP_STAMP(5);
+  __syncthreads();
+  QUIP_STAMP(6);
+
+  // (4) sum the J slices of each row, undo the fixed-point scale (2^-sh) and the
+  //     factor 4 of the byte weights, round to fp16, coalesced store
+  const float unscale = as_f32((uint32_t)(127 - sh - 2) << 23);
+  for (int t = tid; t < row_end - row0; t += nthreads) {
+    float s = 0.f;
+    for (int jj = 0; jj < J; ++jj) s += part[t * J + jj];
+    y[row0 + t] = (f16)(s * unscale);
+  }
+  QUIP_STAMP(7);
+#undef QUIP_STAMP
+}
+
+template <int REP, int ROWS, int NDIG, int MAXT, int XMODE>
+int launch_variant(const void* xsrc, const int* sh, const void* qidxs, const void* grid, void* y,
+                   int n, int k, int J, int G, int rpb, int nblocks, uint64_t* dbg,
+                   hipStream_t stream) {
+  auto kern = e8p_gemv_i8_kernel<REP, ROWS, NDIG, MAXT, XMODE>;
+  const int lds = XMODE ? Lds<REP>::bytes(k) : Lds<REP>::kEnd;
+  static int configured_lds = 0;  // per instantiation; benign race (idempotent attribute)
+  if (lds > configured_lds) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return QUIP_ERR_LAUNCH;
+    configured_lds = lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64 * G * J), lds, stream,
+                     reinterpret_cast<const uint4*>(qidxs), xsrc, sh, reinterpret_cast<f16*>(y),
+                     reinterpret_cast<const uint64_t*>(grid), n, k, J, G, rpb, dbg);
+  return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+}
+
+// Streaming-read probe: same grid / load pattern as the GEMV (rotating nt loads of
+// 1 KiB per wave), no decode.  Gives the read-bandwidth ceiling of this launch
+// geometry for a buffer of the same size (micro-benchmark only).
+template <int ROWS>
+__global__ __launch_bounds__(1024) void stream_probe_kernel(const uint4* __restrict__ W,
+                                                            uint32_t* __restrict__ out, int N,
+                                                            int slices, int J, int G,
+                                                            int rows_per_block) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = wave % J, g = wave / J;
+  const int lp = j * 64 + lane;
+  const bool active = lp < slices;
+  const int row0 = blockIdx.x * rows_per_block;
+  const int row_end = min(N, row0 + rows_per_block);
+  const uint4* Wl = W + (active ? lp : 0);
+  uint32_t acc = 0;
+  uint4 q[ROWS];
+  int r = row0 + g;
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) {
+    q[i] = make_uint4(0, 0, 0, 0);
+    if (r + i * G < row_end) q[i] = ld_nt_u4(Wl + (size_t)(r + i * G) * slices);
+  }
+  for (; r + (2 * ROWS - 1) * G < row_end; r += ROWS * G) {
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      const uint4 qi = q[i];
+      q[i] = ld_nt_u4(Wl + (size_t)(r + (ROWS + i) * G) * slices);
+      acc ^= qi.x ^ qi.y ^ qi.z ^ qi.w;
+    }
+  }
+  for (; r < row_end; r += ROWS * G) {
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      const uint4 qi = q[i];
+      const int rn = r + (ROWS + i) * G;
+      if (rn < row_end) q[i] = ld_nt_u4(Wl + (size_t)rn * slices);
+      if (r + i * G < row_end) acc ^= qi.x ^ qi.y ^ qi.z ^ qi.w;
+    }
+  }
+  if (acc == 0x12345678u) out[0] = acc;  // keep the loads alive
+}
+
+}  // namespace
+
+int stream_probe_launch(const void* qidxs, void* out, int n, int k, const GemvTune& tune,
+                        hipStream_t stream) {
+  const int slices = k / 64, J = (slices + 63) / 64;
+  const int max_waves = tune.max_waves > 0 ? tune.max_waves : 16;
+  int nblocks = tune.blocks > 0 ? tune.blocks : device_cu_count();
+  int rpb = (n + nblocks - 1) / nblocks;
+  int G = tune.waves_g > 0 ? tune.waves_g : (max_waves / J > 0 ? max_waves / J : 1);
+  if (G > rpb) G = rpb;
+  if (G * J > 16) G = 16 / J;
+  if (G < 1) G = 1;
+  nblocks = (n + rpb - 1) / rpb;
+  const int rows = tune.rows ? tune.rows : 2;
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64 * G * J), 0, stream,
+                       reinterpret_cast<const uint4*>(qidxs), reinterpret_cast<uint32_t*>(out), n,
+                       slices, J, G, rpb);
+    return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+  };
+  if (rows == 1) return go(stream_probe_kernel<1>);
+  if (rows == 2) return go(stream_probe_kernel<2>);
+  if (rows == 4) return go(stream_probe_kernel<4>);
+  return go(stream_probe_kernel<8>);
+}
+
+bool e8p_gemv_i8_supported(int n, int k) {
+  if (n < 1 || k < 64 || k % 64 != 0) return false;
+  const int J = (k / 64 + 63) / 64;
+  return J <= 16 && Lds<32>::bytes(k) <= 160 * 1024;
+}
+
+size_t e8p_gemv_planes_bytes(int k) { return (size_t)3 * k + 16; }  // planes + shift word
+
+int x_to_planes_launch(const void* x, void* planes, int k, hipStream_t stream) {
+  if (k < 64 || k % 64 != 0) return QUIP_ERR_BAD_SHAPE;
+  int* sh = reinterpret_cast<int*>(reinterpret_cast<char*>(planes) + (size_t)3 * k);
+  const int threads = k >= 8192 ? 1024 : (k >= 2048 ? 256 : 64);
+  hipLaunchKernelGGL(x_to_planes_kernel, dim3(1), dim3(threads), 0, stream,
+                     reinterpret_cast<const f16*>(x), reinterpret_cast<uint2*>(planes), sh, k);
+  return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+}
+
+// xmode 0: `xsrc` = planes buffer (3*k bytes of digits followed by the int shift);
+// xmode 1: `xsrc` = fp16 x.
+int e8p_gemv_i8_launch(const void* xsrc, int xmode, const void* qidxs, const void* grid, void* y,
+                       int n, int k, const GemvTune& tune, hipStream_t stream) {
+  if (!e8p_gemv_i8_supported(n, k)) return QUIP_ERR_UNSUPPORTED;
+  uint64_t* dbg = reinterpret_cast<uint64_t*>(tune.dbg);
+  const int* sh = xmode ? nullptr
+                        : reinterpret_cast<const int*>(reinterpret_cast<const char*>(xsrc) + (size_t)3 * k);
+  const int slices = k / 64;
+  const int J = (slices + 63) / 64;
+  const int ncu = device_cu_count();
+  const int max_waves = tune.max_waves > 0 ? tune.max_waves : 16;
+  int nblocks = tune.blocks > 0 ? tune.blocks : ncu;
+  int rpb = (n + nblocks - 1) / nblocks;
+  int G = tune.waves_g > 0 ? tune.waves_g : (max_waves / J > 0 ? max_waves / J : 1);
+  if (G > rpb) G = rpb;
+  if (G * J > 16) G = 16 / J;
+  if (G < 1) G = 1;
+  while (rpb * J > kMaxPartials) { nblocks *= 2; rpb = (n + nblocks - 1) / nblocks; }
+  nblocks = (n + rpb - 1) / rpb;
+  const long long bytes = (long long)n * k / 4;
+  const int rep = tune.rep ? tune.rep : (bytes >= (6ll << 20) ? 32 : 1);
+  const int per_wave = (rpb + G - 1) / G;
+  int rows = tune.rows ? tune.rows : (per_wave >= 16 ? 8 : (per_wave >= 8 ? 4 : (per_wave >= 2 ? 2 : 1)));
+  const int ndig = tune.digits ? tune.digits : 3;
+  const bool big = G * J * 64 > 512;  // > 8 waves per workgroup: 128-VGPR budget
+  if (xmode == 1) {  // self-contained fallback: few instantiations
+    if (rows > 2) rows = 2;
+    if (rep == 32)
+      return big ? launch_variant<32, 2, 3, 1024, 1>(xsrc, sh, qidxs, grid, y, n, k, J, G, rpb, nblocks, dbg, stream)
+                 : launch_variant<32, 2, 3, 512, 1>(xsrc, sh, qidxs, grid, y, n, k, J, G, rpb, nblocks, dbg, stream);
+    return big ? launch_variant<1, 2, 3, 1024, 1>(xsrc, sh, qidxs, grid, y, n, k, J, G, rpb, nblocks, dbg, stream)
+               : launch_variant<1, 2, 3, 512, 1>(xsrc, sh, qidxs, grid, y, n, k, J, G, rpb, nblocks, dbg, stream);
+  }
+#define QUIP_CASE(R, RW, ND)                                                                             \
+  if (rep == R && rows == RW && ndig == ND)                                                              \
+    return big ? launch_variant<R, RW, ND, 1024, 0>(xsrc, sh, qidxs, grid, y, n, k, J, G, rpb, nblocks, dbg, stream) \
+               : launch_variant<R, RW, ND, 512, 0>(xsrc, sh, qidxs, grid, y, n, k, J, G, rpb, nblocks, dbg, stream);
+  QUIP_CASE(32, 8, 3) QUIP_CASE(32, 4, 3) QUIP_CASE(32, 2, 3) QUIP_CASE(32, 1, 3)
+  QUIP_CASE(1, 8, 3) QUIP_CASE(1, 4, 3) QUIP_CASE(1, 2, 3) QUIP_CASE(1, 1, 3)
+  QUIP_CASE(32, 8, 2) QUIP_CASE(32, 4, 2) QUIP_CASE(32, 2, 2) QUIP_CASE(1, 2, 2)
+#undef QUIP_CASE
+  return QUIP_ERR_UNSUPPORTED;
+}
+
+}  // namespace quip

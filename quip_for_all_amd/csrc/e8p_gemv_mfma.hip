@@ -1,0 +1,526 @@
+// E8P12 decode GEMV for gfx950, matrix-core variant (default bs=1 path).
+//
+//   y[n] = sum_k W[n,k] x[k],  W = decode(Qidxs (n, k/8) int16)
+//
+// Replaces the M=1 use of tinygemm_m16n8k16_chunk_kernel<.., BLayout_E8, ..>
+// (origin_order.cu:388-555, 604-648).
+//
+// Why matrix cores for a GEMV: measured on MI355X (tools/ubench/valu_rate.hip),
+// v_dot4c_i32_i8 / v_dot2c_f32_f16 / v_perm_b32 issue at ~4 cycles per wave64
+// instruction, so a VALU dot-product kernel needs >= 36 issue cycles per 64 codes
+// and saturates the VALU at roughly half of the HBM rate (profiles/r01_*).  One
+// v_mfma_i32_16x16x64_i8 (~18 cycles) multiplies 128 decoded codes (16 weight rows
+// x 64 k) with up to 16 rows of A at once; here the rows of A are the int8 digit
+// planes of x, so ONE instruction yields the exact integer dot products of all
+// three planes and the VALU is left with the decode only (2 address ops + 2 xor
+// per code).
+//
+// Arithmetic (same integer statement as e8p_gemv_i8.hip, see there for the proof
+// that it equals the reference's decode8weights, origin_order.cu:211-253):
+//     4*w (8 x int8) = T1[code >> 8] ^ T2[code & 255]
+//     x = (h*65536 + m*256 + l) * 2^-sh   (block fixed point, |X| < 2^22, balanced digits)
+//     y[n] = 2^(-sh-2) * (65536*S_h + 256*S_m + S_l),  S_d = sum_k 4w[n,k] * d[k]  (int32, exact)
+// Integer accumulation is exact and order independent: K-splits are combined with
+// LDS integer atomics and the result is bit-reproducible whatever the schedule.
+//
+// Mapping (wave64, lane l: n = l & 15, q = l >> 4):
+//   item   = 16 weight rows x 512 k (one 128-byte line per row): lane (n, q) loads
+//            bytes [16 q, +16) and [64 + 16 q, +16) of row n's line = 2 x 8 codes (each
+//            load instruction covers 64 contiguous bytes per row);
+//   MFMA t (t = 0..7) takes the lane's codes 2t, 2t+1 as its 16-byte B fragment
+//            (k = (t < 4 ? 0 : 256) + 64 q + 16 (t & 3) + 0..15 of the slice) and, as A fragment, the 16
+//            digit bytes of plane (l & 15) at the same k, read from LDS; rows of A
+//            beyond the three planes hold (finite) garbage whose outputs are never
+//            read.  D[m][n]: lane n (q = 0) regs 0..2 = S_h, S_m, S_l of row n.
+//   workgroup = contiguous block of rows, all of K.  x digit planes for up to
+//            8192 k live in LDS at a time; longer K is processed in phases that
+//            reuse the region.  Waves take items round-robin in (row-block, slice)
+//            order, so concurrently running waves read neighbouring lines of the
+//            same 16 rows.
+// LDS: T1/T2 with REP = 32 copies (ds_read_b64 conflict free, 128 KiB), x planes
+// (3 x 8 KiB), int32 accumulators [rows][4].
+#include "quip_device.hip.h"
+#include "quip_internal.h"
+
+namespace quip {
+
+namespace {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) u32x2* lds_u2_ptr;
+typedef const __attribute__((address_space(3))) i32x4* lds_i4_ptr;
+
+constexpr int kMaxRowsPerBlock = 256;  // int32 accumulator rows per workgroup
+
+// LDS map.  REP = 32 copies per table entry (ds_read_b64 conflict free) when the x image
+// is small enough (K <= 8192), REP = 16 (two-way conflicts on average, half the
+// footprint) for longer rows so that the digit planes of the WHOLE row stay resident.
+template <int REP>
+struct Lds {
+  static constexpr int kRow = REP * 8;               // bytes per table entry row
+  static constexpr int kT1 = 0;
+  static constexpr int kT2 = 256 * kRow;
+  static constexpr int kAcc = 2 * 256 * kRow;        // int32 [kMaxRowsPerBlock][4]
+  static constexpr int kX = kAcc + kMaxRowsPerBlock * 16;   // 3 planes x Kp bytes
+  static constexpr int kMaxKp = (160 * 1024 - kX) / 3 / 512 * 512;
+  static int bytes(int kp) { return kX + 3 * kp; }
+};
+static_assert(Lds<32>::kMaxKp >= 8192 && Lds<16>::kMaxKp >= 28672, "LDS budget");
+
+__device__ __forceinline__ uint2 lds_read8(uint32_t addr) {
+  const u32x2 v = *reinterpret_cast<lds_u2_ptr>((uintptr_t)addr);
+  return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ i32x4 lds_read16i(uint32_t addr) {
+  return *reinterpret_cast<lds_i4_ptr>((uintptr_t)addr);
+}
+
+// compile-time image of the sign table (see e8p_gemv_i8.hip)
+struct T2Image {
+  uint2 v[256];
+  constexpr T2Image() : v{} {
+    for (int s = 0; s < 256; ++s) {
+      int par = 0;
+      for (int b = 0; b < 8; ++b) par ^= (s >> b) & 1;
+      const int sv = s ^ par;
+      uint32_t lo = 0, hi = 0;
+      for (int p = 0; p < 4; ++p) {
+        lo |= (((sv >> (7 - e8p_byte_of_pos(p))) & 1) ? 0xfcu : 0u) << (8 * p);
+        hi |= (((sv >> (7 - e8p_byte_of_pos(p + 4))) & 1) ? 0xfcu : 0u) << (8 * p);
+      }
+      const uint32_t sh = par ? 0x02020202u : 0u;
+      v[s].x = lo ^ sh;
+      v[s].y = hi ^ sh;
+    }
+  }
+};
+__device__ const T2Image kT2Img{};
+
+// T1 entry from grid_packed_abs[e]: natural position order (bytes 0,2,1,3 / 4,6,5,7), OR 1
+__device__ __forceinline__ uint2 t1_entry(uint2 packed) {
+  return make_uint2(__builtin_amdgcn_perm(0u, packed.x, 0x03010200u) | 0x01010101u,
+                    __builtin_amdgcn_perm(0u, packed.y, 0x03010200u) | 0x01010101u);
+}
+
+// LDS tables, REP copies per entry.  Entry index is wave uniform, so the sources come
+// through scalar loads (8 entries = one s_load_dwordx16 per table and chunk) that do not
+// queue behind the VMEM loads already in flight; half of the wave writes T1[e], the
+// other half T2[e] (REP = 32) or T1/T2 of two consecutive entries (REP = 16): every
+// ds_write_b64 covers whole, distinct table rows -> conflict free.
+template <int REP>
+__device__ __forceinline__ void fill_tables(char* smem, const uint64_t* __restrict__ grid, int lane,
+                                            int wave, int nwaves) {
+  using L = Lds<REP>;
+  const uint2* g2 = reinterpret_cast<const uint2*>(__builtin_assume_aligned(grid, 64));
+  const bool second = (lane & 32) != 0;                    // lanes 32..63 write T2
+  const int esub = (REP == 16) ? ((lane >> 4) & 1) : 0;    // REP 16: lanes 16..31 / 48..63 take entry+1
+  char* base = smem + (second ? L::kT2 : L::kT1) + (lane & (REP - 1)) * 8;
+  for (int c = wave; c < 32; c += nwaves) {  // chunk of 8 consecutive entries
+    uint2 a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = g2[c * 8 + i]; b[i] = kT2Img.v[c * 8 + i]; }
+    if constexpr (REP == 32) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint2 t1 = t1_entry(a[i]);
+        *reinterpret_cast<uint2*>(base + (c * 8 + i) * L::kRow) = second ? b[i] : t1;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; i += 2) {
+        const uint2 t1a = t1_entry(a[i]), t1b = t1_entry(a[i + 1]);
+        const uint2 va = second ? b[i] : t1a, vb = second ? b[i + 1] : t1b;
+        *reinterpret_cast<uint2*>(base + (c * 8 + i + esub) * L::kRow) = esub ? vb : va;
+      }
+    }
+  }
+}
+
+// 16 codes of this lane -> eight MFMAs, in two steps so that the caller can reload the
+// slot registers between them: item_addresses() consumes the codes completely (32 LDS
+// addresses), item_mfma() runs the table / x reads PIPE steps ahead of their MFMA.
+struct ItemAddr { uint32_t a1l[8], a2l[8], a1h[8], a2h[8]; };
+struct StepOperands { uint2 t1l, t2l, t1h, t2h; i32x4 A; };
+
+template <int REP>
+__device__ __forceinline__ void item_addresses(const u32x4& q0, const u32x4& q1, uint32_t lane_c,
+                                               uint32_t lane_c2, ItemAddr& ad) {
+  const uint32_t d[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if constexpr (REP == 32) {
+      // table_base | idx << 8 | (lane & 31) << 3: byte aligned, one v_perm_b32 each
+      // (T2 base 0x10000 comes from byte 2 of lane_c)
+      ad.a1l[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c0c0500u);
+      ad.a2l[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c020400u);
+      ad.a1h[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c0c0700u);
+      ad.a2h[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c020600u);
+    } else {
+      // table_base | idx << 7 | (lane & 15) << 3: shift + v_and_or_b32
+      ad.a1l[t] = ((d[t] >> 1) & 0x7f80u) | lane_c;
+      ad.a2l[t] = ((d[t] << 7) & 0x7f80u) | lane_c2;
+      ad.a1h[t] = ((d[t] >> 17) & 0x7f80u) | lane_c;
+      ad.a2h[t] = ((d[t] >> 9) & 0x7f80u) | lane_c2;
+    }
+  }
+}
+
+__device__ __forceinline__ i32x4 item_mfma(const ItemAddr& ad, uint32_t xaddr) {
+  constexpr int PIPE = 4;
+  StepOperands op[8];
+  auto issue = [&](int t) {
+    op[t].t1l = lds_read8(ad.a1l[t]); op[t].t2l = lds_read8(ad.a2l[t]);
+    op[t].t1h = lds_read8(ad.a1h[t]); op[t].t2h = lds_read8(ad.a2h[t]);
+    op[t].A = lds_read16i(xaddr + (t < 4 ? 16 * t : 256 + 16 * (t - 4)));
+  };
+#pragma unroll
+  for (int t = 0; t < PIPE; ++t) issue(t);
+  i32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (t + PIPE < 8) issue(t + PIPE);
+    const i32x4 B = {(int)(op[t].t1l.x ^ op[t].t2l.x), (int)(op[t].t1l.y ^ op[t].t2l.y),
+                     (int)(op[t].t1h.x ^ op[t].t2h.x), (int)(op[t].t1h.y ^ op[t].t2h.y)};
+    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(op[t].A, B, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+template <int REP, int SLOTS, int MAXT>
+__global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
+    const uint4* __restrict__ W, const uint8_t* __restrict__ planes, const int* __restrict__ sh_ptr,
+    f16* __restrict__ y, const uint64_t* __restrict__ grid, int N, int K, int Kp,
+    int rows_per_block, uint64_t* __restrict__ dbg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using L = Lds<REP>;
+#define QUIP_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+  QUIP_STAMP(0);
+  const int tid = threadIdx.x;
+  const int nthreads = blockDim.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = __builtin_amdgcn_readfirstlane(nthreads >> 6);
+  const int n = lane & 15, q = lane >> 4;
+  const int row0 = blockIdx.x * rows_per_block;
+  const int rows_here = min(N, row0 + rows_per_block) - row0;
+  const int nrb = (rows_here + 15) >> 4;   // row blocks of this workgroup
+  const int row_u4 = K >> 6;               // uint4 per packed row (K/4 bytes)
+  const int J = Kp >> 9;                   // slices of 512 k
+  const int cnt = nrb * J;                 // items of this workgroup
+
+  // item -> (row block, slice); lanes outside the matrix read a valid (clamped) address
+  // and are neutralised by zero x digits (k padding) / never-read rows
+  // Load j (0, 1) of lane (n, q) reads bytes [64 j + 16 q, +16) of row n's 128-byte slice line, so
+  // each load instruction covers 64 contiguous bytes per row (measured: the 16-byte-at-32-byte-
+  // stride alternative costs ~25 % of the streaming rate).  A slice that sticks out of the row
+  // (K % 512 != 0) re-reads a valid piece; its x digits are zero (k padding).
+  auto item_ptr = [&](int it, int j) -> const uint4* {
+    const int rb = it / J, s = it - rb * J;
+    int row = row0 + rb * 16 + n;
+    row = row < N ? row : N - 1;
+    int off = s * 8 + q + 4 * j;  // uint4 units inside the row
+    off = off < row_u4 ? off : s * 8 + q;
+    return W + (size_t)row * row_u4 + off;
+  };
+
+  // (0) VMEM loads return in issue order: the x digit planes (L2 hits) are requested
+  //     before the (TLB-cold, HBM) weight loads, all through hand-counted asm loads.
+  constexpr int XR = 6;  // 16-byte x pieces per thread: needs nthreads >= 3 * Kp / 96
+  const int xpieces = 3 * (Kp >> 4);
+  u32x4 xr[XR];
+#pragma unroll
+  for (int j = 0; j < XR; ++j) {
+    const int i = tid + j * nthreads;
+    asm_load16(xr[j], reinterpret_cast<const uint4*>(planes) + (i < xpieces ? i : 0));
+  }
+  // past-the-end reloads read the L2-resident x planes (each lane its own 32 bytes)
+  const uint4* hot = reinterpret_cast<const uint4*>(planes) + (size_t)((tid * 2) % (xpieces - 1));
+  u32x4 qa[SLOTS], qb[SLOTS];
+#pragma unroll
+  for (int i = 0; i < SLOTS; ++i) {
+    const int it0 = wave + i * nwaves;
+    const bool real = it0 < cnt;
+    asm_load16_nt(qa[i], real ? item_ptr(it0, 0) : hot);
+    asm_load16_nt(qb[i], real ? item_ptr(it0, 1) : hot + 1);
+  }
+  QUIP_STAMP(1);
+
+  // (1) tables + zeroed accumulators: scalar loads and LDS writes only
+  fill_tables<REP>(smem, grid, lane, wave, nwaves);
+  for (int i = tid; i < kMaxRowsPerBlock * 4; i += nthreads) reinterpret_cast<int*>(smem + L::kAcc)[i] = 0;
+  const int sh = *sh_ptr;
+  QUIP_STAMP(2);
+
+  // (2) x digit planes into LDS once the 6 plane loads have landed (the 2 * SLOTS weight
+  //     loads behind them may still be in flight)
+  asm_wait_vmcnt_x<2 * SLOTS>(xr[0], xr[1], xr[2], xr[3], xr[4], xr[5]);
+#pragma unroll
+  for (int j = 0; j < XR; ++j) {
+    const int i = tid + j * nthreads;
+    if (i < xpieces) *reinterpret_cast<u32x4*>(smem + L::kX + i * 16) = xr[j];
+  }
+  __syncthreads();
+  QUIP_STAMP(3);
+
+  const uint32_t lane_c = (REP == 32) ? (((uint32_t)(lane & 31) << 3) | 0x00010000u)
+                                      : (((uint32_t)(lane & 15) << 3) | (uint32_t)L::kT1);
+  const uint32_t lane_c2 = ((uint32_t)(lane & 15) << 3) | (uint32_t)L::kT2;
+  int* accs = reinterpret_cast<int*>(smem + L::kAcc);
+  // A fragment address of this lane: plane (lane & 15) clamped to a valid plane (rows >= 3
+  // of A are don't-care), k = slice*512 + (t < 4 ? 0 : 256) + q*64 + (t & 3)*16
+  const uint32_t xlane = L::kX + (uint32_t)min(n, 2) * Kp + (uint32_t)q * 64;
+  QUIP_STAMP(4);
+
+  auto run_item = [&](int cur, const ItemAddr& ad) {
+    const int rb = cur / J, sl = cur - rb * J;
+    const i32x4 acc = item_mfma(ad, xlane + (uint32_t)sl * 512);
+    // lanes 0..15 (q == 0) hold S_h, S_m, S_l of row rb*16 + n in acc[0..2]
+    if (q == 0) {
+      int* dst = accs + (rb * 16 + n) * 4;
+      __hip_atomic_fetch_add(dst + 0, acc.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(dst + 1, acc.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(dst + 2, acc.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  };
+
+  // (3) the weight stream.  Every slot is reloaded right after its codes have been turned into
+  //     LDS addresses; once a wave has no further item the reload reads a hot L2 line (the
+  //     x planes) instead, so the VMEM queue always holds exactly 2 * SLOTS loads in
+  //     slot order and "slot i has landed" == vmcnt(2 * (SLOTS - 1)) throughout.
+  for (int it = wave; it < cnt; it += SLOTS * nwaves) {
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      const int cur = it + i * nwaves;
+      asm_wait_vmcnt<2 * (SLOTS - 1)>(qa[i], qb[i]);
+      ItemAddr ad;
+      item_addresses<REP>(qa[i], qb[i], lane_c, lane_c2, ad);
+      // the slot's codes are consumed: pin the addresses, then reload the slot in place
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        asm volatile("" : "+v"(ad.a1l[t]), "+v"(ad.a2l[t]), "+v"(ad.a1h[t]), "+v"(ad.a2h[t]));
+      const int nxt = cur + SLOTS * nwaves;
+      const bool real = nxt < cnt;
+      asm_load16_nt(qa[i], real ? item_ptr(nxt, 0) : hot);
+      asm_load16_nt(qb[i], real ? item_ptr(nxt, 1) : hot + 1);
+      if (cur < cnt) run_item(cur, ad);   // wave-uniform
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the trailing hot-line reloads
+  QUIP_STAMP(5);
+  __syncthreads();
+  QUIP_STAMP(6);
+
+  // (5) y = 2^(-sh-2) * (65536 S_h + 256 S_m + S_l), fp16 RN, coalesced
+  const float unscale = as_f32((uint32_t)(127 - sh - 2) << 23);
+  for (int t = tid; t < rows_here; t += nthreads) {
+    const int* a = accs + t * 4;
+    const float f = __builtin_fmaf((float)a[0], 65536.f, __builtin_fmaf((float)a[1], 256.f, (float)a[2]));
+    y[row0 + t] = (f16)(f * unscale);
+  }
+  QUIP_STAMP(7);
+#undef QUIP_STAMP
+}
+
+template <int REP, int SLOTS, int MAXT>
+int launch(const void* planes, const int* sh, const void* qidxs, const void* grid, void* y, int n, int k,
+           int kp, int rpb, int nblocks, int threads, uint64_t* dbg, hipStream_t stream) {
+  auto kern = e8p_gemv_mfma_kernel<REP, SLOTS, MAXT>;
+  const int lds = Lds<REP>::bytes(kp);
+  static int configured = 0;  // benign race: idempotent attribute
+  if (lds > configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return QUIP_ERR_LAUNCH;
+    configured = lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(threads), lds, stream,
+                     reinterpret_cast<const uint4*>(qidxs), reinterpret_cast<const uint8_t*>(planes), sh,
+                     reinterpret_cast<f16*>(y), reinterpret_cast<const uint64_t*>(grid), n, k, kp, rpb, dbg);
+  return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+}
+
+// Streaming probe with the matrix-core kernel's access pattern (item = 16 rows x LINES x 128 B,
+// waves <-> slices) and no decode: the read-bandwidth ceiling of this pattern.
+template <int LINES>
+__global__ __launch_bounds__(1024) void pattern_probe_kernel(const uint4* __restrict__ W,
+                                                            uint32_t* __restrict__ out, int N, int K,
+                                                            int rows_per_block) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = __builtin_amdgcn_readfirstlane((int)blockDim.x >> 6);
+  const int n = lane & 15, q = lane >> 4;
+  const int row0 = blockIdx.x * rows_per_block;
+  const int rows_here = min(N, row0 + rows_per_block) - row0;
+  const int nrb = (rows_here + 15) >> 4;
+  const int row_u4 = K >> 6;
+  const int J = (K >> 9) / LINES;  // slices of LINES * 512 k
+  const int cnt = nrb * J;
+  uint32_t acc = 0;
+  constexpr int NL = 2 * LINES;
+  u32x4 s0[NL], s1[NL];   // two slots, reloaded in place (never copied while in flight)
+  auto ptr = [&](int it) -> const uint4* {
+    if (it >= cnt) return W + (size_t)lane;   // past the end: a hot line
+    const int rb = it / J, s = it - rb * J;
+    int row = row0 + rb * 16 + n;
+    row = row < N ? row : N - 1;
+    // load j of a lane reads bytes [64 j + 16 q, +16) of the row's slice: every instruction
+    // covers 64 contiguous bytes per row
+    return W + (size_t)row * row_u4 + s * 8 * LINES + q;
+  };
+  {
+    const uint4* p0 = ptr(wave);
+    const uint4* p1 = ptr(wave + nwaves);
+#pragma unroll
+    for (int j = 0; j < NL; ++j) asm_load16_nt(s0[j], p0 + 4 * j);
+#pragma unroll
+    for (int j = 0; j < NL; ++j) asm_load16_nt(s1[j], p1 + 4 * j);
+  }
+  for (int it = wave; it < cnt; it += 2 * nwaves) {
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NL) : "memory");
+#pragma unroll
+    for (int j = 0; j < NL; ++j) { asm volatile("" : "+v"(s0[j])); acc ^= s0[j].x ^ s0[j].y ^ s0[j].z ^ s0[j].w; }
+    asm volatile("" : "+v"(acc));
+    {
+      const uint4* p = ptr(it + 2 * nwaves);
+#pragma unroll
+      for (int j = 0; j < NL; ++j) asm_load16_nt(s0[j], p + 4 * j);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NL) : "memory");
+#pragma unroll
+    for (int j = 0; j < NL; ++j) { asm volatile("" : "+v"(s1[j])); acc ^= s1[j].x ^ s1[j].y ^ s1[j].z ^ s1[j].w; }
+    asm volatile("" : "+v"(acc));
+    {
+      const uint4* p = ptr(it + 3 * nwaves);
+#pragma unroll
+      for (int j = 0; j < NL; ++j) asm_load16_nt(s1[j], p + 4 * j);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
+// x -> plain digit planes [3][Kp] (Kp = K rounded up to 512, zero padded) + shift word.
+__global__ __launch_bounds__(1024) void x_to_planes_linear_kernel(const f16* __restrict__ x,
+                                                                  uint8_t* __restrict__ planes,
+                                                                  int* __restrict__ sh_out, int K, int Kp) {
+  __shared__ uint32_t smax[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  const uint4* xg = reinterpret_cast<const uint4*>(x);
+  const int pieces = K >> 3;
+  uint32_t mx = 0;  // fp16 magnitudes order like their bit patterns
+  for (int p = tid; p < pieces; p += nthreads) {
+    const uint4 v = xg[p];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mx = max(mx, max(w[i] & 0x7fffu, (w[i] >> 16) & 0x7fffu));
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+  if (lane == 0) smax[wave] = mx;
+  __syncthreads();
+  mx = 0;
+  for (int w = 0; w < (nthreads >> 6); ++w) mx = max(mx, smax[w]);
+  const int ebits = (int)(mx >> 10);
+  const int sh = 21 - ((ebits ? ebits : 1) - 15);   // |rint(x * 2^sh)| < 2^22
+  const float scale = as_f32((uint32_t)(sh + 127) << 23);
+  if (tid == 0) *sh_out = sh;
+  for (int p = tid; p < (Kp >> 3); p += nthreads) {
+    uint32_t dg[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    if (p < pieces) {
+      const uint4 v = xg[p];
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f16x2 h2 = as_f16x2(w[i >> 1]);
+        const int X = (int)__builtin_rintf((float)((i & 1) ? h2.y : h2.x) * scale);
+        const int l = (X << 24) >> 24;
+        const int X1 = (X - l) >> 8;
+        const int m = (X1 << 24) >> 24;
+        const int h = (X1 - m) >> 8;
+        const int sft = 8 * (i & 3);
+        dg[0][i >> 2] |= (uint32_t)(h & 0xff) << sft;
+        dg[1][i >> 2] |= (uint32_t)(m & 0xff) << sft;
+        dg[2][i >> 2] |= (uint32_t)(l & 0xff) << sft;
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+      *reinterpret_cast<uint2*>(planes + (size_t)d * Kp + p * 8) = make_uint2(dg[d][0], dg[d][1]);
+  }
+}
+
+}  // namespace
+
+static inline int kp_of(int k) { return (k + 511) & ~511; }
+
+bool e8p_gemv_mfma_supported(int n, int k) {
+  return n >= 1 && k >= 128 && k % 128 == 0 && kp_of(k) <= Lds<16>::kMaxKp;
+}
+
+size_t e8p_gemv_mfma_planes_bytes(int k) { return (size_t)3 * kp_of(k) + 16; }
+
+int x_to_planes_linear_launch(const void* x, void* planes, int k, hipStream_t stream) {
+  if (k < 8 || k % 8 != 0) return QUIP_ERR_BAD_SHAPE;
+  const int kp = kp_of(k);
+  int* sh = reinterpret_cast<int*>(reinterpret_cast<char*>(planes) + (size_t)3 * kp);
+  const int threads = k >= 8192 ? 1024 : (k >= 2048 ? 256 : 64);
+  hipLaunchKernelGGL(x_to_planes_linear_kernel, dim3(1), dim3(threads), 0, stream,
+                     reinterpret_cast<const f16*>(x), reinterpret_cast<uint8_t*>(planes), sh, k, kp);
+  return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+}
+
+int pattern_probe_launch(const void* qidxs, void* out, int n, int k, const GemvTune& tune, hipStream_t stream) {
+  const int ncu = device_cu_count();
+  int nblocks = tune.blocks > 0 ? tune.blocks : ncu;
+  int rpb = (n + nblocks - 1) / nblocks;
+  rpb = (rpb + 15) & ~15;
+  nblocks = (n + rpb - 1) / rpb;
+  int waves = tune.max_waves > 0 ? tune.max_waves : 16;
+  const int lines = tune.rows ? tune.rows : 1;
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64 * waves), 0, stream, reinterpret_cast<const uint4*>(qidxs),
+                       reinterpret_cast<uint32_t*>(out), n, k, rpb);
+    return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+  };
+  if (lines == 1) return go(pattern_probe_kernel<1>);
+  if (lines == 2) return go(pattern_probe_kernel<2>);
+  return go(pattern_probe_kernel<4>);
+}
+
+int e8p_gemv_mfma_launch(const void* planes, const void* qidxs, const void* grid, void* y, int n, int k,
+                         const GemvTune& tune, hipStream_t stream) {
+  if (!e8p_gemv_mfma_supported(n, k)) return QUIP_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(grid) & 63u) != 0) return QUIP_ERR_MISALIGNED;
+  const int kp = kp_of(k);
+  const int* sh = reinterpret_cast<const int*>(reinterpret_cast<const char*>(planes) + (size_t)3 * kp);
+  uint64_t* dbg = reinterpret_cast<uint64_t*>(tune.dbg);
+  const int ncu = device_cu_count();
+  int nblocks = tune.blocks > 0 ? tune.blocks : ncu;
+  int rpb = (n + nblocks - 1) / nblocks;
+  rpb = (rpb + 15) & ~15;
+  if (rpb > kMaxRowsPerBlock) rpb = kMaxRowsPerBlock;
+  nblocks = (n + rpb - 1) / rpb;
+  int waves = tune.max_waves > 0 ? tune.max_waves : 8;   // measured best on MI355X (tools/gemv_bench.py)
+  if (waves > 16) waves = 16;
+  const int min_waves = (3 * (kp >> 4) + 6 * 64 - 1) / (6 * 64);  // 6 x pieces per thread
+  if (waves < min_waves) waves = min_waves;
+  int rep = tune.rep ? tune.rep : (kp <= Lds<32>::kMaxKp ? 32 : 16);
+  if (kp > Lds<32>::kMaxKp) rep = 16;
+  const int items_per_wave = (((rpb + 15) >> 4) * (kp >> 9) + waves - 1) / waves;
+  int slots = tune.rows ? tune.rows : (items_per_wave >= 4 ? 2 : 1);
+  const int threads = waves * 64;
+  if (threads > 512 && slots > 4) slots = 4;  // 128-VGPR budget: deeper queues would spill
+#define QUIP_CASE(R, S)                                                                                   \
+  if (rep == R && slots == S)                                                                             \
+    return threads > 512 ? launch<R, S, 1024>(planes, sh, qidxs, grid, y, n, k, kp, rpb, nblocks, threads, dbg, stream) \
+                         : launch<R, S, 512>(planes, sh, qidxs, grid, y, n, k, kp, rpb, nblocks, threads, dbg, stream);
+  QUIP_CASE(32, 1) QUIP_CASE(32, 2) QUIP_CASE(32, 3) QUIP_CASE(32, 4) QUIP_CASE(32, 6) QUIP_CASE(32, 8)
+  QUIP_CASE(16, 1) QUIP_CASE(16, 2) QUIP_CASE(16, 3) QUIP_CASE(16, 4) QUIP_CASE(16, 6) QUIP_CASE(16, 8)
+#undef QUIP_CASE
+  return QUIP_ERR_UNSUPPORTED;
+}
+
+}  // namespace quip

@@ -22,6 +22,30 @@ __device__ __forceinline__ uint4 ld_nt_u4(const uint4* p) {
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// ---- hand-counted weight stream ------------------------------------------------------
+// hipcc's s_waitcnt insertion drains vmcnt(0) at loop headers / exec-mask joins, which
+// empties a software-pipelined load queue once per iteration.  The streaming loops
+// therefore issue their loads through inline asm (invisible to that pass) and wait
+// with explicit counts: VMEM loads return in issue order, so "the oldest slot has
+// landed" == "at most N newer loads are still outstanding".  The wait statement names
+// the destination registers as read-write so no use can be scheduled above it
+// (cdna_hip_programming.md section 5.7, form ii).
+__device__ __forceinline__ void asm_load16_nt(u32x4& dst, const uint4* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void asm_load16(u32x4& dst, const uint4* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void asm_wait_vmcnt_x(u32x4& a, u32x4& b, u32x4& c, u32x4& d, u32x4& e,
+                                                 u32x4& f) {
+  asm volatile("s_waitcnt vmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void asm_wait_vmcnt(u32x4& a, u32x4& b) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+
 __device__ __forceinline__ f16x2 as_f16x2(uint32_t u) { return __builtin_bit_cast(f16x2, u); }
 __device__ __forceinline__ uint32_t as_u32(f16x2 h) { return __builtin_bit_cast(uint32_t, h); }
 __device__ __forceinline__ float as_f32(uint32_t u) { return __builtin_bit_cast(float, u); }

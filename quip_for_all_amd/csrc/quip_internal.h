@@ -12,15 +12,30 @@ int device_cu_count();
 // Tuning knobs of the E8P decode GEMV (0 = pick automatically).  Exposed through
 // quip_e8p_gemv_tuned() for the micro-benchmark only; the ABI entry points use auto.
 struct GemvTune {
-  int rep = 0;      // LDS table replication: 1 or 16
-  int rows = 0;     // rows in flight per wave iteration: 1, 2 or 4
-  int blocks = 0;   // workgroups
-  int waves_g = 0;  // row-groups per workgroup (waves = waves_g * J)
+  int rep = 0;        // LDS table replication: 1 or 32 (i8 kernel) / 1 or 16 (f16 kernel)
+  int rows = 0;       // rows in flight per wave iteration: 1, 2 or 4
+  int blocks = 0;     // workgroups
+  int waves_g = 0;    // row-groups per workgroup (waves = waves_g * J)
+  int max_waves = 0;  // cap on waves per workgroup (default 16)
+  int digits = 0;     // i8 kernel: int8 digit planes of x, 2 or 3 (default 3)
+  void* dbg = nullptr;  // i8 kernel: device buffer of 8 x uint64 s_memtime stamps per workgroup
 };
+int stream_probe_launch(const void* qidxs, void* out, int n, int k, const GemvTune& tune,
+                        hipStream_t stream);
 
-bool e8p_gemv_m1_supported(int n, int k);
-int e8p_gemv_m1_launch(const void* x, const void* qidxs, const void* grid, void* y, int n, int k,
-                       const GemvTune& tune, hipStream_t stream);
+bool e8p_gemv_i8_supported(int n, int k);
+size_t e8p_gemv_planes_bytes(int k);
+int x_to_planes_launch(const void* x, void* planes, int k, hipStream_t stream);
+// xmode 0: xsrc = digit planes (+ shift word), xmode 1: xsrc = fp16 x (self-contained, slower)
+int e8p_gemv_i8_launch(const void* xsrc, int xmode, const void* qidxs, const void* grid, void* y,
+                       int n, int k, const GemvTune& tune, hipStream_t stream);
+// matrix-core GEMV (default bs=1 path): planes = [3][Kp] digit bytes + shift word
+bool e8p_gemv_mfma_supported(int n, int k);
+size_t e8p_gemv_mfma_planes_bytes(int k);
+int x_to_planes_linear_launch(const void* x, void* planes, int k, hipStream_t stream);
+int e8p_gemv_mfma_launch(const void* planes, const void* qidxs, const void* grid, void* y, int n, int k,
+                         const GemvTune& tune, hipStream_t stream);
+int pattern_probe_launch(const void* qidxs, void* out, int n, int k, const GemvTune& tune, hipStream_t stream);
 
 enum CodebookId { kE8P = 0, kE8PRVQ3 = 1, kE8PRVQ4 = 2, kD4 = 3, kHI = 4 };
 
@@ -34,6 +49,9 @@ int generic_mm_launch(CodebookId cb, const void* x, const void* qidxs, const Cod
                       void* y, int m, int n, int k, hipStream_t stream);
 int decompress_launch(CodebookId cb, const void* qidxs, const CodebookArgs& a, void* w,
                       int64_t rows, int k, hipStream_t stream);
+int had_transform_planes_launch(const void* x, void* planes, int in_features, int n, int K,
+                                const void* had, int transpose, const void* pre, float scale,
+                                hipStream_t stream);
 int had_transform_launch(const void* x, void* y, int64_t rows, int in_features, int out_features,
                          int n, int K, const void* had, int transpose, const void* pre,
                          const void* pre2, const void* post, const void* bias, float scale,
@@ -41,6 +59,11 @@ int had_transform_launch(const void* x, void* y, int64_t rows, int in_features, 
 
 }  // namespace quip
 
+// kernel: 4 = matrix-core GEMV (default), 0 / 3 = VALU integer GEMV (planes / fp16 x), 2 / 5 = read probes
 extern "C" int quip_e8p_gemv_tuned(const void* x, const void* qidxs, const void* grid, void* y,
-                                   int32_t n, int32_t k, int32_t rep, int32_t rows,
-                                   int32_t blocks, int32_t waves_g, quip_stream_t stream);
+                                   int32_t n, int32_t k, int32_t kernel, int32_t rep, int32_t rows,
+                                   int32_t blocks, int32_t waves_g, int32_t max_waves,
+                                   int32_t digits, void* dbg, quip_stream_t stream);
+// kernel 2 in quip_e8p_gemv_tuned = streaming-read probe (y is a 4-byte scratch)
+// lane-ordered digit planes for the VALU integer GEMV (kernel 0); planes: 3*k + 16 bytes
+extern "C" int quip_e8p_x_to_planes_laneorder(const void* x, void* planes, int32_t k, quip_stream_t stream);

@@ -1,7 +1,7 @@
 """QuantLinear with the reference's constructor, buffers, state-dict keys and
 forward contract (qlinear.py:8-159); the eval forward runs on the HIP kernels:
 
-    xh  = wscale * U_in(had_left^T)(SU (.) x)          1 launch  (quip_lib::had_transform)
+    xh  = wscale * U_in(had_left^T)(SU (.) x)          1 launch  (quip_lib::had_transform[_planes])
     z   = decode(Qidxs) @ xh                           1 launch  (codebook mm / decompress+GEMM)
     y   = SV (.) U_out(had_right)(Wscale (.) z)[:out] + bias   1 launch
 
@@ -84,10 +84,19 @@ class QuantLinear(nn.Module):
         if x_dtype != torch.float16:
             x = x.to(torch.float16)
         L_in = self.q_in_features // self.K_left
-        xh = torch.ops.quip_lib.had_transform(
-            x, self.q_in_features, self.q_in_features, self.K_left, self._had("had_left"), True,
-            self._vec(self.SU), None, None, None, self.wscale_float / math.sqrt(L_in))
-        z = self.codebook(xh, self.Qidxs)
+        cb = self.codebook
+        if x.shape[0] == 1 and hasattr(cb, "mm_planes") and cb.planes_supported(self.q_out_features,
+                                                                               self.q_in_features):
+            # bs=1 decode: transform straight into the GEMV's int8 digit planes (no fp16 xh)
+            planes = torch.ops.quip_lib.had_transform_planes(
+                x, self.q_in_features, self.K_left, self._had("had_left"), True, self._vec(self.SU),
+                self.wscale_float / math.sqrt(L_in))
+            z = cb.mm_planes(planes, self.Qidxs)
+        else:
+            xh = torch.ops.quip_lib.had_transform(
+                x, self.q_in_features, self.q_in_features, self.K_left, self._had("had_left"), True,
+                self._vec(self.SU), None, None, None, self.wscale_float / math.sqrt(L_in))
+            z = cb(xh, self.Qidxs)
         L_out = self.q_out_features // self.K_right
         y = torch.ops.quip_lib.had_transform(
             z, self.out_features, self.q_out_features, self.K_right, self._had("had_right"), False,

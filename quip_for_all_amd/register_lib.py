@@ -32,6 +32,9 @@ _SCHEMAS = {
     # replaces the x*SU / pad / hadamard / hadK@ / *SV / +bias op sequence)
     "had_transform": "(Tensor x, int out_features, int n, int K, Tensor? had, bool transpose, "
                      "Tensor? pre, Tensor? pre2, Tensor? post, Tensor? bias, float scale) -> Tensor",
+    # bs=1 decode path: input-side transform straight to int8 digit planes, and the GEMV on them
+    "had_transform_planes": "(Tensor x, int n, int K, Tensor? had, bool transpose, Tensor? pre, float scale) -> Tensor",
+    "e8p_gemv_planes": "(Tensor planes, Tensor Qidxs, Tensor grid) -> Tensor",
 }
 for _name, _schema in _SCHEMAS.items():
     try:
@@ -93,6 +96,34 @@ def _had_transform_cuda(x, out_features, n, K, had, transpose, pre, pre2, post, 
     return y
 
 
+def _had_transform_planes_cuda(x, n, K, had, transpose, pre, scale):
+    xc = _chk_x(x)
+    _need(xc.shape[0] == 1, "had_transform_planes is the bs=1 path (one row)")
+    for t in (had, pre):
+        _need(t is None or (t.dtype == torch.float16 and t.is_contiguous() and t.device == x.device),
+              "had_transform_planes: vectors must be contiguous float16 on x's device")
+    L = capi.lib()
+    planes = torch.empty(L.quip_e8p_planes_bytes(n), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        capi.check(L.quip_had_transform_planes(xc.data_ptr(), planes.data_ptr(), xc.shape[1], n, K, _ptr(had),
+                                               int(bool(transpose)), _ptr(pre), float(scale), _stream(x)),
+                   "quip_had_transform_planes")
+    return planes
+
+
+def _e8p_gemv_planes_cuda(planes, Qidxs, grid):
+    g = _grid_i64(grid, Qidxs)
+    Qc = _chk_q(Qidxs, torch.int16)
+    n, k = Qc.shape[0], Qc.shape[1] * 8
+    L = capi.lib()
+    _need(planes.dtype == torch.uint8 and planes.numel() >= L.quip_e8p_planes_bytes(k), "planes buffer too small")
+    y = torch.empty((1, n), dtype=torch.float16, device=Qidxs.device)
+    with torch.cuda.device(Qidxs.device):
+        capi.check(L.quip_e8p_gemv_planes(planes.data_ptr(), Qc.data_ptr(), g.data_ptr(), y.data_ptr(), n, k,
+                                          _stream(Qidxs)), "quip_e8p_gemv_planes")
+    return y
+
+
 # ---- mm ops -------------------------------------------------------------------------
 def _mm(fn_name, x, Q, qdtype, k_per_col_num, k_per_col_den, extra):
     xc = _chk_x(x)
@@ -102,6 +133,8 @@ def _mm(fn_name, x, Q, qdtype, k_per_col_num, k_per_col_den, extra):
           f"{fn_name}: x has {k} columns but Qidxs {tuple(Q.shape)} encodes {Qc.shape[1] * k_per_col_num // k_per_col_den}")
     _need(Qc.device == x.device, "Qidxs and x must be on the same device")
     y = torch.empty((xc.shape[0], Qc.shape[0]), dtype=x.dtype, device=x.device)
+    if y.numel() == 0:
+        return y
     with torch.cuda.device(x.device):
         fn = getattr(capi.lib(), fn_name)
         capi.check(fn(xc.data_ptr(), Qc.data_ptr(), *extra(), y.data_ptr(), xc.shape[0], Qc.shape[0],
@@ -117,7 +150,21 @@ def _grid_i64(grid: Tensor, x: Tensor):
 
 def _e8p_mm_cuda(x, Qidxs, grid):
     g = _grid_i64(grid, x)
-    return _mm("quip_e8p_mm_origorder", x, Qidxs, torch.int16, 8, 1, lambda: (g.data_ptr(),))
+    xc = _chk_x(x)
+    Qc = _chk_q(Qidxs, torch.int16)
+    m, k, n = xc.shape[0], xc.shape[1], Qc.shape[0]
+    _need(Qc.shape[1] * 8 == k, f"e8p_mm: x has {k} columns but Qidxs {tuple(Qidxs.shape)} encodes {Qc.shape[1] * 8}")
+    _need(Qc.device == x.device, "Qidxs and x must be on the same device")
+    y = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    if y.numel() == 0:
+        return y
+    L = capi.lib()
+    ws_bytes = L.quip_e8p_mm_workspace_bytes(m, n, k)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
+    with torch.cuda.device(x.device):
+        capi.check(L.quip_e8p_mm_origorder_ws(xc.data_ptr(), Qc.data_ptr(), g.data_ptr(), y.data_ptr(), m, n, k,
+                                              _ptr(ws), ws_bytes, _stream(x)), "quip_e8p_mm_origorder_ws")
+    return y
 
 
 def _e8prvq3_mm_cuda(x, Qidxs, grid, grid2, scale):
@@ -193,6 +240,8 @@ def _dec_hi_cuda(Qidxs):
 _IMPLS = {
     "hadamard": _hadamard_cuda,
     "had_transform": _had_transform_cuda,
+    "had_transform_planes": _had_transform_planes_cuda,
+    "e8p_gemv_planes": _e8p_gemv_planes_cuda,
     "e8p_mm_origorder": _e8p_mm_cuda,
     "e8prvq3_mm_origorder": _e8prvq3_mm_cuda,
     "e8prvq4_mm_origorder": _e8prvq4_mm_cuda,
@@ -220,6 +269,9 @@ def _reg_fake(name, fn):
 _reg_fake("hadamard", lambda x, scale: torch.empty_like(x, memory_format=torch.contiguous_format))
 _reg_fake("had_transform", lambda x, out_features, n, K, had, transpose, pre, pre2, post, bias, scale:
           x.new_empty((x.shape[0], out_features)))
+_reg_fake("had_transform_planes", lambda x, n, K, had, transpose, pre, scale:
+          x.new_empty((3 * ((n + 511) // 512 * 512) + 16,), dtype=torch.uint8))
+_reg_fake("e8p_gemv_planes", lambda planes, Q, g: Q.new_empty((1, Q.shape[0]), dtype=torch.float16))
 for _n in ("e8p_mm_origorder", "e8prvq3_mm_origorder", "e8prvq4_mm_origorder", "d4_mm_origorder",
            "hi_mm_origorder"):
     _reg_fake(_n, _fake_mm)

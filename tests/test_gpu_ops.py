@@ -24,11 +24,16 @@ def _cb(Q, cbid, scale=None):
     return Q.codebook.codebook_id[cbid](inference=True, **kw).to(DEV)
 
 
-def _mm_tol(x64, W64, y64):
-    """|y - y_fp64| <= 2^-10 |y| (fp16 RN of the result, 1 ulp) + 2^-21 sum|w x|
-    (fp32 accumulation in any order) -- SURVEY section 7 parity bound."""
+def _mm_tol(x64, W64, y64, xbits=22):
+    """|y - y_fp64| <= 2^-10 |y|          fp16 RN of the result (1 ulp)
+                     + 2^-21 sum|w x|     fp32 accumulation in any order (fp16-domain kernels,
+                                          the reference's tensor-core accumulation)
+                     + 2^-xbits max|x| sum|w|   block fixed-point x of the integer-domain GEMV
+                                          (|X| < 2^22: elements within 2^-11 of max|x| are exact)
+    -- SURVEY section 7 parity bound + DESIGN.md."""
     absdot = np.abs(x64) @ np.abs(W64).T
-    return 2.0 ** -10 * np.abs(y64) + 2.0 ** -21 * absdot + 1e-7
+    fx = 2.0 ** -xbits * np.abs(x64).max(axis=1, keepdims=True) * np.abs(W64).sum(axis=1)[None, :]
+    return 2.0 ** -10 * np.abs(y64) + 2.0 ** -21 * absdot + fx + 1e-7
 
 
 CODEBOOKS = [("E8P12", None), ("E8P12RVQ4B", 1 / 3.45), ("E8P12RVQ4B", -1.0), ("E8P12RVQ3B", 1 / 2.04),
@@ -79,27 +84,87 @@ def test_e8p_gemv_m1_fast_path(Q, n, k):
     assert np.all(err <= _mm_tol(x.astype(np.float64), W64, y64)), err.max()
 
 
-@pytest.mark.parametrize("rep,rows,blocks,g", [(1, 1, 0, 0), (1, 2, 0, 0), (1, 4, 0, 0), (16, 1, 0, 0),
-                                               (16, 2, 0, 0), (16, 4, 0, 0), (16, 4, 64, 2), (1, 2, 512, 1),
-                                               (16, 2, 100, 3)])
-@pytest.mark.parametrize("n,k", [(1000, 4096), (512, 11008), (96, 8192)])
-def test_e8p_gemv_variants(Q, rep, rows, blocks, g, n, k):
-    """every tuning variant of the GEMV computes the same thing"""
+@pytest.mark.parametrize("kernel,rep,rows,blocks,g,maxw,digits", [
+    (4, 0, 1, 0, 0, 16, 0), (4, 0, 2, 0, 0, 16, 0), (4, 0, 3, 0, 0, 12, 0), (4, 16, 2, 0, 0, 16, 0),
+    (4, 16, 1, 0, 0, 8, 0), (4, 16, 3, 100, 0, 16, 0), (4, 32, 2, 0, 0, 8, 0),
+    (4, 0, 2, 64, 0, 16, 0), (4, 0, 2, 1000, 0, 8, 0), (4, 0, 2, 3, 0, 16, 0),
+    (0, 1, 2, 0, 0, 16, 3), (0, 1, 8, 0, 0, 8, 3), (0, 32, 2, 0, 0, 16, 3), (0, 32, 4, 0, 0, 8, 3),
+    (0, 32, 4, 64, 2, 0, 3), (0, 32, 2, 100, 3, 0, 3), (0, 32, 2, 0, 0, 16, 2),
+    (3, 32, 2, 0, 0, 16, 3), (3, 1, 2, 0, 0, 8, 3),
+    ])
+@pytest.mark.parametrize("n,k", [(1000, 4096), (512, 11008), (96, 8192), (37, 28672)])
+def test_e8p_gemv_variants(Q, kernel, rep, rows, blocks, g, maxw, digits, n, k):
+    """every tuning variant of every GEMV kernel computes the same thing (kernel 4: matrix-core GEMV on
+    linear digit planes, 0: VALU integer GEMV on lane-ordered planes, 3: the same converting x itself)"""
     from quip_for_all_amd import capi
+    L = capi.lib()
     P = O.make_layer("E8P12", k, n, seed=5)
     rng = np.random.default_rng(1)
     x = torch.from_numpy(rng.standard_normal((1, k)).astype(np.float16)).to(DEV)
     Qd = torch.from_numpy(P.Qidxs).to(DEV)
     grid = _cb(Q, "E8P12").grid_packed_abs
     y = torch.full((1, n), float("nan"), dtype=torch.float16, device=DEV)
-    rc = capi.lib().quip_e8p_gemv_tuned(x.data_ptr(), Qd.data_ptr(), grid.data_ptr(), y.data_ptr(), n, k,
-                                        rep, rows, blocks, g, torch.cuda.current_stream().cuda_stream)
+    st = torch.cuda.current_stream().cuda_stream
+    xin = x
+    if kernel == 4:
+        xin = torch.empty(L.quip_e8p_planes_bytes(k), dtype=torch.uint8, device=DEV)
+        assert L.quip_e8p_x_to_planes(x.data_ptr(), xin.data_ptr(), k, st) == 0
+    if kernel == 0:
+        xin = torch.empty(3 * k + 16, dtype=torch.uint8, device=DEV)
+        assert L.quip_e8p_x_to_planes_laneorder(x.data_ptr(), xin.data_ptr(), k, st) == 0
+    rc = L.quip_e8p_gemv_tuned(xin.data_ptr(), Qd.data_ptr(), grid.data_ptr(), y.data_ptr(), n, k,
+                               kernel, rep, rows, blocks, g, maxw, digits, None, st)
     assert rc == 0
     W64 = O.decompress_e8p(P.Qidxs).astype(np.float64)
     x64 = x.cpu().numpy().astype(np.float64)
     y64 = x64 @ W64.T
     err = np.abs(y.cpu().numpy().astype(np.float64) - y64)
-    assert np.all(err <= _mm_tol(x64, W64, y64)), err.max()
+    assert np.all(err <= _mm_tol(x64, W64, y64, xbits=13 if digits == 2 else 22)), err.max()
+
+
+def test_e8p_mm_without_workspace_matches(Q):
+    """the workspace-free ABI entry (VALU integer GEMV converting x itself) agrees with the
+    workspace path (matrix-core GEMV) to the last fp16 bit or one ulp: the integer parts are
+    identical, only the fp32 combination of the three digit sums is ordered differently"""
+    from quip_for_all_amd import capi
+    L = capi.lib()
+    n, k = 640, 8192
+    P = O.make_layer("E8P12", k, n, seed=6)
+    x = torch.from_numpy(np.random.default_rng(2).standard_normal((1, k)).astype(np.float16)).to(DEV)
+    Qd = torch.from_numpy(P.Qidxs).to(DEV)
+    cb = _cb(Q, "E8P12")
+    y1 = cb.mm(x, Qd)
+    y2 = torch.empty_like(y1)
+    assert L.quip_e8p_mm_origorder(x.data_ptr(), Qd.data_ptr(), cb.grid_packed_abs.data_ptr(), y2.data_ptr(),
+                                   1, n, k, torch.cuda.current_stream().cuda_stream) == 0
+    d = (y1.float() - y2.float()).abs()
+    assert torch.all(d <= 2.0 ** -10 * y1.float().abs() + 1e-6)
+    assert (d > 0).float().mean() < 0.05
+
+
+def test_e8p_gemv_i8_dynamic_range(Q):
+    """block fixed point: a huge outlier in x must not destroy the small elements beyond the
+    stated bound, tiny / subnormal-only inputs must work, and scaling x by 2^s scales y exactly"""
+    n, k = 256, 4096
+    cb = _cb(Q, "E8P12")
+    P = O.make_layer("E8P12", k, n, seed=21)
+    Qd = torch.from_numpy(P.Qidxs).to(DEV)
+    W64 = O.decompress_e8p(P.Qidxs).astype(np.float64)
+    rng = np.random.default_rng(8)
+    base = rng.standard_normal((1, k)).astype(np.float16)
+    for name, x in (("outlier", np.where(np.arange(k) == 100, np.float16(3000.0), base)),
+                    ("tiny", (base.astype(np.float32) * 2.0 ** -16).astype(np.float16)),
+                    ("subnormal", np.full((1, k), 2.0 ** -24, np.float16)),
+                    ("large", (base.astype(np.float32) * 32).astype(np.float16))):
+        x = np.asarray(x, dtype=np.float16).reshape(1, k)
+        y = cb.mm(torch.from_numpy(x).to(DEV), Qd).cpu().numpy().astype(np.float64)
+        x64 = x.astype(np.float64)
+        y64 = x64 @ W64.T
+        tol = _mm_tol(x64, W64, y64) + 2.0 ** -24   # fp16 subnormal output spacing
+        assert np.all(np.abs(y - y64) <= tol), (name, np.abs(y - y64).max())
+    y1 = cb.mm(torch.from_numpy(base).to(DEV), Qd)
+    y2 = cb.mm(torch.from_numpy((base.astype(np.float32) * 4).astype(np.float16)).to(DEV), Qd)
+    assert torch.equal(y1 * 4, y2)    # power-of-two scaling only moves the block exponent
 
 
 def test_e8p_gemv_special_inputs(Q):
@@ -183,3 +248,53 @@ def test_ops_reject_bad_arguments(Q):
     y = torch.ops.quip_lib.e8p_mm_origorder(torch.zeros(0, 256, dtype=torch.float16, device=DEV), q,
                                             cb.grid_packed_abs)
     assert y.shape == (0, 8)
+
+
+def _decode_planes(planes_u8, n):
+    kp = (n + 511) // 512 * 512
+    p = planes_u8.cpu().numpy()
+    d = p[:3 * kp].reshape(3, kp).view(np.int8).astype(np.int64)
+    sh = int(p[3 * kp:3 * kp + 4].view(np.int32)[0])
+    X = d[0] * 65536 + d[1] * 256 + d[2]
+    return X, sh, kp
+
+
+@pytest.mark.parametrize("n,K", [(4096, 1), (8192, 1), (11008, 43), (28672, 7), (1024, 1), (1408, 11)])
+def test_had_transform_planes(Q, n, K):
+    """input-side transform written as int8 digit planes == oracle transform, to the fixed-point step"""
+    rng = np.random.default_rng(n + K)
+    x = rng.standard_normal((1, n)).astype(np.float16)
+    su = (rng.integers(0, 2, n) * 2 - 1).astype(np.float16)
+    had = None if K == 1 else O.random_orthogonal(K, rng).astype(np.float16)
+    L_ = n // K
+    scale = 0.37 / np.sqrt(L_)
+    planes = torch.ops.quip_lib.had_transform_planes(
+        torch.from_numpy(x).to(DEV), n, K, None if had is None else torch.from_numpy(had).to(DEV), True,
+        torch.from_numpy(su).to(DEV), float(scale))
+    X, sh, kp = _decode_planes(planes, n)
+    assert np.all(np.abs(X) < 2 ** 22)
+    assert np.all(X[n:] == 0)                                     # k padding
+    ref = O.matmul_hadU(x.astype(np.float64) * su.astype(np.float64),
+                        None if had is None else had.astype(np.float64), K, n, scale=0.37, transpose=True)[0]
+    got = X[:n].astype(np.float64) * 2.0 ** -sh
+    # half a fixed-point step + fp32 butterfly error
+    tol = 2.0 ** (-sh - 1) + 2.0 ** -20 * np.linalg.norm(ref) / np.sqrt(n) * np.log2(n) + 1e-9
+    assert np.max(np.abs(got - ref)) <= tol * 1.5, (np.max(np.abs(got - ref)), tol)
+    # the block exponent is not wasteful: the largest |X| uses >= 22 - log2(sqrt(n)) - 1 bits
+    assert np.abs(X).max() >= 2 ** (21 - np.log2(np.sqrt(n)) - 1.5)
+
+
+def test_gemv_planes_end_to_end(Q):
+    """had_transform_planes -> e8p_gemv_planes == oracle (transform then exact product)"""
+    n_out, k = 2048, 4096
+    P = O.make_layer("E8P12", k, n_out, seed=31)
+    cb = _cb(Q, "E8P12")
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((1, k)).astype(np.float16)
+    planes = torch.ops.quip_lib.had_transform_planes(torch.from_numpy(x).to(DEV), k, 1, None, True, None,
+                                                     1.0 / np.sqrt(k))
+    z = cb.mm_planes(planes, torch.from_numpy(P.Qidxs).to(DEV)).cpu().numpy().astype(np.float64)
+    xh = O.fwht(x.astype(np.float64)) / np.sqrt(k)
+    W64 = O.decompress_e8p(P.Qidxs).astype(np.float64)
+    ref = xh @ W64.T
+    assert np.all(np.abs(z - ref) <= 2.0 ** -10 * np.abs(ref) + 2.0 ** -13 * np.abs(xh).max() * np.abs(W64).sum(1)[None] / np.sqrt(k) + 1e-3)
