@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Headline benchmark: greedy bs=1 decode tokens/s of a random-init Llama-2-7B whose linear
+layers are E8P12 2-bit QuantLinear (BASELINE.json configs[1]), on N GPUs of one node.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+* a "step" is one decoded token = one pass of the hot path (224 QuantLinear forwards, plus the
+  attention / norm / lm_head glue) replayed from a captured hipGraph;
+* multi-GPU = independent replicas (the Hadamard transform precludes tensor parallelism, SURVEY
+  8e): every rank decodes its own sequence, no data-path collective; value = all ranks' tokens /
+  max-over-ranks time; scaling "weak";
+* `roofline`: the dominant kernel is the E8P12 decode GEMV.  Its launches are timed live with HIP
+  events on the launch stream (graph of the model's own per-layer weights, so every launch
+  streams different HBM bytes); achieved = algorithmic bytes (Qidxs + x + y) / mean
+  launch duration; peak = 8 TB/s.  `traffic` = measured HBM bytes per launch from the PMC pass
+  committed under profiles/ (null when that file is absent);
+* `cpu_baseline`: the CPU oracle (a port of the reference semantics: the reference has no CPU
+  inference path) timed on this host for one layer of each Llama-7B shape and extrapolated to
+  tokens/s.
+Prints ONE JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+METRIC = "decode tokens/sec bs=1 Llama-7B E8P12 2-bit, 1xMI355X; % HBM roofline"
+HBM_PEAK_GBPS = 8000.0
+
+
+def gemv_roofline(dec):
+    """live HIP-event timing of the GEMV launches of one decode step (all 224 of them, each on
+    its own layer's weights), bs=1 planes path"""
+    import quip_for_all_amd  # noqa: F401
+    from quip_for_all_amd import capi
+    L = capi.lib()
+    dev = dec.dev
+    calls = []     # (planes, Qidxs, grid, y, n, k)
+    for layer in dec.layers:
+        for name in ("q", "k", "v", "o", "gate", "up", "down"):
+            m = layer[name]
+            n, k = m.q_out_features, m.q_in_features
+            x = torch.randn(1, k, device=dev).half()
+            planes = torch.empty(L.quip_e8p_planes_bytes(k), dtype=torch.uint8, device=dev)
+            capi.check(L.quip_e8p_x_to_planes(x.data_ptr(), planes.data_ptr(), k,
+                                              torch.cuda.current_stream().cuda_stream), "x_to_planes")
+            y = torch.empty(1, n, dtype=torch.float16, device=dev)
+            calls.append((planes, m.Qidxs, m.codebook.grid_packed_abs, y, n, k))
+
+    def run():
+        st = torch.cuda.current_stream().cuda_stream
+        for (planes, Q, g, y, n, k) in calls:
+            capi.check(L.quip_e8p_gemv_planes(planes.data_ptr(), Q.data_ptr(), g.data_ptr(), y.data_ptr(), n, k, st),
+                       "gemv")
+    run()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.cuda.graph(graph, stream=side):
+        run()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(6):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        graph.replay()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e-3)
+    t = float(np.median(ts[1:]))
+    algo = sum(n * k // 4 + 2 * k + 2 * n for (_, _, _, _, n, k) in calls)
+    per_launch_bytes = algo / len(calls)
+    per_launch_s = t / len(calls)
+    achieved = per_launch_bytes / per_launch_s / 1e9
+    traffic = None
+    pf = os.path.join(REPO, "profiles", "gemv_hbm_traffic.json")
+    if os.path.exists(pf):
+        try:
+            traffic = json.load(open(pf)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    return {"bound": "hbm", "kernel": "e8p_gemv_mfma_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "launches": len(calls), "algorithmic_bytes_per_launch": round(per_launch_bytes),
+            "mean_launch_us": round(per_launch_s * 1e6, 3)}
+
+
+def cpu_baseline(budget_s=25.0):
+    """CPU oracle ("port": the reference has no CPU path) on one layer of each 7B shape; tokens/s =
+    1 / (32 * (4 t_4096x4096 + 2 t_11008x4096 + t_4096x11008) + lm_head)."""
+    from oracle import c_oracle
+    shapes = {"attn 4096->4096": (4096, 4096, 4), "gate/up 4096->11008": (4096, 11008, 2),
+              "down 11008->4096": (11008, 4096, 1)}
+    threads = c_oracle.num_threads()
+    per_layer = 0.0
+    detail = {}
+    t_start = time.time()
+    for name, (fin, fout, mult) in shapes.items():
+        t = c_oracle.time_qlinear_forward("E8P12", fin, fout, min_time=budget_s / 6.0)
+        detail[name] = round(t * 1e3, 3)
+        per_layer += mult * t
+    lm = c_oracle.time_dense_gemv(32000, 4096, min_time=budget_s / 12.0)
+    tok_s = 1.0 / (32 * per_layer + lm)
+    return {"value": round(tok_s, 4), "unit": "tokens/s", "cores": threads, "kind": "port",
+            "sample": "C oracle (decode + butterfly Hadamard + fp32 GEMV, OpenMP x%d) timed on one QuantLinear of "
+                      "each Llama-2-7B shape %s ms + fp16 lm_head %.2f ms, extrapolated to a 32-layer token; "
+                      "%.0f s of CPU work" % (threads, json.dumps(detail), lm * 1e3, time.time() - t_start)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--model", default="7b", choices=["7b", "70b", "tiny"])
+    ap.add_argument("--codebook", default="E8P12")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback of the hot path)"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    import quip_for_all_amd  # noqa: F401
+    from quip_for_all_amd import decode as D
+    shape = {"7b": D.LLAMA2_7B, "70b": D.LLAMA2_70B, "tiny": D.TINY}[a.model]
+    max_len = a.steps + a.warmup + 8
+    dec = D.LlamaDecoder(shape, a.codebook, max_len=max_len, device=f"cuda:{local_rank}", seed=rank)
+    dec.capture()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    dec.reset(first_token=1 + rank)
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            dec.graph.replay()
+    barrier()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for _ in range(a.steps):
+            dec.graph.replay()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        tok_s = world * a.steps / dt
+        algo_bytes = dec.algorithmic_bytes_per_token()
+        out = {
+            "metric": METRIC, "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "i8xi8->i32 (fp16 I/O)", "data": "synthetic",
+            "config": {"workload": "Llama-2-%s %s random-init, bs=1 greedy decode, static KV cache, 1 hipGraph replay "
+                                   "per token" % (a.model.upper(), a.codebook),
+                       "layers": shape.layers, "hidden": shape.hidden, "ffn": shape.ffn, "vocab": shape.vocab,
+                       "parallelism": "replicas x%d (no collective on the data path)" % world},
+            "token_roofline": {"algorithmic_bytes_per_token": algo_bytes,
+                               "tokens_per_s_at_8TBps": round(HBM_PEAK_GBPS * 1e9 / algo_bytes, 1),
+                               "frac": round(tok_s / world / (HBM_PEAK_GBPS * 1e9 / algo_bytes), 4)},
+        }
+        if a.codebook == "E8P12":
+            out["roofline"] = gemv_roofline(dec)
+        if not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the checker must never take the bench down
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -148,6 +148,25 @@ int quip_had_transform_planes(const void* x, void* planes, int32_t in_features, 
                               const void* had, int32_t transpose, const void* pre_scale, float scale,
                               quip_stream_t stream);
 
+/* Fused variants: the decoder-block glue around a QuantLinear folded into the same launches
+ * (no reference counterpart; they replace separate RMSNorm / SiLU*mul / residual-add kernels of
+ * the surrounding HF decoder layer).  Every pointer of quip_had_fusion may be NULL. */
+typedef struct {
+  const void* residual;   /* fp16 [rows, out_features]: added to the output (f16 variant only)   */
+  const void* rms_weight; /* fp16 [in_features]: input is RMSNorm(x) * rms_weight                 */
+  const void* gate;       /* fp16 [rows, in_features]: input is silu(gate) * x                    */
+  float rms_eps;
+} quip_had_fusion;
+int quip_had_transform_fused_f16(const void* x, void* y, int64_t rows, int32_t in_features,
+                                 int32_t out_features, int32_t n, int32_t K, const void* had,
+                                 int32_t transpose, const void* pre_scale, const void* pre_scale2,
+                                 const void* post_scale, const void* bias, float scale,
+                                 const quip_had_fusion* fusion, quip_stream_t stream);
+int quip_had_transform_planes_fused(const void* x, void* planes, int32_t in_features, int32_t n,
+                                    int32_t K, const void* had, int32_t transpose,
+                                    const void* pre_scale, float scale,
+                                    const quip_had_fusion* fusion, quip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,8 @@ SIGNATURES = {
     "quip_hadamard_f16": [_P, _P, _I64, _I32, _F, _P],
     "quip_had_transform_f16": [_P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _P, _P, _P, _F, _P],
     "quip_had_transform_planes": [_P, _P, _I32, _I32, _I32, _P, _I32, _P, _F, _P],
+    "quip_had_transform_fused_f16": [_P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _P, _P, _P, _F, _P, _P],
+    "quip_had_transform_planes_fused": [_P, _P, _I32, _I32, _I32, _P, _I32, _P, _F, _P, _P],
     "quip_e8p_mm_origorder": [_P, _P, _P, _P, _I32, _I32, _I32, _P],
     "quip_e8p_mm_workspace_bytes": [_I32, _I32, _I32],
     "quip_e8p_mm_origorder_ws": [_P, _P, _P, _P, _I32, _I32, _I32, _P, _c.c_size_t, _P],
@@ -38,6 +40,11 @@ _INTERNAL = {
     "quip_e8p_x_to_planes_laneorder": [_P, _P, _I32, _P],
     "quip_e8p_gemv_tuned": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P],
 }
+
+class HadFusion(_c.Structure):
+    """mirror of quip_had_fusion (include/quip_mi355.h)"""
+    _fields_ = [("residual", _P), ("rms_weight", _P), ("gate", _P), ("rms_eps", _F)]
+
 
 _lib = None
 

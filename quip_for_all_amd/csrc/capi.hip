@@ -77,6 +77,34 @@ int quip_had_transform_planes(const void* x, void* planes, int32_t in_features, 
                                      (hipStream_t)stream);
 }
 
+static HadFusion to_fusion(const quip_had_fusion* f) {
+  HadFusion h;
+  if (f) { h.residual = f->residual; h.rms_weight = f->rms_weight; h.gate = f->gate; h.rms_eps = f->rms_eps; }
+  return h;
+}
+
+int quip_had_transform_fused_f16(const void* x, void* y, int64_t rows, int32_t in_features,
+                                 int32_t out_features, int32_t n, int32_t K, const void* had,
+                                 int32_t transpose, const void* pre_scale, const void* pre_scale2,
+                                 const void* post_scale, const void* bias, float scale,
+                                 const quip_had_fusion* fusion, quip_stream_t stream) {
+  if (!x || !y) return QUIP_ERR_NULL_POINTER;
+  const HadFusion h = to_fusion(fusion);
+  return had_transform_launch(x, y, rows, in_features, out_features, n, K, had, transpose, pre_scale,
+                              pre_scale2, post_scale, bias, scale, (hipStream_t)stream, &h);
+}
+
+int quip_had_transform_planes_fused(const void* x, void* planes, int32_t in_features, int32_t n,
+                                    int32_t K, const void* had, int32_t transpose,
+                                    const void* pre_scale, float scale,
+                                    const quip_had_fusion* fusion, quip_stream_t stream) {
+  if (!x || !planes) return QUIP_ERR_NULL_POINTER;
+  if (!aligned16(planes)) return QUIP_ERR_MISALIGNED;
+  const HadFusion h = to_fusion(fusion);
+  return had_transform_planes_launch(x, planes, in_features, n, K, had, transpose, pre_scale, scale,
+                                     (hipStream_t)stream, &h);
+}
+
 int quip_e8p_mm_origorder(const void* x, const void* qidxs, const void* grid, void* y, int32_t m,
                           int32_t n, int32_t k, quip_stream_t stream) {
   if (!grid) return QUIP_ERR_NULL_POINTER;

@@ -1,223 +1,418 @@
 // Randomised-Hadamard side of QuantLinear.forward on gfx950.
 //
-//   y = post (.) ( scale * (H (x) H_L) (pre (.) pre2 (.) x) )[:out_features] + bias
+//   y = residual + post (.) ( scale * (H (x) H_L) v )[:out_features] + bias,
+//   v = rms(x) * rms_w (.) act(gate) (.) pre (.) pre2 (.) x      (zero padded to n = K * L)
 //
-// where the padded row (n = K * L, L a power of two) is viewed row-major as
-// (K, L), H_L is the Sylvester Walsh-Hadamard matrix applied along L and H is
-// the K x K factor `had` (or had^T) applied along K  -- quant.py:72-88
-// (matmul_hadU_cuda / matmul_hadUt_cuda) fused with the element-wise ops around
-// it in qlinear.py:90-91 (x*SU), :106-107 (per-channel Wscale), :108-114
-// (slice, *SV, +bias).  With K == 1 and no vectors this is quip_lib::hadamard
-// (register_lib.py:10-20).
+// where the padded row is viewed row-major as (K, L), L a power of two, H_L is the Sylvester
+// Walsh-Hadamard matrix applied along L and H is the K x K factor `had` (or had^T) applied
+// along K -- quant.py:72-88 (matmul_hadU_cuda / matmul_hadUt_cuda) fused with the element-wise
+// ops around it in qlinear.py:90-91 (x*SU), :106-107 (per-channel Wscale), :108-114 (slice,
+// *SV, +bias).  With K == 1 and no vectors this is quip_lib::hadamard (register_lib.py:10-20).
+// The optional rms / gate / residual hooks fuse the decoder-block glue around a QuantLinear
+// (RMSNorm before q/k/v/gate/up, SiLU(gate)*up before down, residual add after o/down).
 //
-// (H (x) H_L) = (I (x) H_L)(H (x) I): workgroup (kp, row) first forms row kp of the
-// K-mix, t[j] = sum_k H[kp,k] v[k*L + j] (independent per j), then runs the
-// length-L transform in LDS.  K workgroups per token row run in parallel, which
-// is what makes the 43x43 / 7x7 factors of 11008 / 28672 cheap.
+// (H (x) H_L) = (I (x) H_L)(H (x) I): workgroup (kp, row) first forms row kp of the K-mix,
+// t[j] = sum_k H[kp,k] v[k*L + j] (independent per j), then runs the length-L transform.
+// K workgroups per token row run in parallel: the 43x43 / 7x7 factors of 11008 / 28672 cost
+// one extra pass over the (L2 resident) input row per workgroup.
+//
+// The length-L transform is register blocked: a thread owns 16 elements, does 4 butterfly
+// stages in registers, and the workgroup re-shuffles through LDS between passes (3 passes for
+// L = 4096).  Lengths < 256 or > 16384 take the simple LDS radix-2 kernel.
+//
+// Output either fp16, or (input side of the bs=1 decode path) the block fixed point int8
+// digit planes the matrix-core GEMV consumes (e8p_gemv_mfma.hip): planes[d][Kp], d = h, m, l
+// digits of X = rint(v * 2^sh), |X| < 2^22, then the int shift word.  No fp16 rounding happens
+// between the transform and the GEMV.  The shift comes from a bound every workgroup can
+// compute alone: K == 1: the exact max |v| of the transformed row; K > 1: |v_i| <= ||v||_2 =
+// scale * sqrt(L) * ||H||_2 * ||input||_2 with H ~ orthogonal.
 #include "quip_device.hip.h"
 #include "quip_internal.h"
 
 namespace quip {
 
-__global__ __launch_bounds__(256) void had_transform_kernel(
-    const f16* __restrict__ x, f16* __restrict__ y, int in_features, int out_features, int K, int L,
-    const f16* __restrict__ had, int transpose, const f16* __restrict__ pre,
-    const f16* __restrict__ pre2, const f16* __restrict__ post, const f16* __restrict__ bias,
-    float scale) {
+namespace {
+
+struct HadArgs {
+  const f16* x;
+  const f16* had;       // (K, K) or null
+  const f16* pre;       // [in_features] or null   (SU)
+  const f16* pre2;      // [n] or null              (per-channel Wscale)
+  const f16* post;      // [out_features] or null   (SV)
+  const f16* bias;      // [out_features] or null
+  const f16* residual;  // [rows, out_features] or null, added to the output
+  const f16* rms_w;     // [in_features] or null: RMSNorm weight, v *= rsqrt(mean(x^2) + eps) * rms_w
+  const f16* gate;      // [rows, in_features] or null: v *= silu(gate)
+  f16* y;               // fp16 output [rows, out_features] (planes == null)
+  uint8_t* planes;      // digit planes output (rows == 1) or null
+  int in_features, out_features, n, Kp, K, L, logL, transpose;
+  float scale, rms_eps;
+};
+
+__device__ __forceinline__ float silu(float g) { return g / (1.f + __expf(-g)); }
+
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* red, int tid, int nt) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const float w = __shfl_xor(v, o, 64);
+    v = is_max ? fmaxf(v, w) : v + w;
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int w = 1; w < ((nt + 63) >> 6); ++w) r = is_max ? fmaxf(r, red[w]) : r + red[w];
+  return r;
+}
+
+// input element idx of the current row, all element-wise pre-ops applied (not the rms factor)
+__device__ __forceinline__ float in_val(const HadArgs& a, const f16* xr, const f16* gr, int idx) {
+  if (idx >= a.in_features) return 0.f;  // F.pad (quant.py:73-74)
+  float v = (float)xr[idx];
+  if (a.gate) v *= silu((float)gr[idx]);
+  if (a.rms_w) v *= (float)a.rms_w[idx];
+  if (a.pre) v *= (float)a.pre[idx];
+  if (a.pre2) v *= (float)a.pre2[idx];
+  return v;
+}
+
+// digit split of a block fixed point value (balanced int8 digits, see e8p_gemv_i8.hip)
+__device__ __forceinline__ void digits_of(int X, int& h, int& m, int& l) {
+  l = (X << 24) >> 24;
+  const int X1 = (X - l) >> 8;
+  m = (X1 << 24) >> 24;
+  h = (X1 - m) >> 8;
+}
+
+// shift for |v| <= bound: bound < 2^(E+1) => |rint(v * 2^sh)| < 2^22 with sh = 21 - E
+__device__ __forceinline__ int shift_for(float bound) {
+  int E = (int)((as_u32(bound) >> 23) & 0xff) - 127;
+  E = max(-60, min(60, E));
+  return 21 - E;
+}
+
+// element index held in register r of thread t during pass p (4 new index bits per pass; the
+// last pass may have nb < 4 new bits, the spare register bits then reuse index bits [0, 4 - nb))
+__device__ __forceinline__ int pass_index(int t, int r, int p, int nb) {
+  const int sh_lo = 4 - nb;                       // register high bits -> index bits [0, sh_lo)
+  const int lo_bits = 4 * p - sh_lo;              // thread low bits -> index bits [sh_lo, 4p)
+  const int t_lo = t & ((1 << lo_bits) - 1), t_hi = t >> lo_bits;
+  return (t_hi << (4 * p + nb)) | ((r & ((1 << nb) - 1)) << (4 * p)) | (t_lo << sh_lo) | (r >> nb);
+}
+
+// LDS index with one pad word per 32 (keeps the strided pass reads off a single bank)
+__device__ __forceinline__ int pad(int i) { return i + (i >> 5); }
+
+template <bool PLANES>
+__global__ __launch_bounds__(1024) void had_fast_kernel(HadArgs a) {
   extern __shared__ __attribute__((aligned(16))) float buf[];
+  __shared__ float red[16];
+  const int tid = threadIdx.x, nt = blockDim.x;   // nt == L / 16
+  const int kp = blockIdx.x;
+  const int64_t row = blockIdx.y;
+  const f16* xr = a.x + row * a.in_features;
+  const f16* gr = a.gate ? a.gate + row * a.in_features : nullptr;
+  const int L = a.L, K = a.K;
+
+  // (1) load (and K-mix) this thread's 16 consecutive elements; sums for rms / the planes bound
+  float v[16];
+  float ss_x = 0.f, ss_in = 0.f;
+  const int j0 = tid * 16;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const float h = (K == 1) ? 1.f : (float)(a.transpose ? a.had[k * K + kp] : a.had[kp * K + k]);
+    const int base = (K == 1 ? kp : k) * L + j0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int idx = base + r;
+      const float e = in_val(a, xr, gr, idx);
+      if (a.rms_w && idx < a.in_features) { const float xv = (float)xr[idx]; ss_x += xv * xv; }
+      ss_in += e * e;
+      v[r] = __builtin_fmaf(h, e, v[r]);
+    }
+  }
+  float scale = a.scale;
+  if (a.rms_w) {
+    // K == 1: the workgroup holds the whole row; K > 1: every workgroup reads the whole row
+    const float tot = block_reduce(ss_x, false, red, tid, nt);
+    scale *= rsqrtf(tot / (float)a.in_features + a.rms_eps);
+  }
+
+  // (2) length-L transform: 4 index bits per pass in registers, LDS re-shuffle in between
+  const int npass = (a.logL + 3) >> 2;
+  for (int p = 0; p < npass; ++p) {
+    const int nb = min(4, a.logL - 4 * p);
+    if (p > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = buf[pad(pass_index(tid, r, p, nb))];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s < nb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (!(r & (1 << s))) {
+            const float x0 = v[r], x1 = v[r | (1 << s)];
+            v[r] = x0 + x1;
+            v[r | (1 << s)] = x0 - x1;
+          }
+        }
+      }
+    }
+    if (npass > 1) {
+      __syncthreads();  // everyone has read its pass-p inputs
+#pragma unroll
+      for (int r = 0; r < 16; ++r) buf[pad(pass_index(tid, r, p, nb))] = v[r];
+      __syncthreads();
+    }
+  }
+  if (npass > 1) {  // back to 16 consecutive elements per thread for vector stores
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = buf[pad(j0 + r)];
+  }
+
+  // (3) epilogue
+  if constexpr (PLANES) {
+    float bound;
+    if (K == 1) {
+      float mx = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(v[r] * scale));
+      bound = block_reduce(mx, true, red, tid, nt);
+    } else {
+      bound = sqrtf(block_reduce(ss_in, false, red, tid, nt)) * sqrtf((float)L) * fabsf(scale) * 1.0625f;
+    }
+    const int sh = shift_for(bound);
+    const float s2 = scale * as_f32((uint32_t)(sh + 127) << 23);
+    if (kp == 0 && tid == 0) *reinterpret_cast<int*>(a.planes + (size_t)3 * a.Kp) = sh;
+    uint32_t dg[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int h, m, l;
+      digits_of((int)__builtin_rintf(v[r] * s2), h, m, l);
+      dg[0][r >> 2] |= (uint32_t)(h & 0xff) << (8 * (r & 3));
+      dg[1][r >> 2] |= (uint32_t)(m & 0xff) << (8 * (r & 3));
+      dg[2][r >> 2] |= (uint32_t)(l & 0xff) << (8 * (r & 3));
+    }
+    const int idx = kp * L + j0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+      *reinterpret_cast<uint4*>(a.planes + (size_t)d * a.Kp + idx) = make_uint4(dg[d][0], dg[d][1], dg[d][2], dg[d][3]);
+    if (kp == 0)  // zero the k padding [n, Kp)
+      for (int i = a.n + tid * 16; i < a.Kp; i += nt * 16)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) *reinterpret_cast<uint4*>(a.planes + (size_t)d * a.Kp + i) = make_uint4(0, 0, 0, 0);
+  } else {
+    f16* yr = a.y + row * a.out_features;
+    const f16* rr = a.residual ? a.residual + row * a.out_features : nullptr;
+    const int idx0 = kp * L + j0;
+    if (idx0 + 16 <= a.out_features && (a.out_features & 7) == 0) {
+      f16 o[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float w = v[r] * scale;
+        if (a.post) w *= (float)a.post[idx0 + r];
+        if (a.bias) w += (float)a.bias[idx0 + r];
+        if (rr) w += (float)rr[idx0 + r];
+        o[r] = (f16)w;
+      }
+      uint4* dst = reinterpret_cast<uint4*>(yr + idx0);
+      dst[0] = *reinterpret_cast<uint4*>(&o[0]);
+      dst[1] = *reinterpret_cast<uint4*>(&o[8]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int idx = idx0 + r;
+        if (idx < a.out_features) {
+          float w = v[r] * scale;
+          if (a.post) w *= (float)a.post[idx];
+          if (a.bias) w += (float)a.bias[idx];
+          if (rr) w += (float)rr[idx];
+          yr[idx] = (f16)w;
+        }
+      }
+    }
+  }
+}
+
+// simple LDS radix-2 version for lengths the blocked kernel does not take
+template <bool PLANES>
+__global__ __launch_bounds__(256) void had_small_kernel(HadArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float buf[];
+  __shared__ float red[16];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int kp = blockIdx.x;
   const int64_t row = blockIdx.y;
-  const f16* xr = x + row * in_features;
-
-  auto in_val = [&](int idx) -> float {
-    if (idx >= in_features) return 0.f;  // F.pad (quant.py:73-74)
-    float v = (float)xr[idx];
-    if (pre) v *= (float)pre[idx];
-    if (pre2) v *= (float)pre2[idx];
-    return v;
-  };
-
-  if (K == 1) {
-    for (int j = tid; j < L; j += nt) buf[j] = in_val(j);
-  } else {
-    for (int j = tid; j < L; j += nt) {
-      float acc = 0.f;
-      for (int k = 0; k < K; ++k) {
-        const float h = (float)(transpose ? had[k * K + kp] : had[kp * K + k]);
-        acc = __builtin_fmaf(h, in_val(k * L + j), acc);
-      }
-      buf[j] = acc;
-    }
-  }
-  __syncthreads();
-  for (int h = 1; h < L; h <<= 1) {
-    for (int i = tid; i < (L >> 1); i += nt) {
-      const int i0 = ((i & ~(h - 1)) << 1) | (i & (h - 1));
-      const float a = buf[i0], b = buf[i0 + h];
-      buf[i0] = a + b;
-      buf[i0 + h] = a - b;
-    }
-    __syncthreads();
-  }
-  f16* yr = y + row * out_features;
+  const f16* xr = a.x + row * a.in_features;
+  const f16* gr = a.gate ? a.gate + row * a.in_features : nullptr;
+  const int L = a.L, K = a.K;
+  float ss_x = 0.f, ss_in = 0.f;
   for (int j = tid; j < L; j += nt) {
-    const int idx = kp * L + j;
-    if (idx < out_features) {
-      float v = buf[j] * scale;
-      if (post) v *= (float)post[idx];
-      if (bias) v += (float)bias[idx];
-      yr[idx] = (f16)v;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float h = (K == 1) ? 1.f : (float)(a.transpose ? a.had[k * K + kp] : a.had[kp * K + k]);
+      const int idx = (K == 1 ? kp : k) * L + j;
+      const float e = in_val(a, xr, gr, idx);
+      if (a.rms_w && idx < a.in_features) { const float xv = (float)xr[idx]; ss_x += xv * xv; }
+      ss_in += e * e;
+      acc = __builtin_fmaf(h, e, acc);
     }
+    buf[j] = acc;
   }
-}
-
-// Input-side variant for the bs=1 decode path: same transform, but the result is written
-// as the block fixed point int8 digit planes the matrix-core GEMV consumes
-// (e8p_gemv_mfma.hip: planes[d][Kp], d = 0..2 = h, m, l digits of X = rint(v * 2^sh),
-// |X| < 2^22, followed by the int shift word at byte 3 * Kp).  No fp16 rounding happens
-// between the transform and the GEMV: typical elements keep >= 14 significant bits
-// (fp16 has 11).  The shift comes from a bound every workgroup can compute alone:
-//   K == 1: the exact max |v| of the transformed row;
-//   K  > 1: |v_i| <= ||v||_2 = scale * sqrt(L) * ||H||_2 * ||pre (.) x||_2, H ~ orthogonal
-//           (each of the K workgroups reads the whole input row anyway).
-__global__ __launch_bounds__(256) void had_transform_planes_kernel(
-    const f16* __restrict__ x, uint8_t* __restrict__ planes, int in_features, int n, int Kp, int K,
-    int L, const f16* __restrict__ had, int transpose, const f16* __restrict__ pre, float scale) {
-  extern __shared__ __attribute__((aligned(16))) float buf[];
-  __shared__ float red[8];
-  const int tid = threadIdx.x, nt = blockDim.x;
-  const int kp = blockIdx.x;
-  auto in_val = [&](int idx) -> float {
-    if (idx >= in_features) return 0.f;
-    float v = (float)x[idx];
-    if (pre) v *= (float)pre[idx];
-    return v;
-  };
-  auto block_reduce = [&](float v, bool is_max) -> float {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-      const float w = __shfl_xor(v, o, 64);
-      v = is_max ? fmaxf(v, w) : v + w;
-    }
-    __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
-    float r = red[0];
-    for (int w = 1; w < (nt >> 6); ++w) r = is_max ? fmaxf(r, red[w]) : r + red[w];
-    return r;
-  };
-  float bound;
-  if (K == 1) {
-    for (int j = tid; j < L; j += nt) buf[j] = in_val(j);
-  } else {
-    float ss = 0.f;
-    for (int idx = tid; idx < in_features; idx += nt) { const float v = in_val(idx); ss += v * v; }
-    for (int j = tid; j < L; j += nt) {
-      float acc = 0.f;
-      for (int k = 0; k < K; ++k) {
-        const float h = (float)(transpose ? had[k * K + kp] : had[kp * K + k]);
-        acc = __builtin_fmaf(h, in_val(k * L + j), acc);
-      }
-      buf[j] = acc;
-    }
-    bound = sqrtf(block_reduce(ss, false)) * sqrtf((float)L) * fabsf(scale) * 1.0625f;
-  }
+  float scale = a.scale;
+  if (a.rms_w) scale *= rsqrtf(block_reduce(ss_x, false, red, tid, nt) / (float)a.in_features + a.rms_eps);
   __syncthreads();
   for (int h = 1; h < L; h <<= 1) {
     for (int i = tid; i < (L >> 1); i += nt) {
       const int i0 = ((i & ~(h - 1)) << 1) | (i & (h - 1));
-      const float a = buf[i0], b = buf[i0 + h];
-      buf[i0] = a + b;
-      buf[i0 + h] = a - b;
+      const float x0 = buf[i0], x1 = buf[i0 + h];
+      buf[i0] = x0 + x1;
+      buf[i0 + h] = x0 - x1;
     }
     __syncthreads();
   }
-  if (K == 1) {
-    float mx = 0.f;
-    for (int j = tid; j < L; j += nt) mx = fmaxf(mx, fabsf(buf[j] * scale));
-    bound = block_reduce(mx, true);
-  }
-  // |v| <= bound < 2^(E+1)  =>  |rint(v * 2^sh)| < 2^22 with sh = 21 - E  (bound == 0: any shift)
-  int E = (int)((as_u32(bound) >> 23) & 0xff) - 127;
-  E = max(-60, min(60, E));
-  const int sh = 21 - E;
-  const float s2 = scale * as_f32((uint32_t)(sh + 127) << 23);
-  if (kp == 0 && tid == 0) *reinterpret_cast<int*>(planes + (size_t)3 * Kp) = sh;
-  for (int j4 = tid * 4; j4 < L; j4 += nt * 4) {
-    uint32_t dg[3] = {0, 0, 0};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int X = (int)__builtin_rintf(buf[j4 + e] * s2);
-      const int l = (X << 24) >> 24;
-      const int X1 = (X - l) >> 8;
-      const int m = (X1 << 24) >> 24;
-      const int hh = (X1 - m) >> 8;
-      dg[0] |= (uint32_t)(hh & 0xff) << (8 * e);
-      dg[1] |= (uint32_t)(m & 0xff) << (8 * e);
-      dg[2] |= (uint32_t)(l & 0xff) << (8 * e);
+  if constexpr (PLANES) {
+    float bound;
+    if (K == 1) {
+      float mx = 0.f;
+      for (int j = tid; j < L; j += nt) mx = fmaxf(mx, fabsf(buf[j] * scale));
+      bound = block_reduce(mx, true, red, tid, nt);
+    } else {
+      bound = sqrtf(block_reduce(ss_in, false, red, tid, nt)) * sqrtf((float)L) * fabsf(scale) * 1.0625f;
     }
-    const int idx = kp * L + j4;
+    const int sh = shift_for(bound);
+    const float s2 = scale * as_f32((uint32_t)(sh + 127) << 23);
+    if (kp == 0 && tid == 0) *reinterpret_cast<int*>(a.planes + (size_t)3 * a.Kp) = sh;
+    for (int j4 = tid * 4; j4 < L; j4 += nt * 4) {
+      uint32_t dg[3] = {0, 0, 0};
 #pragma unroll
-    for (int d = 0; d < 3; ++d) *reinterpret_cast<uint32_t*>(planes + (size_t)d * Kp + idx) = dg[d];
+      for (int e = 0; e < 4; ++e) {
+        int h, m, l;
+        digits_of((int)__builtin_rintf(buf[j4 + e] * s2), h, m, l);
+        dg[0] |= (uint32_t)(h & 0xff) << (8 * e);
+        dg[1] |= (uint32_t)(m & 0xff) << (8 * e);
+        dg[2] |= (uint32_t)(l & 0xff) << (8 * e);
+      }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) *reinterpret_cast<uint32_t*>(a.planes + (size_t)d * a.Kp + kp * L + j4) = dg[d];
+    }
+    if (kp == 0)
+      for (int i = a.n + tid * 4; i < a.Kp; i += nt * 4)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) *reinterpret_cast<uint32_t*>(a.planes + (size_t)d * a.Kp + i) = 0u;
+  } else {
+    f16* yr = a.y + row * a.out_features;
+    const f16* rr = a.residual ? a.residual + row * a.out_features : nullptr;
+    for (int j = tid; j < L; j += nt) {
+      const int idx = kp * L + j;
+      if (idx < a.out_features) {
+        float w = buf[j] * scale;
+        if (a.post) w *= (float)a.post[idx];
+        if (a.bias) w += (float)a.bias[idx];
+        if (rr) w += (float)rr[idx];
+        yr[idx] = (f16)w;
+      }
+    }
   }
-  if (kp == 0)  // zero the k padding [n, Kp)
-    for (int i = n + tid * 4; i < Kp; i += nt * 4)
-#pragma unroll
-      for (int d = 0; d < 3; ++d) *reinterpret_cast<uint32_t*>(planes + (size_t)d * Kp + i) = 0u;
 }
 
-int had_transform_planes_launch(const void* x, void* planes, int in_features, int n, int K,
-                                const void* had, int transpose, const void* pre, float scale,
-                                hipStream_t stream) {
-  if (K < 1 || n % K != 0) return QUIP_ERR_BAD_SHAPE;
-  const int L = n / K;
-  if (L < 4 || (L & (L - 1)) != 0 || L > 32768 || n % 4 != 0) return QUIP_ERR_BAD_SHAPE;
-  if (in_features > n || in_features < 1) return QUIP_ERR_BAD_SHAPE;
-  if (K > 1 && !had) return QUIP_ERR_NULL_POINTER;
-  const int kp = (n + 511) & ~511;
-  const int lds = L * 4;
-  static int configured = 0;
-  if (lds > 48 * 1024 && lds > configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(had_transform_planes_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return QUIP_ERR_LAUNCH;
-    configured = lds;
+int launch(const HadArgs& a, int64_t rows, hipStream_t stream) {
+  const int L = a.L;
+  const bool planes = a.planes != nullptr;
+  const bool fast = L >= 256 && L <= 16384;
+  const int lds = fast ? (L + (L >> 5) + 4) * 4 : L * 4;
+  auto cfg = [&](const void* fn, int& configured) {
+    if (lds > 48 * 1024 && lds > configured) {
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return false;
+      configured = lds;
+    }
+    return true;
+  };
+  static int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  const dim3 grid(a.K, (unsigned)rows);
+  if (fast) {
+    const int threads = L / 16;
+    if (planes) {
+      if (!cfg(reinterpret_cast<const void*>(had_fast_kernel<true>), c0)) return QUIP_ERR_LAUNCH;
+      hipLaunchKernelGGL(had_fast_kernel<true>, grid, dim3(threads), lds, stream, a);
+    } else {
+      if (!cfg(reinterpret_cast<const void*>(had_fast_kernel<false>), c1)) return QUIP_ERR_LAUNCH;
+      hipLaunchKernelGGL(had_fast_kernel<false>, grid, dim3(threads), lds, stream, a);
+    }
+  } else {
+    const int threads = L >= 512 ? 256 : 64;
+    if (planes) {
+      if (!cfg(reinterpret_cast<const void*>(had_small_kernel<true>), c2)) return QUIP_ERR_LAUNCH;
+      hipLaunchKernelGGL(had_small_kernel<true>, grid, dim3(threads), lds, stream, a);
+    } else {
+      if (!cfg(reinterpret_cast<const void*>(had_small_kernel<false>), c3)) return QUIP_ERR_LAUNCH;
+      hipLaunchKernelGGL(had_small_kernel<false>, grid, dim3(threads), lds, stream, a);
+    }
   }
-  const int threads = L >= 1024 ? 256 : 64;
-  hipLaunchKernelGGL(had_transform_planes_kernel, dim3(K), dim3(threads), lds, stream,
-                     reinterpret_cast<const f16*>(x), reinterpret_cast<uint8_t*>(planes), in_features, n,
-                     kp, K, L, reinterpret_cast<const f16*>(had), transpose,
-                     reinterpret_cast<const f16*>(pre), scale);
   return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
 }
+
+int check_shape(int in_features, int out_features, int n, int K, const void* had, int& L, int& logL) {
+  if (K < 1 || n % K != 0) return QUIP_ERR_BAD_SHAPE;
+  L = n / K;
+  if (L < 1 || (L & (L - 1)) != 0 || L > 32768) return QUIP_ERR_BAD_SHAPE;
+  if (in_features > n || out_features > n || in_features < 1 || out_features < 1) return QUIP_ERR_BAD_SHAPE;
+  if (K > 1 && !had) return QUIP_ERR_NULL_POINTER;
+  logL = 0;
+  while ((1 << logL) < L) ++logL;
+  return QUIP_OK;
+}
+
+}  // namespace
 
 int had_transform_launch(const void* x, void* y, int64_t rows, int in_features, int out_features,
                          int n, int K, const void* had, int transpose, const void* pre,
                          const void* pre2, const void* post, const void* bias, float scale,
-                         hipStream_t stream) {
-  if (K < 1 || n % K != 0) return QUIP_ERR_BAD_SHAPE;
-  const int L = n / K;
-  if (L < 1 || (L & (L - 1)) != 0 || L > 32768) return QUIP_ERR_BAD_SHAPE;
-  if (in_features > n || out_features > n || in_features < 1 || out_features < 1) return QUIP_ERR_BAD_SHAPE;
-  if (K > 1 && !had) return QUIP_ERR_NULL_POINTER;
+                         hipStream_t stream, const HadFusion* fuse) {
+  HadArgs a{};
+  int rc = check_shape(in_features, out_features, n, K, had, a.L, a.logL);
+  if (rc != QUIP_OK) return rc;
   if (rows <= 0) return QUIP_OK;
   if (rows > 65535) return QUIP_ERR_BAD_SHAPE;  // TODO(round 2): fold rows into grid.x for prefill
-  const int lds = L * 4;
-  static int configured = 0;
-  if (lds > 64 * 1024 && lds > configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(had_transform_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return QUIP_ERR_LAUNCH;
-    configured = lds;
+  a.x = reinterpret_cast<const f16*>(x);
+  a.y = reinterpret_cast<f16*>(y);
+  a.had = reinterpret_cast<const f16*>(had);
+  a.pre = reinterpret_cast<const f16*>(pre);
+  a.pre2 = reinterpret_cast<const f16*>(pre2);
+  a.post = reinterpret_cast<const f16*>(post);
+  a.bias = reinterpret_cast<const f16*>(bias);
+  if (fuse) {
+    a.residual = reinterpret_cast<const f16*>(fuse->residual);
+    a.rms_w = reinterpret_cast<const f16*>(fuse->rms_weight);
+    a.gate = reinterpret_cast<const f16*>(fuse->gate);
+    a.rms_eps = fuse->rms_eps;
   }
-  const int threads = L >= 512 ? 256 : (L >= 128 ? 64 : 64);
-  hipLaunchKernelGGL(had_transform_kernel, dim3(K, (unsigned)rows), dim3(threads), lds, stream,
-                     reinterpret_cast<const f16*>(x), reinterpret_cast<f16*>(y), in_features,
-                     out_features, K, L, reinterpret_cast<const f16*>(had), transpose,
-                     reinterpret_cast<const f16*>(pre), reinterpret_cast<const f16*>(pre2),
-                     reinterpret_cast<const f16*>(post), reinterpret_cast<const f16*>(bias), scale);
-  return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+  a.in_features = in_features; a.out_features = out_features; a.n = n; a.K = K;
+  a.transpose = transpose; a.scale = scale;
+  return launch(a, rows, stream);
+}
+
+int had_transform_planes_launch(const void* x, void* planes, int in_features, int n, int K,
+                                const void* had, int transpose, const void* pre, float scale,
+                                hipStream_t stream, const HadFusion* fuse) {
+  HadArgs a{};
+  int rc = check_shape(in_features, n, n, K, had, a.L, a.logL);
+  if (rc != QUIP_OK) return rc;
+  if (a.L < 4 || n % 16 != 0) return QUIP_ERR_BAD_SHAPE;
+  a.x = reinterpret_cast<const f16*>(x);
+  a.planes = reinterpret_cast<uint8_t*>(planes);
+  a.had = reinterpret_cast<const f16*>(had);
+  a.pre = reinterpret_cast<const f16*>(pre);
+  if (fuse) {
+    a.rms_w = reinterpret_cast<const f16*>(fuse->rms_weight);
+    a.gate = reinterpret_cast<const f16*>(fuse->gate);
+    a.rms_eps = fuse->rms_eps;
+  }
+  a.in_features = in_features; a.out_features = n; a.n = n; a.K = K;
+  a.Kp = (n + 511) & ~511;
+  a.transpose = transpose; a.scale = scale;
+  return launch(a, 1, stream);
 }
 
 }  // namespace quip

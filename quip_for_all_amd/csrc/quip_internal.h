@@ -49,13 +49,20 @@ int generic_mm_launch(CodebookId cb, const void* x, const void* qidxs, const Cod
                       void* y, int m, int n, int k, hipStream_t stream);
 int decompress_launch(CodebookId cb, const void* qidxs, const CodebookArgs& a, void* w,
                       int64_t rows, int k, hipStream_t stream);
-int had_transform_planes_launch(const void* x, void* planes, int in_features, int n, int K,
-                                const void* had, int transpose, const void* pre, float scale,
-                                hipStream_t stream);
+// optional decoder-block glue fused into the Hadamard kernels (all pointers may be null)
+struct HadFusion {
+  const void* residual = nullptr;    // fp16 [rows, out_features], added to the output
+  const void* rms_weight = nullptr;  // fp16 [in_features]: RMSNorm(x) * weight before everything else
+  const void* gate = nullptr;        // fp16 [rows, in_features]: input is silu(gate) * x
+  float rms_eps = 1e-5f;
+};
 int had_transform_launch(const void* x, void* y, int64_t rows, int in_features, int out_features,
                          int n, int K, const void* had, int transpose, const void* pre,
                          const void* pre2, const void* post, const void* bias, float scale,
-                         hipStream_t stream);
+                         hipStream_t stream, const HadFusion* fuse = nullptr);
+int had_transform_planes_launch(const void* x, void* planes, int in_features, int n, int K,
+                                const void* had, int transpose, const void* pre, float scale,
+                                hipStream_t stream, const HadFusion* fuse = nullptr);
 
 }  // namespace quip
 

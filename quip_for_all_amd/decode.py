@@ -1,0 +1,181 @@
+"""bs=1 greedy decode harness for Llama-architecture models whose linear layers are
+QuantLinear (the metric driver of the reference, example_generate.py:9-59,62-110:
+static KV cache + one captured single-token step, sampling on the device).
+
+The reference relies on HF `StaticCache` + `torch.compile(mode="reduce-overhead")`;
+`_setup_cache` is a transformers-4.38 API that no longer exists, and there is no tracing
+compiler in this stack by design, so the step is written once with static shapes and
+captured in a hipGraph (torch.cuda.CUDAGraph): one graph replay per token, no host sync
+inside the loop (the next token id stays on the device).
+
+Only the linear layers are the QuIP# hot path; embeddings, norms, RoPE, attention over the
+cache and the fp16 lm_head use stock torch ops (they are what remains once the GEMVs are
+fast: SURVEY.md 8f rank 1)."""
+import math
+from dataclasses import dataclass
+
+import torch
+import torch.nn.functional as F
+
+from .codebook import codebook_id
+from .qlinear import QuantLinear
+
+
+@dataclass
+class LlamaShape:
+    hidden: int = 4096
+    ffn: int = 11008
+    layers: int = 32
+    heads: int = 32
+    kv_heads: int = 32
+    vocab: int = 32000
+    rms_eps: float = 1e-5
+    rope_theta: float = 10000.0
+
+    @property
+    def head_dim(self):
+        return self.hidden // self.heads
+
+
+LLAMA2_7B = LlamaShape()
+LLAMA2_70B = LlamaShape(hidden=8192, ffn=28672, layers=80, heads=64, kv_heads=8)
+TINY = LlamaShape(hidden=256, ffn=688, layers=2, heads=4, kv_heads=2, vocab=512)
+
+
+def random_quant_linear(in_f, out_f, codebook="E8P12", generator=None, device="cuda", **cb_kwargs):
+    """QuantLinear with uniformly random codes (every code is a valid lattice point), +-1 SU/SV,
+    random orthogonal had factors and a scale that keeps |y| ~ |x| (random-init analogue of a
+    quantised checkpoint)."""
+    cb = codebook_id[codebook](inference=True, **cb_kwargs)
+    layer = QuantLinear(in_f, out_f, cb, bias=False, use_rand=True)
+    g = generator
+    with torch.no_grad():
+        q = layer.Qidxs
+        if q.dtype == torch.int16:
+            layer.Qidxs.copy_(torch.randint(-32768, 32768, q.shape, generator=g, dtype=torch.int32).to(torch.int16))
+        elif q.dtype == torch.uint8:
+            layer.Qidxs.copy_(torch.randint(0, 256, q.shape, generator=g, dtype=torch.int32).to(torch.uint8))
+        else:
+            layer.Qidxs.copy_(torch.randint(-2 ** 31, 2 ** 31 - 1, q.shape, generator=g, dtype=torch.int64).to(torch.int32))
+        layer.SU.copy_((torch.randint(0, 2, (in_f,), generator=g) * 2 - 1).to(torch.float16))
+        layer.SV.copy_((torch.randint(0, 2, (out_f,), generator=g) * 2 - 1).to(torch.float16))
+        wrms = {"E8P12": 1.03, "E8P12RVQ3B": 1.2, "E8P12RVQ4B": 1.2, "D4": 1.21, "HI": 4.6}[codebook]
+        layer.Wscale.fill_(1.0 / (wrms * math.sqrt(in_f)))
+    layer.wscale_float = float(layer.Wscale)      # quantizer.py:836-837
+    return layer.to(device).eval()
+
+
+class LlamaDecoder:
+    """Random-init Llama with QuantLinear projections, static KV cache, bs=1."""
+
+    def __init__(self, shape: LlamaShape = LLAMA2_7B, codebook="E8P12", max_len=256, device="cuda", seed=0,
+                 **cb_kwargs):
+        self.s, self.dev, self.max_len = shape, torch.device(device), max_len
+        g = torch.Generator().manual_seed(seed)
+        s = shape
+        kv = s.kv_heads * s.head_dim
+
+        def ql(i, o):
+            return random_quant_linear(i, o, codebook, g, device, **cb_kwargs)
+
+        def vec(n):
+            return (1.0 + 0.02 * torch.randn(n, generator=g)).to(torch.float16).to(self.dev)
+
+        self.embed = (0.5 * torch.randn(s.vocab, s.hidden, generator=g)).to(torch.float16).to(self.dev)
+        self.lm_head = (torch.randn(s.vocab, s.hidden, generator=g) / math.sqrt(s.hidden)).to(torch.float16).to(self.dev)
+        self.final_norm = vec(s.hidden)
+        self.layers = []
+        for _ in range(s.layers):
+            self.layers.append(dict(
+                ln1=vec(s.hidden), ln2=vec(s.hidden),
+                q=ql(s.hidden, s.hidden), k=ql(s.hidden, kv), v=ql(s.hidden, kv), o=ql(s.hidden, s.hidden),
+                gate=ql(s.hidden, s.ffn), up=ql(s.hidden, s.ffn), down=ql(s.ffn, s.hidden)))
+        self.kcache = torch.zeros(s.layers, s.kv_heads, max_len, s.head_dim, dtype=torch.float16, device=self.dev)
+        self.vcache = torch.zeros_like(self.kcache)
+        inv = 1.0 / (s.rope_theta ** (torch.arange(0, s.head_dim, 2, dtype=torch.float32) / s.head_dim))
+        ang = torch.arange(max_len, dtype=torch.float32)[:, None] * inv[None, :]
+        self.cos = torch.cat([ang.cos(), ang.cos()], -1).to(self.dev)     # (max_len, head_dim) fp32
+        self.sin = torch.cat([ang.sin(), ang.sin()], -1).to(self.dev)
+        self.arange = torch.arange(max_len, device=self.dev)
+        # static step I/O (graph capture): current token id, its position, next token id
+        self.tok = torch.zeros(1, dtype=torch.long, device=self.dev)
+        self.pos = torch.zeros(1, dtype=torch.long, device=self.dev)
+        self.graph = None
+
+    # ---- model bytes the decode step has to stream (roofline denominator) -----------
+    def algorithmic_bytes_per_token(self):
+        b = 0
+        for L in self.layers:
+            for k in ("q", "k", "v", "o", "gate", "up", "down"):
+                m = L[k]
+                b += m.Qidxs.numel() * m.Qidxs.element_size() + 2 * (m.in_features + m.out_features)
+        return b + self.lm_head.numel() * 2
+
+    def _rope(self, x, cos, sin):
+        d = x.shape[-1] // 2
+        rot = torch.cat([-x[..., d:], x[..., :d]], -1)
+        return (x.float() * cos + rot.float() * sin).to(x.dtype)
+
+    def step(self):
+        """one token: reads self.tok / self.pos, writes the greedy next token into self.tok and
+        advances self.pos (all on the device)"""
+        s = self.s
+        h = self.embed[self.tok]                                   # (1, hidden)
+        cos, sin = self.cos[self.pos], self.sin[self.pos]          # (1, head_dim)
+        mask = (self.arange[None, None, None, :] <= self.pos)      # (1,1,1,max_len) keys <= current
+        for i, L in enumerate(self.layers):
+            # RMSNorm is folded into the input-side Hadamard launch of q / k / v (and gate / up)
+            q = L["q"].forward_fused(h, rms_weight=L["ln1"], rms_eps=s.rms_eps).view(1, s.heads, 1, s.head_dim)
+            k = L["k"].forward_fused(h, rms_weight=L["ln1"], rms_eps=s.rms_eps).view(1, s.kv_heads, 1, s.head_dim)
+            v = L["v"].forward_fused(h, rms_weight=L["ln1"], rms_eps=s.rms_eps).view(1, s.kv_heads, 1, s.head_dim)
+            q, k = self._rope(q, cos, sin), self._rope(k, cos, sin)
+            self.kcache[i].index_copy_(1, self.pos, k[0])
+            self.vcache[i].index_copy_(1, self.pos, v[0])
+            a = F.scaled_dot_product_attention(q, self.kcache[i][None], self.vcache[i][None], attn_mask=mask,
+                                               enable_gqa=(s.kv_heads != s.heads))
+            # residual adds ride on the output-side Hadamard launch, SiLU(gate)*up on down's input side
+            h = L["o"].forward_fused(a.reshape(1, s.hidden), residual=h)
+            g = L["gate"].forward_fused(h, rms_weight=L["ln2"], rms_eps=s.rms_eps)
+            u = L["up"].forward_fused(h, rms_weight=L["ln2"], rms_eps=s.rms_eps)
+            h = L["down"].forward_fused(u, gate=g, residual=h)
+        logits = F.rms_norm(h, (s.hidden,), self.final_norm, s.rms_eps) @ self.lm_head.T
+        self.tok.copy_(logits.argmax(-1))
+        self.pos.add_(1)
+        return logits
+
+    def reset(self, first_token=1):
+        self.tok.fill_(first_token)
+        self.pos.zero_()
+
+    def capture(self):
+        """warm up (kernel attribute setup, allocator) and capture one step as a hipGraph"""
+        self.reset()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):
+                self.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.step()
+        torch.cuda.synchronize()
+        self.reset()
+
+    @torch.no_grad()
+    def generate(self, n_tokens, first_token=1, use_graph=True):
+        """greedy decode n_tokens (<= max_len); returns the token ids (device tensor)"""
+        assert n_tokens <= self.max_len
+        self.reset(first_token)
+        if use_graph and self.graph is None:
+            self.capture()
+            self.reset(first_token)
+        out = torch.empty(n_tokens, dtype=torch.long, device=self.dev)
+        for t in range(n_tokens):
+            if use_graph:
+                self.graph.replay()
+            else:
+                self.step()
+            out[t] = self.tok[0]
+        return out

@@ -77,7 +77,16 @@ class QuantLinear(nn.Module):
         return v if v.dtype == torch.float16 else v.to(torch.float16)
 
     def forward(self, input):
+        return self.forward_fused(input)
+
+    def forward_fused(self, input, rms_weight=None, rms_eps=1e-5, gate=None, residual=None):
+        """forward() with optional decoder-block glue folded into the two Hadamard launches:
+        input := RMSNorm(input) * rms_weight (before q/k/v/gate/up), input := silu(gate) * input
+        (before down_proj), output += residual (after o_proj / down_proj).  With all of them
+        None this is exactly QuantLinear.forward of the reference (qlinear.py:87-115)."""
+        fused = rms_weight is not None or gate is not None or residual is not None
         if self.training:
+            assert not fused
             return self._forward_dense(input)
         x = input.reshape(-1, input.shape[-1])
         x_dtype = x.dtype
@@ -88,20 +97,24 @@ class QuantLinear(nn.Module):
         if x.shape[0] == 1 and hasattr(cb, "mm_planes") and cb.planes_supported(self.q_out_features,
                                                                                self.q_in_features):
             # bs=1 decode: transform straight into the GEMV's int8 digit planes (no fp16 xh)
-            planes = torch.ops.quip_lib.had_transform_planes(
+            planes = torch.ops.quip_lib.had_transform_planes_fused(
                 x, self.q_in_features, self.K_left, self._had("had_left"), True, self._vec(self.SU),
-                self.wscale_float / math.sqrt(L_in))
+                self.wscale_float / math.sqrt(L_in), self._vec(rms_weight), rms_eps,
+                None if gate is None else gate.reshape(x.shape).to(torch.float16))
             z = cb.mm_planes(planes, self.Qidxs)
         else:
-            xh = torch.ops.quip_lib.had_transform(
+            xh = torch.ops.quip_lib.had_transform_fused(
                 x, self.q_in_features, self.q_in_features, self.K_left, self._had("had_left"), True,
-                self._vec(self.SU), None, None, None, self.wscale_float / math.sqrt(L_in))
+                self._vec(self.SU), None, None, None, self.wscale_float / math.sqrt(L_in), None,
+                self._vec(rms_weight), rms_eps, None if gate is None else gate.reshape(x.shape).to(torch.float16))
             z = cb(xh, self.Qidxs)
         L_out = self.q_out_features // self.K_right
-        y = torch.ops.quip_lib.had_transform(
+        y = torch.ops.quip_lib.had_transform_fused(
             z, self.out_features, self.q_out_features, self.K_right, self._had("had_right"), False,
             None, self._vec(self.Wscale) if self.per_channel else None, self._vec(self.SV),
-            self._vec(self.bias), 1.0 / math.sqrt(L_out))
+            self._vec(self.bias), 1.0 / math.sqrt(L_out),
+            None if residual is None else residual.reshape(-1, self.out_features).to(torch.float16), None, rms_eps,
+            None)
         if x_dtype != torch.float16:
             y = y.to(x_dtype)
         return y.view(*input.shape[:-1], self.out_features)

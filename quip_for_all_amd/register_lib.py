@@ -35,6 +35,12 @@ _SCHEMAS = {
     # bs=1 decode path: input-side transform straight to int8 digit planes, and the GEMV on them
     "had_transform_planes": "(Tensor x, int n, int K, Tensor? had, bool transpose, Tensor? pre, float scale) -> Tensor",
     "e8p_gemv_planes": "(Tensor planes, Tensor Qidxs, Tensor grid) -> Tensor",
+    # the same two transforms with decoder-block glue folded in (RMSNorm / SiLU*mul in, residual out)
+    "had_transform_fused": "(Tensor x, int out_features, int n, int K, Tensor? had, bool transpose, Tensor? pre, "
+                           "Tensor? pre2, Tensor? post, Tensor? bias, float scale, Tensor? residual, "
+                           "Tensor? rms_weight, float rms_eps, Tensor? gate) -> Tensor",
+    "had_transform_planes_fused": "(Tensor x, int n, int K, Tensor? had, bool transpose, Tensor? pre, float scale, "
+                                  "Tensor? rms_weight, float rms_eps, Tensor? gate) -> Tensor",
 }
 for _name, _schema in _SCHEMAS.items():
     try:
@@ -108,6 +114,50 @@ def _had_transform_planes_cuda(x, n, K, had, transpose, pre, scale):
         capi.check(L.quip_had_transform_planes(xc.data_ptr(), planes.data_ptr(), xc.shape[1], n, K, _ptr(had),
                                                int(bool(transpose)), _ptr(pre), float(scale), _stream(x)),
                    "quip_had_transform_planes")
+    return planes
+
+
+def _fusion(residual, rms_weight, rms_eps, gate, x):
+    for t in (residual, rms_weight, gate):
+        _need(t is None or (t.dtype == torch.float16 and t.is_contiguous() and t.device == x.device),
+              "fusion tensors must be contiguous float16 on x's device")
+    return capi.HadFusion(_ptr(residual), _ptr(rms_weight), _ptr(gate), float(rms_eps))
+
+
+def _had_transform_fused_cuda(x, out_features, n, K, had, transpose, pre, pre2, post, bias, scale, residual,
+                              rms_weight, rms_eps, gate):
+    xc = _chk_x(x)
+    for t in (had, pre, pre2, post, bias):
+        _need(t is None or (t.dtype == torch.float16 and t.is_contiguous() and t.device == x.device),
+              "had_transform: vectors must be contiguous float16 on x's device")
+    _need(gate is None or gate.shape == xc.shape, "gate must have x's shape")
+    _need(residual is None or tuple(residual.shape) == (xc.shape[0], out_features), "residual shape")
+    y = torch.empty((xc.shape[0], out_features), dtype=torch.float16, device=x.device)
+    f = _fusion(residual, rms_weight, rms_eps, gate, x)
+    import ctypes
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().quip_had_transform_fused_f16(
+            xc.data_ptr(), y.data_ptr(), xc.shape[0], xc.shape[1], out_features, n, K, _ptr(had),
+            int(bool(transpose)), _ptr(pre), _ptr(pre2), _ptr(post), _ptr(bias), float(scale), ctypes.byref(f),
+            _stream(x)), "quip_had_transform_fused_f16")
+    return y
+
+
+def _had_transform_planes_fused_cuda(x, n, K, had, transpose, pre, scale, rms_weight, rms_eps, gate):
+    xc = _chk_x(x)
+    _need(xc.shape[0] == 1, "had_transform_planes is the bs=1 path (one row)")
+    for t in (had, pre):
+        _need(t is None or (t.dtype == torch.float16 and t.is_contiguous() and t.device == x.device),
+              "had_transform_planes: vectors must be contiguous float16 on x's device")
+    _need(gate is None or gate.shape == xc.shape, "gate must have x's shape")
+    L = capi.lib()
+    planes = torch.empty(L.quip_e8p_planes_bytes(n), dtype=torch.uint8, device=x.device)
+    f = _fusion(None, rms_weight, rms_eps, gate, x)
+    import ctypes
+    with torch.cuda.device(x.device):
+        capi.check(L.quip_had_transform_planes_fused(xc.data_ptr(), planes.data_ptr(), xc.shape[1], n, K, _ptr(had),
+                                                     int(bool(transpose)), _ptr(pre), float(scale), ctypes.byref(f),
+                                                     _stream(x)), "quip_had_transform_planes_fused")
     return planes
 
 
@@ -242,6 +292,8 @@ _IMPLS = {
     "had_transform": _had_transform_cuda,
     "had_transform_planes": _had_transform_planes_cuda,
     "e8p_gemv_planes": _e8p_gemv_planes_cuda,
+    "had_transform_fused": _had_transform_fused_cuda,
+    "had_transform_planes_fused": _had_transform_planes_fused_cuda,
     "e8p_mm_origorder": _e8p_mm_cuda,
     "e8prvq3_mm_origorder": _e8prvq3_mm_cuda,
     "e8prvq4_mm_origorder": _e8prvq4_mm_cuda,
@@ -270,6 +322,10 @@ _reg_fake("hadamard", lambda x, scale: torch.empty_like(x, memory_format=torch.c
 _reg_fake("had_transform", lambda x, out_features, n, K, had, transpose, pre, pre2, post, bias, scale:
           x.new_empty((x.shape[0], out_features)))
 _reg_fake("had_transform_planes", lambda x, n, K, had, transpose, pre, scale:
+          x.new_empty((3 * ((n + 511) // 512 * 512) + 16,), dtype=torch.uint8))
+_reg_fake("had_transform_fused", lambda x, out_features, n, K, had, transpose, pre, pre2, post, bias, scale, residual,
+          rms_weight, rms_eps, gate: x.new_empty((x.shape[0], out_features)))
+_reg_fake("had_transform_planes_fused", lambda x, n, K, had, transpose, pre, scale, rms_weight, rms_eps, gate:
           x.new_empty((3 * ((n + 511) // 512 * 512) + 16,), dtype=torch.uint8))
 _reg_fake("e8p_gemv_planes", lambda planes, Q, g: Q.new_empty((1, Q.shape[0]), dtype=torch.float16))
 for _n in ("e8p_mm_origorder", "e8prvq3_mm_origorder", "e8prvq4_mm_origorder", "d4_mm_origorder",

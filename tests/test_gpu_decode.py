@@ -1,0 +1,92 @@
+"""Model-level GPU test: the captured bs=1 decode step of a tiny random-init Llama equals (a) its
+own eager step token for token and (b) a float64 numpy re-implementation whose linear layers go
+through the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import quip_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(m):
+    """oracle parameter record from a QuantLinear's buffers"""
+    g = lambda t: None if t is None else t.detach().cpu().numpy()  # noqa: E731
+    return O.QLinearParams(codebook=m.codebook.id, in_features=m.in_features, out_features=m.out_features,
+                           Qidxs=g(m.Qidxs), SU=g(m.SU), SV=g(m.SV), Wscale=g(m.Wscale),
+                           wscale_float=m.wscale_float, had_left=g(m.had_left), had_right=g(m.had_right),
+                           K_left=m.K_left, K_right=m.K_right, q_in=m.q_in_features, q_out=m.q_out_features,
+                           bias=None, per_channel=False,
+                           resid_scale=float(getattr(m.codebook, "opt_resid_scale", 0.0)))
+
+
+def _ref_logits(dec, tokens):
+    """float64 reference of the decoder for a token sequence; returns logits of the last position"""
+    s = dec.s
+    P = [{k: (_params(v) if hasattr(v, "Qidxs") else v.float().cpu().numpy().astype(np.float64))
+          for k, v in L.items()} for L in dec.layers]
+    W = [{k: O.qlinear_dense_weight(p) for k, p in L.items() if isinstance(p, O.QLinearParams)} for L in P]
+    emb = dec.embed.float().cpu().numpy().astype(np.float64)
+    cos, sin = dec.cos.cpu().numpy().astype(np.float64), dec.sin.cpu().numpy().astype(np.float64)
+
+    def rms(h, w):
+        return h / np.sqrt((h * h).mean() + s.rms_eps) * w
+
+    def rope(x, p):
+        d = x.shape[-1] // 2
+        rot = np.concatenate([-x[..., d:], x[..., :d]], -1)
+        return x * cos[p] + rot * sin[p]
+    ks = [[] for _ in P]
+    vs = [[] for _ in P]
+    for p, t in enumerate(tokens):
+        h = emb[t]
+        for i, L in enumerate(P):
+            x = rms(h, L["ln1"])
+            lin = lambda name, v: O.qlinear_forward(L[name], v[None], "exact", W[i][name])[0]  # noqa: E731
+            q = rope(lin("q", x).reshape(s.heads, s.head_dim), p)
+            k = rope(lin("k", x).reshape(s.kv_heads, s.head_dim), p)
+            v = lin("v", x).reshape(s.kv_heads, s.head_dim)
+            ks[i].append(k)
+            vs[i].append(v)
+            K, V = np.stack(ks[i], 1), np.stack(vs[i], 1)          # (kv, T, d)
+            rep = s.heads // s.kv_heads
+            out = np.empty((s.heads, s.head_dim))
+            for hh in range(s.heads):
+                sc = K[hh // rep] @ q[hh] / np.sqrt(s.head_dim)
+                w = np.exp(sc - sc.max())
+                out[hh] = (w / w.sum()) @ V[hh // rep]
+            h = h + lin("o", out.reshape(-1))
+            x = rms(h, L["ln2"])
+            gte = lin("gate", x)
+            h = h + lin("down", gte / (1 + np.exp(-gte)) * lin("up", x))
+        logits = rms(h, dec.final_norm.float().cpu().numpy().astype(np.float64)) @ \
+            dec.lm_head.float().cpu().numpy().astype(np.float64).T
+    return logits
+
+
+@pytest.mark.parametrize("codebook", ["E8P12", "E8P12RVQ4B", "D4"])
+def test_tiny_llama_decode(codebook):
+    from quip_for_all_amd import decode as D
+    dec = D.LlamaDecoder(D.TINY, codebook, max_len=32, device="cuda:0", seed=3)
+    eager = dec.generate(12, first_token=5, use_graph=False).cpu().numpy()
+    graph = dec.generate(12, first_token=5, use_graph=True).cpu().numpy()
+    np.testing.assert_array_equal(eager, graph)
+    # logits of step 3 (tokens 5, eager[0], eager[1]) against the float64 reference
+    dec.reset(5)
+    with torch.no_grad():
+        for _ in range(3):
+            logits = dec.step()
+    ref = _ref_logits(dec, [5, int(eager[0]), int(eager[1])])
+    got = logits.float().cpu().numpy()[0].astype(np.float64)
+    assert np.max(np.abs(got - ref)) <= 0.03 * (np.abs(ref).max() + 1.0), np.max(np.abs(got - ref))
+    assert int(np.argmax(ref)) == int(eager[2]) or np.sort(ref)[-1] - np.sort(ref)[-2] < 0.05
+
+
+def test_decoder_byte_count_matches_survey():
+    from quip_for_all_amd import decode as D
+    s = D.LLAMA2_7B
+    # 1.619 GB Qidxs + 5 MB SU/SV + 262 MB lm_head = 1.886 GB per token
+    q = s.layers * (4 * s.hidden * s.hidden + 3 * s.hidden * s.ffn) // 4
+    suv = s.layers * 2 * (4 * 2 * s.hidden + 2 * (s.hidden + s.ffn) + (s.ffn + s.hidden))
+    assert abs((q + suv + s.vocab * s.hidden * 2) / 1e9 - 1.886) < 0.002

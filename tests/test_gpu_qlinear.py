@@ -125,3 +125,29 @@ def test_full_size_70b_rows_via_properties():
         xs = (x1.float() + x2.float())
         ys = (xs @ Wd.T)
         assert ((y1.float() + y2.float()) - ys).abs().max() <= 2 ** -8 * ys.abs().max()
+
+
+@pytest.mark.parametrize("cbid,fin,fout", [("E8P12", 4096, 4096), ("E8P12", 1408, 512), ("D4", 1024, 1024),
+                                           ("E8P12", 4096, 11008), ("E8P12", 11008, 4096)])
+@pytest.mark.parametrize("M", [1, 3])
+def test_forward_fused_glue(cbid, fin, fout, M):
+    """RMSNorm / SiLU*mul / residual folded into the Hadamard launches == doing them separately"""
+    P = O.make_layer(cbid, fin, fout, seed=fin + fout + M)
+    layer = _layer(P)
+    rng = np.random.default_rng(M)
+    x = rng.standard_normal((M, fin)).astype(np.float16)
+    g = rng.standard_normal((M, fin)).astype(np.float16)
+    w = (1 + 0.1 * rng.standard_normal(fin)).astype(np.float16)
+    res = rng.standard_normal((M, fout)).astype(np.float16)
+    xd, gd, wd, rd = (torch.from_numpy(t).to(DEV) for t in (x, g, w, res))
+    with torch.no_grad():
+        y1 = layer.forward_fused(xd, rms_weight=wd, rms_eps=1e-5).cpu().numpy().astype(np.float64)
+        y2 = layer.forward_fused(xd, gate=gd, residual=rd).cpu().numpy().astype(np.float64)
+    x64, g64 = x.astype(np.float64), g.astype(np.float64)
+    xn = x64 / np.sqrt((x64 ** 2).mean(axis=1, keepdims=True) + 1e-5) * w.astype(np.float64)
+    What = O.qlinear_dense_weight(P)
+    r1 = O.qlinear_forward(P, xn, "exact", What)
+    xs = g64 / (1 + np.exp(-g64)) * x64
+    r2 = O.qlinear_forward(P, xs, "exact", What) + res.astype(np.float64)
+    assert np.all(np.abs(y1 - r1) <= O.parity_bound(P, xn, What)), np.abs(y1 - r1).max()
+    assert np.all(np.abs(y2 - r2) <= O.parity_bound(P, xs, What) + 2.0 ** -10 * np.abs(r2)), np.abs(y2 - r2).max()
