@@ -46,6 +46,7 @@ struct HadArgs {
   f16* y;               // fp16 output [rows, out_features] (planes == null)
   uint8_t* planes;      // digit planes output (rows == 1) or null
   int in_features, out_features, n, Kp, K, L, logL, transpose;
+  int vec, vec_out;     // 16-byte vector loads / stores allowed (alignment + multiple-of-8 sizes)
   float scale, rms_eps;
 };
 
@@ -103,46 +104,169 @@ __device__ __forceinline__ int pass_index(int t, int r, int p, int nb) {
 // LDS index with one pad word per 32 (keeps the strided pass reads off a single bank)
 __device__ __forceinline__ int pad(int i) { return i + (i >> 5); }
 
-template <bool PLANES>
+// 8 consecutive fp16 -> fp32 (16-byte load)
+__device__ __forceinline__ void ld8(const f16* p, float o[8]) {
+  const uint4 u = *reinterpret_cast<const uint4*>(p);
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f16x2 h = as_f16x2(w[i]);
+    o[2 * i] = (float)h.x;
+    o[2 * i + 1] = (float)h.y;
+  }
+}
+
+// 16 consecutive input elements [idx0, idx0 + 16) of the current row with the element-wise
+// pre-ops applied; ss_x accumulates the raw x^2 (RMSNorm statistic).  vec: in_features % 8 == 0
+// and every vector 16-byte aligned (checked on the host), so an 8-chunk is all in or all out.
+__device__ __forceinline__ void in_vals16(const HadArgs& a, const f16* xr, const f16* gr, int idx0, float e[16],
+                                          float& ss_x) {
+  if (a.vec) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = idx0 + 8 * h;
+      float* o = e + 8 * h;
+      if (c < a.in_features) {
+        float t[8];
+        ld8(xr + c, o);
+        if (a.rms_w) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) ss_x = __builtin_fmaf(o[i], o[i], ss_x);
+          ld8(a.rms_w + c, t);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] *= t[i];
+        }
+        if (a.gate) {
+          ld8(gr + c, t);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] *= silu(t[i]);
+        }
+        if (a.pre) {
+          ld8(a.pre + c, t);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] *= t[i];
+        }
+        if (a.pre2) {
+          ld8(a.pre2 + c, t);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] *= t[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = 0.f;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int idx = idx0 + r;
+      e[r] = in_val(a, xr, gr, idx);
+      if (a.rms_w && idx < a.in_features) { const float xv = (float)xr[idx]; ss_x = __builtin_fmaf(xv, xv, ss_x); }
+    }
+  }
+}
+
+// One workgroup transforms E = R * L elements (R rows kp of the (K, L) view), 16 per thread.
+//   wide (TALL == false): R = 1, thread owns 16 consecutive columns, K-mix by looping over k with
+//                         16-byte loads (K == 1, or long rows: 28672 = 7 x 4096);
+//   tall (TALL == true):  64 <= L <= 256 < n, 256 threads, R = 16 * (256 / L): thread owns one
+//                         column and 16 rows of the K-mix (11008 = 43 x 256 or 172 x 64), the H
+//                         tile sits in LDS and is read as broadcasts.
+template <bool PLANES, bool TALL>
 __global__ __launch_bounds__(1024) void had_fast_kernel(HadArgs a) {
   extern __shared__ __attribute__((aligned(16))) float buf[];
   __shared__ float red[16];
-  const int tid = threadIdx.x, nt = blockDim.x;   // nt == L / 16
-  const int kp = blockIdx.x;
+  const int tid = threadIdx.x, nt = blockDim.x;   // nt == E / 16
   const int64_t row = blockIdx.y;
   const f16* xr = a.x + row * a.in_features;
   const f16* gr = a.gate ? a.gate + row * a.in_features : nullptr;
-  const int L = a.L, K = a.K;
+  const int L = a.L, K = a.K, logL = a.logL;
+  const int R = TALL ? (16 * nt) >> logL : 1;
+  const int kp0 = blockIdx.x * R;
+  const int e0 = tid * 16;                         // first of this thread's 16 elements of [R][L]
+  const int kp = kp0 + (e0 >> logL), j0 = e0 & (L - 1);
 
-  // (1) load (and K-mix) this thread's 16 consecutive elements; sums for rms / the planes bound
+  // (1) load + K-mix; sums for rms / the planes bound
   float v[16];
   float ss_x = 0.f, ss_in = 0.f;
-  const int j0 = tid * 16;
 #pragma unroll
   for (int r = 0; r < 16; ++r) v[r] = 0.f;
-  for (int k = 0; k < K; ++k) {
-    const float h = (K == 1) ? 1.f : (float)(a.transpose ? a.had[k * K + kp] : a.had[kp * K + k]);
-    const int base = (K == 1 ? kp : k) * L + j0;
+  if constexpr (!TALL) {
+    if (K == 1) {
+      in_vals16(a, xr, gr, kp * L + j0, v, ss_x);
+    } else {
+      for (int k = 0; k < K; ++k) {
+        const float h = (float)(a.transpose ? a.had[k * K + kp] : a.had[kp * K + k]);
+        float e[16];
+        in_vals16(a, xr, gr, k * L + j0, e, ss_x);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int idx = base + r;
-      const float e = in_val(a, xr, gr, idx);
-      if (a.rms_w && idx < a.in_features) { const float xv = (float)xr[idx]; ss_x += xv * xv; }
-      ss_in += e * e;
-      v[r] = __builtin_fmaf(h, e, v[r]);
+        for (int r = 0; r < 16; ++r) {
+          ss_in = __builtin_fmaf(e[r], e[r], ss_in);
+          v[r] = __builtin_fmaf(h, e[r], v[r]);
+        }
+      }
     }
+  } else {
+    float* hs = buf + (16 * nt + ((16 * nt) >> 5) + 4);   // [K][R] tile of H (rows kp0..kp0+R)
+    for (int i = tid; i < K * R; i += nt) {
+      const int k = i / R, rr = i - k * R, kq = kp0 + rr;
+      hs[i] = kq < K ? (float)(a.transpose ? a.had[k * K + kq] : a.had[kq * K + k]) : 0.f;
+    }
+    __syncthreads();
+    const int g = tid >> logL, j = tid & (L - 1);
+    const float* hg = hs + g * 16;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+      float e[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = (k0 + u) * L + j;
+        const bool ok = (k0 + u) < K && idx < a.in_features;
+        float xv = ok ? (float)xr[idx] : 0.f;
+        if (a.rms_w) { ss_x = __builtin_fmaf(xv, xv, ss_x); xv *= ok ? (float)a.rms_w[idx] : 0.f; }
+        if (a.gate) xv *= ok ? silu((float)gr[idx]) : 0.f;
+        if (a.pre) xv *= ok ? (float)a.pre[idx] : 0.f;
+        if (a.pre2) xv *= ok ? (float)a.pre2[idx] : 0.f;
+        e[u] = xv;
+        ss_in = __builtin_fmaf(xv, xv, ss_in);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (k0 + u < K) {
+          const float4* h4 = reinterpret_cast<const float4*>(hg + (k0 + u) * R);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 h = h4[q];
+            v[4 * q + 0] = __builtin_fmaf(h.x, e[u], v[4 * q + 0]);
+            v[4 * q + 1] = __builtin_fmaf(h.y, e[u], v[4 * q + 1]);
+            v[4 * q + 2] = __builtin_fmaf(h.z, e[u], v[4 * q + 2]);
+            v[4 * q + 3] = __builtin_fmaf(h.w, e[u], v[4 * q + 3]);
+          }
+        }
+      }
+    }
+    // every one of the nt / L column groups saw the whole row
+    const float inv_groups = (float)L / (float)nt;
+    ss_x *= inv_groups;
+    ss_in *= inv_groups;
+    // (row, column) ownership -> 16 consecutive elements per thread
+#pragma unroll
+    for (int r = 0; r < 16; ++r) buf[pad(((g * 16 + r) << logL) + j)] = v[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = buf[pad(e0 + r)];
+    __syncthreads();
   }
   float scale = a.scale;
   if (a.rms_w) {
-    // K == 1: the workgroup holds the whole row; K > 1: every workgroup reads the whole row
+    // every workgroup sees the whole input row (K == 1: it is the row; K > 1: the k loop)
     const float tot = block_reduce(ss_x, false, red, tid, nt);
     scale *= rsqrtf(tot / (float)a.in_features + a.rms_eps);
   }
 
   // (2) length-L transform: 4 index bits per pass in registers, LDS re-shuffle in between
-  const int npass = (a.logL + 3) >> 2;
+  const int npass = (logL + 3) >> 2;
   for (int p = 0; p < npass; ++p) {
-    const int nb = min(4, a.logL - 4 * p);
+    const int nb = min(4, logL - 4 * p);
     if (p > 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = buf[pad(pass_index(tid, r, p, nb))];
@@ -169,8 +293,9 @@ __global__ __launch_bounds__(1024) void had_fast_kernel(HadArgs a) {
   }
   if (npass > 1) {  // back to 16 consecutive elements per thread for vector stores
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = buf[pad(j0 + r)];
+    for (int r = 0; r < 16; ++r) v[r] = buf[pad(e0 + r)];
   }
+  const bool live = kp < K;                       // rows past K in the last tall workgroup
 
   // (3) epilogue
   if constexpr (PLANES) {
@@ -185,7 +310,7 @@ __global__ __launch_bounds__(1024) void had_fast_kernel(HadArgs a) {
     }
     const int sh = shift_for(bound);
     const float s2 = scale * as_f32((uint32_t)(sh + 127) << 23);
-    if (kp == 0 && tid == 0) *reinterpret_cast<int*>(a.planes + (size_t)3 * a.Kp) = sh;
+    if (blockIdx.x == 0 && tid == 0) *reinterpret_cast<int*>(a.planes + (size_t)3 * a.Kp) = sh;
     uint32_t dg[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -196,10 +321,12 @@ __global__ __launch_bounds__(1024) void had_fast_kernel(HadArgs a) {
       dg[2][r >> 2] |= (uint32_t)(l & 0xff) << (8 * (r & 3));
     }
     const int idx = kp * L + j0;
+    if (live) {
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
-      *reinterpret_cast<uint4*>(a.planes + (size_t)d * a.Kp + idx) = make_uint4(dg[d][0], dg[d][1], dg[d][2], dg[d][3]);
-    if (kp == 0)  // zero the k padding [n, Kp)
+      for (int d = 0; d < 3; ++d)
+        *reinterpret_cast<uint4*>(a.planes + (size_t)d * a.Kp + idx) = make_uint4(dg[d][0], dg[d][1], dg[d][2], dg[d][3]);
+    }
+    if (blockIdx.x == 0)  // zero the k padding [n, Kp)
       for (int i = a.n + tid * 16; i < a.Kp; i += nt * 16)
 #pragma unroll
         for (int d = 0; d < 3; ++d) *reinterpret_cast<uint4*>(a.planes + (size_t)d * a.Kp + i) = make_uint4(0, 0, 0, 0);
@@ -207,16 +334,29 @@ __global__ __launch_bounds__(1024) void had_fast_kernel(HadArgs a) {
     f16* yr = a.y + row * a.out_features;
     const f16* rr = a.residual ? a.residual + row * a.out_features : nullptr;
     const int idx0 = kp * L + j0;
-    if (idx0 + 16 <= a.out_features && (a.out_features & 7) == 0) {
+    if (!live) {
+    } else if (idx0 + 16 <= a.out_features && a.vec_out) {
+      float t[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] *= scale;
+      if (a.post) {
+        ld8(a.post + idx0, t); ld8(a.post + idx0 + 8, t + 8);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] *= t[r];
+      }
+      if (a.bias) {
+        ld8(a.bias + idx0, t); ld8(a.bias + idx0 + 8, t + 8);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += t[r];
+      }
+      if (rr) {
+        ld8(rr + idx0, t); ld8(rr + idx0 + 8, t + 8);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += t[r];
+      }
       f16 o[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float w = v[r] * scale;
-        if (a.post) w *= (float)a.post[idx0 + r];
-        if (a.bias) w += (float)a.bias[idx0 + r];
-        if (rr) w += (float)rr[idx0 + r];
-        o[r] = (f16)w;
-      }
+      for (int r = 0; r < 16; ++r) o[r] = (f16)v[r];
       uint4* dst = reinterpret_cast<uint4*>(yr + idx0);
       dst[0] = *reinterpret_cast<uint4*>(&o[0]);
       dst[1] = *reinterpret_cast<uint4*>(&o[8]);
@@ -317,40 +457,44 @@ __global__ __launch_bounds__(256) void had_small_kernel(HadArgs a) {
   }
 }
 
-int launch(const HadArgs& a, int64_t rows, hipStream_t stream) {
-  const int L = a.L;
-  const bool planes = a.planes != nullptr;
-  const bool fast = L >= 256 && L <= 16384;
-  const int lds = fast ? (L + (L >> 5) + 4) * 4 : L * 4;
-  auto cfg = [&](const void* fn, int& configured) {
-    if (lds > 48 * 1024 && lds > configured) {
-      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return false;
-      configured = lds;
-    }
-    return true;
-  };
-  static int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-  const dim3 grid(a.K, (unsigned)rows);
-  if (fast) {
-    const int threads = L / 16;
-    if (planes) {
-      if (!cfg(reinterpret_cast<const void*>(had_fast_kernel<true>), c0)) return QUIP_ERR_LAUNCH;
-      hipLaunchKernelGGL(had_fast_kernel<true>, grid, dim3(threads), lds, stream, a);
-    } else {
-      if (!cfg(reinterpret_cast<const void*>(had_fast_kernel<false>), c1)) return QUIP_ERR_LAUNCH;
-      hipLaunchKernelGGL(had_fast_kernel<false>, grid, dim3(threads), lds, stream, a);
-    }
-  } else {
-    const int threads = L >= 512 ? 256 : 64;
-    if (planes) {
-      if (!cfg(reinterpret_cast<const void*>(had_small_kernel<true>), c2)) return QUIP_ERR_LAUNCH;
-      hipLaunchKernelGGL(had_small_kernel<true>, grid, dim3(threads), lds, stream, a);
-    } else {
-      if (!cfg(reinterpret_cast<const void*>(had_small_kernel<false>), c3)) return QUIP_ERR_LAUNCH;
-      hipLaunchKernelGGL(had_small_kernel<false>, grid, dim3(threads), lds, stream, a);
-    }
+template <typename Kern>
+int launch_one(Kern kern, int& configured, const HadArgs& a, dim3 grid, int threads, int lds, hipStream_t stream) {
+  if (lds > 48 * 1024 && lds > configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+        hipSuccess)
+      return QUIP_ERR_LAUNCH;
+    configured = lds;
   }
+  hipLaunchKernelGGL(kern, grid, dim3(threads), lds, stream, a);
   return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int launch(HadArgs a, int64_t rows, hipStream_t stream) {
+  const int L = a.L, K = a.K;
+  const bool planes = a.planes != nullptr;
+  a.vec = (a.in_features % 8 == 0) && aligned16(a.x) && aligned16(a.gate) && aligned16(a.rms_w) && aligned16(a.pre) &&
+          aligned16(a.pre2);
+  a.vec_out = (a.out_features % 8 == 0) && aligned16(a.y) && aligned16(a.post) && aligned16(a.bias) &&
+              aligned16(a.residual);
+  static int cfg[6] = {0, 0, 0, 0, 0, 0};
+  if (K > 1 && L >= 64 && L <= 256) {   // tall: 256 threads, R = 4096 / L rows per workgroup
+    const int R = 4096 / L;
+    const int lds = (4096 + 128 + 4 + K * R) * 4;
+    const dim3 grid((K + R - 1) / R, (unsigned)rows);
+    return planes ? launch_one(had_fast_kernel<true, true>, cfg[0], a, grid, 256, lds, stream)
+                  : launch_one(had_fast_kernel<false, true>, cfg[1], a, grid, 256, lds, stream);
+  }
+  const dim3 grid(K, (unsigned)rows);
+  if (L >= 256 && L <= 16384) {
+    const int lds = (L + (L >> 5) + 4) * 4;
+    return planes ? launch_one(had_fast_kernel<true, false>, cfg[2], a, grid, L / 16, lds, stream)
+                  : launch_one(had_fast_kernel<false, false>, cfg[3], a, grid, L / 16, lds, stream);
+  }
+  const int threads = L >= 512 ? 256 : 64;
+  return planes ? launch_one(had_small_kernel<true>, cfg[4], a, grid, threads, L * 4, stream)
+                : launch_one(had_small_kernel<false>, cfg[5], a, grid, threads, L * 4, stream);
 }
 
 int check_shape(int in_features, int out_features, int n, int K, const void* had, int& L, int& logL) {
