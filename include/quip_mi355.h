@@ -167,6 +167,20 @@ int quip_had_transform_planes_fused(const void* x, void* planes, int32_t in_feat
                                     const void* pre_scale, float scale,
                                     const quip_had_fusion* fusion, quip_stream_t stream);
 
+/* ---- decode-step glue between q/k/v_proj and o_proj (bs = 1) -------------------------------
+ * Rotary embedding of q and k at position *pos, append of (k, v) to the static KV cache and
+ * single-query softmax attention over positions [0, *pos], one launch.  Replaces, for the
+ * metric driver only, what example_generate.py:9-59 gets from HF LlamaAttention + StaticCache
+ * under torch.compile; it is not a quip_cuda entry point.
+ *   q [heads, head_dim], k / v [kv_heads, head_dim], out [heads, head_dim]: fp16
+ *   cos / sin [max_len, head_dim] fp32 (HF half-rotation tables), pos: device int64 scalar
+ *   kcache / vcache [kv_heads, max_len, head_dim] fp16, row *pos is written
+ * head_dim 64 or 128; scale is the softmax scale (1/sqrt(head_dim)). */
+int quip_rope_attn_decode_f16(const void* q, const void* k, const void* v, const float* cos,
+                              const float* sin, const int64_t* pos, void* kcache, void* vcache,
+                              void* out, int32_t heads, int32_t kv_heads, int32_t head_dim,
+                              int32_t max_len, float scale, quip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

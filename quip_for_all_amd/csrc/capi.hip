@@ -105,6 +105,17 @@ int quip_had_transform_planes_fused(const void* x, void* planes, int32_t in_feat
                                      (hipStream_t)stream, &h);
 }
 
+int quip_rope_attn_decode_f16(const void* q, const void* k, const void* v, const float* cos,
+                              const float* sin, const int64_t* pos, void* kcache, void* vcache,
+                              void* out, int32_t heads, int32_t kv_heads, int32_t head_dim,
+                              int32_t max_len, float scale, quip_stream_t stream) {
+  if (!q || !k || !v || !cos || !sin || !pos || !kcache || !vcache || !out) return QUIP_ERR_NULL_POINTER;
+  if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(kcache) || !aligned16(vcache))
+    return QUIP_ERR_MISALIGNED;
+  return rope_attn_decode_launch(q, k, v, cos, sin, pos, kcache, vcache, out, heads, kv_heads, head_dim,
+                                 max_len, scale, (hipStream_t)stream);
+}
+
 int quip_e8p_mm_origorder(const void* x, const void* qidxs, const void* grid, void* y, int32_t m,
                           int32_t n, int32_t k, quip_stream_t stream) {
   if (!grid) return QUIP_ERR_NULL_POINTER;

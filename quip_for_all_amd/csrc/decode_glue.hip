@@ -1,0 +1,160 @@
+// bs=1 decode glue between the QuantLinear calls of one transformer block: rotary embedding of
+// q / k, KV-cache append and single-query attention over the static cache, in one launch.
+// This is the part of the reference's metric driver (example_generate.py:9-59: HF StaticCache +
+// LlamaAttention under torch.compile) that sits between q/k/v_proj and o_proj; it is not part of
+// quip_cuda.  Fused here because on MI355X every dependent launch of a decode step costs
+// microseconds while the math is nothing.
+//
+// One workgroup per query head, 256 threads.  A key is handled by HD/8 lanes (16 bytes of the
+// fp16 head vector per lane); the 256/(HD/8) lane groups stride over the cached positions with
+// their own online-softmax state and are merged through LDS at the end (flash-decoding inside
+// a workgroup).  The new k / v row is used from registers (and appended to the cache by the
+// first query head of its KV group), so no other workgroup has to see the cache write.
+// Contexts of a few thousand tokens are fine; beyond that a split over workgroups would pay.
+#include "quip_device.hip.h"
+#include "quip_internal.h"
+
+namespace quip {
+namespace {
+
+struct AttnArgs {
+  const f16* q;        // [heads, HD]
+  const f16* k;        // [kv_heads, HD]  (pre-rope)
+  const f16* v;        // [kv_heads, HD]
+  const float* cos;    // [max_len, HD]
+  const float* sin;    // [max_len, HD]
+  const int64_t* pos;  // device scalar: index of the current token
+  f16* kcache;         // [kv_heads, max_len, HD]
+  f16* vcache;
+  f16* out;            // [heads, HD]
+  int heads, kv_heads, max_len;
+  float scale;
+};
+
+__device__ __forceinline__ void unpack8h(const uint4& u, float o[8]) {
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f16x2 h = as_f16x2(w[i]);
+    o[2 * i] = (float)h.x;
+    o[2 * i + 1] = (float)h.y;
+  }
+}
+
+// rotary embedding (HF half-rotation) of the 8 dims [d0, d0 + 8) of one head vector; result
+// rounded to fp16 like the eager graph does
+template <int HD>
+__device__ __forceinline__ void rope8(const f16* vec, const float* cs, const float* sn, int d0, float o[8]) {
+  float a[8], b[8];
+  unpack8h(*reinterpret_cast<const uint4*>(vec + d0), a);
+  const int dp = d0 < HD / 2 ? d0 + HD / 2 : d0 - HD / 2;
+  unpack8h(*reinterpret_cast<const uint4*>(vec + dp), b);
+  const float sgn = d0 < HD / 2 ? -1.f : 1.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (float)(f16)(a[i] * cs[d0 + i] + sgn * b[i] * sn[d0 + i]);
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void rope_attn_decode_kernel(AttnArgs a) {
+  constexpr int LPK = HD / 8;        // lanes per key
+  constexpr int NG = 256 / LPK;      // key groups per workgroup
+  constexpr int U = 4;               // keys in flight per group
+  __shared__ float s_m[NG], s_l[NG];
+  __shared__ float s_acc[NG][HD + 4];
+  const int tid = threadIdx.x, h = blockIdx.x;
+  const int gl = tid % LPK, grp = tid / LPK, d0 = gl * 8;
+  const int group = a.heads / a.kv_heads, kvh = h / group;
+  const int pos = (int)*a.pos;
+  const float* cs = a.cos + (size_t)pos * HD;
+  const float* sn = a.sin + (size_t)pos * HD;
+
+  float q8[8], kn[8], vn[8];
+  rope8<HD>(a.q + (size_t)h * HD, cs, sn, d0, q8);
+  rope8<HD>(a.k + (size_t)kvh * HD, cs, sn, d0, kn);
+  const uint4 vraw = *reinterpret_cast<const uint4*>(a.v + (size_t)kvh * HD + d0);
+  unpack8h(vraw, vn);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) q8[i] *= a.scale;
+  f16* kc = a.kcache + (size_t)kvh * a.max_len * HD;
+  f16* vc = a.vcache + (size_t)kvh * a.max_len * HD;
+  if (h % group == 0 && grp == 0) {   // append the new row (StaticCache.update)
+    uint4 kr;
+    kr.x = pack_f16(kn[0], kn[1]); kr.y = pack_f16(kn[2], kn[3]);
+    kr.z = pack_f16(kn[4], kn[5]); kr.w = pack_f16(kn[6], kn[7]);
+    *reinterpret_cast<uint4*>(kc + (size_t)pos * HD + d0) = kr;
+    *reinterpret_cast<uint4*>(vc + (size_t)pos * HD + d0) = vraw;
+  }
+
+  float m = -INFINITY, l = 0.f, acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  for (int t0 = grp; t0 <= pos; t0 += NG * U) {
+    uint4 kr[U], vr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 + u * NG;
+      const int tc = t < pos ? t : 0;   // t == pos comes from registers, t > pos is masked
+      kr[u] = *reinterpret_cast<const uint4*>(kc + (size_t)tc * HD + d0);
+      vr[u] = *reinterpret_cast<const uint4*>(vc + (size_t)tc * HD + d0);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 + u * NG;
+      float k8[8], v8[8];
+      unpack8h(kr[u], k8);
+      unpack8h(vr[u], v8);
+      if (t == pos) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { k8[i] = kn[i]; v8[i] = vn[i]; }
+      }
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s = __builtin_fmaf(q8[i], k8[i], s);
+#pragma unroll
+      for (int o = 1; o < LPK; o <<= 1) s += __shfl_xor(s, o, 64);
+      if (t <= pos) {
+        const float mn = fmaxf(m, s);
+        const float c = __expf(m - mn), p = __expf(s - mn);
+        l = l * c + p;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = acc[i] * c + p * v8[i];
+        m = mn;
+      }
+    }
+  }
+  if (gl == 0) { s_m[grp] = m; s_l[grp] = l; }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s_acc[grp][d0 + i] = acc[i];
+  __syncthreads();
+  if (tid < HD) {
+    float M = -INFINITY;
+    for (int g = 0; g < NG; ++g) M = fmaxf(M, s_m[g]);
+    float Lsum = 0.f, o = 0.f;
+    for (int g = 0; g < NG; ++g) {
+      const float w = s_m[g] == -INFINITY ? 0.f : __expf(s_m[g] - M);
+      Lsum = __builtin_fmaf(s_l[g], w, Lsum);
+      o = __builtin_fmaf(s_acc[g][tid], w, o);
+    }
+    a.out[(size_t)h * HD + tid] = (f16)(o / Lsum);
+  }
+}
+
+}  // namespace
+
+int rope_attn_decode_launch(const void* q, const void* k, const void* v, const float* cos, const float* sin,
+                            const int64_t* pos, void* kcache, void* vcache, void* out, int heads, int kv_heads,
+                            int head_dim, int max_len, float scale, hipStream_t stream) {
+  if (heads < 1 || kv_heads < 1 || heads % kv_heads != 0 || max_len < 1) return QUIP_ERR_BAD_SHAPE;
+  AttnArgs a{reinterpret_cast<const f16*>(q), reinterpret_cast<const f16*>(k), reinterpret_cast<const f16*>(v),
+             cos, sin, pos, reinterpret_cast<f16*>(kcache), reinterpret_cast<f16*>(vcache),
+             reinterpret_cast<f16*>(out), heads, kv_heads, max_len, scale};
+  if (head_dim == 128)
+    hipLaunchKernelGGL(rope_attn_decode_kernel<128>, dim3(heads), dim3(256), 0, stream, a);
+  else if (head_dim == 64)
+    hipLaunchKernelGGL(rope_attn_decode_kernel<64>, dim3(heads), dim3(256), 0, stream, a);
+  else
+    return QUIP_ERR_UNSUPPORTED;
+  return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+}
+
+}  // namespace quip

@@ -166,14 +166,76 @@ __device__ __forceinline__ void in_vals16(const HadArgs& a, const f16* xr, const
   }
 }
 
+// Two-phase version of in_vals16 for the vec layout: issue every 16-byte load of a chunk first
+// (raw_load16), unpack / multiply later (raw_math16), so that several chunks share one memory
+// round trip instead of paying one per chunk.
+struct Raw16 { uint4 d[5][2]; };   // x, rms_w, gate, pre, pre2
+
+__device__ __forceinline__ void raw_load16(const HadArgs& a, const f16* xr, const f16* gr, int idx0, Raw16& r) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int c = idx0 + 8 * h;
+    const int cc = c < a.in_features ? c : 0;
+    r.d[0][h] = *reinterpret_cast<const uint4*>(xr + cc);
+    if (a.rms_w) r.d[1][h] = *reinterpret_cast<const uint4*>(a.rms_w + cc);
+    if (a.gate) r.d[2][h] = *reinterpret_cast<const uint4*>(gr + cc);
+    if (a.pre) r.d[3][h] = *reinterpret_cast<const uint4*>(a.pre + cc);
+    if (a.pre2) r.d[4][h] = *reinterpret_cast<const uint4*>(a.pre2 + cc);
+  }
+}
+
+__device__ __forceinline__ void unpack8(const uint4& u, float o[8]) {
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f16x2 h = as_f16x2(w[i]);
+    o[2 * i] = (float)h.x;
+    o[2 * i + 1] = (float)h.y;
+  }
+}
+
+__device__ __forceinline__ void raw_math16(const HadArgs& a, int idx0, const Raw16& r, float e[16], float& ss_x) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float* o = e + 8 * h;
+    float t[8];
+    const float keep = (idx0 + 8 * h) < a.in_features ? 1.f : 0.f;   // F.pad zeros
+    unpack8(r.d[0][h], o);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] *= keep;
+    if (a.rms_w) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ss_x = __builtin_fmaf(o[i], o[i], ss_x);
+      unpack8(r.d[1][h], t);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] *= t[i];
+    }
+    if (a.gate) {
+      unpack8(r.d[2][h], t);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] *= silu(t[i]);
+    }
+    if (a.pre) {
+      unpack8(r.d[3][h], t);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] *= t[i];
+    }
+    if (a.pre2) {
+      unpack8(r.d[4][h], t);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] *= t[i];
+    }
+  }
+}
+
 // One workgroup transforms E = R * L elements (R rows kp of the (K, L) view), 16 per thread.
 //   wide (TALL == false): R = 1, thread owns 16 consecutive columns, K-mix by looping over k with
 //                         16-byte loads (K == 1, or long rows: 28672 = 7 x 4096);
 //   tall (TALL == true):  64 <= L <= 256 < n, 256 threads, R = 16 * (256 / L): thread owns one
 //                         column and 16 rows of the K-mix (11008 = 43 x 256 or 172 x 64), the H
 //                         tile sits in LDS and is read as broadcasts.
-template <bool PLANES, bool TALL>
-__global__ __launch_bounds__(1024) void had_fast_kernel(HadArgs a) {
+template <bool PLANES, bool TALL, int MAXT>
+__global__ __launch_bounds__(MAXT) void had_fast_kernel(HadArgs a) {
   extern __shared__ __attribute__((aligned(16))) float buf[];
   __shared__ float red[16];
   const int tid = threadIdx.x, nt = blockDim.x;   // nt == E / 16
@@ -195,14 +257,42 @@ __global__ __launch_bounds__(1024) void had_fast_kernel(HadArgs a) {
     if (K == 1) {
       in_vals16(a, xr, gr, kp * L + j0, v, ss_x);
     } else {
-      for (int k = 0; k < K; ++k) {
-        const float h = (float)(a.transpose ? a.had[k * K + kp] : a.had[kp * K + k]);
-        float e[16];
-        in_vals16(a, xr, gr, k * L + j0, e, ss_x);
+      constexpr int U = MAXT <= 256 ? 2 : 1;       // k values per memory round trip
+      for (int k0 = 0; k0 < K; k0 += U) {
+        float h[U];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          ss_in = __builtin_fmaf(e[r], e[r], ss_in);
-          v[r] = __builtin_fmaf(h, e[r], v[r]);
+        for (int u = 0; u < U; ++u) {
+          const int k = min(k0 + u, K - 1);
+          h[u] = (k0 + u) < K ? (float)(a.transpose ? a.had[k * K + kp] : a.had[kp * K + k]) : 0.f;
+        }
+        if (a.vec) {
+          Raw16 raw[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) raw_load16(a, xr, gr, min(k0 + u, K - 1) * L + j0, raw[u]);
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            float e[16];
+            float sx = 0.f;
+            raw_math16(a, min(k0 + u, K - 1) * L + j0, raw[u], e, sx);
+            if (k0 + u < K) {
+              ss_x += sx;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                ss_in = __builtin_fmaf(e[r], e[r], ss_in);
+                v[r] = __builtin_fmaf(h[u], e[r], v[r]);
+              }
+            }
+          }
+        } else {
+          for (int u = 0; u < U && k0 + u < K; ++u) {
+            float e[16];
+            in_vals16(a, xr, gr, (k0 + u) * L + j0, e, ss_x);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              ss_in = __builtin_fmaf(e[r], e[r], ss_in);
+              v[r] = __builtin_fmaf(h[u], e[r], v[r]);
+            }
+          }
         }
       }
     }
@@ -213,41 +303,56 @@ __global__ __launch_bounds__(1024) void had_fast_kernel(HadArgs a) {
       hs[i] = kq < K ? (float)(a.transpose ? a.had[k * K + kq] : a.had[kq * K + k]) : 0.f;
     }
     __syncthreads();
-    const int g = tid >> logL, j = tid & (L - 1);
-    const float* hg = hs + g * 16;
-    for (int k0 = 0; k0 < K; k0 += 4) {
-      float e[4];
+    // stage the pre-processed input row in LDS (one memory round trip for the whole row)
+    float* xs = hs + K * R;
+    if (a.vec) {
+      constexpr int U = 3;
+      for (int c0 = 0; c0 * 16 < a.n; c0 += U * nt) {
+        Raw16 raw[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int idx = (k0 + u) * L + j;
-        const bool ok = (k0 + u) < K && idx < a.in_features;
-        float xv = ok ? (float)xr[idx] : 0.f;
-        if (a.rms_w) { ss_x = __builtin_fmaf(xv, xv, ss_x); xv *= ok ? (float)a.rms_w[idx] : 0.f; }
-        if (a.gate) xv *= ok ? silu((float)gr[idx]) : 0.f;
-        if (a.pre) xv *= ok ? (float)a.pre[idx] : 0.f;
-        if (a.pre2) xv *= ok ? (float)a.pre2[idx] : 0.f;
-        e[u] = xv;
-        ss_in = __builtin_fmaf(xv, xv, ss_in);
-      }
+        for (int u = 0; u < U; ++u) {
+          const int c = c0 + u * nt + tid;
+          raw_load16(a, xr, gr, c * 16 < a.n ? c * 16 : 0, raw[u]);
+        }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (k0 + u < K) {
-          const float4* h4 = reinterpret_cast<const float4*>(hg + (k0 + u) * R);
+        for (int u = 0; u < U; ++u) {
+          const int c = c0 + u * nt + tid;
+          float e[16];
+          float sx = 0.f;
+          raw_math16(a, c * 16 < a.n ? c * 16 : 0, raw[u], e, sx);
+          if (c * 16 < a.n) {
+            ss_x += sx;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float4 h = h4[q];
-            v[4 * q + 0] = __builtin_fmaf(h.x, e[u], v[4 * q + 0]);
-            v[4 * q + 1] = __builtin_fmaf(h.y, e[u], v[4 * q + 1]);
-            v[4 * q + 2] = __builtin_fmaf(h.z, e[u], v[4 * q + 2]);
-            v[4 * q + 3] = __builtin_fmaf(h.w, e[u], v[4 * q + 3]);
+            for (int r = 0; r < 16; ++r) ss_in = __builtin_fmaf(e[r], e[r], ss_in);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              *reinterpret_cast<float4*>(xs + c * 16 + 4 * q) = make_float4(e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]);
           }
         }
       }
+    } else {
+      for (int i = tid; i < a.n; i += nt) {
+        const float e = in_val(a, xr, gr, i);
+        if (a.rms_w && i < a.in_features) { const float xv = (float)xr[i]; ss_x = __builtin_fmaf(xv, xv, ss_x); }
+        ss_in = __builtin_fmaf(e, e, ss_in);
+        xs[i] = e;
+      }
     }
-    // every one of the nt / L column groups saw the whole row
-    const float inv_groups = (float)L / (float)nt;
-    ss_x *= inv_groups;
-    ss_in *= inv_groups;
+    __syncthreads();
+    const int g = tid >> logL, j = tid & (L - 1);
+    const float* hg = hs + g * 16;
+    for (int k = 0; k < K; ++k) {
+      const float e = xs[(k << logL) + j];
+      const float4* h4 = reinterpret_cast<const float4*>(hg + k * R);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 h = h4[q];
+        v[4 * q + 0] = __builtin_fmaf(h.x, e, v[4 * q + 0]);
+        v[4 * q + 1] = __builtin_fmaf(h.y, e, v[4 * q + 1]);
+        v[4 * q + 2] = __builtin_fmaf(h.z, e, v[4 * q + 2]);
+        v[4 * q + 3] = __builtin_fmaf(h.w, e, v[4 * q + 3]);
+      }
+    }
     // (row, column) ownership -> 16 consecutive elements per thread
 #pragma unroll
     for (int r = 0; r < 16; ++r) buf[pad(((g * 16 + r) << logL) + j)] = v[r];
@@ -478,19 +583,22 @@ int launch(HadArgs a, int64_t rows, hipStream_t stream) {
           aligned16(a.pre2);
   a.vec_out = (a.out_features % 8 == 0) && aligned16(a.y) && aligned16(a.post) && aligned16(a.bias) &&
               aligned16(a.residual);
-  static int cfg[6] = {0, 0, 0, 0, 0, 0};
+  static int cfg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (K > 1 && L >= 64 && L <= 256) {   // tall: 256 threads, R = 4096 / L rows per workgroup
     const int R = 4096 / L;
-    const int lds = (4096 + 128 + 4 + K * R) * 4;
+    const int lds = (4096 + 128 + 4 + K * R + a.n) * 4;
     const dim3 grid((K + R - 1) / R, (unsigned)rows);
-    return planes ? launch_one(had_fast_kernel<true, true>, cfg[0], a, grid, 256, lds, stream)
-                  : launch_one(had_fast_kernel<false, true>, cfg[1], a, grid, 256, lds, stream);
+    return planes ? launch_one(had_fast_kernel<true, true, 256>, cfg[0], a, grid, 256, lds, stream)
+                  : launch_one(had_fast_kernel<false, true, 256>, cfg[1], a, grid, 256, lds, stream);
   }
   const dim3 grid(K, (unsigned)rows);
   if (L >= 256 && L <= 16384) {
     const int lds = (L + (L >> 5) + 4) * 4;
-    return planes ? launch_one(had_fast_kernel<true, false>, cfg[2], a, grid, L / 16, lds, stream)
-                  : launch_one(had_fast_kernel<false, false>, cfg[3], a, grid, L / 16, lds, stream);
+    if (L <= 4096)
+      return planes ? launch_one(had_fast_kernel<true, false, 256>, cfg[2], a, grid, L / 16, lds, stream)
+                    : launch_one(had_fast_kernel<false, false, 256>, cfg[3], a, grid, L / 16, lds, stream);
+    return planes ? launch_one(had_fast_kernel<true, false, 1024>, cfg[6], a, grid, L / 16, lds, stream)
+                  : launch_one(had_fast_kernel<false, false, 1024>, cfg[7], a, grid, L / 16, lds, stream);
   }
   const int threads = L >= 512 ? 256 : 64;
   return planes ? launch_one(had_small_kernel<true>, cfg[4], a, grid, threads, L * 4, stream)

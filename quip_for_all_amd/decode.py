@@ -101,6 +101,7 @@ class LlamaDecoder:
         self.tok = torch.zeros(1, dtype=torch.long, device=self.dev)
         self.pos = torch.zeros(1, dtype=torch.long, device=self.dev)
         self.graph = None
+        self.fused_attention = s.head_dim in (64, 128)
 
     # ---- model bytes the decode step has to stream (roofline denominator) -----------
     def algorithmic_bytes_per_token(self):
@@ -121,18 +122,26 @@ class LlamaDecoder:
         advances self.pos (all on the device)"""
         s = self.s
         h = self.embed[self.tok]                                   # (1, hidden)
-        cos, sin = self.cos[self.pos], self.sin[self.pos]          # (1, head_dim)
-        mask = (self.arange[None, None, None, :] <= self.pos)      # (1,1,1,max_len) keys <= current
+        if not self.fused_attention:
+            cos, sin = self.cos[self.pos], self.sin[self.pos]          # (1, head_dim)
+            mask = (self.arange[None, None, None, :] <= self.pos)      # (1,1,1,max_len) keys <= current
         for i, L in enumerate(self.layers):
             # RMSNorm is folded into the input-side Hadamard launch of q / k / v (and gate / up)
-            q = L["q"].forward_fused(h, rms_weight=L["ln1"], rms_eps=s.rms_eps).view(1, s.heads, 1, s.head_dim)
-            k = L["k"].forward_fused(h, rms_weight=L["ln1"], rms_eps=s.rms_eps).view(1, s.kv_heads, 1, s.head_dim)
-            v = L["v"].forward_fused(h, rms_weight=L["ln1"], rms_eps=s.rms_eps).view(1, s.kv_heads, 1, s.head_dim)
-            q, k = self._rope(q, cos, sin), self._rope(k, cos, sin)
-            self.kcache[i].index_copy_(1, self.pos, k[0])
-            self.vcache[i].index_copy_(1, self.pos, v[0])
-            a = F.scaled_dot_product_attention(q, self.kcache[i][None], self.vcache[i][None], attn_mask=mask,
-                                               enable_gqa=(s.kv_heads != s.heads))
+            q = L["q"].forward_fused(h, rms_weight=L["ln1"], rms_eps=s.rms_eps)
+            k = L["k"].forward_fused(h, rms_weight=L["ln1"], rms_eps=s.rms_eps)
+            v = L["v"].forward_fused(h, rms_weight=L["ln1"], rms_eps=s.rms_eps)
+            if self.fused_attention:
+                # rope + cache append + attention over [0, pos]: one launch
+                a = torch.ops.quip_lib.rope_attn_decode(
+                    q.view(s.heads, s.head_dim), k.view(s.kv_heads, s.head_dim), v.view(s.kv_heads, s.head_dim),
+                    self.cos, self.sin, self.pos, self.kcache[i], self.vcache[i])
+            else:
+                q = self._rope(q.view(1, s.heads, 1, s.head_dim), cos, sin)
+                k = self._rope(k.view(1, s.kv_heads, 1, s.head_dim), cos, sin)
+                self.kcache[i].index_copy_(1, self.pos, k[0])
+                self.vcache[i].index_copy_(1, self.pos, v.view(s.kv_heads, 1, s.head_dim))
+                a = F.scaled_dot_product_attention(q, self.kcache[i][None], self.vcache[i][None], attn_mask=mask,
+                                                   enable_gqa=(s.kv_heads != s.heads))
             # residual adds ride on the output-side Hadamard launch, SiLU(gate)*up on down's input side
             h = L["o"].forward_fused(a.reshape(1, s.hidden), residual=h)
             g = L["gate"].forward_fused(h, rms_weight=L["ln2"], rms_eps=s.rms_eps)

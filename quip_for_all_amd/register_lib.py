@@ -39,6 +39,9 @@ _SCHEMAS = {
     "had_transform_fused": "(Tensor x, int out_features, int n, int K, Tensor? had, bool transpose, Tensor? pre, "
                            "Tensor? pre2, Tensor? post, Tensor? bias, float scale, Tensor? residual, "
                            "Tensor? rms_weight, float rms_eps, Tensor? gate) -> Tensor",
+    # decode-step glue between q/k/v_proj and o_proj: rope + KV-cache append + single-query attention
+    "rope_attn_decode": "(Tensor q, Tensor k, Tensor v, Tensor cos, Tensor sin, Tensor pos, Tensor(a!) kcache, "
+                        "Tensor(b!) vcache) -> Tensor",
     "had_transform_planes_fused": "(Tensor x, int n, int K, Tensor? had, bool transpose, Tensor? pre, float scale, "
                                   "Tensor? rms_weight, float rms_eps, Tensor? gate) -> Tensor",
 }
@@ -159,6 +162,29 @@ def _had_transform_planes_fused_cuda(x, n, K, had, transpose, pre, scale, rms_we
                                                      int(bool(transpose)), _ptr(pre), float(scale), ctypes.byref(f),
                                                      _stream(x)), "quip_had_transform_planes_fused")
     return planes
+
+
+def _rope_attn_decode_cuda(q, k, v, cos, sin, pos, kcache, vcache):
+    """q (heads, hd), k / v (kv_heads, hd) fp16; cos / sin (max_len, hd) fp32; pos int64 device scalar;
+    kcache / vcache (kv_heads, max_len, hd) fp16 (row pos is written) -> (heads, hd) fp16"""
+    import math
+    for t in (q, k, v, kcache, vcache):
+        _need(t.dtype == torch.float16 and t.is_contiguous() and t.is_cuda, "rope_attn_decode: fp16 contiguous CUDA tensors")
+    _need(cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous(),
+          "cos / sin must be contiguous float32")
+    _need(pos.dtype == torch.int64 and pos.numel() == 1 and pos.is_cuda, "pos must be an int64 device scalar")
+    heads, hd = q.shape
+    kvh, max_len = kcache.shape[0], kcache.shape[1]
+    _need(tuple(k.shape) == (kvh, hd) and tuple(v.shape) == (kvh, hd) and tuple(vcache.shape) == tuple(kcache.shape)
+          and kcache.shape[2] == hd and tuple(cos.shape) == (max_len, hd) and tuple(sin.shape) == (max_len, hd),
+          "rope_attn_decode: shape mismatch")
+    out = torch.empty_like(q)
+    with torch.cuda.device(q.device):
+        capi.check(capi.lib().quip_rope_attn_decode_f16(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), cos.data_ptr(), sin.data_ptr(), pos.data_ptr(),
+            kcache.data_ptr(), vcache.data_ptr(), out.data_ptr(), heads, kvh, hd, max_len, 1.0 / math.sqrt(hd),
+            _stream(q)), "quip_rope_attn_decode_f16")
+    return out
 
 
 def _e8p_gemv_planes_cuda(planes, Qidxs, grid):
@@ -292,6 +318,7 @@ _IMPLS = {
     "had_transform": _had_transform_cuda,
     "had_transform_planes": _had_transform_planes_cuda,
     "e8p_gemv_planes": _e8p_gemv_planes_cuda,
+    "rope_attn_decode": _rope_attn_decode_cuda,
     "had_transform_fused": _had_transform_fused_cuda,
     "had_transform_planes_fused": _had_transform_planes_fused_cuda,
     "e8p_mm_origorder": _e8p_mm_cuda,
@@ -327,6 +354,7 @@ _reg_fake("had_transform_fused", lambda x, out_features, n, K, had, transpose, p
           rms_weight, rms_eps, gate: x.new_empty((x.shape[0], out_features)))
 _reg_fake("had_transform_planes_fused", lambda x, n, K, had, transpose, pre, scale, rms_weight, rms_eps, gate:
           x.new_empty((3 * ((n + 511) // 512 * 512) + 16,), dtype=torch.uint8))
+_reg_fake("rope_attn_decode", lambda q, k, v, cos, sin, pos, kcache, vcache: torch.empty_like(q))
 _reg_fake("e8p_gemv_planes", lambda planes, Q, g: Q.new_empty((1, Q.shape[0]), dtype=torch.float16))
 for _n in ("e8p_mm_origorder", "e8prvq3_mm_origorder", "e8prvq4_mm_origorder", "d4_mm_origorder",
            "hi_mm_origorder"):

@@ -90,3 +90,42 @@ def test_decoder_byte_count_matches_survey():
     q = s.layers * (4 * s.hidden * s.hidden + 3 * s.hidden * s.ffn) // 4
     suv = s.layers * 2 * (4 * 2 * s.hidden + 2 * (s.hidden + s.ffn) + (s.ffn + s.hidden))
     assert abs((q + suv + s.vocab * s.hidden * 2) / 1e9 - 1.886) < 0.002
+
+
+@pytest.mark.parametrize("heads,kv_heads,hd,pos", [(32, 32, 128, 0), (32, 32, 128, 37), (8, 2, 128, 200),
+                                                   (4, 2, 64, 5), (4, 4, 64, 130), (64, 8, 128, 1000)])
+def test_rope_attn_decode_matches_torch(heads, kv_heads, hd, pos):
+    """fused rope + cache append + single-query attention == the eager torch ops it replaces"""
+    import quip_for_all_amd  # noqa: F401
+    import torch.nn.functional as F
+    dev = "cuda"
+    g = torch.Generator().manual_seed(pos + heads)
+    max_len = pos + 9
+    q = torch.randn(heads, hd, generator=g).half().to(dev)
+    k = torch.randn(kv_heads, hd, generator=g).half().to(dev)
+    v = torch.randn(kv_heads, hd, generator=g).half().to(dev)
+    kc = torch.randn(kv_heads, max_len, hd, generator=g).half().to(dev)
+    vc = torch.randn(kv_heads, max_len, hd, generator=g).half().to(dev)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    ang = torch.arange(max_len, dtype=torch.float32)[:, None] * inv[None, :]
+    cos = torch.cat([ang.cos(), ang.cos()], -1).to(dev)
+    sin = torch.cat([ang.sin(), ang.sin()], -1).to(dev)
+    p = torch.tensor([pos], device=dev)
+    kc2, vc2 = kc.clone(), vc.clone()
+    out = torch.ops.quip_lib.rope_attn_decode(q, k, v, cos, sin, p, kc2, vc2)
+
+    def rope(x):
+        d = hd // 2
+        rot = torch.cat([-x[..., d:], x[..., :d]], -1)
+        return (x.float() * cos[pos] + rot.float() * sin[pos]).half()
+    qr, kr = rope(q), rope(k)
+    kc[:, pos] = kr
+    vc[:, pos] = v
+    assert torch.equal(kc2, kc) and torch.equal(vc2, vc)          # cache append is bit exact
+    rep = heads // kv_heads
+    K = kc[:, :pos + 1].double().repeat_interleave(rep, 0)
+    V = vc[:, :pos + 1].double().repeat_interleave(rep, 0)
+    s = torch.einsum("hd,htd->ht", qr.double(), K) / hd ** 0.5
+    ref = torch.einsum("ht,htd->hd", torch.softmax(s, -1), V)
+    err = (out.double() - ref).abs().max().item()
+    assert err <= 2e-3 * max(1.0, ref.abs().max().item()), err
