@@ -167,6 +167,35 @@ int quip_had_transform_planes_fused(const void* x, void* planes, int32_t in_feat
                                     const void* pre_scale, float scale,
                                     const quip_had_fusion* fusion, quip_stream_t stream);
 
+/* ---- grouped launches -------------------------------------------------------------------------
+ * Several QuantLinear modules that read the same activation (q/k/v_proj, gate/up_proj) are
+ * independent reference calls (qlinear.py:87-115 once per module); at bs = 1 each launch costs
+ * more than its math, so the three stages of up to QUIP_MAX_GROUP modules can each be issued as
+ * one launch.  All problems of a group share n, K, transpose (Hadamard) resp. k (GEMV). */
+#define QUIP_MAX_GROUP 3
+typedef struct quip_had_problem {
+  const void* x;           /* fp16 [rows, in_features] */
+  void* out;               /* fp16 [rows, out_features], or digit planes (planes group) */
+  const void* had;         /* (K, K) fp16 or NULL */
+  const void* pre_scale;   /* fp16 [in_features] or NULL */
+  const void* pre_scale2;  /* fp16 [n] or NULL */
+  const void* post_scale;  /* fp16 [out_features] or NULL */
+  const void* bias;        /* fp16 [out_features] or NULL */
+  const void* residual;    /* fusion hooks as in quip_had_fusion, all optional */
+  const void* rms_weight;
+  const void* gate;
+  int32_t in_features, out_features;
+  float scale, rms_eps;
+} quip_had_problem;
+int quip_had_transform_group_f16(const quip_had_problem* problems, int32_t count, int64_t rows,
+                                 int32_t n, int32_t K, int32_t transpose, quip_stream_t stream);
+int quip_had_transform_planes_group(const quip_had_problem* problems, int32_t count, int32_t n,
+                                    int32_t K, int32_t transpose, quip_stream_t stream);
+/* count GEMVs y[i] = W[i] x[i] (W[i]: (ns[i], k) E8P12 codes, x[i] as digit planes) */
+int quip_e8p_gemv_planes_group(const void* const* planes, const void* const* qidxs,
+                               const void* grid_packed_abs, void* const* ys, const int32_t* ns,
+                               int32_t count, int32_t k, quip_stream_t stream);
+
 /* ---- decode-step glue between q/k/v_proj and o_proj (bs = 1) -------------------------------
  * Rotary embedding of q and k at position *pos, append of (k, v) to the static KV cache and
  * single-query softmax attention over positions [0, *pos], one launch.  Replaces, for the

@@ -19,6 +19,9 @@ SIGNATURES = {
     "quip_had_transform_planes": [_P, _P, _I32, _I32, _I32, _P, _I32, _P, _F, _P],
     "quip_had_transform_fused_f16": [_P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _P, _P, _P, _F, _P, _P],
     "quip_had_transform_planes_fused": [_P, _P, _I32, _I32, _I32, _P, _I32, _P, _F, _P, _P],
+    "quip_had_transform_group_f16": [_P, _I32, _I64, _I32, _I32, _I32, _P],
+    "quip_had_transform_planes_group": [_P, _I32, _I32, _I32, _I32, _P],
+    "quip_e8p_gemv_planes_group": [_P, _P, _P, _P, _P, _I32, _I32, _P],
     "quip_rope_attn_decode_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _P],
     "quip_e8p_mm_origorder": [_P, _P, _P, _P, _I32, _I32, _I32, _P],
     "quip_e8p_mm_workspace_bytes": [_I32, _I32, _I32],
@@ -41,6 +44,16 @@ _INTERNAL = {
     "quip_e8p_x_to_planes_laneorder": [_P, _P, _I32, _P],
     "quip_e8p_gemv_tuned": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P],
 }
+
+class HadProblem(_c.Structure):
+    """mirror of quip_had_problem (include/quip_mi355.h)"""
+    _fields_ = [("x", _P), ("out", _P), ("had", _P), ("pre_scale", _P), ("pre_scale2", _P), ("post_scale", _P),
+                ("bias", _P), ("residual", _P), ("rms_weight", _P), ("gate", _P), ("in_features", _I32),
+                ("out_features", _I32), ("scale", _F), ("rms_eps", _F)]
+
+
+MAX_GROUP = 3
+
 
 class HadFusion(_c.Structure):
     """mirror of quip_had_fusion (include/quip_mi355.h)"""

@@ -54,6 +54,12 @@ class E8P12_codebook(_Codebook):
         """shapes the matrix-core bs=1 GEMV takes (csrc/e8p_gemv_mfma.hip)"""
         return q_in % 128 == 0 and 128 <= q_in <= 28672 and q_out >= 1
 
+    @staticmethod
+    def planes_group_supported(q_outs, q_in):
+        """1..3 GEMVs of a common k in one launch: all digit planes must fit in LDS next to the tables"""
+        kp = (q_in + 511) // 512 * 512
+        return 1 <= len(q_outs) <= 3 and len(q_outs) * kp <= 31232
+
     def mm_planes(self, planes, Qidxs):
         """bs=1 product with x given as int8 digit planes (quip_lib::had_transform_planes)"""
         return torch.ops.quip_lib.e8p_gemv_planes(planes, Qidxs, self.grid_packed_abs)

@@ -105,6 +105,49 @@ int quip_had_transform_planes_fused(const void* x, void* planes, int32_t in_feat
                                      (hipStream_t)stream, &h);
 }
 
+static int group_had(const quip_had_problem* problems, int32_t count, bool planes, int64_t rows, int32_t n,
+                     int32_t K, int32_t transpose, quip_stream_t stream) {
+  if (!problems) return QUIP_ERR_NULL_POINTER;
+  if (count < 1 || count > QUIP_MAX_GROUP) return QUIP_ERR_BAD_SHAPE;
+  HadProblem pr[QUIP_MAX_GROUP];
+  for (int i = 0; i < count; ++i) {
+    const quip_had_problem& s = problems[i];
+    if (!s.x || !s.out) return QUIP_ERR_NULL_POINTER;
+    pr[i].x = s.x; pr[i].out = s.out; pr[i].had = s.had; pr[i].pre = s.pre_scale; pr[i].pre2 = s.pre_scale2;
+    pr[i].post = s.post_scale; pr[i].bias = s.bias; pr[i].residual = s.residual; pr[i].rms_weight = s.rms_weight;
+    pr[i].gate = s.gate; pr[i].in_features = s.in_features; pr[i].out_features = s.out_features;
+    pr[i].scale = s.scale; pr[i].rms_eps = s.rms_eps;
+  }
+  return had_transform_group_launch(pr, count, planes, rows, n, K, transpose, (hipStream_t)stream);
+}
+
+int quip_had_transform_group_f16(const quip_had_problem* problems, int32_t count, int64_t rows,
+                                 int32_t n, int32_t K, int32_t transpose, quip_stream_t stream) {
+  return group_had(problems, count, false, rows, n, K, transpose, stream);
+}
+
+int quip_had_transform_planes_group(const quip_had_problem* problems, int32_t count, int32_t n,
+                                    int32_t K, int32_t transpose, quip_stream_t stream) {
+  return group_had(problems, count, true, 1, n, K, transpose, stream);
+}
+
+int quip_e8p_gemv_planes_group(const void* const* planes, const void* const* qidxs,
+                               const void* grid_packed_abs, void* const* ys, const int32_t* ns,
+                               int32_t count, int32_t k, quip_stream_t stream) {
+  if (!planes || !qidxs || !grid_packed_abs || !ys || !ns) return QUIP_ERR_NULL_POINTER;
+  if (count < 1 || count > QUIP_MAX_GROUP) return QUIP_ERR_BAD_SHAPE;
+  int n32[QUIP_MAX_GROUP];
+  for (int i = 0; i < count; ++i) {
+    if (!planes[i] || !qidxs[i] || !ys[i]) return QUIP_ERR_NULL_POINTER;
+    if (!aligned16(planes[i]) || !aligned16(qidxs[i])) return QUIP_ERR_MISALIGNED;
+    if (ns[i] < 1) return QUIP_ERR_BAD_SHAPE;
+    n32[i] = ns[i];
+  }
+  if (k < 1 || k % 8 != 0) return QUIP_ERR_BAD_SHAPE;
+  return e8p_gemv_mfma_group_launch(planes, qidxs, grid_packed_abs, ys, n32, count, k, GemvTune{},
+                                    (hipStream_t)stream);
+}
+
 int quip_rope_attn_decode_f16(const void* q, const void* k, const void* v, const float* cos,
                               const float* sin, const int64_t* pos, void* kcache, void* vcache,
                               void* out, int32_t heads, int32_t kv_heads, int32_t head_dim,

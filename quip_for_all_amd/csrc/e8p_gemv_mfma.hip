@@ -64,7 +64,7 @@ struct Lds {
   static constexpr int kAcc = 2 * 256 * kRow;        // int32 [kMaxRowsPerBlock][4]
   static constexpr int kX = kAcc + kMaxRowsPerBlock * 16;   // 3 planes x Kp bytes
   static constexpr int kMaxKp = (160 * 1024 - kX) / 3 / 512 * 512;
-  static int bytes(int kp) { return kX + 3 * kp; }
+  static int bytes(int kp, int g = 1) { return kX + 3 * kp * g; }
 };
 static_assert(Lds<32>::kMaxKp >= 8192 && Lds<16>::kMaxKp >= 28672, "LDS budget");
 
@@ -187,11 +187,21 @@ __device__ __forceinline__ i32x4 item_mfma(const ItemAddr& ad, uint32_t xaddr) {
   return acc;
 }
 
-template <int REP, int SLOTS, int MAXT>
+// Up to G independent GEMVs of the same K in one launch (q/k/v or gate/up of a decoder block):
+// workgroup b owns rows [b * rpb[p], +rpb[p]) of every problem p; its items run over all of
+// them, so the tables are built once and the launch / drain cost is paid once.
+template <int G>
+struct GemvGroup {
+  const uint4* W[G];
+  const uint8_t* planes[G];
+  f16* y[G];
+  int N[G];
+  int rpb[G];
+};
+
+template <int REP, int SLOTS, int MAXT, int G>
 __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
-    const uint4* __restrict__ W, const uint8_t* __restrict__ planes, const int* __restrict__ sh_ptr,
-    f16* __restrict__ y, const uint64_t* __restrict__ grid, int N, int K, int Kp,
-    int rows_per_block, uint64_t* __restrict__ dbg) {
+    GemvGroup<G> gp, const uint64_t* __restrict__ grid, int K, int Kp, uint64_t* __restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using L = Lds<REP>;
 #define QUIP_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -202,22 +212,48 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwaves = __builtin_amdgcn_readfirstlane(nthreads >> 6);
   const int n = lane & 15, q = lane >> 4;
-  const int row0 = blockIdx.x * rows_per_block;
-  const int rows_here = min(N, row0 + rows_per_block) - row0;
-  const int nrb = (rows_here + 15) >> 4;   // row blocks of this workgroup
   const int row_u4 = K >> 6;               // uint4 per packed row (K/4 bytes)
   const int J = Kp >> 9;                   // slices of 512 k
-  const int cnt = nrb * J;                 // items of this workgroup
+  int row0[G], rows_here[G], cbase[G + 1], rbase[G];   // per problem: first row, rows, item base, acc row base
+  cbase[0] = 0;
+#pragma unroll
+  for (int p = 0; p < G; ++p) {
+    row0[p] = blockIdx.x * gp.rpb[p];
+    rows_here[p] = max(0, min(gp.N[p], row0[p] + gp.rpb[p]) - row0[p]);
+    cbase[p + 1] = cbase[p] + ((rows_here[p] + 15) >> 4) * J;
+    rbase[p] = p == 0 ? 0 : rbase[p - 1] + gp.rpb[p - 1];
+  }
+  const int cnt = cbase[G];                // items of this workgroup
 
-  // item -> (row block, slice); lanes outside the matrix read a valid (clamped) address
+  // item -> (problem, row block, slice); wave uniform
+  auto problem_of = [&](int it) -> int {
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < G; ++i) p += it >= cbase[i] ? 1 : 0;
+    return p;
+  };
+  auto pick = [&](const int* arr, int p) -> int {
+    int v = arr[0];
+#pragma unroll
+    for (int i = 1; i < G; ++i) v = p == i ? arr[i] : v;
+    return v;
+  };
+
+  // lanes outside the matrix read a valid (clamped) address
   // and are neutralised by zero x digits (k padding) / never-read rows
   // Load j (0, 1) of lane (n, q) reads bytes [64 j + 16 q, +16) of row n's 128-byte slice line, so
   // each load instruction covers 64 contiguous bytes per row (measured: the 16-byte-at-32-byte-
   // stride alternative costs ~25 % of the streaming rate).  A slice that sticks out of the row
   // (K % 512 != 0) re-reads a valid piece; its x digits are zero (k padding).
   auto item_ptr = [&](int it, int j) -> const uint4* {
-    const int rb = it / J, s = it - rb * J;
-    int row = row0 + rb * 16 + n;
+    const int p = problem_of(it);
+    const int li = it - pick(cbase, p);
+    const int rb = li / J, s = li - rb * J;
+    const int N = pick(gp.N, p);
+    const uint4* W = gp.W[0];
+#pragma unroll
+    for (int i = 1; i < G; ++i) W = p == i ? gp.W[i] : W;
+    int row = pick(row0, p) + rb * 16 + n;
     row = row < N ? row : N - 1;
     int off = s * 8 + q + 4 * j;  // uint4 units inside the row
     off = off < row_u4 ? off : s * 8 + q;
@@ -226,16 +262,24 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
 
   // (0) VMEM loads return in issue order: the x digit planes (L2 hits) are requested
   //     before the (TLB-cold, HBM) weight loads, all through hand-counted asm loads.
-  constexpr int XR = 6;  // 16-byte x pieces per thread: needs nthreads >= 3 * Kp / 96
-  const int xpieces = 3 * (Kp >> 4);
+  constexpr int XR = 6;  // 16-byte x pieces per thread: needs nthreads >= G * 3 * Kp / 96
+  const int ppieces = 3 * (Kp >> 4);       // pieces per problem
+  const int xpieces = G * ppieces;
   u32x4 xr[XR];
 #pragma unroll
   for (int j = 0; j < XR; ++j) {
     const int i = tid + j * nthreads;
-    asm_load16(xr[j], reinterpret_cast<const uint4*>(planes) + (i < xpieces ? i : 0));
+    const int ic = i < xpieces ? i : 0;
+    int p = 0;
+#pragma unroll
+    for (int g = 1; g < G; ++g) p += ic >= g * ppieces ? 1 : 0;
+    const uint8_t* src = gp.planes[0];
+#pragma unroll
+    for (int g = 1; g < G; ++g) src = p == g ? gp.planes[g] : src;
+    asm_load16(xr[j], reinterpret_cast<const uint4*>(src) + (ic - p * ppieces));
   }
   // past-the-end reloads read the L2-resident x planes (each lane its own 32 bytes)
-  const uint4* hot = reinterpret_cast<const uint4*>(planes) + (size_t)((tid * 2) % (xpieces - 1));
+  const uint4* hot = reinterpret_cast<const uint4*>(gp.planes[0]) + (size_t)((tid * 2) % (ppieces - 1));
   u32x4 qa[SLOTS], qb[SLOTS];
 #pragma unroll
   for (int i = 0; i < SLOTS; ++i) {
@@ -249,7 +293,9 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
   // (1) tables + zeroed accumulators: scalar loads and LDS writes only
   fill_tables<REP>(smem, grid, lane, wave, nwaves);
   for (int i = tid; i < kMaxRowsPerBlock * 4; i += nthreads) reinterpret_cast<int*>(smem + L::kAcc)[i] = 0;
-  const int sh = *sh_ptr;
+  int sh[G];
+#pragma unroll
+  for (int p = 0; p < G; ++p) sh[p] = *reinterpret_cast<const int*>(gp.planes[p] + (size_t)3 * Kp);
   QUIP_STAMP(2);
 
   // (2) x digit planes into LDS once the 6 plane loads have landed (the 2 * SLOTS weight
@@ -273,11 +319,13 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
   QUIP_STAMP(4);
 
   auto run_item = [&](int cur, const ItemAddr& ad) {
-    const int rb = cur / J, sl = cur - rb * J;
-    const i32x4 acc = item_mfma(ad, xlane + (uint32_t)sl * 512);
+    const int p = problem_of(cur);
+    const int li = cur - pick(cbase, p);
+    const int rb = li / J, sl = li - rb * J;
+    const i32x4 acc = item_mfma(ad, xlane + (uint32_t)(p * 3 * Kp + sl * 512));
     // lanes 0..15 (q == 0) hold S_h, S_m, S_l of row rb*16 + n in acc[0..2]
     if (q == 0) {
-      int* dst = accs + (rb * 16 + n) * 4;
+      int* dst = accs + (pick(rbase, p) + rb * 16 + n) * 4;
       __hip_atomic_fetch_add(dst + 0, acc.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       __hip_atomic_fetch_add(dst + 1, acc.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       __hip_atomic_fetch_add(dst + 2, acc.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -314,21 +362,24 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
   QUIP_STAMP(6);
 
   // (5) y = 2^(-sh-2) * (65536 S_h + 256 S_m + S_l), fp16 RN, coalesced
-  const float unscale = as_f32((uint32_t)(127 - sh - 2) << 23);
-  for (int t = tid; t < rows_here; t += nthreads) {
-    const int* a = accs + t * 4;
-    const float f = __builtin_fmaf((float)a[0], 65536.f, __builtin_fmaf((float)a[1], 256.f, (float)a[2]));
-    y[row0 + t] = (f16)(f * unscale);
+#pragma unroll
+  for (int p = 0; p < G; ++p) {
+    const float unscale = as_f32((uint32_t)(127 - sh[p] - 2) << 23);
+    for (int t = tid; t < rows_here[p]; t += nthreads) {
+      const int* a = accs + (rbase[p] + t) * 4;
+      const float f = __builtin_fmaf((float)a[0], 65536.f, __builtin_fmaf((float)a[1], 256.f, (float)a[2]));
+      gp.y[p][row0[p] + t] = (f16)(f * unscale);
+    }
   }
   QUIP_STAMP(7);
 #undef QUIP_STAMP
 }
 
-template <int REP, int SLOTS, int MAXT>
-int launch(const void* planes, const int* sh, const void* qidxs, const void* grid, void* y, int n, int k,
-           int kp, int rpb, int nblocks, int threads, uint64_t* dbg, hipStream_t stream) {
-  auto kern = e8p_gemv_mfma_kernel<REP, SLOTS, MAXT>;
-  const int lds = Lds<REP>::bytes(kp);
+template <int REP, int SLOTS, int MAXT, int G>
+int launch(const GemvGroup<G>& gp, const void* grid, int k, int kp, int nblocks, int threads, uint64_t* dbg,
+           hipStream_t stream) {
+  auto kern = e8p_gemv_mfma_kernel<REP, SLOTS, MAXT, G>;
+  const int lds = Lds<REP>::bytes(kp, G);
   static int configured = 0;  // benign race: idempotent attribute
   if (lds > configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -336,9 +387,8 @@ int launch(const void* planes, const int* sh, const void* qidxs, const void* gri
       return QUIP_ERR_LAUNCH;
     configured = lds;
   }
-  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(threads), lds, stream,
-                     reinterpret_cast<const uint4*>(qidxs), reinterpret_cast<const uint8_t*>(planes), sh,
-                     reinterpret_cast<f16*>(y), reinterpret_cast<const uint64_t*>(grid), n, k, kp, rpb, dbg);
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(threads), lds, stream, gp,
+                     reinterpret_cast<const uint64_t*>(grid), k, kp, dbg);
   return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
 }
 
@@ -495,7 +545,6 @@ int e8p_gemv_mfma_launch(const void* planes, const void* qidxs, const void* grid
   if (!e8p_gemv_mfma_supported(n, k)) return QUIP_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(grid) & 63u) != 0) return QUIP_ERR_MISALIGNED;
   const int kp = kp_of(k);
-  const int* sh = reinterpret_cast<const int*>(reinterpret_cast<const char*>(planes) + (size_t)3 * kp);
   uint64_t* dbg = reinterpret_cast<uint64_t*>(tune.dbg);
   const int ncu = device_cu_count();
   int nblocks = tune.blocks > 0 ? tune.blocks : ncu;
@@ -513,14 +562,80 @@ int e8p_gemv_mfma_launch(const void* planes, const void* qidxs, const void* grid
   int slots = tune.rows ? tune.rows : (items_per_wave >= 4 ? 2 : 1);
   const int threads = waves * 64;
   if (threads > 512 && slots > 4) slots = 4;  // 128-VGPR budget: deeper queues would spill
-#define QUIP_CASE(R, S)                                                                                   \
-  if (rep == R && slots == S)                                                                             \
-    return threads > 512 ? launch<R, S, 1024>(planes, sh, qidxs, grid, y, n, k, kp, rpb, nblocks, threads, dbg, stream) \
-                         : launch<R, S, 512>(planes, sh, qidxs, grid, y, n, k, kp, rpb, nblocks, threads, dbg, stream);
+  GemvGroup<1> gp{{reinterpret_cast<const uint4*>(qidxs)}, {reinterpret_cast<const uint8_t*>(planes)},
+                  {reinterpret_cast<f16*>(y)}, {n}, {rpb}};
+#define QUIP_CASE(R, S)                                                                        \
+  if (rep == R && slots == S)                                                                  \
+    return threads > 512 ? launch<R, S, 1024, 1>(gp, grid, k, kp, nblocks, threads, dbg, stream) \
+                         : launch<R, S, 512, 1>(gp, grid, k, kp, nblocks, threads, dbg, stream);
   QUIP_CASE(32, 1) QUIP_CASE(32, 2) QUIP_CASE(32, 3) QUIP_CASE(32, 4) QUIP_CASE(32, 6) QUIP_CASE(32, 8)
   QUIP_CASE(16, 1) QUIP_CASE(16, 2) QUIP_CASE(16, 3) QUIP_CASE(16, 4) QUIP_CASE(16, 6) QUIP_CASE(16, 8)
 #undef QUIP_CASE
   return QUIP_ERR_UNSUPPORTED;
+}
+
+bool e8p_gemv_mfma_group_supported(const int* ns, int count, int k) {
+  if (count < 1 || count > 3) return false;
+  for (int i = 0; i < count; ++i)
+    if (!e8p_gemv_mfma_supported(ns[i], k)) return false;
+  return count * kp_of(k) <= Lds<16>::kMaxKp;
+}
+
+template <int G>
+static int group_launch(const void* const* planes, const void* const* qidxs, const void* grid, void* const* ys,
+                        const int* ns, int k, const GemvTune& tune, hipStream_t stream) {
+  const int kp = kp_of(k);
+  const int ncu = device_cu_count();
+  int nblocks = tune.blocks > 0 ? tune.blocks : ncu;
+  GemvGroup<G> gp;
+  int total_rpb = 0;
+  for (;;) {
+    total_rpb = 0;
+    for (int p = 0; p < G; ++p) {
+      int rpb = (ns[p] + nblocks - 1) / nblocks;
+      rpb = (rpb + 15) & ~15;
+      gp.rpb[p] = rpb;
+      total_rpb += rpb;
+    }
+    if (total_rpb <= kMaxRowsPerBlock) break;
+    nblocks *= 2;   // more, smaller workgroups until the accumulator rows fit
+  }
+  int used = 0, items = 0;
+  for (int p = 0; p < G; ++p) {
+    gp.W[p] = reinterpret_cast<const uint4*>(qidxs[p]);
+    gp.planes[p] = reinterpret_cast<const uint8_t*>(planes[p]);
+    gp.y[p] = reinterpret_cast<f16*>(ys[p]);
+    gp.N[p] = ns[p];
+    used = used > (ns[p] + gp.rpb[p] - 1) / gp.rpb[p] ? used : (ns[p] + gp.rpb[p] - 1) / gp.rpb[p];
+    items += (gp.rpb[p] >> 4) * (kp >> 9);
+  }
+  nblocks = used;
+  int waves = tune.max_waves > 0 ? tune.max_waves : 8;
+  if (waves > 16) waves = 16;
+  const int min_waves = (G * 3 * (kp >> 4) + 6 * 64 - 1) / (6 * 64);
+  if (waves < min_waves) waves = min_waves;
+  if (waves > 16) return QUIP_ERR_UNSUPPORTED;
+  const int rep = (G * kp <= Lds<32>::kMaxKp && tune.rep != 16) ? 32 : 16;
+  const int slots = tune.rows ? (tune.rows >= 2 ? 2 : 1) : ((items + waves - 1) / waves >= 4 ? 2 : 1);
+  const int threads = waves * 64;
+  uint64_t* dbg = reinterpret_cast<uint64_t*>(tune.dbg);
+#define QUIP_CASE(R, S)                                                                        \
+  if (rep == R && slots == S)                                                                  \
+    return threads > 512 ? launch<R, S, 1024, G>(gp, grid, k, kp, nblocks, threads, dbg, stream) \
+                         : launch<R, S, 512, G>(gp, grid, k, kp, nblocks, threads, dbg, stream);
+  QUIP_CASE(32, 1) QUIP_CASE(32, 2) QUIP_CASE(16, 1) QUIP_CASE(16, 2)
+#undef QUIP_CASE
+  return QUIP_ERR_UNSUPPORTED;
+}
+
+int e8p_gemv_mfma_group_launch(const void* const* planes, const void* const* qidxs, const void* grid,
+                               void* const* ys, const int* ns, int count, int k, const GemvTune& tune,
+                               hipStream_t stream) {
+  if (!e8p_gemv_mfma_group_supported(ns, count, k)) return QUIP_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(grid) & 63u) != 0) return QUIP_ERR_MISALIGNED;
+  if (count == 1) return e8p_gemv_mfma_launch(planes[0], qidxs[0], grid, ys[0], ns[0], k, tune, stream);
+  if (count == 2) return group_launch<2>(planes, qidxs, grid, ys, ns, k, tune, stream);
+  return group_launch<3>(planes, qidxs, grid, ys, ns, k, tune, stream);
 }
 
 }  // namespace quip

@@ -50,6 +50,9 @@ struct HadArgs {
   float scale, rms_eps;
 };
 
+constexpr int kMaxGroup = 3;   // problems per launch (q/k/v, gate/up)
+struct HadGroup { HadArgs p[kMaxGroup]; };
+
 __device__ __forceinline__ float silu(float g) { return g / (1.f + __expf(-g)); }
 
 __device__ __forceinline__ float block_reduce(float v, bool is_max, float* red, int tid, int nt) {
@@ -235,7 +238,8 @@ __device__ __forceinline__ void raw_math16(const HadArgs& a, int idx0, const Raw
 //                         column and 16 rows of the K-mix (11008 = 43 x 256 or 172 x 64), the H
 //                         tile sits in LDS and is read as broadcasts.
 template <bool PLANES, bool TALL, int MAXT>
-__global__ __launch_bounds__(MAXT) void had_fast_kernel(HadArgs a) {
+__global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
+  const HadArgs a = grp.p[blockIdx.z];
   extern __shared__ __attribute__((aligned(16))) float buf[];
   __shared__ float red[16];
   const int tid = threadIdx.x, nt = blockDim.x;   // nt == E / 16
@@ -483,7 +487,8 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadArgs a) {
 
 // simple LDS radix-2 version for lengths the blocked kernel does not take
 template <bool PLANES>
-__global__ __launch_bounds__(256) void had_small_kernel(HadArgs a) {
+__global__ __launch_bounds__(256) void had_small_kernel(HadGroup grp) {
+  const HadArgs a = grp.p[blockIdx.z];
   extern __shared__ __attribute__((aligned(16))) float buf[];
   __shared__ float red[16];
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -563,46 +568,50 @@ __global__ __launch_bounds__(256) void had_small_kernel(HadArgs a) {
 }
 
 template <typename Kern>
-int launch_one(Kern kern, int& configured, const HadArgs& a, dim3 grid, int threads, int lds, hipStream_t stream) {
+int launch_one(Kern kern, int& configured, const HadGroup& g, dim3 grid, int threads, int lds, hipStream_t stream) {
   if (lds > 48 * 1024 && lds > configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
         hipSuccess)
       return QUIP_ERR_LAUNCH;
     configured = lds;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(threads), lds, stream, a);
+  hipLaunchKernelGGL(kern, grid, dim3(threads), lds, stream, g);
   return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-int launch(HadArgs a, int64_t rows, hipStream_t stream) {
-  const int L = a.L, K = a.K;
-  const bool planes = a.planes != nullptr;
-  a.vec = (a.in_features % 8 == 0) && aligned16(a.x) && aligned16(a.gate) && aligned16(a.rms_w) && aligned16(a.pre) &&
-          aligned16(a.pre2);
-  a.vec_out = (a.out_features % 8 == 0) && aligned16(a.y) && aligned16(a.post) && aligned16(a.bias) &&
-              aligned16(a.residual);
+// `count` problems of the same (n, K, L) and kind (planes / fp16) in one launch (grid.z)
+int launch(HadGroup& g, int count, int64_t rows, hipStream_t stream) {
+  const int L = g.p[0].L, K = g.p[0].K, n = g.p[0].n;
+  const bool planes = g.p[0].planes != nullptr;
+  for (int i = 0; i < count; ++i) {
+    HadArgs& a = g.p[i];
+    a.vec = (a.in_features % 8 == 0) && aligned16(a.x) && aligned16(a.gate) && aligned16(a.rms_w) &&
+            aligned16(a.pre) && aligned16(a.pre2);
+    a.vec_out = (a.out_features % 8 == 0) && aligned16(a.y) && aligned16(a.post) && aligned16(a.bias) &&
+                aligned16(a.residual);
+  }
   static int cfg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (K > 1 && L >= 64 && L <= 256) {   // tall: 256 threads, R = 4096 / L rows per workgroup
     const int R = 4096 / L;
-    const int lds = (4096 + 128 + 4 + K * R + a.n) * 4;
-    const dim3 grid((K + R - 1) / R, (unsigned)rows);
-    return planes ? launch_one(had_fast_kernel<true, true, 256>, cfg[0], a, grid, 256, lds, stream)
-                  : launch_one(had_fast_kernel<false, true, 256>, cfg[1], a, grid, 256, lds, stream);
+    const int lds = (4096 + 128 + 4 + K * R + n) * 4;
+    const dim3 grid((K + R - 1) / R, (unsigned)rows, count);
+    return planes ? launch_one(had_fast_kernel<true, true, 256>, cfg[0], g, grid, 256, lds, stream)
+                  : launch_one(had_fast_kernel<false, true, 256>, cfg[1], g, grid, 256, lds, stream);
   }
-  const dim3 grid(K, (unsigned)rows);
+  const dim3 grid(K, (unsigned)rows, count);
   if (L >= 256 && L <= 16384) {
     const int lds = (L + (L >> 5) + 4) * 4;
     if (L <= 4096)
-      return planes ? launch_one(had_fast_kernel<true, false, 256>, cfg[2], a, grid, L / 16, lds, stream)
-                    : launch_one(had_fast_kernel<false, false, 256>, cfg[3], a, grid, L / 16, lds, stream);
-    return planes ? launch_one(had_fast_kernel<true, false, 1024>, cfg[6], a, grid, L / 16, lds, stream)
-                  : launch_one(had_fast_kernel<false, false, 1024>, cfg[7], a, grid, L / 16, lds, stream);
+      return planes ? launch_one(had_fast_kernel<true, false, 256>, cfg[2], g, grid, L / 16, lds, stream)
+                    : launch_one(had_fast_kernel<false, false, 256>, cfg[3], g, grid, L / 16, lds, stream);
+    return planes ? launch_one(had_fast_kernel<true, false, 1024>, cfg[6], g, grid, L / 16, lds, stream)
+                  : launch_one(had_fast_kernel<false, false, 1024>, cfg[7], g, grid, L / 16, lds, stream);
   }
   const int threads = L >= 512 ? 256 : 64;
-  return planes ? launch_one(had_small_kernel<true>, cfg[4], a, grid, threads, L * 4, stream)
-                : launch_one(had_small_kernel<false>, cfg[5], a, grid, threads, L * 4, stream);
+  return planes ? launch_one(had_small_kernel<true>, cfg[4], g, grid, threads, L * 4, stream)
+                : launch_one(had_small_kernel<false>, cfg[5], g, grid, threads, L * 4, stream);
 }
 
 int check_shape(int in_features, int out_features, int n, int K, const void* had, int& L, int& logL) {
@@ -616,55 +625,67 @@ int check_shape(int in_features, int out_features, int n, int K, const void* had
   return QUIP_OK;
 }
 
+int fill(HadArgs& a, const HadProblem& pr, bool planes, int n, int K, int transpose) {
+  int rc = check_shape(pr.in_features, planes ? n : pr.out_features, n, K, pr.had, a.L, a.logL);
+  if (rc != QUIP_OK) return rc;
+  if (!pr.x || !pr.out) return QUIP_ERR_NULL_POINTER;
+  a.x = reinterpret_cast<const f16*>(pr.x);
+  if (planes) a.planes = reinterpret_cast<uint8_t*>(pr.out); else a.y = reinterpret_cast<f16*>(pr.out);
+  a.had = reinterpret_cast<const f16*>(pr.had);
+  a.pre = reinterpret_cast<const f16*>(pr.pre);
+  a.pre2 = reinterpret_cast<const f16*>(pr.pre2);
+  a.post = reinterpret_cast<const f16*>(pr.post);
+  a.bias = reinterpret_cast<const f16*>(pr.bias);
+  a.residual = reinterpret_cast<const f16*>(pr.residual);
+  a.rms_w = reinterpret_cast<const f16*>(pr.rms_weight);
+  a.gate = reinterpret_cast<const f16*>(pr.gate);
+  a.rms_eps = pr.rms_eps;
+  a.in_features = pr.in_features; a.out_features = planes ? n : pr.out_features; a.n = n; a.K = K;
+  a.Kp = (n + 511) & ~511;
+  a.transpose = transpose; a.scale = pr.scale;
+  return QUIP_OK;
+}
+
 }  // namespace
+
+int had_transform_group_launch(const HadProblem* problems, int count, bool planes, int64_t rows, int n, int K,
+                               int transpose, hipStream_t stream) {
+  if (count < 1 || count > kMaxGroup || !problems) return QUIP_ERR_BAD_SHAPE;
+  HadGroup g{};
+  for (int i = 0; i < count; ++i) {
+    const int rc = fill(g.p[i], problems[i], planes, n, K, transpose);
+    if (rc != QUIP_OK) return rc;
+    if (planes && (reinterpret_cast<uintptr_t>(problems[i].out) & 15) != 0) return QUIP_ERR_MISALIGNED;
+  }
+  if (planes && (g.p[0].L < 4 || n % 16 != 0 || rows != 1)) return QUIP_ERR_BAD_SHAPE;
+  if (rows <= 0) return QUIP_OK;
+  if (rows > 65535) return QUIP_ERR_BAD_SHAPE;  // TODO(round 2): fold rows into grid.x for prefill
+  return launch(g, count, rows, stream);
+}
 
 int had_transform_launch(const void* x, void* y, int64_t rows, int in_features, int out_features,
                          int n, int K, const void* had, int transpose, const void* pre,
                          const void* pre2, const void* post, const void* bias, float scale,
                          hipStream_t stream, const HadFusion* fuse) {
-  HadArgs a{};
-  int rc = check_shape(in_features, out_features, n, K, had, a.L, a.logL);
-  if (rc != QUIP_OK) return rc;
-  if (rows <= 0) return QUIP_OK;
-  if (rows > 65535) return QUIP_ERR_BAD_SHAPE;  // TODO(round 2): fold rows into grid.x for prefill
-  a.x = reinterpret_cast<const f16*>(x);
-  a.y = reinterpret_cast<f16*>(y);
-  a.had = reinterpret_cast<const f16*>(had);
-  a.pre = reinterpret_cast<const f16*>(pre);
-  a.pre2 = reinterpret_cast<const f16*>(pre2);
-  a.post = reinterpret_cast<const f16*>(post);
-  a.bias = reinterpret_cast<const f16*>(bias);
-  if (fuse) {
-    a.residual = reinterpret_cast<const f16*>(fuse->residual);
-    a.rms_w = reinterpret_cast<const f16*>(fuse->rms_weight);
-    a.gate = reinterpret_cast<const f16*>(fuse->gate);
-    a.rms_eps = fuse->rms_eps;
+  HadProblem pr;
+  pr.x = x; pr.out = y; pr.had = had; pr.pre = pre; pr.pre2 = pre2; pr.post = post; pr.bias = bias;
+  pr.in_features = in_features; pr.out_features = out_features; pr.scale = scale;
+  if (fuse) { pr.residual = fuse->residual; pr.rms_weight = fuse->rms_weight; pr.gate = fuse->gate; pr.rms_eps = fuse->rms_eps; }
+  if (rows <= 0) {   // shape errors still reported for empty batches
+    HadArgs a{};
+    return check_shape(in_features, out_features, n, K, had, a.L, a.logL);
   }
-  a.in_features = in_features; a.out_features = out_features; a.n = n; a.K = K;
-  a.transpose = transpose; a.scale = scale;
-  return launch(a, rows, stream);
+  return had_transform_group_launch(&pr, 1, false, rows, n, K, transpose, stream);
 }
 
 int had_transform_planes_launch(const void* x, void* planes, int in_features, int n, int K,
                                 const void* had, int transpose, const void* pre, float scale,
                                 hipStream_t stream, const HadFusion* fuse) {
-  HadArgs a{};
-  int rc = check_shape(in_features, n, n, K, had, a.L, a.logL);
-  if (rc != QUIP_OK) return rc;
-  if (a.L < 4 || n % 16 != 0) return QUIP_ERR_BAD_SHAPE;
-  a.x = reinterpret_cast<const f16*>(x);
-  a.planes = reinterpret_cast<uint8_t*>(planes);
-  a.had = reinterpret_cast<const f16*>(had);
-  a.pre = reinterpret_cast<const f16*>(pre);
-  if (fuse) {
-    a.rms_w = reinterpret_cast<const f16*>(fuse->rms_weight);
-    a.gate = reinterpret_cast<const f16*>(fuse->gate);
-    a.rms_eps = fuse->rms_eps;
-  }
-  a.in_features = in_features; a.out_features = n; a.n = n; a.K = K;
-  a.Kp = (n + 511) & ~511;
-  a.transpose = transpose; a.scale = scale;
-  return launch(a, 1, stream);
+  HadProblem pr;
+  pr.x = x; pr.out = planes; pr.had = had; pr.pre = pre;
+  pr.in_features = in_features; pr.out_features = n; pr.scale = scale;
+  if (fuse) { pr.rms_weight = fuse->rms_weight; pr.gate = fuse->gate; pr.rms_eps = fuse->rms_eps; }
+  return had_transform_group_launch(&pr, 1, true, 1, n, K, transpose, stream);
 }
 
 }  // namespace quip

@@ -56,6 +56,27 @@ struct HadFusion {
   const void* gate = nullptr;        // fp16 [rows, in_features]: input is silu(gate) * x
   float rms_eps = 1e-5f;
 };
+// one Hadamard problem of a grouped launch (same n, K, transpose, kind for the whole group)
+struct HadProblem {
+  const void* x = nullptr;
+  void* out = nullptr;               // fp16 [rows, out_features] or digit planes
+  const void* had = nullptr;
+  const void* pre = nullptr;
+  const void* pre2 = nullptr;
+  const void* post = nullptr;
+  const void* bias = nullptr;
+  const void* residual = nullptr;
+  const void* rms_weight = nullptr;
+  const void* gate = nullptr;
+  int in_features = 0, out_features = 0;
+  float scale = 1.f, rms_eps = 1e-5f;
+};
+int had_transform_group_launch(const HadProblem* problems, int count, bool planes, int64_t rows, int n, int K,
+                               int transpose, hipStream_t stream);
+bool e8p_gemv_mfma_group_supported(const int* ns, int count, int k);
+int e8p_gemv_mfma_group_launch(const void* const* planes, const void* const* qidxs, const void* grid,
+                               void* const* ys, const int* ns, int count, int k, const GemvTune& tune,
+                               hipStream_t stream);
 int had_transform_launch(const void* x, void* y, int64_t rows, int in_features, int out_features,
                          int n, int K, const void* had, int transpose, const void* pre,
                          const void* pre2, const void* post, const void* bias, float scale,

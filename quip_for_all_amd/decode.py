@@ -18,7 +18,7 @@ import torch
 import torch.nn.functional as F
 
 from .codebook import codebook_id
-from .qlinear import QuantLinear
+from .qlinear import QuantLinear, forward_group
 
 
 @dataclass
@@ -127,9 +127,8 @@ class LlamaDecoder:
             mask = (self.arange[None, None, None, :] <= self.pos)      # (1,1,1,max_len) keys <= current
         for i, L in enumerate(self.layers):
             # RMSNorm is folded into the input-side Hadamard launch of q / k / v (and gate / up)
-            q = L["q"].forward_fused(h, rms_weight=L["ln1"], rms_eps=s.rms_eps)
-            k = L["k"].forward_fused(h, rms_weight=L["ln1"], rms_eps=s.rms_eps)
-            v = L["v"].forward_fused(h, rms_weight=L["ln1"], rms_eps=s.rms_eps)
+            # q / k / v (and gate / up below): one launch per stage for the whole group
+            q, k, v = forward_group([L["q"], L["k"], L["v"]], h, rms_weight=L["ln1"], rms_eps=s.rms_eps)
             if self.fused_attention:
                 # rope + cache append + attention over [0, pos]: one launch
                 a = torch.ops.quip_lib.rope_attn_decode(
@@ -144,8 +143,7 @@ class LlamaDecoder:
                                                    enable_gqa=(s.kv_heads != s.heads))
             # residual adds ride on the output-side Hadamard launch, SiLU(gate)*up on down's input side
             h = L["o"].forward_fused(a.reshape(1, s.hidden), residual=h)
-            g = L["gate"].forward_fused(h, rms_weight=L["ln2"], rms_eps=s.rms_eps)
-            u = L["up"].forward_fused(h, rms_weight=L["ln2"], rms_eps=s.rms_eps)
+            g, u = forward_group([L["gate"], L["up"]], h, rms_weight=L["ln2"], rms_eps=s.rms_eps)
             h = L["down"].forward_fused(u, gate=g, residual=h)
         logits = F.rms_norm(h, (s.hidden,), self.final_norm, s.rms_eps) @ self.lm_head.T
         self.tok.copy_(logits.argmax(-1))

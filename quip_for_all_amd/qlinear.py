@@ -200,3 +200,47 @@ class QuantLinear(nn.Module):
                 layer.bias.copy_(torch.from_numpy(P.bias))
         layer.wscale_float = float(P.wscale_float)
         return layer
+
+
+def forward_group(layers, input, rms_weight=None, rms_eps=1e-5, residual=None):
+    """[l(input) for l in layers] for 1..3 QuantLinear modules that read the same bs=1 activation
+    (q/k/v_proj, gate/up_proj), each of the three stages issued as ONE launch for the whole group
+    instead of one per module; results are identical to calling the modules one by one
+    (qlinear.py:87-115 per module).  Falls back to per-module calls whenever the group does not
+    qualify (different input transform shapes, batch > 1, non-E8P12 codebook)."""
+    x = input.reshape(-1, input.shape[-1])
+    l0 = layers[0]
+    cb = l0.codebook
+    residual = residual if residual is not None else [None] * len(layers)
+    ok = (1 < len(layers) <= 3 and x.shape[0] == 1 and x.dtype == torch.float16 and not l0.training
+          and hasattr(cb, "mm_planes")
+          and all(type(l.codebook) is type(cb) and l.in_features == l0.in_features
+                  and l.q_in_features == l0.q_in_features and l.K_left == l0.K_left
+                  and cb.planes_supported(l.q_out_features, l.q_in_features) for l in layers)
+          and cb.planes_group_supported([l.q_out_features for l in layers], l0.q_in_features))
+    if not ok:
+        return [l.forward_fused(input, rms_weight=rms_weight, rms_eps=rms_eps, residual=r)
+                for l, r in zip(layers, residual)]
+    L_in = l0.q_in_features // l0.K_left
+    planes = torch.ops.quip_lib.had_transform_planes_group(
+        x, l0.q_in_features, l0.K_left, [l._had("had_left") for l in layers], True, [l._vec(l.SU) for l in layers],
+        [l.wscale_float / math.sqrt(L_in) for l in layers], l0._vec(rms_weight), rms_eps, None)
+    zs = torch.ops.quip_lib.e8p_gemv_planes_group(planes, [l.Qidxs for l in layers], cb.grid_packed_abs)
+    # output transforms: one launch per set of modules with the same (q_out, K_right)
+    ys = [None] * len(layers)
+    todo = list(range(len(layers)))
+    while todo:
+        i0 = todo[0]
+        same = [i for i in todo if layers[i].q_out_features == layers[i0].q_out_features
+                and layers[i].K_right == layers[i0].K_right]
+        todo = [i for i in todo if i not in same]
+        ls = [layers[i] for i in same]
+        L_out = ls[0].q_out_features // ls[0].K_right
+        outs = torch.ops.quip_lib.had_transform_group(
+            [zs[i] for i in same], [l.out_features for l in ls], ls[0].q_out_features, ls[0].K_right,
+            [l._had("had_right") for l in ls], False, [l._vec(l.Wscale) if l.per_channel else None for l in ls],
+            [l._vec(l.SV) for l in ls], [l._vec(l.bias) for l in ls], [1.0 / math.sqrt(L_out)] * len(ls),
+            [None if residual[i] is None else residual[i].reshape(1, -1).to(torch.float16) for i in same])
+        for i, o in zip(same, outs):
+            ys[i] = o.view(*input.shape[:-1], layers[i].out_features)
+    return ys

@@ -39,6 +39,13 @@ _SCHEMAS = {
     "had_transform_fused": "(Tensor x, int out_features, int n, int K, Tensor? had, bool transpose, Tensor? pre, "
                            "Tensor? pre2, Tensor? post, Tensor? bias, float scale, Tensor? residual, "
                            "Tensor? rms_weight, float rms_eps, Tensor? gate) -> Tensor",
+    # grouped launches: the three stages of up to 3 QuantLinear modules reading the same activation
+    "had_transform_planes_group": "(Tensor x, int n, int K, Tensor?[] had, bool transpose, Tensor?[] pre, "
+                                  "float[] scale, Tensor? rms_weight, float rms_eps, Tensor? gate) -> Tensor[]",
+    "e8p_gemv_planes_group": "(Tensor[] planes, Tensor[] Qidxs, Tensor grid) -> Tensor[]",
+    "had_transform_group": "(Tensor[] x, int[] out_features, int n, int K, Tensor?[] had, bool transpose, "
+                           "Tensor?[] pre2, Tensor?[] post, Tensor?[] bias, float[] scale, Tensor?[] residual) "
+                           "-> Tensor[]",
     # decode-step glue between q/k/v_proj and o_proj: rope + KV-cache append + single-query attention
     "rope_attn_decode": "(Tensor q, Tensor k, Tensor v, Tensor cos, Tensor sin, Tensor pos, Tensor(a!) kcache, "
                         "Tensor(b!) vcache) -> Tensor",
@@ -162,6 +169,73 @@ def _had_transform_planes_fused_cuda(x, n, K, had, transpose, pre, scale, rms_we
                                                      int(bool(transpose)), _ptr(pre), float(scale), ctypes.byref(f),
                                                      _stream(x)), "quip_had_transform_planes_fused")
     return planes
+
+
+def _vec_ok(t, dev):
+    _need(t is None or (t.dtype == torch.float16 and t.is_contiguous() and t.device == dev),
+          "vectors must be contiguous float16 on x's device")
+    return _ptr(t)
+
+
+def _had_transform_planes_group_cuda(x, n, K, had, transpose, pre, scale, rms_weight, rms_eps, gate):
+    xc = _chk_x(x)
+    count = len(pre)
+    _need(xc.shape[0] == 1, "had_transform_planes_group is the bs=1 path (one row)")
+    _need(1 <= count <= capi.MAX_GROUP and len(had) == count and len(scale) == count, "group of 1..3 problems")
+    _need(gate is None or gate.shape == xc.shape, "gate must have x's shape")
+    L = capi.lib()
+    nbytes = L.quip_e8p_planes_bytes(n)
+    outs = [torch.empty(nbytes, dtype=torch.uint8, device=x.device) for _ in range(count)]
+    arr = (capi.HadProblem * count)()
+    for i in range(count):
+        arr[i] = capi.HadProblem(xc.data_ptr(), outs[i].data_ptr(), _vec_ok(had[i], x.device), _vec_ok(pre[i], x.device),
+                                 None, None, None, None, _vec_ok(rms_weight, x.device), _vec_ok(gate, x.device),
+                                 xc.shape[1], n, float(scale[i]), float(rms_eps))
+    with torch.cuda.device(x.device):
+        capi.check(L.quip_had_transform_planes_group(arr, count, n, K, int(bool(transpose)), _stream(x)),
+                   "quip_had_transform_planes_group")
+    return outs
+
+
+def _had_transform_group_cuda(x, out_features, n, K, had, transpose, pre2, post, bias, scale, residual):
+    count = len(x)
+    _need(1 <= count <= capi.MAX_GROUP and all(len(v) == count for v in (out_features, had, pre2, post, bias, scale,
+                                                                          residual)), "group of 1..3 problems")
+    xs = [_chk_x(t) for t in x]
+    rows = xs[0].shape[0]
+    _need(all(t.shape == xs[0].shape and t.device == xs[0].device for t in xs), "group inputs must share a shape")
+    dev = xs[0].device
+    outs = [torch.empty((rows, int(o)), dtype=torch.float16, device=dev) for o in out_features]
+    arr = (capi.HadProblem * count)()
+    for i in range(count):
+        _need(residual[i] is None or tuple(residual[i].shape) == tuple(outs[i].shape), "residual shape")
+        arr[i] = capi.HadProblem(xs[i].data_ptr(), outs[i].data_ptr(), _vec_ok(had[i], dev), None, _vec_ok(pre2[i], dev),
+                                 _vec_ok(post[i], dev), _vec_ok(bias[i], dev), _vec_ok(residual[i], dev), None, None,
+                                 xs[i].shape[1], int(out_features[i]), float(scale[i]), 1e-5)
+    with torch.cuda.device(dev):
+        capi.check(capi.lib().quip_had_transform_group_f16(arr, count, rows, n, K, int(bool(transpose)), _stream(xs[0])),
+                   "quip_had_transform_group_f16")
+    return outs
+
+
+def _e8p_gemv_planes_group_cuda(planes, Qidxs, grid):
+    import ctypes
+    count = len(planes)
+    _need(1 <= count <= capi.MAX_GROUP and len(Qidxs) == count, "group of 1..3 problems")
+    k = Qidxs[0].shape[1] * 8
+    dev = planes[0].device
+    for pl, q in zip(planes, Qidxs):
+        _need(q.dtype == torch.int16 and q.is_contiguous() and q.shape[1] * 8 == k and q.device == dev,
+              "Qidxs must be contiguous int16 (n, k/8) with a common k")
+        _need(pl.dtype == torch.uint8 and pl.is_contiguous() and pl.device == dev, "planes must be uint8")
+    outs = [torch.empty((1, q.shape[0]), dtype=torch.float16, device=dev) for q in Qidxs]
+    vp = ctypes.c_void_p * count
+    ns = (ctypes.c_int32 * count)(*[q.shape[0] for q in Qidxs])
+    with torch.cuda.device(dev):
+        capi.check(capi.lib().quip_e8p_gemv_planes_group(
+            vp(*[p.data_ptr() for p in planes]), vp(*[q.data_ptr() for q in Qidxs]), grid.data_ptr(),
+            vp(*[o.data_ptr() for o in outs]), ns, count, k, _stream(planes[0])), "quip_e8p_gemv_planes_group")
+    return outs
 
 
 def _rope_attn_decode_cuda(q, k, v, cos, sin, pos, kcache, vcache):
@@ -319,6 +393,9 @@ _IMPLS = {
     "had_transform_planes": _had_transform_planes_cuda,
     "e8p_gemv_planes": _e8p_gemv_planes_cuda,
     "rope_attn_decode": _rope_attn_decode_cuda,
+    "had_transform_planes_group": _had_transform_planes_group_cuda,
+    "had_transform_group": _had_transform_group_cuda,
+    "e8p_gemv_planes_group": _e8p_gemv_planes_group_cuda,
     "had_transform_fused": _had_transform_fused_cuda,
     "had_transform_planes_fused": _had_transform_planes_fused_cuda,
     "e8p_mm_origorder": _e8p_mm_cuda,
@@ -354,6 +431,12 @@ _reg_fake("had_transform_fused", lambda x, out_features, n, K, had, transpose, p
           rms_weight, rms_eps, gate: x.new_empty((x.shape[0], out_features)))
 _reg_fake("had_transform_planes_fused", lambda x, n, K, had, transpose, pre, scale, rms_weight, rms_eps, gate:
           x.new_empty((3 * ((n + 511) // 512 * 512) + 16,), dtype=torch.uint8))
+_reg_fake("had_transform_planes_group", lambda x, n, K, had, transpose, pre, scale, rms_weight, rms_eps, gate:
+          [x.new_empty((3 * ((n + 511) // 512 * 512) + 16,), dtype=torch.uint8) for _ in pre])
+_reg_fake("had_transform_group", lambda x, out_features, n, K, had, transpose, pre2, post, bias, scale, residual:
+          [t.new_empty((t.shape[0], int(o))) for t, o in zip(x, out_features)])
+_reg_fake("e8p_gemv_planes_group", lambda planes, Qidxs, grid:
+          [p.new_empty((1, q.shape[0]), dtype=torch.float16) for p, q in zip(planes, Qidxs)])
 _reg_fake("rope_attn_decode", lambda q, k, v, cos, sin, pos, kcache, vcache: torch.empty_like(q))
 _reg_fake("e8p_gemv_planes", lambda planes, Q, g: Q.new_empty((1, Q.shape[0]), dtype=torch.float16))
 for _n in ("e8p_mm_origorder", "e8prvq3_mm_origorder", "e8prvq4_mm_origorder", "d4_mm_origorder",

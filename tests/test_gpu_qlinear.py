@@ -151,3 +151,26 @@ def test_forward_fused_glue(cbid, fin, fout, M):
     r2 = O.qlinear_forward(P, xs, "exact", What) + res.astype(np.float64)
     assert np.all(np.abs(y1 - r1) <= O.parity_bound(P, xn, What)), np.abs(y1 - r1).max()
     assert np.all(np.abs(y2 - r2) <= O.parity_bound(P, xs, What) + 2.0 ** -10 * np.abs(r2)), np.abs(y2 - r2).max()
+
+
+@pytest.mark.parametrize("fin,fouts", [(4096, (4096, 4096, 4096)), (4096, (11008, 11008)), (8192, (8192, 1024, 1024)),
+                                       (1408, (512, 256)), (11008, (4096, 4096)), (4096, (4096,)),
+                                       (8192, (28672, 28672))])
+def test_forward_group_equals_single_calls(fin, fouts):
+    """grouped launches (q/k/v, gate/up) give exactly what the modules give one by one"""
+    from quip_for_all_amd.qlinear import forward_group
+    layers = [_layer(O.make_layer("E8P12", fin, fo, seed=fin + fo + i)) for i, fo in enumerate(fouts)]
+    rng = np.random.default_rng(fin)
+    x = torch.from_numpy(rng.standard_normal((1, fin)).astype(np.float16)).to(DEV)
+    w = torch.from_numpy((1 + 0.1 * rng.standard_normal(fin)).astype(np.float16)).to(DEV)
+    res = [torch.from_numpy(rng.standard_normal((1, fo)).astype(np.float16)).to(DEV) for fo in fouts]
+    with torch.no_grad():
+        for kw in ({}, {"rms_weight": w}):
+            single = [l.forward_fused(x, **kw) for l in layers]
+            group = forward_group(layers, x, **kw)
+            for a, b in zip(single, group):
+                assert torch.equal(a, b)
+        single = [l.forward_fused(x, residual=r) for l, r in zip(layers, res)]
+        group = forward_group(layers, x, residual=res)
+        for a, b in zip(single, group):
+            assert torch.equal(a, b)
