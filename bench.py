@@ -10,9 +10,9 @@ layers are E8P12 2-bit QuantLinear (BASELINE.json configs[1]), on N GPUs of one 
 * multi-GPU = independent replicas (the Hadamard transform precludes tensor parallelism, SURVEY
   8e): every rank decodes its own sequence, no data-path collective; value = all ranks' tokens /
   max-over-ranks time; scaling "weak";
-* `roofline`: the dominant kernel is the E8P12 decode GEMV.  Its launches are timed live with HIP
-  events on the launch stream (graph of the model's own per-layer weights, so every launch
-  streams different HBM bytes); achieved = algorithmic bytes (Qidxs + x + y) / mean
+* `roofline`: the dominant kernel is the E8P12 decode GEMV.  Its launches (4 per decoder block:
+  q/k/v group, o, gate/up group, down) are timed live with HIP events on the launch stream
+  (graph over the model's own per-layer weights, so every launch streams different HBM bytes); achieved = algorithmic bytes (Qidxs + x + y) / mean
   launch duration; peak = 8 TB/s.  `traffic` = measured HBM bytes per launch from the PMC pass
   committed under profiles/ (null when that file is absent);
 * `cpu_baseline`: the CPU oracle (a port of the reference semantics: the reference has no CPU
@@ -36,29 +36,36 @@ HBM_PEAK_GBPS = 8000.0
 
 
 def gemv_roofline(dec):
-    """live HIP-event timing of the GEMV launches of one decode step (all 224 of them, each on
-    its own layer's weights), bs=1 planes path"""
+    """live HIP-event timing of the GEMV launches of one decode step exactly as the decoder issues
+    them (per block: q/k/v group, o, gate/up group, down; each on its own layer's weights), bs=1
+    planes path, replayed from a hipGraph on the launch stream"""
     import quip_for_all_amd  # noqa: F401
     from quip_for_all_amd import capi
     L = capi.lib()
     dev = dec.dev
-    calls = []     # (planes, Qidxs, grid, y, n, k)
+    op = torch.ops.quip_lib
+    calls = []     # ([planes], [Qidxs], grid)
+    algo = 0
     for layer in dec.layers:
-        for name in ("q", "k", "v", "o", "gate", "up", "down"):
-            m = layer[name]
-            n, k = m.q_out_features, m.q_in_features
-            x = torch.randn(1, k, device=dev).half()
-            planes = torch.empty(L.quip_e8p_planes_bytes(k), dtype=torch.uint8, device=dev)
-            capi.check(L.quip_e8p_x_to_planes(x.data_ptr(), planes.data_ptr(), k,
-                                              torch.cuda.current_stream().cuda_stream), "x_to_planes")
-            y = torch.empty(1, n, dtype=torch.float16, device=dev)
-            calls.append((planes, m.Qidxs, m.codebook.grid_packed_abs, y, n, k))
+        for names in (("q", "k", "v"), ("o",), ("gate", "up"), ("down",)):
+            ms = [layer[n] for n in names]
+            k = ms[0].q_in_features
+            planes = []
+            for m in ms:
+                x = torch.randn(1, k, device=dev).half()
+                pl = torch.empty(L.quip_e8p_planes_bytes(k), dtype=torch.uint8, device=dev)
+                capi.check(L.quip_e8p_x_to_planes(x.data_ptr(), pl.data_ptr(), k,
+                                                  torch.cuda.current_stream().cuda_stream), "x_to_planes")
+                planes.append(pl)
+                algo += m.q_out_features * k // 4 + 2 * k + 2 * m.q_out_features
+            calls.append((planes, [m.Qidxs for m in ms], ms[0].codebook.grid_packed_abs))
 
     def run():
-        st = torch.cuda.current_stream().cuda_stream
-        for (planes, Q, g, y, n, k) in calls:
-            capi.check(L.quip_e8p_gemv_planes(planes.data_ptr(), Q.data_ptr(), g.data_ptr(), y.data_ptr(), n, k, st),
-                       "gemv")
+        for planes, Qs, g in calls:
+            if len(planes) == 1:
+                op.e8p_gemv_planes(planes[0], Qs[0], g)
+            else:
+                op.e8p_gemv_planes_group(planes, Qs, g)
     run()
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
@@ -76,7 +83,6 @@ def gemv_roofline(dec):
         torch.cuda.synchronize()
         ts.append(a.elapsed_time(b) * 1e-3)
     t = float(np.median(ts[1:]))
-    algo = sum(n * k // 4 + 2 * k + 2 * n for (_, _, _, _, n, k) in calls)
     per_launch_bytes = algo / len(calls)
     per_launch_s = t / len(calls)
     achieved = per_launch_bytes / per_launch_s / 1e9
@@ -115,6 +121,39 @@ def cpu_baseline(budget_s=25.0):
                       "%.0f s of CPU work" % (threads, json.dumps(detail), lm * 1e3, time.time() - t_start)}
 
 
+def max_over_ranks(dist, dt, device):
+    """the job's step time is the slowest replica's"""
+    if dist is None:
+        return dt
+    tt = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
+
+
+def aggregate_tokens_per_s(world, steps, dt):
+    """whole-job throughput of `world` independent replicas that each decoded `steps` tokens"""
+    return world * steps / dt
+
+
+def dist_selftest(a, rank, world):
+    """replica plumbing only, no GPU: every rank "decodes" for a rank-dependent synthetic time"""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    dt = 0.001 * a.steps * (rank + 1)          # rank r needs (r + 1) ms per token
+    dt = max_over_ranks(dist if world > 1 else None, dt, "cpu")
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "steps": a.steps,
+                          "value": round(aggregate_tokens_per_s(world, a.steps, dt), 4),
+                          "ms_per_step": round(dt / a.steps * 1e3, 4), "scaling": "weak"}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,11 +162,16 @@ def main():
     ap.add_argument("--model", default="7b", choices=["7b", "70b", "tiny"])
     ap.add_argument("--codebook", default="E8P12")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-selftest", action="store_true",
+                    help="exercise only the replica plumbing (rendezvous, barrier, max-over-ranks, rank-0 line) "
+                         "with a synthetic per-rank time; runs on CPU with gloo (tests/test_bench_replicas.py)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.dist_selftest:
+        return dist_selftest(a, rank, world)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback of the hot path)"
     torch.cuda.set_device(local_rank)
     dist = None
@@ -162,13 +206,10 @@ def main():
             dec.graph.replay()
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(dist, dt, f"cuda:{local_rank}")
 
     if rank == 0:
-        tok_s = world * a.steps / dt
+        tok_s = aggregate_tokens_per_s(world, a.steps, dt)
         algo_bytes = dec.algorithmic_bytes_per_token()
         out = {
             "metric": METRIC, "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": a.steps,

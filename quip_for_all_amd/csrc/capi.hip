@@ -227,6 +227,17 @@ int quip_e8p_gemv_tuned(const void* x, const void* qidxs, const void* grid, void
   return e8p_gemv_i8_launch(x, kernel == 3 ? 1 : 0, qidxs, grid, y, n, k, t, (hipStream_t)stream);
 }
 
+int quip_e8p_gemv_group_tuned(const void* const* planes, const void* const* qidxs, const void* grid,
+                              void* const* ys, const int32_t* ns, int32_t count, int32_t k, int32_t rep,
+                              int32_t rows, int32_t blocks, int32_t max_waves, void* dbg,
+                              quip_stream_t stream) {
+  GemvTune t;
+  t.rep = rep; t.rows = rows; t.blocks = blocks; t.max_waves = max_waves; t.dbg = dbg;
+  int n32[QUIP_MAX_GROUP];
+  for (int i = 0; i < count && i < QUIP_MAX_GROUP; ++i) n32[i] = ns[i];
+  return e8p_gemv_mfma_group_launch(planes, qidxs, grid, ys, n32, count, k, t, (hipStream_t)stream);
+}
+
 int quip_e8prvq3_mm_origorder(const void* x, const void* qidxs, const void* grid,
                               const void* grid2, float scale, void* y, int32_t m, int32_t n,
                               int32_t k, quip_stream_t stream) {

@@ -199,7 +199,10 @@ struct GemvGroup {
   int rpb[G];
 };
 
-template <int REP, int SLOTS, int MAXT, int G>
+// ONESHOT: the workgroup has at most SLOTS * nwaves items, so every wave requests all of its
+// items up front and never reloads a slot (decode shapes of a 7B model: 8..48 items per
+// workgroup); otherwise slots are reloaded in place while the stream lasts.
+template <int REP, int SLOTS, int MAXT, int G, bool ONESHOT>
 __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
     GemvGroup<G> gp, const uint64_t* __restrict__ grid, int K, int Kp, uint64_t* __restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -232,13 +235,19 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
     for (int i = 1; i < G; ++i) p += it >= cbase[i] ? 1 : 0;
     return p;
   };
+  // arr[p] for a wave-uniform p without ever indexing dynamically: a select chain the optimiser
+  // recognises as arr[p] would put the array in scratch memory, and scratch accesses are VMEM
+  // operations that would corrupt the hand-counted vmcnt waits below.  The empty asm keeps each
+  // step opaque (and in an SGPR).
   auto pick = [&](const int* arr, int p) -> int {
     int v = arr[0];
 #pragma unroll
-    for (int i = 1; i < G; ++i) v = p == i ? arr[i] : v;
+    for (int i = 1; i < G; ++i) {
+      v = p == i ? arr[i] : v;
+      asm volatile("" : "+s"(v));
+    }
     return v;
   };
-
   // lanes outside the matrix read a valid (clamped) address
   // and are neutralised by zero x digits (k padding) / never-read rows
   // Load j (0, 1) of lane (n, q) reads bytes [64 j + 16 q, +16) of row n's 128-byte slice line, so
@@ -252,7 +261,10 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
     const int N = pick(gp.N, p);
     const uint4* W = gp.W[0];
 #pragma unroll
-    for (int i = 1; i < G; ++i) W = p == i ? gp.W[i] : W;
+    for (int i = 1; i < G; ++i) {
+      W = p == i ? gp.W[i] : W;
+      asm volatile("" : "+s"(W));
+    }
     int row = pick(row0, p) + rb * 16 + n;
     row = row < N ? row : N - 1;
     int off = s * 8 + q + 4 * j;  // uint4 units inside the row
@@ -273,9 +285,12 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
     int p = 0;
 #pragma unroll
     for (int g = 1; g < G; ++g) p += ic >= g * ppieces ? 1 : 0;
-    const uint8_t* src = gp.planes[0];
+    const uint8_t* src = gp.planes[0];   // per-lane choice (pieces of several problems in one wave)
 #pragma unroll
-    for (int g = 1; g < G; ++g) src = p == g ? gp.planes[g] : src;
+    for (int g = 1; g < G; ++g) {
+      src = p == g ? gp.planes[g] : src;
+      asm volatile("" : "+v"(src));
+    }
     asm_load16(xr[j], reinterpret_cast<const uint4*>(src) + (ic - p * ppieces));
   }
   // past-the-end reloads read the L2-resident x planes (each lane its own 32 bytes)
@@ -336,24 +351,48 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
   //     LDS addresses; once a wave has no further item the reload reads a hot L2 line (the
   //     x planes) instead, so the VMEM queue always holds exactly 2 * SLOTS loads in
   //     slot order and "slot i has landed" == vmcnt(2 * (SLOTS - 1)) throughout.
-  for (int it = wave; it < cnt; it += SLOTS * nwaves) {
+  if constexpr (ONESHOT) {
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
-      const int cur = it + i * nwaves;
-      asm_wait_vmcnt<2 * (SLOTS - 1)>(qa[i], qb[i]);
-      ItemAddr ad;
-      item_addresses<REP>(qa[i], qb[i], lane_c, lane_c2, ad);
-      // the slot's codes are consumed: pin the addresses, then reload the slot in place
-#pragma unroll
-      for (int t = 0; t < 8; ++t)
-        asm volatile("" : "+v"(ad.a1l[t]), "+v"(ad.a2l[t]), "+v"(ad.a1h[t]), "+v"(ad.a2h[t]));
-      const int nxt = cur + SLOTS * nwaves;
-      const bool real = nxt < cnt;
-      asm_load16_nt(qa[i], real ? item_ptr(nxt, 0) : hot);
-      asm_load16_nt(qb[i], real ? item_ptr(nxt, 1) : hot + 1);
-      if (cur < cnt) run_item(cur, ad);   // wave-uniform
+      const int cur = wave + i * nwaves;
+      switch (SLOTS - 1 - i) {   // folds after unrolling: loads of slots > i may still be in flight
+        case 0: asm_wait_vmcnt<0>(qa[i], qb[i]); break;
+        case 1: asm_wait_vmcnt<2>(qa[i], qb[i]); break;
+        case 2: asm_wait_vmcnt<4>(qa[i], qb[i]); break;
+        case 3: asm_wait_vmcnt<6>(qa[i], qb[i]); break;
+        case 4: asm_wait_vmcnt<8>(qa[i], qb[i]); break;
+        case 5: asm_wait_vmcnt<10>(qa[i], qb[i]); break;
+        case 6: asm_wait_vmcnt<12>(qa[i], qb[i]); break;
+        default: asm_wait_vmcnt<14>(qa[i], qb[i]); break;
+      }
+      if (cur < cnt) {   // wave-uniform
+        ItemAddr ad;
+        item_addresses<REP>(qa[i], qb[i], lane_c, lane_c2, ad);
+        run_item(cur, ad);
+      }
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    for (int it = wave; it < cnt; it += SLOTS * nwaves) {
+#pragma unroll
+      for (int i = 0; i < SLOTS; ++i) {
+        const int cur = it + i * nwaves;
+        asm_wait_vmcnt<2 * (SLOTS - 1)>(qa[i], qb[i]);
+        ItemAddr ad;
+        item_addresses<REP>(qa[i], qb[i], lane_c, lane_c2, ad);
+        // the slot's codes are consumed: pin the addresses, then reload the slot in place
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          asm volatile("" : "+v"(ad.a1l[t]), "+v"(ad.a2l[t]), "+v"(ad.a1h[t]), "+v"(ad.a2h[t]));
+        const int nxt = cur + SLOTS * nwaves;
+        const bool real = nxt < cnt;
+        asm_load16_nt(qa[i], real ? item_ptr(nxt, 0) : hot);
+        asm_load16_nt(qb[i], real ? item_ptr(nxt, 1) : hot + 1);
+        if (cur < cnt) run_item(cur, ad);   // wave-uniform
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the trailing hot-line reloads
@@ -375,10 +414,10 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
 #undef QUIP_STAMP
 }
 
-template <int REP, int SLOTS, int MAXT, int G>
+template <int REP, int SLOTS, int MAXT, int G, bool ONESHOT = false>
 int launch(const GemvGroup<G>& gp, const void* grid, int k, int kp, int nblocks, int threads, uint64_t* dbg,
            hipStream_t stream) {
-  auto kern = e8p_gemv_mfma_kernel<REP, SLOTS, MAXT, G>;
+  auto kern = e8p_gemv_mfma_kernel<REP, SLOTS, MAXT, G, ONESHOT>;
   const int lds = Lds<REP>::bytes(kp, G);
   static int configured = 0;  // benign race: idempotent attribute
   if (lds > configured) {
@@ -540,6 +579,19 @@ int pattern_probe_launch(const void* qidxs, void* out, int n, int k, const GemvT
   return go(pattern_probe_kernel<4>);
 }
 
+// one-shot regime: all items of a wave in flight at once (SLOTS = items per wave, rounded up)
+template <int G>
+static int launch_oneshot(const GemvGroup<G>& gp, const void* grid, int k, int kp, int nblocks, int threads,
+                          int rep, int items_per_wave, uint64_t* dbg, hipStream_t stream) {
+#define QUIP_ONE(R, S)                                                              \
+  if (rep == R && items_per_wave <= S)                                              \
+    return launch<R, S, 512, G, true>(gp, grid, k, kp, nblocks, threads, dbg, stream);
+  QUIP_ONE(32, 1) QUIP_ONE(32, 2) QUIP_ONE(32, 3) QUIP_ONE(32, 4) QUIP_ONE(32, 6) QUIP_ONE(32, 8)
+  QUIP_ONE(16, 1) QUIP_ONE(16, 2) QUIP_ONE(16, 3) QUIP_ONE(16, 4) QUIP_ONE(16, 6) QUIP_ONE(16, 8)
+#undef QUIP_ONE
+  return QUIP_ERR_UNSUPPORTED;
+}
+
 int e8p_gemv_mfma_launch(const void* planes, const void* qidxs, const void* grid, void* y, int n, int k,
                          const GemvTune& tune, hipStream_t stream) {
   if (!e8p_gemv_mfma_supported(n, k)) return QUIP_ERR_UNSUPPORTED;
@@ -561,16 +613,24 @@ int e8p_gemv_mfma_launch(const void* planes, const void* qidxs, const void* grid
   const int items_per_wave = (((rpb + 15) >> 4) * (kp >> 9) + waves - 1) / waves;
   int slots = tune.rows ? tune.rows : (items_per_wave >= 4 ? 2 : 1);
   const int threads = waves * 64;
-  if (threads > 512 && slots > 4) slots = 4;  // 128-VGPR budget: deeper queues would spill
+  if (threads > 512 && slots > 3) slots = 3;  // 128-VGPR budget: deeper queues would spill, and
+                                              // scratch traffic would corrupt the counted vmcnt waits
   GemvGroup<1> gp{{reinterpret_cast<const uint4*>(qidxs)}, {reinterpret_cast<const uint8_t*>(planes)},
                   {reinterpret_cast<f16*>(y)}, {n}, {rpb}};
+  if (!tune.rows && threads <= 512 && items_per_wave <= 8)
+    return launch_oneshot<1>(gp, grid, k, kp, nblocks, threads, rep, items_per_wave, dbg, stream);
 #define QUIP_CASE(R, S)                                                                        \
-  if (rep == R && slots == S)                                                                  \
-    return threads > 512 ? launch<R, S, 1024, 1>(gp, grid, k, kp, nblocks, threads, dbg, stream) \
-                         : launch<R, S, 512, 1>(gp, grid, k, kp, nblocks, threads, dbg, stream);
+  if (rep == R && slots == S && threads <= 512)                                                \
+    return launch<R, S, 512, 1>(gp, grid, k, kp, nblocks, threads, dbg, stream);
+#define QUIP_CASE_BIG(R, S)                                                                    \
+  if (rep == R && slots == S && threads > 512)                                                 \
+    return launch<R, S, 1024, 1>(gp, grid, k, kp, nblocks, threads, dbg, stream);
   QUIP_CASE(32, 1) QUIP_CASE(32, 2) QUIP_CASE(32, 3) QUIP_CASE(32, 4) QUIP_CASE(32, 6) QUIP_CASE(32, 8)
   QUIP_CASE(16, 1) QUIP_CASE(16, 2) QUIP_CASE(16, 3) QUIP_CASE(16, 4) QUIP_CASE(16, 6) QUIP_CASE(16, 8)
+  QUIP_CASE_BIG(32, 1) QUIP_CASE_BIG(32, 2) QUIP_CASE_BIG(32, 3)
+  QUIP_CASE_BIG(16, 1) QUIP_CASE_BIG(16, 2) QUIP_CASE_BIG(16, 3)
 #undef QUIP_CASE
+#undef QUIP_CASE_BIG
   return QUIP_ERR_UNSUPPORTED;
 }
 
@@ -619,6 +679,8 @@ static int group_launch(const void* const* planes, const void* const* qidxs, con
   const int slots = tune.rows ? (tune.rows >= 2 ? 2 : 1) : ((items + waves - 1) / waves >= 4 ? 2 : 1);
   const int threads = waves * 64;
   uint64_t* dbg = reinterpret_cast<uint64_t*>(tune.dbg);
+  if (!tune.rows && threads <= 512 && (items + waves - 1) / waves <= 8)
+    return launch_oneshot<G>(gp, grid, k, kp, nblocks, threads, rep, (items + waves - 1) / waves, dbg, stream);
 #define QUIP_CASE(R, S)                                                                        \
   if (rep == R && slots == S)                                                                  \
     return threads > 512 ? launch<R, S, 1024, G>(gp, grid, k, kp, nblocks, threads, dbg, stream) \
