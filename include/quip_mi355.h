@@ -196,6 +196,32 @@ int quip_e8p_gemv_planes_group(const void* const* planes, const void* const* qid
                                const void* grid_packed_abs, void* const* ys, const int32_t* ns,
                                int32_t count, int32_t k, quip_stream_t stream);
 
+/* ---- GEMV with the input side of the layer(s) computed in its prologue (bs = 1, K_left == 1) ----
+ * For `count` (1..3) E8P12 modules reading the same activation of width k (a power of two,
+ * 1024..8192, in_features == q_in_features == k):
+ *   h        = z ? post (.) (z_scale * H_k z) + residual : x        (z: the PRODUCER module's GEMV
+ *              output whose output transform qlinear.py:108-114 is thereby folded in; h is also
+ *              stored to h_out)
+ *   ys[i]    = W_i . ( scale[i] * rms(h) * H_k (h (.) rms_weight (.) pre_scale[i]) )   [ns[i]]
+ * i.e. qlinear.py:90-100 + e8p12.py:147-150 of every module, with the decoder block's RMSNorm in
+ * front, in ONE launch.  ys are the raw GEMV outputs (before the modules' own output transform).
+ * Bit identical to quip_had_transform_fused_f16 -> quip_had_transform_planes_group ->
+ * quip_e8p_gemv_planes_group.  QUIP_ERR_UNSUPPORTED when the shape does not qualify. */
+typedef struct quip_gemv_fused_in {
+  const void* x;           /* fp16 [k] (used when z == NULL) */
+  const void* z;           /* fp16 [k] or NULL */
+  const void* post_scale;  /* fp16 [k]: producer's SV (z != NULL) */
+  const void* residual;    /* fp16 [k] or NULL */
+  void* h_out;             /* fp16 [k] (z != NULL), must not alias residual */
+  const void* rms_weight;  /* fp16 [k] or NULL */
+  const void* pre_scale[QUIP_MAX_GROUP];   /* SU of every module */
+  float scale[QUIP_MAX_GROUP];             /* wscale_float / sqrt(k) of every module */
+  float z_scale, rms_eps;
+} quip_gemv_fused_in;
+int quip_e8p_gemv_fused(const quip_gemv_fused_in* in, const void* const* qidxs,
+                        const void* grid_packed_abs, void* const* ys, const int32_t* ns,
+                        int32_t count, int32_t k, quip_stream_t stream);
+
 /* ---- decode-step glue between q/k/v_proj and o_proj (bs = 1) -------------------------------
  * Rotary embedding of q and k at position *pos, append of (k, v) to the static KV cache and
  * single-query softmax attention over positions [0, *pos], one launch.  Replaces, for the

@@ -22,6 +22,7 @@ SIGNATURES = {
     "quip_had_transform_group_f16": [_P, _I32, _I64, _I32, _I32, _I32, _P],
     "quip_had_transform_planes_group": [_P, _I32, _I32, _I32, _I32, _P],
     "quip_e8p_gemv_planes_group": [_P, _P, _P, _P, _P, _I32, _I32, _P],
+    "quip_e8p_gemv_fused": [_P, _P, _P, _P, _P, _I32, _I32, _P],
     "quip_rope_attn_decode_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _P],
     "quip_e8p_mm_origorder": [_P, _P, _P, _P, _I32, _I32, _I32, _P],
     "quip_e8p_mm_workspace_bytes": [_I32, _I32, _I32],
@@ -54,6 +55,12 @@ class HadProblem(_c.Structure):
 
 
 MAX_GROUP = 3
+
+
+class GemvFusedIn(_c.Structure):
+    """mirror of quip_gemv_fused_in (include/quip_mi355.h)"""
+    _fields_ = [("x", _P), ("z", _P), ("post_scale", _P), ("residual", _P), ("h_out", _P), ("rms_weight", _P),
+                ("pre_scale", _P * 3), ("scale", _F * 3), ("z_scale", _F), ("rms_eps", _F)]
 
 
 class HadFusion(_c.Structure):

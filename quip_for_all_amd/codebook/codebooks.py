@@ -60,6 +60,14 @@ class E8P12_codebook(_Codebook):
         kp = (q_in + 511) // 512 * 512
         return 1 <= len(q_outs) <= 3 and len(q_outs) * kp <= 31232
 
+    @staticmethod
+    def fused_supported(count, q_in):
+        """GEMV with the input transform in its prologue (csrc/e8p_gemv_mfma.hip, FusedIn): k a power
+        of two in 1024..8192, tables + count x planes + the transform buffer within 160 KB of LDS"""
+        pow2 = q_in & (q_in - 1) == 0
+        lds = 2 * 256 * 16 * 8 + 256 * 16 + 3 * q_in * count + (q_in + q_in // 32 + 4 + 16) * 4
+        return 1 <= count <= 3 and pow2 and 1024 <= q_in <= 8192 and lds <= 160 * 1024
+
     def mm_planes(self, planes, Qidxs):
         """bs=1 product with x given as int8 digit planes (quip_lib::had_transform_planes)"""
         return torch.ops.quip_lib.e8p_gemv_planes(planes, Qidxs, self.grid_packed_abs)

@@ -148,6 +148,32 @@ int quip_e8p_gemv_planes_group(const void* const* planes, const void* const* qid
                                     (hipStream_t)stream);
 }
 
+int quip_e8p_gemv_fused(const quip_gemv_fused_in* in, const void* const* qidxs,
+                        const void* grid_packed_abs, void* const* ys, const int32_t* ns,
+                        int32_t count, int32_t k, quip_stream_t stream) {
+  if (!in || !qidxs || !grid_packed_abs || !ys || !ns) return QUIP_ERR_NULL_POINTER;
+  if (count < 1 || count > QUIP_MAX_GROUP) return QUIP_ERR_BAD_SHAPE;
+  GemvFusedIn f;
+  f.x = in->x; f.z = in->z; f.post = in->post_scale; f.residual = in->residual; f.h_out = in->h_out;
+  f.rms_w = in->rms_weight; f.z_scale = in->z_scale; f.rms_eps = in->rms_eps;
+  if (!f.z && !f.x) return QUIP_ERR_NULL_POINTER;
+  if (f.z && (!f.post || !f.h_out)) return QUIP_ERR_NULL_POINTER;
+  if (f.z && f.h_out == f.residual) return QUIP_ERR_BAD_SHAPE;
+  if (!aligned16(f.x) || !aligned16(f.z) || !aligned16(f.post) || !aligned16(f.residual) || !aligned16(f.h_out) ||
+      !aligned16(f.rms_w))
+    return QUIP_ERR_MISALIGNED;
+  int n32[QUIP_MAX_GROUP];
+  for (int i = 0; i < count; ++i) {
+    if (!qidxs[i] || !ys[i] || !in->pre_scale[i]) return QUIP_ERR_NULL_POINTER;
+    if (!aligned16(qidxs[i]) || !aligned16(in->pre_scale[i])) return QUIP_ERR_MISALIGNED;
+    if (ns[i] < 1) return QUIP_ERR_BAD_SHAPE;
+    f.pre[i] = in->pre_scale[i];
+    f.scale[i] = in->scale[i];
+    n32[i] = ns[i];
+  }
+  return e8p_gemv_mfma_fused_launch(f, qidxs, grid_packed_abs, ys, n32, count, k, GemvTune{}, (hipStream_t)stream);
+}
+
 int quip_rope_attn_decode_f16(const void* q, const void* k, const void* v, const float* cos,
                               const float* sin, const int64_t* pos, void* kcache, void* vcache,
                               void* out, int32_t heads, int32_t kv_heads, int32_t head_dim,

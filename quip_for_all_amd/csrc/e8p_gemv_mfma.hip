@@ -39,7 +39,7 @@
 //            same 16 rows.
 // LDS: T1/T2 with REP = 32 copies (ds_read_b64 conflict free, 128 KiB), x planes
 // (3 x 8 KiB), int32 accumulators [rows][4].
-#include "quip_device.hip.h"
+#include "had_device.hip.h"
 #include "quip_internal.h"
 
 namespace quip {
@@ -65,6 +65,8 @@ struct Lds {
   static constexpr int kX = kAcc + kMaxRowsPerBlock * 16;   // 3 planes x Kp bytes
   static constexpr int kMaxKp = (160 * 1024 - kX) / 3 / 512 * 512;
   static int bytes(int kp, int g = 1) { return kX + 3 * kp * g; }
+  // fused prologue: + the Hadamard shuffle buffer (fp32, padded) and 16 reduction words
+  static int bytes_fused(int kp, int g) { return kX + 3 * kp * g + (had::buf_floats(kp) + 16) * 4; }
 };
 static_assert(Lds<32>::kMaxKp >= 8192 && Lds<16>::kMaxKp >= 28672, "LDS budget");
 
@@ -199,12 +201,34 @@ struct GemvGroup {
   int rpb[G];
 };
 
+// Input side of the GEMV computed in the prologue instead of by separate launches (bs = 1 decode,
+// K_left == 1, n = k a power of two):
+//   z != null:  h = post (.) (z_scale * H_n z) + residual      (the producer's output transform,
+//               qlinear.py:108-114; workgroup 0 stores h to h_out, every workgroup keeps its copy)
+//   else:       h = x
+//   problem g:  planes_g = digits( scale[g] * rms(h) * H_n (h (.) rms_w (.) pre[g]) )
+//               (RMSNorm + SU + input transform, qlinear.py:90-100)
+// Every workgroup repeats the (tiny) transforms on its own: no extra launch, no extra HBM round
+// trip.  The arithmetic is had_device.hip.h's, bit identical to the stand-alone kernels.
+struct FusedIn {
+  const f16* x;
+  const f16* z;
+  const f16* post;
+  const f16* residual;
+  f16* h_out;
+  const f16* rms_w;
+  const f16* pre[3];
+  float scale[3];
+  float z_scale, rms_eps;
+  int n, logn;
+};
+
 // ONESHOT: the workgroup has at most SLOTS * nwaves items, so every wave requests all of its
 // items up front and never reloads a slot (decode shapes of a 7B model: 8..48 items per
 // workgroup); otherwise slots are reloaded in place while the stream lasts.
-template <int REP, int SLOTS, int MAXT, int G, bool ONESHOT>
+template <int REP, int SLOTS, int MAXT, int G, bool ONESHOT, bool FUSED>
 __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
-    GemvGroup<G> gp, const uint64_t* __restrict__ grid, int K, int Kp, uint64_t* __restrict__ dbg) {
+    GemvGroup<G> gp, FusedIn fi, const uint64_t* __restrict__ grid, int K, int Kp, uint64_t* __restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using L = Lds<REP>;
 #define QUIP_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -272,29 +296,57 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
     return W + (size_t)row * row_u4 + off;
   };
 
-  // (0) VMEM loads return in issue order: the x digit planes (L2 hits) are requested
-  //     before the (TLB-cold, HBM) weight loads, all through hand-counted asm loads.
+  // (0) VMEM loads return in issue order: the x digit planes (L2 hits) -- or, fused, the fp16
+  //     vectors the prologue transforms -- are requested before the (TLB-cold, HBM) weight
+  //     loads, all through hand-counted asm loads.
   constexpr int XR = 6;  // 16-byte x pieces per thread: needs nthreads >= G * 3 * Kp / 96
   const int ppieces = 3 * (Kp >> 4);       // pieces per problem
   const int xpieces = G * ppieces;
   u32x4 xr[XR];
+  // fused: thread t < n / 16 owns elements [16 t, 16 t + 16) = pieces 2 t, 2 t + 1 of every vector
+  const bool act = FUSED && tid < (fi.n >> 4);   // wave uniform (n % 1024 == 0)
+  u32x4 pin[2], ppost[2], pres[2], prms[2], ppre[G][2];
+  const uint4* hot;
+  if constexpr (FUSED) {
+    // Every thread issues every load unconditionally (threads past n / 16 re-read a valid piece,
+    // absent vectors fall back to the input vector): a load under a branch would make the
+    // compiler merge its destination with another value, i.e. copy a register whose load is
+    // still in flight.
+    const f16* in = fi.z ? fi.z : fi.x;
+    const int c = (tid & ((fi.n >> 4) - 1)) * 2;
+    const uint4* s_in = reinterpret_cast<const uint4*>(in) + c;
+    const uint4* s_post = reinterpret_cast<const uint4*>(fi.z ? fi.post : in) + c;
+    const uint4* s_res = reinterpret_cast<const uint4*>((fi.z && fi.residual) ? fi.residual : in) + c;
+    const uint4* s_rms = reinterpret_cast<const uint4*>(fi.rms_w ? fi.rms_w : in) + c;
 #pragma unroll
-  for (int j = 0; j < XR; ++j) {
-    const int i = tid + j * nthreads;
-    const int ic = i < xpieces ? i : 0;
-    int p = 0;
+    for (int h = 0; h < 2; ++h) {
+      asm_load16(pin[h], s_in + h);
+      asm_load16(ppost[h], s_post + h);
+      asm_load16(pres[h], s_res + h);
+      asm_load16(prms[h], s_rms + h);
 #pragma unroll
-    for (int g = 1; g < G; ++g) p += ic >= g * ppieces ? 1 : 0;
-    const uint8_t* src = gp.planes[0];   // per-lane choice (pieces of several problems in one wave)
-#pragma unroll
-    for (int g = 1; g < G; ++g) {
-      src = p == g ? gp.planes[g] : src;
-      asm volatile("" : "+v"(src));
+      for (int g = 0; g < G; ++g) asm_load16(ppre[g][h], reinterpret_cast<const uint4*>(fi.pre[g]) + c + h);
     }
-    asm_load16(xr[j], reinterpret_cast<const uint4*>(src) + (ic - p * ppieces));
+    hot = reinterpret_cast<const uint4*>(fi.z ? fi.z : fi.x) + (size_t)((tid * 2) % ((fi.n >> 3) - 1));
+  } else {
+#pragma unroll
+    for (int j = 0; j < XR; ++j) {
+      const int i = tid + j * nthreads;
+      const int ic = i < xpieces ? i : 0;
+      int p = 0;
+#pragma unroll
+      for (int g = 1; g < G; ++g) p += ic >= g * ppieces ? 1 : 0;
+      const uint8_t* src = gp.planes[0];   // per-lane choice (pieces of several problems in one wave)
+#pragma unroll
+      for (int g = 1; g < G; ++g) {
+        src = p == g ? gp.planes[g] : src;
+        asm volatile("" : "+v"(src));
+      }
+      asm_load16(xr[j], reinterpret_cast<const uint4*>(src) + (ic - p * ppieces));
+    }
+    // past-the-end reloads read the L2-resident x planes (each lane its own 32 bytes)
+    hot = reinterpret_cast<const uint4*>(gp.planes[0]) + (size_t)((tid * 2) % (ppieces - 1));
   }
-  // past-the-end reloads read the L2-resident x planes (each lane its own 32 bytes)
-  const uint4* hot = reinterpret_cast<const uint4*>(gp.planes[0]) + (size_t)((tid * 2) % (ppieces - 1));
   u32x4 qa[SLOTS], qb[SLOTS];
 #pragma unroll
   for (int i = 0; i < SLOTS; ++i) {
@@ -309,19 +361,90 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
   fill_tables<REP>(smem, grid, lane, wave, nwaves);
   for (int i = tid; i < kMaxRowsPerBlock * 4; i += nthreads) reinterpret_cast<int*>(smem + L::kAcc)[i] = 0;
   int sh[G];
+  if constexpr (!FUSED) {
 #pragma unroll
-  for (int p = 0; p < G; ++p) sh[p] = *reinterpret_cast<const int*>(gp.planes[p] + (size_t)3 * Kp);
+    for (int p = 0; p < G; ++p) sh[p] = *reinterpret_cast<const int*>(gp.planes[p] + (size_t)3 * Kp);
+  }
   QUIP_STAMP(2);
 
-  // (2) x digit planes into LDS once the 6 plane loads have landed (the 2 * SLOTS weight
-  //     loads behind them may still be in flight)
-  asm_wait_vmcnt_x<2 * SLOTS>(xr[0], xr[1], xr[2], xr[3], xr[4], xr[5]);
+  if constexpr (FUSED) {
+    // (2f) the input side of the layer, computed here (see FusedIn).  All vector loads of the
+    //      prologue are older than the weight loads: "at most 2 * SLOTS outstanding" == landed.
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * SLOTS) : "memory");
 #pragma unroll
-  for (int j = 0; j < XR; ++j) {
-    const int i = tid + j * nthreads;
-    if (i < xpieces) *reinterpret_cast<u32x4*>(smem + L::kX + i * 16) = xr[j];
+    for (int h = 0; h < 2; ++h) {
+      asm volatile("" : "+v"(pin[h]), "+v"(ppost[h]), "+v"(pres[h]), "+v"(prms[h]));
+#pragma unroll
+      for (int g = 0; g < G; ++g) asm volatile("" : "+v"(ppre[g][h]));
+    }
+    auto as4 = [](const u32x4& v) { return make_uint4(v.x, v.y, v.z, v.w); };
+    float* buf = reinterpret_cast<float*>(smem + L::kX + G * 3 * Kp);
+    float* red = buf + had::buf_floats(Kp);
+    const int nfht = fi.n >> 4;
+    float xf[16];
+    had::unpack8(as4(pin[0]), xf);
+    had::unpack8(as4(pin[1]), xf + 8);
+    if (fi.z) {
+      had::fht16(xf, buf, tid, fi.logn, act);
+      float tp[16], tr[16];
+      had::unpack8(as4(ppost[0]), tp);
+      had::unpack8(as4(ppost[1]), tp + 8);
+      had::unpack8(as4(pres[0]), tr);
+      had::unpack8(as4(pres[1]), tr + 8);
+      f16 o[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        o[r] = had::out_elem(xf[r], fi.z_scale, true, tp[r], false, 0.f, fi.residual != nullptr, tr[r]);
+      if (act && blockIdx.x == 0) {
+        uint4* dst = reinterpret_cast<uint4*>(fi.h_out + tid * 16);
+        dst[0] = *reinterpret_cast<uint4*>(&o[0]);
+        dst[1] = *reinterpret_cast<uint4*>(&o[8]);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xf[r] = (float)o[r];
+    }
+    float tot = 0.f;
+    if (fi.rms_w) {
+      float ss = 0.f;
+      had::sumsq8(xf, ss);
+      had::sumsq8(xf + 8, ss);
+      tot = had::block_reduce(act ? ss : 0.f, false, red, tid, nfht);
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float e[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) e[r] = xf[r];
+      if (fi.rms_w) {
+        had::mul8(e, as4(prms[0]));
+        had::mul8(e + 8, as4(prms[1]));
+      }
+      had::mul8(e, as4(ppre[g][0]));
+      had::mul8(e + 8, as4(ppre[g][1]));
+      const float scale = fi.rms_w ? had::rms_scale(fi.scale[g], tot, fi.n, fi.rms_eps) : fi.scale[g];
+      had::fht16(e, buf, tid, fi.logn, act);
+      const float bound = had::block_reduce(act ? had::absmax16(e, scale) : 0.f, true, red, tid, nfht);
+      sh[g] = had::shift_for(bound);
+      uint4 dg[3];
+      had::planes16(e, scale, sh[g], dg);
+      if (act) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+          *reinterpret_cast<uint4*>(smem + L::kX + (g * 3 + d) * Kp + tid * 16) = dg[d];
+      }
+    }
+    __syncthreads();
+  } else {
+    // (2) x digit planes into LDS once the 6 plane loads have landed (the 2 * SLOTS weight
+    //     loads behind them may still be in flight)
+    asm_wait_vmcnt_x<2 * SLOTS>(xr[0], xr[1], xr[2], xr[3], xr[4], xr[5]);
+#pragma unroll
+    for (int j = 0; j < XR; ++j) {
+      const int i = tid + j * nthreads;
+      if (i < xpieces) *reinterpret_cast<u32x4*>(smem + L::kX + i * 16) = xr[j];
+    }
+    __syncthreads();
   }
-  __syncthreads();
   QUIP_STAMP(3);
 
   const uint32_t lane_c = (REP == 32) ? (((uint32_t)(lane & 31) << 3) | 0x00010000u)
@@ -414,11 +537,12 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
 #undef QUIP_STAMP
 }
 
-template <int REP, int SLOTS, int MAXT, int G, bool ONESHOT = false>
+template <int REP, int SLOTS, int MAXT, int G, bool ONESHOT = false, bool FUSED = false>
 int launch(const GemvGroup<G>& gp, const void* grid, int k, int kp, int nblocks, int threads, uint64_t* dbg,
-           hipStream_t stream) {
-  auto kern = e8p_gemv_mfma_kernel<REP, SLOTS, MAXT, G, ONESHOT>;
-  const int lds = Lds<REP>::bytes(kp, G);
+           hipStream_t stream, const FusedIn* fin = nullptr) {
+  auto kern = e8p_gemv_mfma_kernel<REP, SLOTS, MAXT, G, ONESHOT, FUSED>;
+  const int lds = FUSED ? Lds<REP>::bytes_fused(kp, G) : Lds<REP>::bytes(kp, G);
+  const FusedIn fi = fin ? *fin : FusedIn{};
   static int configured = 0;  // benign race: idempotent attribute
   if (lds > configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -426,7 +550,7 @@ int launch(const GemvGroup<G>& gp, const void* grid, int k, int kp, int nblocks,
       return QUIP_ERR_LAUNCH;
     configured = lds;
   }
-  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(threads), lds, stream, gp,
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(threads), lds, stream, gp, fi,
                      reinterpret_cast<const uint64_t*>(grid), k, kp, dbg);
   return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
 }
@@ -688,6 +812,75 @@ static int group_launch(const void* const* planes, const void* const* qidxs, con
   QUIP_CASE(32, 1) QUIP_CASE(32, 2) QUIP_CASE(16, 1) QUIP_CASE(16, 2)
 #undef QUIP_CASE
   return QUIP_ERR_UNSUPPORTED;
+}
+
+// ---- fused input side (FusedIn) ------------------------------------------------------------
+bool e8p_gemv_mfma_fused_supported(const int* ns, int count, int k) {
+  if (count < 1 || count > 3) return false;
+  if (k < 1024 || k > 8192 || (k & (k - 1)) != 0) return false;   // K_left == 1, n / 16 FHT threads <= 512
+  for (int i = 0; i < count; ++i)
+    if (ns[i] < 1) return false;
+  return Lds<16>::bytes_fused(k, count) <= 160 * 1024;
+}
+
+template <int G>
+static int fused_launch(const GemvFusedIn& in, const void* const* qidxs, const void* grid, void* const* ys,
+                        const int* ns, int k, const GemvTune& tune, hipStream_t stream) {
+  const int kp = k;   // power of two >= 1024: no k padding
+  const int ncu = device_cu_count();
+  int nblocks = tune.blocks > 0 ? tune.blocks : ncu;
+  GemvGroup<G> gp;
+  for (;;) {
+    int total_rpb = 0;
+    for (int p = 0; p < G; ++p) {
+      int rpb = (ns[p] + nblocks - 1) / nblocks;
+      rpb = (rpb + 15) & ~15;
+      gp.rpb[p] = rpb;
+      total_rpb += rpb;
+    }
+    if (total_rpb <= kMaxRowsPerBlock) break;
+    nblocks *= 2;
+  }
+  int used = 0, items = 0;
+  FusedIn fi{};
+  fi.x = reinterpret_cast<const f16*>(in.x);
+  fi.z = reinterpret_cast<const f16*>(in.z);
+  fi.post = reinterpret_cast<const f16*>(in.post);
+  fi.residual = reinterpret_cast<const f16*>(in.residual);
+  fi.h_out = reinterpret_cast<f16*>(in.h_out);
+  fi.rms_w = reinterpret_cast<const f16*>(in.rms_w);
+  fi.z_scale = in.z_scale; fi.rms_eps = in.rms_eps; fi.n = k;
+  fi.logn = 0;
+  while ((1 << fi.logn) < k) ++fi.logn;
+  for (int p = 0; p < G; ++p) {
+    gp.W[p] = reinterpret_cast<const uint4*>(qidxs[p]);
+    gp.planes[p] = nullptr;
+    gp.y[p] = reinterpret_cast<f16*>(ys[p]);
+    gp.N[p] = ns[p];
+    fi.pre[p] = reinterpret_cast<const f16*>(in.pre[p]);
+    fi.scale[p] = in.scale[p];
+    used = used > (ns[p] + gp.rpb[p] - 1) / gp.rpb[p] ? used : (ns[p] + gp.rpb[p] - 1) / gp.rpb[p];
+    items += (gp.rpb[p] >> 4) * (kp >> 9);
+  }
+  nblocks = used;
+  const int waves = 8, threads = 512;       // n / 16 <= 512 transform threads
+  const int ipw = (items + waves - 1) / waves;
+  uint64_t* dbg = reinterpret_cast<uint64_t*>(tune.dbg);
+#define QUIP_ONE(S)                                                                                   \
+  if (ipw <= S) return launch<16, S, 512, G, true, true>(gp, grid, k, kp, nblocks, threads, dbg, stream, &fi);
+  QUIP_ONE(1) QUIP_ONE(2) QUIP_ONE(3) QUIP_ONE(4) QUIP_ONE(6) QUIP_ONE(8)
+#undef QUIP_ONE
+  return launch<16, 2, 512, G, false, true>(gp, grid, k, kp, nblocks, threads, dbg, stream, &fi);
+}
+
+int e8p_gemv_mfma_fused_launch(const GemvFusedIn& in, const void* const* qidxs, const void* grid,
+                               void* const* ys, const int* ns, int count, int k, const GemvTune& tune,
+                               hipStream_t stream) {
+  if (!e8p_gemv_mfma_fused_supported(ns, count, k)) return QUIP_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(grid) & 63u) != 0) return QUIP_ERR_MISALIGNED;
+  if (count == 1) return fused_launch<1>(in, qidxs, grid, ys, ns, k, tune, stream);
+  if (count == 2) return fused_launch<2>(in, qidxs, grid, ys, ns, k, tune, stream);
+  return fused_launch<3>(in, qidxs, grid, ys, ns, k, tune, stream);
 }
 
 int e8p_gemv_mfma_group_launch(const void* const* planes, const void* const* qidxs, const void* grid,

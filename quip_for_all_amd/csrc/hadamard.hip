@@ -26,7 +26,7 @@
 // between the transform and the GEMV.  The shift comes from a bound every workgroup can
 // compute alone: K == 1: the exact max |v| of the transformed row; K > 1: |v_i| <= ||v||_2 =
 // scale * sqrt(L) * ||H||_2 * ||input||_2 with H ~ orthogonal.
-#include "quip_device.hip.h"
+#include "had_device.hip.h"
 #include "quip_internal.h"
 
 namespace quip {
@@ -53,21 +53,9 @@ struct HadArgs {
 constexpr int kMaxGroup = 3;   // problems per launch (q/k/v, gate/up)
 struct HadGroup { HadArgs p[kMaxGroup]; };
 
-__device__ __forceinline__ float silu(float g) { return g / (1.f + __expf(-g)); }
-
-__device__ __forceinline__ float block_reduce(float v, bool is_max, float* red, int tid, int nt) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    const float w = __shfl_xor(v, o, 64);
-    v = is_max ? fmaxf(v, w) : v + w;
-  }
-  __syncthreads();
-  if ((tid & 63) == 0) red[tid >> 6] = v;
-  __syncthreads();
-  float r = red[0];
-  for (int w = 1; w < ((nt + 63) >> 6); ++w) r = is_max ? fmaxf(r, red[w]) : r + red[w];
-  return r;
-}
+using had::block_reduce;
+using had::pad;
+using had::silu;
 
 // input element idx of the current row, all element-wise pre-ops applied (not the rms factor)
 __device__ __forceinline__ float in_val(const HadArgs& a, const f16* xr, const f16* gr, int idx) {
@@ -80,44 +68,9 @@ __device__ __forceinline__ float in_val(const HadArgs& a, const f16* xr, const f
   return v;
 }
 
-// digit split of a block fixed point value (balanced int8 digits, see e8p_gemv_i8.hip)
-__device__ __forceinline__ void digits_of(int X, int& h, int& m, int& l) {
-  l = (X << 24) >> 24;
-  const int X1 = (X - l) >> 8;
-  m = (X1 << 24) >> 24;
-  h = (X1 - m) >> 8;
-}
-
-// shift for |v| <= bound: bound < 2^(E+1) => |rint(v * 2^sh)| < 2^22 with sh = 21 - E
-__device__ __forceinline__ int shift_for(float bound) {
-  int E = (int)((as_u32(bound) >> 23) & 0xff) - 127;
-  E = max(-60, min(60, E));
-  return 21 - E;
-}
-
-// element index held in register r of thread t during pass p (4 new index bits per pass; the
-// last pass may have nb < 4 new bits, the spare register bits then reuse index bits [0, 4 - nb))
-__device__ __forceinline__ int pass_index(int t, int r, int p, int nb) {
-  const int sh_lo = 4 - nb;                       // register high bits -> index bits [0, sh_lo)
-  const int lo_bits = 4 * p - sh_lo;              // thread low bits -> index bits [sh_lo, 4p)
-  const int t_lo = t & ((1 << lo_bits) - 1), t_hi = t >> lo_bits;
-  return (t_hi << (4 * p + nb)) | ((r & ((1 << nb) - 1)) << (4 * p)) | (t_lo << sh_lo) | (r >> nb);
-}
-
-// LDS index with one pad word per 32 (keeps the strided pass reads off a single bank)
-__device__ __forceinline__ int pad(int i) { return i + (i >> 5); }
-
 // 8 consecutive fp16 -> fp32 (16-byte load)
-__device__ __forceinline__ void ld8(const f16* p, float o[8]) {
-  const uint4 u = *reinterpret_cast<const uint4*>(p);
-  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const f16x2 h = as_f16x2(w[i]);
-    o[2 * i] = (float)h.x;
-    o[2 * i + 1] = (float)h.y;
-  }
-}
+__device__ __forceinline__ void ld8(const f16* p, float o[8]) { had::unpack8(*reinterpret_cast<const uint4*>(p), o); }
+__device__ __forceinline__ uint4 ldp(const f16* p) { return *reinterpret_cast<const uint4*>(p); }
 
 // 16 consecutive input elements [idx0, idx0 + 16) of the current row with the element-wise
 // pre-ops applied; ss_x accumulates the raw x^2 (RMSNorm statistic).  vec: in_features % 8 == 0
@@ -130,30 +83,14 @@ __device__ __forceinline__ void in_vals16(const HadArgs& a, const f16* xr, const
       const int c = idx0 + 8 * h;
       float* o = e + 8 * h;
       if (c < a.in_features) {
-        float t[8];
         ld8(xr + c, o);
         if (a.rms_w) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) ss_x = __builtin_fmaf(o[i], o[i], ss_x);
-          ld8(a.rms_w + c, t);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] *= t[i];
+          had::sumsq8(o, ss_x);
+          had::mul8(o, ldp(a.rms_w + c));
         }
-        if (a.gate) {
-          ld8(gr + c, t);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] *= silu(t[i]);
-        }
-        if (a.pre) {
-          ld8(a.pre + c, t);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] *= t[i];
-        }
-        if (a.pre2) {
-          ld8(a.pre2 + c, t);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] *= t[i];
-        }
+        if (a.gate) had::silu_mul8(o, ldp(gr + c));
+        if (a.pre) had::mul8(o, ldp(a.pre + c));
+        if (a.pre2) had::mul8(o, ldp(a.pre2 + c));
       } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = 0.f;
@@ -187,47 +124,21 @@ __device__ __forceinline__ void raw_load16(const HadArgs& a, const f16* xr, cons
   }
 }
 
-__device__ __forceinline__ void unpack8(const uint4& u, float o[8]) {
-  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const f16x2 h = as_f16x2(w[i]);
-    o[2 * i] = (float)h.x;
-    o[2 * i + 1] = (float)h.y;
-  }
-}
-
 __device__ __forceinline__ void raw_math16(const HadArgs& a, int idx0, const Raw16& r, float e[16], float& ss_x) {
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     float* o = e + 8 * h;
-    float t[8];
     const float keep = (idx0 + 8 * h) < a.in_features ? 1.f : 0.f;   // F.pad zeros
-    unpack8(r.d[0][h], o);
+    had::unpack8(r.d[0][h], o);
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] *= keep;
     if (a.rms_w) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) ss_x = __builtin_fmaf(o[i], o[i], ss_x);
-      unpack8(r.d[1][h], t);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) o[i] *= t[i];
+      had::sumsq8(o, ss_x);
+      had::mul8(o, r.d[1][h]);
     }
-    if (a.gate) {
-      unpack8(r.d[2][h], t);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) o[i] *= silu(t[i]);
-    }
-    if (a.pre) {
-      unpack8(r.d[3][h], t);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) o[i] *= t[i];
-    }
-    if (a.pre2) {
-      unpack8(r.d[4][h], t);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) o[i] *= t[i];
-    }
+    if (a.gate) had::silu_mul8(o, r.d[2][h]);
+    if (a.pre) had::mul8(o, r.d[3][h]);
+    if (a.pre2) had::mul8(o, r.d[4][h]);
   }
 }
 
@@ -369,71 +280,29 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
   if (a.rms_w) {
     // every workgroup sees the whole input row (K == 1: it is the row; K > 1: the k loop)
     const float tot = block_reduce(ss_x, false, red, tid, nt);
-    scale *= rsqrtf(tot / (float)a.in_features + a.rms_eps);
+    scale = had::rms_scale(a.scale, tot, a.in_features, a.rms_eps);
   }
 
   // (2) length-L transform: 4 index bits per pass in registers, LDS re-shuffle in between
-  const int npass = (logL + 3) >> 2;
-  for (int p = 0; p < npass; ++p) {
-    const int nb = min(4, logL - 4 * p);
-    if (p > 0) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = buf[pad(pass_index(tid, r, p, nb))];
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (s < nb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if (!(r & (1 << s))) {
-            const float x0 = v[r], x1 = v[r | (1 << s)];
-            v[r] = x0 + x1;
-            v[r | (1 << s)] = x0 - x1;
-          }
-        }
-      }
-    }
-    if (npass > 1) {
-      __syncthreads();  // everyone has read its pass-p inputs
-#pragma unroll
-      for (int r = 0; r < 16; ++r) buf[pad(pass_index(tid, r, p, nb))] = v[r];
-      __syncthreads();
-    }
-  }
-  if (npass > 1) {  // back to 16 consecutive elements per thread for vector stores
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = buf[pad(e0 + r)];
-  }
+  had::fht16(v, buf, tid, logL, true);
   const bool live = kp < K;                       // rows past K in the last tall workgroup
 
   // (3) epilogue
   if constexpr (PLANES) {
     float bound;
     if (K == 1) {
-      float mx = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(v[r] * scale));
-      bound = block_reduce(mx, true, red, tid, nt);
+      bound = block_reduce(had::absmax16(v, scale), true, red, tid, nt);
     } else {
       bound = sqrtf(block_reduce(ss_in, false, red, tid, nt)) * sqrtf((float)L) * fabsf(scale) * 1.0625f;
     }
-    const int sh = shift_for(bound);
-    const float s2 = scale * as_f32((uint32_t)(sh + 127) << 23);
+    const int sh = had::shift_for(bound);
     if (blockIdx.x == 0 && tid == 0) *reinterpret_cast<int*>(a.planes + (size_t)3 * a.Kp) = sh;
-    uint32_t dg[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int h, m, l;
-      digits_of((int)__builtin_rintf(v[r] * s2), h, m, l);
-      dg[0][r >> 2] |= (uint32_t)(h & 0xff) << (8 * (r & 3));
-      dg[1][r >> 2] |= (uint32_t)(m & 0xff) << (8 * (r & 3));
-      dg[2][r >> 2] |= (uint32_t)(l & 0xff) << (8 * (r & 3));
-    }
+    uint4 dg[3];
+    had::planes16(v, scale, sh, dg);
     const int idx = kp * L + j0;
     if (live) {
 #pragma unroll
-      for (int d = 0; d < 3; ++d)
-        *reinterpret_cast<uint4*>(a.planes + (size_t)d * a.Kp + idx) = make_uint4(dg[d][0], dg[d][1], dg[d][2], dg[d][3]);
+      for (int d = 0; d < 3; ++d) *reinterpret_cast<uint4*>(a.planes + (size_t)d * a.Kp + idx) = dg[d];
     }
     if (blockIdx.x == 0)  // zero the k padding [n, Kp)
       for (int i = a.n + tid * 16; i < a.Kp; i += nt * 16)
@@ -445,27 +314,15 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
     const int idx0 = kp * L + j0;
     if (!live) {
     } else if (idx0 + 16 <= a.out_features && a.vec_out) {
-      float t[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] *= scale;
-      if (a.post) {
-        ld8(a.post + idx0, t); ld8(a.post + idx0 + 8, t + 8);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] *= t[r];
-      }
-      if (a.bias) {
-        ld8(a.bias + idx0, t); ld8(a.bias + idx0 + 8, t + 8);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] += t[r];
-      }
-      if (rr) {
-        ld8(rr + idx0, t); ld8(rr + idx0 + 8, t + 8);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] += t[r];
-      }
+      float tp[16], tb[16], tr[16];
+      if (a.post) { ld8(a.post + idx0, tp); ld8(a.post + idx0 + 8, tp + 8); }
+      if (a.bias) { ld8(a.bias + idx0, tb); ld8(a.bias + idx0 + 8, tb + 8); }
+      if (rr) { ld8(rr + idx0, tr); ld8(rr + idx0 + 8, tr + 8); }
       f16 o[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[r] = (f16)v[r];
+      for (int r = 0; r < 16; ++r)
+        o[r] = had::out_elem(v[r], scale, a.post != nullptr, a.post ? tp[r] : 0.f, a.bias != nullptr,
+                             a.bias ? tb[r] : 0.f, rr != nullptr, rr ? tr[r] : 0.f);
       uint4* dst = reinterpret_cast<uint4*>(yr + idx0);
       dst[0] = *reinterpret_cast<uint4*>(&o[0]);
       dst[1] = *reinterpret_cast<uint4*>(&o[8]);
@@ -473,13 +330,10 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int idx = idx0 + r;
-        if (idx < a.out_features) {
-          float w = v[r] * scale;
-          if (a.post) w *= (float)a.post[idx];
-          if (a.bias) w += (float)a.bias[idx];
-          if (rr) w += (float)rr[idx];
-          yr[idx] = (f16)w;
-        }
+        if (idx < a.out_features)
+          yr[idx] = had::out_elem(v[r], scale, a.post != nullptr, a.post ? (float)a.post[idx] : 0.f,
+                                  a.bias != nullptr, a.bias ? (float)a.bias[idx] : 0.f, rr != nullptr,
+                                  rr ? (float)rr[idx] : 0.f);
       }
     }
   }
@@ -511,7 +365,7 @@ __global__ __launch_bounds__(256) void had_small_kernel(HadGroup grp) {
     buf[j] = acc;
   }
   float scale = a.scale;
-  if (a.rms_w) scale *= rsqrtf(block_reduce(ss_x, false, red, tid, nt) / (float)a.in_features + a.rms_eps);
+  if (a.rms_w) scale = had::rms_scale(a.scale, block_reduce(ss_x, false, red, tid, nt), a.in_features, a.rms_eps);
   __syncthreads();
   for (int h = 1; h < L; h <<= 1) {
     for (int i = tid; i < (L >> 1); i += nt) {
@@ -526,20 +380,20 @@ __global__ __launch_bounds__(256) void had_small_kernel(HadGroup grp) {
     float bound;
     if (K == 1) {
       float mx = 0.f;
-      for (int j = tid; j < L; j += nt) mx = fmaxf(mx, fabsf(buf[j] * scale));
+      for (int j = tid; j < L; j += nt) mx = fmaxf(mx, fabsf(had::fmul(buf[j], scale)));
       bound = block_reduce(mx, true, red, tid, nt);
     } else {
       bound = sqrtf(block_reduce(ss_in, false, red, tid, nt)) * sqrtf((float)L) * fabsf(scale) * 1.0625f;
     }
-    const int sh = shift_for(bound);
-    const float s2 = scale * as_f32((uint32_t)(sh + 127) << 23);
+    const int sh = had::shift_for(bound);
+    const float s2 = had::fmul(scale, as_f32((uint32_t)(sh + 127) << 23));
     if (kp == 0 && tid == 0) *reinterpret_cast<int*>(a.planes + (size_t)3 * a.Kp) = sh;
     for (int j4 = tid * 4; j4 < L; j4 += nt * 4) {
       uint32_t dg[3] = {0, 0, 0};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         int h, m, l;
-        digits_of((int)__builtin_rintf(buf[j4 + e] * s2), h, m, l);
+        had::digits_of((int)__builtin_rintf(had::fmul(buf[j4 + e], s2)), h, m, l);
         dg[0] |= (uint32_t)(h & 0xff) << (8 * e);
         dg[1] |= (uint32_t)(m & 0xff) << (8 * e);
         dg[2] |= (uint32_t)(l & 0xff) << (8 * e);
@@ -557,11 +411,9 @@ __global__ __launch_bounds__(256) void had_small_kernel(HadGroup grp) {
     for (int j = tid; j < L; j += nt) {
       const int idx = kp * L + j;
       if (idx < a.out_features) {
-        float w = buf[j] * scale;
-        if (a.post) w *= (float)a.post[idx];
-        if (a.bias) w += (float)a.bias[idx];
-        if (rr) w += (float)rr[idx];
-        yr[idx] = (f16)w;
+        yr[idx] = had::out_elem(buf[j], scale, a.post != nullptr, a.post ? (float)a.post[idx] : 0.f,
+                                a.bias != nullptr, a.bias ? (float)a.bias[idx] : 0.f, rr != nullptr,
+                                rr ? (float)rr[idx] : 0.f);
       }
     }
   }

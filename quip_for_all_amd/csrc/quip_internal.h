@@ -77,6 +77,22 @@ bool e8p_gemv_mfma_group_supported(const int* ns, int count, int k);
 int e8p_gemv_mfma_group_launch(const void* const* planes, const void* const* qidxs, const void* grid,
                                void* const* ys, const int* ns, int count, int k, const GemvTune& tune,
                                hipStream_t stream);
+// input side of a bs=1 GEMV computed in its prologue (see FusedIn in e8p_gemv_mfma.hip)
+struct GemvFusedIn {
+  const void* x = nullptr;         // fp16 [k]: the activation (when z == null)
+  const void* z = nullptr;         // fp16 [k]: producer's GEMV output, still to be output-transformed
+  const void* post = nullptr;      // fp16 [k]: producer's SV            (z != null)
+  const void* residual = nullptr;  // fp16 [k] or null: added to the producer's output
+  void* h_out = nullptr;           // fp16 [k]: receives the producer's output (z != null)
+  const void* rms_w = nullptr;     // fp16 [k] or null: RMSNorm weight
+  const void* pre[3] = {nullptr, nullptr, nullptr};   // SU of every problem
+  float scale[3] = {1.f, 1.f, 1.f};                   // wscale / sqrt(k)
+  float z_scale = 1.f, rms_eps = 1e-5f;
+};
+bool e8p_gemv_mfma_fused_supported(const int* ns, int count, int k);
+int e8p_gemv_mfma_fused_launch(const GemvFusedIn& in, const void* const* qidxs, const void* grid,
+                               void* const* ys, const int* ns, int count, int k, const GemvTune& tune,
+                               hipStream_t stream);
 int had_transform_launch(const void* x, void* y, int64_t rows, int in_features, int out_features,
                          int n, int K, const void* had, int transpose, const void* pre,
                          const void* pre2, const void* post, const void* bias, float scale,

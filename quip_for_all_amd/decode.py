@@ -18,7 +18,8 @@ import torch
 import torch.nn.functional as F
 
 from .codebook import codebook_id
-from .qlinear import QuantLinear, forward_group
+from .qlinear import (QuantLinear, forward_group, fused_in_supported, gemv_fused, gemv_unfused,
+                      out_transform_group)
 
 
 @dataclass
@@ -39,6 +40,7 @@ class LlamaShape:
 
 LLAMA2_7B = LlamaShape()
 LLAMA2_70B = LlamaShape(hidden=8192, ffn=28672, layers=80, heads=64, kv_heads=8)
+SMALL = LlamaShape(hidden=1024, ffn=2816, layers=2, heads=8, kv_heads=4, vocab=1024)   # takes the fused-prologue path
 TINY = LlamaShape(hidden=256, ffn=688, layers=2, heads=4, kv_heads=2, vocab=512)
 
 
@@ -102,6 +104,12 @@ class LlamaDecoder:
         self.pos = torch.zeros(1, dtype=torch.long, device=self.dev)
         self.graph = None
         self.fused_attention = s.head_dim in (64, 128)
+        L0 = self.layers[0]
+        self.fused_prologue = (fused_in_supported([L0["q"], L0["k"], L0["v"]], prev=L0["down"])
+                               and fused_in_supported([L0["o"]])
+                               and fused_in_supported([L0["gate"], L0["up"]], prev=L0["o"])
+                               and L0["down"].codebook.planes_supported(L0["down"].q_out_features,
+                                                                        L0["down"].q_in_features))
 
     # ---- model bytes the decode step has to stream (roofline denominator) -----------
     def algorithmic_bytes_per_token(self):
@@ -117,34 +125,67 @@ class LlamaDecoder:
         rot = torch.cat([-x[..., d:], x[..., :d]], -1)
         return (x.float() * cos + rot.float() * sin).to(x.dtype)
 
+    def _attention(self, i, q, k, v, cos, sin, mask):
+        s = self.s
+        if self.fused_attention:
+            # rope + cache append + attention over [0, pos]: one launch
+            return torch.ops.quip_lib.rope_attn_decode(
+                q.view(s.heads, s.head_dim), k.view(s.kv_heads, s.head_dim), v.view(s.kv_heads, s.head_dim),
+                self.cos, self.sin, self.pos, self.kcache[i], self.vcache[i])
+        q = self._rope(q.view(1, s.heads, 1, s.head_dim), cos, sin)
+        k = self._rope(k.view(1, s.kv_heads, 1, s.head_dim), cos, sin)
+        self.kcache[i].index_copy_(1, self.pos, k[0])
+        self.vcache[i].index_copy_(1, self.pos, v.view(s.kv_heads, 1, s.head_dim))
+        return F.scaled_dot_product_attention(q, self.kcache[i][None], self.vcache[i][None], attn_mask=mask,
+                                              enable_gqa=(s.kv_heads != s.heads))
+
     def step(self):
         """one token: reads self.tok / self.pos, writes the greedy next token into self.tok and
         advances self.pos (all on the device)"""
         s = self.s
         h = self.embed[self.tok]                                   # (1, hidden)
+        cos = sin = mask = None
         if not self.fused_attention:
             cos, sin = self.cos[self.pos], self.sin[self.pos]          # (1, head_dim)
             mask = (self.arange[None, None, None, :] <= self.pos)      # (1,1,1,max_len) keys <= current
+        if self.fused_prologue:
+            return self._step_fused(h, cos, sin, mask)
         for i, L in enumerate(self.layers):
-            # RMSNorm is folded into the input-side Hadamard launch of q / k / v (and gate / up)
-            # q / k / v (and gate / up below): one launch per stage for the whole group
+            # q / k / v (and gate / up below): one launch per stage for the whole group; RMSNorm rides on
+            # the input-side Hadamard launch
             q, k, v = forward_group([L["q"], L["k"], L["v"]], h, rms_weight=L["ln1"], rms_eps=s.rms_eps)
-            if self.fused_attention:
-                # rope + cache append + attention over [0, pos]: one launch
-                a = torch.ops.quip_lib.rope_attn_decode(
-                    q.view(s.heads, s.head_dim), k.view(s.kv_heads, s.head_dim), v.view(s.kv_heads, s.head_dim),
-                    self.cos, self.sin, self.pos, self.kcache[i], self.vcache[i])
-            else:
-                q = self._rope(q.view(1, s.heads, 1, s.head_dim), cos, sin)
-                k = self._rope(k.view(1, s.kv_heads, 1, s.head_dim), cos, sin)
-                self.kcache[i].index_copy_(1, self.pos, k[0])
-                self.vcache[i].index_copy_(1, self.pos, v.view(s.kv_heads, 1, s.head_dim))
-                a = F.scaled_dot_product_attention(q, self.kcache[i][None], self.vcache[i][None], attn_mask=mask,
-                                                   enable_gqa=(s.kv_heads != s.heads))
+            a = self._attention(i, q, k, v, cos, sin, mask)
             # residual adds ride on the output-side Hadamard launch, SiLU(gate)*up on down's input side
             h = L["o"].forward_fused(a.reshape(1, s.hidden), residual=h)
             g, u = forward_group([L["gate"], L["up"]], h, rms_weight=L["ln2"], rms_eps=s.rms_eps)
             h = L["down"].forward_fused(u, gate=g, residual=h)
+        return self._head(h)
+
+    def _step_fused(self, h, cos, sin, mask):
+        """8 launches per block: the GEMV launches of q/k/v, o and gate/up compute their own input
+        transform (RMSNorm, SU, Hadamard) and the output transform + residual of the module before
+        them (down of the previous block, o) in their prologue."""
+        s = self.s
+        zd = prev_down = None
+        for i, L in enumerate(self.layers):
+            qkv = [L["q"], L["k"], L["v"]]
+            if zd is None:
+                _, zs = gemv_fused(qkv, x=h, rms_weight=L["ln1"], rms_eps=s.rms_eps)
+            else:   # finishes the previous block: h += down(...)
+                h, zs = gemv_fused(qkv, prev=prev_down, z=zd, residual=h, rms_weight=L["ln1"], rms_eps=s.rms_eps)
+            q, k, v = out_transform_group(qkv, zs)
+            a = self._attention(i, q, k, v, cos, sin, mask)
+            _, (zo,) = gemv_fused([L["o"]], x=a.reshape(1, s.hidden))
+            h, zgu = gemv_fused([L["gate"], L["up"]], prev=L["o"], z=zo, residual=h, rms_weight=L["ln2"],
+                                rms_eps=s.rms_eps)
+            g, u = out_transform_group([L["gate"], L["up"]], zgu)
+            zd = gemv_unfused(L["down"], u, gate=g)
+            prev_down = L["down"]
+        (h,) = out_transform_group([prev_down], [zd], residual=[h])
+        return self._head(h)
+
+    def _head(self, h):
+        s = self.s
         logits = F.rms_norm(h, (s.hidden,), self.final_norm, s.rms_eps) @ self.lm_head.T
         self.tok.copy_(logits.argmax(-1))
         self.pos.add_(1)

@@ -244,3 +244,78 @@ def forward_group(layers, input, rms_weight=None, rms_eps=1e-5, residual=None):
         for i, o in zip(same, outs):
             ys[i] = o.view(*input.shape[:-1], layers[i].out_features)
     return ys
+
+
+# ---- stage-wise execution for the bs=1 decode step ---------------------------------------------
+# QuantLinear.forward = input transform -> GEMV -> output transform.  The decode loop runs the
+# stages of neighbouring modules together: the GEMV launch of a group computes its own input
+# transform (and, if given, the output transform + residual add of the module that produced its
+# input) in its prologue; the output transform of the group is one more launch.
+
+def _pow2(n):
+    return n & (n - 1) == 0
+
+
+def fused_in_supported(layers, prev=None):
+    """can `gemv_fused` run these modules (and fold `prev`'s output side in)?"""
+    l0 = layers[0]
+    cb = l0.codebook
+    ok = (hasattr(cb, "fused_supported") and cb.fused_supported(len(layers), l0.q_in_features)
+          and all(type(l.codebook) is type(cb) and not l.training and l.K_left == 1 and l.SU is not None
+                  and l.in_features == l.q_in_features == l0.q_in_features for l in layers))
+    if ok and prev is not None:
+        ok = (prev.K_right == 1 and prev.out_features == prev.q_out_features == l0.in_features
+              and prev.bias is None and not prev.per_channel and prev.SV is not None)
+    return ok
+
+
+def gemv_fused(layers, x=None, prev=None, z=None, residual=None, rms_weight=None, rms_eps=1e-5):
+    """One launch: input side + GEMV of 1..3 modules reading the same bs=1 activation.
+    Either `x` (1, k) is the activation, or `z` is the raw GEMV output of module `prev` whose output
+    transform (+ `residual`) is folded in.  Returns (h, [z_i]): h = prev's finished output (None
+    when x was given), z_i = raw GEMV outputs, to be finished by `out_transform_group`."""
+    l0 = layers[0]
+    k = l0.q_in_features
+    res = torch.ops.quip_lib.e8p_gemv_fused(
+        None if z is not None else x.reshape(1, k), None if z is None else z.reshape(1, k),
+        None if z is None else prev._vec(prev.SV), None if residual is None else residual.reshape(1, k),
+        None if rms_weight is None else l0._vec(rms_weight), rms_eps,
+        1.0 if z is None else 1.0 / math.sqrt(prev.q_out_features // prev.K_right),
+        [l._vec(l.SU) for l in layers], [l.wscale_float / math.sqrt(k) for l in layers],
+        [l.Qidxs for l in layers], l0.codebook.grid_packed_abs)
+    if z is None:
+        return None, list(res)
+    return res[0], list(res[1:])
+
+
+def out_transform_group(layers, zs, residual=None):
+    """output side (qlinear.py:106-114) of 1..3 modules from their raw GEMV outputs; one launch per
+    set of modules with the same (q_out, K_right)"""
+    residual = residual if residual is not None else [None] * len(layers)
+    ys = [None] * len(layers)
+    todo = list(range(len(layers)))
+    while todo:
+        i0 = todo[0]
+        same = [i for i in todo if layers[i].q_out_features == layers[i0].q_out_features
+                and layers[i].K_right == layers[i0].K_right]
+        todo = [i for i in todo if i not in same]
+        ls = [layers[i] for i in same]
+        L_out = ls[0].q_out_features // ls[0].K_right
+        outs = torch.ops.quip_lib.had_transform_group(
+            [zs[i] for i in same], [l.out_features for l in ls], ls[0].q_out_features, ls[0].K_right,
+            [l._had("had_right") for l in ls], False, [l._vec(l.Wscale) if l.per_channel else None for l in ls],
+            [l._vec(l.SV) for l in ls], [l._vec(l.bias) for l in ls], [1.0 / math.sqrt(L_out)] * len(ls),
+            [None if residual[i] is None else residual[i].reshape(1, -1).to(torch.float16) for i in same])
+        for i, o in zip(same, outs):
+            ys[i] = o
+    return ys
+
+
+def gemv_unfused(layer, x, gate=None, rms_weight=None, rms_eps=1e-5):
+    """raw GEMV output of one module through the separate input-transform launch (any K_left)"""
+    L_in = layer.q_in_features // layer.K_left
+    planes = torch.ops.quip_lib.had_transform_planes_fused(
+        x.reshape(1, -1), layer.q_in_features, layer.K_left, layer._had("had_left"), True, layer._vec(layer.SU),
+        layer.wscale_float / math.sqrt(L_in), layer._vec(rms_weight), rms_eps,
+        None if gate is None else gate.reshape(1, -1))
+    return layer.codebook.mm_planes(planes, layer.Qidxs)

@@ -46,6 +46,9 @@ _SCHEMAS = {
     "had_transform_group": "(Tensor[] x, int[] out_features, int n, int K, Tensor?[] had, bool transpose, "
                            "Tensor?[] pre2, Tensor?[] post, Tensor?[] bias, float[] scale, Tensor?[] residual) "
                            "-> Tensor[]",
+    # GEMV(s) with the input side computed in the prologue: [h_out]? + [y_i]; see quip_e8p_gemv_fused
+    "e8p_gemv_fused": "(Tensor? x, Tensor? z, Tensor? post, Tensor? residual, Tensor? rms_weight, float rms_eps, "
+                      "float z_scale, Tensor[] pre, float[] scale, Tensor[] Qidxs, Tensor grid) -> Tensor[]",
     # decode-step glue between q/k/v_proj and o_proj: rope + KV-cache append + single-query attention
     "rope_attn_decode": "(Tensor q, Tensor k, Tensor v, Tensor cos, Tensor sin, Tensor pos, Tensor(a!) kcache, "
                         "Tensor(b!) vcache) -> Tensor",
@@ -238,6 +241,40 @@ def _e8p_gemv_planes_group_cuda(planes, Qidxs, grid):
     return outs
 
 
+def _e8p_gemv_fused_cuda(x, z, post, residual, rms_weight, rms_eps, z_scale, pre, scale, Qidxs, grid):
+    import ctypes
+    count = len(Qidxs)
+    _need(1 <= count <= capi.MAX_GROUP and len(pre) == count and len(scale) == count, "group of 1..3 problems")
+    k = Qidxs[0].shape[1] * 8
+    src = z if z is not None else x
+    _need(src is not None and src.numel() == k and src.dtype == torch.float16 and src.is_contiguous(),
+          "x / z must be a contiguous fp16 vector of k elements")
+    dev = src.device
+    for q in Qidxs:
+        _need(q.dtype == torch.int16 and q.is_contiguous() and q.shape[1] * 8 == k and q.device == dev,
+              "Qidxs must be contiguous int16 (n, k/8) with a common k")
+    for t in [post, residual, rms_weight] + list(pre):
+        _need(t is None or (t.numel() == k and t.dtype == torch.float16 and t.is_contiguous() and t.device == dev),
+              "vectors must be contiguous fp16 of k elements")
+    _need(z is None or post is not None, "post (the producer's SV) is required with z")
+    outs = [torch.empty((1, q.shape[0]), dtype=torch.float16, device=dev) for q in Qidxs]
+    h_out = torch.empty((1, k), dtype=torch.float16, device=dev) if z is not None else None
+    fin = capi.GemvFusedIn()
+    fin.x, fin.z, fin.post_scale, fin.residual = _ptr(x), _ptr(z), _ptr(post), _ptr(residual)
+    fin.h_out, fin.rms_weight = _ptr(h_out), _ptr(rms_weight)
+    for i in range(count):
+        fin.pre_scale[i] = pre[i].data_ptr()
+        fin.scale[i] = float(scale[i])
+    fin.z_scale, fin.rms_eps = float(z_scale), float(rms_eps)
+    vp = ctypes.c_void_p * count
+    ns = (ctypes.c_int32 * count)(*[q.shape[0] for q in Qidxs])
+    with torch.cuda.device(dev):
+        capi.check(capi.lib().quip_e8p_gemv_fused(
+            ctypes.byref(fin), vp(*[q.data_ptr() for q in Qidxs]), grid.data_ptr(),
+            vp(*[o.data_ptr() for o in outs]), ns, count, k, _stream(src)), "quip_e8p_gemv_fused")
+    return ([h_out] if h_out is not None else []) + outs
+
+
 def _rope_attn_decode_cuda(q, k, v, cos, sin, pos, kcache, vcache):
     """q (heads, hd), k / v (kv_heads, hd) fp16; cos / sin (max_len, hd) fp32; pos int64 device scalar;
     kcache / vcache (kv_heads, max_len, hd) fp16 (row pos is written) -> (heads, hd) fp16"""
@@ -393,6 +430,7 @@ _IMPLS = {
     "had_transform_planes": _had_transform_planes_cuda,
     "e8p_gemv_planes": _e8p_gemv_planes_cuda,
     "rope_attn_decode": _rope_attn_decode_cuda,
+    "e8p_gemv_fused": _e8p_gemv_fused_cuda,
     "had_transform_planes_group": _had_transform_planes_group_cuda,
     "had_transform_group": _had_transform_group_cuda,
     "e8p_gemv_planes_group": _e8p_gemv_planes_group_cuda,
@@ -437,6 +475,9 @@ _reg_fake("had_transform_group", lambda x, out_features, n, K, had, transpose, p
           [t.new_empty((t.shape[0], int(o))) for t, o in zip(x, out_features)])
 _reg_fake("e8p_gemv_planes_group", lambda planes, Qidxs, grid:
           [p.new_empty((1, q.shape[0]), dtype=torch.float16) for p, q in zip(planes, Qidxs)])
+_reg_fake("e8p_gemv_fused", lambda x, z, post, residual, rms_weight, rms_eps, z_scale, pre, scale, Qidxs, grid:
+          ([z.new_empty((1, z.numel()))] if z is not None else []) +
+          [q.new_empty((1, q.shape[0]), dtype=torch.float16) for q in Qidxs])
 _reg_fake("rope_attn_decode", lambda q, k, v, cos, sin, pos, kcache, vcache: torch.empty_like(q))
 _reg_fake("e8p_gemv_planes", lambda planes, Q, g: Q.new_empty((1, Q.shape[0]), dtype=torch.float16))
 for _n in ("e8p_mm_origorder", "e8prvq3_mm_origorder", "e8prvq4_mm_origorder", "d4_mm_origorder",

@@ -129,3 +129,29 @@ def test_rope_attn_decode_matches_torch(heads, kv_heads, hd, pos):
     ref = torch.einsum("ht,htd->hd", torch.softmax(s, -1), V)
     err = (out.double() - ref).abs().max().item()
     assert err <= 2e-3 * max(1.0, ref.abs().max().item()), err
+
+
+def test_fused_prologue_step_equals_unfused_step():
+    """SMALL (hidden 1024) takes the fused-prologue decode step; it must produce exactly the logits
+    and tokens of the step built from separate launches (same arithmetic, had_device.hip.h)"""
+    from quip_for_all_amd import decode as D
+    dec = D.LlamaDecoder(D.SMALL, "E8P12", max_len=32, device="cuda:0", seed=11)
+    assert dec.fused_prologue
+    fused_tokens = dec.generate(10, first_token=7, use_graph=False)
+    dec.reset(7)
+    with torch.no_grad():
+        lf = [dec.step().clone() for _ in range(4)]
+    dec.fused_prologue = False
+    plain_tokens = dec.generate(10, first_token=7, use_graph=False)
+    dec.reset(7)
+    with torch.no_grad():
+        lp = [dec.step().clone() for _ in range(4)]
+    assert torch.equal(fused_tokens, plain_tokens)
+    for a, b in zip(lf, lp):
+        assert torch.equal(a, b)
+    dec.fused_prologue = True
+    graph_tokens = dec.generate(10, first_token=7, use_graph=True)
+    assert torch.equal(graph_tokens, fused_tokens)
+    ref = _ref_logits(dec, [7, int(fused_tokens[0]), int(fused_tokens[1])])
+    got = lf[2].float().cpu().numpy()[0].astype(np.float64)
+    assert np.max(np.abs(got - ref)) <= 0.03 * (np.abs(ref).max() + 1.0)

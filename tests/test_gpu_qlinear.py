@@ -174,3 +174,38 @@ def test_forward_group_equals_single_calls(fin, fouts):
         group = forward_group(layers, x, residual=res)
         for a, b in zip(single, group):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("k,fouts,with_prev,with_rms", [
+    (4096, (4096, 4096, 4096), True, True), (4096, (4096,), False, False), (4096, (11008, 11008), True, True),
+    (1024, (1024, 512, 512), True, True), (8192, (8192, 1024, 1024), False, True), (8192, (8192,), False, False),
+    (2048, (2048, 640), True, False), (8192, (28672, 28672), True, True)])
+def test_gemv_fused_prologue_bit_identical(k, fouts, with_prev, with_rms):
+    """quip_e8p_gemv_fused == output transform of the producer -> grouped input transforms ->
+    grouped GEMV, bit for bit (raw GEMV outputs and the producer's finished output)"""
+    from quip_for_all_amd import qlinear as QL
+    layers = [_layer(O.make_layer("E8P12", k, fo, seed=k + fo + i)) for i, fo in enumerate(fouts)]
+    if not QL.fused_in_supported(layers):
+        pytest.skip("shape not served by the fused prologue (LDS budget)")
+    rng = np.random.default_rng(k + len(fouts))
+    t = lambda a: torch.from_numpy(a.astype(np.float16)).to(DEV)  # noqa: E731
+    w = t(1 + 0.1 * rng.standard_normal(k)) if with_rms else None
+    with torch.no_grad():
+        if with_prev:
+            prev = _layer(O.make_layer("E8P12", 1024, k, seed=k + 7))
+            assert QL.fused_in_supported(layers, prev=prev)
+            z = t(rng.standard_normal((1, k)) * 8)
+            res = t(rng.standard_normal((1, k)))
+            h, zs = QL.gemv_fused(layers, prev=prev, z=z, residual=res, rms_weight=w)
+            (h_ref,) = QL.out_transform_group([prev], [z], residual=[res])
+            assert torch.equal(h, h_ref)
+            x = h_ref
+        else:
+            x = t(rng.standard_normal((1, k)))
+            h, zs = QL.gemv_fused(layers, x=x, rms_weight=w)
+            assert h is None
+        planes = torch.ops.quip_lib.had_transform_planes_group(
+            x, k, 1, [None] * len(layers), True, [l._vec(l.SU) for l in layers],
+            [l.wscale_float / np.sqrt(k) for l in layers], w, 1e-5, None)
+        for l, pl, zf in zip(layers, planes, zs):
+            assert torch.equal(zf, torch.ops.quip_lib.e8p_gemv_planes(pl, l.Qidxs, l.codebook.grid_packed_abs))
