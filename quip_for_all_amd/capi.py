@@ -43,6 +43,7 @@ SIGNATURES = {
 # not part of the public header: tuning hook used by the micro-benchmarks only
 _INTERNAL = {
     "quip_e8p_x_to_planes_laneorder": [_P, _P, _I32, _P],
+    "quip_e8p_gemv_fused_tuned": [_P, _P, _P, _P, _P, _I32, _I32, _P, _P],
     "quip_e8p_gemv_group_tuned": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P],
     "quip_e8p_gemv_tuned": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P],
 }

@@ -253,6 +253,21 @@ int quip_e8p_gemv_tuned(const void* x, const void* qidxs, const void* grid, void
   return e8p_gemv_i8_launch(x, kernel == 3 ? 1 : 0, qidxs, grid, y, n, k, t, (hipStream_t)stream);
 }
 
+int quip_e8p_gemv_fused_tuned(const quip_gemv_fused_in* in, const void* const* qidxs, const void* grid,
+                              void* const* ys, const int32_t* ns, int32_t count, int32_t k, void* dbg,
+                              quip_stream_t stream) {
+  GemvFusedIn f;
+  f.x = in->x; f.z = in->z; f.post = in->post_scale; f.residual = in->residual; f.h_out = in->h_out;
+  f.rms_w = in->rms_weight; f.z_scale = in->z_scale; f.rms_eps = in->rms_eps;
+  int n32[QUIP_MAX_GROUP];
+  for (int i = 0; i < count && i < QUIP_MAX_GROUP; ++i) {
+    f.pre[i] = in->pre_scale[i]; f.scale[i] = in->scale[i]; n32[i] = ns[i];
+  }
+  GemvTune t;
+  t.dbg = dbg;
+  return e8p_gemv_mfma_fused_launch(f, qidxs, grid, ys, n32, count, k, t, (hipStream_t)stream);
+}
+
 int quip_e8p_gemv_group_tuned(const void* const* planes, const void* const* qidxs, const void* grid,
                               void* const* ys, const int32_t* ns, int32_t count, int32_t k, int32_t rep,
                               int32_t rows, int32_t blocks, int32_t max_waves, void* dbg,

@@ -232,6 +232,7 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using L = Lds<REP>;
 #define QUIP_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define QUIP_STAMP2(i) do { if (dbg && threadIdx.x == 0) dbg[(2048 + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
   QUIP_STAMP(0);
   const int tid = threadIdx.x;
   const int nthreads = blockDim.x;
@@ -377,6 +378,7 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
 #pragma unroll
       for (int g = 0; g < G; ++g) asm volatile("" : "+v"(ppre[g][h]));
     }
+    QUIP_STAMP2(0);
     auto as4 = [](const u32x4& v) { return make_uint4(v.x, v.y, v.z, v.w); };
     float* buf = reinterpret_cast<float*>(smem + L::kX + G * 3 * Kp);
     float* red = buf + had::buf_floats(Kp);
@@ -403,6 +405,7 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) xf[r] = (float)o[r];
     }
+    QUIP_STAMP2(1);
     float tot = 0.f;
     if (fi.rms_w) {
       float ss = 0.f;
@@ -422,8 +425,11 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
       had::mul8(e, as4(ppre[g][0]));
       had::mul8(e + 8, as4(ppre[g][1]));
       const float scale = fi.rms_w ? had::rms_scale(fi.scale[g], tot, fi.n, fi.rms_eps) : fi.scale[g];
+      if (g == 0) QUIP_STAMP2(2);
       had::fht16(e, buf, tid, fi.logn, act);
+      if (g == 0) QUIP_STAMP2(3);
       const float bound = had::block_reduce(act ? had::absmax16(e, scale) : 0.f, true, red, tid, nfht);
+      if (g == 0) QUIP_STAMP2(4);
       sh[g] = had::shift_for(bound);
       uint4 dg[3];
       had::planes16(e, scale, sh[g], dg);
@@ -432,6 +438,7 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
         for (int d = 0; d < 3; ++d)
           *reinterpret_cast<uint4*>(smem + L::kX + (g * 3 + d) * Kp + tid * 16) = dg[d];
       }
+      if (g == 0) QUIP_STAMP2(5);
     }
     __syncthreads();
   } else {
@@ -535,6 +542,7 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
   }
   QUIP_STAMP(7);
 #undef QUIP_STAMP
+#undef QUIP_STAMP2
 }
 
 template <int REP, int SLOTS, int MAXT, int G, bool ONESHOT = false, bool FUSED = false>

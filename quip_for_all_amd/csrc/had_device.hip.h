@@ -42,17 +42,34 @@ __device__ __forceinline__ int pass_index(int t, int r, int p, int nb) {
   return (t_hi << (4 * p + nb)) | ((r & ((1 << nb) - 1)) << (4 * p)) | (t_lo << sh_lo) | (r >> nb);
 }
 
+// wave64 reduction on DPP only; the result lands in lane 63.  The max variant is for
+// non-negative values (rows masked out of a row_bcast step contribute 0).
+template <bool IS_MAX, int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_step(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+  const float w = __builtin_bit_cast(float, t);
+  return IS_MAX ? fmaxf(v, w) : fadd(v, w);
+}
+template <bool IS_MAX>
+__device__ __forceinline__ float wave_reduce_to_lane63(float v) {
+  v = dpp_step<IS_MAX, 0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v = dpp_step<IS_MAX, 0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v = dpp_step<IS_MAX, 0x141, 0xf>(v);  // row_half_mirror
+  v = dpp_step<IS_MAX, 0x140, 0xf>(v);  // row_mirror: every lane of a 16-row holds the row result
+  v = dpp_step<IS_MAX, 0x142, 0xa>(v);  // row_bcast:15 -> rows 1, 3
+  v = dpp_step<IS_MAX, 0x143, 0xc>(v);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
 // Workgroup reduction over the first nt threads (nt a multiple of 64 or < 64); EVERY thread of the
-// workgroup must call it (barriers), threads >= nt contribute nothing.  Fixed order: lanes by
-// butterfly, then waves 0, 1, 2, ... -> the same value wherever the same data is reduced.
+// workgroup must call it (barriers), threads >= nt contribute nothing.  Fixed order: DPP tree
+// inside a wave, then waves 0, 1, 2, ... -> the same value wherever the same data is reduced.
+// is_max: values must be >= 0.
 __device__ __forceinline__ float block_reduce(float v, bool is_max, float* red, int tid, int nt) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    const float w = __shfl_xor(v, o, 64);
-    v = is_max ? fmaxf(v, w) : fadd(v, w);
-  }
+  v = is_max ? wave_reduce_to_lane63<true>(v) : wave_reduce_to_lane63<false>(v);
   __syncthreads();
-  if ((tid & 63) == 0 && tid < nt) red[tid >> 6] = v;
+  if ((tid & 63) == 63 && tid < nt) red[tid >> 6] = v;
+  if (nt < 64 && tid == nt - 1) red[0] = v;   // (not used by the blocked kernels: nt >= 64 there)
   __syncthreads();
   float r = red[0];
   for (int w = 1; w < ((nt + 63) >> 6); ++w) r = is_max ? fmaxf(r, red[w]) : fadd(r, red[w]);
@@ -93,43 +110,88 @@ __device__ __forceinline__ float rms_scale(float scale, float sumsq, int n, floa
   return fmul(scale, rsqrtf(fadd(mean, eps)));
 }
 
-// Length-2^logL Walsh-Hadamard transform of E = 16 * (#active threads) values viewed as rows of
-// 2^logL: thread t holds the 16 consecutive elements [16 t, 16 t + 16).  4 butterfly stages per
+// Length-2^LOGL Walsh-Hadamard transform of E = 16 * (#active threads) values viewed as rows of
+// 2^LOGL: thread t holds the 16 consecutive elements [16 t, 16 t + 16).  4 butterfly stages per
 // pass in registers, re-shuffle through LDS (buf: buf_floats(E) floats) between passes.  Every
 // thread of the workgroup must call it; only `active` threads (t < E / 16) touch data.
-__device__ __forceinline__ void fht16(float v[16], float* buf, int t, int logL, bool active) {
-  const int npass = (logL + 3) >> 2;
-  for (int p = 0; p < npass; ++p) {
-    const int nb = min(4, logL - 4 * p);
-    if (p > 0 && active) {
+// LOGL is a compile-time constant: the element index of register r in pass P is
+// (thread bits) | (register bits) with disjoint bit fields, and pad(a | b) = pad(a) + pad(b) for
+// disjoint fields, so every LDS access is `thread base + immediate offset`.
+template <int LOGL, int P>
+struct FhtPass {
+  static constexpr int NB = (LOGL - 4 * P) < 4 ? (LOGL - 4 * P) : 4;   // new index bits of this pass
+  static constexpr int SH_LO = 4 - NB;
+  static constexpr int LO_BITS = 4 * P - SH_LO;
+  __device__ static constexpr int rpart(int r) { return ((r & ((1 << NB) - 1)) << (4 * P)) | (r >> NB); }
+  __device__ static constexpr int rpad(int r) { return rpart(r) + (rpart(r) >> 5); }
+  __device__ static __forceinline__ int tbase(int t) {
+    const int t_lo = t & ((1 << LO_BITS) - 1), t_hi = t >> LO_BITS;
+    const int tp = (t_hi << (4 * P + NB)) | (t_lo << SH_LO);
+    return tp + (tp >> 5);
+  }
+  __device__ static __forceinline__ void butterflies(float v[16]) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = buf[pad(pass_index(t, r, p, nb))];
-    }
+    for (int s = 0; s < NB; ++s) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (s < nb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if (!(r & (1 << s))) {
-            const float x0 = v[r], x1 = v[r | (1 << s)];
-            v[r] = fadd(x0, x1);
-            v[r | (1 << s)] = fsub(x0, x1);
-          }
+      for (int r = 0; r < 16; ++r) {
+        if (!(r & (1 << s))) {
+          const float x0 = v[r], x1 = v[r | (1 << s)];
+          v[r] = fadd(x0, x1);
+          v[r | (1 << s)] = fsub(x0, x1);
         }
       }
     }
-    if (npass > 1) {
-      __syncthreads();  // everyone has read its pass-p inputs
-      if (active) {
+  }
+  __device__ static __forceinline__ void load(float v[16], const float* buf, int t) {
+    const float* b = buf + tbase(t);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) buf[pad(pass_index(t, r, p, nb))] = v[r];
-      }
+    for (int r = 0; r < 16; ++r) v[r] = b[rpad(r)];
+  }
+  __device__ static __forceinline__ void store(const float v[16], float* buf, int t) {
+    float* b = buf + tbase(t);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) b[rpad(r)] = v[r];
+  }
+};
+
+template <int LOGL, int P>
+__device__ __forceinline__ void fht16_passes(float v[16], float* buf, int t, bool active) {
+  constexpr int NPASS = (LOGL + 3) / 4;
+  if constexpr (P < NPASS) {
+    using Pass = FhtPass<LOGL, P>;
+    if (P > 0 && active) Pass::load(v, buf, t);
+    Pass::butterflies(v);
+    if (NPASS > 1) {
+      __syncthreads();  // everyone has read its pass-P inputs
+      if (active) Pass::store(v, buf, t);
       __syncthreads();
     }
+    fht16_passes<LOGL, P + 1>(v, buf, t, active);
   }
-  if (npass > 1 && active) {  // back to 16 consecutive elements per thread
+}
+
+template <int LOGL>
+__device__ __forceinline__ void fht16_fixed(float v[16], float* buf, int t, bool active) {
+  fht16_passes<LOGL, 0>(v, buf, t, active);
+  if (LOGL > 4 && active) {  // back to 16 consecutive elements per thread
+    const float* b = buf + (16 * t + ((16 * t) >> 5));
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = buf[pad(t * 16 + r)];
+    for (int r = 0; r < 16; ++r) v[r] = b[r];
+  }
+}
+
+// run-time dispatch over the lengths the kernels take (2^8 .. 2^14)
+__device__ __forceinline__ void fht16(float v[16], float* buf, int t, int logL, bool active) {
+  switch (logL) {
+    case 6: fht16_fixed<6>(v, buf, t, active); break;
+    case 7: fht16_fixed<7>(v, buf, t, active); break;
+    case 8: fht16_fixed<8>(v, buf, t, active); break;
+    case 9: fht16_fixed<9>(v, buf, t, active); break;
+    case 10: fht16_fixed<10>(v, buf, t, active); break;
+    case 11: fht16_fixed<11>(v, buf, t, active); break;
+    case 12: fht16_fixed<12>(v, buf, t, active); break;
+    case 13: fht16_fixed<13>(v, buf, t, active); break;
+    default: fht16_fixed<14>(v, buf, t, active); break;
   }
 }
 

@@ -111,6 +111,9 @@ extern "C" int quip_e8p_gemv_tuned(const void* x, const void* qidxs, const void*
                                    int32_t n, int32_t k, int32_t kernel, int32_t rep, int32_t rows,
                                    int32_t blocks, int32_t waves_g, int32_t max_waves,
                                    int32_t digits, void* dbg, quip_stream_t stream);
+extern "C" int quip_e8p_gemv_fused_tuned(const quip_gemv_fused_in* in, const void* const* qidxs, const void* grid,
+                                         void* const* ys, const int32_t* ns, int32_t count, int32_t k,
+                                         void* dbg, quip_stream_t stream);
 extern "C" int quip_e8p_gemv_group_tuned(const void* const* planes, const void* const* qidxs, const void* grid,
                                          void* const* ys, const int32_t* ns, int32_t count, int32_t k,
                                          int32_t rep, int32_t rows, int32_t blocks, int32_t max_waves,

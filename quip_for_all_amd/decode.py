@@ -105,7 +105,8 @@ class LlamaDecoder:
         self.graph = None
         self.fused_attention = s.head_dim in (64, 128)
         L0 = self.layers[0]
-        self.fused_prologue = (fused_in_supported([L0["q"], L0["k"], L0["v"]], prev=L0["down"])
+        import os
+        self.fused_prologue = (os.environ.get("QUIP_FUSED_PROLOGUE", "1") != "0" and fused_in_supported([L0["q"], L0["k"], L0["v"]], prev=L0["down"])
                                and fused_in_supported([L0["o"]])
                                and fused_in_supported([L0["gate"], L0["up"]], prev=L0["o"])
                                and L0["down"].codebook.planes_supported(L0["down"].q_out_features,
