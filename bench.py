@@ -186,7 +186,8 @@ def main():
     from quip_for_all_amd import decode as D
     shape = {"7b": D.LLAMA2_7B, "70b": D.LLAMA2_70B, "tiny": D.TINY}[a.model]
     max_len = a.steps + a.warmup + 8
-    dec = D.LlamaDecoder(shape, a.codebook, max_len=max_len, device=f"cuda:{local_rank}", seed=rank)
+    dec = D.LlamaDecoder(shape, a.codebook, max_len=max_len, device=f"cuda:{local_rank}", seed=rank,
+                         device_init=(a.model == "70b"))
     dec.capture()
 
     def barrier():

@@ -51,16 +51,25 @@ def random_quant_linear(in_f, out_f, codebook="E8P12", generator=None, device="c
     cb = codebook_id[codebook](inference=True, **cb_kwargs)
     layer = QuantLinear(in_f, out_f, cb, bias=False, use_rand=True)
     g = generator
+    dev = torch.device(device)
+    on_dev = g is not None and g.device.type == dev.type == "cuda"   # large models: draw the codes on the GPU
+    gdev = dev if on_dev else "cpu"
     with torch.no_grad():
         q = layer.Qidxs
         if q.dtype == torch.int16:
-            layer.Qidxs.copy_(torch.randint(-32768, 32768, q.shape, generator=g, dtype=torch.int32).to(torch.int16))
+            codes = torch.randint(-32768, 32768, q.shape, generator=g, dtype=torch.int32, device=gdev).to(torch.int16)
         elif q.dtype == torch.uint8:
-            layer.Qidxs.copy_(torch.randint(0, 256, q.shape, generator=g, dtype=torch.int32).to(torch.uint8))
+            codes = torch.randint(0, 256, q.shape, generator=g, dtype=torch.int32, device=gdev).to(torch.uint8)
         else:
-            layer.Qidxs.copy_(torch.randint(-2 ** 31, 2 ** 31 - 1, q.shape, generator=g, dtype=torch.int64).to(torch.int32))
-        layer.SU.copy_((torch.randint(0, 2, (in_f,), generator=g) * 2 - 1).to(torch.float16))
-        layer.SV.copy_((torch.randint(0, 2, (out_f,), generator=g) * 2 - 1).to(torch.float16))
+            codes = torch.randint(-2 ** 31, 2 ** 31 - 1, q.shape, generator=g, dtype=torch.int64,
+                                  device=gdev).to(torch.int32)
+        su = (torch.randint(0, 2, (in_f,), generator=g, device=gdev) * 2 - 1).to(torch.float16)
+        sv = (torch.randint(0, 2, (out_f,), generator=g, device=gdev) * 2 - 1).to(torch.float16)
+        if on_dev:
+            layer = layer.to(dev)
+        layer.Qidxs.copy_(codes)
+        layer.SU.copy_(su)
+        layer.SV.copy_(sv)
         wrms = {"E8P12": 1.03, "E8P12RVQ3B": 1.2, "E8P12RVQ4B": 1.2, "D4": 1.21, "HI": 4.6}[codebook]
         layer.Wscale.fill_(1.0 / (wrms * math.sqrt(in_f)))
     layer.wscale_float = float(layer.Wscale)      # quantizer.py:836-837
@@ -71,14 +80,15 @@ class LlamaDecoder:
     """Random-init Llama with QuantLinear projections, static KV cache, bs=1."""
 
     def __init__(self, shape: LlamaShape = LLAMA2_7B, codebook="E8P12", max_len=256, device="cuda", seed=0,
-                 **cb_kwargs):
+                 device_init=False, **cb_kwargs):
         self.s, self.dev, self.max_len = shape, torch.device(device), max_len
         g = torch.Generator().manual_seed(seed)
+        gq = torch.Generator(device=self.dev).manual_seed(seed) if device_init else g
         s = shape
         kv = s.kv_heads * s.head_dim
 
         def ql(i, o):
-            return random_quant_linear(i, o, codebook, g, device, **cb_kwargs)
+            return random_quant_linear(i, o, codebook, gq, device, **cb_kwargs)
 
         def vec(n):
             return (1.0 + 0.02 * torch.randn(n, generator=g)).to(torch.float16).to(self.dev)
