@@ -139,6 +139,32 @@ __device__ __forceinline__ void fill_tables(char* smem, const uint64_t* __restri
   }
 }
 
+// Faster build used by the GEMV kernel: wave w < 8 owns table rows [32 w, 32 w + 32); lane l holds
+// the 8-byte source of row 32 w + (l & 31) -- T1 source (grid_packed_abs) in lanes 0..31, T2 image in
+// lanes 32..63 -- fetched with ONE vector load issued as the very first load of the kernel, and
+// writes it REP times into its own row, copy (l + c) mod REP at step c: the lanes of a half-wave
+// hit REP distinct bank pairs per step (no broadcast through SGPRs, no scalar-load latency chain).
+__device__ __forceinline__ const uint2* table_source_ptr(const uint64_t* grid, int lane, int wave) {
+  const int e = (wave & 7) * 32 + (lane & 31);
+  const uint2* t1 = reinterpret_cast<const uint2*>(grid) + e;
+  const uint2* t2 = &kT2Img.v[e];
+  return (lane & 32) ? t2 : t1;
+}
+template <int REP>
+__device__ __forceinline__ void fill_tables_from_lane(char* smem, const u32x2& src, int lane, int wave) {
+  using L = Lds<REP>;
+  const bool second = (lane & 32) != 0;
+  const uint2 raw = make_uint2(src.x, src.y);
+  const uint2 t1 = t1_entry(raw);
+  const u32x2 val = {second ? raw.x : t1.x, second ? raw.y : t1.y};
+  const uint32_t rowbase = (uint32_t)(second ? L::kT2 : L::kT1) + (uint32_t)(wave * 32 + (lane & 31)) * L::kRow;
+#pragma unroll
+  for (int c = 0; c < REP; ++c) {
+    const uint32_t copy = (uint32_t)(lane + c) & (REP - 1);
+    *reinterpret_cast<__attribute__((address_space(3))) u32x2*>((uintptr_t)(rowbase + copy * 8)) = val;
+  }
+}
+
 // 16 codes of this lane -> eight MFMAs, in two steps so that the caller can reload the
 // slot registers between them: item_addresses() consumes the codes completely (32 LDS
 // addresses), item_mfma() runs the table / x reads PIPE steps ahead of their MFMA.
@@ -300,6 +326,8 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
   // (0) VMEM loads return in issue order: the x digit planes (L2 hits) -- or, fused, the fp16
   //     vectors the prologue transforms -- are requested before the (TLB-cold, HBM) weight
   //     loads, all through hand-counted asm loads.
+  u32x2 tsrc;   // this lane's table source entry: the first load of the kernel, so the first to land
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(tsrc) : "v"(table_source_ptr(grid, lane, wave)) : "memory");
   constexpr int XR = 6;  // 16-byte x pieces per thread: needs nthreads >= G * 3 * Kp / 96
   const int ppieces = 3 * (Kp >> 4);       // pieces per problem
   const int xpieces = G * ppieces;
@@ -358,9 +386,11 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
   }
   QUIP_STAMP(1);
 
-  // (1) tables + zeroed accumulators: scalar loads and LDS writes only
-  fill_tables<REP>(smem, grid, lane, wave, nwaves);
+  // (1) zeroed accumulators, then the tables as soon as the table source load has landed (every
+  //     later load may still be in flight)
   for (int i = tid; i < kMaxRowsPerBlock * 4; i += nthreads) reinterpret_cast<int*>(smem + L::kAcc)[i] = 0;
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(tsrc) : "n"((FUSED ? 2 * (4 + G) : XR) + 2 * SLOTS) : "memory");
+  if (wave < 8) fill_tables_from_lane<REP>(smem, tsrc, lane, wave);
   int sh[G];
   if constexpr (!FUSED) {
 #pragma unroll
@@ -738,6 +768,7 @@ int e8p_gemv_mfma_launch(const void* planes, const void* qidxs, const void* grid
   nblocks = (n + rpb - 1) / rpb;
   int waves = tune.max_waves > 0 ? tune.max_waves : 8;   // measured best on MI355X (tools/gemv_bench.py)
   if (waves > 16) waves = 16;
+  if (waves < 8) waves = 8;    // the table build uses waves 0..7
   const int min_waves = (3 * (kp >> 4) + 6 * 64 - 1) / (6 * 64);  // 6 x pieces per thread
   if (waves < min_waves) waves = min_waves;
   int rep = tune.rep ? tune.rep : (kp <= Lds<32>::kMaxKp ? 32 : 16);
@@ -804,6 +835,7 @@ static int group_launch(const void* const* planes, const void* const* qidxs, con
   nblocks = used;
   int waves = tune.max_waves > 0 ? tune.max_waves : 8;
   if (waves > 16) waves = 16;
+  if (waves < 8) waves = 8;
   const int min_waves = (G * 3 * (kp >> 4) + 6 * 64 - 1) / (6 * 64);
   if (waves < min_waves) waves = min_waves;
   if (waves > 16) return QUIP_ERR_UNSUPPORTED;
