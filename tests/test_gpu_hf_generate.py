@@ -1,0 +1,62 @@
+"""Drop-in check on the GPU: a checkpoint directory in the reference's format is loaded with
+`load_quantized_model`, moved to the GPU and run through the stock HF `generate` loop (the
+north-star claim); logits and greedy tokens must match the same HF model with every QuantLinear
+replaced by a dense nn.Linear holding `calc_weight()` (qlinear.py:144-159 identity)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+transformers = pytest.importorskip("transformers")
+
+from tests.test_quantizer_host import _fill_random, _tiny_config   # noqa: E402
+
+
+@pytest.mark.parametrize("codebook", ["E8P12", "E8P12RVQ4B"])
+def test_hf_generate_with_loaded_quantized_model(tmp_path, codebook):
+    from transformers import AutoModelForCausalLM
+    from quip_for_all_amd.quantizer import QuipQuantizer, load_quantized_model, get_layers
+    from quip_for_all_amd.qlinear import QuantLinear
+    torch.manual_seed(0)
+    model = AutoModelForCausalLM.from_config(_tiny_config(), dtype=torch.float16)
+    qz = QuipQuantizer(codebook=codebook, inference=True, ft_epochs=0)
+    qz.convert_model(model)
+    _fill_random(model, seed=3)
+    qz.save(model, str(tmp_path))
+    q = load_quantized_model(str(tmp_path), device_map={"": "cuda:0"})
+    assert q.is_quantized and next(q.parameters()).is_cuda
+    # dense twin: QuantLinear -> nn.Linear(calc_weight)
+    dense = copy.deepcopy(q)
+    dense.is_quantized = False
+    for name, layer in get_layers(dense, [QuantLinear]).items():
+        W = layer.calc_weight(cache=False).float()          # (q_in, q_out): y = x_pad @ W
+        lin = torch.nn.Linear(layer.in_features, layer.out_features, bias=False, device="cuda:0", dtype=torch.float32)
+        Wd = W[:layer.in_features, :layer.out_features]
+        su = layer.SU.float() if layer.SU is not None else 1.0
+        sv = layer.SV.float() if layer.SV is not None else 1.0
+        lin.weight.data = ((Wd * su[:, None] if torch.is_tensor(su) else Wd) * (sv[None, :] if torch.is_tensor(sv) else 1.0)).T.contiguous()
+        parent = dense
+        *path, leaf = name.split(".")
+        for p in path:
+            parent = parent[int(p)] if p.isdigit() else getattr(parent, p)
+        setattr(parent, leaf, lin)
+    dense = dense.float()
+    ids = torch.tensor([[1, 17, 42, 99, 7, 250]], device="cuda:0")
+    with torch.no_grad():
+        lq = q(ids).logits.float()
+        ld = dense(ids).logits.float()
+    err = (lq - ld).abs().max().item()
+    assert err <= 0.03 * (ld.abs().max().item() + 1.0), err
+    with torch.no_grad():
+        out_q = q.generate(ids, max_new_tokens=8, do_sample=False)
+        assert out_q.shape == (1, 14) and torch.equal(out_q[:, :6], ids)
+        # teacher-forced check of the greedy path: every token the quantized model picked is (within
+        # fp16 noise) the arg-max of the dense twin at that position.  Comparing two free-running
+        # greedy paths would diverge at the first near-tie of this random-weight model.
+        ld = dense(out_q).logits.float()[0]
+    for t in range(5, 13):
+        tok = int(out_q[0, t + 1])
+        margin = (ld[t].max() - ld[t, tok]).item()
+        assert margin <= 0.03 * (ld[t].abs().max().item() + 1.0), (t, tok, margin)
