@@ -58,10 +58,14 @@ constexpr int kMaxRowsPerBlock = 256;  // int32 accumulator rows per workgroup
 // footprint) for longer rows so that the digit planes of the WHOLE row stay resident.
 template <int REP>
 struct Lds {
-  static constexpr int kRow = REP * 8;               // bytes per table entry row
+  // REP = 32 / 16: both tables with that many copies; REP = 24: T1 x 32 (conflict free), T2 x 16
+  static constexpr int kRep1 = REP == 16 ? 16 : 32;
+  static constexpr int kRep2 = REP == 32 ? 32 : 16;
+  static constexpr int kRow1 = kRep1 * 8;            // bytes per T1 entry row
+  static constexpr int kRow2 = kRep2 * 8;            // bytes per T2 entry row
   static constexpr int kT1 = 0;
-  static constexpr int kT2 = 256 * kRow;
-  static constexpr int kAcc = 2 * 256 * kRow;        // int32 [kMaxRowsPerBlock][4]
+  static constexpr int kT2 = 256 * kRow1;
+  static constexpr int kAcc = kT2 + 256 * kRow2;     // int32 [kMaxRowsPerBlock][4]
   static constexpr int kX = kAcc + kMaxRowsPerBlock * 16;   // 3 planes x Kp bytes
   static constexpr int kMaxKp = (160 * 1024 - kX) / 3 / 512 * 512;
   static int bytes(int kp, int g = 1) { return kX + 3 * kp * g; }
@@ -105,41 +109,7 @@ __device__ __forceinline__ uint2 t1_entry(uint2 packed) {
                     __builtin_amdgcn_perm(0u, packed.y, 0x03010200u) | 0x01010101u);
 }
 
-// LDS tables, REP copies per entry.  Entry index is wave uniform, so the sources come
-// through scalar loads (8 entries = one s_load_dwordx16 per table and chunk) that do not
-// queue behind the VMEM loads already in flight; half of the wave writes T1[e], the
-// other half T2[e] (REP = 32) or T1/T2 of two consecutive entries (REP = 16): every
-// ds_write_b64 covers whole, distinct table rows -> conflict free.
-template <int REP>
-__device__ __forceinline__ void fill_tables(char* smem, const uint64_t* __restrict__ grid, int lane,
-                                            int wave, int nwaves) {
-  using L = Lds<REP>;
-  const uint2* g2 = reinterpret_cast<const uint2*>(__builtin_assume_aligned(grid, 64));
-  const bool second = (lane & 32) != 0;                    // lanes 32..63 write T2
-  const int esub = (REP == 16) ? ((lane >> 4) & 1) : 0;    // REP 16: lanes 16..31 / 48..63 take entry+1
-  char* base = smem + (second ? L::kT2 : L::kT1) + (lane & (REP - 1)) * 8;
-  for (int c = wave; c < 32; c += nwaves) {  // chunk of 8 consecutive entries
-    uint2 a[8], b[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { a[i] = g2[c * 8 + i]; b[i] = kT2Img.v[c * 8 + i]; }
-    if constexpr (REP == 32) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const uint2 t1 = t1_entry(a[i]);
-        *reinterpret_cast<uint2*>(base + (c * 8 + i) * L::kRow) = second ? b[i] : t1;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; i += 2) {
-        const uint2 t1a = t1_entry(a[i]), t1b = t1_entry(a[i + 1]);
-        const uint2 va = second ? b[i] : t1a, vb = second ? b[i + 1] : t1b;
-        *reinterpret_cast<uint2*>(base + (c * 8 + i + esub) * L::kRow) = esub ? vb : va;
-      }
-    }
-  }
-}
-
-// Faster build used by the GEMV kernel: wave w < 8 owns table rows [32 w, 32 w + 32); lane l holds
+// LDS tables: wave w < 8 owns table rows [32 w, 32 w + 32); lane l holds
 // the 8-byte source of row 32 w + (l & 31) -- T1 source (grid_packed_abs) in lanes 0..31, T2 image in
 // lanes 32..63 -- fetched with ONE vector load issued as the very first load of the kernel, and
 // writes it REP times into its own row, copy (l + c) mod REP at step c: the lanes of a half-wave
@@ -157,11 +127,16 @@ __device__ __forceinline__ void fill_tables_from_lane(char* smem, const u32x2& s
   const uint2 raw = make_uint2(src.x, src.y);
   const uint2 t1 = t1_entry(raw);
   const u32x2 val = {second ? raw.x : t1.x, second ? raw.y : t1.y};
-  const uint32_t rowbase = (uint32_t)(second ? L::kT2 : L::kT1) + (uint32_t)(wave * 32 + (lane & 31)) * L::kRow;
+  const uint32_t row = (uint32_t)(wave * 32 + (lane & 31));
+  const uint32_t rowbase = second ? (uint32_t)L::kT2 + row * L::kRow2 : (uint32_t)L::kT1 + row * L::kRow1;
+  const uint32_t mask = second ? (L::kRep2 - 1) : (L::kRep1 - 1);
 #pragma unroll
-  for (int c = 0; c < REP; ++c) {
-    const uint32_t copy = (uint32_t)(lane + c) & (REP - 1);
-    *reinterpret_cast<__attribute__((address_space(3))) u32x2*>((uintptr_t)(rowbase + copy * 8)) = val;
+  for (int c = 0; c < 32; ++c) {
+    if (c < L::kRep1 || c < L::kRep2) {
+      const uint32_t copy = (uint32_t)(lane + c) & mask;
+      if (c < (second ? L::kRep2 : L::kRep1))
+        *reinterpret_cast<__attribute__((address_space(3))) u32x2*>((uintptr_t)(rowbase + copy * 8)) = val;
+    }
   }
 }
 
@@ -169,7 +144,6 @@ __device__ __forceinline__ void fill_tables_from_lane(char* smem, const u32x2& s
 // slot registers between them: item_addresses() consumes the codes completely (32 LDS
 // addresses), item_mfma() runs the table / x reads PIPE steps ahead of their MFMA.
 struct ItemAddr { uint32_t a1l[8], a2l[8], a1h[8], a2h[8]; };
-struct StepOperands { uint2 t1l, t2l, t1h, t2h; i32x4 A; };
 
 template <int REP>
 __device__ __forceinline__ void item_addresses(const u32x4& q0, const u32x4& q1, uint32_t lane_c,
@@ -177,22 +151,27 @@ __device__ __forceinline__ void item_addresses(const u32x4& q0, const u32x4& q1,
   const uint32_t d[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    if constexpr (REP == 32) {
-      // table_base | idx << 8 | (lane & 31) << 3: byte aligned, one v_perm_b32 each
-      // (T2 base 0x10000 comes from byte 2 of lane_c)
+    if constexpr (REP != 16) {
+      // T1 (32 copies): table_base | idx << 8 | (lane & 31) << 3: byte aligned, one v_perm_b32
       ad.a1l[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c0c0500u);
-      ad.a2l[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c020400u);
       ad.a1h[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c0c0700u);
+    } else {
+      // 16 copies: table_base | idx << 7 | (lane & 15) << 3: shift + v_and_or_b32
+      ad.a1l[t] = ((d[t] >> 1) & 0x7f80u) | lane_c;
+      ad.a1h[t] = ((d[t] >> 17) & 0x7f80u) | lane_c;
+    }
+    if constexpr (REP == 32) {
+      // T2 base 0x10000 comes from byte 2 of lane_c
+      ad.a2l[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c020400u);
       ad.a2h[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c020600u);
     } else {
-      // table_base | idx << 7 | (lane & 15) << 3: shift + v_and_or_b32
-      ad.a1l[t] = ((d[t] >> 1) & 0x7f80u) | lane_c;
       ad.a2l[t] = ((d[t] << 7) & 0x7f80u) | lane_c2;
-      ad.a1h[t] = ((d[t] >> 17) & 0x7f80u) | lane_c;
       ad.a2h[t] = ((d[t] >> 9) & 0x7f80u) | lane_c2;
     }
   }
 }
+
+struct StepOperands { uint2 t1l, t2l, t1h, t2h; i32x4 A; };
 
 __device__ __forceinline__ i32x4 item_mfma(const ItemAddr& ad, uint32_t xaddr) {
   constexpr int PIPE = 4;
@@ -358,10 +337,14 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
     }
     hot = reinterpret_cast<const uint4*>(fi.z ? fi.z : fi.x) + (size_t)((tid * 2) % ((fi.n >> 3) - 1));
   } else {
+    // every workgroup reads the same planes: start each one at a different piece so that they do
+    // not convoy on the same L2 channels
+    const int rot = (int)((blockIdx.x * 613u) % (uint32_t)xpieces);
 #pragma unroll
     for (int j = 0; j < XR; ++j) {
       const int i = tid + j * nthreads;
-      const int ic = i < xpieces ? i : 0;
+      int ic = i < xpieces ? i + rot : 0;
+      ic = ic >= xpieces ? ic - xpieces : ic;
       int p = 0;
 #pragma unroll
       for (int g = 1; g < G; ++g) p += ic >= g * ppieces ? 1 : 0;
@@ -475,16 +458,19 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
     // (2) x digit planes into LDS once the 6 plane loads have landed (the 2 * SLOTS weight
     //     loads behind them may still be in flight)
     asm_wait_vmcnt_x<2 * SLOTS>(xr[0], xr[1], xr[2], xr[3], xr[4], xr[5]);
+    const int rot = (int)((blockIdx.x * 613u) % (uint32_t)xpieces);
 #pragma unroll
     for (int j = 0; j < XR; ++j) {
       const int i = tid + j * nthreads;
-      if (i < xpieces) *reinterpret_cast<u32x4*>(smem + L::kX + i * 16) = xr[j];
+      int ic = i + rot;
+      ic = ic >= xpieces ? ic - xpieces : ic;
+      if (i < xpieces) *reinterpret_cast<u32x4*>(smem + L::kX + ic * 16) = xr[j];
     }
     __syncthreads();
   }
   QUIP_STAMP(3);
 
-  const uint32_t lane_c = (REP == 32) ? (((uint32_t)(lane & 31) << 3) | 0x00010000u)
+  const uint32_t lane_c = (REP != 16) ? (((uint32_t)(lane & 31) << 3) | 0x00010000u)
                                       : (((uint32_t)(lane & 15) << 3) | (uint32_t)L::kT1);
   const uint32_t lane_c2 = ((uint32_t)(lane & 15) << 3) | (uint32_t)L::kT2;
   int* accs = reinterpret_cast<int*>(smem + L::kAcc);
@@ -493,6 +479,9 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
   const uint32_t xlane = L::kX + (uint32_t)min(n, 2) * Kp + (uint32_t)q * 64;
   QUIP_STAMP(4);
 
+  // (tried and measured slower on MI355X: slice-major item order with the A fragments of a slice
+  //  kept in registers across row blocks -- the stream is bound by the DRAM access pattern, not by
+  //  LDS reads, and slice-major makes the waves drift apart)
   auto run_item = [&](int cur, const ItemAddr& ad) {
     const int p = problem_of(cur);
     const int li = cur - pick(cbase, p);
@@ -749,9 +738,18 @@ static int launch_oneshot(const GemvGroup<G>& gp, const void* grid, int k, int k
   if (rep == R && items_per_wave <= S)                                              \
     return launch<R, S, 512, G, true>(gp, grid, k, kp, nblocks, threads, dbg, stream);
   QUIP_ONE(32, 1) QUIP_ONE(32, 2) QUIP_ONE(32, 3) QUIP_ONE(32, 4) QUIP_ONE(32, 6) QUIP_ONE(32, 8)
+  QUIP_ONE(24, 1) QUIP_ONE(24, 2) QUIP_ONE(24, 3) QUIP_ONE(24, 4) QUIP_ONE(24, 6) QUIP_ONE(24, 8)
   QUIP_ONE(16, 1) QUIP_ONE(16, 2) QUIP_ONE(16, 3) QUIP_ONE(16, 4) QUIP_ONE(16, 6) QUIP_ONE(16, 8)
 #undef QUIP_ONE
   return QUIP_ERR_UNSUPPORTED;
+}
+
+// table replication for `g` x vectors of kp digits each: 32 / 32 copies when everything fits, then
+// T1 x 32 + T2 x 16, then 16 / 16
+static int pick_rep(int g, int kp, int forced) {
+  if (forced == 16 || g * kp > Lds<24>::kMaxKp) return 16;
+  if (forced == 24 || g * kp > Lds<32>::kMaxKp) return 24;
+  return 32;
 }
 
 int e8p_gemv_mfma_launch(const void* planes, const void* qidxs, const void* grid, void* y, int n, int k,
@@ -771,12 +769,11 @@ int e8p_gemv_mfma_launch(const void* planes, const void* qidxs, const void* grid
   if (waves < 8) waves = 8;    // the table build uses waves 0..7
   const int min_waves = (3 * (kp >> 4) + 6 * 64 - 1) / (6 * 64);  // 6 x pieces per thread
   if (waves < min_waves) waves = min_waves;
-  int rep = tune.rep ? tune.rep : (kp <= Lds<32>::kMaxKp ? 32 : 16);
-  if (kp > Lds<32>::kMaxKp) rep = 16;
+  const int rep = pick_rep(1, kp, tune.rep);
   const int items_per_wave = (((rpb + 15) >> 4) * (kp >> 9) + waves - 1) / waves;
   int slots = tune.rows ? tune.rows : (items_per_wave >= 4 ? 2 : 1);
   const int threads = waves * 64;
-  if (threads > 512 && slots > 3) slots = 3;  // 128-VGPR budget: deeper queues would spill, and
+  if (threads > 512 && slots > 2) slots = 2;  // 128-VGPR budget: deeper queues would spill, and
                                               // scratch traffic would corrupt the counted vmcnt waits
   GemvGroup<1> gp{{reinterpret_cast<const uint4*>(qidxs)}, {reinterpret_cast<const uint8_t*>(planes)},
                   {reinterpret_cast<f16*>(y)}, {n}, {rpb}};
@@ -789,9 +786,11 @@ int e8p_gemv_mfma_launch(const void* planes, const void* qidxs, const void* grid
   if (rep == R && slots == S && threads > 512)                                                 \
     return launch<R, S, 1024, 1>(gp, grid, k, kp, nblocks, threads, dbg, stream);
   QUIP_CASE(32, 1) QUIP_CASE(32, 2) QUIP_CASE(32, 3) QUIP_CASE(32, 4) QUIP_CASE(32, 6) QUIP_CASE(32, 8)
+  QUIP_CASE(24, 1) QUIP_CASE(24, 2) QUIP_CASE(24, 3) QUIP_CASE(24, 4)
   QUIP_CASE(16, 1) QUIP_CASE(16, 2) QUIP_CASE(16, 3) QUIP_CASE(16, 4) QUIP_CASE(16, 6) QUIP_CASE(16, 8)
-  QUIP_CASE_BIG(32, 1) QUIP_CASE_BIG(32, 2) QUIP_CASE_BIG(32, 3)
-  QUIP_CASE_BIG(16, 1) QUIP_CASE_BIG(16, 2) QUIP_CASE_BIG(16, 3)
+  QUIP_CASE_BIG(32, 1) QUIP_CASE_BIG(32, 2)
+  QUIP_CASE_BIG(24, 1) QUIP_CASE_BIG(24, 2)
+  QUIP_CASE_BIG(16, 1) QUIP_CASE_BIG(16, 2)
 #undef QUIP_CASE
 #undef QUIP_CASE_BIG
   return QUIP_ERR_UNSUPPORTED;
@@ -839,7 +838,7 @@ static int group_launch(const void* const* planes, const void* const* qidxs, con
   const int min_waves = (G * 3 * (kp >> 4) + 6 * 64 - 1) / (6 * 64);
   if (waves < min_waves) waves = min_waves;
   if (waves > 16) return QUIP_ERR_UNSUPPORTED;
-  const int rep = (G * kp <= Lds<32>::kMaxKp && tune.rep != 16) ? 32 : 16;
+  const int rep = pick_rep(G, kp, tune.rep);
   const int slots = tune.rows ? (tune.rows >= 2 ? 2 : 1) : ((items + waves - 1) / waves >= 4 ? 2 : 1);
   const int threads = waves * 64;
   uint64_t* dbg = reinterpret_cast<uint64_t*>(tune.dbg);
@@ -849,7 +848,7 @@ static int group_launch(const void* const* planes, const void* const* qidxs, con
   if (rep == R && slots == S)                                                                  \
     return threads > 512 ? launch<R, S, 1024, G>(gp, grid, k, kp, nblocks, threads, dbg, stream) \
                          : launch<R, S, 512, G>(gp, grid, k, kp, nblocks, threads, dbg, stream);
-  QUIP_CASE(32, 1) QUIP_CASE(32, 2) QUIP_CASE(16, 1) QUIP_CASE(16, 2)
+  QUIP_CASE(32, 1) QUIP_CASE(32, 2) QUIP_CASE(24, 1) QUIP_CASE(24, 2) QUIP_CASE(16, 1) QUIP_CASE(16, 2)
 #undef QUIP_CASE
   return QUIP_ERR_UNSUPPORTED;
 }
