@@ -247,6 +247,7 @@ int quip_e8p_gemv_tuned(const void* x, const void* qidxs, const void* grid, void
   t.max_waves = max_waves; t.digits = digits; t.dbg = dbg;
   if (kernel == 2) return stream_probe_launch(qidxs, y, n, k, t, (hipStream_t)stream);
   if (kernel == 5) return pattern_probe_launch(qidxs, y, n, k, t, (hipStream_t)stream);
+  if (kernel == 6) return shape_probe_launch(qidxs, y, n, k, t, (hipStream_t)stream);
   if (kernel == 4) return e8p_gemv_mfma_launch(x, qidxs, grid, y, n, k, t, (hipStream_t)stream);
   // kernel 4: matrix-core GEMV on linear digit planes; kernel 0: VALU integer GEMV on lane-ordered
   // digit planes; kernel 3: the same converting fp16 x itself

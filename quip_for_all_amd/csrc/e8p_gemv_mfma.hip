@@ -642,6 +642,73 @@ __global__ __launch_bounds__(1024) void pattern_probe_kernel(const uint4* __rest
   if (acc == 0x12345678u) out[0] = acc;
 }
 
+// Streaming probe for the shape of a load instruction: every wave keeps 2 slots x 2 loads in flight
+// over the workgroup's (contiguous) row range like the GEMV does; one load instruction covers
+// R rows x (1024 / R) contiguous bytes (R = 16: the GEMV's pattern, 4, or 1 = fully contiguous).
+template <int R>
+__global__ __launch_bounds__(1024) void shape_probe_kernel(const uint4* __restrict__ W, uint32_t* __restrict__ out,
+                                                          int N, int K, int rows_per_block) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = __builtin_amdgcn_readfirstlane((int)blockDim.x >> 6);
+  const int row0 = blockIdx.x * rows_per_block;
+  const int rows_here = min(N, row0 + rows_per_block) - row0;
+  const int row_u4 = K >> 6;                       // uint4 per row
+  constexpr int CH = 64 / R;                        // uint4 per row per instruction
+  const int chunks = row_u4 / (2 * CH);             // items along a row (2 instructions each)
+  const int rgroups = (rows_here + R - 1) / R;
+  const int cnt = rgroups * chunks;
+  const int lr = lane / CH, lc = lane % CH;         // lane -> (row in group, uint4 in chunk)
+  auto ptr = [&](int it) -> const uint4* {
+    if (it >= cnt) return W + (size_t)lane;
+    const int rg = it / chunks, c = it - rg * chunks;
+    int row = row0 + rg * R + lr;
+    row = row < N ? row : N - 1;
+    return W + (size_t)row * row_u4 + c * 2 * CH + lc;
+  };
+  u32x4 a0, a1, b0, b1;
+  uint32_t acc = 0;
+  {
+    const uint4* p0 = ptr(wave);
+    const uint4* p1 = ptr(wave + nwaves);
+    asm_load16_nt(a0, p0); asm_load16_nt(a1, p0 + CH);
+    asm_load16_nt(b0, p1); asm_load16_nt(b1, p1 + CH);
+  }
+  for (int it = wave; it < cnt; it += 2 * nwaves) {
+    asm_wait_vmcnt<2>(a0, a1);
+    acc ^= a0.x ^ a0.y ^ a0.z ^ a0.w ^ a1.x ^ a1.y ^ a1.z ^ a1.w;
+    asm volatile("" : "+v"(acc));
+    { const uint4* p = ptr(it + 2 * nwaves); asm_load16_nt(a0, p); asm_load16_nt(a1, p + CH); }
+    asm_wait_vmcnt<2>(b0, b1);
+    acc ^= b0.x ^ b0.y ^ b0.z ^ b0.w ^ b1.x ^ b1.y ^ b1.z ^ b1.w;
+    asm volatile("" : "+v"(acc));
+    { const uint4* p = ptr(it + 3 * nwaves); asm_load16_nt(b0, p); asm_load16_nt(b1, p + CH); }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
+}  // namespace
+
+int shape_probe_launch(const void* qidxs, void* out, int n, int k, const GemvTune& tune, hipStream_t stream) {
+  const int ncu = device_cu_count();
+  int nblocks = tune.blocks > 0 ? tune.blocks : ncu;
+  int rpb = (n + nblocks - 1) / nblocks;
+  rpb = (rpb + 15) & ~15;
+  nblocks = (n + rpb - 1) / rpb;
+  const int waves = tune.max_waves > 0 ? tune.max_waves : 8;
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64 * waves), 0, stream, reinterpret_cast<const uint4*>(qidxs),
+                       reinterpret_cast<uint32_t*>(out), n, k, rpb);
+    return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+  };
+  if (tune.rows == 1) return go(shape_probe_kernel<1>);
+  if (tune.rows == 4) return go(shape_probe_kernel<4>);
+  return go(shape_probe_kernel<16>);
+}
+
+namespace {
+
 // x -> plain digit planes [3][Kp] (Kp = K rounded up to 512, zero padded) + shift word.
 __global__ __launch_bounds__(1024) void x_to_planes_linear_kernel(const f16* __restrict__ x,
                                                                   uint8_t* __restrict__ planes,

@@ -35,6 +35,7 @@ size_t e8p_gemv_mfma_planes_bytes(int k);
 int x_to_planes_linear_launch(const void* x, void* planes, int k, hipStream_t stream);
 int e8p_gemv_mfma_launch(const void* planes, const void* qidxs, const void* grid, void* y, int n, int k,
                          const GemvTune& tune, hipStream_t stream);
+int shape_probe_launch(const void* qidxs, void* out, int n, int k, const GemvTune& tune, hipStream_t stream);
 int pattern_probe_launch(const void* qidxs, void* out, int n, int k, const GemvTune& tune, hipStream_t stream);
 
 enum CodebookId { kE8P = 0, kE8PRVQ3 = 1, kE8PRVQ4 = 2, kD4 = 3, kHI = 4 };
