@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QUIP_ABI_VERSION 1
+#define QUIP_ABI_VERSION 2
 
 typedef void* quip_stream_t; /* hipStream_t */
 
@@ -186,6 +186,15 @@ typedef struct quip_had_problem {
   const void* gate;
   int32_t in_features, out_features;
   float scale, rms_eps;
+  /* chain (optional; K == 1 and in_features == n): the input row is the finished output of the
+   * PRODUCER module, computed first from its raw GEMV output z:
+   *   x = z_post_scale (.) (z_scale * H_n z) + z_residual    (qlinear.py:108-114 of the producer)
+   * rounded to fp16 and also stored to h_out (by the first problem of the group).  x is ignored. */
+  const void* z;             /* fp16 [rows, n] or NULL */
+  const void* z_post_scale;  /* fp16 [n] */
+  const void* z_residual;    /* fp16 [rows, n] or NULL */
+  void* h_out;               /* fp16 [rows, n], must not alias z_residual */
+  float z_scale;
 } quip_had_problem;
 int quip_had_transform_group_f16(const quip_had_problem* problems, int32_t count, int64_t rows,
                                  int32_t n, int32_t K, int32_t transpose, quip_stream_t stream);

@@ -47,6 +47,13 @@ struct HadArgs {
   uint8_t* planes;      // digit planes output (rows == 1) or null
   int in_features, out_features, n, Kp, K, L, logL, transpose;
   int vec, vec_out;     // 16-byte vector loads / stores allowed (alignment + multiple-of-8 sizes)
+  // chain: the input row is itself the output side of the producer module, computed here first:
+  //   x = z_post (.) (z_scale * H_n z) + z_res   (rounded to fp16, stored to h_out by the z == 0 problem)
+  const f16* z;         // [rows, n] or null
+  const f16* z_post;    // [n]
+  const f16* z_res;     // [rows, n] or null
+  f16* h_out;           // [rows, n]
+  float z_scale;
   float scale, rms_eps;
 };
 
@@ -169,7 +176,40 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) v[r] = 0.f;
   if constexpr (!TALL) {
-    if (K == 1) {
+    if (K == 1 && a.z) {
+      // producer's output transform + residual first (host guarantees vec, in_features == n == L)
+      const f16* zr = a.z + row * a.n;
+      float tp[16], tr[16];
+      ld8(zr + j0, v); ld8(zr + j0 + 8, v + 8);
+      ld8(a.z_post + j0, tp); ld8(a.z_post + j0 + 8, tp + 8);
+      if (a.z_res) { ld8(a.z_res + row * a.n + j0, tr); ld8(a.z_res + row * a.n + j0 + 8, tr + 8); }
+      had::fht16(v, buf, tid, logL, true);
+      f16 o[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        o[r] = had::out_elem(v[r], a.z_scale, true, tp[r], false, 0.f, a.z_res != nullptr, a.z_res ? tr[r] : 0.f);
+      if (blockIdx.z == 0) {
+        uint4* dst = reinterpret_cast<uint4*>(a.h_out + row * a.n + j0);
+        dst[0] = *reinterpret_cast<uint4*>(&o[0]);
+        dst[1] = *reinterpret_cast<uint4*>(&o[8]);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = (float)o[r];
+      // then the element-wise input ops of this module, as in_vals16 applies them
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float* e = v + 8 * h;
+        const int c = j0 + 8 * h;
+        if (a.rms_w) {
+          had::sumsq8(e, ss_x);
+          had::mul8(e, ldp(a.rms_w + c));
+        }
+        if (a.gate) had::silu_mul8(e, ldp(gr + c));
+        if (a.pre) had::mul8(e, ldp(a.pre + c));
+        if (a.pre2) had::mul8(e, ldp(a.pre2 + c));
+      }
+      __syncthreads();   // the shuffle buffer is reused by the transform below
+    } else if (K == 1) {
       in_vals16(a, xr, gr, kp * L + j0, v, ss_x);
     } else {
       constexpr int U = MAXT <= 256 ? 2 : 1;       // k values per memory round trip
@@ -480,8 +520,8 @@ int check_shape(int in_features, int out_features, int n, int K, const void* had
 int fill(HadArgs& a, const HadProblem& pr, bool planes, int n, int K, int transpose) {
   int rc = check_shape(pr.in_features, planes ? n : pr.out_features, n, K, pr.had, a.L, a.logL);
   if (rc != QUIP_OK) return rc;
-  if (!pr.x || !pr.out) return QUIP_ERR_NULL_POINTER;
-  a.x = reinterpret_cast<const f16*>(pr.x);
+  if ((!pr.x && !pr.z) || !pr.out) return QUIP_ERR_NULL_POINTER;
+  a.x = reinterpret_cast<const f16*>(pr.x ? pr.x : pr.z);
   if (planes) a.planes = reinterpret_cast<uint8_t*>(pr.out); else a.y = reinterpret_cast<f16*>(pr.out);
   a.had = reinterpret_cast<const f16*>(pr.had);
   a.pre = reinterpret_cast<const f16*>(pr.pre);
@@ -492,6 +532,19 @@ int fill(HadArgs& a, const HadProblem& pr, bool planes, int n, int K, int transp
   a.rms_w = reinterpret_cast<const f16*>(pr.rms_weight);
   a.gate = reinterpret_cast<const f16*>(pr.gate);
   a.rms_eps = pr.rms_eps;
+  a.z = reinterpret_cast<const f16*>(pr.z);
+  a.z_post = reinterpret_cast<const f16*>(pr.z_post);
+  a.z_res = reinterpret_cast<const f16*>(pr.z_residual);
+  a.h_out = reinterpret_cast<f16*>(pr.h_out);
+  a.z_scale = pr.z_scale;
+  if (pr.z) {   // chain: plain power-of-two width, blocked kernel, vector access
+    if (K != 1 || pr.in_features != n || a.L < 256 || a.L > 16384) return QUIP_ERR_UNSUPPORTED;
+    if (!pr.z_post || !pr.h_out) return QUIP_ERR_NULL_POINTER;
+    if (pr.h_out == pr.z_residual) return QUIP_ERR_BAD_SHAPE;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(pr.z) | reinterpret_cast<uintptr_t>(pr.z_post) |
+                         reinterpret_cast<uintptr_t>(pr.z_residual) | reinterpret_cast<uintptr_t>(pr.h_out);
+    if (al & 15) return QUIP_ERR_MISALIGNED;
+  }
   a.in_features = pr.in_features; a.out_features = planes ? n : pr.out_features; a.n = n; a.K = K;
   a.Kp = (n + 511) & ~511;
   a.transpose = transpose; a.scale = pr.scale;

@@ -71,6 +71,12 @@ struct HadProblem {
   const void* gate = nullptr;
   int in_features = 0, out_features = 0;
   float scale = 1.f, rms_eps = 1e-5f;
+  // chain (K == 1, in_features == n): x := z_post (.) (z_scale * H_n z) + z_residual, also stored to h_out
+  const void* z = nullptr;
+  const void* z_post = nullptr;
+  const void* z_residual = nullptr;
+  void* h_out = nullptr;
+  float z_scale = 1.f;
 };
 int had_transform_group_launch(const HadProblem* problems, int count, bool planes, int64_t rows, int n, int K,
                                int transpose, hipStream_t stream);

@@ -18,8 +18,8 @@ import torch
 import torch.nn.functional as F
 
 from .codebook import codebook_id
-from .qlinear import (QuantLinear, forward_group, fused_in_supported, gemv_fused, gemv_unfused,
-                      out_transform_group)
+from .qlinear import (QuantLinear, chain_supported, forward_group, fused_in_supported, gemv_chain, gemv_fused,
+                      gemv_unfused, out_transform_group)
 
 
 @dataclass
@@ -121,6 +121,9 @@ class LlamaDecoder:
                                and fused_in_supported([L0["gate"], L0["up"]], prev=L0["o"])
                                and L0["down"].codebook.planes_supported(L0["down"].q_out_features,
                                                                         L0["down"].q_in_features))
+        self.chain = (self.fused_prologue and os.environ.get("QUIP_CHAIN", "1") != "0"
+                      and chain_supported([L0["q"], L0["k"], L0["v"]], L0["down"])
+                      and chain_supported([L0["gate"], L0["up"]], L0["o"]))
 
     # ---- model bytes the decode step has to stream (roofline denominator) -----------
     def algorithmic_bytes_per_token(self):
@@ -183,17 +186,24 @@ class LlamaDecoder:
             if zd is None:
                 _, zs = gemv_fused(qkv, x=h, rms_weight=L["ln1"], rms_eps=s.rms_eps)
             else:   # finishes the previous block: h += down(...)
-                h, zs = gemv_fused(qkv, prev=prev_down, z=zd, residual=h, rms_weight=L["ln1"], rms_eps=s.rms_eps)
+                h, zs = self._zx(qkv, prev_down, zd, h, L["ln1"])
             q, k, v = out_transform_group(qkv, zs)
             a = self._attention(i, q, k, v, cos, sin, mask)
             _, (zo,) = gemv_fused([L["o"]], x=a.reshape(1, s.hidden))
-            h, zgu = gemv_fused([L["gate"], L["up"]], prev=L["o"], z=zo, residual=h, rms_weight=L["ln2"],
-                                rms_eps=s.rms_eps)
+            h, zgu = self._zx([L["gate"], L["up"]], L["o"], zo, h, L["ln2"])
             g, u = out_transform_group([L["gate"], L["up"]], zgu)
             zd = gemv_unfused(L["down"], u, gate=g)
             prev_down = L["down"]
         (h,) = out_transform_group([prev_down], [zd], residual=[h])
         return self._head(h)
+
+    def _zx(self, layers, prev, z, residual, ln):
+        """producer's output side + consumers' input side + GEMV: as a Hadamard chain launch (one
+        workgroup per consumer, in parallel) followed by the grouped GEMV, or inside the GEMV
+        prologue (every workgroup repeats all transforms one after the other)"""
+        if self.chain:
+            return gemv_chain(layers, prev, z, residual=residual, rms_weight=ln, rms_eps=self.s.rms_eps)
+        return gemv_fused(layers, prev=prev, z=z, residual=residual, rms_weight=ln, rms_eps=self.s.rms_eps)
 
     def _head(self, h):
         s = self.s

@@ -319,3 +319,36 @@ def gemv_unfused(layer, x, gate=None, rms_weight=None, rms_eps=1e-5):
         layer.wscale_float / math.sqrt(L_in), layer._vec(rms_weight), rms_eps,
         None if gate is None else gate.reshape(1, -1))
     return layer.codebook.mm_planes(planes, layer.Qidxs)
+
+
+def chain_supported(layers, prev):
+    """can `gemv_chain` fold `prev`'s output side into the input transforms of `layers`?"""
+    l0 = layers[0]
+    cb = l0.codebook
+    n = l0.q_in_features
+    return (hasattr(cb, "planes_group_supported") and 1 <= len(layers) <= 3 and _pow2(n) and 256 <= n <= 16384
+            and all(type(l.codebook) is type(cb) and not l.training and l.K_left == 1 and l.SU is not None
+                    and l.in_features == l.q_in_features == n
+                    and cb.planes_supported(l.q_out_features, n) for l in layers)
+            and cb.planes_group_supported([l.q_out_features for l in layers], n)
+            and prev.K_right == 1 and prev.out_features == prev.q_out_features == n
+            and prev.bias is None and not prev.per_channel and prev.SV is not None)
+
+
+def gemv_chain(layers, prev, z, residual=None, rms_weight=None, rms_eps=1e-5):
+    """Two launches: (1) one Hadamard launch with a workgroup per consumer module that first
+    finishes the producer `prev` (output transform of its raw GEMV output `z`, + `residual`) and
+    then runs its own input transform (RMSNorm, SU, Hadamard -> digit planes); (2) the grouped
+    GEMV.  Returns (h, [z_i]) like gemv_fused."""
+    l0 = layers[0]
+    n = l0.q_in_features
+    res = torch.ops.quip_lib.had_chain_planes_group(
+        z.reshape(1, n), prev._vec(prev.SV), None if residual is None else residual.reshape(1, n),
+        1.0 / math.sqrt(prev.q_out_features // prev.K_right), n, [l._vec(l.SU) for l in layers],
+        [l.wscale_float / math.sqrt(n) for l in layers], None if rms_weight is None else l0._vec(rms_weight), rms_eps)
+    h, planes = res[0], list(res[1:])
+    if len(layers) == 1:
+        zs = [l0.codebook.mm_planes(planes[0], l0.Qidxs)]
+    else:
+        zs = list(torch.ops.quip_lib.e8p_gemv_planes_group(planes, [l.Qidxs for l in layers], l0.codebook.grid_packed_abs))
+    return h, zs

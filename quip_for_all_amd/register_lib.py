@@ -43,6 +43,10 @@ _SCHEMAS = {
     "had_transform_planes_group": "(Tensor x, int n, int K, Tensor?[] had, bool transpose, Tensor?[] pre, "
                                   "float[] scale, Tensor? rms_weight, float rms_eps, Tensor? gate) -> Tensor[]",
     "e8p_gemv_planes_group": "(Tensor[] planes, Tensor[] Qidxs, Tensor grid) -> Tensor[]",
+    # chain: output side of the producer module (z, its SV, residual) + input transforms of 1..3 consumers;
+    # returns [h] + planes
+    "had_chain_planes_group": "(Tensor z, Tensor z_post, Tensor? z_residual, float z_scale, int n, Tensor[] pre, "
+                              "float[] scale, Tensor? rms_weight, float rms_eps) -> Tensor[]",
     "had_transform_group": "(Tensor[] x, int[] out_features, int n, int K, Tensor?[] had, bool transpose, "
                            "Tensor?[] pre2, Tensor?[] post, Tensor?[] bias, float[] scale, Tensor?[] residual) "
                            "-> Tensor[]",
@@ -198,6 +202,28 @@ def _had_transform_planes_group_cuda(x, n, K, had, transpose, pre, scale, rms_we
         capi.check(L.quip_had_transform_planes_group(arr, count, n, K, int(bool(transpose)), _stream(x)),
                    "quip_had_transform_planes_group")
     return outs
+
+
+def _had_chain_planes_group_cuda(z, z_post, z_residual, z_scale, n, pre, scale, rms_weight, rms_eps):
+    zc = _chk_x(z)
+    count = len(pre)
+    _need(zc.shape == (1, n), "had_chain_planes_group is the bs=1 path: z must be (1, n)")
+    _need(1 <= count <= capi.MAX_GROUP and len(scale) == count, "group of 1..3 problems")
+    _need(z_residual is None or tuple(z_residual.shape) == (1, n), "residual shape")
+    L = capi.lib()
+    nbytes = L.quip_e8p_planes_bytes(n)
+    outs = [torch.empty(nbytes, dtype=torch.uint8, device=z.device) for _ in range(count)]
+    h = torch.empty((1, n), dtype=torch.float16, device=z.device)
+    arr = (capi.HadProblem * count)()
+    for i in range(count):
+        arr[i] = capi.HadProblem(None, outs[i].data_ptr(), None, _vec_ok(pre[i], z.device), None, None, None, None,
+                                 _vec_ok(rms_weight, z.device), None, n, n, float(scale[i]), float(rms_eps),
+                                 zc.data_ptr(), _vec_ok(z_post, z.device), _vec_ok(z_residual, z.device),
+                                 h.data_ptr(), float(z_scale))
+    with torch.cuda.device(z.device):
+        capi.check(L.quip_had_transform_planes_group(arr, count, n, 1, 1, _stream(z)),
+                   "quip_had_transform_planes_group (chain)")
+    return [h] + outs
 
 
 def _had_transform_group_cuda(x, out_features, n, K, had, transpose, pre2, post, bias, scale, residual):
@@ -432,6 +458,7 @@ _IMPLS = {
     "rope_attn_decode": _rope_attn_decode_cuda,
     "e8p_gemv_fused": _e8p_gemv_fused_cuda,
     "had_transform_planes_group": _had_transform_planes_group_cuda,
+    "had_chain_planes_group": _had_chain_planes_group_cuda,
     "had_transform_group": _had_transform_group_cuda,
     "e8p_gemv_planes_group": _e8p_gemv_planes_group_cuda,
     "had_transform_fused": _had_transform_fused_cuda,
@@ -471,6 +498,8 @@ _reg_fake("had_transform_planes_fused", lambda x, n, K, had, transpose, pre, sca
           x.new_empty((3 * ((n + 511) // 512 * 512) + 16,), dtype=torch.uint8))
 _reg_fake("had_transform_planes_group", lambda x, n, K, had, transpose, pre, scale, rms_weight, rms_eps, gate:
           [x.new_empty((3 * ((n + 511) // 512 * 512) + 16,), dtype=torch.uint8) for _ in pre])
+_reg_fake("had_chain_planes_group", lambda z, z_post, z_residual, z_scale, n, pre, scale, rms_weight, rms_eps:
+          [z.new_empty((1, n))] + [z.new_empty((3 * ((n + 511) // 512 * 512) + 16,), dtype=torch.uint8) for _ in pre])
 _reg_fake("had_transform_group", lambda x, out_features, n, K, had, transpose, pre2, post, bias, scale, residual:
           [t.new_empty((t.shape[0], int(o))) for t, o in zip(x, out_features)])
 _reg_fake("e8p_gemv_planes_group", lambda planes, Qidxs, grid:

@@ -141,6 +141,10 @@ def test_fused_prologue_step_equals_unfused_step():
     dec.reset(7)
     with torch.no_grad():
         lf = [dec.step().clone() for _ in range(4)]
+    assert dec.chain
+    dec.chain = False          # the same step with every transform inside the GEMV prologues
+    prologue_tokens = dec.generate(10, first_token=7, use_graph=False)
+    assert torch.equal(prologue_tokens, fused_tokens)
     dec.fused_prologue = False
     plain_tokens = dec.generate(10, first_token=7, use_graph=False)
     dec.reset(7)
@@ -149,7 +153,7 @@ def test_fused_prologue_step_equals_unfused_step():
     assert torch.equal(fused_tokens, plain_tokens)
     for a, b in zip(lf, lp):
         assert torch.equal(a, b)
-    dec.fused_prologue = True
+    dec.fused_prologue = dec.chain = True
     graph_tokens = dec.generate(10, first_token=7, use_graph=True)
     assert torch.equal(graph_tokens, fused_tokens)
     ref = _ref_logits(dec, [7, int(fused_tokens[0]), int(fused_tokens[1])])

@@ -209,3 +209,29 @@ def test_gemv_fused_prologue_bit_identical(k, fouts, with_prev, with_rms):
             [l.wscale_float / np.sqrt(k) for l in layers], w, 1e-5, None)
         for l, pl, zf in zip(layers, planes, zs):
             assert torch.equal(zf, torch.ops.quip_lib.e8p_gemv_planes(pl, l.Qidxs, l.codebook.grid_packed_abs))
+
+
+@pytest.mark.parametrize("k,fouts,with_rms,with_res", [(4096, (4096, 4096, 4096), True, True), (4096, (11008, 11008), True, True),
+                                                       (1024, (1024, 512, 512), True, False), (8192, (8192,), False, True),
+                                                       (256, (256, 128), True, True)])
+def test_gemv_chain_bit_identical(k, fouts, with_rms, with_res):
+    """Hadamard chain launch (producer's output side + consumers' input side) + grouped GEMV ==
+    the separate launches, bit for bit"""
+    from quip_for_all_amd import qlinear as QL
+    layers = [_layer(O.make_layer("E8P12", k, fo, seed=k + fo + i)) for i, fo in enumerate(fouts)]
+    prev = _layer(O.make_layer("E8P12", 512, k, seed=k + 11))
+    assert QL.chain_supported(layers, prev)
+    rng = np.random.default_rng(k)
+    t = lambda a: torch.from_numpy(a.astype(np.float16)).to(DEV)  # noqa: E731
+    w = t(1 + 0.1 * rng.standard_normal(k)) if with_rms else None
+    z = t(rng.standard_normal((1, k)) * 8)
+    res = t(rng.standard_normal((1, k))) if with_res else None
+    with torch.no_grad():
+        h, zs = QL.gemv_chain(layers, prev, z, residual=res, rms_weight=w)
+        (h_ref,) = QL.out_transform_group([prev], [z], residual=[res])
+        assert torch.equal(h, h_ref)
+        planes = torch.ops.quip_lib.had_transform_planes_group(
+            h_ref, k, 1, [None] * len(layers), True, [l._vec(l.SU) for l in layers],
+            [l.wscale_float / np.sqrt(k) for l in layers], w, 1e-5, None)
+        for l, pl, zf in zip(layers, planes, zs):
+            assert torch.equal(zf, torch.ops.quip_lib.e8p_gemv_planes(pl, l.Qidxs, l.codebook.grid_packed_abs))
