@@ -296,6 +296,7 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
     __syncthreads();
     const int g = tid >> logL, j = tid & (L - 1);
     const float* hg = hs + g * 16;
+#pragma unroll 4   // batches the LDS reads of 4 k steps (one wave per SIMD: nothing else hides their latency)
     for (int k = 0; k < K; ++k) {
       const float e = xs[(k << logL) + j];
       const float4* h4 = reinterpret_cast<const float4*>(hg + k * R);
