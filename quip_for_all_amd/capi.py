@@ -5,7 +5,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libquip_mi355.so")
+LIB_PATH = os.environ.get("QUIP_LIB_PATH") or os.path.join(_HERE, "lib", "libquip_mi355.so")   # override: debug builds
 
 _c = ctypes
 _P, _I32, _I64, _F = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_float

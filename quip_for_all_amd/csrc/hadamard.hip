@@ -31,6 +31,16 @@
 
 namespace quip {
 
+#ifdef QUIP_HAD_STAMPS
+__device__ unsigned long long g_had_stamps[16];
+#define HSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.z == 0) g_had_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int quip_had_read_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_had_stamps), sizeof(g_had_stamps)) == hipSuccess ? 0 : -1;
+}
+#else
+#define HSTAMP(i) do {} while (0)
+#endif
+
 namespace {
 
 struct HadArgs {
@@ -165,11 +175,17 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
   const f16* xr = a.x + row * a.in_features;
   const f16* gr = a.gate ? a.gate + row * a.in_features : nullptr;
   const int L = a.L, K = a.K, logL = a.logL;
-  const int R = TALL ? (16 * nt) >> logL : 1;
+  // tall: the tile is 4096 elements = 256 "tile threads" x 16; the workgroup has 4 x 256 threads that
+  // share the row staging and split the k range of the K-mix; threads >= 256 then only keep barriers
+  constexpr int kTile = 256;
+  const bool act = !TALL || tid < kTile;
+  const int nta = TALL ? kTile : nt;              // threads that hold transform data
+  const int R = TALL ? (16 * kTile) >> logL : 1;
   const int kp0 = blockIdx.x * R;
   const int e0 = tid * 16;                         // first of this thread's 16 elements of [R][L]
   const int kp = kp0 + (e0 >> logL), j0 = e0 & (L - 1);
 
+  HSTAMP(0);
   // (1) load + K-mix; sums for rms / the planes bound
   float v[16];
   float ss_x = 0.f, ss_in = 0.f;
@@ -252,38 +268,26 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
       }
     }
   } else {
-    float* hs = buf + (16 * nt + ((16 * nt) >> 5) + 4);   // [K][R] tile of H (rows kp0..kp0+R)
+    float* hs = buf + had::buf_floats(16 * kTile);        // [K][R] tile of H (rows kp0..kp0+R)
     for (int i = tid; i < K * R; i += nt) {
       const int k = i / R, rr = i - k * R, kq = kp0 + rr;
       hs[i] = kq < K ? (float)(a.transpose ? a.had[k * K + kq] : a.had[kq * K + k]) : 0.f;
     }
-    __syncthreads();
+    HSTAMP(1);
     // stage the pre-processed input row in LDS (one memory round trip for the whole row)
     float* xs = hs + K * R;
+    float* part = xs + a.n;                               // [3][16][256] partial K-mix sums
     if (a.vec) {
-      constexpr int U = 3;
-      for (int c0 = 0; c0 * 16 < a.n; c0 += U * nt) {
-        Raw16 raw[U];
+      for (int c = tid; c * 16 < a.n; c += nt) {
+        Raw16 raw;
+        raw_load16(a, xr, gr, c * 16, raw);
+        float e[16];
+        raw_math16(a, c * 16, raw, e, ss_x);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int c = c0 + u * nt + tid;
-          raw_load16(a, xr, gr, c * 16 < a.n ? c * 16 : 0, raw[u]);
-        }
+        for (int r = 0; r < 16; ++r) ss_in = __builtin_fmaf(e[r], e[r], ss_in);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int c = c0 + u * nt + tid;
-          float e[16];
-          float sx = 0.f;
-          raw_math16(a, c * 16 < a.n ? c * 16 : 0, raw[u], e, sx);
-          if (c * 16 < a.n) {
-            ss_x += sx;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ss_in = __builtin_fmaf(e[r], e[r], ss_in);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              *reinterpret_cast<float4*>(xs + c * 16 + 4 * q) = make_float4(e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]);
-          }
-        }
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(xs + c * 16 + 4 * q) = make_float4(e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]);
       }
     } else {
       for (int i = tid; i < a.n; i += nt) {
@@ -294,10 +298,16 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
       }
     }
     __syncthreads();
-    const int g = tid >> logL, j = tid & (L - 1);
+    HSTAMP(2);
+    // K-mix: thread group tg takes the k range [tg * kq, (tg + 1) * kq); tile thread t owns column j of
+    // 16 rows
+    const int ngroups = nt / kTile, tg = tid / kTile, t = tid - tg * kTile;
+    const int kq = (K + ngroups - 1) / ngroups;
+    const int k_lo = tg * kq, k_hi = min(K, k_lo + kq);
+    const int g = t >> logL, j = t & (L - 1);
     const float* hg = hs + g * 16;
-#pragma unroll 4   // batches the LDS reads of 4 k steps (one wave per SIMD: nothing else hides their latency)
-    for (int k = 0; k < K; ++k) {
+#pragma unroll 4   // batches the LDS reads of 4 k steps
+    for (int k = k_lo; k < k_hi; ++k) {
       const float e = xs[(k << logL) + j];
       const float4* h4 = reinterpret_cast<const float4*>(hg + k * R);
 #pragma unroll
@@ -309,12 +319,26 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
         v[4 * q + 3] = __builtin_fmaf(h.w, e, v[4 * q + 3]);
       }
     }
-    // (row, column) ownership -> 16 consecutive elements per thread
+    if (tg > 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) buf[pad(((g * 16 + r) << logL) + j)] = v[r];
+      for (int r = 0; r < 16; ++r) part[((tg - 1) * 16 + r) * kTile + t] = v[r];
+    }
     __syncthreads();
+    HSTAMP(3);
+    if (act) {
+      for (int o = 1; o < ngroups; ++o) {   // fixed order: group 0 + 1 + 2 + 3
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = buf[pad(e0 + r)];
+        for (int r = 0; r < 16; ++r) v[r] = had::fadd(v[r], part[((o - 1) * 16 + r) * kTile + t]);
+      }
+      // (row, column) ownership -> 16 consecutive elements per thread
+#pragma unroll
+      for (int r = 0; r < 16; ++r) buf[pad(((g * 16 + r) << logL) + j)] = v[r];
+    }
+    __syncthreads();
+    if (act) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = buf[pad(e0 + r)];
+    }
     __syncthreads();
   }
   float scale = a.scale;
@@ -324,15 +348,17 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
     scale = had::rms_scale(a.scale, tot, a.in_features, a.rms_eps);
   }
 
+  HSTAMP(4);
   // (2) length-L transform: 4 index bits per pass in registers, LDS re-shuffle in between
-  had::fht16(v, buf, tid, logL, true);
-  const bool live = kp < K;                       // rows past K in the last tall workgroup
+  had::fht16(v, buf, tid, logL, act);
+  HSTAMP(5);
+  const bool live = act && kp < K;                // rows past K in the last tall workgroup
 
   // (3) epilogue
   if constexpr (PLANES) {
     float bound;
     if (K == 1) {
-      bound = block_reduce(had::absmax16(v, scale), true, red, tid, nt);
+      bound = block_reduce(act ? had::absmax16(v, scale) : 0.f, true, red, tid, nta);
     } else {
       bound = sqrtf(block_reduce(ss_in, false, red, tid, nt)) * sqrtf((float)L) * fabsf(scale) * 1.0625f;
     }
@@ -378,6 +404,7 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
       }
     }
   }
+  HSTAMP(6);
 }
 
 // simple LDS radix-2 version for lengths the blocked kernel does not take
@@ -488,10 +515,10 @@ int launch(HadGroup& g, int count, int64_t rows, hipStream_t stream) {
   static int cfg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (K > 1 && L >= 64 && L <= 256) {   // tall: 256 threads, R = 4096 / L rows per workgroup
     const int R = 4096 / L;
-    const int lds = (4096 + 128 + 4 + K * R + n) * 4;
+    const int lds = (had::buf_floats(4096) + K * R + n + 3 * 4096) * 4;
     const dim3 grid((K + R - 1) / R, (unsigned)rows, count);
-    return planes ? launch_one(had_fast_kernel<true, true, 256>, cfg[0], g, grid, 256, lds, stream)
-                  : launch_one(had_fast_kernel<false, true, 256>, cfg[1], g, grid, 256, lds, stream);
+    return planes ? launch_one(had_fast_kernel<true, true, 1024>, cfg[0], g, grid, 1024, lds, stream)
+                  : launch_one(had_fast_kernel<false, true, 1024>, cfg[1], g, grid, 1024, lds, stream);
   }
   const dim3 grid(K, (unsigned)rows, count);
   if (L >= 256 && L <= 16384) {
