@@ -269,14 +269,14 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
     }
   } else {
     float* hs = buf + had::buf_floats(16 * kTile);        // [K][R] tile of H (rows kp0..kp0+R)
-    for (int i = tid; i < K * R; i += nt) {
+    for (int i = tid; i < ((K + 3) & ~3) * R; i += nt) {
       const int k = i / R, rr = i - k * R, kq = kp0 + rr;
-      hs[i] = kq < K ? (float)(a.transpose ? a.had[k * K + kq] : a.had[kq * K + k]) : 0.f;
+      hs[i] = (kq < K && k < K) ? (float)(a.transpose ? a.had[k * K + kq] : a.had[kq * K + k]) : 0.f;
     }
     HSTAMP(1);
     // stage the pre-processed input row in LDS (one memory round trip for the whole row)
-    float* xs = hs + K * R;
-    float* part = xs + a.n;                               // [3][16][256] partial K-mix sums
+    float* xs = hs + ((K + 3) & ~3) * R;                  // [K][L + 8] (padded rows: fewer bank conflicts)
+    const int xstride = L + 8;
     if (a.vec) {
       for (int c = tid; c * 16 < a.n; c += nt) {
         Raw16 raw;
@@ -285,55 +285,46 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
         raw_math16(a, c * 16, raw, e, ss_x);
 #pragma unroll
         for (int r = 0; r < 16; ++r) ss_in = __builtin_fmaf(e[r], e[r], ss_in);
+        float* dst = xs + ((c * 16) >> logL) * xstride + ((c * 16) & (L - 1));
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<float4*>(xs + c * 16 + 4 * q) = make_float4(e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]);
+          *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]);
       }
     } else {
       for (int i = tid; i < a.n; i += nt) {
         const float e = in_val(a, xr, gr, i);
         if (a.rms_w && i < a.in_features) { const float xv = (float)xr[i]; ss_x = __builtin_fmaf(xv, xv, ss_x); }
         ss_in = __builtin_fmaf(e, e, ss_in);
-        xs[i] = e;
+        xs[(i >> logL) * xstride + (i & (L - 1))] = e;
       }
     }
     __syncthreads();
     HSTAMP(2);
-    // K-mix: thread group tg takes the k range [tg * kq, (tg + 1) * kq); tile thread t owns column j of
-    // 16 rows
-    const int ngroups = nt / kTile, tg = tid / kTile, t = tid - tg * kTile;
-    const int kq = (K + ngroups - 1) / ngroups;
-    const int k_lo = tg * kq, k_hi = min(K, k_lo + kq);
-    const int g = t >> logL, j = t & (L - 1);
-    const float* hg = hs + g * 16;
-#pragma unroll 4   // batches the LDS reads of 4 k steps
-    for (int k = k_lo; k < k_hi; ++k) {
-      const float e = xs[(k << logL) + j];
-      const float4* h4 = reinterpret_cast<const float4*>(hg + k * R);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 h = h4[q];
-        v[4 * q + 0] = __builtin_fmaf(h.x, e, v[4 * q + 0]);
-        v[4 * q + 1] = __builtin_fmaf(h.y, e, v[4 * q + 1]);
-        v[4 * q + 2] = __builtin_fmaf(h.z, e, v[4 * q + 2]);
-        v[4 * q + 3] = __builtin_fmaf(h.w, e, v[4 * q + 3]);
+    // K-mix on the matrix cores (fp32 in, fp32 accumulate): out[r][j] = sum_k H[kp0 + r][k] x[k][j] is
+    // (R / 16) x (L / 16) = 16 tiles of 16 x 16, one per wave; v_mfma_f32_16x16x4_f32 takes
+    // A[row = l & 15][k = l >> 4], B[k = l >> 4][col = l & 15].  (Read through LDS broadcasts the H
+    // tile costs 64 lanes x 16 B of LDS return bandwidth per k and row group: measured 5.3K cycles.)
+    {
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      const int wave = tid >> 6, lane = tid & 63;
+      const int ctiles = L >> 4;
+      const int rt = wave / ctiles, ct = wave - rt * ctiles;
+      const int lr = lane & 15, lq = lane >> 4;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float* hp = hs + rt * 16 + lr;                 // + k * R
+      const float* xp = xs + ct * 16 + lr;                 // + k * xstride
+      for (int k0 = 0; k0 < K; k0 += 4) {
+        const int k = k0 + lq;
+        const float av = hp[k * R];                        // rows of H past K are zero filled below
+        const float bv = xp[min(k, K - 1) * xstride];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
       }
-    }
-    if (tg > 0) {
+      // D[row = 4 * (l >> 4) + i][col = l & 15] -> [row][col] image of the tile
 #pragma unroll
-      for (int r = 0; r < 16; ++r) part[((tg - 1) * 16 + r) * kTile + t] = v[r];
+      for (int i = 0; i < 4; ++i)
+        buf[pad(((rt * 16 + 4 * lq + i) << logL) + ct * 16 + lr)] = acc[i];
     }
-    __syncthreads();
     HSTAMP(3);
-    if (act) {
-      for (int o = 1; o < ngroups; ++o) {   // fixed order: group 0 + 1 + 2 + 3
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = had::fadd(v[r], part[((o - 1) * 16 + r) * kTile + t]);
-      }
-      // (row, column) ownership -> 16 consecutive elements per thread
-#pragma unroll
-      for (int r = 0; r < 16; ++r) buf[pad(((g * 16 + r) << logL) + j)] = v[r];
-    }
     __syncthreads();
     if (act) {
 #pragma unroll
@@ -515,7 +506,7 @@ int launch(HadGroup& g, int count, int64_t rows, hipStream_t stream) {
   static int cfg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (K > 1 && L >= 64 && L <= 256) {   // tall: 256 threads, R = 4096 / L rows per workgroup
     const int R = 4096 / L;
-    const int lds = (had::buf_floats(4096) + K * R + n + 3 * 4096) * 4;
+    const int lds = (had::buf_floats(4096) + ((K + 3) & ~3) * R + K * (L + 8)) * 4;
     const dim3 grid((K + R - 1) / R, (unsigned)rows, count);
     return planes ? launch_one(had_fast_kernel<true, true, 1024>, cfg[0], g, grid, 1024, lds, stream)
                   : launch_one(had_fast_kernel<false, true, 1024>, cfg[1], g, grid, 1024, lds, stream);
