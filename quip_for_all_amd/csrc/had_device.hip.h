@@ -67,9 +67,12 @@ __device__ __forceinline__ float wave_reduce_to_lane63(float v) {
 // workgroup must call it (barriers), threads >= nt contribute nothing.  Fixed order: DPP tree
 // inside a wave, then waves 0, 1, 2, ... -> the same value wherever the same data is reduced.
 // is_max: values must be >= 0.
-__device__ __forceinline__ float block_reduce(float v, bool is_max, float* red, int tid, int nt) {
+// lead_barrier = false: the caller guarantees that nobody can still be reading `red` (a slot
+// used once per kernel), which saves one barrier.
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* red, int tid, int nt,
+                                              bool lead_barrier = true) {
   v = is_max ? wave_reduce_to_lane63<true>(v) : wave_reduce_to_lane63<false>(v);
-  __syncthreads();
+  if (lead_barrier) __syncthreads();
   if ((tid & 63) == 63 && tid < nt) red[tid >> 6] = v;
   if (nt < 64 && tid == nt - 1) red[0] = v;   // (not used by the blocked kernels: nt >= 64 there)
   __syncthreads();
@@ -156,45 +159,57 @@ struct FhtPass {
   }
 };
 
-template <int LOGL, int P>
-__device__ __forceinline__ void fht16_passes(float v[16], float* buf, int t, bool active) {
+// PP (ping-pong): pass P stores to half (P & 1) of a buffer of 2 * buf_floats(E) floats, so that a
+// pass needs ONE barrier (store -> barrier -> load) instead of two; one more barrier at entry
+// protects the buffer from earlier readers.  Same data movement, same results.
+template <int LOGL, int P, bool PP>
+__device__ __forceinline__ void fht16_passes(float v[16], float* buf, int stride, int t, bool active) {
   constexpr int NPASS = (LOGL + 3) / 4;
   if constexpr (P < NPASS) {
     using Pass = FhtPass<LOGL, P>;
-    if (P > 0 && active) Pass::load(v, buf, t);
+    float* cur = PP ? buf + (P & 1) * stride : buf;
+    float* prev = PP ? buf + ((P + 1) & 1) * stride : buf;
+    if (P > 0 && active) Pass::load(v, prev, t);
     Pass::butterflies(v);
     if (NPASS > 1) {
-      __syncthreads();  // everyone has read its pass-P inputs
-      if (active) Pass::store(v, buf, t);
+      if (!PP || P == 0) __syncthreads();  // !PP: everyone has read its pass-P inputs; PP: entry barrier
+      if (active) Pass::store(v, cur, t);
       __syncthreads();
     }
-    fht16_passes<LOGL, P + 1>(v, buf, t, active);
+    fht16_passes<LOGL, P + 1, PP>(v, buf, stride, t, active);
   }
 }
 
-template <int LOGL>
-__device__ __forceinline__ void fht16_fixed(float v[16], float* buf, int t, bool active) {
-  fht16_passes<LOGL, 0>(v, buf, t, active);
+template <int LOGL, bool PP>
+__device__ __forceinline__ void fht16_fixed(float v[16], float* buf, int stride, int t, bool active) {
+  fht16_passes<LOGL, 0, PP>(v, buf, stride, t, active);
+  constexpr int NPASS = (LOGL + 3) / 4;
   if (LOGL > 4 && active) {  // back to 16 consecutive elements per thread
-    const float* b = buf + (16 * t + ((16 * t) >> 5));
+    const float* b = buf + (PP ? ((NPASS - 1) & 1) * stride : 0) + (16 * t + ((16 * t) >> 5));
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = b[r];
   }
 }
 
-// run-time dispatch over the lengths the kernels take (2^8 .. 2^14)
-__device__ __forceinline__ void fht16(float v[16], float* buf, int t, int logL, bool active) {
+// run-time dispatch over the lengths the kernels take (2^6 .. 2^14).  pp_stride = 0: single buffer;
+// otherwise the distance (floats) between the two halves of a ping-pong buffer.
+template <bool PP>
+__device__ __forceinline__ void fht16_dispatch(float v[16], float* buf, int stride, int t, int logL, bool active) {
   switch (logL) {
-    case 6: fht16_fixed<6>(v, buf, t, active); break;
-    case 7: fht16_fixed<7>(v, buf, t, active); break;
-    case 8: fht16_fixed<8>(v, buf, t, active); break;
-    case 9: fht16_fixed<9>(v, buf, t, active); break;
-    case 10: fht16_fixed<10>(v, buf, t, active); break;
-    case 11: fht16_fixed<11>(v, buf, t, active); break;
-    case 12: fht16_fixed<12>(v, buf, t, active); break;
-    case 13: fht16_fixed<13>(v, buf, t, active); break;
-    default: fht16_fixed<14>(v, buf, t, active); break;
+    case 6: fht16_fixed<6, PP>(v, buf, stride, t, active); break;
+    case 7: fht16_fixed<7, PP>(v, buf, stride, t, active); break;
+    case 8: fht16_fixed<8, PP>(v, buf, stride, t, active); break;
+    case 9: fht16_fixed<9, PP>(v, buf, stride, t, active); break;
+    case 10: fht16_fixed<10, PP>(v, buf, stride, t, active); break;
+    case 11: fht16_fixed<11, PP>(v, buf, stride, t, active); break;
+    case 12: fht16_fixed<12, PP>(v, buf, stride, t, active); break;
+    case 13: fht16_fixed<13, PP>(v, buf, stride, t, active); break;
+    default: fht16_fixed<14, PP>(v, buf, stride, t, active); break;
   }
+}
+__device__ __forceinline__ void fht16(float v[16], float* buf, int t, int logL, bool active, int pp_stride = 0) {
+  if (pp_stride) fht16_dispatch<true>(v, buf, pp_stride, t, logL, active);
+  else fht16_dispatch<false>(v, buf, 0, t, logL, active);
 }
 
 // digit split of a block fixed point value (balanced int8 digits, see e8p_gemv_i8.hip)

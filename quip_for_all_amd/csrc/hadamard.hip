@@ -64,6 +64,7 @@ struct HadArgs {
   const f16* z_res;     // [rows, n] or null
   f16* h_out;           // [rows, n]
   float z_scale;
+  int pp;               // floats between the two halves of the ping-pong shuffle buffer (0: single buffer)
   float scale, rms_eps;
 };
 
@@ -169,7 +170,7 @@ template <bool PLANES, bool TALL, int MAXT>
 __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
   const HadArgs a = grp.p[blockIdx.z];
   extern __shared__ __attribute__((aligned(16))) float buf[];
-  __shared__ float red[16];
+  __shared__ float red[32];     // two slots, each used once: no barrier before their writes
   const int tid = threadIdx.x, nt = blockDim.x;   // nt == E / 16
   const int64_t row = blockIdx.y;
   const f16* xr = a.x + row * a.in_features;
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
       ld8(zr + j0, v); ld8(zr + j0 + 8, v + 8);
       ld8(a.z_post + j0, tp); ld8(a.z_post + j0 + 8, tp + 8);
       if (a.z_res) { ld8(a.z_res + row * a.n + j0, tr); ld8(a.z_res + row * a.n + j0 + 8, tr + 8); }
-      had::fht16(v, buf, tid, logL, true);
+      had::fht16(v, buf, tid, logL, true, a.pp);
       f16 o[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r)
@@ -335,13 +336,13 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
   float scale = a.scale;
   if (a.rms_w) {
     // every workgroup sees the whole input row (K == 1: it is the row; K > 1: the k loop)
-    const float tot = block_reduce(ss_x, false, red, tid, nt);
+    const float tot = block_reduce(ss_x, false, red, tid, nt, false);
     scale = had::rms_scale(a.scale, tot, a.in_features, a.rms_eps);
   }
 
   HSTAMP(4);
   // (2) length-L transform: 4 index bits per pass in registers, LDS re-shuffle in between
-  had::fht16(v, buf, tid, logL, act);
+  had::fht16(v, buf, tid, logL, act, a.pp);
   HSTAMP(5);
   const bool live = act && kp < K;                // rows past K in the last tall workgroup
 
@@ -349,9 +350,9 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
   if constexpr (PLANES) {
     float bound;
     if (K == 1) {
-      bound = block_reduce(act ? had::absmax16(v, scale) : 0.f, true, red, tid, nta);
+      bound = block_reduce(act ? had::absmax16(v, scale) : 0.f, true, red + 16, tid, nta, false);
     } else {
-      bound = sqrtf(block_reduce(ss_in, false, red, tid, nt)) * sqrtf((float)L) * fabsf(scale) * 1.0625f;
+      bound = sqrtf(block_reduce(ss_in, false, red + 16, tid, nt, false)) * sqrtf((float)L) * fabsf(scale) * 1.0625f;
     }
     const int sh = had::shift_for(bound);
     if (blockIdx.x == 0 && tid == 0) *reinterpret_cast<int*>(a.planes + (size_t)3 * a.Kp) = sh;
@@ -506,14 +507,18 @@ int launch(HadGroup& g, int count, int64_t rows, hipStream_t stream) {
   static int cfg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (K > 1 && L >= 64 && L <= 256) {   // tall: 256 threads, R = 4096 / L rows per workgroup
     const int R = 4096 / L;
-    const int lds = (had::buf_floats(4096) + ((K + 3) & ~3) * R + K * (L + 8)) * 4;
+    // [shuffle buffer | H tile | x rows | second half of the ping-pong buffer]
+    const int pp = had::buf_floats(4096) + ((K + 3) & ~3) * R + K * (L + 8);
+    const int lds = (pp + had::buf_floats(4096)) * 4;
+    for (int i = 0; i < count; ++i) g.p[i].pp = pp;
     const dim3 grid((K + R - 1) / R, (unsigned)rows, count);
     return planes ? launch_one(had_fast_kernel<true, true, 1024>, cfg[0], g, grid, 1024, lds, stream)
                   : launch_one(had_fast_kernel<false, true, 1024>, cfg[1], g, grid, 1024, lds, stream);
   }
   const dim3 grid(K, (unsigned)rows, count);
   if (L >= 256 && L <= 16384) {
-    const int lds = (L + (L >> 5) + 4) * 4;
+    const int lds = 2 * had::buf_floats(L) * 4;
+    for (int i = 0; i < count; ++i) g.p[i].pp = had::buf_floats(L);
     if (L <= 4096)
       return planes ? launch_one(had_fast_kernel<true, false, 256>, cfg[2], g, grid, L / 16, lds, stream)
                     : launch_one(had_fast_kernel<false, false, 256>, cfg[3], g, grid, L / 16, lds, stream);
