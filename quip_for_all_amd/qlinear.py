@@ -212,20 +212,30 @@ def forward_group(layers, input, rms_weight=None, rms_eps=1e-5, residual=None):
     l0 = layers[0]
     cb = l0.codebook
     residual = residual if residual is not None else [None] * len(layers)
-    ok = (1 < len(layers) <= 3 and x.shape[0] == 1 and x.dtype == torch.float16 and not l0.training
-          and hasattr(cb, "mm_planes")
-          and all(type(l.codebook) is type(cb) and l.in_features == l0.in_features
-                  and l.q_in_features == l0.q_in_features and l.K_left == l0.K_left
-                  and cb.planes_supported(l.q_out_features, l.q_in_features) for l in layers)
-          and cb.planes_group_supported([l.q_out_features for l in layers], l0.q_in_features))
-    if not ok:
+    same_in = (1 < len(layers) <= 3 and x.dtype == torch.float16 and not l0.training and x.shape[0] >= 1
+               and all(type(l.codebook) is type(cb) and l.in_features == l0.in_features
+                       and l.q_in_features == l0.q_in_features and l.K_left == l0.K_left for l in layers))
+    planes_ok = (same_in and x.shape[0] == 1 and hasattr(cb, "mm_planes")
+                 and all(cb.planes_supported(l.q_out_features, l.q_in_features) for l in layers)
+                 and cb.planes_group_supported([l.q_out_features for l in layers], l0.q_in_features))
+    if not same_in:
         return [l.forward_fused(input, rms_weight=rms_weight, rms_eps=rms_eps, residual=r)
                 for l, r in zip(layers, residual)]
     L_in = l0.q_in_features // l0.K_left
-    planes = torch.ops.quip_lib.had_transform_planes_group(
-        x, l0.q_in_features, l0.K_left, [l._had("had_left") for l in layers], True, [l._vec(l.SU) for l in layers],
-        [l.wscale_float / math.sqrt(L_in) for l in layers], l0._vec(rms_weight), rms_eps, None)
-    zs = torch.ops.quip_lib.e8p_gemv_planes_group(planes, [l.Qidxs for l in layers], cb.grid_packed_abs)
+    if planes_ok:
+        planes = torch.ops.quip_lib.had_transform_planes_group(
+            x, l0.q_in_features, l0.K_left, [l._had("had_left") for l in layers], True,
+            [l._vec(l.SU) for l in layers], [l.wscale_float / math.sqrt(L_in) for l in layers],
+            l0._vec(rms_weight), rms_eps, None)
+        zs = torch.ops.quip_lib.e8p_gemv_planes_group(planes, [l.Qidxs for l in layers], cb.grid_packed_abs)
+    else:
+        # any codebook / any batch: grouped fp16 input transforms, one codebook product per module
+        n = len(layers)
+        xh = torch.ops.quip_lib.had_transform_group(
+            [x] * n, [l0.q_in_features] * n, l0.q_in_features, l0.K_left, [l._had("had_left") for l in layers], True,
+            [None] * n, [None] * n, [None] * n, [l.wscale_float / math.sqrt(L_in) for l in layers], [None] * n,
+            [l._vec(l.SU) for l in layers], l0._vec(rms_weight), rms_eps)
+        zs = [l.codebook(h, l.Qidxs) for l, h in zip(layers, xh)]
     # output transforms: one launch per set of modules with the same (q_out, K_right)
     ys = [None] * len(layers)
     todo = list(range(len(layers)))
@@ -240,7 +250,8 @@ def forward_group(layers, input, rms_weight=None, rms_eps=1e-5, residual=None):
             [zs[i] for i in same], [l.out_features for l in ls], ls[0].q_out_features, ls[0].K_right,
             [l._had("had_right") for l in ls], False, [l._vec(l.Wscale) if l.per_channel else None for l in ls],
             [l._vec(l.SV) for l in ls], [l._vec(l.bias) for l in ls], [1.0 / math.sqrt(L_out)] * len(ls),
-            [None if residual[i] is None else residual[i].reshape(1, -1).to(torch.float16) for i in same])
+            [None if residual[i] is None else residual[i].reshape(x.shape[0], -1).to(torch.float16) for i in same],
+            [None] * len(ls), None, rms_eps)
         for i, o in zip(same, outs):
             ys[i] = o.view(*input.shape[:-1], layers[i].out_features)
     return ys
@@ -305,7 +316,8 @@ def out_transform_group(layers, zs, residual=None):
             [zs[i] for i in same], [l.out_features for l in ls], ls[0].q_out_features, ls[0].K_right,
             [l._had("had_right") for l in ls], False, [l._vec(l.Wscale) if l.per_channel else None for l in ls],
             [l._vec(l.SV) for l in ls], [l._vec(l.bias) for l in ls], [1.0 / math.sqrt(L_out)] * len(ls),
-            [None if residual[i] is None else residual[i].reshape(1, -1).to(torch.float16) for i in same])
+            [None if residual[i] is None else residual[i].reshape(1, -1).to(torch.float16) for i in same],
+            [None] * len(ls), None, 1e-5)
         for i, o in zip(same, outs):
             ys[i] = o
     return ys

@@ -48,8 +48,8 @@ _SCHEMAS = {
     "had_chain_planes_group": "(Tensor z, Tensor z_post, Tensor? z_residual, float z_scale, int n, Tensor[] pre, "
                               "float[] scale, Tensor? rms_weight, float rms_eps) -> Tensor[]",
     "had_transform_group": "(Tensor[] x, int[] out_features, int n, int K, Tensor?[] had, bool transpose, "
-                           "Tensor?[] pre2, Tensor?[] post, Tensor?[] bias, float[] scale, Tensor?[] residual) "
-                           "-> Tensor[]",
+                           "Tensor?[] pre2, Tensor?[] post, Tensor?[] bias, float[] scale, Tensor?[] residual, "
+                           "Tensor?[] pre, Tensor? rms_weight, float rms_eps) -> Tensor[]",
     # GEMV(s) with the input side computed in the prologue: [h_out]? + [y_i]; see quip_e8p_gemv_fused
     "e8p_gemv_fused": "(Tensor? x, Tensor? z, Tensor? post, Tensor? residual, Tensor? rms_weight, float rms_eps, "
                       "float z_scale, Tensor[] pre, float[] scale, Tensor[] Qidxs, Tensor grid) -> Tensor[]",
@@ -226,10 +226,11 @@ def _had_chain_planes_group_cuda(z, z_post, z_residual, z_scale, n, pre, scale, 
     return [h] + outs
 
 
-def _had_transform_group_cuda(x, out_features, n, K, had, transpose, pre2, post, bias, scale, residual):
+def _had_transform_group_cuda(x, out_features, n, K, had, transpose, pre2, post, bias, scale, residual, pre,
+                              rms_weight, rms_eps):
     count = len(x)
     _need(1 <= count <= capi.MAX_GROUP and all(len(v) == count for v in (out_features, had, pre2, post, bias, scale,
-                                                                          residual)), "group of 1..3 problems")
+                                                                          residual, pre)), "group of 1..3 problems")
     xs = [_chk_x(t) for t in x]
     rows = xs[0].shape[0]
     _need(all(t.shape == xs[0].shape and t.device == xs[0].device for t in xs), "group inputs must share a shape")
@@ -238,9 +239,10 @@ def _had_transform_group_cuda(x, out_features, n, K, had, transpose, pre2, post,
     arr = (capi.HadProblem * count)()
     for i in range(count):
         _need(residual[i] is None or tuple(residual[i].shape) == tuple(outs[i].shape), "residual shape")
-        arr[i] = capi.HadProblem(xs[i].data_ptr(), outs[i].data_ptr(), _vec_ok(had[i], dev), None, _vec_ok(pre2[i], dev),
-                                 _vec_ok(post[i], dev), _vec_ok(bias[i], dev), _vec_ok(residual[i], dev), None, None,
-                                 xs[i].shape[1], int(out_features[i]), float(scale[i]), 1e-5)
+        arr[i] = capi.HadProblem(xs[i].data_ptr(), outs[i].data_ptr(), _vec_ok(had[i], dev), _vec_ok(pre[i], dev),
+                                 _vec_ok(pre2[i], dev), _vec_ok(post[i], dev), _vec_ok(bias[i], dev),
+                                 _vec_ok(residual[i], dev), _vec_ok(rms_weight, dev), None,
+                                 xs[i].shape[1], int(out_features[i]), float(scale[i]), float(rms_eps))
     with torch.cuda.device(dev):
         capi.check(capi.lib().quip_had_transform_group_f16(arr, count, rows, n, K, int(bool(transpose)), _stream(xs[0])),
                    "quip_had_transform_group_f16")
@@ -500,7 +502,8 @@ _reg_fake("had_transform_planes_group", lambda x, n, K, had, transpose, pre, sca
           [x.new_empty((3 * ((n + 511) // 512 * 512) + 16,), dtype=torch.uint8) for _ in pre])
 _reg_fake("had_chain_planes_group", lambda z, z_post, z_residual, z_scale, n, pre, scale, rms_weight, rms_eps:
           [z.new_empty((1, n))] + [z.new_empty((3 * ((n + 511) // 512 * 512) + 16,), dtype=torch.uint8) for _ in pre])
-_reg_fake("had_transform_group", lambda x, out_features, n, K, had, transpose, pre2, post, bias, scale, residual:
+_reg_fake("had_transform_group", lambda x, out_features, n, K, had, transpose, pre2, post, bias, scale, residual, pre,
+          rms_weight, rms_eps:
           [t.new_empty((t.shape[0], int(o))) for t, o in zip(x, out_features)])
 _reg_fake("e8p_gemv_planes_group", lambda planes, Qidxs, grid:
           [p.new_empty((1, q.shape[0]), dtype=torch.float16) for p, q in zip(planes, Qidxs)])

@@ -235,3 +235,22 @@ def test_gemv_chain_bit_identical(k, fouts, with_rms, with_res):
             [l.wscale_float / np.sqrt(k) for l in layers], w, 1e-5, None)
         for l, pl, zf in zip(layers, planes, zs):
             assert torch.equal(zf, torch.ops.quip_lib.e8p_gemv_planes(pl, l.Qidxs, l.codebook.grid_packed_abs))
+
+
+@pytest.mark.parametrize("cbid,fin,fouts,M", [("E8P12RVQ4B", 4096, (4096, 4096, 4096), 1), ("D4", 1408, (512, 688), 1),
+                                              ("HI", 256, (256, 688), 3), ("E8P12", 4096, (11008, 11008), 4),
+                                              ("E8P12RVQ3B", 256, (256, 256, 128), 1)])
+def test_forward_group_generic_codebooks_and_batches(cbid, fin, fouts, M):
+    """grouped transforms around the per-module codebook product (any codebook, any batch) give exactly
+    what the modules give one by one"""
+    from quip_for_all_amd.qlinear import forward_group
+    layers = [_layer(O.make_layer(cbid, fin, fo, seed=fin + fo + i)) for i, fo in enumerate(fouts)]
+    rng = np.random.default_rng(fin + M)
+    x = torch.from_numpy(rng.standard_normal((M, fin)).astype(np.float16)).to(DEV)
+    w = torch.from_numpy((1 + 0.1 * rng.standard_normal(fin)).astype(np.float16)).to(DEV)
+    res = [torch.from_numpy(rng.standard_normal((M, fo)).astype(np.float16)).to(DEV) for fo in fouts]
+    with torch.no_grad():
+        single = [l.forward_fused(x, rms_weight=w, residual=r) for l, r in zip(layers, res)]
+        group = forward_group(layers, x, rms_weight=w, residual=res)
+        for a, b in zip(single, group):
+            assert torch.equal(a, b)
