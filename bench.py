@@ -182,6 +182,12 @@ def main():
                                     device_id=torch.device("cuda", local_rank))
         dist = dist_mod
 
+    if not os.path.exists(os.path.join(REPO, "quip_for_all_amd", "lib", "libquip_mi355.so")):
+        import __graft_entry__ as G      # build product missing from this checkout: compile it (rank 0 first)
+        if rank == 0:
+            G.build()
+        if dist is not None:
+            dist.barrier()
     import quip_for_all_amd  # noqa: F401
     from quip_for_all_amd import decode as D
     shape = {"7b": D.LLAMA2_7B, "70b": D.LLAMA2_70B, "tiny": D.TINY}[a.model]

@@ -14,6 +14,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The native library and the C oracle are build products (git-ignored).  If a checkout arrives
+    without them, build them once (hipcc cross-compiles gfx950 without a GPU) instead of failing every
+    test; the product itself never builds or falls back silently (capi.lib() raises)."""
+    lib = os.path.join(REPO, "quip_for_all_amd", "lib", "libquip_mi355.so")
+    oracle_so = os.path.join(REPO, "oracle", "_build", "libquip_oracle.so")
+    if not (os.path.exists(lib) and os.path.exists(oracle_so)):
+        import __graft_entry__ as G
+        if not os.path.exists(lib):
+            G.build_library(verbose=False)
+        if not os.path.exists(oracle_so):
+            G.build_oracle(verbose=False)
+
+
 @pytest.fixture(scope="session")
 def golden():
     d = np.load(os.path.join(REPO, "tests", "golden", "reference_golden.npz"))

@@ -66,7 +66,7 @@ def run_case(ns, k):
         a.record(); gr.replay(); b.record(); torch.cuda.synchronize()
         best = min(best, a.elapsed_time(b) * 1e3 / NSETS)
     mb = sum(n * k // 4 for n in ns) / 1e6
-    print(f"ns={ns} k={k}: {mb:.1f} MB  {best:.2f} us/launch = {mb / best * 1e-3 * 1e3:.0f} GB/s ; {len(d)} WGs")
+    print(f"ns={ns} k={k}: {mb:.1f} MB  {best:.2f} us/launch = {mb / best:.2f} TB/s ; {len(d)} WGs")
     print("   WG start skew: median %d max %d ; WG end: median %d max %d (ticks ~ 100 MHz? see s_memtime)" %
           (np.median(rel[:, 0]), rel[:, 0].max(), np.median(rel[:, 7]), rel[:, 7].max()))
     print("   " + "  ".join("%s %d/%d" % (nm, np.median(ph[:, i]), np.percentile(ph[:, i], 90)) for i, nm in enumerate(names)))

@@ -31,5 +31,5 @@ for (n, k) in [(28672, 8192), (8192, 8192), (8192, 28672)]:
                 a.record(); g.replay(); b.record(); torch.cuda.synchronize()
                 best = min(best, a.elapsed_time(b) * 1e3 / len(pool))
             mb = n * k / 4 / 1e6
-            print(f"N={n} K={k} waves={waves} R={R:2d}: {best:6.2f} us  {mb / best / 1e3:.2f} TB/s", flush=True)
+            print(f"N={n} K={k} waves={waves} R={R:2d}: {best:6.2f} us  {mb / best:.2f} TB/s", flush=True)
     del pool; torch.cuda.empty_cache()
