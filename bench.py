@@ -43,9 +43,10 @@ def gemv_roofline(dec):
     from quip_for_all_amd import capi
     L = capi.lib()
     dev = dec.dev
-    op = torch.ops.quip_lib
-    calls = []     # ([planes], [Qidxs], grid)
+    from quip_for_all_amd.qlinear import _GROUP_MAX_BYTES, _gemv_planes_grouped
+    calls = []     # (modules, [planes])
     algo = 0
+    launches = 0
     for layer in dec.layers:
         for names in (("q", "k", "v"), ("o",), ("gate", "up"), ("down",)):
             ms = [layer[n] for n in names]
@@ -58,14 +59,13 @@ def gemv_roofline(dec):
                                                   torch.cuda.current_stream().cuda_stream), "x_to_planes")
                 planes.append(pl)
                 algo += m.q_out_features * k // 4 + 2 * k + 2 * m.q_out_features
-            calls.append((planes, [m.Qidxs for m in ms], ms[0].codebook.grid_packed_abs))
+            calls.append((ms, planes))
+            nbytes = sum(m.Qidxs.numel() * m.Qidxs.element_size() for m in ms)
+            launches += 1 if (len(ms) == 1 or nbytes <= _GROUP_MAX_BYTES) else len(ms)   # the decoder's grouping policy
 
     def run():
-        for planes, Qs, g in calls:
-            if len(planes) == 1:
-                op.e8p_gemv_planes(planes[0], Qs[0], g)
-            else:
-                op.e8p_gemv_planes_group(planes, Qs, g)
+        for ms, planes in calls:
+            _gemv_planes_grouped(ms, planes)
     run()
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
@@ -83,8 +83,8 @@ def gemv_roofline(dec):
         torch.cuda.synchronize()
         ts.append(a.elapsed_time(b) * 1e-3)
     t = float(np.median(ts[1:]))
-    per_launch_bytes = algo / len(calls)
-    per_launch_s = t / len(calls)
+    per_launch_bytes = algo / launches
+    per_launch_s = t / launches
     achieved = per_launch_bytes / per_launch_s / 1e9
     traffic = None
     pf = os.path.join(REPO, "profiles", "gemv_hbm_traffic.json")
@@ -95,7 +95,7 @@ def gemv_roofline(dec):
             traffic = None
     return {"bound": "hbm", "kernel": "e8p_gemv_mfma_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-            "launches": len(calls), "algorithmic_bytes_per_launch": round(per_launch_bytes),
+            "launches": launches, "algorithmic_bytes_per_launch": round(per_launch_bytes),
             "mean_launch_us": round(per_launch_s * 1e6, 3)}
 
 

@@ -19,7 +19,7 @@ import torch.nn.functional as F
 
 from .codebook import codebook_id
 from .qlinear import (QuantLinear, chain_supported, forward_group, fused_in_supported, gemv_chain, gemv_fused,
-                      gemv_unfused, out_transform_group)
+                      gemv_group_unfused, gemv_unfused, out_transform_group)
 
 
 @dataclass
@@ -116,14 +116,16 @@ class LlamaDecoder:
         self.fused_attention = s.head_dim in (64, 128)
         L0 = self.layers[0]
         import os
-        self.fused_prologue = (os.environ.get("QUIP_FUSED_PROLOGUE", "1") != "0" and fused_in_supported([L0["q"], L0["k"], L0["v"]], prev=L0["down"])
-                               and fused_in_supported([L0["o"]])
-                               and fused_in_supported([L0["gate"], L0["up"]], prev=L0["o"])
-                               and L0["down"].codebook.planes_supported(L0["down"].q_out_features,
-                                                                        L0["down"].q_in_features))
-        self.chain = (self.fused_prologue and os.environ.get("QUIP_CHAIN", "1") != "0"
-                      and chain_supported([L0["q"], L0["k"], L0["v"]], L0["down"])
-                      and chain_supported([L0["gate"], L0["up"]], L0["o"]))
+        qkv0, gu0 = [L0["q"], L0["k"], L0["v"]], [L0["gate"], L0["up"]]
+        planes_ok = all(hasattr(m.codebook, "mm_planes") and m.codebook.planes_supported(m.q_out_features, m.q_in_features)
+                        for m in L0.values() if isinstance(m, QuantLinear))
+        # stage-wise step (10 launches per block): chain launches where the shapes allow, else the GEMV prologue
+        self.chain = (planes_ok and os.environ.get("QUIP_CHAIN", "1") != "0"
+                      and chain_supported(qkv0, L0["down"]) and chain_supported(gu0, L0["o"]))
+        prologue_ok = (planes_ok and fused_in_supported(qkv0, prev=L0["down"]) and fused_in_supported(gu0, prev=L0["o"]))
+        self.o_fused = planes_ok and fused_in_supported([L0["o"]])
+        self.qkv_fused = planes_ok and fused_in_supported(qkv0)
+        self.fused_prologue = os.environ.get("QUIP_FUSED_PROLOGUE", "1") != "0" and (self.chain or prologue_ok)
 
     # ---- model bytes the decode step has to stream (roofline denominator) -----------
     def algorithmic_bytes_per_token(self):
@@ -183,13 +185,18 @@ class LlamaDecoder:
         zd = prev_down = None
         for i, L in enumerate(self.layers):
             qkv = [L["q"], L["k"], L["v"]]
-            if zd is None:
+            if zd is None and self.qkv_fused:
                 _, zs = gemv_fused(qkv, x=h, rms_weight=L["ln1"], rms_eps=s.rms_eps)
+            elif zd is None:
+                zs = gemv_group_unfused(qkv, h, rms_weight=L["ln1"], rms_eps=s.rms_eps)
             else:   # finishes the previous block: h += down(...)
                 h, zs = self._zx(qkv, prev_down, zd, h, L["ln1"])
             q, k, v = out_transform_group(qkv, zs)
             a = self._attention(i, q, k, v, cos, sin, mask)
-            _, (zo,) = gemv_fused([L["o"]], x=a.reshape(1, s.hidden))
+            if self.o_fused:
+                _, (zo,) = gemv_fused([L["o"]], x=a.reshape(1, s.hidden))
+            else:
+                zo = gemv_unfused(L["o"], a.reshape(1, s.hidden))
             h, zgu = self._zx([L["gate"], L["up"]], L["o"], zo, h, L["ln2"])
             g, u = out_transform_group([L["gate"], L["up"]], zgu)
             zd = gemv_unfused(L["down"], u, gate=g)

@@ -11,6 +11,7 @@ three launches exactly where the reference materialises fp16 tensors; inside a
 launch the arithmetic is fp32.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -202,6 +203,21 @@ class QuantLinear(nn.Module):
         return layer
 
 
+# A grouped GEMV launch pays launch / table build / drain once, but needs room for every x vector in
+# LDS (fewer table copies -> bank conflicts).  Measured on MI355X (tools/gemv_group_phases.py): grouping
+# wins while the launch is latency bound (7B shapes, 70B q/k/v) and loses for two 59 MB matrices
+# (70B gate/up: 33.4 us grouped vs 2 x 14.5-15.4 us).
+_GROUP_MAX_BYTES = int(os.environ.get("QUIP_GROUP_MAX_MB", "48")) << 20
+
+
+def _gemv_planes_grouped(layers, planes):
+    cb = layers[0].codebook
+    nbytes = sum(l.Qidxs.numel() * l.Qidxs.element_size() for l in layers)
+    if len(layers) > 1 and nbytes <= _GROUP_MAX_BYTES:
+        return list(torch.ops.quip_lib.e8p_gemv_planes_group(planes, [l.Qidxs for l in layers], cb.grid_packed_abs))
+    return [cb.mm_planes(p, l.Qidxs) for l, p in zip(layers, planes)]
+
+
 def forward_group(layers, input, rms_weight=None, rms_eps=1e-5, residual=None):
     """[l(input) for l in layers] for 1..3 QuantLinear modules that read the same bs=1 activation
     (q/k/v_proj, gate/up_proj), each of the three stages issued as ONE launch for the whole group
@@ -227,7 +243,7 @@ def forward_group(layers, input, rms_weight=None, rms_eps=1e-5, residual=None):
             x, l0.q_in_features, l0.K_left, [l._had("had_left") for l in layers], True,
             [l._vec(l.SU) for l in layers], [l.wscale_float / math.sqrt(L_in) for l in layers],
             l0._vec(rms_weight), rms_eps, None)
-        zs = torch.ops.quip_lib.e8p_gemv_planes_group(planes, [l.Qidxs for l in layers], cb.grid_packed_abs)
+        zs = _gemv_planes_grouped(layers, planes)
     else:
         # any codebook / any batch: grouped fp16 input transforms, one codebook product per module
         n = len(layers)
@@ -323,6 +339,17 @@ def out_transform_group(layers, zs, residual=None):
     return ys
 
 
+def gemv_group_unfused(layers, x, rms_weight=None, rms_eps=1e-5):
+    """raw GEMV outputs of 1..3 modules reading x: grouped input-transform launch + grouped GEMV"""
+    l0 = layers[0]
+    L_in = l0.q_in_features // l0.K_left
+    planes = torch.ops.quip_lib.had_transform_planes_group(
+        x.reshape(1, -1), l0.q_in_features, l0.K_left, [l._had("had_left") for l in layers], True,
+        [l._vec(l.SU) for l in layers], [l.wscale_float / math.sqrt(L_in) for l in layers],
+        None if rms_weight is None else l0._vec(rms_weight), rms_eps, None)
+    return _gemv_planes_grouped(layers, list(planes))
+
+
 def gemv_unfused(layer, x, gate=None, rms_weight=None, rms_eps=1e-5):
     """raw GEMV output of one module through the separate input-transform launch (any K_left)"""
     L_in = layer.q_in_features // layer.K_left
@@ -359,8 +386,4 @@ def gemv_chain(layers, prev, z, residual=None, rms_weight=None, rms_eps=1e-5):
         1.0 / math.sqrt(prev.q_out_features // prev.K_right), n, [l._vec(l.SU) for l in layers],
         [l.wscale_float / math.sqrt(n) for l in layers], None if rms_weight is None else l0._vec(rms_weight), rms_eps)
     h, planes = res[0], list(res[1:])
-    if len(layers) == 1:
-        zs = [l0.codebook.mm_planes(planes[0], l0.Qidxs)]
-    else:
-        zs = list(torch.ops.quip_lib.e8p_gemv_planes_group(planes, [l.Qidxs for l in layers], l0.codebook.grid_packed_abs))
-    return h, zs
+    return h, _gemv_planes_grouped(layers, planes)

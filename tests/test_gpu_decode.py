@@ -154,6 +154,9 @@ def test_fused_prologue_step_equals_unfused_step():
     for a, b in zip(lf, lp):
         assert torch.equal(a, b)
     dec.fused_prologue = dec.chain = True
+    dec.qkv_fused = dec.o_fused = False       # the shapes a 70B model takes: no GEMV-prologue transforms at all
+    assert torch.equal(dec.generate(10, first_token=7, use_graph=False), fused_tokens)
+    dec.qkv_fused = dec.o_fused = True
     graph_tokens = dec.generate(10, first_token=7, use_graph=True)
     assert torch.equal(graph_tokens, fused_tokens)
     ref = _ref_logits(dec, [7, int(fused_tokens[0]), int(fused_tokens[1])])

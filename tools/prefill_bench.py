@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Config 5 (prefill, M = 16 x 2048 rows): QuantLinear.forward per 7B shape through the M >= 32 path
+(Hadamard -> decompress -> dense fp16 GEMM -> Hadamard), achieved TFLOP/s of the linear layers vs the
+2.5 PFLOP/s dense fp16 MFMA peak, and the split between the stages."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from quip_for_all_amd import decode as D  # noqa
+dev = "cuda:0"
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+g = torch.Generator().manual_seed(0)
+tot_t = tot_f = 0.0
+for name, (fin, fout, mult) in {"attn 4096->4096": (4096, 4096, 4), "gate/up 4096->11008": (4096, 11008, 2),
+                                "down 11008->4096": (11008, 4096, 1)}.items():
+    layer = D.random_quant_linear(fin, fout, "E8P12", g, dev)
+    x = torch.randn(M, fin, device=dev, dtype=torch.float16)
+    def t(fn, n=5):
+        fn(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n): fn()
+        b.record(); torch.cuda.synchronize()
+        return a.elapsed_time(b) / n
+    with torch.no_grad():
+        full = t(lambda: layer(x))
+        W = layer.codebook.decompress_weight(layer.Qidxs)
+        dec = t(lambda: layer.codebook.decompress_weight(layer.Qidxs))
+        xh = torch.randn(M, layer.q_in_features, device=dev, dtype=torch.float16)
+        gemm = t(lambda: xh @ W.T)
+    fl = 2.0 * M * fin * fout
+    print(f"{name:22s} M={M}: forward {full:8.3f} ms = {fl / full / 1e9:7.1f} TFLOP/s ({fl / full / 1e9 / 2500:.2%} of 2.5 PF) | "
+          f"decompress {dec:.3f} ms, GEMM {gemm:.3f} ms ({fl / gemm / 1e9:.0f} TFLOP/s), transforms+rest {full - dec - gemm:.3f} ms")
+    tot_t += mult * full; tot_f += mult * fl
+print(f"per block: {tot_t:.2f} ms, {tot_f / tot_t / 1e9:.1f} TFLOP/s; 32 blocks: {32 * tot_t:.1f} ms time-to-first-token (linear layers only)")
