@@ -46,6 +46,18 @@ namespace quip {
 
 namespace {
 
+// Shape of one weight load instruction.  0 (default): 16 rows x 64 B straight in the MFMA layout.
+// 1: 8 rows x 128 B (whole cache lines; lane = (row l >> 3, 16-byte chunk l & 7)), redistributed to the
+// MFMA's (row l & 15, k block l >> 4) layout with ds_bpermute after landing.  A pure read probe
+// streams whole lines 8-9 % faster (tools/shape_probe.py: 11.6 vs 12.7 us for 58.7 MB), but the 16
+// ds_bpermute per item go through the LDS pipe the table lookups already load: measured 4.85 vs
+// 4.52 us (4096^2), 24.7 vs 20.9 us (8192 x 28672), 42.7 vs 33.4 us (2 x 28672 x 8192).  Kept for
+// experiments (-DQUIP_GEMV_R8=1); parity-tested in both settings.
+#ifndef QUIP_GEMV_R8
+#define QUIP_GEMV_R8 0
+#endif
+constexpr bool kR8 = QUIP_GEMV_R8 != 0;
+
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(3))) u32x2* lds_u2_ptr;
@@ -171,6 +183,27 @@ __device__ __forceinline__ void item_addresses(const u32x4& q0, const u32x4& q1,
   }
 }
 
+// kR8: the two landed loads hold, in lane (r = l >> 3, c = l & 7), chunk c (codes 8c .. 8c+7, k = 64c ..)
+// of rows r (qa) and 8 + r (qb).  MFMA step t of lane (n, q) takes dword j = t & 3 of chunk
+// c = 2q + (t >> 2) of row n, i.e. k = 128q + 64(t >> 2) + 16(t & 3) of the slice (the A fragments are
+// read with the same mapping): two ds_bpermute per step (rows < 8 / >= 8) and a select.
+__device__ __forceinline__ void redistribute_r8(const u32x4& qa, const u32x4& qb, int lane, u32x4& da, u32x4& db) {
+  const int n = lane & 15, q = lane >> 4;
+  const int src0 = (((n & 7) << 3) + 2 * q) << 2, src1 = src0 + 4;
+  const bool lo = n < 8;
+  const uint32_t a[4] = {qa.x, qa.y, qa.z, qa.w}, b[4] = {qb.x, qb.y, qb.z, qb.w};
+  uint32_t d[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int a0 = __builtin_amdgcn_ds_bpermute(src0, (int)a[j]), b0 = __builtin_amdgcn_ds_bpermute(src0, (int)b[j]);
+    const int a1 = __builtin_amdgcn_ds_bpermute(src1, (int)a[j]), b1 = __builtin_amdgcn_ds_bpermute(src1, (int)b[j]);
+    d[j] = (uint32_t)(lo ? a0 : b0);
+    d[4 + j] = (uint32_t)(lo ? a1 : b1);
+  }
+  da = u32x4{d[0], d[1], d[2], d[3]};
+  db = u32x4{d[4], d[5], d[6], d[7]};
+}
+
 struct StepOperands { uint2 t1l, t2l, t1h, t2h; i32x4 A; };
 
 __device__ __forceinline__ i32x4 item_mfma(const ItemAddr& ad, uint32_t xaddr) {
@@ -179,7 +212,7 @@ __device__ __forceinline__ i32x4 item_mfma(const ItemAddr& ad, uint32_t xaddr) {
   auto issue = [&](int t) {
     op[t].t1l = lds_read8(ad.a1l[t]); op[t].t2l = lds_read8(ad.a2l[t]);
     op[t].t1h = lds_read8(ad.a1h[t]); op[t].t2h = lds_read8(ad.a2h[t]);
-    op[t].A = lds_read16i(xaddr + (t < 4 ? 16 * t : 256 + 16 * (t - 4)));
+    op[t].A = lds_read16i(xaddr + (kR8 ? 64 * (t >> 2) + 16 * (t & 3) : (t < 4 ? 16 * t : 256 + 16 * (t - 4))));
   };
 #pragma unroll
   for (int t = 0; t < PIPE; ++t) issue(t);
@@ -295,10 +328,17 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
       W = p == i ? gp.W[i] : W;
       asm volatile("" : "+s"(W));
     }
-    int row = pick(row0, p) + rb * 16 + n;
+    int row, off;     // off: uint4 units inside the row
+    if (kR8) {        // load j covers rows 8j .. 8j+7 of the row block, the slice's whole 128-byte line each
+      row = pick(row0, p) + rb * 16 + 8 * j + (lane >> 3);
+      off = s * 8 + (lane & 7);
+      off = off < row_u4 ? off : s * 8 + (lane & 1);   // K % 512 != 0: re-read a valid piece (x digits are 0)
+    } else {
+      row = pick(row0, p) + rb * 16 + n;
+      off = s * 8 + q + 4 * j;
+      off = off < row_u4 ? off : s * 8 + q;
+    }
     row = row < N ? row : N - 1;
-    int off = s * 8 + q + 4 * j;  // uint4 units inside the row
-    off = off < row_u4 ? off : s * 8 + q;
     return W + (size_t)row * row_u4 + off;
   };
 
@@ -476,7 +516,7 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
   int* accs = reinterpret_cast<int*>(smem + L::kAcc);
   // A fragment address of this lane: plane (lane & 15) clamped to a valid plane (rows >= 3
   // of A are don't-care), k = slice*512 + (t < 4 ? 0 : 256) + q*64 + (t & 3)*16
-  const uint32_t xlane = L::kX + (uint32_t)min(n, 2) * Kp + (uint32_t)q * 64;
+  const uint32_t xlane = L::kX + (uint32_t)min(n, 2) * Kp + (uint32_t)q * (kR8 ? 128 : 64);
   QUIP_STAMP(4);
 
   // (tried and measured slower on MI355X: slice-major item order with the A fragments of a slice
@@ -516,7 +556,13 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
       }
       if (cur < cnt) {   // wave-uniform
         ItemAddr ad;
-        item_addresses<REP>(qa[i], qb[i], lane_c, lane_c2, ad);
+        if (kR8) {
+          u32x4 da, db;
+          redistribute_r8(qa[i], qb[i], lane, da, db);
+          item_addresses<REP>(da, db, lane_c, lane_c2, ad);
+        } else {
+          item_addresses<REP>(qa[i], qb[i], lane_c, lane_c2, ad);
+        }
         run_item(cur, ad);
       }
       asm volatile("" ::: "memory");
@@ -529,7 +575,13 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
         const int cur = it + i * nwaves;
         asm_wait_vmcnt<2 * (SLOTS - 1)>(qa[i], qb[i]);
         ItemAddr ad;
-        item_addresses<REP>(qa[i], qb[i], lane_c, lane_c2, ad);
+        if (kR8) {
+          u32x4 da, db;
+          redistribute_r8(qa[i], qb[i], lane, da, db);
+          item_addresses<REP>(da, db, lane_c, lane_c2, ad);
+        } else {
+          item_addresses<REP>(qa[i], qb[i], lane_c, lane_c2, ad);
+        }
         // the slot's codes are consumed: pin the addresses, then reload the slot in place
 #pragma unroll
         for (int t = 0; t < 8; ++t)
@@ -704,6 +756,8 @@ int shape_probe_launch(const void* qidxs, void* out, int n, int k, const GemvTun
   };
   if (tune.rows == 1) return go(shape_probe_kernel<1>);
   if (tune.rows == 4) return go(shape_probe_kernel<4>);
+  if (tune.rows == 8) return go(shape_probe_kernel<8>);
+  if (tune.rows == 2) return go(shape_probe_kernel<2>);
   return go(shape_probe_kernel<16>);
 }
 
