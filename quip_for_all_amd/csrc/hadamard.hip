@@ -588,8 +588,23 @@ int had_transform_group_launch(const HadProblem* problems, int count, bool plane
   }
   if (planes && (g.p[0].L < 4 || n % 16 != 0 || rows != 1)) return QUIP_ERR_BAD_SHAPE;
   if (rows <= 0) return QUIP_OK;
-  if (rows > 65535) return QUIP_ERR_BAD_SHAPE;  // TODO(round 2): fold rows into grid.x for prefill
-  return launch(g, count, rows, stream);
+  // grid.y carries the token rows (<= 65535 per launch): longer batches go out in slices
+  constexpr int64_t kMaxRows = 65535;
+  for (int64_t r0 = 0; r0 < rows; r0 += kMaxRows) {
+    const int64_t nr = rows - r0 < kMaxRows ? rows - r0 : kMaxRows;
+    HadGroup part = g;
+    for (int i = 0; i < count; ++i) {
+      HadArgs& a = part.p[i];
+      a.x += r0 * a.in_features;
+      if (a.gate) a.gate += r0 * a.in_features;
+      if (a.y) a.y += r0 * a.out_features;
+      if (a.residual) a.residual += r0 * a.out_features;
+      if (a.z) { a.z += r0 * a.n; a.h_out += r0 * a.n; if (a.z_res) a.z_res += r0 * a.n; }
+    }
+    const int rc = launch(part, count, nr, stream);
+    if (rc != QUIP_OK) return rc;
+  }
+  return QUIP_OK;
 }
 
 int had_transform_launch(const void* x, void* y, int64_t rows, int in_features, int out_features,

@@ -103,6 +103,18 @@ class QuantLinear(nn.Module):
                 self.wscale_float / math.sqrt(L_in), self._vec(rms_weight), rms_eps,
                 None if gate is None else gate.reshape(x.shape).to(torch.float16))
             z = cb.mm_planes(planes, self.Qidxs)
+        elif (2 <= x.shape[0] <= 3 and hasattr(cb, "mm_planes")
+              and cb.planes_supported(self.q_out_features, self.q_in_features)
+              and cb.planes_group_supported([self.q_out_features] * x.shape[0], self.q_in_features)):
+            # 2..3 rows: every row gets its own digit planes (one grouped transform launch), then one
+            # grouped GEMV launch that walks the same codes once per row -- the skinny path on the
+            # matrix cores; exact integer arithmetic like bs=1
+            M = x.shape[0]
+            planes = torch.ops.quip_lib.had_transform_planes_group(
+                x, self.q_in_features, self.K_left, [self._had("had_left")] * M, True, [self._vec(self.SU)] * M,
+                [self.wscale_float / math.sqrt(L_in)] * M, self._vec(rms_weight), rms_eps,
+                None if gate is None else gate.reshape(x.shape).to(torch.float16))
+            z = torch.ops.quip_lib.e8p_mm_planes_rows(planes, self.Qidxs, cb.grid_packed_abs)
         else:
             xh = torch.ops.quip_lib.had_transform_fused(
                 x, self.q_in_features, self.q_in_features, self.K_left, self._had("had_left"), True,

@@ -43,6 +43,8 @@ _SCHEMAS = {
     "had_transform_planes_group": "(Tensor x, int n, int K, Tensor?[] had, bool transpose, Tensor?[] pre, "
                                   "float[] scale, Tensor? rms_weight, float rms_eps, Tensor? gate) -> Tensor[]",
     "e8p_gemv_planes_group": "(Tensor[] planes, Tensor[] Qidxs, Tensor grid) -> Tensor[]",
+    # 2..3 activation rows against ONE weight matrix: the grouped GEMV with the same codes for every row
+    "e8p_mm_planes_rows": "(Tensor[] planes, Tensor Qidxs, Tensor grid) -> Tensor",
     # chain: output side of the producer module (z, its SV, residual) + input transforms of 1..3 consumers;
     # returns [h] + planes
     "had_chain_planes_group": "(Tensor z, Tensor z_post, Tensor? z_residual, float z_scale, int n, Tensor[] pre, "
@@ -184,20 +186,41 @@ def _vec_ok(t, dev):
     return _ptr(t)
 
 
+def _e8p_mm_planes_rows_cuda(planes, Qidxs, grid):
+    import ctypes
+    count = len(planes)
+    _need(1 <= count <= capi.MAX_GROUP, "1..3 rows")
+    _need(Qidxs.dtype == torch.int16 and Qidxs.is_contiguous(), "Qidxs must be contiguous int16 (n, k/8)")
+    n, k = Qidxs.shape[0], Qidxs.shape[1] * 8
+    dev = Qidxs.device
+    out = torch.empty((count, n), dtype=torch.float16, device=dev)
+    vp = ctypes.c_void_p * count
+    ns = (ctypes.c_int32 * count)(*([n] * count))
+    with torch.cuda.device(dev):
+        capi.check(capi.lib().quip_e8p_gemv_planes_group(
+            vp(*[p.data_ptr() for p in planes]), vp(*([Qidxs.data_ptr()] * count)), grid.data_ptr(),
+            vp(*[out.data_ptr() + 2 * n * i for i in range(count)]), ns, count, k, _stream(out)),
+            "quip_e8p_gemv_planes_group (rows)")
+    return out
+
+
 def _had_transform_planes_group_cuda(x, n, K, had, transpose, pre, scale, rms_weight, rms_eps, gate):
     xc = _chk_x(x)
     count = len(pre)
-    _need(xc.shape[0] == 1, "had_transform_planes_group is the bs=1 path (one row)")
+    _need(xc.shape[0] in (1, count), "had_transform_planes_group: x has one row (shared) or one row per problem")
     _need(1 <= count <= capi.MAX_GROUP and len(had) == count and len(scale) == count, "group of 1..3 problems")
     _need(gate is None or gate.shape == xc.shape, "gate must have x's shape")
     L = capi.lib()
     nbytes = L.quip_e8p_planes_bytes(n)
     outs = [torch.empty(nbytes, dtype=torch.uint8, device=x.device) for _ in range(count)]
     arr = (capi.HadProblem * count)()
+    per_row = xc.shape[0] == count and count > 1
+    gptr = _vec_ok(gate, x.device)
     for i in range(count):
-        arr[i] = capi.HadProblem(xc.data_ptr(), outs[i].data_ptr(), _vec_ok(had[i], x.device), _vec_ok(pre[i], x.device),
-                                 None, None, None, None, _vec_ok(rms_weight, x.device), _vec_ok(gate, x.device),
-                                 xc.shape[1], n, float(scale[i]), float(rms_eps))
+        off = 2 * xc.shape[1] * i if per_row else 0
+        arr[i] = capi.HadProblem(xc.data_ptr() + off, outs[i].data_ptr(), _vec_ok(had[i], x.device),
+                                 _vec_ok(pre[i], x.device), None, None, None, None, _vec_ok(rms_weight, x.device),
+                                 None if gptr is None else gptr + off, xc.shape[1], n, float(scale[i]), float(rms_eps))
     with torch.cuda.device(x.device):
         capi.check(L.quip_had_transform_planes_group(arr, count, n, K, int(bool(transpose)), _stream(x)),
                    "quip_had_transform_planes_group")
@@ -463,6 +486,7 @@ _IMPLS = {
     "had_chain_planes_group": _had_chain_planes_group_cuda,
     "had_transform_group": _had_transform_group_cuda,
     "e8p_gemv_planes_group": _e8p_gemv_planes_group_cuda,
+    "e8p_mm_planes_rows": _e8p_mm_planes_rows_cuda,
     "had_transform_fused": _had_transform_fused_cuda,
     "had_transform_planes_fused": _had_transform_planes_fused_cuda,
     "e8p_mm_origorder": _e8p_mm_cuda,
@@ -505,6 +529,8 @@ _reg_fake("had_chain_planes_group", lambda z, z_post, z_residual, z_scale, n, pr
 _reg_fake("had_transform_group", lambda x, out_features, n, K, had, transpose, pre2, post, bias, scale, residual, pre,
           rms_weight, rms_eps:
           [t.new_empty((t.shape[0], int(o))) for t, o in zip(x, out_features)])
+_reg_fake("e8p_mm_planes_rows", lambda planes, Qidxs, grid:
+          Qidxs.new_empty((len(planes), Qidxs.shape[0]), dtype=torch.float16))
 _reg_fake("e8p_gemv_planes_group", lambda planes, Qidxs, grid:
           [p.new_empty((1, q.shape[0]), dtype=torch.float16) for p, q in zip(planes, Qidxs)])
 _reg_fake("e8p_gemv_fused", lambda x, z, post, residual, rms_weight, rms_eps, z_scale, pre, scale, Qidxs, grid:

@@ -298,3 +298,15 @@ def test_gemv_planes_end_to_end(Q):
     W64 = O.decompress_e8p(P.Qidxs).astype(np.float64)
     ref = xh @ W64.T
     assert np.all(np.abs(z - ref) <= 2.0 ** -10 * np.abs(ref) + 2.0 ** -13 * np.abs(xh).max() * np.abs(W64).sum(1)[None] / np.sqrt(k) + 1e-3)
+
+
+def test_hadamard_more_rows_than_one_grid_dimension(Q):
+    """rows > 65535 (prefill batches) are served in slices; every row equals the single-row result"""
+    import quip_for_all_amd  # noqa: F401
+    rows, n = 70000, 256
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(rows, n, generator=g).half().cuda()
+    y = torch.ops.quip_lib.hadamard(x, 1.0 / 16.0)
+    pick = torch.tensor([0, 1, 65534, 65535, 65536, 69999], device="cuda")
+    ref = torch.ops.quip_lib.hadamard(x[pick].contiguous(), 1.0 / 16.0)
+    assert torch.equal(y[pick], ref)

@@ -254,3 +254,22 @@ def test_forward_group_generic_codebooks_and_batches(cbid, fin, fouts, M):
         group = forward_group(layers, x, rms_weight=w, residual=res)
         for a, b in zip(single, group):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("fin,fout,M", [(4096, 4096, 2), (4096, 11008, 3), (11008, 4096, 2), (1408, 512, 3)])
+def test_skinny_rows_on_matrix_core_path(fin, fout, M):
+    """2..3 rows go through per-row digit planes + the grouped GEMV; each row must equal the bs=1
+    result of that row bit for bit (same integer arithmetic) and sit inside the oracle bound"""
+    P = O.make_layer("E8P12", fin, fout, seed=fin + fout + M)
+    layer = _layer(P)
+    rng = np.random.default_rng(M + fin)
+    x = rng.standard_normal((M, fin)).astype(np.float16)
+    xd = torch.from_numpy(x).to(DEV)
+    with torch.no_grad():
+        y = layer(xd)
+        rows = [layer(xd[i:i + 1]) for i in range(M)]
+    for i in range(M):
+        assert torch.equal(y[i:i + 1], rows[i])
+    What = O.qlinear_dense_weight(P)
+    ref = O.qlinear_forward(P, x.astype(np.float64), "exact", What)
+    assert np.all(np.abs(y.cpu().numpy().astype(np.float64) - ref) <= O.parity_bound(P, x.astype(np.float64), What))
