@@ -166,7 +166,9 @@ __device__ __forceinline__ void raw_math16(const HadArgs& a, int idx0, const Raw
 //   tall (TALL == true):  64 <= L <= 256 < n, 256 threads, R = 16 * (256 / L): thread owns one
 //                         column and 16 rows of the K-mix (11008 = 43 x 256 or 172 x 64), the H
 //                         tile sits in LDS and is read as broadcasts.
-template <bool PLANES, bool TALL, int MAXT>
+// KONE: instantiation for K == 1 only (no K-mix code: far fewer registers, so that many token rows
+// of a prefill batch are resident per CU)
+template <bool PLANES, bool TALL, int MAXT, bool KONE = false>
 __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
   const HadArgs a = grp.p[blockIdx.z];
   extern __shared__ __attribute__((aligned(16))) float buf[];
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) v[r] = 0.f;
   if constexpr (!TALL) {
-    if (K == 1 && a.z) {
+    if ((KONE || K == 1) && a.z) {
       // producer's output transform + residual first (host guarantees vec, in_features == n == L)
       const f16* zr = a.z + row * a.n;
       float tp[16], tr[16];
@@ -226,9 +228,9 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
         if (a.pre2) had::mul8(e, ldp(a.pre2 + c));
       }
       __syncthreads();   // the shuffle buffer is reused by the transform below
-    } else if (K == 1) {
+    } else if (KONE || K == 1) {
       in_vals16(a, xr, gr, kp * L + j0, v, ss_x);
-    } else {
+    } else if constexpr (!KONE) {
       constexpr int U = MAXT <= 256 ? 2 : 1;       // k values per memory round trip
       for (int k0 = 0; k0 < K; k0 += U) {
         float h[U];
@@ -517,8 +519,16 @@ int launch(HadGroup& g, int count, int64_t rows, hipStream_t stream) {
   }
   const dim3 grid(K, (unsigned)rows, count);
   if (L >= 256 && L <= 16384) {
-    const int lds = 2 * had::buf_floats(L) * 4;
-    for (int i = 0; i < count; ++i) g.p[i].pp = had::buf_floats(L);
+    // ping-pong shuffle buffer for the latency-bound decode launches; batches (prefill) take the single
+    // buffer so that more rows are resident per CU
+    const bool batch = rows > 8;
+    const int lds = (batch ? 1 : 2) * had::buf_floats(L) * 4;
+    for (int i = 0; i < count; ++i) g.p[i].pp = batch ? 0 : had::buf_floats(L);
+    if (L <= 4096 && K == 1) {
+      static int c1[2] = {0, 0};
+      return planes ? launch_one(had_fast_kernel<true, false, 256, true>, c1[0], g, grid, L / 16, lds, stream)
+                    : launch_one(had_fast_kernel<false, false, 256, true>, c1[1], g, grid, L / 16, lds, stream);
+    }
     if (L <= 4096)
       return planes ? launch_one(had_fast_kernel<true, false, 256>, cfg[2], g, grid, L / 16, lds, stream)
                     : launch_one(had_fast_kernel<false, false, 256>, cfg[3], g, grid, L / 16, lds, stream);
