@@ -205,6 +205,15 @@ int quip_e8p_gemv_planes_group(const void* const* planes, const void* const* qid
                                const void* grid_packed_abs, void* const* ys, const int32_t* ns,
                                int32_t count, int32_t k, quip_stream_t stream);
 
+/* D4 codebook (d4.py:26-96, origin_order.cu:143-168) on the same integer-domain matrix-core GEMV:
+ * qidxs uint8 (n, k/4), grid_f16 the fp16 (256, 4) table; 2w of every entry is an int8, so the
+ * arithmetic is exact like E8P12's.  x as digit planes (quip_e8p_x_to_planes / quip_had_transform_planes). */
+int quip_d4_gemv_planes(const void* planes, const void* qidxs, const void* grid_f16, void* y /* fp16[n] */,
+                        int32_t n, int32_t k, quip_stream_t stream);
+int quip_d4_gemv_planes_group(const void* const* planes, const void* const* qidxs, const void* grid_f16,
+                              void* const* ys, const int32_t* ns, int32_t count, int32_t k,
+                              quip_stream_t stream);
+
 /* ---- GEMV with the input side of the layer(s) computed in its prologue (bs = 1, K_left == 1) ----
  * For `count` (1..3) E8P12 modules reading the same activation of width k (a power of two,
  * 1024..8192, in_features == q_in_features == k):

@@ -72,6 +72,9 @@ class E8P12_codebook(_Codebook):
         """bs=1 product with x given as int8 digit planes (quip_lib::had_transform_planes)"""
         return torch.ops.quip_lib.e8p_gemv_planes(planes, Qidxs, self.grid_packed_abs)
 
+    def mm_planes_group(self, planes, Qidxs):
+        return list(torch.ops.quip_lib.e8p_gemv_planes_group(planes, Qidxs, self.grid_packed_abs))
+
 
 class E8P12RVQ4B_codebook(_Codebook):
     def __init__(self, inference=False, opt_resid_scale=None, **kwargs):
@@ -150,6 +153,22 @@ class D4_codebook(_Codebook):
 
     def mm(self, input, Qidxs):
         return torch.ops.quip_lib.d4_mm_origorder(input, Qidxs, self.grid)
+
+    # bs=1: the same integer-domain matrix-core GEMV as E8P12 (2w of every D4 entry is an int8)
+    @staticmethod
+    def planes_supported(q_out, q_in):
+        return q_in % 128 == 0 and 128 <= q_in <= 28672 and q_out >= 1
+
+    @staticmethod
+    def planes_group_supported(q_outs, q_in):
+        kp = (q_in + 511) // 512 * 512
+        return 1 <= len(q_outs) <= 3 and len(q_outs) * kp <= 31232
+
+    def mm_planes(self, planes, Qidxs):
+        return torch.ops.quip_lib.d4_gemv_planes(planes, Qidxs, self.grid)
+
+    def mm_planes_group(self, planes, Qidxs):
+        return list(torch.ops.quip_lib.d4_gemv_planes_group(planes, Qidxs, self.grid))
 
 
 class HI4B1C_codebook(_Codebook):

@@ -150,6 +150,34 @@ int quip_e8p_gemv_planes_group(const void* const* planes, const void* const* qid
                                     (hipStream_t)stream);
 }
 
+int quip_d4_gemv_planes(const void* planes, const void* qidxs, const void* grid_f16, void* y, int32_t n,
+                        int32_t k, quip_stream_t stream) {
+  if (!planes || !qidxs || !grid_f16 || !y) return QUIP_ERR_NULL_POINTER;
+  if (n < 1 || k < 1 || k % 8 != 0) return QUIP_ERR_BAD_SHAPE;
+  if (!aligned16(planes) || !aligned16(qidxs)) return QUIP_ERR_MISALIGNED;
+  GemvTune t;
+  t.rep = 64;   // D4 mode of the matrix-core GEMV
+  return e8p_gemv_mfma_launch(planes, qidxs, grid_f16, y, n, k, t, (hipStream_t)stream);
+}
+
+int quip_d4_gemv_planes_group(const void* const* planes, const void* const* qidxs, const void* grid_f16,
+                              void* const* ys, const int32_t* ns, int32_t count, int32_t k,
+                              quip_stream_t stream) {
+  if (!planes || !qidxs || !grid_f16 || !ys || !ns) return QUIP_ERR_NULL_POINTER;
+  if (count < 1 || count > QUIP_MAX_GROUP) return QUIP_ERR_BAD_SHAPE;
+  int n32[QUIP_MAX_GROUP];
+  for (int i = 0; i < count; ++i) {
+    if (!planes[i] || !qidxs[i] || !ys[i]) return QUIP_ERR_NULL_POINTER;
+    if (!aligned16(planes[i]) || !aligned16(qidxs[i])) return QUIP_ERR_MISALIGNED;
+    if (ns[i] < 1) return QUIP_ERR_BAD_SHAPE;
+    n32[i] = ns[i];
+  }
+  if (k < 1 || k % 8 != 0) return QUIP_ERR_BAD_SHAPE;
+  GemvTune t;
+  t.rep = 64;
+  return e8p_gemv_mfma_group_launch(planes, qidxs, grid_f16, ys, n32, count, k, t, (hipStream_t)stream);
+}
+
 int quip_e8p_gemv_fused(const quip_gemv_fused_in* in, const void* const* qidxs,
                         const void* grid_packed_abs, void* const* ys, const int32_t* ns,
                         int32_t count, int32_t k, quip_stream_t stream) {

@@ -71,10 +71,13 @@ constexpr int kMaxRowsPerBlock = 256;  // int32 accumulator rows per workgroup
 template <int REP>
 struct Lds {
   // REP = 32 / 16: both tables with that many copies; REP = 24: T1 x 32 (conflict free), T2 x 16
-  static constexpr int kRep1 = REP == 16 ? 16 : 32;
+  // REP = 64: the D4 codebook -- ONE table of 256 x 4-byte entries (2w of the code's 4 weights as int8),
+  //           64 copies (a private copy per lane: no conflicts), no sign table
+  static constexpr bool kD4 = REP == 64;
+  static constexpr int kRep1 = kD4 ? 64 : (REP == 16 ? 16 : 32);
   static constexpr int kRep2 = REP == 32 ? 32 : 16;
-  static constexpr int kRow1 = kRep1 * 8;            // bytes per T1 entry row
-  static constexpr int kRow2 = kRep2 * 8;            // bytes per T2 entry row
+  static constexpr int kRow1 = kRep1 * (kD4 ? 4 : 8);   // bytes per T1 entry row
+  static constexpr int kRow2 = kD4 ? 0 : kRep2 * 8;     // bytes per T2 entry row
   static constexpr int kT1 = 0;
   static constexpr int kT2 = 256 * kRow1;
   static constexpr int kAcc = kT2 + 256 * kRow2;     // int32 [kMaxRowsPerBlock][4]
@@ -132,9 +135,29 @@ __device__ __forceinline__ const uint2* table_source_ptr(const uint64_t* grid, i
   const uint2* t2 = &kT2Img.v[e];
   return (lane & 32) ? t2 : t1;
 }
+// D4: `grid` is the fp16 (256, 4) table (d4.py:26-96); every lane reads entry 32 w + (l & 31) (8 bytes)
+__device__ __forceinline__ const uint2* table_source_ptr_d4(const uint64_t* grid, int lane, int wave) {
+  return reinterpret_cast<const uint2*>(grid) + ((wave & 7) * 32 + (lane & 31));
+}
 template <int REP>
 __device__ __forceinline__ void fill_tables_from_lane(char* smem, const u32x2& src, int lane, int wave) {
   using L = Lds<REP>;
+  if constexpr (L::kD4) {
+    // 4 fp16 half-integers -> int8 2w; lanes l and l + 32 hold the same entry and write copies
+    // [0, 32) resp. [32, 64) of its row, rotating so that a step touches 32 distinct banks
+    const f16x2 lo = as_f16x2(src.x), hi = as_f16x2(src.y);
+    const int b0 = (int)(2.f * (float)lo.x), b1 = (int)(2.f * (float)lo.y);
+    const int b2 = (int)(2.f * (float)hi.x), b3 = (int)(2.f * (float)hi.y);
+    const uint32_t val = (uint32_t)(b0 & 0xff) | ((uint32_t)(b1 & 0xff) << 8) | ((uint32_t)(b2 & 0xff) << 16) |
+                         ((uint32_t)(b3 & 0xff) << 24);
+    const uint32_t rowbase = (uint32_t)L::kT1 + (uint32_t)(wave * 32 + (lane & 31)) * L::kRow1 + (uint32_t)(lane & 32) * 4;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      const uint32_t copy = (uint32_t)(lane + c) & 31u;
+      *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>((uintptr_t)(rowbase + copy * 4)) = val;
+    }
+    return;
+  }
   const bool second = (lane & 32) != 0;
   const uint2 raw = make_uint2(src.x, src.y);
   const uint2 t1 = t1_entry(raw);
@@ -161,6 +184,18 @@ template <int REP>
 __device__ __forceinline__ void item_addresses(const u32x4& q0, const u32x4& q1, uint32_t lane_c,
                                                uint32_t lane_c2, ItemAddr& ad) {
   const uint32_t d[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+  if constexpr (REP == 64) {
+    // D4: dword t = 4 one-byte codes = the 16 weights of MFMA step t; entry address =
+    // code << 8 | lane << 2 (lane_c), one v_perm_b32 per code
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      ad.a1l[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c0c0400u);
+      ad.a2l[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c0c0500u);
+      ad.a1h[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c0c0600u);
+      ad.a2h[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c0c0700u);
+    }
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     if constexpr (REP != 16) {
@@ -205,6 +240,30 @@ __device__ __forceinline__ void redistribute_r8(const u32x4& qa, const u32x4& qb
 }
 
 struct StepOperands { uint2 t1l, t2l, t1h, t2h; i32x4 A; };
+
+__device__ __forceinline__ uint32_t lds_read4(uint32_t addr) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>((uintptr_t)addr);
+}
+
+// D4: the B fragment of a step is four 4-byte table entries, no sign fix-up
+__device__ __forceinline__ i32x4 item_mfma_d4(const ItemAddr& ad, uint32_t xaddr) {
+  constexpr int PIPE = 4;
+  i32x4 B[8], A[8];
+  auto issue = [&](int t) {
+    B[t] = i32x4{(int)lds_read4(ad.a1l[t]), (int)lds_read4(ad.a2l[t]), (int)lds_read4(ad.a1h[t]),
+                 (int)lds_read4(ad.a2h[t])};
+    A[t] = lds_read16i(xaddr + (t < 4 ? 16 * t : 256 + 16 * (t - 4)));
+  };
+#pragma unroll
+  for (int t = 0; t < PIPE; ++t) issue(t);
+  i32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (t + PIPE < 8) issue(t + PIPE);
+    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t], B[t], acc, 0, 0, 0);
+  }
+  return acc;
+}
 
 __device__ __forceinline__ i32x4 item_mfma(const ItemAddr& ad, uint32_t xaddr) {
   constexpr int PIPE = 4;
@@ -346,7 +405,10 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
   //     vectors the prologue transforms -- are requested before the (TLB-cold, HBM) weight
   //     loads, all through hand-counted asm loads.
   u32x2 tsrc;   // this lane's table source entry: the first load of the kernel, so the first to land
-  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(tsrc) : "v"(table_source_ptr(grid, lane, wave)) : "memory");
+  asm volatile("global_load_dwordx2 %0, %1, off"
+               : "=v"(tsrc)
+               : "v"(L::kD4 ? table_source_ptr_d4(grid, lane, wave) : table_source_ptr(grid, lane, wave))
+               : "memory");
   constexpr int XR = 6;  // 16-byte x pieces per thread: needs nthreads >= G * 3 * Kp / 96
   const int ppieces = 3 * (Kp >> 4);       // pieces per problem
   const int xpieces = G * ppieces;
@@ -510,8 +572,9 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
   }
   QUIP_STAMP(3);
 
-  const uint32_t lane_c = (REP != 16) ? (((uint32_t)(lane & 31) << 3) | 0x00010000u)
-                                      : (((uint32_t)(lane & 15) << 3) | (uint32_t)L::kT1);
+  const uint32_t lane_c = L::kD4 ? ((uint32_t)lane << 2)
+                          : (REP != 16) ? (((uint32_t)(lane & 31) << 3) | 0x00010000u)
+                                        : (((uint32_t)(lane & 15) << 3) | (uint32_t)L::kT1);
   const uint32_t lane_c2 = ((uint32_t)(lane & 15) << 3) | (uint32_t)L::kT2;
   int* accs = reinterpret_cast<int*>(smem + L::kAcc);
   // A fragment address of this lane: plane (lane & 15) clamped to a valid plane (rows >= 3
@@ -526,7 +589,8 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
     const int p = problem_of(cur);
     const int li = cur - pick(cbase, p);
     const int rb = li / J, sl = li - rb * J;
-    const i32x4 acc = item_mfma(ad, xlane + (uint32_t)(p * 3 * Kp + sl * 512));
+    const uint32_t xa = xlane + (uint32_t)(p * 3 * Kp + sl * 512);
+    const i32x4 acc = L::kD4 ? item_mfma_d4(ad, xa) : item_mfma(ad, xa);
     // lanes 0..15 (q == 0) hold S_h, S_m, S_l of row rb*16 + n in acc[0..2]
     if (q == 0) {
       int* dst = accs + (pick(rbase, p) + rb * 16 + n) * 4;
@@ -604,7 +668,7 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
   // (5) y = 2^(-sh-2) * (65536 S_h + 256 S_m + S_l), fp16 RN, coalesced
 #pragma unroll
   for (int p = 0; p < G; ++p) {
-    const float unscale = as_f32((uint32_t)(127 - sh[p] - 2) << 23);
+    const float unscale = as_f32((uint32_t)(127 - sh[p] - (L::kD4 ? 1 : 2)) << 23);   // table entries are 4w (E8P) / 2w (D4)
     for (int t = tid; t < rows_here[p]; t += nthreads) {
       const int* a = accs + (rbase[p] + t) * 4;
       const float f = __builtin_fmaf((float)a[0], 65536.f, __builtin_fmaf((float)a[1], 256.f, (float)a[2]));
@@ -861,6 +925,7 @@ static int launch_oneshot(const GemvGroup<G>& gp, const void* grid, int k, int k
   QUIP_ONE(32, 1) QUIP_ONE(32, 2) QUIP_ONE(32, 3) QUIP_ONE(32, 4) QUIP_ONE(32, 6) QUIP_ONE(32, 8)
   QUIP_ONE(24, 1) QUIP_ONE(24, 2) QUIP_ONE(24, 3) QUIP_ONE(24, 4) QUIP_ONE(24, 6) QUIP_ONE(24, 8)
   QUIP_ONE(16, 1) QUIP_ONE(16, 2) QUIP_ONE(16, 3) QUIP_ONE(16, 4) QUIP_ONE(16, 6) QUIP_ONE(16, 8)
+  QUIP_ONE(64, 1) QUIP_ONE(64, 2) QUIP_ONE(64, 3) QUIP_ONE(64, 4) QUIP_ONE(64, 6) QUIP_ONE(64, 8)
 #undef QUIP_ONE
   return QUIP_ERR_UNSUPPORTED;
 }
@@ -868,6 +933,7 @@ static int launch_oneshot(const GemvGroup<G>& gp, const void* grid, int k, int k
 // table replication for `g` x vectors of kp digits each: 32 / 32 copies when everything fits, then
 // T1 x 32 + T2 x 16, then 16 / 16
 static int pick_rep(int g, int kp, int forced) {
+  if (forced == 64) return 64;   // D4
   if (forced == 16 || g * kp > Lds<24>::kMaxKp) return 16;
   if (forced == 24 || g * kp > Lds<32>::kMaxKp) return 24;
   return 32;
@@ -912,6 +978,7 @@ int e8p_gemv_mfma_launch(const void* planes, const void* qidxs, const void* grid
   QUIP_CASE_BIG(32, 1) QUIP_CASE_BIG(32, 2)
   QUIP_CASE_BIG(24, 1) QUIP_CASE_BIG(24, 2)
   QUIP_CASE_BIG(16, 1) QUIP_CASE_BIG(16, 2)
+  QUIP_CASE(64, 1) QUIP_CASE(64, 2) QUIP_CASE_BIG(64, 1) QUIP_CASE_BIG(64, 2)
 #undef QUIP_CASE
 #undef QUIP_CASE_BIG
   return QUIP_ERR_UNSUPPORTED;
@@ -970,6 +1037,7 @@ static int group_launch(const void* const* planes, const void* const* qidxs, con
     return threads > 512 ? launch<R, S, 1024, G>(gp, grid, k, kp, nblocks, threads, dbg, stream) \
                          : launch<R, S, 512, G>(gp, grid, k, kp, nblocks, threads, dbg, stream);
   QUIP_CASE(32, 1) QUIP_CASE(32, 2) QUIP_CASE(24, 1) QUIP_CASE(24, 2) QUIP_CASE(16, 1) QUIP_CASE(16, 2)
+  QUIP_CASE(64, 1) QUIP_CASE(64, 2)
 #undef QUIP_CASE
   return QUIP_ERR_UNSUPPORTED;
 }

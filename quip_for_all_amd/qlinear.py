@@ -103,7 +103,7 @@ class QuantLinear(nn.Module):
                 self.wscale_float / math.sqrt(L_in), self._vec(rms_weight), rms_eps,
                 None if gate is None else gate.reshape(x.shape).to(torch.float16))
             z = cb.mm_planes(planes, self.Qidxs)
-        elif (2 <= x.shape[0] <= 3 and hasattr(cb, "mm_planes")
+        elif (2 <= x.shape[0] <= 3 and hasattr(cb, "grid_packed_abs") and hasattr(cb, "mm_planes")
               and cb.planes_supported(self.q_out_features, self.q_in_features)
               and cb.planes_group_supported([self.q_out_features] * x.shape[0], self.q_in_features)):
             # 2..3 rows: every row gets its own digit planes (one grouped transform launch), then one
@@ -226,7 +226,7 @@ def _gemv_planes_grouped(layers, planes):
     cb = layers[0].codebook
     nbytes = sum(l.Qidxs.numel() * l.Qidxs.element_size() for l in layers)
     if len(layers) > 1 and nbytes <= _GROUP_MAX_BYTES:
-        return list(torch.ops.quip_lib.e8p_gemv_planes_group(planes, [l.Qidxs for l in layers], cb.grid_packed_abs))
+        return cb.mm_planes_group(planes, [l.Qidxs for l in layers])
     return [cb.mm_planes(p, l.Qidxs) for l, p in zip(layers, planes)]
 
 

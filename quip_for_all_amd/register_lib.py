@@ -43,6 +43,8 @@ _SCHEMAS = {
     "had_transform_planes_group": "(Tensor x, int n, int K, Tensor?[] had, bool transpose, Tensor?[] pre, "
                                   "float[] scale, Tensor? rms_weight, float rms_eps, Tensor? gate) -> Tensor[]",
     "e8p_gemv_planes_group": "(Tensor[] planes, Tensor[] Qidxs, Tensor grid) -> Tensor[]",
+    "d4_gemv_planes": "(Tensor planes, Tensor Qidxs, Tensor grid) -> Tensor",
+    "d4_gemv_planes_group": "(Tensor[] planes, Tensor[] Qidxs, Tensor grid) -> Tensor[]",
     # 2..3 activation rows against ONE weight matrix: the grouped GEMV with the same codes for every row
     "e8p_mm_planes_rows": "(Tensor[] planes, Tensor Qidxs, Tensor grid) -> Tensor",
     # chain: output side of the producer module (z, its SV, residual) + input transforms of 1..3 consumers;
@@ -184,6 +186,43 @@ def _vec_ok(t, dev):
     _need(t is None or (t.dtype == torch.float16 and t.is_contiguous() and t.device == dev),
           "vectors must be contiguous float16 on x's device")
     return _ptr(t)
+
+
+def _d4_grid(grid):
+    _need(grid.dtype == torch.float16 and grid.is_contiguous() and tuple(grid.shape) == (256, 4),
+          "D4 grid must be the contiguous fp16 (256, 4) table")
+    return grid
+
+
+def _d4_gemv_planes_cuda(planes, Qidxs, grid):
+    _need(Qidxs.dtype == torch.uint8 and Qidxs.is_contiguous(), "Qidxs must be contiguous uint8 (n, k/4)")
+    _need(planes.dtype == torch.uint8 and planes.is_contiguous() and planes.device == Qidxs.device, "planes: uint8")
+    n, k = Qidxs.shape[0], Qidxs.shape[1] * 4
+    y = torch.empty((1, n), dtype=torch.float16, device=Qidxs.device)
+    with torch.cuda.device(Qidxs.device):
+        capi.check(capi.lib().quip_d4_gemv_planes(planes.data_ptr(), Qidxs.data_ptr(), _d4_grid(grid).data_ptr(),
+                                                  y.data_ptr(), n, k, _stream(Qidxs)), "quip_d4_gemv_planes")
+    return y
+
+
+def _d4_gemv_planes_group_cuda(planes, Qidxs, grid):
+    import ctypes
+    count = len(planes)
+    _need(1 <= count <= capi.MAX_GROUP and len(Qidxs) == count, "group of 1..3 problems")
+    k = Qidxs[0].shape[1] * 4
+    dev = planes[0].device
+    for pl, q in zip(planes, Qidxs):
+        _need(q.dtype == torch.uint8 and q.is_contiguous() and q.shape[1] * 4 == k and q.device == dev,
+              "Qidxs must be contiguous uint8 (n, k/4) with a common k")
+        _need(pl.dtype == torch.uint8 and pl.is_contiguous() and pl.device == dev, "planes must be uint8")
+    outs = [torch.empty((1, q.shape[0]), dtype=torch.float16, device=dev) for q in Qidxs]
+    vp = ctypes.c_void_p * count
+    ns = (ctypes.c_int32 * count)(*[q.shape[0] for q in Qidxs])
+    with torch.cuda.device(dev):
+        capi.check(capi.lib().quip_d4_gemv_planes_group(
+            vp(*[p.data_ptr() for p in planes]), vp(*[q.data_ptr() for q in Qidxs]), _d4_grid(grid).data_ptr(),
+            vp(*[o.data_ptr() for o in outs]), ns, count, k, _stream(planes[0])), "quip_d4_gemv_planes_group")
+    return outs
 
 
 def _e8p_mm_planes_rows_cuda(planes, Qidxs, grid):
@@ -487,6 +526,8 @@ _IMPLS = {
     "had_transform_group": _had_transform_group_cuda,
     "e8p_gemv_planes_group": _e8p_gemv_planes_group_cuda,
     "e8p_mm_planes_rows": _e8p_mm_planes_rows_cuda,
+    "d4_gemv_planes": _d4_gemv_planes_cuda,
+    "d4_gemv_planes_group": _d4_gemv_planes_group_cuda,
     "had_transform_fused": _had_transform_fused_cuda,
     "had_transform_planes_fused": _had_transform_planes_fused_cuda,
     "e8p_mm_origorder": _e8p_mm_cuda,
@@ -529,6 +570,9 @@ _reg_fake("had_chain_planes_group", lambda z, z_post, z_residual, z_scale, n, pr
 _reg_fake("had_transform_group", lambda x, out_features, n, K, had, transpose, pre2, post, bias, scale, residual, pre,
           rms_weight, rms_eps:
           [t.new_empty((t.shape[0], int(o))) for t, o in zip(x, out_features)])
+_reg_fake("d4_gemv_planes", lambda planes, Qidxs, grid: Qidxs.new_empty((1, Qidxs.shape[0]), dtype=torch.float16))
+_reg_fake("d4_gemv_planes_group", lambda planes, Qidxs, grid:
+          [q.new_empty((1, q.shape[0]), dtype=torch.float16) for q in Qidxs])
 _reg_fake("e8p_mm_planes_rows", lambda planes, Qidxs, grid:
           Qidxs.new_empty((len(planes), Qidxs.shape[0]), dtype=torch.float16))
 _reg_fake("e8p_gemv_planes_group", lambda planes, Qidxs, grid:

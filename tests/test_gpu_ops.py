@@ -310,3 +310,29 @@ def test_hadamard_more_rows_than_one_grid_dimension(Q):
     pick = torch.tensor([0, 1, 65534, 65535, 65536, 69999], device="cuda")
     ref = torch.ops.quip_lib.hadamard(x[pick].contiguous(), 1.0 / 16.0)
     assert torch.equal(y[pick], ref)
+
+
+@pytest.mark.parametrize("n,k", [(4096, 4096), (11008, 4096), (4096, 11008), (512, 1408), (1000, 256), (28672, 8192)])
+def test_d4_gemv_planes_exact_integer_path(Q, n, k):
+    """D4 on the matrix-core GEMV: x -> digit planes -> integer product with the 2w int8 table;
+    equals the float64 product with the oracle's D4 weights within one fp16 rounding of y plus the
+    22-bit block fixed point of x (the same bound as E8P12's GEMV)"""
+    cb = _cb(Q, "D4")
+    rng = np.random.default_rng(n + k)
+    q = rng.integers(0, 256, size=(n, k // 4), dtype=np.uint8)
+    x = rng.standard_normal((1, k)).astype(np.float16)
+    xd = torch.from_numpy(x).to(DEV)
+    L = Q.capi.lib()
+    planes = torch.empty(L.quip_e8p_planes_bytes(k), dtype=torch.uint8, device=DEV)
+    Q.capi.check(L.quip_e8p_x_to_planes(xd.data_ptr(), planes.data_ptr(), k, torch.cuda.current_stream().cuda_stream), "planes")
+    qd = torch.from_numpy(q).to(DEV)
+    y = cb.mm_planes(planes, qd).cpu().numpy().astype(np.float64)
+    W64 = O.decompress_d4(q).astype(np.float64)
+    x64 = x.astype(np.float64)
+    y64 = x64 @ W64.T
+    assert np.all(np.abs(y - y64) <= _mm_tol(x64, W64, y64)), np.abs(y - y64).max()
+    # grouped launch == single launches, and == the generic D4 kernel within its own tolerance
+    y2 = cb.mm_planes_group([planes, planes], [qd, qd])
+    assert torch.equal(y2[0], y2[1]) and np.array_equal(y2[0].cpu().numpy().astype(np.float64), y)
+    yg = cb.mm(xd, qd).cpu().numpy().astype(np.float64)
+    assert np.all(np.abs(yg - y64) <= _mm_tol(x64, W64, y64) + 2.0 ** -9 * np.abs(y64))
