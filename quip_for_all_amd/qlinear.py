@@ -182,7 +182,7 @@ class QuantLinear(nn.Module):
 
     # ------------------------------------------------------------------ test / bench helper
     @classmethod
-    def from_oracle_params(cls, P):
+    def from_params(cls, P):
         """Build a layer from a plain-attribute parameter record (numpy arrays named as
         the state-dict keys); used by tests, smoke() and bench to share seeded inputs."""
         from .codebook import codebook_id

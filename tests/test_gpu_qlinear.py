@@ -12,7 +12,7 @@ DEV = "cuda:0"
 
 def _layer(P):
     import quip_for_all_amd as Q
-    return Q.QuantLinear.from_oracle_params(P).to(DEV).eval()
+    return Q.QuantLinear.from_params(P).to(DEV).eval()
 
 
 def test_reference_module_goldens(golden, golden_meta):

@@ -5,7 +5,7 @@ import quip_for_all_amd as Q
 from quip_for_all_amd import qlinear as QL
 from oracle import quip_oracle as O
 DEV = "cuda:0"
-def _layer(P): return Q.QuantLinear.from_oracle_params(P).to(DEV).eval()
+def _layer(P): return Q.QuantLinear.from_params(P).to(DEV).eval()
 k, fouts = 4096, (4096, 4096, 4096)
 layers = [_layer(O.make_layer("E8P12", k, fo, seed=k + fo + i)) for i, fo in enumerate(fouts)]
 rng = np.random.default_rng(k + len(fouts))
