@@ -56,6 +56,10 @@ namespace {
 #ifndef QUIP_GEMV_R8
 #define QUIP_GEMV_R8 0
 #endif
+// one-shot mode: slots requested ahead of the one being decoded
+#ifndef QUIP_GEMV_DEPTH
+#define QUIP_GEMV_DEPTH 3
+#endif
 constexpr bool kR8 = QUIP_GEMV_R8 != 0;
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -461,9 +465,14 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
     // past-the-end reloads read the L2-resident x planes (each lane its own 32 bytes)
     hot = reinterpret_cast<const uint4*>(gp.planes[0]) + (size_t)((tid * 2) % (ppieces - 1));
   }
+  // Weight loads in flight per wave.  Streaming mode: all SLOTS slots, reloaded in place.  One-shot
+  // mode: every item has its own slot registers but only kDepth slots are requested ahead of the
+  // one being decoded (slot i + kDepth is requested when slot i has landed), so that the address /
+  // TA work of the loads overlaps with the LDS-bound decode of other waves instead of preceding it.
+  constexpr int kDepth = ONESHOT ? (SLOTS < QUIP_GEMV_DEPTH ? SLOTS : QUIP_GEMV_DEPTH) : SLOTS;
   u32x4 qa[SLOTS], qb[SLOTS];
 #pragma unroll
-  for (int i = 0; i < SLOTS; ++i) {
+  for (int i = 0; i < kDepth; ++i) {
     const int it0 = wave + i * nwaves;
     const bool real = it0 < cnt;
     asm_load16_nt(qa[i], real ? item_ptr(it0, 0) : hot);
@@ -474,7 +483,7 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
   // (1) zeroed accumulators, then the tables as soon as the table source load has landed (every
   //     later load may still be in flight)
   for (int i = tid; i < kMaxRowsPerBlock * 4; i += nthreads) reinterpret_cast<int*>(smem + L::kAcc)[i] = 0;
-  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(tsrc) : "n"((FUSED ? 2 * (4 + G) : XR) + 2 * SLOTS) : "memory");
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(tsrc) : "n"((FUSED ? 2 * (4 + G) : XR) + 2 * kDepth) : "memory");
   if (wave < 8) fill_tables_from_lane<REP>(smem, tsrc, lane, wave);
   int sh[G];
   if constexpr (!FUSED) {
@@ -486,7 +495,7 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
   if constexpr (FUSED) {
     // (2f) the input side of the layer, computed here (see FusedIn).  All vector loads of the
     //      prologue are older than the weight loads: "at most 2 * SLOTS outstanding" == landed.
-    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * SLOTS) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * kDepth) : "memory");
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       asm volatile("" : "+v"(pin[h]), "+v"(ppost[h]), "+v"(pres[h]), "+v"(prms[h]));
@@ -559,7 +568,7 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
   } else {
     // (2) x digit planes into LDS once the 6 plane loads have landed (the 2 * SLOTS weight
     //     loads behind them may still be in flight)
-    asm_wait_vmcnt_x<2 * SLOTS>(xr[0], xr[1], xr[2], xr[3], xr[4], xr[5]);
+    asm_wait_vmcnt_x<2 * kDepth>(xr[0], xr[1], xr[2], xr[3], xr[4], xr[5]);
     const int rot = (int)((blockIdx.x * 613u) % (uint32_t)xpieces);
 #pragma unroll
     for (int j = 0; j < XR; ++j) {
@@ -608,7 +617,9 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
       const int cur = wave + i * nwaves;
-      switch (SLOTS - 1 - i) {   // folds after unrolling: loads of slots > i may still be in flight
+      // slots 0 .. min(i + kDepth, SLOTS) - 1 have been requested: once slot i has landed at most
+      // min(kDepth - 1, SLOTS - 1 - i) newer slots are outstanding (folds after unrolling)
+      switch ((kDepth - 1) < (SLOTS - 1 - i) ? (kDepth - 1) : (SLOTS - 1 - i)) {
         case 0: asm_wait_vmcnt<0>(qa[i], qb[i]); break;
         case 1: asm_wait_vmcnt<2>(qa[i], qb[i]); break;
         case 2: asm_wait_vmcnt<4>(qa[i], qb[i]); break;
@@ -617,6 +628,12 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
         case 5: asm_wait_vmcnt<10>(qa[i], qb[i]); break;
         case 6: asm_wait_vmcnt<12>(qa[i], qb[i]); break;
         default: asm_wait_vmcnt<14>(qa[i], qb[i]); break;
+      }
+      if (i + kDepth < SLOTS) {   // request the slot kDepth ahead (its own registers, nothing to wait for)
+        const int nxt = wave + (i + kDepth) * nwaves;
+        const bool real = nxt < cnt;
+        asm_load16_nt(qa[(i + kDepth) < SLOTS ? (i + kDepth) : 0], real ? item_ptr(nxt, 0) : hot);
+        asm_load16_nt(qb[(i + kDepth) < SLOTS ? (i + kDepth) : 0], real ? item_ptr(nxt, 1) : hot + 1);
       }
       if (cur < cnt) {   // wave-uniform
         ItemAddr ad;

@@ -17,7 +17,8 @@ L = capi.lib()
 grid = Q.codebook.codebook_id["E8P12"](inference=True).to(dev).grid_packed_abs
 names = ["issue loads", "tables+zero", "planes->LDS+bar", "lane consts", "main loop", "barrier", "epilogue"]
 rep, rows, maxw = (int(v) for v in (sys.argv[1:4] if len(sys.argv) >= 4 else (0, 0, 0)))
-NSETS = 24
+NSETS = int(os.environ.get("NSETS", "24"))
+HOT = os.environ.get("HOT", "0") == "1"    # every launch on the same weights (L2 / MALL resident)
 
 
 def run_case(ns, k):
@@ -39,7 +40,7 @@ def run_case(ns, k):
 
     def launch(i, dbg):
         st = torch.cuda.current_stream().cuda_stream
-        capi.check(L.quip_e8p_gemv_group_tuned(vp(*[p.data_ptr() for p in planes]), vp(*[q.data_ptr() for q in sets[i % NSETS]]),
+        capi.check(L.quip_e8p_gemv_group_tuned(vp(*[p.data_ptr() for p in planes]), vp(*[q.data_ptr() for q in sets[0 if HOT else i % NSETS]]),
                                                grid.data_ptr(), vp(*[y.data_ptr() for y in ys]), nsa, cnt, k, rep, rows, 0,
                                                maxw, dbg, st), "group")
     dbg = torch.zeros(4096 * 8, dtype=torch.int64, device=dev)
