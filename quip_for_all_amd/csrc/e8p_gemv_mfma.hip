@@ -56,9 +56,11 @@ namespace {
 #ifndef QUIP_GEMV_R8
 #define QUIP_GEMV_R8 0
 #endif
-// one-shot mode: slots requested ahead of the one being decoded
+// one-shot mode: slots requested ahead of the one being decoded.  Measured on the 7B shapes (us per
+// launch, q/k/v group | gate/up group | down | 8192^2): depth 1: 8.35 10.61 6.74 7.61; 2: 8.67 10.72 7.02
+// 7.53; 3: 8.86 10.75 7.77 8.21; 4: 8.79 11.33 7.61 8.62; all upfront: 8.78 12.22 7.64 8.61.
 #ifndef QUIP_GEMV_DEPTH
-#define QUIP_GEMV_DEPTH 3
+#define QUIP_GEMV_DEPTH 1
 #endif
 constexpr bool kR8 = QUIP_GEMV_R8 != 0;
 
