@@ -970,14 +970,18 @@ int e8p_gemv_mfma_launch(const void* planes, const void* qidxs, const void* grid
   rpb = (rpb + 15) & ~15;
   if (rpb > kMaxRowsPerBlock) rpb = kMaxRowsPerBlock;
   nblocks = (n + rpb - 1) / rpb;
-  int waves = tune.max_waves > 0 ? tune.max_waves : 8;   // measured best on MI355X (tools/gemv_bench.py)
+  // Measured on MI355X (tools/gemv_bench.py, us per launch): up to 8 items per wave -> one-shot mode on
+  // 8 waves; longer streams -> ONE slot per wave in flight and more waves (28672 x 8192: 15.4 us with
+  // 12 waves x 1 slot vs 16.6 with 8 x 2; 8192 x 28672: 18.4 with 16 x 1 vs 20.2 with 14 x 2).
+  const int items = ((rpb + 15) >> 4) * (kp >> 9);
+  int waves = tune.max_waves > 0 ? tune.max_waves : (items <= 64 ? 8 : (kp > 16384 ? 16 : 12));
   if (waves > 16) waves = 16;
   if (waves < 8) waves = 8;    // the table build uses waves 0..7
   const int min_waves = (3 * (kp >> 4) + 6 * 64 - 1) / (6 * 64);  // 6 x pieces per thread
   if (waves < min_waves) waves = min_waves;
   const int rep = pick_rep(1, kp, tune.rep);
-  const int items_per_wave = (((rpb + 15) >> 4) * (kp >> 9) + waves - 1) / waves;
-  int slots = tune.rows ? tune.rows : (items_per_wave >= 4 ? 2 : 1);
+  const int items_per_wave = (items + waves - 1) / waves;
+  int slots = tune.rows ? tune.rows : 1;
   const int threads = waves * 64;
   if (threads > 512 && slots > 2) slots = 2;  // 128-VGPR budget: deeper queues would spill, and
                                               // scratch traffic would corrupt the counted vmcnt waits
