@@ -248,11 +248,16 @@ int quip_e8p_gemv_fused(const quip_gemv_fused_in* in, const void* const* qidxs,
  *   q [heads, head_dim], k / v [kv_heads, head_dim], out [heads, head_dim]: fp16
  *   cos / sin [max_len, head_dim] fp32 (HF half-rotation tables), pos: device int64 scalar
  *   kcache / vcache [kv_heads, max_len, head_dim] fp16, row *pos is written
- * head_dim 64 or 128; scale is the softmax scale (1/sqrt(head_dim)). */
+ * head_dim 64 or 128; scale is the softmax scale (1/sqrt(head_dim)).
+ * workspace (optional): quip_rope_attn_workspace_bytes(heads, head_dim) bytes, zeroed ONCE by the
+ * caller and then reused by every call on that stream: with it, contexts beyond 256 positions are
+ * split over 8 workgroups per head whose partial softmax states are merged by the last one to finish
+ * (the one-workgroup-per-head walk is latency bound: 89 us at 2048 positions).  NULL: never split. */
+size_t quip_rope_attn_workspace_bytes(int32_t heads, int32_t head_dim);
 int quip_rope_attn_decode_f16(const void* q, const void* k, const void* v, const float* cos,
                               const float* sin, const int64_t* pos, void* kcache, void* vcache,
                               void* out, int32_t heads, int32_t kv_heads, int32_t head_dim,
-                              int32_t max_len, float scale, quip_stream_t stream);
+                              int32_t max_len, float scale, void* workspace, quip_stream_t stream);
 
 #ifdef __cplusplus
 }

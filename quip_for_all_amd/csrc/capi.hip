@@ -204,15 +204,20 @@ int quip_e8p_gemv_fused(const quip_gemv_fused_in* in, const void* const* qidxs,
   return e8p_gemv_mfma_fused_launch(f, qidxs, grid_packed_abs, ys, n32, count, k, GemvTune{}, (hipStream_t)stream);
 }
 
+size_t quip_rope_attn_workspace_bytes(int32_t heads, int32_t head_dim) {
+  return heads > 0 && head_dim > 0 ? rope_attn_workspace_bytes(heads, head_dim) : 0;
+}
+
 int quip_rope_attn_decode_f16(const void* q, const void* k, const void* v, const float* cos,
                               const float* sin, const int64_t* pos, void* kcache, void* vcache,
                               void* out, int32_t heads, int32_t kv_heads, int32_t head_dim,
-                              int32_t max_len, float scale, quip_stream_t stream) {
+                              int32_t max_len, float scale, void* workspace, quip_stream_t stream) {
   if (!q || !k || !v || !cos || !sin || !pos || !kcache || !vcache || !out) return QUIP_ERR_NULL_POINTER;
   if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(kcache) || !aligned16(vcache))
     return QUIP_ERR_MISALIGNED;
+  if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return QUIP_ERR_MISALIGNED;
   return rope_attn_decode_launch(q, k, v, cos, sin, pos, kcache, vcache, out, heads, kv_heads, head_dim,
-                                 max_len, scale, (hipStream_t)stream);
+                                 max_len, scale, (hipStream_t)stream, workspace);
 }
 
 int quip_e8p_mm_origorder(const void* x, const void* qidxs, const void* grid, void* y, int32_t m,

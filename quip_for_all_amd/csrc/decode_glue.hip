@@ -29,7 +29,12 @@ struct AttnArgs {
   f16* out;            // [heads, HD]
   int heads, kv_heads, max_len;
   float scale;
+  float* ws;           // split mode: partial (acc[HD], m, l) per (head, split); null: one workgroup per head
+  unsigned* counters;  // split mode: arrivals per head (zero between launches)
 };
+
+constexpr int kSplits = 8;  // workgroups per head for long contexts (grid.y)
+constexpr int kSplitFromPos = 256;    // shorter contexts: split 0 does everything, no workspace traffic
 
 __device__ __forceinline__ void unpack8h(const uint4& u, float o[8]) {
   const uint32_t w[4] = {u.x, u.y, u.z, u.w};
@@ -65,6 +70,14 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(AttnArgs a) {
   const int gl = tid % LPK, grp = tid / LPK, d0 = gl * 8;
   const int group = a.heads / a.kv_heads, kvh = h / group;
   const int pos = (int)*a.pos;
+  // split mode (long context, workspace given): workgroup (h, s) takes positions [t_lo, t_hi); the last
+  // workgroup of a head to arrive merges the partial softmax states (flash-decoding across CUs)
+  const bool split = a.ws != nullptr && pos >= kSplitFromPos;
+  const int sidx = blockIdx.y;
+  if (!split && sidx > 0) return;
+  const int chunk = split ? (pos + kSplits) / kSplits : pos + 1;      // ceil((pos + 1) / kSplits)
+  const int t_lo = split ? sidx * chunk : 0;
+  const int t_hi = split ? min(pos + 1, t_lo + chunk) : pos + 1;       // exclusive
   const float* cs = a.cos + (size_t)pos * HD;
   const float* sn = a.sin + (size_t)pos * HD;
 
@@ -77,7 +90,7 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(AttnArgs a) {
   for (int i = 0; i < 8; ++i) q8[i] *= a.scale;
   f16* kc = a.kcache + (size_t)kvh * a.max_len * HD;
   f16* vc = a.vcache + (size_t)kvh * a.max_len * HD;
-  if (h % group == 0 && grp == 0) {   // append the new row (StaticCache.update)
+  if (h % group == 0 && grp == 0 && sidx == 0) {   // append the new row (StaticCache.update)
     uint4 kr;
     kr.x = pack_f16(kn[0], kn[1]); kr.y = pack_f16(kn[2], kn[3]);
     kr.z = pack_f16(kn[4], kn[5]); kr.w = pack_f16(kn[6], kn[7]);
@@ -88,7 +101,7 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(AttnArgs a) {
   float m = -INFINITY, l = 0.f, acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-  for (int t0 = grp; t0 <= pos; t0 += NG * U) {
+  for (int t0 = t_lo + grp; t0 < t_hi; t0 += NG * U) {
     uint4 kr[U], vr[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -112,7 +125,7 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(AttnArgs a) {
       for (int i = 0; i < 8; ++i) s = __builtin_fmaf(q8[i], k8[i], s);
 #pragma unroll
       for (int o = 1; o < LPK; o <<= 1) s += __shfl_xor(s, o, 64);
-      if (t <= pos) {
+      if (t < t_hi) {
         const float mn = fmaxf(m, s);
         const float c = __expf(m - mn), p = __expf(s - mn);
         l = l * c + p;
@@ -126,32 +139,84 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(AttnArgs a) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) s_acc[grp][d0 + i] = acc[i];
   __syncthreads();
+  float M = -INFINITY, Lsum = 0.f, o = 0.f;
   if (tid < HD) {
-    float M = -INFINITY;
     for (int g = 0; g < NG; ++g) M = fmaxf(M, s_m[g]);
-    float Lsum = 0.f, o = 0.f;
     for (int g = 0; g < NG; ++g) {
       const float w = s_m[g] == -INFINITY ? 0.f : __expf(s_m[g] - M);
       Lsum = __builtin_fmaf(s_l[g], w, Lsum);
       o = __builtin_fmaf(s_acc[g][tid], w, o);
     }
-    a.out[(size_t)h * HD + tid] = (f16)(o / Lsum);
   }
+  if (!split) {
+    if (tid < HD) a.out[(size_t)h * HD + tid] = (f16)(o / Lsum);
+    return;
+  }
+  // Publish this split's state, then count arrivals; the last one merges.  The exchange uses
+  // agent-scope atomic stores / loads (coherent across the XCDs' L2s by themselves) ordered by
+  // "all my stores have completed" (s_waitcnt vmcnt(0)) -> barrier -> counter increment, instead of
+  // __threadfence(): a release fence writes back the whole L2, measured ~20 us per launch here.
+  float* mine = a.ws + ((size_t)h * kSplits + sidx) * (HD + 4);
+  if (tid < HD) __hip_atomic_store(mine + tid, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) {
+    __hip_atomic_store(mine + HD, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(mine + HD + 1, Lsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __shared__ unsigned s_old;
+  __syncthreads();
+  if (tid == 0) s_old = __hip_atomic_fetch_add(a.counters + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (s_old != kSplits - 1) return;
+  asm volatile("" ::: "memory");
+  if (tid < HD) {
+    float* base = a.ws + (size_t)h * kSplits * (HD + 4);
+    float ms[kSplits], ls[kSplits], os[kSplits];
+#pragma unroll
+    for (int s2 = 0; s2 < kSplits; ++s2) {
+      ms[s2] = __hip_atomic_load(base + s2 * (HD + 4) + HD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ls[s2] = __hip_atomic_load(base + s2 * (HD + 4) + HD + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      os[s2] = __hip_atomic_load(base + s2 * (HD + 4) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    float Mx = -INFINITY;
+#pragma unroll
+    for (int s2 = 0; s2 < kSplits; ++s2) Mx = fmaxf(Mx, ms[s2]);
+    float L2 = 0.f, o2 = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < kSplits; ++s2) {
+      const float w = ms[s2] == -INFINITY ? 0.f : __expf(ms[s2] - Mx);
+      L2 = __builtin_fmaf(ls[s2], w, L2);
+      o2 = __builtin_fmaf(os[s2], w, o2);
+    }
+    a.out[(size_t)h * HD + tid] = (f16)(o2 / L2);
+  }
+  if (tid == 0) __hip_atomic_store(a.counters + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
 }
 
 }  // namespace
 
+size_t rope_attn_workspace_bytes(int heads, int head_dim) {
+  return (size_t)heads * kSplits * (head_dim + 4) * sizeof(float) + (size_t)heads * sizeof(unsigned);
+}
+
 int rope_attn_decode_launch(const void* q, const void* k, const void* v, const float* cos, const float* sin,
                             const int64_t* pos, void* kcache, void* vcache, void* out, int heads, int kv_heads,
-                            int head_dim, int max_len, float scale, hipStream_t stream) {
+                            int head_dim, int max_len, float scale, hipStream_t stream, void* workspace) {
   if (heads < 1 || kv_heads < 1 || heads % kv_heads != 0 || max_len < 1) return QUIP_ERR_BAD_SHAPE;
   AttnArgs a{reinterpret_cast<const f16*>(q), reinterpret_cast<const f16*>(k), reinterpret_cast<const f16*>(v),
              cos, sin, pos, reinterpret_cast<f16*>(kcache), reinterpret_cast<f16*>(vcache),
-             reinterpret_cast<f16*>(out), heads, kv_heads, max_len, scale};
+             reinterpret_cast<f16*>(out), heads, kv_heads, max_len, scale, nullptr, nullptr};
+  const bool split = workspace != nullptr && max_len > kSplitFromPos;
+  if (split) {
+    a.ws = reinterpret_cast<float*>(workspace);
+    a.counters = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) +
+                                             (size_t)heads * kSplits * (head_dim + 4) * sizeof(float));
+  }
+  const dim3 grid(heads, split ? kSplits : 1);
   if (head_dim == 128)
-    hipLaunchKernelGGL(rope_attn_decode_kernel<128>, dim3(heads), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(rope_attn_decode_kernel<128>, grid, dim3(256), 0, stream, a);
   else if (head_dim == 64)
-    hipLaunchKernelGGL(rope_attn_decode_kernel<64>, dim3(heads), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(rope_attn_decode_kernel<64>, grid, dim3(256), 0, stream, a);
   else
     return QUIP_ERR_UNSUPPORTED;
   return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;

@@ -106,7 +106,8 @@ int had_transform_launch(const void* x, void* y, int64_t rows, int in_features, 
                          hipStream_t stream, const HadFusion* fuse = nullptr);
 int rope_attn_decode_launch(const void* q, const void* k, const void* v, const float* cos, const float* sin,
                             const int64_t* pos, void* kcache, void* vcache, void* out, int heads, int kv_heads,
-                            int head_dim, int max_len, float scale, hipStream_t stream);
+                            int head_dim, int max_len, float scale, hipStream_t stream, void* workspace = nullptr);
+size_t rope_attn_workspace_bytes(int heads, int head_dim);
 int had_transform_planes_launch(const void* x, void* planes, int in_features, int n, int K,
                                 const void* had, int transpose, const void* pre, float scale,
                                 hipStream_t stream, const HadFusion* fuse = nullptr);

@@ -114,6 +114,8 @@ class LlamaDecoder:
         self.pos = torch.zeros(1, dtype=torch.long, device=self.dev)
         self.graph = None
         self.fused_attention = s.head_dim in (64, 128)
+        from .register_lib import rope_attn_workspace
+        self.attn_ws = rope_attn_workspace(s.heads, s.head_dim, self.dev) if self.fused_attention else None
         L0 = self.layers[0]
         import os
         qkv0, gu0 = [L0["q"], L0["k"], L0["v"]], [L0["gate"], L0["up"]]
@@ -147,7 +149,7 @@ class LlamaDecoder:
             # rope + cache append + attention over [0, pos]: one launch
             return torch.ops.quip_lib.rope_attn_decode(
                 q.view(s.heads, s.head_dim), k.view(s.kv_heads, s.head_dim), v.view(s.kv_heads, s.head_dim),
-                self.cos, self.sin, self.pos, self.kcache[i], self.vcache[i])
+                self.cos, self.sin, self.pos, self.kcache[i], self.vcache[i], self.attn_ws)
         q = self._rope(q.view(1, s.heads, 1, s.head_dim), cos, sin)
         k = self._rope(k.view(1, s.kv_heads, 1, s.head_dim), cos, sin)
         self.kcache[i].index_copy_(1, self.pos, k[0])

@@ -59,7 +59,7 @@ _SCHEMAS = {
                       "float z_scale, Tensor[] pre, float[] scale, Tensor[] Qidxs, Tensor grid) -> Tensor[]",
     # decode-step glue between q/k/v_proj and o_proj: rope + KV-cache append + single-query attention
     "rope_attn_decode": "(Tensor q, Tensor k, Tensor v, Tensor cos, Tensor sin, Tensor pos, Tensor(a!) kcache, "
-                        "Tensor(b!) vcache) -> Tensor",
+                        "Tensor(b!) vcache, Tensor(c!)? workspace) -> Tensor",
     "had_transform_planes_fused": "(Tensor x, int n, int K, Tensor? had, bool transpose, Tensor? pre, float scale, "
                                   "Tensor? rms_weight, float rms_eps, Tensor? gate) -> Tensor",
 }
@@ -365,7 +365,12 @@ def _e8p_gemv_fused_cuda(x, z, post, residual, rms_weight, rms_eps, z_scale, pre
     return ([h_out] if h_out is not None else []) + outs
 
 
-def _rope_attn_decode_cuda(q, k, v, cos, sin, pos, kcache, vcache):
+def rope_attn_workspace(heads, head_dim, device):
+    """zeroed scratch for the split (long context) mode of rope_attn_decode; allocate once, reuse"""
+    return torch.zeros(capi.lib().quip_rope_attn_workspace_bytes(heads, head_dim), dtype=torch.uint8, device=device)
+
+
+def _rope_attn_decode_cuda(q, k, v, cos, sin, pos, kcache, vcache, workspace=None):
     """q (heads, hd), k / v (kv_heads, hd) fp16; cos / sin (max_len, hd) fp32; pos int64 device scalar;
     kcache / vcache (kv_heads, max_len, hd) fp16 (row pos is written) -> (heads, hd) fp16"""
     import math
@@ -380,11 +385,15 @@ def _rope_attn_decode_cuda(q, k, v, cos, sin, pos, kcache, vcache):
           and kcache.shape[2] == hd and tuple(cos.shape) == (max_len, hd) and tuple(sin.shape) == (max_len, hd),
           "rope_attn_decode: shape mismatch")
     out = torch.empty_like(q)
+    if workspace is not None:
+        _need(workspace.dtype == torch.uint8 and workspace.is_contiguous() and workspace.device == q.device
+              and workspace.numel() >= capi.lib().quip_rope_attn_workspace_bytes(heads, hd),
+              "workspace: use rope_attn_workspace(heads, head_dim, device)")
     with torch.cuda.device(q.device):
         capi.check(capi.lib().quip_rope_attn_decode_f16(
             q.data_ptr(), k.data_ptr(), v.data_ptr(), cos.data_ptr(), sin.data_ptr(), pos.data_ptr(),
             kcache.data_ptr(), vcache.data_ptr(), out.data_ptr(), heads, kvh, hd, max_len, 1.0 / math.sqrt(hd),
-            _stream(q)), "quip_rope_attn_decode_f16")
+            _ptr(workspace), _stream(q)), "quip_rope_attn_decode_f16")
     return out
 
 
@@ -580,7 +589,7 @@ _reg_fake("e8p_gemv_planes_group", lambda planes, Qidxs, grid:
 _reg_fake("e8p_gemv_fused", lambda x, z, post, residual, rms_weight, rms_eps, z_scale, pre, scale, Qidxs, grid:
           ([z.new_empty((1, z.numel()))] if z is not None else []) +
           [q.new_empty((1, q.shape[0]), dtype=torch.float16) for q in Qidxs])
-_reg_fake("rope_attn_decode", lambda q, k, v, cos, sin, pos, kcache, vcache: torch.empty_like(q))
+_reg_fake("rope_attn_decode", lambda q, k, v, cos, sin, pos, kcache, vcache, workspace=None: torch.empty_like(q))
 _reg_fake("e8p_gemv_planes", lambda planes, Q, g: Q.new_empty((1, Q.shape[0]), dtype=torch.float16))
 for _n in ("e8p_mm_origorder", "e8prvq3_mm_origorder", "e8prvq4_mm_origorder", "d4_mm_origorder",
            "hi_mm_origorder"):

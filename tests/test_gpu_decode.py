@@ -93,7 +93,8 @@ def test_decoder_byte_count_matches_survey():
 
 
 @pytest.mark.parametrize("heads,kv_heads,hd,pos", [(32, 32, 128, 0), (32, 32, 128, 37), (8, 2, 128, 200),
-                                                   (4, 2, 64, 5), (4, 4, 64, 130), (64, 8, 128, 1000)])
+                                                   (4, 2, 64, 5), (4, 4, 64, 130), (64, 8, 128, 1000),
+                                                   (32, 32, 128, 256), (8, 8, 64, 2047), (16, 2, 128, 4100)])
 def test_rope_attn_decode_matches_torch(heads, kv_heads, hd, pos):
     """fused rope + cache append + single-query attention == the eager torch ops it replaces"""
     import quip_for_all_amd  # noqa: F401
@@ -112,7 +113,16 @@ def test_rope_attn_decode_matches_torch(heads, kv_heads, hd, pos):
     sin = torch.cat([ang.sin(), ang.sin()], -1).to(dev)
     p = torch.tensor([pos], device=dev)
     kc2, vc2 = kc.clone(), vc.clone()
-    out = torch.ops.quip_lib.rope_attn_decode(q, k, v, cos, sin, p, kc2, vc2)
+    out = torch.ops.quip_lib.rope_attn_decode(q, k, v, cos, sin, p, kc2, vc2, None)
+    # split mode (workspace given; used from 256 positions on): same result up to the merge order, and the
+    # workspace is reusable (arrival counters are reset by the merging workgroup)
+    from quip_for_all_amd.register_lib import rope_attn_workspace
+    ws = rope_attn_workspace(heads, hd, dev)
+    for _ in range(3):
+        kc3, vc3 = kc.clone(), vc.clone()
+        out_s = torch.ops.quip_lib.rope_attn_decode(q, k, v, cos, sin, p, kc3, vc3, ws)
+        assert torch.equal(kc3, kc2) and torch.equal(vc3, vc2)
+        assert (out_s.float() - out.float()).abs().max().item() <= 2e-3 * max(1.0, out.float().abs().max().item())
 
     def rope(x):
         d = hd // 2
