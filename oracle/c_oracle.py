@@ -45,29 +45,40 @@ def fwht(x):
     return y
 
 
-def qlinear_forward(P, x):
-    """one token row through the C forward; P is an oracle QLinearParams (E8P12, scalar Wscale)"""
+def _prepare(P):
+    """C argument buffers of a layer (built once; keeps the numpy arrays alive)"""
     assert P.codebook == "E8P12" and not P.per_channel
     f32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
-    xx = f32(np.asarray(x).reshape(-1))
-    y = np.empty(P.out_features, np.float32)
-    keep = [f32(P.SU), f32(P.SV), f32(P.bias), f32(P.had_left), f32(P.had_right),
+    return [f32(P.SU), f32(P.SV), f32(P.bias), f32(P.had_left), f32(P.had_right),
             np.ascontiguousarray(P.Qidxs).view(np.uint16), np.ascontiguousarray(O.e8p_grid_packed_abs())]
+
+
+def _call(P, keep, xx, y):
     c = ctypes
     lib().quip_oracle_qlinear_e8p(_p(xx), _p(y), c.c_long(P.in_features), c.c_long(P.out_features),
                                   c.c_long(P.q_in), c.c_long(P.q_out), _p(keep[5]), _p(keep[6]), _p(keep[0]),
                                   _p(keep[1]), _p(keep[2]), c.c_float(P.wscale_float), c.c_long(P.K_left),
                                   _p(keep[3]), c.c_long(P.K_right), _p(keep[4]))
+
+
+def qlinear_forward(P, x):
+    """one token row through the C forward; P is an oracle QLinearParams (E8P12, scalar Wscale)"""
+    xx = np.ascontiguousarray(np.asarray(x).reshape(-1), dtype=np.float32)
+    y = np.empty(P.out_features, np.float32)
+    _call(P, _prepare(P), xx, y)
     return y
 
 
 def time_qlinear_forward(codebook, fin, fout, min_time=3.0):
+    """seconds per call of the C forward alone (argument buffers and tables prepared outside the loop)"""
     P = O.make_layer(codebook, fin, fout, seed=1)
-    x = np.random.default_rng(0).standard_normal(fin).astype(np.float32)
-    qlinear_forward(P, x)
+    xx = np.random.default_rng(0).standard_normal(fin).astype(np.float32)
+    y = np.empty(P.out_features, np.float32)
+    keep = _prepare(P)
+    _call(P, keep, xx, y)
     n, t0 = 0, time.perf_counter()
     while True:
-        qlinear_forward(P, x)
+        _call(P, keep, xx, y)
         n += 1
         dt = time.perf_counter() - t0
         if dt >= min_time and n >= 3:
