@@ -302,6 +302,8 @@ struct GemvGroup {
   f16* y[G];
   int N[G];
   int rpb[G];
+  int boff[G];   // workgroup b serves row range ((b - boff) mod gridDim.x) of the problem: problems that need
+                 // fewer workgroups than the launch has start at different workgroups (70B k / v next to q)
 };
 
 // Input side of the GEMV computed in the prologue instead of by separate launches (bs = 1 decode,
@@ -349,7 +351,9 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
   cbase[0] = 0;
 #pragma unroll
   for (int p = 0; p < G; ++p) {
-    row0[p] = blockIdx.x * gp.rpb[p];
+    int bp = (int)blockIdx.x - gp.boff[p];
+    bp = bp < 0 ? bp + (int)gridDim.x : bp;
+    row0[p] = bp * gp.rpb[p];
     rows_here[p] = max(0, min(gp.N[p], row0[p] + gp.rpb[p]) - row0[p]);
     cbase[p + 1] = cbase[p] + ((rows_here[p] + 15) >> 4) * J;
     rbase[p] = p == 0 ? 0 : rbase[p - 1] + gp.rpb[p - 1];
@@ -986,7 +990,7 @@ int e8p_gemv_mfma_launch(const void* planes, const void* qidxs, const void* grid
   if (threads > 512 && slots > 2) slots = 2;  // 128-VGPR budget: deeper queues would spill, and
                                               // scratch traffic would corrupt the counted vmcnt waits
   GemvGroup<1> gp{{reinterpret_cast<const uint4*>(qidxs)}, {reinterpret_cast<const uint8_t*>(planes)},
-                  {reinterpret_cast<f16*>(y)}, {n}, {rpb}};
+                  {reinterpret_cast<f16*>(y)}, {n}, {rpb}, {0}};
   if (!tune.rows && threads <= 512 && items_per_wave <= 8)
     return launch_oneshot<1>(gp, grid, k, kp, nblocks, threads, rep, items_per_wave, dbg, stream);
 #define QUIP_CASE(R, S)                                                                        \
@@ -1043,6 +1047,17 @@ static int group_launch(const void* const* planes, const void* const* qidxs, con
     items += (gp.rpb[p] >> 4) * (kp >> 9);
   }
   nblocks = used;
+  {   // stagger the problems that do not fill the launch
+    int next = 0;
+    for (int p = 0; p < G; ++p) {
+      const int need = (ns[p] + gp.rpb[p] - 1) / gp.rpb[p];
+      gp.boff[p] = 0;
+      if (need < nblocks) {
+        gp.boff[p] = next % nblocks;
+        next += need;
+      }
+    }
+  }
   int waves = tune.max_waves > 0 ? tune.max_waves : 8;
   if (waves > 16) waves = 16;
   if (waves < 8) waves = 8;
@@ -1114,6 +1129,7 @@ static int fused_launch(const GemvFusedIn& in, const void* const* qidxs, const v
     items += (gp.rpb[p] >> 4) * (kp >> 9);
   }
   nblocks = used;
+  for (int p = 0; p < G; ++p) gp.boff[p] = 0;
   const int waves = 8, threads = 512;       // n / 16 <= 512 transform threads
   const int ipw = (items + waves - 1) / waves;
   uint64_t* dbg = reinterpret_cast<uint64_t*>(tune.dbg);
