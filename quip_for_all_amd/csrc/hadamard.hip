@@ -65,6 +65,8 @@ struct HadArgs {
   f16* h_out;           // [rows, n]
   float z_scale;
   int pp;               // floats between the two halves of the ping-pong shuffle buffer (0: single buffer)
+  int tgroups;          // wide K > 1: thread groups that split the k range (partials combined through LDS)
+  int part_off;         // floats from buf to the partial-sum area
   float scale, rms_eps;
 };
 
@@ -180,12 +182,14 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
   const int L = a.L, K = a.K, logL = a.logL;
   // tall: the tile is 4096 elements = 256 "tile threads" x 16; the workgroup has 4 x 256 threads that
   // share the row staging and split the k range of the K-mix; threads >= 256 then only keep barriers
+  // wide with K > 1: a.tgroups groups of L / 16 threads each take every tgroups-th k of the K-mix
   constexpr int kTile = 256;
-  const bool act = !TALL || tid < kTile;
-  const int nta = TALL ? kTile : nt;              // threads that hold transform data
+  const int nta = TALL ? kTile : nt / a.tgroups;   // threads that hold transform data ("tile threads")
+  const int tgrp = tid / nta, tt = tid - tgrp * nta;
+  const bool act = tgrp == 0;
   const int R = TALL ? (16 * kTile) >> logL : 1;
   const int kp0 = blockIdx.x * R;
-  const int e0 = tid * 16;                         // first of this thread's 16 elements of [R][L]
+  const int e0 = tt * 16;                          // first of this thread's 16 elements of [R][L]
   const int kp = kp0 + (e0 >> logL), j0 = e0 & (L - 1);
 
   HSTAMP(0);
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
       ld8(zr + j0, v); ld8(zr + j0 + 8, v + 8);
       ld8(a.z_post + j0, tp); ld8(a.z_post + j0 + 8, tp + 8);
       if (a.z_res) { ld8(a.z_res + row * a.n + j0, tr); ld8(a.z_res + row * a.n + j0 + 8, tr + 8); }
-      had::fht16(v, buf, tid, logL, true, a.pp);
+      had::fht16(v, buf, tt, logL, true, a.pp);
       f16 o[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r)
@@ -232,23 +236,24 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
       in_vals16(a, xr, gr, kp * L + j0, v, ss_x);
     } else if constexpr (!KONE) {
       constexpr int U = MAXT <= 256 ? 2 : 1;       // k values per memory round trip
-      for (int k0 = 0; k0 < K; k0 += U) {
+      const int TG = a.tgroups;
+      for (int k0 = tgrp; k0 < K; k0 += U * TG) {
         float h[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const int k = min(k0 + u, K - 1);
-          h[u] = (k0 + u) < K ? (float)(a.transpose ? a.had[k * K + kp] : a.had[kp * K + k]) : 0.f;
+          const int k = min(k0 + u * TG, K - 1);
+          h[u] = (k0 + u * TG) < K ? (float)(a.transpose ? a.had[k * K + kp] : a.had[kp * K + k]) : 0.f;
         }
         if (a.vec) {
           Raw16 raw[U];
 #pragma unroll
-          for (int u = 0; u < U; ++u) raw_load16(a, xr, gr, min(k0 + u, K - 1) * L + j0, raw[u]);
+          for (int u = 0; u < U; ++u) raw_load16(a, xr, gr, min(k0 + u * TG, K - 1) * L + j0, raw[u]);
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             float e[16];
             float sx = 0.f;
-            raw_math16(a, min(k0 + u, K - 1) * L + j0, raw[u], e, sx);
-            if (k0 + u < K) {
+            raw_math16(a, min(k0 + u * TG, K - 1) * L + j0, raw[u], e, sx);
+            if (k0 + u * TG < K) {
               ss_x += sx;
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
@@ -258,14 +263,28 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
             }
           }
         } else {
-          for (int u = 0; u < U && k0 + u < K; ++u) {
+          for (int u = 0; u < U && k0 + u * TG < K; ++u) {
             float e[16];
-            in_vals16(a, xr, gr, (k0 + u) * L + j0, e, ss_x);
+            in_vals16(a, xr, gr, (k0 + u * TG) * L + j0, e, ss_x);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               ss_in = __builtin_fmaf(e[r], e[r], ss_in);
               v[r] = __builtin_fmaf(h[u], e[r], v[r]);
             }
+          }
+        }
+      }
+      if (TG > 1) {   // combine the groups' partial sums in a fixed order: 0 + 1 + 2 + 3
+        float* part = buf + a.part_off;
+        if (tgrp > 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) part[((tgrp - 1) * 16 + r) * nta + tt] = v[r];
+        }
+        __syncthreads();
+        if (act) {
+          for (int o = 1; o < TG; ++o) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = had::fadd(v[r], part[((o - 1) * 16 + r) * nta + tt]);
           }
         }
       }
@@ -344,7 +363,7 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
 
   HSTAMP(4);
   // (2) length-L transform: 4 index bits per pass in registers, LDS re-shuffle in between
-  had::fht16(v, buf, tid, logL, act, a.pp);
+  had::fht16(v, buf, tt, logL, act, a.pp);
   HSTAMP(5);
   const bool live = act && kp < K;                // rows past K in the last tall workgroup
 
@@ -524,6 +543,20 @@ int launch(HadGroup& g, int count, int64_t rows, hipStream_t stream) {
     const bool batch = rows > 8;
     const int lds = (batch ? 1 : 2) * had::buf_floats(L) * 4;
     for (int i = 0; i < count; ++i) g.p[i].pp = batch ? 0 : had::buf_floats(L);
+    for (int i = 0; i < count; ++i) { g.p[i].tgroups = 1; g.p[i].part_off = 0; }
+    if (L <= 4096 && K > 1 && rows <= 8) {
+      // latency-bound decode launch of a long row (28672 = 7 x 4096): up to 4 thread groups split the k loop
+      int tg = K < 4 ? K : 4;
+      while ((L / 16) * tg > 1024) --tg;
+      if (tg > 1) {
+        const int part = 2 * had::buf_floats(L);
+        const int lds2 = (part + (tg - 1) * 16 * (L / 16)) * 4;
+        for (int i = 0; i < count; ++i) { g.p[i].tgroups = tg; g.p[i].part_off = part; g.p[i].pp = had::buf_floats(L); }
+        static int c2[2] = {0, 0};
+        return planes ? launch_one(had_fast_kernel<true, false, 1024>, c2[0], g, grid, (L / 16) * tg, lds2, stream)
+                      : launch_one(had_fast_kernel<false, false, 1024>, c2[1], g, grid, (L / 16) * tg, lds2, stream);
+      }
+    }
     if (L <= 4096 && K == 1) {
       static int c1[2] = {0, 0};
       return planes ? launch_one(had_fast_kernel<true, false, 256, true>, c1[0], g, grid, L / 16, lds, stream)
@@ -571,6 +604,8 @@ int fill(HadArgs& a, const HadProblem& pr, bool planes, int n, int K, int transp
   a.z_res = reinterpret_cast<const f16*>(pr.z_residual);
   a.h_out = reinterpret_cast<f16*>(pr.h_out);
   a.z_scale = pr.z_scale;
+  a.tgroups = 1;
+  a.part_off = 0;
   if (pr.z) {   // chain: plain power-of-two width, blocked kernel, vector access
     if (K != 1 || pr.in_features != n || a.L < 256 || a.L > 16384) return QUIP_ERR_UNSUPPORTED;
     if (!pr.z_post || !pr.h_out) return QUIP_ERR_NULL_POINTER;
