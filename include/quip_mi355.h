@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QUIP_ABI_VERSION 2
+#define QUIP_ABI_VERSION 3
 
 typedef void* quip_stream_t; /* hipStream_t */
 
@@ -195,6 +195,12 @@ typedef struct quip_had_problem {
   const void* z_residual;    /* fp16 [rows, n] or NULL */
   void* h_out;               /* fp16 [rows, n], must not alias z_residual */
   float z_scale;
+  /* planes only.  != 0: write the planes of the E8P12RVQ4B virtual vector instead: per 8-group g
+   * [resid_scale * x_g | x_g] (2n digits, quip_e8p_planes_bytes(2n) bytes).  An RVQ4 row read as
+   * 16-bit E8P codes is a (n_out, 2k) E8P12 matrix whose 8-groups alternate residual / main codes
+   * (code = main << 16 | resid, e8p12_rvq4.py:37-67), so quip_e8p_gemv_planes(planes, qidxs, ..., n_out,
+   * 2k) IS the RVQ4 product W x with W = E8P(main) + resid_scale * E8P(resid), summed exactly. */
+  float resid_scale;
 } quip_had_problem;
 int quip_had_transform_group_f16(const quip_had_problem* problems, int32_t count, int64_t rows,
                                  int32_t n, int32_t K, int32_t transpose, quip_stream_t stream);

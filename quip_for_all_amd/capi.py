@@ -56,7 +56,8 @@ class HadProblem(_c.Structure):
     _fields_ = [("x", _P), ("out", _P), ("had", _P), ("pre_scale", _P), ("pre_scale2", _P), ("post_scale", _P),
                 ("bias", _P), ("residual", _P), ("rms_weight", _P), ("gate", _P), ("in_features", _I32),
                 ("out_features", _I32), ("scale", _F), ("rms_eps", _F),
-                ("z", _P), ("z_post_scale", _P), ("z_residual", _P), ("h_out", _P), ("z_scale", _F)]
+                ("z", _P), ("z_post_scale", _P), ("z_residual", _P), ("h_out", _P), ("z_scale", _F),
+                ("resid_scale", _F)]
 
 
 MAX_GROUP = 3

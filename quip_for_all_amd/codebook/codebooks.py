@@ -100,6 +100,31 @@ class E8P12RVQ4B_codebook(_Codebook):
         return torch.ops.quip_lib.e8prvq4_mm_origorder(input, Qidxs, self.grid_packed_abs,
                                                        self.opt_resid_scale)
 
+    # bs=1 on the E8P12 matrix-core GEMV: read as 16-bit codes an RVQ4 row is an E8P12 row of 2k
+    # weights whose 8-groups alternate residual / main codes, and W x = W' x' with
+    # x' = [s * x_g | x_g]_g (s = the fp16 residual scale the reference uses, origin_order.cu:337-385).
+    # The Hadamard launch writes the digit planes of x' (resid_scale argument); main + s * resid is
+    # summed exactly instead of being rounded to fp16 per weight.
+    @property
+    def planes_resid_scale(self):
+        return float(torch.tensor(self.opt_resid_scale, dtype=torch.float16))
+
+    @staticmethod
+    def planes_supported(q_out, q_in):
+        return (2 * q_in) % 128 == 0 and 128 <= 2 * q_in <= 28672 and q_out >= 1
+
+    @staticmethod
+    def planes_group_supported(q_outs, q_in):
+        kp = (2 * q_in + 511) // 512 * 512
+        return 1 <= len(q_outs) <= 3 and len(q_outs) * kp <= 31232
+
+    def mm_planes(self, planes, Qidxs):
+        return torch.ops.quip_lib.e8p_gemv_planes(planes, Qidxs.view(torch.int16), self.grid_packed_abs)
+
+    def mm_planes_group(self, planes, Qidxs):
+        return list(torch.ops.quip_lib.e8p_gemv_planes_group(planes, [q.view(torch.int16) for q in Qidxs],
+                                                             self.grid_packed_abs))
+
 
 class E8P12RVQ3B_codebook(_Codebook):
     def __init__(self, inference=False, opt_resid_scale=None, **kwargs):

@@ -65,6 +65,7 @@ struct HadArgs {
   f16* h_out;           // [rows, n]
   float z_scale;
   int pp;               // floats between the two halves of the ping-pong shuffle buffer (0: single buffer)
+  float rvq_scale;      // != 0: planes of the E8P12RVQ4B virtual vector (see the PLANES epilogue)
   int tgroups;          // wide K > 1: thread groups that split the k range (partials combined through LDS)
   int part_off;         // floats from buf to the partial-sum area
   float scale, rms_eps;
@@ -375,6 +376,31 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
     } else {
       bound = sqrtf(block_reduce(ss_in, false, red + 16, tid, nt, false)) * sqrtf((float)L) * fabsf(scale) * 1.0625f;
     }
+    if (a.rvq_scale != 0.f) {
+      // E8P12RVQ4B: a code is (main16 << 16 | resid16) and w = E8P(main) + s * E8P(resid)
+      // (e8p12_rvq4.py:37-67).  Read as 16-bit E8P codes, the row is a matrix with 2n columns whose
+      // 8-groups alternate resid, main; its product with x' = [s * x_g | x_g]_g is the RVQ4 product.
+      // So the E8P12 GEMV runs unchanged on the planes of x' (length 2n), written here.
+      const float rs = a.rvq_scale;
+      const int sh = had::shift_for(bound * fmaxf(1.f, fabsf(rs)));
+      if (blockIdx.x == 0 && tid == 0) *reinterpret_cast<int*>(a.planes + (size_t)3 * a.Kp) = sh;
+      uint4 dm[3], dr[3];
+      had::planes16(v, scale, sh, dm);
+      had::planes16(v, had::fmul(scale, rs), sh, dr);
+      const int idx = 2 * (kp * L + j0);
+      if (live) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          uint4* dst = reinterpret_cast<uint4*>(a.planes + (size_t)d * a.Kp + idx);
+          dst[0] = make_uint4(dr[d].x, dr[d].y, dm[d].x, dm[d].y);
+          dst[1] = make_uint4(dr[d].z, dr[d].w, dm[d].z, dm[d].w);
+        }
+      }
+      if (blockIdx.x == 0)  // zero the k padding [2n, Kp)
+        for (int i = 2 * a.n + tid * 16; i < a.Kp; i += nt * 16)
+#pragma unroll
+          for (int d = 0; d < 3; ++d) *reinterpret_cast<uint4*>(a.planes + (size_t)d * a.Kp + i) = make_uint4(0, 0, 0, 0);
+    } else {
     const int sh = had::shift_for(bound);
     if (blockIdx.x == 0 && tid == 0) *reinterpret_cast<int*>(a.planes + (size_t)3 * a.Kp) = sh;
     uint4 dg[3];
@@ -388,6 +414,7 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
       for (int i = a.n + tid * 16; i < a.Kp; i += nt * 16)
 #pragma unroll
         for (int d = 0; d < 3; ++d) *reinterpret_cast<uint4*>(a.planes + (size_t)d * a.Kp + i) = make_uint4(0, 0, 0, 0);
+    }
   } else {
     f16* yr = a.y + row * a.out_features;
     const f16* rr = a.residual ? a.residual + row * a.out_features : nullptr;
@@ -616,6 +643,11 @@ int fill(HadArgs& a, const HadProblem& pr, bool planes, int n, int K, int transp
   }
   a.in_features = pr.in_features; a.out_features = planes ? n : pr.out_features; a.n = n; a.K = K;
   a.Kp = (n + 511) & ~511;
+  a.rvq_scale = planes ? pr.resid_scale : 0.f;
+  if (a.rvq_scale != 0.f) {
+    if (!(a.L >= 256 || (K > 1 && a.L >= 64))) return QUIP_ERR_UNSUPPORTED;   // blocked kernels only
+    a.Kp = (2 * n + 511) & ~511;
+  }
   a.transpose = transpose; a.scale = pr.scale;
   return QUIP_OK;
 }

@@ -77,6 +77,7 @@ struct HadProblem {
   const void* z_residual = nullptr;
   void* h_out = nullptr;
   float z_scale = 1.f;
+  float resid_scale = 0.f;   // planes only: != 0 -> planes of the E8P12RVQ4B virtual vector [s * x_g | x_g] (2n digits)
 };
 int had_transform_group_launch(const HadProblem* problems, int count, bool planes, int64_t rows, int n, int K,
                                int transpose, hipStream_t stream);

@@ -101,9 +101,10 @@ class QuantLinear(nn.Module):
             planes = torch.ops.quip_lib.had_transform_planes_fused(
                 x, self.q_in_features, self.K_left, self._had("had_left"), True, self._vec(self.SU),
                 self.wscale_float / math.sqrt(L_in), self._vec(rms_weight), rms_eps,
-                None if gate is None else gate.reshape(x.shape).to(torch.float16))
+                None if gate is None else gate.reshape(x.shape).to(torch.float16),
+                getattr(cb, "planes_resid_scale", 0.0))
             z = cb.mm_planes(planes, self.Qidxs)
-        elif (2 <= x.shape[0] <= 3 and hasattr(cb, "grid_packed_abs") and hasattr(cb, "mm_planes")
+        elif (2 <= x.shape[0] <= 3 and cb.id == "E8P12" and hasattr(cb, "mm_planes")
               and cb.planes_supported(self.q_out_features, self.q_in_features)
               and cb.planes_group_supported([self.q_out_features] * x.shape[0], self.q_in_features)):
             # 2..3 rows: every row gets its own digit planes (one grouped transform launch), then one
@@ -254,7 +255,7 @@ def forward_group(layers, input, rms_weight=None, rms_eps=1e-5, residual=None):
         planes = torch.ops.quip_lib.had_transform_planes_group(
             x, l0.q_in_features, l0.K_left, [l._had("had_left") for l in layers], True,
             [l._vec(l.SU) for l in layers], [l.wscale_float / math.sqrt(L_in) for l in layers],
-            l0._vec(rms_weight), rms_eps, None)
+            l0._vec(rms_weight), rms_eps, None, getattr(cb, "planes_resid_scale", 0.0))
         zs = _gemv_planes_grouped(layers, planes)
     else:
         # any codebook / any batch: grouped fp16 input transforms, one codebook product per module
@@ -358,7 +359,8 @@ def gemv_group_unfused(layers, x, rms_weight=None, rms_eps=1e-5):
     planes = torch.ops.quip_lib.had_transform_planes_group(
         x.reshape(1, -1), l0.q_in_features, l0.K_left, [l._had("had_left") for l in layers], True,
         [l._vec(l.SU) for l in layers], [l.wscale_float / math.sqrt(L_in) for l in layers],
-        None if rms_weight is None else l0._vec(rms_weight), rms_eps, None)
+        None if rms_weight is None else l0._vec(rms_weight), rms_eps, None,
+        getattr(l0.codebook, "planes_resid_scale", 0.0))
     return _gemv_planes_grouped(layers, list(planes))
 
 
@@ -368,7 +370,7 @@ def gemv_unfused(layer, x, gate=None, rms_weight=None, rms_eps=1e-5):
     planes = torch.ops.quip_lib.had_transform_planes_fused(
         x.reshape(1, -1), layer.q_in_features, layer.K_left, layer._had("had_left"), True, layer._vec(layer.SU),
         layer.wscale_float / math.sqrt(L_in), layer._vec(rms_weight), rms_eps,
-        None if gate is None else gate.reshape(1, -1))
+        None if gate is None else gate.reshape(1, -1), getattr(layer.codebook, "planes_resid_scale", 0.0))
     return layer.codebook.mm_planes(planes, layer.Qidxs)
 
 
@@ -396,6 +398,7 @@ def gemv_chain(layers, prev, z, residual=None, rms_weight=None, rms_eps=1e-5):
     res = torch.ops.quip_lib.had_chain_planes_group(
         z.reshape(1, n), prev._vec(prev.SV), None if residual is None else residual.reshape(1, n),
         1.0 / math.sqrt(prev.q_out_features // prev.K_right), n, [l._vec(l.SU) for l in layers],
-        [l.wscale_float / math.sqrt(n) for l in layers], None if rms_weight is None else l0._vec(rms_weight), rms_eps)
+        [l.wscale_float / math.sqrt(n) for l in layers], None if rms_weight is None else l0._vec(rms_weight), rms_eps,
+        getattr(l0.codebook, "planes_resid_scale", 0.0))
     h, planes = res[0], list(res[1:])
     return h, _gemv_planes_grouped(layers, planes)

@@ -41,7 +41,8 @@ _SCHEMAS = {
                            "Tensor? rms_weight, float rms_eps, Tensor? gate) -> Tensor",
     # grouped launches: the three stages of up to 3 QuantLinear modules reading the same activation
     "had_transform_planes_group": "(Tensor x, int n, int K, Tensor?[] had, bool transpose, Tensor?[] pre, "
-                                  "float[] scale, Tensor? rms_weight, float rms_eps, Tensor? gate) -> Tensor[]",
+                                  "float[] scale, Tensor? rms_weight, float rms_eps, Tensor? gate, "
+                                  "float resid_scale=0.0) -> Tensor[]",
     "e8p_gemv_planes_group": "(Tensor[] planes, Tensor[] Qidxs, Tensor grid) -> Tensor[]",
     "d4_gemv_planes": "(Tensor planes, Tensor Qidxs, Tensor grid) -> Tensor",
     "d4_gemv_planes_group": "(Tensor[] planes, Tensor[] Qidxs, Tensor grid) -> Tensor[]",
@@ -50,7 +51,7 @@ _SCHEMAS = {
     # chain: output side of the producer module (z, its SV, residual) + input transforms of 1..3 consumers;
     # returns [h] + planes
     "had_chain_planes_group": "(Tensor z, Tensor z_post, Tensor? z_residual, float z_scale, int n, Tensor[] pre, "
-                              "float[] scale, Tensor? rms_weight, float rms_eps) -> Tensor[]",
+                              "float[] scale, Tensor? rms_weight, float rms_eps, float resid_scale=0.0) -> Tensor[]",
     "had_transform_group": "(Tensor[] x, int[] out_features, int n, int K, Tensor?[] had, bool transpose, "
                            "Tensor?[] pre2, Tensor?[] post, Tensor?[] bias, float[] scale, Tensor?[] residual, "
                            "Tensor?[] pre, Tensor? rms_weight, float rms_eps) -> Tensor[]",
@@ -61,7 +62,7 @@ _SCHEMAS = {
     "rope_attn_decode": "(Tensor q, Tensor k, Tensor v, Tensor cos, Tensor sin, Tensor pos, Tensor(a!) kcache, "
                         "Tensor(b!) vcache, Tensor(c!)? workspace) -> Tensor",
     "had_transform_planes_fused": "(Tensor x, int n, int K, Tensor? had, bool transpose, Tensor? pre, float scale, "
-                                  "Tensor? rms_weight, float rms_eps, Tensor? gate) -> Tensor",
+                                  "Tensor? rms_weight, float rms_eps, Tensor? gate, float resid_scale=0.0) -> Tensor",
 }
 for _name, _schema in _SCHEMAS.items():
     try:
@@ -164,7 +165,10 @@ def _had_transform_fused_cuda(x, out_features, n, K, had, transpose, pre, pre2, 
     return y
 
 
-def _had_transform_planes_fused_cuda(x, n, K, had, transpose, pre, scale, rms_weight, rms_eps, gate):
+def _had_transform_planes_fused_cuda(x, n, K, had, transpose, pre, scale, rms_weight, rms_eps, gate, resid_scale=0.0):
+    if resid_scale != 0.0:     # the RVQ4 virtual-vector layout is served by the problem-struct entry point
+        return _had_transform_planes_group_cuda(x, n, K, [had], transpose, [pre], [scale], rms_weight, rms_eps, gate,
+                                                resid_scale)[0]
     xc = _chk_x(x)
     _need(xc.shape[0] == 1, "had_transform_planes is the bs=1 path (one row)")
     for t in (had, pre):
@@ -243,14 +247,14 @@ def _e8p_mm_planes_rows_cuda(planes, Qidxs, grid):
     return out
 
 
-def _had_transform_planes_group_cuda(x, n, K, had, transpose, pre, scale, rms_weight, rms_eps, gate):
+def _had_transform_planes_group_cuda(x, n, K, had, transpose, pre, scale, rms_weight, rms_eps, gate, resid_scale=0.0):
     xc = _chk_x(x)
     count = len(pre)
     _need(xc.shape[0] in (1, count), "had_transform_planes_group: x has one row (shared) or one row per problem")
     _need(1 <= count <= capi.MAX_GROUP and len(had) == count and len(scale) == count, "group of 1..3 problems")
     _need(gate is None or gate.shape == xc.shape, "gate must have x's shape")
     L = capi.lib()
-    nbytes = L.quip_e8p_planes_bytes(n)
+    nbytes = L.quip_e8p_planes_bytes(2 * n if resid_scale != 0.0 else n)
     outs = [torch.empty(nbytes, dtype=torch.uint8, device=x.device) for _ in range(count)]
     arr = (capi.HadProblem * count)()
     per_row = xc.shape[0] == count and count > 1
@@ -259,21 +263,22 @@ def _had_transform_planes_group_cuda(x, n, K, had, transpose, pre, scale, rms_we
         off = 2 * xc.shape[1] * i if per_row else 0
         arr[i] = capi.HadProblem(xc.data_ptr() + off, outs[i].data_ptr(), _vec_ok(had[i], x.device),
                                  _vec_ok(pre[i], x.device), None, None, None, None, _vec_ok(rms_weight, x.device),
-                                 None if gptr is None else gptr + off, xc.shape[1], n, float(scale[i]), float(rms_eps))
+                                 None if gptr is None else gptr + off, xc.shape[1], n, float(scale[i]), float(rms_eps),
+                                 None, None, None, None, 1.0, float(resid_scale))
     with torch.cuda.device(x.device):
         capi.check(L.quip_had_transform_planes_group(arr, count, n, K, int(bool(transpose)), _stream(x)),
                    "quip_had_transform_planes_group")
     return outs
 
 
-def _had_chain_planes_group_cuda(z, z_post, z_residual, z_scale, n, pre, scale, rms_weight, rms_eps):
+def _had_chain_planes_group_cuda(z, z_post, z_residual, z_scale, n, pre, scale, rms_weight, rms_eps, resid_scale=0.0):
     zc = _chk_x(z)
     count = len(pre)
     _need(zc.shape == (1, n), "had_chain_planes_group is the bs=1 path: z must be (1, n)")
     _need(1 <= count <= capi.MAX_GROUP and len(scale) == count, "group of 1..3 problems")
     _need(z_residual is None or tuple(z_residual.shape) == (1, n), "residual shape")
     L = capi.lib()
-    nbytes = L.quip_e8p_planes_bytes(n)
+    nbytes = L.quip_e8p_planes_bytes(2 * n if resid_scale != 0.0 else n)
     outs = [torch.empty(nbytes, dtype=torch.uint8, device=z.device) for _ in range(count)]
     h = torch.empty((1, n), dtype=torch.float16, device=z.device)
     arr = (capi.HadProblem * count)()
@@ -281,7 +286,7 @@ def _had_chain_planes_group_cuda(z, z_post, z_residual, z_scale, n, pre, scale, 
         arr[i] = capi.HadProblem(None, outs[i].data_ptr(), None, _vec_ok(pre[i], z.device), None, None, None, None,
                                  _vec_ok(rms_weight, z.device), None, n, n, float(scale[i]), float(rms_eps),
                                  zc.data_ptr(), _vec_ok(z_post, z.device), _vec_ok(z_residual, z.device),
-                                 h.data_ptr(), float(z_scale))
+                                 h.data_ptr(), float(z_scale), float(resid_scale))
     with torch.cuda.device(z.device):
         capi.check(L.quip_had_transform_planes_group(arr, count, n, 1, 1, _stream(z)),
                    "quip_had_transform_planes_group (chain)")
@@ -570,12 +575,18 @@ _reg_fake("had_transform_planes", lambda x, n, K, had, transpose, pre, scale:
           x.new_empty((3 * ((n + 511) // 512 * 512) + 16,), dtype=torch.uint8))
 _reg_fake("had_transform_fused", lambda x, out_features, n, K, had, transpose, pre, pre2, post, bias, scale, residual,
           rms_weight, rms_eps, gate: x.new_empty((x.shape[0], out_features)))
-_reg_fake("had_transform_planes_fused", lambda x, n, K, had, transpose, pre, scale, rms_weight, rms_eps, gate:
-          x.new_empty((3 * ((n + 511) // 512 * 512) + 16,), dtype=torch.uint8))
-_reg_fake("had_transform_planes_group", lambda x, n, K, had, transpose, pre, scale, rms_weight, rms_eps, gate:
-          [x.new_empty((3 * ((n + 511) // 512 * 512) + 16,), dtype=torch.uint8) for _ in pre])
-_reg_fake("had_chain_planes_group", lambda z, z_post, z_residual, z_scale, n, pre, scale, rms_weight, rms_eps:
-          [z.new_empty((1, n))] + [z.new_empty((3 * ((n + 511) // 512 * 512) + 16,), dtype=torch.uint8) for _ in pre])
+def _planes_numel(n, resid_scale):
+    m = 2 * n if resid_scale != 0.0 else n
+    return 3 * ((m + 511) // 512 * 512) + 16
+
+
+_reg_fake("had_transform_planes_fused", lambda x, n, K, had, transpose, pre, scale, rms_weight, rms_eps, gate,
+          resid_scale=0.0: x.new_empty((_planes_numel(n, resid_scale),), dtype=torch.uint8))
+_reg_fake("had_transform_planes_group", lambda x, n, K, had, transpose, pre, scale, rms_weight, rms_eps, gate,
+          resid_scale=0.0: [x.new_empty((_planes_numel(n, resid_scale),), dtype=torch.uint8) for _ in pre])
+_reg_fake("had_chain_planes_group", lambda z, z_post, z_residual, z_scale, n, pre, scale, rms_weight, rms_eps,
+          resid_scale=0.0: [z.new_empty((1, n))] + [z.new_empty((_planes_numel(n, resid_scale),), dtype=torch.uint8)
+                                                     for _ in pre])
 _reg_fake("had_transform_group", lambda x, out_features, n, K, had, transpose, pre2, post, bias, scale, residual, pre,
           rms_weight, rms_eps:
           [t.new_empty((t.shape[0], int(o))) for t, o in zip(x, out_features)])

@@ -336,3 +336,36 @@ def test_d4_gemv_planes_exact_integer_path(Q, n, k):
     assert torch.equal(y2[0], y2[1]) and np.array_equal(y2[0].cpu().numpy().astype(np.float64), y)
     yg = cb.mm(xd, qd).cpu().numpy().astype(np.float64)
     assert np.all(np.abs(yg - y64) <= _mm_tol(x64, W64, y64) + 2.0 ** -9 * np.abs(y64))
+
+
+@pytest.mark.parametrize("n,k,scale", [(4096, 4096, None), (11008, 4096, None), (4096, 2048, 0.25), (512, 256, -1.0),
+                                       (8192, 8192, None)])
+def test_rvq4_on_the_e8p_gemv_through_the_virtual_vector(Q, n, k, scale):
+    """E8P12RVQ4B at bs=1: Hadamard launch writes the planes of x' = [s x_g | x_g], the E8P12 GEMV runs on the
+    int16 view of the codes.  Result = W x with W = E8P(main) + s E8P(resid) summed EXACTLY: tight against
+    the unrounded float64 weights, and within the reference's own per-weight fp16 rounding (2^-11 |w| per
+    weight, origin_order.cu:337-385) of the oracle's rounded weights."""
+    cb = _cb(Q, "E8P12RVQ4B", scale)
+    s16 = cb.planes_resid_scale
+    rng = np.random.default_rng(n + k)
+    q = rng.integers(-2 ** 31, 2 ** 31 - 1, size=(n, k // 8), dtype=np.int64).astype(np.int32)
+    x = rng.standard_normal((1, k)).astype(np.float16)
+    xd, qd = torch.from_numpy(x).to(DEV), torch.from_numpy(q).to(DEV)
+    planes = torch.ops.quip_lib.had_transform_planes_fused(xd, k, 1, None, True, None, 1.0 / np.sqrt(k), None, 1e-5,
+                                                           None, s16)
+    y = cb.mm_planes(planes, qd).cpu().numpy().astype(np.float64)
+    xh = O.fwht(x.astype(np.float64)) / np.sqrt(k)
+    qu = q.view(np.uint32)
+    main = O.e8p_decode_i8((qu >> 16).astype(np.uint16)).astype(np.float64) / 4.0
+    res = O.e8p_decode_i8((qu & 0xFFFF).astype(np.uint16)).astype(np.float64) / 4.0
+    Wexact = (main + s16 * res).reshape(n, -1)
+    ref = xh @ Wexact.T
+    wx = np.abs(xh) @ np.abs(Wexact).T
+    assert np.all(np.abs(y - ref) <= 2.0 ** -10 * np.abs(ref) + 2.0 ** -20 * wx + 1e-6), np.abs(y - ref).max()
+    Wref = O.decompress_e8prvq4(q, cb.opt_resid_scale).astype(np.float64)
+    ref2 = xh @ Wref.T
+    assert np.all(np.abs(y - ref2) <= 2.0 ** -10 * np.abs(ref2) + 2.0 ** -11 * wx + 1e-6)
+    # and the generic (per-weight rounding) kernel agrees within the same bound
+    xh16 = torch.ops.quip_lib.had_transform(xd, k, k, 1, None, True, None, None, None, None, 1.0 / np.sqrt(k))
+    yg = cb.mm(xh16, qd).cpu().numpy().astype(np.float64)
+    assert np.all(np.abs(y - yg) <= 2.0 ** -9 * np.abs(ref2) + 2.0 ** -10 * wx + 1e-6)
