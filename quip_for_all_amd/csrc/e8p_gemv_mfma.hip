@@ -942,6 +942,15 @@ int pattern_probe_launch(const void* qidxs, void* out, int n, int k, const GemvT
 template <int G>
 static int launch_oneshot(const GemvGroup<G>& gp, const void* grid, int k, int kp, int nblocks, int threads,
                           int rep, int items_per_wave, uint64_t* dbg, hipStream_t stream) {
+  // 9..16 waves: the 128-VGPR budget of a 1024-thread workgroup holds up to 4 slot register sets
+#define QUIP_ONE_BIG(R, S)                                                          \
+  if (threads > 512 && rep == R && items_per_wave <= S)                             \
+    return launch<R, S, 1024, G, true>(gp, grid, k, kp, nblocks, threads, dbg, stream);
+  QUIP_ONE_BIG(32, 1) QUIP_ONE_BIG(32, 2) QUIP_ONE_BIG(32, 3) QUIP_ONE_BIG(32, 4)
+  QUIP_ONE_BIG(24, 1) QUIP_ONE_BIG(24, 2) QUIP_ONE_BIG(24, 3) QUIP_ONE_BIG(24, 4)
+  QUIP_ONE_BIG(16, 1) QUIP_ONE_BIG(16, 2) QUIP_ONE_BIG(16, 3) QUIP_ONE_BIG(16, 4)
+#undef QUIP_ONE_BIG
+  if (threads > 512) return QUIP_ERR_UNSUPPORTED;
 #define QUIP_ONE(R, S)                                                              \
   if (rep == R && items_per_wave <= S)                                              \
     return launch<R, S, 512, G, true>(gp, grid, k, kp, nblocks, threads, dbg, stream);
@@ -991,7 +1000,7 @@ int e8p_gemv_mfma_launch(const void* planes, const void* qidxs, const void* grid
                                               // scratch traffic would corrupt the counted vmcnt waits
   GemvGroup<1> gp{{reinterpret_cast<const uint4*>(qidxs)}, {reinterpret_cast<const uint8_t*>(planes)},
                   {reinterpret_cast<f16*>(y)}, {n}, {rpb}, {0}};
-  if (!tune.rows && threads <= 512 && items_per_wave <= 8)
+  if (!tune.rows && ((threads <= 512 && items_per_wave <= 8) || (threads > 512 && rep != 64 && items_per_wave <= 4)))
     return launch_oneshot<1>(gp, grid, k, kp, nblocks, threads, rep, items_per_wave, dbg, stream);
 #define QUIP_CASE(R, S)                                                                        \
   if (rep == R && slots == S && threads <= 512)                                                \
@@ -1047,6 +1056,7 @@ static int group_launch(const void* const* planes, const void* const* qidxs, con
     items += (gp.rpb[p] >> 4) * (kp >> 9);
   }
   nblocks = used;
+  const bool many_items = items >= 40 && items <= 48;   // one-shot on 12 waves (measured: gate/up group 10.0 vs 10.7 us)
   {   // stagger the problems that do not fill the launch
     int next = 0;
     for (int p = 0; p < G; ++p) {
@@ -1058,7 +1068,7 @@ static int group_launch(const void* const* planes, const void* const* qidxs, con
       }
     }
   }
-  int waves = tune.max_waves > 0 ? tune.max_waves : 8;
+  int waves = tune.max_waves > 0 ? tune.max_waves : (many_items ? 12 : 8);
   if (waves > 16) waves = 16;
   if (waves < 8) waves = 8;
   const int min_waves = (G * 3 * (kp >> 4) + 6 * 64 - 1) / (6 * 64);
@@ -1068,7 +1078,8 @@ static int group_launch(const void* const* planes, const void* const* qidxs, con
   const int slots = tune.rows ? (tune.rows >= 2 ? 2 : 1) : ((items + waves - 1) / waves >= 4 ? 2 : 1);
   const int threads = waves * 64;
   uint64_t* dbg = reinterpret_cast<uint64_t*>(tune.dbg);
-  if (!tune.rows && threads <= 512 && (items + waves - 1) / waves <= 8)
+  if (!tune.rows && ((threads <= 512 && (items + waves - 1) / waves <= 8) ||
+                     (threads > 512 && rep != 64 && (items + waves - 1) / waves <= 4)))
     return launch_oneshot<G>(gp, grid, k, kp, nblocks, threads, rep, (items + waves - 1) / waves, dbg, stream);
 #define QUIP_CASE(R, S)                                                                        \
   if (rep == R && slots == S)                                                                  \
