@@ -56,6 +56,10 @@ namespace {
 #ifndef QUIP_GEMV_R8
 #define QUIP_GEMV_R8 0
 #endif
+// MFMA steps whose table / A reads are in flight ahead of the MFMA that consumes them
+#ifndef QUIP_GEMV_PIPE
+#define QUIP_GEMV_PIPE 4
+#endif
 // one-shot mode: slots requested ahead of the one being decoded.  Measured on the 7B shapes (us per
 // launch, q/k/v group | gate/up group | down | 8192^2): depth 1: 8.35 10.61 6.74 7.61; 2: 8.67 10.72 7.02
 // 7.53; 3: 8.86 10.75 7.77 8.21; 4: 8.79 11.33 7.61 8.62; all upfront: 8.78 12.22 7.64 8.61.
@@ -253,7 +257,7 @@ __device__ __forceinline__ uint32_t lds_read4(uint32_t addr) {
 
 // D4: the B fragment of a step is four 4-byte table entries, no sign fix-up
 __device__ __forceinline__ i32x4 item_mfma_d4(const ItemAddr& ad, uint32_t xaddr) {
-  constexpr int PIPE = 4;
+  constexpr int PIPE = QUIP_GEMV_PIPE;
   i32x4 B[8], A[8];
   auto issue = [&](int t) {
     B[t] = i32x4{(int)lds_read4(ad.a1l[t]), (int)lds_read4(ad.a2l[t]), (int)lds_read4(ad.a1h[t]),
@@ -272,7 +276,7 @@ __device__ __forceinline__ i32x4 item_mfma_d4(const ItemAddr& ad, uint32_t xaddr
 }
 
 __device__ __forceinline__ i32x4 item_mfma(const ItemAddr& ad, uint32_t xaddr) {
-  constexpr int PIPE = 4;
+  constexpr int PIPE = QUIP_GEMV_PIPE;
   StepOperands op[8];
   auto issue = [&](int t) {
     op[t].t1l = lds_read8(ad.a1l[t]); op[t].t2l = lds_read8(ad.a2l[t]);
