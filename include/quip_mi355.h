@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QUIP_ABI_VERSION 3
+#define QUIP_ABI_VERSION 4
 
 typedef void* quip_stream_t; /* hipStream_t */
 
@@ -201,6 +201,12 @@ typedef struct quip_had_problem {
    * (code = main << 16 | resid, e8p12_rvq4.py:37-67), so quip_e8p_gemv_planes(planes, qidxs, ..., n_out,
    * 2k) IS the RVQ4 product W x with W = E8P(main) + resid_scale * E8P(resid), summed exactly. */
   float resid_scale;
+  /* planes only.  2: write the planes of the HI virtual vector (2n digits): per 8-group
+   * [x0 x2 0 0 | x4 x6 0 0 | x1 x3 0 0 | x5 x7 0 0].  An HI row (nibble i = column [0,2,4,6,1,3,5,7][i],
+   * w = nibble - 7.5, hi.py:41-63) read as one-byte codes is a D4-style matrix with 2n columns and the
+   * table entry [lo - 7.5, hi - 7.5, 0, 0], so quip_d4_gemv_planes(planes, qidxs, that_table, y, n_out, 2k)
+   * IS the HI product.  0 (or 1): plain / RVQ4 (resid_scale). */
+  int32_t planes_layout;
 } quip_had_problem;
 int quip_had_transform_group_f16(const quip_had_problem* problems, int32_t count, int64_t rows,
                                  int32_t n, int32_t K, int32_t transpose, quip_stream_t stream);

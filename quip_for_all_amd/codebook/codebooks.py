@@ -211,6 +211,36 @@ class HI4B1C_codebook(_Codebook):
             self.register_buffer("grid", g, persistent=False)
             self.register_buffer("grid_norm", (g @ g.T).diag(), persistent=False)
 
+    # bs=1 on the D4 mode of the matrix-core GEMV: a code byte (two nibbles) is a "D4 code" of the
+    # virtual (n_out, 2k) matrix with entry [lo - 7.5, hi - 7.5, 0, 0]; the Hadamard launch writes the
+    # planes of the matching virtual vector (csrc/hadamard.hip, HI layout).  Exact: 2w is an int8.
+    planes_resid_scale = float("inf")      # register_lib.HI_PLANES: selects the HI planes layout
+
+    def _virtual_grid(self, device):
+        g = getattr(self, "_vgrid", None)
+        if g is None or g.device != device:
+            b = torch.arange(256)
+            g = torch.stack([(b & 15).float() - 7.5, (b >> 4).float() - 7.5, torch.zeros(256), torch.zeros(256)], 1)
+            g = g.to(torch.float16).contiguous().to(device)
+            self._vgrid = g
+        return g
+
+    @staticmethod
+    def planes_supported(q_out, q_in):
+        return (2 * q_in) % 128 == 0 and 128 <= 2 * q_in <= 28672 and q_out >= 1
+
+    @staticmethod
+    def planes_group_supported(q_outs, q_in):
+        kp = (2 * q_in + 511) // 512 * 512
+        return 1 <= len(q_outs) <= 3 and len(q_outs) * kp <= 31232
+
+    def mm_planes(self, planes, Qidxs):
+        return torch.ops.quip_lib.d4_gemv_planes(planes, Qidxs.view(torch.uint8), self._virtual_grid(Qidxs.device))
+
+    def mm_planes_group(self, planes, Qidxs):
+        return list(torch.ops.quip_lib.d4_gemv_planes_group(planes, [q.view(torch.uint8) for q in Qidxs],
+                                                            self._virtual_grid(Qidxs[0].device)))
+
     def maybe_pack_idxs(self, idxs):
         """nibble i <- column [0,2,4,6,1,3,5,7][i] of each 8-group (hi.py:41-50)"""
         out = torch.zeros(idxs.shape[0], idxs.shape[1] // 8, dtype=idxs.dtype, device=idxs.device)

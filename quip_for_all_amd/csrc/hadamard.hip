@@ -66,6 +66,7 @@ struct HadArgs {
   float z_scale;
   int pp;               // floats between the two halves of the ping-pong shuffle buffer (0: single buffer)
   float rvq_scale;      // != 0: planes of the E8P12RVQ4B virtual vector (see the PLANES epilogue)
+  int hi_layout;        // != 0: planes of the HI virtual vector (see the PLANES epilogue)
   int tgroups;          // wide K > 1: thread groups that split the k range (partials combined through LDS)
   int part_off;         // floats from buf to the partial-sum area
   float scale, rms_eps;
@@ -376,7 +377,39 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
     } else {
       bound = sqrtf(block_reduce(ss_in, false, red + 16, tid, nt, false)) * sqrtf((float)L) * fabsf(scale) * 1.0625f;
     }
-    if (a.rvq_scale != 0.f) {
+    if (a.hi_layout) {
+      // HI (4-bit scalar, w = nibble - 7.5, hi.py:41-63): a code byte holds the nibbles of columns
+      // (0,2) (4,6) (1,3) (5,7) of its 8-group.  Read as D4 codes (one byte = 4 weights) with the table
+      // entry [lo - 7.5, hi - 7.5, 0, 0], the row is a D4 matrix with 2n columns, and its product with
+      // x' = [x0 x2 0 0 | x4 x6 0 0 | x1 x3 0 0 | x5 x7 0 0]_g is the HI product: the D4 mode of the
+      // matrix-core GEMV runs unchanged on the planes of x' (length 2n), written here.
+      const int sh = had::shift_for(bound);
+      if (blockIdx.x == 0 && tid == 0) *reinterpret_cast<int*>(a.planes + (size_t)3 * a.Kp) = sh;
+      float vp[2][16];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const float* e = v + 8 * g;
+        const float o16[16] = {e[0], e[2], 0.f, 0.f, e[4], e[6], 0.f, 0.f, e[1], e[3], 0.f, 0.f, e[5], e[7], 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) vp[g][i] = o16[i];
+      }
+      uint4 d0[3], d1[3];
+      had::planes16(vp[0], scale, sh, d0);
+      had::planes16(vp[1], scale, sh, d1);
+      const int idx = 2 * (kp * L + j0);
+      if (live) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          uint4* dst = reinterpret_cast<uint4*>(a.planes + (size_t)d * a.Kp + idx);
+          dst[0] = d0[d];
+          dst[1] = d1[d];
+        }
+      }
+      if (blockIdx.x == 0)  // zero the k padding [2n, Kp)
+        for (int i = 2 * a.n + tid * 16; i < a.Kp; i += nt * 16)
+#pragma unroll
+          for (int d = 0; d < 3; ++d) *reinterpret_cast<uint4*>(a.planes + (size_t)d * a.Kp + i) = make_uint4(0, 0, 0, 0);
+    } else if (a.rvq_scale != 0.f) {
       // E8P12RVQ4B: a code is (main16 << 16 | resid16) and w = E8P(main) + s * E8P(resid)
       // (e8p12_rvq4.py:37-67).  Read as 16-bit E8P codes, the row is a matrix with 2n columns whose
       // 8-groups alternate resid, main; its product with x' = [s * x_g | x_g]_g is the RVQ4 product.
@@ -644,7 +677,10 @@ int fill(HadArgs& a, const HadProblem& pr, bool planes, int n, int K, int transp
   a.in_features = pr.in_features; a.out_features = planes ? n : pr.out_features; a.n = n; a.K = K;
   a.Kp = (n + 511) & ~511;
   a.rvq_scale = planes ? pr.resid_scale : 0.f;
-  if (a.rvq_scale != 0.f) {
+  a.hi_layout = planes && pr.planes_layout == 2;
+  if (a.hi_layout) a.rvq_scale = 0.f;
+  if (planes && pr.planes_layout != 0 && pr.planes_layout != 1 && pr.planes_layout != 2) return QUIP_ERR_BAD_SHAPE;
+  if (a.rvq_scale != 0.f || a.hi_layout) {
     if (!(a.L >= 256 || (K > 1 && a.L >= 64))) return QUIP_ERR_UNSUPPORTED;   // blocked kernels only
     a.Kp = (2 * n + 511) & ~511;
   }

@@ -78,6 +78,7 @@ struct HadProblem {
   void* h_out = nullptr;
   float z_scale = 1.f;
   float resid_scale = 0.f;   // planes only: != 0 -> planes of the E8P12RVQ4B virtual vector [s * x_g | x_g] (2n digits)
+  int planes_layout = 0;     // planes only: 0 plain (or RVQ4 when resid_scale != 0), 2 = HI virtual vector (2n digits)
 };
 int had_transform_group_launch(const HadProblem* problems, int count, bool planes, int64_t rows, int n, int K,
                                int transpose, hipStream_t stream);

@@ -264,7 +264,7 @@ def _had_transform_planes_group_cuda(x, n, K, had, transpose, pre, scale, rms_we
         arr[i] = capi.HadProblem(xc.data_ptr() + off, outs[i].data_ptr(), _vec_ok(had[i], x.device),
                                  _vec_ok(pre[i], x.device), None, None, None, None, _vec_ok(rms_weight, x.device),
                                  None if gptr is None else gptr + off, xc.shape[1], n, float(scale[i]), float(rms_eps),
-                                 None, None, None, None, 1.0, float(resid_scale))
+                                 None, None, None, None, 1.0, *_layout(resid_scale))
     with torch.cuda.device(x.device):
         capi.check(L.quip_had_transform_planes_group(arr, count, n, K, int(bool(transpose)), _stream(x)),
                    "quip_had_transform_planes_group")
@@ -286,7 +286,7 @@ def _had_chain_planes_group_cuda(z, z_post, z_residual, z_scale, n, pre, scale, 
         arr[i] = capi.HadProblem(None, outs[i].data_ptr(), None, _vec_ok(pre[i], z.device), None, None, None, None,
                                  _vec_ok(rms_weight, z.device), None, n, n, float(scale[i]), float(rms_eps),
                                  zc.data_ptr(), _vec_ok(z_post, z.device), _vec_ok(z_residual, z.device),
-                                 h.data_ptr(), float(z_scale), float(resid_scale))
+                                 h.data_ptr(), float(z_scale), *_layout(resid_scale))
     with torch.cuda.device(z.device):
         capi.check(L.quip_had_transform_planes_group(arr, count, n, 1, 1, _stream(z)),
                    "quip_had_transform_planes_group (chain)")
@@ -575,6 +575,14 @@ _reg_fake("had_transform_planes", lambda x, n, K, had, transpose, pre, scale:
           x.new_empty((3 * ((n + 511) // 512 * 512) + 16,), dtype=torch.uint8))
 _reg_fake("had_transform_fused", lambda x, out_features, n, K, had, transpose, pre, pre2, post, bias, scale, residual,
           rms_weight, rms_eps, gate: x.new_empty((x.shape[0], out_features)))
+HI_PLANES = float("inf")     # resid_scale value that selects the HI virtual-vector layout of the planes ops
+
+
+def _layout(resid_scale):
+    """(resid_scale, planes_layout) of a quip_had_problem from the ops' single float argument"""
+    return (0.0, 2) if resid_scale == HI_PLANES else (float(resid_scale), 0)
+
+
 def _planes_numel(n, resid_scale):
     m = 2 * n if resid_scale != 0.0 else n
     return 3 * ((m + 511) // 512 * 512) + 16

@@ -369,3 +369,22 @@ def test_rvq4_on_the_e8p_gemv_through_the_virtual_vector(Q, n, k, scale):
     xh16 = torch.ops.quip_lib.had_transform(xd, k, k, 1, None, True, None, None, None, None, 1.0 / np.sqrt(k))
     yg = cb.mm(xh16, qd).cpu().numpy().astype(np.float64)
     assert np.all(np.abs(y - yg) <= 2.0 ** -9 * np.abs(ref2) + 2.0 ** -10 * wx + 1e-6)
+
+
+@pytest.mark.parametrize("n,k", [(4096, 4096), (11008, 4096), (512, 256), (8192, 8192)])
+def test_hi_on_the_d4_mode_through_the_virtual_vector(Q, n, k):
+    """HI at bs=1: planes of x' = [x0 x2 0 0 | x4 x6 0 0 | x1 x3 0 0 | x5 x7 0 0], D4 mode of the GEMV on the
+    byte view of the codes with the entry [lo - 7.5, hi - 7.5, 0, 0]: exact integer arithmetic"""
+    cb = _cb(Q, "HI")
+    rng = np.random.default_rng(n + k)
+    q = rng.integers(-2 ** 31, 2 ** 31 - 1, size=(n, k // 8), dtype=np.int64).astype(np.int32)
+    x = rng.standard_normal((1, k)).astype(np.float16)
+    xd, qd = torch.from_numpy(x).to(DEV), torch.from_numpy(q).to(DEV)
+    planes = torch.ops.quip_lib.had_transform_planes_fused(xd, k, 1, None, True, None, 1.0 / np.sqrt(k), None, 1e-5,
+                                                           None, cb.planes_resid_scale)
+    y = cb.mm_planes(planes, qd).cpu().numpy().astype(np.float64)
+    xh = O.fwht(x.astype(np.float64)) / np.sqrt(k)
+    W64 = O.decompress_hi(q).astype(np.float64)
+    ref = xh @ W64.T
+    wx = np.abs(xh) @ np.abs(W64).T
+    assert np.all(np.abs(y - ref) <= 2.0 ** -10 * np.abs(ref) + 2.0 ** -20 * wx + 1e-6), np.abs(y - ref).max()

@@ -130,7 +130,7 @@ def test_full_size_70b_rows_via_properties():
 @pytest.mark.parametrize("cbid,fin,fout", [("E8P12", 4096, 4096), ("E8P12", 1408, 512), ("D4", 1024, 1024),
                                            ("E8P12", 4096, 11008), ("E8P12", 11008, 4096),
                                            ("E8P12RVQ4B", 4096, 11008), ("E8P12RVQ4B", 11008, 4096),
-                                           ("D4", 11008, 4096)])
+                                           ("D4", 11008, 4096), ("HI", 4096, 4096), ("HI", 11008, 4096)])
 @pytest.mark.parametrize("M", [1, 3])
 def test_forward_fused_glue(cbid, fin, fout, M):
     """RMSNorm / SiLU*mul / residual folded into the Hadamard launches == doing them separately"""
