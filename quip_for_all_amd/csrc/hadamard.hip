@@ -330,23 +330,25 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
     // tile costs 64 lanes x 16 B of LDS return bandwidth per k and row group: measured 5.3K cycles.)
     {
       typedef float f32x4 __attribute__((ext_vector_type(4)));
-      const int wave = tid >> 6, lane = tid & 63;
+      const int wave = tid >> 6, lane = tid & 63, nwv = nt >> 6;
       const int ctiles = L >> 4;
-      const int rt = wave / ctiles, ct = wave - rt * ctiles;
       const int lr = lane & 15, lq = lane >> 4;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      const float* hp = hs + rt * 16 + lr;                 // + k * R
-      const float* xp = xs + ct * 16 + lr;                 // + k * xstride
-      for (int k0 = 0; k0 < K; k0 += 4) {
-        const int k = k0 + lq;
-        const float av = hp[k * R];                        // rows of H past K are zero filled below
-        const float bv = xp[min(k, K - 1) * xstride];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-      }
-      // D[row = 4 * (l >> 4) + i][col = l & 15] -> [row][col] image of the tile
+      for (int tile = wave; tile < 16; tile += nwv) {      // 16 waves: one tile each; 8 waves (batches): two
+        const int rt = tile / ctiles, ct = tile - rt * ctiles;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* hp = hs + rt * 16 + lr;                 // + k * R
+        const float* xp = xs + ct * 16 + lr;                 // + k * xstride
+        for (int k0 = 0; k0 < K; k0 += 4) {
+          const int k = k0 + lq;
+          const float av = hp[k * R];                        // rows of H past K are zero filled below
+          const float bv = xp[min(k, K - 1) * xstride];
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        }
+        // D[row = 4 * (l >> 4) + i][col = l & 15] -> [row][col] image of the tile
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        buf[pad(((rt * 16 + 4 * lq + i) << logL) + ct * 16 + lr)] = acc[i];
+        for (int i = 0; i < 4; ++i)
+          buf[pad(((rt * 16 + 4 * lq + i) << logL) + ct * 16 + lr)] = acc[i];
+      }
     }
     HSTAMP(3);
     __syncthreads();
@@ -589,12 +591,16 @@ int launch(HadGroup& g, int count, int64_t rows, hipStream_t stream) {
   if (K > 1 && L >= 64 && L <= 256) {   // tall: 256 threads, R = 4096 / L rows per workgroup
     const int R = 4096 / L;
     // [shuffle buffer | H tile | x rows | second half of the ping-pong buffer]
+    // decode launches: 1024 threads, ping-pong buffer (latency); batches: 512 threads, single buffer, so
+    // that two workgroups share a CU (one at a time made prefill throughput = workgroup latency)
+    const bool batch = rows > 8;
     const int pp = had::buf_floats(4096) + ((K + 3) & ~3) * R + K * (L + 8);
-    const int lds = (pp + had::buf_floats(4096)) * 4;
-    for (int i = 0; i < count; ++i) g.p[i].pp = pp;
+    const int lds = (pp + (batch ? 0 : had::buf_floats(4096))) * 4;
+    for (int i = 0; i < count; ++i) g.p[i].pp = batch ? 0 : pp;
     const dim3 grid((K + R - 1) / R, (unsigned)rows, count);
-    return planes ? launch_one(had_fast_kernel<true, true, 1024>, cfg[0], g, grid, 1024, lds, stream)
-                  : launch_one(had_fast_kernel<false, true, 1024>, cfg[1], g, grid, 1024, lds, stream);
+    const int threads = batch ? 512 : 1024;
+    return planes ? launch_one(had_fast_kernel<true, true, 1024>, cfg[0], g, grid, threads, lds, stream)
+                  : launch_one(had_fast_kernel<false, true, 1024>, cfg[1], g, grid, threads, lds, stream);
   }
   const dim3 grid(K, (unsigned)rows, count);
   if (L >= 256 && L <= 16384) {
