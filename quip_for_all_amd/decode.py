@@ -102,6 +102,44 @@ class LlamaDecoder:
                 ln1=vec(s.hidden), ln2=vec(s.hidden),
                 q=ql(s.hidden, s.hidden), k=ql(s.hidden, kv), v=ql(s.hidden, kv), o=ql(s.hidden, s.hidden),
                 gate=ql(s.hidden, s.ffn), up=ql(s.hidden, s.ffn), down=ql(s.ffn, s.hidden)))
+        self._init_runtime()
+
+    @classmethod
+    def from_hf(cls, model, max_len=256, device=None):
+        """Fast bs=1 decoder around a Llama-architecture HF model whose linear layers are QuantLinear
+        (what `load_quantized_model` returns): shares the modules / weights, adds the static KV cache and
+        the captured step.  Needs `model.model.{embed_tokens, layers, norm}` and `model.lm_head`."""
+        cfg = model.config
+        dev = torch.device(device) if device is not None else next(model.parameters()).device
+        self = cls.__new__(cls)
+        heads = cfg.num_attention_heads
+        rope = getattr(cfg, "rope_theta", None)
+        if rope is None:
+            rp = getattr(cfg, "rope_parameters", None) or {}
+            rope = rp.get("rope_theta", 10000.0) if isinstance(rp, dict) else 10000.0
+        self.s = LlamaShape(hidden=cfg.hidden_size, ffn=cfg.intermediate_size, layers=cfg.num_hidden_layers,
+                            heads=heads, kv_heads=getattr(cfg, "num_key_value_heads", heads) or heads,
+                            vocab=cfg.vocab_size, rms_eps=cfg.rms_norm_eps, rope_theta=float(rope))
+        self.dev, self.max_len = dev, max_len
+        h16 = lambda t: t.detach().to(device=dev, dtype=torch.float16).contiguous()  # noqa: E731
+        self.embed = h16(model.model.embed_tokens.weight)
+        self.lm_head = h16(model.lm_head.weight)
+        self.final_norm = h16(model.model.norm.weight)
+        self.layers = []
+        for blk in model.model.layers:
+            a, m = blk.self_attn, blk.mlp
+            mods = dict(q=a.q_proj, k=a.k_proj, v=a.v_proj, o=a.o_proj, gate=m.gate_proj, up=m.up_proj, down=m.down_proj)
+            for name, mod in mods.items():
+                if not isinstance(mod, QuantLinear):
+                    raise TypeError(f"{name}_proj is {type(mod).__name__}, expected QuantLinear")
+                mod.to(dev).eval()
+            self.layers.append(dict(ln1=h16(blk.input_layernorm.weight), ln2=h16(blk.post_attention_layernorm.weight),
+                                    **mods))
+        self._init_runtime()
+        return self
+
+    def _init_runtime(self):
+        s, max_len = self.s, self.max_len
         self.kcache = torch.zeros(s.layers, s.kv_heads, max_len, s.head_dim, dtype=torch.float16, device=self.dev)
         self.vcache = torch.zeros_like(self.kcache)
         inv = 1.0 / (s.rope_theta ** (torch.arange(0, s.head_dim, 2, dtype=torch.float32) / s.head_dim))

@@ -60,3 +60,29 @@ def test_hf_generate_with_loaded_quantized_model(tmp_path, codebook):
         tok = int(out_q[0, t + 1])
         margin = (ld[t].max() - ld[t, tok]).item()
         assert margin <= 0.03 * (ld[t].abs().max().item() + 1.0), (t, tok, margin)
+
+
+def test_fast_decoder_from_loaded_hf_model(tmp_path):
+    """load_quantized_model -> LlamaDecoder.from_hf: the captured fast decode loop on the loaded checkpoint
+    follows the stock HF forward of the same model (teacher-forced arg-max check, fp16 noise margin)"""
+    from transformers import AutoModelForCausalLM
+    from quip_for_all_amd.quantizer import QuipQuantizer, load_quantized_model
+    from quip_for_all_amd.decode import LlamaDecoder
+    torch.manual_seed(1)
+    model = AutoModelForCausalLM.from_config(_tiny_config(), dtype=torch.float16)
+    qz = QuipQuantizer(codebook="E8P12", inference=True, ft_epochs=0)
+    qz.convert_model(model)
+    _fill_random(model, seed=9)
+    qz.save(model, str(tmp_path))
+    q = load_quantized_model(str(tmp_path), device_map={"": "cuda:0"})
+    dec = LlamaDecoder.from_hf(q, max_len=32)
+    toks = dec.generate(12, first_token=5, use_graph=True)
+    eager = dec.generate(12, first_token=5, use_graph=False)
+    assert torch.equal(toks, eager)
+    seq = torch.cat([torch.tensor([5], device="cuda:0"), toks])[None]
+    with torch.no_grad():
+        logits = q(seq).logits.float()[0]
+    for t in range(12):
+        tok = int(toks[t])
+        margin = (logits[t].max() - logits[t, tok]).item()
+        assert margin <= 0.03 * (logits[t].abs().max().item() + 1.0), (t, tok, margin)
