@@ -280,18 +280,27 @@ class LlamaDecoder:
         self.reset()
 
     @torch.no_grad()
-    def generate(self, n_tokens, first_token=1, use_graph=True):
-        """greedy decode n_tokens (<= max_len); returns the token ids (device tensor)"""
-        assert n_tokens <= self.max_len
+    def generate(self, n_tokens, first_token=1, use_graph=True, prompt=None):
+        """greedy decode n_tokens; returns the token ids (device tensor).  `prompt` (1-D token ids) is fed
+        token by token through the same step (teacher forced, filling the KV cache), then decoding
+        continues greedily from its last token; prompt length + n_tokens <= max_len + 1."""
+        if prompt is not None:
+            prompt = torch.as_tensor(prompt, dtype=torch.long, device=self.dev).reshape(-1)
+            first_token = int(prompt[0])
+        n_prompt = 0 if prompt is None else prompt.numel() - 1
+        assert n_prompt + n_tokens <= self.max_len
         self.reset(first_token)
         if use_graph and self.graph is None:
             self.capture()
             self.reset(first_token)
         out = torch.empty(n_tokens, dtype=torch.long, device=self.dev)
-        for t in range(n_tokens):
+        for t in range(n_prompt + n_tokens):
             if use_graph:
                 self.graph.replay()
             else:
                 self.step()
-            out[t] = self.tok[0]
+            if t < n_prompt:
+                self.tok.copy_(prompt[t + 1:t + 2].view_as(self.tok))
+            else:
+                out[t - n_prompt] = self.tok.reshape(-1)[0]
         return out

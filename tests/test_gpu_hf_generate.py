@@ -86,3 +86,13 @@ def test_fast_decoder_from_loaded_hf_model(tmp_path):
         tok = int(toks[t])
         margin = (logits[t].max() - logits[t, tok]).item()
         assert margin <= 0.03 * (logits[t].abs().max().item() + 1.0), (t, tok, margin)
+    # with a prompt: the prompt is teacher forced through the same captured step
+    prompt = torch.tensor([5, 17, 3, 99, 42], device="cuda:0")
+    ptoks = dec.generate(8, prompt=prompt)
+    seq = torch.cat([prompt, ptoks])[None]
+    with torch.no_grad():
+        logits = q(seq).logits.float()[0]
+    for t in range(8):
+        row = logits[prompt.numel() - 1 + t]
+        margin = (row.max() - row[int(ptoks[t])]).item()
+        assert margin <= 0.03 * (row.abs().max().item() + 1.0), (t, margin)
