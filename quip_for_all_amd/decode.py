@@ -151,6 +151,7 @@ class LlamaDecoder:
         self.tok = torch.zeros(1, dtype=torch.long, device=self.dev)
         self.pos = torch.zeros(1, dtype=torch.long, device=self.dev)
         self.graph = None
+        self.sampling = None
         self.fused_attention = s.head_dim in (64, 128)
         from .register_lib import rope_attn_workspace
         self.attn_ws = rope_attn_workspace(s.heads, s.head_dim, self.dev) if self.fused_attention else None
@@ -252,10 +253,28 @@ class LlamaDecoder:
             return gemv_chain(layers, prev, z, residual=residual, rms_weight=ln, rms_eps=self.s.rms_eps)
         return gemv_fused(layers, prev=prev, z=z, residual=residual, rms_weight=ln, rms_eps=self.s.rms_eps)
 
+    def set_sampling(self, temperature=None, top_k=None):
+        """greedy (default, temperature None / 0) or the reference demo's sampler
+        (example_generate.py:9-26: logits / T, optional top-k cut, softmax, exponential-race arg-max --
+        no host synchronisation).  The choice is part of the captured step: changing it re-captures."""
+        new = None if not temperature else (float(temperature), None if top_k is None else int(top_k))
+        if new != getattr(self, "sampling", None):
+            self.sampling, self.graph = new, None
+
     def _head(self, h):
         s = self.s
         logits = F.rms_norm(h, (s.hidden,), self.final_norm, s.rms_eps) @ self.lm_head.T
-        self.tok.copy_(logits.argmax(-1))
+        if getattr(self, "sampling", None) is None:
+            self.tok.copy_(logits.argmax(-1))
+        else:
+            temperature, top_k = self.sampling
+            lg = logits.float() / max(temperature, 1e-5)
+            if top_k is not None:
+                v, _ = torch.topk(lg, min(top_k, lg.size(-1)))
+                lg = torch.where(lg < v[..., -1:], -float("inf"), lg)
+            probs = torch.softmax(lg, dim=-1)
+            q = torch.empty_like(probs).exponential_(1)
+            self.tok.copy_(torch.argmax(probs / q, dim=-1))
         self.pos.add_(1)
         return logits
 
@@ -275,13 +294,14 @@ class LlamaDecoder:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
-            self.step()
+            self.step_logits = self.step()      # static output of the captured step (valid after each replay)
         torch.cuda.synchronize()
         self.reset()
 
     @torch.no_grad()
-    def generate(self, n_tokens, first_token=1, use_graph=True, prompt=None):
-        """greedy decode n_tokens; returns the token ids (device tensor).  `prompt` (1-D token ids) is fed
+    def generate(self, n_tokens, first_token=1, use_graph=True, prompt=None, temperature=None, top_k=None):
+        """decode n_tokens (greedy, or sampled when a temperature is given: set_sampling); returns the
+        token ids (device tensor).  `prompt` (1-D token ids) is fed
         token by token through the same step (teacher forced, filling the KV cache), then decoding
         continues greedily from its last token; prompt length + n_tokens <= max_len + 1."""
         if prompt is not None:
@@ -289,6 +309,7 @@ class LlamaDecoder:
             first_token = int(prompt[0])
         n_prompt = 0 if prompt is None else prompt.numel() - 1
         assert n_prompt + n_tokens <= self.max_len
+        self.set_sampling(temperature, top_k)
         self.reset(first_token)
         if use_graph and self.graph is None:
             self.capture()
@@ -298,7 +319,7 @@ class LlamaDecoder:
             if use_graph:
                 self.graph.replay()
             else:
-                self.step()
+                self.step_logits = self.step()
             if t < n_prompt:
                 self.tok.copy_(prompt[t + 1:t + 2].view_as(self.tok))
             else:

@@ -172,3 +172,31 @@ def test_fused_prologue_step_equals_unfused_step():
     ref = _ref_logits(dec, [7, int(fused_tokens[0]), int(fused_tokens[1])])
     got = lf[2].float().cpu().numpy()[0].astype(np.float64)
     assert np.max(np.abs(got - ref)) <= 0.03 * (np.abs(ref).max() + 1.0)
+
+
+def test_sampling_step_matches_reference_sampler_semantics():
+    """example_generate.py:9-26: temperature + top-k + exponential-race arg-max inside the captured step.
+    top_k=1 is greedy; with top_k=5 every sampled token is one of the 5 largest logits of its own step,
+    and the draws differ between steps (the graph-safe generator advances on replay)."""
+    from quip_for_all_amd.decode import LlamaDecoder, SMALL as LLAMA_TINY
+    dec = LlamaDecoder(LLAMA_TINY, max_len=64, device="cuda:0", seed=3)
+    greedy = dec.generate(16, first_token=7)
+    k1 = dec.generate(16, first_token=7, temperature=0.6, top_k=1)
+    assert torch.equal(greedy, k1)
+    torch.manual_seed(0)
+    dec.set_sampling(0.6, 5)
+    dec.reset(7)
+    dec.capture()
+    dec.reset(7)
+    toks, n_not_top1 = [], 0
+    for _ in range(48):
+        dec.graph.replay()
+        lg = dec.step_logits.float()[0]
+        t = int(dec.tok[0])
+        top = torch.topk(lg, 5).indices.tolist()
+        assert t in top
+        n_not_top1 += t != top[0]
+        toks.append(t)
+    assert n_not_top1 > 0, "48 draws at T=0.6 over 5 candidates never left the arg-max: sampler is not sampling"
+    # back to greedy: re-captures and reproduces the greedy tokens
+    assert torch.equal(dec.generate(16, first_token=7), greedy)
