@@ -66,6 +66,10 @@ namespace {
 #ifndef QUIP_GEMV_DEPTH
 #define QUIP_GEMV_DEPTH 1
 #endif
+// streaming mode with one slot per wave: items handed out dynamically (LDS counter) instead of round-robin
+#ifndef QUIP_GEMV_DYNAMIC
+#define QUIP_GEMV_DYNAMIC 1
+#endif
 constexpr bool kR8 = QUIP_GEMV_R8 != 0;
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -658,6 +662,29 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
       }
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
+    }
+  } else if constexpr (SLOTS == 1 && QUIP_GEMV_DYNAMIC && !kR8) {
+    // One slot per wave, items handed out by an LDS counter (word 3 of accumulator row 0, zeroed with
+    // the accumulators): the SIMD arbiters favour the oldest waves, so with a fixed round-robin split the
+    // young waves finish last and the workgroup's tail runs with few loads in flight.
+    int cur = wave;
+    while (cur < cnt) {   // wave-uniform
+      int nxt = 0;
+      if (lane == 0) nxt = __hip_atomic_fetch_add(accs + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      nxt = __builtin_amdgcn_readfirstlane(nxt) + nwaves;
+      asm_wait_vmcnt<0>(qa[0], qb[0]);
+      ItemAddr ad;
+      item_addresses<REP>(qa[0], qb[0], lane_c, lane_c2, ad);
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        asm volatile("" : "+v"(ad.a1l[t]), "+v"(ad.a2l[t]), "+v"(ad.a1h[t]), "+v"(ad.a2h[t]));
+      const bool real = nxt < cnt;
+      asm_load16_nt(qa[0], real ? item_ptr(nxt, 0) : hot);
+      asm_load16_nt(qb[0], real ? item_ptr(nxt, 1) : hot + 1);
+      run_item(cur, ad);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
     }
   } else {
     for (int it = wave; it < cnt; it += SLOTS * nwaves) {
