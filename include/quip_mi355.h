@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QUIP_ABI_VERSION 4
+#define QUIP_ABI_VERSION 5
 
 typedef void* quip_stream_t; /* hipStream_t */
 
@@ -71,11 +71,14 @@ int quip_hadamard_f16(const void* x, void* y, int64_t rows, int32_t n, float sca
 int quip_e8p_mm_origorder(const void* x, const void* qidxs /* int16 (n, k/8) */,
                           const void* grid_packed_abs /* int64[256] */, void* y,
                           int32_t m, int32_t n, int32_t k, quip_stream_t stream);
-/* Workspace variant of the E8P12 product.  At m == 1 (bs=1 decode) the fast path first
- * rewrites x as block fixed point int8 digit planes (one tiny launch) and then runs the
- * integer-domain decode GEMV; the planes live in caller-provided scratch so that the library
- * still allocates nothing.  quip_e8p_mm_origorder() without workspace stays valid (it converts
- * x inside every workgroup: self-contained but slower).  Other m: workspace unused. */
+/* Workspace variant of the E8P12 product.  For 1 <= m < 32 (the range the codebook module sends to this
+ * op, e8p12.py:147-150) the fast path first rewrites every row of x as block fixed point int8 digit planes
+ * (one small launch, one workgroup per row) and then runs the integer-domain matrix-core GEMV -- m == 1:
+ * the bs=1 kernel; m > 1: rows mode, passes of quip_e8p_gemv_max_rows(n, k) rows over the codes (see
+ * quip_e8p_gemv_planes_rows).  The planes live in caller-provided scratch (m plane images), so the library
+ * still allocates nothing.  quip_e8p_mm_origorder() without workspace stays valid (m == 1: converts x
+ * inside every workgroup; m > 1: the generic fused decode + fp32 FMA kernel): self-contained but slower.
+ * m >= 32 or unsupported shapes: workspace unused (bytes == 0). */
 size_t quip_e8p_mm_workspace_bytes(int32_t m, int32_t n, int32_t k);
 int quip_e8p_mm_origorder_ws(const void* x, const void* qidxs, const void* grid_packed_abs, void* y,
                              int32_t m, int32_t n, int32_t k, void* workspace,
@@ -212,6 +215,24 @@ int quip_had_transform_group_f16(const quip_had_problem* problems, int32_t count
                                  int32_t n, int32_t K, int32_t transpose, quip_stream_t stream);
 int quip_had_transform_planes_group(const quip_had_problem* problems, int32_t count, int32_t n,
                                     int32_t K, int32_t transpose, quip_stream_t stream);
+/* ---- skinny GEMM on the matrix cores: 2..5 activation rows per pass over the codes ----------------
+ * Replaces the 1 < M < 32 use of e8p_mm_origorder (origin_order.cu:388-555, 604-648; e8p12.py:147-150).
+ * The MFMA of the bs=1 GEMV has 16 A rows and a single activation row fills 3 of them (its digit
+ * planes); rows mode fills up to 15 with (activation row, plane) pairs, so `rows` activation rows are
+ * multiplied in the ONE pass over the codes that bs=1 needs -- same exact integer sums per row, i.e. row
+ * r of y is bit identical to quip_e8p_gemv_planes on row r alone.
+ *   quip_had_transform_planes_rows: problem->x (rows, in_features) fp16 -> problem->out: `rows` plane
+ *     images back to back, quip_e8p_planes_bytes(n) bytes each (same fusion fields as the planes group,
+ *     row-wise; no chain fields).
+ *   quip_e8p_gemv_max_rows(n, k): rows one launch takes for this shape (LDS budget: 5 for k <= 4096,
+ *     3 for k <= 8192, 2 for k <= 15360, else 1); 0 if the shape is unsupported.
+ *   quip_e8p_gemv_planes_rows: y (rows, n) fp16 row major; rows <= quip_e8p_gemv_max_rows(n, k). */
+int quip_had_transform_planes_rows(const quip_had_problem* problem, int64_t rows, int32_t n, int32_t K,
+                                   int32_t transpose, quip_stream_t stream);
+int32_t quip_e8p_gemv_max_rows(int32_t n, int32_t k);
+int quip_e8p_gemv_planes_rows(const void* planes, const void* qidxs, const void* grid_packed_abs, void* y,
+                              int32_t rows, int32_t n, int32_t k, quip_stream_t stream);
+
 /* count GEMVs y[i] = W[i] x[i] (W[i]: (ns[i], k) E8P12 codes, x[i] as digit planes) */
 int quip_e8p_gemv_planes_group(const void* const* planes, const void* const* qidxs,
                                const void* grid_packed_abs, void* const* ys, const int32_t* ns,

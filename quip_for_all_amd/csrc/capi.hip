@@ -135,6 +135,22 @@ int quip_had_transform_planes_group(const quip_had_problem* problems, int32_t co
   return group_had(problems, count, true, 1, n, K, transpose, stream);
 }
 
+int quip_had_transform_planes_rows(const quip_had_problem* problem, int64_t rows, int32_t n, int32_t K,
+                                   int32_t transpose, quip_stream_t stream) {
+  if (rows < 1) return rows == 0 ? QUIP_OK : QUIP_ERR_BAD_SHAPE;
+  return group_had(problem, 1, true, rows, n, K, transpose, stream);
+}
+
+int32_t quip_e8p_gemv_max_rows(int32_t n, int32_t k) { return (n > 0 && k > 0) ? e8p_gemv_mfma_max_rows(n, k) : 0; }
+
+int quip_e8p_gemv_planes_rows(const void* planes, const void* qidxs, const void* grid_packed_abs, void* y,
+                              int32_t rows, int32_t n, int32_t k, quip_stream_t stream) {
+  if (!planes || !qidxs || !grid_packed_abs || !y) return QUIP_ERR_NULL_POINTER;
+  if (rows < 1 || n < 1 || k < 1 || k % 8 != 0) return QUIP_ERR_BAD_SHAPE;
+  if (!aligned16(planes) || !aligned16(qidxs)) return QUIP_ERR_MISALIGNED;
+  return e8p_gemv_mfma_rows_launch(planes, qidxs, grid_packed_abs, y, rows, n, k, GemvTune{}, (hipStream_t)stream);
+}
+
 int quip_e8p_gemv_planes_group(const void* const* planes, const void* const* qidxs,
                                const void* grid_packed_abs, void* const* ys, const int32_t* ns,
                                int32_t count, int32_t k, quip_stream_t stream) {
@@ -238,7 +254,7 @@ static inline bool aligned64(const void* p) { return (reinterpret_cast<uintptr_t
 size_t quip_e8p_planes_bytes(int32_t k) { return k > 0 ? e8p_gemv_mfma_planes_bytes(k) : 0; }
 
 size_t quip_e8p_mm_workspace_bytes(int32_t m, int32_t n, int32_t k) {
-  return (m == 1 && e8p_gemv_mfma_supported(n, k)) ? e8p_gemv_mfma_planes_bytes(k) : 0;
+  return (m >= 1 && m < 32 && e8p_gemv_mfma_supported(n, k)) ? (size_t)m * e8p_gemv_mfma_planes_bytes(k) : 0;
 }
 
 int quip_e8p_x_to_planes(const void* x, void* planes, int32_t k, quip_stream_t stream) {
@@ -259,12 +275,24 @@ int quip_e8p_gemv_planes(const void* planes, const void* qidxs, const void* grid
 int quip_e8p_mm_origorder_ws(const void* x, const void* qidxs, const void* grid, void* y, int32_t m,
                              int32_t n, int32_t k, void* workspace, size_t workspace_bytes,
                              quip_stream_t stream) {
-  if (x && qidxs && grid && y && workspace && m == 1 && n > 0 && e8p_gemv_mfma_supported(n, k) &&
+  if (x && qidxs && grid && y && workspace && m >= 1 && m < 32 && n > 0 && e8p_gemv_mfma_supported(n, k) &&
       aligned16(x) && aligned16(qidxs) && aligned16(workspace) && aligned64(grid) &&
-      workspace_bytes >= e8p_gemv_mfma_planes_bytes(k)) {
-    const int rc = x_to_planes_linear_launch(x, workspace, k, (hipStream_t)stream);
+      workspace_bytes >= (size_t)m * e8p_gemv_mfma_planes_bytes(k)) {
+    // 1 <= M < 32 on the matrix cores: digit planes of every row, then passes of up to
+    // e8p_gemv_mfma_max_rows rows over the codes (M == 1: the plain GEMV)
+    const int rc = x_to_planes_linear_launch(x, workspace, k, (hipStream_t)stream, m);
     if (rc != QUIP_OK) return rc;
-    return e8p_gemv_mfma_launch(workspace, qidxs, grid, y, n, k, GemvTune{}, (hipStream_t)stream);
+    if (m == 1) return e8p_gemv_mfma_launch(workspace, qidxs, grid, y, n, k, GemvTune{}, (hipStream_t)stream);
+    const int per = e8p_gemv_mfma_max_rows(n, k);
+    const size_t pstride = e8p_gemv_mfma_planes_bytes(k);
+    for (int r0 = 0; r0 < m; r0 += per) {
+      const int mr = m - r0 < per ? m - r0 : per;
+      const int rc2 = e8p_gemv_mfma_rows_launch(reinterpret_cast<const char*>(workspace) + (size_t)r0 * pstride, qidxs,
+                                                grid, reinterpret_cast<char*>(y) + (size_t)r0 * n * 2, mr, n, k,
+                                                GemvTune{}, (hipStream_t)stream);
+      if (rc2 != QUIP_OK) return rc2;
+    }
+    return QUIP_OK;
   }
   return quip_e8p_mm_origorder(x, qidxs, grid, y, m, n, k, stream);
 }

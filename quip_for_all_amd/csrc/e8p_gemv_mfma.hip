@@ -339,9 +339,17 @@ struct FusedIn {
 // ONESHOT: the workgroup has at most SLOTS * nwaves items, so every wave requests all of its
 // items up front and never reloads a slot (decode shapes of a 7B model: 8..48 items per
 // workgroup); otherwise slots are reloaded in place while the stream lasts.
-template <int REP, int SLOTS, int MAXT, int G, bool ONESHOT, bool FUSED>
+//
+// ROWS (G == 1): `mrows` <= 5 activation rows against the ONE weight matrix (skinny GEMM, the reference's
+// M < 32 use of tinygemm_m16n8k16_chunk_kernel, origin_order.cu:388-555).  The 16 A rows of the MFMA
+// carry (activation row r, digit plane d) = 3 r + d, so the codes are streamed and decoded ONCE and every
+// activation row costs no further instruction: D row 3 r + d = S_d of activation row r.  gp.planes[0]
+// holds the rows' plane images back to back (stride 3 Kp + 16 bytes), gp.y[0] is (mrows, N) row major.
+template <int REP, int SLOTS, int MAXT, int G, bool ONESHOT, bool FUSED, bool ROWS = false>
 __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
-    GemvGroup<G> gp, FusedIn fi, const uint64_t* __restrict__ grid, int K, int Kp, uint64_t* __restrict__ dbg) {
+    GemvGroup<G> gp, FusedIn fi, const uint64_t* __restrict__ grid, int K, int Kp, uint64_t* __restrict__ dbg,
+    int mrows) {
+  static_assert(!ROWS || (G == 1 && !FUSED), "rows mode: one matrix, planes from memory");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using L = Lds<REP>;
 #define QUIP_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -428,8 +436,9 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
                : "v"(L::kD4 ? table_source_ptr_d4(grid, lane, wave) : table_source_ptr(grid, lane, wave))
                : "memory");
   constexpr int XR = 6;  // 16-byte x pieces per thread: needs nthreads >= G * 3 * Kp / 96
-  const int ppieces = 3 * (Kp >> 4);       // pieces per problem
-  const int xpieces = G * ppieces;
+  const int ppieces = 3 * (Kp >> 4);       // pieces per problem (rows mode: per activation row)
+  const int xpieces = (ROWS ? mrows : G) * ppieces;
+  const size_t pstride = (size_t)3 * Kp + 16;   // rows mode: bytes between the rows' plane images
   u32x4 xr[XR];
   // fused: thread t < n / 16 owns elements [16 t, 16 t + 16) = pieces 2 t, 2 t + 1 of every vector
   const bool act = FUSED && tid < (fi.n >> 4);   // wave uniform (n % 1024 == 0)
@@ -467,12 +476,16 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
       ic = ic >= xpieces ? ic - xpieces : ic;
       int p = 0;
 #pragma unroll
-      for (int g = 1; g < G; ++g) p += ic >= g * ppieces ? 1 : 0;
+      for (int g = 1; g < (ROWS ? 5 : G); ++g) p += ic >= g * ppieces ? 1 : 0;
       const uint8_t* src = gp.planes[0];   // per-lane choice (pieces of several problems in one wave)
+      if constexpr (ROWS) {
+        src += (size_t)p * pstride;
+      } else {
 #pragma unroll
-      for (int g = 1; g < G; ++g) {
-        src = p == g ? gp.planes[g] : src;
-        asm volatile("" : "+v"(src));
+        for (int g = 1; g < G; ++g) {
+          src = p == g ? gp.planes[g] : src;
+          asm volatile("" : "+v"(src));
+        }
       }
       asm_load16(xr[j], reinterpret_cast<const uint4*>(src) + (ic - p * ppieces));
     }
@@ -499,8 +512,12 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
   for (int i = tid; i < kMaxRowsPerBlock * 4; i += nthreads) reinterpret_cast<int*>(smem + L::kAcc)[i] = 0;
   asm volatile("s_waitcnt vmcnt(%1)" : "+v"(tsrc) : "n"((FUSED ? 2 * (4 + G) : XR) + 2 * kDepth) : "memory");
   if (wave < 8) fill_tables_from_lane<REP>(smem, tsrc, lane, wave);
-  int sh[G];
-  if constexpr (!FUSED) {
+  int sh[ROWS ? 5 : G];
+  if constexpr (ROWS) {
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+      sh[r] = *reinterpret_cast<const int*>(gp.planes[0] + (size_t)(r < mrows ? r : 0) * pstride + (size_t)3 * Kp);
+  } else if constexpr (!FUSED) {
 #pragma unroll
     for (int p = 0; p < G; ++p) sh[p] = *reinterpret_cast<const int*>(gp.planes[p] + (size_t)3 * Kp);
   }
@@ -602,7 +619,14 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
   int* accs = reinterpret_cast<int*>(smem + L::kAcc);
   // A fragment address of this lane: plane (lane & 15) clamped to a valid plane (rows >= 3
   // of A are don't-care), k = slice*512 + (t < 4 ? 0 : 256) + q*64 + (t & 3)*16
-  const uint32_t xlane = L::kX + (uint32_t)min(n, 2) * Kp + (uint32_t)q * (kR8 ? 128 : 64);
+  const uint32_t xlane = L::kX + (uint32_t)min(n, ROWS ? 3 * mrows - 1 : 2) * Kp + (uint32_t)q * (kR8 ? 128 : 64);
+  // rows mode: this lane's four D rows m = 4 q + i are (activation row m / 3, plane m % 3)
+  int roff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = 4 * q + i;
+    roff[i] = (ROWS && m < 3 * mrows) ? ((m / 3) * gp.rpb[0]) * 4 + (m % 3) : -1;
+  }
   QUIP_STAMP(4);
 
   // (tried and measured slower on MI355X: slice-major item order with the A fragments of a slice
@@ -614,8 +638,13 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
     const int rb = li / J, sl = li - rb * J;
     const uint32_t xa = xlane + (uint32_t)(p * 3 * Kp + sl * 512);
     const i32x4 acc = L::kD4 ? item_mfma_d4(ad, xa) : item_mfma(ad, xa);
-    // lanes 0..15 (q == 0) hold S_h, S_m, S_l of row rb*16 + n in acc[0..2]
-    if (q == 0) {
+    if constexpr (ROWS) {
+      int* dst = accs + (rb * 16 + n) * 4;
+      const int a4[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (roff[i] >= 0) __hip_atomic_fetch_add(dst + roff[i], a4[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else if (q == 0) {   // lanes 0..15 (q == 0) hold S_h, S_m, S_l of row rb*16 + n in acc[0..2]
       int* dst = accs + (pick(rbase, p) + rb * 16 + n) * 4;
       __hip_atomic_fetch_add(dst + 0, acc.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       __hip_atomic_fetch_add(dst + 1, acc.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -720,8 +749,21 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
   QUIP_STAMP(6);
 
   // (5) y = 2^(-sh-2) * (65536 S_h + 256 S_m + S_l), fp16 RN, coalesced
+  if constexpr (ROWS) {
 #pragma unroll
-  for (int p = 0; p < G; ++p) {
+    for (int r = 0; r < 5; ++r) {
+      if (r < mrows) {
+        const float unscale = as_f32((uint32_t)(127 - sh[r] - (L::kD4 ? 1 : 2)) << 23);
+        for (int t = tid; t < rows_here[0]; t += nthreads) {
+          const int* a = accs + (r * gp.rpb[0] + t) * 4;
+          const float f = __builtin_fmaf((float)a[0], 65536.f, __builtin_fmaf((float)a[1], 256.f, (float)a[2]));
+          gp.y[0][(size_t)r * gp.N[0] + row0[0] + t] = (f16)(f * unscale);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < (ROWS ? 0 : G); ++p) {
     const float unscale = as_f32((uint32_t)(127 - sh[p] - (L::kD4 ? 1 : 2)) << 23);   // table entries are 4w (E8P) / 2w (D4)
     for (int t = tid; t < rows_here[p]; t += nthreads) {
       const int* a = accs + (rbase[p] + t) * 4;
@@ -734,11 +776,11 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
 #undef QUIP_STAMP2
 }
 
-template <int REP, int SLOTS, int MAXT, int G, bool ONESHOT = false, bool FUSED = false>
+template <int REP, int SLOTS, int MAXT, int G, bool ONESHOT = false, bool FUSED = false, bool ROWS = false>
 int launch(const GemvGroup<G>& gp, const void* grid, int k, int kp, int nblocks, int threads, uint64_t* dbg,
-           hipStream_t stream, const FusedIn* fin = nullptr) {
-  auto kern = e8p_gemv_mfma_kernel<REP, SLOTS, MAXT, G, ONESHOT, FUSED>;
-  const int lds = FUSED ? Lds<REP>::bytes_fused(kp, G) : Lds<REP>::bytes(kp, G);
+           hipStream_t stream, const FusedIn* fin = nullptr, int mrows = 1) {
+  auto kern = e8p_gemv_mfma_kernel<REP, SLOTS, MAXT, G, ONESHOT, FUSED, ROWS>;
+  const int lds = FUSED ? Lds<REP>::bytes_fused(kp, G) : Lds<REP>::bytes(kp, ROWS ? mrows : G);
   const FusedIn fi = fin ? *fin : FusedIn{};
   static int configured = 0;  // benign race: idempotent attribute
   if (lds > configured) {
@@ -748,7 +790,7 @@ int launch(const GemvGroup<G>& gp, const void* grid, int k, int kp, int nblocks,
     configured = lds;
   }
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(threads), lds, stream, gp, fi,
-                     reinterpret_cast<const uint64_t*>(grid), k, kp, dbg);
+                     reinterpret_cast<const uint64_t*>(grid), k, kp, dbg, mrows);
   return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
 }
 
@@ -887,6 +929,10 @@ __global__ __launch_bounds__(1024) void x_to_planes_linear_kernel(const f16* __r
                                                                   int* __restrict__ sh_out, int K, int Kp) {
   __shared__ uint32_t smax[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  // one workgroup per activation row: row r reads x + r K and writes the image at planes + r (3 Kp + 16)
+  x += (size_t)blockIdx.x * K;
+  planes += (size_t)blockIdx.x * ((size_t)3 * Kp + 16);
+  sh_out = reinterpret_cast<int*>(reinterpret_cast<uint8_t*>(sh_out) + (size_t)blockIdx.x * ((size_t)3 * Kp + 16));
   const uint4* xg = reinterpret_cast<const uint4*>(x);
   const int pieces = K >> 3;
   uint32_t mx = 0;  // fp16 magnitudes order like their bit patterns
@@ -941,12 +987,12 @@ bool e8p_gemv_mfma_supported(int n, int k) {
 
 size_t e8p_gemv_mfma_planes_bytes(int k) { return (size_t)3 * kp_of(k) + 16; }
 
-int x_to_planes_linear_launch(const void* x, void* planes, int k, hipStream_t stream) {
-  if (k < 8 || k % 8 != 0) return QUIP_ERR_BAD_SHAPE;
+int x_to_planes_linear_launch(const void* x, void* planes, int k, hipStream_t stream, int rows) {
+  if (k < 8 || k % 8 != 0 || rows < 1) return QUIP_ERR_BAD_SHAPE;
   const int kp = kp_of(k);
   int* sh = reinterpret_cast<int*>(reinterpret_cast<char*>(planes) + (size_t)3 * kp);
   const int threads = k >= 8192 ? 1024 : (k >= 2048 ? 256 : 64);
-  hipLaunchKernelGGL(x_to_planes_linear_kernel, dim3(1), dim3(threads), 0, stream,
+  hipLaunchKernelGGL(x_to_planes_linear_kernel, dim3(rows), dim3(threads), 0, stream,
                      reinterpret_cast<const f16*>(x), reinterpret_cast<uint8_t*>(planes), sh, k, kp);
   return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
 }
@@ -1048,6 +1094,55 @@ int e8p_gemv_mfma_launch(const void* planes, const void* qidxs, const void* grid
   QUIP_CASE(64, 1) QUIP_CASE(64, 2) QUIP_CASE_BIG(64, 1) QUIP_CASE_BIG(64, 2)
 #undef QUIP_CASE
 #undef QUIP_CASE_BIG
+  return QUIP_ERR_UNSUPPORTED;
+}
+
+// ---- rows mode: up to 5 activation rows per launch ------------------------------------------
+int e8p_gemv_mfma_max_rows(int n, int k) {
+  if (!e8p_gemv_mfma_supported(n, k)) return 0;
+  const int m = Lds<16>::kMaxKp / kp_of(k);
+  return m > 5 ? 5 : m;
+}
+
+int e8p_gemv_mfma_rows_launch(const void* planes, const void* qidxs, const void* grid, void* y, int mrows, int n,
+                              int k, const GemvTune& tune, hipStream_t stream) {
+  if (mrows < 1 || mrows > e8p_gemv_mfma_max_rows(n, k)) return QUIP_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(grid) & 63u) != 0) return QUIP_ERR_MISALIGNED;
+  const int kp = kp_of(k);
+  uint64_t* dbg = reinterpret_cast<uint64_t*>(tune.dbg);
+  int nblocks = tune.blocks > 0 ? tune.blocks : device_cu_count();
+  int rpb;
+  for (;;) {   // accumulator rows: mrows per weight row
+    rpb = (n + nblocks - 1) / nblocks;
+    rpb = (rpb + 15) & ~15;
+    if (mrows * rpb <= kMaxRowsPerBlock) break;
+    nblocks *= 2;
+  }
+  nblocks = (n + rpb - 1) / rpb;
+  const int items = (rpb >> 4) * (kp >> 9);
+  int waves = tune.max_waves > 0 ? tune.max_waves : (items <= 64 ? 8 : 12);
+  const int min_waves = (mrows * 3 * (kp >> 4) + 6 * 64 - 1) / (6 * 64);   // 6 plane pieces per thread
+  if (waves < min_waves) waves = min_waves;
+  if (waves < 8) waves = 8;
+  if (waves > 16) return QUIP_ERR_UNSUPPORTED;
+  const int threads = waves * 64;
+  const int ipw = (items + waves - 1) / waves;
+  const int rep = mrows * kp <= Lds<32>::kMaxKp ? 32 : 16;
+  GemvGroup<1> gp{{reinterpret_cast<const uint4*>(qidxs)}, {reinterpret_cast<const uint8_t*>(planes)},
+                  {reinterpret_cast<f16*>(y)}, {n}, {rpb}, {0}};
+#define QUIP_ROWS(R, S, T, ONE)                                                                   \
+  if (rep == R && (T == 1024) == (threads > 512) && (ONE ? ipw <= S : true))                      \
+    return launch<R, S, T, 1, ONE, false, true>(gp, grid, k, kp, nblocks, threads, dbg, stream, nullptr, mrows);
+  if ((threads <= 512 && ipw <= 8) || (threads > 512 && ipw <= 4)) {
+    QUIP_ROWS(32, 1, 512, true) QUIP_ROWS(32, 2, 512, true) QUIP_ROWS(32, 3, 512, true) QUIP_ROWS(32, 4, 512, true)
+    QUIP_ROWS(32, 6, 512, true) QUIP_ROWS(32, 8, 512, true)
+    QUIP_ROWS(16, 1, 512, true) QUIP_ROWS(16, 2, 512, true) QUIP_ROWS(16, 3, 512, true) QUIP_ROWS(16, 4, 512, true)
+    QUIP_ROWS(16, 6, 512, true) QUIP_ROWS(16, 8, 512, true)
+    QUIP_ROWS(32, 1, 1024, true) QUIP_ROWS(32, 2, 1024, true) QUIP_ROWS(32, 3, 1024, true) QUIP_ROWS(32, 4, 1024, true)
+    QUIP_ROWS(16, 1, 1024, true) QUIP_ROWS(16, 2, 1024, true) QUIP_ROWS(16, 3, 1024, true) QUIP_ROWS(16, 4, 1024, true)
+  }
+  QUIP_ROWS(32, 1, 512, false) QUIP_ROWS(16, 1, 512, false) QUIP_ROWS(32, 1, 1024, false) QUIP_ROWS(16, 1, 1024, false)
+#undef QUIP_ROWS
   return QUIP_ERR_UNSUPPORTED;
 }
 

@@ -54,7 +54,7 @@ struct HadArgs {
   const f16* rms_w;     // [in_features] or null: RMSNorm weight, v *= rsqrt(mean(x^2) + eps) * rms_w
   const f16* gate;      // [rows, in_features] or null: v *= silu(gate)
   f16* y;               // fp16 output [rows, out_features] (planes == null)
-  uint8_t* planes;      // digit planes output (rows == 1) or null
+  uint8_t* planes;      // digit planes output (one image of 3 Kp + 16 bytes per token row) or null
   int in_features, out_features, n, Kp, K, L, logL, transpose;
   int vec, vec_out;     // 16-byte vector loads / stores allowed (alignment + multiple-of-8 sizes)
   // chain: the input row is itself the output side of the producer module, computed here first:
@@ -174,7 +174,8 @@ __device__ __forceinline__ void raw_math16(const HadArgs& a, int idx0, const Raw
 // of a prefill batch are resident per CU)
 template <bool PLANES, bool TALL, int MAXT, bool KONE = false>
 __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
-  const HadArgs a = grp.p[blockIdx.z];
+  HadArgs a = grp.p[blockIdx.z];
+  if constexpr (PLANES) a.planes += (size_t)blockIdx.y * ((size_t)3 * a.Kp + 16);   // one plane image per token row
   extern __shared__ __attribute__((aligned(16))) float buf[];
   __shared__ float red[32];     // two slots, each used once: no barrier before their writes
   const int tid = threadIdx.x, nt = blockDim.x;   // nt == E / 16
@@ -485,7 +486,8 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
 // simple LDS radix-2 version for lengths the blocked kernel does not take
 template <bool PLANES>
 __global__ __launch_bounds__(256) void had_small_kernel(HadGroup grp) {
-  const HadArgs a = grp.p[blockIdx.z];
+  HadArgs a = grp.p[blockIdx.z];
+  if constexpr (PLANES) a.planes += (size_t)blockIdx.y * ((size_t)3 * a.Kp + 16);   // one plane image per token row
   extern __shared__ __attribute__((aligned(16))) float buf[];
   __shared__ float red[16];
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -705,7 +707,7 @@ int had_transform_group_launch(const HadProblem* problems, int count, bool plane
     if (rc != QUIP_OK) return rc;
     if (planes && (reinterpret_cast<uintptr_t>(problems[i].out) & 15) != 0) return QUIP_ERR_MISALIGNED;
   }
-  if (planes && (g.p[0].L < 4 || n % 16 != 0 || rows != 1)) return QUIP_ERR_BAD_SHAPE;
+  if (planes && (g.p[0].L < 4 || n % 16 != 0)) return QUIP_ERR_BAD_SHAPE;
   if (rows <= 0) return QUIP_OK;
   // grid.y carries the token rows (<= 65535 per launch): longer batches go out in slices
   constexpr int64_t kMaxRows = 65535;
@@ -717,6 +719,7 @@ int had_transform_group_launch(const HadProblem* problems, int count, bool plane
       a.x += r0 * a.in_features;
       if (a.gate) a.gate += r0 * a.in_features;
       if (a.y) a.y += r0 * a.out_features;
+      if (a.planes) a.planes += r0 * ((int64_t)3 * a.Kp + 16);
       if (a.residual) a.residual += r0 * a.out_features;
       if (a.z) { a.z += r0 * a.n; a.h_out += r0 * a.n; if (a.z_res) a.z_res += r0 * a.n; }
     }

@@ -32,7 +32,7 @@ int e8p_gemv_i8_launch(const void* xsrc, int xmode, const void* qidxs, const voi
 // matrix-core GEMV (default bs=1 path): planes = [3][Kp] digit bytes + shift word
 bool e8p_gemv_mfma_supported(int n, int k);
 size_t e8p_gemv_mfma_planes_bytes(int k);
-int x_to_planes_linear_launch(const void* x, void* planes, int k, hipStream_t stream);
+int x_to_planes_linear_launch(const void* x, void* planes, int k, hipStream_t stream, int rows = 1);
 int e8p_gemv_mfma_launch(const void* planes, const void* qidxs, const void* grid, void* y, int n, int k,
                          const GemvTune& tune, hipStream_t stream);
 int shape_probe_launch(const void* qidxs, void* out, int n, int k, const GemvTune& tune, hipStream_t stream);
@@ -82,6 +82,10 @@ struct HadProblem {
 };
 int had_transform_group_launch(const HadProblem* problems, int count, bool planes, int64_t rows, int n, int K,
                                int transpose, hipStream_t stream);
+// rows mode: up to e8p_gemv_mfma_max_rows(n, k) <= 5 activation rows against one matrix in one pass
+int e8p_gemv_mfma_max_rows(int n, int k);
+int e8p_gemv_mfma_rows_launch(const void* planes, const void* qidxs, const void* grid, void* y, int mrows, int n,
+                              int k, const GemvTune& tune, hipStream_t stream);
 bool e8p_gemv_mfma_group_supported(const int* ns, int count, int k);
 int e8p_gemv_mfma_group_launch(const void* const* planes, const void* const* qidxs, const void* grid,
                                void* const* ys, const int* ns, int count, int k, const GemvTune& tune,

@@ -48,6 +48,11 @@ _SCHEMAS = {
     "d4_gemv_planes_group": "(Tensor[] planes, Tensor[] Qidxs, Tensor grid) -> Tensor[]",
     # 2..3 activation rows against ONE weight matrix: the grouped GEMV with the same codes for every row
     "e8p_mm_planes_rows": "(Tensor[] planes, Tensor Qidxs, Tensor grid) -> Tensor",
+    # skinny GEMM on the matrix cores: M rows -> (M, planes_bytes) plane images -> (M, n); the GEMV op splits
+    # the rows into passes of quip_e8p_gemv_max_rows(n, k) (5 for k <= 4096) rows each
+    "had_transform_planes_rows": "(Tensor x, int n, int K, Tensor? had, bool transpose, Tensor? pre, float scale, "
+                                 "Tensor? rms_weight, float rms_eps, Tensor? gate) -> Tensor",
+    "e8p_gemv_planes_rows": "(Tensor planes, Tensor Qidxs, Tensor grid) -> Tensor",
     # chain: output side of the producer module (z, its SV, residual) + input transforms of 1..3 consumers;
     # returns [h] + planes
     "had_chain_planes_group": "(Tensor z, Tensor z_post, Tensor? z_residual, float z_scale, int n, Tensor[] pre, "
@@ -227,6 +232,43 @@ def _d4_gemv_planes_group_cuda(planes, Qidxs, grid):
             vp(*[p.data_ptr() for p in planes]), vp(*[q.data_ptr() for q in Qidxs]), _d4_grid(grid).data_ptr(),
             vp(*[o.data_ptr() for o in outs]), ns, count, k, _stream(planes[0])), "quip_d4_gemv_planes_group")
     return outs
+
+
+def _had_transform_planes_rows_cuda(x, n, K, had, transpose, pre, scale, rms_weight, rms_eps, gate):
+    xc = _chk_x(x)
+    _need(gate is None or (gate.shape == xc.shape and gate.dtype == torch.float16 and gate.is_contiguous()),
+          "gate must be contiguous float16 with x's shape")
+    L = capi.lib()
+    rows = xc.shape[0]
+    out = torch.empty((rows, L.quip_e8p_planes_bytes(n)), dtype=torch.uint8, device=x.device)
+    pr = capi.HadProblem(xc.data_ptr(), out.data_ptr(), _vec_ok(had, x.device), _vec_ok(pre, x.device), None, None,
+                         None, None, _vec_ok(rms_weight, x.device), _ptr(gate), xc.shape[1], n, float(scale),
+                         float(rms_eps), None, None, None, None, 1.0, 0.0, 0)
+    import ctypes
+    with torch.cuda.device(x.device):
+        capi.check(L.quip_had_transform_planes_rows(ctypes.byref(pr), rows, n, K, int(bool(transpose)), _stream(x)),
+                   "quip_had_transform_planes_rows")
+    return out
+
+
+def _e8p_gemv_planes_rows_cuda(planes, Qidxs, grid):
+    _need(Qidxs.dtype == torch.int16 and Qidxs.is_contiguous(), "Qidxs must be contiguous int16 (n, k/8)")
+    n, k = Qidxs.shape[0], Qidxs.shape[1] * 8
+    L = capi.lib()
+    _need(planes.dim() == 2 and planes.dtype == torch.uint8 and planes.is_contiguous()
+          and planes.shape[1] == L.quip_e8p_planes_bytes(k) and planes.device == Qidxs.device,
+          "planes must be the (rows, quip_e8p_planes_bytes(k)) uint8 images of had_transform_planes_rows")
+    rows = planes.shape[0]
+    per = L.quip_e8p_gemv_max_rows(n, k)
+    _need(per >= 1, "shape not supported by the matrix-core GEMV")
+    out = torch.empty((rows, n), dtype=torch.float16, device=Qidxs.device)
+    with torch.cuda.device(Qidxs.device):
+        for r0 in range(0, rows, per):
+            m = min(per, rows - r0)
+            capi.check(L.quip_e8p_gemv_planes_rows(planes[r0].data_ptr(), Qidxs.data_ptr(), grid.data_ptr(),
+                                                   out[r0].data_ptr(), m, n, k, _stream(out)),
+                       "quip_e8p_gemv_planes_rows")
+    return out
 
 
 def _e8p_mm_planes_rows_cuda(planes, Qidxs, grid):
@@ -540,6 +582,8 @@ _IMPLS = {
     "had_transform_group": _had_transform_group_cuda,
     "e8p_gemv_planes_group": _e8p_gemv_planes_group_cuda,
     "e8p_mm_planes_rows": _e8p_mm_planes_rows_cuda,
+    "had_transform_planes_rows": _had_transform_planes_rows_cuda,
+    "e8p_gemv_planes_rows": _e8p_gemv_planes_rows_cuda,
     "d4_gemv_planes": _d4_gemv_planes_cuda,
     "d4_gemv_planes_group": _d4_gemv_planes_group_cuda,
     "had_transform_fused": _had_transform_fused_cuda,
@@ -601,6 +645,10 @@ _reg_fake("had_transform_group", lambda x, out_features, n, K, had, transpose, p
 _reg_fake("d4_gemv_planes", lambda planes, Qidxs, grid: Qidxs.new_empty((1, Qidxs.shape[0]), dtype=torch.float16))
 _reg_fake("d4_gemv_planes_group", lambda planes, Qidxs, grid:
           [q.new_empty((1, q.shape[0]), dtype=torch.float16) for q in Qidxs])
+_reg_fake("had_transform_planes_rows", lambda x, n, K, had, transpose, pre, scale, rms_weight, rms_eps, gate:
+          x.new_empty((x.shape[0], _planes_numel(n, 0.0)), dtype=torch.uint8))
+_reg_fake("e8p_gemv_planes_rows", lambda planes, Qidxs, grid:
+          Qidxs.new_empty((planes.shape[0], Qidxs.shape[0]), dtype=torch.float16))
 _reg_fake("e8p_mm_planes_rows", lambda planes, Qidxs, grid:
           Qidxs.new_empty((len(planes), Qidxs.shape[0]), dtype=torch.float16))
 _reg_fake("e8p_gemv_planes_group", lambda planes, Qidxs, grid:

@@ -388,3 +388,28 @@ def test_hi_on_the_d4_mode_through_the_virtual_vector(Q, n, k):
     ref = xh @ W64.T
     wx = np.abs(xh) @ np.abs(W64).T
     assert np.all(np.abs(y - ref) <= 2.0 ** -10 * np.abs(ref) + 2.0 ** -20 * wx + 1e-6), np.abs(y - ref).max()
+
+
+@pytest.mark.parametrize("n,k,M", [(4096, 4096, 5), (512, 4096, 1), (11008, 4096, 4), (4096, 11008, 2), (4096, 11008, 5),
+                                   (1024, 8192, 3), (28672, 8192, 3), (8192, 28672, 2), (48, 1024, 5), (4100, 2048, 5)])
+def test_e8p_gemv_planes_rows_equal_single_row_gemv(n, k, M):
+    """rows-mode GEMV (quip_e8p_gemv_planes_rows): row r of the result is bit identical to the bs=1 GEMV on
+    row r's planes, and the plane images of had_transform_planes_rows equal the single-row transform's"""
+    import quip_for_all_amd as Q
+    rng = np.random.default_rng(n + k + M)
+    qidx = torch.from_numpy(rng.integers(-32768, 32768, (n, k // 8), dtype=np.int16)).to(DEV)
+    x = torch.from_numpy((rng.standard_normal((M, k)) * rng.uniform(0.1, 4.0, (M, 1))).astype(np.float16)).to(DEV)
+    su = torch.from_numpy(rng.choice([-1.0, 1.0], k).astype(np.float16)).to(DEV)
+    grid = Q.codebook.codebook_id["E8P12"](inference=True).to(DEV).grid_packed_abs
+    op = torch.ops.quip_lib
+    from quip_for_all_amd.quant import get_hadK
+    had, K, _ = get_hadK(k, True)
+    had = None if had is None else had.to(DEV).half().contiguous()
+    planes = op.had_transform_planes_rows(x, k, K, had, True, su, 0.37, None, 1e-5, None)
+    y = op.e8p_gemv_planes_rows(planes, qidx, grid)
+    assert y.shape == (M, n)
+    for r in range(M):
+        pr = op.had_transform_planes_fused(x[r:r + 1], k, K, had, True, su, 0.37, None, 1e-5, None)
+        used = 3 * ((k + 511) // 512 * 512) + 4          # planes + shift word (12 bytes of padding follow)
+        assert torch.equal(planes[r][:used], pr[:used]), r
+        assert torch.equal(y[r:r + 1], op.e8p_gemv_planes(pr, qidx, grid)), r

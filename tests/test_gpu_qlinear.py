@@ -258,10 +258,14 @@ def test_forward_group_generic_codebooks_and_batches(cbid, fin, fouts, M):
             assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("fin,fout,M", [(4096, 4096, 2), (4096, 11008, 3), (11008, 4096, 2), (1408, 512, 3)])
+@pytest.mark.parametrize("fin,fout,M", [(4096, 4096, 2), (4096, 11008, 3), (11008, 4096, 2), (1408, 512, 3),
+                                        (4096, 4096, 5), (4096, 4096, 4), (4096, 11008, 5), (11008, 4096, 5),
+                                        (4096, 4096, 13), (8192, 1024, 7), (8192, 8192, 3), (1024, 8192, 16),
+                                        (256, 688, 5), (688, 256, 6), (4096, 28672, 2)])
 def test_skinny_rows_on_matrix_core_path(fin, fout, M):
-    """2..3 rows go through per-row digit planes + the grouped GEMV; each row must equal the bs=1
-    result of that row bit for bit (same integer arithmetic) and sit inside the oracle bound"""
+    """2..16 rows go through per-row digit planes + the rows-mode GEMV ((row, plane) pairs in the MFMA's A
+    rows: up to 5 rows per pass over the codes); each row must equal the bs=1 result of that row bit for
+    bit (same integer arithmetic) and sit inside the oracle bound"""
     P = O.make_layer("E8P12", fin, fout, seed=fin + fout + M)
     layer = _layer(P)
     rng = np.random.default_rng(M + fin)
