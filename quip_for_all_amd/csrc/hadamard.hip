@@ -209,7 +209,20 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
       ld8(zr + j0, v); ld8(zr + j0 + 8, v + 8);
       ld8(a.z_post + j0, tp); ld8(a.z_post + j0 + 8, tp + 8);
       if (a.z_res) { ld8(a.z_res + row * a.n + j0, tr); ld8(a.z_res + row * a.n + j0 + 8, tr + 8); }
+      // the consumer's element-wise vectors are requested now, one memory round trip with z (requested after
+      // the transform they cost a second, fully exposed one: measured 0.8 us of a 6.3 us launch)
+      uint4 qw[2], qg[2], qp[2], qp2[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = j0 + 8 * h;
+        if (a.rms_w) qw[h] = ldp(a.rms_w + c);
+        if (a.gate) qg[h] = ldp(gr + c);
+        if (a.pre) qp[h] = ldp(a.pre + c);
+        if (a.pre2) qp2[h] = ldp(a.pre2 + c);
+      }
+      HSTAMP(7);
       had::fht16(v, buf, tt, logL, true, a.pp);
+      HSTAMP(8);
       f16 o[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r)
@@ -225,16 +238,16 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         float* e = v + 8 * h;
-        const int c = j0 + 8 * h;
         if (a.rms_w) {
           had::sumsq8(e, ss_x);
-          had::mul8(e, ldp(a.rms_w + c));
+          had::mul8(e, qw[h]);
         }
-        if (a.gate) had::silu_mul8(e, ldp(gr + c));
-        if (a.pre) had::mul8(e, ldp(a.pre + c));
-        if (a.pre2) had::mul8(e, ldp(a.pre2 + c));
+        if (a.gate) had::silu_mul8(e, qg[h]);
+        if (a.pre) had::mul8(e, qp[h]);
+        if (a.pre2) had::mul8(e, qp2[h]);
       }
       __syncthreads();   // the shuffle buffer is reused by the transform below
+      HSTAMP(9);
     } else if (KONE || K == 1) {
       in_vals16(a, xr, gr, kp * L + j0, v, ss_x);
     } else if constexpr (!KONE) {
