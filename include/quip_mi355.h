@@ -233,6 +233,15 @@ int32_t quip_e8p_gemv_max_rows(int32_t n, int32_t k);
 int quip_e8p_gemv_planes_rows(const void* planes, const void* qidxs, const void* grid_packed_abs, void* y,
                               int32_t rows, int32_t n, int32_t k, quip_stream_t stream);
 
+/* ---- quantise-time codebook search (E8P12_codebook.round / quantize, e8p12.py:125-137) -------------
+ * idx[i] = arg max_c (2 x_i . g_c - |g_c|^2) over the 65 536 E8P12 codewords, vals[i] = g_idx[i]; x, vals:
+ * fp32 (nvec, 8) row major, 16-byte aligned; idx: int64 [nvec] (the reference's arg max dtype).  The
+ * reference evaluates a (nvec, 8) x (8, 65 536) GEMM per LDLQ step (quant.py:103-135); this uses the
+ * codebook's structure (abs row, even sign flips, +-1/4 shift): 512 candidates per vector, exact up to
+ * fp32 rounding of the score (ties / near-ties may resolve to a different, equally near codeword). */
+int quip_e8p_quantize_f32(const void* x, int64_t nvec, const void* grid_packed_abs, void* vals, void* idx,
+                          quip_stream_t stream);
+
 /* count GEMVs y[i] = W[i] x[i] (W[i]: (ns[i], k) E8P12 codes, x[i] as digit planes) */
 int quip_e8p_gemv_planes_group(const void* const* planes, const void* const* qidxs,
                                const void* grid_packed_abs, void* const* ys, const int32_t* ns,

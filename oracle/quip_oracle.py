@@ -612,3 +612,81 @@ def make_layer(codebook: str, in_features: int, out_features: int, seed: int = 0
                          had_right=hr, K_left=K_l, K_right=K_r, q_in=q_in,
                          q_out=q_out, bias=b, per_channel=per_channel,
                          resid_scale=float(resid_scale))
+
+
+# --------------------------------------------------------------------------
+# Quantise-time path: nearest-codeword search and LDLQ
+# --------------------------------------------------------------------------
+
+_FULL_GRID_F64 = None
+
+
+def e8p_full_grid_f64() -> np.ndarray:
+    global _FULL_GRID_F64
+    if _FULL_GRID_F64 is None:
+        _FULL_GRID_F64 = e8p_full_grid_i8().astype(np.float64) / 4.0
+    return _FULL_GRID_F64
+
+
+def round_dense(X: np.ndarray, grid: np.ndarray, chunk: int = 256):
+    """``round`` of every codebook (e8p12.py:125-128, d4.py:116-120, hi.py:30-33):
+    idx = arg max_c 2 x . g_c - |g_c|^2 (first maximum), brute force in float64."""
+    X = np.asarray(X, dtype=np.float64)
+    gn = (grid * grid).sum(-1)
+    idx = np.empty(X.shape[0], dtype=np.int64)
+    for i in range(0, X.shape[0], chunk):
+        idx[i:i + chunk] = (2.0 * X[i:i + chunk] @ grid.T - gn).argmax(-1)
+    return grid[idx], idx
+
+
+def quantize(codebook: str, X: np.ndarray, resid_scale: Optional[float] = None):
+    """``cb.quantize(X)`` -> (vals, idx) (e8p12.py:130-137, e8p12_rvq4.py:37-45,
+    e8p12_rvq3.py:81-92, d4.py:116-123, hi.py:35-39); idx before maybe_pack_idxs."""
+    X = np.asarray(X, dtype=np.float64)
+    if codebook == "E8P12":
+        return round_dense(X, e8p_full_grid_f64())
+    if codebook in ("E8P12RVQ4B", "E8P12RVQ3B"):
+        s = resid_scale if resid_scale is not None else (1 / 3.45 if codebook == "E8P12RVQ4B" else 1 / 2.04)
+        v0, i0 = round_dense(X, e8p_full_grid_f64())
+        rgrid = e8p_full_grid_f64() if codebook == "E8P12RVQ4B" else e81b_grid().astype(np.float64)
+        v1, i1 = round_dense((X - v0) / s, rgrid)
+        return v0 + v1 * s, (i0 << (16 if codebook == "E8P12RVQ4B" else 8)) + i1
+    if codebook == "D4":
+        return round_dense(X, d4_grid())
+    if codebook == "HI":
+        return round_dense(X, (np.arange(-8, 8) + 0.5)[:, None].astype(np.float64))
+    raise ValueError(codebook)
+
+
+def code_size(codebook: str) -> int:
+    return {"D4": 4, "HI": 1}.get(codebook, 8)
+
+
+def block_ldl(L: np.ndarray, b: int) -> np.ndarray:
+    """quant.py:90-102: every block column times the inverse of its diagonal block."""
+    n = L.shape[0]
+    out = np.array(L, dtype=np.float64)
+    for i in range(n // b):
+        out[:, i * b:(i + 1) * b] = out[:, i * b:(i + 1) * b] @ np.linalg.inv(L[i * b:(i + 1) * b, i * b:(i + 1) * b].astype(np.float64))
+    return out
+
+
+def ldlq(Wr: np.ndarray, Hr: np.ndarray, codebook: str, tune_iters: int = 0, resid_scale: Optional[float] = None):
+    """quant.py:105-135 in float64: hatW_k = Q(W_k + (W_{>k} - hatW_{>k}) L_{>k,k}) from the last column
+    group to the first, then `tune_iters` sweeps against the exact proxy gradient.  -> (hatWr, idx (m, n/b))"""
+    Wr = np.asarray(Wr, dtype=np.float64)
+    Hr = np.asarray(Hr, dtype=np.float64)
+    m, n = Wr.shape
+    b = code_size(codebook)
+    L = block_ldl(np.linalg.cholesky(Hr), b)
+    hat = np.zeros_like(Wr)
+    idx = np.zeros((m, n // b), dtype=np.int64)
+    for k in reversed(range(n // b)):
+        lo, hi = b * k, b * (k + 1)
+        hat[:, lo:hi], idx[:, k] = quantize(codebook, Wr[:, lo:hi] + (Wr[:, hi:] - hat[:, hi:]) @ L[hi:, lo:hi], resid_scale)
+    for _ in range(tune_iters):
+        for k in reversed(range(n // b)):
+            lo, hi = b * k, b * (k + 1)
+            t = hat[:, lo:hi] + (Wr - hat) @ Hr[:, lo:hi] @ np.linalg.inv(Hr[lo:hi, lo:hi])
+            hat[:, lo:hi], idx[:, k] = quantize(codebook, t, resid_scale)
+    return hat, idx

@@ -1,7 +1,9 @@
 """Codebook modules: tables as (non-persistent) buffers + the M-threshold
 dispatch of the reference's forward() (e8p12.py:139-156, e8p12_rvq3.py:109-129,
-e8p12_rvq4.py:50-67, d4.py:128-139, hi.py:52-63).  Quantise-time methods
-(round / quantize) are out of scope of this build."""
+e8p12_rvq4.py:50-67, d4.py:128-139, hi.py:52-63), and the quantise-time nearest-codeword search
+`quantize` (e8p12.py:125-137, e8p12_rvq3.py:81-92, e8p12_rvq4.py:32-45, d4.py:116-123, hi.py:30-39):
+the 65 536-entry E8P12 search is a structured HIP kernel (csrc/quantize.hip), the 256 / 16-entry tables
+(E81B residual, D4, HI) are a small dense arg max like the reference's."""
 from fractions import Fraction
 
 import torch
@@ -14,7 +16,21 @@ class _Codebook(nn.Module):
     mm_threshold = 32  # fused mm kernel for M < threshold, else decompress + dense GEMM
 
     def quantize(self, X, return_idx=True):
-        raise NotImplementedError("quantise-time codebook search is outside the inference hot path")
+        raise NotImplementedError
+
+    @staticmethod
+    def _round_dense(X, grid, grid_norm=None):
+        """arg max_c 2 X . g_c - |g_c|^2 over a small table (the reference's round())"""
+        grid = grid.to(X.dtype)
+        gn = (grid * grid).sum(-1) if grid_norm is None else grid_norm.to(X.dtype)
+        idx = (2 * X @ grid.T - gn).argmax(-1)
+        return grid[idx], idx
+
+    def _round_e8p(self, X):
+        """nearest E8P12 codeword of every row of X (N, 8): (vals in X.dtype, idx int64)"""
+        assert X.shape[-1] == 8
+        vals, idx = torch.ops.quip_lib.e8p_quantize(X.detach().to(torch.float32).contiguous(), self.grid_packed_abs)
+        return vals.to(X.dtype), idx
 
     def maybe_pack_idxs(self, idxs):
         return idxs
@@ -42,6 +58,13 @@ class E8P12_codebook(_Codebook):
             g = torch.from_numpy(tables.e8p_full_grid().copy())
             self.register_buffer("grid", g, persistent=False)
             self.register_buffer("grid_norm", g.norm(dim=-1) ** 2, persistent=False)
+
+    def round(self, X, grid=None, grid_norm=None):
+        return self._round_e8p(X)
+
+    def quantize(self, X, return_idx=True):
+        vals, idx = self._round_e8p(X)
+        return (vals, idx) if return_idx else vals
 
     def decompress_weight(self, Qidxs):
         return torch.ops.quip_lib.decompress_e8p_origorder(Qidxs, self.grid_packed_abs)
@@ -91,6 +114,13 @@ class E8P12RVQ4B_codebook(_Codebook):
         self.opt_resid_scale = 1 / 3.45 if opt_resid_scale is None else opt_resid_scale
         self.register_buffer("grid_packed_abs", torch.from_numpy(tables.e8p_grid_packed_abs().copy()),
                              persistent=False)
+
+    def quantize(self, X, return_idx=True):
+        """two E8P12 stages: x ~ g_a + s * g_b, code = a << 16 | b (e8p12_rvq4.py:37-45)"""
+        init_vals, init_idxs = self._round_e8p(X)
+        resid_vals, resid_idxs = self._round_e8p((X - init_vals) / self.opt_resid_scale)
+        final = init_vals + resid_vals * self.opt_resid_scale
+        return (final, (init_idxs << 16) + resid_idxs) if return_idx else final
 
     def decompress_weight(self, Qidxs):
         return torch.ops.quip_lib.decompress_e8prvq4_origorder(Qidxs, self.grid_packed_abs,
@@ -143,6 +173,13 @@ class E8P12RVQ3B_codebook(_Codebook):
         self.register_buffer("e81b_grid_packed", torch.from_numpy(tables.e81b_grid_packed().copy()),
                              persistent=False)
 
+    def quantize(self, X, return_idx=True):
+        """E8P12 stage + 256-entry E81B residual: code = a << 8 | b (e8p12_rvq3.py:81-92)"""
+        init_vals, init_idxs = self._round_e8p(X)
+        resid_vals, resid_idxs = self._round_dense((X - init_vals) / self.opt_resid_scale, self.e81b_grid)
+        final = init_vals + resid_vals * self.opt_resid_scale
+        return (final, (init_idxs << 8) + resid_idxs) if return_idx else final
+
     def maybe_pack_idxs(self, idxs):
         """keep the low 3 bytes of every int32 index (e8p12_rvq3.py:102-107)"""
         b = idxs.contiguous().view(torch.int8).view(idxs.shape[0], idxs.shape[1], -1)
@@ -172,6 +209,11 @@ class D4_codebook(_Codebook):
         # the kernels need fp16 entries (8-byte rows); keep the buffer in fp16 so that
         # per-layer copies are valid whatever the caller casts
         self.register_buffer("grid", torch.from_numpy(tables.d4_grid().copy()).half(), persistent=False)
+
+    def quantize(self, X, return_idx=True):
+        assert X.shape[-1] == self.codesz
+        vals, idx = self._round_dense(X, self.grid.float())
+        return (vals, idx.to(self.idx_dtype)) if return_idx else vals
 
     def decompress_weight(self, Qidxs):
         return torch.ops.quip_lib.decompress_d4_origorder(Qidxs, self.grid)
@@ -240,6 +282,12 @@ class HI4B1C_codebook(_Codebook):
     def mm_planes_group(self, planes, Qidxs):
         return list(torch.ops.quip_lib.d4_gemv_planes_group(planes, [q.view(torch.uint8) for q in Qidxs],
                                                             self._virtual_grid(Qidxs[0].device)))
+
+    def quantize(self, X, return_idx=True):
+        assert X.shape[-1] == self.codesz
+        g = (torch.arange(-8, 8, device=X.device, dtype=X.dtype) + 0.5).unsqueeze(-1)
+        vals, idx = self._round_dense(X, g)
+        return (vals, idx.to(self.idx_dtype)) if return_idx else vals
 
     def maybe_pack_idxs(self, idxs):
         """nibble i <- column [0,2,4,6,1,3,5,7][i] of each 8-group (hi.py:41-50)"""

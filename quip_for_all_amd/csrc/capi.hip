@@ -141,6 +141,15 @@ int quip_had_transform_planes_rows(const quip_had_problem* problem, int64_t rows
   return group_had(problem, 1, true, rows, n, K, transpose, stream);
 }
 
+int quip_e8p_quantize_f32(const void* x, int64_t nvec, const void* grid_packed_abs, void* vals, void* idx,
+                          quip_stream_t stream) {
+  if (nvec < 0) return QUIP_ERR_BAD_SHAPE;
+  if (nvec == 0) return QUIP_OK;
+  if (!x || !grid_packed_abs || !vals || !idx) return QUIP_ERR_NULL_POINTER;
+  if (!aligned16(x) || !aligned16(vals) || (reinterpret_cast<uintptr_t>(idx) & 7) != 0) return QUIP_ERR_MISALIGNED;
+  return e8p_quantize_launch(x, nvec, grid_packed_abs, vals, idx, (hipStream_t)stream);
+}
+
 int32_t quip_e8p_gemv_max_rows(int32_t n, int32_t k) { return (n > 0 && k > 0) ? e8p_gemv_mfma_max_rows(n, k) : 0; }
 
 int quip_e8p_gemv_planes_rows(const void* planes, const void* qidxs, const void* grid_packed_abs, void* y,

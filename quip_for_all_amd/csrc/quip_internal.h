@@ -82,6 +82,9 @@ struct HadProblem {
 };
 int had_transform_group_launch(const HadProblem* problems, int count, bool planes, int64_t rows, int n, int K,
                                int transpose, hipStream_t stream);
+// quantise-time nearest E8P12 codeword (quantize.hip): x fp32 (nvec, 8) -> vals fp32 (nvec, 8), idx int64 (nvec)
+int e8p_quantize_launch(const void* x, int64_t nvec, const void* grid_packed_abs, void* vals, void* idx,
+                        hipStream_t stream);
 // rows mode: up to e8p_gemv_mfma_max_rows(n, k) <= 5 activation rows against one matrix in one pass
 int e8p_gemv_mfma_max_rows(int n, int k);
 int e8p_gemv_mfma_rows_launch(const void* planes, const void* qidxs, const void* grid, void* y, int mrows, int n,

@@ -108,9 +108,11 @@ class QuipQuantizer:
         return cls(**config_dict)                                                      # quantizer.py:150-163
 
     def quantize_model(self, *args, **kwargs):
-        raise NotImplementedError("Quantising a model (LDLQ rounding, Hessians, fine-tuning) is outside the scope of "
-                                  "the MI355X inference path; quantise with the reference and load the result with "
-                                  "load_quantized_model().")
+        raise NotImplementedError("The model-level calibration pipeline (dataset, per-block Hessians, fine-tuning; "
+                                  "quantizer.py:250-715) is outside the scope of the MI355X inference path: quantise "
+                                  "with the reference and load the result with load_quantized_model().  The "
+                                  "layer-level pieces are here: quip_for_all_amd.quip.QUIP (Hessian, incoherence "
+                                  "processing, LDLQ on the HIP codebook search) -> QuantLinear.pack().")
 
     def convert_model(self, model: nn.Module) -> nn.Module:
         """replace every linear layer inside the transformer blocks by an (empty) QuantLinear

@@ -53,6 +53,8 @@ _SCHEMAS = {
     "had_transform_planes_rows": "(Tensor x, int n, int K, Tensor? had, bool transpose, Tensor? pre, float scale, "
                                  "Tensor? rms_weight, float rms_eps, Tensor? gate) -> Tensor",
     "e8p_gemv_planes_rows": "(Tensor planes, Tensor Qidxs, Tensor grid) -> Tensor",
+    # quantise-time nearest E8P12 codeword: X (N, 8) fp32 -> (vals (N, 8) fp32, idx (N) int64)
+    "e8p_quantize": "(Tensor X, Tensor grid) -> (Tensor, Tensor)",
     # chain: output side of the producer module (z, its SV, residual) + input transforms of 1..3 consumers;
     # returns [h] + planes
     "had_chain_planes_group": "(Tensor z, Tensor z_post, Tensor? z_residual, float z_scale, int n, Tensor[] pre, "
@@ -249,6 +251,18 @@ def _had_transform_planes_rows_cuda(x, n, K, had, transpose, pre, scale, rms_wei
         capi.check(L.quip_had_transform_planes_rows(ctypes.byref(pr), rows, n, K, int(bool(transpose)), _stream(x)),
                    "quip_had_transform_planes_rows")
     return out
+
+
+def _e8p_quantize_cuda(X, grid):
+    _need(X.dim() == 2 and X.shape[1] == 8 and X.dtype == torch.float32 and X.is_contiguous(),
+          "e8p_quantize: X must be contiguous float32 (N, 8)")
+    g = _grid_i64(grid, X)
+    vals = torch.empty_like(X)
+    idx = torch.empty(X.shape[0], dtype=torch.int64, device=X.device)
+    with torch.cuda.device(X.device):
+        capi.check(capi.lib().quip_e8p_quantize_f32(X.data_ptr(), X.shape[0], g.data_ptr(), vals.data_ptr(),
+                                                    idx.data_ptr(), _stream(X)), "quip_e8p_quantize_f32")
+    return vals, idx
 
 
 def _e8p_gemv_planes_rows_cuda(planes, Qidxs, grid):
@@ -584,6 +598,7 @@ _IMPLS = {
     "e8p_mm_planes_rows": _e8p_mm_planes_rows_cuda,
     "had_transform_planes_rows": _had_transform_planes_rows_cuda,
     "e8p_gemv_planes_rows": _e8p_gemv_planes_rows_cuda,
+    "e8p_quantize": _e8p_quantize_cuda,
     "d4_gemv_planes": _d4_gemv_planes_cuda,
     "d4_gemv_planes_group": _d4_gemv_planes_group_cuda,
     "had_transform_fused": _had_transform_fused_cuda,
@@ -649,6 +664,7 @@ _reg_fake("had_transform_planes_rows", lambda x, n, K, had, transpose, pre, scal
           x.new_empty((x.shape[0], _planes_numel(n, 0.0)), dtype=torch.uint8))
 _reg_fake("e8p_gemv_planes_rows", lambda planes, Qidxs, grid:
           Qidxs.new_empty((planes.shape[0], Qidxs.shape[0]), dtype=torch.float16))
+_reg_fake("e8p_quantize", lambda X, grid: (torch.empty_like(X), X.new_empty((X.shape[0],), dtype=torch.int64)))
 _reg_fake("e8p_mm_planes_rows", lambda planes, Qidxs, grid:
           Qidxs.new_empty((len(planes), Qidxs.shape[0]), dtype=torch.float16))
 _reg_fake("e8p_gemv_planes_group", lambda planes, Qidxs, grid:
