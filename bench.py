@@ -86,8 +86,12 @@ def gemv_roofline(dec):
     per_launch_bytes = algo / launches
     per_launch_s = t / launches
     achieved = per_launch_bytes / per_launch_s / 1e9
+    # measured HBM bytes per GEMV launch: the committed PMC pass of THIS workload (tools/prof_bench.sh),
+    # one file per model; null when there is none for the model being run
     traffic = None
-    pf = os.path.join(REPO, "profiles", "gemv_hbm_traffic.json")
+    name = "gemv_hbm_traffic.json" if dec.s.hidden == 4096 and dec.s.layers == 32 else \
+        f"gemv_hbm_traffic_h{dec.s.hidden}_l{dec.s.layers}.json"
+    pf = os.path.join(REPO, "profiles", name)
     if os.path.exists(pf):
         try:
             traffic = json.load(open(pf)).get("hbm_bytes_per_launch")

@@ -11,7 +11,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 16 --warmup 4 --no-cpu-baseline $*"
 timeout 900 rocprofv3 --kernel-trace --stats -d $out/kt -o kt -- $CMD > $out/kt.log 2>&1
-tail -1 $out/kt.log | cut -c1-900 > $R/gpurun_out/${tag}_bench_line.json
+grep "^{\"metric\"" $out/kt.log | tail -1 | cut -c1-1400 > $R/gpurun_out/${tag}_bench_line.json
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/pmc -o pmc -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline "$@" > $out/pmc.log 2>&1
 python - <<PY
 import glob, sqlite3, json
