@@ -98,6 +98,10 @@ class E8P12_codebook(_Codebook):
     def mm_planes_group(self, planes, Qidxs):
         return list(torch.ops.quip_lib.e8p_gemv_planes_group(planes, Qidxs, self.grid_packed_abs))
 
+    def mm_planes_rows(self, planes, Qidxs):
+        """skinny product: planes (M, planes_bytes) -> (M, n), passes of up to 5 rows over the codes"""
+        return torch.ops.quip_lib.e8p_gemv_planes_rows(planes, Qidxs, self.grid_packed_abs)
+
 
 class E8P12RVQ4B_codebook(_Codebook):
     def __init__(self, inference=False, opt_resid_scale=None, **kwargs):
@@ -154,6 +158,9 @@ class E8P12RVQ4B_codebook(_Codebook):
     def mm_planes_group(self, planes, Qidxs):
         return list(torch.ops.quip_lib.e8p_gemv_planes_group(planes, [q.view(torch.int16) for q in Qidxs],
                                                              self.grid_packed_abs))
+
+    def mm_planes_rows(self, planes, Qidxs):
+        return torch.ops.quip_lib.e8p_gemv_planes_rows(planes, Qidxs.view(torch.int16), self.grid_packed_abs)
 
 
 class E8P12RVQ3B_codebook(_Codebook):

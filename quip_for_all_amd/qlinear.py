@@ -20,7 +20,7 @@ from .quant import get_hadK, matmul_hadU_cuda
 
 
 class QuantLinear(nn.Module):
-    # E8P12 forwards with 2 .. skinny_max_rows rows take the matrix-core rows-mode GEMV (passes of up to 5
+    # E8P12 / E8P12RVQ4B forwards with 2 .. skinny_max_rows rows take the matrix-core rows-mode GEMV (passes of up to 5
     # rows over the codes); more rows (< 32) the generic fused mm, >= 32 decompress + dense GEMM
     skinny_max_rows = int(os.environ.get("QUIP_SKINNY_MAX_ROWS", "31"))
 
@@ -107,17 +107,18 @@ class QuantLinear(nn.Module):
                 None if gate is None else gate.reshape(x.shape).to(torch.float16),
                 getattr(cb, "planes_resid_scale", 0.0))
             z = cb.mm_planes(planes, self.Qidxs)
-        elif (2 <= x.shape[0] <= self.skinny_max_rows and cb.id == "E8P12" and hasattr(cb, "mm_planes")
+        elif (2 <= x.shape[0] <= self.skinny_max_rows and hasattr(cb, "mm_planes_rows")
               and cb.planes_supported(self.q_out_features, self.q_in_features)):
-            # skinny GEMM on the matrix cores: every row gets its own digit planes (one transform launch);
-            # the GEMV's MFMA carries (row, plane) pairs in its 16 A rows, so up to 5 rows share ONE pass
-            # over the codes (more rows / longer k: several passes) -- exact integer arithmetic, every
-            # row bit identical to its bs=1 result
+            # skinny GEMM on the matrix cores (E8P12, E8P12RVQ4B): every row gets its own digit planes (one
+            # transform launch); the GEMV's MFMA carries (row, plane) pairs in its 16 A rows, so up to 5 rows
+            # share ONE pass over the codes (more rows / longer k: several passes) -- exact integer
+            # arithmetic, every row bit identical to its bs=1 result
             planes = torch.ops.quip_lib.had_transform_planes_rows(
                 x, self.q_in_features, self.K_left, self._had("had_left"), True, self._vec(self.SU),
                 self.wscale_float / math.sqrt(L_in), self._vec(rms_weight), rms_eps,
-                None if gate is None else gate.reshape(x.shape).to(torch.float16).contiguous())
-            z = torch.ops.quip_lib.e8p_gemv_planes_rows(planes, self.Qidxs, cb.grid_packed_abs)
+                None if gate is None else gate.reshape(x.shape).to(torch.float16).contiguous(),
+                getattr(cb, "planes_resid_scale", 0.0))
+            z = cb.mm_planes_rows(planes, self.Qidxs)
         else:
             xh = torch.ops.quip_lib.had_transform_fused(
                 x, self.q_in_features, self.q_in_features, self.K_left, self._had("had_left"), True,
@@ -249,7 +250,7 @@ def forward_group(layers, input, rms_weight=None, rms_eps=1e-5, residual=None):
     planes_ok = (same_in and x.shape[0] == 1 and hasattr(cb, "mm_planes")
                  and all(cb.planes_supported(l.q_out_features, l.q_in_features) for l in layers)
                  and cb.planes_group_supported([l.q_out_features for l in layers], l0.q_in_features))
-    skinny = (same_in and 2 <= x.shape[0] <= l0.skinny_max_rows and cb.id == "E8P12" and hasattr(cb, "mm_planes")
+    skinny = (same_in and 2 <= x.shape[0] <= l0.skinny_max_rows and hasattr(cb, "mm_planes_rows")
               and all(cb.planes_supported(l.q_out_features, l.q_in_features) for l in layers))
     if not same_in or skinny:   # skinny batches: every module takes its rows-mode path (planes per row)
         return [l.forward_fused(input, rms_weight=rms_weight, rms_eps=rms_eps, residual=r)

@@ -51,7 +51,7 @@ _SCHEMAS = {
     # skinny GEMM on the matrix cores: M rows -> (M, planes_bytes) plane images -> (M, n); the GEMV op splits
     # the rows into passes of quip_e8p_gemv_max_rows(n, k) (5 for k <= 4096) rows each
     "had_transform_planes_rows": "(Tensor x, int n, int K, Tensor? had, bool transpose, Tensor? pre, float scale, "
-                                 "Tensor? rms_weight, float rms_eps, Tensor? gate) -> Tensor",
+                                 "Tensor? rms_weight, float rms_eps, Tensor? gate, float resid_scale=0.0) -> Tensor",
     "e8p_gemv_planes_rows": "(Tensor planes, Tensor Qidxs, Tensor grid) -> Tensor",
     # quantise-time nearest E8P12 codeword: X (N, 8) fp32 -> (vals (N, 8) fp32, idx (N) int64)
     "e8p_quantize": "(Tensor X, Tensor grid) -> (Tensor, Tensor)",
@@ -236,16 +236,16 @@ def _d4_gemv_planes_group_cuda(planes, Qidxs, grid):
     return outs
 
 
-def _had_transform_planes_rows_cuda(x, n, K, had, transpose, pre, scale, rms_weight, rms_eps, gate):
+def _had_transform_planes_rows_cuda(x, n, K, had, transpose, pre, scale, rms_weight, rms_eps, gate, resid_scale=0.0):
     xc = _chk_x(x)
     _need(gate is None or (gate.shape == xc.shape and gate.dtype == torch.float16 and gate.is_contiguous()),
           "gate must be contiguous float16 with x's shape")
     L = capi.lib()
     rows = xc.shape[0]
-    out = torch.empty((rows, L.quip_e8p_planes_bytes(n)), dtype=torch.uint8, device=x.device)
+    out = torch.empty((rows, _planes_numel(n, resid_scale)), dtype=torch.uint8, device=x.device)
     pr = capi.HadProblem(xc.data_ptr(), out.data_ptr(), _vec_ok(had, x.device), _vec_ok(pre, x.device), None, None,
                          None, None, _vec_ok(rms_weight, x.device), _ptr(gate), xc.shape[1], n, float(scale),
-                         float(rms_eps), None, None, None, None, 1.0, 0.0, 0)
+                         float(rms_eps), None, None, None, None, 1.0, *_layout(resid_scale))
     import ctypes
     with torch.cuda.device(x.device):
         capi.check(L.quip_had_transform_planes_rows(ctypes.byref(pr), rows, n, K, int(bool(transpose)), _stream(x)),
@@ -660,8 +660,8 @@ _reg_fake("had_transform_group", lambda x, out_features, n, K, had, transpose, p
 _reg_fake("d4_gemv_planes", lambda planes, Qidxs, grid: Qidxs.new_empty((1, Qidxs.shape[0]), dtype=torch.float16))
 _reg_fake("d4_gemv_planes_group", lambda planes, Qidxs, grid:
           [q.new_empty((1, q.shape[0]), dtype=torch.float16) for q in Qidxs])
-_reg_fake("had_transform_planes_rows", lambda x, n, K, had, transpose, pre, scale, rms_weight, rms_eps, gate:
-          x.new_empty((x.shape[0], _planes_numel(n, 0.0)), dtype=torch.uint8))
+_reg_fake("had_transform_planes_rows", lambda x, n, K, had, transpose, pre, scale, rms_weight, rms_eps, gate,
+          resid_scale=0.0: x.new_empty((x.shape[0], _planes_numel(n, resid_scale)), dtype=torch.uint8))
 _reg_fake("e8p_gemv_planes_rows", lambda planes, Qidxs, grid:
           Qidxs.new_empty((planes.shape[0], Qidxs.shape[0]), dtype=torch.float16))
 _reg_fake("e8p_quantize", lambda X, grid: (torch.empty_like(X), X.new_empty((X.shape[0],), dtype=torch.int64)))

@@ -262,11 +262,11 @@ def test_forward_group_generic_codebooks_and_batches(cbid, fin, fouts, M):
                                         (4096, 4096, 5), (4096, 4096, 4), (4096, 11008, 5), (11008, 4096, 5),
                                         (4096, 4096, 13), (8192, 1024, 7), (8192, 8192, 3), (1024, 8192, 16),
                                         (256, 688, 5), (688, 256, 6), (4096, 28672, 2)])
-def test_skinny_rows_on_matrix_core_path(fin, fout, M):
+def test_skinny_rows_on_matrix_core_path(fin, fout, M, cbid="E8P12"):
     """2..16 rows go through per-row digit planes + the rows-mode GEMV ((row, plane) pairs in the MFMA's A
     rows: up to 5 rows per pass over the codes); each row must equal the bs=1 result of that row bit for
     bit (same integer arithmetic) and sit inside the oracle bound"""
-    P = O.make_layer("E8P12", fin, fout, seed=fin + fout + M)
+    P = O.make_layer(cbid, fin, fout, seed=fin + fout + M)
     layer = _layer(P)
     rng = np.random.default_rng(M + fin)
     x = rng.standard_normal((M, fin)).astype(np.float16)
@@ -279,3 +279,10 @@ def test_skinny_rows_on_matrix_core_path(fin, fout, M):
     What = O.qlinear_dense_weight(P)
     ref = O.qlinear_forward(P, x.astype(np.float64), "exact", What)
     assert np.all(np.abs(y.cpu().numpy().astype(np.float64) - ref) <= O.parity_bound(P, x.astype(np.float64), What))
+
+
+
+@pytest.mark.parametrize("fin,fout,M", [(4096, 4096, 2), (4096, 4096, 7), (256, 688, 3), (4096, 11008, 4)])
+def test_skinny_rows_rvq4_on_matrix_core_path(fin, fout, M):
+    """E8P12RVQ4B rows: the same rows-mode GEMV on the int16 view of the codes (virtual 2k-wide rows)"""
+    test_skinny_rows_on_matrix_core_path(fin, fout, M, cbid="E8P12RVQ4B")
