@@ -256,6 +256,18 @@ int quip_d4_gemv_planes_group(const void* const* planes, const void* const* qidx
                               void* const* ys, const int32_t* ns, int32_t count, int32_t k,
                               quip_stream_t stream);
 
+/* E8P12RVQ3B (3-byte codes: resid8 | e8p16 << 8, e8p12_rvq3.py:81-107) on the matrix-core GEMV.  The caller
+ * repacks the codes once (at load time) to int32 (main16 << 16 | resid8 << 8), shape (n, k/8): read as 16-bit
+ * codes that is an RVQ4-style row of 2k virtual weights (8-groups alternate residual / main) and
+ * W x = W' x' with x' = [s x_g | x_g]_g -- the planes of x' come from the Hadamard launch with
+ * quip_had_problem.resid_scale = s, exactly as for E8P12RVQ4B.  The low code of every pair indexes the E81B
+ * table instead of the E8P tables: e81b_i8 = int8 [256][8] = 4 * e81b_grid (natural column order, 8-byte
+ * aligned).  main + s * resid is summed exactly (the reference rounds it to fp16 per weight,
+ * origin_order.cu:287-335).  k = in features (the launch runs on 2k); 2k <= 25600 (count * 2k for groups). */
+int quip_e8prvq3_gemv_planes_group(const void* const* planes, const void* const* qidxs_repacked,
+                                   const void* grid_packed_abs, const void* e81b_i8, void* const* ys,
+                                   const int32_t* ns, int32_t count, int32_t k, quip_stream_t stream);
+
 /* ---- GEMV with the input side of the layer(s) computed in its prologue (bs = 1, K_left == 1) ----
  * For `count` (1..3) E8P12 modules reading the same activation of width k (a power of two,
  * 1024..8192, in_features == q_in_features == k):

@@ -187,6 +187,49 @@ class E8P12RVQ3B_codebook(_Codebook):
         final = init_vals + resid_vals * self.opt_resid_scale
         return (final, (init_idxs << 8) + resid_idxs) if return_idx else final
 
+    # bs=1 on the matrix-core GEMV: repacked once to int32 (main16 << 16 | resid8 << 8) the row is an RVQ4-style
+    # row of 2k virtual weights (8-groups alternate residual / main) whose LOW codes index the E81B table
+    # (csrc/e8p_gemv_mfma.hip, table modes 40 / 20); x' = [s * x_g | x_g]_g as for RVQ4.  The repacked copy
+    # (4 bytes per 8 weights next to the checkpoint's 3) is made on first use and kept per Qidxs buffer.
+    @property
+    def planes_resid_scale(self):
+        return float(torch.tensor(self.opt_resid_scale, dtype=torch.float16))
+
+    @staticmethod
+    def planes_supported(q_out, q_in):
+        return (2 * q_in) % 128 == 0 and 128 <= 2 * q_in <= 25600 and q_out >= 1
+
+    @staticmethod
+    def planes_group_supported(q_outs, q_in):
+        kp = (2 * q_in + 511) // 512 * 512
+        return 1 <= len(q_outs) <= 3 and len(q_outs) * kp <= 25600
+
+    def _e81b_i8(self, device):
+        t = getattr(self, "_e81b_i8_cache", None)
+        if t is None or t.device != device:
+            t = (self.e81b_grid.to(torch.float32) * 4).round().to(torch.int8).contiguous().to(device)
+            self._e81b_i8_cache = t
+        return t
+
+    def _repacked(self, Qidxs):
+        # one repacked copy per Qidxs buffer (a codebook object may serve many layers), refreshed when the
+        # buffer is written to
+        cache = self.__dict__.setdefault("_repack_cache", {})
+        key = (Qidxs.data_ptr(), tuple(Qidxs.shape))
+        hit = cache.get(key)
+        if hit is None or hit[0] != Qidxs._version:
+            b = Qidxs.contiguous().view(torch.uint8).view(Qidxs.shape[0], -1, 3).to(torch.int32)
+            hit = (Qidxs._version, ((b[..., 2] << 24) | (b[..., 1] << 16) | (b[..., 0] << 8)).contiguous())
+            cache[key] = hit
+        return hit[1]
+
+    def mm_planes(self, planes, Qidxs):
+        return self.mm_planes_group([planes], [Qidxs])[0]
+
+    def mm_planes_group(self, planes, Qidxs):
+        return list(torch.ops.quip_lib.e8prvq3_gemv_planes_group(
+            planes, [self._repacked(q) for q in Qidxs], self.grid_packed_abs, self._e81b_i8(Qidxs[0].device)))
+
     def maybe_pack_idxs(self, idxs):
         """keep the low 3 bytes of every int32 index (e8p12_rvq3.py:102-107)"""
         b = idxs.contiguous().view(torch.int8).view(idxs.shape[0], idxs.shape[1], -1)

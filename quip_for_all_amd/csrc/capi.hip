@@ -177,6 +177,28 @@ int quip_e8p_gemv_planes_group(const void* const* planes, const void* const* qid
                                     (hipStream_t)stream);
 }
 
+// E8P12RVQ3B on the matrix-core GEMV: codes repacked to (main16 << 16 | resid8 << 8), i.e. an RVQ4-style row of
+// 2k virtual weights whose low 16-bit codes index the E81B table (T3) instead of the E8P tables
+int quip_e8prvq3_gemv_planes_group(const void* const* planes, const void* const* qidxs_repacked,
+                                   const void* grid_packed_abs, const void* e81b_i8, void* const* ys,
+                                   const int32_t* ns, int32_t count, int32_t k, quip_stream_t stream) {
+  if (!planes || !qidxs_repacked || !grid_packed_abs || !e81b_i8 || !ys || !ns) return QUIP_ERR_NULL_POINTER;
+  if (count < 1 || count > QUIP_MAX_GROUP) return QUIP_ERR_BAD_SHAPE;
+  int n32[QUIP_MAX_GROUP];
+  for (int i = 0; i < count; ++i) {
+    if (!planes[i] || !qidxs_repacked[i] || !ys[i]) return QUIP_ERR_NULL_POINTER;
+    if (!aligned16(planes[i]) || !aligned16(qidxs_repacked[i])) return QUIP_ERR_MISALIGNED;
+    if (ns[i] < 1) return QUIP_ERR_BAD_SHAPE;
+    n32[i] = ns[i];
+  }
+  if (k < 1 || k % 8 != 0) return QUIP_ERR_BAD_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(e81b_i8) & 7) != 0) return QUIP_ERR_MISALIGNED;
+  GemvTune t;
+  t.rep = 40;
+  t.grid2 = e81b_i8;
+  return e8p_gemv_mfma_group_launch(planes, qidxs_repacked, grid_packed_abs, ys, n32, count, 2 * k, t, (hipStream_t)stream);
+}
+
 int quip_d4_gemv_planes(const void* planes, const void* qidxs, const void* grid_f16, void* y, int32_t n,
                         int32_t k, quip_stream_t stream) {
   if (!planes || !qidxs || !grid_f16 || !y) return QUIP_ERR_NULL_POINTER;

@@ -87,14 +87,20 @@ struct Lds {
   // REP = 32 / 16: both tables with that many copies; REP = 24: T1 x 32 (conflict free), T2 x 16
   // REP = 64: the D4 codebook -- ONE table of 256 x 4-byte entries (2w of the code's 4 weights as int8),
   //           64 copies (a private copy per lane: no conflicts), no sign table
+  // REP = 40 / 20: E8P12RVQ3B -- the E8P tables (32 / 16 copies of T1, 16 of T2) plus T3 = the 256 x 8-byte
+  //           E81B residual table (4r as int8; 16 / 8 copies), looked up by the LOW code of every dword
   static constexpr bool kD4 = REP == 64;
-  static constexpr int kRep1 = kD4 ? 64 : (REP == 16 ? 16 : 32);
+  static constexpr bool kRvq3 = REP == 40 || REP == 20;
+  static constexpr int kRep1 = kD4 ? 64 : ((REP == 16 || REP == 20) ? 16 : 32);
   static constexpr int kRep2 = REP == 32 ? 32 : 16;
+  static constexpr int kRep3 = REP == 40 ? 16 : (REP == 20 ? 8 : 0);
   static constexpr int kRow1 = kRep1 * (kD4 ? 4 : 8);   // bytes per T1 entry row
   static constexpr int kRow2 = kD4 ? 0 : kRep2 * 8;     // bytes per T2 entry row
+  static constexpr int kRow3 = kRep3 * 8;               // bytes per T3 entry row
   static constexpr int kT1 = 0;
   static constexpr int kT2 = 256 * kRow1;
-  static constexpr int kAcc = kT2 + 256 * kRow2;     // int32 [kMaxRowsPerBlock][4]
+  static constexpr int kT3 = kT2 + 256 * kRow2;
+  static constexpr int kAcc = kT3 + 256 * kRow3;     // int32 [kMaxRowsPerBlock][4]
   static constexpr int kX = kAcc + kMaxRowsPerBlock * 16;   // 3 planes x Kp bytes
   static constexpr int kMaxKp = (160 * 1024 - kX) / 3 / 512 * 512;
   static int bytes(int kp, int g = 1) { return kX + 3 * kp * g; }
@@ -102,6 +108,7 @@ struct Lds {
   static int bytes_fused(int kp, int g) { return kX + 3 * kp * g + (had::buf_floats(kp) + 16) * 4; }
 };
 static_assert(Lds<32>::kMaxKp >= 8192 && Lds<16>::kMaxKp >= 28672, "LDS budget");
+static_assert(Lds<40>::kMaxKp >= 8192 && Lds<20>::kMaxKp >= 22528, "LDS budget (RVQ3: 2 x 4096, 2 x 11008)");
 
 __device__ __forceinline__ uint2 lds_read8(uint32_t addr) {
   const u32x2 v = *reinterpret_cast<lds_u2_ptr>((uintptr_t)addr);
@@ -153,6 +160,22 @@ __device__ __forceinline__ const uint2* table_source_ptr(const uint64_t* grid, i
 __device__ __forceinline__ const uint2* table_source_ptr_d4(const uint64_t* grid, int lane, int wave) {
   return reinterpret_cast<const uint2*>(grid) + ((wave & 7) * 32 + (lane & 31));
 }
+// RVQ3: T3 row 32 w + (l & 31) from this lane's 8-byte E81B entry; lanes l and l + 32 share a row and
+// write the two halves of its copies
+template <int REP>
+__device__ __forceinline__ void fill_t3_from_lane(char* smem, const u32x2& src, int lane, int wave) {
+  using L = Lds<REP>;
+  if constexpr (L::kRvq3) {
+    const uint32_t rowbase = (uint32_t)L::kT3 + (uint32_t)(wave * 32 + (lane & 31)) * L::kRow3;
+    constexpr int half = L::kRep3 / 2;
+#pragma unroll
+    for (int c = 0; c < half; ++c) {
+      const uint32_t copy = (((uint32_t)(lane + c)) & (uint32_t)(half - 1)) + ((lane & 32) ? half : 0);
+      *reinterpret_cast<__attribute__((address_space(3))) u32x2*>((uintptr_t)(rowbase + copy * 8)) = src;
+    }
+  }
+}
+
 template <int REP>
 __device__ __forceinline__ void fill_tables_from_lane(char* smem, const u32x2& src, int lane, int wave) {
   using L = Lds<REP>;
@@ -196,7 +219,7 @@ struct ItemAddr { uint32_t a1l[8], a2l[8], a1h[8], a2h[8]; };
 
 template <int REP>
 __device__ __forceinline__ void item_addresses(const u32x4& q0, const u32x4& q1, uint32_t lane_c,
-                                               uint32_t lane_c2, ItemAddr& ad) {
+                                               uint32_t lane_c2, ItemAddr& ad, uint32_t lane_c3 = 0) {
   const uint32_t d[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
   if constexpr (REP == 64) {
     // D4: dword t = 4 one-byte codes = the 16 weights of MFMA step t; entry address =
@@ -212,7 +235,7 @@ __device__ __forceinline__ void item_addresses(const u32x4& q0, const u32x4& q1,
   }
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    if constexpr (REP != 16) {
+    if constexpr (Lds<REP>::kRep1 == 32) {
       // T1 (32 copies): table_base | idx << 8 | (lane & 31) << 3: byte aligned, one v_perm_b32
       ad.a1l[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c0c0500u);
       ad.a1h[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c0c0700u);
@@ -220,6 +243,11 @@ __device__ __forceinline__ void item_addresses(const u32x4& q0, const u32x4& q1,
       // 16 copies: table_base | idx << 7 | (lane & 15) << 3: shift + v_and_or_b32
       ad.a1l[t] = ((d[t] >> 1) & 0x7f80u) | lane_c;
       ad.a1h[t] = ((d[t] >> 17) & 0x7f80u) | lane_c;
+    }
+    if constexpr (Lds<REP>::kRvq3) {
+      // RVQ3: the low code of the dword is (residual index << 8 | 0) and reads T3 (E81B); its sign byte is 0
+      // and T2[0] == 0, so the generic "T1 ^ T2" below leaves the T3 entry unchanged
+      ad.a1l[t] = Lds<REP>::kRep3 == 16 ? (((d[t] >> 1) & 0x7f80u) | lane_c3) : (((d[t] >> 2) & 0x3fc0u) | lane_c3);
     }
     if constexpr (REP == 32) {
       // T2 base 0x10000 comes from byte 2 of lane_c
@@ -312,6 +340,7 @@ struct GemvGroup {
   int rpb[G];
   int boff[G];   // workgroup b serves row range ((b - boff) mod gridDim.x) of the problem: problems that need
                  // fewer workgroups than the launch has start at different workgroups (70B k / v next to q)
+  const void* grid2;   // RVQ3 table modes (REP 40 / 20): the E81B residual table, 256 x 8 int8 (4r); else unused
 };
 
 // Input side of the GEMV computed in the prologue instead of by separate launches (bs = 1 decode,
@@ -350,6 +379,7 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
     GemvGroup<G> gp, FusedIn fi, const uint64_t* __restrict__ grid, int K, int Kp, uint64_t* __restrict__ dbg,
     int mrows) {
   static_assert(!ROWS || (G == 1 && !FUSED), "rows mode: one matrix, planes from memory");
+  static_assert(!Lds<REP>::kRvq3 || !FUSED, "RVQ3 tables: planes from memory");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using L = Lds<REP>;
 #define QUIP_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -435,6 +465,12 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
                : "=v"(tsrc)
                : "v"(L::kD4 ? table_source_ptr_d4(grid, lane, wave) : table_source_ptr(grid, lane, wave))
                : "memory");
+  u32x2 tsrc3;  // RVQ3: this lane's E81B entry, the second load of the kernel (any later wait covers it)
+  if constexpr (L::kRvq3)
+    asm volatile("global_load_dwordx2 %0, %1, off"
+                 : "=v"(tsrc3)
+                 : "v"(reinterpret_cast<const uint2*>(gp.grid2) + ((wave & 7) * 32 + (lane & 31)))
+                 : "memory");
   constexpr int XR = 6;  // 16-byte x pieces per thread: needs nthreads >= G * 3 * Kp / 96
   const int ppieces = 3 * (Kp >> 4);       // pieces per problem (rows mode: per activation row)
   const int xpieces = (ROWS ? mrows : G) * ppieces;
@@ -512,6 +548,10 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
   for (int i = tid; i < kMaxRowsPerBlock * 4; i += nthreads) reinterpret_cast<int*>(smem + L::kAcc)[i] = 0;
   asm volatile("s_waitcnt vmcnt(%1)" : "+v"(tsrc) : "n"((FUSED ? 2 * (4 + G) : XR) + 2 * kDepth) : "memory");
   if (wave < 8) fill_tables_from_lane<REP>(smem, tsrc, lane, wave);
+  if constexpr (L::kRvq3) {
+    asm volatile("" : "+v"(tsrc3));
+    if (wave < 8) fill_t3_from_lane<REP>(smem, tsrc3, lane, wave);
+  }
   int sh[ROWS ? 5 : G];
   if constexpr (ROWS) {
 #pragma unroll
@@ -613,9 +653,10 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
   QUIP_STAMP(3);
 
   const uint32_t lane_c = L::kD4 ? ((uint32_t)lane << 2)
-                          : (REP != 16) ? (((uint32_t)(lane & 31) << 3) | 0x00010000u)
-                                        : (((uint32_t)(lane & 15) << 3) | (uint32_t)L::kT1);
+                          : (L::kRep1 == 32) ? (((uint32_t)(lane & 31) << 3) | 0x00010000u)
+                                             : (((uint32_t)(lane & 15) << 3) | (uint32_t)L::kT1);
   const uint32_t lane_c2 = ((uint32_t)(lane & 15) << 3) | (uint32_t)L::kT2;
+  const uint32_t lane_c3 = L::kRvq3 ? ((((uint32_t)lane & (uint32_t)(L::kRep3 - 1)) << 3) | (uint32_t)L::kT3) : 0u;
   int* accs = reinterpret_cast<int*>(smem + L::kAcc);
   // A fragment address of this lane: plane (lane & 15) clamped to a valid plane (rows >= 3
   // of A are don't-care), k = slice*512 + (t < 4 ? 0 : 256) + q*64 + (t & 3)*16
@@ -683,9 +724,9 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
         if (kR8) {
           u32x4 da, db;
           redistribute_r8(qa[i], qb[i], lane, da, db);
-          item_addresses<REP>(da, db, lane_c, lane_c2, ad);
+          item_addresses<REP>(da, db, lane_c, lane_c2, ad, lane_c3);
         } else {
-          item_addresses<REP>(qa[i], qb[i], lane_c, lane_c2, ad);
+          item_addresses<REP>(qa[i], qb[i], lane_c, lane_c2, ad, lane_c3);
         }
         run_item(cur, ad);
       }
@@ -703,7 +744,7 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
       nxt = __builtin_amdgcn_readfirstlane(nxt) + nwaves;
       asm_wait_vmcnt<0>(qa[0], qb[0]);
       ItemAddr ad;
-      item_addresses<REP>(qa[0], qb[0], lane_c, lane_c2, ad);
+      item_addresses<REP>(qa[0], qb[0], lane_c, lane_c2, ad, lane_c3);
 #pragma unroll
       for (int t = 0; t < 8; ++t)
         asm volatile("" : "+v"(ad.a1l[t]), "+v"(ad.a2l[t]), "+v"(ad.a1h[t]), "+v"(ad.a2h[t]));
@@ -725,9 +766,9 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
         if (kR8) {
           u32x4 da, db;
           redistribute_r8(qa[i], qb[i], lane, da, db);
-          item_addresses<REP>(da, db, lane_c, lane_c2, ad);
+          item_addresses<REP>(da, db, lane_c, lane_c2, ad, lane_c3);
         } else {
-          item_addresses<REP>(qa[i], qb[i], lane_c, lane_c2, ad);
+          item_addresses<REP>(qa[i], qb[i], lane_c, lane_c2, ad, lane_c3);
         }
         // the slot's codes are consumed: pin the addresses, then reload the slot in place
 #pragma unroll
@@ -1026,6 +1067,8 @@ static int launch_oneshot(const GemvGroup<G>& gp, const void* grid, int k, int k
   QUIP_ONE_BIG(32, 1) QUIP_ONE_BIG(32, 2) QUIP_ONE_BIG(32, 3) QUIP_ONE_BIG(32, 4)
   QUIP_ONE_BIG(24, 1) QUIP_ONE_BIG(24, 2) QUIP_ONE_BIG(24, 3) QUIP_ONE_BIG(24, 4)
   QUIP_ONE_BIG(16, 1) QUIP_ONE_BIG(16, 2) QUIP_ONE_BIG(16, 3) QUIP_ONE_BIG(16, 4)
+  QUIP_ONE_BIG(40, 1) QUIP_ONE_BIG(40, 2) QUIP_ONE_BIG(40, 3) QUIP_ONE_BIG(40, 4)
+  QUIP_ONE_BIG(20, 1) QUIP_ONE_BIG(20, 2) QUIP_ONE_BIG(20, 3) QUIP_ONE_BIG(20, 4)
 #undef QUIP_ONE_BIG
   if (threads > 512) return QUIP_ERR_UNSUPPORTED;
 #define QUIP_ONE(R, S)                                                              \
@@ -1035,6 +1078,8 @@ static int launch_oneshot(const GemvGroup<G>& gp, const void* grid, int k, int k
   QUIP_ONE(24, 1) QUIP_ONE(24, 2) QUIP_ONE(24, 3) QUIP_ONE(24, 4) QUIP_ONE(24, 6) QUIP_ONE(24, 8)
   QUIP_ONE(16, 1) QUIP_ONE(16, 2) QUIP_ONE(16, 3) QUIP_ONE(16, 4) QUIP_ONE(16, 6) QUIP_ONE(16, 8)
   QUIP_ONE(64, 1) QUIP_ONE(64, 2) QUIP_ONE(64, 3) QUIP_ONE(64, 4) QUIP_ONE(64, 6) QUIP_ONE(64, 8)
+  QUIP_ONE(40, 1) QUIP_ONE(40, 2) QUIP_ONE(40, 3) QUIP_ONE(40, 4) QUIP_ONE(40, 6) QUIP_ONE(40, 8)
+  QUIP_ONE(20, 1) QUIP_ONE(20, 2) QUIP_ONE(20, 3) QUIP_ONE(20, 4) QUIP_ONE(20, 6) QUIP_ONE(20, 8)
 #undef QUIP_ONE
   return QUIP_ERR_UNSUPPORTED;
 }
@@ -1043,6 +1088,7 @@ static int launch_oneshot(const GemvGroup<G>& gp, const void* grid, int k, int k
 // T1 x 32 + T2 x 16, then 16 / 16
 static int pick_rep(int g, int kp, int forced) {
   if (forced == 64) return 64;   // D4
+  if (forced == 40) return g * kp <= Lds<40>::kMaxKp ? 40 : 20;   // E8P12RVQ3B
   if (forced == 16 || g * kp > Lds<24>::kMaxKp) return 16;
   if (forced == 24 || g * kp > Lds<32>::kMaxKp) return 24;
   return 32;
@@ -1076,7 +1122,9 @@ int e8p_gemv_mfma_launch(const void* planes, const void* qidxs, const void* grid
   if (threads > 512 && slots > 2) slots = 2;  // 128-VGPR budget: deeper queues would spill, and
                                               // scratch traffic would corrupt the counted vmcnt waits
   GemvGroup<1> gp{{reinterpret_cast<const uint4*>(qidxs)}, {reinterpret_cast<const uint8_t*>(planes)},
-                  {reinterpret_cast<f16*>(y)}, {n}, {rpb}, {0}};
+                  {reinterpret_cast<f16*>(y)}, {n}, {rpb}, {0}, tune.grid2};
+  if ((rep == 40 || rep == 20) && !tune.grid2) return QUIP_ERR_NULL_POINTER;
+  if (rep == 20 && kp > Lds<20>::kMaxKp) return QUIP_ERR_UNSUPPORTED;
   if (!tune.rows && ((threads <= 512 && items_per_wave <= 8) || (threads > 512 && rep != 64 && items_per_wave <= 4)))
     return launch_oneshot<1>(gp, grid, k, kp, nblocks, threads, rep, items_per_wave, dbg, stream);
 #define QUIP_CASE(R, S)                                                                        \
@@ -1092,6 +1140,8 @@ int e8p_gemv_mfma_launch(const void* planes, const void* qidxs, const void* grid
   QUIP_CASE_BIG(24, 1) QUIP_CASE_BIG(24, 2)
   QUIP_CASE_BIG(16, 1) QUIP_CASE_BIG(16, 2)
   QUIP_CASE(64, 1) QUIP_CASE(64, 2) QUIP_CASE_BIG(64, 1) QUIP_CASE_BIG(64, 2)
+  QUIP_CASE(40, 1) QUIP_CASE(40, 2) QUIP_CASE_BIG(40, 1) QUIP_CASE_BIG(40, 2)
+  QUIP_CASE(20, 1) QUIP_CASE(20, 2) QUIP_CASE_BIG(20, 1) QUIP_CASE_BIG(20, 2)
 #undef QUIP_CASE
 #undef QUIP_CASE_BIG
   return QUIP_ERR_UNSUPPORTED;
@@ -1160,6 +1210,7 @@ static int group_launch(const void* const* planes, const void* const* qidxs, con
   const int ncu = device_cu_count();
   int nblocks = tune.blocks > 0 ? tune.blocks : ncu;
   GemvGroup<G> gp;
+  gp.grid2 = tune.grid2;
   int total_rpb = 0;
   for (;;) {
     total_rpb = 0;
@@ -1201,6 +1252,8 @@ static int group_launch(const void* const* planes, const void* const* qidxs, con
   if (waves < min_waves) waves = min_waves;
   if (waves > 16) return QUIP_ERR_UNSUPPORTED;
   const int rep = pick_rep(G, kp, tune.rep);
+  if ((rep == 40 || rep == 20) && !tune.grid2) return QUIP_ERR_NULL_POINTER;
+  if (rep == 20 && G * kp > Lds<20>::kMaxKp) return QUIP_ERR_UNSUPPORTED;
   const int slots = tune.rows ? (tune.rows >= 2 ? 2 : 1) : ((items + waves - 1) / waves >= 4 ? 2 : 1);
   const int threads = waves * 64;
   uint64_t* dbg = reinterpret_cast<uint64_t*>(tune.dbg);
@@ -1212,7 +1265,7 @@ static int group_launch(const void* const* planes, const void* const* qidxs, con
     return threads > 512 ? launch<R, S, 1024, G>(gp, grid, k, kp, nblocks, threads, dbg, stream) \
                          : launch<R, S, 512, G>(gp, grid, k, kp, nblocks, threads, dbg, stream);
   QUIP_CASE(32, 1) QUIP_CASE(32, 2) QUIP_CASE(24, 1) QUIP_CASE(24, 2) QUIP_CASE(16, 1) QUIP_CASE(16, 2)
-  QUIP_CASE(64, 1) QUIP_CASE(64, 2)
+  QUIP_CASE(64, 1) QUIP_CASE(64, 2) QUIP_CASE(40, 1) QUIP_CASE(40, 2) QUIP_CASE(20, 1) QUIP_CASE(20, 2)
 #undef QUIP_CASE
   return QUIP_ERR_UNSUPPORTED;
 }
@@ -1233,6 +1286,7 @@ static int fused_launch(const GemvFusedIn& in, const void* const* qidxs, const v
   const int ncu = device_cu_count();
   int nblocks = tune.blocks > 0 ? tune.blocks : ncu;
   GemvGroup<G> gp;
+  gp.grid2 = nullptr;
   for (;;) {
     int total_rpb = 0;
     for (int p = 0; p < G; ++p) {

@@ -18,6 +18,7 @@ struct GemvTune {
   int waves_g = 0;    // row-groups per workgroup (waves = waves_g * J)
   int max_waves = 0;  // cap on waves per workgroup (default 16)
   int digits = 0;     // i8 kernel: int8 digit planes of x, 2 or 3 (default 3)
+  const void* grid2 = nullptr;   // matrix-core GEMV, rep == 40 (E8P12RVQ3B): the E81B table, 256 x 8 int8 (4r)
   void* dbg = nullptr;  // i8 kernel: device buffer of 8 x uint64 s_memtime stamps per workgroup
 };
 int stream_probe_launch(const void* qidxs, void* out, int n, int k, const GemvTune& tune,

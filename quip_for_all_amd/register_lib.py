@@ -44,6 +44,8 @@ _SCHEMAS = {
                                   "float[] scale, Tensor? rms_weight, float rms_eps, Tensor? gate, "
                                   "float resid_scale=0.0) -> Tensor[]",
     "e8p_gemv_planes_group": "(Tensor[] planes, Tensor[] Qidxs, Tensor grid) -> Tensor[]",
+    # E8P12RVQ3B on the matrix-core GEMV: Qidxs repacked to int32 (main16 << 16 | resid8 << 8), e81b_i8 = int8 (256, 8)
+    "e8prvq3_gemv_planes_group": "(Tensor[] planes, Tensor[] Qidxs, Tensor grid, Tensor e81b_i8) -> Tensor[]",
     "d4_gemv_planes": "(Tensor planes, Tensor Qidxs, Tensor grid) -> Tensor",
     "d4_gemv_planes_group": "(Tensor[] planes, Tensor[] Qidxs, Tensor grid) -> Tensor[]",
     # 2..3 activation rows against ONE weight matrix: the grouped GEMV with the same codes for every row
@@ -214,6 +216,29 @@ def _d4_gemv_planes_cuda(planes, Qidxs, grid):
         capi.check(capi.lib().quip_d4_gemv_planes(planes.data_ptr(), Qidxs.data_ptr(), _d4_grid(grid).data_ptr(),
                                                   y.data_ptr(), n, k, _stream(Qidxs)), "quip_d4_gemv_planes")
     return y
+
+
+def _e8prvq3_gemv_planes_group_cuda(planes, Qidxs, grid, e81b_i8):
+    import ctypes
+    count = len(planes)
+    _need(1 <= count <= capi.MAX_GROUP and len(Qidxs) == count, "group of 1..3 problems")
+    k = Qidxs[0].shape[1] * 8
+    dev = planes[0].device
+    for pl, q in zip(planes, Qidxs):
+        _need(q.dtype == torch.int32 and q.is_contiguous() and q.shape[1] * 8 == k and q.device == dev,
+              "Qidxs must be the repacked contiguous int32 (n, k/8) codes with a common k")
+        _need(pl.dtype == torch.uint8 and pl.is_contiguous() and pl.device == dev, "planes must be uint8")
+    _need(e81b_i8.dtype == torch.int8 and tuple(e81b_i8.shape) == (256, 8) and e81b_i8.is_contiguous()
+          and e81b_i8.device == dev, "e81b_i8 must be the contiguous int8 (256, 8) table")
+    g = _grid_i64(grid, planes[0])
+    outs = [torch.empty((1, q.shape[0]), dtype=torch.float16, device=dev) for q in Qidxs]
+    vp = ctypes.c_void_p * count
+    ns = (ctypes.c_int32 * count)(*[q.shape[0] for q in Qidxs])
+    with torch.cuda.device(dev):
+        capi.check(capi.lib().quip_e8prvq3_gemv_planes_group(
+            vp(*[p.data_ptr() for p in planes]), vp(*[q.data_ptr() for q in Qidxs]), g.data_ptr(), e81b_i8.data_ptr(),
+            vp(*[o.data_ptr() for o in outs]), ns, count, k, _stream(planes[0])), "quip_e8prvq3_gemv_planes_group")
+    return outs
 
 
 def _d4_gemv_planes_group_cuda(planes, Qidxs, grid):
@@ -599,6 +624,7 @@ _IMPLS = {
     "had_transform_planes_rows": _had_transform_planes_rows_cuda,
     "e8p_gemv_planes_rows": _e8p_gemv_planes_rows_cuda,
     "e8p_quantize": _e8p_quantize_cuda,
+    "e8prvq3_gemv_planes_group": _e8prvq3_gemv_planes_group_cuda,
     "d4_gemv_planes": _d4_gemv_planes_cuda,
     "d4_gemv_planes_group": _d4_gemv_planes_group_cuda,
     "had_transform_fused": _had_transform_fused_cuda,
@@ -657,6 +683,8 @@ _reg_fake("had_chain_planes_group", lambda z, z_post, z_residual, z_scale, n, pr
 _reg_fake("had_transform_group", lambda x, out_features, n, K, had, transpose, pre2, post, bias, scale, residual, pre,
           rms_weight, rms_eps:
           [t.new_empty((t.shape[0], int(o))) for t, o in zip(x, out_features)])
+_reg_fake("e8prvq3_gemv_planes_group", lambda planes, Qidxs, grid, e81b_i8:
+          [q.new_empty((1, q.shape[0]), dtype=torch.float16) for q in Qidxs])
 _reg_fake("d4_gemv_planes", lambda planes, Qidxs, grid: Qidxs.new_empty((1, Qidxs.shape[0]), dtype=torch.float16))
 _reg_fake("d4_gemv_planes_group", lambda planes, Qidxs, grid:
           [q.new_empty((1, q.shape[0]), dtype=torch.float16) for q in Qidxs])

@@ -130,7 +130,9 @@ def test_full_size_70b_rows_via_properties():
 @pytest.mark.parametrize("cbid,fin,fout", [("E8P12", 4096, 4096), ("E8P12", 1408, 512), ("D4", 1024, 1024),
                                            ("E8P12", 4096, 11008), ("E8P12", 11008, 4096),
                                            ("E8P12RVQ4B", 4096, 11008), ("E8P12RVQ4B", 11008, 4096),
-                                           ("D4", 11008, 4096), ("HI", 4096, 4096), ("HI", 11008, 4096)])
+                                           ("D4", 11008, 4096), ("HI", 4096, 4096), ("HI", 11008, 4096),
+                                           ("E8P12RVQ3B", 4096, 4096), ("E8P12RVQ3B", 4096, 11008),
+                                           ("E8P12RVQ3B", 11008, 4096), ("E8P12RVQ3B", 256, 688)])
 @pytest.mark.parametrize("M", [1, 3])
 def test_forward_fused_glue(cbid, fin, fout, M):
     """RMSNorm / SiLU*mul / residual folded into the Hadamard launches == doing them separately"""
@@ -286,3 +288,28 @@ def test_skinny_rows_on_matrix_core_path(fin, fout, M, cbid="E8P12"):
 def test_skinny_rows_rvq4_on_matrix_core_path(fin, fout, M):
     """E8P12RVQ4B rows: the same rows-mode GEMV on the int16 view of the codes (virtual 2k-wide rows)"""
     test_skinny_rows_on_matrix_core_path(fin, fout, M, cbid="E8P12RVQ4B")
+
+
+@pytest.mark.parametrize("fin,fouts", [(4096, (4096, 4096, 4096)), (4096, (11008, 11008)), (256, (256, 688))])
+def test_rvq3_grouped_planes_path_equals_single_calls(fin, fouts):
+    """E8P12RVQ3B bs=1: grouped launches on the matrix-core GEMV (repacked codes + E81B table mode) give
+    exactly what the modules give one by one, and the repacked copy follows an in-place update of Qidxs"""
+    from quip_for_all_amd.qlinear import forward_group
+    layers = [_layer(O.make_layer("E8P12RVQ3B", fin, fo, seed=fin + fo + i)) for i, fo in enumerate(fouts)]
+    assert all(l.codebook.planes_supported(l.q_out_features, l.q_in_features) for l in layers)
+    rng = np.random.default_rng(fin)
+    x = torch.from_numpy(rng.standard_normal((1, fin)).astype(np.float16)).to(DEV)
+    with torch.no_grad():
+        single = [l(x) for l in layers]
+        group = forward_group(layers, x)
+        for a, b in zip(single, group):
+            assert torch.equal(a, b)
+        l0 = layers[0]
+        l0.Qidxs.copy_(layers[1].Qidxs[:l0.Qidxs.shape[0]] if layers[1].Qidxs.shape == l0.Qidxs.shape else l0.Qidxs.flip(0))
+        y_new = l0(x)
+        l0.train()
+        y_dense = l0(x)          # training branch: x @ calc_weight() from the CURRENT codes
+        l0.eval()
+    assert not torch.equal(y_new, single[0])
+    tol = 6 * 2.0 ** -11 * (y_dense.float().abs() + 4 * y_dense.float().pow(2).mean().sqrt()) + 1e-3
+    assert torch.all((y_new.float() - y_dense.float()).abs() <= tol)
