@@ -496,6 +496,172 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
   HSTAMP(6);
 }
 
+// Tall transform for BATCHES (prefill: thousands of token rows), fp16 output.  had_fast_kernel<*, TALL> is shaped
+// for latency: three workgroups per row, each staging the whole row.  Here ONE workgroup owns a whole row at a
+// time and walks over many rows (grid.x < rows): the row is staged once, in the padded [k][j] layout the
+// transform's shuffle buffer uses anyway; wave ct runs the K-mix of column tile ct for all (<= 3) row tiles
+// with the H fragments held in registers across rows (one B read feeds three MFMAs) and writes the result over
+// its own input columns; then the length-L transform and the epilogue run on 3 L threads.  The per-tile MFMA
+// sequence, the butterflies and the element-wise operations are those of had_fast_kernel, so the results are
+// bit identical to it.  512 threads (128 VGPRs) and 48 (L + L / 32) floats of LDS (50.7 KB at L = 256): two
+// workgroups per CU, one in its K-mix while the other loads / transforms / stores (H sits in LDS, 9 KB more).  The 48 rows are
+// transformed in two halves of 24 (3 L / 2 threads each).
+// Requires 64 <= L <= 256, K <= 48, vector access, no RMSNorm statistic (host-checked).
+__global__ __launch_bounds__(512, 4) void had_tall_batch_kernel(HadGroup grp, int rows) {
+  const HadArgs a = grp.p[blockIdx.z];
+  extern __shared__ __attribute__((aligned(16))) float buf[];
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int L = a.L, K = a.K, logL = a.logL;
+  const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+  const int ctiles = L >> 4, ksteps = (K + 3) >> 2;
+  // H as the MFMA's A operand, A[row kq][k] at hs[k * 48 + kq], zero outside (K, K); staged once per workgroup
+  // (registers would hold it across rows too, but 36 more VGPRs cost the second resident workgroup)
+  float* hs = buf + had::buf_floats(48 * L);
+  for (int i = tid; i < 48 * 48; i += nt) {
+    const int k = i / 48, kq = i - k * 48;
+    hs[i] = (kq < K && k < K) ? (float)(a.transpose ? a.had[k * K + kq] : a.had[kq * K + k]) : 0.f;
+  }
+  const int fht_threads = (3 * L) >> 1;            // 24 rows x L / 16 per half
+  const bool fact = tid < fht_threads;
+  const int half_elems = 24 * L, half_floats = half_elems + (half_elems >> 5);   // 24 L is a multiple of 32
+  const int j0 = (tid * 16) & (L - 1);
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const f16* xr = a.x + (int64_t)row * a.in_features;
+    const f16* gr = a.gate ? a.gate + (int64_t)row * a.in_features : nullptr;
+    // (1) the pre-processed row, [k][j] in the padded layout
+#pragma unroll 1
+    for (int c = tid; c * 16 < a.n; c += nt) {
+      Raw16 raw;
+      raw_load16(a, xr, gr, c * 16, raw);
+      float e[16];
+      float ss = 0.f;
+      raw_math16(a, c * 16, raw, e, ss);
+      float* dst = buf + c * 16 + ((c * 16) >> 5);   // 16 elements inside one 32-block: constant pad offset
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[r] = e[r];
+    }
+    __syncthreads();
+    // (2) K-mix on the matrix cores, in place per column tile
+    for (int ct = wave; ct < ctiles; ct += (nt >> 6)) {
+      f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      const int col = ct * 16 + lr;
+#pragma unroll 2
+      for (int ks = 0; ks < ksteps; ++ks) {
+        {
+          const int k = min(4 * ks + lq, K - 1);
+          const float bv = buf[pad((k << logL) + col)];
+#pragma unroll
+          for (int rt = 0; rt < 3; ++rt)
+            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hs[(4 * ks + lq) * 48 + rt * 16 + lr], bv, acc[rt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) buf[pad(((rt * 16 + 4 * lq + i) << logL) + col)] = acc[rt][i];
+    }
+    __syncthreads();
+    // (3) + (4): length-L transform of the 48 rows (rows >= K are zero) and the epilogue, 24 rows at a time
+    for (int half = 0; half < 2; ++half) {
+      float* hb = buf + half * half_floats;
+      const int kp = half * 24 + ((tid * 16) >> logL);
+      f16* yr = a.y + (int64_t)row * a.out_features;
+      const f16* rr = a.residual ? a.residual + (int64_t)row * a.out_features : nullptr;
+      const int idx0 = kp * L + j0;
+      const bool whole = fact && kp < K && idx0 + 16 <= a.out_features;
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = fact ? hb[pad(tid * 16 + r)] : 0.f;
+      if (logL == 8) had::fht16_fixed<8, false>(v, hb, 0, tid, fact);          // only the three tall lengths
+      else if (logL == 7) had::fht16_fixed<7, false>(v, hb, 0, tid, fact);
+      else had::fht16_fixed<6, false>(v, hb, 0, tid, fact);
+      if (fact && kp < K) {
+        if (whole) {
+          // packed vectors requested together, unpacked eight at a time (register budget: 128)
+          uint4 qpost[2], qbias[2], qres[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            if (a.post) qpost[h] = ldp(a.post + idx0 + 8 * h);
+            if (a.bias) qbias[h] = ldp(a.bias + idx0 + 8 * h);
+            if (rr) qres[h] = ldp(rr + idx0 + 8 * h);
+          }
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float tp[8], tb[8], tr[8];
+            if (a.post) had::unpack8(qpost[h], tp);
+            if (a.bias) had::unpack8(qbias[h], tb);
+            if (rr) had::unpack8(qres[h], tr);
+            f16 o[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+              o[r] = had::out_elem(v[8 * h + r], a.scale, a.post != nullptr, a.post ? tp[r] : 0.f, a.bias != nullptr,
+                                   a.bias ? tb[r] : 0.f, rr != nullptr, rr ? tr[r] : 0.f);
+            reinterpret_cast<uint4*>(yr + idx0)[h] = *reinterpret_cast<uint4*>(&o[0]);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int idx = idx0 + r;
+            if (idx < a.out_features)
+              yr[idx] = had::out_elem(v[r], a.scale, a.post != nullptr, a.post ? (float)a.post[idx] : 0.f,
+                                      a.bias != nullptr, a.bias ? (float)a.bias[idx] : 0.f, rr != nullptr,
+                                      rr ? (float)rr[idx] : 0.f);
+          }
+        }
+      }
+    }
+    __syncthreads();   // the buffer is restaged for the next row
+  }
+}
+
+// K == 1 transform for BATCHES (prefill), fp16 output, L = 2^LOGL in {1024, 2048, 4096}: the same arithmetic as
+// had_fast_kernel<false, false, 256, true> without its decode-only paths (chain, planes, RMSNorm statistic), so
+// that it fits 64 VGPRs: eight row-workgroups resident per CU instead of four -- a batch of rows is bound by the
+// bytes in flight, not by the latency of one row.
+template <int LOGL>
+__global__ __launch_bounds__(256, 8) void had_kone_batch_kernel(HadGroup grp) {
+  const HadArgs a = grp.p[blockIdx.z];
+  extern __shared__ __attribute__((aligned(16))) float buf[];
+  constexpr int L = 1 << LOGL;
+  const int tid = threadIdx.x;
+  const int64_t row = blockIdx.y;
+  const f16* xr = a.x + row * a.in_features;
+  const f16* gr = a.gate ? a.gate + row * a.in_features : nullptr;
+  const int j0 = tid * 16;
+  float v[16];
+  float ss = 0.f;
+  in_vals16(a, xr, gr, j0, v, ss);
+  had::fht16_fixed<LOGL, false>(v, buf, 0, tid, true);
+  f16* yr = a.y + row * a.out_features;
+  const f16* rr = a.residual ? a.residual + row * a.out_features : nullptr;
+  if (j0 + 16 <= a.out_features) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float tp[8], tb[8], tr[8];
+      if (a.post) ld8(a.post + j0 + 8 * h, tp);
+      if (a.bias) ld8(a.bias + j0 + 8 * h, tb);
+      if (rr) ld8(rr + j0 + 8 * h, tr);
+      f16 o[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        o[r] = had::out_elem(v[8 * h + r], a.scale, a.post != nullptr, a.post ? tp[r] : 0.f, a.bias != nullptr,
+                             a.bias ? tb[r] : 0.f, rr != nullptr, rr ? tr[r] : 0.f);
+      reinterpret_cast<uint4*>(yr + j0)[h] = *reinterpret_cast<uint4*>(&o[0]);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int idx = j0 + r;
+      if (idx < a.out_features)
+        yr[idx] = had::out_elem(v[r], a.scale, a.post != nullptr, a.post ? (float)a.post[idx] : 0.f,
+                                a.bias != nullptr, a.bias ? (float)a.bias[idx] : 0.f, rr != nullptr,
+                                rr ? (float)rr[idx] : 0.f);
+    }
+  }
+  (void)L;
+}
+
 // simple LDS radix-2 version for lengths the blocked kernel does not take
 template <bool PLANES>
 __global__ __launch_bounds__(256) void had_small_kernel(HadGroup grp) {
@@ -609,6 +775,26 @@ int launch(HadGroup& g, int count, int64_t rows, hipStream_t stream) {
     // decode launches: 1024 threads, ping-pong buffer (latency); batches: 512 threads, single buffer, so
     // that two workgroups share a CU (one at a time made prefill throughput = workgroup latency)
     const bool batch = rows > 8;
+    {   // prefill batches: one workgroup per row at a time (had_tall_batch_kernel)
+      bool ok = rows >= 32 && K <= 48 && !planes;
+      for (int i = 0; i < count; ++i)
+        ok = ok && g.p[i].vec && g.p[i].vec_out && !g.p[i].rms_w && !g.p[i].pre2 && !g.p[i].z && g.p[i].out_features % 8 == 0;
+      if (ok) {
+        static int cfgb = 0;
+        const int lds = (had::buf_floats(48 * L) + 48 * 48) * 4;
+        const int threads = L >= 256 ? 512 : 256;      // >= 3 L / 2 transform threads, >= 4 K-mix waves
+        const int64_t want = 2 * (int64_t)device_cu_count();       // two resident workgroups per CU
+        const dim3 grid((unsigned)(rows < want ? rows : want), 1, count);
+        if (lds > 48 * 1024 && lds > cfgb) {
+          if (hipFuncSetAttribute(reinterpret_cast<const void*>(had_tall_batch_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return QUIP_ERR_LAUNCH;
+          cfgb = lds;
+        }
+        hipLaunchKernelGGL(had_tall_batch_kernel, grid, dim3(threads), lds, stream, g, (int)rows);
+        return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+      }
+    }
     const int pp = had::buf_floats(4096) + ((K + 3) & ~3) * R + K * (L + 8);
     const int lds = (pp + (batch ? 0 : had::buf_floats(4096))) * 4;
     for (int i = 0; i < count; ++i) g.p[i].pp = batch ? 0 : pp;
@@ -636,6 +822,18 @@ int launch(HadGroup& g, int count, int64_t rows, hipStream_t stream) {
         static int c2[2] = {0, 0};
         return planes ? launch_one(had_fast_kernel<true, false, 1024>, c2[0], g, grid, (L / 16) * tg, lds2, stream)
                       : launch_one(had_fast_kernel<false, false, 1024>, c2[1], g, grid, (L / 16) * tg, lds2, stream);
+      }
+    }
+    if (K == 1 && !planes && rows >= 32 && (L == 1024 || L == 2048 || L == 4096)) {   // prefill batches
+      bool ok = true;
+      for (int i = 0; i < count; ++i)
+        ok = ok && g.p[i].vec && g.p[i].vec_out && !g.p[i].rms_w && !g.p[i].z && g.p[i].out_features % 8 == 0;
+      if (ok) {
+        const int lds1 = had::buf_floats(L) * 4;
+        if (L == 4096) hipLaunchKernelGGL(had_kone_batch_kernel<12>, grid, dim3(L / 16), lds1, stream, g);
+        else if (L == 2048) hipLaunchKernelGGL(had_kone_batch_kernel<11>, grid, dim3(L / 16), lds1, stream, g);
+        else hipLaunchKernelGGL(had_kone_batch_kernel<10>, grid, dim3(L / 16), lds1, stream, g);
+        return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
       }
     }
     if (L <= 4096 && K == 1) {

@@ -413,3 +413,57 @@ def test_e8p_gemv_planes_rows_equal_single_row_gemv(n, k, M):
         used = 3 * ((k + 511) // 512 * 512) + 4          # planes + shift word (12 bytes of padding follow)
         assert torch.equal(planes[r][:used], pr[:used]), r
         assert torch.equal(y[r:r + 1], op.e8p_gemv_planes(pr, qidx, grid)), r
+
+
+@pytest.mark.parametrize("n,rows", [(11008, 70), (2752, 33), (5504, 64), (11008, 600), (688 * 4, 40)])
+@pytest.mark.parametrize("side", ["in", "out"])
+def test_tall_hadamard_batches_equal_single_rows(n, rows, side):
+    """prefill batches of the tall transform (one workgroup per row, K-mix in place: had_tall_batch_kernel) give
+    bit for bit what the latency-shaped launch gives row by row; input side with gate / pre-scale, output side with
+    post-scale / bias / residual and a ragged out_features"""
+    from quip_for_all_amd.quant import get_hadK
+    torch.manual_seed(n + rows)
+    had, K, qn = get_hadK(n, True)
+    assert qn == n and K > 1
+    hd = had.to(DEV).half().contiguous()
+    op = torch.ops.quip_lib
+    x = torch.randn(rows, n, device=DEV).half()
+    v1 = torch.randn(n, device=DEV).half()
+    if side == "in":
+        g = torch.randn(rows, n, device=DEV).half()
+        full = op.had_transform_fused(x, n, n, K, hd, True, v1, None, None, None, 0.37, None, None, 1e-5, g)
+        for r in (0, 1, rows // 2, rows - 1):
+            one = op.had_transform_fused(x[r:r + 1], n, n, K, hd, True, v1, None, None, None, 0.37, None, None, 1e-5, g[r:r + 1])
+            assert torch.equal(full[r:r + 1], one), r
+    else:
+        out_f = n - 24
+        bias = torch.randn(out_f, device=DEV).half()
+        res = torch.randn(rows, out_f, device=DEV).half()
+        post = v1[:out_f].contiguous()
+        full = op.had_transform_fused(x, out_f, n, K, hd, False, None, None, post, bias, 0.11, res, None, 1e-5, None)
+        for r in (0, 1, rows // 2, rows - 1):
+            one = op.had_transform_fused(x[r:r + 1], out_f, n, K, hd, False, None, None, post, bias, 0.11, res[r:r + 1], None, 1e-5, None)
+            assert torch.equal(full[r:r + 1], one), r
+        assert full.shape == (rows, out_f)
+
+
+@pytest.mark.parametrize("n,rows,out_f", [(4096, 100, 4096), (1024, 33, 1000), (2048, 64, 2048), (4096, 70000, 4096)])
+def test_kone_hadamard_batches_equal_single_rows(n, rows, out_f):
+    """prefill batches of the power-of-two transform (had_kone_batch_kernel: 64 VGPRs, eight rows resident per CU)
+    give bit for bit what the latency-shaped launch gives row by row (input side with gate / SU, output side with
+    SV / bias / residual and a ragged out_features)"""
+    torch.manual_seed(n + rows)
+    op = torch.ops.quip_lib
+    x = torch.randn(rows, n, device=DEV).half()
+    su = torch.randn(n, device=DEV).half()
+    g = torch.randn(rows, n, device=DEV).half()
+    full_in = op.had_transform_fused(x, n, n, 1, None, True, su, None, None, None, 0.37, None, None, 1e-5, g)
+    bias = torch.randn(out_f, device=DEV).half()
+    res = torch.randn(rows, out_f, device=DEV).half()
+    post = su[:out_f].contiguous()
+    full_out = op.had_transform_fused(x, out_f, n, 1, None, False, None, None, post, bias, 0.11, res, None, 1e-5, None)
+    for r in (0, 1, rows // 2, rows - 1):
+        one = op.had_transform_fused(x[r:r + 1], n, n, 1, None, True, su, None, None, None, 0.37, None, None, 1e-5, g[r:r + 1])
+        assert torch.equal(full_in[r:r + 1], one), r
+        one = op.had_transform_fused(x[r:r + 1], out_f, n, 1, None, False, None, None, post, bias, 0.11, res[r:r + 1], None, 1e-5, None)
+        assert torch.equal(full_out[r:r + 1], one), r
