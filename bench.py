@@ -125,6 +125,40 @@ def cpu_baseline(budget_s=25.0):
                       "%.0f s of CPU work" % (threads, json.dumps(detail), lm * 1e3, time.time() - t_start)}
 
 
+def prefill_config5(dec, batch=16, seq=2048):
+    """BASELINE.json configs[4] (bs=16 x seq=2048 prefill, the MFMA batched-GEMM path) as an extra of the N=1 line:
+    the seven QuantLinear forwards of ONE decoder block of the benchmarked model on M = batch * seq rows
+    (Hadamard -> decompress -> dense fp16 GEMM -> Hadamard, as the reference does for M >= 32), HIP-event timed;
+    MFMA roofline = 2 M in out flops over the 2.5 PFLOP/s dense fp16 peak (MI355X_MICROARCH.md)."""
+    import torch
+    L = dec.layers[0]
+    M = batch * seq
+    dev = dec.dev
+    mods = [L[k] for k in ("q", "k", "v", "o", "gate", "up", "down")]
+    xs = {m.in_features: torch.randn(M, m.in_features, device=dev, dtype=torch.float16) for m in mods}
+    flops = sum(2.0 * M * m.in_features * m.out_features for m in mods)
+    with torch.no_grad():
+        for m in mods:      # warm-up (allocator, GEMM heuristics)
+            m(xs[m.in_features])
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for m in mods:
+                m(xs[m.in_features])
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+    ms = sorted(ts)[1]
+    return {"workload": "Llama-2-7B E8P12, bs=%d x seq=%d prefill: the 7 QuantLinear forwards of one decoder block "
+                        "(Hadamard + decompress + dense fp16 GEMM + Hadamard), M=%d rows" % (batch, seq, M),
+            "ms_per_block": round(ms, 3), "tflops": round(flops / ms / 1e9, 1),
+            "roofline": {"bound": "mfma", "achieved": round(flops / ms / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": round(flops / ms / 1e9 / 2500.0, 4)},
+            "ttft_linear_layers_ms": round(ms * dec.s.layers, 1)}
+
+
 def max_over_ranks(dist, dt, device):
     """the job's step time is the slowest replica's"""
     if dist is None:
@@ -166,6 +200,7 @@ def main():
     ap.add_argument("--model", default="7b", choices=["7b", "70b", "tiny"])
     ap.add_argument("--codebook", default="E8P12")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefill", action="store_true", help="skip the configs[4] prefill extra of the N=1 7B line")
     ap.add_argument("--dist-selftest", action="store_true",
                     help="exercise only the replica plumbing (rendezvous, barrier, max-over-ranks, rank-0 line) "
                          "with a synthetic per-rank time; runs on CPU with gloo (tests/test_bench_replicas.py)")
@@ -236,6 +271,11 @@ def main():
         }
         if a.codebook == "E8P12":
             out["roofline"] = gemv_roofline(dec)
+        if a.model == "7b" and a.codebook == "E8P12" and world == 1 and not a.no_prefill:
+            try:
+                out["prefill"] = prefill_config5(dec)
+            except Exception as e:  # an extra, never the headline
+                out["prefill"] = {"error": repr(e)}
         if not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline()
