@@ -497,34 +497,33 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
 }
 
 // Tall transform for BATCHES (prefill: thousands of token rows), fp16 output.  had_fast_kernel<*, TALL> is shaped
-// for latency: three workgroups per row, each staging the whole row.  Here ONE workgroup owns a whole row at a
-// time and walks over many rows (grid.x < rows): the row is staged once, in the padded [k][j] layout the
-// transform's shuffle buffer uses anyway; wave ct runs the K-mix of column tile ct for all (<= 3) row tiles
-// with the H fragments held in registers across rows (one B read feeds three MFMAs) and writes the result over
-// its own input columns; then the length-L transform and the epilogue run on 3 L threads.  The per-tile MFMA
-// sequence, the butterflies and the element-wise operations are those of had_fast_kernel, so the results are
-// bit identical to it.  512 threads (128 VGPRs) and 48 (L + L / 32) floats of LDS (50.7 KB at L = 256): two
-// workgroups per CU, one in its K-mix while the other loads / transforms / stores (H sits in LDS, 9 KB more).  The 48 rows are
-// transformed in two halves of 24 (3 L / 2 threads each).
+// for latency: three workgroups per row, each staging the whole row.  Here ONE 256-thread workgroup owns a whole
+// row at a time and walks over many rows (grid.x < rows): the row is staged once, in the padded [k][j] layout the
+// transform's shuffle buffer uses anyway; wave w runs the K-mix of column tiles w, w + 4, ... for all (<= 3) row
+// tiles (one B read feeds three MFMAs, H sits in LDS as fp16) and writes the result over its own input columns;
+// then the length-L transform and the epilogue run 4096 elements (16 rows at L = 256) at a time.  The per-tile
+// MFMA sequence, the butterflies and the element-wise operations are those of had_fast_kernel, so the results
+// are bit identical to it.  LDS: roundup4(K) (L + L / 32) floats + H = 51 KB at 43 x 256: THREE workgroups per
+// CU, in different phases (load / matrix cores / transform + store) most of the time.
 // Requires 64 <= L <= 256, K <= 48, vector access, no RMSNorm statistic (host-checked).
-__global__ __launch_bounds__(512, 4) void had_tall_batch_kernel(HadGroup grp, int rows) {
+__global__ __launch_bounds__(256, 3) void had_tall_batch_kernel(HadGroup grp, int rows) {
   const HadArgs a = grp.p[blockIdx.z];
   extern __shared__ __attribute__((aligned(16))) float buf[];
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = threadIdx.x, nt = blockDim.x;   // 256
   const int L = a.L, K = a.K, logL = a.logL;
   const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
   const int ctiles = L >> 4, ksteps = (K + 3) >> 2;
-  // H as the MFMA's A operand, A[row kq][k] at hs[k * 48 + kq], zero outside (K, K); staged once per workgroup
-  // (registers would hold it across rows too, but 36 more VGPRs cost the second resident workgroup)
-  float* hs = buf + had::buf_floats(48 * L);
+  const int BR = (K + 3) & ~3;                     // buffer rows: inputs k < K, outputs kp < BR (kp >= K are zero)
+  // H as the MFMA's A operand, A[row kq][k] at hs[k * 48 + kq] (fp16 as stored), zero outside (K, K).  (Held in
+  // registers across rows instead -- 36 VGPRs -- it spills under the three-workgroup budget and is not faster.)
+  f16* hs = reinterpret_cast<f16*>(buf + had::buf_floats(BR * L));
   for (int i = tid; i < 48 * 48; i += nt) {
     const int k = i / 48, kq = i - k * 48;
-    hs[i] = (kq < K && k < K) ? (float)(a.transpose ? a.had[k * K + kq] : a.had[kq * K + k]) : 0.f;
+    hs[i] = (kq < K && k < K) ? (a.transpose ? a.had[k * K + kq] : a.had[kq * K + k]) : (f16)0.f;
   }
-  const int fht_threads = (3 * L) >> 1;            // 24 rows x L / 16 per half
-  const bool fact = tid < fht_threads;
-  const int half_elems = 24 * L, half_floats = half_elems + (half_elems >> 5);   // 24 L is a multiple of 32
+  const int rr = (nt * 16) >> logL;                // rows per transform round (4096 elements)
+  const int round_floats = nt * 16 + ((nt * 16) >> 5);
   const int j0 = (tid * 16) & (L - 1);
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const f16* xr = a.x + (int64_t)row * a.in_features;
@@ -548,26 +547,28 @@ __global__ __launch_bounds__(512, 4) void had_tall_batch_kernel(HadGroup grp, in
       const int col = ct * 16 + lr;
 #pragma unroll 2
       for (int ks = 0; ks < ksteps; ++ks) {
-        {
-          const int k = min(4 * ks + lq, K - 1);
-          const float bv = buf[pad((k << logL) + col)];
+        const int k = min(4 * ks + lq, K - 1);
+        const float bv = buf[pad((k << logL) + col)];
 #pragma unroll
-          for (int rt = 0; rt < 3; ++rt)
-            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hs[(4 * ks + lq) * 48 + rt * 16 + lr], bv, acc[rt], 0, 0, 0);
-        }
+        for (int rt = 0; rt < 3; ++rt)
+          acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)hs[(4 * ks + lq) * 48 + rt * 16 + lr], bv, acc[rt], 0, 0, 0);
       }
 #pragma unroll
       for (int rt = 0; rt < 3; ++rt)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) buf[pad(((rt * 16 + 4 * lq + i) << logL) + col)] = acc[rt][i];
+        for (int i = 0; i < 4; ++i) {
+          const int orow = rt * 16 + 4 * lq + i;
+          if (orow < BR) buf[pad((orow << logL) + col)] = acc[rt][i];
+        }
     }
     __syncthreads();
-    // (3) + (4): length-L transform of the 48 rows (rows >= K are zero) and the epilogue, 24 rows at a time
-    for (int half = 0; half < 2; ++half) {
-      float* hb = buf + half * half_floats;
-      const int kp = half * 24 + ((tid * 16) >> logL);
+    // (3) + (4): length-L transform of the BR rows and the epilogue, 4096 elements at a time
+    for (int rd = 0; rd * rr < BR; ++rd) {
+      float* hb = buf + rd * round_floats;
+      const int kp = rd * rr + ((tid * 16) >> logL);
+      const bool fact = kp < BR;
       f16* yr = a.y + (int64_t)row * a.out_features;
-      const f16* rr = a.residual ? a.residual + (int64_t)row * a.out_features : nullptr;
+      const f16* rr_ = a.residual ? a.residual + (int64_t)row * a.out_features : nullptr;
       const int idx0 = kp * L + j0;
       const bool whole = fact && kp < K && idx0 + 16 <= a.out_features;
       float v[16];
@@ -578,25 +579,25 @@ __global__ __launch_bounds__(512, 4) void had_tall_batch_kernel(HadGroup grp, in
       else had::fht16_fixed<6, false>(v, hb, 0, tid, fact);
       if (fact && kp < K) {
         if (whole) {
-          // packed vectors requested together, unpacked eight at a time (register budget: 128)
+          // packed vectors requested together, unpacked eight at a time
           uint4 qpost[2], qbias[2], qres[2];
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             if (a.post) qpost[h] = ldp(a.post + idx0 + 8 * h);
             if (a.bias) qbias[h] = ldp(a.bias + idx0 + 8 * h);
-            if (rr) qres[h] = ldp(rr + idx0 + 8 * h);
+            if (rr_) qres[h] = ldp(rr_ + idx0 + 8 * h);
           }
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             float tp[8], tb[8], tr[8];
             if (a.post) had::unpack8(qpost[h], tp);
             if (a.bias) had::unpack8(qbias[h], tb);
-            if (rr) had::unpack8(qres[h], tr);
+            if (rr_) had::unpack8(qres[h], tr);
             f16 o[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r)
               o[r] = had::out_elem(v[8 * h + r], a.scale, a.post != nullptr, a.post ? tp[r] : 0.f, a.bias != nullptr,
-                                   a.bias ? tb[r] : 0.f, rr != nullptr, rr ? tr[r] : 0.f);
+                                   a.bias ? tb[r] : 0.f, rr_ != nullptr, rr_ ? tr[r] : 0.f);
             reinterpret_cast<uint4*>(yr + idx0)[h] = *reinterpret_cast<uint4*>(&o[0]);
           }
         } else {
@@ -605,8 +606,8 @@ __global__ __launch_bounds__(512, 4) void had_tall_batch_kernel(HadGroup grp, in
             const int idx = idx0 + r;
             if (idx < a.out_features)
               yr[idx] = had::out_elem(v[r], a.scale, a.post != nullptr, a.post ? (float)a.post[idx] : 0.f,
-                                      a.bias != nullptr, a.bias ? (float)a.bias[idx] : 0.f, rr != nullptr,
-                                      rr ? (float)rr[idx] : 0.f);
+                                      a.bias != nullptr, a.bias ? (float)a.bias[idx] : 0.f, rr_ != nullptr,
+                                      rr_ ? (float)rr_[idx] : 0.f);
           }
         }
       }
@@ -781,9 +782,10 @@ int launch(HadGroup& g, int count, int64_t rows, hipStream_t stream) {
         ok = ok && g.p[i].vec && g.p[i].vec_out && !g.p[i].rms_w && !g.p[i].pre2 && !g.p[i].z && g.p[i].out_features % 8 == 0;
       if (ok) {
         static int cfgb = 0;
-        const int lds = (had::buf_floats(48 * L) + 48 * 48) * 4;
-        const int threads = L >= 256 ? 512 : 256;      // >= 3 L / 2 transform threads, >= 4 K-mix waves
-        const int64_t want = 2 * (int64_t)device_cu_count();       // two resident workgroups per CU
+        const int BR = (K + 3) & ~3;
+        const int lds = had::buf_floats(BR * L) * 4 + 48 * 48 * 2;
+        const int threads = 256;
+        const int64_t want = 3 * (int64_t)device_cu_count();       // three resident workgroups per CU
         const dim3 grid((unsigned)(rows < want ? rows : want), 1, count);
         if (lds > 48 * 1024 && lds > cfgb) {
           if (hipFuncSetAttribute(reinterpret_cast<const void*>(had_tall_batch_kernel),
