@@ -210,6 +210,10 @@ typedef struct quip_had_problem {
    * table entry [lo - 7.5, hi - 7.5, 0, 0], so quip_d4_gemv_planes(planes, qidxs, that_table, y, n_out, 2k)
    * IS the HI product.  0 (or 1): plain / RVQ4 (resid_scale). */
   int32_t planes_layout;
+  /* fp16 group launches with K == 1 only.  != 0: this problem's own transform width (a power of two, 256..16384)
+   * instead of the launch's n, so that output transforms of different widths (q_proj next to the narrower k / v of
+   * a grouped-query model) share one launch; no rms_weight in such a group.  0: the launch's n. */
+  int32_t n;
 } quip_had_problem;
 int quip_had_transform_group_f16(const quip_had_problem* problems, int32_t count, int64_t rows,
                                  int32_t n, int32_t K, int32_t transpose, quip_stream_t stream);

@@ -62,7 +62,7 @@ class HadProblem(_c.Structure):
                 ("bias", _P), ("residual", _P), ("rms_weight", _P), ("gate", _P), ("in_features", _I32),
                 ("out_features", _I32), ("scale", _F), ("rms_eps", _F),
                 ("z", _P), ("z_post_scale", _P), ("z_residual", _P), ("h_out", _P), ("z_scale", _F),
-                ("resid_scale", _F), ("planes_layout", _I32)]
+                ("resid_scale", _F), ("planes_layout", _I32), ("n", _I32)]
 
 
 MAX_GROUP = 3

@@ -117,6 +117,7 @@ static int group_had(const quip_had_problem* problems, int32_t count, bool plane
     pr[i].z_scale = s.z_scale;
     pr[i].resid_scale = s.resid_scale;
     pr[i].planes_layout = s.planes_layout;
+    pr[i].n = s.n;
     pr[i].x = s.x; pr[i].out = s.out; pr[i].had = s.had; pr[i].pre = s.pre_scale; pr[i].pre2 = s.pre_scale2;
     pr[i].post = s.post_scale; pr[i].bias = s.bias; pr[i].residual = s.residual; pr[i].rms_weight = s.rms_weight;
     pr[i].gate = s.gate; pr[i].in_features = s.in_features; pr[i].out_features = s.out_features;

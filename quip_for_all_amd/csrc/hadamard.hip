@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256, 3) void had_tall_batch_kernel(HadGroup grp, in
     for (int ct = wave; ct < ctiles; ct += (nt >> 6)) {
       f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
       const int col = ct * 16 + lr;
-#pragma unroll 2
+#pragma unroll 6
       for (int ks = 0; ks < ksteps; ++ks) {
         const int k = min(4 * ks + lq, K - 1);
         const float bv = buf[pad((k << logL) + col)];
@@ -806,6 +806,25 @@ int launch(HadGroup& g, int count, int64_t rows, hipStream_t stream) {
                   : launch_one(had_fast_kernel<false, true, 1024>, cfg[1], g, grid, threads, lds, stream);
   }
   const dim3 grid(K, (unsigned)rows, count);
+  bool mixed = false;
+  for (int i = 1; i < count; ++i) mixed = mixed || g.p[i].L != L;
+  if (mixed) {
+    // K == 1 problems of different power-of-two widths (host-checked: fp16 output, no RMSNorm statistic) in one
+    // launch: the workgroup has the threads of the widest problem, a narrower problem keeps its first L / 16
+    // threads active (thread groups > 0 only take part in the barriers)
+    int Lmax = L;
+    for (int i = 1; i < count; ++i) Lmax = g.p[i].L > Lmax ? g.p[i].L : Lmax;
+    const bool batch = rows > 8;
+    for (int i = 0; i < count; ++i) {
+      g.p[i].tgroups = Lmax / g.p[i].L;
+      g.p[i].part_off = 0;
+      g.p[i].pp = batch ? 0 : had::buf_floats(g.p[i].L);
+    }
+    const int lds = (batch ? 1 : 2) * had::buf_floats(Lmax) * 4;
+    static int cm[2] = {0, 0};
+    return Lmax <= 4096 ? launch_one(had_fast_kernel<false, false, 256, true>, cm[0], g, grid, Lmax / 16, lds, stream)
+                        : launch_one(had_fast_kernel<false, false, 1024>, cm[1], g, grid, Lmax / 16, lds, stream);
+  }
   if (L >= 256 && L <= 16384) {
     // ping-pong shuffle buffer for the latency-bound decode launches; batches (prefill) take the single
     // buffer so that more rows are resident per CU
@@ -916,8 +935,11 @@ int had_transform_group_launch(const HadProblem* problems, int count, bool plane
   if (count < 1 || count > kMaxGroup || !problems) return QUIP_ERR_BAD_SHAPE;
   HadGroup g{};
   for (int i = 0; i < count; ++i) {
-    const int rc = fill(g.p[i], problems[i], planes, n, K, transpose);
+    const int ni = problems[i].n > 0 ? problems[i].n : n;
+    if (ni != n && (planes || K != 1 || problems[i].rms_weight || problems[i].z)) return QUIP_ERR_UNSUPPORTED;
+    const int rc = fill(g.p[i], problems[i], planes, ni, K, transpose);
     if (rc != QUIP_OK) return rc;
+    if (ni != n && (g.p[i].L < 256 || g.p[i].L > 16384)) return QUIP_ERR_UNSUPPORTED;
     if (planes && (reinterpret_cast<uintptr_t>(problems[i].out) & 15) != 0) return QUIP_ERR_MISALIGNED;
   }
   if (planes && (g.p[0].L < 4 || n % 16 != 0)) return QUIP_ERR_BAD_SHAPE;

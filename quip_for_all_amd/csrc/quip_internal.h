@@ -80,6 +80,7 @@ struct HadProblem {
   float z_scale = 1.f;
   float resid_scale = 0.f;   // planes only: != 0 -> planes of the E8P12RVQ4B virtual vector [s * x_g | x_g] (2n digits)
   int planes_layout = 0;     // planes only: 0 plain (or RVQ4 when resid_scale != 0), 2 = HI virtual vector (2n digits)
+  int n = 0;                 // fp16, K == 1: this problem's own width (0: the launch's n)
 };
 int had_transform_group_launch(const HadProblem* problems, int count, bool planes, int64_t rows, int n, int K,
                                int transpose, hipStream_t stream);

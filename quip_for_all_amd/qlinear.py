@@ -334,24 +334,33 @@ def gemv_fused(layers, x=None, prev=None, z=None, residual=None, rms_weight=None
 
 
 def out_transform_group(layers, zs, residual=None):
-    """output side (qlinear.py:106-114) of 1..3 modules from their raw GEMV outputs; one launch per
-    set of modules with the same (q_out, K_right)"""
+    """output side (qlinear.py:106-114) of 1..3 modules from their raw GEMV outputs; one launch per set of
+    modules with the same (q_out, K_right) -- and ONE launch for power-of-two widths that differ (q_proj next
+    to the narrower k / v_proj of a grouped-query model)"""
     residual = residual if residual is not None else [None] * len(layers)
     ys = [None] * len(layers)
     todo = list(range(len(layers)))
+
+    def mixable(l):
+        return l.K_right == 1 and 256 <= l.q_out_features <= 16384 and _pow2(l.q_out_features)
     while todo:
         i0 = todo[0]
         same = [i for i in todo if layers[i].q_out_features == layers[i0].q_out_features
                 and layers[i].K_right == layers[i0].K_right]
+        ns = None
+        if mixable(layers[i0]) and any(mixable(layers[i]) and i not in same for i in todo):
+            same = [i for i in todo if mixable(layers[i])]
+            ns = [layers[i].q_out_features for i in same]
         todo = [i for i in todo if i not in same]
         ls = [layers[i] for i in same]
         L_out = ls[0].q_out_features // ls[0].K_right
         outs = torch.ops.quip_lib.had_transform_group(
             [zs[i] for i in same], [l.out_features for l in ls], ls[0].q_out_features, ls[0].K_right,
             [l._had("had_right") for l in ls], False, [l._vec(l.Wscale) if l.per_channel else None for l in ls],
-            [l._vec(l.SV) for l in ls], [l._vec(l.bias) for l in ls], [1.0 / math.sqrt(L_out)] * len(ls),
+            [l._vec(l.SV) for l in ls], [l._vec(l.bias) for l in ls],
+            [1.0 / math.sqrt(l.q_out_features // l.K_right) for l in ls],
             [None if residual[i] is None else residual[i].reshape(1, -1).to(torch.float16) for i in same],
-            [None] * len(ls), None, 1e-5)
+            [None] * len(ls), None, 1e-5, ns)
         for i, o in zip(same, outs):
             ys[i] = o
     return ys

@@ -63,7 +63,7 @@ _SCHEMAS = {
                               "float[] scale, Tensor? rms_weight, float rms_eps, float resid_scale=0.0) -> Tensor[]",
     "had_transform_group": "(Tensor[] x, int[] out_features, int n, int K, Tensor?[] had, bool transpose, "
                            "Tensor?[] pre2, Tensor?[] post, Tensor?[] bias, float[] scale, Tensor?[] residual, "
-                           "Tensor?[] pre, Tensor? rms_weight, float rms_eps) -> Tensor[]",
+                           "Tensor?[] pre, Tensor? rms_weight, float rms_eps, int[]? ns=None) -> Tensor[]",
     # GEMV(s) with the input side computed in the prologue: [h_out]? + [y_i]; see quip_e8p_gemv_fused
     "e8p_gemv_fused": "(Tensor? x, Tensor? z, Tensor? post, Tensor? residual, Tensor? rms_weight, float rms_eps, "
                       "float z_scale, Tensor[] pre, float[] scale, Tensor[] Qidxs, Tensor grid) -> Tensor[]",
@@ -375,13 +375,16 @@ def _had_chain_planes_group_cuda(z, z_post, z_residual, z_scale, n, pre, scale, 
 
 
 def _had_transform_group_cuda(x, out_features, n, K, had, transpose, pre2, post, bias, scale, residual, pre,
-                              rms_weight, rms_eps):
+                              rms_weight, rms_eps, ns=None):
     count = len(x)
     _need(1 <= count <= capi.MAX_GROUP and all(len(v) == count for v in (out_features, had, pre2, post, bias, scale,
                                                                           residual, pre)), "group of 1..3 problems")
     xs = [_chk_x(t) for t in x]
     rows = xs[0].shape[0]
-    _need(all(t.shape == xs[0].shape and t.device == xs[0].device for t in xs), "group inputs must share a shape")
+    _need(all(t.shape[0] == rows and t.device == xs[0].device for t in xs), "group inputs must share rows / device")
+    _need(ns is not None or all(t.shape == xs[0].shape for t in xs), "group inputs must share a shape (or pass ns)")
+    _need(ns is None or (len(ns) == count and K == 1 and rms_weight is None),
+          "ns: one width per problem, K == 1, no rms_weight")
     dev = xs[0].device
     outs = [torch.empty((rows, int(o)), dtype=torch.float16, device=dev) for o in out_features]
     arr = (capi.HadProblem * count)()
@@ -391,6 +394,8 @@ def _had_transform_group_cuda(x, out_features, n, K, had, transpose, pre2, post,
                                  _vec_ok(pre2[i], dev), _vec_ok(post[i], dev), _vec_ok(bias[i], dev),
                                  _vec_ok(residual[i], dev), _vec_ok(rms_weight, dev), None,
                                  xs[i].shape[1], int(out_features[i]), float(scale[i]), float(rms_eps))
+        if ns is not None:
+            arr[i].n = int(ns[i])
     with torch.cuda.device(dev):
         capi.check(capi.lib().quip_had_transform_group_f16(arr, count, rows, n, K, int(bool(transpose)), _stream(xs[0])),
                    "quip_had_transform_group_f16")
@@ -681,7 +686,7 @@ _reg_fake("had_chain_planes_group", lambda z, z_post, z_residual, z_scale, n, pr
           resid_scale=0.0: [z.new_empty((1, n))] + [z.new_empty((_planes_numel(n, resid_scale),), dtype=torch.uint8)
                                                      for _ in pre])
 _reg_fake("had_transform_group", lambda x, out_features, n, K, had, transpose, pre2, post, bias, scale, residual, pre,
-          rms_weight, rms_eps:
+          rms_weight, rms_eps, ns=None:
           [t.new_empty((t.shape[0], int(o))) for t, o in zip(x, out_features)])
 _reg_fake("e8prvq3_gemv_planes_group", lambda planes, Qidxs, grid, e81b_i8:
           [q.new_empty((1, q.shape[0]), dtype=torch.float16) for q in Qidxs])

@@ -313,3 +313,19 @@ def test_rvq3_grouped_planes_path_equals_single_calls(fin, fouts):
     assert not torch.equal(y_new, single[0])
     tol = 6 * 2.0 ** -11 * (y_dense.float().abs() + 4 * y_dense.float().pow(2).mean().sqrt()) + 1e-3
     assert torch.all((y_new.float() - y_dense.float()).abs() <= tol)
+
+
+def test_out_transform_group_mixed_widths_equals_single():
+    """grouped-query shapes: q_proj (8192 wide) and k / v_proj (1024 wide) output transforms in ONE launch give
+    exactly what the per-module launches give (also 4096 + 1024 + 512)"""
+    from quip_for_all_amd.qlinear import out_transform_group
+    for fin, fouts in ((1024, (8192, 1024, 1024)), (512, (4096, 1024, 512))):
+        layers = [_layer(O.make_layer("E8P12", fin, fo, seed=fin + fo + i)) for i, fo in enumerate(fouts)]
+        rng = np.random.default_rng(fin)
+        zs = [torch.from_numpy(rng.standard_normal((1, fo)).astype(np.float16)).to(DEV) for fo in fouts]
+        res = [torch.from_numpy(rng.standard_normal((1, fo)).astype(np.float16)).to(DEV) for fo in fouts]
+        with torch.no_grad():
+            grouped = out_transform_group(layers, zs, residual=res)
+            for l, z, r, g in zip(layers, zs, res, grouped):
+                (single,) = out_transform_group([l], [z], residual=[r])
+                assert torch.equal(single, g)
