@@ -333,6 +333,9 @@ def gemv_fused(layers, x=None, prev=None, z=None, residual=None, rms_weight=None
     return res[0], list(res[1:])
 
 
+_MIXED_OUT = os.environ.get("QUIP_MIXED_OUT", "1") != "0"     # A/B switch for the mixed-width output launch
+
+
 def out_transform_group(layers, zs, residual=None):
     """output side (qlinear.py:106-114) of 1..3 modules from their raw GEMV outputs; one launch per set of
     modules with the same (q_out, K_right) -- and ONE launch for power-of-two widths that differ (q_proj next
@@ -342,7 +345,8 @@ def out_transform_group(layers, zs, residual=None):
     todo = list(range(len(layers)))
 
     def mixable(l):
-        return l.K_right == 1 and 256 <= l.q_out_features <= 16384 and _pow2(l.q_out_features)
+        return (_MIXED_OUT and l.K_right == 1 and 256 <= l.q_out_features <= 16384 and _pow2(l.q_out_features)
+                and not l.per_channel)
     while todo:
         i0 = todo[0]
         same = [i for i in todo if layers[i].q_out_features == layers[i0].q_out_features
