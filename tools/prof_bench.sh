@@ -52,3 +52,5 @@ with open(f"{R}/gpurun_out/{tag}_bench_fetch_size.txt", "w") as f:
 PY
 head -30 $R/gpurun_out/${tag}_bench_kernel_trace.txt | cut -c1-200
 cat $R/gpurun_out/${tag}_bench_fetch_size.txt | cut -c1-200 | head -20
+# the raw rocprofv3 databases are tens of MB: keep the summaries only (gpurun copies back <= 64 MiB)
+rm -rf $out/kt $out/pmc
