@@ -246,6 +246,15 @@ int quip_e8p_gemv_planes_rows(const void* planes, const void* qidxs, const void*
 int quip_e8p_quantize_f32(const void* x, int64_t nvec, const void* grid_packed_abs, void* vals, void* idx,
                           quip_stream_t stream);
 
+/* Rows mode for the other table modes of the same kernel.  mode 0: E8P12 (== quip_e8p_gemv_planes_rows);
+ * mode 64: D4 (qidxs uint8 (n, k/4), grid = fp16 (256, 4) table; HI through its virtual 2k layout, see
+ * quip_had_problem.planes_layout); mode 40: E8P12RVQ3B (qidxs = repacked int32 codes viewed as 2k virtual
+ * weights -- pass k = 2 * in features --, grid = grid_packed_abs, grid2 = e81b_i8, see
+ * quip_e8prvq3_gemv_planes_group).  grid2 is ignored otherwise. */
+int32_t quip_gemv_max_rows_mode(int32_t n, int32_t k, int32_t mode);
+int quip_gemv_planes_rows_mode(const void* planes, const void* qidxs, const void* grid, const void* grid2, void* y,
+                               int32_t rows, int32_t n, int32_t k, int32_t mode, quip_stream_t stream);
+
 /* count GEMVs y[i] = W[i] x[i] (W[i]: (ns[i], k) E8P12 codes, x[i] as digit planes) */
 int quip_e8p_gemv_planes_group(const void* const* planes, const void* const* qidxs,
                                const void* grid_packed_abs, void* const* ys, const int32_t* ns,

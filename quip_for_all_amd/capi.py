@@ -25,6 +25,8 @@ SIGNATURES = {
     "quip_had_transform_planes_rows": [_P, _I64, _I32, _I32, _I32, _P],
     "quip_e8p_gemv_max_rows": [_I32, _I32],
     "quip_e8p_quantize_f32": [_P, _I64, _P, _P, _P, _P],
+    "quip_gemv_max_rows_mode": [_I32, _I32, _I32],
+    "quip_gemv_planes_rows_mode": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
     "quip_e8p_gemv_planes_rows": [_P, _P, _P, _P, _I32, _I32, _I32, _P],
     "quip_e8prvq3_gemv_planes_group": [_P, _P, _P, _P, _P, _P, _I32, _I32, _P],
     "quip_d4_gemv_planes": [_P, _P, _P, _P, _I32, _I32, _P],

@@ -230,6 +230,10 @@ class E8P12RVQ3B_codebook(_Codebook):
         return list(torch.ops.quip_lib.e8prvq3_gemv_planes_group(
             planes, [self._repacked(q) for q in Qidxs], self.grid_packed_abs, self._e81b_i8(Qidxs[0].device)))
 
+    def mm_planes_rows(self, planes, Qidxs):
+        return torch.ops.quip_lib.gemv_planes_rows_mode(planes, self._repacked(Qidxs), self.grid_packed_abs,
+                                                        self._e81b_i8(Qidxs.device), 40)
+
     def maybe_pack_idxs(self, idxs):
         """keep the low 3 bytes of every int32 index (e8p12_rvq3.py:102-107)"""
         b = idxs.contiguous().view(torch.int8).view(idxs.shape[0], idxs.shape[1], -1)
@@ -287,6 +291,9 @@ class D4_codebook(_Codebook):
     def mm_planes_group(self, planes, Qidxs):
         return list(torch.ops.quip_lib.d4_gemv_planes_group(planes, Qidxs, self.grid))
 
+    def mm_planes_rows(self, planes, Qidxs):
+        return torch.ops.quip_lib.gemv_planes_rows_mode(planes, Qidxs, self.grid, None, 64)
+
 
 class HI4B1C_codebook(_Codebook):
     def __init__(self, inference=False, **kwargs):
@@ -338,6 +345,10 @@ class HI4B1C_codebook(_Codebook):
         g = (torch.arange(-8, 8, device=X.device, dtype=X.dtype) + 0.5).unsqueeze(-1)
         vals, idx = self._round_dense(X, g)
         return (vals, idx.to(self.idx_dtype)) if return_idx else vals
+
+    def mm_planes_rows(self, planes, Qidxs):
+        return torch.ops.quip_lib.gemv_planes_rows_mode(planes, Qidxs.view(torch.uint8), self._virtual_grid(Qidxs.device),
+                                                        None, 64)
 
     def maybe_pack_idxs(self, idxs):
         """nibble i <- column [0,2,4,6,1,3,5,7][i] of each 8-group (hi.py:41-50)"""

@@ -161,6 +161,24 @@ int quip_e8p_gemv_planes_rows(const void* planes, const void* qidxs, const void*
   return e8p_gemv_mfma_rows_launch(planes, qidxs, grid_packed_abs, y, rows, n, k, GemvTune{}, (hipStream_t)stream);
 }
 
+// rows mode with another table mode: 64 = D4 table (fp16 (256, 4) grid; HI through its virtual layout),
+// 40 = E8P12RVQ3B (repacked codes, k = 2 * in features, grid2 = e81b_i8)
+int32_t quip_gemv_max_rows_mode(int32_t n, int32_t k, int32_t mode) {
+  return (n > 0 && k > 0 && (mode == 0 || mode == 64 || mode == 40)) ? e8p_gemv_mfma_max_rows(n, k, mode) : 0;
+}
+
+int quip_gemv_planes_rows_mode(const void* planes, const void* qidxs, const void* grid, const void* grid2, void* y,
+                               int32_t rows, int32_t n, int32_t k, int32_t mode, quip_stream_t stream) {
+  if (!planes || !qidxs || !grid || !y) return QUIP_ERR_NULL_POINTER;
+  if (rows < 1 || n < 1 || k < 1 || k % 8 != 0) return QUIP_ERR_BAD_SHAPE;
+  if (mode != 0 && mode != 64 && mode != 40) return QUIP_ERR_BAD_SHAPE;
+  if (!aligned16(planes) || !aligned16(qidxs)) return QUIP_ERR_MISALIGNED;
+  GemvTune t;
+  t.rep = mode;
+  t.grid2 = grid2;
+  return e8p_gemv_mfma_rows_launch(planes, qidxs, grid, y, rows, n, k, t, (hipStream_t)stream);
+}
+
 int quip_e8p_gemv_planes_group(const void* const* planes, const void* const* qidxs,
                                const void* grid_packed_abs, void* const* ys, const int32_t* ns,
                                int32_t count, int32_t k, quip_stream_t stream) {

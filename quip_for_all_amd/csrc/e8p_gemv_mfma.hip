@@ -1148,16 +1148,20 @@ int e8p_gemv_mfma_launch(const void* planes, const void* qidxs, const void* grid
 }
 
 // ---- rows mode: up to 5 activation rows per launch ------------------------------------------
-int e8p_gemv_mfma_max_rows(int n, int k) {
+// mode: 0 = E8P12 tables, 64 = D4 table (also HI through its virtual layout), 40 = E8P12RVQ3B tables
+int e8p_gemv_mfma_max_rows(int n, int k, int mode) {
   if (!e8p_gemv_mfma_supported(n, k)) return 0;
-  const int m = Lds<16>::kMaxKp / kp_of(k);
+  const int budget = mode == 64 ? Lds<64>::kMaxKp : (mode == 40 ? Lds<20>::kMaxKp : Lds<16>::kMaxKp);
+  const int m = budget / kp_of(k);
   return m > 5 ? 5 : m;
 }
 
 int e8p_gemv_mfma_rows_launch(const void* planes, const void* qidxs, const void* grid, void* y, int mrows, int n,
                               int k, const GemvTune& tune, hipStream_t stream) {
-  if (mrows < 1 || mrows > e8p_gemv_mfma_max_rows(n, k)) return QUIP_ERR_UNSUPPORTED;
-  if ((reinterpret_cast<uintptr_t>(grid) & 63u) != 0) return QUIP_ERR_MISALIGNED;
+  const int mode = tune.rep == 64 ? 64 : (tune.rep == 40 ? 40 : 0);
+  if (mrows < 1 || mrows > e8p_gemv_mfma_max_rows(n, k, mode)) return QUIP_ERR_UNSUPPORTED;
+  if (mode != 64 && (reinterpret_cast<uintptr_t>(grid) & 63u) != 0) return QUIP_ERR_MISALIGNED;
+  if (mode == 40 && !tune.grid2) return QUIP_ERR_NULL_POINTER;
   const int kp = kp_of(k);
   uint64_t* dbg = reinterpret_cast<uint64_t*>(tune.dbg);
   int nblocks = tune.blocks > 0 ? tune.blocks : device_cu_count();
@@ -1177,13 +1181,20 @@ int e8p_gemv_mfma_rows_launch(const void* planes, const void* qidxs, const void*
   if (waves > 16) return QUIP_ERR_UNSUPPORTED;
   const int threads = waves * 64;
   const int ipw = (items + waves - 1) / waves;
-  const int rep = mrows * kp <= Lds<32>::kMaxKp ? 32 : 16;
+  const int rep = mode == 64 ? 64 : (mode == 40 ? (mrows * kp <= Lds<40>::kMaxKp ? 40 : 20)
+                                               : (mrows * kp <= Lds<32>::kMaxKp ? 32 : 16));
   GemvGroup<1> gp{{reinterpret_cast<const uint4*>(qidxs)}, {reinterpret_cast<const uint8_t*>(planes)},
-                  {reinterpret_cast<f16*>(y)}, {n}, {rpb}, {0}};
+                  {reinterpret_cast<f16*>(y)}, {n}, {rpb}, {0}, tune.grid2};
 #define QUIP_ROWS(R, S, T, ONE)                                                                   \
   if (rep == R && (T == 1024) == (threads > 512) && (ONE ? ipw <= S : true))                      \
     return launch<R, S, T, 1, ONE, false, true>(gp, grid, k, kp, nblocks, threads, dbg, stream, nullptr, mrows);
   if ((threads <= 512 && ipw <= 8) || (threads > 512 && ipw <= 4)) {
+#define QUIP_ROWS_ONE(R)                                                                                          \
+    QUIP_ROWS(R, 1, 512, true) QUIP_ROWS(R, 2, 512, true) QUIP_ROWS(R, 3, 512, true) QUIP_ROWS(R, 4, 512, true)   \
+    QUIP_ROWS(R, 6, 512, true) QUIP_ROWS(R, 8, 512, true)                                                         \
+    QUIP_ROWS(R, 1, 1024, true) QUIP_ROWS(R, 2, 1024, true) QUIP_ROWS(R, 3, 1024, true) QUIP_ROWS(R, 4, 1024, true)
+    QUIP_ROWS_ONE(64) QUIP_ROWS_ONE(40) QUIP_ROWS_ONE(20)
+#undef QUIP_ROWS_ONE
     QUIP_ROWS(32, 1, 512, true) QUIP_ROWS(32, 2, 512, true) QUIP_ROWS(32, 3, 512, true) QUIP_ROWS(32, 4, 512, true)
     QUIP_ROWS(32, 6, 512, true) QUIP_ROWS(32, 8, 512, true)
     QUIP_ROWS(16, 1, 512, true) QUIP_ROWS(16, 2, 512, true) QUIP_ROWS(16, 3, 512, true) QUIP_ROWS(16, 4, 512, true)
@@ -1192,6 +1203,8 @@ int e8p_gemv_mfma_rows_launch(const void* planes, const void* qidxs, const void*
     QUIP_ROWS(16, 1, 1024, true) QUIP_ROWS(16, 2, 1024, true) QUIP_ROWS(16, 3, 1024, true) QUIP_ROWS(16, 4, 1024, true)
   }
   QUIP_ROWS(32, 1, 512, false) QUIP_ROWS(16, 1, 512, false) QUIP_ROWS(32, 1, 1024, false) QUIP_ROWS(16, 1, 1024, false)
+  QUIP_ROWS(64, 1, 512, false) QUIP_ROWS(64, 1, 1024, false) QUIP_ROWS(40, 1, 512, false) QUIP_ROWS(40, 1, 1024, false)
+  QUIP_ROWS(20, 1, 512, false) QUIP_ROWS(20, 1, 1024, false)
 #undef QUIP_ROWS
   return QUIP_ERR_UNSUPPORTED;
 }

@@ -88,7 +88,7 @@ int had_transform_group_launch(const HadProblem* problems, int count, bool plane
 int e8p_quantize_launch(const void* x, int64_t nvec, const void* grid_packed_abs, void* vals, void* idx,
                         hipStream_t stream);
 // rows mode: up to e8p_gemv_mfma_max_rows(n, k) <= 5 activation rows against one matrix in one pass
-int e8p_gemv_mfma_max_rows(int n, int k);
+int e8p_gemv_mfma_max_rows(int n, int k, int mode = 0);   // mode: 0 E8P12, 64 D4 / HI, 40 E8P12RVQ3B (2k virtual)
 int e8p_gemv_mfma_rows_launch(const void* planes, const void* qidxs, const void* grid, void* y, int mrows, int n,
                               int k, const GemvTune& tune, hipStream_t stream);
 bool e8p_gemv_mfma_group_supported(const int* ns, int count, int k);

@@ -55,6 +55,8 @@ _SCHEMAS = {
     "had_transform_planes_rows": "(Tensor x, int n, int K, Tensor? had, bool transpose, Tensor? pre, float scale, "
                                  "Tensor? rms_weight, float rms_eps, Tensor? gate, float resid_scale=0.0) -> Tensor",
     "e8p_gemv_planes_rows": "(Tensor planes, Tensor Qidxs, Tensor grid) -> Tensor",
+    # the same for the other table modes: 64 = D4 table (Qidxs uint8 (n, k/4)), 40 = E8P12RVQ3B (repacked int32 codes)
+    "gemv_planes_rows_mode": "(Tensor planes, Tensor Qidxs, Tensor grid, Tensor? grid2, int mode) -> Tensor",
     # quantise-time nearest E8P12 codeword: X (N, 8) fp32 -> (vals (N, 8) fp32, idx (N) int64)
     "e8p_quantize": "(Tensor X, Tensor grid) -> (Tensor, Tensor)",
     # chain: output side of the producer module (z, its SV, residual) + input transforms of 1..3 consumers;
@@ -307,6 +309,35 @@ def _e8p_gemv_planes_rows_cuda(planes, Qidxs, grid):
             capi.check(L.quip_e8p_gemv_planes_rows(planes[r0].data_ptr(), Qidxs.data_ptr(), grid.data_ptr(),
                                                    out[r0].data_ptr(), m, n, k, _stream(out)),
                        "quip_e8p_gemv_planes_rows")
+    return out
+
+
+def _gemv_planes_rows_mode_cuda(planes, Qidxs, grid, grid2, mode):
+    _need(mode in (64, 40), "mode: 64 (D4 table) or 40 (E8P12RVQ3B tables)")
+    _need(Qidxs.is_contiguous() and Qidxs.dtype == (torch.uint8 if mode == 64 else torch.int32),
+          "Qidxs: contiguous uint8 (n, k/4) for mode 64, repacked int32 (n, k/8) for mode 40")
+    n = Qidxs.shape[0]
+    k = Qidxs.shape[1] * 4 if mode == 64 else Qidxs.shape[1] * 16       # mode 40: 2 * in features virtual weights
+    L = capi.lib()
+    _need(planes.dim() == 2 and planes.dtype == torch.uint8 and planes.is_contiguous()
+          and planes.shape[1] == L.quip_e8p_planes_bytes(k) and planes.device == Qidxs.device,
+          "planes must be (rows, quip_e8p_planes_bytes(k)) uint8 images")
+    if mode == 64:
+        g = _d4_grid(grid)
+    else:
+        g = _grid_i64(grid, planes)
+        _need(grid2 is not None and grid2.dtype == torch.int8 and tuple(grid2.shape) == (256, 8) and grid2.is_contiguous(),
+              "grid2 must be the contiguous int8 (256, 8) E81B table")
+    rows = planes.shape[0]
+    per = L.quip_gemv_max_rows_mode(n, k, mode)
+    _need(per >= 1, "shape not supported by the matrix-core GEMV")
+    out = torch.empty((rows, n), dtype=torch.float16, device=Qidxs.device)
+    with torch.cuda.device(Qidxs.device):
+        for r0 in range(0, rows, per):
+            m = min(per, rows - r0)
+            capi.check(L.quip_gemv_planes_rows_mode(planes[r0].data_ptr(), Qidxs.data_ptr(), g.data_ptr(), _ptr(grid2),
+                                                    out[r0].data_ptr(), m, n, k, mode, _stream(out)),
+                       "quip_gemv_planes_rows_mode")
     return out
 
 
@@ -629,6 +660,7 @@ _IMPLS = {
     "had_transform_planes_rows": _had_transform_planes_rows_cuda,
     "e8p_gemv_planes_rows": _e8p_gemv_planes_rows_cuda,
     "e8p_quantize": _e8p_quantize_cuda,
+    "gemv_planes_rows_mode": _gemv_planes_rows_mode_cuda,
     "e8prvq3_gemv_planes_group": _e8prvq3_gemv_planes_group_cuda,
     "d4_gemv_planes": _d4_gemv_planes_cuda,
     "d4_gemv_planes_group": _d4_gemv_planes_group_cuda,
@@ -696,6 +728,8 @@ _reg_fake("d4_gemv_planes_group", lambda planes, Qidxs, grid:
 _reg_fake("had_transform_planes_rows", lambda x, n, K, had, transpose, pre, scale, rms_weight, rms_eps, gate,
           resid_scale=0.0: x.new_empty((x.shape[0], _planes_numel(n, resid_scale)), dtype=torch.uint8))
 _reg_fake("e8p_gemv_planes_rows", lambda planes, Qidxs, grid:
+          Qidxs.new_empty((planes.shape[0], Qidxs.shape[0]), dtype=torch.float16))
+_reg_fake("gemv_planes_rows_mode", lambda planes, Qidxs, grid, grid2, mode:
           Qidxs.new_empty((planes.shape[0], Qidxs.shape[0]), dtype=torch.float16))
 _reg_fake("e8p_quantize", lambda X, grid: (torch.empty_like(X), X.new_empty((X.shape[0],), dtype=torch.int64)))
 _reg_fake("e8p_mm_planes_rows", lambda planes, Qidxs, grid:

@@ -290,6 +290,15 @@ def test_skinny_rows_rvq4_on_matrix_core_path(fin, fout, M):
     test_skinny_rows_on_matrix_core_path(fin, fout, M, cbid="E8P12RVQ4B")
 
 
+@pytest.mark.parametrize("cbid,fin,fout,M", [("D4", 4096, 4096, 5), ("D4", 4096, 11008, 9), ("D4", 11008, 4096, 3),
+                                              ("HI", 4096, 4096, 4), ("HI", 256, 688, 7), ("E8P12RVQ3B", 4096, 4096, 4),
+                                              ("E8P12RVQ3B", 256, 688, 5), ("E8P12RVQ3B", 4096, 11008, 2)])
+def test_skinny_rows_other_codebooks_on_matrix_core_path(cbid, fin, fout, M):
+    """D4 / HI (D4 table mode) and E8P12RVQ3B (E81B table mode) rows: same rows-mode GEMV, each row bit identical to
+    its bs=1 result"""
+    test_skinny_rows_on_matrix_core_path(fin, fout, M, cbid=cbid)
+
+
 @pytest.mark.parametrize("fin,fouts", [(4096, (4096, 4096, 4096)), (4096, (11008, 11008)), (256, (256, 688))])
 def test_rvq3_grouped_planes_path_equals_single_calls(fin, fouts):
     """E8P12RVQ3B bs=1: grouped launches on the matrix-core GEMV (repacked codes + E81B table mode) give
