@@ -541,24 +541,43 @@ __global__ __launch_bounds__(256, 3) void had_tall_batch_kernel(HadGroup grp, in
       for (int r = 0; r < 16; ++r) dst[r] = e[r];
     }
     __syncthreads();
-    // (2) K-mix on the matrix cores, in place per column tile
-    for (int ct = wave; ct < ctiles; ct += (nt >> 6)) {
-      f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-      const int col = ct * 16 + lr;
-#pragma unroll 6
+    // (2) K-mix on the matrix cores, in place per column tile.  A wave runs its (<= 4) column tiles TOGETHER: per
+    //     k step one A read per row tile feeds all of them, and the 3 x tiles MFMAs of a step (>= 96 cycles of
+    //     matrix-core time) cover the LDS latency of the next step's operands.
+    {
+      const int nw = nt >> 6;
+      const int tpw = (ctiles + nw - 1) / nw;        // 4 (L = 256), 2 (128), 1 (64)
+      f32x4 acc[4][3];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt) acc[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
       for (int ks = 0; ks < ksteps; ++ks) {
         const int k = min(4 * ks + lq, K - 1);
-        const float bv = buf[pad((k << logL) + col)];
+        float av[3], bv[4];
 #pragma unroll
-        for (int rt = 0; rt < 3; ++rt)
-          acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)hs[(4 * ks + lq) * 48 + rt * 16 + lr], bv, acc[rt], 0, 0, 0);
+        for (int rt = 0; rt < 3; ++rt) av[rt] = (float)hs[(4 * ks + lq) * 48 + rt * 16 + lr];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bv[t] = t < tpw ? buf[pad((k << logL) + (wave + t * nw) * 16 + lr)] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (t < tpw) {
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt], bv[t], acc[t][rt], 0, 0, 0);
+          }
       }
 #pragma unroll
-      for (int rt = 0; rt < 3; ++rt)
+      for (int t = 0; t < 4; ++t)
+        if (t < tpw) {
+          const int col = (wave + t * nw) * 16 + lr;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int orow = rt * 16 + 4 * lq + i;
-          if (orow < BR) buf[pad((orow << logL) + col)] = acc[rt][i];
+          for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int orow = rt * 16 + 4 * lq + i;
+              if (orow < BR) buf[pad((orow << logL) + col)] = acc[t][rt][i];
+            }
         }
     }
     __syncthreads();
