@@ -214,12 +214,17 @@ class E8P12RVQ3B_codebook(_Codebook):
     def _repacked(self, Qidxs):
         # one repacked copy per Qidxs buffer (a codebook object may serve many layers), refreshed when the
         # buffer is written to
+        import weakref
         cache = self.__dict__.setdefault("_repack_cache", {})
         key = (Qidxs.data_ptr(), tuple(Qidxs.shape))
         hit = cache.get(key)
-        if hit is None or hit[0] != Qidxs._version:
+        # valid only for the very tensor object it was made from (a freed buffer's address can be reused), unmodified
+        if hit is None or hit[0] != Qidxs._version or hit[2]() is not Qidxs:
+            for k_ in [k_ for k_, h in cache.items() if h[2]() is None]:
+                del cache[k_]                                           # buffers that are gone
             b = Qidxs.contiguous().view(torch.uint8).view(Qidxs.shape[0], -1, 3).to(torch.int32)
-            hit = (Qidxs._version, ((b[..., 2] << 24) | (b[..., 1] << 16) | (b[..., 0] << 8)).contiguous())
+            hit = (Qidxs._version, ((b[..., 2] << 24) | (b[..., 1] << 16) | (b[..., 0] << 8)).contiguous(),
+                   weakref.ref(Qidxs))
             cache[key] = hit
         return hit[1]
 
