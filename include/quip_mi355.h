@@ -321,6 +321,9 @@ int quip_e8p_gemv_fused(const quip_gemv_fused_in* in, const void* const* qidxs,
  * split over 8 workgroups per head whose partial softmax states are merged by the last one to finish
  * (the one-workgroup-per-head walk is latency bound: 89 us at 2048 positions).  NULL: never split. */
 size_t quip_rope_attn_workspace_bytes(int32_t heads, int32_t head_dim);
+/* Greedy tail of the decode step: tok[0] = first index of the largest of the n fp16 logits (torch.argmax's tie
+ * rule), pos[0] += 1 (both int64 on the device) -- one launch instead of reduce + copy + add. */
+int quip_argmax_step_f16(const void* logits, int32_t n, void* tok, void* pos, quip_stream_t stream);
 int quip_rope_attn_decode_f16(const void* q, const void* k, const void* v, const float* cos,
                               const float* sin, const int64_t* pos, void* kcache, void* vcache,
                               void* out, int32_t heads, int32_t kv_heads, int32_t head_dim,

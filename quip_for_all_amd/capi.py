@@ -33,6 +33,7 @@ SIGNATURES = {
     "quip_d4_gemv_planes_group": [_P, _P, _P, _P, _P, _I32, _I32, _P],
     "quip_e8p_gemv_fused": [_P, _P, _P, _P, _P, _I32, _I32, _P],
     "quip_rope_attn_workspace_bytes": [_I32, _I32],
+    "quip_argmax_step_f16": [_P, _I32, _P, _P, _P],
     "quip_rope_attn_decode_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _P, _P],
     "quip_e8p_mm_origorder": [_P, _P, _P, _P, _I32, _I32, _I32, _P],
     "quip_e8p_mm_workspace_bytes": [_I32, _I32, _I32],

@@ -272,6 +272,13 @@ int quip_e8p_gemv_fused(const quip_gemv_fused_in* in, const void* const* qidxs,
   return e8p_gemv_mfma_fused_launch(f, qidxs, grid_packed_abs, ys, n32, count, k, GemvTune{}, (hipStream_t)stream);
 }
 
+int quip_argmax_step_f16(const void* logits, int32_t n, void* tok, void* pos, quip_stream_t stream) {
+  if (!logits || !tok || !pos) return QUIP_ERR_NULL_POINTER;
+  if (!aligned16(logits) || (reinterpret_cast<uintptr_t>(tok) & 7) || (reinterpret_cast<uintptr_t>(pos) & 7))
+    return QUIP_ERR_MISALIGNED;
+  return argmax_step_launch(logits, n, tok, pos, (hipStream_t)stream);
+}
+
 size_t quip_rope_attn_workspace_bytes(int32_t heads, int32_t head_dim) {
   return heads > 0 && head_dim > 0 ? rope_attn_workspace_bytes(heads, head_dim) : 0;
 }

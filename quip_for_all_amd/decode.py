@@ -265,6 +265,9 @@ class LlamaDecoder:
         s = self.s
         logits = F.rms_norm(h, (s.hidden,), self.final_norm, s.rms_eps) @ self.lm_head.T
         if getattr(self, "sampling", None) is None:
+            if logits.dtype == torch.float16 and logits.is_cuda:
+                torch.ops.quip_lib.argmax_step(logits, self.tok, self.pos)      # tok <- argmax, pos += 1: one launch
+                return logits
             self.tok.copy_(logits.argmax(-1))
         else:
             temperature, top_k = self.sampling

@@ -72,6 +72,8 @@ _SCHEMAS = {
     # decode-step glue between q/k/v_proj and o_proj: rope + KV-cache append + single-query attention
     "rope_attn_decode": "(Tensor q, Tensor k, Tensor v, Tensor cos, Tensor sin, Tensor pos, Tensor(a!) kcache, "
                         "Tensor(b!) vcache, Tensor(c!)? workspace) -> Tensor",
+    # greedy tail of the decode step: tok <- argmax(logits) (first maximum), pos += 1
+    "argmax_step": "(Tensor logits, Tensor(a!) tok, Tensor(b!) pos) -> ()",
     "had_transform_planes_fused": "(Tensor x, int n, int K, Tensor? had, bool transpose, Tensor? pre, float scale, "
                                   "Tensor? rms_weight, float rms_eps, Tensor? gate, float resid_scale=0.0) -> Tensor",
 }
@@ -278,6 +280,16 @@ def _had_transform_planes_rows_cuda(x, n, K, had, transpose, pre, scale, rms_wei
         capi.check(L.quip_had_transform_planes_rows(ctypes.byref(pr), rows, n, K, int(bool(transpose)), _stream(x)),
                    "quip_had_transform_planes_rows")
     return out
+
+
+def _argmax_step_cuda(logits, tok, pos):
+    _need(logits.dtype == torch.float16 and logits.is_contiguous() and logits.dim() <= 2
+          and (logits.dim() == 1 or logits.shape[0] == 1), "argmax_step: logits must be contiguous float16 (1, n)")
+    _need(tok.dtype == torch.int64 and pos.dtype == torch.int64 and tok.numel() >= 1 and pos.numel() >= 1
+          and tok.device == logits.device and pos.device == logits.device, "tok / pos: int64 on the logits' device")
+    with torch.cuda.device(logits.device):
+        capi.check(capi.lib().quip_argmax_step_f16(logits.data_ptr(), logits.numel(), tok.data_ptr(), pos.data_ptr(),
+                                                   _stream(logits)), "quip_argmax_step_f16")
 
 
 def _e8p_quantize_cuda(X, grid):
@@ -660,6 +672,7 @@ _IMPLS = {
     "had_transform_planes_rows": _had_transform_planes_rows_cuda,
     "e8p_gemv_planes_rows": _e8p_gemv_planes_rows_cuda,
     "e8p_quantize": _e8p_quantize_cuda,
+    "argmax_step": _argmax_step_cuda,
     "gemv_planes_rows_mode": _gemv_planes_rows_mode_cuda,
     "e8prvq3_gemv_planes_group": _e8prvq3_gemv_planes_group_cuda,
     "d4_gemv_planes": _d4_gemv_planes_cuda,
@@ -731,6 +744,7 @@ _reg_fake("e8p_gemv_planes_rows", lambda planes, Qidxs, grid:
           Qidxs.new_empty((planes.shape[0], Qidxs.shape[0]), dtype=torch.float16))
 _reg_fake("gemv_planes_rows_mode", lambda planes, Qidxs, grid, grid2, mode:
           Qidxs.new_empty((planes.shape[0], Qidxs.shape[0]), dtype=torch.float16))
+_reg_fake("argmax_step", lambda logits, tok, pos: None)
 _reg_fake("e8p_quantize", lambda X, grid: (torch.empty_like(X), X.new_empty((X.shape[0],), dtype=torch.int64)))
 _reg_fake("e8p_mm_planes_rows", lambda planes, Qidxs, grid:
           Qidxs.new_empty((len(planes), Qidxs.shape[0]), dtype=torch.float16))

@@ -200,3 +200,19 @@ def test_sampling_step_matches_reference_sampler_semantics():
     assert n_not_top1 > 0, "48 draws at T=0.6 over 5 candidates never left the arg-max: sampler is not sampling"
     # back to greedy: re-captures and reproduces the greedy tokens
     assert torch.equal(dec.generate(16, first_token=7), greedy)
+
+
+@pytest.mark.parametrize("n", [1, 7, 512, 32000, 32001, 128256])
+def test_argmax_step_matches_torch(n):
+    """greedy tail kernel: first index of the maximum (ties!), pos += 1"""
+    torch.manual_seed(n)
+    lg = (torch.randn(1, n, device="cuda:0") * 3).half()
+    if n > 16:
+        lg[0, n // 3] = lg.max() + 1          # a clear winner ...
+        lg[0, n // 2] = lg[0, n // 3]         # ... tied with a later index: the first one wins
+    tok = torch.zeros(1, dtype=torch.long, device="cuda:0")
+    pos = torch.full((1,), 41, dtype=torch.long, device="cuda:0")
+    torch.ops.quip_lib.argmax_step(lg, tok, pos)
+    assert int(tok[0]) == int(lg.float().argmax(-1)[0]) and int(pos[0]) == 42
+    if n > 16:
+        assert int(tok[0]) == n // 3
