@@ -81,6 +81,25 @@ __device__ __forceinline__ float block_reduce(float v, bool is_max, float* red, 
   return r;
 }
 
+// A sum (over the first nt threads) and a maximum of non-negative values (over the first nta <= nt threads) in
+// ONE pass: same trees, hence the same two values, as block_reduce(sum, false, red, ..) and
+// block_reduce(mx, true, red + 16, ..) -- one barrier and one LDS round trip instead of two.  red: 32 floats
+// nobody else is using (no leading barrier).
+__device__ __forceinline__ void block_reduce_sum_max(float& sum, float& mx, float* red, int tid, int nt, int nta) {
+  sum = wave_reduce_to_lane63<false>(sum);
+  mx = wave_reduce_to_lane63<true>(mx);
+  if ((tid & 63) == 63 && tid < nt) red[tid >> 6] = sum;
+  if ((tid & 63) == 63 && tid < nta) red[16 + (tid >> 6)] = mx;
+  if (nt < 64 && tid == nt - 1) red[0] = sum;
+  if (nta < 64 && tid == nta - 1) red[16] = mx;
+  __syncthreads();
+  float r = red[0], q = red[16];
+  for (int w = 1; w < ((nt + 63) >> 6); ++w) r = fadd(r, red[w]);
+  for (int w = 1; w < ((nta + 63) >> 6); ++w) q = fmaxf(q, red[16 + w]);
+  sum = r;
+  mx = q;
+}
+
 // 8 fp16 of a 16-byte piece -> fp32
 __device__ __forceinline__ void unpack8(const uint4& u, float o[8]) {
   const uint32_t w[4] = {u.x, u.y, u.z, u.w};

@@ -373,7 +373,10 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
     __syncthreads();
   }
   float scale = a.scale;
-  if (a.rms_w) {
+  // planes of a K == 1 transform: the RMSNorm statistic is only needed with the planes' bound, after the
+  // transform -- both workgroup reductions then share one pass (see the epilogue)
+  const bool defer_rms = PLANES && !TALL && (KONE || K == 1) && a.rms_w != nullptr;
+  if (a.rms_w && !defer_rms) {
     // every workgroup sees the whole input row (K == 1: it is the row; K > 1: the k loop)
     const float tot = block_reduce(ss_x, false, red, tid, nt, false);
     scale = had::rms_scale(a.scale, tot, a.in_features, a.rms_eps);
@@ -388,7 +391,14 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
   // (3) epilogue
   if constexpr (PLANES) {
     float bound;
-    if (K == 1) {
+    if (defer_rms) {
+      // max_r |fl(v_r * scale)| == fl(max_r |v_r| * |scale|) (rounding is monotonic and sign symmetric): reduce the
+      // unscaled maximum together with the sum of squares, then scale -- the same bits as two separate passes
+      float tot = ss_x, mx = act ? had::absmax16(v, 1.f) : 0.f;
+      had::block_reduce_sum_max(tot, mx, red, tid, nt, nta);
+      scale = had::rms_scale(a.scale, tot, a.in_features, a.rms_eps);
+      bound = had::fmul(mx, fabsf(scale));
+    } else if (K == 1) {
       bound = block_reduce(act ? had::absmax16(v, scale) : 0.f, true, red + 16, tid, nta, false);
     } else {
       bound = sqrtf(block_reduce(ss_in, false, red + 16, tid, nt, false)) * sqrtf((float)L) * fabsf(scale) * 1.0625f;
