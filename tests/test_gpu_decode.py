@@ -216,3 +216,18 @@ def test_argmax_step_matches_torch(n):
     assert int(tok[0]) == int(lg.float().argmax(-1)[0]) and int(pos[0]) == 42
     if n > 16:
         assert int(tok[0]) == n // 3
+
+
+def test_llama3_8b_shaped_decoder_graph_equals_eager():
+    """grouped-query attention, ffn = 7 x 2048 (K = 7 wide transforms), q / k / v of different widths in one output
+    launch, 128 K vocabulary: the captured step equals the eager step and the plain (unfused) step"""
+    from quip_for_all_amd.decode import LlamaDecoder, LlamaShape
+    shape = LlamaShape(hidden=4096, ffn=14336, layers=2, heads=32, kv_heads=8, vocab=128256)
+    dec = LlamaDecoder(shape, max_len=32, device="cuda:0", seed=5, device_init=True)
+    a = dec.generate(6, first_token=11, use_graph=True)
+    b = dec.generate(6, first_token=11, use_graph=False)
+    assert torch.equal(a, b)
+    dec.fused_prologue = False
+    dec.graph = None
+    c = dec.generate(6, first_token=11, use_graph=False)
+    assert torch.equal(a, c)
