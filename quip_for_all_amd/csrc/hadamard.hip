@@ -645,12 +645,12 @@ __global__ __launch_bounds__(256, 3) void had_tall_batch_kernel(HadGroup grp, in
   }
 }
 
-// K == 1 transform for BATCHES (prefill), fp16 output, L = 2^LOGL in {1024, 2048, 4096}: the same arithmetic as
+// K == 1 transform for BATCHES (prefill), fp16 output, L = 2^LOGL in {1024, 2048, 4096, 8192}: the same arithmetic as
 // had_fast_kernel<false, false, 256, true> without its decode-only paths (chain, planes, RMSNorm statistic), so
 // that it fits 64 VGPRs: eight row-workgroups resident per CU instead of four -- a batch of rows is bound by the
 // bytes in flight, not by the latency of one row.
 template <int LOGL>
-__global__ __launch_bounds__(256, 8) void had_kone_batch_kernel(HadGroup grp) {
+__global__ __launch_bounds__((LOGL > 12 ? 512 : 256), (LOGL > 12 ? 4 : 8)) void had_kone_batch_kernel(HadGroup grp) {
   const HadArgs a = grp.p[blockIdx.z];
   extern __shared__ __attribute__((aligned(16))) float buf[];
   constexpr int L = 1 << LOGL;
@@ -874,13 +874,14 @@ int launch(HadGroup& g, int count, int64_t rows, hipStream_t stream) {
                       : launch_one(had_fast_kernel<false, false, 1024>, c2[1], g, grid, (L / 16) * tg, lds2, stream);
       }
     }
-    if (K == 1 && !planes && rows >= 32 && (L == 1024 || L == 2048 || L == 4096)) {   // prefill batches
+    if (K == 1 && !planes && rows >= 32 && (L == 1024 || L == 2048 || L == 4096 || L == 8192)) {   // prefill batches
       bool ok = true;
       for (int i = 0; i < count; ++i)
         ok = ok && g.p[i].vec && g.p[i].vec_out && !g.p[i].rms_w && !g.p[i].z && g.p[i].out_features % 8 == 0;
       if (ok) {
         const int lds1 = had::buf_floats(L) * 4;
-        if (L == 4096) hipLaunchKernelGGL(had_kone_batch_kernel<12>, grid, dim3(L / 16), lds1, stream, g);
+        if (L == 8192) hipLaunchKernelGGL(had_kone_batch_kernel<13>, grid, dim3(L / 16), lds1, stream, g);
+        else if (L == 4096) hipLaunchKernelGGL(had_kone_batch_kernel<12>, grid, dim3(L / 16), lds1, stream, g);
         else if (L == 2048) hipLaunchKernelGGL(had_kone_batch_kernel<11>, grid, dim3(L / 16), lds1, stream, g);
         else hipLaunchKernelGGL(had_kone_batch_kernel<10>, grid, dim3(L / 16), lds1, stream, g);
         return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;

@@ -447,7 +447,8 @@ def test_tall_hadamard_batches_equal_single_rows(n, rows, side):
         assert full.shape == (rows, out_f)
 
 
-@pytest.mark.parametrize("n,rows,out_f", [(4096, 100, 4096), (1024, 33, 1000), (2048, 64, 2048), (4096, 70000, 4096)])
+@pytest.mark.parametrize("n,rows,out_f", [(4096, 100, 4096), (1024, 33, 1000), (2048, 64, 2048), (4096, 70000, 4096),
+                                          (8192, 48, 8192)])
 def test_kone_hadamard_batches_equal_single_rows(n, rows, out_f):
     """prefill batches of the power-of-two transform (had_kone_batch_kernel: 64 VGPRs, eight rows resident per CU)
     give bit for bit what the latency-shaped launch gives row by row (input side with gate / SU, output side with
