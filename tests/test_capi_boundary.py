@@ -92,3 +92,27 @@ def test_quantlinear_layout_matches_reference(golden_meta):
         ref = {k: v for k, v in lay.items() if not k.startswith("_")}
         assert mine == ref, cbid
         assert [L.K_left, L.K_right, L.q_in_features, L.q_out_features] == lay["_K"]
+
+
+def test_product_fails_loudly_without_the_native_library(tmp_path):
+    """no CPU fallback: with the library missing the first native call raises QuipNativeError (fresh interpreter,
+    QUIP_LIB_PATH pointing at nothing)"""
+    import subprocess
+    import sys
+    code = ("import quip_for_all_amd.capi as c\n"
+            "try:\n    c.lib()\nexcept c.QuipNativeError as e:\n    print('RAISED', 'no CPU fallback' in str(e).lower() or 'missing' in str(e))\n"
+            "else:\n    print('LOADED')\n")
+    env = dict(os.environ, QUIP_LIB_PATH=str(tmp_path / "nope.so"), PYTHONPATH=REPO)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=REPO, timeout=300)
+    assert "RAISED True" in out.stdout, (out.stdout, out.stderr[-500:])
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under quip_for_all_amd/ may import it"""
+    import re
+    pkg = os.path.join(REPO, "quip_for_all_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(root, f)
