@@ -276,7 +276,7 @@ def main():
                 out["prefill"] = prefill_config5(dec)
             except Exception as e:  # an extra, never the headline
                 out["prefill"] = {"error": repr(e)}
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only (bench contract)
             try:
                 out["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # the checker must never take the bench down
