@@ -56,6 +56,9 @@ _INTERNAL = {
     "quip_e8p_x_to_planes_laneorder": [_P, _P, _I32, _P],
     "quip_e8p_gemv_fused_tuned": [_P, _P, _P, _P, _P, _I32, _I32, _P, _P],
     "quip_e8p_gemv_group_tuned": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P],
+    "quip_e8p_gemv_v2_tuned": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P],
+    "quip_e8p_gemv_v2_group_tuned": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P],
+    "quip_e8p_gemv_v2_workspace_bytes": [_I32],
     "quip_e8p_gemv_tuned": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P],
 }
 

@@ -376,6 +376,32 @@ int quip_e8p_gemv_tuned(const void* x, const void* qidxs, const void* grid, void
   return e8p_gemv_i8_launch(x, kernel == 3 ? 1 : 0, qidxs, grid, y, n, k, t, (hipStream_t)stream);
 }
 
+int quip_e8p_gemv_v2_tuned(const void* planes, const void* qidxs, const void* grid, void* y, void* ws, int32_t n,
+                           int32_t k, int32_t rep2, int32_t slots, int32_t blocks, int32_t ksplit,
+                           int32_t max_waves, int32_t runlen, void* dbg, quip_stream_t stream) {
+  if (!planes || !qidxs || !grid || !y) return QUIP_ERR_NULL_POINTER;
+  GemvTune t;
+  t.rep = rep2; t.rows = slots; t.blocks = blocks; t.waves_g = ksplit; t.max_waves = max_waves; t.dbg = dbg;
+  t.digits = runlen;
+  return e8p_gemv_v2_launch(planes, qidxs, grid, y, ws, n, k, t, (hipStream_t)stream);
+}
+
+int quip_e8p_gemv_v2_group_tuned(const void* const* planes, const void* const* qidxs, const void* grid,
+                                 void* const* ys, void* ws, const int32_t* ns, int32_t count, int32_t k, int32_t rep,
+                                 int32_t slots, int32_t blocks, int32_t ksplit, int32_t max_waves, int32_t runlen,
+                                 void* dbg, quip_stream_t stream) {
+  if (!planes || !qidxs || !grid || !ys || !ns) return QUIP_ERR_NULL_POINTER;
+  if (count < 1 || count > QUIP_MAX_GROUP) return QUIP_ERR_UNSUPPORTED;
+  GemvTune t;
+  t.rep = rep; t.rows = slots; t.blocks = blocks; t.waves_g = ksplit; t.max_waves = max_waves; t.dbg = dbg;
+  t.digits = runlen;
+  int n32[QUIP_MAX_GROUP];
+  for (int i = 0; i < count; ++i) n32[i] = ns[i];
+  return e8p_gemv_v2_group_launch(planes, qidxs, grid, ys, ws, n32, count, k, t, (hipStream_t)stream);
+}
+
+size_t quip_e8p_gemv_v2_workspace_bytes(int32_t n) { return e8p_gemv_v2_workspace_words(n) * 4; }
+
 int quip_e8p_gemv_fused_tuned(const quip_gemv_fused_in* in, const void* const* qidxs, const void* grid,
                               void* const* ys, const int32_t* ns, int32_t count, int32_t k, void* dbg,
                               quip_stream_t stream) {

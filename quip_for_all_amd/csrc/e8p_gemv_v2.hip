@@ -1,0 +1,581 @@
+// E8P12 decode GEMV for gfx950, second generation of the matrix-core kernel (e8p_gemv_mfma.hip):
+// same arithmetic (4w = T1[abs] ^ T2[sign] as int8, x as three balanced int8 digit planes, exact int32
+// sums from v_mfma_i32_16x16x64_i8, one fp16 rounding of y -- every output bit identical to the first
+// kernel's), different mapping.
+//
+// Replaces the M = 1 use of tinygemm_m16n8k16_chunk_kernel<.., BLayout_E8, ..> (origin_order.cu:388-555,
+// 604-648).
+//
+// What changed, and why (profiles/r01_*: the first kernel streamed at the rate of its access pattern,
+// 16 rows x 64 B per load instruction, and spent 3-4 us per launch outside the stream):
+//
+//  * Whole-line loads.  The MFMA has 16 A rows and x needs three (its digit planes).  Here the A rows form
+//    FOUR groups h = 0..3 of (plane 0, 1, 2, spare); group h holds the digits of k-chunk 4h + q where the
+//    plain layout holds chunk q.  B column n = 4h + r then carries weight row r, chunk 4h + q, and only
+//    D rows 4h..4h+2 of column 4h + r mean anything: S_d of row r over the chunks of group h.  So ONE load
+//    instruction covers 4 weight rows x 256 contiguous bytes (lane (n, q): row n & 3, 16-byte chunk
+//    4 (n >> 2) + q) and feeds four MFMAs without any lane exchange.
+//  * A wave walks along K for the same four rows ("run": up to `runlen` consecutive 1024-k segments of a row
+//    quad) and keeps the sums in the MFMA accumulator; it touches the LDS accumulators once per run.
+//    Runs are handed out by an LDS counter, so that the waves the SIMD arbiters favour take more of them
+//    and the workgroup's tail stays short.
+//  * x digits in LDS are stored in fragment order ([q][t][3h + d] 16-byte units per 1024 k), which makes the
+//    ds_read_b128 of the A fragments bank-conflict free (plane-major storage put planes 0 / 1 / 2 of one
+//    k on the same banks).
+//  * K split across workgroups (ksplit > 1) whenever the digit image of the whole row does not fit beside
+//    the tables: partial sums are integers, so they are combined with agent-scope integer atomics in a
+//    caller-provided zeroed workspace and the last workgroup to arrive converts, stores y and leaves the
+//    workspace zeroed again.  Exact, order independent, bit identical to the unsplit launch.
+//  * Up to three problems of the same K per launch (q/k/v, gate/up): tables, launch and drain paid once.
+//  * SLOTS load instructions (1 KiB each) per wave are in flight from the first instructions of the kernel,
+//    so the table build runs in the shadow of the first HBM burst.
+#include "quip_device.hip.h"
+#include "quip_internal.h"
+
+namespace quip {
+
+namespace {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) u32x2* lds_u2_ptr;
+typedef const __attribute__((address_space(3))) i32x4* lds_i4_ptr;
+
+constexpr int kSegBytes = 3072;   // LDS bytes of the digit image per 1024 k: 16 (q, t) rows x 12 units x 16 B
+constexpr int kMaxG = 3;
+
+// LDS map: T1 (REP1 copies) at 0, T2 (REP2 copies) behind it, then the digit images of this workgroup's K range
+// (one per problem) and the int32 accumulators [rows][4] (+ one word: the run counter).
+// (REP1, REP2) = (32, 32): every table lookup conflict free, 128 KiB; (32, 16): two-way conflicts on the sign
+// lookups, 96 KiB; (16, 16): two-way on both, 64 KiB (short launches: half the table build).
+template <int REP1, int REP2>
+struct V2Lds {
+  static constexpr int kT2 = 256 * REP1 * 8;
+  static constexpr int kX = kT2 + 256 * REP2 * 8;
+  static constexpr int kTotal = 160 * 1024;
+};
+
+__device__ __forceinline__ uint2 v2_lds_read8(uint32_t addr) {
+  const u32x2 v = *reinterpret_cast<lds_u2_ptr>((uintptr_t)addr);
+  return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ i32x4 v2_lds_read16i(uint32_t addr) {
+  return *reinterpret_cast<lds_i4_ptr>((uintptr_t)addr);
+}
+
+// compile-time image of the sign table: entry s = XOR mask that turns the bytes 4a | 1 of an abs entry
+// into 4w (negation of a byte whose low bits are 11 is ^0xFC; the odd-parity shift -2 is ^0x02);
+// restates decode8weights, origin_order.cu:211-253
+struct V2T2Image {
+  uint2 v[256];
+  constexpr V2T2Image() : v{} {
+    for (int s = 0; s < 256; ++s) {
+      int par = 0;
+      for (int b = 0; b < 8; ++b) par ^= (s >> b) & 1;
+      const int sv = s ^ par;
+      uint32_t lo = 0, hi = 0;
+      for (int p = 0; p < 4; ++p) {
+        lo |= (((sv >> (7 - e8p_byte_of_pos(p))) & 1) ? 0xfcu : 0u) << (8 * p);
+        hi |= (((sv >> (7 - e8p_byte_of_pos(p + 4))) & 1) ? 0xfcu : 0u) << (8 * p);
+      }
+      const uint32_t sh = par ? 0x02020202u : 0u;
+      v[s].x = lo ^ sh;
+      v[s].y = hi ^ sh;
+    }
+  }
+};
+__device__ const V2T2Image kV2T2Img{};
+
+struct V2Args {
+  const uint4* W[kMaxG];          // (N, K / 8) int16 codes
+  const uint8_t* planes[kMaxG];   // [3][kp_src] digit bytes + int32 shift word at 3 * kp_src
+  f16* y[kMaxG];
+  int* ws[kMaxG];                 // ksplit > 1: zeroed int32 [N][4] accumulators followed by [row blocks] arrival counters
+  int N[kMaxG];
+  int rpb[kMaxG];                 // rows per workgroup (multiple of 4)
+  const uint64_t* grid;           // grid_packed_abs
+  int K;
+  int kp_src;                     // digits per plane in `planes` (K rounded up to 512)
+  int segs;                       // 1024-k segments of a row (ceil)
+  int spw;                        // segments per workgroup (K split)
+  int ksplit;
+  int runlen;                     // segments per run
+  uint64_t* dbg;
+};
+
+template <int REP1, int REP2, int SLOTS, int G>
+__global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using L = V2Lds<REP1, REP2>;
+#define V2_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+  V2_STAMP(0);
+  const int tid = threadIdx.x;
+  const int nthreads = blockDim.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = __builtin_amdgcn_readfirstlane(nthreads >> 6);
+  const int n = lane & 15, q = lane >> 4;
+  const int r = n & 3, h = n >> 2;
+  const int rb = (int)blockIdx.x / a.ksplit, ks = (int)blockIdx.x - rb * a.ksplit;
+  const int seg0 = ks * a.spw;
+  const int S = min(a.segs, seg0 + a.spw) - seg0;     // segments of this workgroup
+  const int rpr = (S + a.runlen - 1) / a.runlen;      // runs per row quad
+  const int row_u4 = a.K >> 6;                        // uint4 per packed row
+  int row0[G], rows_here[G], qbase[G + 1], rbase[G];  // first row, rows, first row quad / accumulator row of a problem
+  qbase[0] = 0;
+#pragma unroll
+  for (int p = 0; p < G; ++p) {
+    row0[p] = rb * a.rpb[p];
+    rows_here[p] = max(0, min(a.N[p], row0[p] + a.rpb[p]) - row0[p]);
+    qbase[p + 1] = qbase[p] + ((rows_here[p] + 3) >> 2);
+    rbase[p] = p == 0 ? 0 : rbase[p - 1] + a.rpb[p - 1];
+  }
+  const int nruns = qbase[G] * rpr;
+  const uint32_t xbase = (uint32_t)L::kX;
+  const uint32_t accbase = xbase + (uint32_t)(G * S) * kSegBytes;
+  int* accs = reinterpret_cast<int*>(smem + accbase);
+  const int accwords = (rbase[G - 1] + a.rpb[G - 1]) * 4;
+  int* counter = accs + accwords;
+
+  // (0) loads, in the order in which they are needed (VMEM returns in issue order); everything is counted
+  int sh[G];
+#pragma unroll
+  for (int p = 0; p < G; ++p)
+    asm volatile("global_load_dword %0, %1, off" : "=v"(sh[p]) : "v"(a.planes[p] + (size_t)3 * a.kp_src) : "memory");
+  u32x2 tsrc;
+  {
+    const int e = (wave & 7) * 32 + (lane & 31);
+    const uint2* t1 = reinterpret_cast<const uint2*>(a.grid) + e;
+    const uint2* t2 = &kV2T2Img.v[e];
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(tsrc) : "v"((lane & 32) ? t2 : t1) : "memory");
+  }
+  // digit images: 16-byte piece i = (problem p, plane d, k16 index g) in source order; every workgroup starts at
+  // a different piece so that they do not all queue on the same L2 channels
+  constexpr int XR = 6;
+  const int gper = S * 64;                  // pieces per plane in this workgroup's K range
+  const int ppp = 3 * gper;                 // pieces per problem
+  const int xpieces = G * ppp;
+  const int src_pieces = a.kp_src >> 4;     // pieces per plane in the source
+  const int rot = (int)(((uint32_t)blockIdx.x * 613u) % (uint32_t)xpieces);
+  u32x4 xr[XR];
+  uint32_t xdst[XR];                        // LDS destination; 0xffffffff: none; bit 31: store zeros
+  const uint4* hot = reinterpret_cast<const uint4*>(a.planes[0]) + (tid & 127);   // L2-resident filler for past-the-end slots
+#pragma unroll
+  for (int j = 0; j < XR; ++j) {
+    if (j * nthreads >= xpieces) {   // workgroup uniform: nothing left to fetch, keep the load count
+      asm_load16(xr[j], hot);
+      xdst[j] = 0xffffffffu;
+      continue;
+    }
+    const int i = tid + j * nthreads;
+    int ic = i + rot;
+    ic = ic >= xpieces ? ic - xpieces : ic;
+    ic = i < xpieces ? ic : 0;
+    int p = 0;
+#pragma unroll
+    for (int g2 = 1; g2 < G; ++g2) p += ic >= g2 * ppp ? 1 : 0;
+    const int jj = ic - p * ppp;
+    const int d = (jj >= gper ? 1 : 0) + (jj >= 2 * gper ? 1 : 0);
+    const int g = jj - d * gper;
+    const int s = g >> 6, c = (g >> 2) & 15, t = g & 3;
+    const int sp = seg0 * 64 + g;
+    const bool real = sp < src_pieces;      // beyond the source's zero padding: zeros
+    const uint8_t* src = a.planes[0];
+#pragma unroll
+    for (int g2 = 1; g2 < G; ++g2) {
+      src = p == g2 ? a.planes[g2] : src;
+      asm volatile("" : "+v"(src));
+    }
+    asm_load16(xr[j], reinterpret_cast<const uint4*>(src + (size_t)d * a.kp_src) + (real ? sp : 0));
+    const uint32_t dst = xbase + (uint32_t)(p * S + s) * kSegBytes + (uint32_t)((((c & 3) * 4 + t) * 12 + 3 * (c >> 2) + d) * 16);
+    xdst[j] = i < xpieces ? (dst | (real ? 0u : 0x80000000u)) : 0xffffffffu;
+  }
+
+  // run -> (problem, row quad, first segment, length); everything wave uniform
+  auto problem_of_quad = [&](int gq) -> int {
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < G; ++i) p += gq >= qbase[i] ? 1 : 0;
+    return p;
+  };
+  auto pick = [&](const int* arr, int p) -> int {   // arr[p] without dynamic indexing (scratch accesses are VMEM)
+    int v = arr[0];
+#pragma unroll
+    for (int i = 1; i < G; ++i) {
+      v = p == i ? arr[i] : v;
+      asm volatile("" : "+s"(v));
+    }
+    return v;
+  };
+  // load cursor
+  int l_run = wave;                   // current run (>= nruns: none)
+  int l_gq = 0, l_seg = 0, l_left = 0;
+  auto open_run = [&](int run) {
+    l_run = run;
+    if (run < nruns) {
+      l_gq = run / rpr;
+      const int ri = run - l_gq * rpr;
+      l_seg = ri * a.runlen;
+      l_left = min(a.runlen, S - l_seg);
+    } else {
+      l_left = 0;
+    }
+  };
+  open_run(wave);
+  // per-slot description of the unit in flight: accumulator row quad, digit image offset, flags
+  int s_gq[SLOTS], s_x[SLOTS], s_flag[SLOTS];   // flag: 0 filler, 1 unit, 3 unit that ends its run
+  auto issue = [&](u32x4& dst, int& m_gq, int& m_x, int& m_flag) {
+    const bool real = l_left > 0;   // wave uniform
+    const int p = problem_of_quad(l_gq);
+    int row = pick(row0, p) + 4 * (l_gq - pick(qbase, p)) + r;
+    const int N = pick(a.N, p);
+    row = row < N ? row : N - 1;
+    int off = (seg0 + l_seg) * 16 + 4 * h + q;
+    off = off < row_u4 ? off : (seg0 + l_seg) * 16;     // K % 1024 != 0: re-read a valid piece (its digits are zero)
+    const uint4* W = a.W[0];
+#pragma unroll
+    for (int i = 1; i < G; ++i) {
+      W = p == i ? a.W[i] : W;
+      asm volatile("" : "+s"(W));
+    }
+    const uint4* ptr = real ? W + (size_t)row * row_u4 + off : hot;
+    asm_load16_nt(dst, ptr);
+    m_gq = (pick(rbase, p) >> 2) + (l_gq - pick(qbase, p));
+    m_x = __builtin_amdgcn_readfirstlane((p * S + l_seg) * kSegBytes);   // wave uniform: keep it out of the VALU
+    m_flag = real ? (l_left == 1 ? 3 : 1) : 0;
+    if (real) {
+      ++l_seg;
+      --l_left;
+    }
+  };
+  // claims the next run for the load cursor when the current one is used up (between units, once the LDS
+  // counter exists)
+  auto refill = [&]() {
+    if (l_left == 0 && l_run < nruns) {
+      int nxt = 0;
+      if (lane == 0) nxt = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      open_run(__builtin_amdgcn_readfirstlane(nxt) + nwaves);
+    }
+  };
+  u32x4 slot[SLOTS];
+  // (no refill here: the run counter does not exist yet; a first run shorter than SLOTS leaves filler slots)
+#pragma unroll
+  for (int i = 0; i < SLOTS; ++i) issue(slot[i], s_gq[i], s_x[i], s_flag[i]);
+  V2_STAMP(1);
+
+  // (1) accumulators + run counter, tables
+  for (int i = tid; i <= accwords; i += nthreads) accs[i] = 0;
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(tsrc) : "n"(XR + SLOTS) : "memory");
+  if (wave < 8) {
+    const bool second = (lane & 32) != 0;
+    const uint32_t t1x = __builtin_amdgcn_perm(0u, tsrc.x, 0x03010200u) | 0x01010101u;
+    const uint32_t t1y = __builtin_amdgcn_perm(0u, tsrc.y, 0x03010200u) | 0x01010101u;
+    const u32x2 val = {second ? tsrc.x : t1x, second ? tsrc.y : t1y};
+    const uint32_t row = (uint32_t)(wave * 32 + (lane & 31));
+    const uint32_t rowbase = second ? (uint32_t)L::kT2 + row * (REP2 * 8) : row * (REP1 * 8);
+    const uint32_t mask = second ? (uint32_t)(REP2 - 1) : (uint32_t)(REP1 - 1);
+    constexpr int kMaxRep = REP1 > REP2 ? REP1 : REP2;
+#pragma unroll
+    for (int c = 0; c < kMaxRep; ++c) {
+      if (c < (second ? REP2 : REP1)) {
+        const uint32_t copy = (uint32_t)(lane + c) & mask;
+        *reinterpret_cast<__attribute__((address_space(3))) u32x2*>((uintptr_t)(rowbase + copy * 8)) = val;
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < G; ++p) asm volatile("" : "+v"(sh[p]));   // landed before tsrc
+  V2_STAMP(2);
+
+  // (2) digit images into LDS in fragment order: unit ((q * 4 + t) * 12 + 3 h + d) of segment s holds plane d,
+  //     k = 1024 s + 64 (4 h + q) + 16 t .. +15
+  asm volatile("s_waitcnt vmcnt(%6)"
+               : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5])
+               : "n"(SLOTS)
+               : "memory");
+#pragma unroll
+  for (int j = 0; j < XR; ++j) {
+    if (xdst[j] != 0xffffffffu) {
+      const u32x4 v = (xdst[j] & 0x80000000u) ? u32x4{0u, 0u, 0u, 0u} : xr[j];
+      *reinterpret_cast<__attribute__((address_space(3))) u32x4*>((uintptr_t)(xdst[j] & 0x7fffffffu)) = v;
+    }
+  }
+  __syncthreads();
+  V2_STAMP(3);
+
+  uint32_t lane_c1, lane_c2;
+  if constexpr (REP1 == 32) lane_c1 = ((uint32_t)(lane & 31) << 3) | ((uint32_t)(L::kT2 >> 16) << 16);
+  else lane_c1 = (uint32_t)(lane & 15) << 3;
+  lane_c2 = ((uint32_t)(lane & 15) << 3) | (uint32_t)L::kT2;
+  // A fragment of this lane (A row m = lane & 15 = 4 h' + d', k block q): unit (q * 4 + t) * 12 + 3 h' + min(d', 2)
+  const uint32_t xlane = xbase + (uint32_t)((q * 48 + 3 * (n >> 2) + min(n & 3, 2)) * 16);
+  const bool dvalid = q == h;      // this lane's D registers 0..2 = S_h, S_m, S_l of row r over chunk group h
+
+  // (3) the stream
+  i32x4 acc = {0, 0, 0, 0}, prev = {0, 0, 0, 0};
+  bool more = true;
+  while (more) {
+    more = false;
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      asm volatile("s_waitcnt vmcnt(%1)" : "+v"(slot[i]) : "n"(SLOTS - 1) : "memory");
+      uint32_t a1l[4], a2l[4], a1h[4], a2h[4];
+      const uint32_t dw[4] = {slot[i].x, slot[i].y, slot[i].z, slot[i].w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if constexpr (REP1 == 32) {
+          // T1 (32 copies): idx << 8 | (lane & 31) << 3: byte aligned, one v_perm_b32
+          a1l[t] = __builtin_amdgcn_perm(dw[t], lane_c1, 0x0c0c0500u);
+          a1h[t] = __builtin_amdgcn_perm(dw[t], lane_c1, 0x0c0c0700u);
+        } else {
+          a1l[t] = ((dw[t] >> 1) & 0x7f80u) | lane_c1;
+          a1h[t] = ((dw[t] >> 17) & 0x7f80u) | lane_c1;
+        }
+        if constexpr (REP1 == 32 && REP2 == 32) {
+          // T2 base 0x10000 comes from byte 2 of lane_c1
+          a2l[t] = __builtin_amdgcn_perm(dw[t], lane_c1, 0x0c020400u);
+          a2h[t] = __builtin_amdgcn_perm(dw[t], lane_c1, 0x0c020600u);
+        } else {
+          a2l[t] = ((dw[t] << 7) & 0x7f80u) | lane_c2;
+          a2h[t] = ((dw[t] >> 9) & 0x7f80u) | lane_c2;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(a1l[t]), "+v"(a2l[t]), "+v"(a1h[t]), "+v"(a2h[t]));
+      const int gq = s_gq[i], xo = s_x[i], flag = s_flag[i];
+      refill();
+      issue(slot[i], s_gq[i], s_x[i], s_flag[i]);
+      more = more || s_flag[i] != 0;
+      if (flag) {   // wave uniform
+        const uint32_t xa = xlane + (uint32_t)xo;
+        uint2 t1l[4], t2l[4], t1h[4], t2h[4];
+        i32x4 A[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          t1l[t] = v2_lds_read8(a1l[t]); t2l[t] = v2_lds_read8(a2l[t]);
+          t1h[t] = v2_lds_read8(a1h[t]); t2h[t] = v2_lds_read8(a2h[t]);
+          A[t] = v2_lds_read16i(xa + (uint32_t)t * 192u);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const i32x4 B = {(int)(t1l[t].x ^ t2l[t].x), (int)(t1l[t].y ^ t2l[t].y),
+                           (int)(t1h[t].x ^ t2h[t].x), (int)(t1h[t].y ^ t2h[t].y)};
+          acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t], B, acc, 0, 0, 0);
+        }
+        if (flag & 2) {   // run finished: hand its sums to the LDS accumulators
+          // The MFMA accumulator is never reset (a reset in this rare branch made the compiler copy / select the
+          // MFMA result in the common path, i.e. drain the matrix pipeline after every unit): a run's sums are
+          // the difference to the accumulator at the previous flush (int32 wrap-around arithmetic is exact here).
+          const int dx = acc.x - prev.x, dy = acc.y - prev.y, dz = acc.z - prev.z;
+          // prev += d, i.e. prev = acc.  Through asm: a plain assignment is if-converted into selects on the MFMA
+          // result outside this branch.  The asm reads only VALU results (an asm statement that read the MFMA
+          // result itself would need hand-placed wait states).
+          asm volatile("v_add_u32 %0, %0, %3\n\tv_add_u32 %1, %1, %4\n\tv_add_u32 %2, %2, %5"
+                       : "+v"(prev.x), "+v"(prev.y), "+v"(prev.z)
+                       : "v"(dx), "v"(dy), "v"(dz));
+          if (dvalid) {
+            int* dst = accs + (gq * 4 + r) * 4;
+            __hip_atomic_fetch_add(dst + 0, dx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(dst + 1, dy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(dst + 2, dz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the trailing filler loads
+  V2_STAMP(4);
+  if (a.dbg && lane == 0)   // slot 7: the last wave to leave the stream
+    atomicMax(reinterpret_cast<unsigned long long*>(a.dbg + blockIdx.x * 8 + 7), (unsigned long long)__builtin_amdgcn_s_memtime());
+  __syncthreads();
+  V2_STAMP(5);
+
+  // (4) y = 2^(-sh-2) (65536 S_h + 256 S_m + S_l), one fp16 rounding
+  if (a.ksplit == 1) {
+#pragma unroll
+    for (int p = 0; p < G; ++p) {
+      const float unscale = as_f32((uint32_t)(127 - sh[p] - 2) << 23);
+      for (int t = tid; t < rows_here[p]; t += nthreads) {
+        const int* s3 = accs + (rbase[p] + t) * 4;
+        const float f = __builtin_fmaf((float)s3[0], 65536.f, __builtin_fmaf((float)s3[1], 256.f, (float)s3[2]));
+        a.y[p][row0[p] + t] = (f16)(f * unscale);
+      }
+    }
+  } else {
+    // partial sums of this K range -> workspace (agent-scope integer atomics: exact, order independent)
+#pragma unroll
+    for (int p = 0; p < G; ++p) {
+      for (int t = tid; t < rows_here[p]; t += nthreads) {
+        const int* s3 = accs + (rbase[p] + t) * 4;
+        int* g = a.ws[p] + (size_t)(row0[p] + t) * 4;
+        __hip_atomic_fetch_add(g + 0, s3[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(g + 1, s3[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(g + 2, s3[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's atomics have been performed
+    __syncthreads();                                    // ... and everybody's
+    int* cnt = a.ws[0] + (size_t)a.N[0] * 4 + rb;
+    int* flag = accs;                                   // LDS word, free after the barrier
+    if (tid == 0) *flag = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*flag == a.ksplit - 1) {                        // last to arrive: every partial sum is in
+#pragma unroll
+      for (int p = 0; p < G; ++p) {
+        const float unscale = as_f32((uint32_t)(127 - sh[p] - 2) << 23);
+        for (int t = tid; t < rows_here[p]; t += nthreads) {
+          int* g = a.ws[p] + (size_t)(row0[p] + t) * 4;
+          const int s0 = __hip_atomic_exchange(g + 0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int s1 = __hip_atomic_exchange(g + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int s2 = __hip_atomic_exchange(g + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const float f = __builtin_fmaf((float)s0, 65536.f, __builtin_fmaf((float)s1, 256.f, (float)s2));
+          a.y[p][row0[p] + t] = (f16)(f * unscale);
+        }
+      }
+      if (tid == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  V2_STAMP(6);
+#undef V2_STAMP
+}
+
+template <int REP1, int REP2, int SLOTS, int G>
+int v2_launch(const V2Args& a, int nblocks, int threads, int lds, hipStream_t stream) {
+  auto kern = e8p_gemv_v2_kernel<REP1, REP2, SLOTS, G>;
+  static int configured = 0;   // benign race: idempotent attribute
+  if (lds > configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+        hipSuccess)
+      return QUIP_ERR_LAUNCH;
+    configured = lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(threads), lds, stream, a);
+  return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+}
+
+// rep code: 32 = (32, 32) copies, 24 = (32, 16), 16 = (16, 16)
+static int lds_x(int rep) { return rep == 32 ? V2Lds<32, 32>::kX : (rep == 24 ? V2Lds<32, 16>::kX : V2Lds<16, 16>::kX); }
+
+template <int G>
+int v2_group_launch(const void* const* planes, const void* const* qidxs, const void* grid, void* const* ys,
+                    void* ws, const int* ns, int k, const GemvTune& tune, hipStream_t stream) {
+  const int ncu = device_cu_count();
+  const int segs = (k + 1023) >> 10;
+  const int slots = tune.rows > 0 ? tune.rows : 2;
+  // Candidates (table replication, K split).  K is split only when the digit images of the whole rows do not fit
+  // even beside the smallest tables, because combining partial sums across workgroups costs two more memory round
+  // trips at the end of the launch; among forced splits (full tables) the one with the fewest units per
+  // workgroup wins.
+  int rep = 0, ksplit = 0, nrb = 0, spw = 0, rpb[kMaxG] = {0, 0, 0}, best = 0;
+  auto consider = [&](int rp, int ks) -> bool {
+    int nrb_c = (tune.blocks > 0 ? tune.blocks : ncu) / ks;
+    if (nrb_c < 1) nrb_c = 1;
+    int rp_c[kMaxG] = {0, 0, 0}, rows = 0, quads = 0, need = 1;
+    for (;;) {   // accumulator rows must fit: more row blocks until they do
+      rows = 0; quads = 0; need = 1;
+      for (int p = 0; p < G; ++p) {
+        int v = (ns[p] + nrb_c - 1) / nrb_c;
+        v = (v + 3) & ~3;
+        rp_c[p] = v;
+        rows += v;
+        quads += v >> 2;
+        const int nb = (ns[p] + v - 1) / v;
+        need = nb > need ? nb : need;
+      }
+      if (rows <= 1024) break;
+      nrb_c *= 2;
+    }
+    const int spw_c = (segs + ks - 1) / ks;
+    const int room = (V2Lds<16, 16>::kTotal - lds_x(rp) - rows * 16 - 16) / kSegBytes;
+    if (G * spw_c > room || G * 3 * spw_c * 64 > 6 * 1024) return false;
+    const int cost = quads * spw_c;
+    if (!ksplit || cost < best) {
+      ksplit = ks; nrb = need; spw = spw_c; best = cost; rep = rp;
+      for (int p = 0; p < G; ++p) rpb[p] = rp_c[p];
+    }
+    return true;
+  };
+  if (tune.rep || tune.waves_g) {
+    const int rp = tune.rep ? tune.rep : 32;
+    for (int ks = tune.waves_g > 0 ? tune.waves_g : 1; ks <= segs; ++ks)
+      if (consider(rp, ks)) break;
+  } else {
+    const int reps[3] = {32, 24, 16};
+    for (int ri = 0; ri < 3 && !ksplit; ++ri) consider(reps[ri], 1);
+    if (!ksplit)
+      for (int ks = 2, tried = 0; ks <= segs && tried < 4; ++ks) tried += consider(32, ks) ? 1 : 0;
+  }
+  if (!ksplit) return QUIP_ERR_UNSUPPORTED;
+  ksplit = (segs + spw - 1) / spw;
+  if (ksplit > 1 && !ws) return QUIP_ERR_NULL_POINTER;
+  V2Args a;
+  size_t ws_off = 0;
+  int quads = 0, rows = 0;
+  for (int p = 0; p < kMaxG; ++p) {
+    const int pp = p < G ? p : 0;
+    a.W[p] = reinterpret_cast<const uint4*>(qidxs[pp]);
+    a.planes[p] = reinterpret_cast<const uint8_t*>(planes[pp]);
+    a.y[p] = reinterpret_cast<f16*>(ys[pp]);
+    a.N[p] = ns[pp];
+    a.rpb[p] = rpb[pp];
+    a.ws[p] = ws ? reinterpret_cast<int*>(ws) + ws_off : nullptr;
+    if (p < G) {
+      ws_off += e8p_gemv_v2_workspace_words(ns[p]);
+      quads += rpb[p] >> 2;
+      rows += rpb[p];
+    }
+  }
+  a.grid = reinterpret_cast<const uint64_t*>(grid);
+  a.K = k;
+  a.kp_src = (k + 511) & ~511;
+  a.segs = segs; a.spw = spw; a.ksplit = ksplit;
+  a.dbg = reinterpret_cast<uint64_t*>(tune.dbg);
+  int waves = tune.max_waves > 0 ? tune.max_waves : 16;
+  if (waves < 8) waves = 8;     // the table build uses waves 0..7
+  if (waves > 16) waves = 16;
+  while (waves < 16 && G * 3 * spw * 64 > 6 * waves * 64) ++waves;   // 6 digit pieces per thread
+  // run length: the longest (fewest LDS flushes, longest contiguous reads) that still leaves about four runs per wave
+  int runlen = tune.digits > 0 ? tune.digits : spw;
+  if (tune.digits <= 0)
+    while (runlen > slots && quads * ((spw + runlen - 1) / runlen) < 4 * waves) runlen = (runlen + 1) / 2;
+  if (runlen > spw) runlen = spw;
+  if (runlen < 1) runlen = 1;
+  a.runlen = runlen;
+  const int threads = waves * 64;
+  const int lds = lds_x(rep) + G * spw * kSegBytes + rows * 16 + 16;
+  const int nblocks = nrb * ksplit;
+#define QUIP_V2(R1, R2, RR, S) \
+  if (rep == RR && slots == S) return v2_launch<R1, R2, S, G>(a, nblocks, threads, lds, stream);
+  QUIP_V2(32, 32, 32, 1) QUIP_V2(32, 32, 32, 2) QUIP_V2(32, 32, 32, 3) QUIP_V2(32, 32, 32, 4)
+  QUIP_V2(32, 16, 24, 1) QUIP_V2(32, 16, 24, 2) QUIP_V2(32, 16, 24, 3) QUIP_V2(32, 16, 24, 4)
+  QUIP_V2(16, 16, 16, 1) QUIP_V2(16, 16, 16, 2) QUIP_V2(16, 16, 16, 3) QUIP_V2(16, 16, 16, 4)
+#undef QUIP_V2
+  return QUIP_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+bool e8p_gemv_v2_supported(int n, int k) { return n >= 1 && k >= 128 && k % 128 == 0; }
+
+// int32 words of zeroed workspace a problem may need (accumulators + arrival counters)
+size_t e8p_gemv_v2_workspace_words(int n) { return (size_t)n * 4 + (size_t)((n + 3) / 4) + 64; }
+
+int e8p_gemv_v2_group_launch(const void* const* planes, const void* const* qidxs, const void* grid, void* const* ys,
+                             void* ws, const int* ns, int count, int k, const GemvTune& tune, hipStream_t stream) {
+  if (count < 1 || count > kMaxG) return QUIP_ERR_UNSUPPORTED;
+  for (int i = 0; i < count; ++i)
+    if (!e8p_gemv_v2_supported(ns[i], k)) return QUIP_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(grid) & 63u) != 0) return QUIP_ERR_MISALIGNED;
+  if (count == 1) return v2_group_launch<1>(planes, qidxs, grid, ys, ws, ns, k, tune, stream);
+  if (count == 2) return v2_group_launch<2>(planes, qidxs, grid, ys, ws, ns, k, tune, stream);
+  return v2_group_launch<3>(planes, qidxs, grid, ys, ws, ns, k, tune, stream);
+}
+
+int e8p_gemv_v2_launch(const void* planes, const void* qidxs, const void* grid, void* y, void* ws, int n, int k,
+                       const GemvTune& tune, hipStream_t stream) {
+  return e8p_gemv_v2_group_launch(&planes, &qidxs, grid, &y, ws, &n, 1, k, tune, stream);
+}
+
+}  // namespace quip

@@ -36,6 +36,16 @@ size_t e8p_gemv_mfma_planes_bytes(int k);
 int x_to_planes_linear_launch(const void* x, void* planes, int k, hipStream_t stream, int rows = 1);
 int e8p_gemv_mfma_launch(const void* planes, const void* qidxs, const void* grid, void* y, int n, int k,
                          const GemvTune& tune, hipStream_t stream);
+// second-generation matrix-core GEMV (e8p_gemv_v2.hip): whole-line loads, K split over workgroups.
+// ws: zeroed int32 workspace of e8p_gemv_v2_workspace_words(n) words (needed when K is split; left zeroed).
+// tune: rep = 32 / 24 / 16 -> (32, 32) / (32, 16) / (16, 16) table copies, rows = load slots per wave,
+// waves_g = K split, digits = segments per run, blocks, max_waves (0: automatic)
+bool e8p_gemv_v2_supported(int n, int k);
+size_t e8p_gemv_v2_workspace_words(int n);
+int e8p_gemv_v2_group_launch(const void* const* planes, const void* const* qidxs, const void* grid, void* const* ys,
+                             void* ws, const int* ns, int count, int k, const GemvTune& tune, hipStream_t stream);
+int e8p_gemv_v2_launch(const void* planes, const void* qidxs, const void* grid, void* y, void* ws, int n, int k,
+                       const GemvTune& tune, hipStream_t stream);
 int shape_probe_launch(const void* qidxs, void* out, int n, int k, const GemvTune& tune, hipStream_t stream);
 int pattern_probe_launch(const void* qidxs, void* out, int n, int k, const GemvTune& tune, hipStream_t stream);
 
@@ -138,6 +148,14 @@ extern "C" int quip_e8p_gemv_group_tuned(const void* const* planes, const void* 
                                          void* const* ys, const int32_t* ns, int32_t count, int32_t k,
                                          int32_t rep, int32_t rows, int32_t blocks, int32_t max_waves,
                                          void* dbg, quip_stream_t stream);
+extern "C" int quip_e8p_gemv_v2_tuned(const void* planes, const void* qidxs, const void* grid, void* y, void* ws,
+                                      int32_t n, int32_t k, int32_t rep2, int32_t slots, int32_t blocks,
+                                      int32_t ksplit, int32_t max_waves, int32_t runlen, void* dbg, quip_stream_t stream);
+extern "C" int quip_e8p_gemv_v2_group_tuned(const void* const* planes, const void* const* qidxs, const void* grid,
+                                            void* const* ys, void* ws, const int32_t* ns, int32_t count, int32_t k,
+                                            int32_t rep, int32_t slots, int32_t blocks, int32_t ksplit,
+                                            int32_t max_waves, int32_t runlen, void* dbg, quip_stream_t stream);
+extern "C" size_t quip_e8p_gemv_v2_workspace_bytes(int32_t n);
 // kernel 2 in quip_e8p_gemv_tuned = streaming-read probe (y is a 4-byte scratch)
 // lane-ordered digit planes for the VALU integer GEMV (kernel 0); planes: 3*k + 16 bytes
 extern "C" int quip_e8p_x_to_planes_laneorder(const void* x, void* planes, int32_t k, quip_stream_t stream);

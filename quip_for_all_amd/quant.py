@@ -6,20 +6,36 @@ import os
 import torch
 
 _HAD_TABLES = None
+_HAD_TABLES_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "hadamard_tables.npz")
 
 
 def _had_tables():
-    """Non-power-of-two Hadamard factors for use_rand=False (quant.py:8,34-39).
-    The reference ships them as hadamard.safetensors; this build reads the same
-    file when QUIP_HADAMARD_TABLES points at it."""
+    """Non-power-of-two Hadamard factors for use_rand=False (quant.py:8,34-39): the +-1 matrices of order 4 * odd
+    (12 .. 252) the reference ships as the data file hadamard.safetensors, bundled bit-packed in
+    data/hadamard_tables.npz (made by tests/golden/make_hadamard_tables.py; every matrix satisfies H H^T = n I,
+    checked on CPU by tests/test_hadamard_tables.py).  QUIP_HADAMARD_TABLES may point at a safetensors file with
+    the reference's layout instead.  A missing file raises: silently padding to the next power of two would change
+    (K, padded n) and with them the shape of Qidxs of every checkpoint quantised with use_rand=False."""
     global _HAD_TABLES
     if _HAD_TABLES is None:
         path = os.environ.get("QUIP_HADAMARD_TABLES", "")
-        if path and os.path.exists(path):
+        if path:
+            if not os.path.exists(path):
+                raise FileNotFoundError(f"QUIP_HADAMARD_TABLES={path} does not exist")
             from safetensors.torch import load_file
-            _HAD_TABLES = load_file(path)
+            _HAD_TABLES = {k: v.to(torch.float32) for k, v in load_file(path).items()}
         else:
-            _HAD_TABLES = {}
+            if not os.path.exists(_HAD_TABLES_FILE):
+                raise FileNotFoundError(
+                    f"{_HAD_TABLES_FILE} is missing: get_hadK(use_rand=False) needs the Hadamard factor tables "
+                    "(regenerate with tests/golden/make_hadamard_tables.py or set QUIP_HADAMARD_TABLES)")
+            import numpy as np
+            z = np.load(_HAD_TABLES_FILE)
+            tabs = {}
+            for n in z["orders"].tolist():
+                bits = np.unpackbits(z[f"bits_{n}"])[: n * n].reshape(n, n)
+                tabs[str(n)] = torch.from_numpy(bits.astype(np.float32) * 2.0 - 1.0)
+            _HAD_TABLES = tabs
     return _HAD_TABLES
 
 

@@ -153,20 +153,67 @@ class QuipQuantizer:
                 self._replace_by_quant_layers(layer, names, full)
 
     def save(self, model: nn.Module, save_dir: str, max_shard_size: str = "10GB", safe_serialization: bool = False):
-        """state dict + model config + quantization_config.json (quantizer.py:718-756).  Written as a
-        single file (`pytorch_model.bin` or `model.safetensors`); `load_quantized_model` reads both
-        this and the reference's sharded layout."""
+        """state dict + model config + quantization_config.json (quantizer.py:718-756).  Same on-disk layout as
+        the reference's `Accelerator.save_model`: `pytorch_model.bin` / `model.safetensors`, or, when the state dict
+        exceeds `max_shard_size`, `pytorch_model-0000i-of-0000N.bin` (`model-...safetensors`) plus the
+        `*.index.json` weight map.  Tensors that share storage (tied embeddings) are written once for
+        safetensors; `load_quantized_model` re-ties them."""
         os.makedirs(save_dir, exist_ok=True)
-        sd = {k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()}
-        if safe_serialization:
-            from safetensors.torch import save_file
-            save_file(sd, os.path.join(save_dir, "model.safetensors"))
+        sd, seen = {}, {}
+        for k, v in model.state_dict().items():
+            v = v.detach()
+            if safe_serialization and v.numel() > 0:
+                key = (v.device, v.data_ptr(), tuple(v.shape), tuple(v.stride()), v.dtype)
+                if key in seen:
+                    continue                 # tied weight: keep the first name only
+                seen[key] = k
+            sd[k] = v.cpu().contiguous()
+        limit = _parse_size(max_shard_size)
+        shards, cur, cur_bytes = [], {}, 0
+        for k, v in sd.items():
+            nbytes = v.numel() * v.element_size()
+            if cur and cur_bytes + nbytes > limit:
+                shards.append(cur)
+                cur, cur_bytes = {}, 0
+            cur[k] = v
+            cur_bytes += nbytes
+        shards.append(cur)
+        base, ext = ("model", ".safetensors") if safe_serialization else ("pytorch_model", ".bin")
+
+        def write(tensors, path):
+            if safe_serialization:
+                from safetensors.torch import save_file
+                save_file(tensors, path, metadata={"format": "pt"})
+            else:
+                torch.save(tensors, path)
+        if len(shards) == 1:
+            write(shards[0], os.path.join(save_dir, base + ext))
         else:
-            torch.save(sd, os.path.join(save_dir, "pytorch_model.bin"))
+            weight_map = {}
+            for i, sh in enumerate(shards):
+                name = f"{base}-{i + 1:05d}-of-{len(shards):05d}{ext}"
+                write(sh, os.path.join(save_dir, name))
+                weight_map.update({k: name for k in sh})
+            total = sum(v.numel() * v.element_size() for v in sd.values())
+            with open(os.path.join(save_dir, base + ext + ".index.json"), "w", encoding="utf-8") as f:
+                json.dump({"metadata": {"total_size": total}, "weight_map": weight_map}, f, indent=2, sort_keys=True)
         if hasattr(model, "config"):
             model.config.save_pretrained(save_dir)
         with open(os.path.join(save_dir, QUIP_CONFIG), "w", encoding="utf-8") as f:
             json.dump(self.to_dict(), f, indent=2)
+
+
+def _parse_size(size) -> int:
+    """'10GB' / '300KB' / '5MiB' / int -> bytes (the size strings accelerate / huggingface_hub accept)"""
+    if isinstance(size, int):
+        return size
+    s = str(size).strip().upper()
+    units = [("GIB", 2 ** 30), ("MIB", 2 ** 20), ("KIB", 2 ** 10), ("GB", 10 ** 9), ("MB", 10 ** 6), ("KB", 10 ** 3),
+             ("B", 1)]
+    for u, m in units:
+        if s.endswith(u):
+            return int(float(s[:-len(u)]) * m)
+    return int(s)
 
 
 def _checkpoint_files(folder: str) -> List[str]:
@@ -224,7 +271,10 @@ def load_quantized_model(save_folder: str, revision: Optional[str] = None,
     config = AutoConfig.from_pretrained(save_folder, trust_remote_code=trust_remote_code, revision=revision)
     if isinstance(torch_dtype, str):
         torch_dtype = getattr(torch, torch_dtype)
-    with torch.device("meta"):
+    # parameters on the meta device, buffers real (rotary inv_freq, causal masks, ... are computed by the model's
+    # constructor and are not in the checkpoint): what the reference's init_empty_weights(include_buffers=False)
+    # does (quantizer.py:805-809)
+    with _params_on_meta():
         model = AutoModelForCausalLM.from_config(config, trust_remote_code=trust_remote_code, dtype=torch_dtype)
     qcfg = getattr(config, "quantization_config", None)
     if qcfg is None:
@@ -238,15 +288,22 @@ def load_quantized_model(save_folder: str, revision: Optional[str] = None,
     qcfg["ft_epochs"] = 0
     quantizer = QuipQuantizer.from_dict(qcfg)
     model = quantizer.convert_model(model)
-    # materialise the meta tensors on the CPU (the QuantLinear buffers and codebook tables are real
+    # materialise the meta parameters on the CPU (the QuantLinear buffers and codebook tables are real
     # already and must be kept), then fill from the checkpoint
-    _materialize_meta(model)
+    was_meta = _materialize_meta(model)
     sd = load_state_dict_from_folder(save_folder)
     own = model.state_dict()
     missing = [k for k in own if k not in sd]
-    # non-persistent / derived tensors (rotary inv_freq, tied lm_head, fake `weight` of QuantLinear) may be absent
-    hard_missing = [k for k in missing if not (k.endswith("inv_freq") or k.endswith(".weight") and
-                                               k[:-len(".weight")] + ".Qidxs" in own or k == "lm_head.weight")]
+
+    def soft(k):
+        # the fake 0-dim `weight` of a QuantLinear; SU / SV of layers packed with merge_su / merge_sv (the reference
+        # drops those parameters, qlinear.py:117-131, loads non-strictly and leaves them at their init of ones,
+        # which the post-load step then removes); a tied lm_head
+        stem, _, leaf = k.rpartition(".")
+        if stem + ".Qidxs" in own and leaf in ("weight", "SU", "SV"):
+            return True
+        return k == "lm_head.weight" and bool(getattr(config, "tie_word_embeddings", False))
+    hard_missing = [k for k in missing if not soft(k) and (k in was_meta or k.rpartition(".")[0] + ".Qidxs" in own)]
     if hard_missing:
         raise KeyError(f"checkpoint lacks {len(hard_missing)} tensors, e.g. {hard_missing[:5]}")
     cast = {}
@@ -254,9 +311,15 @@ def load_quantized_model(save_folder: str, revision: Optional[str] = None,
         if k in own:
             cast[k] = v.to(own[k].dtype) if v.is_floating_point() and own[k].is_floating_point() else v
     model.load_state_dict(cast, strict=False)
-    if "lm_head.weight" in missing and hasattr(model, "tie_weights"):
-        model.tie_weights()
-    _reinit_rotary(model, config)
+    for k in missing:                      # merge_suv layers: SU / SV stay at ones
+        stem, _, leaf = k.rpartition(".")
+        if leaf in ("SU", "SV") and stem + ".Qidxs" in own:
+            getattr(recurse_getattr(model, stem), leaf).data.fill_(1.0)
+    if hasattr(model, "tie_weights") and ("lm_head.weight" in missing or getattr(config, "tie_word_embeddings", False)):
+        model.tie_weights()                # materialising the meta parameters untied them
+    left = [n for n, t in list(model.named_parameters()) + list(model.named_buffers()) if t.is_meta]
+    if left:
+        raise RuntimeError(f"tensors left on the meta device after loading: {left[:5]}")
     finalize_quant_layers(model, merge_suv=quantizer.merge_suv)
     if device_map is not None:
         dev = device_map if isinstance(device_map, (str, torch.device)) else device_map.get("", "cpu")
@@ -268,25 +331,42 @@ def load_quantized_model(save_folder: str, revision: Optional[str] = None,
     return model
 
 
+class _params_on_meta:
+    """Context in which nn.Module parameters are created on the meta device while buffers stay real -- the
+    behaviour of accelerate.init_empty_weights(include_buffers=False) that the reference relies on
+    (quantizer.py:805), without depending on accelerate."""
+
+    def __enter__(self):
+        self._orig = nn.Module.register_parameter
+
+        def register_parameter(module, name, param):
+            self._orig(module, name, param)
+            if param is not None and not param.is_meta:
+                cls = type(module._parameters[name])
+                kw = dict(module._parameters[name].__dict__)
+                kw["requires_grad"] = param.requires_grad
+                module._parameters[name] = cls(module._parameters[name].to(torch.device("meta")), **kw)
+        nn.Module.register_parameter = register_parameter
+        return self
+
+    def __exit__(self, *exc):
+        nn.Module.register_parameter = self._orig
+        return False
+
+
 def _materialize_meta(model: nn.Module, device="cpu"):
-    for m in model.modules():
+    """zero tensors for everything still on the meta device; returns the qualified names it replaced (parameters
+    only after _params_on_meta; buffers too for models built under torch.device('meta'))"""
+    replaced = set()
+    for mname, m in model.named_modules():
+        pre = mname + "." if mname else ""
         for name, p in list(m._parameters.items()):
             if p is not None and p.is_meta:
                 m._parameters[name] = nn.Parameter(torch.zeros(p.shape, dtype=p.dtype, device=device),
                                                    requires_grad=p.requires_grad)
+                replaced.add(pre + name)
         for name, b in list(m._buffers.items()):
             if b is not None and b.is_meta:
                 m._buffers[name] = torch.zeros(b.shape, dtype=b.dtype, device=device)
-
-
-def _reinit_rotary(model, config):
-    """rotary `inv_freq` buffers are non-persistent and were created on the meta device"""
-    for m in model.modules():
-        if hasattr(m, "inv_freq") and hasattr(m, "rope_init_fn"):
-            try:
-                inv, _ = m.rope_init_fn(config, torch.device("cpu"))
-                m.inv_freq = inv
-                if hasattr(m, "original_inv_freq"):
-                    m.original_inv_freq = inv
-            except Exception:
-                pass
+                replaced.add(pre + name)
+    return replaced
