@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QUIP_ABI_VERSION 5
+#define QUIP_ABI_VERSION 6
 
 typedef void* quip_stream_t; /* hipStream_t */
 
@@ -61,6 +61,12 @@ int quip_device_cu_count(void);
  * (register_lib.py:18-20; call sites quant.py:78,82).  x and y may alias. */
 int quip_hadamard_f16(const void* x, void* y, int64_t rows, int32_t n, float scale,
                       quip_stream_t stream);
+/* The same transform for every dtype the reference's op accepts (fast_hadamard_transform takes fp16 / bf16 / fp32,
+ * register_lib.py:10-20; fp32 inside, one rounding to the I/O type).  dtype: QUIP_DTYPE_*.  fp16 goes to
+ * quip_hadamard_f16's kernels. */
+enum { QUIP_DTYPE_F16 = 0, QUIP_DTYPE_BF16 = 1, QUIP_DTYPE_F32 = 2 };
+int quip_hadamard(const void* x, void* y, int64_t rows, int32_t n, float scale, int32_t dtype,
+                  quip_stream_t stream);
 
 /* ---- quip_lib::*_mm_origorder ---------------------------------------------
  * Replace quiptools_cuda.{e8p,e8prvq3,e8prvq4,d4,hi}_mm_origorder
@@ -259,6 +265,18 @@ int quip_gemv_planes_rows_mode(const void* planes, const void* qidxs, const void
 int quip_e8p_gemv_planes_group(const void* const* planes, const void* const* qidxs,
                                const void* grid_packed_abs, void* const* ys, const int32_t* ns,
                                int32_t count, int32_t k, quip_stream_t stream);
+/* Workspace variants of the two launches above.  Rows longer than the LDS image of x allows (k > ~20K, e.g. the
+ * Llama-70B down projection, or E8P12RVQ4B's 2k-wide virtual rows) are split along k over workgroups; the integer
+ * partial sums meet in `workspace` (agent-scope atomics; the last workgroup of a row block converts and stores y).
+ * The workspace must be ZERO when first used and is left zero by every launch, so one buffer serves all launches
+ * of a stream: quip_e8p_gemv_workspace_bytes(sum of ns) bytes, 16-byte aligned.  Without a workspace (NULL) such
+ * shapes run on the first-generation kernel where it supports them.  Results are bit identical either way. */
+size_t quip_e8p_gemv_workspace_bytes(int32_t n_total);
+int quip_e8p_gemv_planes_ws(const void* planes, const void* qidxs, const void* grid_packed_abs, void* y, int32_t n,
+                            int32_t k, void* workspace, size_t workspace_bytes, quip_stream_t stream);
+int quip_e8p_gemv_planes_group_ws(const void* const* planes, const void* const* qidxs, const void* grid_packed_abs,
+                                  void* const* ys, const int32_t* ns, int32_t count, int32_t k, void* workspace,
+                                  size_t workspace_bytes, quip_stream_t stream);
 
 /* D4 codebook (d4.py:26-96, origin_order.cu:143-168) on the same integer-domain matrix-core GEMV:
  * qidxs uint8 (n, k/4), grid_f16 the fp16 (256, 4) table; 2w of every entry is an int8, so the

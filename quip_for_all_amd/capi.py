@@ -15,6 +15,7 @@ SIGNATURES = {
     "quip_abi_version": [],
     "quip_device_cu_count": [],
     "quip_hadamard_f16": [_P, _P, _I64, _I32, _F, _P],
+    "quip_hadamard": [_P, _P, _I64, _I32, _F, _I32, _P],
     "quip_had_transform_f16": [_P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _P, _P, _P, _F, _P],
     "quip_had_transform_planes": [_P, _P, _I32, _I32, _I32, _P, _I32, _P, _F, _P],
     "quip_had_transform_fused_f16": [_P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _P, _P, _P, _F, _P, _P],
@@ -22,6 +23,9 @@ SIGNATURES = {
     "quip_had_transform_group_f16": [_P, _I32, _I64, _I32, _I32, _I32, _P],
     "quip_had_transform_planes_group": [_P, _I32, _I32, _I32, _I32, _P],
     "quip_e8p_gemv_planes_group": [_P, _P, _P, _P, _P, _I32, _I32, _P],
+    "quip_e8p_gemv_workspace_bytes": [_I32],
+    "quip_e8p_gemv_planes_ws": [_P, _P, _P, _P, _I32, _I32, _P, _c.c_size_t, _P],
+    "quip_e8p_gemv_planes_group_ws": [_P, _P, _P, _P, _P, _I32, _I32, _P, _c.c_size_t, _P],
     "quip_had_transform_planes_rows": [_P, _I64, _I32, _I32, _I32, _P],
     "quip_e8p_gemv_max_rows": [_I32, _I32],
     "quip_e8p_quantize_f32": [_P, _I64, _P, _P, _P, _P],

@@ -1,6 +1,8 @@
 // extern "C" entry points of libquip_mi355.so (see include/quip_mi355.h).
 // Argument validation lives here; the reference validated nothing
 // (origin_order.cu:557-788 have no dtype / shape / contiguity checks).
+#include <stdlib.h>
+
 #include "quip_internal.h"
 
 namespace quip {
@@ -19,6 +21,7 @@ int device_cu_count() {
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline bool aligned64(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 63u) == 0; }
 
 static int mm_common(CodebookId cb, const void* x, const void* q, const CodebookArgs& a, void* y,
                      int m, int n, int k, int kdiv, hipStream_t s) {
@@ -56,6 +59,13 @@ int quip_hadamard_f16(const void* x, void* y, int64_t rows, int32_t n, float sca
   if (!x || !y) return QUIP_ERR_NULL_POINTER;
   return had_transform_launch(x, y, rows, n, n, n, 1, nullptr, 0, nullptr, nullptr, nullptr,
                               nullptr, scale, (hipStream_t)stream);
+}
+
+int quip_hadamard(const void* x, void* y, int64_t rows, int32_t n, float scale, int32_t dtype,
+                  quip_stream_t stream) {
+  if (!x || !y) return QUIP_ERR_NULL_POINTER;
+  if (dtype == QUIP_DTYPE_F16) return quip_hadamard_f16(x, y, rows, n, scale, stream);
+  return hadamard_generic_launch(x, y, rows, n, scale, dtype, (hipStream_t)stream);
 }
 
 int quip_had_transform_f16(const void* x, void* y, int64_t rows, int32_t in_features,
@@ -179,9 +189,45 @@ int quip_gemv_planes_rows_mode(const void* planes, const void* qidxs, const void
   return e8p_gemv_mfma_rows_launch(planes, qidxs, grid, y, rows, n, k, t, (hipStream_t)stream);
 }
 
-int quip_e8p_gemv_planes_group(const void* const* planes, const void* const* qidxs,
-                               const void* grid_packed_abs, void* const* ys, const int32_t* ns,
-                               int32_t count, int32_t k, quip_stream_t stream) {
+// Which of the two matrix-core GEMVs serves a launch (measured on MI355X, tools/gemv_v2_bench.py): the second
+// generation (whole-line loads, K split) wins from Llama-70B sizes on -- K >= 8192 with >= 16 MB of codes, or
+// >= 32 MB of codes -- and is the only one for rows longer than 28672 (E8P12RVQ4B's 2k-wide virtual rows at 70B);
+// short launches stay on the first kernel (one-shot loads on 8 waves).  QUIP_GEMV_V2=0 / 1 forces one of them.
+static int gemv_v2_mode() {
+  static int mode = -2;
+  if (mode == -2) {
+    const char* e = getenv("QUIP_GEMV_V2");
+    mode = e ? atoi(e) : -1;
+  }
+  return mode;
+}
+
+static int e8p_gemv_dispatch(const void* const* planes, const void* const* qidxs, const void* grid, void* const* ys,
+                             const int* ns, int count, int k, void* ws, size_t ws_bytes, hipStream_t stream) {
+  size_t bytes = 0, need = 0;
+  for (int i = 0; i < count; ++i) {
+    bytes += (size_t)ns[i] * (size_t)k / 4;
+    need += e8p_gemv_v2_workspace_words(ns[i]) * 4;
+  }
+  if (ws && ws_bytes < need) ws = nullptr;
+  const bool v1_ok = e8p_gemv_mfma_group_supported(ns, count, k);
+  const int mode = gemv_v2_mode();
+  bool v2 = mode == 1 || !v1_ok || (mode != 0 && ((k >= 8192 && bytes >= ((size_t)16 << 20)) || bytes >= ((size_t)32 << 20)));
+  if (v2) {
+    const int rc = e8p_gemv_v2_group_launch(planes, qidxs, grid, ys, ws, ns, count, k, GemvTune{}, stream);
+    if (rc == QUIP_OK || !v1_ok || (rc != QUIP_ERR_NULL_POINTER && rc != QUIP_ERR_UNSUPPORTED)) return rc;
+    // needs a K split but no workspace was given: the first kernel takes it
+  }
+  return e8p_gemv_mfma_group_launch(planes, qidxs, grid, ys, ns, count, k, GemvTune{}, stream);
+}
+
+size_t quip_e8p_gemv_workspace_bytes(int32_t n_total) {
+  return n_total < 1 ? 0 : (e8p_gemv_v2_workspace_words(n_total) + 2 * 64) * 4;
+}
+
+static int gemv_group_common(const void* const* planes, const void* const* qidxs, const void* grid_packed_abs,
+                             void* const* ys, const int32_t* ns, int32_t count, int32_t k, void* ws, size_t ws_bytes,
+                             quip_stream_t stream) {
   if (!planes || !qidxs || !grid_packed_abs || !ys || !ns) return QUIP_ERR_NULL_POINTER;
   if (count < 1 || count > QUIP_MAX_GROUP) return QUIP_ERR_BAD_SHAPE;
   int n32[QUIP_MAX_GROUP];
@@ -192,8 +238,26 @@ int quip_e8p_gemv_planes_group(const void* const* planes, const void* const* qid
     n32[i] = ns[i];
   }
   if (k < 1 || k % 8 != 0) return QUIP_ERR_BAD_SHAPE;
-  return e8p_gemv_mfma_group_launch(planes, qidxs, grid_packed_abs, ys, n32, count, k, GemvTune{},
-                                    (hipStream_t)stream);
+  if (!aligned64(grid_packed_abs) || (ws && !aligned16(ws))) return QUIP_ERR_MISALIGNED;
+  return e8p_gemv_dispatch(planes, qidxs, grid_packed_abs, ys, n32, count, k, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int quip_e8p_gemv_planes_group_ws(const void* const* planes, const void* const* qidxs, const void* grid_packed_abs,
+                                  void* const* ys, const int32_t* ns, int32_t count, int32_t k, void* workspace,
+                                  size_t workspace_bytes, quip_stream_t stream) {
+  return gemv_group_common(planes, qidxs, grid_packed_abs, ys, ns, count, k, workspace, workspace_bytes, stream);
+}
+
+int quip_e8p_gemv_planes_ws(const void* planes, const void* qidxs, const void* grid, void* y, int32_t n, int32_t k,
+                            void* workspace, size_t workspace_bytes, quip_stream_t stream) {
+  if (n == 0) return QUIP_OK;
+  return gemv_group_common(&planes, &qidxs, grid, &y, &n, 1, k, workspace, workspace_bytes, stream);
+}
+
+int quip_e8p_gemv_planes_group(const void* const* planes, const void* const* qidxs,
+                               const void* grid_packed_abs, void* const* ys, const int32_t* ns,
+                               int32_t count, int32_t k, quip_stream_t stream) {
+  return gemv_group_common(planes, qidxs, grid_packed_abs, ys, ns, count, k, nullptr, 0, stream);
 }
 
 // E8P12RVQ3B on the matrix-core GEMV: codes repacked to (main16 << 16 | resid8 << 8), i.e. an RVQ4-style row of
@@ -306,7 +370,6 @@ int quip_e8p_mm_origorder(const void* x, const void* qidxs, const void* grid, vo
   return mm_common(kE8P, x, qidxs, a, y, m, n, k, 8, (hipStream_t)stream);
 }
 
-static inline bool aligned64(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 63u) == 0; }
 
 size_t quip_e8p_planes_bytes(int32_t k) { return k > 0 ? e8p_gemv_mfma_planes_bytes(k) : 0; }
 
@@ -326,7 +389,7 @@ int quip_e8p_gemv_planes(const void* planes, const void* qidxs, const void* grid
   if (n < 0) return QUIP_ERR_BAD_SHAPE;
   if (n == 0) return QUIP_OK;
   if (!aligned16(planes) || !aligned16(qidxs) || !aligned64(grid)) return QUIP_ERR_MISALIGNED;
-  return e8p_gemv_mfma_launch(planes, qidxs, grid, y, n, k, GemvTune{}, (hipStream_t)stream);
+  return gemv_group_common(&planes, &qidxs, grid, &y, &n, 1, k, nullptr, 0, stream);
 }
 
 int quip_e8p_mm_origorder_ws(const void* x, const void* qidxs, const void* grid, void* y, int32_t m,

@@ -69,7 +69,15 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(AttnArgs a) {
   const int tid = threadIdx.x, h = blockIdx.x;
   const int gl = tid % LPK, grp = tid / LPK, d0 = gl * 8;
   const int group = a.heads / a.kv_heads, kvh = h / group;
-  const int pos = (int)*a.pos;
+  const long long pos64 = *a.pos;
+  // A position outside the cache (one step past max_len, a corrupted counter) must not index cos / sin or the
+  // cache: nothing is appended, the head's output becomes NaN (visible downstream) and every workgroup of the
+  // launch leaves before touching the split workspace.
+  if (pos64 < 0 || pos64 >= (long long)a.max_len) {
+    if (blockIdx.y == 0 && tid < HD) a.out[(size_t)h * HD + tid] = __builtin_bit_cast(f16, (unsigned short)0x7e00);
+    return;
+  }
+  const int pos = (int)pos64;
   // split mode (long context, workspace given): workgroup (h, s) takes positions [t_lo, t_hi); the last
   // workgroup of a head to arrive merges the partial softmax states (flash-decoding across CUs)
   const bool split = a.ws != nullptr && pos >= kSplitFromPos;

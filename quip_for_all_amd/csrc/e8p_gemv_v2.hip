@@ -149,17 +149,19 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
     const uint2* t2 = &kV2T2Img.v[e];
     asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(tsrc) : "v"((lane & 32) ? t2 : t1) : "memory");
   }
-  // digit images: 16-byte piece i = (problem p, plane d, k16 index g) in source order; every workgroup starts at
-  // a different piece so that they do not all queue on the same L2 channels
+  const uint4* hot = reinterpret_cast<const uint4*>(a.planes[0]) + (tid & 127);   // L2-resident filler for past-the-end slots
+  // digit images, requested BEFORE the weights (loads return in issue order; with the weights first -- HBM requests a
+  // few hundred instructions earlier -- every shape measured slower: the digit copy then waits for the first HBM
+  // burst): 16-byte piece i = (problem p, plane d, k16 index g) in source order; every workgroup starts at a
+  // different piece so that they do not all queue on the same L2 channels
   constexpr int XR = 6;
   const int gper = S * 64;                  // pieces per plane in this workgroup's K range
   const int ppp = 3 * gper;                 // pieces per problem
   const int xpieces = G * ppp;
   const int src_pieces = a.kp_src >> 4;     // pieces per plane in the source
-  const int rot = (int)(((uint32_t)blockIdx.x * 613u) % (uint32_t)xpieces);
+  const int rot = (int)(((uint32_t)blockIdx.x * 5u) & 31u) * (xpieces >> 5);   // xpieces is a multiple of 192
   u32x4 xr[XR];
   uint32_t xdst[XR];                        // LDS destination; 0xffffffff: none; bit 31: store zeros
-  const uint4* hot = reinterpret_cast<const uint4*>(a.planes[0]) + (tid & 127);   // L2-resident filler for past-the-end slots
 #pragma unroll
   for (int j = 0; j < XR; ++j) {
     if (j * nthreads >= xpieces) {   // workgroup uniform: nothing left to fetch, keep the load count
@@ -190,6 +192,7 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
     const uint32_t dst = xbase + (uint32_t)(p * S + s) * kSegBytes + (uint32_t)((((c & 3) * 4 + t) * 12 + 3 * (c >> 2) + d) * 16);
     xdst[j] = i < xpieces ? (dst | (real ? 0u : 0x80000000u)) : 0xffffffffu;
   }
+
 
   // run -> (problem, row quad, first segment, length); everything wave uniform
   auto problem_of_quad = [&](int gq) -> int {
@@ -536,10 +539,10 @@ int v2_group_launch(const void* const* planes, const void* const* qidxs, const v
   if (waves < 8) waves = 8;     // the table build uses waves 0..7
   if (waves > 16) waves = 16;
   while (waves < 16 && G * 3 * spw * 64 > 6 * waves * 64) ++waves;   // 6 digit pieces per thread
-  // run length: the longest (fewest LDS flushes, longest contiguous reads) that still leaves about four runs per wave
+  // run length: the longest (fewest LDS flushes, longest contiguous reads) that still leaves about three runs per wave (measured)
   int runlen = tune.digits > 0 ? tune.digits : spw;
   if (tune.digits <= 0)
-    while (runlen > slots && quads * ((spw + runlen - 1) / runlen) < 4 * waves) runlen = (runlen + 1) / 2;
+    while (runlen > slots && quads * ((spw + runlen - 1) / runlen) < 3 * waves) runlen = (runlen + 1) / 2;
   if (runlen > spw) runlen = spw;
   if (runlen < 1) runlen = 1;
   a.runlen = runlen;

@@ -114,9 +114,32 @@ class LlamaDecoder:
         self = cls.__new__(cls)
         heads = cfg.num_attention_heads
         rope = getattr(cfg, "rope_theta", None)
+        rp = getattr(cfg, "rope_parameters", None) or getattr(cfg, "rope_scaling", None) or {}
         if rope is None:
-            rp = getattr(cfg, "rope_parameters", None) or {}
             rope = rp.get("rope_theta", 10000.0) if isinstance(rp, dict) else 10000.0
+        # what this decoder does not implement must not pass silently (the HF forward of the same model would differ)
+        head_dim = getattr(cfg, "head_dim", None) or cfg.hidden_size // heads
+        if head_dim * heads != cfg.hidden_size:
+            raise NotImplementedError(f"head_dim {head_dim} x {heads} heads != hidden_size {cfg.hidden_size}")
+        prf = rp.get("partial_rotary_factor", None) if isinstance(rp, dict) else None
+        prf = getattr(cfg, "partial_rotary_factor", prf)
+        if prf not in (None, 1, 1.0):
+            raise NotImplementedError(f"partial rotary embeddings (factor {prf}) are not supported")
+        if getattr(cfg, "sliding_window", None) and getattr(cfg, "use_sliding_window", True) and \
+                any(t != "full_attention" for t in (getattr(cfg, "layer_types", None) or ["sliding_attention"])):
+            raise NotImplementedError("sliding-window attention is not supported")
+        # rotary frequencies and attention scaling as the model computes them (llama3 / linear / yarn scaling change
+        # inv_freq at every position; taking only rope_theta from the config would silently give other logits)
+        self._inv_freq, self._att_scale = None, 1.0
+        rot = getattr(model.model, "rotary_emb", None)
+        if rot is not None and hasattr(rot, "inv_freq"):
+            rope_type = getattr(rot, "rope_type", None) or (rp.get("rope_type", "default") if isinstance(rp, dict) else "default")
+            if rope_type in ("dynamic", "longrope"):
+                raise NotImplementedError(f"rope_type {rope_type!r}: frequencies depend on the sequence length")
+            inv = rot.inv_freq.detach().to(torch.float32).cpu()
+            if inv.numel() != head_dim // 2:
+                raise NotImplementedError(f"rotary_emb.inv_freq has {inv.numel()} entries for head_dim {head_dim}")
+            self._inv_freq, self._att_scale = inv, float(getattr(rot, "attention_scaling", 1.0) or 1.0)
         self.s = LlamaShape(hidden=cfg.hidden_size, ffn=cfg.intermediate_size, layers=cfg.num_hidden_layers,
                             heads=heads, kv_heads=getattr(cfg, "num_key_value_heads", heads) or heads,
                             vocab=cfg.vocab_size, rms_eps=cfg.rms_norm_eps, rope_theta=float(rope))
@@ -142,10 +165,13 @@ class LlamaDecoder:
         s, max_len = self.s, self.max_len
         self.kcache = torch.zeros(s.layers, s.kv_heads, max_len, s.head_dim, dtype=torch.float16, device=self.dev)
         self.vcache = torch.zeros_like(self.kcache)
-        inv = 1.0 / (s.rope_theta ** (torch.arange(0, s.head_dim, 2, dtype=torch.float32) / s.head_dim))
+        inv = getattr(self, "_inv_freq", None)
+        if inv is None:
+            inv = 1.0 / (s.rope_theta ** (torch.arange(0, s.head_dim, 2, dtype=torch.float32) / s.head_dim))
+        att = float(getattr(self, "_att_scale", 1.0))
         ang = torch.arange(max_len, dtype=torch.float32)[:, None] * inv[None, :]
-        self.cos = torch.cat([ang.cos(), ang.cos()], -1).to(self.dev)     # (max_len, head_dim) fp32
-        self.sin = torch.cat([ang.sin(), ang.sin()], -1).to(self.dev)
+        self.cos = (torch.cat([ang.cos(), ang.cos()], -1) * att).to(self.dev)     # (max_len, head_dim) fp32
+        self.sin = (torch.cat([ang.sin(), ang.sin()], -1) * att).to(self.dev)
         self.arange = torch.arange(max_len, device=self.dev)
         # static step I/O (graph capture): current token id, its position, next token id
         self.tok = torch.zeros(1, dtype=torch.long, device=self.dev)

@@ -92,6 +92,9 @@ class QuantLinear(nn.Module):
         if self.training:
             assert not fused
             return self._forward_dense(input)
+        if input.shape[-1] != self.in_features:     # the reference fails in `x * self.SU` (qlinear.py:90-91)
+            raise RuntimeError(f"QuantLinear: input has {input.shape[-1]} features, expected in_features = "
+                               f"{self.in_features}")
         x = input.reshape(-1, input.shape[-1])
         x_dtype = x.dtype
         if x_dtype != torch.float16:

@@ -103,6 +103,19 @@ def _chk_x(x: Tensor):
     return x.contiguous()
 
 
+def _chk_lens(what, in_features, out_features, n, K, had=None, pre=None, pre2=None, post=None, bias=None,
+              rms_weight=None):
+    """element counts of the vectors a transform launch reads (a short vector would be read out of bounds):
+    pre / rms_weight multiply the `in_features` inputs, pre2 the n transformed values, post / bias the
+    `out_features` outputs, had is the (K, K) factor"""
+    _need(0 < in_features <= n and 0 < out_features <= n and K >= 1 and n % K == 0,
+          f"{what}: in_features {in_features} / out_features {out_features} must be in (0, n = {n}], K = {K} must divide n")
+    for name, t, want in (("had", had, K * K), ("pre", pre, in_features), ("rms_weight", rms_weight, in_features),
+                          ("pre2", pre2, n), ("post", post, out_features), ("bias", bias, out_features)):
+        _need(t is None or t.numel() == want, f"{what}: {name} has {0 if t is None else t.numel()} elements, expected {want}")
+    _need(K == 1 or had is not None, f"{what}: K = {K} needs the (K, K) factor")
+
+
 def _chk_q(q: Tensor, dtype):
     _need(q.dim() == 2, "Qidxs must be 2-D")
     _need(q.dtype == dtype, f"Qidxs must be {dtype}, got {q.dtype}")
@@ -110,16 +123,24 @@ def _chk_q(q: Tensor, dtype):
 
 
 # ---- hadamard ---------------------------------------------------------------------
+_HAD_DTYPES = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}     # QUIP_DTYPE_*
+
+
 def _hadamard_cuda(x: Tensor, scale: float) -> Tensor:
-    _need(x.dtype == torch.float16, f"hadamard: float16 only in this build, got {x.dtype}")
+    """fp16 / bf16 / fp32 like fast_hadamard_transform (register_lib.py:10-20); fp32 inside, output in x's dtype"""
+    _need(x.dtype in _HAD_DTYPES, f"hadamard: float16 / bfloat16 / float32, got {x.dtype}")
     n = x.shape[-1]
     _need(n & (n - 1) == 0 and 0 < n <= 32768, f"hadamard length {n} must be a power of two <= 32768")
     xc = x.contiguous()
     y = torch.empty_like(xc)
     rows = xc.numel() // n
     with torch.cuda.device(x.device):
-        capi.check(capi.lib().quip_hadamard_f16(xc.data_ptr(), y.data_ptr(), rows, n, float(scale),
-                                                _stream(x)), "quip_hadamard_f16")
+        if x.dtype == torch.float16:
+            capi.check(capi.lib().quip_hadamard_f16(xc.data_ptr(), y.data_ptr(), rows, n, float(scale),
+                                                    _stream(x)), "quip_hadamard_f16")
+        else:
+            capi.check(capi.lib().quip_hadamard(xc.data_ptr(), y.data_ptr(), rows, n, float(scale),
+                                                _HAD_DTYPES[x.dtype], _stream(x)), "quip_hadamard")
     return y
 
 
@@ -128,6 +149,7 @@ def _had_transform_cuda(x, out_features, n, K, had, transpose, pre, pre2, post, 
     for t in (had, pre, pre2, post, bias):
         _need(t is None or (t.dtype == torch.float16 and t.is_contiguous() and t.device == x.device),
               "had_transform: vectors must be contiguous float16 on x's device")
+    _chk_lens("had_transform", xc.shape[1], out_features, n, K, had, pre, pre2, post, bias)
     y = torch.empty((xc.shape[0], out_features), dtype=torch.float16, device=x.device)
     with torch.cuda.device(x.device):
         capi.check(capi.lib().quip_had_transform_f16(
@@ -143,6 +165,7 @@ def _had_transform_planes_cuda(x, n, K, had, transpose, pre, scale):
     for t in (had, pre):
         _need(t is None or (t.dtype == torch.float16 and t.is_contiguous() and t.device == x.device),
               "had_transform_planes: vectors must be contiguous float16 on x's device")
+    _chk_lens("had_transform_planes", xc.shape[1], n, n, K, had, pre)
     L = capi.lib()
     planes = torch.empty(L.quip_e8p_planes_bytes(n), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
@@ -167,6 +190,7 @@ def _had_transform_fused_cuda(x, out_features, n, K, had, transpose, pre, pre2, 
               "had_transform: vectors must be contiguous float16 on x's device")
     _need(gate is None or gate.shape == xc.shape, "gate must have x's shape")
     _need(residual is None or tuple(residual.shape) == (xc.shape[0], out_features), "residual shape")
+    _chk_lens("had_transform_fused", xc.shape[1], out_features, n, K, had, pre, pre2, post, bias, rms_weight)
     y = torch.empty((xc.shape[0], out_features), dtype=torch.float16, device=x.device)
     f = _fusion(residual, rms_weight, rms_eps, gate, x)
     import ctypes
@@ -188,6 +212,7 @@ def _had_transform_planes_fused_cuda(x, n, K, had, transpose, pre, scale, rms_we
         _need(t is None or (t.dtype == torch.float16 and t.is_contiguous() and t.device == x.device),
               "had_transform_planes: vectors must be contiguous float16 on x's device")
     _need(gate is None or gate.shape == xc.shape, "gate must have x's shape")
+    _chk_lens("had_transform_planes_fused", xc.shape[1], n, n, K, had, pre, rms_weight=rms_weight)
     L = capi.lib()
     planes = torch.empty(L.quip_e8p_planes_bytes(n), dtype=torch.uint8, device=x.device)
     f = _fusion(None, rms_weight, rms_eps, gate, x)
@@ -269,6 +294,7 @@ def _had_transform_planes_rows_cuda(x, n, K, had, transpose, pre, scale, rms_wei
     xc = _chk_x(x)
     _need(gate is None or (gate.shape == xc.shape and gate.dtype == torch.float16 and gate.is_contiguous()),
           "gate must be contiguous float16 with x's shape")
+    _chk_lens("had_transform_planes_rows", xc.shape[1], n, n, K, had, pre, rms_weight=rms_weight)
     L = capi.lib()
     rows = xc.shape[0]
     out = torch.empty((rows, _planes_numel(n, resid_scale)), dtype=torch.uint8, device=x.device)
@@ -314,11 +340,12 @@ def _e8p_gemv_planes_rows_cuda(planes, Qidxs, grid):
     rows = planes.shape[0]
     per = L.quip_e8p_gemv_max_rows(n, k)
     _need(per >= 1, "shape not supported by the matrix-core GEMV")
+    g = _grid_i64(grid, Qidxs)
     out = torch.empty((rows, n), dtype=torch.float16, device=Qidxs.device)
     with torch.cuda.device(Qidxs.device):
         for r0 in range(0, rows, per):
             m = min(per, rows - r0)
-            capi.check(L.quip_e8p_gemv_planes_rows(planes[r0].data_ptr(), Qidxs.data_ptr(), grid.data_ptr(),
+            capi.check(L.quip_e8p_gemv_planes_rows(planes[r0].data_ptr(), Qidxs.data_ptr(), g.data_ptr(),
                                                    out[r0].data_ptr(), m, n, k, _stream(out)),
                        "quip_e8p_gemv_planes_rows")
     return out
@@ -363,9 +390,10 @@ def _e8p_mm_planes_rows_cuda(planes, Qidxs, grid):
     out = torch.empty((count, n), dtype=torch.float16, device=dev)
     vp = ctypes.c_void_p * count
     ns = (ctypes.c_int32 * count)(*([n] * count))
+    g = _grid_i64(grid, Qidxs)
     with torch.cuda.device(dev):
         capi.check(capi.lib().quip_e8p_gemv_planes_group(
-            vp(*[p.data_ptr() for p in planes]), vp(*([Qidxs.data_ptr()] * count)), grid.data_ptr(),
+            vp(*[p.data_ptr() for p in planes]), vp(*([Qidxs.data_ptr()] * count)), g.data_ptr(),
             vp(*[out.data_ptr() + 2 * n * i for i in range(count)]), ns, count, k, _stream(out)),
             "quip_e8p_gemv_planes_group (rows)")
     return out
@@ -377,6 +405,8 @@ def _had_transform_planes_group_cuda(x, n, K, had, transpose, pre, scale, rms_we
     _need(xc.shape[0] in (1, count), "had_transform_planes_group: x has one row (shared) or one row per problem")
     _need(1 <= count <= capi.MAX_GROUP and len(had) == count and len(scale) == count, "group of 1..3 problems")
     _need(gate is None or gate.shape == xc.shape, "gate must have x's shape")
+    for i in range(count):
+        _chk_lens("had_transform_planes_group", xc.shape[1], n, n, K, had[i], pre[i], rms_weight=rms_weight)
     L = capi.lib()
     nbytes = L.quip_e8p_planes_bytes(2 * n if resid_scale != 0.0 else n)
     outs = [torch.empty(nbytes, dtype=torch.uint8, device=x.device) for _ in range(count)]
@@ -401,6 +431,8 @@ def _had_chain_planes_group_cuda(z, z_post, z_residual, z_scale, n, pre, scale, 
     _need(zc.shape == (1, n), "had_chain_planes_group is the bs=1 path: z must be (1, n)")
     _need(1 <= count <= capi.MAX_GROUP and len(scale) == count, "group of 1..3 problems")
     _need(z_residual is None or tuple(z_residual.shape) == (1, n), "residual shape")
+    for i in range(count):
+        _chk_lens("had_chain_planes_group", n, n, n, 1, None, pre[i], post=z_post, rms_weight=rms_weight)
     L = capi.lib()
     nbytes = L.quip_e8p_planes_bytes(2 * n if resid_scale != 0.0 else n)
     outs = [torch.empty(nbytes, dtype=torch.uint8, device=z.device) for _ in range(count)]
@@ -433,6 +465,9 @@ def _had_transform_group_cuda(x, out_features, n, K, had, transpose, pre2, post,
     arr = (capi.HadProblem * count)()
     for i in range(count):
         _need(residual[i] is None or tuple(residual[i].shape) == tuple(outs[i].shape), "residual shape")
+        ni = int(ns[i]) if ns is not None else n
+        _chk_lens("had_transform_group", xs[i].shape[1], int(out_features[i]), ni, K, had[i], pre[i], pre2[i], post[i],
+                  bias[i], rms_weight)
         arr[i] = capi.HadProblem(xs[i].data_ptr(), outs[i].data_ptr(), _vec_ok(had[i], dev), _vec_ok(pre[i], dev),
                                  _vec_ok(pre2[i], dev), _vec_ok(post[i], dev), _vec_ok(bias[i], dev),
                                  _vec_ok(residual[i], dev), _vec_ok(rms_weight, dev), None,
@@ -443,6 +478,23 @@ def _had_transform_group_cuda(x, out_features, n, K, had, transpose, pre2, post,
         capi.check(capi.lib().quip_had_transform_group_f16(arr, count, rows, n, K, int(bool(transpose)), _stream(xs[0])),
                    "quip_had_transform_group_f16")
     return outs
+
+
+_GEMV_WS = {}
+
+
+def _gemv_workspace(dev, n_total):
+    """zeroed int32 scratch for K-split GEMV launches, one per device, kept for the life of the process (it is
+    captured by hipGraphs); every launch leaves it zeroed, launches on one stream share it"""
+    need = capi.lib().quip_e8p_gemv_workspace_bytes(int(n_total))
+    key = (dev.type, dev.index)
+    ws = _GEMV_WS.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        _need(not torch.cuda.is_current_stream_capturing() or ws is None or ws.numel() * 4 >= need,
+              "GEMV workspace would have to grow during graph capture; run one eager step first")
+        ws = torch.zeros(max(need // 4, 1 << 20), dtype=torch.int32, device=dev)
+        _GEMV_WS[key] = ws
+    return ws
 
 
 def _e8p_gemv_planes_group_cuda(planes, Qidxs, grid):
@@ -458,10 +510,13 @@ def _e8p_gemv_planes_group_cuda(planes, Qidxs, grid):
     outs = [torch.empty((1, q.shape[0]), dtype=torch.float16, device=dev) for q in Qidxs]
     vp = ctypes.c_void_p * count
     ns = (ctypes.c_int32 * count)(*[q.shape[0] for q in Qidxs])
+    g = _grid_i64(grid, planes[0])
+    ws = _gemv_workspace(dev, sum(q.shape[0] for q in Qidxs))
     with torch.cuda.device(dev):
-        capi.check(capi.lib().quip_e8p_gemv_planes_group(
-            vp(*[p.data_ptr() for p in planes]), vp(*[q.data_ptr() for q in Qidxs]), grid.data_ptr(),
-            vp(*[o.data_ptr() for o in outs]), ns, count, k, _stream(planes[0])), "quip_e8p_gemv_planes_group")
+        capi.check(capi.lib().quip_e8p_gemv_planes_group_ws(
+            vp(*[p.data_ptr() for p in planes]), vp(*[q.data_ptr() for q in Qidxs]), g.data_ptr(),
+            vp(*[o.data_ptr() for o in outs]), ns, count, k, ws.data_ptr(), ws.numel() * 4, _stream(planes[0])),
+            "quip_e8p_gemv_planes_group_ws")
     return outs
 
 
@@ -492,9 +547,10 @@ def _e8p_gemv_fused_cuda(x, z, post, residual, rms_weight, rms_eps, z_scale, pre
     fin.z_scale, fin.rms_eps = float(z_scale), float(rms_eps)
     vp = ctypes.c_void_p * count
     ns = (ctypes.c_int32 * count)(*[q.shape[0] for q in Qidxs])
+    g = _grid_i64(grid, src)
     with torch.cuda.device(dev):
         capi.check(capi.lib().quip_e8p_gemv_fused(
-            ctypes.byref(fin), vp(*[q.data_ptr() for q in Qidxs]), grid.data_ptr(),
+            ctypes.byref(fin), vp(*[q.data_ptr() for q in Qidxs]), g.data_ptr(),
             vp(*[o.data_ptr() for o in outs]), ns, count, k, _stream(src)), "quip_e8p_gemv_fused")
     return ([h_out] if h_out is not None else []) + outs
 
@@ -538,9 +594,10 @@ def _e8p_gemv_planes_cuda(planes, Qidxs, grid):
     L = capi.lib()
     _need(planes.dtype == torch.uint8 and planes.numel() >= L.quip_e8p_planes_bytes(k), "planes buffer too small")
     y = torch.empty((1, n), dtype=torch.float16, device=Qidxs.device)
+    ws = _gemv_workspace(Qidxs.device, n)
     with torch.cuda.device(Qidxs.device):
-        capi.check(L.quip_e8p_gemv_planes(planes.data_ptr(), Qc.data_ptr(), g.data_ptr(), y.data_ptr(), n, k,
-                                          _stream(Qidxs)), "quip_e8p_gemv_planes")
+        capi.check(L.quip_e8p_gemv_planes_ws(planes.data_ptr(), Qc.data_ptr(), g.data_ptr(), y.data_ptr(), n, k,
+                                             ws.data_ptr(), ws.numel() * 4, _stream(Qidxs)), "quip_e8p_gemv_planes_ws")
     return y
 
 

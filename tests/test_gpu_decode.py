@@ -231,3 +231,32 @@ def test_llama3_8b_shaped_decoder_graph_equals_eager():
     dec.graph = None
     c = dec.generate(6, first_token=11, use_graph=False)
     assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("bad_pos", [-1, 64, 10 ** 12])
+def test_rope_attn_decode_refuses_positions_outside_the_cache(bad_pos):
+    """one step past max_len (or a corrupted position) must not touch memory outside cos / sin / the cache: nothing
+    is appended, the output is NaN (visible downstream), also in split mode with a workspace"""
+    from quip_for_all_amd.register_lib import rope_attn_workspace
+    heads, kvh, hd, max_len = 8, 2, 128, 64
+    g = torch.Generator().manual_seed(0)
+    q = torch.randn(heads, hd, generator=g).half().cuda()
+    k = torch.randn(kvh, hd, generator=g).half().cuda()
+    v = torch.randn(kvh, hd, generator=g).half().cuda()
+    cos = torch.rand(max_len, hd, generator=g).cuda()
+    sin = torch.rand(max_len, hd, generator=g).cuda()
+    guard = 4096      # canaries around the caches
+    buf = torch.full((2, guard + kvh * max_len * hd + guard,), 1.0, dtype=torch.float16, device="cuda")
+    kc = buf[0, guard:guard + kvh * max_len * hd].view(kvh, max_len, hd)
+    vc = buf[1, guard:guard + kvh * max_len * hd].view(kvh, max_len, hd)
+    before = buf.clone()
+    p = torch.tensor([bad_pos], dtype=torch.int64, device="cuda")
+    for ws in (None, rope_attn_workspace(heads, hd, "cuda")):
+        out = torch.ops.quip_lib.rope_attn_decode(q, k, v, cos, sin, p, kc, vc, ws)
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(out).all())
+        assert torch.equal(buf, before)
+    # the next valid call is unaffected (split counters untouched)
+    p.fill_(3)
+    out = torch.ops.quip_lib.rope_attn_decode(q, k, v, cos, sin, p, kc, vc, None)
+    assert bool(torch.isfinite(out).all())

@@ -96,3 +96,42 @@ def test_fast_decoder_from_loaded_hf_model(tmp_path):
         row = logits[prompt.numel() - 1 + t]
         margin = (row.max() - row[int(ptoks[t])]).item()
         assert margin <= 0.03 * (row.abs().max().item() + 1.0), (t, margin)
+
+
+def test_fast_decoder_takes_the_models_rotary_embedding(tmp_path):
+    """Llama-3.1-style rope scaling: LlamaDecoder.from_hf must use the model's scaled inv_freq (not plain
+    theta) -- its logits follow the HF forward -- and must refuse what it does not implement."""
+    from transformers import AutoModelForCausalLM
+    from quip_for_all_amd.quantizer import QuipQuantizer, load_quantized_model
+    from quip_for_all_amd.decode import LlamaDecoder
+    cfg = _tiny_config()
+    scaling = {"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+               "original_max_position_embeddings": 16, "rope_theta": 10000.0}
+    if hasattr(cfg, "rope_parameters"):
+        cfg.rope_parameters = scaling
+    else:
+        cfg.rope_scaling = scaling
+    torch.manual_seed(2)
+    model = AutoModelForCausalLM.from_config(cfg, dtype=torch.float16)
+    plain = 1.0 / (10000.0 ** (torch.arange(0, 64, 2, dtype=torch.float32) / 64))
+    assert not torch.allclose(model.model.rotary_emb.inv_freq.float().cpu(), plain), "config did not scale the rope"
+    qz = QuipQuantizer(codebook="E8P12", inference=True, ft_epochs=0)
+    qz.convert_model(model)
+    _fill_random(model, seed=11)
+    qz.save(model, str(tmp_path))
+    q = load_quantized_model(str(tmp_path), device_map={"": "cuda:0"})
+    dec = LlamaDecoder.from_hf(q, max_len=48)
+    assert torch.allclose(dec.cos[:, :32].cpu(), torch.cos(torch.arange(48.)[:, None] * q.model.rotary_emb.inv_freq.float().cpu()[None]), atol=1e-6)
+    prompt = torch.tensor([5, 17, 3, 99, 42, 7, 1, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 43], device="cuda:0")
+    toks = dec.generate(10, prompt=prompt)
+    seq = torch.cat([prompt, toks])[None]
+    with torch.no_grad():
+        logits = q(seq).logits.float()[0]
+    for t in range(10):
+        row = logits[prompt.numel() - 1 + t]
+        margin = (row.max() - row[int(toks[t])]).item()
+        assert margin <= 0.03 * (row.abs().max().item() + 1.0), (t, margin)
+    # unsupported options raise instead of decoding something else
+    q.config.sliding_window, q.config.layer_types = 16, ["sliding_attention"] * q.config.num_hidden_layers
+    with pytest.raises(NotImplementedError):
+        LlamaDecoder.from_hf(q, max_len=48)

@@ -468,3 +468,54 @@ def test_kone_hadamard_batches_equal_single_rows(n, rows, out_f):
         assert torch.equal(full_in[r:r + 1], one), r
         one = op.had_transform_fused(x[r:r + 1], out_f, n, 1, None, False, None, None, post, bias, 0.11, res[r:r + 1], None, 1e-5, None)
         assert torch.equal(full_out[r:r + 1], one), r
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16])
+@pytest.mark.parametrize("n,rows", [(2, 3), (64, 5), (1024, 7), (4096, 3), (32768, 2)])
+def test_hadamard_op_all_dtypes(Q, dtype, n, rows):
+    """quip_lib::hadamard takes the dtypes of the reference's op (fast_hadamard_transform: fp16 / bf16 / fp32,
+    register_lib.py:10-20): fp32 arithmetic inside, ONE rounding to the I/O dtype.  Bound: the float64 transform of the
+    same (already rounded) input, plus fp32 accumulation noise, plus half an ulp of the output type."""
+    rng = np.random.default_rng(n + rows)
+    x = torch.from_numpy(rng.standard_normal((rows, n)).astype(np.float32)).to(dtype)
+    s = 1.0 / np.sqrt(n)
+    y = torch.ops.quip_lib.hadamard(x.to(DEV), s)
+    assert y.dtype == dtype and y.shape == x.shape
+    ref = O.fwht(x.double().numpy()) * s
+    ulp = {torch.float16: 2.0 ** -11, torch.bfloat16: 2.0 ** -8, torch.float32: 2.0 ** -24}[dtype]
+    scale = np.abs(O.fwht(np.abs(x.double().numpy()))) * s        # sum |x_i| / sqrt(n): accumulation error scale
+    tol = ulp * np.abs(ref) + 2.0 ** -21 * scale + 1e-30
+    assert np.all(np.abs(y.double().cpu().numpy() - ref) <= tol)
+    # 3-D, non-contiguous input like the reference's call sites (quant.py:78-82)
+    x3 = x.to(DEV).reshape(rows, 1, n).expand(rows, 2, n).transpose(0, 1)
+    y3 = torch.ops.quip_lib.hadamard(x3, s)
+    assert torch.equal(y3[0], y) and torch.equal(y3[1], y)
+
+
+def test_transform_vector_lengths_are_checked(Q):
+    """short SU / SV / bias / had / rms_weight vectors would be read out of bounds by the kernels: the ops refuse"""
+    x = torch.zeros(1, 256, dtype=torch.float16, device=DEV)
+    ok = torch.ones(256, dtype=torch.float16, device=DEV)
+    short = torch.ones(100, dtype=torch.float16, device=DEV)
+    op = torch.ops.quip_lib
+    op.had_transform_fused(x, 256, 256, 1, None, True, ok, None, ok, ok, 1.0, None, ok, 1e-5, None)
+    for kw in (dict(pre=short), dict(post=short), dict(bias=short), dict(rms=short)):
+        with pytest.raises((ValueError, RuntimeError)):
+            op.had_transform_fused(x, 256, 256, 1, None, True, kw.get("pre", ok), None, kw.get("post", ok),
+                                   kw.get("bias", ok), 1.0, None, kw.get("rms", ok), 1e-5, None)
+    with pytest.raises((ValueError, RuntimeError)):
+        op.had_transform_planes_fused(x, 256, 1, None, True, short, 1.0, None, 1e-5, None)
+    x688 = torch.zeros(1, 688, dtype=torch.float16, device=DEV)
+    with pytest.raises((ValueError, RuntimeError)):      # (K, K) factor too small
+        op.had_transform_fused(x688, 688, 688, 43, torch.ones(10, 10, dtype=torch.float16, device=DEV), True, None, None,
+                               None, None, 1.0, None, None, 1e-5, None)
+    # a CPU-resident grid must not reach the kernel as a pointer
+    cb = _cb(Q, "E8P12")
+    planes = op.had_transform_planes_fused(x, 256, 1, None, True, ok, 1.0, None, 1e-5, None)
+    Qd = torch.zeros(64, 32, dtype=torch.int16, device=DEV)
+    with pytest.raises((ValueError, RuntimeError)):
+        op.e8p_gemv_planes_group([planes], [Qd], cb.grid_packed_abs.cpu())
+    # QuantLinear refuses an input of the wrong width (the reference fails in x * SU)
+    layer = Q.qlinear.QuantLinear(256, 64, cb, bias=False).to(DEV).eval()
+    with pytest.raises(RuntimeError):
+        layer(torch.zeros(1, 128, dtype=torch.float16, device=DEV))
