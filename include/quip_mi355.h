@@ -77,6 +77,13 @@ int quip_hadamard(const void* x, void* y, int64_t rows, int32_t n, float scale, 
 int quip_e8p_mm_origorder(const void* x, const void* qidxs /* int16 (n, k/8) */,
                           const void* grid_packed_abs /* int64[256] */, void* y,
                           int32_t m, int32_t n, int32_t k, quip_stream_t stream);
+/* Batched E8P12 product for M >= 32 (prompt prefill): fused dequant + MFMA GEMM, y (m, n) = x (m, k) @ W^T with
+ * W = decode(qidxs), fp16 in / fp32 accumulation / fp16 out -- the arithmetic of the reference's M >= 32 path
+ * (e8p12.py:152-155: decompress_e8p_origorder + `x @ W.T`; origin_order.cu:837-885) without ever materialising W.
+ * Any m >= 1 is computed correctly; k % 64 == 0, n % 2 == 0.  QUIP_ERR_UNSUPPORTED otherwise (callers then use
+ * quip_decompress_e8p_origorder + a dense GEMM). */
+int quip_e8p_mm_batched(const void* x, const void* qidxs /* int16 (n, k/8) */, const void* grid_packed_abs,
+                        void* y, int64_t m, int32_t n, int32_t k, quip_stream_t stream);
 /* Workspace variant of the E8P12 product.  For 1 <= m < 32 (the range the codebook module sends to this
  * op, e8p12.py:147-150) the fast path first rewrites every row of x as block fixed point int8 digit planes
  * (one small launch, one workgroup per row) and then runs the integer-domain matrix-core GEMV -- m == 1:

@@ -4,6 +4,7 @@ e8p12_rvq4.py:50-67, d4.py:128-139, hi.py:52-63), and the quantise-time nearest-
 `quantize` (e8p12.py:125-137, e8p12_rvq3.py:81-92, e8p12_rvq4.py:32-45, d4.py:116-123, hi.py:30-39):
 the 65 536-entry E8P12 search is a structured HIP kernel (csrc/quantize.hip), the 256 / 16-entry tables
 (E81B residual, D4, HI) are a small dense arg max like the reference's."""
+import os
 from fractions import Fraction
 
 import torch
@@ -71,6 +72,20 @@ class E8P12_codebook(_Codebook):
 
     def mm(self, input, Qidxs):
         return torch.ops.quip_lib.e8p_mm_origorder(input, Qidxs, self.grid_packed_abs)
+
+    # M >= mm_threshold: fused dequant + MFMA GEMM (csrc/e8p_prefill_gemm.hip) instead of the reference's
+    # decompress + dense GEMM (e8p12.py:152-155) -- same arithmetic (exact fp16 weights, fp32 accumulation, one fp16
+    # rounding), no dense W in memory.  QUIP_BATCHED_MM=0 selects the reference-shaped path (A/B, odd shapes).
+    fused_batched = os.environ.get("QUIP_BATCHED_MM", "1") != "0"
+
+    def forward(self, input, Qidxs):
+        if input.size(0) < self.mm_threshold:
+            return self.mm(input, Qidxs)
+        if (self.fused_batched and input.is_cuda and input.dtype == torch.float16 and input.dim() == 2
+                and Qidxs.shape[0] % 2 == 0 and input.shape[1] % 64 == 0):
+            return torch.ops.quip_lib.e8p_mm_batched(input, Qidxs, self.grid_packed_abs)
+        W = self.decompress_weight(Qidxs)
+        return input @ W.T
 
     @staticmethod
     def planes_supported(q_out, q_in):

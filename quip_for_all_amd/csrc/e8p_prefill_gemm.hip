@@ -1,0 +1,248 @@
+// Fused E8P12 dequant + GEMM for batches (M >= 32 rows: prompt prefill), gfx950.
+//
+//   Y[m, n] = sum_k X[m, k] * W[n, k],   W = decode(Qidxs (N, K/8) int16),  fp16 x fp16 -> fp32 -> fp16
+//
+// Replaces, for M >= 32, the reference's decompress + dense GEMM pair (codebook/e8p12.py:152-155:
+// `decompress_e8p_origorder` materialises the dense fp16 W, quip_cuda/origin_order.cu:837-885, then `x @ W.T` runs
+// in cuBLAS): here W never exists in memory.  Arithmetic is the reference's: exact fp16 weights, fp16 activations,
+// fp32 accumulation (v_mfma_f32_32x32x16_f16), one rounding of the result to fp16.
+//
+// Why this maps well on CDNA4: the B operand of v_mfma_f32_32x32x16_f16 is, per lane, 8 consecutive-k fp16 values
+// of one output column -- exactly the 8 weights of ONE E8P code.  So a lane decodes one 16-bit code (two 8-byte
+// LDS table lookups, one XOR -> eight int8 = 4w; v_perm + v_pk_add_f16 turn them into fp16 through the
+// 0x5c00 | (4w + 128) = 288 + w identity, cf. origin_order.cu:275-282) and holds a complete B fragment: no dense
+// tile, no LDS round trip, no transposition for W.
+//
+// Workgroup = 256 x 256 output tile, 8 waves; wave w owns columns [32 w, 32 w + 32) for all 256 rows (8 row blocks
+// of 32 -> 8 accumulator tiles = 128 registers).  With this split every code of the tile is decoded exactly once
+// per workgroup (a 2 x 4 wave grid would decode each twice), the codes go straight from global memory to registers
+// (nobody shares them), and only X goes through LDS: 256 x 64 fp16 per K step, double buffered, filled by
+// global_load_lds_dwordx4 (no staging registers).  The LDS image is lane-linear, so the bank swizzle
+// (16-byte chunk c of row m stored at c ^ ((m >> 1) & 7): conflict-free ds_read_b128 of the A fragments) is
+// applied to the per-lane SOURCE address.  The MFMA's k index is relabelled so that a lane's four codes of a K
+// step (8 bytes, one load) feed four consecutive MFMAs: k block l >> 5 of step j <-> k = 32 (l >> 5) + 8 j.
+//
+// Workgroup -> tile: blocks are dealt to the XCDs round robin (b % 8); an XCD walks the column tiles of one row tile
+// before moving to the next row tile, so the 32 workgroups resident on an XCD share two X slabs in its L2.
+//
+// Bound: MFMA (2 M N K flops at the dense fp16 peak).  LDS: 2 x 32 KiB tables (16 copies: two-way conflicts) +
+// 2 x 32 KiB X tiles.
+#include "quip_device.hip.h"
+#include "quip_internal.h"
+
+namespace quip {
+
+namespace {
+
+typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t pu32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t pu32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBM = 256, kBN = 256, kBK = 64;
+constexpr int kRep = 16;
+constexpr int kT1 = 0;
+constexpr int kT2 = 256 * kRep * 8;          // 32 KiB
+constexpr int kA = 2 * kT2;                  // 64 KiB: two X tiles of 32 KiB
+constexpr int kTileBytes = kBM * kBK * 2;
+constexpr int kLds = kA + 2 * kTileBytes;    // 128 KiB
+
+// sign table image (same statement as the GEMV's: 4w = T1[abs] ^ T2[sign] byte-wise, origin_order.cu:211-253)
+struct PT2Image {
+  uint2 v[256];
+  constexpr PT2Image() : v{} {
+    for (int s = 0; s < 256; ++s) {
+      int par = 0;
+      for (int b = 0; b < 8; ++b) par ^= (s >> b) & 1;
+      const int sv = s ^ par;
+      uint32_t lo = 0, hi = 0;
+      for (int p = 0; p < 4; ++p) {
+        lo |= (((sv >> (7 - e8p_byte_of_pos(p))) & 1) ? 0xfcu : 0u) << (8 * p);
+        hi |= (((sv >> (7 - e8p_byte_of_pos(p + 4))) & 1) ? 0xfcu : 0u) << (8 * p);
+      }
+      const uint32_t sh = par ? 0x02020202u : 0u;
+      v[s].x = lo ^ sh;
+      v[s].y = hi ^ sh;
+    }
+  }
+};
+__device__ const PT2Image kPT2Img{};
+
+__device__ __forceinline__ uint2 p_lds_read8(uint32_t addr) {
+  const pu32x2 v = *reinterpret_cast<const __attribute__((address_space(3))) pu32x2*>((uintptr_t)addr);
+  return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ f16x8v p_lds_read_frag(uint32_t addr) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) f16x8v*>((uintptr_t)addr);
+}
+
+// four int8 (as 4w + 128, i.e. bytes u) -> two packed fp16 pairs: 0x5c00 | u = 256 + u / 4 = 288 + w
+__device__ __forceinline__ void bytes_to_f16x4(uint32_t u4, uint32_t& lo, uint32_t& hi) {
+  const uint32_t k5c = 0x5c5c5c5cu;
+  const uint32_t a = __builtin_amdgcn_perm(u4, k5c, 0x00050004u);   // [u0, 5c, u1, 5c]
+  const uint32_t b = __builtin_amdgcn_perm(u4, k5c, 0x00070006u);   // [u2, 5c, u3, 5c]
+  const f16x2 m288 = {(f16)-288.f, (f16)-288.f};
+  lo = as_u32(as_f16x2(a) + m288);
+  hi = as_u32(as_f16x2(b) + m288);
+}
+
+__global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __restrict__ X,
+                                                                  const uint16_t* __restrict__ Wc,
+                                                                  const uint64_t* __restrict__ grid,
+                                                                  f16* __restrict__ Y, int M, int N, int K, int MT,
+                                                                  int NT) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+  const int mt = (idx / NT) * 8 + xcd, nt = idx - (idx / NT) * NT;
+  if (mt >= MT) return;
+  const int m0 = mt * kBM, n0 = nt * kBN;
+  const int KT = K / kBK;
+
+  // ---- X tile loader (global_load_lds): instruction i of this wave fills LDS slots [(8 i + wave) * 64, +64) of the
+  // tile; slot s = (row s >> 3, stored chunk s & 7) holds source chunk (s & 7) ^ ((row >> 1) & 7) of that row
+  const f16* xsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (8 * i + wave) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    const int gr = min(m0 + row, M - 1);
+    xsrc[i] = X + (size_t)gr * K + c * 8;
+  }
+  auto issue_x = [&](int t, int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(xsrc[i] + (size_t)t * kBK),
+          (__attribute__((address_space(3))) void*)(smem + kA + buf * kTileBytes + (8 * i + wave) * 1024), 16, 0, 0);
+  };
+  // ---- codes: lane (n = lane & 31, kb = lane >> 5) holds the 4 codes k = 64 t + 32 kb + 8 j .. (j = 0..3) of column
+  // n0 + 32 wave + n
+  const int ncol = n0 + 32 * wave + (lane & 31);
+  const int kb = lane >> 5;
+  const uint16_t* wsrc = Wc + (size_t)min(ncol, N - 1) * (K >> 3) + kb * 4;
+  auto load_codes = [&](int t) -> pu32x2 {
+    return *reinterpret_cast<const pu32x2*>(wsrc + (size_t)t * (kBK / 8));
+  };
+
+  issue_x(0, 0);
+  pu32x2 codes = load_codes(0);
+
+  // ---- tables: T1' = (4a | 1) ^ 0x80.. (the ^0x80 turns 4w into the unsigned byte 4w + 128 the fp16 conversion
+  // wants), T2 = sign masks; 16 copies each, copy (lane + c) & 15 at step c
+  {
+    const int e = wave * 32 + (lane & 31);
+    const bool second = (lane & 32) != 0;
+    const uint2 raw = second ? kPT2Img.v[e] : reinterpret_cast<const uint2*>(grid)[e];
+    const uint32_t t1x = (__builtin_amdgcn_perm(0u, raw.x, 0x03010200u) | 0x01010101u) ^ 0x80808080u;
+    const uint32_t t1y = (__builtin_amdgcn_perm(0u, raw.y, 0x03010200u) | 0x01010101u) ^ 0x80808080u;
+    const pu32x2 val = {second ? raw.x : t1x, second ? raw.y : t1y};
+    const uint32_t rowbase = (second ? (uint32_t)kT2 : (uint32_t)kT1) + (uint32_t)e * (kRep * 8);
+#pragma unroll
+    for (int c = 0; c < kRep; ++c) {
+      const uint32_t copy = (uint32_t)(lane + c) & (kRep - 1);
+      *reinterpret_cast<__attribute__((address_space(3))) pu32x2*>((uintptr_t)(rowbase + copy * 8)) = val;
+    }
+  }
+  const uint32_t lane_c1 = (uint32_t)(lane & 15) << 3;
+  const uint32_t lane_c2 = lane_c1 | (uint32_t)kT2;
+  // A fragment address of this lane for k step j (without tile base / row block): row m = lane & 31
+  const int m = lane & 31;
+  uint32_t aoff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) aoff[j] = (uint32_t)(m * 128 + (((kb * 4 + j) ^ ((m >> 1) & 7)) << 4));
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+  for (int t = 0; t < KT; ++t) {
+    __syncthreads();     // X tile t has landed (all waves), tile t - 1's buffer is free
+    pu32x2 nxt = codes;
+    if (t + 1 < KT) {
+      issue_x(t + 1, (t + 1) & 1);
+      nxt = load_codes(t + 1);
+    }
+    const uint32_t abase = (uint32_t)(kA + (t & 1) * kTileBytes);
+    const uint32_t cw[2] = {codes.x, codes.y};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t d = cw[j >> 1];
+      uint32_t a1, a2;
+      if (j & 1) {
+        a1 = ((d >> 17) & 0x7f80u) | lane_c1;
+        a2 = ((d >> 9) & 0x7f80u) | lane_c2;
+      } else {
+        a1 = ((d >> 1) & 0x7f80u) | lane_c1;
+        a2 = ((d << 7) & 0x7f80u) | lane_c2;
+      }
+      const uint2 t1 = p_lds_read8(a1), t2 = p_lds_read8(a2);
+      pu32x4 bw;
+      uint32_t w0, w1, w2, w3;
+      bytes_to_f16x4(t1.x ^ t2.x, w0, w1);
+      bytes_to_f16x4(t1.y ^ t2.y, w2, w3);
+      bw = pu32x4{w0, w1, w2, w3};
+      const f16x8v B = __builtin_bit_cast(f16x8v, bw);
+      const uint32_t aj = abase + aoff[j];
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const f16x8v A = p_lds_read_frag(aj + (uint32_t)b * 4096u);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, acc[b], 0, 0, 0);
+      }
+    }
+    codes = nxt;
+  }
+
+  // ---- epilogue: D row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the 32-row block, column = lane & 31.  Neighbour
+  // lanes exchange one value per register pair so that every lane stores two adjacent columns (4 bytes): even lanes
+  // the even register's row, odd lanes the odd register's
+  const bool odd = (lane & 1) != 0;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const float mine = odd ? acc[b][r + 1] : acc[b][r];
+      const float give = odd ? acc[b][r] : acc[b][r + 1];
+      const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, true));
+      const int rr = odd ? r + 1 : r;
+      const int row = m0 + 32 * b + (rr & 3) + 8 * (rr >> 2) + 4 * kb;
+      const int col = ncol & ~1;
+      const uint32_t pk = odd ? pack_f16(got, mine) : pack_f16(mine, got);
+      if (row < M && col + 1 < N) {
+        *reinterpret_cast<uint32_t*>(Y + (size_t)row * N + col) = pk;
+      } else if (row < M && col < N) {
+        Y[(size_t)row * N + col] = odd ? (f16)got : (f16)mine;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+bool e8p_prefill_gemm_supported(int64_t m, int n, int k) {
+  return m >= 1 && n >= 2 && n % 2 == 0 && k >= kBK && k % kBK == 0 && m < ((int64_t)1 << 31);
+}
+
+int e8p_prefill_gemm_launch(const void* x, const void* qidxs, const void* grid, void* y, int64_t m, int n, int k,
+                            hipStream_t stream) {
+  if (!e8p_prefill_gemm_supported(m, n, k)) return QUIP_ERR_UNSUPPORTED;
+  const int MT = (int)((m + kBM - 1) / kBM), NT = (n + kBN - 1) / kBN;
+  const int64_t blocks = (int64_t)((MT + 7) / 8) * NT * 8;
+  if (blocks > 0x7fffffff) return QUIP_ERR_UNSUPPORTED;
+  static bool configured = false;   // benign race: idempotent attribute
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(e8p_prefill_gemm_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess)
+      return QUIP_ERR_LAUNCH;
+    configured = true;
+  }
+  hipLaunchKernelGGL(e8p_prefill_gemm_kernel, dim3((unsigned)blocks), dim3(512), kLds, stream,
+                     reinterpret_cast<const f16*>(x), reinterpret_cast<const uint16_t*>(qidxs),
+                     reinterpret_cast<const uint64_t*>(grid), reinterpret_cast<f16*>(y), (int)m, n, k, MT, NT);
+  return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+}
+
+}  // namespace quip

@@ -121,6 +121,10 @@ bool e8p_gemv_mfma_fused_supported(const int* ns, int count, int k);
 int e8p_gemv_mfma_fused_launch(const GemvFusedIn& in, const void* const* qidxs, const void* grid,
                                void* const* ys, const int* ns, int count, int k, const GemvTune& tune,
                                hipStream_t stream);
+// fused E8P12 dequant + MFMA GEMM for batches (e8p_prefill_gemm.hip): y (m, n) = x (m, k) @ decode(qidxs)^T
+bool e8p_prefill_gemm_supported(int64_t m, int n, int k);
+int e8p_prefill_gemm_launch(const void* x, const void* qidxs, const void* grid, void* y, int64_t m, int n, int k,
+                            hipStream_t stream);
 // bf16 / fp32 (and plain fp16) Walsh-Hadamard transform of the last dimension (hadamard_generic.hip)
 int hadamard_generic_launch(const void* x, void* y, int64_t rows, int n, float scale, int dtype, hipStream_t stream);
 int had_transform_launch(const void* x, void* y, int64_t rows, int in_features, int out_features,

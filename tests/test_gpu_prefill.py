@@ -1,0 +1,88 @@
+"""Fused E8P12 dequant + MFMA GEMM for batches (csrc/e8p_prefill_gemm.hip; replaces the reference's M >= 32
+decompress + dense GEMM, codebook/e8p12.py:152-155, origin_order.cu:837-885).  Bound: the float64 product of the
+SAME fp16 operands, one fp16 rounding of the result + fp32 accumulation in any order (the MFMA's and cuBLAS's orders
+differ too)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import quip_oracle as O
+from tests.test_gpu_ops import DEV, _cb
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Q():
+    assert torch.cuda.is_available()
+    import quip_for_all_amd as Q
+    return Q
+
+
+def _tol(x64, W64, y64):
+    absdot = np.abs(x64) @ np.abs(W64).T
+    return 2.0 ** -10 * np.abs(y64) + 2.0 ** -21 * absdot + 1e-7
+
+
+@pytest.mark.parametrize("m", [1, 32, 40, 255, 256, 257, 700])
+@pytest.mark.parametrize("n,k", [(64, 64), (256, 256), (30, 128), (290, 704), (512, 4096), (96, 11008)])
+def test_batched_product_against_oracle(Q, m, n, k):
+    P = O.make_layer("E8P12", k, n, seed=m + n + k)
+    rng = np.random.default_rng(m * 7 + n)
+    x = torch.from_numpy(rng.standard_normal((m, k)).astype(np.float16)).to(DEV)
+    Qd = torch.from_numpy(P.Qidxs).to(DEV)
+    cb = _cb(Q, "E8P12")
+    y = torch.ops.quip_lib.e8p_mm_batched(x, Qd, cb.grid_packed_abs)
+    assert y.shape == (m, n) and y.dtype == torch.float16
+    W64 = O.decompress_e8p(P.Qidxs).astype(np.float64)
+    x64 = x.cpu().numpy().astype(np.float64)
+    y64 = x64 @ W64.T
+    err = np.abs(y.cpu().numpy().astype(np.float64) - y64)
+    assert np.all(err <= _tol(x64, W64, y64)), (err.max(), np.unravel_index(err.argmax(), err.shape))
+
+
+def test_codebook_forward_takes_the_fused_path_and_matches_the_reference_shaped_one(Q):
+    """E8P12_codebook.forward for M >= 32: fused kernel == decompress + dense GEMM within fp32 accumulation order;
+    exactly linear in x's rows (a row's result does not depend on which other rows are in the batch)"""
+    cb = _cb(Q, "E8P12")
+    g = torch.Generator().manual_seed(5)
+    n, k, m = 1024, 2048, 320
+    Qd = torch.randint(-32768, 32768, (n, k // 8), generator=g, dtype=torch.int32).to(torch.int16).to(DEV)
+    x = torch.randn(m, k, generator=g).half().to(DEV)
+    y = cb(x, Qd)
+    W = cb.decompress_weight(Qd)
+    ref = (x.float() @ W.float().T)
+    assert torch.all((y.float() - ref).abs() <= 2.0 ** -10 * ref.abs() + 2.0 ** -19 * (x.float().abs() @ W.float().abs().T))
+    y2 = cb(x[37:37 + 64].contiguous(), Qd)
+    assert torch.equal(y[37:37 + 64], y2), "rows are independent of their position in the batch"
+    try:
+        type(cb).fused_batched = False
+        y_ref_path = cb(x, Qd)
+    finally:
+        type(cb).fused_batched = True
+    assert torch.all((y.float() - y_ref_path.float()).abs() <= 2.0 ** -9 * ref.abs() + 2.0 ** -18 * (x.float().abs() @ W.float().abs().T))
+
+
+@pytest.mark.parametrize("fin,fout", [(4096, 11008), (11008, 4096)])
+def test_config5_full_size(Q, fin, fout):
+    """BASELINE configs[4] at its real size: M = 16 x 2048 rows through QuantLinear.forward (batch Hadamard kernels +
+    fused dequant GEMM).  Sampled rows against the float64 oracle of the whole module, and row-against-single-row
+    bit identity of the batch path."""
+    from quip_for_all_amd.qlinear import QuantLinear
+    P = O.make_layer("E8P12", fin, fout, seed=17)
+    layer = QuantLinear.from_params(P).to(DEV).eval()
+    M = 16 * 2048
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(M, fin, generator=g, device=DEV, dtype=torch.float16)
+    with torch.no_grad():
+        y = layer(x)
+    assert y.shape == (M, fout) and bool(torch.isfinite(y).all())
+    rows = [0, 1, 255, 256, 4097, 20000, M - 1]
+    xs = x[rows].cpu().numpy()
+    yo = O.qlinear_forward(P, xs, mode="exact")
+    bound = O.parity_bound(yo)
+    err = np.abs(y[rows].cpu().numpy().astype(np.float64) - yo)
+    assert np.all(err <= bound), float((err / bound).max())
+    with torch.no_grad():
+        y32 = layer(x[4096:4096 + 32].contiguous())
+    assert torch.equal(y32, y[4096:4096 + 32]), "a row's result does not depend on the batch it is in"
