@@ -128,7 +128,8 @@ def cpu_baseline(budget_s=25.0):
 def prefill_config5(dec, batch=16, seq=2048):
     """BASELINE.json configs[4] (bs=16 x seq=2048 prefill, the MFMA batched-GEMM path) as an extra of the N=1 line:
     the seven QuantLinear forwards of ONE decoder block of the benchmarked model on M = batch * seq rows
-    (Hadamard -> decompress -> dense fp16 GEMM -> Hadamard, as the reference does for M >= 32), HIP-event timed;
+    (batch Hadamard kernels -> fused E8P12 dequant + MFMA GEMM, csrc/e8p_prefill_gemm.hip -> batch Hadamard; no dense W
+    and no vendor GEMM on the path), HIP-event timed;
     MFMA roofline = 2 M in out flops over the 2.5 PFLOP/s dense fp16 peak (MI355X_MICROARCH.md)."""
     import torch
     L = dec.layers[0]
@@ -152,7 +153,7 @@ def prefill_config5(dec, batch=16, seq=2048):
             ts.append(a.elapsed_time(b))
     ms = sorted(ts)[1]
     return {"workload": "Llama-2-7B E8P12, bs=%d x seq=%d prefill: the 7 QuantLinear forwards of one decoder block "
-                        "(Hadamard + decompress + dense fp16 GEMM + Hadamard), M=%d rows" % (batch, seq, M),
+                        "(Hadamard + fused dequant MFMA GEMM + Hadamard), M=%d rows" % (batch, seq, M),
             "ms_per_block": round(ms, 3), "tflops": round(flops / ms / 1e9, 1),
             "roofline": {"bound": "mfma", "achieved": round(flops / ms / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": round(flops / ms / 1e9 / 2500.0, 4)},

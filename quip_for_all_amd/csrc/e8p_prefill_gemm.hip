@@ -26,7 +26,10 @@
 // before moving to the next row tile, so the 32 workgroups resident on an XCD share two X slabs in its L2.
 //
 // Bound: MFMA (2 M N K flops at the dense fp16 peak).  LDS: 2 x 32 KiB tables (16 copies: two-way conflicts) +
-// 2 x 32 KiB X tiles.
+// 3 x 32 KiB X tiles (prefetch distance 2, counted vmcnt + raw s_barrier: with one tile in flight the HBM / L2
+// latency of the X stream was exposed every K step).
+#include <type_traits>
+
 #include "quip_device.hip.h"
 #include "quip_internal.h"
 
@@ -43,9 +46,10 @@ constexpr int kBM = 256, kBN = 256, kBK = 64;
 constexpr int kRep = 16;
 constexpr int kT1 = 0;
 constexpr int kT2 = 256 * kRep * 8;          // 32 KiB
-constexpr int kA = 2 * kT2;                  // 64 KiB: two X tiles of 32 KiB
+constexpr int kA = 2 * kT2;                  // 64 KiB; behind it the X tiles of 32 KiB
 constexpr int kTileBytes = kBM * kBK * 2;
-constexpr int kLds = kA + 2 * kTileBytes;    // 128 KiB
+constexpr int kStages = 3;                   // X tiles in LDS: two in flight while one is multiplied
+constexpr int kLds = kA + kStages * kTileBytes;   // 160 KiB
 
 // sign table image (same statement as the GEMV's: 4w = T1[abs] ^ T2[sign] byte-wise, origin_order.cu:211-253)
 struct PT2Image {
@@ -122,12 +126,19 @@ __global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __r
   const int ncol = n0 + 32 * wave + (lane & 31);
   const int kb = lane >> 5;
   const uint16_t* wsrc = Wc + (size_t)min(ncol, N - 1) * (K >> 3) + kb * 4;
-  auto load_codes = [&](int t) -> pu32x2 {
-    return *reinterpret_cast<const pu32x2*>(wsrc + (size_t)t * (kBK / 8));
+  // (asm: beside LDS-DMA loads in flight hipcc waits vmcnt(0) for any ordinary register load, which would drain the
+  //  prefetch queue every tile; all VMEM traffic of the K loop is counted by hand instead)
+  auto load_codes = [&](pu32x2& dst, int t) {
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(wsrc + (size_t)t * (kBK / 8)) : "memory");
   };
 
+  // prefetch distance 2: tiles 0 and 1 are requested here, tile t + 2 at the top of iteration t.  Per tile and wave:
+  // one code load + four LDS-DMA instructions = 5 VMEM operations.
+  pu32x2 cq[kStages];
+  load_codes(cq[0], 0);
   issue_x(0, 0);
-  pu32x2 codes = load_codes(0);
+  load_codes(cq[1], min(1, KT - 1));      // (past the end: tile KT - 1 again -- the queue depth stays constant, so
+  issue_x(min(1, KT - 1), 1);             //  every wait below is the same counted wait, with no branch around it)
 
   // ---- tables: T1' = (4a | 1) ^ 0x80.. (the ^0x80 turns 4w into the unsigned byte 4w + 128 the fp16 conversion
   // wants), T2 = sign masks; 16 copies each, copy (lane + c) & 15 at step c
@@ -159,43 +170,95 @@ __global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __r
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
 
-  for (int t = 0; t < KT; ++t) {
-    __syncthreads();     // X tile t has landed (all waves), tile t - 1's buffer is free
-    pu32x2 nxt = codes;
-    if (t + 1 < KT) {
-      issue_x(t + 1, (t + 1) & 1);
-      nxt = load_codes(t + 1);
+  // ---- the K loop.  k steps of 16 (8 MFMAs per wave each) flow across the 64-wide tiles without a bubble: during
+  // step g the two table lookups and the eight A fragments of step g + 1 are requested (asm LDS reads, pinned by
+  // sched_barrier: left to itself the compiler issues two fragment reads, waits, issues two MFMAs); after four of the
+  // step's MFMAs the lookups have landed (lgkmcnt(8): the oldest two of ten reads) and the next B fragment is
+  // decoded under the other four.  The only workgroup synchronisation is in the MIDDLE of a tile: "tile t + 1 has
+  // landed" (vmcnt(0) + barrier), which also says that everybody is done with tile t - 1, whose buffer the loads
+  // of tile t + 2 then take.  So step 3 of tile t can already request step 0 of tile t + 1.
+  pu32x2 tl[2][2];      // [parity of the step][T1 / T2 entry]
+  pu32x4 Af[2][8];
+  auto request = [&](uint32_t d, bool hi, uint32_t aj, pu32x2 (&tt)[2], pu32x4 (&A8)[8]) {
+    uint32_t a1, a2;
+    if (hi) {
+      a1 = ((d >> 17) & 0x7f80u) | lane_c1;
+      a2 = ((d >> 9) & 0x7f80u) | lane_c2;
+    } else {
+      a1 = ((d >> 1) & 0x7f80u) | lane_c1;
+      a2 = ((d << 7) & 0x7f80u) | lane_c2;
     }
-    const uint32_t abase = (uint32_t)(kA + (t & 1) * kTileBytes);
-    const uint32_t cw[2] = {codes.x, codes.y};
+    asm volatile("ds_read_b64 %0, %1" : "=v"(tt[0]) : "v"(a1));
+    asm volatile("ds_read_b64 %0, %1" : "=v"(tt[1]) : "v"(a2));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(A8[0]) : "v"(aj));
+    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(A8[1]) : "v"(aj));
+    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(A8[2]) : "v"(aj));
+    asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(A8[3]) : "v"(aj));
+    asm volatile("ds_read_b128 %0, %1 offset:16384" : "=v"(A8[4]) : "v"(aj));
+    asm volatile("ds_read_b128 %0, %1 offset:20480" : "=v"(A8[5]) : "v"(aj));
+    asm volatile("ds_read_b128 %0, %1 offset:24576" : "=v"(A8[6]) : "v"(aj));
+    asm volatile("ds_read_b128 %0, %1 offset:28672" : "=v"(A8[7]) : "v"(aj));
+  };
+  auto frag_b = [&](const pu32x2 (&tt)[2]) -> f16x8v {
+    uint32_t w0, w1, w2, w3;
+    bytes_to_f16x4(tt[0].x ^ tt[1].x, w0, w1);
+    bytes_to_f16x4(tt[0].y ^ tt[1].y, w2, w3);
+    return __builtin_bit_cast(f16x8v, pu32x4{w0, w1, w2, w3});
+  };
+  // tiles 0 and 1 (and the tables) are in LDS; first step's operands
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(cq[0]), "+v"(cq[1]) : : "memory");
+  __syncthreads();
+  request(cq[0].x, false, (uint32_t)kA + aoff[0], tl[0], Af[0]);
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(tl[0][0]), "+v"(tl[0][1]), "+v"(Af[0][0]), "+v"(Af[0][1]), "+v"(Af[0][2]), "+v"(Af[0][3]),
+                 "+v"(Af[0][4]), "+v"(Af[0][5]), "+v"(Af[0][6]), "+v"(Af[0][7]));
+  f16x8v B = frag_b(tl[0]);
+
+  // one tile: `st` = t % 3 (its buffer / code register), compile-time through the 3x unrolled loop
+  auto tile = [&](int t, auto stc) {
+    constexpr int st = decltype(stc)::value;
+    constexpr int st1 = (st + 1) % kStages, st2 = (st + 2) % kStages;
+    const uint32_t abase = (uint32_t)(kA + st * kTileBytes);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const uint32_t d = cw[j >> 1];
-      uint32_t a1, a2;
-      if (j & 1) {
-        a1 = ((d >> 17) & 0x7f80u) | lane_c1;
-        a2 = ((d >> 9) & 0x7f80u) | lane_c2;
-      } else {
-        a1 = ((d >> 1) & 0x7f80u) | lane_c1;
-        a2 = ((d << 7) & 0x7f80u) | lane_c2;
-      }
-      const uint2 t1 = p_lds_read8(a1), t2 = p_lds_read8(a2);
-      pu32x4 bw;
-      uint32_t w0, w1, w2, w3;
-      bytes_to_f16x4(t1.x ^ t2.x, w0, w1);
-      bytes_to_f16x4(t1.y ^ t2.y, w2, w3);
-      bw = pu32x4{w0, w1, w2, w3};
-      const f16x8v B = __builtin_bit_cast(f16x8v, bw);
-      const uint32_t aj = abase + aoff[j];
+      const int c = j & 1, nx = c ^ 1;
+      // operands of the next step: step j + 1 of this tile, or step 0 of the next one
+      if (j < 3)
+        request(j + 1 < 2 ? cq[st].x : cq[st].y, ((j + 1) & 1) != 0, abase + aoff[j + 1], tl[nx], Af[nx]);
+      else
+        request(cq[st1].x, false, (uint32_t)(kA + st1 * kTileBytes) + aoff[0], tl[nx], Af[nx]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        const f16x8v A = p_lds_read_frag(aj + (uint32_t)b * 4096u);
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, acc[b], 0, 0, 0);
+      for (int b = 0; b < 4; ++b)
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, Af[c][b]), B, acc[b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(tl[nx][0]), "+v"(tl[nx][1]));
+      const f16x8v Bn = frag_b(tl[nx]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int b = 4; b < 8; ++b)
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, Af[c][b]), B, acc[b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(Af[nx][0]), "+v"(Af[nx][1]), "+v"(Af[nx][2]), "+v"(Af[nx][3]), "+v"(Af[nx][4]),
+                     "+v"(Af[nx][5]), "+v"(Af[nx][6]), "+v"(Af[nx][7]));
+      B = Bn;
+      if (j == 1) {
+        // middle of the tile: tile t + 1 (requested in the middle of tile t - 1) has landed everywhere; tile t - 1 is
+        // dead, its buffer takes tile t + 2 (past the end: tile KT - 1 again, harmless, keeps the code uniform)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(cq[st1]) : : "memory");
+        __builtin_amdgcn_s_barrier();
+        load_codes(cq[st2], min(t + 2, KT - 1));
+        issue_x(min(t + 2, KT - 1), st2);
       }
     }
-    codes = nxt;
+  };
+  for (int t = 0; t < KT; t += kStages) {
+    tile(t, std::integral_constant<int, 0>{});
+    if (t + 1 < KT) tile(t + 1, std::integral_constant<int, 1>{});
+    if (t + 2 < KT) tile(t + 2, std::integral_constant<int, 2>{});
   }
-
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing filler tile
   // ---- epilogue: D row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the 32-row block, column = lane & 31.  Neighbour
   // lanes exchange one value per register pair so that every lane stores two adjacent columns (4 bytes): even lanes
   // the even register's row, odd lanes the odd register's
