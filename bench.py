@@ -88,17 +88,24 @@ def gemv_roofline(dec):
     achieved = per_launch_bytes / per_launch_s / 1e9
     # measured HBM bytes per GEMV launch: the committed PMC pass of THIS workload (tools/prof_bench.sh),
     # one file per model; null when there is none for the model being run
-    traffic = None
+    traffic = traffic_src = None
     name = "gemv_hbm_traffic.json" if dec.s.hidden == 4096 and dec.s.layers == 32 else \
         f"gemv_hbm_traffic_h{dec.s.hidden}_l{dec.s.layers}.json"
     pf = os.path.join(REPO, "profiles", name)
     if os.path.exists(pf):
         try:
-            traffic = json.load(open(pf)).get("hbm_bytes_per_launch")
+            j = json.load(open(pf))
+            traffic = j.get("hbm_bytes_per_launch")
+            # PMC counters need rocprofv3 around the process, so this figure is not measured in this run: it is the
+            # committed FETCH_SIZE pass of the same workload (tools/prof_bench.sh), stamped with where it came from
+            traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2, %s)" % (name, j.get("measured_at", "round 1"))
         except Exception:
             traffic = None
-    return {"bound": "hbm", "kernel": "e8p_gemv_mfma_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+    big = any(m.Qidxs.numel() * 2 >= (16 << 20) and m.q_in_features >= 8192 for layer in dec.layers[:1]
+              for m in layer.values() if hasattr(m, "Qidxs"))
+    return {"bound": "hbm", "kernel": "e8p_gemv_v2_kernel (launches >= 16 MB at k >= 8192) / e8p_gemv_mfma_kernel" if big
+            else "e8p_gemv_mfma_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "launches": launches, "algorithmic_bytes_per_launch": round(per_launch_bytes),
             "mean_launch_us": round(per_launch_s * 1e6, 3)}
 
@@ -152,12 +159,82 @@ def prefill_config5(dec, batch=16, seq=2048):
             torch.cuda.synchronize()
             ts.append(a.elapsed_time(b))
     ms = sorted(ts)[1]
-    return {"workload": "Llama-2-7B E8P12, bs=%d x seq=%d prefill: the 7 QuantLinear forwards of one decoder block "
+    # time to first token of ONE 2048-token prompt through the whole model (LlamaDecoder.prefill: all blocks incl.
+    # causal attention, rotary embedding, cache fill, final norm + lm_head of the last token)
+    ttft = None
+    try:
+        import quip_for_all_amd.decode as Dm
+        d2 = dec if dec.max_len >= seq else None
+        if d2 is None:
+            d2 = object.__new__(Dm.LlamaDecoder)
+            d2.__dict__.update(dec.__dict__)
+            d2.max_len = seq
+            d2._init_runtime()
+        prompt = torch.randint(0, dec.s.vocab, (seq,), device=dev)
+        with torch.no_grad():
+            d2.prefill(prompt)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            d2.prefill(prompt)
+            b.record()
+            torch.cuda.synchronize()
+        ttft = round(a.elapsed_time(b), 2)
+        del d2
+    except Exception as e:  # an extra of an extra
+        ttft = repr(e)
+    return {"ttft_ms_one_2048_token_prompt_whole_model": ttft,
+            "workload": "Llama-2-7B E8P12, bs=%d x seq=%d prefill: the 7 QuantLinear forwards of one decoder block "
                         "(Hadamard + fused dequant MFMA GEMM + Hadamard), M=%d rows" % (batch, seq, M),
             "ms_per_block": round(ms, 3), "tflops": round(flops / ms / 1e9, 1),
             "roofline": {"bound": "mfma", "achieved": round(flops / ms / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": round(flops / ms / 1e9 / 2500.0, 4)},
             "ttft_linear_layers_ms": round(ms * dec.s.layers, 1)}
+
+
+def decode_parity_check(dec, n_tokens=8):
+    """outside the timed region: the first `n_tokens` greedy tokens of the captured (fused, grouped) step equal those
+    of the eager step with every fusion switched off (one launch per stage and module group: the reference's
+    op sequence per QuantLinear) on the SAME 32-layer model the bench times"""
+    import torch
+    with torch.no_grad():
+        fused = dec.generate(n_tokens, first_token=7, use_graph=True).cpu().tolist()
+        saved = (dec.fused_prologue, dec.chain)
+        try:
+            dec.fused_prologue, dec.chain = False, False      # (the fused transforms / GEMVs are bit identical by design;
+            plain = dec.generate(n_tokens, first_token=7, use_graph=False).cpu().tolist()   # attention stays as it is)
+        finally:
+            dec.fused_prologue, dec.chain = saved
+    return {"tokens": n_tokens, "captured_fused_step_equals_eager_unfused_step": fused == plain,
+            "first_tokens": fused}
+
+
+def time_decoder(D, shape, codebook, steps, warmup, device, **cb_kwargs):
+    """tokens/s of one more configuration (BASELINE configs[2], [3]) with the same procedure as the headline"""
+    import torch
+    dec = D.LlamaDecoder(shape, codebook, max_len=steps + warmup + 8, device=device, seed=0,
+                         device_init=shape.hidden >= 8192, **cb_kwargs)
+    dec.capture()
+    dec.reset(first_token=1)
+    with torch.no_grad():
+        for _ in range(warmup):
+            dec.graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            dec.graph.replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    algo = dec.algorithmic_bytes_per_token()
+    out = {"codebook": codebook, "layers": shape.layers, "hidden": shape.hidden, "ffn": shape.ffn,
+           "tokens_per_s": round(steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+           "warmup": warmup, "algorithmic_bytes_per_token": algo,
+           "token_roofline_frac": round(steps / dt / (HBM_PEAK_GBPS * 1e9 / algo), 4)}
+    if codebook == "E8P12":
+        out["gemv_roofline"] = gemv_roofline(dec)
+    del dec
+    torch.cuda.empty_cache()
+    return out
 
 
 def max_over_ranks(dist, dt, device):
@@ -202,6 +279,8 @@ def main():
     ap.add_argument("--codebook", default="E8P12")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefill", action="store_true", help="skip the configs[4] prefill extra of the N=1 7B line")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the configs[2] / [3] extras (70B E8P12, 7B E8P12RVQ4B, 7B D4) of the N=1 7B line")
     ap.add_argument("--dist-selftest", action="store_true",
                     help="exercise only the replica plumbing (rendezvous, barrier, max-over-ranks, rank-0 line) "
                          "with a synthetic per-rank time; runs on CPU with gloo (tests/test_bench_replicas.py)")
@@ -272,11 +351,28 @@ def main():
         }
         if a.codebook == "E8P12":
             out["roofline"] = gemv_roofline(dec)
+        try:
+            out["parity"] = decode_parity_check(dec)
+        except Exception as e:
+            out["parity"] = {"error": repr(e)}
         if a.model == "7b" and a.codebook == "E8P12" and world == 1 and not a.no_prefill:
             try:
                 out["prefill"] = prefill_config5(dec)
             except Exception as e:  # an extra, never the headline
                 out["prefill"] = {"error": repr(e)}
+        if a.model == "7b" and a.codebook == "E8P12" and world == 1 and not a.no_extras:
+            # BASELINE configs[2] and [3], timed by the same procedure after the headline (never part of `value`)
+            del dec
+            torch.cuda.empty_cache()
+            extras = {}
+            for key, (shp, cbk, st, kw) in {"llama2_70b_e8p12": (D.LLAMA2_70B, "E8P12", 32, {}),
+                                            "llama2_7b_e8p12rvq4b": (D.LLAMA2_7B, "E8P12RVQ4B", 64, {}),
+                                            "llama2_7b_d4": (D.LLAMA2_7B, "D4", 64, {})}.items():
+                try:
+                    extras[key] = time_decoder(D, shp, cbk, st, 8, f"cuda:{local_rank}", **kw)
+                except Exception as e:
+                    extras[key] = {"error": repr(e)}
+            out["extras"] = extras
         if not a.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only (bench contract)
             try:
                 out["cpu_baseline"] = cpu_baseline()

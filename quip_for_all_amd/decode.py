@@ -307,6 +307,33 @@ class LlamaDecoder:
         self.pos.add_(1)
         return logits
 
+    @torch.no_grad()
+    def prefill(self, tokens):
+        """Batched prompt pass (the reference demo's prefill, example_generate.py:36-47): all `tokens` (1-D ids) go
+        through every block at once -- QuantLinear on (P, hidden) rows (M >= 32: the fused dequant MFMA GEMM, fewer
+        rows: the skinny paths), rotary embedding for positions 0..P-1, causal attention, K / V written to rows 0..P-1
+        of the static cache -- and the position counter is left at P.  Returns the logits of the last token (1, vocab)."""
+        s = self.s
+        tokens = torch.as_tensor(tokens, dtype=torch.long, device=self.dev).reshape(-1)
+        P = tokens.numel()
+        assert 1 <= P <= self.max_len
+        h = self.embed[tokens]                                          # (P, hidden)
+        cos, sin = self.cos[:P], self.sin[:P]                           # (P, head_dim)
+        for i, L in enumerate(self.layers):
+            q, k, v = forward_group([L["q"], L["k"], L["v"]], h, rms_weight=L["ln1"], rms_eps=s.rms_eps)
+            q = self._rope(q.view(P, s.heads, s.head_dim).transpose(0, 1), cos, sin)          # (heads, P, hd)
+            k = self._rope(k.view(P, s.kv_heads, s.head_dim).transpose(0, 1), cos, sin)
+            v = v.view(P, s.kv_heads, s.head_dim).transpose(0, 1)
+            self.kcache[i][:, :P].copy_(k)
+            self.vcache[i][:, :P].copy_(v)
+            a = F.scaled_dot_product_attention(q[None], k[None], v[None], is_causal=True,
+                                               enable_gqa=(s.kv_heads != s.heads))[0]         # (heads, P, hd)
+            h = L["o"].forward_fused(a.transpose(0, 1).reshape(P, s.hidden), residual=h)
+            g, u = forward_group([L["gate"], L["up"]], h, rms_weight=L["ln2"], rms_eps=s.rms_eps)
+            h = L["down"].forward_fused(u, gate=g, residual=h)
+        self.pos.fill_(P)
+        return F.rms_norm(h[-1:], (s.hidden,), self.final_norm, s.rms_eps) @ self.lm_head.T
+
     def reset(self, first_token=1):
         self.tok.fill_(first_token)
         self.pos.zero_()
@@ -328,11 +355,12 @@ class LlamaDecoder:
         self.reset()
 
     @torch.no_grad()
-    def generate(self, n_tokens, first_token=1, use_graph=True, prompt=None, temperature=None, top_k=None):
+    def generate(self, n_tokens, first_token=1, use_graph=True, prompt=None, temperature=None, top_k=None,
+                 batched_prefill=True):
         """decode n_tokens (greedy, or sampled when a temperature is given: set_sampling); returns the
-        token ids (device tensor).  `prompt` (1-D token ids) is fed
-        token by token through the same step (teacher forced, filling the KV cache), then decoding
-        continues greedily from its last token; prompt length + n_tokens <= max_len + 1."""
+        token ids (device tensor).  `prompt` (1-D token ids): all but its last token go through ONE batched
+        pass (`prefill`; batched_prefill=False feeds them token by token through the captured step instead, teacher
+        forced), then decoding continues from the last prompt token; prompt length + n_tokens <= max_len + 1."""
         if prompt is not None:
             prompt = torch.as_tensor(prompt, dtype=torch.long, device=self.dev).reshape(-1)
             first_token = int(prompt[0])
@@ -344,6 +372,12 @@ class LlamaDecoder:
             self.capture()
             self.reset(first_token)
         out = torch.empty(n_tokens, dtype=torch.long, device=self.dev)
+        if batched_prefill and n_prompt >= 1:
+            # all prompt tokens but the last in one batched pass (fills cache rows 0..P-2); the last one goes through
+            # the captured step like every generated token
+            self.prefill(prompt[:-1])
+            self.tok.copy_(prompt[-1:].view_as(self.tok))
+            n_prompt = 0
         for t in range(n_prompt + n_tokens):
             if use_graph:
                 self.graph.replay()

@@ -260,3 +260,45 @@ def test_rope_attn_decode_refuses_positions_outside_the_cache(bad_pos):
     p.fill_(3)
     out = torch.ops.quip_lib.rope_attn_decode(q, k, v, cos, sin, p, kc, vc, None)
     assert bool(torch.isfinite(out).all())
+
+
+@pytest.mark.parametrize("shape_name,plen", [("TINY", 6), ("TINY", 45), ("SMALL", 40), ("SMALL", 3)])
+def test_batched_prompt_prefill_matches_token_by_token(shape_name, plen):
+    """LlamaDecoder.prefill (example_generate.py:36-47: the prompt in ONE batched pass, M >= 32 rows through the fused
+    dequant GEMM) fills the KV cache and gives the last-token logits that feeding the prompt token by token through
+    the decode step gives (different but equivalent kernels: batch Hadamard / GEMM / SDPA vs bs=1 transforms / GEMV /
+    fused attention -> fp16-noise agreement), and generation continues identically from there"""
+    from quip_for_all_amd import decode as D
+    shape = getattr(D, shape_name)
+    dec = D.LlamaDecoder(shape, "E8P12", max_len=64, device="cuda:0", seed=3)
+    g = torch.Generator().manual_seed(plen)
+    prompt = torch.randint(0, shape.vocab, (plen,), generator=g).cuda()
+    # token by token (teacher forced), eager
+    dec.reset(int(prompt[0]))
+    with torch.no_grad():
+        for t in range(plen):
+            logits_step = dec.step().float().clone()
+            if t + 1 < plen:
+                dec.tok.copy_(prompt[t + 1:t + 2].view_as(dec.tok))
+    kc_step, vc_step = dec.kcache.clone(), dec.vcache.clone()
+    # batched
+    dec.kcache.zero_(); dec.vcache.zero_()
+    logits_b = dec.prefill(prompt).float()
+    assert int(dec.pos) == plen
+    scale = float(logits_step.abs().max())
+    assert float((logits_b - logits_step).abs().max()) <= 0.03 * (scale + 1.0)
+    kerr = (dec.kcache[:, :, :plen].float() - kc_step[:, :, :plen].float()).abs().max()
+    verr = (dec.vcache[:, :, :plen].float() - vc_step[:, :, :plen].float()).abs().max()
+    assert float(kerr) <= 0.03 * (float(kc_step.abs().max()) + 1.0) and float(verr) <= 0.03 * (float(vc_step.abs().max()) + 1.0)
+    # generate(): batched prefill and token-by-token prefill pick tokens that are (within fp16 noise) each other's
+    # arg max -- checked teacher forced on the batched run's own tokens
+    toks = dec.generate(6, prompt=prompt, batched_prefill=True)
+    dec.reset(int(prompt[0]))
+    seq = torch.cat([prompt, toks])
+    with torch.no_grad():
+        for t in range(plen + 5):
+            lg = dec.step().float()[0]
+            dec.tok.copy_(seq[t + 1:t + 2].view_as(dec.tok))
+            if t >= plen - 1:
+                tok = int(seq[t + 1])
+                assert float(lg.max() - lg[tok]) <= 0.03 * (float(lg.abs().max()) + 1.0), (t, tok)

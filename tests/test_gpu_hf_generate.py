@@ -75,7 +75,7 @@ def test_fast_decoder_from_loaded_hf_model(tmp_path):
     _fill_random(model, seed=9)
     qz.save(model, str(tmp_path))
     q = load_quantized_model(str(tmp_path), device_map={"": "cuda:0"})
-    dec = LlamaDecoder.from_hf(q, max_len=32)
+    dec = LlamaDecoder.from_hf(q, max_len=64)
     toks = dec.generate(12, first_token=5, use_graph=True)
     eager = dec.generate(12, first_token=5, use_graph=False)
     assert torch.equal(toks, eager)
@@ -86,16 +86,22 @@ def test_fast_decoder_from_loaded_hf_model(tmp_path):
         tok = int(toks[t])
         margin = (logits[t].max() - logits[t, tok]).item()
         assert margin <= 0.03 * (logits[t].abs().max().item() + 1.0), (t, tok, margin)
-    # with a prompt: the prompt is teacher forced through the same captured step
-    prompt = torch.tensor([5, 17, 3, 99, 42], device="cuda:0")
-    ptoks = dec.generate(8, prompt=prompt)
-    seq = torch.cat([prompt, ptoks])[None]
-    with torch.no_grad():
-        logits = q(seq).logits.float()[0]
-    for t in range(8):
-        row = logits[prompt.numel() - 1 + t]
-        margin = (row.max() - row[int(ptoks[t])]).item()
-        assert margin <= 0.03 * (row.abs().max().item() + 1.0), (t, margin)
+    # with a prompt (batched prefill of all but its last token; 40 tokens: the M >= 32 fused GEMM path)
+    for prompt in (torch.tensor([5, 17, 3, 99, 42], device="cuda:0"),
+                   torch.randint(0, 320, (40,), generator=torch.Generator().manual_seed(4)).cuda()):
+        _check_prompt(q, dec, prompt)
+
+
+def _check_prompt(q, dec, prompt):
+    if True:
+        ptoks = dec.generate(8, prompt=prompt)
+        seq = torch.cat([prompt, ptoks])[None]
+        with torch.no_grad():
+            logits = q(seq).logits.float()[0]
+        for t in range(8):
+            row = logits[prompt.numel() - 1 + t]
+            margin = (row.max() - row[int(ptoks[t])]).item()
+            assert margin <= 0.03 * (row.abs().max().item() + 1.0), (t, margin)
 
 
 def test_fast_decoder_takes_the_models_rotary_embedding(tmp_path):
