@@ -190,8 +190,8 @@ int quip_gemv_planes_rows_mode(const void* planes, const void* qidxs, const void
 }
 
 // Which of the two matrix-core GEMVs serves a launch (measured on MI355X, tools/gemv_v2_bench.py): the second
-// generation (whole-line loads, K split) wins from Llama-70B sizes on -- K >= 8192 with >= 16 MB of codes, or
-// >= 32 MB of codes -- and is the only one for rows longer than 28672 (E8P12RVQ4B's 2k-wide virtual rows at 70B);
+// generation (whole-line loads, K split) wins from Llama-70B sizes on -- K >= 8192 with >= 16 MB of codes, or >= 20 MB
+// of codes in the launch (7B gate / up group) -- and is the only one for rows longer than 28672 (E8P12RVQ4B's 2k-wide virtual rows at 70B);
 // short launches stay on the first kernel (one-shot loads on 8 waves).  QUIP_GEMV_V2=0 / 1 forces one of them.
 static int gemv_v2_mode() {
   static int mode = -2;
@@ -212,7 +212,7 @@ static int e8p_gemv_dispatch(const void* const* planes, const void* const* qidxs
   if (ws && ws_bytes < need) ws = nullptr;
   const bool v1_ok = e8p_gemv_mfma_group_supported(ns, count, k);
   const int mode = gemv_v2_mode();
-  bool v2 = mode == 1 || !v1_ok || (mode != 0 && ((k >= 8192 && bytes >= ((size_t)16 << 20)) || bytes >= ((size_t)32 << 20)));
+  bool v2 = mode == 1 || !v1_ok || (mode != 0 && ((k >= 8192 && bytes >= ((size_t)16 << 20)) || bytes >= ((size_t)20 << 20)));
   if (v2) {
     const int rc = e8p_gemv_v2_group_launch(planes, qidxs, grid, ys, ws, ns, count, k, GemvTune{}, stream);
     if (rc == QUIP_OK || !v1_ok || (rc != QUIP_ERR_NULL_POINTER && rc != QUIP_ERR_UNSUPPORTED)) return rc;

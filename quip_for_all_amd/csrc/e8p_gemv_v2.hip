@@ -213,47 +213,62 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
   // load cursor
   int l_run = wave;                   // current run (>= nruns: none)
   int l_gq = 0, l_seg = 0, l_left = 0;
-  auto open_run = [&](int run) {
+  // The run's per-lane source pointer and per-run constants are computed when a run is opened; a unit then costs
+  // one 64-bit add (the per-unit address arithmetic was a third of the VALU instructions of the stream).
+  const uint4* l_ptr = hot;           // this lane's 16 bytes of the run's next unit
+  int l_mgq = 0, l_xoff = 0;          // accumulator row quad / digit image offset of the run's next unit
+  const bool ragged = (a.K & 1023) != 0;   // the row's last segment is partial: lanes past the row re-read a valid
+                                           // piece (their digits are zero)
+  auto open_run = [&](int run) __attribute__((always_inline)) {
+    // (branch free on purpose: with the assignments under `if (run < nruns) .. else ..` LLVM sinks the two branches'
+    //  stores into one store through a pointer phi, which keeps the cursor variables in scratch memory -- and scratch
+    //  accesses are VMEM operations the counted waits do not know about)
     l_run = run;
-    if (run < nruns) {
-      l_gq = run / rpr;
-      const int ri = run - l_gq * rpr;
-      l_seg = ri * a.runlen;
-      l_left = min(a.runlen, S - l_seg);
-    } else {
-      l_left = 0;
-    }
-  };
-  open_run(wave);
-  // per-slot description of the unit in flight: accumulator row quad, digit image offset, flags
-  int s_gq[SLOTS], s_x[SLOTS], s_flag[SLOTS];   // flag: 0 filler, 1 unit, 3 unit that ends its run
-  auto issue = [&](u32x4& dst, int& m_gq, int& m_x, int& m_flag) {
-    const bool real = l_left > 0;   // wave uniform
-    const int p = problem_of_quad(l_gq);
-    int row = pick(row0, p) + 4 * (l_gq - pick(qbase, p)) + r;
+    const bool ok = run < nruns;
+    const int rc = ok ? run : 0;
+    l_gq = __builtin_amdgcn_readfirstlane(rc / rpr);   // (the division runs on the VALU; the quotient is wave uniform)
+    const int ri = rc - l_gq * rpr;
+    l_seg = ri * a.runlen;
+    l_left = ok ? min(a.runlen, S - l_seg) : 0;
+    const int p = __builtin_amdgcn_readfirstlane(problem_of_quad(l_gq));
+    const int qb = pick(qbase, p);
+    int row = pick(row0, p) + 4 * (l_gq - qb) + r;
     const int N = pick(a.N, p);
     row = row < N ? row : N - 1;
-    int off = (seg0 + l_seg) * 16 + 4 * h + q;
-    off = off < row_u4 ? off : (seg0 + l_seg) * 16;     // K % 1024 != 0: re-read a valid piece (its digits are zero)
     const uint4* W = a.W[0];
 #pragma unroll
     for (int i = 1; i < G; ++i) {
       W = p == i ? a.W[i] : W;
       asm volatile("" : "+s"(W));
     }
-    const uint4* ptr = real ? W + (size_t)row * row_u4 + off : hot;
+    l_ptr = W + (size_t)row * row_u4 + (seg0 + l_seg) * 16 + 4 * h + q;
+    l_mgq = (pick(rbase, p) >> 2) + (l_gq - qb);
+    l_xoff = __builtin_amdgcn_readfirstlane((p * S + l_seg) * kSegBytes);
+  };
+  open_run(wave);
+  // per-slot description of the unit in flight: accumulator row quad, digit image offset, flags
+  int s_gq[SLOTS], s_x[SLOTS], s_flag[SLOTS];   // flag: 0 filler, 1 unit, 3 unit that ends its run
+  auto issue = [&](u32x4& dst, int& m_gq, int& m_x, int& m_flag) __attribute__((always_inline)) {
+    const bool real = l_left > 0;   // wave uniform
+    const uint4* ptr = real ? l_ptr : hot;
+    if (ragged && real && seg0 + l_seg == a.segs - 1) {   // wave uniform condition
+      const int off = (seg0 + l_seg) * 16 + 4 * h + q;
+      ptr = off < row_u4 ? ptr : ptr - (4 * h + q);
+    }
     asm_load16_nt(dst, ptr);
-    m_gq = (pick(rbase, p) >> 2) + (l_gq - pick(qbase, p));
-    m_x = __builtin_amdgcn_readfirstlane((p * S + l_seg) * kSegBytes);   // wave uniform: keep it out of the VALU
+    m_gq = l_mgq;
+    m_x = l_xoff;
     m_flag = real ? (l_left == 1 ? 3 : 1) : 0;
     if (real) {
       ++l_seg;
       --l_left;
+      l_ptr += 16;
+      l_xoff += kSegBytes;
     }
   };
   // claims the next run for the load cursor when the current one is used up (between units, once the LDS
   // counter exists)
-  auto refill = [&]() {
+  auto refill = [&]() __attribute__((always_inline)) {
     if (l_left == 0 && l_run < nruns) {
       int nxt = 0;
       if (lane == 0) nxt = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -535,7 +550,8 @@ int v2_group_launch(const void* const* planes, const void* const* qidxs, const v
   a.kp_src = (k + 511) & ~511;
   a.segs = segs; a.spw = spw; a.ksplit = ksplit;
   a.dbg = reinterpret_cast<uint64_t*>(tune.dbg);
-  int waves = tune.max_waves > 0 ? tune.max_waves : 16;
+  // 16 waves for long streams; 12 when a workgroup has few units (8192^2: 64 units, 7.2 vs 7.9 us with 16)
+  int waves = tune.max_waves > 0 ? tune.max_waves : (quads * spw >= 128 ? 16 : 12);
   if (waves < 8) waves = 8;     // the table build uses waves 0..7
   if (waves > 16) waves = 16;
   while (waves < 16 && G * 3 * spw * 64 > 6 * waves * 64) ++waves;   // 6 digit pieces per thread

@@ -80,7 +80,7 @@ def test_config5_full_size(Q, fin, fout):
     rows = [0, 1, 255, 256, 4097, 20000, M - 1]
     xs = x[rows].cpu().numpy()
     yo = O.qlinear_forward(P, xs, mode="exact")
-    bound = O.parity_bound(P, xs)
+    bound = O.ulp_bound(P, xs)
     err = np.abs(y[rows].cpu().numpy().astype(np.float64) - yo)
     assert np.all(err <= bound), float((err / bound).max())
     with torch.no_grad():

@@ -44,4 +44,4 @@ def test_forward_sweep(cbid, fin, fout, M, bias, per_channel, seed):
     x64 = x.astype(np.float64)
     ref = O.qlinear_forward(P, x64, "exact", What)
     err = np.abs(y.cpu().numpy().astype(np.float64) - ref)
-    assert np.all(err <= O.parity_bound(P, x64, What)), float(err.max())
+    assert np.all(err <= O.ulp_bound(P, x64, What)), float((err / O.ulp_bound(P, x64, What, ulps=1.0)).max())

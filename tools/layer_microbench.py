@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """SURVEY 8d layer micro-bench, one shape per process (run under rocprofv3 by tools/layer_microbench.sh):
-the default bs=1 E8P12 GEMV launch (quip_e8p_gemv_planes) on ONE (out, in) shape, weights cycled through a pool
+the default bs=1 E8P12 GEMV launch (quip_e8p_gemv_planes_ws: the product's entry point, which picks the kernel by
+shape) on ONE (out, in) shape, weights cycled through a pool
 larger than the 256 MB Infinity Cache, 200 launches per hipGraph replay, HIP-event timed.
 usage: layer_microbench.py N K"""
 import json, os, sys
@@ -21,7 +22,8 @@ planes = torch.empty(L.quip_e8p_planes_bytes(k), dtype=torch.uint8, device=dev)
 st = lambda: torch.cuda.current_stream().cuda_stream   # noqa: E731
 capi.check(L.quip_e8p_x_to_planes(x.data_ptr(), planes.data_ptr(), k, st()), "planes")
 y = torch.empty(1, n, dtype=torch.float16, device=dev)
-call = lambda i: capi.check(L.quip_e8p_gemv_planes(planes.data_ptr(), pool[i % npool].data_ptr(), grid.data_ptr(), y.data_ptr(), n, k, st()), "gemv")  # noqa: E731
+ws = torch.zeros(L.quip_e8p_gemv_workspace_bytes(n) // 4, dtype=torch.int32, device=dev)   # K-split scratch (stays zero)
+call = lambda i: capi.check(L.quip_e8p_gemv_planes_ws(planes.data_ptr(), pool[i % npool].data_ptr(), grid.data_ptr(), y.data_ptr(), n, k, ws.data_ptr(), ws.numel() * 4, st()), "gemv")  # noqa: E731
 for i in range(3):
     call(i)
 torch.cuda.synchronize()
