@@ -117,6 +117,15 @@ class E8P12_codebook(_Codebook):
         """skinny product: planes (M, planes_bytes) -> (M, n), passes of up to 5 rows over the codes"""
         return torch.ops.quip_lib.e8p_gemv_planes_rows(planes, Qidxs, self.grid_packed_abs)
 
+    @staticmethod
+    def skinny_supported(m, q_out, q_in):
+        """shapes the single-pass fp16 skinny product takes (csrc/e8p_skinny_gemm.hip)"""
+        return 1 <= m <= 32 and q_out % 2 == 0 and q_in % 128 == 0 and q_in >= 128
+
+    def mm_skinny(self, xh, Qidxs):
+        """(M <= 32, k) fp16 (already input-transformed) -> (M, n): one pass over the codes, fp16 MFMA"""
+        return torch.ops.quip_lib.e8p_mm_skinny(xh, Qidxs, self.grid_packed_abs)
+
 
 class E8P12RVQ4B_codebook(_Codebook):
     def __init__(self, inference=False, opt_resid_scale=None, **kwargs):

@@ -392,6 +392,16 @@ int quip_e8p_gemv_planes(const void* planes, const void* qidxs, const void* grid
   return gemv_group_common(&planes, &qidxs, grid, &y, &n, 1, k, nullptr, 0, stream);
 }
 
+int quip_e8p_mm_skinny(const void* x, const void* qidxs, const void* grid, void* y, int32_t m, int32_t n, int32_t k,
+                       quip_stream_t stream) {
+  if (!x || !qidxs || !grid || !y) return QUIP_ERR_NULL_POINTER;
+  if (m < 0 || n < 1 || k < 8) return QUIP_ERR_BAD_SHAPE;
+  if (m == 0) return QUIP_OK;
+  if (!aligned16(x) || !aligned16(qidxs) || (reinterpret_cast<uintptr_t>(y) & 3u) || (reinterpret_cast<uintptr_t>(grid) & 7u))
+    return QUIP_ERR_MISALIGNED;
+  return e8p_skinny_gemm_launch(x, qidxs, grid, y, m, n, k, (hipStream_t)stream);
+}
+
 int quip_e8p_mm_batched(const void* x, const void* qidxs, const void* grid, void* y, int64_t m, int32_t n, int32_t k,
                         quip_stream_t stream) {
   if (!x || !qidxs || !grid || !y) return QUIP_ERR_NULL_POINTER;

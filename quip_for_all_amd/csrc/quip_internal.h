@@ -125,6 +125,10 @@ int e8p_gemv_mfma_fused_launch(const GemvFusedIn& in, const void* const* qidxs, 
 bool e8p_prefill_gemm_supported(int64_t m, int n, int k);
 int e8p_prefill_gemm_launch(const void* x, const void* qidxs, const void* grid, void* y, int64_t m, int n, int k,
                             hipStream_t stream);
+// single-pass skinny E8P12 product, 1 <= m <= 32 rows, fp16 MFMA (e8p_skinny_gemm.hip)
+bool e8p_skinny_gemm_supported(int m, int n, int k);
+int e8p_skinny_gemm_launch(const void* x, const void* qidxs, const void* grid, void* y, int m, int n, int k,
+                           hipStream_t stream);
 // bf16 / fp32 (and plain fp16) Walsh-Hadamard transform of the last dimension (hadamard_generic.hip)
 int hadamard_generic_launch(const void* x, void* y, int64_t rows, int n, float scale, int dtype, hipStream_t stream);
 int had_transform_launch(const void* x, void* y, int64_t rows, int in_features, int out_features,

@@ -23,6 +23,11 @@ class QuantLinear(nn.Module):
     # E8P12 / E8P12RVQ4B forwards with 2 .. skinny_max_rows rows take the matrix-core rows-mode GEMV (passes of up to 5
     # rows over the codes); more rows (< 32) the generic fused mm, >= 32 decompress + dense GEMM
     skinny_max_rows = int(os.environ.get("QUIP_SKINNY_MAX_ROWS", "31"))
+    # 1 < M < 32 rows.  As long as ONE pass of rows mode carries them (5 rows for k <= 4096, 3 for k <= 8192, ...) the
+    # exact integer path is used: every row bit identical to its bs=1 result.  More rows: E8P12 takes the single-pass
+    # fp16-MFMA skinny kernel (csrc/e8p_skinny_gemm.hip: the reference's arithmetic -- fp16 x fp16 -> fp32 -- not bit
+    # identical to bs=1); skinny_exact = True (QUIP_SKINNY_EXACT=1) keeps the exact multi-pass path for everything.
+    skinny_exact = os.environ.get("QUIP_SKINNY_EXACT", "0") != "0"
 
     def __init__(self, in_features, out_features, codebook, bias=True, use_rand=True,
                  per_channel=False, weight_dtype=torch.float16):
@@ -67,6 +72,18 @@ class QuantLinear(nn.Module):
             self.bias = None
 
     # ------------------------------------------------------------------ forward
+    def _rows_per_pass(self):
+        """activation rows one exact rows-mode pass carries for this layer's shape (0: rows mode unavailable)"""
+        r = getattr(self, "_rpp", None)
+        if r is None:
+            from . import capi
+            cb = self.codebook
+            r = 0
+            if hasattr(cb, "mm_planes_rows") and cb.planes_supported(self.q_out_features, self.q_in_features):
+                r = int(capi.lib().quip_e8p_gemv_max_rows(self.q_out_features, self.q_in_features)) if cb.id == "E8P12" else 5
+            self._rpp = r
+        return r
+
     def _had(self, name):
         h = getattr(self, name)
         if h is not None and (h.dtype != torch.float16 or not h.is_contiguous()):
@@ -110,6 +127,15 @@ class QuantLinear(nn.Module):
                 None if gate is None else gate.reshape(x.shape).to(torch.float16),
                 getattr(cb, "planes_resid_scale", 0.0))
             z = cb.mm_planes(planes, self.Qidxs)
+        elif (2 <= x.shape[0] <= self.skinny_max_rows and not self.skinny_exact and hasattr(cb, "mm_skinny")
+              and cb.skinny_supported(x.shape[0], self.q_out_features, self.q_in_features)
+              and x.shape[0] > self._rows_per_pass()):
+            # more rows than one exact pass carries: single-pass skinny product on fp16 activations
+            xh = torch.ops.quip_lib.had_transform_fused(
+                x, self.q_in_features, self.q_in_features, self.K_left, self._had("had_left"), True,
+                self._vec(self.SU), None, None, None, self.wscale_float / math.sqrt(L_in), None,
+                self._vec(rms_weight), rms_eps, None if gate is None else gate.reshape(x.shape).to(torch.float16))
+            z = cb.mm_skinny(xh, self.Qidxs)
         elif (2 <= x.shape[0] <= self.skinny_max_rows and hasattr(cb, "mm_planes_rows")
               and cb.planes_supported(self.q_out_features, self.q_in_features)):
             # skinny GEMM on the matrix cores (E8P12, E8P12RVQ4B): every row gets its own digit planes (one

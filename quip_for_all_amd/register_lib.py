@@ -46,6 +46,8 @@ _SCHEMAS = {
     "e8p_gemv_planes_group": "(Tensor[] planes, Tensor[] Qidxs, Tensor grid) -> Tensor[]",
     # M >= 32 (prefill): fused dequant + MFMA GEMM, x (M, k) fp16 -> (M, n) fp16; no dense W (csrc/e8p_prefill_gemm.hip)
     "e8p_mm_batched": "(Tensor x, Tensor Qidxs, Tensor grid) -> Tensor",
+    # 2 <= M <= 32 rows in one pass over the codes, fp16 MFMA (csrc/e8p_skinny_gemm.hip)
+    "e8p_mm_skinny": "(Tensor x, Tensor Qidxs, Tensor grid) -> Tensor",
     # E8P12RVQ3B on the matrix-core GEMV: Qidxs repacked to int32 (main16 << 16 | resid8 << 8), e81b_i8 = int8 (256, 8)
     "e8prvq3_gemv_planes_group": "(Tensor[] planes, Tensor[] Qidxs, Tensor grid, Tensor e81b_i8) -> Tensor[]",
     "d4_gemv_planes": "(Tensor planes, Tensor Qidxs, Tensor grid) -> Tensor",
@@ -611,6 +613,25 @@ def _e8p_mm_batched_cuda(x, Qidxs, grid):
     return y
 
 
+def e8p_mm_skinny_supported(m, n, k):
+    return 1 <= m <= 32 and n >= 2 and n % 2 == 0 and k >= 128 and k % 128 == 0
+
+
+def _e8p_mm_skinny_cuda(x, Qidxs, grid):
+    g = _grid_i64(grid, x)
+    xc = _chk_x(x)
+    Qc = _chk_q(Qidxs, torch.int16)
+    m, k, n = xc.shape[0], xc.shape[1], Qc.shape[0]
+    _need(Qc.shape[1] * 8 == k, f"e8p_mm_skinny: x has {k} columns but Qidxs {tuple(Qidxs.shape)} encodes {Qc.shape[1] * 8}")
+    _need(Qc.device == x.device, "Qidxs and x must be on the same device")
+    _need(e8p_mm_skinny_supported(m, n, k), f"e8p_mm_skinny: shape ({m}, {n}, {k}) needs m <= 32, k % 128 == 0, n % 2 == 0")
+    y = torch.empty((m, n), dtype=torch.float16, device=x.device)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().quip_e8p_mm_skinny(xc.data_ptr(), Qc.data_ptr(), g.data_ptr(), y.data_ptr(), m, n, k,
+                                                 _stream(x)), "quip_e8p_mm_skinny")
+    return y
+
+
 def _e8p_gemv_planes_cuda(planes, Qidxs, grid):
     g = _grid_i64(grid, Qidxs)
     Qc = _chk_q(Qidxs, torch.int16)
@@ -750,6 +771,7 @@ _IMPLS = {
     "had_transform_group": _had_transform_group_cuda,
     "e8p_gemv_planes_group": _e8p_gemv_planes_group_cuda,
     "e8p_mm_batched": _e8p_mm_batched_cuda,
+    "e8p_mm_skinny": _e8p_mm_skinny_cuda,
     "e8p_mm_planes_rows": _e8p_mm_planes_rows_cuda,
     "had_transform_planes_rows": _had_transform_planes_rows_cuda,
     "e8p_gemv_planes_rows": _e8p_gemv_planes_rows_cuda,
@@ -836,6 +858,7 @@ _reg_fake("e8p_gemv_fused", lambda x, z, post, residual, rms_weight, rms_eps, z_
           ([z.new_empty((1, z.numel()))] if z is not None else []) +
           [q.new_empty((1, q.shape[0]), dtype=torch.float16) for q in Qidxs])
 _reg_fake("rope_attn_decode", lambda q, k, v, cos, sin, pos, kcache, vcache, workspace=None: torch.empty_like(q))
+_reg_fake("e8p_mm_skinny", lambda x, Q, g: x.new_empty((x.shape[0], Q.shape[0]), dtype=torch.float16))
 _reg_fake("e8p_mm_batched", lambda x, Q, g: x.new_empty((x.shape[0], Q.shape[0]), dtype=torch.float16))
 _reg_fake("e8p_gemv_planes", lambda planes, Q, g: Q.new_empty((1, Q.shape[0]), dtype=torch.float16))
 for _n in ("e8p_mm_origorder", "e8prvq3_mm_origorder", "e8prvq4_mm_origorder", "d4_mm_origorder",

@@ -68,3 +68,42 @@ def test_gemv_v2_kernels_use_no_scratch_and_only_counted_loads():
         assert sum("global_load_dwordx2" in l for l in loads) == 1, kname
         assert sum(" nt" in l for l in loads) == 2 * slots, kname
         assert all(l.startswith(("global_load_dword ", "global_load_dwordx2", "global_load_dwordx4")) for l in loads)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_skinny_kernel_touches_no_register_in_flight():
+    """e8p_skinny_gemm.hip counts its vector-memory queue by hand around asm loads, so the compiler does not know
+    which registers are still going to be written.  A first version tied such registers to the wait ("+v"): in some
+    instantiations the allocator then copied them BEFORE the wait, and one launch in a few hundred multiplied stale
+    codes.  tools/check_inflight.py follows every path of the compiled kernels with the in-order vmcnt queue and
+    reports any instruction that reads or writes the destination of a load still in it; also: no scratch."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import check_inflight
+    src = os.path.join(REPO, "quip_for_all_amd", "csrc", "e8p_skinny_gemm.hip")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", "-", src,
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, check=True)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+    assert len(scratch) == 4 and not any(scratch), scratch
+    kernels = [(n, l) for n, l in check_inflight.kernels_of(r.stdout) if "e8p_skinny_gemm_kernel" in n]
+    assert len(kernels) == 4
+    for name, lines in kernels:
+        assert any("global_load_lds_dwordx4" in l for l in lines), name
+        assert check_inflight.check_kernel(lines) == [], name
+
+
+def test_inflight_checker_flags_a_copy_before_the_wait():
+    """the checker itself, on a hand-written listing: a tied-operand copy ahead of the wait is reported, the same
+    sequence with the wait first is clean, and a conditional skip of the wait is followed"""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import check_inflight
+    bad = ["global_load_dwordx4 v[22:25], v[36:37], off", "global_load_lds_dwordx4 v[2:3], off", "v_mov_b32_e32 v26, v22",
+           "s_waitcnt vmcnt(1)", "v_add_u32_e32 v1, v26, v23", "s_endpgm"]
+    got = check_inflight.check_kernel(bad)
+    assert [g[0] for g in got] == [2]
+    good = [bad[0], bad[1], bad[3], bad[2], bad[4], bad[5]]
+    assert check_inflight.check_kernel(good) == []
+    skip = ["global_load_dwordx2 v[4:5], v[0:1], off", "s_cbranch_scc1 .L1", "s_waitcnt vmcnt(0)", ".L1:",
+            "v_add_u32_e32 v6, v4, v5", "s_endpgm"]
+    assert [g[0] for g in check_inflight.check_kernel(skip)] == [4]

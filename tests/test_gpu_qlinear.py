@@ -270,6 +270,7 @@ def test_skinny_rows_on_matrix_core_path(fin, fout, M, cbid="E8P12"):
     bit (same integer arithmetic) and sit inside the oracle bound"""
     P = O.make_layer(cbid, fin, fout, seed=fin + fout + M)
     layer = _layer(P)
+    layer.skinny_exact = True       # the exact integer path for every row count (QUIP_SKINNY_EXACT=1)
     rng = np.random.default_rng(M + fin)
     x = rng.standard_normal((M, fin)).astype(np.float16)
     xd = torch.from_numpy(x).to(DEV)
@@ -281,6 +282,50 @@ def test_skinny_rows_on_matrix_core_path(fin, fout, M, cbid="E8P12"):
     What = O.qlinear_dense_weight(P)
     ref = O.qlinear_forward(P, x.astype(np.float64), "exact", What)
     assert np.all(np.abs(y.cpu().numpy().astype(np.float64) - ref) <= O.ulp_bound(P, x.astype(np.float64), What))
+    # default dispatch: as long as one exact pass carries the rows nothing changes; beyond that E8P12 takes the
+    # single-pass fp16 skinny kernel -- inside the same stated bound, but not bit identical to bs=1 any more
+    layer.skinny_exact = False
+    with torch.no_grad():
+        yd = layer(xd)
+    if M <= layer._rows_per_pass() or cbid != "E8P12":
+        assert torch.equal(yd, y)
+    else:
+        assert np.all(np.abs(yd.cpu().numpy().astype(np.float64) - ref) <= O.ulp_bound(P, x.astype(np.float64), What))
+
+
+@pytest.mark.parametrize("fin,fout", [(4096, 4096), (4096, 11008), (11008, 4096), (8192, 8192), (8192, 28672),
+                                      (28672, 8192), (256, 688), (1408, 512)])
+@pytest.mark.parametrize("M", [6, 16, 31, 32])
+def test_single_pass_skinny_kernel(fin, fout, M):
+    """6 <= M <= 32 rows through the fp16-MFMA skinny product (csrc/e8p_skinny_gemm.hip; the 1 < M < 32 use of the
+    reference's tinygemm kernel, origin_order.cu:388-555): the op against the float64 product of the same fp16
+    operands (one fp16 rounding + fp32 accumulation), the module inside the stated ulp bound, and a row's result
+    independent of the batch it sits in"""
+    import quip_for_all_amd as Q
+    P = O.make_layer("E8P12", fin, fout, seed=fin + fout)
+    layer = _layer(P)
+    cb = layer.codebook
+    rng = np.random.default_rng(M + fout)
+    k, n = layer.q_in_features, layer.q_out_features
+    if not cb.skinny_supported(M, n, k):
+        pytest.skip("k % 128 != 0: rows mode / generic path")
+    xh = torch.from_numpy(rng.standard_normal((M, k)).astype(np.float16)).to(DEV)
+    z = torch.ops.quip_lib.e8p_mm_skinny(xh, layer.Qidxs, cb.grid_packed_abs)
+    Wq = O.decompress_e8p(P.Qidxs).astype(np.float64)
+    x64 = xh.cpu().numpy().astype(np.float64)
+    z64 = x64 @ Wq.T
+    tol = 2.0 ** -10 * np.abs(z64) + 2.0 ** -21 * (np.abs(x64) @ np.abs(Wq).T) + 1e-7
+    assert np.all(np.abs(z.cpu().numpy().astype(np.float64) - z64) <= tol)
+    z2 = torch.ops.quip_lib.e8p_mm_skinny(xh[3:3 + 2].contiguous(), layer.Qidxs, cb.grid_packed_abs)
+    assert torch.equal(z[3:5], z2), "a row's result does not depend on the other rows"
+    if M < 32:
+        x = torch.from_numpy(rng.standard_normal((M, fin)).astype(np.float16)).to(DEV)
+        with torch.no_grad():
+            y = layer(x)
+        What = O.qlinear_dense_weight(P)
+        x64m = x.cpu().numpy().astype(np.float64)
+        ref = O.qlinear_forward(P, x64m, "exact", What)
+        assert np.all(np.abs(y.cpu().numpy().astype(np.float64) - ref) <= O.ulp_bound(P, x64m, What))
 
 
 
@@ -338,3 +383,21 @@ def test_out_transform_group_mixed_widths_equals_single():
             for l, z, r, g in zip(layers, zs, res, grouped):
                 (single,) = out_transform_group([l], [z], residual=[r])
                 assert torch.equal(single, g)
+
+
+@pytest.mark.parametrize("n,k", [(4096, 4096), (4096, 11008), (11008, 4096), (64, 2048)])
+def test_single_pass_skinny_kernel_repeated_launches(n, k):
+    """the same codes, fresh activations, 40 launches per row count back to back with other kernels in between
+    (whatever those leave behind in LDS and in registers): every launch against the fp32 product.  K = 11008 gives
+    the 16 K-slices of a workgroup unequal lengths (5 and 6 units)."""
+    import quip_for_all_amd as Q
+    cb = Q.codebook.codebook_id["E8P12"](inference=True).to(DEV)
+    g = torch.Generator(device="cpu").manual_seed(n + k)
+    q = torch.randint(-32768, 32767, (n, k // 8), dtype=torch.int32, generator=g).to(torch.int16).to(DEV)
+    W = cb.decompress_weight(q).float()
+    for M in (2, 6, 16, 17, 31):
+        for it in range(40):
+            x = torch.randn(M, k, generator=g).half().to(DEV)
+            y = torch.ops.quip_lib.e8p_mm_skinny(x, q, cb.grid_packed_abs).float()
+            ref = x.float() @ W.T
+            assert bool(((y - ref).abs() <= 2e-3 * ref.abs().max()).all()), (M, it)

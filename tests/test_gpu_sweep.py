@@ -38,8 +38,13 @@ def test_forward_sweep(cbid, fin, fout, M, bias, per_channel, seed):
     with torch.no_grad():
         y = layer(xd)
         if 1 < M < 32:
+            layer.skinny_exact = True       # the exact integer path: every row bit identical to its bs=1 result
+            ye = layer(xd)
             for r in sorted({0, M // 2, M - 1}):
-                assert torch.equal(y[r:r + 1], layer(xd[r:r + 1])), (r, "row differs from its bs=1 result")
+                assert torch.equal(ye[r:r + 1], layer(xd[r:r + 1])), (r, "row differs from its bs=1 result")
+            layer.skinny_exact = False
+            if M <= layer._rows_per_pass() or cbid != "E8P12":
+                assert torch.equal(y, ye)
     What = O.qlinear_dense_weight(P)
     x64 = x.astype(np.float64)
     ref = O.qlinear_forward(P, x64, "exact", What)

@@ -1,26 +1,27 @@
 #!/usr/bin/env python3
-"""Graph-timed skinny products per shape and M: quip_lib::e8p_mm_origorder (M > 1: the generic fused mm on
-fp16 x) next to the rows-mode matrix-core GEMV on digit planes (e8p_gemv_planes_rows, planes precomputed)."""
+"""Graph-timed skinny products per shape and M: the exact rows-mode matrix-core GEMV on digit planes
+(e8p_gemv_planes_rows, planes precomputed: passes of up to 5 rows) next to the single-pass fp16 skinny kernel
+(e8p_mm_skinny, x already fp16)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import quip_for_all_amd as Q  # noqa
 dev = "cuda:0"
 cb = Q.codebook.codebook_id["E8P12"](inference=True).to(dev)
-for (n, k) in [(4096, 4096), (11008, 4096), (4096, 11008), (8192, 8192)]:
+for (n, k) in [(4096, 4096), (11008, 4096), (4096, 11008), (8192, 8192), (28672, 8192), (8192, 28672)]:
     nm = max(4, (400 << 20) // (n * k // 4))
     pool = [torch.randint(-32768, 32767, (n, k // 8), dtype=torch.int32, device=dev).to(torch.int16) for _ in range(nm)]
     from quip_for_all_amd.quant import get_hadK
     had, K, _ = get_hadK(k, True)
     had = None if had is None else had.to(dev).half().contiguous()
-    for M in (1, 2, 3, 4, 5, 8, 10, 16, 31):
-      for mode in ("mm", "rows"):
+    for M in (1, 2, 4, 5, 8, 16, 31):
+      for mode in ("rows", "skinny"):
         x = torch.randn(M, k, device=dev).half()
         planes = torch.ops.quip_lib.had_transform_planes_rows(x, k, K, had, True, None, 1.0, None, 1e-5, None)
         def run():
             for q in pool:
-                if mode == "mm":
-                    torch.ops.quip_lib.e8p_mm_origorder(x, q, cb.grid_packed_abs)
+                if mode == "skinny":
+                    torch.ops.quip_lib.e8p_mm_skinny(x, q, cb.grid_packed_abs)
                 else:
                     torch.ops.quip_lib.e8p_gemv_planes_rows(planes, q, cb.grid_packed_abs)
         run(); torch.cuda.synchronize()
@@ -33,5 +34,5 @@ for (n, k) in [(4096, 4096), (11008, 4096), (4096, 11008), (8192, 8192)]:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(); g.replay(); b.record(); torch.cuda.synchronize()
             best = min(best, a.elapsed_time(b) * 1e3 / len(pool))
-        print(f"N={n} K={k} M={M:2d} {mode:4s}: {best:7.2f} us  ({n * k / 4 / 1e6 / best:.2f} TB/s of codes)", flush=True)
+        print(f"N={n} K={k} M={M:2d} {mode:6s}: {best:7.2f} us  ({n * k / 4 / 1e6 / best:.2f} TB/s of codes)", flush=True)
     del pool; torch.cuda.empty_cache()
