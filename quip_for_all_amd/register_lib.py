@@ -343,9 +343,18 @@ def _e8p_gemv_planes_rows_cuda(planes, Qidxs, grid):
           "planes must be the (rows, quip_e8p_planes_bytes(k)) uint8 images of had_transform_planes_rows")
     rows = planes.shape[0]
     per = L.quip_e8p_gemv_max_rows(n, k)
-    _need(per >= 1, "shape not supported by the matrix-core GEMV")
     g = _grid_i64(grid, Qidxs)
     out = torch.empty((rows, n), dtype=torch.float16, device=Qidxs.device)
+    if per < 1:
+        # rows longer than rows mode holds in LDS (k > 28672: E8P12RVQ4B's 2k-wide virtual rows at 70B): one bs=1
+        # launch per row through the dispatcher (the K-splitting kernel) -- the same exact integer sums
+        ws = _gemv_workspace(Qidxs.device, n)
+        with torch.cuda.device(Qidxs.device):
+            for r in range(rows):
+                capi.check(L.quip_e8p_gemv_planes_ws(planes[r].data_ptr(), Qidxs.data_ptr(), g.data_ptr(),
+                                                     out[r].data_ptr(), n, k, ws.data_ptr(), ws.numel() * 4,
+                                                     _stream(out)), "quip_e8p_gemv_planes_ws")
+        return out
     with torch.cuda.device(Qidxs.device):
         for r0 in range(0, rows, per):
             m = min(per, rows - r0)

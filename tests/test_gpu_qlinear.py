@@ -127,6 +127,27 @@ def test_full_size_70b_rows_via_properties():
         assert ((y1.float() + y2.float()) - ys).abs().max() <= 2 ** -8 * ys.abs().max()
 
 
+@pytest.mark.parametrize("fin,fout,M", [(28672, 512, 1), (28672, 512, 2), (16384, 256, 1)])
+def test_rvq4_rows_longer_than_28672_on_matrix_core_path(fin, fout, M):
+    """E8P12RVQ4B at Llama-2-70B's down_proj width: the 2k = 57344-wide virtual row is beyond the first GEMV
+    kernel's LDS budget and is taken by the K-splitting kernel (csrc/e8p_gemv_v2.hip) through the op's dispatcher --
+    module forward against the oracle, rows bit identical to bs=1"""
+    import quip_for_all_amd as Q
+    P = O.make_layer("E8P12RVQ4B", fin, fout, seed=fin + fout)
+    layer = _layer(P)
+    assert layer.codebook.planes_supported(layer.q_out_features, layer.q_in_features)
+    x = np.random.default_rng(M).standard_normal((M, fin)).astype(np.float16)
+    xd = torch.from_numpy(x).to(DEV)
+    with torch.no_grad():
+        y = layer(xd)
+        for r in range(M):
+            assert torch.equal(y[r:r + 1], layer(xd[r:r + 1]))
+    What = O.qlinear_dense_weight(P)
+    x64 = x.astype(np.float64)
+    ref = O.qlinear_forward(P, x64, "exact", What)
+    assert np.all(np.abs(y.cpu().numpy().astype(np.float64) - ref) <= O.ulp_bound(P, x64, What))
+
+
 @pytest.mark.parametrize("cbid,fin,fout", [("E8P12", 4096, 4096), ("E8P12", 1408, 512), ("D4", 1024, 1024),
                                            ("E8P12", 4096, 11008), ("E8P12", 11008, 4096),
                                            ("E8P12RVQ4B", 4096, 11008), ("E8P12RVQ4B", 11008, 4096),
