@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QUIP_ABI_VERSION 6
+#define QUIP_ABI_VERSION 7
 
 typedef void* quip_stream_t; /* hipStream_t */
 
@@ -360,6 +360,17 @@ int quip_rope_attn_decode_f16(const void* q, const void* k, const void* v, const
                               const float* sin, const int64_t* pos, void* kcache, void* vcache,
                               void* out, int32_t heads, int32_t kv_heads, int32_t head_dim,
                               int32_t max_len, float scale, void* workspace, quip_stream_t stream);
+
+/* The same launch on the RAW GEMV outputs of q / k / v_proj: their output-side transforms (SV (.) H z * scales[i],
+ * qlinear.py:106-114 with K = 1, no bias) run in the launch's prologue -- same bits as quip_had_transform_f16 followed
+ * by quip_rope_attn_decode_f16, one dependent launch less per decoder block.  z[3] / post[3]: fp16 [heads * head_dim]
+ * each (q, k, v); needs heads == kv_heads and heads * head_dim a power of two in 256..4096
+ * (quip_rope_attn_decode_z_supported). */
+int quip_rope_attn_decode_z_supported(int32_t heads, int32_t kv_heads, int32_t head_dim);
+int quip_rope_attn_decode_z_f16(const void* const* z, const void* const* post, const float* scales, const float* cos,
+                                const float* sin, const int64_t* pos, void* kcache, void* vcache, void* out,
+                                int32_t heads, int32_t kv_heads, int32_t head_dim, int32_t max_len, float scale,
+                                void* workspace, quip_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -39,6 +39,8 @@ SIGNATURES = {
     "quip_rope_attn_workspace_bytes": [_I32, _I32],
     "quip_argmax_step_f16": [_P, _I32, _P, _P, _P],
     "quip_rope_attn_decode_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _P, _P],
+    "quip_rope_attn_decode_z_supported": [_I32, _I32, _I32],
+    "quip_rope_attn_decode_z_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _P, _P],
     "quip_e8p_mm_origorder": [_P, _P, _P, _P, _I32, _I32, _I32, _P],
     "quip_e8p_mm_batched": [_P, _P, _P, _P, _I64, _I32, _I32, _P],
     "quip_e8p_mm_skinny": [_P, _P, _P, _P, _I32, _I32, _I32, _P],

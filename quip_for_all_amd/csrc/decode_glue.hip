@@ -11,11 +11,26 @@
 // a workgroup).  The new k / v row is used from registers (and appended to the cache by the
 // first query head of its KV group), so no other workgroup has to see the cache write.
 // Contexts of a few thousand tokens are fine; beyond that a split over workgroups would pay.
+//
+// ZIN variant (round 2): the launch takes the RAW GEMV outputs of q / k / v_proj and runs their output-side
+// Hadamard transform (SV (.) H z / sqrt(n), qlinear.py:106-114 with K = 1) in its own prologue -- three groups of 256
+// threads transform q, k and v side by side with the functions of had_device.hip.h (the same bits as the separate
+// transform launch it replaces), the 8 threads that own this head's 128 values leave them in LDS, and the
+// attention proper continues on the first 256 threads.  Every head repeats the three 4096-point transforms
+// (~0.5 us on otherwise idle CUs) instead of one more dependent launch per block (~5 us).
+#include "had_device.hip.h"
 #include "quip_device.hip.h"
 #include "quip_internal.h"
 
 namespace quip {
 namespace {
+
+struct AttnZ {
+  const f16* z[3];      // raw GEMV outputs of q / k / v_proj, [n] each
+  const f16* post[3];   // SV of the three modules, [n]
+  float scale[3];       // 1 / sqrt(n)
+  int n, logL;          // common width (heads * HD == kv_heads * HD == n), a power of two <= 4096
+};
 
 struct AttnArgs {
   const f16* q;        // [heads, HD]
@@ -49,18 +64,18 @@ __device__ __forceinline__ void unpack8h(const uint4& u, float o[8]) {
 // rotary embedding (HF half-rotation) of the 8 dims [d0, d0 + 8) of one head vector; result
 // rounded to fp16 like the eager graph does
 template <int HD>
-__device__ __forceinline__ void rope8(const f16* vec, const float* cs, const float* sn, int d0, float o[8]) {
+__device__ __forceinline__ void rope8(const f16* vec, const float c8[8], const float s8[8], int d0, float o[8]) {
   float a[8], b[8];
   unpack8h(*reinterpret_cast<const uint4*>(vec + d0), a);
   const int dp = d0 < HD / 2 ? d0 + HD / 2 : d0 - HD / 2;
   unpack8h(*reinterpret_cast<const uint4*>(vec + dp), b);
   const float sgn = d0 < HD / 2 ? -1.f : 1.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) o[i] = (float)(f16)(a[i] * cs[d0 + i] + sgn * b[i] * sn[d0 + i]);
+  for (int i = 0; i < 8; ++i) o[i] = (float)(f16)(a[i] * c8[i] + sgn * b[i] * s8[i]);
 }
 
-template <int HD>
-__global__ __launch_bounds__(256) void rope_attn_decode_kernel(AttnArgs a) {
+template <int HD, bool ZIN>
+__global__ __launch_bounds__(ZIN ? 768 : 256) void rope_attn_decode_kernel(AttnArgs a, AttnZ zz) {
   constexpr int LPK = HD / 8;        // lanes per key
   constexpr int NG = 256 / LPK;      // key groups per workgroup
   constexpr int U = 4;               // keys in flight per group
@@ -69,6 +84,18 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(AttnArgs a) {
   const int tid = threadIdx.x, h = blockIdx.x;
   const int gl = tid % LPK, grp = tid / LPK, d0 = gl * 8;
   const int group = a.heads / a.kv_heads, kvh = h / group;
+  // ZIN: the transform inputs do not depend on the position: requested before it is read
+  const int g3 = tid >> 8, tt = tid & 255, e0 = tt * 16;
+  const bool zact = ZIN && e0 < zz.n;
+  uint4 zraw[2] = {}, praw[2] = {};
+  if constexpr (ZIN) {
+    if (zact) {
+      zraw[0] = *reinterpret_cast<const uint4*>(zz.z[g3] + e0);
+      zraw[1] = *reinterpret_cast<const uint4*>(zz.z[g3] + e0 + 8);
+      praw[0] = *reinterpret_cast<const uint4*>(zz.post[g3] + e0);
+      praw[1] = *reinterpret_cast<const uint4*>(zz.post[g3] + e0 + 8);
+    }
+  }
   const long long pos64 = *a.pos;
   // A position outside the cache (one step past max_len, a corrupted counter) must not index cos / sin or the
   // cache: nothing is appended, the head's output becomes NaN (visible downstream) and every workgroup of the
@@ -89,10 +116,44 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(AttnArgs a) {
   const float* cs = a.cos + (size_t)pos * HD;
   const float* sn = a.sin + (size_t)pos * HD;
 
+  const f16* qh = a.q + (size_t)h * HD;
+  const f16* kh = a.k + (size_t)kvh * HD;
+  const f16* vh = a.v + (size_t)kvh * HD;
+  // rotary factors of this thread's 8 dims (requested before the transforms: one memory round trip less)
+  float c8[8], s8[8];
+  if (tid < 256) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { c8[i] = cs[d0 + i]; s8[i] = sn[d0 + i]; }
+  }
+  if constexpr (ZIN) {
+    extern __shared__ __attribute__((aligned(16))) float zbuf[];   // 3 x had::buf_floats(n)
+    __shared__ __attribute__((aligned(16))) f16 s_qkv[3][HD];
+    const bool act = zact;
+    float v[16], tp[16];
+    had::unpack8(zraw[0], v);
+    had::unpack8(zraw[1], v + 8);
+    had::unpack8(praw[0], tp);
+    had::unpack8(praw[1], tp + 8);
+    had::fht16(v, zbuf + g3 * had::buf_floats(zz.n), tt, zz.logL, act, 0);
+    const int base = (g3 == 0 ? h : kvh) * HD;
+    if (act && e0 >= base && e0 < base + HD) {
+      f16 o[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = had::out_elem(v[r], zz.scale[g3], true, tp[r], false, 0.f, false, 0.f);
+      uint4* dst = reinterpret_cast<uint4*>(&s_qkv[g3][e0 - base]);
+      dst[0] = *reinterpret_cast<uint4*>(&o[0]);
+      dst[1] = *reinterpret_cast<uint4*>(&o[8]);
+    }
+    __syncthreads();
+    if (tid >= 256) return;
+    qh = s_qkv[0];
+    kh = s_qkv[1];
+    vh = s_qkv[2];
+  }
   float q8[8], kn[8], vn[8];
-  rope8<HD>(a.q + (size_t)h * HD, cs, sn, d0, q8);
-  rope8<HD>(a.k + (size_t)kvh * HD, cs, sn, d0, kn);
-  const uint4 vraw = *reinterpret_cast<const uint4*>(a.v + (size_t)kvh * HD + d0);
+  rope8<HD>(qh, c8, s8, d0, q8);
+  rope8<HD>(kh, c8, s8, d0, kn);
+  const uint4 vraw = *reinterpret_cast<const uint4*>(vh + d0);
   unpack8h(vraw, vn);
 #pragma unroll
   for (int i = 0; i < 8; ++i) q8[i] *= a.scale;
@@ -207,13 +268,9 @@ size_t rope_attn_workspace_bytes(int heads, int head_dim) {
   return (size_t)heads * kSplits * (head_dim + 4) * sizeof(float) + (size_t)heads * sizeof(unsigned);
 }
 
-int rope_attn_decode_launch(const void* q, const void* k, const void* v, const float* cos, const float* sin,
-                            const int64_t* pos, void* kcache, void* vcache, void* out, int heads, int kv_heads,
-                            int head_dim, int max_len, float scale, hipStream_t stream, void* workspace) {
-  if (heads < 1 || kv_heads < 1 || heads % kv_heads != 0 || max_len < 1) return QUIP_ERR_BAD_SHAPE;
-  AttnArgs a{reinterpret_cast<const f16*>(q), reinterpret_cast<const f16*>(k), reinterpret_cast<const f16*>(v),
-             cos, sin, pos, reinterpret_cast<f16*>(kcache), reinterpret_cast<f16*>(vcache),
-             reinterpret_cast<f16*>(out), heads, kv_heads, max_len, scale, nullptr, nullptr};
+static int rope_attn_launch_common(AttnArgs a, const AttnZ* zz, int head_dim, int max_len, hipStream_t stream,
+                                   void* workspace) {
+  const int heads = a.heads;
   const bool split = workspace != nullptr && max_len > kSplitFromPos;
   if (split) {
     a.ws = reinterpret_cast<float*>(workspace);
@@ -221,13 +278,61 @@ int rope_attn_decode_launch(const void* q, const void* k, const void* v, const f
                                              (size_t)heads * kSplits * (head_dim + 4) * sizeof(float));
   }
   const dim3 grid(heads, split ? kSplits : 1);
-  if (head_dim == 128)
-    hipLaunchKernelGGL(rope_attn_decode_kernel<128>, grid, dim3(256), 0, stream, a);
-  else if (head_dim == 64)
-    hipLaunchKernelGGL(rope_attn_decode_kernel<64>, grid, dim3(256), 0, stream, a);
-  else
-    return QUIP_ERR_UNSUPPORTED;
+  if (zz) {
+    const size_t lds = 3 * (size_t)had::buf_floats(zz->n) * sizeof(float);
+    if (head_dim == 128)
+      hipLaunchKernelGGL((rope_attn_decode_kernel<128, true>), grid, dim3(768), lds, stream, a, *zz);
+    else if (head_dim == 64)
+      hipLaunchKernelGGL((rope_attn_decode_kernel<64, true>), grid, dim3(768), lds, stream, a, *zz);
+    else
+      return QUIP_ERR_UNSUPPORTED;
+  } else {
+    const AttnZ none{};
+    if (head_dim == 128)
+      hipLaunchKernelGGL((rope_attn_decode_kernel<128, false>), grid, dim3(256), 0, stream, a, none);
+    else if (head_dim == 64)
+      hipLaunchKernelGGL((rope_attn_decode_kernel<64, false>), grid, dim3(256), 0, stream, a, none);
+    else
+      return QUIP_ERR_UNSUPPORTED;
+  }
   return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+}
+
+int rope_attn_decode_launch(const void* q, const void* k, const void* v, const float* cos, const float* sin,
+                            const int64_t* pos, void* kcache, void* vcache, void* out, int heads, int kv_heads,
+                            int head_dim, int max_len, float scale, hipStream_t stream, void* workspace) {
+  if (heads < 1 || kv_heads < 1 || heads % kv_heads != 0 || max_len < 1) return QUIP_ERR_BAD_SHAPE;
+  AttnArgs a{reinterpret_cast<const f16*>(q), reinterpret_cast<const f16*>(k), reinterpret_cast<const f16*>(v),
+             cos, sin, pos, reinterpret_cast<f16*>(kcache), reinterpret_cast<f16*>(vcache),
+             reinterpret_cast<f16*>(out), heads, kv_heads, max_len, scale, nullptr, nullptr};
+  return rope_attn_launch_common(a, nullptr, head_dim, max_len, stream, workspace);
+}
+
+bool rope_attn_decode_z_supported(int heads, int kv_heads, int head_dim) {
+  const int n = heads * head_dim;
+  return heads >= 1 && heads == kv_heads && (head_dim == 64 || head_dim == 128) && n >= 256 && n <= 4096 &&
+         (n & (n - 1)) == 0;
+}
+
+int rope_attn_decode_z_launch(const void* const* z, const void* const* post, const float* scales, const float* cos,
+                              const float* sin, const int64_t* pos, void* kcache, void* vcache, void* out, int heads,
+                              int kv_heads, int head_dim, int max_len, float scale, hipStream_t stream,
+                              void* workspace) {
+  if (heads < 1 || kv_heads < 1 || max_len < 1) return QUIP_ERR_BAD_SHAPE;
+  if (!rope_attn_decode_z_supported(heads, kv_heads, head_dim)) return QUIP_ERR_UNSUPPORTED;
+  AttnArgs a{nullptr, nullptr, nullptr, cos, sin, pos, reinterpret_cast<f16*>(kcache),
+             reinterpret_cast<f16*>(vcache), reinterpret_cast<f16*>(out), heads, kv_heads, max_len, scale, nullptr,
+             nullptr};
+  AttnZ zz{};
+  const int n = heads * head_dim;
+  for (int i = 0; i < 3; ++i) {
+    zz.z[i] = reinterpret_cast<const f16*>(z[i]);
+    zz.post[i] = reinterpret_cast<const f16*>(post[i]);
+    zz.scale[i] = scales[i];
+  }
+  zz.n = n;
+  zz.logL = 31 - __builtin_clz((unsigned)n);
+  return rope_attn_launch_common(a, &zz, head_dim, max_len, stream, workspace);
 }
 
 // Greedy tail of the decode step (example_generate.py's argmax sampling with temperature 0): next token =

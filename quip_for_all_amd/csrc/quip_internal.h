@@ -139,6 +139,11 @@ int rope_attn_decode_launch(const void* q, const void* k, const void* v, const f
                             const int64_t* pos, void* kcache, void* vcache, void* out, int heads, int kv_heads,
                             int head_dim, int max_len, float scale, hipStream_t stream, void* workspace = nullptr);
 size_t rope_attn_workspace_bytes(int heads, int head_dim);
+bool rope_attn_decode_z_supported(int heads, int kv_heads, int head_dim);
+int rope_attn_decode_z_launch(const void* const* z, const void* const* post, const float* scales, const float* cos,
+                              const float* sin, const int64_t* pos, void* kcache, void* vcache, void* out, int heads,
+                              int kv_heads, int head_dim, int max_len, float scale, hipStream_t stream,
+                              void* workspace);
 int argmax_step_launch(const void* logits, int n, void* tok, void* pos, hipStream_t stream);
 int had_transform_planes_launch(const void* x, void* planes, int in_features, int n, int K,
                                 const void* had, int transpose, const void* pre, float scale,

@@ -193,6 +193,13 @@ class LlamaDecoder:
         self.o_fused = planes_ok and fused_in_supported([L0["o"]])
         self.qkv_fused = planes_ok and fused_in_supported(qkv0)
         self.fused_prologue = os.environ.get("QUIP_FUSED_PROLOGUE", "1") != "0" and (self.chain or prologue_ok)
+        # q / k / v output transforms inside the attention launch (multi-head attention, power-of-two hidden <= 4096,
+        # plain SV output side)
+        from .register_lib import rope_attn_decode_z_supported
+        self.attn_z = (self.fused_prologue and self.fused_attention and os.environ.get("QUIP_ATTN_Z", "1") != "0"
+                       and rope_attn_decode_z_supported(s.heads, s.kv_heads, s.head_dim)
+                       and all(l.K_right == 1 and not l.per_channel and l.bias is None
+                               and l.q_out_features == l.out_features == s.hidden for l in qkv0))
 
     # ---- model bytes the decode step has to stream (roofline denominator) -----------
     def algorithmic_bytes_per_token(self):
@@ -258,8 +265,14 @@ class LlamaDecoder:
                 zs = gemv_group_unfused(qkv, h, rms_weight=L["ln1"], rms_eps=s.rms_eps)
             else:   # finishes the previous block: h += down(...)
                 h, zs = self._zx(qkv, prev_down, zd, h, L["ln1"])
-            q, k, v = out_transform_group(qkv, zs)
-            a = self._attention(i, q, k, v, cos, sin, mask)
+            if self.attn_z:
+                # the K = 1 output transforms of q / k / v in the attention launch's prologue: 9 launches per block
+                a = torch.ops.quip_lib.rope_attn_decode_z(
+                    list(zs), [l._vec(l.SV) for l in qkv], [1.0 / math.sqrt(l.q_out_features) for l in qkv],
+                    self.cos, self.sin, self.pos, self.kcache[i], self.vcache[i], self.attn_ws)
+            else:
+                q, k, v = out_transform_group(qkv, zs)
+                a = self._attention(i, q, k, v, cos, sin, mask)
             if self.o_fused:
                 _, (zo,) = gemv_fused([L["o"]], x=a.reshape(1, s.hidden))
             else:

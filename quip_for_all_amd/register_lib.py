@@ -44,6 +44,10 @@ _SCHEMAS = {
                                   "float[] scale, Tensor? rms_weight, float rms_eps, Tensor? gate, "
                                   "float resid_scale=0.0) -> Tensor[]",
     "e8p_gemv_planes_group": "(Tensor[] planes, Tensor[] Qidxs, Tensor grid) -> Tensor[]",
+    # rope + KV append + attention on the RAW GEMV outputs of q / k / v_proj (their K = 1 output transforms in the
+    # launch's prologue): zs / posts = [q, k, v], scales = 1 / sqrt(n)
+    "rope_attn_decode_z": "(Tensor[] zs, Tensor[] posts, float[] scales, Tensor cos, Tensor sin, Tensor pos, "
+                          "Tensor(a!) kcache, Tensor(b!) vcache, Tensor? workspace=None) -> Tensor",
     # M >= 32 (prefill): fused dequant + MFMA GEMM, x (M, k) fp16 -> (M, n) fp16; no dense W (csrc/e8p_prefill_gemm.hip)
     "e8p_mm_batched": "(Tensor x, Tensor Qidxs, Tensor grid) -> Tensor",
     # 2 <= M <= 32 rows in one pass over the codes, fp16 MFMA (csrc/e8p_skinny_gemm.hip)
@@ -600,6 +604,46 @@ def _rope_attn_decode_cuda(q, k, v, cos, sin, pos, kcache, vcache, workspace=Non
     return out
 
 
+def rope_attn_decode_z_supported(heads, kv_heads, head_dim):
+    return bool(capi.lib().quip_rope_attn_decode_z_supported(heads, kv_heads, head_dim))
+
+
+def _rope_attn_decode_z_cuda(zs, posts, scales, cos, sin, pos, kcache, vcache, workspace=None):
+    """zs / posts: the raw GEMV outputs (1, n) or (n,) and SV vectors (n,) of q / k / v_proj, fp16; the rest as
+    rope_attn_decode -> (heads, hd) fp16"""
+    import ctypes
+    import math
+    _need(len(zs) == 3 and len(posts) == 3 and len(scales) == 3, "rope_attn_decode_z: q, k, v")
+    kvh, max_len, hd = kcache.shape
+    n = zs[0].numel()
+    heads = n // hd
+    for t in list(zs) + list(posts):
+        _need(t.dtype == torch.float16 and t.is_contiguous() and t.is_cuda and t.numel() == n,
+              "rope_attn_decode_z: fp16 contiguous CUDA vectors of one common length")
+    for t in (kcache, vcache):
+        _need(t.dtype == torch.float16 and t.is_contiguous() and t.is_cuda, "rope_attn_decode_z: fp16 caches")
+    _need(heads * hd == n and rope_attn_decode_z_supported(heads, kvh, hd),
+          "rope_attn_decode_z: needs heads == kv_heads and heads * head_dim a power of two in 256..4096")
+    _need(cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous()
+          and tuple(cos.shape) == (max_len, hd) and tuple(sin.shape) == (max_len, hd), "cos / sin: float32 (max_len, hd)")
+    _need(pos.dtype == torch.int64 and pos.numel() == 1 and pos.is_cuda, "pos must be an int64 device scalar")
+    _need(tuple(vcache.shape) == tuple(kcache.shape), "cache shapes differ")
+    out = torch.empty((heads, hd), dtype=torch.float16, device=kcache.device)
+    if workspace is not None:
+        _need(workspace.dtype == torch.uint8 and workspace.is_contiguous() and workspace.device == kcache.device
+              and workspace.numel() >= capi.lib().quip_rope_attn_workspace_bytes(heads, hd),
+              "workspace: use rope_attn_workspace(heads, head_dim, device)")
+    zp = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in zs])
+    pp = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in posts])
+    sc = (ctypes.c_float * 3)(*[float(x) for x in scales])
+    with torch.cuda.device(kcache.device):
+        capi.check(capi.lib().quip_rope_attn_decode_z_f16(
+            zp, pp, sc, cos.data_ptr(), sin.data_ptr(), pos.data_ptr(), kcache.data_ptr(), vcache.data_ptr(),
+            out.data_ptr(), heads, kvh, hd, max_len, 1.0 / math.sqrt(hd), _ptr(workspace), _stream(kcache)),
+            "quip_rope_attn_decode_z_f16")
+    return out
+
+
 def e8p_mm_batched_supported(m, n, k):
     """shapes the fused batched product takes (quip_e8p_mm_batched)"""
     return m >= 1 and n >= 2 and n % 2 == 0 and k >= 64 and k % 64 == 0
@@ -774,6 +818,7 @@ _IMPLS = {
     "had_transform_planes": _had_transform_planes_cuda,
     "e8p_gemv_planes": _e8p_gemv_planes_cuda,
     "rope_attn_decode": _rope_attn_decode_cuda,
+    "rope_attn_decode_z": _rope_attn_decode_z_cuda,
     "e8p_gemv_fused": _e8p_gemv_fused_cuda,
     "had_transform_planes_group": _had_transform_planes_group_cuda,
     "had_chain_planes_group": _had_chain_planes_group_cuda,
@@ -867,6 +912,8 @@ _reg_fake("e8p_gemv_fused", lambda x, z, post, residual, rms_weight, rms_eps, z_
           ([z.new_empty((1, z.numel()))] if z is not None else []) +
           [q.new_empty((1, q.shape[0]), dtype=torch.float16) for q in Qidxs])
 _reg_fake("rope_attn_decode", lambda q, k, v, cos, sin, pos, kcache, vcache, workspace=None: torch.empty_like(q))
+_reg_fake("rope_attn_decode_z", lambda zs, posts, scales, cos, sin, pos, kcache, vcache, workspace=None:
+          kcache.new_empty((zs[0].numel() // kcache.shape[2], kcache.shape[2])))
 _reg_fake("e8p_mm_skinny", lambda x, Q, g: x.new_empty((x.shape[0], Q.shape[0]), dtype=torch.float16))
 _reg_fake("e8p_mm_batched", lambda x, Q, g: x.new_empty((x.shape[0], Q.shape[0]), dtype=torch.float16))
 _reg_fake("e8p_gemv_planes", lambda planes, Q, g: Q.new_empty((1, Q.shape[0]), dtype=torch.float16))
