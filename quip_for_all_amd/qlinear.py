@@ -248,11 +248,12 @@ class QuantLinear(nn.Module):
         return layer
 
 
-# A grouped GEMV launch pays launch / table build / drain once, but needs room for every x vector in
-# LDS (fewer table copies -> bank conflicts).  Measured on MI355X (tools/gemv_group_phases.py): grouping
-# wins while the launch is latency bound (7B shapes, 70B q/k/v) and loses for two 59 MB matrices
-# (70B gate/up: 33.4 us grouped vs 2 x 14.5-15.4 us).
-_GROUP_MAX_BYTES = int(os.environ.get("QUIP_GROUP_MAX_MB", "48")) << 20
+# A grouped GEMV launch pays launch / table build / pipeline fill / drain once.  The first kernel needs room for
+# every x vector in LDS (fewer table copies -> bank conflicts), and two 59 MB matrices lost there (70B gate/up: 33.4 us
+# grouped vs 2 x 14.5-15.4 us); the K-splitting kernel the dispatcher picks for launches >= 16-20 MB keeps full
+# tables: 70B gate/up grouped 27.3 us = 0.54 of 8 TB/s vs 2 x 15.3 us, q/k/v 11.0 vs 12.3 us (tools/gemv_v2_bench.py
+# --groups), so groups are only cut off far above any Llama block.
+_GROUP_MAX_BYTES = int(os.environ.get("QUIP_GROUP_MAX_MB", "256")) << 20
 
 
 def _gemv_planes_grouped(layers, planes):
