@@ -268,7 +268,7 @@ int quip_e8p_quantize_f32(const void* x, int64_t nvec, const void* grid_packed_a
 
 /* Rows mode for the other table modes of the same kernel.  mode 0: E8P12 (== quip_e8p_gemv_planes_rows);
  * mode 64: D4 (qidxs uint8 (n, k/4), grid = fp16 (256, 4) table; HI through its virtual 2k layout, see
- * quip_had_problem.planes_layout); mode 40: E8P12RVQ3B (qidxs = repacked int32 codes viewed as 2k virtual
+ * quip_had_problem.planes_layout); mode 40: E8P12RVQ3B (qidxs = the checkpoint's 3-byte codes, read as 2k virtual
  * weights -- pass k = 2 * in features --, grid = grid_packed_abs, grid2 = e81b_i8, see
  * quip_e8prvq3_gemv_planes_group).  grid2 is ignored otherwise. */
 int32_t quip_gemv_max_rows_mode(int32_t n, int32_t k, int32_t mode);
@@ -301,15 +301,17 @@ int quip_d4_gemv_planes_group(const void* const* planes, const void* const* qidx
                               void* const* ys, const int32_t* ns, int32_t count, int32_t k,
                               quip_stream_t stream);
 
-/* E8P12RVQ3B (3-byte codes: resid8 | e8p16 << 8, e8p12_rvq3.py:81-107) on the matrix-core GEMV.  The caller
- * repacks the codes once (at load time) to int32 (main16 << 16 | resid8 << 8), shape (n, k/8): read as 16-bit
- * codes that is an RVQ4-style row of 2k virtual weights (8-groups alternate residual / main) and
- * W x = W' x' with x' = [s x_g | x_g]_g -- the planes of x' come from the Hadamard launch with
+/* E8P12RVQ3B (3-byte codes: resid8 | e8p16 << 8, e8p12_rvq3.py:81-107) on the matrix-core GEMV.  qidxs is the
+ * checkpoint's own packed tensor (n rows of 3 k / 8 bytes, the int32 (n, 3 k / 32) Qidxs of the reference; rows need
+ * 4-byte alignment only): a lane loads 12 bytes = 4 codes, and a code read behind a zero byte is the dword
+ * (main16 << 16 | resid8 << 8) -- as 16-bit codes an RVQ4-style row of 2k virtual weights (8-groups alternate
+ * residual / main), W x = W' x' with x' = [s x_g | x_g]_g: the planes of x' come from the Hadamard launch with
  * quip_had_problem.resid_scale = s, exactly as for E8P12RVQ4B.  The low code of every pair indexes the E81B
  * table instead of the E8P tables: e81b_i8 = int8 [256][8] = 4 * e81b_grid (natural column order, 8-byte
  * aligned).  main + s * resid is summed exactly (the reference rounds it to fp16 per weight,
- * origin_order.cu:287-335).  k = in features (the launch runs on 2k); 2k <= 25600 (count * 2k for groups). */
-int quip_e8prvq3_gemv_planes_group(const void* const* planes, const void* const* qidxs_repacked,
+ * origin_order.cu:287-335).  k = in features (the launch runs on 2k), k % 32 == 0; 2k <= 25600 (count * 2k for
+ * groups).  (ABI 7: up to version 6 this entry point took codes repacked to 4 bytes.) */
+int quip_e8prvq3_gemv_planes_group(const void* const* planes, const void* const* qidxs,
                                    const void* grid_packed_abs, const void* e81b_i8, void* const* ys,
                                    const int32_t* ns, int32_t count, int32_t k, quip_stream_t stream);
 

@@ -213,10 +213,10 @@ class E8P12RVQ3B_codebook(_Codebook):
         final = init_vals + resid_vals * self.opt_resid_scale
         return (final, (init_idxs << 8) + resid_idxs) if return_idx else final
 
-    # bs=1 on the matrix-core GEMV: repacked once to int32 (main16 << 16 | resid8 << 8) the row is an RVQ4-style
-    # row of 2k virtual weights (8-groups alternate residual / main) whose LOW codes index the E81B table
-    # (csrc/e8p_gemv_mfma.hip, table modes 40 / 20); x' = [s * x_g | x_g]_g as for RVQ4.  The repacked copy
-    # (4 bytes per 8 weights next to the checkpoint's 3) is made on first use and kept per Qidxs buffer.
+    # bs=1 on the matrix-core GEMV: a 3-byte code [resid8, e8p_lo, e8p_hi] read behind a zero byte is the dword
+    # (main16 << 16 | resid8 << 8), i.e. an RVQ4-style row of 2k virtual weights (8-groups alternate residual / main)
+    # whose LOW codes index the E81B table (csrc/e8p_gemv_mfma.hip, table modes 40 / 20); x' = [s * x_g | x_g]_g as
+    # for RVQ4.  The kernel streams the checkpoint's own bytes (12-byte loads = 4 codes per lane): no repacked copy.
     @property
     def planes_resid_scale(self):
         return float(torch.tensor(self.opt_resid_scale, dtype=torch.float16))
@@ -237,32 +237,15 @@ class E8P12RVQ3B_codebook(_Codebook):
             self._e81b_i8_cache = t
         return t
 
-    def _repacked(self, Qidxs):
-        # one repacked copy per Qidxs buffer (a codebook object may serve many layers), refreshed when the
-        # buffer is written to
-        import weakref
-        cache = self.__dict__.setdefault("_repack_cache", {})
-        key = (Qidxs.data_ptr(), tuple(Qidxs.shape))
-        hit = cache.get(key)
-        # valid only for the very tensor object it was made from (a freed buffer's address can be reused), unmodified
-        if hit is None or hit[0] != Qidxs._version or hit[2]() is not Qidxs:
-            for k_ in [k_ for k_, h in cache.items() if h[2]() is None]:
-                del cache[k_]                                           # buffers that are gone
-            b = Qidxs.contiguous().view(torch.uint8).view(Qidxs.shape[0], -1, 3).to(torch.int32)
-            hit = (Qidxs._version, ((b[..., 2] << 24) | (b[..., 1] << 16) | (b[..., 0] << 8)).contiguous(),
-                   weakref.ref(Qidxs))
-            cache[key] = hit
-        return hit[1]
-
     def mm_planes(self, planes, Qidxs):
         return self.mm_planes_group([planes], [Qidxs])[0]
 
     def mm_planes_group(self, planes, Qidxs):
         return list(torch.ops.quip_lib.e8prvq3_gemv_planes_group(
-            planes, [self._repacked(q) for q in Qidxs], self.grid_packed_abs, self._e81b_i8(Qidxs[0].device)))
+            planes, list(Qidxs), self.grid_packed_abs, self._e81b_i8(Qidxs[0].device)))
 
     def mm_planes_rows(self, planes, Qidxs):
-        return torch.ops.quip_lib.gemv_planes_rows_mode(planes, self._repacked(Qidxs), self.grid_packed_abs,
+        return torch.ops.quip_lib.gemv_planes_rows_mode(planes, Qidxs, self.grid_packed_abs,
                                                         self._e81b_i8(Qidxs.device), 40)
 
     def maybe_pack_idxs(self, idxs):

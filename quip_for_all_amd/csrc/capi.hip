@@ -172,7 +172,7 @@ int quip_e8p_gemv_planes_rows(const void* planes, const void* qidxs, const void*
 }
 
 // rows mode with another table mode: 64 = D4 table (fp16 (256, 4) grid; HI through its virtual layout),
-// 40 = E8P12RVQ3B (repacked codes, k = 2 * in features, grid2 = e81b_i8)
+// 40 = E8P12RVQ3B (the 3-byte codes, k = 2 * in features, grid2 = e81b_i8)
 int32_t quip_gemv_max_rows_mode(int32_t n, int32_t k, int32_t mode) {
   return (n > 0 && k > 0 && (mode == 0 || mode == 64 || mode == 40)) ? e8p_gemv_mfma_max_rows(n, k, mode) : 0;
 }
@@ -182,6 +182,7 @@ int quip_gemv_planes_rows_mode(const void* planes, const void* qidxs, const void
   if (!planes || !qidxs || !grid || !y) return QUIP_ERR_NULL_POINTER;
   if (rows < 1 || n < 1 || k < 1 || k % 8 != 0) return QUIP_ERR_BAD_SHAPE;
   if (mode != 0 && mode != 64 && mode != 40) return QUIP_ERR_BAD_SHAPE;
+  if (mode == 40 && k % 64 != 0) return QUIP_ERR_BAD_SHAPE;   // rows of 3 (k / 2) / 8 bytes, dword aligned
   if (!aligned16(planes) || !aligned16(qidxs)) return QUIP_ERR_MISALIGNED;
   GemvTune t;
   t.rep = mode;
@@ -260,26 +261,26 @@ int quip_e8p_gemv_planes_group(const void* const* planes, const void* const* qid
   return gemv_group_common(planes, qidxs, grid_packed_abs, ys, ns, count, k, nullptr, 0, stream);
 }
 
-// E8P12RVQ3B on the matrix-core GEMV: codes repacked to (main16 << 16 | resid8 << 8), i.e. an RVQ4-style row of
+// E8P12RVQ3B on the matrix-core GEMV: a 3-byte code behind a zero byte is (main16 << 16 | resid8 << 8), i.e. an RVQ4-style row of
 // 2k virtual weights whose low 16-bit codes index the E81B table (T3) instead of the E8P tables
-int quip_e8prvq3_gemv_planes_group(const void* const* planes, const void* const* qidxs_repacked,
+int quip_e8prvq3_gemv_planes_group(const void* const* planes, const void* const* qidxs,
                                    const void* grid_packed_abs, const void* e81b_i8, void* const* ys,
                                    const int32_t* ns, int32_t count, int32_t k, quip_stream_t stream) {
-  if (!planes || !qidxs_repacked || !grid_packed_abs || !e81b_i8 || !ys || !ns) return QUIP_ERR_NULL_POINTER;
+  if (!planes || !qidxs || !grid_packed_abs || !e81b_i8 || !ys || !ns) return QUIP_ERR_NULL_POINTER;
   if (count < 1 || count > QUIP_MAX_GROUP) return QUIP_ERR_BAD_SHAPE;
   int n32[QUIP_MAX_GROUP];
   for (int i = 0; i < count; ++i) {
-    if (!planes[i] || !qidxs_repacked[i] || !ys[i]) return QUIP_ERR_NULL_POINTER;
-    if (!aligned16(planes[i]) || !aligned16(qidxs_repacked[i])) return QUIP_ERR_MISALIGNED;
+    if (!planes[i] || !qidxs[i] || !ys[i]) return QUIP_ERR_NULL_POINTER;
+    if (!aligned16(planes[i]) || (reinterpret_cast<uintptr_t>(qidxs[i]) & 3) != 0) return QUIP_ERR_MISALIGNED;
     if (ns[i] < 1) return QUIP_ERR_BAD_SHAPE;
     n32[i] = ns[i];
   }
-  if (k < 1 || k % 8 != 0) return QUIP_ERR_BAD_SHAPE;
+  if (k < 1 || k % 32 != 0) return QUIP_ERR_BAD_SHAPE;   // rows of 3 k / 8 bytes, dword aligned
   if ((reinterpret_cast<uintptr_t>(e81b_i8) & 7) != 0) return QUIP_ERR_MISALIGNED;
   GemvTune t;
   t.rep = 40;
   t.grid2 = e81b_i8;
-  return e8p_gemv_mfma_group_launch(planes, qidxs_repacked, grid_packed_abs, ys, n32, count, 2 * k, t, (hipStream_t)stream);
+  return e8p_gemv_mfma_group_launch(planes, qidxs, grid_packed_abs, ys, n32, count, 2 * k, t, (hipStream_t)stream);
 }
 
 int quip_d4_gemv_planes(const void* planes, const void* qidxs, const void* grid_f16, void* y, int32_t n,

@@ -41,6 +41,7 @@
 // (3 x 8 KiB), int32 accumulators [rows][4].
 #include "had_device.hip.h"
 #include "quip_internal.h"
+#include <type_traits>
 
 namespace quip {
 
@@ -88,7 +89,8 @@ struct Lds {
   // REP = 64: the D4 codebook -- ONE table of 256 x 4-byte entries (2w of the code's 4 weights as int8),
   //           64 copies (a private copy per lane: no conflicts), no sign table
   // REP = 40 / 20: E8P12RVQ3B -- the E8P tables (32 / 16 copies of T1, 16 of T2) plus T3 = the 256 x 8-byte
-  //           E81B residual table (4r as int8; 16 / 8 copies), looked up by the LOW code of every dword
+  //           E81B residual table (4r as int8; 16 / 8 copies), looked up by the LOW code of every dword; the
+  //           weight stream is the checkpoint's own 3-byte codes (12-byte loads, 3 k / 8 bytes per row)
   static constexpr bool kD4 = REP == 64;
   static constexpr bool kRvq3 = REP == 40 || REP == 20;
   static constexpr int kRep1 = kD4 ? 64 : ((REP == 16 || REP == 20) ? 16 : 32);
@@ -217,9 +219,25 @@ __device__ __forceinline__ void fill_tables_from_lane(char* smem, const u32x2& s
 // addresses), item_mfma() runs the table / x reads PIPE steps ahead of their MFMA.
 struct ItemAddr { uint32_t a1l[8], a2l[8], a1h[8], a2h[8]; };
 
+// E8P12RVQ3B: a checkpoint code is 3 bytes [resid8, e8p_lo, e8p_hi] (e8p12_rvq3.py:81-107); the decode below works
+// on dwords (main16 << 16 | resid8 << 8), i.e. the same three bytes behind a zero byte.  A lane's 12 landed bytes =
+// four codes: one shift, two v_perm_b32 and one mask.
+__device__ __forceinline__ u32x4 rvq3_dwords(const u32x3& w) {
+  return u32x4{w.x << 8, __builtin_amdgcn_perm(w.y, w.x, 0x0504030cu), __builtin_amdgcn_perm(w.z, w.y, 0x0403020cu),
+               w.z & 0xffffff00u};
+}
+
 template <int REP>
 __device__ __forceinline__ void item_addresses(const u32x4& q0, const u32x4& q1, uint32_t lane_c,
+                                               uint32_t lane_c2, ItemAddr& ad, uint32_t lane_c3 = 0);
+template <int REP>
+__device__ __forceinline__ void item_addresses(const u32x3& q0, const u32x3& q1, uint32_t lane_c,
                                                uint32_t lane_c2, ItemAddr& ad, uint32_t lane_c3 = 0) {
+  item_addresses<REP>(rvq3_dwords(q0), rvq3_dwords(q1), lane_c, lane_c2, ad, lane_c3);
+}
+template <int REP>
+__device__ __forceinline__ void item_addresses(const u32x4& q0, const u32x4& q1, uint32_t lane_c,
+                                               uint32_t lane_c2, ItemAddr& ad, uint32_t lane_c3) {
   const uint32_t d[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
   if constexpr (REP == 64) {
     // D4: dword t = 4 one-byte codes = the 16 weights of MFMA step t; entry address =
@@ -444,7 +462,7 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
       asm volatile("" : "+s"(W));
     }
     int row, off;     // off: uint4 units inside the row
-    if (kR8) {        // load j covers rows 8j .. 8j+7 of the row block, the slice's whole 128-byte line each
+    if constexpr (kR8) {        // load j covers rows 8j .. 8j+7 of the row block, the slice's whole 128-byte line each
       row = pick(row0, p) + rb * 16 + 8 * j + (lane >> 3);
       off = s * 8 + (lane & 7);
       off = off < row_u4 ? off : s * 8 + (lane & 1);   // K % 512 != 0: re-read a valid piece (x digits are 0)
@@ -454,6 +472,8 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
       off = off < row_u4 ? off : s * 8 + q;
     }
     row = row < N ? row : N - 1;
+    if constexpr (L::kRvq3)   // 12-byte pieces of the native 3-byte code stream (same piece index)
+      return reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(W) + ((size_t)row * row_u4 + off) * 12);
     return W + (size_t)row * row_u4 + off;
   };
 
@@ -533,7 +553,9 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
   // one being decoded (slot i + kDepth is requested when slot i has landed), so that the address /
   // TA work of the loads overlaps with the LDS-bound decode of other waves instead of preceding it.
   constexpr int kDepth = ONESHOT ? (SLOTS < QUIP_GEMV_DEPTH ? SLOTS : QUIP_GEMV_DEPTH) : SLOTS;
-  u32x4 qa[SLOTS], qb[SLOTS];
+  static_assert(!(L::kRvq3 && kR8), "RVQ3: 12-byte pieces, no line redistribution");
+  using Slot = std::conditional_t<L::kRvq3, u32x3, u32x4>;
+  Slot qa[SLOTS], qb[SLOTS];
 #pragma unroll
   for (int i = 0; i < kDepth; ++i) {
     const int it0 = wave + i * nwaves;
@@ -721,7 +743,7 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
       }
       if (cur < cnt) {   // wave-uniform
         ItemAddr ad;
-        if (kR8) {
+        if constexpr (kR8) {
           u32x4 da, db;
           redistribute_r8(qa[i], qb[i], lane, da, db);
           item_addresses<REP>(da, db, lane_c, lane_c2, ad, lane_c3);
@@ -763,7 +785,7 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
         const int cur = it + i * nwaves;
         asm_wait_vmcnt<2 * (SLOTS - 1)>(qa[i], qb[i]);
         ItemAddr ad;
-        if (kR8) {
+        if constexpr (kR8) {
           u32x4 da, db;
           redistribute_r8(qa[i], qb[i], lane, da, db);
           item_addresses<REP>(da, db, lane_c, lane_c2, ad, lane_c3);

@@ -45,6 +45,15 @@ template <int N>
 __device__ __forceinline__ void asm_wait_vmcnt(u32x4& a, u32x4& b) {
   asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
 }
+// 12-byte slots (E8P12RVQ3B's native 3-byte codes: four codes per lane and load)
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void asm_load16_nt(u32x3& dst, const uint4* p) {
+  asm volatile("global_load_dwordx3 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void asm_wait_vmcnt(u32x3& a, u32x3& b) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
 
 __device__ __forceinline__ f16x2 as_f16x2(uint32_t u) { return __builtin_bit_cast(f16x2, u); }
 __device__ __forceinline__ uint32_t as_u32(f16x2 h) { return __builtin_bit_cast(uint32_t, h); }

@@ -52,7 +52,7 @@ _SCHEMAS = {
     "e8p_mm_batched": "(Tensor x, Tensor Qidxs, Tensor grid) -> Tensor",
     # 2 <= M <= 32 rows in one pass over the codes, fp16 MFMA (csrc/e8p_skinny_gemm.hip)
     "e8p_mm_skinny": "(Tensor x, Tensor Qidxs, Tensor grid) -> Tensor",
-    # E8P12RVQ3B on the matrix-core GEMV: Qidxs repacked to int32 (main16 << 16 | resid8 << 8), e81b_i8 = int8 (256, 8)
+    # E8P12RVQ3B on the matrix-core GEMV: Qidxs = the checkpoint's 3-byte codes (int32 (n, 3k/32)), e81b_i8 = int8 (256, 8)
     "e8prvq3_gemv_planes_group": "(Tensor[] planes, Tensor[] Qidxs, Tensor grid, Tensor e81b_i8) -> Tensor[]",
     "d4_gemv_planes": "(Tensor planes, Tensor Qidxs, Tensor grid) -> Tensor",
     "d4_gemv_planes_group": "(Tensor[] planes, Tensor[] Qidxs, Tensor grid) -> Tensor[]",
@@ -63,7 +63,7 @@ _SCHEMAS = {
     "had_transform_planes_rows": "(Tensor x, int n, int K, Tensor? had, bool transpose, Tensor? pre, float scale, "
                                  "Tensor? rms_weight, float rms_eps, Tensor? gate, float resid_scale=0.0) -> Tensor",
     "e8p_gemv_planes_rows": "(Tensor planes, Tensor Qidxs, Tensor grid) -> Tensor",
-    # the same for the other table modes: 64 = D4 table (Qidxs uint8 (n, k/4)), 40 = E8P12RVQ3B (repacked int32 codes)
+    # the same for the other table modes: 64 = D4 table (Qidxs uint8 (n, k/4)), 40 = E8P12RVQ3B (the 3-byte codes)
     "gemv_planes_rows_mode": "(Tensor planes, Tensor Qidxs, Tensor grid, Tensor? grid2, int mode) -> Tensor",
     # quantise-time nearest E8P12 codeword: X (N, 8) fp32 -> (vals (N, 8) fp32, idx (N) int64)
     "e8p_quantize": "(Tensor X, Tensor grid) -> (Tensor, Tensor)",
@@ -259,11 +259,12 @@ def _e8prvq3_gemv_planes_group_cuda(planes, Qidxs, grid, e81b_i8):
     import ctypes
     count = len(planes)
     _need(1 <= count <= capi.MAX_GROUP and len(Qidxs) == count, "group of 1..3 problems")
-    k = Qidxs[0].shape[1] * 8
+    _need(Qidxs[0].shape[1] % 3 == 0, "Qidxs: the checkpoint's packed int32 (n, 3 k / 32) codes")
+    k = Qidxs[0].shape[1] * 32 // 3
     dev = planes[0].device
     for pl, q in zip(planes, Qidxs):
-        _need(q.dtype == torch.int32 and q.is_contiguous() and q.shape[1] * 8 == k and q.device == dev,
-              "Qidxs must be the repacked contiguous int32 (n, k/8) codes with a common k")
+        _need(q.dtype == torch.int32 and q.is_contiguous() and q.shape[1] * 32 == 3 * k and q.device == dev,
+              "Qidxs must be the checkpoint's contiguous int32 (n, 3 k / 32) tensors (3-byte codes) with a common k")
         _need(pl.dtype == torch.uint8 and pl.is_contiguous() and pl.device == dev, "planes must be uint8")
     _need(e81b_i8.dtype == torch.int8 and tuple(e81b_i8.shape) == (256, 8) and e81b_i8.is_contiguous()
           and e81b_i8.device == dev, "e81b_i8 must be the contiguous int8 (256, 8) table")
@@ -371,9 +372,10 @@ def _e8p_gemv_planes_rows_cuda(planes, Qidxs, grid):
 def _gemv_planes_rows_mode_cuda(planes, Qidxs, grid, grid2, mode):
     _need(mode in (64, 40), "mode: 64 (D4 table) or 40 (E8P12RVQ3B tables)")
     _need(Qidxs.is_contiguous() and Qidxs.dtype == (torch.uint8 if mode == 64 else torch.int32),
-          "Qidxs: contiguous uint8 (n, k/4) for mode 64, repacked int32 (n, k/8) for mode 40")
+          "Qidxs: contiguous uint8 (n, k/4) for mode 64, the checkpoint's int32 (n, 3 k / 32) 3-byte codes for mode 40")
     n = Qidxs.shape[0]
-    k = Qidxs.shape[1] * 4 if mode == 64 else Qidxs.shape[1] * 16       # mode 40: 2 * in features virtual weights
+    _need(mode == 64 or Qidxs.shape[1] % 3 == 0, "mode 40: Qidxs (n, 3 k / 32)")
+    k = Qidxs.shape[1] * 4 if mode == 64 else Qidxs.shape[1] * 64 // 3   # mode 40: 2 * in features virtual weights
     L = capi.lib()
     _need(planes.dim() == 2 and planes.dtype == torch.uint8 and planes.is_contiguous()
           and planes.shape[1] == L.quip_e8p_planes_bytes(k) and planes.device == Qidxs.device,

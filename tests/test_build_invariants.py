@@ -16,12 +16,18 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-def test_gemv_kernels_use_no_scratch():
+def test_gemv_kernels_use_no_scratch_and_touch_no_register_in_flight():
+    """e8p_gemv_mfma.hip, every instantiation: no scratch, and (tools/check_inflight.py) no instruction reads or writes
+    a register that a counted load is still going to write -- the slots are tied asm operands here, so a copy ahead
+    of the wait is exactly what the allocator could emit; the E8P12RVQ3B modes stream 12-byte slots"""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import check_inflight
     src = os.path.join(REPO, "quip_for_all_amd", "csrc", "e8p_gemv_mfma.hip")
-    err = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-o", os.devnull, src,
-                          "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, check=True).stderr
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", "-", src,
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, check=True)
     name, seen, bad = None, 0, []
-    for line in err.splitlines():
+    for line in r.stderr.splitlines():
         m = re.search(r"Function Name: (\S+)", line)
         if m:
             name = m.group(1)
@@ -32,6 +38,16 @@ def test_gemv_kernels_use_no_scratch():
                 bad.append((name, int(m.group(1))))
     assert seen >= 20, "resource remarks not found"
     assert not bad, bad
+    kernels = [(n, l) for n, l in check_inflight.kernels_of(r.stdout) if "e8p_gemv_mfma_kernel" in n]
+    assert len(kernels) >= 20
+    native = 0
+    for kname, lines in kernels:
+        assert check_inflight.check_kernel(lines) == [], kname
+        rvq3 = re.search(r"e8p_gemv_mfma_kernelILi(40|20)E", kname) is not None
+        has3 = any("global_load_dwordx3" in l for l in lines)
+        assert rvq3 == has3, kname          # the RVQ3 modes, and only they, load 12-byte pieces
+        native += rvq3
+    assert native >= 10
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")

@@ -367,8 +367,9 @@ def test_skinny_rows_other_codebooks_on_matrix_core_path(cbid, fin, fout, M):
 
 @pytest.mark.parametrize("fin,fouts", [(4096, (4096, 4096, 4096)), (4096, (11008, 11008)), (256, (256, 688))])
 def test_rvq3_grouped_planes_path_equals_single_calls(fin, fouts):
-    """E8P12RVQ3B bs=1: grouped launches on the matrix-core GEMV (repacked codes + E81B table mode) give
-    exactly what the modules give one by one, and the repacked copy follows an in-place update of Qidxs"""
+    """E8P12RVQ3B bs=1: grouped launches on the matrix-core GEMV (the checkpoint's 3-byte codes + E81B table mode)
+    give exactly what the modules give one by one; the kernel reads Qidxs itself, so an in-place update of the
+    codes is seen by the next call"""
     from quip_for_all_amd.qlinear import forward_group
     layers = [_layer(O.make_layer("E8P12RVQ3B", fin, fo, seed=fin + fo + i)) for i, fo in enumerate(fouts)]
     assert all(l.codebook.planes_supported(l.q_out_features, l.q_in_features) for l in layers)
