@@ -20,6 +20,17 @@ int device_cu_count() {
   return cached[dev];
 }
 
+int ensure_dyn_lds(DynLdsCache& cache, const void* kernel, int lds) {
+  if (lds <= 48 * 1024) return QUIP_OK;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return QUIP_ERR_LAUNCH;
+  const bool slot = dev >= 0 && dev < 16;
+  if (slot && lds <= cache.bytes[dev]) return QUIP_OK;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return QUIP_ERR_LAUNCH;
+  if (slot) cache.bytes[dev] = lds;
+  return QUIP_OK;
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline bool aligned64(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 63u) == 0; }
 

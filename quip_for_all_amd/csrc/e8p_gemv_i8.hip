@@ -409,13 +409,8 @@ int launch_variant(const void* xsrc, const int* sh, const void* qidxs, const voi
                    hipStream_t stream) {
   auto kern = e8p_gemv_i8_kernel<REP, ROWS, NDIG, MAXT, XMODE>;
   const int lds = XMODE ? Lds<REP>::bytes(k) : Lds<REP>::kEnd;
-  static int configured_lds = 0;  // per instantiation; benign race (idempotent attribute)
-  if (lds > configured_lds) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return QUIP_ERR_LAUNCH;
-    configured_lds = lds;
-  }
+  static DynLdsCache configured;   // per instantiation, per device
+  if (ensure_dyn_lds(configured, reinterpret_cast<const void*>(kern), lds) != QUIP_OK) return QUIP_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64 * G * J), lds, stream,
                      reinterpret_cast<const uint4*>(qidxs), xsrc, sh, reinterpret_cast<f16*>(y),
                      reinterpret_cast<const uint64_t*>(grid), n, k, J, G, rpb, dbg);

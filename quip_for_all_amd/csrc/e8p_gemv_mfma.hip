@@ -845,13 +845,8 @@ int launch(const GemvGroup<G>& gp, const void* grid, int k, int kp, int nblocks,
   auto kern = e8p_gemv_mfma_kernel<REP, SLOTS, MAXT, G, ONESHOT, FUSED, ROWS>;
   const int lds = FUSED ? Lds<REP>::bytes_fused(kp, G) : Lds<REP>::bytes(kp, ROWS ? mrows : G);
   const FusedIn fi = fin ? *fin : FusedIn{};
-  static int configured = 0;  // benign race: idempotent attribute
-  if (lds > configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return QUIP_ERR_LAUNCH;
-    configured = lds;
-  }
+  static DynLdsCache configured;   // per instantiation, per device
+  if (ensure_dyn_lds(configured, reinterpret_cast<const void*>(kern), lds) != QUIP_OK) return QUIP_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(threads), lds, stream, gp, fi,
                      reinterpret_cast<const uint64_t*>(grid), k, kp, dbg, mrows);
   return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;

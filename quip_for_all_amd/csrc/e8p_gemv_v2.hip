@@ -462,13 +462,8 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
 template <int REP1, int REP2, int SLOTS, int G>
 int v2_launch(const V2Args& a, int nblocks, int threads, int lds, hipStream_t stream) {
   auto kern = e8p_gemv_v2_kernel<REP1, REP2, SLOTS, G>;
-  static int configured = 0;   // benign race: idempotent attribute
-  if (lds > configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-        hipSuccess)
-      return QUIP_ERR_LAUNCH;
-    configured = lds;
-  }
+  static DynLdsCache configured;   // per instantiation, per device
+  if (ensure_dyn_lds(configured, reinterpret_cast<const void*>(kern), lds) != QUIP_OK) return QUIP_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(threads), lds, stream, a);
   return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
 }

@@ -295,13 +295,9 @@ int e8p_prefill_gemm_launch(const void* x, const void* qidxs, const void* grid, 
   const int MT = (int)((m + kBM - 1) / kBM), NT = (n + kBN - 1) / kBN;
   const int64_t blocks = (int64_t)((MT + 7) / 8) * NT * 8;
   if (blocks > 0x7fffffff) return QUIP_ERR_UNSUPPORTED;
-  static bool configured = false;   // benign race: idempotent attribute
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(e8p_prefill_gemm_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess)
-      return QUIP_ERR_LAUNCH;
-    configured = true;
-  }
+  static DynLdsCache configured;   // per device
+  if (ensure_dyn_lds(configured, reinterpret_cast<const void*>(e8p_prefill_gemm_kernel), kLds) != QUIP_OK)
+    return QUIP_ERR_LAUNCH;
   hipLaunchKernelGGL(e8p_prefill_gemm_kernel, dim3((unsigned)blocks), dim3(512), kLds, stream,
                      reinterpret_cast<const f16*>(x), reinterpret_cast<const uint16_t*>(qidxs),
                      reinterpret_cast<const uint64_t*>(grid), reinterpret_cast<f16*>(y), (int)m, n, k, MT, NT);

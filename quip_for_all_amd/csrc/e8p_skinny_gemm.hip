@@ -296,13 +296,8 @@ int e8p_skinny_gemm_launch(const void* x, const void* qidxs, const void* grid, v
   // many columns: two column blocks x 8 slices
   const bool one = (n + 63) / 64 < 2 * device_cu_count() / 3;
   auto go = [&](auto kern, int cols, int slot) -> int {
-    static bool configured[4] = {false, false, false, false};   // benign race: idempotent attribute
-    if (!configured[slot]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kSLds) !=
-          hipSuccess)
-        return QUIP_ERR_LAUNCH;
-      configured[slot] = true;
-    }
+    static DynLdsCache configured[4];   // per instantiation, per device
+    if (ensure_dyn_lds(configured[slot], reinterpret_cast<const void*>(kern), kSLds) != QUIP_OK) return QUIP_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3((n + cols - 1) / cols), dim3(1024), kSLds, stream, reinterpret_cast<const f16*>(x),
                        reinterpret_cast<const uint16_t*>(qidxs), reinterpret_cast<const uint64_t*>(grid),
                        reinterpret_cast<f16*>(y), m, n, k);

@@ -774,13 +774,9 @@ __global__ __launch_bounds__(256) void had_small_kernel(HadGroup grp) {
 }
 
 template <typename Kern>
-int launch_one(Kern kern, int& configured, const HadGroup& g, dim3 grid, int threads, int lds, hipStream_t stream) {
-  if (lds > 48 * 1024 && lds > configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-        hipSuccess)
-      return QUIP_ERR_LAUNCH;
-    configured = lds;
-  }
+int launch_one(Kern kern, DynLdsCache& configured, const HadGroup& g, dim3 grid, int threads, int lds,
+               hipStream_t stream) {
+  if (ensure_dyn_lds(configured, reinterpret_cast<const void*>(kern), lds) != QUIP_OK) return QUIP_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, grid, dim3(threads), lds, stream, g);
   return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
 }
@@ -798,7 +794,7 @@ int launch(HadGroup& g, int count, int64_t rows, hipStream_t stream) {
     a.vec_out = (a.out_features % 8 == 0) && aligned16(a.y) && aligned16(a.post) && aligned16(a.bias) &&
                 aligned16(a.residual);
   }
-  static int cfg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  static DynLdsCache cfg[8];   // per kernel instantiation, per device
   if (K > 1 && L >= 64 && L <= 256) {   // tall: 256 threads, R = 4096 / L rows per workgroup
     const int R = 4096 / L;
     // [shuffle buffer | H tile | x rows | second half of the ping-pong buffer]
@@ -810,18 +806,14 @@ int launch(HadGroup& g, int count, int64_t rows, hipStream_t stream) {
       for (int i = 0; i < count; ++i)
         ok = ok && g.p[i].vec && g.p[i].vec_out && !g.p[i].rms_w && !g.p[i].pre2 && !g.p[i].z && g.p[i].out_features % 8 == 0;
       if (ok) {
-        static int cfgb = 0;
+        static DynLdsCache cfgb;
         const int BR = (K + 3) & ~3;
         const int lds = had::buf_floats(BR * L) * 4 + 48 * 48 * 2;
         const int threads = 256;
         const int64_t want = 3 * (int64_t)device_cu_count();       // three resident workgroups per CU
         const dim3 grid((unsigned)(rows < want ? rows : want), 1, count);
-        if (lds > 48 * 1024 && lds > cfgb) {
-          if (hipFuncSetAttribute(reinterpret_cast<const void*>(had_tall_batch_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return QUIP_ERR_LAUNCH;
-          cfgb = lds;
-        }
+        if (ensure_dyn_lds(cfgb, reinterpret_cast<const void*>(had_tall_batch_kernel), lds) != QUIP_OK)
+          return QUIP_ERR_LAUNCH;
         hipLaunchKernelGGL(had_tall_batch_kernel, grid, dim3(threads), lds, stream, g, (int)rows);
         return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
       }
@@ -850,7 +842,7 @@ int launch(HadGroup& g, int count, int64_t rows, hipStream_t stream) {
       g.p[i].pp = batch ? 0 : had::buf_floats(g.p[i].L);
     }
     const int lds = (batch ? 1 : 2) * had::buf_floats(Lmax) * 4;
-    static int cm[2] = {0, 0};
+    static DynLdsCache cm[2];
     return Lmax <= 4096 ? launch_one(had_fast_kernel<false, false, 256, true>, cm[0], g, grid, Lmax / 16, lds, stream)
                         : launch_one(had_fast_kernel<false, false, 1024>, cm[1], g, grid, Lmax / 16, lds, stream);
   }
@@ -869,7 +861,7 @@ int launch(HadGroup& g, int count, int64_t rows, hipStream_t stream) {
         const int part = 2 * had::buf_floats(L);
         const int lds2 = (part + (tg - 1) * 16 * (L / 16)) * 4;
         for (int i = 0; i < count; ++i) { g.p[i].tgroups = tg; g.p[i].part_off = part; g.p[i].pp = had::buf_floats(L); }
-        static int c2[2] = {0, 0};
+        static DynLdsCache c2[2];
         return planes ? launch_one(had_fast_kernel<true, false, 1024>, c2[0], g, grid, (L / 16) * tg, lds2, stream)
                       : launch_one(had_fast_kernel<false, false, 1024>, c2[1], g, grid, (L / 16) * tg, lds2, stream);
       }
@@ -888,7 +880,7 @@ int launch(HadGroup& g, int count, int64_t rows, hipStream_t stream) {
       }
     }
     if (L <= 4096 && K == 1) {
-      static int c1[2] = {0, 0};
+      static DynLdsCache c1[2];
       return planes ? launch_one(had_fast_kernel<true, false, 256, true>, c1[0], g, grid, L / 16, lds, stream)
                     : launch_one(had_fast_kernel<false, false, 256, true>, c1[1], g, grid, L / 16, lds, stream);
     }

@@ -65,13 +65,8 @@ int launch_generic(const void* x, void* y, int64_t rows, int n, float scale, hip
   const int threads = n >= 2048 ? 1024 : (n >= 128 ? n / 2 : 64);
   const int lds = n * 4;
   auto kern = hadamard_generic_kernel<T>;
-  static int configured = 0;
-  if (lds > configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-        hipSuccess)
-      return QUIP_ERR_LAUNCH;
-    configured = lds;
-  }
+  static DynLdsCache configured;   // per instantiation, per device
+  if (ensure_dyn_lds(configured, reinterpret_cast<const void*>(kern), lds) != QUIP_OK) return QUIP_ERR_LAUNCH;
   for (int64_t r0 = 0; r0 < rows; r0 += 1 << 30) {   // grid.x limit
     const int64_t m = rows - r0 < (1 << 30) ? rows - r0 : (1 << 30);
     hipLaunchKernelGGL(kern, dim3((unsigned)m), dim3(threads), lds, stream, reinterpret_cast<const T*>(x) + r0 * n,

@@ -9,6 +9,12 @@ namespace quip {
 
 int device_cu_count();
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: one static DynLdsCache per kernel
+// instantiation (at its launch site) remembers the largest size configured on each device of the process, so a
+// process that drives several GPUs configures the kernel on each of them.  (Benign race: the attribute is idempotent.)
+struct DynLdsCache { int bytes[16] = {}; };
+int ensure_dyn_lds(DynLdsCache& cache, const void* kernel, int lds);   // QUIP_OK / QUIP_ERR_LAUNCH
+
 // Tuning knobs of the E8P decode GEMV (0 = pick automatically).  Exposed through
 // quip_e8p_gemv_tuned() for the micro-benchmark only; the ABI entry points use auto.
 struct GemvTune {
