@@ -310,10 +310,17 @@ int quip_d4_gemv_planes_group(const void* const* planes, const void* const* qidx
  * table instead of the E8P tables: e81b_i8 = int8 [256][8] = 4 * e81b_grid (natural column order, 8-byte
  * aligned).  main + s * resid is summed exactly (the reference rounds it to fp16 per weight,
  * origin_order.cu:287-335).  k = in features (the launch runs on 2k), k % 32 == 0; 2k <= 25600 (count * 2k for
- * groups).  (ABI 7: up to version 6 this entry point took codes repacked to 4 bytes.) */
+ * groups) without a workspace.  (ABI 7: up to version 6 this entry point took codes repacked to 4 bytes.) */
 int quip_e8prvq3_gemv_planes_group(const void* const* planes, const void* const* qidxs,
                                    const void* grid_packed_abs, const void* e81b_i8, void* const* ys,
                                    const int32_t* ns, int32_t count, int32_t k, quip_stream_t stream);
+/* The same with a caller workspace (quip_e8p_gemv_workspace_bytes(n), zeroed once, see quip_e8p_gemv_planes_ws): a
+ * single problem whose virtual row is longer than 25600 (Llama-2-70B down_proj: 2k = 57344) is then taken by the
+ * K-splitting kernel with a third-table mode; everything else runs as above. */
+int quip_e8prvq3_gemv_planes_group_ws(const void* const* planes, const void* const* qidxs,
+                                      const void* grid_packed_abs, const void* e81b_i8, void* const* ys,
+                                      const int32_t* ns, int32_t count, int32_t k, void* workspace,
+                                      size_t workspace_bytes, quip_stream_t stream);
 
 /* ---- GEMV with the input side of the layer(s) computed in its prologue (bs = 1, K_left == 1) ----
  * For `count` (1..3) E8P12 modules reading the same activation of width k (a power of two,

@@ -33,6 +33,7 @@ SIGNATURES = {
     "quip_gemv_planes_rows_mode": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
     "quip_e8p_gemv_planes_rows": [_P, _P, _P, _P, _I32, _I32, _I32, _P],
     "quip_e8prvq3_gemv_planes_group": [_P, _P, _P, _P, _P, _P, _I32, _I32, _P],
+    "quip_e8prvq3_gemv_planes_group_ws": [_P, _P, _P, _P, _P, _P, _I32, _I32, _P, _c.c_size_t, _P],
     "quip_d4_gemv_planes": [_P, _P, _P, _P, _I32, _I32, _P],
     "quip_d4_gemv_planes_group": [_P, _P, _P, _P, _P, _I32, _I32, _P],
     "quip_e8p_gemv_fused": [_P, _P, _P, _P, _P, _I32, _I32, _P],

@@ -223,7 +223,8 @@ class E8P12RVQ3B_codebook(_Codebook):
 
     @staticmethod
     def planes_supported(q_out, q_in):
-        return (2 * q_in) % 128 == 0 and 128 <= 2 * q_in <= 25600 and q_out >= 1
+        # virtual rows longer than 25600 (70B down_proj: 2 k = 57344): the K-splitting kernel's third-table mode
+        return (2 * q_in) % 128 == 0 and 128 <= 2 * q_in <= 57344 and q_out >= 1
 
     @staticmethod
     def planes_group_supported(q_outs, q_in):

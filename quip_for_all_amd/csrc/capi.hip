@@ -274,24 +274,45 @@ int quip_e8p_gemv_planes_group(const void* const* planes, const void* const* qid
 
 // E8P12RVQ3B on the matrix-core GEMV: a 3-byte code behind a zero byte is (main16 << 16 | resid8 << 8), i.e. an RVQ4-style row of
 // 2k virtual weights whose low 16-bit codes index the E81B table (T3) instead of the E8P tables
-int quip_e8prvq3_gemv_planes_group(const void* const* planes, const void* const* qidxs,
-                                   const void* grid_packed_abs, const void* e81b_i8, void* const* ys,
-                                   const int32_t* ns, int32_t count, int32_t k, quip_stream_t stream) {
+static int e8prvq3_group_common(const void* const* planes, const void* const* qidxs, const void* grid_packed_abs,
+                                const void* e81b_i8, void* const* ys, const int32_t* ns, int32_t count, int32_t k,
+                                void* ws, size_t ws_bytes, quip_stream_t stream) {
   if (!planes || !qidxs || !grid_packed_abs || !e81b_i8 || !ys || !ns) return QUIP_ERR_NULL_POINTER;
   if (count < 1 || count > QUIP_MAX_GROUP) return QUIP_ERR_BAD_SHAPE;
   int n32[QUIP_MAX_GROUP];
+  size_t need = 0;
   for (int i = 0; i < count; ++i) {
     if (!planes[i] || !qidxs[i] || !ys[i]) return QUIP_ERR_NULL_POINTER;
     if (!aligned16(planes[i]) || (reinterpret_cast<uintptr_t>(qidxs[i]) & 3) != 0) return QUIP_ERR_MISALIGNED;
     if (ns[i] < 1) return QUIP_ERR_BAD_SHAPE;
     n32[i] = ns[i];
+    need += e8p_gemv_v2_workspace_words(ns[i]) * 4;
   }
   if (k < 1 || k % 32 != 0) return QUIP_ERR_BAD_SHAPE;   // rows of 3 k / 8 bytes, dword aligned
-  if ((reinterpret_cast<uintptr_t>(e81b_i8) & 7) != 0) return QUIP_ERR_MISALIGNED;
+  if ((reinterpret_cast<uintptr_t>(e81b_i8) & 7) != 0 || (ws && !aligned16(ws))) return QUIP_ERR_MISALIGNED;
   GemvTune t;
   t.rep = 40;
   t.grid2 = e81b_i8;
-  return e8p_gemv_mfma_group_launch(planes, qidxs, grid_packed_abs, ys, n32, count, 2 * k, t, (hipStream_t)stream);
+  const int rc = e8p_gemv_mfma_group_launch(planes, qidxs, grid_packed_abs, ys, n32, count, 2 * k, t, (hipStream_t)stream);
+  if (rc != QUIP_ERR_UNSUPPORTED) return rc;
+  // virtual rows beyond the first kernel's LDS budget (70B down_proj: 2k = 57344): the K-splitting kernel, one problem
+  if (count != 1) return QUIP_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < need) return QUIP_ERR_NULL_POINTER;
+  return e8p_gemv_v2_group_launch(planes, qidxs, grid_packed_abs, ys, ws, n32, 1, 2 * k, t, (hipStream_t)stream);
+}
+
+int quip_e8prvq3_gemv_planes_group(const void* const* planes, const void* const* qidxs,
+                                   const void* grid_packed_abs, const void* e81b_i8, void* const* ys,
+                                   const int32_t* ns, int32_t count, int32_t k, quip_stream_t stream) {
+  return e8prvq3_group_common(planes, qidxs, grid_packed_abs, e81b_i8, ys, ns, count, k, nullptr, 0, stream);
+}
+
+int quip_e8prvq3_gemv_planes_group_ws(const void* const* planes, const void* const* qidxs,
+                                      const void* grid_packed_abs, const void* e81b_i8, void* const* ys,
+                                      const int32_t* ns, int32_t count, int32_t k, void* workspace,
+                                      size_t workspace_bytes, quip_stream_t stream) {
+  return e8prvq3_group_common(planes, qidxs, grid_packed_abs, e81b_i8, ys, ns, count, k, workspace, workspace_bytes,
+                              stream);
 }
 
 int quip_d4_gemv_planes(const void* planes, const void* qidxs, const void* grid_f16, void* y, int32_t n,

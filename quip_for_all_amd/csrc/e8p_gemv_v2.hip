@@ -29,6 +29,8 @@
 //  * Up to three problems of the same K per launch (q/k/v, gate/up): tables, launch and drain paid once.
 //  * SLOTS load instructions (1 KiB each) per wave are in flight from the first instructions of the kernel,
 //    so the table build runs in the shadow of the first HBM burst.
+#include <type_traits>
+
 #include "quip_device.hip.h"
 #include "quip_internal.h"
 
@@ -48,12 +50,23 @@ constexpr int kMaxG = 3;
 // (one per problem) and the int32 accumulators [rows][4] (+ one word: the run counter).
 // (REP1, REP2) = (32, 32): every table lookup conflict free, 128 KiB; (32, 16): two-way conflicts on the sign
 // lookups, 96 KiB; (16, 16): two-way on both, 64 KiB (short launches: half the table build).
-template <int REP1, int REP2>
+// RVQ3 (E8P12RVQ3B, see e8p_gemv_mfma.hip table modes 40 / 20): a third table T3 = the 256 x 8-byte E81B residual
+// entries (4r as int8), 16 copies, behind T2; the weight stream is the checkpoint's 3-byte codes (12-byte slots).
+template <int REP1, int REP2, bool RVQ3 = false>
 struct V2Lds {
   static constexpr int kT2 = 256 * REP1 * 8;
-  static constexpr int kX = kT2 + 256 * REP2 * 8;
+  static constexpr int kT3 = kT2 + 256 * REP2 * 8;
+  static constexpr int kRep3 = 16;
+  static constexpr int kX = kT3 + (RVQ3 ? 256 * kRep3 * 8 : 0);
   static constexpr int kTotal = 160 * 1024;
 };
+
+// a lane's 12 landed bytes = four 3-byte codes [resid8, e8p_lo, e8p_hi] -> the dwords (main16 << 16 | resid8 << 8)
+__device__ __forceinline__ u32x4 v2_rvq3_dwords(const u32x3& w) {
+  return u32x4{w.x << 8, __builtin_amdgcn_perm(w.y, w.x, 0x0504030cu), __builtin_amdgcn_perm(w.z, w.y, 0x0403020cu),
+               w.z & 0xffffff00u};
+}
+__device__ __forceinline__ u32x4 v2_rvq3_dwords(const u32x4& w) { return w; }
 
 __device__ __forceinline__ uint2 v2_lds_read8(uint32_t addr) {
   const u32x2 v = *reinterpret_cast<lds_u2_ptr>((uintptr_t)addr);
@@ -94,6 +107,7 @@ struct V2Args {
   int N[kMaxG];
   int rpb[kMaxG];                 // rows per workgroup (multiple of 4)
   const uint64_t* grid;           // grid_packed_abs
+  const uint64_t* grid2;          // RVQ3: the E81B table, int8 [256][8] (4r); else unused
   int K;
   int kp_src;                     // digits per plane in `planes` (K rounded up to 512)
   int segs;                       // 1024-k segments of a row (ceil)
@@ -103,10 +117,12 @@ struct V2Args {
   uint64_t* dbg;
 };
 
-template <int REP1, int REP2, int SLOTS, int G>
+template <int REP1, int REP2, int SLOTS, int G, bool RVQ3 = false>
 __global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using L = V2Lds<REP1, REP2>;
+  using L = V2Lds<REP1, REP2, RVQ3>;
+  using Slot = std::conditional_t<RVQ3, u32x3, u32x4>;
+  constexpr int kUnit = RVQ3 ? 12 : 16;   // bytes of a lane's piece of the code stream (four dwords' worth of codes)
 #define V2_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
   V2_STAMP(0);
   const int tid = threadIdx.x;
@@ -149,6 +165,12 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
     const uint2* t2 = &kV2T2Img.v[e];
     asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(tsrc) : "v"((lane & 32) ? t2 : t1) : "memory");
   }
+  u32x2 tsrc3 = {0u, 0u};   // RVQ3: this lane's E81B entry (requested right behind tsrc: any later wait covers both)
+  if constexpr (RVQ3)
+    asm volatile("global_load_dwordx2 %0, %1, off"
+                 : "=v"(tsrc3)
+                 : "v"(reinterpret_cast<const uint2*>(a.grid2) + ((wave & 7) * 32 + (lane & 31)))
+                 : "memory");
   const uint4* hot = reinterpret_cast<const uint4*>(a.planes[0]) + (tid & 127);   // L2-resident filler for past-the-end slots
   // digit images, requested BEFORE the weights (loads return in issue order; with the weights first -- HBM requests a
   // few hundred instructions earlier -- every shape measured slower: the digit copy then waits for the first HBM
@@ -215,7 +237,7 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
   int l_gq = 0, l_seg = 0, l_left = 0;
   // The run's per-lane source pointer and per-run constants are computed when a run is opened; a unit then costs
   // one 64-bit add (the per-unit address arithmetic was a third of the VALU instructions of the stream).
-  const uint4* l_ptr = hot;           // this lane's 16 bytes of the run's next unit
+  const char* l_ptr = reinterpret_cast<const char*>(hot);   // this lane's kUnit bytes of the run's next unit
   int l_mgq = 0, l_xoff = 0;          // accumulator row quad / digit image offset of the run's next unit
   const bool ragged = (a.K & 1023) != 0;   // the row's last segment is partial: lanes past the row re-read a valid
                                            // piece (their digits are zero)
@@ -241,28 +263,28 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
       W = p == i ? a.W[i] : W;
       asm volatile("" : "+s"(W));
     }
-    l_ptr = W + (size_t)row * row_u4 + (seg0 + l_seg) * 16 + 4 * h + q;
+    l_ptr = reinterpret_cast<const char*>(W) + ((size_t)row * row_u4 + (seg0 + l_seg) * 16 + 4 * h + q) * kUnit;
     l_mgq = (pick(rbase, p) >> 2) + (l_gq - qb);
     l_xoff = __builtin_amdgcn_readfirstlane((p * S + l_seg) * kSegBytes);
   };
   open_run(wave);
   // per-slot description of the unit in flight: accumulator row quad, digit image offset, flags
   int s_gq[SLOTS], s_x[SLOTS], s_flag[SLOTS];   // flag: 0 filler, 1 unit, 3 unit that ends its run
-  auto issue = [&](u32x4& dst, int& m_gq, int& m_x, int& m_flag) __attribute__((always_inline)) {
+  auto issue = [&](Slot& dst, int& m_gq, int& m_x, int& m_flag) __attribute__((always_inline)) {
     const bool real = l_left > 0;   // wave uniform
-    const uint4* ptr = real ? l_ptr : hot;
+    const char* ptr = real ? l_ptr : reinterpret_cast<const char*>(hot);
     if (ragged && real && seg0 + l_seg == a.segs - 1) {   // wave uniform condition
       const int off = (seg0 + l_seg) * 16 + 4 * h + q;
-      ptr = off < row_u4 ? ptr : ptr - (4 * h + q);
+      ptr = off < row_u4 ? ptr : ptr - (4 * h + q) * kUnit;
     }
-    asm_load16_nt(dst, ptr);
+    asm_load16_nt(dst, reinterpret_cast<const uint4*>(ptr));
     m_gq = l_mgq;
     m_x = l_xoff;
     m_flag = real ? (l_left == 1 ? 3 : 1) : 0;
     if (real) {
       ++l_seg;
       --l_left;
-      l_ptr += 16;
+      l_ptr += 16 * kUnit;
       l_xoff += kSegBytes;
     }
   };
@@ -275,7 +297,7 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
       open_run(__builtin_amdgcn_readfirstlane(nxt) + nwaves);
     }
   };
-  u32x4 slot[SLOTS];
+  Slot slot[SLOTS];
   // (no refill here: the run counter does not exist yet; a first run shorter than SLOTS leaves filler slots)
 #pragma unroll
   for (int i = 0; i < SLOTS; ++i) issue(slot[i], s_gq[i], s_x[i], s_flag[i]);
@@ -298,6 +320,19 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
       if (c < (second ? REP2 : REP1)) {
         const uint32_t copy = (uint32_t)(lane + c) & mask;
         *reinterpret_cast<__attribute__((address_space(3))) u32x2*>((uintptr_t)(rowbase + copy * 8)) = val;
+      }
+    }
+  }
+  if constexpr (RVQ3) {
+    // T3 row 32 w + (l & 31) from this lane's E81B entry; lanes l and l + 32 share a row and write the even / odd
+    // halves of its 16 copies
+    asm volatile("" : "+v"(tsrc3));   // landed with tsrc (requested right behind it, before anything waited for)
+    if (wave < 8) {
+      const uint32_t rowbase = (uint32_t)L::kT3 + (uint32_t)(wave * 32 + (lane & 31)) * (L::kRep3 * 8);
+#pragma unroll
+      for (int c = 0; c < L::kRep3 / 2; ++c) {
+        const uint32_t copy = ((uint32_t)(lane + c) & (uint32_t)(L::kRep3 / 2 - 1)) * 2 + (uint32_t)(lane >> 5);
+        *reinterpret_cast<__attribute__((address_space(3))) u32x2*>((uintptr_t)(rowbase + copy * 8)) = tsrc3;
       }
     }
   }
@@ -325,6 +360,7 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
   if constexpr (REP1 == 32) lane_c1 = ((uint32_t)(lane & 31) << 3) | ((uint32_t)(L::kT2 >> 16) << 16);
   else lane_c1 = (uint32_t)(lane & 15) << 3;
   lane_c2 = ((uint32_t)(lane & 15) << 3) | (uint32_t)L::kT2;
+  const uint32_t lane_c3 = ((uint32_t)(lane & 15) << 3) | (uint32_t)L::kT3;
   // A fragment of this lane (A row m = lane & 15 = 4 h' + d', k block q): unit (q * 4 + t) * 12 + 3 h' + min(d', 2)
   const uint32_t xlane = xbase + (uint32_t)((q * 48 + 3 * (n >> 2) + min(n & 3, 2)) * 16);
   const bool dvalid = q == h;      // this lane's D registers 0..2 = S_h, S_m, S_l of row r over chunk group h
@@ -338,7 +374,8 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
     for (int i = 0; i < SLOTS; ++i) {
       asm volatile("s_waitcnt vmcnt(%1)" : "+v"(slot[i]) : "n"(SLOTS - 1) : "memory");
       uint32_t a1l[4], a2l[4], a1h[4], a2h[4];
-      const uint32_t dw[4] = {slot[i].x, slot[i].y, slot[i].z, slot[i].w};
+      const u32x4 dq = v2_rvq3_dwords(slot[i]);
+      const uint32_t dw[4] = {dq.x, dq.y, dq.z, dq.w};
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         if constexpr (REP1 == 32) {
@@ -348,6 +385,11 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
         } else {
           a1l[t] = ((dw[t] >> 1) & 0x7f80u) | lane_c1;
           a1h[t] = ((dw[t] >> 17) & 0x7f80u) | lane_c1;
+        }
+        if constexpr (RVQ3) {
+          // the low code of the dword is (residual index << 8 | 0) and reads T3 (E81B); its sign byte is 0 and
+          // T2[0] == 0, so the common "T1 ^ T2" below leaves the T3 entry unchanged
+          a1l[t] = ((dw[t] >> 1) & 0x7f80u) | lane_c3;
         }
         if constexpr (REP1 == 32 && REP2 == 32) {
           // T2 base 0x10000 comes from byte 2 of lane_c1
@@ -459,17 +501,20 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
 #undef V2_STAMP
 }
 
-template <int REP1, int REP2, int SLOTS, int G>
+template <int REP1, int REP2, int SLOTS, int G, bool RVQ3 = false>
 int v2_launch(const V2Args& a, int nblocks, int threads, int lds, hipStream_t stream) {
-  auto kern = e8p_gemv_v2_kernel<REP1, REP2, SLOTS, G>;
+  auto kern = e8p_gemv_v2_kernel<REP1, REP2, SLOTS, G, RVQ3>;
   static DynLdsCache configured;   // per instantiation, per device
   if (ensure_dyn_lds(configured, reinterpret_cast<const void*>(kern), lds) != QUIP_OK) return QUIP_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(threads), lds, stream, a);
   return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
 }
 
-// rep code: 32 = (32, 32) copies, 24 = (32, 16), 16 = (16, 16)
-static int lds_x(int rep) { return rep == 32 ? V2Lds<32, 32>::kX : (rep == 24 ? V2Lds<32, 16>::kX : V2Lds<16, 16>::kX); }
+// rep code: 32 = (32, 32) copies, 24 = (32, 16), 16 = (16, 16); 40 = E8P12RVQ3B: (32, 16) + T3 x 16
+static int lds_x(int rep) {
+  if (rep == 40) return V2Lds<32, 16, true>::kX;
+  return rep == 32 ? V2Lds<32, 32>::kX : (rep == 24 ? V2Lds<32, 16>::kX : V2Lds<16, 16>::kX);
+}
 
 template <int G>
 int v2_group_launch(const void* const* planes, const void* const* qidxs, const void* grid, void* const* ys,
@@ -510,7 +555,11 @@ int v2_group_launch(const void* const* planes, const void* const* qidxs, const v
     }
     return true;
   };
-  if (tune.rep || tune.waves_g) {
+  if (tune.rep == 40) {            // E8P12RVQ3B: one table configuration
+    if (G != 1 || !tune.grid2) return QUIP_ERR_UNSUPPORTED;
+    for (int ks = 1; ks <= segs; ++ks)
+      if (consider(40, ks)) break;
+  } else if (tune.rep || tune.waves_g) {
     const int rp = tune.rep ? tune.rep : 32;
     for (int ks = tune.waves_g > 0 ? tune.waves_g : 1; ks <= segs; ++ks)
       if (consider(rp, ks)) break;
@@ -541,6 +590,7 @@ int v2_group_launch(const void* const* planes, const void* const* qidxs, const v
     }
   }
   a.grid = reinterpret_cast<const uint64_t*>(grid);
+  a.grid2 = reinterpret_cast<const uint64_t*>(tune.grid2);
   a.K = k;
   a.kp_src = (k + 511) & ~511;
   a.segs = segs; a.spw = spw; a.ksplit = ksplit;
@@ -560,6 +610,8 @@ int v2_group_launch(const void* const* planes, const void* const* qidxs, const v
   const int threads = waves * 64;
   const int lds = lds_x(rep) + G * spw * kSegBytes + rows * 16 + 16;
   const int nblocks = nrb * ksplit;
+  if constexpr (G == 1)
+    if (rep == 40) return v2_launch<32, 16, 2, 1, true>(a, nblocks, threads, lds, stream);
 #define QUIP_V2(R1, R2, RR, S) \
   if (rep == RR && slots == S) return v2_launch<R1, R2, S, G>(a, nblocks, threads, lds, stream);
   QUIP_V2(32, 32, 32, 1) QUIP_V2(32, 32, 32, 2) QUIP_V2(32, 32, 32, 3) QUIP_V2(32, 32, 32, 4)

@@ -272,10 +272,12 @@ def _e8prvq3_gemv_planes_group_cuda(planes, Qidxs, grid, e81b_i8):
     outs = [torch.empty((1, q.shape[0]), dtype=torch.float16, device=dev) for q in Qidxs]
     vp = ctypes.c_void_p * count
     ns = (ctypes.c_int32 * count)(*[q.shape[0] for q in Qidxs])
+    ws = _gemv_workspace(dev, sum(q.shape[0] for q in Qidxs))
     with torch.cuda.device(dev):
-        capi.check(capi.lib().quip_e8prvq3_gemv_planes_group(
+        capi.check(capi.lib().quip_e8prvq3_gemv_planes_group_ws(
             vp(*[p.data_ptr() for p in planes]), vp(*[q.data_ptr() for q in Qidxs]), g.data_ptr(), e81b_i8.data_ptr(),
-            vp(*[o.data_ptr() for o in outs]), ns, count, k, _stream(planes[0])), "quip_e8prvq3_gemv_planes_group")
+            vp(*[o.data_ptr() for o in outs]), ns, count, k, ws.data_ptr(), ws.numel() * 4, _stream(planes[0])),
+            "quip_e8prvq3_gemv_planes_group_ws")
     return outs
 
 
@@ -388,6 +390,9 @@ def _gemv_planes_rows_mode_cuda(planes, Qidxs, grid, grid2, mode):
               "grid2 must be the contiguous int8 (256, 8) E81B table")
     rows = planes.shape[0]
     per = L.quip_gemv_max_rows_mode(n, k, mode)
+    if per < 1 and mode == 40:
+        # virtual rows longer than rows mode holds in LDS (70B down_proj): one bs=1 launch per row (K-splitting kernel)
+        return torch.cat([_e8prvq3_gemv_planes_group_cuda([planes[r]], [Qidxs], grid, grid2)[0] for r in range(rows)])
     _need(per >= 1, "shape not supported by the matrix-core GEMV")
     out = torch.empty((rows, n), dtype=torch.float16, device=Qidxs.device)
     with torch.cuda.device(Qidxs.device):

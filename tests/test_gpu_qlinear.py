@@ -127,13 +127,14 @@ def test_full_size_70b_rows_via_properties():
         assert ((y1.float() + y2.float()) - ys).abs().max() <= 2 ** -8 * ys.abs().max()
 
 
-@pytest.mark.parametrize("fin,fout,M", [(28672, 512, 1), (28672, 512, 2), (16384, 256, 1)])
-def test_rvq4_rows_longer_than_28672_on_matrix_core_path(fin, fout, M):
-    """E8P12RVQ4B at Llama-2-70B's down_proj width: the 2k = 57344-wide virtual row is beyond the first GEMV
-    kernel's LDS budget and is taken by the K-splitting kernel (csrc/e8p_gemv_v2.hip) through the op's dispatcher --
-    module forward against the oracle, rows bit identical to bs=1"""
+@pytest.mark.parametrize("cbid", ["E8P12RVQ4B", "E8P12RVQ3B"])
+@pytest.mark.parametrize("fin,fout,M", [(28672, 512, 1), (28672, 512, 2), (16384, 256, 1), (14336, 1000, 1)])
+def test_rvq_rows_longer_than_28672_on_matrix_core_path(cbid, fin, fout, M):
+    """E8P12RVQ4B / RVQ3B at Llama-2-70B's down_proj width: the 2k = 57344-wide virtual row is beyond the first GEMV
+    kernel's LDS budget and is taken by the K-splitting kernel (csrc/e8p_gemv_v2.hip; RVQ3: its third-table mode on
+    the 3-byte codes) -- module forward against the oracle, rows bit identical to bs=1"""
     import quip_for_all_amd as Q
-    P = O.make_layer("E8P12RVQ4B", fin, fout, seed=fin + fout)
+    P = O.make_layer(cbid, fin, fout, seed=fin + fout)
     layer = _layer(P)
     assert layer.codebook.planes_supported(layer.q_out_features, layer.q_in_features)
     x = np.random.default_rng(M).standard_normal((M, fin)).astype(np.float16)
