@@ -25,9 +25,10 @@
 // Workgroup -> tile: blocks are dealt to the XCDs round robin (b % 8); an XCD walks the column tiles of one row tile
 // before moving to the next row tile, so the 32 workgroups resident on an XCD share two X slabs in its L2.
 //
-// Bound: MFMA (2 M N K flops at the dense fp16 peak).  LDS: 2 x 32 KiB tables (16 copies: two-way conflicts) +
-// 3 x 32 KiB X tiles (prefetch distance 2, counted vmcnt + raw s_barrier: with one tile in flight the HBM / L2
-// latency of the X stream was exposed every K step).
+// Bound: MFMA (2 M N K flops at the dense fp16 peak).  LDS: 2 x 16 KiB tables (8 copies) + 4 x 32 KiB X tiles
+// (one multiplied, one landed, two in flight: counted vmcnt + raw s_barrier).  Measured: three tiles with 16 table
+// copies (tile t + 1 awaited one tile time after its request) and this layout (two tile times) run at the same
+// rate, i.e. the K loop does not wait on memory; halving the A-fragment LDS reads (experiment) changed 2-3 %.
 #include <type_traits>
 
 #include "quip_device.hip.h"
@@ -43,12 +44,12 @@ typedef uint32_t pu32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t pu32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBM = 256, kBN = 256, kBK = 64;
-constexpr int kRep = 16;
+constexpr int kRep = 8;
 constexpr int kT1 = 0;
-constexpr int kT2 = 256 * kRep * 8;          // 32 KiB
-constexpr int kA = 2 * kT2;                  // 64 KiB; behind it the X tiles of 32 KiB
+constexpr int kT2 = 256 * kRep * 8;          // 16 KiB
+constexpr int kA = 2 * kT2;                  // 32 KiB; behind it the X tiles of 32 KiB
 constexpr int kTileBytes = kBM * kBK * 2;
-constexpr int kStages = 3;                   // X tiles in LDS: two in flight while one is multiplied
+constexpr int kStages = 4;                   // X tiles in LDS: one multiplied, one landed, two in flight
 constexpr int kLds = kA + kStages * kTileBytes;   // 160 KiB
 
 // sign table image (same statement as the GEMV's: 4w = T1[abs] ^ T2[sign] byte-wise, origin_order.cu:211-253)
@@ -132,16 +133,27 @@ __global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __r
     asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(wsrc + (size_t)t * (kBK / 8)) : "memory");
   };
 
-  // prefetch distance 2: tiles 0 and 1 are requested here, tile t + 2 at the top of iteration t.  Per tile and wave:
-  // one code load + four LDS-DMA instructions = 5 VMEM operations.
-  pu32x2 cq[kStages];
+  // tiles 0, 1 and 2 are requested here, tile t + 3 in the middle of tile t.  Per tile and wave: one code load + four
+  // LDS-DMA instructions = 5 VMEM operations.
+  // cq[]: registers the code loads write (in flight); cv[]: the codes of the current / next tile, taken over by an
+  // asm that waits and then moves them (a register in flight is never a tied operand: the compiler may copy a tied
+  // operand ahead of the asm, i.e. ahead of the wait -- see e8p_skinny_gemm.hip)
+  pu32x2 cq[kStages], cv[2];
   load_codes(cq[0], 0);
   issue_x(0, 0);
   load_codes(cq[1], min(1, KT - 1));      // (past the end: tile KT - 1 again -- the queue depth stays constant, so
   issue_x(min(1, KT - 1), 1);             //  every wait below is the same counted wait, with no branch around it)
+  load_codes(cq[2], min(2, KT - 1));
+  issue_x(min(2, KT - 1), 2);
+  auto take = [](pu32x2& dst, const pu32x2& src, auto nw) {
+    asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
+                 : "=&v"(dst.x), "=&v"(dst.y)
+                 : "v"(src.x), "v"(src.y), "n"(decltype(nw)::value)
+                 : "memory");
+  };
 
   // ---- tables: T1' = (4a | 1) ^ 0x80.. (the ^0x80 turns 4w into the unsigned byte 4w + 128 the fp16 conversion
-  // wants), T2 = sign masks; 16 copies each, copy (lane + c) & 15 at step c
+  // wants), T2 = sign masks; kRep copies each, copy (lane + c) & (kRep - 1) at step c
   {
     const int e = wave * 32 + (lane & 31);
     const bool second = (lane & 32) != 0;
@@ -156,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __r
       *reinterpret_cast<__attribute__((address_space(3))) pu32x2*>((uintptr_t)(rowbase + copy * 8)) = val;
     }
   }
-  const uint32_t lane_c1 = (uint32_t)(lane & 15) << 3;
+  const uint32_t lane_c1 = (uint32_t)(lane & (kRep - 1)) << 3;
   const uint32_t lane_c2 = lane_c1 | (uint32_t)kT2;
   // A fragment address of this lane for k step j (without tile base / row block): row m = lane & 31
   const int m = lane & 31;
@@ -182,11 +194,11 @@ __global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __r
   auto request = [&](uint32_t d, bool hi, uint32_t aj, pu32x2 (&tt)[2], pu32x4 (&A8)[8]) {
     uint32_t a1, a2;
     if (hi) {
-      a1 = ((d >> 17) & 0x7f80u) | lane_c1;
-      a2 = ((d >> 9) & 0x7f80u) | lane_c2;
+      a1 = ((d >> 18) & 0x3fc0u) | lane_c1;      // entry row = 8 copies x 8 bytes
+      a2 = ((d >> 10) & 0x3fc0u) | lane_c2;
     } else {
-      a1 = ((d >> 1) & 0x7f80u) | lane_c1;
-      a2 = ((d << 7) & 0x7f80u) | lane_c2;
+      a1 = ((d >> 2) & 0x3fc0u) | lane_c1;
+      a2 = ((d << 6) & 0x3fc0u) | lane_c2;
     }
     asm volatile("ds_read_b64 %0, %1" : "=v"(tt[0]) : "v"(a1));
     asm volatile("ds_read_b64 %0, %1" : "=v"(tt[1]) : "v"(a2));
@@ -206,27 +218,27 @@ __global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __r
     return __builtin_bit_cast(f16x8v, pu32x4{w0, w1, w2, w3});
   };
   // tiles 0 and 1 (and the tables) are in LDS; first step's operands
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(cq[0]), "+v"(cq[1]) : : "memory");
+  take(cv[0], cq[0], std::integral_constant<int, 0>{});   // (everything requested so far has landed)
   __syncthreads();
-  request(cq[0].x, false, (uint32_t)kA + aoff[0], tl[0], Af[0]);
+  request(cv[0].x, false, (uint32_t)kA + aoff[0], tl[0], Af[0]);
   asm volatile("s_waitcnt lgkmcnt(0)"
                : "+v"(tl[0][0]), "+v"(tl[0][1]), "+v"(Af[0][0]), "+v"(Af[0][1]), "+v"(Af[0][2]), "+v"(Af[0][3]),
                  "+v"(Af[0][4]), "+v"(Af[0][5]), "+v"(Af[0][6]), "+v"(Af[0][7]));
   f16x8v B = frag_b(tl[0]);
 
-  // one tile: `st` = t % 3 (its buffer / code register), compile-time through the 3x unrolled loop
+  // one tile: `st` = t % 4 (its buffer / code register), compile-time through the 4x unrolled loop
   auto tile = [&](int t, auto stc) {
     constexpr int st = decltype(stc)::value;
-    constexpr int st1 = (st + 1) % kStages, st2 = (st + 2) % kStages;
+    constexpr int st1 = (st + 1) % kStages, st3 = (st + 3) % kStages, cur = st & 1, nxt = cur ^ 1;
     const uint32_t abase = (uint32_t)(kA + st * kTileBytes);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = j & 1, nx = c ^ 1;
       // operands of the next step: step j + 1 of this tile, or step 0 of the next one
       if (j < 3)
-        request(j + 1 < 2 ? cq[st].x : cq[st].y, ((j + 1) & 1) != 0, abase + aoff[j + 1], tl[nx], Af[nx]);
+        request(j + 1 < 2 ? cv[cur].x : cv[cur].y, ((j + 1) & 1) != 0, abase + aoff[j + 1], tl[nx], Af[nx]);
       else
-        request(cq[st1].x, false, (uint32_t)(kA + st1 * kTileBytes) + aoff[0], tl[nx], Af[nx]);
+        request(cv[nxt].x, false, (uint32_t)(kA + st1 * kTileBytes) + aoff[0], tl[nx], Af[nx]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int b = 0; b < 4; ++b)
@@ -244,12 +256,13 @@ __global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __r
                      "+v"(Af[nx][5]), "+v"(Af[nx][6]), "+v"(Af[nx][7]));
       B = Bn;
       if (j == 1) {
-        // middle of the tile: tile t + 1 (requested in the middle of tile t - 1) has landed everywhere; tile t - 1 is
-        // dead, its buffer takes tile t + 2 (past the end: tile KT - 1 again, harmless, keeps the code uniform)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(cq[st1]) : : "memory");
+        // middle of the tile: tile t + 1 (requested in the middle of tile t - 2: two tile times ago) has landed
+        // everywhere -- the 5 operations of tile t + 2 may still be in flight; tile t - 1 is dead, its buffer takes
+        // tile t + 3 (past the end: tile KT - 1 again, harmless, keeps the code uniform)
+        take(cv[nxt], cq[st1], std::integral_constant<int, 5>{});
         __builtin_amdgcn_s_barrier();
-        load_codes(cq[st2], min(t + 2, KT - 1));
-        issue_x(min(t + 2, KT - 1), st2);
+        load_codes(cq[st3], min(t + 3, KT - 1));
+        issue_x(min(t + 3, KT - 1), st3);
       }
     }
   };
@@ -257,6 +270,7 @@ __global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __r
     tile(t, std::integral_constant<int, 0>{});
     if (t + 1 < KT) tile(t + 1, std::integral_constant<int, 1>{});
     if (t + 2 < KT) tile(t + 2, std::integral_constant<int, 2>{});
+    if (t + 3 < KT) tile(t + 3, std::integral_constant<int, 3>{});
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing filler tile
   // ---- epilogue: D row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the 32-row block, column = lane & 31.  Neighbour
