@@ -38,7 +38,7 @@ with open(f"{R}/gpurun_out/{tag}_bench_fetch_size.txt", "w") as f:
         gsum = gcnt = 0
         for name, n, s, avg in rows[:30]:
             print("%-100s %8d %16.1f %16.2f" % (name[:100], n, s, avg), file=f)
-            if "e8p_gemv_mfma_kernel" in name:
+            if "e8p_gemv_mfma_kernel" in name or "e8p_gemv_v2_kernel" in name:
                 gsum += s; gcnt += n
         if gcnt:
             raw = gsum / gcnt
@@ -46,9 +46,11 @@ with open(f"{R}/gpurun_out/{tag}_bench_fetch_size.txt", "w") as f:
             # 16 B/lane streaming read at 64 B: double it (MI355X_MICROARCH.md, HBM section)
             j = {"counter": "FETCH_SIZE", "raw_mean_per_launch": raw, "unit_assumed": "KB", "gfx950_correction": 2.0,
                  "hbm_bytes_per_launch": raw * 1024 * 2.0, "gemv_dispatches": gcnt,
+                 "kernels": "e8p_gemv_mfma_kernel + e8p_gemv_v2_kernel dispatches of the run",
+                 "measured_at": "round 2 (%s), tools/prof_bench.sh %s" % (tag, "$*"),
                  "source": "rocprofv3 --pmc FETCH_SIZE pass of bench.py, tools/prof_bench.sh"}
             print("# GEMV:", json.dumps(j), file=f)
-            json.dump(j, open(f"{R}/gpurun_out/gemv_hbm_traffic.json", "w"))
+            json.dump(j, open(f"{R}/gpurun_out/{tag}_gemv_hbm_traffic.json", "w"))
 PY
 head -30 $R/gpurun_out/${tag}_bench_kernel_trace.txt | cut -c1-200
 cat $R/gpurun_out/${tag}_bench_fetch_size.txt | cut -c1-200 | head -20
