@@ -77,11 +77,13 @@ int quip_hadamard(const void* x, void* y, int64_t rows, int32_t n, float scale, 
 int quip_e8p_mm_origorder(const void* x, const void* qidxs /* int16 (n, k/8) */,
                           const void* grid_packed_abs /* int64[256] */, void* y,
                           int32_t m, int32_t n, int32_t k, quip_stream_t stream);
-/* Skinny E8P12 product, 1 <= m <= 32 rows in ONE pass over the codes (the 1 < M < 32 use of the reference's
+/* Skinny E8P12 product, up to 32 rows in ONE pass over the codes (the 1 < M < 32 use of the reference's
  * tinygemm_m16n8k16_chunk_kernel, origin_order.cu:388-555; e8p12.py:147-150) with the reference's arithmetic: fp16
- * activations x exact fp16 weights, fp32 accumulation on the matrix cores, one fp16 rounding.  Not bit identical to the
- * exact integer path of quip_e8p_mm_origorder_ws / quip_e8p_gemv_planes_rows (which stays available); a row's result
- * does not depend on the other rows of the batch.  k % 128 == 0, n % 2 == 0, else QUIP_ERR_UNSUPPORTED. */
+ * activations x exact fp16 weights, fp32 accumulation on the matrix cores, one fp16 rounding.  m > 32: chunks of 32
+ * rows in the same launch (one pass over the codes per chunk; faster than quip_e8p_mm_batched up to m * n of about
+ * 3.5e6).  Not bit identical to the exact integer path of quip_e8p_mm_origorder_ws / quip_e8p_gemv_planes_rows (which
+ * stays available); a row's result does not depend on the other rows of the batch.  k % 128 == 0, n % 2 == 0, else
+ * QUIP_ERR_UNSUPPORTED. */
 int quip_e8p_mm_skinny(const void* x, const void* qidxs /* int16 (n, k/8) */, const void* grid_packed_abs, void* y,
                        int32_t m, int32_t n, int32_t k, quip_stream_t stream);
 /* Batched E8P12 product for M >= 32 (prompt prefill): fused dequant + MFMA GEMM, y (m, n) = x (m, k) @ W^T with

@@ -83,6 +83,12 @@ class E8P12_codebook(_Codebook):
             return self.mm(input, Qidxs)
         if (self.fused_batched and input.is_cuda and input.dtype == torch.float16 and input.dim() == 2
                 and Qidxs.shape[0] % 2 == 0 and input.shape[1] % 64 == 0):
+            m, n = input.shape[0], Qidxs.shape[0]
+            # up to about a thousand rows the single-pass skinny kernel on chunks of 32 rows (many small workgroups,
+            # a few microseconds each) beats the 256 x 256-tile GEMM, whose K loop alone takes 110-260 us however few
+            # tiles there are (tools/midm_bench.py: 4096 x 4096 at M = 64: 11 vs 106 us; crossover M n ~ 3.5e6)
+            if m * n <= self.skinny_chunks_max_mn and self.skinny_supported(m, n, input.shape[1]):
+                return torch.ops.quip_lib.e8p_mm_skinny(input, Qidxs, self.grid_packed_abs)
             return torch.ops.quip_lib.e8p_mm_batched(input, Qidxs, self.grid_packed_abs)
         W = self.decompress_weight(Qidxs)
         return input @ W.T
@@ -117,10 +123,13 @@ class E8P12_codebook(_Codebook):
         """skinny product: planes (M, planes_bytes) -> (M, n), passes of up to 5 rows over the codes"""
         return torch.ops.quip_lib.e8p_gemv_planes_rows(planes, Qidxs, self.grid_packed_abs)
 
+    skinny_chunks_max_mn = int(os.environ.get("QUIP_SKINNY_MAX_MN", str(3_500_000)))
+
     @staticmethod
     def skinny_supported(m, q_out, q_in):
-        """shapes the single-pass fp16 skinny product takes (csrc/e8p_skinny_gemm.hip)"""
-        return 1 <= m <= 32 and q_out % 2 == 0 and q_in % 128 == 0 and q_in >= 128
+        """shapes the single-pass fp16 skinny product takes (csrc/e8p_skinny_gemm.hip; rows beyond 32: chunks of 32
+        in one launch)"""
+        return m >= 1 and q_out % 2 == 0 and q_in % 128 == 0 and q_in >= 128
 
     def mm_skinny(self, xh, Qidxs):
         """(M <= 32, k) fp16 (already input-transformed) -> (M, n): one pass over the codes, fp16 MFMA"""

@@ -99,9 +99,16 @@ __global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __r
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
-  const int mt = (idx / NT) * 8 + xcd, nt = idx - (idx / NT) * NT;
-  if (mt >= MT) return;
+  int mt, nt;
+  if (MT >= 8) {
+    const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+    mt = (idx / NT) * 8 + xcd;
+    nt = idx - (idx / NT) * NT;
+    if (mt >= MT) return;
+  } else {   // fewer row tiles than XCDs: plain order (the XCD-aware one would leave 8 - MT XCDs idle)
+    mt = (int)blockIdx.x % MT;
+    nt = (int)blockIdx.x / MT;
+  }
   const int m0 = mt * kBM, n0 = nt * kBN;
   const int KT = K / kBK;
 
@@ -307,7 +314,7 @@ int e8p_prefill_gemm_launch(const void* x, const void* qidxs, const void* grid, 
                             hipStream_t stream) {
   if (!e8p_prefill_gemm_supported(m, n, k)) return QUIP_ERR_UNSUPPORTED;
   const int MT = (int)((m + kBM - 1) / kBM), NT = (n + kBN - 1) / kBN;
-  const int64_t blocks = (int64_t)((MT + 7) / 8) * NT * 8;
+  const int64_t blocks = MT >= 8 ? (int64_t)((MT + 7) / 8) * NT * 8 : (int64_t)MT * NT;
   if (blocks > 0x7fffffff) return QUIP_ERR_UNSUPPORTED;
   static DynLdsCache configured;   // per device
   if (ensure_dyn_lds(configured, reinterpret_cast<const void*>(e8p_prefill_gemm_kernel), kLds) != QUIP_OK)

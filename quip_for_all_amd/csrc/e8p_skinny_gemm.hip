@@ -99,6 +99,11 @@ __global__ __launch_bounds__(1024) void e8p_skinny_gemm_kernel(const f16* __rest
                                                                const uint64_t* __restrict__ grid,
                                                                f16* __restrict__ Y, int M, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // more than 32 rows: grid.y walks over chunks of 32 rows (each workgroup streams its columns' codes again; the
+  // chunks of one column block run side by side and share them in L2)
+  X += (size_t)blockIdx.y * 32 * K;
+  Y += (size_t)blockIdx.y * 32 * N;
+  M = min(32, M - (int)blockIdx.y * 32);
   constexpr int NKS = 16 / CB;
   constexpr int L = MP / 16;                 // load instructions per granule
   constexpr int kGran = MP * 64;             // bytes of a granule: MP rows x 32 k
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(1024) void e8p_skinny_gemm_kernel(const f16* __rest
 }  // namespace
 
 bool e8p_skinny_gemm_supported(int m, int n, int k) {
-  return m >= 1 && m <= 32 && n >= 2 && n % 2 == 0 && k >= 128 && k % 128 == 0;
+  return m >= 1 && m <= 32 * 65535 && n >= 2 && n % 2 == 0 && k >= 128 && k % 128 == 0;
 }
 
 int e8p_skinny_gemm_launch(const void* x, const void* qidxs, const void* grid, void* y, int m, int n, int k,
@@ -294,11 +299,14 @@ int e8p_skinny_gemm_launch(const void* x, const void* qidxs, const void* grid, v
   if (!e8p_skinny_gemm_supported(m, n, k)) return QUIP_ERR_UNSUPPORTED;
   // few columns: one column block of 32 per workgroup and 16 slices of K (more workgroups, shorter chains per wave);
   // many columns: two column blocks x 8 slices
+  // (a function of n alone: the K slicing fixes the order of the fp32 sums, and a row's result must not depend on
+  //  how many rows the launch has)
   const bool one = (n + 63) / 64 < 2 * device_cu_count() / 3;
   auto go = [&](auto kern, int cols, int slot) -> int {
     static DynLdsCache configured[4];   // per instantiation, per device
     if (ensure_dyn_lds(configured[slot], reinterpret_cast<const void*>(kern), kSLds) != QUIP_OK) return QUIP_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3((n + cols - 1) / cols), dim3(1024), kSLds, stream, reinterpret_cast<const f16*>(x),
+    hipLaunchKernelGGL(kern, dim3((n + cols - 1) / cols, (m + 31) / 32), dim3(1024), kSLds, stream,
+                       reinterpret_cast<const f16*>(x),
                        reinterpret_cast<const uint16_t*>(qidxs), reinterpret_cast<const uint64_t*>(grid),
                        reinterpret_cast<f16*>(y), m, n, k);
     return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;

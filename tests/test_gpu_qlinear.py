@@ -317,9 +317,9 @@ def test_skinny_rows_on_matrix_core_path(fin, fout, M, cbid="E8P12"):
 
 @pytest.mark.parametrize("fin,fout", [(4096, 4096), (4096, 11008), (11008, 4096), (8192, 8192), (8192, 28672),
                                       (28672, 8192), (256, 688), (1408, 512)])
-@pytest.mark.parametrize("M", [6, 16, 31, 32])
+@pytest.mark.parametrize("M", [6, 16, 31, 32, 33, 100, 257])
 def test_single_pass_skinny_kernel(fin, fout, M):
-    """6 <= M <= 32 rows through the fp16-MFMA skinny product (csrc/e8p_skinny_gemm.hip; the 1 < M < 32 use of the
+    """6 <= M <= 32 rows (and more: chunks of 32 in one launch) through the fp16-MFMA skinny product (csrc/e8p_skinny_gemm.hip; the 1 < M < 32 use of the
     reference's tinygemm kernel, origin_order.cu:388-555): the op against the float64 product of the same fp16
     operands (one fp16 rounding + fp32 accumulation), the module inside the stated ulp bound, and a row's result
     independent of the batch it sits in"""
@@ -340,6 +340,9 @@ def test_single_pass_skinny_kernel(fin, fout, M):
     assert np.all(np.abs(z.cpu().numpy().astype(np.float64) - z64) <= tol)
     z2 = torch.ops.quip_lib.e8p_mm_skinny(xh[3:3 + 2].contiguous(), layer.Qidxs, cb.grid_packed_abs)
     assert torch.equal(z[3:5], z2), "a row's result does not depend on the other rows"
+    if M > 40:   # ... nor on the chunk it falls into
+        z3 = torch.ops.quip_lib.e8p_mm_skinny(xh[M - 7:].contiguous(), layer.Qidxs, cb.grid_packed_abs)
+        assert torch.equal(z[M - 7:], z3)
     if M < 32:
         x = torch.from_numpy(rng.standard_normal((M, fin)).astype(np.float16)).to(DEV)
         with torch.no_grad():
