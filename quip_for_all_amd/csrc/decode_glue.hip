@@ -71,7 +71,11 @@ __device__ __forceinline__ void rope8(const f16* vec, const float c8[8], const f
   unpack8h(*reinterpret_cast<const uint4*>(vec + dp), b);
   const float sgn = d0 < HD / 2 ? -1.f : 1.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) o[i] = (float)(f16)(a[i] * c8[i] + sgn * b[i] * s8[i]);
+  // x * cos + rot * sin with every operation rounded on its own, as the eager graph does (and so that the two
+  // instantiations of the kernel cannot contract the expression differently: an fma in one of them moved single
+  // cache elements by one fp16 ulp)
+  // (had::fmul / fadd: compiled with contraction switched off; __fmul_rn and friends are plain operators to hipcc)
+  for (int i = 0; i < 8; ++i) o[i] = (float)(f16)had::fadd(had::fmul(a[i], c8[i]), had::fmul(sgn * b[i], s8[i]));
 }
 
 template <int HD, bool ZIN>

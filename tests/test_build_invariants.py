@@ -75,15 +75,19 @@ def test_gemv_v2_kernels_use_no_scratch_and_only_counted_loads():
     for kname, body in kernels:
         m = re.match(r".*e8p_gemv_v2_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", kname)
         slots, g = int(m.group(3)), int(m.group(4))
+        rvq3 = "Lb1E" in kname      # the third-table mode: 12-byte slots (dwordx3), a second table source load
         lines = body.splitlines()
-        last_nt = max(i for i, l in enumerate(lines) if "global_load_dwordx4" in l and " nt" in l)
+        wide = "global_load_dwordx3" if rvq3 else "global_load_dwordx4"
+        last_nt = max(i for i, l in enumerate(lines) if wide in l and " nt" in l)
         loads = [l.strip() for l in lines[:last_nt + 1] if re.search(r"\b(global|buffer|scratch|flat)_load", l)]
-        # prologue: G shift words, 1 table entry, up to 6 + 6 digit pieces (filler / real branch), SLOTS weight
-        # loads; stream: SLOTS reloads
+        # prologue: G shift words, 1 table entry (2 with the third table), up to 6 + 6 digit pieces (filler / real
+        # branch), SLOTS weight loads; stream: SLOTS reloads
         assert sum("global_load_dword " in l for l in loads) == g, (kname, loads)
-        assert sum("global_load_dwordx2" in l for l in loads) == 1, kname
+        assert sum("global_load_dwordx2" in l for l in loads) == (2 if rvq3 else 1), kname
         assert sum(" nt" in l for l in loads) == 2 * slots, kname
-        assert all(l.startswith(("global_load_dword ", "global_load_dwordx2", "global_load_dwordx4")) for l in loads)
+        assert all((wide in l) for l in loads if " nt" in l), kname
+        assert all(l.startswith(("global_load_dword ", "global_load_dwordx2", "global_load_dwordx3", "global_load_dwordx4"))
+                   for l in loads)
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
