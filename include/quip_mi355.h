@@ -81,7 +81,7 @@ int quip_e8p_mm_origorder(const void* x, const void* qidxs /* int16 (n, k/8) */,
  * tinygemm_m16n8k16_chunk_kernel, origin_order.cu:388-555; e8p12.py:147-150) with the reference's arithmetic: fp16
  * activations x exact fp16 weights, fp32 accumulation on the matrix cores, one fp16 rounding.  m > 32: chunks of 32
  * rows in the same launch (one pass over the codes per chunk; faster than quip_e8p_mm_batched up to m * n of about
- * 3.5e6).  Not bit identical to the exact integer path of quip_e8p_mm_origorder_ws / quip_e8p_gemv_planes_rows (which
+ * 1.8e6).  Not bit identical to the exact integer path of quip_e8p_mm_origorder_ws / quip_e8p_gemv_planes_rows (which
  * stays available); a row's result does not depend on the other rows of the batch.  k % 128 == 0, n % 2 == 0, else
  * QUIP_ERR_UNSUPPORTED. */
 int quip_e8p_mm_skinny(const void* x, const void* qidxs /* int16 (n, k/8) */, const void* grid_packed_abs, void* y,

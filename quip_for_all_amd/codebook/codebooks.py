@@ -84,9 +84,10 @@ class E8P12_codebook(_Codebook):
         if (self.fused_batched and input.is_cuda and input.dtype == torch.float16 and input.dim() == 2
                 and Qidxs.shape[0] % 2 == 0 and input.shape[1] % 64 == 0):
             m, n = input.shape[0], Qidxs.shape[0]
-            # up to about a thousand rows the single-pass skinny kernel on chunks of 32 rows (many small workgroups,
-            # a few microseconds each) beats the 256 x 256-tile GEMM, whose K loop alone takes 110-260 us however few
-            # tiles there are (tools/midm_bench.py: 4096 x 4096 at M = 64: 11 vs 106 us; crossover M n ~ 3.5e6)
+            # up to a few hundred rows the single-pass skinny kernel on chunks of 32 rows (many small workgroups, a
+            # few microseconds each) beats the tile GEMM, whose K loop alone takes 55 (K = 4096, 128-row tiles) to
+            # 125 us (K = 11008) however few tiles there are (tools/midm_bench.py: 4096 x 4096 at M = 64: 10 vs 55 us,
+            # M = 256: 34 vs 56; crossover M n ~ 1.8e6)
             if m * n <= self.skinny_chunks_max_mn and self.skinny_supported(m, n, input.shape[1]):
                 return torch.ops.quip_lib.e8p_mm_skinny(input, Qidxs, self.grid_packed_abs)
             return torch.ops.quip_lib.e8p_mm_batched(input, Qidxs, self.grid_packed_abs)
@@ -123,7 +124,7 @@ class E8P12_codebook(_Codebook):
         """skinny product: planes (M, planes_bytes) -> (M, n), passes of up to 5 rows over the codes"""
         return torch.ops.quip_lib.e8p_gemv_planes_rows(planes, Qidxs, self.grid_packed_abs)
 
-    skinny_chunks_max_mn = int(os.environ.get("QUIP_SKINNY_MAX_MN", str(3_500_000)))
+    skinny_chunks_max_mn = int(os.environ.get("QUIP_SKINNY_MAX_MN", str(1_800_000)))
 
     @staticmethod
     def skinny_supported(m, q_out, q_in):

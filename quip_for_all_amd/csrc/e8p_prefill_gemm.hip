@@ -29,6 +29,7 @@
 // (one multiplied, one landed, two in flight: counted vmcnt + raw s_barrier).  Measured: three tiles with 16 table
 // copies (tile t + 1 awaited one tile time after its request) and this layout (two tile times) run at the same
 // rate, i.e. the K loop does not wait on memory; halving the A-fragment LDS reads (experiment) changed 2-3 %.
+#include <cstdlib>
 #include <type_traits>
 
 #include "quip_device.hip.h"
@@ -91,6 +92,9 @@ __device__ __forceinline__ void bytes_to_f16x4(uint32_t u4, uint32_t& lo, uint32
   hi = as_u32(as_f16x2(b) + m288);
 }
 
+// NB = row blocks of 32 per wave: 8 (256-row tiles) or 4 (128-row tiles, for launches whose 256-row tiles would not
+// fill the GPU: a few thousand rows against 4096 columns)
+template <int NB>
 __global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __restrict__ X,
                                                                   const uint16_t* __restrict__ Wc,
                                                                   const uint64_t* __restrict__ grid,
@@ -109,14 +113,16 @@ __global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __r
     mt = (int)blockIdx.x % MT;
     nt = (int)blockIdx.x / MT;
   }
-  const int m0 = mt * kBM, n0 = nt * kBN;
+  constexpr int BM = 32 * NB;
+  const int m0 = mt * BM, n0 = nt * kBN;
   const int KT = K / kBK;
 
   // ---- X tile loader (global_load_lds): instruction i of this wave fills LDS slots [(8 i + wave) * 64, +64) of the
   // tile; slot s = (row s >> 3, stored chunk s & 7) holds source chunk (s & 7) ^ ((row >> 1) & 7) of that row
-  const f16* xsrc[4];
+  constexpr int XL = NB / 2;            // loader instructions per wave and tile (8 rows x 128 bytes each)
+  const f16* xsrc[XL];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < XL; ++i) {
     const int row = (8 * i + wave) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
     const int gr = min(m0 + row, M - 1);
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __r
   }
   auto issue_x = [&](int t, int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < XL; ++i)
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(xsrc[i] + (size_t)t * kBK),
           (__attribute__((address_space(3))) void*)(smem + kA + buf * kTileBytes + (8 * i + wave) * 1024), 16, 0, 0);
@@ -183,9 +189,9 @@ __global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __r
 #pragma unroll
   for (int j = 0; j < 4; ++j) aoff[j] = (uint32_t)(m * 128 + (((kb * 4 + j) ^ ((m >> 1) & 7)) << 4));
 
-  f32x16 acc[8];
+  f32x16 acc[NB];
 #pragma unroll
-  for (int b = 0; b < 8; ++b)
+  for (int b = 0; b < NB; ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
 
@@ -197,8 +203,8 @@ __global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __r
   // landed" (vmcnt(0) + barrier), which also says that everybody is done with tile t - 1, whose buffer the loads
   // of tile t + 2 then take.  So step 3 of tile t can already request step 0 of tile t + 1.
   pu32x2 tl[2][2];      // [parity of the step][T1 / T2 entry]
-  pu32x4 Af[2][8];
-  auto request = [&](uint32_t d, bool hi, uint32_t aj, pu32x2 (&tt)[2], pu32x4 (&A8)[8]) {
+  pu32x4 Af[2][NB];
+  auto request = [&](uint32_t d, bool hi, uint32_t aj, pu32x2 (&tt)[2], pu32x4 (&A8)[NB]) {
     uint32_t a1, a2;
     if (hi) {
       a1 = ((d >> 18) & 0x3fc0u) | lane_c1;      // entry row = 8 copies x 8 bytes
@@ -213,10 +219,20 @@ __global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __r
     asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(A8[1]) : "v"(aj));
     asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(A8[2]) : "v"(aj));
     asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(A8[3]) : "v"(aj));
-    asm volatile("ds_read_b128 %0, %1 offset:16384" : "=v"(A8[4]) : "v"(aj));
-    asm volatile("ds_read_b128 %0, %1 offset:20480" : "=v"(A8[5]) : "v"(aj));
-    asm volatile("ds_read_b128 %0, %1 offset:24576" : "=v"(A8[6]) : "v"(aj));
-    asm volatile("ds_read_b128 %0, %1 offset:28672" : "=v"(A8[7]) : "v"(aj));
+    if constexpr (NB == 8) {
+      asm volatile("ds_read_b128 %0, %1 offset:16384" : "=v"(A8[4]) : "v"(aj));
+      asm volatile("ds_read_b128 %0, %1 offset:20480" : "=v"(A8[5]) : "v"(aj));
+      asm volatile("ds_read_b128 %0, %1 offset:24576" : "=v"(A8[6]) : "v"(aj));
+      asm volatile("ds_read_b128 %0, %1 offset:28672" : "=v"(A8[7]) : "v"(aj));
+    }
+  };
+  // all fragment reads of a request have landed
+  auto landed = [&](pu32x4 (&A8)[NB]) {
+    if constexpr (NB == 8)
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(A8[0]), "+v"(A8[1]), "+v"(A8[2]), "+v"(A8[3]), "+v"(A8[4]), "+v"(A8[5]), "+v"(A8[6]), "+v"(A8[7]));
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A8[0]), "+v"(A8[1]), "+v"(A8[2]), "+v"(A8[3]));
   };
   auto frag_b = [&](const pu32x2 (&tt)[2]) -> f16x8v {
     uint32_t w0, w1, w2, w3;
@@ -228,9 +244,8 @@ __global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __r
   take(cv[0], cq[0], std::integral_constant<int, 0>{});   // (everything requested so far has landed)
   __syncthreads();
   request(cv[0].x, false, (uint32_t)kA + aoff[0], tl[0], Af[0]);
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(tl[0][0]), "+v"(tl[0][1]), "+v"(Af[0][0]), "+v"(Af[0][1]), "+v"(Af[0][2]), "+v"(Af[0][3]),
-                 "+v"(Af[0][4]), "+v"(Af[0][5]), "+v"(Af[0][6]), "+v"(Af[0][7]));
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tl[0][0]), "+v"(tl[0][1]));
+  landed(Af[0]);
   f16x8v B = frag_b(tl[0]);
 
   // one tile: `st` = t % 4 (its buffer / code register), compile-time through the 4x unrolled loop
@@ -248,25 +263,23 @@ __global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __r
         request(cv[nxt].x, false, (uint32_t)(kA + st1 * kTileBytes) + aoff[0], tl[nx], Af[nx]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
+      for (int b = 0; b < NB / 2; ++b)
         acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, Af[c][b]), B, acc[b], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(tl[nx][0]), "+v"(tl[nx][1]));
+      asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(tl[nx][0]), "+v"(tl[nx][1]) : "n"(NB));   // the two oldest of 2 + NB
       const f16x8v Bn = frag_b(tl[nx]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int b = 4; b < 8; ++b)
+      for (int b = NB / 2; b < NB; ++b)
         acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, Af[c][b]), B, acc[b], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(Af[nx][0]), "+v"(Af[nx][1]), "+v"(Af[nx][2]), "+v"(Af[nx][3]), "+v"(Af[nx][4]),
-                     "+v"(Af[nx][5]), "+v"(Af[nx][6]), "+v"(Af[nx][7]));
+      landed(Af[nx]);
       B = Bn;
       if (j == 1) {
         // middle of the tile: tile t + 1 (requested in the middle of tile t - 2: two tile times ago) has landed
         // everywhere -- the 5 operations of tile t + 2 may still be in flight; tile t - 1 is dead, its buffer takes
         // tile t + 3 (past the end: tile KT - 1 again, harmless, keeps the code uniform)
-        take(cv[nxt], cq[st1], std::integral_constant<int, 5>{});
+        take(cv[nxt], cq[st1], std::integral_constant<int, 1 + XL>{});
         __builtin_amdgcn_s_barrier();
         load_codes(cq[st3], min(t + 3, KT - 1));
         issue_x(min(t + 3, KT - 1), st3);
@@ -285,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __r
   // the even register's row, odd lanes the odd register's
   const bool odd = (lane & 1) != 0;
 #pragma unroll
-  for (int b = 0; b < 8; ++b) {
+  for (int b = 0; b < NB; ++b) {
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
       const float mine = odd ? acc[b][r + 1] : acc[b][r];
@@ -313,16 +326,24 @@ bool e8p_prefill_gemm_supported(int64_t m, int n, int k) {
 int e8p_prefill_gemm_launch(const void* x, const void* qidxs, const void* grid, void* y, int64_t m, int n, int k,
                             hipStream_t stream) {
   if (!e8p_prefill_gemm_supported(m, n, k)) return QUIP_ERR_UNSUPPORTED;
-  const int MT = (int)((m + kBM - 1) / kBM), NT = (n + kBN - 1) / kBN;
+  const int NT = (n + kBN - 1) / kBN;
+  // 128-row tiles while 256-row tiles would leave CUs without a workgroup (the K loop of a workgroup takes the same
+  // time whatever the tile height: a second half-filled round costs less than idle CUs)
+  static const int force = getenv("QUIP_PREFILL_TILE") ? atoi(getenv("QUIP_PREFILL_TILE")) : 0;   // 128 / 256: experiments
+  const bool half = force ? force == 128 : (m + kBM - 1) / kBM * NT < device_cu_count();
+  const int bm = half ? kBM / 2 : kBM;
+  const int MT = (int)((m + bm - 1) / bm);
   const int64_t blocks = MT >= 8 ? (int64_t)((MT + 7) / 8) * NT * 8 : (int64_t)MT * NT;
   if (blocks > 0x7fffffff) return QUIP_ERR_UNSUPPORTED;
-  static DynLdsCache configured;   // per device
-  if (ensure_dyn_lds(configured, reinterpret_cast<const void*>(e8p_prefill_gemm_kernel), kLds) != QUIP_OK)
-    return QUIP_ERR_LAUNCH;
-  hipLaunchKernelGGL(e8p_prefill_gemm_kernel, dim3((unsigned)blocks), dim3(512), kLds, stream,
-                     reinterpret_cast<const f16*>(x), reinterpret_cast<const uint16_t*>(qidxs),
-                     reinterpret_cast<const uint64_t*>(grid), reinterpret_cast<f16*>(y), (int)m, n, k, MT, NT);
-  return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+  auto go = [&](auto kern, DynLdsCache& configured) -> int {
+    if (ensure_dyn_lds(configured, reinterpret_cast<const void*>(kern), kLds) != QUIP_OK) return QUIP_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), kLds, stream, reinterpret_cast<const f16*>(x),
+                       reinterpret_cast<const uint16_t*>(qidxs), reinterpret_cast<const uint64_t*>(grid),
+                       reinterpret_cast<f16*>(y), (int)m, n, k, MT, NT);
+    return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+  };
+  static DynLdsCache c8, c4;   // per device
+  return half ? go(e8p_prefill_gemm_kernel<4>, c4) : go(e8p_prefill_gemm_kernel<8>, c8);
 }
 
 }  // namespace quip
