@@ -884,6 +884,11 @@ int launch(HadGroup& g, int count, int64_t rows, hipStream_t stream) {
       return planes ? launch_one(had_fast_kernel<true, false, 256, true>, c1[0], g, grid, L / 16, lds, stream)
                     : launch_one(had_fast_kernel<false, false, 256, true>, c1[1], g, grid, L / 16, lds, stream);
     }
+    if (L == 8192 && K == 1) {   // Llama-2-70B's hidden size: the K == 1 instantiation (no K-mix code) on 512 threads
+      static DynLdsCache c8[2];
+      return planes ? launch_one(had_fast_kernel<true, false, 512, true>, c8[0], g, grid, L / 16, lds, stream)
+                    : launch_one(had_fast_kernel<false, false, 512, true>, c8[1], g, grid, L / 16, lds, stream);
+    }
     if (L <= 4096)
       return planes ? launch_one(had_fast_kernel<true, false, 256>, cfg[2], g, grid, L / 16, lds, stream)
                     : launch_one(had_fast_kernel<false, false, 256>, cfg[3], g, grid, L / 16, lds, stream);
