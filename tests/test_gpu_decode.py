@@ -361,3 +361,22 @@ def test_decoder_step_with_transforms_in_the_attention_launch():
     assert torch.equal(t9, t10) and torch.equal(g9, t10)
     for a, b in zip(l9, l10):
         assert torch.equal(a, b)
+
+
+def test_prefill_graph_equals_eager_prefill():
+    """the prompt pass replayed from a hipGraph (captured per prompt length): logits, cache rows and position equal
+    the eager pass, also for a second prompt of the same length"""
+    from quip_for_all_amd import decode as D
+    dec = D.LlamaDecoder(D.SMALL, "E8P12", max_len=64, device="cuda:0", seed=9)
+    g = torch.Generator().manual_seed(1)
+    for rep in range(2):
+        toks = torch.randint(0, D.SMALL.vocab, (40,), generator=g)
+        dec.reset()
+        with torch.no_grad():
+            le = dec.prefill(toks).clone()
+        ke, ve, pe = dec.kcache.clone(), dec.vcache.clone(), int(dec.pos)
+        dec.reset()
+        dec.kcache.zero_(); dec.vcache.zero_()
+        lg = dec.prefill_graph(toks).clone()
+        assert torch.equal(lg, le) and int(dec.pos) == pe == 40
+        assert torch.equal(dec.kcache, ke) and torch.equal(dec.vcache, ve)
