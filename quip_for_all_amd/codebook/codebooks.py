@@ -42,6 +42,11 @@ class _Codebook(nn.Module):
         W = self.decompress_weight(Qidxs)
         return input @ W.T
 
+    def forward_reference(self, input, Qidxs):
+        """the reference's own op sequence, whatever faster path exists: `*_mm_origorder` below the threshold,
+        decompress + dense GEMM from it on (codebook/e8p12.py:139-156 and its siblings)"""
+        return _Codebook.forward(self, input, Qidxs)
+
 
 class E8P12_codebook(_Codebook):
     def __init__(self, inference=False, **kwargs):

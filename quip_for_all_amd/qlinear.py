@@ -28,6 +28,11 @@ class QuantLinear(nn.Module):
     # fp16-MFMA skinny kernel (csrc/e8p_skinny_gemm.hip: the reference's arithmetic -- fp16 x fp16 -> fp32 -- not bit
     # identical to bs=1); skinny_exact = True (QUIP_SKINNY_EXACT=1) keeps the exact multi-pass path for everything.
     skinny_exact = os.environ.get("QUIP_SKINNY_EXACT", "0") != "0"
+    # reference_ops = True (QUIP_REFERENCE_OPS=1): the forward issues the reference's op sequence only -- fp16 Hadamard
+    # output, `*_mm_origorder` (M < 32: decode + fp32 FMA on exactly the reference's weights, RVQ: main + s * resid
+    # rounded to fp16 per weight as in origin_order.cu:330-385) or decompress + dense GEMM -- instead of the digit-plane
+    # GEMV / skinny / fused-GEMM kernels.  For validating a checkpoint against the reference's numerics.
+    reference_ops = os.environ.get("QUIP_REFERENCE_OPS", "0") != "0"
 
     def __init__(self, in_features, out_features, codebook, bias=True, use_rand=True,
                  per_channel=False, weight_dtype=torch.float16):
@@ -118,8 +123,14 @@ class QuantLinear(nn.Module):
             x = x.to(torch.float16)
         L_in = self.q_in_features // self.K_left
         cb = self.codebook
-        if x.shape[0] == 1 and hasattr(cb, "mm_planes") and cb.planes_supported(self.q_out_features,
-                                                                               self.q_in_features):
+        if self.reference_ops:
+            xh = torch.ops.quip_lib.had_transform_fused(
+                x, self.q_in_features, self.q_in_features, self.K_left, self._had("had_left"), True,
+                self._vec(self.SU), None, None, None, self.wscale_float / math.sqrt(L_in), None,
+                self._vec(rms_weight), rms_eps, None if gate is None else gate.reshape(x.shape).to(torch.float16))
+            z = cb.forward_reference(xh, self.Qidxs)
+        elif x.shape[0] == 1 and hasattr(cb, "mm_planes") and cb.planes_supported(self.q_out_features,
+                                                                                 self.q_in_features):
             # bs=1 decode: transform straight into the GEMV's int8 digit planes (no fp16 xh)
             planes = torch.ops.quip_lib.had_transform_planes_fused(
                 x, self.q_in_features, self.K_left, self._had("had_left"), True, self._vec(self.SU),

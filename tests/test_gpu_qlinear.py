@@ -427,3 +427,39 @@ def test_single_pass_skinny_kernel_repeated_launches(n, k):
             y = torch.ops.quip_lib.e8p_mm_skinny(x, q, cb.grid_packed_abs).float()
             ref = x.float() @ W.T
             assert bool(((y - ref).abs() <= 2e-3 * ref.abs().max()).all()), (M, it)
+
+
+@pytest.mark.parametrize("cbid", ["E8P12", "E8P12RVQ4B", "E8P12RVQ3B", "D4", "HI"])
+@pytest.mark.parametrize("M", [1, 7, 40])
+def test_reference_op_sequence_stays_selectable(cbid, M):
+    """QuantLinear.reference_ops (QUIP_REFERENCE_OPS=1): the forward through the reference's op sequence -- fp16
+    Hadamard, `*_mm_origorder` / decompress + dense GEMM -- equals composing those ops by hand, sits inside the
+    stated bound, and the default (digit-plane / skinny / fused) forward agrees with it to the same bound"""
+    import math
+    P = O.make_layer(cbid, 1408 if cbid != "E8P12RVQ3B" else 1024, 688, seed=77)
+    layer = _layer(P)
+    x = np.random.default_rng(M).standard_normal((M, layer.in_features)).astype(np.float16)
+    xd = torch.from_numpy(x).to(DEV)
+    with torch.no_grad():
+        y_fast = layer(xd)
+        layer.reference_ops = True
+        y_ref = layer(xd)
+        layer.reference_ops = False
+        cb = layer.codebook
+        L_in = layer.q_in_features // layer.K_left
+        xh = torch.ops.quip_lib.had_transform_fused(
+            xd, layer.q_in_features, layer.q_in_features, layer.K_left, layer._had("had_left"), True,
+            layer._vec(layer.SU), None, None, None, layer.wscale_float / math.sqrt(L_in), None, None, 1e-5, None)
+        z = cb.mm(xh, layer.Qidxs) if M < cb.mm_threshold else xh @ cb.decompress_weight(layer.Qidxs).T
+        L_out = layer.q_out_features // layer.K_right
+        y_hand = torch.ops.quip_lib.had_transform_fused(
+            z, layer.out_features, layer.q_out_features, layer.K_right, layer._had("had_right"), False, None,
+            layer._vec(layer.Wscale) if layer.per_channel else None, layer._vec(layer.SV), layer._vec(layer.bias),
+            1.0 / math.sqrt(L_out), None, None, 1e-5, None)
+    assert torch.equal(y_ref, y_hand)
+    What = O.qlinear_dense_weight(P)
+    x64 = x.astype(np.float64)
+    ref = O.qlinear_forward(P, x64, "exact", What)
+    bound = O.ulp_bound(P, x64, What)
+    assert np.all(np.abs(y_ref.cpu().numpy().astype(np.float64) - ref) <= bound)
+    assert np.all(np.abs(y_fast.cpu().numpy().astype(np.float64) - ref) <= bound)
