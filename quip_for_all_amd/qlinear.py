@@ -118,6 +118,8 @@ class QuantLinear(nn.Module):
             raise RuntimeError(f"QuantLinear: input has {input.shape[-1]} features, expected in_features = "
                                f"{self.in_features}")
         x = input.reshape(-1, input.shape[-1])
+        if x.shape[0] == 0:          # an empty batch: nothing to launch (the eager ops of the reference return empty too)
+            return input.new_empty((*input.shape[:-1], self.out_features))
         x_dtype = x.dtype
         if x_dtype != torch.float16:
             x = x.to(torch.float16)

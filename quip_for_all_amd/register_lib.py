@@ -142,6 +142,8 @@ def _hadamard_cuda(x: Tensor, scale: float) -> Tensor:
     xc = x.contiguous()
     y = torch.empty_like(xc)
     rows = xc.numel() // n
+    if rows == 0:
+        return y
     with torch.cuda.device(x.device):
         if x.dtype == torch.float16:
             capi.check(capi.lib().quip_hadamard_f16(xc.data_ptr(), y.data_ptr(), rows, n, float(scale),

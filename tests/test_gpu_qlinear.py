@@ -463,3 +463,16 @@ def test_reference_op_sequence_stays_selectable(cbid, M):
     bound = O.ulp_bound(P, x64, What)
     assert np.all(np.abs(y_ref.cpu().numpy().astype(np.float64) - ref) <= bound)
     assert np.all(np.abs(y_fast.cpu().numpy().astype(np.float64) - ref) <= bound)
+
+
+def test_empty_batch_returns_empty():
+    """zero rows: QuantLinear.forward and quip_lib::hadamard return empty tensors of the right shape, no launch"""
+    P = O.make_layer("E8P12", 256, 688, seed=2)
+    layer = _layer(P)
+    with torch.no_grad():
+        y = layer(torch.empty(0, 256, device=DEV, dtype=torch.float16))
+        y3 = layer(torch.empty(2, 0, 256, device=DEV, dtype=torch.bfloat16))
+    assert tuple(y.shape) == (0, 688) and y.dtype == torch.float16
+    assert tuple(y3.shape) == (2, 0, 688) and y3.dtype == torch.bfloat16
+    h = torch.ops.quip_lib.hadamard(torch.empty(0, 512, device=DEV, dtype=torch.float16), 1.0)
+    assert tuple(h.shape) == (0, 512)
