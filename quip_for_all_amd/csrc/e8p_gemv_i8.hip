@@ -227,7 +227,7 @@ __global__ __launch_bounds__(1024) void x_to_planes_kernel(const f16* __restrict
   for (int w = 0; w < (nthreads >> 6); ++w) mx = max(mx, smax[w]);
   // exponent of the largest magnitude; X = rint(x * 2^sh) then satisfies |X| < 2^22
   const int ebits = (int)(mx >> 10);
-  const int sh = 21 - ((ebits ? ebits : 1) - 15);
+  const int sh = ebits == 31 ? kShiftNotFinite : 21 - ((ebits ? ebits : 1) - 15);   // 31: an inf or a NaN in x
   const float scale = as_f32((uint32_t)(sh + 127) << 23);
   if (tid == 0) *sh_out = sh;
   for (int p = tid; p < pieces; p += nthreads) {
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_i8_kernel(
 
   // (4) sum the J slices of each row, undo the fixed-point scale (2^-sh) and the
   //     factor 4 of the byte weights, round to fp16, coalesced store
-  const float unscale = as_f32((uint32_t)(127 - sh - 2) << 23);
+  const float unscale = unscale_of(sh, 2);
   for (int t = tid; t < row_end - row0; t += nthreads) {
     float s = 0.f;
     for (int jj = 0; jj < J; ++jj) s += part[t * J + jj];

@@ -816,7 +816,7 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
       if (r < mrows) {
-        const float unscale = as_f32((uint32_t)(127 - sh[r] - (L::kD4 ? 1 : 2)) << 23);
+        const float unscale = unscale_of(sh[r], L::kD4 ? 1 : 2);
         for (int t = tid; t < rows_here[0]; t += nthreads) {
           const int* a = accs + (r * gp.rpb[0] + t) * 4;
           const float f = __builtin_fmaf((float)a[0], 65536.f, __builtin_fmaf((float)a[1], 256.f, (float)a[2]));
@@ -827,7 +827,7 @@ __global__ __launch_bounds__(MAXT) void e8p_gemv_mfma_kernel(
   }
 #pragma unroll
   for (int p = 0; p < (ROWS ? 0 : G); ++p) {
-    const float unscale = as_f32((uint32_t)(127 - sh[p] - (L::kD4 ? 1 : 2)) << 23);   // table entries are 4w (E8P) / 2w (D4)
+    const float unscale = unscale_of(sh[p], L::kD4 ? 1 : 2);   // table entries are 4w (E8P) / 2w (D4)
     for (int t = tid; t < rows_here[p]; t += nthreads) {
       const int* a = accs + (rbase[p] + t) * 4;
       const float f = __builtin_fmaf((float)a[0], 65536.f, __builtin_fmaf((float)a[1], 256.f, (float)a[2]));
@@ -1007,7 +1007,8 @@ __global__ __launch_bounds__(1024) void x_to_planes_linear_kernel(const f16* __r
   mx = 0;
   for (int w = 0; w < (nthreads >> 6); ++w) mx = max(mx, smax[w]);
   const int ebits = (int)(mx >> 10);
-  const int sh = 21 - ((ebits ? ebits : 1) - 15);   // |rint(x * 2^sh)| < 2^22
+  // exponent field 31 = an inf or a NaN in the row: no block exponent, the epilogue answers NaN
+  const int sh = ebits == 31 ? kShiftNotFinite : 21 - ((ebits ? ebits : 1) - 15);   // |rint(x * 2^sh)| < 2^22
   const float scale = as_f32((uint32_t)(sh + 127) << 23);
   if (tid == 0) *sh_out = sh;
   for (int p = tid; p < (Kp >> 3); p += nthreads) {

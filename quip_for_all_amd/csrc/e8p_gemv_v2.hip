@@ -456,7 +456,7 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
   if (a.ksplit == 1) {
 #pragma unroll
     for (int p = 0; p < G; ++p) {
-      const float unscale = as_f32((uint32_t)(127 - sh[p] - 2) << 23);
+      const float unscale = unscale_of(sh[p], 2);
       for (int t = tid; t < rows_here[p]; t += nthreads) {
         const int* s3 = accs + (rbase[p] + t) * 4;
         const float f = __builtin_fmaf((float)s3[0], 65536.f, __builtin_fmaf((float)s3[1], 256.f, (float)s3[2]));
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
     if (*flag == a.ksplit - 1) {                        // last to arrive: every partial sum is in
 #pragma unroll
       for (int p = 0; p < G; ++p) {
-        const float unscale = as_f32((uint32_t)(127 - sh[p] - 2) << 23);
+        const float unscale = unscale_of(sh[p], 2);
         for (int t = tid; t < rows_here[p]; t += nthreads) {
           int* g = a.ws[p] + (size_t)(row0[p] + t) * 4;
           const int s0 = __hip_atomic_exchange(g + 0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -240,7 +240,10 @@ __device__ __forceinline__ void digits_of(int X, int& h, int& m, int& l) {
 }
 
 // shift for |v| <= bound: bound < 2^(E+1) => |rint(v * 2^sh)| < 2^22 with sh = 21 - E
+// A bound that is not finite (an inf or NaN activation; absmax16() turns a NaN into +inf so that fmaxf cannot
+// drop it) gives kShiftNotFinite, which unscale_of() turns into a NaN output row like the fp path's.
 __device__ __forceinline__ int shift_for(float bound) {
+  if (!(bound < __builtin_inff())) return kShiftNotFinite;
   int E = (int)((as_u32(bound) >> 23) & 0xff) - 127;
   E = max(-60, min(60, E));
   return 21 - E;
@@ -249,7 +252,10 @@ __device__ __forceinline__ int shift_for(float bound) {
 __device__ __forceinline__ float absmax16(const float v[16], float scale) {
   float mx = 0.f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(fmul(v[r], scale)));
+  for (int r = 0; r < 16; ++r) {
+    const float a = fabsf(fmul(v[r], scale));
+    mx = fmaxf(mx, a == a ? a : __builtin_inff());
+  }
   return mx;
 }
 

@@ -734,7 +734,10 @@ __global__ __launch_bounds__(256) void had_small_kernel(HadGroup grp) {
     float bound;
     if (K == 1) {
       float mx = 0.f;
-      for (int j = tid; j < L; j += nt) mx = fmaxf(mx, fabsf(had::fmul(buf[j], scale)));
+      for (int j = tid; j < L; j += nt) {
+        const float m = fabsf(had::fmul(buf[j], scale));
+        mx = fmaxf(mx, m == m ? m : __builtin_inff());   // fmaxf would drop a NaN
+      }
       bound = block_reduce(mx, true, red, tid, nt);
     } else {
       bound = sqrtf(block_reduce(ss_in, false, red, tid, nt)) * sqrtf((float)L) * fabsf(scale) * 1.0625f;

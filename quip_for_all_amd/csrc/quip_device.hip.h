@@ -60,6 +60,14 @@ __device__ __forceinline__ uint32_t as_u32(f16x2 h) { return __builtin_bit_cast(
 __device__ __forceinline__ float as_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ uint32_t as_u32(float f) { return __builtin_bit_cast(uint32_t, f); }
 
+// Block exponent of an activation row that holds an inf or a NaN: its digit planes mean nothing and the GEMV
+// epilogues answer NaN for the whole row (what the Hadamard transform of such a row is in floating point).
+constexpr int kShiftNotFinite = 1 << 20;
+// 2^-(sh + extra): the factor that takes the integer sums of a row at block exponent sh back to floats
+__device__ __forceinline__ float unscale_of(int sh, int extra) {
+  return sh == kShiftNotFinite ? as_f32(0x7fc00000u) : as_f32((uint32_t)(127 - sh - extra) << 23);
+}
+
 // acc + a.lo*b.lo + a.hi*b.hi  (v_dot2_f32_f16: fp16 products exact in fp32)
 __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float acc) {
   return __builtin_amdgcn_fdot2(as_f16x2(a), as_f16x2(b), acc, false);

@@ -476,3 +476,26 @@ def test_empty_batch_returns_empty():
     assert tuple(y3.shape) == (2, 0, 688) and y3.dtype == torch.bfloat16
     h = torch.ops.quip_lib.hadamard(torch.empty(0, 512, device=DEV, dtype=torch.float16), 1.0)
     assert tuple(h.shape) == (0, 512)
+
+
+@pytest.mark.parametrize("cb,fin,fout", [("E8P12", 1024, 512), ("E8P12", 688, 256), ("D4", 1024, 512),
+                                         ("E8P12RVQ4B", 1024, 512), ("E8P12RVQ3B", 1024, 512), ("HI", 1024, 512)])
+def test_non_finite_activation_rows_stay_non_finite(cb, fin, fout):
+    """an inf or a NaN in an activation row makes that whole output row non-finite in every kernel regime (the
+    transform spreads it over the row, as in the reference's fp path) and leaves the other rows alone: the
+    digit-plane paths carry it in the block exponent word, where the integer arithmetic would lose it"""
+    P = O.make_layer(cb, fin, fout, seed=5)
+    layer = _layer(P)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for M in (1, 3, 8, 40):
+        for bad in (float("nan"), float("inf"), -float("inf")):
+            x = torch.randn(M, fin, generator=g).half().to(DEV)
+            row = M // 2
+            x[row, fin - 3] = bad
+            with torch.no_grad():
+                y = layer(x).float()
+                clean = layer(torch.nan_to_num(x, nan=0.0, posinf=0.0, neginf=0.0)).float()
+            assert not torch.isfinite(y[row]).any(), (M, bad)
+            keep = [r for r in range(M) if r != row]
+            assert torch.isfinite(y[keep]).all(), (M, bad)
+            assert torch.equal(y[keep], clean[keep]), (M, bad)
