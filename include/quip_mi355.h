@@ -100,7 +100,8 @@ int quip_e8p_mm_batched(const void* x, const void* qidxs /* int16 (n, k/8) */, c
  * quip_e8p_gemv_planes_rows).  The planes live in caller-provided scratch (m plane images), so the library
  * still allocates nothing.  quip_e8p_mm_origorder() without workspace stays valid (m == 1: converts x
  * inside every workgroup; m > 1: the generic fused decode + fp32 FMA kernel): self-contained but slower.
- * m >= 32 or unsupported shapes: workspace unused (bytes == 0). */
+ * m >= 32 or unsupported shapes: workspace unused (bytes == 0).
+ * A row of x with an inf or a NaN gives a NaN output row (shift word 1 << 20 in its plane image), never zeros. */
 size_t quip_e8p_mm_workspace_bytes(int32_t m, int32_t n, int32_t k);
 int quip_e8p_mm_origorder_ws(const void* x, const void* qidxs, const void* grid_packed_abs, void* y,
                              int32_t m, int32_t n, int32_t k, void* workspace,
