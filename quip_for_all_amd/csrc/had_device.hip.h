@@ -153,15 +153,32 @@ struct FhtPass {
     const int tp = (t_hi << (4 * P + NB)) | (t_lo << SH_LO);
     return tp + (tp >> 5);
   }
+  // Two butterflies per instruction (v_pk_add_f32 on the register pairs (v[2i], v[2i + 1])): the same IEEE additions
+  // as fadd / fsub one at a time, half the VALU issue slots -- the batch transforms are bound by those.
   __device__ static __forceinline__ void butterflies(float v[16]) {
+#pragma clang fp contract(off)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    if (NB >= 1) {
 #pragma unroll
-    for (int s = 0; s < NB; ++s) {
+      for (int r = 0; r < 16; r += 2) {     // partners inside a pair: (a + b, a - b)
+        const f32x2 a = {v[r], v[r]}, b = {v[r + 1], -v[r + 1]};
+        const f32x2 c = a + b;
+        v[r] = c.x;
+        v[r + 1] = c.y;
+      }
+    }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+    for (int s = 1; s < NB; ++s) {
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
         if (!(r & (1 << s))) {
-          const float x0 = v[r], x1 = v[r | (1 << s)];
-          v[r] = fadd(x0, x1);
-          v[r | (1 << s)] = fsub(x0, x1);
+          const int q = r | (1 << s);
+          const f32x2 x0 = {v[r], v[r + 1]}, x1 = {v[q], v[q + 1]};
+          const f32x2 p = x0 + x1, m = x0 - x1;
+          v[r] = p.x;
+          v[r + 1] = p.y;
+          v[q] = m.x;
+          v[q + 1] = m.y;
         }
       }
     }

@@ -508,129 +508,313 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
 
 // Tall transform for BATCHES (prefill: thousands of token rows), fp16 output.  had_fast_kernel<*, TALL> is shaped
 // for latency: three workgroups per row, each staging the whole row.  Here ONE 256-thread workgroup owns a whole
-// row at a time and walks over many rows (grid.x < rows): the row is staged once, in the padded [k][j] layout the
-// transform's shuffle buffer uses anyway; wave w runs the K-mix of column tiles w, w + 4, ... for all (<= 3) row
-// tiles (one B read feeds three MFMAs, H sits in LDS as fp16) and writes the result over its own input columns;
-// then the length-L transform and the epilogue run 4096 elements (16 rows at L = 256) at a time.  The per-tile
-// MFMA sequence, the butterflies and the element-wise operations are those of had_fast_kernel, so the results
-// are bit identical to it.  LDS: roundup4(K) (L + L / 32) floats + H = 51 KB at 43 x 256: THREE workgroups per
-// CU, in different phases (load / matrix cores / transform + store) most of the time.
+// row at a time and walks over many rows (grid.x < rows), three workgroups per CU in different phases:
+//   (1) the pre-processed row goes to LDS in the padded [k][j] layout.  Its raw 16-byte pieces were requested
+//       while the PREVIOUS row was in phases 2 and 3 (registers), so no memory latency is exposed here;
+//   (2) wave w runs the K-mix of column tiles w, w + 4, ... for all (<= 3) row tiles on the matrix cores (one B
+//       read feeds three MFMAs, H sits in LDS as fp16) and writes the result over its own input columns;
+//   (3) the length-L transform, 4096 elements at a time: a thread holds 16 consecutive columns, so index bits
+//       0..3 are register butterflies and bits 4..LOGL-1 are butterflies between the L / 16 <= 16 lanes of one
+//       DPP row -- no LDS traffic and no barrier inside the transform (fht16_fixed costs 48 LDS accesses per
+//       thread and four workgroup barriers per round); the epilogue vectors of a round are requested before its
+//       butterflies.
+// The per-tile MFMA sequence, the butterfly order (index bits 0, 1, ... LOGL-1; x0 + x1 and x0 - x1 with x0 the
+// element whose bit is clear) and the element-wise operations are those of had_fast_kernel, so the results are bit
+// identical to it.  LDS: roundup4(K) (L + L / 32) floats + H = 51 KB at 43 x 256.
 // Requires 64 <= L <= 256, K <= 48, vector access, no RMSNorm statistic (host-checked).
-__global__ __launch_bounds__(256, 3) void had_tall_batch_kernel(HadGroup grp, int rows) {
+// the value lane ^ (1 << S) holds, S = 0..3: bits 0, 1 by DPP quad permutes (VALU), bits 2, 3 by ds_swizzle (the
+// LDS crossbar without memory: the transform phase is bound by VALU issue slots, the LDS pipe idles there)
+template <int S>
+__device__ __forceinline__ float lane_xor(float v) {
+  const int i = __builtin_bit_cast(int, v);
+  if constexpr (S == 0) return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(i, 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  else if constexpr (S == 1) return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(i, 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  else if constexpr (S == 2) return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(i, 0x101F));   // bit mode: xor 4
+  else return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(i, 0x201F));                         // xor 8
+}
+template <int S>
+__device__ __forceinline__ void lane_stage(float v[16], int lane) {
+#pragma clang fp contract(off)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  // bit clear: x0 + x1 = partner + own; bit set: x0 - x1 = partner - own: one packed fma with (+-1, +-1), exact product
+  const float sg = ((lane >> S) & 1) ? -1.f : 1.f;
+  const f32x2 sg2 = {sg, sg};
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    const f32x2 own = {v[r], v[r + 1]}, par = {lane_xor<S>(v[r]), lane_xor<S>(v[r + 1])};
+    const f32x2 w = __builtin_elementwise_fma(own, sg2, par);
+    v[r] = w.x;
+    v[r + 1] = w.y;
+  }
+}
+template <int LOGL>
+__device__ __forceinline__ void fht16_lanes(float v[16], int lane) {
+  had::FhtPass<LOGL, 0>::butterflies(v);
+  if constexpr (LOGL > 4) lane_stage<0>(v, lane);
+  if constexpr (LOGL > 5) lane_stage<1>(v, lane);
+  if constexpr (LOGL > 6) lane_stage<2>(v, lane);
+  if constexpr (LOGL > 7) lane_stage<3>(v, lane);
+}
+// LDS traffic of this workgroup is complete and visible, nothing else is waited for (the row prefetch stays in flight)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// "these loads have landed" as far as the compiler's wait bookkeeping goes: it places its own s_waitcnt before this
+// point and none later.  gfx9 counts loads and stores in ONE counter, so a wait for a load that is placed after
+// stores is a wait for those stores as well (a few microseconds per row here) -- the row loop therefore waits for
+// everything it has requested BEFORE its first store, at a point where the requests are a whole phase old.
+__device__ __forceinline__ void landed(const u32x4 (&q)[3][2]) {
+  asm volatile("" ::"v"(q[0][0]), "v"(q[0][1]), "v"(q[1][0]), "v"(q[1][1]), "v"(q[2][0]), "v"(q[2][1]));
+}
+// row-invariant vectors stay PACKED in their registers: without this the compiler converts them to fp32 once,
+// outside the row loop, and keeps twice the registers
+__device__ __forceinline__ void keep_packed(u32x4 (&q)[3][2]) {
+  asm volatile("" : "+v"(q[0][0]), "+v"(q[0][1]), "+v"(q[1][0]), "+v"(q[1][1]), "+v"(q[2][0]), "+v"(q[2][1]));
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// 8 fp16 -> 4 pairs; element-wise products / sums two at a time (v_pk_mul_f32 / v_pk_add_f32: the IEEE operations of
+// had::fmul / had::fadd, half the issue slots)
+__device__ __forceinline__ void unpack8p(const u32x4& u, f32x2 o[4]) {
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f16x2 h = as_f16x2(w[i]);
+    o[i] = f32x2{(float)h.x, (float)h.y};
+  }
+}
+__device__ __forceinline__ void mul8p(f32x2 o[4], const u32x4& u) {
+#pragma clang fp contract(off)
+  f32x2 t[4];
+  unpack8p(u, t);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = o[i] * t[i];
+}
+__device__ __forceinline__ void add8p(f32x2 o[4], const u32x4& u) {
+#pragma clang fp contract(off)
+  f32x2 t[4];
+  unpack8p(u, t);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = o[i] + t[i];
+}
+
+// SIDE 0: input side (element-wise work before the transform: gate, pre; fp16 = scale * transform after it);
+// SIDE 1: output side (post, bias, residual after it).  One or the other per launch (host-checked): each side keeps
+// its vectors in registers, both together do not fit two workgroups per CU.
+template <int LOGL, int SIDE>
+__global__ __launch_bounds__(256, 2) void had_tall_batch_kernel(HadGroup grp, int rows) {
+#pragma clang fp contract(off)
   const HadArgs a = grp.p[blockIdx.z];
   extern __shared__ __attribute__((aligned(16))) float buf[];
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  const int tid = threadIdx.x, nt = blockDim.x;   // 256
-  const int L = a.L, K = a.K, logL = a.logL;
+  constexpr int nt = 256, L = 1 << LOGL, nw = 4;
+  constexpr int ctiles = L >> 4, tpw = ctiles / nw;   // column tiles per wave: 4 (L = 256), 2 (128), 1 (64)
+  constexpr int rr = (nt * 16) >> LOGL;             // rows per transform round (4096 elements)
+  constexpr int round_floats = nt * 16 + ((nt * 16) >> 5);
+  const int tid = threadIdx.x, K = a.K;
   const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
-  const int ctiles = L >> 4, ksteps = (K + 3) >> 2;
+  const int ksteps = (K + 3) >> 2;
   const int BR = (K + 3) & ~3;                     // buffer rows: inputs k < K, outputs kp < BR (kp >= K are zero)
-  // H as the MFMA's A operand, A[row kq][k] at hs[k * 48 + kq] (fp16 as stored), zero outside (K, K).  (Held in
-  // registers across rows instead -- 36 VGPRs -- it spills under the three-workgroup budget and is not faster.)
+  // H as the MFMA's A operand, A[row kq][k] at hs[k * 48 + kq] (fp16 as stored), zero outside (K, K).
   f16* hs = reinterpret_cast<f16*>(buf + had::buf_floats(BR * L));
   for (int i = tid; i < 48 * 48; i += nt) {
     const int k = i / 48, kq = i - k * 48;
     hs[i] = (kq < K && k < K) ? (a.transpose ? a.had[k * K + kq] : a.had[kq * K + k]) : (f16)0.f;
   }
-  const int rr = (nt * 16) >> logL;                // rows per transform round (4096 elements)
-  const int round_floats = nt * 16 + ((nt * 16) >> 5);
   const int j0 = (tid * 16) & (L - 1);
-  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
-    const f16* xr = a.x + (int64_t)row * a.in_features;
-    const f16* gr = a.gate ? a.gate + (int64_t)row * a.in_features : nullptr;
-    // (1) the pre-processed row, [k][j] in the padded layout
-#pragma unroll 1
-    for (int c = tid; c * 16 < a.n; c += nt) {
-      Raw16 raw;
-      raw_load16(a, xr, gr, c * 16, raw);
-      float e[16];
-      float ss = 0.f;
-      raw_math16(a, c * 16, raw, e, ss);
-      float* dst = buf + c * 16 + ((c * 16) >> 5);   // 16 elements inside one 32-block: constant pad offset
+  // LDS addresses as `lane base + compile-time offset` (pad(a + b) = pad(a) + pad(b) when a is a multiple of 32 --
+  // written out, because the compiler keeps every pad(...) of the loops below in a register of its own otherwise)
+  constexpr int RS = L + (L >> 5);                       // floats per buffer row
+  float* const stage = buf + tid * 16 + (tid >> 1);      // pad(16 tid); + round_floats per 4096 elements
+  const int cb = wave * 16 + lr;                         // column of this lane in its first tile; tile t: + 64 t
+  float* const mixcol = buf + cb + (cb >> 5);            // pad(cb); tile t: + 66 t, row k: + k RS
+  // this thread's pieces of a row, input side: 16-element chunks tid, tid + 256, tid + 512 (n <= 48 x 256 =
+  // 3 x 4096) at 32-bit byte offsets (requests are `uniform row base + lane offset`); output side: the 16 columns
+  // from j0 of row rd rr + (16 tid >> LOGL), round rd = 0, 1, 2
+  u32x4 xq[3][2], gq[3][2], pq[3][2];                    // x (next row), gate (next row), pre (all rows)
+  u32x4 qpost[3][2], qbias[3][2], qres[3][2];            // post, bias (all rows), residual (this row)
+  uint32_t off[3][2];
+  const bool padded = a.in_features < a.n;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dst[r] = e[r];
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = (tid + i * nt) * 16 + 8 * h;
+      off[i][h] = (uint32_t)(c < a.in_features ? c : 0) * 2u;
+      if (SIDE == 0 && a.pre && (tid + i * nt) * 16 < a.n)
+        pq[i][h] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.pre) + off[i][h]);
     }
-    __syncthreads();
+  bool whole[3];
+#pragma unroll
+  for (int rd = 0; rd < 3; ++rd) {
+    const int idx0 = (rd * rr + ((tid * 16) >> LOGL)) * L + j0;
+    whole[rd] = rd * rr + ((tid * 16) >> LOGL) < K && idx0 + 16 <= a.out_features;
+    if (SIDE == 1 && whole[rd]) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (a.post) qpost[rd][h] = *reinterpret_cast<const u32x4*>(a.post + idx0 + 8 * h);
+        if (a.bias) qbias[rd][h] = *reinterpret_cast<const u32x4*>(a.bias + idx0 + 8 * h);
+      }
+    }
+  }
+  auto fetch = [&](int row) {
+    const char* xr = reinterpret_cast<const char*>(a.x + (int64_t)row * a.in_features);
+    const char* gr = reinterpret_cast<const char*>(a.gate ? a.gate + (int64_t)row * a.in_features : nullptr);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if ((tid + i * nt) * 16 < a.n) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          xq[i][h] = *reinterpret_cast<const u32x4*>(xr + off[i][h]);
+          if (SIDE == 0 && a.gate) gq[i][h] = *reinterpret_cast<const u32x4*>(gr + off[i][h]);
+        }
+      }
+    }
+  };
+  if ((int)blockIdx.x < rows) fetch(blockIdx.x);
+  // the loop starts with nothing pending (see landed())
+  landed(xq);
+  if (SIDE == 0) { landed(gq); landed(pq); } else { landed(qpost); landed(qbias); }
+#ifdef QUIP_HAD_STAMPS
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
+#define TSTAMP(i) do { const unsigned long long now = __builtin_amdgcn_s_memtime(); tacc[i] += now - tl; tl = now; } while (0)
+#else
+#define TSTAMP(i) do {} while (0)
+#endif
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    f16* yr = a.y + (int64_t)row * a.out_features;
+    const f16* rr_ = a.residual ? a.residual + (int64_t)row * a.out_features : nullptr;
+    if (SIDE == 1 && rr_) {
+#pragma unroll
+      for (int rd = 0; rd < 3; ++rd)
+        if (whole[rd]) {
+          const int idx0 = (rd * rr + ((tid * 16) >> LOGL)) * L + j0;
+          const char* rb = reinterpret_cast<const char*>(rr_);   // uniform row base + 32-bit lane offset
+          qres[rd][0] = *reinterpret_cast<const u32x4*>(rb + (uint32_t)idx0 * 2u);
+          qres[rd][1] = *reinterpret_cast<const u32x4*>(rb + (uint32_t)idx0 * 2u + 16u);
+        }
+    }
+    // (1) the pre-processed row, [k][j] in the padded layout
+    if (SIDE == 0) keep_packed(pq);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int idx0 = (tid + i * nt) * 16;
+      if (idx0 < a.n) {
+        float* dst = stage + i * round_floats;   // pad(idx0): 16 elements inside one 32-block, constant pad offset
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          f32x2 o[4];
+          unpack8p(xq[i][h], o);
+          if (padded) {                          // F.pad zeros
+            const float keep = (idx0 + 8 * h) < a.in_features ? 1.f : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = o[r] * f32x2{keep, keep};
+          }
+          if (SIDE == 0 && a.gate) {
+            f32x2 t[4];
+            unpack8p(gq[i][h], t);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = o[r] * f32x2{silu(t[r].x), silu(t[r].y)};
+          }
+          if (SIDE == 0 && a.pre) mul8p(o, pq[i][h]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            dst[8 * h + 2 * r] = o[r].x;
+            dst[8 * h + 2 * r + 1] = o[r].y;
+          }
+          __builtin_amdgcn_sched_barrier(0);   // one piece at a time: interleaved, the six pieces do not fit the registers
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // (hoisted above the arithmetic, the requests would need a second set of registers)
+    if (row + (int)gridDim.x < rows) fetch(row + gridDim.x);   // lands during phase 2
+    TSTAMP(0);
+    lds_barrier();
+    TSTAMP(1);
     // (2) K-mix on the matrix cores, in place per column tile.  A wave runs its (<= 4) column tiles TOGETHER: per
     //     k step one A read per row tile feeds all of them, and the 3 x tiles MFMAs of a step (>= 96 cycles of
     //     matrix-core time) cover the LDS latency of the next step's operands.
     {
-      const int nw = nt >> 6;
-      const int tpw = (ctiles + nw - 1) / nw;        // 4 (L = 256), 2 (128), 1 (64)
-      f32x4 acc[4][3];
+      f32x4 acc[tpw][3];
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < tpw; ++t)
 #pragma unroll
         for (int rt = 0; rt < 3; ++rt) acc[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-      for (int ks = 0; ks < ksteps; ++ks) {
+      // operands of step ks + 1 are requested before the MFMAs of step ks (the loop is not unrolled by the compiler:
+      // left alone every step waits for its own LDS reads)
+      f16 ah[3];
+      float bv[tpw];
+      auto operands = [&](int ks, f16 (&ah_)[3], float (&bv_)[tpw]) {
         const int k = min(4 * ks + lq, K - 1);
-        float av[3], bv[4];
 #pragma unroll
-        for (int rt = 0; rt < 3; ++rt) av[rt] = (float)hs[(4 * ks + lq) * 48 + rt * 16 + lr];
+        for (int rt = 0; rt < 3; ++rt) ah_[rt] = hs[(4 * ks + lq) * 48 + rt * 16 + lr];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) bv[t] = t < tpw ? buf[pad((k << logL) + (wave + t * nw) * 16 + lr)] : 0.f;
+        for (int t = 0; t < tpw; ++t) bv_[t] = mixcol[k * RS + 66 * t];
+      };
+      operands(0, ah, bv);
+#pragma unroll 1
+      for (int ks = 0; ks < ksteps; ++ks) {
+        f16 an[3];
+        float bn[tpw];
+        operands(min(ks + 1, ksteps - 1), an, bn);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-          if (t < tpw) {
+        for (int t = 0; t < tpw; ++t)
 #pragma unroll
-            for (int rt = 0; rt < 3; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt], bv[t], acc[t][rt], 0, 0, 0);
-          }
+          for (int rt = 0; rt < 3; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)ah[rt], bv[t], acc[t][rt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt) ah[rt] = an[rt];
+#pragma unroll
+        for (int t = 0; t < tpw; ++t) bv[t] = bn[t];
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-        if (t < tpw) {
-          const int col = (wave + t * nw) * 16 + lr;
+      for (int rt = 0; rt < 3; ++rt) {
+        float* const orow4 = mixcol + 4 * lq * RS;             // output rows rt 16 + 4 lq + i
+        if (rt * 16 + 4 * lq < BR) {                           // BR is a multiple of 4: all four rows or none
 #pragma unroll
-          for (int rt = 0; rt < 3; ++rt)
+          for (int t = 0; t < tpw; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int orow = rt * 16 + 4 * lq + i;
-              if (orow < BR) buf[pad((orow << logL) + col)] = acc[t][rt][i];
-            }
+            for (int i = 0; i < 4; ++i) orow4[(rt * 16 + i) * RS + 66 * t] = acc[t][rt][i];
         }
+      }
     }
-    __syncthreads();
-    // (3) + (4): length-L transform of the BR rows and the epilogue, 4096 elements at a time
-    for (int rd = 0; rd * rr < BR; ++rd) {
-      float* hb = buf + rd * round_floats;
-      const int kp = rd * rr + ((tid * 16) >> logL);
-      const bool fact = kp < BR;
-      f16* yr = a.y + (int64_t)row * a.out_features;
-      const f16* rr_ = a.residual ? a.residual + (int64_t)row * a.out_features : nullptr;
-      const int idx0 = kp * L + j0;
-      const bool whole = fact && kp < K && idx0 + 16 <= a.out_features;
-      float v[16];
+    TSTAMP(2);
+    lds_barrier();
+    TSTAMP(3);
+    // everything requested so far has had phase 2 to arrive; no load is waited for after the first store below
+    landed(xq);
+    if (SIDE == 0) landed(gq); else { landed(qres); keep_packed(qpost); keep_packed(qbias); }
+    // (3) + (4): length-L transform of the K rows and the epilogue, 4096 elements at a time
 #pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = fact ? hb[pad(tid * 16 + r)] : 0.f;
-      if (logL == 8) had::fht16_fixed<8, false>(v, hb, 0, tid, fact);          // only the three tall lengths
-      else if (logL == 7) had::fht16_fixed<7, false>(v, hb, 0, tid, fact);
-      else had::fht16_fixed<6, false>(v, hb, 0, tid, fact);
-      if (fact && kp < K) {
-        if (whole) {
-          // packed vectors requested together, unpacked eight at a time
-          uint4 qpost[2], qbias[2], qres[2];
+    for (int rd = 0; rd < 3; ++rd) {
+      if (rd * rr < K) {
+        const int kp = rd * rr + ((tid * 16) >> LOGL);
+        const bool live = kp < K;
+        const float* hb = live ? stage + rd * round_floats : stage;
+        const int idx0 = kp * L + j0;
+        float v[16];
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            if (a.post) qpost[h] = ldp(a.post + idx0 + 8 * h);
-            if (a.bias) qbias[h] = ldp(a.bias + idx0 + 8 * h);
-            if (rr_) qres[h] = ldp(rr_ + idx0 + 8 * h);
-          }
+        for (int r = 0; r < 16; ++r) v[r] = hb[r];   // (rows >= K of the last round: never stored)
+        fht16_lanes<LOGL>(v, lane);
+        if (whole[rd]) {
+          const f32x2 sc = {a.scale, a.scale};
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            float tp[8], tb[8], tr[8];
-            if (a.post) had::unpack8(qpost[h], tp);
-            if (a.bias) had::unpack8(qbias[h], tb);
-            if (rr_) had::unpack8(qres[h], tr);
-            f16 o[8];
+            f32x2 o[4];
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
-              o[r] = had::out_elem(v[8 * h + r], a.scale, a.post != nullptr, a.post ? tp[r] : 0.f, a.bias != nullptr,
-                                   a.bias ? tb[r] : 0.f, rr_ != nullptr, rr_ ? tr[r] : 0.f);
-            reinterpret_cast<uint4*>(yr + idx0)[h] = *reinterpret_cast<uint4*>(&o[0]);
+            for (int r = 0; r < 4; ++r) o[r] = f32x2{v[8 * h + 2 * r], v[8 * h + 2 * r + 1]} * sc;
+            if (SIDE == 1) {
+              if (a.post) mul8p(o, qpost[rd][h]);
+              if (a.bias) add8p(o, qbias[rd][h]);
+              if (rr_) add8p(o, qres[rd][h]);
+            }
+            uint4 pk;
+            pk.x = as_u32(__builtin_convertvector(o[0], f16x2));
+            pk.y = as_u32(__builtin_convertvector(o[1], f16x2));
+            pk.z = as_u32(__builtin_convertvector(o[2], f16x2));
+            pk.w = as_u32(__builtin_convertvector(o[3], f16x2));
+            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(yr) + ((uint32_t)idx0 * 2u + 16u * h)) = pk;
           }
-        } else {
-#pragma unroll
+        } else if (live) {   // the ragged end of out_features
+#pragma unroll 1
           for (int r = 0; r < 16; ++r) {
             const int idx = idx0 + r;
             if (idx < a.out_features)
@@ -641,8 +825,14 @@ __global__ __launch_bounds__(256, 3) void had_tall_batch_kernel(HadGroup grp, in
         }
       }
     }
-    __syncthreads();   // the buffer is restaged for the next row
+    TSTAMP(4);
+    lds_barrier();   // the buffer is restaged for the next row
+    TSTAMP(5);
   }
+#ifdef QUIP_HAD_STAMPS
+  if (tid == 0 && blockIdx.x == 0 && blockIdx.z == 0)
+    for (int i = 0; i < 6; ++i) g_had_stamps[8 + i] = tacc[i];
+#endif
 }
 
 // K == 1 transform for BATCHES (prefill), fp16 output, L = 2^LOGL in {1024, 2048, 4096, 8192}: the same arithmetic as
@@ -808,17 +998,30 @@ int launch(HadGroup& g, int count, int64_t rows, hipStream_t stream) {
       bool ok = rows >= 32 && K <= 48 && !planes;
       for (int i = 0; i < count; ++i)
         ok = ok && g.p[i].vec && g.p[i].vec_out && !g.p[i].rms_w && !g.p[i].pre2 && !g.p[i].z && g.p[i].out_features % 8 == 0;
+      // element-wise vectors of one side only (input: gate, pre; output: post, bias, residual), see the kernel
+      bool in_side = false, out_side = false;
+      for (int i = 0; i < count; ++i) {
+        in_side = in_side || g.p[i].gate || g.p[i].pre;
+        out_side = out_side || g.p[i].post || g.p[i].bias || g.p[i].residual;
+      }
+      ok = ok && !(in_side && out_side);
       if (ok) {
-        static DynLdsCache cfgb;
+        static DynLdsCache cfgb[6];
         const int BR = (K + 3) & ~3;
         const int lds = had::buf_floats(BR * L) * 4 + 48 * 48 * 2;
         const int threads = 256;
-        const int64_t want = 3 * (int64_t)device_cu_count();       // three resident workgroups per CU
+        const int64_t want = 2 * (int64_t)device_cu_count();       // two resident workgroups per CU
         const dim3 grid((unsigned)(rows < want ? rows : want), 1, count);
-        if (ensure_dyn_lds(cfgb, reinterpret_cast<const void*>(had_tall_batch_kernel), lds) != QUIP_OK)
-          return QUIP_ERR_LAUNCH;
-        hipLaunchKernelGGL(had_tall_batch_kernel, grid, dim3(threads), lds, stream, g, (int)rows);
-        return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+        auto go = [&](auto kern, DynLdsCache& cache) {
+          if (ensure_dyn_lds(cache, reinterpret_cast<const void*>(kern), lds) != QUIP_OK) return (int)QUIP_ERR_LAUNCH;
+          hipLaunchKernelGGL(kern, grid, dim3(threads), lds, stream, g, (int)rows);
+          return hipGetLastError() == hipSuccess ? (int)QUIP_OK : (int)QUIP_ERR_LAUNCH;
+        };
+        const int logL = g.p[0].logL;
+        if (!in_side) return logL == 8 ? go(had_tall_batch_kernel<8, 1>, cfgb[0]) : logL == 7 ? go(had_tall_batch_kernel<7, 1>, cfgb[1])
+                                                                                               : go(had_tall_batch_kernel<6, 1>, cfgb[2]);
+        return logL == 8 ? go(had_tall_batch_kernel<8, 0>, cfgb[3]) : logL == 7 ? go(had_tall_batch_kernel<7, 0>, cfgb[4])
+                                                                                 : go(had_tall_batch_kernel<6, 0>, cfgb[5]);
       }
     }
     const int pp = had::buf_floats(4096) + ((K + 3) & ~3) * R + K * (L + 8);
