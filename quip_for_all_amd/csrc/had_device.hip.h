@@ -195,13 +195,62 @@ struct FhtPass {
   }
 };
 
+// Butterflies on index bits 4..7 = lane bits 0..3 (thread t holds elements [16 t, 16 t + 16), so these partners sit
+// in the same DPP row of 16 lanes): the value lane ^ (1 << S) holds comes over by a DPP move (bits 0, 1: quad
+// permutes; bit 3: row rotate by 8) or ds_swizzle (bit 2; the LDS crossbar, no memory), and
+//   bit clear: x0 + x1 = partner + own,   bit set: x0 - x1 = partner - own
+// is one packed fma with (+-1, +-1) (exact product): the same IEEE additions as a pass through LDS, without its
+// 32 LDS accesses per thread and two workgroup barriers.
+template <int S>
+__device__ __forceinline__ float lane_xor(float v) {
+  const int i = __builtin_bit_cast(int, v);
+  if constexpr (S == 0) return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(i, 0xB1, 0xf, 0xf, true));        // quad_perm [1,0,3,2]
+  else if constexpr (S == 1) return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(i, 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  else if constexpr (S == 2) return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(i, 0x101F));              // bit mode: xor 4
+  else return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(i, 0x128, 0xf, 0xf, true));                        // row_ror:8
+}
+template <int S>
+__device__ __forceinline__ void lane_stage(float v[16], int t) {
+#pragma clang fp contract(off)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const float sg = ((t >> S) & 1) ? -1.f : 1.f;
+  const f32x2 sg2 = {sg, sg};
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    const f32x2 own = {v[r], v[r + 1]}, par = {lane_xor<S>(v[r]), lane_xor<S>(v[r + 1])};
+    const f32x2 w = __builtin_elementwise_fma(own, sg2, par);
+    v[r] = w.x;
+    v[r + 1] = w.y;
+  }
+}
+// index bits 0 .. min(LOGL, 8) - 1 of the transform, entirely in registers and between lanes
+template <int LOGL>
+__device__ __forceinline__ void fht16_lanes(float v[16], int t) {
+  FhtPass<LOGL, 0>::butterflies(v);
+  if constexpr (LOGL > 4) lane_stage<0>(v, t);
+  if constexpr (LOGL > 5) lane_stage<1>(v, t);
+  if constexpr (LOGL > 6) lane_stage<2>(v, t);
+  if constexpr (LOGL > 7) lane_stage<3>(v, t);
+}
+
 // PP (ping-pong): pass P stores to half (P & 1) of a buffer of 2 * buf_floats(E) floats, so that a
 // pass needs ONE barrier (store -> barrier -> load) instead of two; one more barrier at entry
 // protects the buffer from earlier readers.  Same data movement, same results.
 template <int LOGL, int P, bool PP>
 __device__ __forceinline__ void fht16_passes(float v[16], float* buf, int stride, int t, bool active) {
   constexpr int NPASS = (LOGL + 3) / 4;
-  if constexpr (P < NPASS) {
+  if constexpr (P == 0 && LOGL > 4) {
+    // passes 0 and 1 without LDS (fht16_lanes); longer transforms hand over in natural order -- pass 0's store
+    // mapping -- in the half pass 1 would have written
+    fht16_lanes<LOGL>(v, t);
+    if constexpr (NPASS > 2) {
+      float* cur = PP ? buf + stride : buf;
+      __syncthreads();   // the buffer's earlier readers are done
+      if (active) FhtPass<LOGL, 0>::store(v, cur, t);
+      __syncthreads();
+      fht16_passes<LOGL, 2, PP>(v, buf, stride, t, active);
+    }
+  } else if constexpr (P < NPASS) {
     using Pass = FhtPass<LOGL, P>;
     float* cur = PP ? buf + (P & 1) * stride : buf;
     float* prev = PP ? buf + ((P + 1) & 1) * stride : buf;
@@ -220,7 +269,7 @@ template <int LOGL, bool PP>
 __device__ __forceinline__ void fht16_fixed(float v[16], float* buf, int stride, int t, bool active) {
   fht16_passes<LOGL, 0, PP>(v, buf, stride, t, active);
   constexpr int NPASS = (LOGL + 3) / 4;
-  if (LOGL > 4 && active) {  // back to 16 consecutive elements per thread
+  if (NPASS > 2 && active) {  // back to 16 consecutive elements per thread (up to 2^8 they never left)
     const float* b = buf + (PP ? ((NPASS - 1) & 1) * stride : 0) + (16 * t + ((16 * t) >> 5));
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = b[r];

@@ -522,39 +522,6 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
 // element whose bit is clear) and the element-wise operations are those of had_fast_kernel, so the results are bit
 // identical to it.  LDS: roundup4(K) (L + L / 32) floats + H = 51 KB at 43 x 256.
 // Requires 64 <= L <= 256, K <= 48, vector access, no RMSNorm statistic (host-checked).
-// the value lane ^ (1 << S) holds, S = 0..3: bits 0, 1 by DPP quad permutes (VALU), bits 2, 3 by ds_swizzle (the
-// LDS crossbar without memory: the transform phase is bound by VALU issue slots, the LDS pipe idles there)
-template <int S>
-__device__ __forceinline__ float lane_xor(float v) {
-  const int i = __builtin_bit_cast(int, v);
-  if constexpr (S == 0) return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(i, 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
-  else if constexpr (S == 1) return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(i, 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
-  else if constexpr (S == 2) return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(i, 0x101F));   // bit mode: xor 4
-  else return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(i, 0x201F));                         // xor 8
-}
-template <int S>
-__device__ __forceinline__ void lane_stage(float v[16], int lane) {
-#pragma clang fp contract(off)
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  // bit clear: x0 + x1 = partner + own; bit set: x0 - x1 = partner - own: one packed fma with (+-1, +-1), exact product
-  const float sg = ((lane >> S) & 1) ? -1.f : 1.f;
-  const f32x2 sg2 = {sg, sg};
-#pragma unroll
-  for (int r = 0; r < 16; r += 2) {
-    const f32x2 own = {v[r], v[r + 1]}, par = {lane_xor<S>(v[r]), lane_xor<S>(v[r + 1])};
-    const f32x2 w = __builtin_elementwise_fma(own, sg2, par);
-    v[r] = w.x;
-    v[r + 1] = w.y;
-  }
-}
-template <int LOGL>
-__device__ __forceinline__ void fht16_lanes(float v[16], int lane) {
-  had::FhtPass<LOGL, 0>::butterflies(v);
-  if constexpr (LOGL > 4) lane_stage<0>(v, lane);
-  if constexpr (LOGL > 5) lane_stage<1>(v, lane);
-  if constexpr (LOGL > 6) lane_stage<2>(v, lane);
-  if constexpr (LOGL > 7) lane_stage<3>(v, lane);
-}
 // LDS traffic of this workgroup is complete and visible, nothing else is waited for (the row prefetch stays in flight)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // "these loads have landed" as far as the compiler's wait bookkeeping goes: it places its own s_waitcnt before this
@@ -793,7 +760,7 @@ __global__ __launch_bounds__(256, 2) void had_tall_batch_kernel(HadGroup grp, in
         float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = hb[r];   // (rows >= K of the last round: never stored)
-        fht16_lanes<LOGL>(v, lane);
+        had::fht16_lanes<LOGL>(v, lane);
         if (whole[rd]) {
           const f32x2 sc = {a.scale, a.scale};
 #pragma unroll
