@@ -508,20 +508,19 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
 
 // Tall transform for BATCHES (prefill: thousands of token rows), fp16 output.  had_fast_kernel<*, TALL> is shaped
 // for latency: three workgroups per row, each staging the whole row.  Here ONE 256-thread workgroup owns a whole
-// row at a time and walks over many rows (grid.x < rows), three workgroups per CU in different phases:
+// row at a time and walks over many rows (grid.x < rows), two workgroups per CU:
 //   (1) the pre-processed row goes to LDS in the padded [k][j] layout.  Its raw 16-byte pieces were requested
 //       while the PREVIOUS row was in phases 2 and 3 (registers), so no memory latency is exposed here;
 //   (2) wave w runs the K-mix of column tiles w, w + 4, ... for all (<= 3) row tiles on the matrix cores (one B
 //       read feeds three MFMAs, H sits in LDS as fp16) and writes the result over its own input columns;
 //   (3) the length-L transform, 4096 elements at a time: a thread holds 16 consecutive columns, so index bits
 //       0..3 are register butterflies and bits 4..LOGL-1 are butterflies between the L / 16 <= 16 lanes of one
-//       DPP row -- no LDS traffic and no barrier inside the transform (fht16_fixed costs 48 LDS accesses per
-//       thread and four workgroup barriers per round); the epilogue vectors of a round are requested before its
-//       butterflies.
+//       DPP row (had::fht16_lanes: no LDS traffic, no barrier), then the packed epilogue and 16-byte stores.
 // The per-tile MFMA sequence, the butterfly order (index bits 0, 1, ... LOGL-1; x0 + x1 and x0 - x1 with x0 the
 // element whose bit is clear) and the element-wise operations are those of had_fast_kernel, so the results are bit
-// identical to it.  LDS: roundup4(K) (L + L / 32) floats + H = 51 KB at 43 x 256.
-// Requires 64 <= L <= 256, K <= 48, vector access, no RMSNorm statistic (host-checked).
+// identical to it.  LDS: roundup4(K) (L + L / 32) floats + H = 51 KB at 43 x 256; ~230 VGPRs (the prefetched row and
+// one side's vectors stay in registers).
+// Requires 64 <= L <= 256, K <= 48, vector access, no RMSNorm statistic, vectors of one side only (host-checked).
 // LDS traffic of this workgroup is complete and visible, nothing else is waited for (the row prefetch stays in flight)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // "these loads have landed" as far as the compiler's wait bookkeeping goes: it places its own s_waitcnt before this
