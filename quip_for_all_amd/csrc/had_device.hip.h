@@ -114,17 +114,64 @@ __device__ __forceinline__ void sumsq8(const float o[8], float& ss) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) ss = __fmaf_rn(o[i], o[i], ss);
 }
-__device__ __forceinline__ void mul8(float o[8], const uint4& piece) {
-  float t[8];
-  unpack8(piece, t);
+// Element-wise products and sums two at a time (v_pk_mul_f32 / v_pk_add_f32 on register pairs): the IEEE operations of
+// fmul / fadd, half the issue slots.  Q: uint4 or a 4 x uint32 vector.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <typename Q>
+__device__ __forceinline__ void unpack8p(const Q& u, f32x2 o[4]) {
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-  for (int i = 0; i < 8; ++i) o[i] = fmul(o[i], t[i]);
+  for (int i = 0; i < 4; ++i) {
+    const f16x2 h = as_f16x2(w[i]);
+    o[i] = f32x2{(float)h.x, (float)h.y};
+  }
+}
+template <typename Q>
+__device__ __forceinline__ void mul8p(f32x2 o[4], const Q& u) {
+#pragma clang fp contract(off)
+  f32x2 t[4];
+  unpack8p(u, t);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = o[i] * t[i];
+}
+template <typename Q>
+__device__ __forceinline__ void add8p(f32x2 o[4], const Q& u) {
+#pragma clang fp contract(off)
+  f32x2 t[4];
+  unpack8p(u, t);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = o[i] + t[i];
+}
+// 4 pairs -> 8 fp16 (round to nearest even, v_cvt_pk_f16_f32)
+__device__ __forceinline__ uint4 pack8p(const f32x2 o[4]) {
+  uint4 pk;
+  pk.x = as_u32(__builtin_convertvector(o[0], f16x2));
+  pk.y = as_u32(__builtin_convertvector(o[1], f16x2));
+  pk.z = as_u32(__builtin_convertvector(o[2], f16x2));
+  pk.w = as_u32(__builtin_convertvector(o[3], f16x2));
+  return pk;
+}
+__device__ __forceinline__ void mul8(float o[8], const uint4& piece) {
+#pragma clang fp contract(off)
+  f32x2 t[4];
+  unpack8p(piece, t);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x2 r = f32x2{o[2 * i], o[2 * i + 1]} * t[i];
+    o[2 * i] = r.x;
+    o[2 * i + 1] = r.y;
+  }
 }
 __device__ __forceinline__ void silu_mul8(float o[8], const uint4& gate_piece) {
-  float t[8];
-  unpack8(gate_piece, t);
+#pragma clang fp contract(off)
+  f32x2 t[4];
+  unpack8p(gate_piece, t);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) o[i] = fmul(o[i], silu(t[i]));
+  for (int i = 0; i < 4; ++i) {
+    const f32x2 r = f32x2{o[2 * i], o[2 * i + 1]} * f32x2{silu(t[i].x), silu(t[i].y)};
+    o[2 * i] = r.x;
+    o[2 * i + 1] = r.y;
+  }
 }
 
 // RMSNorm factor folded into the transform scale

@@ -76,6 +76,10 @@ constexpr int kMaxGroup = 3;   // problems per launch (q/k/v, gate/up)
 struct HadGroup { HadArgs p[kMaxGroup]; };
 
 using had::block_reduce;
+using had::f32x2;
+using had::unpack8p;
+using had::mul8p;
+using had::add8p;
 using had::pad;
 using had::silu;
 
@@ -480,18 +484,27 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
     const int idx0 = kp * L + j0;
     if (!live) {
     } else if (idx0 + 16 <= a.out_features && a.vec_out) {
-      float tp[16], tb[16], tr[16];
-      if (a.post) { ld8(a.post + idx0, tp); ld8(a.post + idx0 + 8, tp + 8); }
-      if (a.bias) { ld8(a.bias + idx0, tb); ld8(a.bias + idx0 + 8, tb + 8); }
-      if (rr) { ld8(rr + idx0, tr); ld8(rr + idx0 + 8, tr + 8); }
-      f16 o[16];
+      // out_elem() two elements at a time, the optional vectors behind uniform branches: requested together, applied
+      // in out_elem()'s order (scale, post, bias, residual; one rounding each, then fp16)
+      uint4 qp[2], qb[2], qr[2];
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        o[r] = had::out_elem(v[r], scale, a.post != nullptr, a.post ? tp[r] : 0.f, a.bias != nullptr,
-                             a.bias ? tb[r] : 0.f, rr != nullptr, rr ? tr[r] : 0.f);
-      uint4* dst = reinterpret_cast<uint4*>(yr + idx0);
-      dst[0] = *reinterpret_cast<uint4*>(&o[0]);
-      dst[1] = *reinterpret_cast<uint4*>(&o[8]);
+      for (int h = 0; h < 2; ++h) {
+        if (a.post) qp[h] = ldp(a.post + idx0 + 8 * h);
+        if (a.bias) qb[h] = ldp(a.bias + idx0 + 8 * h);
+        if (rr) qr[h] = ldp(rr + idx0 + 8 * h);
+      }
+      const f32x2 sc = {scale, scale};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma clang fp contract(off)
+        f32x2 o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = f32x2{v[8 * h + 2 * r], v[8 * h + 2 * r + 1]} * sc;
+        if (a.post) mul8p(o, qp[h]);
+        if (a.bias) add8p(o, qb[h]);
+        if (rr) add8p(o, qr[h]);
+        reinterpret_cast<uint4*>(yr + idx0)[h] = had::pack8p(o);
+      }
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -535,32 +548,6 @@ __device__ __forceinline__ void landed(const u32x4 (&q)[3][2]) {
 __device__ __forceinline__ void keep_packed(u32x4 (&q)[3][2]) {
   asm volatile("" : "+v"(q[0][0]), "+v"(q[0][1]), "+v"(q[1][0]), "+v"(q[1][1]), "+v"(q[2][0]), "+v"(q[2][1]));
 }
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// 8 fp16 -> 4 pairs; element-wise products / sums two at a time (v_pk_mul_f32 / v_pk_add_f32: the IEEE operations of
-// had::fmul / had::fadd, half the issue slots)
-__device__ __forceinline__ void unpack8p(const u32x4& u, f32x2 o[4]) {
-  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const f16x2 h = as_f16x2(w[i]);
-    o[i] = f32x2{(float)h.x, (float)h.y};
-  }
-}
-__device__ __forceinline__ void mul8p(f32x2 o[4], const u32x4& u) {
-#pragma clang fp contract(off)
-  f32x2 t[4];
-  unpack8p(u, t);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = o[i] * t[i];
-}
-__device__ __forceinline__ void add8p(f32x2 o[4], const u32x4& u) {
-#pragma clang fp contract(off)
-  f32x2 t[4];
-  unpack8p(u, t);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = o[i] + t[i];
-}
-
 // SIDE 0: input side (element-wise work before the transform: gate, pre; fp16 = scale * transform after it);
 // SIDE 1: output side (post, bias, residual after it).  One or the other per launch (host-checked): each side keeps
 // its vectors in registers, both together do not fit two workgroups per CU.
@@ -772,12 +759,7 @@ __global__ __launch_bounds__(256, 2) void had_tall_batch_kernel(HadGroup grp, in
               if (a.bias) add8p(o, qbias[rd][h]);
               if (rr_) add8p(o, qres[rd][h]);
             }
-            uint4 pk;
-            pk.x = as_u32(__builtin_convertvector(o[0], f16x2));
-            pk.y = as_u32(__builtin_convertvector(o[1], f16x2));
-            pk.z = as_u32(__builtin_convertvector(o[2], f16x2));
-            pk.w = as_u32(__builtin_convertvector(o[3], f16x2));
-            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(yr) + ((uint32_t)idx0 * 2u + 16u * h)) = pk;
+            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(yr) + ((uint32_t)idx0 * 2u + 16u * h)) = had::pack8p(o);
           }
         } else if (live) {   // the ragged end of out_features
 #pragma unroll 1
@@ -823,17 +805,20 @@ __global__ __launch_bounds__((LOGL > 12 ? 512 : 256), (LOGL > 12 ? 4 : 8)) void 
   const f16* rr = a.residual ? a.residual + row * a.out_features : nullptr;
   if (j0 + 16 <= a.out_features) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      float tp[8], tb[8], tr[8];
-      if (a.post) ld8(a.post + j0 + 8 * h, tp);
-      if (a.bias) ld8(a.bias + j0 + 8 * h, tb);
-      if (rr) ld8(rr + j0 + 8 * h, tr);
-      f16 o[8];
+    for (int h = 0; h < 2; ++h) {   // out_elem() two elements at a time, optional vectors behind uniform branches
+#pragma clang fp contract(off)
+      uint4 qp, qb, qr;
+      if (a.post) qp = ldp(a.post + j0 + 8 * h);
+      if (a.bias) qb = ldp(a.bias + j0 + 8 * h);
+      if (rr) qr = ldp(rr + j0 + 8 * h);
+      const f32x2 sc = {a.scale, a.scale};
+      f32x2 o[4];
 #pragma unroll
-      for (int r = 0; r < 8; ++r)
-        o[r] = had::out_elem(v[8 * h + r], a.scale, a.post != nullptr, a.post ? tp[r] : 0.f, a.bias != nullptr,
-                             a.bias ? tb[r] : 0.f, rr != nullptr, rr ? tr[r] : 0.f);
-      reinterpret_cast<uint4*>(yr + j0)[h] = *reinterpret_cast<uint4*>(&o[0]);
+      for (int r = 0; r < 4; ++r) o[r] = f32x2{v[8 * h + 2 * r], v[8 * h + 2 * r + 1]} * sc;
+      if (a.post) mul8p(o, qp);
+      if (a.bias) add8p(o, qb);
+      if (rr) add8p(o, qr);
+      reinterpret_cast<uint4*>(yr + j0)[h] = had::pack8p(o);
     }
   } else {
 #pragma unroll

@@ -416,7 +416,7 @@ def test_e8p_gemv_planes_rows_equal_single_row_gemv(n, k, M):
 
 
 @pytest.mark.parametrize("n,rows", [(11008, 70), (2752, 33), (5504, 64), (11008, 600), (688 * 4, 40)])
-@pytest.mark.parametrize("side", ["in", "out"])
+@pytest.mark.parametrize("side", ["in", "out", "both"])
 def test_tall_hadamard_batches_equal_single_rows(n, rows, side):
     """prefill batches of the tall transform (one workgroup per row, K-mix in place: had_tall_batch_kernel) give
     bit for bit what the latency-shaped launch gives row by row; input side with gate / pre-scale, output side with
@@ -434,6 +434,14 @@ def test_tall_hadamard_batches_equal_single_rows(n, rows, side):
         full = op.had_transform_fused(x, n, n, K, hd, True, v1, None, None, None, 0.37, None, None, 1e-5, g)
         for r in (0, 1, rows // 2, rows - 1):
             one = op.had_transform_fused(x[r:r + 1], n, n, K, hd, True, v1, None, None, None, 0.37, None, None, 1e-5, g[r:r + 1])
+            assert torch.equal(full[r:r + 1], one), r
+    elif side == "both":
+        # vectors of both sides in one launch: not the batch kernel's case (it keeps one side's vectors in registers),
+        # the launch takes the row-parallel kernel -- same bits
+        post = torch.randn(n, device=DEV).half()
+        full = op.had_transform_fused(x, n, n, K, hd, True, v1, None, post, None, 0.37, None, None, 1e-5, None)
+        for r in (0, rows // 2, rows - 1):
+            one = op.had_transform_fused(x[r:r + 1], n, n, K, hd, True, v1, None, post, None, 0.37, None, None, 1e-5, None)
             assert torch.equal(full[r:r + 1], one), r
     else:
         out_f = n - 24
