@@ -833,6 +833,81 @@ __global__ __launch_bounds__((LOGL > 12 ? 512 : 256), (LOGL > 12 ? 4 : 8)) void 
   (void)L;
 }
 
+// Small odd K (3, 5, 7: 5120 = 5 x 1024, 14336 = 7 x 2048, 28672 = 7 x 4096) times a long power of two, for BATCHES
+// (prefill), fp16 output.  The row-parallel launch gives every (kp, row) its own workgroup, which reads all K input
+// sub-rows: K times the input traffic (28672-wide rows ran at 0.8-1.0 TB/s r+w).  Here one workgroup of L / 16 threads
+// owns a token row: a thread reads its 16 columns of the K sub-rows ONCE (K x 16 fp32 in registers), and for
+// kp = 0 .. K-1 forms the K-mix (the single-row launch's partial fma chains and their order), runs the length-L
+// transform and stores -- the same functions, so the same bits as the row alone.
+template <int LOGL, int K>
+__global__ __launch_bounds__(1 << (LOGL - 4)) void had_wide_batch_kernel(HadGroup grp) {
+  const HadArgs a = grp.p[blockIdx.z];
+  extern __shared__ __attribute__((aligned(16))) float buf[];
+  constexpr int L = 1 << LOGL;
+  const int tid = threadIdx.x;
+  const int64_t row = blockIdx.y;
+  const f16* xr = a.x + row * a.in_features;
+  const f16* gr = a.gate ? a.gate + row * a.in_features : nullptr;
+  const int j0 = tid * 16;
+  float e[K][16];
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) in_vals16(a, xr, gr, k * L + j0, e[k], ss);
+  f16* yr = a.y + row * a.out_features;
+  const f16* rr = a.residual ? a.residual + row * a.out_features : nullptr;
+#pragma unroll
+  for (int kp = 0; kp < K; ++kp) {
+    // the single-row launch splits the k loop over TG = min(K, 4) thread groups (k = g, g + TG, ...: one fma chain
+    // each) and adds the partial sums in the order ((p0 + p1) + p2) + p3: the same here, so that a row of a batch and
+    // the row alone agree bit for bit
+    constexpr int TG = K < 4 ? K : 4;
+    float v[16];
+#pragma unroll
+    for (int g = 0; g < TG; ++g) {
+      float p[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p[r] = 0.f;
+#pragma unroll
+      for (int k = g; k < K; k += TG) {
+        const float h = (float)(a.transpose ? a.had[k * K + kp] : a.had[kp * K + k]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[r] = __builtin_fmaf(h, e[k][r], p[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = g == 0 ? p[r] : had::fadd(v[r], p[r]);
+    }
+    had::fht16_fixed<LOGL, false>(v, buf, 0, tid, true);
+    const int idx0 = kp * L + j0;
+    if (idx0 + 16 <= a.out_features) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {   // out_elem() two elements at a time, optional vectors behind uniform branches
+#pragma clang fp contract(off)
+        uint4 qp, qb, qr;
+        if (a.post) qp = ldp(a.post + idx0 + 8 * h);
+        if (a.bias) qb = ldp(a.bias + idx0 + 8 * h);
+        if (rr) qr = ldp(rr + idx0 + 8 * h);
+        const f32x2 sc = {a.scale, a.scale};
+        f32x2 o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = f32x2{v[8 * h + 2 * r], v[8 * h + 2 * r + 1]} * sc;
+        if (a.post) mul8p(o, qp);
+        if (a.bias) add8p(o, qb);
+        if (rr) add8p(o, qr);
+        reinterpret_cast<uint4*>(yr + idx0)[h] = had::pack8p(o);
+      }
+    } else {
+#pragma unroll 1
+      for (int r = 0; r < 16; ++r) {
+        const int idx = idx0 + r;
+        if (idx < a.out_features)
+          yr[idx] = had::out_elem(v[r], a.scale, a.post != nullptr, a.post ? (float)a.post[idx] : 0.f,
+                                  a.bias != nullptr, a.bias ? (float)a.bias[idx] : 0.f, rr != nullptr,
+                                  rr ? (float)rr[idx] : 0.f);
+      }
+    }
+  }
+}
+
 // simple LDS radix-2 version for lengths the blocked kernel does not take
 template <bool PLANES>
 __global__ __launch_bounds__(256) void had_small_kernel(HadGroup grp) {
@@ -1021,6 +1096,27 @@ int launch(HadGroup& g, int count, int64_t rows, hipStream_t stream) {
         static DynLdsCache c2[2];
         return planes ? launch_one(had_fast_kernel<true, false, 1024>, c2[0], g, grid, (L / 16) * tg, lds2, stream)
                       : launch_one(had_fast_kernel<false, false, 1024>, c2[1], g, grid, (L / 16) * tg, lds2, stream);
+      }
+    }
+    if ((K == 3 || K == 5 || K == 7) && !planes && rows > 8 && L >= 512 && L <= 4096) {   // batches, small odd K
+      bool ok = true;
+      for (int i = 0; i < count; ++i)
+        ok = ok && g.p[i].vec && g.p[i].vec_out && !g.p[i].rms_w && !g.p[i].z && g.p[i].out_features % 8 == 0;
+      if (ok) {
+        const int lds1 = had::buf_floats(L) * 4;
+        const dim3 grid1(1, (unsigned)rows, count);
+        const int logL = g.p[0].logL;
+        auto go = [&](auto kern) {
+          hipLaunchKernelGGL(kern, grid1, dim3(L / 16), lds1, stream, g);
+          return hipGetLastError() == hipSuccess ? (int)QUIP_OK : (int)QUIP_ERR_LAUNCH;
+        };
+#define QUIP_WIDE_BATCH(KK)                                                                               \
+        return logL == 12 ? go(had_wide_batch_kernel<12, KK>) : logL == 11 ? go(had_wide_batch_kernel<11, KK>) \
+             : logL == 10 ? go(had_wide_batch_kernel<10, KK>) : go(had_wide_batch_kernel<9, KK>)
+        if (K == 3) { QUIP_WIDE_BATCH(3); }
+        if (K == 5) { QUIP_WIDE_BATCH(5); }
+        QUIP_WIDE_BATCH(7);
+#undef QUIP_WIDE_BATCH
       }
     }
     if (K == 1 && !planes && rows >= 32 && (L == 1024 || L == 2048 || L == 4096 || L == 8192)) {   // prefill batches

@@ -415,6 +415,14 @@ def test_e8p_gemv_planes_rows_equal_single_row_gemv(n, k, M):
         assert torch.equal(y[r:r + 1], op.e8p_gemv_planes(pr, qidx, grid)), r
 
 
+@pytest.mark.parametrize("n,rows", [(28672, 40), (14336, 33), (5120, 70), (1536, 64), (12288, 32), (3584, 100)])
+@pytest.mark.parametrize("side", ["in", "out", "both"])
+def test_wide_small_k_hadamard_batches_equal_single_rows(n, rows, side):
+    """prefill batches of K = 3, 5, 7 times a power of two >= 512 (had_wide_batch_kernel: one workgroup per token row
+    reads the K sub-rows once) give bit for bit what the row-parallel launch gives row by row"""
+    test_tall_hadamard_batches_equal_single_rows(n, rows, side)
+
+
 @pytest.mark.parametrize("n,rows", [(11008, 70), (2752, 33), (5504, 64), (11008, 600), (688 * 4, 40)])
 @pytest.mark.parametrize("side", ["in", "out", "both"])
 def test_tall_hadamard_batches_equal_single_rows(n, rows, side):

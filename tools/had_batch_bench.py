@@ -15,7 +15,8 @@ def t(fn, n=10):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n
 op = torch.ops.quip_lib
-for n in (4096, 11008, 1024, 8192):
+sizes = [int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else [4096, 11008, 1024, 8192]
+for n in sizes:
     had, K, _ = get_hadK(n, True)
     hd = None if had is None else had.to(dev).half().contiguous()
     x = torch.randn(rows, n, device=dev).half(); su = torch.ones(n, device=dev).half()
