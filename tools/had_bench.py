@@ -21,7 +21,8 @@ def graph_time(fn, reps=200):
         best = min(best, a.elapsed_time(b) * 1e3 / reps)
     return best
 
-for n in (4096, 11008, 8192, 28672, 1024):
+SIZES = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [4096, 11008, 8192, 28672, 1024]
+for n in SIZES:
     for rand in (True, False):
         try:
             had, K, qn = get_hadK(n, rand)
