@@ -533,7 +533,7 @@ __global__ __launch_bounds__(MAXT) void had_fast_kernel(HadGroup grp) {
 // element whose bit is clear) and the element-wise operations are those of had_fast_kernel, so the results are bit
 // identical to it.  LDS: roundup4(K) (L + L / 32) floats + H = 51 KB at 43 x 256; ~230 VGPRs (the prefetched row and
 // one side's vectors stay in registers).
-// Requires 64 <= L <= 256, K <= 48, vector access, no RMSNorm statistic, vectors of one side only (host-checked).
+// Requires 64 <= L <= 256, K <= 48 (L = 64: K <= 176), n <= 12288, vector access, no RMSNorm statistic, vectors of one side only (host-checked).
 // LDS traffic of this workgroup is complete and visible, nothing else is waited for (the row prefetch stays in flight)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // "these loads have landed" as far as the compiler's wait bookkeeping goes: it places its own s_waitcnt before this
@@ -551,8 +551,8 @@ __device__ __forceinline__ void keep_packed(u32x4 (&q)[3][2]) {
 // SIDE 0: input side (element-wise work before the transform: gate, pre; fp16 = scale * transform after it);
 // SIDE 1: output side (post, bias, residual after it).  One or the other per launch (host-checked): each side keeps
 // its vectors in registers, both together do not fit two workgroups per CU.
-template <int LOGL, int SIDE>
-__global__ __launch_bounds__(256, 2) void had_tall_batch_kernel(HadGroup grp, int rows) {
+template <int LOGL, int SIDE, int RT>
+__global__ __launch_bounds__(256, RT > 3 ? 1 : 2) void had_tall_batch_kernel(HadGroup grp, int rows) {
 #pragma clang fp contract(off)
   const HadArgs a = grp.p[blockIdx.z];
   extern __shared__ __attribute__((aligned(16))) float buf[];
@@ -565,10 +565,13 @@ __global__ __launch_bounds__(256, 2) void had_tall_batch_kernel(HadGroup grp, in
   const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
   const int ksteps = (K + 3) >> 2;
   const int BR = (K + 3) & ~3;                     // buffer rows: inputs k < K, outputs kp < BR (kp >= K are zero)
-  // H as the MFMA's A operand, A[row kq][k] at hs[k * 48 + kq] (fp16 as stored), zero outside (K, K).
+  // H as the MFMA's A operand, A[row kq][k] at hs[k * KP + kq] (fp16 as stored), zero outside (K, K).  RT row tiles of
+  // 16: 3 (K <= 48) or 11 (K <= 176: 11008 = 172 x 64 with the table factors of get_hadK(use_rand=False); 62 KB of H
+  // next to the 45 KB row: one workgroup per CU)
+  constexpr int KP = RT * 16;
   f16* hs = reinterpret_cast<f16*>(buf + had::buf_floats(BR * L));
-  for (int i = tid; i < 48 * 48; i += nt) {
-    const int k = i / 48, kq = i - k * 48;
+  for (int i = tid; i < KP * KP; i += nt) {
+    const int k = i / KP, kq = i - k * KP;
     hs[i] = (kq < K && k < K) ? (a.transpose ? a.had[k * K + kq] : a.had[kq * K + k]) : (f16)0.f;
   }
   const int j0 = (tid * 16) & (L - 1);
@@ -685,41 +688,41 @@ __global__ __launch_bounds__(256, 2) void had_tall_batch_kernel(HadGroup grp, in
     //     k step one A read per row tile feeds all of them, and the 3 x tiles MFMAs of a step (>= 96 cycles of
     //     matrix-core time) cover the LDS latency of the next step's operands.
     {
-      f32x4 acc[tpw][3];
+      f32x4 acc[tpw][RT];
 #pragma unroll
       for (int t = 0; t < tpw; ++t)
 #pragma unroll
-        for (int rt = 0; rt < 3; ++rt) acc[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int rt = 0; rt < RT; ++rt) acc[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
       // operands of step ks + 1 are requested before the MFMAs of step ks (the loop is not unrolled by the compiler:
       // left alone every step waits for its own LDS reads)
-      f16 ah[3];
+      f16 ah[RT];
       float bv[tpw];
-      auto operands = [&](int ks, f16 (&ah_)[3], float (&bv_)[tpw]) {
+      auto operands = [&](int ks, f16 (&ah_)[RT], float (&bv_)[tpw]) {
         const int k = min(4 * ks + lq, K - 1);
 #pragma unroll
-        for (int rt = 0; rt < 3; ++rt) ah_[rt] = hs[(4 * ks + lq) * 48 + rt * 16 + lr];
+        for (int rt = 0; rt < RT; ++rt) ah_[rt] = hs[(4 * ks + lq) * KP + rt * 16 + lr];
 #pragma unroll
         for (int t = 0; t < tpw; ++t) bv_[t] = mixcol[k * RS + 66 * t];
       };
       operands(0, ah, bv);
 #pragma unroll 1
       for (int ks = 0; ks < ksteps; ++ks) {
-        f16 an[3];
+        f16 an[RT];
         float bn[tpw];
         operands(min(ks + 1, ksteps - 1), an, bn);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < tpw; ++t)
 #pragma unroll
-          for (int rt = 0; rt < 3; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)ah[rt], bv[t], acc[t][rt], 0, 0, 0);
+          for (int rt = 0; rt < RT; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)ah[rt], bv[t], acc[t][rt], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int rt = 0; rt < 3; ++rt) ah[rt] = an[rt];
+        for (int rt = 0; rt < RT; ++rt) ah[rt] = an[rt];
 #pragma unroll
         for (int t = 0; t < tpw; ++t) bv[t] = bn[t];
       }
 #pragma unroll
-      for (int rt = 0; rt < 3; ++rt) {
+      for (int rt = 0; rt < RT; ++rt) {
         float* const orow4 = mixcol + 4 * lq * RS;             // output rows rt 16 + 4 lq + i
         if (rt * 16 + 4 * lq < BR) {                           // BR is a multiple of 4: all four rows or none
 #pragma unroll
@@ -1021,7 +1024,7 @@ int launch(HadGroup& g, int count, int64_t rows, hipStream_t stream) {
     // that two workgroups share a CU (one at a time made prefill throughput = workgroup latency)
     const bool batch = rows > 8;
     {   // prefill batches: one workgroup per row at a time (had_tall_batch_kernel)
-      bool ok = rows >= 32 && K <= 48 && !planes;
+      bool ok = rows >= 32 && (K <= 48 || (K <= 176 && L == 64)) && n <= 12288 && !planes;
       for (int i = 0; i < count; ++i)
         ok = ok && g.p[i].vec && g.p[i].vec_out && !g.p[i].rms_w && !g.p[i].pre2 && !g.p[i].z && g.p[i].out_features % 8 == 0;
       // element-wise vectors of one side only (input: gate, pre; output: post, bias, residual), see the kernel
@@ -1032,11 +1035,12 @@ int launch(HadGroup& g, int count, int64_t rows, hipStream_t stream) {
       }
       ok = ok && !(in_side && out_side);
       if (ok) {
-        static DynLdsCache cfgb[6];
+        static DynLdsCache cfgb[8];
         const int BR = (K + 3) & ~3;
-        const int lds = had::buf_floats(BR * L) * 4 + 48 * 48 * 2;
+        const int KP = K <= 48 ? 48 : 176;
+        const int lds = had::buf_floats(BR * L) * 4 + KP * KP * 2;
         const int threads = 256;
-        const int64_t want = 2 * (int64_t)device_cu_count();       // two resident workgroups per CU
+        const int64_t want = (K <= 48 ? 2 : 1) * (int64_t)device_cu_count();       // resident workgroups per CU
         const dim3 grid((unsigned)(rows < want ? rows : want), 1, count);
         auto go = [&](auto kern, DynLdsCache& cache) {
           if (ensure_dyn_lds(cache, reinterpret_cast<const void*>(kern), lds) != QUIP_OK) return (int)QUIP_ERR_LAUNCH;
@@ -1044,10 +1048,11 @@ int launch(HadGroup& g, int count, int64_t rows, hipStream_t stream) {
           return hipGetLastError() == hipSuccess ? (int)QUIP_OK : (int)QUIP_ERR_LAUNCH;
         };
         const int logL = g.p[0].logL;
-        if (!in_side) return logL == 8 ? go(had_tall_batch_kernel<8, 1>, cfgb[0]) : logL == 7 ? go(had_tall_batch_kernel<7, 1>, cfgb[1])
-                                                                                               : go(had_tall_batch_kernel<6, 1>, cfgb[2]);
-        return logL == 8 ? go(had_tall_batch_kernel<8, 0>, cfgb[3]) : logL == 7 ? go(had_tall_batch_kernel<7, 0>, cfgb[4])
-                                                                                 : go(had_tall_batch_kernel<6, 0>, cfgb[5]);
+        if (K > 48) return in_side ? go(had_tall_batch_kernel<6, 0, 11>, cfgb[6]) : go(had_tall_batch_kernel<6, 1, 11>, cfgb[7]);
+        if (!in_side) return logL == 8 ? go(had_tall_batch_kernel<8, 1, 3>, cfgb[0]) : logL == 7 ? go(had_tall_batch_kernel<7, 1, 3>, cfgb[1])
+                                                                                                  : go(had_tall_batch_kernel<6, 1, 3>, cfgb[2]);
+        return logL == 8 ? go(had_tall_batch_kernel<8, 0, 3>, cfgb[3]) : logL == 7 ? go(had_tall_batch_kernel<7, 0, 3>, cfgb[4])
+                                                                                    : go(had_tall_batch_kernel<6, 0, 3>, cfgb[5]);
       }
     }
     const int pp = had::buf_floats(4096) + ((K + 3) & ~3) * R + K * (L + 8);

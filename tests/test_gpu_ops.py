@@ -423,15 +423,23 @@ def test_wide_small_k_hadamard_batches_equal_single_rows(n, rows, side):
     test_tall_hadamard_batches_equal_single_rows(n, rows, side)
 
 
+@pytest.mark.parametrize("n,rows", [(11008, 40), (11008, 300), (5120, 64), (2752, 33)])
+@pytest.mark.parametrize("side", ["in", "out"])
+def test_tall_hadamard_batches_with_table_factors(n, rows, side):
+    """the +-1 factors of get_hadK(use_rand=False): 11008 = 172 x 64 (eleven row tiles of H in the batch kernel),
+    5120 = 20 x 256, 2752 = 172 x 16 (not the batch kernel's: row-parallel launch) -- batch rows equal single rows"""
+    test_tall_hadamard_batches_equal_single_rows(n, rows, side, use_rand=False)
+
+
 @pytest.mark.parametrize("n,rows", [(11008, 70), (2752, 33), (5504, 64), (11008, 600), (688 * 4, 40)])
 @pytest.mark.parametrize("side", ["in", "out", "both"])
-def test_tall_hadamard_batches_equal_single_rows(n, rows, side):
+def test_tall_hadamard_batches_equal_single_rows(n, rows, side, use_rand=True):
     """prefill batches of the tall transform (one workgroup per row, K-mix in place: had_tall_batch_kernel) give
     bit for bit what the latency-shaped launch gives row by row; input side with gate / pre-scale, output side with
     post-scale / bias / residual and a ragged out_features"""
     from quip_for_all_amd.quant import get_hadK
     torch.manual_seed(n + rows)
-    had, K, qn = get_hadK(n, True)
+    had, K, qn = get_hadK(n, use_rand)
     assert qn == n and K > 1
     hd = had.to(DEV).half().contiguous()
     op = torch.ops.quip_lib

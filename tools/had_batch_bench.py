@@ -15,9 +15,11 @@ def t(fn, n=10):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n
 op = torch.ops.quip_lib
+RAND = not (len(sys.argv) > 3 and sys.argv[3] == 'tables')   # 'tables': get_hadK(use_rand=False) factors
 sizes = [int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else [4096, 11008, 1024, 8192]
 for n in sizes:
-    had, K, _ = get_hadK(n, True)
+    had, K, qn = get_hadK(n, RAND)
+    if qn != n: continue
     hd = None if had is None else had.to(dev).half().contiguous()
     x = torch.randn(rows, n, device=dev).half(); su = torch.ones(n, device=dev).half()
     ti = t(lambda: op.had_transform_fused(x, n, n, K, hd, True, su, None, None, None, 1.0 / math.sqrt(n // K), None, None, 1e-5, None))
