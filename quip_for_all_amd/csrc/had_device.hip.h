@@ -363,11 +363,14 @@ __device__ __forceinline__ int shift_for(float bound) {
 }
 
 __device__ __forceinline__ float absmax16(const float v[16], float scale) {
+#pragma clang fp contract(off)
   float mx = 0.f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const float a = fabsf(fmul(v[r], scale));
+  for (int r = 0; r < 16; r += 2) {   // the products two at a time (v_pk_mul_f32: fmul's rounding)
+    const f32x2 p = f32x2{v[r], v[r + 1]} * f32x2{scale, scale};
+    const float a = fabsf(p.x), b = fabsf(p.y);
     mx = fmaxf(mx, a == a ? a : __builtin_inff());
+    mx = fmaxf(mx, b == b ? b : __builtin_inff());
   }
   return mx;
 }
@@ -383,14 +386,17 @@ __device__ __forceinline__ uint32_t low_bytes4(int a, int b, int c, int d) {
   return lo | hi;
 }
 __device__ __forceinline__ void planes16(const float v[16], float scale, int sh, uint4 out[3]) {
+#pragma clang fp contract(off)
   const float s2 = fmul(scale, as_f32((uint32_t)(sh + 127) << 23));
   uint32_t dg[3][4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     int X[4], X1[4], H[4];
+    const f32x2 p01 = f32x2{v[4 * g], v[4 * g + 1]} * f32x2{s2, s2}, p23 = f32x2{v[4 * g + 2], v[4 * g + 3]} * f32x2{s2, s2};
+    const float pr[4] = {p01.x, p01.y, p23.x, p23.y};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      X[i] = (int)__builtin_rintf(fmul(v[4 * g + i], s2));
+      X[i] = (int)__builtin_rintf(pr[i]);
       X1[i] = (X[i] + 128) >> 8;
       H[i] = (X1[i] + 128) >> 8;
     }
