@@ -20,8 +20,9 @@ from .quant import get_hadK, matmul_hadU_cuda
 
 
 class QuantLinear(nn.Module):
-    # E8P12 / E8P12RVQ4B forwards with 2 .. skinny_max_rows rows take the matrix-core rows-mode GEMV (passes of up to 5
-    # rows over the codes); more rows (< 32) the generic fused mm, >= 32 decompress + dense GEMM
+    # forwards with 2 .. skinny_max_rows rows take the small-batch kernels (rows mode of the matrix-core GEMV, the
+    # single-pass skinny kernel: see skinny_exact below); more rows go to the codebook's batched product (E8P12: chunked
+    # skinny kernel / fused dequant MFMA GEMM; the other codebooks: decompress + dense GEMM)
     skinny_max_rows = int(os.environ.get("QUIP_SKINNY_MAX_ROWS", "31"))
     # 1 < M < 32 rows.  As long as ONE pass of rows mode carries them (5 rows for k <= 4096, 3 for k <= 8192, ...) the
     # exact integer path is used: every row bit identical to its bs=1 result.  More rows: E8P12 takes the single-pass
