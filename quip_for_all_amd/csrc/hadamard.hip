@@ -551,8 +551,8 @@ __device__ __forceinline__ void keep_packed(u32x4 (&q)[3][2]) {
 // SIDE 0: input side (element-wise work before the transform: gate, pre; fp16 = scale * transform after it);
 // SIDE 1: output side (post, bias, residual after it).  One or the other per launch (host-checked): each side keeps
 // its vectors in registers, both together do not fit two workgroups per CU.
-template <int LOGL, int SIDE, int RT>
-__global__ __launch_bounds__(256, RT > 3 ? 1 : 2) void had_tall_batch_kernel(HadGroup grp, int rows) {
+template <int LOGL, int SIDE, int RT, bool PAIR>
+__global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2) void had_tall_batch_kernel(HadGroup grp, int rows) {
 #pragma clang fp contract(off)
   const HadArgs a = grp.p[blockIdx.z];
   extern __shared__ __attribute__((aligned(16))) float buf[];
@@ -561,7 +561,10 @@ __global__ __launch_bounds__(256, RT > 3 ? 1 : 2) void had_tall_batch_kernel(Had
   constexpr int ctiles = L >> 4, tpw = ctiles / nw;   // column tiles per wave: 4 (L = 256), 2 (128), 1 (64)
   constexpr int rr = (nt * 16) >> LOGL;             // rows per transform round (4096 elements)
   constexpr int round_floats = nt * 16 + ((nt * 16) >> 5);
-  const int tid = threadIdx.x, K = a.K;
+  // PAIR: two groups of 256 threads in one workgroup, each with its own row buffer, sharing H (K > 48: two workgroups
+  // with their own 62 KB of H do not fit a CU); group 1 runs one phase behind group 0 (see the row loop)
+  constexpr int G = PAIR ? 2 : 1;
+  const int tid = threadIdx.x & 255, half = PAIR ? threadIdx.x >> 8 : 0, K = a.K;
   const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
   const int ksteps = (K + 3) >> 2;
   const int BR = (K + 3) & ~3;                     // buffer rows: inputs k < K, outputs kp < BR (kp >= K are zero)
@@ -569,8 +572,10 @@ __global__ __launch_bounds__(256, RT > 3 ? 1 : 2) void had_tall_batch_kernel(Had
   // 16: 3 (K <= 48) or 11 (K <= 176: 11008 = 172 x 64 with the table factors of get_hadK(use_rand=False); 62 KB of H
   // next to the 45 KB row: one workgroup per CU)
   constexpr int KP = RT * 16;
-  f16* hs = reinterpret_cast<f16*>(buf + had::buf_floats(BR * L));
-  for (int i = tid; i < KP * KP; i += nt) {
+  const int RowF = (had::buf_floats(BR * L) + 3) & ~3;
+  float* const gbuf = buf + half * RowF;
+  f16* hs = reinterpret_cast<f16*>(buf + G * RowF);
+  for (int i = threadIdx.x; i < KP * KP; i += G * nt) {
     const int k = i / KP, kq = i - k * KP;
     hs[i] = (kq < K && k < K) ? (a.transpose ? a.had[k * K + kq] : a.had[kq * K + k]) : (f16)0.f;
   }
@@ -578,9 +583,9 @@ __global__ __launch_bounds__(256, RT > 3 ? 1 : 2) void had_tall_batch_kernel(Had
   // LDS addresses as `lane base + compile-time offset` (pad(a + b) = pad(a) + pad(b) when a is a multiple of 32 --
   // written out, because the compiler keeps every pad(...) of the loops below in a register of its own otherwise)
   constexpr int RS = L + (L >> 5);                       // floats per buffer row
-  float* const stage = buf + tid * 16 + (tid >> 1);      // pad(16 tid); + round_floats per 4096 elements
+  float* const stage = gbuf + tid * 16 + (tid >> 1);      // pad(16 tid); + round_floats per 4096 elements
   const int cb = wave * 16 + lr;                         // column of this lane in its first tile; tile t: + 64 t
-  float* const mixcol = buf + cb + (cb >> 5);            // pad(cb); tile t: + 66 t, row k: + k RS
+  float* const mixcol = gbuf + cb + (cb >> 5);            // pad(cb); tile t: + 66 t, row k: + k RS
   // this thread's pieces of a row, input side: 16-element chunks tid, tid + 256, tid + 512 (n <= 48 x 256 =
   // 3 x 4096) at 32-bit byte offsets (requests are `uniform row base + lane offset`); output side: the 16 columns
   // from j0 of row rd rr + (16 tid >> LOGL), round rd = 0, 1, 2
@@ -624,7 +629,9 @@ __global__ __launch_bounds__(256, RT > 3 ? 1 : 2) void had_tall_batch_kernel(Had
       }
     }
   };
-  if ((int)blockIdx.x < rows) fetch(blockIdx.x);
+  // rows vw, vw + stride, ... of this group; both groups run the same number of iterations (barriers are workgroup wide)
+  const int vw = blockIdx.x * G + half, stride = G * gridDim.x, iters = (rows + stride - 1) / stride;
+  if (vw < rows) fetch(vw);
   // the loop starts with nothing pending (see landed())
   landed(xq);
   if (SIDE == 0) { landed(gq); landed(pq); } else { landed(qpost); landed(qbias); }
@@ -634,10 +641,18 @@ __global__ __launch_bounds__(256, RT > 3 ? 1 : 2) void had_tall_batch_kernel(Had
 #else
 #define TSTAMP(i) do {} while (0)
 #endif
-  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+  // Phases per row: (1) stage, (2) K-mix on the matrix cores, (3) transform + epilogue, a barrier after each.  In a
+  // PAIR group 1 enters one barrier late, so its phase p runs beside group 0's phase p + 1.  (That the K-mix of one
+  // group -- matrix cores, hardly any VALU -- would hide behind the butterflies of the other did not happen: at K = 43
+  // the paired form is as fast as two independent workgroups per CU, 0.59 / 0.67 ms; the counters of either show the
+  // matrix cores busy 42 %, VALU 36 %, LDS 28 % of the time, adding up instead of overlapping.)
+  if (PAIR && half) lds_barrier();
+  for (int it = 0; it < iters; ++it) {
+    const int row = vw + it * stride;
+    const bool valid = row < rows;
     f16* yr = a.y + (int64_t)row * a.out_features;
     const f16* rr_ = a.residual ? a.residual + (int64_t)row * a.out_features : nullptr;
-    if (SIDE == 1 && rr_) {
+    if (SIDE == 1 && rr_ && valid) {
 #pragma unroll
       for (int rd = 0; rd < 3; ++rd)
         if (whole[rd]) {
@@ -652,7 +667,7 @@ __global__ __launch_bounds__(256, RT > 3 ? 1 : 2) void had_tall_batch_kernel(Had
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int idx0 = (tid + i * nt) * 16;
-      if (idx0 < a.n) {
+      if (idx0 < a.n && valid) {
         float* dst = stage + i * round_floats;   // pad(idx0): 16 elements inside one 32-block, constant pad offset
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -680,14 +695,14 @@ __global__ __launch_bounds__(256, RT > 3 ? 1 : 2) void had_tall_batch_kernel(Had
       }
     }
     __builtin_amdgcn_sched_barrier(0);   // (hoisted above the arithmetic, the requests would need a second set of registers)
-    if (row + (int)gridDim.x < rows) fetch(row + gridDim.x);   // lands during phase 2
+    if (row + stride < rows) fetch(row + stride);   // lands during phase 2
     TSTAMP(0);
     lds_barrier();
     TSTAMP(1);
     // (2) K-mix on the matrix cores, in place per column tile.  A wave runs its (<= 4) column tiles TOGETHER: per
     //     k step one A read per row tile feeds all of them, and the 3 x tiles MFMAs of a step (>= 96 cycles of
     //     matrix-core time) cover the LDS latency of the next step's operands.
-    {
+    if (valid) {
       f32x4 acc[tpw][RT];
 #pragma unroll
       for (int t = 0; t < tpw; ++t)
@@ -741,7 +756,7 @@ __global__ __launch_bounds__(256, RT > 3 ? 1 : 2) void had_tall_batch_kernel(Had
     // (3) + (4): length-L transform of the K rows and the epilogue, 4096 elements at a time
 #pragma unroll
     for (int rd = 0; rd < 3; ++rd) {
-      if (rd * rr < K) {
+      if (rd * rr < K && valid) {
         const int kp = rd * rr + ((tid * 16) >> LOGL);
         const bool live = kp < K;
         const float* hb = live ? stage + rd * round_floats : stage;
@@ -780,8 +795,9 @@ __global__ __launch_bounds__(256, RT > 3 ? 1 : 2) void had_tall_batch_kernel(Had
     lds_barrier();   // the buffer is restaged for the next row
     TSTAMP(5);
   }
+  if (PAIR && !half) lds_barrier();   // (group 1's last phase)
 #ifdef QUIP_HAD_STAMPS
-  if (tid == 0 && blockIdx.x == 0 && blockIdx.z == 0)
+  if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.z == 0)
     for (int i = 0; i < 6; ++i) g_had_stamps[8 + i] = tacc[i];
 #endif
 }
@@ -1038,21 +1054,22 @@ int launch(HadGroup& g, int count, int64_t rows, hipStream_t stream) {
         static DynLdsCache cfgb[8];
         const int BR = (K + 3) & ~3;
         const int KP = K <= 48 ? 48 : 176;
-        const int lds = had::buf_floats(BR * L) * 4 + KP * KP * 2;
-        const int threads = 256;
-        const int64_t want = (K <= 48 ? 2 : 1) * (int64_t)device_cu_count();       // resident workgroups per CU
-        const dim3 grid((unsigned)(rows < want ? rows : want), 1, count);
+        const bool pair = K > 48;   // two rows in flight in ONE workgroup per CU (they share the 62 KB of H); else two workgroups
+        const int lds = (pair ? 2 : 1) * ((had::buf_floats(BR * L) + 3) & ~3) * 4 + KP * KP * 2;
+        const int threads = pair ? 512 : 256;
+        const int64_t want = (pair ? 1 : 2) * (int64_t)device_cu_count(), units = pair ? (rows + 1) / 2 : rows;
+        const dim3 grid((unsigned)(units < want ? units : want), 1, count);
         auto go = [&](auto kern, DynLdsCache& cache) {
           if (ensure_dyn_lds(cache, reinterpret_cast<const void*>(kern), lds) != QUIP_OK) return (int)QUIP_ERR_LAUNCH;
           hipLaunchKernelGGL(kern, grid, dim3(threads), lds, stream, g, (int)rows);
           return hipGetLastError() == hipSuccess ? (int)QUIP_OK : (int)QUIP_ERR_LAUNCH;
         };
         const int logL = g.p[0].logL;
-        if (K > 48) return in_side ? go(had_tall_batch_kernel<6, 0, 11>, cfgb[6]) : go(had_tall_batch_kernel<6, 1, 11>, cfgb[7]);
-        if (!in_side) return logL == 8 ? go(had_tall_batch_kernel<8, 1, 3>, cfgb[0]) : logL == 7 ? go(had_tall_batch_kernel<7, 1, 3>, cfgb[1])
-                                                                                                  : go(had_tall_batch_kernel<6, 1, 3>, cfgb[2]);
-        return logL == 8 ? go(had_tall_batch_kernel<8, 0, 3>, cfgb[3]) : logL == 7 ? go(had_tall_batch_kernel<7, 0, 3>, cfgb[4])
-                                                                                    : go(had_tall_batch_kernel<6, 0, 3>, cfgb[5]);
+        if (K > 48) return in_side ? go(had_tall_batch_kernel<6, 0, 11, true>, cfgb[6]) : go(had_tall_batch_kernel<6, 1, 11, true>, cfgb[7]);
+        if (!in_side) return logL == 8 ? go(had_tall_batch_kernel<8, 1, 3, false>, cfgb[0]) : logL == 7 ? go(had_tall_batch_kernel<7, 1, 3, false>, cfgb[1])
+                                                                                                  : go(had_tall_batch_kernel<6, 1, 3, false>, cfgb[2]);
+        return logL == 8 ? go(had_tall_batch_kernel<8, 0, 3, false>, cfgb[3]) : logL == 7 ? go(had_tall_batch_kernel<7, 0, 3, false>, cfgb[4])
+                                                                                    : go(had_tall_batch_kernel<6, 0, 3, false>, cfgb[5]);
       }
     }
     const int pp = had::buf_floats(4096) + ((K + 3) & ~3) * R + K * (L + 8);
