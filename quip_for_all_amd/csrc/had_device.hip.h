@@ -289,7 +289,9 @@ __device__ __forceinline__ void fht16_passes(float v[16], float* buf, int stride
   if constexpr (P == 0 && LOGL > 4) {
     // passes 0 and 1 without LDS (fht16_lanes); longer transforms hand over in natural order -- pass 0's store
     // mapping -- in the half pass 1 would have written
+    if constexpr (NPASS <= 2) __syncthreads();   // callers order their own LDS data (reduction slots, staged rows) across this call
     fht16_lanes<LOGL>(v, t);
+    if constexpr (NPASS <= 2) __syncthreads();
     if constexpr (NPASS > 2) {
       float* cur = PP ? buf + stride : buf;
       __syncthreads();   // the buffer's earlier readers are done
