@@ -1,0 +1,299 @@
+// Decode core shared by the matrix-core GEMV (e8p_gemv_mfma.hip) and the persistent decode engine
+// (decode_engine.hip): LDS table layout, table build, code -> LDS address arithmetic and the eight
+// v_mfma_i32_16x16x64_i8 steps of one item (16 weight rows x 512 k).  See e8p_gemv_mfma.hip for the
+// arithmetic and the mapping; everything here is internal linkage (each translation unit gets its own copy).
+#pragma once
+#include "had_device.hip.h"
+#include "quip_internal.h"
+#include <type_traits>
+
+#ifndef QUIP_GEMV_R8
+#define QUIP_GEMV_R8 0
+#endif
+#ifndef QUIP_GEMV_PIPE
+#define QUIP_GEMV_PIPE 4
+#endif
+
+namespace quip {
+namespace {
+
+constexpr bool kR8 = QUIP_GEMV_R8 != 0;
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) u32x2* lds_u2_ptr;
+typedef const __attribute__((address_space(3))) i32x4* lds_i4_ptr;
+
+constexpr int kMaxRowsPerBlock = 256;  // int32 accumulator rows per workgroup
+
+// LDS map.  REP = 32 copies per table entry (ds_read_b64 conflict free) when the x image
+// is small enough (K <= 8192), REP = 16 (two-way conflicts on average, half the
+// footprint) for longer rows so that the digit planes of the WHOLE row stay resident.
+template <int REP>
+struct Lds {
+  // REP = 32 / 16: both tables with that many copies; REP = 24: T1 x 32 (conflict free), T2 x 16
+  // REP = 64: the D4 codebook -- ONE table of 256 x 4-byte entries (2w of the code's 4 weights as int8),
+  //           64 copies (a private copy per lane: no conflicts), no sign table
+  // REP = 40 / 20: E8P12RVQ3B -- the E8P tables (32 / 16 copies of T1, 16 of T2) plus T3 = the 256 x 8-byte
+  //           E81B residual table (4r as int8; 16 / 8 copies), looked up by the LOW code of every dword; the
+  //           weight stream is the checkpoint's own 3-byte codes (12-byte loads, 3 k / 8 bytes per row)
+  static constexpr bool kD4 = REP == 64;
+  static constexpr bool kRvq3 = REP == 40 || REP == 20;
+  static constexpr int kRep1 = kD4 ? 64 : ((REP == 16 || REP == 20) ? 16 : 32);
+  static constexpr int kRep2 = REP == 32 ? 32 : 16;
+  static constexpr int kRep3 = REP == 40 ? 16 : (REP == 20 ? 8 : 0);
+  static constexpr int kRow1 = kRep1 * (kD4 ? 4 : 8);   // bytes per T1 entry row
+  static constexpr int kRow2 = kD4 ? 0 : kRep2 * 8;     // bytes per T2 entry row
+  static constexpr int kRow3 = kRep3 * 8;               // bytes per T3 entry row
+  static constexpr int kT1 = 0;
+  static constexpr int kT2 = 256 * kRow1;
+  static constexpr int kT3 = kT2 + 256 * kRow2;
+  static constexpr int kAcc = kT3 + 256 * kRow3;     // int32 [kMaxRowsPerBlock][4]
+  static constexpr int kX = kAcc + kMaxRowsPerBlock * 16;   // 3 planes x Kp bytes
+  static constexpr int kMaxKp = (160 * 1024 - kX) / 3 / 512 * 512;
+  static int bytes(int kp, int g = 1) { return kX + 3 * kp * g; }
+  // fused prologue: + the Hadamard shuffle buffer (fp32, padded) and 16 reduction words
+  static int bytes_fused(int kp, int g) { return kX + 3 * kp * g + (had::buf_floats(kp) + 16) * 4; }
+};
+static_assert(Lds<32>::kMaxKp >= 8192 && Lds<16>::kMaxKp >= 28672, "LDS budget");
+static_assert(Lds<40>::kMaxKp >= 8192 && Lds<20>::kMaxKp >= 22528, "LDS budget (RVQ3: 2 x 4096, 2 x 11008)");
+
+__device__ __forceinline__ uint2 lds_read8(uint32_t addr) {
+  const u32x2 v = *reinterpret_cast<lds_u2_ptr>((uintptr_t)addr);
+  return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ i32x4 lds_read16i(uint32_t addr) {
+  return *reinterpret_cast<lds_i4_ptr>((uintptr_t)addr);
+}
+
+// compile-time image of the sign table (see e8p_gemv_i8.hip)
+struct T2Image {
+  uint2 v[256];
+  constexpr T2Image() : v{} {
+    for (int s = 0; s < 256; ++s) {
+      int par = 0;
+      for (int b = 0; b < 8; ++b) par ^= (s >> b) & 1;
+      const int sv = s ^ par;
+      uint32_t lo = 0, hi = 0;
+      for (int p = 0; p < 4; ++p) {
+        lo |= (((sv >> (7 - e8p_byte_of_pos(p))) & 1) ? 0xfcu : 0u) << (8 * p);
+        hi |= (((sv >> (7 - e8p_byte_of_pos(p + 4))) & 1) ? 0xfcu : 0u) << (8 * p);
+      }
+      const uint32_t sh = par ? 0x02020202u : 0u;
+      v[s].x = lo ^ sh;
+      v[s].y = hi ^ sh;
+    }
+  }
+};
+__device__ const T2Image kT2Img{};
+
+// T1 entry from grid_packed_abs[e]: natural position order (bytes 0,2,1,3 / 4,6,5,7), OR 1
+__device__ __forceinline__ uint2 t1_entry(uint2 packed) {
+  return make_uint2(__builtin_amdgcn_perm(0u, packed.x, 0x03010200u) | 0x01010101u,
+                    __builtin_amdgcn_perm(0u, packed.y, 0x03010200u) | 0x01010101u);
+}
+
+// LDS tables: wave w < 8 owns table rows [32 w, 32 w + 32); lane l holds
+// the 8-byte source of row 32 w + (l & 31) -- T1 source (grid_packed_abs) in lanes 0..31, T2 image in
+// lanes 32..63 -- fetched with ONE vector load issued as the very first load of the kernel, and
+// writes it REP times into its own row, copy (l + c) mod REP at step c: the lanes of a half-wave
+// hit REP distinct bank pairs per step (no broadcast through SGPRs, no scalar-load latency chain).
+__device__ __forceinline__ const uint2* table_source_ptr(const uint64_t* grid, int lane, int wave) {
+  const int e = (wave & 7) * 32 + (lane & 31);
+  const uint2* t1 = reinterpret_cast<const uint2*>(grid) + e;
+  const uint2* t2 = &kT2Img.v[e];
+  return (lane & 32) ? t2 : t1;
+}
+// D4: `grid` is the fp16 (256, 4) table (d4.py:26-96); every lane reads entry 32 w + (l & 31) (8 bytes)
+__device__ __forceinline__ const uint2* table_source_ptr_d4(const uint64_t* grid, int lane, int wave) {
+  return reinterpret_cast<const uint2*>(grid) + ((wave & 7) * 32 + (lane & 31));
+}
+// RVQ3: T3 row 32 w + (l & 31) from this lane's 8-byte E81B entry; lanes l and l + 32 share a row and
+// write the two halves of its copies
+template <int REP>
+__device__ __forceinline__ void fill_t3_from_lane(char* smem, const u32x2& src, int lane, int wave) {
+  using L = Lds<REP>;
+  if constexpr (L::kRvq3) {
+    const uint32_t rowbase = (uint32_t)L::kT3 + (uint32_t)(wave * 32 + (lane & 31)) * L::kRow3;
+    constexpr int half = L::kRep3 / 2;
+#pragma unroll
+    for (int c = 0; c < half; ++c) {
+      const uint32_t copy = (((uint32_t)(lane + c)) & (uint32_t)(half - 1)) + ((lane & 32) ? half : 0);
+      *reinterpret_cast<__attribute__((address_space(3))) u32x2*>((uintptr_t)(rowbase + copy * 8)) = src;
+    }
+  }
+}
+
+template <int REP>
+__device__ __forceinline__ void fill_tables_from_lane(char* smem, const u32x2& src, int lane, int wave) {
+  using L = Lds<REP>;
+  if constexpr (L::kD4) {
+    // 4 fp16 half-integers -> int8 2w; lanes l and l + 32 hold the same entry and write copies
+    // [0, 32) resp. [32, 64) of its row, rotating so that a step touches 32 distinct banks
+    const f16x2 lo = as_f16x2(src.x), hi = as_f16x2(src.y);
+    const int b0 = (int)(2.f * (float)lo.x), b1 = (int)(2.f * (float)lo.y);
+    const int b2 = (int)(2.f * (float)hi.x), b3 = (int)(2.f * (float)hi.y);
+    const uint32_t val = (uint32_t)(b0 & 0xff) | ((uint32_t)(b1 & 0xff) << 8) | ((uint32_t)(b2 & 0xff) << 16) |
+                         ((uint32_t)(b3 & 0xff) << 24);
+    const uint32_t rowbase = (uint32_t)L::kT1 + (uint32_t)(wave * 32 + (lane & 31)) * L::kRow1 + (uint32_t)(lane & 32) * 4;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      const uint32_t copy = (uint32_t)(lane + c) & 31u;
+      *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>((uintptr_t)(rowbase + copy * 4)) = val;
+    }
+    return;
+  }
+  const bool second = (lane & 32) != 0;
+  const uint2 raw = make_uint2(src.x, src.y);
+  const uint2 t1 = t1_entry(raw);
+  const u32x2 val = {second ? raw.x : t1.x, second ? raw.y : t1.y};
+  const uint32_t row = (uint32_t)(wave * 32 + (lane & 31));
+  const uint32_t rowbase = second ? (uint32_t)L::kT2 + row * L::kRow2 : (uint32_t)L::kT1 + row * L::kRow1;
+  const uint32_t mask = second ? (L::kRep2 - 1) : (L::kRep1 - 1);
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    if (c < L::kRep1 || c < L::kRep2) {
+      const uint32_t copy = (uint32_t)(lane + c) & mask;
+      if (c < (second ? L::kRep2 : L::kRep1))
+        *reinterpret_cast<__attribute__((address_space(3))) u32x2*>((uintptr_t)(rowbase + copy * 8)) = val;
+    }
+  }
+}
+
+// 16 codes of this lane -> eight MFMAs, in two steps so that the caller can reload the
+// slot registers between them: item_addresses() consumes the codes completely (32 LDS
+// addresses), item_mfma() runs the table / x reads PIPE steps ahead of their MFMA.
+struct ItemAddr { uint32_t a1l[8], a2l[8], a1h[8], a2h[8]; };
+
+// E8P12RVQ3B: a checkpoint code is 3 bytes [resid8, e8p_lo, e8p_hi] (e8p12_rvq3.py:81-107); the decode below works
+// on dwords (main16 << 16 | resid8 << 8), i.e. the same three bytes behind a zero byte.  A lane's 12 landed bytes =
+// four codes: one shift, two v_perm_b32 and one mask.
+__device__ __forceinline__ u32x4 rvq3_dwords(const u32x3& w) {
+  return u32x4{w.x << 8, __builtin_amdgcn_perm(w.y, w.x, 0x0504030cu), __builtin_amdgcn_perm(w.z, w.y, 0x0403020cu),
+               w.z & 0xffffff00u};
+}
+
+template <int REP>
+__device__ __forceinline__ void item_addresses(const u32x4& q0, const u32x4& q1, uint32_t lane_c,
+                                               uint32_t lane_c2, ItemAddr& ad, uint32_t lane_c3 = 0);
+template <int REP>
+__device__ __forceinline__ void item_addresses(const u32x3& q0, const u32x3& q1, uint32_t lane_c,
+                                               uint32_t lane_c2, ItemAddr& ad, uint32_t lane_c3 = 0) {
+  item_addresses<REP>(rvq3_dwords(q0), rvq3_dwords(q1), lane_c, lane_c2, ad, lane_c3);
+}
+template <int REP>
+__device__ __forceinline__ void item_addresses(const u32x4& q0, const u32x4& q1, uint32_t lane_c,
+                                               uint32_t lane_c2, ItemAddr& ad, uint32_t lane_c3) {
+  const uint32_t d[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+  if constexpr (REP == 64) {
+    // D4: dword t = 4 one-byte codes = the 16 weights of MFMA step t; entry address =
+    // code << 8 | lane << 2 (lane_c), one v_perm_b32 per code
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      ad.a1l[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c0c0400u);
+      ad.a2l[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c0c0500u);
+      ad.a1h[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c0c0600u);
+      ad.a2h[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c0c0700u);
+    }
+    return;
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if constexpr (Lds<REP>::kRep1 == 32) {
+      // T1 (32 copies): table_base | idx << 8 | (lane & 31) << 3: byte aligned, one v_perm_b32
+      ad.a1l[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c0c0500u);
+      ad.a1h[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c0c0700u);
+    } else {
+      // 16 copies: table_base | idx << 7 | (lane & 15) << 3: shift + v_and_or_b32
+      ad.a1l[t] = ((d[t] >> 1) & 0x7f80u) | lane_c;
+      ad.a1h[t] = ((d[t] >> 17) & 0x7f80u) | lane_c;
+    }
+    if constexpr (Lds<REP>::kRvq3) {
+      // RVQ3: the low code of the dword is (residual index << 8 | 0) and reads T3 (E81B); its sign byte is 0
+      // and T2[0] == 0, so the generic "T1 ^ T2" below leaves the T3 entry unchanged
+      ad.a1l[t] = Lds<REP>::kRep3 == 16 ? (((d[t] >> 1) & 0x7f80u) | lane_c3) : (((d[t] >> 2) & 0x3fc0u) | lane_c3);
+    }
+    if constexpr (REP == 32) {
+      // T2 base 0x10000 comes from byte 2 of lane_c
+      ad.a2l[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c020400u);
+      ad.a2h[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c020600u);
+    } else {
+      ad.a2l[t] = ((d[t] << 7) & 0x7f80u) | lane_c2;
+      ad.a2h[t] = ((d[t] >> 9) & 0x7f80u) | lane_c2;
+    }
+  }
+}
+
+// kR8: the two landed loads hold, in lane (r = l >> 3, c = l & 7), chunk c (codes 8c .. 8c+7, k = 64c ..)
+// of rows r (qa) and 8 + r (qb).  MFMA step t of lane (n, q) takes dword j = t & 3 of chunk
+// c = 2q + (t >> 2) of row n, i.e. k = 128q + 64(t >> 2) + 16(t & 3) of the slice (the A fragments are
+// read with the same mapping): two ds_bpermute per step (rows < 8 / >= 8) and a select.
+__device__ __forceinline__ void redistribute_r8(const u32x4& qa, const u32x4& qb, int lane, u32x4& da, u32x4& db) {
+  const int n = lane & 15, q = lane >> 4;
+  const int src0 = (((n & 7) << 3) + 2 * q) << 2, src1 = src0 + 4;
+  const bool lo = n < 8;
+  const uint32_t a[4] = {qa.x, qa.y, qa.z, qa.w}, b[4] = {qb.x, qb.y, qb.z, qb.w};
+  uint32_t d[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int a0 = __builtin_amdgcn_ds_bpermute(src0, (int)a[j]), b0 = __builtin_amdgcn_ds_bpermute(src0, (int)b[j]);
+    const int a1 = __builtin_amdgcn_ds_bpermute(src1, (int)a[j]), b1 = __builtin_amdgcn_ds_bpermute(src1, (int)b[j]);
+    d[j] = (uint32_t)(lo ? a0 : b0);
+    d[4 + j] = (uint32_t)(lo ? a1 : b1);
+  }
+  da = u32x4{d[0], d[1], d[2], d[3]};
+  db = u32x4{d[4], d[5], d[6], d[7]};
+}
+
+struct StepOperands { uint2 t1l, t2l, t1h, t2h; i32x4 A; };
+
+__device__ __forceinline__ uint32_t lds_read4(uint32_t addr) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>((uintptr_t)addr);
+}
+
+// D4: the B fragment of a step is four 4-byte table entries, no sign fix-up
+__device__ __forceinline__ i32x4 item_mfma_d4(const ItemAddr& ad, uint32_t xaddr) {
+  constexpr int PIPE = QUIP_GEMV_PIPE;
+  i32x4 B[8], A[8];
+  auto issue = [&](int t) {
+    B[t] = i32x4{(int)lds_read4(ad.a1l[t]), (int)lds_read4(ad.a2l[t]), (int)lds_read4(ad.a1h[t]),
+                 (int)lds_read4(ad.a2h[t])};
+    A[t] = lds_read16i(xaddr + (t < 4 ? 16 * t : 256 + 16 * (t - 4)));
+  };
+#pragma unroll
+  for (int t = 0; t < PIPE; ++t) issue(t);
+  i32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (t + PIPE < 8) issue(t + PIPE);
+    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t], B[t], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// HALF: bytes between the digits of k and k + 256 of a plane (256 in the plain [3][Kp] image; the engine pads
+// every 256 digits by 16 bytes)
+template <int HALF = 256>
+__device__ __forceinline__ i32x4 item_mfma(const ItemAddr& ad, uint32_t xaddr) {
+  constexpr int PIPE = QUIP_GEMV_PIPE;
+  StepOperands op[8];
+  auto issue = [&](int t) {
+    op[t].t1l = lds_read8(ad.a1l[t]); op[t].t2l = lds_read8(ad.a2l[t]);
+    op[t].t1h = lds_read8(ad.a1h[t]); op[t].t2h = lds_read8(ad.a2h[t]);
+    op[t].A = lds_read16i(xaddr + (kR8 ? 64 * (t >> 2) + 16 * (t & 3) : (t < 4 ? 16 * t : HALF + 16 * (t - 4))));
+  };
+#pragma unroll
+  for (int t = 0; t < PIPE; ++t) issue(t);
+  i32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (t + PIPE < 8) issue(t + PIPE);
+    const i32x4 B = {(int)(op[t].t1l.x ^ op[t].t2l.x), (int)(op[t].t1l.y ^ op[t].t2l.y),
+                     (int)(op[t].t1h.x ^ op[t].t2h.x), (int)(op[t].t1h.y ^ op[t].t2h.y)};
+    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(op[t].A, B, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+}  // namespace
+}  // namespace quip

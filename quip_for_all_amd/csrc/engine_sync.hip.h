@@ -1,0 +1,77 @@
+// Cross-workgroup hand-off primitives of the persistent decode engine (gfx950).
+//
+// Per-XCD L2s are not coherent with each other and a CU's vector L1 is never refreshed by another
+// CU's stores, so every word that crosses workgroups inside a launch is written and read with
+// device-scope (sc1) accesses:
+//   granule  = one naturally aligned 8-byte {value, tag} written by ONE sc1 store; the data is its
+//              own flag (a reader re-reads until tag == epoch), no fence on either side;
+//   payload  = 16-byte sc1 stores, drained (vmcnt(0)) by every storing wave, then ONE sc1 flag
+//              store; the reader polls the flag with sc1 loads and reads the payload with sc1 loads.
+// Every spin is bounded: a reader that gives up raises the launch-wide error word and every other
+// spin loop leaves as soon as it sees that word, so a stuck launch ends instead of hanging the GPU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace quip {
+namespace esync {
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+constexpr uint32_t kSpinLimit = 1u << 21;   // polls before a reader gives up (a poll is ~0.5-1 us)
+
+// ---- stores ---------------------------------------------------------------------------------
+__device__ __forceinline__ void st_granule(void* p, uint32_t value, uint32_t tag) {
+  const u32x2_t v = {value, tag};
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st_granule2(void* p, uint32_t v0, uint32_t v1, uint32_t tag) {   // two granules, 16 B
+  const u32x4_t v = {v0, tag, v1, tag};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st_payload16(void* p, const u32x4_t& v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st_word(void* p, uint32_t v) {
+  asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// ---- loads (issued, not waited: the caller waits with drain() / a counted vmcnt) ------------
+__device__ __forceinline__ void ld16(u32x4_t& dst, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void ld8(u32x2_t& dst, const void* p) {
+  asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void ld4(uint32_t& dst, const void* p) {
+  asm volatile("global_load_dword %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory");
+}
+template <typename T>
+__device__ __forceinline__ void own(T& v) { asm volatile("" : "+v"(v)); }   // after a wait: the value is the register's
+
+// ---- bounded spinning -----------------------------------------------------------------------
+// One step of a spin loop of a whole wave: `done` is this lane's condition.  Returns true when the
+// wave may leave (everything arrived, or the launch is already failing).  err: the launch-wide error
+// word (0 = fine); code: who gives up.
+__device__ __forceinline__ bool spin_step(bool done, uint32_t& spins, uint32_t* err, uint32_t code) {
+  if (__all(done)) return true;
+  ++spins;
+  if ((spins & 63u) == 0u) {
+    uint32_t e;
+    ld4(e, err);
+    drain();
+    own(e);
+    if (__builtin_amdgcn_readfirstlane(e) != 0u) return true;
+    if (spins >= kSpinLimit) {
+      if ((threadIdx.x & 63) == 0) st_word(err, code);
+      return true;
+    }
+  }
+  __builtin_amdgcn_s_sleep(1);
+  return false;
+}
+
+}  // namespace esync
+}  // namespace quip
