@@ -384,6 +384,39 @@ int quip_rope_attn_decode_z_f16(const void* const* z, const void* const* post, c
                                 int32_t heads, int32_t kv_heads, int32_t head_dim, int32_t max_len, float scale,
                                 void* workspace, quip_stream_t stream);
 
+/* ---- persistent decode engine, stage 1: the MLP half of a decoder block in ONE launch -------------------------
+ * z_down = raw product of down_proj on  SU_d (.) silu(g) (.) u,  g / u = the finished outputs of gate_proj / up_proj
+ * computed from the digit planes of their transformed input (quip_had_transform_planes_group): what
+ * quip_e8p_gemv_planes_group + quip_had_transform_group_f16 + quip_had_transform_planes_fused + quip_e8p_gemv_planes
+ * do in four launches (qlinear.py:103-114 for gate / up, :90-103 for down; origin_order.cu:388-555 at m = 1).
+ * n_ffn = K * L with K x K the orthogonal factor of quant.py:26-39 (had_right of gate / up, had_left of down) and L a
+ * power of two in 16..256; the launch has L workgroups that exchange data through `workspace` and must all be
+ * resident, so L <= the number of CUs and NOTHING else may occupy the device while it runs (one engine launch at a
+ * time per device; launches that share a workspace must be stream ordered).  Every wait inside the launch is bounded:
+ * a launch that gives up writes a non-zero code to workspace word 1 (quip_ffn_engine_status) instead of hanging.
+ * workspace: quip_ffn_engine_workspace_bytes(n_ffn, K) bytes, zeroed ONCE at allocation, then owned by the engine. */
+typedef struct quip_ffn_engine_args {
+  const void* w_gate;       /* Qidxs (n_ffn, hidden / 8) int16 */
+  const void* w_up;
+  const void* w_down;       /* Qidxs (hidden, n_ffn / 8) int16 */
+  const void* planes_gate;  /* 3 * Kp + 16 bytes each (Kp = hidden rounded up to 512) */
+  const void* planes_up;
+  const void* had3;         /* fp16 [3][K * K rounded up to 8]: gate.had_right, up.had_right, down.had_left */
+  const void* sv_gate;      /* fp16 [n_ffn] */
+  const void* sv_up;
+  const void* su_down;      /* fp16 [n_ffn] */
+  void* z_down;             /* fp16 [hidden] */
+  const void* grid_packed_abs;
+  void* workspace;
+  void* dbg;                /* NULL, or 16 uint64 clock stamps per workgroup (bench) */
+  float out_scale;          /* 1 / sqrt(L) */
+  float in_scale;           /* down.wscale_float / sqrt(L) */
+  int32_t hidden, n_ffn, K;
+} quip_ffn_engine_args;
+int quip_ffn_engine_supported(int32_t hidden, int32_t n_ffn, int32_t K);
+size_t quip_ffn_engine_workspace_bytes(int32_t n_ffn, int32_t K);
+int quip_ffn_engine(const quip_ffn_engine_args* args, quip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,9 @@ SIGNATURES = {
     "quip_rope_attn_decode_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _P, _P],
     "quip_rope_attn_decode_z_supported": [_I32, _I32, _I32],
     "quip_rope_attn_decode_z_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _P, _P],
+    "quip_ffn_engine_supported": [_I32, _I32, _I32],
+    "quip_ffn_engine_workspace_bytes": [_I32, _I32],
+    "quip_ffn_engine": [_P, _P],
     "quip_e8p_mm_origorder": [_P, _P, _P, _P, _I32, _I32, _I32, _P],
     "quip_e8p_mm_batched": [_P, _P, _P, _P, _I64, _I32, _I32, _P],
     "quip_e8p_mm_skinny": [_P, _P, _P, _P, _I32, _I32, _I32, _P],
@@ -87,6 +90,14 @@ class GemvFusedIn(_c.Structure):
     """mirror of quip_gemv_fused_in (include/quip_mi355.h)"""
     _fields_ = [("x", _P), ("z", _P), ("post_scale", _P), ("residual", _P), ("h_out", _P), ("rms_weight", _P),
                 ("pre_scale", _P * 3), ("scale", _F * 3), ("z_scale", _F), ("rms_eps", _F)]
+
+
+class FfnEngineArgs(_c.Structure):
+    """mirror of quip_ffn_engine_args (include/quip_mi355.h)"""
+    _fields_ = [("w_gate", _P), ("w_up", _P), ("w_down", _P), ("planes_gate", _P), ("planes_up", _P), ("had3", _P),
+                ("sv_gate", _P), ("sv_up", _P), ("su_down", _P), ("z_down", _P), ("grid_packed_abs", _P),
+                ("workspace", _P), ("dbg", _P), ("out_scale", _F), ("in_scale", _F), ("hidden", _I32),
+                ("n_ffn", _I32), ("K", _I32)]
 
 
 class HadFusion(_c.Structure):

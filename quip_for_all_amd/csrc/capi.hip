@@ -376,6 +376,34 @@ int quip_argmax_step_f16(const void* logits, int32_t n, void* tok, void* pos, qu
   return argmax_step_launch(logits, n, tok, pos, (hipStream_t)stream);
 }
 
+int quip_ffn_engine_supported(int32_t hidden, int32_t n_ffn, int32_t K) {
+  return ffn_engine_supported(hidden, n_ffn, K) ? 1 : 0;
+}
+
+size_t quip_ffn_engine_workspace_bytes(int32_t n_ffn, int32_t K) {
+  return (n_ffn > 0 && K > 0 && n_ffn % K == 0) ? ffn_engine_workspace_bytes(n_ffn, K) : 0;
+}
+
+int quip_ffn_engine(const quip_ffn_engine_args* in, quip_stream_t stream) {
+  if (!in) return QUIP_ERR_NULL_POINTER;
+  if (!in->w_gate || !in->w_up || !in->w_down || !in->planes_gate || !in->planes_up || !in->had3 || !in->sv_gate ||
+      !in->sv_up || !in->su_down || !in->z_down || !in->grid_packed_abs || !in->workspace)
+    return QUIP_ERR_NULL_POINTER;
+  if (!aligned16(in->w_gate) || !aligned16(in->w_up) || !aligned16(in->w_down) || !aligned16(in->planes_gate) ||
+      !aligned16(in->planes_up) || !aligned16(in->had3) || !aligned16(in->sv_gate) || !aligned16(in->sv_up) ||
+      !aligned16(in->su_down) || !aligned16(in->workspace) || (reinterpret_cast<uintptr_t>(in->grid_packed_abs) & 63u) != 0)
+    return QUIP_ERR_MISALIGNED;
+  if (in->hidden < 1 || in->n_ffn < 1 || in->K < 1) return QUIP_ERR_BAD_SHAPE;
+  FfnEngineArgs a;
+  a.w_gate = in->w_gate; a.w_up = in->w_up; a.w_down = in->w_down;
+  a.planes_gate = in->planes_gate; a.planes_up = in->planes_up; a.had3 = in->had3;
+  a.sv_gate = in->sv_gate; a.sv_up = in->sv_up; a.su_down = in->su_down;
+  a.z_down = in->z_down; a.grid = in->grid_packed_abs; a.workspace = in->workspace; a.dbg = in->dbg;
+  a.out_scale = in->out_scale; a.in_scale = in->in_scale;
+  a.hidden = in->hidden; a.n_ffn = in->n_ffn; a.K = in->K;
+  return ffn_engine_launch(a, (hipStream_t)stream);
+}
+
 size_t quip_rope_attn_workspace_bytes(int32_t heads, int32_t head_dim) {
   return heads > 0 && head_dim > 0 ? rope_attn_workspace_bytes(heads, head_dim) : 0;
 }

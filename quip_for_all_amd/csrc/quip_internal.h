@@ -151,6 +151,29 @@ int rope_attn_decode_z_launch(const void* const* z, const void* const* post, con
                               int kv_heads, int head_dim, int max_len, float scale, hipStream_t stream,
                               void* workspace);
 int argmax_step_launch(const void* logits, int n, void* tok, void* pos, hipStream_t stream);
+// persistent decode engine, stage 1 (decode_engine.hip): GEMV[gate, up] -> output transforms -> SiLU product ->
+// input transform of down -> GEMV[down] of one decoder block in one launch
+struct FfnEngineArgs {
+  const void* w_gate = nullptr;      // Qidxs (n_ffn, hidden / 8) int16
+  const void* w_up = nullptr;
+  const void* w_down = nullptr;      // Qidxs (hidden, n_ffn / 8) int16
+  const void* planes_gate = nullptr; // digit planes of gate's / up's transformed input (3 Kp + 16 bytes each)
+  const void* planes_up = nullptr;
+  const void* had3 = nullptr;        // fp16 [3][K * K rounded up to 8]: gate.had_right, up.had_right, down.had_left
+  const void* sv_gate = nullptr;     // fp16 [n_ffn]
+  const void* sv_up = nullptr;
+  const void* su_down = nullptr;     // fp16 [n_ffn]
+  void* z_down = nullptr;            // fp16 [hidden]: raw product of down_proj
+  const void* grid = nullptr;        // grid_packed_abs
+  void* workspace = nullptr;         // ffn_engine_workspace_bytes(), zeroed once at allocation
+  void* dbg = nullptr;               // optional: 16 uint64 s_memtime stamps per workgroup
+  float out_scale = 1.f;             // 1 / sqrt(L), L = n_ffn / K
+  float in_scale = 1.f;              // down.wscale_float / sqrt(L)
+  int hidden = 0, n_ffn = 0, K = 0;
+};
+bool ffn_engine_supported(int hidden, int n_ffn, int K);
+size_t ffn_engine_workspace_bytes(int n_ffn, int K);
+int ffn_engine_launch(const FfnEngineArgs& in, hipStream_t stream);
 int had_transform_planes_launch(const void* x, void* planes, int in_features, int n, int K,
                                 const void* had, int transpose, const void* pre, float scale,
                                 hipStream_t stream, const HadFusion* fuse = nullptr);

@@ -18,8 +18,8 @@ import torch
 import torch.nn.functional as F
 
 from .codebook import codebook_id
-from .qlinear import (QuantLinear, chain_supported, forward_group, fused_in_supported, gemv_chain, gemv_fused,
-                      gemv_group_unfused, gemv_unfused, out_transform_group)
+from .qlinear import (QuantLinear, chain_planes, chain_supported, ffn_engine, ffn_engine_ok, forward_group,
+                      fused_in_supported, gemv_chain, gemv_fused, gemv_group_unfused, gemv_unfused, out_transform_group)
 
 
 @dataclass
@@ -193,6 +193,14 @@ class LlamaDecoder:
         self.o_fused = planes_ok and fused_in_supported([L0["o"]])
         self.qkv_fused = planes_ok and fused_in_supported(qkv0)
         self.fused_prologue = os.environ.get("QUIP_FUSED_PROLOGUE", "1") != "0" and (self.chain or prologue_ok)
+        # the MLP half of a block (GEMV[gate, up], two transforms, GEMV[down]) as ONE persistent launch
+        # (csrc/decode_engine.hip); QUIP_FFN_ENGINE=0 keeps the four stage-wise launches
+        self.ffn_eng = (self.fused_prologue and self.chain and os.environ.get("QUIP_FFN_ENGINE", "1") != "0"
+                        and all(ffn_engine_ok(L["gate"], L["up"], L["down"]) for L in self.layers))
+        self.ffn_ws = None
+        if self.ffn_eng:
+            from .register_lib import ffn_engine_workspace
+            self.ffn_ws = ffn_engine_workspace(s.ffn, L0["gate"].K_right, self.dev)
         # q / k / v output transforms inside the attention launch (multi-head attention, power-of-two hidden <= 4096,
         # plain SV output side)
         from .register_lib import rope_attn_decode_z_supported
@@ -277,9 +285,14 @@ class LlamaDecoder:
                 _, (zo,) = gemv_fused([L["o"]], x=a.reshape(1, s.hidden))
             else:
                 zo = gemv_unfused(L["o"], a.reshape(1, s.hidden))
-            h, zgu = self._zx([L["gate"], L["up"]], L["o"], zo, h, L["ln2"])
-            g, u = out_transform_group([L["gate"], L["up"]], zgu)
-            zd = gemv_unfused(L["down"], u, gate=g)
+            if self.ffn_eng:
+                h, planes = chain_planes([L["gate"], L["up"]], L["o"], zo, residual=h, rms_weight=L["ln2"],
+                                         rms_eps=s.rms_eps)
+                zd = ffn_engine(L["gate"], L["up"], L["down"], planes, self.ffn_ws)
+            else:
+                h, zgu = self._zx([L["gate"], L["up"]], L["o"], zo, h, L["ln2"])
+                g, u = out_transform_group([L["gate"], L["up"]], zgu)
+                zd = gemv_unfused(L["down"], u, gate=g)
             prev_down = L["down"]
         (h,) = out_transform_group([prev_down], [zd], residual=[h])
         return self._head(h)

@@ -464,3 +464,57 @@ def gemv_chain(layers, prev, z, residual=None, rms_weight=None, rms_eps=1e-5):
         getattr(l0.codebook, "planes_resid_scale", 0.0))
     h, planes = res[0], list(res[1:])
     return h, _gemv_planes_grouped(layers, planes)
+
+
+# ---- persistent decode engine, stage 1: the MLP half of a block in one launch (csrc/decode_engine.hip) -----------
+def ffn_engine_ok(gate, up, down):
+    """can the engine run gate / up / down of a block?  E8P12 on all three, the same K x K factor size on the
+    ffn side (K > 1, L = n_ffn / K a power of two <= 256), plain SV / SU sides, no padding, no bias on gate / up"""
+    from .register_lib import ffn_engine_supported
+    cb = gate.codebook
+    n_ffn, hidden = gate.out_features, gate.in_features
+    ok = (getattr(cb, "id", None) == "E8P12" and all(type(l.codebook) is type(cb) and not l.training and not l.per_channel
+                                                     for l in (gate, up, down))
+          and up.out_features == n_ffn and up.in_features == hidden and down.in_features == n_ffn
+          and down.out_features == hidden
+          and gate.q_out_features == n_ffn and up.q_out_features == n_ffn and down.q_in_features == n_ffn
+          and gate.q_in_features == hidden and down.q_out_features == hidden
+          and gate.K_right == up.K_right == down.K_left and gate.K_right > 1
+          and gate.bias is None and up.bias is None
+          and gate.SV is not None and up.SV is not None and down.SU is not None)
+    return bool(ok and ffn_engine_supported(hidden, n_ffn, gate.K_right))
+
+
+def _engine_had3(gate, up, down):
+    """the three K x K factors packed as fp16 [3][K * K rounded up to 8] (cached on `down`)"""
+    t = getattr(down, "_eng_had3", None)
+    if t is None or t.device != down.Qidxs.device:
+        K = gate.K_right
+        kkp = (K * K + 7) // 8 * 8
+        t = torch.zeros(3, kkp, dtype=torch.float16, device=down.Qidxs.device)
+        for i, h in enumerate((gate.had_right, up.had_right, down.had_left)):
+            t[i, :K * K] = h.detach().to(torch.float16).reshape(-1)
+        down._eng_had3 = t
+    return t
+
+
+def ffn_engine(gate, up, down, planes, workspace, dbg=None):
+    """raw product of down_proj (1, hidden) from the digit planes of gate's / up's transformed input"""
+    K = gate.K_right
+    L = gate.q_out_features // K
+    return torch.ops.quip_lib.ffn_engine(
+        planes[0], planes[1], gate.Qidxs, up.Qidxs, down.Qidxs, _engine_had3(gate, up, down), gate._vec(gate.SV),
+        up._vec(up.SV), down._vec(down.SU), gate.codebook.grid_packed_abs, workspace, 1.0 / math.sqrt(L),
+        down.wscale_float / math.sqrt(L), K, dbg)
+
+
+def chain_planes(layers, prev, z, residual=None, rms_weight=None, rms_eps=1e-5):
+    """the Hadamard chain launch of `gemv_chain` alone: (h, [planes_i])"""
+    l0 = layers[0]
+    n = l0.q_in_features
+    res = torch.ops.quip_lib.had_chain_planes_group(
+        z.reshape(1, n), prev._vec(prev.SV), None if residual is None else residual.reshape(1, n),
+        1.0 / math.sqrt(prev.q_out_features // prev.K_right), n, [l._vec(l.SU) for l in layers],
+        [l.wscale_float / math.sqrt(n) for l in layers], None if rms_weight is None else l0._vec(rms_weight), rms_eps,
+        getattr(l0.codebook, "planes_resid_scale", 0.0))
+    return res[0], list(res[1:])

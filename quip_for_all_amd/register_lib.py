@@ -77,6 +77,11 @@ _SCHEMAS = {
     # GEMV(s) with the input side computed in the prologue: [h_out]? + [y_i]; see quip_e8p_gemv_fused
     "e8p_gemv_fused": "(Tensor? x, Tensor? z, Tensor? post, Tensor? residual, Tensor? rms_weight, float rms_eps, "
                       "float z_scale, Tensor[] pre, float[] scale, Tensor[] Qidxs, Tensor grid) -> Tensor[]",
+    # persistent decode engine, stage 1: GEMV[gate, up] -> output transforms -> SiLU product -> input transform of down
+    # -> GEMV[down] in one launch (csrc/decode_engine.hip); returns down's raw product (1, hidden)
+    "ffn_engine": "(Tensor planes_gate, Tensor planes_up, Tensor q_gate, Tensor q_up, Tensor q_down, Tensor had3, "
+                  "Tensor sv_gate, Tensor sv_up, Tensor su_down, Tensor grid, Tensor(a!) workspace, float out_scale, "
+                  "float in_scale, int K, Tensor? dbg=None) -> Tensor",
     # decode-step glue between q/k/v_proj and o_proj: rope + KV-cache append + single-query attention
     "rope_attn_decode": "(Tensor q, Tensor k, Tensor v, Tensor cos, Tensor sin, Tensor pos, Tensor(a!) kcache, "
                         "Tensor(b!) vcache, Tensor(c!)? workspace) -> Tensor",
@@ -581,6 +586,52 @@ def _e8p_gemv_fused_cuda(x, z, post, residual, rms_weight, rms_eps, z_scale, pre
     return ([h_out] if h_out is not None else []) + outs
 
 
+def ffn_engine_supported(hidden, n_ffn, K):
+    return bool(capi.lib().quip_ffn_engine_supported(int(hidden), int(n_ffn), int(K)))
+
+
+def ffn_engine_workspace(n_ffn, K, device):
+    """hand-off area of the engine launches of one decoder (zeroed once; launches sharing it must be stream ordered)"""
+    return torch.zeros(capi.lib().quip_ffn_engine_workspace_bytes(int(n_ffn), int(K)), dtype=torch.uint8, device=device)
+
+
+def ffn_engine_status(workspace):
+    """0, or the code of the wait that gave up in an engine launch on this workspace (synchronises)"""
+    return int(workspace[:8].view(torch.int32)[1].item())
+
+
+def _ffn_engine_cuda(planes_gate, planes_up, q_gate, q_up, q_down, had3, sv_gate, sv_up, su_down, grid, workspace,
+                     out_scale, in_scale, K, dbg=None):
+    dev = planes_gate.device
+    n_ffn, hidden = q_gate.shape[0], q_gate.shape[1] * 8
+    for q in (q_gate, q_up, q_down):
+        _need(q.dtype == torch.int16 and q.is_contiguous() and q.device == dev, "Qidxs must be contiguous int16")
+    _need(q_up.shape == q_gate.shape and q_down.shape == (hidden, n_ffn // 8), "gate / up (n_ffn, hidden / 8), down (hidden, n_ffn / 8)")
+    _need(ffn_engine_supported(hidden, n_ffn, K), f"ffn_engine: shape (hidden {hidden}, n_ffn {n_ffn}, K {K}) not supported")
+    kp = (hidden + 511) // 512 * 512
+    for pl in (planes_gate, planes_up):
+        _need(pl.dtype == torch.uint8 and pl.is_contiguous() and pl.numel() == 3 * kp + 16 and pl.device == dev,
+              "planes must be uint8 images of 3 Kp + 16 bytes")
+    kkp = (K * K + 7) // 8 * 8
+    _need(had3.dtype == torch.float16 and had3.is_contiguous() and had3.numel() == 3 * kkp and had3.device == dev,
+          "had3 must be fp16 [3][K * K rounded up to 8]")
+    for v in (sv_gate, sv_up, su_down):
+        _need(v.dtype == torch.float16 and v.is_contiguous() and v.numel() == n_ffn and v.device == dev,
+              "sv_gate / sv_up / su_down must be fp16 vectors of n_ffn elements")
+    _need(workspace.dtype == torch.uint8 and workspace.device == dev
+          and workspace.numel() >= capi.lib().quip_ffn_engine_workspace_bytes(n_ffn, K), "workspace too small")
+    g = _grid_i64(grid, planes_gate)
+    out = torch.empty((1, hidden), dtype=torch.float16, device=dev)
+    a = capi.FfnEngineArgs(q_gate.data_ptr(), q_up.data_ptr(), q_down.data_ptr(), planes_gate.data_ptr(),
+                           planes_up.data_ptr(), had3.data_ptr(), sv_gate.data_ptr(), sv_up.data_ptr(),
+                           su_down.data_ptr(), out.data_ptr(), g.data_ptr(), workspace.data_ptr(), _ptr(dbg),
+                           float(out_scale), float(in_scale), hidden, n_ffn, int(K))
+    import ctypes
+    with torch.cuda.device(dev):
+        capi.check(capi.lib().quip_ffn_engine(ctypes.byref(a), _stream(planes_gate)), "quip_ffn_engine")
+    return out
+
+
 def rope_attn_workspace(heads, head_dim, device):
     """zeroed scratch for the split (long context) mode of rope_attn_decode; allocate once, reuse"""
     return torch.zeros(capi.lib().quip_rope_attn_workspace_bytes(heads, head_dim), dtype=torch.uint8, device=device)
@@ -828,6 +879,7 @@ _IMPLS = {
     "had_transform_planes": _had_transform_planes_cuda,
     "e8p_gemv_planes": _e8p_gemv_planes_cuda,
     "rope_attn_decode": _rope_attn_decode_cuda,
+    "ffn_engine": _ffn_engine_cuda,
     "rope_attn_decode_z": _rope_attn_decode_z_cuda,
     "e8p_gemv_fused": _e8p_gemv_fused_cuda,
     "had_transform_planes_group": _had_transform_planes_group_cuda,
@@ -921,6 +973,8 @@ _reg_fake("e8p_gemv_planes_group", lambda planes, Qidxs, grid:
 _reg_fake("e8p_gemv_fused", lambda x, z, post, residual, rms_weight, rms_eps, z_scale, pre, scale, Qidxs, grid:
           ([z.new_empty((1, z.numel()))] if z is not None else []) +
           [q.new_empty((1, q.shape[0]), dtype=torch.float16) for q in Qidxs])
+_reg_fake("ffn_engine", lambda planes_gate, planes_up, q_gate, q_up, q_down, had3, sv_gate, sv_up, su_down, grid, workspace,
+          out_scale, in_scale, K, dbg=None: q_down.new_empty((1, q_down.shape[0]), dtype=torch.float16))
 _reg_fake("rope_attn_decode", lambda q, k, v, cos, sin, pos, kcache, vcache, workspace=None: torch.empty_like(q))
 _reg_fake("rope_attn_decode_z", lambda zs, posts, scales, cos, sin, pos, kcache, vcache, workspace=None:
           kcache.new_empty((zs[0].numel() // kcache.shape[2], kcache.shape[2])))
