@@ -401,7 +401,7 @@ typedef struct quip_ffn_engine_args {
   const void* w_down;       /* Qidxs (hidden, n_ffn / 8) int16 */
   const void* planes_gate;  /* 3 * Kp + 16 bytes each (Kp = hidden rounded up to 512) */
   const void* planes_up;
-  const void* had3;         /* fp16 [3][K * K rounded up to 8]: gate.had_right, up.had_right, down.had_left */
+  const void* had3;         /* fp16: gate.had_right, up.had_right (K x K row major, each padded to a multiple of 8 elements), down.had_left transposed, zero padded to (K16, K16), K16 = K rounded up to 16 */
   const void* sv_gate;      /* fp16 [n_ffn] */
   const void* sv_up;
   const void* su_down;      /* fp16 [n_ffn] */

@@ -36,6 +36,7 @@
 // every spin is bounded (engine_sync.hip.h) and a launch that gives up leaves a code in ctl[1].
 #include "e8p_gemv_core.hip.h"
 #include "engine_sync.hip.h"
+#include <cstdlib>
 
 namespace quip {
 
@@ -49,15 +50,15 @@ struct FfnArgs {
   const uint4* Wd;
   const uint8_t* planes_g;   // [3][Kp_in] digits + shift word (output of the input-transform launch)
   const uint8_t* planes_u;
-  const f16* had3;           // [3][KKP]: gate.had_right, up.had_right, down.had_left (K x K, row major), each padded to
-                             // KKP = K * K rounded up to 8 elements (16-byte pieces)
+  const f16* had3;           // gate.had_right, up.had_right (K x K row major, each padded to KKP = K * K rounded up to 8
+                             // elements), then down.had_left TRANSPOSED and zero padded to [KP16][KP16], KP16 = K rounded up to 16
   const f16* sv_g;           // [n_ffn]
   const f16* sv_u;
   const f16* su_d;           // [n_ffn]
   f16* zd;                   // [hidden]: raw product of down_proj
   const uint64_t* grid;      // grid_packed_abs
   uint64_t* inbox;           // [K][2][L] granules
-  uint64_t* frow;            // [K][L] granules
+  uint64_t* frow;            // [L][KP16] granules: element (k, j) of the transformed rows at j * KP16 + k
   uint32_t* ctl;             // [0] generation (epoch of the last finished launch), [1] error code
   uint64_t* dbg;             // optional s_memtime stamps, 16 per workgroup
   float out_scale;           // 1 / sqrt(L)                    (gate / up output side)
@@ -77,14 +78,17 @@ struct EngLds {
   static constexpr int kAccRows = 2 * RB * 16 + 16;        // gate, up, down
   static constexpr int kAcc = T::kAcc;
   static constexpr int KKP = (K * K + 7) & ~7;             // elements of a padded K x K factor
-  static constexpr int kHad = kAcc + kAccRows * 16;        // fp16 [3][KKP]
-  static constexpr int kHadBytes = 3 * KKP * 2;
+  static constexpr int KP16 = (K + 15) & ~15;              // K rounded up to the k step of the fp16 MFMA
+  static constexpr int kHad = kAcc + kAccRows * 16;        // fp16: gate [KKP], up [KKP] (row major), down TRANSPOSED [KP16][KP16]
+  static constexpr int kHadElems = 2 * KKP + KP16 * KP16;
+  static constexpr int kHadBytes = kHadElems * 2;
   static constexpr int kZ = kHad + kHadBytes;              // float [2][RB * 16]: z of this column
   static constexpr int kRed = kZ + 2 * RB * 16 * 4;        // 64 floats of reduction scratch
-  static constexpr int kR = kRed + 256;                    // region R: planes of gate / up, then the gathered rows, then down's planes
-  static constexpr int kFStride = L + 16;                  // floats per gathered row (bank spread for the MFMA operand reads)
-  static constexpr int kFRows = (K + 3) & ~3;
-  static constexpr int kFBytes = kFRows * kFStride * 4;
+  static constexpr int kVec = kRed + 256;                  // row owner: SV_gate, SV_up, SU_down of its row (fp16 [3][L])
+  static constexpr int kR = kVec + ((3 * L * 2 + 15) & ~15);   // region R: planes of gate / up, then the gathered rows, then down's planes
+  // gathered rows, transposed: dwords (fp16 hi | fp16 lo << 16) [L][KP16], k contiguous (one 16-byte read = the four k of
+  // an MFMA operand, hi and lo)
+  static constexpr int kFBytes = L * KP16 * 4;
   static constexpr int KpD = (K * L + 511) & ~511;         // digits of down's input
   static constexpr int kPlaneD = (KpD / 256) * 272;        // a plane of down: 16 bytes of padding per 256 digits
   static int bytes(int kp_in) {
@@ -145,11 +149,22 @@ __global__ __launch_bounds__(kEngThreads) void ffn_engine_kernel(FfnArgs a) {
   };
 
   // ---- (0) requests: table source, digit planes of gate / up, the first weight slots --------------------------
+  // row owners (w < K) keep SV_gate / SV_up / SU_down of their row in LDS: requested first (every workgroup issues the
+  // load, so the counted waits below are the same everywhere), cold in HBM at this point and needed in stage (4)
+  constexpr int VPIECES = 3 * L / 8;
+  static_assert(VPIECES <= kEngThreads, "one vector piece per thread");
+  u32x4 vr;
+  {
+    const int i = tid < VPIECES ? tid : 0;
+    const int vsel = i / (L / 8), piece = i - vsel * (L / 8);
+    const f16* vsrc = (vsel == 0 ? a.sv_g : (vsel == 1 ? a.sv_u : a.su_d)) + (size_t)(w < K ? w : 0) * L + piece * 8;
+    asm_load16(vr, reinterpret_cast<const uint4*>(vsrc));
+  }
   u32x2 tsrc;
   asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(tsrc) : "v"(table_source_ptr(a.grid, lane, wave)) : "memory");
   uint32_t gen;
   esync::ld4(gen, a.ctl);
-  constexpr int HPIECES = 3 * E::KKP / 8;          // 16-byte pieces of the three K x K factors
+  constexpr int HPIECES = E::kHadElems / 8;       // 16-byte pieces of the three K x K factors
   constexpr int XH = (HPIECES + kEngThreads - 1) / kEngThreads;
   u32x4 hr[XH];
 #pragma unroll
@@ -188,6 +203,8 @@ __global__ __launch_bounds__(kEngThreads) void ffn_engine_kernel(FfnArgs a) {
   asm volatile("s_waitcnt vmcnt(%1)" : "+v"(gen) : "n"(XH + XR + kAhead) : "memory");
   const uint32_t epoch = (uint32_t)__builtin_amdgcn_readfirstlane((int)gen) + 1u;
   asm volatile("s_waitcnt vmcnt(%0)" : : "n"(XR + kAhead) : "memory");
+  esync::own(vr);     // older than everything waited for so far
+  if (tid < VPIECES) *reinterpret_cast<u32x4*>(smem + E::kVec + tid * 16) = vr;
 #pragma unroll
   for (int j = 0; j < XH; ++j) {
     esync::own(hr[j]);
@@ -273,14 +290,22 @@ __global__ __launch_bounds__(kEngThreads) void ffn_engine_kernel(FfnArgs a) {
     zbuf[tid] = (float)z;
   }
   __syncthreads();
-  if (tid < 2 * 64 && (tid & 63) < K) {
-    const int m = tid >> 6, kq = tid & 63;
-    const f16* hs = reinterpret_cast<const f16*>(smem + E::kHad) + m * E::KKP + kq * K;
+  {
+    // output (m, k') = thread quad o = tid >> 2; lane p of the quad sums k = p, p + 4, ...; the quad adds its four chains
+    const int o = tid >> 2, part = tid & 3;
+    const int m = o >> 6, kq = o & 63;
+    const bool live = kq < K;
+    const f16* hs = reinterpret_cast<const f16*>(smem + E::kHad) + m * E::KKP + (live ? kq : 0) * K;
     const float* zz = zbuf + m * RB * 16;
     float t = 0.f;
-#pragma unroll 4
-    for (int k = 0; k < K; ++k) t = __builtin_fmaf((float)hs[k], zz[k], t);
-    esync::st_granule(a.inbox + ((size_t)(kq * 2 + m) * L + w), as_u32(t), epoch);
+#pragma unroll
+    for (int k4 = 0; k4 < (K + 3) / 4; ++k4) {
+      const int k = 4 * k4 + part;
+      if (k < K) t = __builtin_fmaf((float)hs[k], zz[k], t);
+    }
+    t += __shfl_xor(t, 1, 64);
+    t += __shfl_xor(t, 2, 64);
+    if (live && part == 0) esync::st_granule(a.inbox + ((size_t)(kq * 2 + m) * L + w), as_u32(t), epoch);
   }
   ENG_STAMP(5);
 
@@ -305,6 +330,7 @@ __global__ __launch_bounds__(kEngThreads) void ffn_engine_kernel(FfnArgs a) {
       }
       if (esync::spin_step(ok || !active, spins, a.ctl + 1, 0x1000u + (uint32_t)w)) break;
     }
+    if (a.dbg && lane == 0) a.dbg[w * 16 + 12] = __builtin_amdgcn_s_memtime();
     float v[16];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -313,8 +339,8 @@ __global__ __launch_bounds__(kEngThreads) void ffn_engine_kernel(FfnArgs a) {
     }
     had::fht16_lanes<LOGL>(v, t);
     // output side of gate / up: fp16( (v * scale) * SV ), element (w, 16 t + r) of the (K, L) view
-    const int e0 = w * L + (active ? t : 0) * 16;
-    const f16* sv = (m ? a.sv_u : a.sv_g) + e0;
+    const f16* vecs = reinterpret_cast<const f16*>(smem + E::kVec);
+    const f16* sv = vecs + m * L + (active ? t : 0) * 16;
     float o[16];
     {
       float svf[16];
@@ -327,8 +353,9 @@ __global__ __launch_bounds__(kEngThreads) void ffn_engine_kernel(FfnArgs a) {
     float e[16];
     {
       float suf[16];
-      had::unpack8(*reinterpret_cast<const uint4*>(a.su_d + e0), suf);
-      had::unpack8(*reinterpret_cast<const uint4*>(a.su_d + e0 + 8), suf + 8);
+      const f16* su = vecs + 2 * L + (active ? t : 0) * 16;
+      had::unpack8(*reinterpret_cast<const uint4*>(su), suf);
+      had::unpack8(*reinterpret_cast<const uint4*>(su + 8), suf + 8);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float u = __shfl(o[r], (lane + 16) & 63, 64);
@@ -337,80 +364,127 @@ __global__ __launch_bounds__(kEngThreads) void ffn_engine_kernel(FfnArgs a) {
     }
     had::fht16_lanes<LOGL>(e, t);
     if (lane < 16 && t < TPR) {
-      uint64_t* dst = a.frow + ((size_t)w * L + t * 16);
+      // element (k = w, j = 16 t + r) as fp16 hi + lo of the prescaled value (exact power of two: the unnormalised
+      // length-L transform stays inside the fp16 range), stored where the consumers' operand reads want it
+      constexpr float kPre = 1.f / (float)(1 << ((LOGL + 1) / 2));
 #pragma unroll
-      for (int j = 0; j < 8; ++j) esync::st_granule2(dst + 2 * j, as_u32(e[2 * j]), as_u32(e[2 * j + 1]), epoch);
+      for (int r = 0; r < 16; ++r) {
+        const float v = e[r] * kPre;
+        const f16 hi = (f16)v;
+        const f16 lo = (f16)(v - (float)hi);
+        const uint32_t pair = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
+        esync::st_granule(a.frow + ((size_t)(16 * t + r) * E::KP16 + w), pair, epoch);
+      }
     }
   }
   ENG_STAMP(6);
 
-  // ---- (5) gather the K rows (every workgroup), stage as fp32 [k][L + 16] ---------------------------------------
+  // B fragments of stage (6) (had_d^T, already in LDS): read now, they do not depend on the hand-off.
+  // v_mfma_f32_16x16x16_f16: A[row = l & 15][k = 4 (l >> 4) + i], B[k = 4 (l >> 4) + i][col = l & 15]
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  constexpr int KSTEPS = E::KP16 / 16;
+  f16x4 bfr[KSTEPS][RB];
   {
-    constexpr int PIECES = K * L / 2;              // 16-byte pieces = 2 granules
+    const f16* hdT = reinterpret_cast<const f16*>(smem + E::kHad) + 2 * E::KKP;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+      for (int ct = 0; ct < RB; ++ct)
+        bfr[s][ct] = *reinterpret_cast<const f16x4*>(hdT + (16 * ct + n) * E::KP16 + 16 * s + 4 * q);
+  }
+  // ---- (5) gather the K rows (every workgroup): the value fields go to LDS as they are --------------------------------
+  {
+    constexpr int KPAIRS = (K + 1) / 2;            // 16-byte pieces (2 granules = k, k + 1) per column j
+    constexpr int PIECES = L * KPAIRS;
     constexpr int NP = (PIECES + kEngThreads - 1) / kEngThreads;
-    float* fs = reinterpret_cast<float*>(smem + E::kR);
-    // rows K .. kFRows - 1 of the staging area are the zero padding of the k loop
-    for (int i = tid; i < (E::kFRows - K) * E::kFStride; i += kEngThreads) fs[K * E::kFStride + i] = 0.f;
+    uint32_t* ft = reinterpret_cast<uint32_t*>(smem + E::kR);
+    // k = 2 KPAIRS .. KP16 - 1 of every column: zero (the region held digit bytes; B is zero there, but 0 * NaN is not)
+    if constexpr (E::KP16 > 2 * KPAIRS) {
+      for (int j = tid; j < L; j += kEngThreads)
+#pragma unroll
+        for (int k = 2 * KPAIRS; k < E::KP16; ++k) ft[j * E::KP16 + k] = 0u;
+    }
+    // wait on ONE granule per row (the last column its owner stores) with one wave; sweeping all K L granules while
+    // they are still being produced would put 256 x 8 K L bytes per pass on the fabric the producers need
+    if (wave == 0) {
+      uint32_t spins0 = 0;
+      const uint64_t* last = a.frow + ((size_t)(L - 1) * E::KP16 + (lane < K ? lane : 0));
+      for (;;) {
+        esync::u32x2_t f;
+        esync::ld8(f, last);
+        esync::drain();
+        esync::own(f);
+        if (esync::spin_step(f.y == epoch, spins0, a.ctl + 1, 0x3000u + (uint32_t)w)) break;
+      }
+    }
+    __syncthreads();
+    if (a.dbg && tid == 0) a.dbg[w * 16 + 13] = __builtin_amdgcn_s_memtime();
     u32x4_t p[NP];
     uint32_t spins = 0;
     for (;;) {
 #pragma unroll
       for (int j = 0; j < NP; ++j) {
         const int i = tid + kEngThreads * j;
-        esync::ld16(p[j], a.frow + 2 * (size_t)(i < PIECES ? i : 0));
+        const int ic = i < PIECES ? i : 0;
+        const int col = ic / KPAIRS, kp = ic - col * KPAIRS;
+        esync::ld16(p[j], a.frow + ((size_t)col * E::KP16 + 2 * kp));
       }
       esync::drain();
       bool ok = true;
 #pragma unroll
       for (int j = 0; j < NP; ++j) {
         esync::own(p[j]);
-        ok = ok && p[j].y == epoch && p[j].w == epoch;
+        const int i = tid + kEngThreads * j;
+        const int ic = i < PIECES ? i : 0;
+        const int kp = ic % KPAIRS;
+        ok = ok && p[j].y == epoch && (2 * kp + 1 >= K || p[j].w == epoch);
       }
       if (esync::spin_step(ok, spins, a.ctl + 1, 0x2000u + (uint32_t)w)) break;
     }
+    if (a.dbg && tid == 0) a.dbg[w * 16 + 14] = __builtin_amdgcn_s_memtime();
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       const int i = tid + kEngThreads * j;
       if (i < PIECES) {
-        const int el = 2 * i, k = el >> LOGL, c = el & (L - 1);
-        *reinterpret_cast<float2*>(fs + k * E::kFStride + c) = make_float2(as_f32(p[j].x), as_f32(p[j].z));
+        const int col = i / KPAIRS, kp = i - col * KPAIRS;
+        *reinterpret_cast<uint2*>(ft + col * E::KP16 + 2 * kp) = make_uint2(p[j].x, (2 * kp + 1 < K) ? p[j].z : 0u);
       }
     }
   }
   __syncthreads();
   ENG_STAMP(7);
 
-  // ---- (6) (H^T (x) I) on the matrix cores: D[j][k'] = sum_k f[k][j] had_d[k][k'] ------------------------------
-  //      v_mfma_f32_16x16x4_f32: A[row = l & 15][k = l >> 4], B[k = l >> 4][col = l & 15], D[row = 4 (l >> 4) + i][col = l & 15]
+  // ---- (6) (H^T (x) I) on the matrix cores: D[j][k'] = sum_k f[k][j] had_d[k][k'], f = hi + lo (fp16 x fp16 products are
+  //      exact in the fp32 accumulator; had_d is fp16 in the checkpoint).  D[row = 4 (l >> 4) + i][col = l & 15]
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   constexpr int JT = L / 16;                                   // row tiles of D (columns j of the view)
   constexpr int JTW = (JT + kEngWaves - 1) / kEngWaves;       // per wave
-  constexpr int KSTEPS = E::kFRows / 4;
   f32x4 acc[JTW][RB];
 #pragma unroll
   for (int jt = 0; jt < JTW; ++jt)
 #pragma unroll
     for (int ct = 0; ct < RB; ++ct) acc[jt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
   {
-    const float* fs = reinterpret_cast<const float*>(smem + E::kR);
-    const f16* hd = reinterpret_cast<const f16*>(smem + E::kHad) + 2 * E::KKP;
-    for (int s = 0; s < KSTEPS; ++s) {
-      const int k = 4 * s + q;
-      float bv[RB];
+    const uint32_t* ft = reinterpret_cast<const uint32_t*>(smem + E::kR);
 #pragma unroll
-      for (int ct = 0; ct < RB; ++ct) {
-        const int kc = 16 * ct + n;
-        bv[ct] = (k < K && kc < K) ? (float)hd[k * K + kc] : 0.f;
-      }
+    for (int s = 0; s < KSTEPS; ++s) {
 #pragma unroll
       for (int jt = 0; jt < JTW; ++jt) {
         const int tile = wave + jt * kEngWaves;
-        const float av = fs[k * E::kFStride + (tile < JT ? tile : 0) * 16 + n];
+        const u32x4 d = *reinterpret_cast<const u32x4*>(ft + (16 * (tile < JT ? tile : 0) + n) * E::KP16 + 16 * s + 4 * q);
+        // four (hi | lo << 16) dwords -> the hi and the lo operand (4 halves each)
+        const uint2 h2 = make_uint2(__builtin_amdgcn_perm(d.y, d.x, 0x05040100u), __builtin_amdgcn_perm(d.w, d.z, 0x05040100u));
+        const uint2 l2 = make_uint2(__builtin_amdgcn_perm(d.y, d.x, 0x07060302u), __builtin_amdgcn_perm(d.w, d.z, 0x07060302u));
+        const f16x4 ah = __builtin_bit_cast(f16x4, h2), al = __builtin_bit_cast(f16x4, l2);
 #pragma unroll
-        for (int ct = 0; ct < RB; ++ct) acc[jt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[ct], acc[jt][ct], 0, 0, 0);
+        for (int ct = 0; ct < RB; ++ct) {
+          acc[jt][ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bfr[s][ct], acc[jt][ct], 0, 0, 0);
+          acc[jt][ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bfr[s][ct], acc[jt][ct], 0, 0, 0);
+        }
       }
     }
   }
+  const float in_scale = a.in_scale * (float)(1 << ((LOGL + 1) / 2));   // undoes the prescale (exact)
   // exact maximum of |scale * x| over the whole vector -> block exponent
   float mx = 0.f;
 #pragma unroll
@@ -419,7 +493,7 @@ __global__ __launch_bounds__(kEngThreads) void ffn_engine_kernel(FfnArgs a) {
     for (int ct = 0; ct < RB; ++ct)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float m = fabsf(had::fmul(acc[jt][ct][i], a.in_scale));
+        const float m = fabsf(had::fmul(acc[jt][ct][i], in_scale));
         mx = fmaxf(mx, m == m ? m : __builtin_inff());
       }
   float* red = reinterpret_cast<float*>(smem + E::kRed);
@@ -430,7 +504,7 @@ __global__ __launch_bounds__(kEngThreads) void ffn_engine_kernel(FfnArgs a) {
   // four consecutive digits j = 16 tile + 4 q + (0..3) of row k' = 16 ct + n
   {
     uint8_t* pl = reinterpret_cast<uint8_t*>(smem + E::kR);
-    const float s2 = had::fmul(a.in_scale, as_f32((uint32_t)(sh_d + 127) << 23));
+    const float s2 = had::fmul(in_scale, as_f32((uint32_t)(sh_d + 127) << 23));
 #pragma unroll
     for (int jt = 0; jt < JTW; ++jt) {
       const int tile = wave + jt * kEngWaves;
@@ -527,8 +601,8 @@ bool ffn_shape_of(int hidden, int n_ffn, int K, FfnShape& s) {
 }  // namespace
 
 size_t ffn_engine_workspace_bytes(int n_ffn, int K) {
-  // ctl (64 bytes), inbox [K][2][L] and rows [K][L] granules
-  return 64 + (size_t)K * 2 * (n_ffn / K) * 8 + (size_t)n_ffn * 8;
+  // ctl (64 bytes), inbox [K][2][L] granules, transformed rows [L][K rounded up to 16] granules
+  return 64 + (size_t)K * 2 * (n_ffn / K) * 8 + (size_t)(n_ffn / K) * ((K + 15) & ~15) * 8;
 }
 
 bool ffn_engine_supported(int hidden, int n_ffn, int K) {
@@ -558,6 +632,8 @@ int ffn_engine_launch(const FfnEngineArgs& in, hipStream_t stream) {
   a.frow = a.inbox + (size_t)in.K * 2 * L;
   a.dbg = reinterpret_cast<uint64_t*>(in.dbg);
   a.out_scale = in.out_scale; a.in_scale = in.in_scale; a.hidden = in.hidden;
+  static const int rep16 = [] { const char* e = getenv("QUIP_ENG_REP"); return e && atoi(e) == 16; }();
+  if (s.K == 43 && s.logL == 8 && rep16) return launch_ffn<16, 43, 8, 6, 3>(a, stream);
   if (s.K == 43 && s.logL == 8) return launch_ffn<24, 43, 8, 6, 3>(a, stream);
   if (s.K == 11 && s.logL == 8) return launch_ffn<24, 11, 8, 1, 1>(a, stream);
   if (s.K == 43 && s.logL == 7) return launch_ffn<24, 43, 7, 3, 2>(a, stream);

@@ -159,7 +159,7 @@ struct FfnEngineArgs {
   const void* w_down = nullptr;      // Qidxs (hidden, n_ffn / 8) int16
   const void* planes_gate = nullptr; // digit planes of gate's / up's transformed input (3 Kp + 16 bytes each)
   const void* planes_up = nullptr;
-  const void* had3 = nullptr;        // fp16 [3][K * K rounded up to 8]: gate.had_right, up.had_right, down.had_left
+  const void* had3 = nullptr;        // fp16: gate.had_right, up.had_right (K x K row major, each padded to a multiple of 8 elements), down.had_left transposed, zero padded to (K16, K16), K16 = K rounded up to 16
   const void* sv_gate = nullptr;     // fp16 [n_ffn]
   const void* sv_up = nullptr;
   const void* su_down = nullptr;     // fp16 [n_ffn]

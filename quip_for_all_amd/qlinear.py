@@ -486,14 +486,19 @@ def ffn_engine_ok(gate, up, down):
 
 
 def _engine_had3(gate, up, down):
-    """the three K x K factors packed as fp16 [3][K * K rounded up to 8] (cached on `down`)"""
+    """the three K x K factors as the engine reads them (cached on `down`): gate.had_right, up.had_right row major,
+    each padded to K * K rounded up to 8 elements, then down.had_left transposed and zero padded to (KP16, KP16),
+    KP16 = K rounded up to 16"""
     t = getattr(down, "_eng_had3", None)
     if t is None or t.device != down.Qidxs.device:
         K = gate.K_right
-        kkp = (K * K + 7) // 8 * 8
-        t = torch.zeros(3, kkp, dtype=torch.float16, device=down.Qidxs.device)
-        for i, h in enumerate((gate.had_right, up.had_right, down.had_left)):
-            t[i, :K * K] = h.detach().to(torch.float16).reshape(-1)
+        kkp, kp16 = (K * K + 7) // 8 * 8, (K + 15) // 16 * 16
+        t = torch.zeros(2 * kkp + kp16 * kp16, dtype=torch.float16, device=down.Qidxs.device)
+        t[:K * K] = gate.had_right.detach().to(torch.float16).reshape(-1)
+        t[kkp:kkp + K * K] = up.had_right.detach().to(torch.float16).reshape(-1)
+        hdT = torch.zeros(kp16, kp16, dtype=torch.float16, device=t.device)
+        hdT[:K, :K] = down.had_left.detach().to(torch.float16).T
+        t[2 * kkp:] = hdT.reshape(-1)
         down._eng_had3 = t
     return t
 

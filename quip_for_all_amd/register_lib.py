@@ -612,9 +612,9 @@ def _ffn_engine_cuda(planes_gate, planes_up, q_gate, q_up, q_down, had3, sv_gate
     for pl in (planes_gate, planes_up):
         _need(pl.dtype == torch.uint8 and pl.is_contiguous() and pl.numel() == 3 * kp + 16 and pl.device == dev,
               "planes must be uint8 images of 3 Kp + 16 bytes")
-    kkp = (K * K + 7) // 8 * 8
-    _need(had3.dtype == torch.float16 and had3.is_contiguous() and had3.numel() == 3 * kkp and had3.device == dev,
-          "had3 must be fp16 [3][K * K rounded up to 8]")
+    kkp, kp16 = (K * K + 7) // 8 * 8, (K + 15) // 16 * 16
+    _need(had3.dtype == torch.float16 and had3.is_contiguous() and had3.numel() == 2 * kkp + kp16 * kp16
+          and had3.device == dev, "had3 must be the fp16 pack of qlinear._engine_had3")
     for v in (sv_gate, sv_up, su_down):
         _need(v.dtype == torch.float16 and v.is_contiguous() and v.numel() == n_ffn and v.device == dev,
               "sv_gate / sv_up / su_down must be fp16 vectors of n_ffn elements")
