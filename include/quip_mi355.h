@@ -417,6 +417,40 @@ int quip_ffn_engine_supported(int32_t hidden, int32_t n_ffn, int32_t K);
 size_t quip_ffn_engine_workspace_bytes(int32_t n_ffn, int32_t K);
 int quip_ffn_engine(const quip_ffn_engine_args* args, quip_stream_t stream);
 
+/* ---- persistent decode engine, stage 2: consecutive decoder blocks in ONE launch -------------------------------
+ * One token (bs = 1) through n_layers Llama decoder blocks whose seven projections are E8P12 QuantLinear modules:
+ * per block RMSNorm, q / k / v_proj, rotary embedding, KV-cache append at *pos, attention over [0, *pos], o_proj,
+ * residual, RMSNorm, gate / up_proj, SiLU product, down_proj, residual (the HF LlamaDecoderLayer of the reference's
+ * metric driver, example_generate.py:28-33, with qlinear.py:87-115 for every projection) -- the nine launches per block
+ * of the stage-wise step.  Shape: hidden 4096, 32 heads of 128 (multi-head), n_ffn = 43 x 256 (Llama-2-7B);
+ * quip_block_engine_supported says so.  256 workgroups exchange data through `workspace` and must all be resident:
+ * nothing else may occupy the device while the launch runs; launches sharing a workspace must be stream ordered.
+ * Every wait is bounded; a launch that gives up leaves a non-zero code in workspace word 1.
+ * layers: n_layers descriptors of quip_block_engine_layer_bytes() = 256 bytes each, in device memory:
+ *   uint64 W[7]   Qidxs of q, k, v, o, gate, up, down        uint64 ln[2]  input / post-attention RMSNorm weights (fp16)
+ *   uint64 su[7]  SU of the same seven modules (fp16)          uint64 sv[7]  SV (fp16)
+ *   uint64 had3   the K x K factors packed as for quip_ffn_engine
+ *   uint64 kcache, vcache   fp16 [heads, max_len, 128], row *pos is written
+ *   float  sc[7]  wscale_float / sqrt(L_in) (L_in = 4096; down: 256), then 5 floats of padding
+ * workspace: quip_block_engine_workspace_bytes() bytes, zeroed once at allocation. */
+typedef struct quip_block_engine_args {
+  const void* layers;
+  const void* h_in;          /* fp16 [4096]: embedding row of the token */
+  void* h_out;               /* fp16 [4096]: hidden state after the last block */
+  const void* pos;           /* int64 device scalar */
+  const float* cos;          /* fp32 [max_len, 128] */
+  const float* sin;
+  const void* grid_packed_abs;
+  void* workspace;
+  void* dbg;                 /* NULL, or 32 uint64 clock stamps per workgroup of block dbg_layer */
+  int32_t n_layers, max_len, dbg_layer;
+  float rms_eps, attn_scale;
+} quip_block_engine_args;
+int quip_block_engine_supported(int32_t hidden, int32_t heads, int32_t kv_heads, int32_t head_dim, int32_t n_ffn, int32_t K);
+size_t quip_block_engine_workspace_bytes(void);
+size_t quip_block_engine_layer_bytes(void);
+int quip_block_engine(const quip_block_engine_args* args, quip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,10 @@ SIGNATURES = {
     "quip_rope_attn_decode_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _P, _P],
     "quip_rope_attn_decode_z_supported": [_I32, _I32, _I32],
     "quip_rope_attn_decode_z_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _P, _P],
+    "quip_block_engine_supported": [_I32, _I32, _I32, _I32, _I32, _I32],
+    "quip_block_engine_workspace_bytes": [],
+    "quip_block_engine_layer_bytes": [],
+    "quip_block_engine": [_P, _P],
     "quip_ffn_engine_supported": [_I32, _I32, _I32],
     "quip_ffn_engine_workspace_bytes": [_I32, _I32],
     "quip_ffn_engine": [_P, _P],
@@ -98,6 +102,13 @@ class FfnEngineArgs(_c.Structure):
                 ("sv_gate", _P), ("sv_up", _P), ("su_down", _P), ("z_down", _P), ("grid_packed_abs", _P),
                 ("workspace", _P), ("dbg", _P), ("out_scale", _F), ("in_scale", _F), ("hidden", _I32),
                 ("n_ffn", _I32), ("K", _I32)]
+
+
+class BlockEngineArgs(_c.Structure):
+    """mirror of quip_block_engine_args (include/quip_mi355.h)"""
+    _fields_ = [("layers", _P), ("h_in", _P), ("h_out", _P), ("pos", _P), ("cos", _P), ("sin", _P),
+                ("grid_packed_abs", _P), ("workspace", _P), ("dbg", _P), ("n_layers", _I32), ("max_len", _I32),
+                ("dbg_layer", _I32), ("rms_eps", _F), ("attn_scale", _F)]
 
 
 class HadFusion(_c.Structure):

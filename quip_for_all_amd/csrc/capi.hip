@@ -404,6 +404,29 @@ int quip_ffn_engine(const quip_ffn_engine_args* in, quip_stream_t stream) {
   return ffn_engine_launch(a, (hipStream_t)stream);
 }
 
+int quip_block_engine_supported(int32_t hidden, int32_t heads, int32_t kv_heads, int32_t head_dim, int32_t n_ffn, int32_t K) {
+  return block_engine_supported(hidden, heads, kv_heads, head_dim, n_ffn, K) ? 1 : 0;
+}
+
+size_t quip_block_engine_workspace_bytes(void) { return block_engine_workspace_bytes(); }
+size_t quip_block_engine_layer_bytes(void) { return block_engine_layer_bytes(); }
+
+int quip_block_engine(const quip_block_engine_args* in, quip_stream_t stream) {
+  if (!in) return QUIP_ERR_NULL_POINTER;
+  if (!in->layers || !in->h_in || !in->h_out || !in->pos || !in->cos || !in->sin || !in->grid_packed_abs || !in->workspace)
+    return QUIP_ERR_NULL_POINTER;
+  if (!aligned16(in->layers) || !aligned16(in->h_in) || !aligned16(in->h_out) || !aligned16(in->workspace) ||
+      (reinterpret_cast<uintptr_t>(in->grid_packed_abs) & 63u) != 0)
+    return QUIP_ERR_MISALIGNED;
+  if (in->n_layers < 1 || in->max_len < 1) return QUIP_ERR_BAD_SHAPE;
+  BlockEngineArgs a;
+  a.layers = in->layers; a.h_in = in->h_in; a.h_out = in->h_out; a.pos = in->pos; a.cos = in->cos; a.sin = in->sin;
+  a.grid = in->grid_packed_abs; a.workspace = in->workspace; a.dbg = in->dbg;
+  a.n_layers = in->n_layers; a.max_len = in->max_len; a.dbg_layer = in->dbg_layer;
+  a.rms_eps = in->rms_eps; a.attn_scale = in->attn_scale;
+  return block_engine_launch(a, (hipStream_t)stream);
+}
+
 size_t quip_rope_attn_workspace_bytes(int32_t heads, int32_t head_dim) {
   return heads > 0 && head_dim > 0 ? rope_attn_workspace_bytes(heads, head_dim) : 0;
 }

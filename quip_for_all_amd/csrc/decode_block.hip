@@ -1,0 +1,914 @@
+// Persistent decode engine for gfx950, stage 2: whole decoder blocks -- any number of consecutive ones -- in ONE launch.
+//
+// One token (bs = 1) through blocks [0, n_layers) of a Llama-architecture decoder whose seven projections are E8P12
+// QuantLinear modules (qlinear.py:87-115 each; the block itself is the reference metric driver's HF LlamaDecoderLayer,
+// example_generate.py:28-33: RMSNorm, q / k / v, rotary embedding, static KV cache, attention, o, residual, RMSNorm,
+// gate / up, SiLU product, down, residual).  The stage-wise step issues 9 launches per block; each one rebuilds its
+// decode tables, starts its weight stream only once its input exists and pays a drain and a cold prologue, while the
+// arithmetic between two matrix-vector products is a few thousand flops.  Here:
+//   * 256 workgroups (one per CU) stay resident for all blocks; the E8P decode tables are built once per launch;
+//   * the codes of every projection are requested one dependency edge ahead of their use and wait in registers (nine
+//     static 2 x 16-byte slots per wave: q k v / gate x 3 | o / up x 3 | down x 3), in bursts placed right AFTER a
+//     hand-off has completed and sized to land before the next one polls, so that no poll queues behind them;
+//   * every product's 4096-vector goes to ALL workgroups as 8-byte {2 x fp16, tag} granules (engine_sync.hip.h) and
+//     every workgroup repeats the small transforms between two products on its own copy (RMSNorm, SU / SV, 4096-point
+//     Walsh-Hadamard: the functions of had_device.hip.h, same operations in the same order as the stand-alone
+//     kernels, so the same bits); the 11008-wide MLP edge is the distributed two-hop computation of decode_engine.hip;
+//   * attention runs on the workgroup that owns the first 16 rows of its head (the other seven wait for the result).
+// Row ownership: q / k / v / o / down rows [16 w, 16 w + 16); gate / up rows k * 256 + w, k = 0..42 (column w of the
+// (43, 256) view, decode_engine.hip).
+//
+// Shape: hidden = 4096 = 256 x 16, heads x 128 = 4096 (multi-head attention), n_ffn = 43 x 256 -- Llama-2-7B.  Other
+// shapes stay on the stage-wise step.
+// Liveness: all 256 workgroups must be resident (one per CU by LDS footprint; nothing else may run on the device);
+// every wait is bounded and a launch that gives up leaves a code in ctl[1] (engine_sync.hip.h).
+#include "e8p_gemv_core.hip.h"
+#include "engine_sync.hip.h"
+
+namespace quip {
+
+namespace {
+
+using esync::u32x2_t;
+using esync::u32x4_t;
+
+// one decoder block as the kernel reads it (256 bytes; built by the host once per model)
+struct BlockLayer {
+  const uint4* W[7];       // Qidxs of q, k, v, o, gate, up, down
+  const f16* ln[2];        // input_layernorm, post_attention_layernorm weights [4096]
+  const f16* su[7];        // SU of q, k, v, o, gate, up, down
+  const f16* sv[7];        // SV of q, k, v, o, gate, up, down
+  const f16* had3;         // the packed K x K factors of the MLP (qlinear._engine_had3)
+  f16* kcache;             // [heads, max_len, 128]
+  f16* vcache;
+  float sc[7];             // wscale_float / sqrt(L_in) of q, k, v, o, gate, up, down (L_in = 4096, down: 256)
+  float pad_[5];
+};
+static_assert(sizeof(BlockLayer) == 256, "layer descriptor layout");
+
+struct BlockArgs {
+  const BlockLayer* layers;
+  const f16* h_in;         // [4096]: the embedding row of the current token
+  f16* h_out;              // [4096]: hidden state after the last block
+  const int64_t* pos;      // device scalar
+  const float* cos;        // [max_len, 128]
+  const float* sin;
+  const uint64_t* grid;    // grid_packed_abs
+  char* ws;                // workspace (block_engine_workspace_bytes)
+  uint64_t* dbg;           // optional: 32 clock stamps per workgroup of block `dbg_layer`
+  int n_layers, max_len, dbg_layer;
+  float rms_eps, attn_scale;
+};
+
+constexpr int kWaves = 8, kThreads = 512;
+constexpr int HID = 4096, NWG = 256, RPW = 16, HD = 128, NH = 32;
+constexpr int FK = 43, FLOGL = 8, FL = 256, NFFN = FK * FL, FRB = 3;
+constexpr int KPD = 11264, JD = 22;                  // digits of down's input, slices
+constexpr int kRowU4 = HID / 64, kRowU4D = NFFN / 64;
+constexpr int NSLOT = 9;                             // X0-2: q k v, then gate's row blocks | X3-5: o, then up's | X6-8: down
+
+// workspace: ctl | z_q z_k z_v | a | z_o | z_d (2048 granules each) | inbox [43][2][256] | rows [256][48]
+constexpr size_t kWsCtl = 0, kWsZ = 64, kWsVec = 2048 * 8;
+constexpr size_t kWsInbox = kWsZ + 6 * kWsVec, kWsRows = kWsInbox + (size_t)FK * 2 * FL * 8;
+constexpr size_t kWsBytes = kWsRows + (size_t)FL * 48 * 8;
+
+template <int REP>
+struct BLds {
+  using T = Lds<REP>;
+  static constexpr int KKP = (FK * FK + 7) & ~7, KP16 = 48;
+  static constexpr int kAcc = T::kAcc;                       // int32 [176][4]: q k v (48) | o (16) | gate up (96) | down (16)
+  static constexpr int kAccRows = 176;
+  static constexpr int kHad = kAcc + kAccRows * 16;          // fp16 had3 image
+  static constexpr int kHadElems = 2 * KKP + KP16 * KP16;
+  static constexpr int kZcol = kHad + kHadElems * 2;         // float [2][48]: z of this column (MLP)
+  static constexpr int kRed = kZcol + 2 * 48 * 4;            // float [64] reduction scratch, int [8] shift words
+  static constexpr int kVec = kRed + 256 + 32;               // row owner: SV_gate, SV_up, SU_down rows (fp16 [3][256])
+  static constexpr int kH = kVec + 3 * FL * 2;               // fp16 [4096]: residual stream
+  static constexpr int kQkv = kH + HID * 2;                  // fp16 [3][128]: this head's q, k, v; [128] attention output
+  static constexpr int kR = kQkv + 4 * HD * 2;               // region R
+  // region R: [buf0: FHT shuffle buffer of group 0][area: digit planes (3 x 3 x 4096) | group 1's buffer | gathered vector |
+  //            MLP rows | down's planes | attention partials]
+  static constexpr int kBuf0 = kR;
+  static constexpr int kBufBytes = ((had::buf_floats(HID) * 4) + 15) & ~15;
+  static constexpr int kArea = kBuf0 + kBufBytes;
+  static constexpr int kAreaBytes = 50 * 1024;               // >= 36 KB planes, 48 KB MLP rows, 35.1 KB down planes
+  static constexpr int kBuf1 = kArea + 3 * 3 * HID - kBufBytes;   // tail of the planes area (dead before any plane is written there)
+  static constexpr int kZs = kArea;                          // gathered vector(s), fp16
+  static constexpr int kPlaneD = (KPD / 256) * 272;
+  static constexpr int kBytes = kArea + kAreaBytes;
+};
+static_assert(BLds<16>::kBytes <= 160 * 1024, "LDS budget");
+
+template <int REP>
+__global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using B = BLds<REP>;
+  using T = Lds<REP>;
+  // Everything derived from the thread index is RE-derived from an opaque copy at the top of every stage (rederive()):
+  // left to itself the compiler hoists ~70 lane-dependent addresses out of the block loop and spills them.
+  int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w = blockIdx.x;
+  int n = lane & 15, q = lane >> 4;
+  int grp = tid >> 8, tt = tid & 255;              // transform groups of 256 threads, 16 elements per thread
+  int e0 = tt * 16;
+  uint32_t* ctl = reinterpret_cast<uint32_t*>(a.ws + kWsCtl);
+  uint64_t* zbufs = reinterpret_cast<uint64_t*>(a.ws + kWsZ);       // [6][2048]: q k v a o d
+  uint64_t* inbox = reinterpret_cast<uint64_t*>(a.ws + kWsInbox);
+  uint64_t* frow = reinterpret_cast<uint64_t*>(a.ws + kWsRows);
+  int dbg_on = 0;
+#define BSTAMP(i) do { if (a.dbg_layer == -(100 + (i))) return; if (dbg_on && tid == 0) a.dbg[w * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+
+  // ---- weight slots ---------------------------------------------------------------------------------------------
+  u32x4 qa[NSLOT], qb[NSLOT];
+  // item kinds: 0..3 = q, k, v, o (rows [16 w, +16), slice = wave); 4..9 = gate / up row block (kind - 4) % 3 of matrix
+  // (kind - 4) / 3 (rows k * 256 + w); 10..12 = down, slice (kind - 10) * 8 + wave.  A load = scalar base of the matrix
+  // + a 32-bit byte offset of this lane (+ 64 for the second half of the item): eight offsets live across the blocks.
+  uint32_t vo_row, vo_gu[FRB], vo_d[3], vo_d2b;
+  uint32_t lane_c, lane_c2, xlane;
+  float* fbuf;
+  auto rederive = [&]() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    tid = t; lane = t & 63; n = lane & 15; q = lane >> 4; grp = t >> 8; tt = t & 255; e0 = tt * 16;
+    vo_row = (uint32_t)(((w * RPW + n) * kRowU4 + wave * 8 + q) * 16);
+#pragma unroll
+    for (int rb = 0; rb < FRB; ++rb) {
+      int kr = rb * 16 + n;
+      kr = kr < FK ? kr : FK - 1;
+      vo_gu[rb] = (uint32_t)(((kr * FL + w) * kRowU4 + wave * 8 + q) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int sl0 = i * kWaves + wave;
+      const int sl = sl0 < JD ? sl0 : 0;
+      vo_d[i] = (uint32_t)(((w * RPW + n) * kRowU4D + sl * 8 + q) * 16);
+      if (i == 2) {
+        int off = sl * 8 + q + 4;
+        off = off < kRowU4D ? off : kRowU4D - 1;       // the row's last slice is a half one: its digits beyond are zero
+        vo_d2b = (uint32_t)(((w * RPW + n) * kRowU4D + off) * 16);
+      }
+    }
+    lane_c = (Lds<REP>::kRep1 == 32) ? ((((uint32_t)lane & 31u) << 3) | 0x00010000u)
+                                     : ((((uint32_t)lane & 15u) << 3) | (uint32_t)Lds<REP>::kT1);
+    lane_c2 = (((uint32_t)lane & 15u) << 3) | (uint32_t)Lds<REP>::kT2;
+    xlane = (uint32_t)BLds<REP>::kArea + (uint32_t)min(n, 2) * (uint32_t)HID + (uint32_t)q * 64u + (uint32_t)wave * 512u;
+    fbuf = reinterpret_cast<float*>(smem + (grp ? BLds<REP>::kBuf1 : BLds<REP>::kBuf0));
+  };
+  rederive();
+  // a pointer the descriptor holds, as a scalar register pair (the same value in every lane)
+  auto uni = [](const uint4* p) -> const uint4* {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return reinterpret_cast<const uint4*>(((uint64_t)hi << 32) | lo);
+  };
+  auto ld_item = [&](u32x4& da, u32x4& db, const uint4* base0, uint32_t vo) {
+    const uint4* base = uni(base0);
+    // s_nop: the base was just written by v_readfirstlane (VALU write of an SGPR -> VMEM read needs 5 wait states, and
+    // the compiler pads no hazard for an instruction inside an asm statement)
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 nt" : "=v"(da) : "v"(vo), "s"(base) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:64 nt" : "=v"(db) : "v"(vo), "s"(base) : "memory");
+  };
+  // slot of an item kind: q k v -> X0-2, o -> X3, gate -> X0-2, up -> X3-5, down -> X6-8
+#define SLOT_OF(kind) ((kind) < 4 ? (kind) : (kind) - 4)
+#define ISSUE(Ld, kind) do {                                                                                          \
+    if ((kind) < 4) ld_item(qa[SLOT_OF(kind)], qb[SLOT_OF(kind)], Ld.W[(kind) < 4 ? (kind) : 0], vo_row);             \
+    else if ((kind) < 10) ld_item(qa[SLOT_OF(kind)], qb[SLOT_OF(kind)], Ld.W[4 + ((kind) - 4) / FRB], vo_gu[((kind) - 4) % FRB]); \
+    else if ((kind) < 12) ld_item(qa[SLOT_OF(kind)], qb[SLOT_OF(kind)], Ld.W[6], vo_d[(kind) >= 10 ? ((kind) - 10) % 3 : 0]);     \
+    else {                                                                                                             \
+      const uint4* bd_ = uni(Ld.W[6]);                                                                                 \
+      asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 nt" : "=v"(qa[8]) : "v"(vo_d[2]), "s"(bd_) : "memory");    \
+      asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(qb[8]) : "v"(vo_d2b), "s"(bd_) : "memory");              \
+    }                                                                                                                  \
+  } while (0)
+  // after a drain: every slot is a plain register again
+  auto own_slots = [&]() {
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) { esync::own(qa[s]); esync::own(qb[s]); }
+  };
+
+  // ---- prologue ---------------------------------------------------------------------------------------------------
+  u32x2 tsrc;
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(tsrc) : "v"(table_source_ptr(a.grid, lane, wave)) : "memory");
+  uint32_t gen;
+  esync::ld4(gen, ctl);
+  u32x4 hpiece;
+  asm_load16(hpiece, reinterpret_cast<const uint4*>(a.h_in) + tid);
+  {
+    const BlockLayer& L0 = a.layers[0];
+    ISSUE(L0, 0); ISSUE(L0, 1); ISSUE(L0, 2);
+  }
+  int* accs = reinterpret_cast<int*>(smem + B::kAcc);
+  for (int i = tid; i < B::kAccRows * 4; i += kThreads) accs[i] = 0;
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(tsrc) : "n"(2 + 6) : "memory");
+  fill_tables_from_lane<REP>(smem, tsrc, lane, wave);
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(gen) : "n"(1 + 6) : "memory");
+  const uint32_t ebase = ((uint32_t)__builtin_amdgcn_readfirstlane((int)gen) + 1u) << 10;
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(hpiece) : "n"(6) : "memory");
+  *reinterpret_cast<u32x4*>(smem + B::kH + tid * 16) = hpiece;
+  const long long pos64 = *a.pos;
+  const bool pos_ok = pos64 >= 0 && pos64 < (long long)a.max_len;
+  const int pos = pos_ok ? (int)pos64 : 0;
+  __syncthreads();
+  uint32_t hop = 0;                                 // hand-offs so far in this launch (tag = ebase | hop)
+
+  float* red = reinterpret_cast<float*>(smem + B::kRed);
+  int* shs = reinterpret_cast<int*>(smem + B::kRed + 256);
+  f16* hres = reinterpret_cast<f16*>(smem + B::kH);
+
+  // sum (rms statistic) and maximum over the 256 threads of each transform group, in block_reduce's order
+  auto group_reduce2 = [&](float& sum, float& mx) {
+    sum = had::wave_reduce_to_lane63<false>(sum);
+    mx = had::wave_reduce_to_lane63<true>(mx);
+    __syncthreads();                                  // earlier readers of `red` are done
+    if (lane == 63) { red[wave] = sum; red[16 + wave] = mx; }
+    __syncthreads();
+    const int b = grp * 4;
+    sum = had::fadd(had::fadd(had::fadd(red[b], red[b + 1]), red[b + 2]), red[b + 3]);
+    mx = fmaxf(fmaxf(fmaxf(red[16 + b], red[16 + b + 1]), red[16 + b + 2]), red[16 + b + 3]);
+  };
+
+  // ---- all-gather of one or more 4096-vectors (2048 granules each, {2 x fp16, tag}) into LDS as fp16 -------------------
+  // NV vectors starting at zbufs[first]; every thread sweeps 2 NV 16-byte pieces; returns with the data in smem + kZs
+  auto gather = [&](auto nv_tag, int first, uint32_t tag, uint32_t code) {
+    constexpr int NV = decltype(nv_tag)::value;
+    u32x4_t p[2 * NV];
+    uint32_t spins = 0;
+    const uint64_t* src = zbufs + (size_t)first * 2048;
+    for (;;) {
+#pragma unroll
+      for (int j = 0; j < 2 * NV; ++j) esync::ld16(p[j], src + 2 * (tid + kThreads * j));
+      esync::drain();
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < 2 * NV; ++j) {
+        esync::own(p[j]);
+        ok = ok && p[j].y == tag && p[j].w == tag;
+      }
+      if (esync::spin_step(ok, spins, ctl + 1, code + (uint32_t)w)) break;
+    }
+    uint32_t* zs = reinterpret_cast<uint32_t*>(smem + B::kZs);
+#pragma unroll
+    for (int j = 0; j < 2 * NV; ++j)
+      *reinterpret_cast<uint2*>(zs + 2 * (tid + kThreads * j)) = make_uint2(p[j].x, p[j].z);
+    own_slots();
+    __syncthreads();
+  };
+  // this workgroup's 16 values of a product (accumulator rows [row0, row0 + 16), block exponent sh) -> 8 granules
+  auto publish16 = [&](int vec, int row0, int sh, uint32_t tag) {
+    if (tid < 8) {
+      const int* s3 = accs + (row0 + 2 * tid) * 4;
+      const float us = unscale_of(sh, 2);
+      const float f0 = __builtin_fmaf((float)s3[0], 65536.f, __builtin_fmaf((float)s3[1], 256.f, (float)s3[2]));
+      const float f1 = __builtin_fmaf((float)s3[4], 65536.f, __builtin_fmaf((float)s3[5], 256.f, (float)s3[6]));
+      esync::st_granule(zbufs + (size_t)vec * 2048 + w * 8 + tid, pack_f16(f0 * us, f1 * us), tag);
+    }
+  };
+  auto zero_acc = [&](int row0, int rows) {
+    for (int i = tid; i < rows * 4; i += kThreads) accs[row0 * 4 + i] = 0;
+  };
+
+  // ---- output side of the producer (+ residual) and the input transforms of NC consumers ----------------------------
+  //   have_z: h += SV_prev (.) H z / 64 (z gathered in smem + kZs)     [qlinear.py:106-114 of the producer]
+  //   consumer c: planes_c = digits( sc[c] * rms(h) * H (h (.) ln (.) su[c]) )   [RMSNorm + qlinear.py:90-100]
+  // group g handles consumers g, g + 2; planes of consumer c at area + c * 3 * 4096
+  auto edge = [&](auto nc_tag, bool have_z, const f16* sv_prev, const f16* ln, const f16* const* su, const float* sc) {
+    constexpr int NC = decltype(nc_tag)::value;
+    constexpr int ROUNDS = (NC + 1) / 2;
+    // the vectors of this thread's 16 elements: requested before anything waits
+    uint4 psv[2], pln[2], psu[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      if (have_z) psv[hh] = *reinterpret_cast<const uint4*>(sv_prev + e0 + 8 * hh);
+      if (NC > 0) {
+        pln[hh] = *reinterpret_cast<const uint4*>(ln + e0 + 8 * hh);
+        psu[hh] = *reinterpret_cast<const uint4*>(su[grp < NC ? grp : 0] + e0 + 8 * hh);
+      }
+    }
+    if (have_z) {
+      float v[16], tp[16], tr[16];
+      const f16* zs = reinterpret_cast<const f16*>(smem + B::kZs);
+      had::unpack8(*reinterpret_cast<const uint4*>(zs + e0), v);
+      had::unpack8(*reinterpret_cast<const uint4*>(zs + e0 + 8), v + 8);
+      had::unpack8(*reinterpret_cast<const uint4*>(hres + e0), tr);
+      had::unpack8(*reinterpret_cast<const uint4*>(hres + e0 + 8), tr + 8);
+      had::unpack8(psv[0], tp);
+      had::unpack8(psv[1], tp + 8);
+      had::fht16_fixed<12, false>(v, fbuf, 0, tt, grp == 0);
+      f16 o[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = had::out_elem(v[r], 1.f / 64.f, true, tp[r], false, 0.f, true, tr[r]);
+      if (grp == 0) {
+        uint4* dst = reinterpret_cast<uint4*>(hres + e0);
+        dst[0] = *reinterpret_cast<uint4*>(&o[0]);
+        dst[1] = *reinterpret_cast<uint4*>(&o[8]);
+      }
+      __syncthreads();
+    }
+    if constexpr (NC > 0) {
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r) {
+        const int c = 2 * r + grp;
+        const bool act = c < NC;
+        uint4 psn[2];      // the next round's SU, requested before this round's transform
+        if (r + 1 < ROUNDS) {
+          const int cn = 2 * (r + 1) + grp;
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) psn[hh] = *reinterpret_cast<const uint4*>(su[cn < NC ? cn : 0] + e0 + 8 * hh);
+        }
+        float e[16];
+        had::unpack8(*reinterpret_cast<const uint4*>(hres + e0), e);
+        had::unpack8(*reinterpret_cast<const uint4*>(hres + e0 + 8), e + 8);
+        float ss = 0.f;
+        had::sumsq8(e, ss);
+        had::sumsq8(e + 8, ss);
+        had::mul8(e, pln[0]);
+        had::mul8(e + 8, pln[1]);
+        had::mul8(e, psu[0]);
+        had::mul8(e + 8, psu[1]);
+        had::fht16_fixed<12, false>(e, fbuf, 0, tt, act);
+        float tot = ss, mx = had::absmax16(e, 1.f);
+        group_reduce2(tot, mx);
+        const float scale = had::rms_scale(sc[act ? c : 0], tot, HID, a.rms_eps);
+        const int sh = had::shift_for(had::fmul(mx, fabsf(scale)));
+        uint4 dg[3];
+        had::planes16(e, scale, sh, dg);
+        if (act) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) *reinterpret_cast<uint4*>(smem + B::kArea + (c * 3 + d) * HID + e0) = dg[d];
+          if (tt == 0) shs[c] = sh;
+        }
+        if (r + 1 < ROUNDS) { psu[0] = psn[0]; psu[1] = psn[1]; }
+      }
+      __syncthreads();
+    }
+  };
+
+  // ---- one item of a product: slot s, digit planes at xa ------------------------------------------------------------
+  auto run_item = [&](int s, uint32_t xa, int accrow) {
+    ItemAddr ad;
+    item_addresses<REP>(qa[s], qb[s], lane_c, lane_c2, ad, 0u);
+    const i32x4 r = item_mfma(ad, xa);
+    if (q == 0) {
+      int* dst = accs + (accrow + n) * 4;
+      __hip_atomic_fetch_add(dst + 0, r.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(dst + 1, r.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(dst + 2, r.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  };
+
+  for (int l = 0; l < a.n_layers; ++l) {
+    const BlockLayer& Ld = a.layers[l];
+    dbg_on = a.dbg != nullptr && l == a.dbg_layer;
+    rederive();
+    BSTAMP(0);
+    // ================= P1: (previous down's output side) + input transforms of q, k, v; their products ===============
+    if (l > 0) {
+      gather(std::integral_constant<int, 1>{}, 5, ebase | hop, 0x4000u);
+      ISSUE(Ld, 0); ISSUE(Ld, 1); ISSUE(Ld, 2);        // burst A: q, k, v of this block (X0-2: gate's slots, consumed)
+    }
+    BSTAMP(1);
+    edge(std::integral_constant<int, 3>{}, l > 0, l > 0 ? a.layers[l - 1].sv[6] : nullptr, Ld.ln[0], Ld.su, Ld.sc);
+    BSTAMP(2);
+    esync::drain();                                    // q, k, v have landed (requested one transform stage ago)
+    own_slots();
+#pragma unroll
+    for (int c = 0; c < 3; ++c) run_item(c, xlane + (uint32_t)(c * 3 * HID), c * 16);
+    __syncthreads();
+    ++hop;                                             // hand-off: z_q, z_k, z_v
+#pragma unroll
+    for (int c = 0; c < 3; ++c) publish16(c, c * 16, shs[c], ebase | hop);
+    __syncthreads();
+    zero_acc(0, 48);
+    BSTAMP(3);
+
+    // ================= P2: attention ====================================================================================
+    rederive();
+    const bool head_wg = (w & 7) == 0;
+    const int hd = w >> 3;
+    if (head_wg) {
+      // vectors first, then the gather
+      uint4 psv[2][2];
+      float c8[8], s8[8];
+      const int d0 = (tid & 15) * 8;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        psv[0][hh] = *reinterpret_cast<const uint4*>(Ld.sv[grp] + e0 + 8 * hh);        // q (group 0) / k (group 1)
+        psv[1][hh] = *reinterpret_cast<const uint4*>(Ld.sv[2] + e0 + 8 * hh);          // v
+      }
+      {
+        const float* cs = a.cos + (size_t)pos * HD;
+        const float* sn = a.sin + (size_t)pos * HD;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { c8[i] = cs[d0 + i]; s8[i] = sn[d0 + i]; }
+      }
+      gather(std::integral_constant<int, 3>{}, 0, ebase | hop, 0x5000u);
+      ISSUE(Ld, 3);                                    // burst B: o of this block (X3)
+      BSTAMP(4);
+      f16* s_qkv = reinterpret_cast<f16*>(smem + B::kQkv);
+      const f16* zs = reinterpret_cast<const f16*>(smem + B::kZs);
+      // both inputs of this thread are read before the first transform (group 1's shuffle buffer lies over z_v)
+      float zin[2][16];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int c = r == 0 ? grp : 2;
+        had::unpack8(*reinterpret_cast<const uint4*>(zs + c * HID + e0), zin[r]);
+        had::unpack8(*reinterpret_cast<const uint4*>(zs + c * HID + e0 + 8), zin[r] + 8);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int c = r == 0 ? grp : 2;               // round 0: q | k, round 1: v (group 0)
+        const bool act = r == 0 || grp == 0;
+        float tp[16];
+        had::unpack8(psv[r][0], tp);
+        had::unpack8(psv[r][1], tp + 8);
+        had::fht16_fixed<12, false>(zin[r], fbuf, 0, tt, act);
+        if (act && e0 >= hd * HD && e0 < hd * HD + HD) {
+          f16 o[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) o[i] = had::out_elem(zin[r][i], 1.f / 64.f, true, tp[i], false, 0.f, false, 0.f);
+          uint4* dst = reinterpret_cast<uint4*>(s_qkv + c * HD + (e0 - hd * HD));
+          dst[0] = *reinterpret_cast<uint4*>(&o[0]);
+          dst[1] = *reinterpret_cast<uint4*>(&o[8]);
+        }
+      }
+      __syncthreads();
+      BSTAMP(5);
+      // single-query attention of head hd over positions [0, pos] (decode_glue.hip's arithmetic): 16 lanes per key,
+      // 16 key groups with their own online-softmax state, merged through LDS
+      constexpr int LPK = HD / 8, NG = 256 / LPK, U = 4;
+      float* s_m = reinterpret_cast<float*>(smem + B::kArea);
+      float* s_l = s_m + NG;
+      float* s_acc = s_l + NG;                         // [NG][HD + 4]
+      if (tid < 256) {
+        const int g = tid / LPK;
+        auto unpack8h = [](const uint4& u, float o[8]) {
+          const uint32_t ww[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const f16x2 hh = as_f16x2(ww[i]);
+            o[2 * i] = (float)hh.x;
+            o[2 * i + 1] = (float)hh.y;
+          }
+        };
+        auto rope8 = [&](const f16* vec, float o[8]) {
+          float x[8], y[8];
+          unpack8h(*reinterpret_cast<const uint4*>(vec + d0), x);
+          const int dp = d0 < HD / 2 ? d0 + HD / 2 : d0 - HD / 2;
+          unpack8h(*reinterpret_cast<const uint4*>(vec + dp), y);
+          const float sgn = d0 < HD / 2 ? -1.f : 1.f;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = (float)(f16)had::fadd(had::fmul(x[i], c8[i]), had::fmul(sgn * y[i], s8[i]));
+        };
+        float q8[8], kn[8], vn[8];
+        rope8(s_qkv, q8);
+        rope8(s_qkv + HD, kn);
+        const uint4 vraw = *reinterpret_cast<const uint4*>(s_qkv + 2 * HD + d0);
+        unpack8h(vraw, vn);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q8[i] *= a.attn_scale;
+        f16* kc = Ld.kcache + (size_t)hd * a.max_len * HD;
+        f16* vc = Ld.vcache + (size_t)hd * a.max_len * HD;
+        if (g == 0 && pos_ok) {                        // append the new row (StaticCache.update)
+          uint4 kr;
+          kr.x = pack_f16(kn[0], kn[1]); kr.y = pack_f16(kn[2], kn[3]);
+          kr.z = pack_f16(kn[4], kn[5]); kr.w = pack_f16(kn[6], kn[7]);
+          *reinterpret_cast<uint4*>(kc + (size_t)pos * HD + d0) = kr;
+          *reinterpret_cast<uint4*>(vc + (size_t)pos * HD + d0) = vraw;
+        }
+        float m = -INFINITY, lsum = 0.f, acc8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc8[i] = 0.f;
+        const int t_hi = pos + 1;
+        for (int t0 = g; t0 < t_hi; t0 += NG * U) {
+          uint4 kr[U], vr[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int t = t0 + u * NG;
+            const int tc = t < pos ? t : 0;
+            kr[u] = *reinterpret_cast<const uint4*>(kc + (size_t)tc * HD + d0);
+            vr[u] = *reinterpret_cast<const uint4*>(vc + (size_t)tc * HD + d0);
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int t = t0 + u * NG;
+            float k8[8], v8[8];
+            unpack8h(kr[u], k8);
+            unpack8h(vr[u], v8);
+            if (t == pos) {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) { k8[i] = kn[i]; v8[i] = vn[i]; }
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s = __builtin_fmaf(q8[i], k8[i], s);
+#pragma unroll
+            for (int o = 1; o < LPK; o <<= 1) s += __shfl_xor(s, o, 64);
+            if (t < t_hi) {
+              const float mn = fmaxf(m, s);
+              const float cc = __expf(m - mn), pp = __expf(s - mn);
+              lsum = lsum * cc + pp;
+#pragma unroll
+              for (int i = 0; i < 8; ++i) acc8[i] = acc8[i] * cc + pp * v8[i];
+              m = mn;
+            }
+          }
+        }
+        if ((tid & (LPK - 1)) == 0) { s_m[g] = m; s_l[g] = lsum; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s_acc[g * (HD + 4) + d0 + i] = acc8[i];
+      }
+      __syncthreads();
+      f16* s_a = s_qkv + 3 * HD;
+      if (tid < HD) {
+        float M = -INFINITY, Lsum = 0.f, o = 0.f;
+        for (int g = 0; g < NG; ++g) M = fmaxf(M, s_m[g]);
+        for (int g = 0; g < NG; ++g) {
+          const float ww = s_m[g] == -INFINITY ? 0.f : __expf(s_m[g] - M);
+          Lsum = __builtin_fmaf(s_l[g], ww, Lsum);
+          o = __builtin_fmaf(s_acc[g * (HD + 4) + tid], ww, o);
+        }
+        s_a[tid] = pos_ok ? (f16)(o / Lsum) : __builtin_bit_cast(f16, (unsigned short)0x7e00);
+      }
+      __syncthreads();
+      ++hop;                                           // hand-off: attention output
+      if (tid < 64) {
+        const uint32_t pr = *reinterpret_cast<const uint32_t*>(s_a + 2 * tid);
+        esync::st_granule(zbufs + (size_t)3 * 2048 + hd * 64 + tid, pr, ebase | hop);
+      }
+    } else {
+      ++hop;
+    }
+    BSTAMP(6);
+    rederive();
+    {
+      // o_proj's input side: x = H (a (.) SU_o) * sc  (no norm), every workgroup
+      uint4 psu[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) psu[hh] = *reinterpret_cast<const uint4*>(Ld.su[3] + e0 + 8 * hh);
+      gather(std::integral_constant<int, 1>{}, 3, ebase | hop, 0x6000u);
+      if (!head_wg) ISSUE(Ld, 3);                      // burst B for the workgroups that skipped the transforms
+      ISSUE(Ld, 4); ISSUE(Ld, 5); ISSUE(Ld, 6);        // and gate's row blocks (X0-2: q, k, v consumed)
+      BSTAMP(7);
+      const f16* zs = reinterpret_cast<const f16*>(smem + B::kZs);
+      float e[16];
+      had::unpack8(*reinterpret_cast<const uint4*>(zs + e0), e);
+      had::unpack8(*reinterpret_cast<const uint4*>(zs + e0 + 8), e + 8);
+      had::mul8(e, psu[0]);
+      had::mul8(e + 8, psu[1]);
+      had::fht16_fixed<12, false>(e, fbuf, 0, tt, grp == 0);
+      float dummy = 0.f, mx = had::absmax16(e, Ld.sc[3]);
+      group_reduce2(dummy, mx);
+      const int sh = had::shift_for(mx);
+      uint4 dg[3];
+      had::planes16(e, Ld.sc[3], sh, dg);
+      if (grp == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) *reinterpret_cast<uint4*>(smem + B::kArea + d * HID + e0) = dg[d];
+        if (tt == 0) shs[3] = sh;
+      }
+      __syncthreads();
+    }
+    BSTAMP(8);
+    esync::drain();
+    own_slots();
+    run_item(3, xlane, 48);
+    __syncthreads();
+    ++hop;                                             // hand-off: z_o
+    publish16(4, 48, shs[3], ebase | hop);
+    __syncthreads();
+    zero_acc(48, 16);
+    BSTAMP(9);
+
+    // ================= P3: o's output side + residual, RMSNorm, input transforms of gate / up; their products =========
+    rederive();
+    gather(std::integral_constant<int, 1>{}, 4, ebase | hop, 0x7000u);
+    ISSUE(Ld, 7); ISSUE(Ld, 8); ISSUE(Ld, 9);          // burst C: up's row blocks (X3-5) and down (X6-8)
+    ISSUE(Ld, 10); ISSUE(Ld, 11); ISSUE(Ld, 12);
+    BSTAMP(10);
+    edge(std::integral_constant<int, 2>{}, true, Ld.sv[3], Ld.ln[1], Ld.su + 4, Ld.sc + 4);
+    BSTAMP(11);
+    // row owners: SV_gate / SV_up / SU_down of their row, and everybody's image of the K x K factors, for the MLP edge
+    {
+      constexpr int VPIECES = 3 * FL / 8;
+      if (w < FK && tid < VPIECES) {
+        const int vsel = tid / (FL / 8), piece = tid - vsel * (FL / 8);
+        const f16* vsrc = (vsel == 0 ? Ld.sv[4] : (vsel == 1 ? Ld.sv[5] : Ld.su[6])) + (size_t)w * FL + piece * 8;
+        *reinterpret_cast<uint4*>(smem + B::kVec + tid * 16) = *reinterpret_cast<const uint4*>(vsrc);
+      }
+      constexpr int HPIECES = B::kHadElems / 8;
+      for (int i = tid; i < HPIECES; i += kThreads)
+        *reinterpret_cast<uint4*>(smem + B::kHad + i * 16) = reinterpret_cast<const uint4*>(Ld.had3)[i];
+    }
+    esync::drain();
+    own_slots();
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int m = i / FRB;
+      run_item(i, xlane + (uint32_t)(m * 3 * HID), 64 + i * 16);
+    }
+    __syncthreads();
+    BSTAMP(12);
+
+    // ================= P4: the MLP edge (decode_engine.hip) and down's product ==========================================
+    rederive();
+    {
+      float* zcol = reinterpret_cast<float*>(smem + B::kZcol);
+      if (tid < 96) {
+        const int m = tid / 48;
+        const int* s3 = accs + (64 + tid) * 4;
+        const float f = __builtin_fmaf((float)s3[0], 65536.f, __builtin_fmaf((float)s3[1], 256.f, (float)s3[2]));
+        zcol[tid] = (float)(f16)(f * unscale_of(shs[m], 2));
+      }
+      __syncthreads();
+      zero_acc(64, 96);
+      ++hop;                                           // hand-off: column -> row owners
+      const uint32_t tag1 = ebase | hop;
+      {
+        const int o = tid >> 2, part = tid & 3;
+        const int m = o >> 6, kq = o & 63;
+        const bool live = kq < FK;
+        const f16* hs = reinterpret_cast<const f16*>(smem + B::kHad) + m * B::KKP + (live ? kq : 0) * FK;
+        const float* zz = zcol + m * 48;
+        float t = 0.f;
+#pragma unroll
+        for (int k4 = 0; k4 < (FK + 3) / 4; ++k4) {
+          const int k = 4 * k4 + part;
+          if (k < FK) t = __builtin_fmaf((float)hs[k], zz[k], t);
+        }
+        t += __shfl_xor(t, 1, 64);
+        t += __shfl_xor(t, 2, 64);
+        if (live && part == 0) esync::st_granule(inbox + ((size_t)(kq * 2 + m) * FL + w), as_u32(t), tag1);
+      }
+      ++hop;                                           // hand-off: rows -> everybody
+      const uint32_t tag2 = ebase | hop;
+      BSTAMP(13);
+      if (w < FK && wave == 0) {
+        const int m = (lane >> 4) & 1, t = lane & 15;
+        const bool active = lane < 32;
+        const uint64_t* src = inbox + ((size_t)(w * 2 + m) * FL + t * 16);
+        u32x4_t g[8];
+        uint32_t spins = 0;
+        for (;;) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) esync::ld16(g[j], src + 2 * j);
+          esync::drain();
+          bool ok = true;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            esync::own(g[j]);
+            ok = ok && g[j].y == tag1 && g[j].w == tag1;
+          }
+          if (esync::spin_step(ok || !active, spins, ctl + 1, 0x1000u + (uint32_t)w)) break;
+        }
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          v[2 * j] = as_f32(g[j].x);
+          v[2 * j + 1] = as_f32(g[j].z);
+        }
+        had::fht16_lanes<FLOGL>(v, t);
+        const f16* vecs = reinterpret_cast<const f16*>(smem + B::kVec);
+        const f16* sv = vecs + m * FL + t * 16;
+        float o[16];
+        {
+          float svf[16];
+          had::unpack8(*reinterpret_cast<const uint4*>(sv), svf);
+          had::unpack8(*reinterpret_cast<const uint4*>(sv + 8), svf + 8);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[r] = (float)had::out_elem(v[r], 1.f / 16.f, true, svf[r], false, 0.f, false, 0.f);
+        }
+        float e[16];
+        {
+          float suf[16];
+          const f16* su = vecs + 2 * FL + t * 16;
+          had::unpack8(*reinterpret_cast<const uint4*>(su), suf);
+          had::unpack8(*reinterpret_cast<const uint4*>(su + 8), suf + 8);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float u = __shfl(o[r], (lane + 16) & 63, 64);
+            e[r] = had::fmul(had::fmul(u, had::silu(o[r])), suf[r]);
+          }
+        }
+        had::fht16_lanes<FLOGL>(e, t);
+        if (lane < 16) {
+          constexpr float kPre = 1.f / 16.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float vv = e[r] * kPre;
+            const f16 hi = (f16)vv;
+            const f16 lo = (f16)(vv - (float)hi);
+            const uint32_t pair = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
+            esync::st_granule(frow + ((size_t)(16 * t + r) * B::KP16 + w), pair, tag2);
+          }
+        }
+      }
+      BSTAMP(14);
+      // B fragments of the K-mix (had_d^T in LDS)
+      typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+      f16x4 bfr[3][FRB];
+      {
+        const f16* hdT = reinterpret_cast<const f16*>(smem + B::kHad) + 2 * B::KKP;
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+          for (int ct = 0; ct < FRB; ++ct)
+            bfr[s][ct] = *reinterpret_cast<const f16x4*>(hdT + (16 * ct + n) * B::KP16 + 16 * s + 4 * q);
+      }
+      // gather the rows
+      {
+        constexpr int KPAIRS = (FK + 1) / 2, PIECES = FL * KPAIRS, NP = (PIECES + kThreads - 1) / kThreads;
+        uint32_t* ft = reinterpret_cast<uint32_t*>(smem + B::kArea);
+        for (int j = tid; j < FL; j += kThreads)
+#pragma unroll
+          for (int k = 2 * KPAIRS; k < B::KP16; ++k) ft[j * B::KP16 + k] = 0u;
+        if (wave == 0) {
+          uint32_t spins0 = 0;
+          const uint64_t* last = frow + ((size_t)(FL - 1) * B::KP16 + (lane < FK ? lane : 0));
+          for (;;) {
+            u32x2_t f;
+            esync::ld8(f, last);
+            esync::drain();
+            esync::own(f);
+            if (esync::spin_step(f.y == tag2, spins0, ctl + 1, 0x3000u + (uint32_t)w)) break;
+          }
+        }
+        __syncthreads();
+        u32x4_t p[NP];
+        uint32_t spins = 0;
+        for (;;) {
+#pragma unroll
+          for (int j = 0; j < NP; ++j) {
+            const int i = tid + kThreads * j;
+            const int ic = i < PIECES ? i : 0;
+            const int col = ic / KPAIRS, kp = ic - col * KPAIRS;
+            esync::ld16(p[j], frow + ((size_t)col * B::KP16 + 2 * kp));
+          }
+          esync::drain();
+          bool ok = true;
+#pragma unroll
+          for (int j = 0; j < NP; ++j) {
+            esync::own(p[j]);
+            const int i = tid + kThreads * j;
+            const int ic = i < PIECES ? i : 0;
+            const int kp = ic % KPAIRS;
+            ok = ok && p[j].y == tag2 && (2 * kp + 1 >= FK || p[j].w == tag2);
+          }
+          if (esync::spin_step(ok, spins, ctl + 1, 0x2000u + (uint32_t)w)) break;
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+          const int i = tid + kThreads * j;
+          if (i < PIECES) {
+            const int col = i / KPAIRS, kp = i - col * KPAIRS;
+            *reinterpret_cast<uint2*>(ft + col * B::KP16 + 2 * kp) = make_uint2(p[j].x, (2 * kp + 1 < FK) ? p[j].z : 0u);
+          }
+        }
+        own_slots();
+      }
+      __syncthreads();
+      BSTAMP(15);
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      f32x4 acc[2][FRB];
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int ct = 0; ct < FRB; ++ct) acc[jt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+      {
+        const uint32_t* ft = reinterpret_cast<const uint32_t*>(smem + B::kArea);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) {
+            const int tile = wave + jt * kWaves;
+            const u32x4 d = *reinterpret_cast<const u32x4*>(ft + (16 * tile + n) * B::KP16 + 16 * s + 4 * q);
+            const uint2 h2 = make_uint2(__builtin_amdgcn_perm(d.y, d.x, 0x05040100u), __builtin_amdgcn_perm(d.w, d.z, 0x05040100u));
+            const uint2 l2 = make_uint2(__builtin_amdgcn_perm(d.y, d.x, 0x07060302u), __builtin_amdgcn_perm(d.w, d.z, 0x07060302u));
+            const f16x4 ah = __builtin_bit_cast(f16x4, h2), al = __builtin_bit_cast(f16x4, l2);
+#pragma unroll
+            for (int ct = 0; ct < FRB; ++ct) {
+              acc[jt][ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bfr[s][ct], acc[jt][ct], 0, 0, 0);
+              acc[jt][ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bfr[s][ct], acc[jt][ct], 0, 0, 0);
+            }
+          }
+        }
+      }
+      const float in_scale = Ld.sc[6] * 16.f;
+      float mx = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int ct = 0; ct < FRB; ++ct)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float mm = fabsf(had::fmul(acc[jt][ct][i], in_scale));
+            mx = fmaxf(mx, mm == mm ? mm : __builtin_inff());
+          }
+      const float bound = had::block_reduce(mx, true, red, tid, kThreads);
+      const int sh_d = had::shift_for(bound);
+      {
+        uint8_t* pl = reinterpret_cast<uint8_t*>(smem + B::kArea);
+        const float s2 = had::fmul(in_scale, as_f32((uint32_t)(sh_d + 127) << 23));
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+          const int tile = wave + jt * kWaves;
+#pragma unroll
+          for (int ct = 0; ct < FRB; ++ct) {
+            const int kc = 16 * ct + n;
+            int X[4], X1[4], H[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              X[i] = (int)__builtin_rintf(had::fmul(acc[jt][ct][i], s2));
+              X1[i] = (X[i] + 128) >> 8;
+              H[i] = (X1[i] + 128) >> 8;
+            }
+            if (kc < FK) {
+              const int kk = kc * FL + 16 * tile + 4 * q;
+              const int off = (kk >> 8) * 272 + (kk & 255);
+              *reinterpret_cast<uint32_t*>(pl + off) = had::low_bytes4(H[0], H[1], H[2], H[3]);
+              *reinterpret_cast<uint32_t*>(pl + B::kPlaneD + off) = had::low_bytes4(X1[0], X1[1], X1[2], X1[3]);
+              *reinterpret_cast<uint32_t*>(pl + 2 * B::kPlaneD + off) = had::low_bytes4(X[0], X[1], X[2], X[3]);
+            }
+          }
+        }
+        for (int i = NFFN + 4 * tid; i < KPD; i += 4 * kThreads) {
+          const int off = (i >> 8) * 272 + (i & 255);
+#pragma unroll
+          for (int d = 0; d < 3; ++d) *reinterpret_cast<uint32_t*>(pl + d * B::kPlaneD + off) = 0u;
+        }
+      }
+      __syncthreads();
+      BSTAMP(16);
+      const uint32_t xlane_d = (uint32_t)B::kArea + (uint32_t)min(n, 2) * (uint32_t)B::kPlaneD + (uint32_t)q * 64u;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int sl = i * kWaves + wave;
+        if (sl < JD) {
+          ItemAddr ad;
+          item_addresses<REP>(qa[6 + i], qb[6 + i], lane_c, lane_c2, ad, 0u);
+          const i32x4 d4 = item_mfma<272>(ad, xlane_d + (uint32_t)(sl * 544));
+          if (q == 0) {
+            int* dst = accs + (160 + n) * 4;
+            __hip_atomic_fetch_add(dst + 0, d4.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(dst + 1, d4.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(dst + 2, d4.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+      __syncthreads();
+      ++hop;                                           // hand-off: z_d
+      publish16(5, 160, sh_d, ebase | hop);
+      __syncthreads();
+      zero_acc(160, 16);
+      BSTAMP(17);
+    }
+  }
+  // ---- the last block's down: output side + residual -> h_out ------------------------------------------------------
+  rederive();
+  gather(std::integral_constant<int, 1>{}, 5, ebase | hop, 0x4000u);
+  {
+    const f16* const* none = nullptr;
+    edge(std::integral_constant<int, 0>{}, true, a.layers[a.n_layers - 1].sv[6], nullptr, none, nullptr);
+  }
+  if (w == 0) {
+    *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.h_out) + tid * 16) = *reinterpret_cast<const u32x4*>(smem + B::kH + tid * 16);
+    if (tid == 0) esync::st_word(ctl, ebase >> 10);
+  }
+#undef BSTAMP
+#undef ISSUE
+}
+
+}  // namespace
+
+size_t block_engine_workspace_bytes() { return kWsBytes; }
+size_t block_engine_layer_bytes() { return sizeof(BlockLayer); }
+
+bool block_engine_supported(int hidden, int heads, int kv_heads, int head_dim, int n_ffn, int K) {
+  return hidden == HID && heads == NH && kv_heads == NH && head_dim == HD && n_ffn == NFFN && K == FK &&
+         device_cu_count() >= NWG;
+}
+
+int block_engine_launch(const BlockEngineArgs& in, hipStream_t stream) {
+  if (in.n_layers < 1 || in.n_layers > 160) return QUIP_ERR_BAD_SHAPE;     // 6 hand-offs per block, 10-bit counter
+  BlockArgs a;
+  a.layers = reinterpret_cast<const BlockLayer*>(in.layers);
+  a.h_in = reinterpret_cast<const f16*>(in.h_in);
+  a.h_out = reinterpret_cast<f16*>(in.h_out);
+  a.pos = reinterpret_cast<const int64_t*>(in.pos);
+  a.cos = in.cos; a.sin = in.sin;
+  a.grid = reinterpret_cast<const uint64_t*>(in.grid);
+  a.ws = reinterpret_cast<char*>(in.workspace);
+  a.dbg = reinterpret_cast<uint64_t*>(in.dbg);
+  a.n_layers = in.n_layers; a.max_len = in.max_len; a.dbg_layer = in.dbg_layer;
+  a.rms_eps = in.rms_eps; a.attn_scale = in.attn_scale;
+  auto kern = decode_block_kernel<16>;
+  const int lds = BLds<16>::kBytes;
+  static DynLdsCache configured;
+  if (ensure_dyn_lds(configured, reinterpret_cast<const void*>(kern), lds) != QUIP_OK) return QUIP_ERR_LAUNCH;
+  hipLaunchKernelGGL(kern, dim3(NWG), dim3(kThreads), lds, stream, a);
+  return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+}
+
+}  // namespace quip

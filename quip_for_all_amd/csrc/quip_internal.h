@@ -174,6 +174,24 @@ struct FfnEngineArgs {
 bool ffn_engine_supported(int hidden, int n_ffn, int K);
 size_t ffn_engine_workspace_bytes(int n_ffn, int K);
 int ffn_engine_launch(const FfnEngineArgs& in, hipStream_t stream);
+// persistent decode engine, stage 2 (decode_block.hip): consecutive decoder blocks of a Llama-2-7B-shaped model, one token
+struct BlockEngineArgs {
+  const void* layers = nullptr;      // n_layers descriptors of block_engine_layer_bytes() bytes each (device memory)
+  const void* h_in = nullptr;        // fp16 [hidden]
+  void* h_out = nullptr;             // fp16 [hidden]
+  const void* pos = nullptr;         // int64 device scalar
+  const float* cos = nullptr;        // fp32 [max_len, head_dim]
+  const float* sin = nullptr;
+  const void* grid = nullptr;        // grid_packed_abs
+  void* workspace = nullptr;         // block_engine_workspace_bytes(), zeroed once
+  void* dbg = nullptr;
+  int n_layers = 0, max_len = 0, dbg_layer = -1;
+  float rms_eps = 1e-5f, attn_scale = 1.f;
+};
+bool block_engine_supported(int hidden, int heads, int kv_heads, int head_dim, int n_ffn, int K);
+size_t block_engine_workspace_bytes();
+size_t block_engine_layer_bytes();
+int block_engine_launch(const BlockEngineArgs& in, hipStream_t stream);
 int had_transform_planes_launch(const void* x, void* planes, int in_features, int n, int K,
                                 const void* had, int transpose, const void* pre, float scale,
                                 hipStream_t stream, const HadFusion* fuse = nullptr);

@@ -201,6 +201,10 @@ class LlamaDecoder:
         if self.ffn_eng:
             from .register_lib import ffn_engine_workspace
             self.ffn_ws = ffn_engine_workspace(s.ffn, L0["gate"].K_right, self.dev)
+        # all blocks of a token as ONE persistent launch (csrc/decode_block.hip); QUIP_BLOCK_ENGINE=0 keeps the stage-wise step
+        self.block_eng = False
+        if self.ffn_eng and os.environ.get("QUIP_BLOCK_ENGINE", "1") != "0":
+            self._init_block_engine()
         # q / k / v output transforms inside the attention launch (multi-head attention, power-of-two hidden <= 4096,
         # plain SV output side)
         from .register_lib import rope_attn_decode_z_supported
@@ -208,6 +212,52 @@ class LlamaDecoder:
                        and rope_attn_decode_z_supported(s.heads, s.kv_heads, s.head_dim)
                        and all(l.K_right == 1 and not l.per_channel and l.bias is None
                                and l.q_out_features == l.out_features == s.hidden for l in qkv0))
+
+    def _init_block_engine(self):
+        """descriptors + workspace of the persistent block launch, when every block qualifies"""
+        import numpy as np
+        from .qlinear import _engine_had3
+        from .register_lib import block_engine_supported, block_engine_workspace
+        s = self.s
+        L0 = self.layers[0]
+        names = ("q", "k", "v", "o", "gate", "up", "down")
+
+        def plain(m, n_in, n_out):
+            return (getattr(m.codebook, "id", None) == "E8P12" and not m.per_channel and m.bias is None and not m.training
+                    and m.SU is not None and m.SV is not None and m.in_features == m.q_in_features == n_in
+                    and m.out_features == m.q_out_features == n_out)
+        ok = block_engine_supported(s.hidden, s.heads, s.kv_heads, s.head_dim, s.ffn, L0["gate"].K_right)
+        for L in self.layers:
+            ok = ok and all(plain(L[k], s.hidden, s.hidden) and L[k].K_left == 1 and L[k].K_right == 1 for k in "qkvo")
+            ok = ok and all(plain(L[k], s.hidden, s.ffn) and L[k].K_left == 1 for k in ("gate", "up"))
+            ok = ok and plain(L["down"], s.ffn, s.hidden) and L["down"].K_right == 1
+        if not ok:
+            return
+        keep, rec = [], np.zeros((len(self.layers), 32), dtype=np.uint64)
+        for i, L in enumerate(self.layers):
+            mods = [L[k] for k in names]
+            vec = lambda t: t.detach().to(torch.float16).contiguous()     # noqa: E731
+            su, sv = [vec(m.SU) for m in mods], [vec(m.SV) for m in mods]
+            ln = [vec(L["ln1"]), vec(L["ln2"])]
+            had3 = _engine_had3(L["gate"], L["up"], L["down"])
+            keep += su + sv + ln + [had3]
+            ptrs = ([m.Qidxs.data_ptr() for m in mods] + [t.data_ptr() for t in ln] + [t.data_ptr() for t in su]
+                    + [t.data_ptr() for t in sv] + [had3.data_ptr(), self.kcache[i].data_ptr(), self.vcache[i].data_ptr()])
+            rec[i, :26] = np.array(ptrs, dtype=np.uint64)
+            sc = [m.wscale_float / math.sqrt(m.q_in_features // m.K_left) for m in mods]
+            rec[i, 26:].view(np.float32)[:7] = np.array(sc, dtype=np.float32)
+        self._eng_keep = keep
+        self.eng_layers = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).to(self.dev)
+        self.eng_ws = block_engine_workspace(self.dev)
+        self.block_eng = True
+
+    def engine_status(self):
+        """0, or the code of a wait that gave up inside a persistent launch (synchronises)"""
+        from .register_lib import ffn_engine_status
+        for ws in (getattr(self, "eng_ws", None), getattr(self, "ffn_ws", None)):
+            if ws is not None and ffn_engine_status(ws) != 0:
+                return ffn_engine_status(ws)
+        return 0
 
     # ---- model bytes the decode step has to stream (roofline denominator, SURVEY 8d) -----------
     def algorithmic_bytes_per_token(self):
@@ -246,6 +296,11 @@ class LlamaDecoder:
         if not self.fused_attention:
             cos, sin = self.cos[self.pos], self.sin[self.pos]          # (1, head_dim)
             mask = (self.arange[None, None, None, :] <= self.pos)      # (1,1,1,max_len) keys <= current
+        if getattr(self, "block_eng", False):
+            h = torch.ops.quip_lib.block_engine(self.eng_layers, h.reshape(-1), self.pos, self.cos, self.sin,
+                                                self.layers[0]["q"].codebook.grid_packed_abs, self.eng_ws,
+                                                len(self.layers), self.max_len, s.rms_eps, 1.0 / math.sqrt(s.head_dim))
+            return self._head(h.reshape(1, -1))
         if self.fused_prologue:
             return self._step_fused(h, cos, sin, mask)
         for i, L in enumerate(self.layers):

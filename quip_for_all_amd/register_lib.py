@@ -82,6 +82,10 @@ _SCHEMAS = {
     "ffn_engine": "(Tensor planes_gate, Tensor planes_up, Tensor q_gate, Tensor q_up, Tensor q_down, Tensor had3, "
                   "Tensor sv_gate, Tensor sv_up, Tensor su_down, Tensor grid, Tensor(a!) workspace, float out_scale, "
                   "float in_scale, int K, Tensor? dbg=None) -> Tensor",
+    # persistent decode engine, stage 2: n_layers decoder blocks of one token in one launch (csrc/decode_block.hip).
+    # `layers` = the packed descriptors (decode.py builds them; they point at the KV caches, which the launch appends to)
+    "block_engine": "(Tensor layers, Tensor h_in, Tensor pos, Tensor cos, Tensor sin, Tensor grid, Tensor(a!) workspace, "
+                    "int n_layers, int max_len, float rms_eps, float attn_scale, Tensor? dbg=None, int dbg_layer=-1) -> Tensor",
     # decode-step glue between q/k/v_proj and o_proj: rope + KV-cache append + single-query attention
     "rope_attn_decode": "(Tensor q, Tensor k, Tensor v, Tensor cos, Tensor sin, Tensor pos, Tensor(a!) kcache, "
                         "Tensor(b!) vcache, Tensor(c!)? workspace) -> Tensor",
@@ -632,6 +636,38 @@ def _ffn_engine_cuda(planes_gate, planes_up, q_gate, q_up, q_down, had3, sv_gate
     return out
 
 
+def block_engine_supported(hidden, heads, kv_heads, head_dim, n_ffn, K):
+    return bool(capi.lib().quip_block_engine_supported(int(hidden), int(heads), int(kv_heads), int(head_dim), int(n_ffn), int(K)))
+
+
+def block_engine_workspace(device):
+    return torch.zeros(capi.lib().quip_block_engine_workspace_bytes(), dtype=torch.uint8, device=device)
+
+
+def _block_engine_cuda(layers, h_in, pos, cos, sin, grid, workspace, n_layers, max_len, rms_eps, attn_scale, dbg=None,
+                       dbg_layer=-1):
+    dev = h_in.device
+    lb = capi.lib().quip_block_engine_layer_bytes()
+    _need(layers.dtype == torch.uint8 and layers.is_contiguous() and layers.numel() >= n_layers * lb and layers.device == dev,
+          "layers must be the packed descriptors (uint8, n_layers x 256 bytes) on the device")
+    _need(h_in.dtype == torch.float16 and h_in.is_contiguous() and h_in.numel() == 4096, "h_in: fp16 [4096]")
+    _need(pos.dtype == torch.int64 and pos.numel() == 1 and pos.device == dev, "pos: int64 device scalar")
+    for t in (cos, sin):
+        _need(t.dtype == torch.float32 and t.is_contiguous() and t.shape == (max_len, 128) and t.device == dev,
+              "cos / sin: fp32 [max_len, 128]")
+    _need(workspace.dtype == torch.uint8 and workspace.device == dev
+          and workspace.numel() >= capi.lib().quip_block_engine_workspace_bytes(), "workspace too small")
+    g = _grid_i64(grid, h_in)
+    out = torch.empty_like(h_in)
+    a = capi.BlockEngineArgs(layers.data_ptr(), h_in.data_ptr(), out.data_ptr(), pos.data_ptr(), cos.data_ptr(),
+                             sin.data_ptr(), g.data_ptr(), workspace.data_ptr(), _ptr(dbg), int(n_layers), int(max_len),
+                             int(dbg_layer), float(rms_eps), float(attn_scale))
+    import ctypes
+    with torch.cuda.device(dev):
+        capi.check(capi.lib().quip_block_engine(ctypes.byref(a), _stream(h_in)), "quip_block_engine")
+    return out
+
+
 def rope_attn_workspace(heads, head_dim, device):
     """zeroed scratch for the split (long context) mode of rope_attn_decode; allocate once, reuse"""
     return torch.zeros(capi.lib().quip_rope_attn_workspace_bytes(heads, head_dim), dtype=torch.uint8, device=device)
@@ -880,6 +916,7 @@ _IMPLS = {
     "e8p_gemv_planes": _e8p_gemv_planes_cuda,
     "rope_attn_decode": _rope_attn_decode_cuda,
     "ffn_engine": _ffn_engine_cuda,
+    "block_engine": _block_engine_cuda,
     "rope_attn_decode_z": _rope_attn_decode_z_cuda,
     "e8p_gemv_fused": _e8p_gemv_fused_cuda,
     "had_transform_planes_group": _had_transform_planes_group_cuda,
@@ -975,6 +1012,8 @@ _reg_fake("e8p_gemv_fused", lambda x, z, post, residual, rms_weight, rms_eps, z_
           [q.new_empty((1, q.shape[0]), dtype=torch.float16) for q in Qidxs])
 _reg_fake("ffn_engine", lambda planes_gate, planes_up, q_gate, q_up, q_down, had3, sv_gate, sv_up, su_down, grid, workspace,
           out_scale, in_scale, K, dbg=None: q_down.new_empty((1, q_down.shape[0]), dtype=torch.float16))
+_reg_fake("block_engine", lambda layers, h_in, pos, cos, sin, grid, workspace, n_layers, max_len, rms_eps, attn_scale,
+          dbg=None, dbg_layer=-1: torch.empty_like(h_in))
 _reg_fake("rope_attn_decode", lambda q, k, v, cos, sin, pos, kcache, vcache, workspace=None: torch.empty_like(q))
 _reg_fake("rope_attn_decode_z", lambda zs, posts, scales, cos, sin, pos, kcache, vcache, workspace=None:
           kcache.new_empty((zs[0].numel() // kcache.shape[2], kcache.shape[2])))

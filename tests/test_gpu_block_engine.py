@@ -1,0 +1,80 @@
+"""Persistent decode engine, stage 2 (csrc/decode_block.hip): all decoder blocks of a token in one launch, against the
+stage-wise step of the same model.  With the MLP half of the stage-wise step on its own persistent launch
+(csrc/decode_engine.hip) both paths execute the same rounded operations in the same order, so hidden states, logits
+and KV caches have to agree bit for bit; against the plain stage-wise step (four launches for the MLP half) the MLP
+edge differs by its block exponent and the order of two commuting factors (tests/test_gpu_engine.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _decoder(layers, block_engine, ffn_engine=True, max_len=48, seed=3):
+    from quip_for_all_amd import decode as D
+    shape = D.LlamaShape(hidden=4096, ffn=11008, layers=layers, heads=32, kv_heads=32, vocab=2048)
+    old = {k: os.environ.get(k) for k in ("QUIP_BLOCK_ENGINE", "QUIP_FFN_ENGINE")}
+    os.environ["QUIP_BLOCK_ENGINE"] = "1" if block_engine else "0"
+    os.environ["QUIP_FFN_ENGINE"] = "1" if ffn_engine else "0"
+    try:
+        dec = D.LlamaDecoder(shape, "E8P12", max_len=max_len, device=DEV, seed=seed, device_init=True)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return dec
+
+
+def _same_weights(dst, src):
+    """the K x K factors are drawn from scipy's global generator (get_hadK, quant.py:26-39): copy them over"""
+    with torch.no_grad():
+        for Ld, Ls in zip(dst.layers, src.layers):
+            for k in ("gate", "up", "down"):
+                for name in ("had_left", "had_right"):
+                    if getattr(Ls[k], name) is not None:
+                        getattr(Ld[k], name).copy_(getattr(Ls[k], name))
+                if hasattr(Ld[k], "_eng_had3"):
+                    del Ld[k]._eng_had3
+    if getattr(dst, "block_eng", False):
+        dst._init_block_engine()
+
+
+@pytest.mark.parametrize("layers", [1, 3])
+def test_block_engine_equals_stagewise_step_bit_for_bit(layers):
+    a = _decoder(layers, True)
+    b = _decoder(layers, False)
+    _same_weights(b, a)
+    assert a.block_eng and not b.block_eng and b.ffn_eng
+    for dec in (a, b):
+        dec.reset(first_token=7)
+    with torch.no_grad():
+        for t in range(6):
+            la = a.step().clone()
+            lb = b.step().clone()
+            assert a.engine_status() == 0 and b.engine_status() == 0
+            assert torch.equal(a.tok, b.tok), f"token {t}"
+            assert torch.equal(la, lb), f"logits of token {t}: max diff {(la.float() - lb.float()).abs().max().item()}"
+    assert torch.equal(a.kcache[:, :, :6], b.kcache[:, :, :6]) and torch.equal(a.vcache[:, :, :6], b.vcache[:, :, :6])
+
+
+def test_block_engine_captured_generation_matches_plain_stagewise_tokens():
+    """the captured step on the persistent launch against the plain stage-wise step (no engine at all): logits agree
+    to the MLP edge's rounding, the greedy tokens of a short generation are the same"""
+    a = _decoder(2, True, max_len=40)
+    c = _decoder(2, False, ffn_engine=False, max_len=40)
+    _same_weights(c, a)
+    assert a.block_eng and not c.block_eng and not c.ffn_eng
+    ta = a.generate(24, first_token=5, use_graph=True).cpu().numpy()
+    la = a.step_logits.float().cpu().numpy()
+    tc = c.generate(24, first_token=5, use_graph=True).cpu().numpy()
+    lc = c.step_logits.float().cpu().numpy()
+    assert a.engine_status() == 0
+    same = int((ta == tc).sum())
+    print(f"greedy tokens equal: {same} / {len(ta)}; last-step logits max diff {np.abs(la - lc).max():.4f} (|logit| max {np.abs(lc).max():.2f})")
+    assert same == len(ta)
+    assert np.abs(la - lc).max() <= 2.0 ** -8 * np.abs(lc).max()
