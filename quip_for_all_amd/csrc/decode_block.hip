@@ -24,6 +24,7 @@
 // every wait is bounded and a launch that gives up leaves a code in ctl[1] (engine_sync.hip.h).
 #include "e8p_gemv_core.hip.h"
 #include "engine_sync.hip.h"
+#include "fht_wg512.hip.h"
 
 namespace quip {
 
@@ -82,7 +83,10 @@ struct BLds {
   static constexpr int kHadElems = 2 * KKP + KP16 * KP16;
   static constexpr int kZcol = kHad + kHadElems * 2;         // float [2][48]: z of this column (MLP)
   static constexpr int kRed = kZcol + 2 * 48 * 4;            // float [64] reduction scratch, int [8] shift words
-  static constexpr int kVec = kRed + 256 + 32;               // row owner: SV_gate, SV_up, SU_down rows (fp16 [3][256])
+  static constexpr int kDesc = kRed + 256 + 32;              // the current block's descriptor (256 bytes): pointers are read
+                                                             // from here, not from memory (a vector load of a pointer ahead of
+                                                             // every request would wait for the requests before it)
+  static constexpr int kVec = kDesc + 256;                   // row owner: SV_gate, SV_up, SU_down rows (fp16 [3][256])
   static constexpr int kH = kVec + 3 * FL * 2;               // fp16 [4096]: residual stream
   static constexpr int kQkv = kH + HID * 2;                  // fp16 [3][128]: this head's q, k, v; [128] attention output
   static constexpr int kR = kQkv + 4 * HD * 2;               // region R
@@ -110,28 +114,29 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int w = blockIdx.x;
   int n = lane & 15, q = lane >> 4;
-  int grp = tid >> 8, tt = tid & 255;              // transform groups of 256 threads, 16 elements per thread
-  int e0 = tt * 16;
   uint32_t* ctl = reinterpret_cast<uint32_t*>(a.ws + kWsCtl);
   uint64_t* zbufs = reinterpret_cast<uint64_t*>(a.ws + kWsZ);       // [6][2048]: q k v a o d
   uint64_t* inbox = reinterpret_cast<uint64_t*>(a.ws + kWsInbox);
   uint64_t* frow = reinterpret_cast<uint64_t*>(a.ws + kWsRows);
   int dbg_on = 0;
-#define BSTAMP(i) do { if (a.dbg_layer == -(100 + (i))) return; if (dbg_on && tid == 0) a.dbg[w * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define BSTAMP(i) do { if (dbg_on && tid == 0) a.dbg[w * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
   // ---- weight slots ---------------------------------------------------------------------------------------------
   u32x4 qa[NSLOT], qb[NSLOT];
-  // item kinds: 0..3 = q, k, v, o (rows [16 w, +16), slice = wave); 4..9 = gate / up row block (kind - 4) % 3 of matrix
-  // (kind - 4) / 3 (rows k * 256 + w); 10..12 = down, slice (kind - 10) * 8 + wave.  A load = scalar base of the matrix
-  // + a 32-bit byte offset of this lane (+ 64 for the second half of the item): eight offsets live across the blocks.
-  uint32_t vo_row, vo_gu[FRB], vo_d[3], vo_d2b;
+  // item kinds: 0..2 = row blocks 3 w + kind of the stacked [q; k; v] rows (256 row blocks of 16 rows per matrix: a
+  // workgroup's three blocks touch at most two of the matrices, so ONE round of input transforms serves it), 3 = o rows
+  // [16 w, +16) (slice = wave); 4..9 = gate / up row block (kind - 4) % 3 of matrix (kind - 4) / 3 (rows k * 256 + w);
+  // 10..12 = down, slice (kind - 10) * 8 + wave.  A load = scalar base of the matrix + a 32-bit byte offset of this
+  // lane (+ 64 for the second half of the item).
+  uint32_t vo_row, vo_q[3], vo_gu[FRB], vo_d[3], vo_d2b;
   uint32_t lane_c, lane_c2, xlane;
-  float* fbuf;
   auto rederive = [&]() {
     int t = threadIdx.x;
     asm volatile("" : "+v"(t));
-    tid = t; lane = t & 63; n = lane & 15; q = lane >> 4; grp = t >> 8; tt = t & 255; e0 = tt * 16;
+    tid = t; lane = t & 63; n = lane & 15; q = lane >> 4;
     vo_row = (uint32_t)(((w * RPW + n) * kRowU4 + wave * 8 + q) * 16);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) vo_q[i] = (uint32_t)(((((3 * w + i) & 255) * 16 + n) * kRowU4 + wave * 8 + q) * 16);
 #pragma unroll
     for (int rb = 0; rb < FRB; ++rb) {
       int kr = rb * 16 + n;
@@ -153,7 +158,6 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
                                      : ((((uint32_t)lane & 15u) << 3) | (uint32_t)Lds<REP>::kT1);
     lane_c2 = (((uint32_t)lane & 15u) << 3) | (uint32_t)Lds<REP>::kT2;
     xlane = (uint32_t)BLds<REP>::kArea + (uint32_t)min(n, 2) * (uint32_t)HID + (uint32_t)q * 64u + (uint32_t)wave * 512u;
-    fbuf = reinterpret_cast<float*>(smem + (grp ? BLds<REP>::kBuf1 : BLds<REP>::kBuf0));
   };
   rederive();
   // a pointer the descriptor holds, as a scalar register pair (the same value in every lane)
@@ -173,7 +177,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   // slot of an item kind: q k v -> X0-2, o -> X3, gate -> X0-2, up -> X3-5, down -> X6-8
 #define SLOT_OF(kind) ((kind) < 4 ? (kind) : (kind) - 4)
 #define ISSUE(Ld, kind) do {                                                                                          \
-    if ((kind) < 4) ld_item(qa[SLOT_OF(kind)], qb[SLOT_OF(kind)], Ld.W[(kind) < 4 ? (kind) : 0], vo_row);             \
+    if ((kind) < 3) ld_item(qa[SLOT_OF(kind)], qb[SLOT_OF(kind)], Ld.W[(3 * w + ((kind) < 3 ? (kind) : 0)) >> 8], vo_q[(kind) < 3 ? (kind) : 0]); \
+    else if ((kind) == 3) ld_item(qa[3], qb[3], Ld.W[3], vo_row);                                                      \
     else if ((kind) < 10) ld_item(qa[SLOT_OF(kind)], qb[SLOT_OF(kind)], Ld.W[4 + ((kind) - 4) / FRB], vo_gu[((kind) - 4) % FRB]); \
     else if ((kind) < 12) ld_item(qa[SLOT_OF(kind)], qb[SLOT_OF(kind)], Ld.W[6], vo_d[(kind) >= 10 ? ((kind) - 10) % 3 : 0]);     \
     else {                                                                                                             \
@@ -210,24 +215,12 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   const long long pos64 = *a.pos;
   const bool pos_ok = pos64 >= 0 && pos64 < (long long)a.max_len;
   const int pos = pos_ok ? (int)pos64 : 0;
-  __syncthreads();
+  had::wg_barrier<true>();
   uint32_t hop = 0;                                 // hand-offs so far in this launch (tag = ebase | hop)
 
   float* red = reinterpret_cast<float*>(smem + B::kRed);
   int* shs = reinterpret_cast<int*>(smem + B::kRed + 256);
   f16* hres = reinterpret_cast<f16*>(smem + B::kH);
-
-  // sum (rms statistic) and maximum over the 256 threads of each transform group, in block_reduce's order
-  auto group_reduce2 = [&](float& sum, float& mx) {
-    sum = had::wave_reduce_to_lane63<false>(sum);
-    mx = had::wave_reduce_to_lane63<true>(mx);
-    __syncthreads();                                  // earlier readers of `red` are done
-    if (lane == 63) { red[wave] = sum; red[16 + wave] = mx; }
-    __syncthreads();
-    const int b = grp * 4;
-    sum = had::fadd(had::fadd(had::fadd(red[b], red[b + 1]), red[b + 2]), red[b + 3]);
-    mx = fmaxf(fmaxf(fmaxf(red[16 + b], red[16 + b + 1]), red[16 + b + 2]), red[16 + b + 3]);
-  };
 
   // ---- all-gather of one or more 4096-vectors (2048 granules each, {2 x fp16, tag}) into LDS as fp16 -------------------
   // NV vectors starting at zbufs[first]; every thread sweeps 2 NV 16-byte pieces; returns with the data in smem + kZs
@@ -253,96 +246,112 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     for (int j = 0; j < 2 * NV; ++j)
       *reinterpret_cast<uint2*>(zs + 2 * (tid + kThreads * j)) = make_uint2(p[j].x, p[j].z);
     own_slots();
-    __syncthreads();
+    had::wg_barrier<true>();
   };
   // this workgroup's 16 values of a product (accumulator rows [row0, row0 + 16), block exponent sh) -> 8 granules
-  auto publish16 = [&](int vec, int row0, int sh, uint32_t tag) {
+  auto publish16 = [&](int vec, int gr0, int row0, int sh, uint32_t tag) {      // gr0: first granule of the block in its vector
     if (tid < 8) {
       const int* s3 = accs + (row0 + 2 * tid) * 4;
       const float us = unscale_of(sh, 2);
       const float f0 = __builtin_fmaf((float)s3[0], 65536.f, __builtin_fmaf((float)s3[1], 256.f, (float)s3[2]));
       const float f1 = __builtin_fmaf((float)s3[4], 65536.f, __builtin_fmaf((float)s3[5], 256.f, (float)s3[6]));
-      esync::st_granule(zbufs + (size_t)vec * 2048 + w * 8 + tid, pack_f16(f0 * us, f1 * us), tag);
+      esync::st_granule(zbufs + (size_t)vec * 2048 + gr0 + tid, pack_f16(f0 * us, f1 * us), tag);
     }
   };
   auto zero_acc = [&](int row0, int rows) {
     for (int i = tid; i < rows * 4; i += kThreads) accs[row0 * 4 + i] = 0;
   };
 
-  // ---- output side of the producer (+ residual) and the input transforms of NC consumers ----------------------------
-  //   have_z: h += SV_prev (.) H z / 64 (z gathered in smem + kZs)     [qlinear.py:106-114 of the producer]
-  //   consumer c: planes_c = digits( sc[c] * rms(h) * H (h (.) ln (.) su[c]) )   [RMSNorm + qlinear.py:90-100]
-  // group g handles consumers g, g + 2; planes of consumer c at area + c * 3 * 4096
-  auto edge = [&](auto nc_tag, bool have_z, const f16* sv_prev, const f16* ln, const f16* const* su, const float* sc) {
+  // ---- output side of the producer (+ residual) and the input transforms of up to two consumers --------------------------
+  //   zvec >= 0: gather z (hand-off `tag`), then h += SV_prev (.) H z / 64                [qlinear.py:106-114 of the producer]
+  //   NC consumers i (NC = 0 | 2; `two` false: only consumer 0): planes_i = digits( sc_i * rms(h) * H (h (.) ln (.) su_i) )
+  //   [RMSNorm + qlinear.py:90-100]; planes of consumer i at area + i * 3 * 4096, block exponent in shs[i]
+  // Transforms: fht_wg512.hip.h (all 512 threads, 8 elements each: input element 8 tid + r, output element tid + 512 k).
+  // The vectors of this thread's elements are requested before the gather waits; after_gather() runs right after it.
+  float* xbuf = reinterpret_cast<float*>(smem + B::kBuf0);
+  auto edge = [&](auto nc_tag, int zvec, uint32_t tag, uint32_t code, const f16* sv_prev, const f16* ln, const f16* su0,
+                  const f16* su1, float sc0, float sc1, bool two, auto after_gather, int sb = -1) {
+#define ESTAMP(i) do { if (sb >= 0) BSTAMP(sb + (i)); } while (0)
     constexpr int NC = decltype(nc_tag)::value;
-    constexpr int ROUNDS = (NC + 1) / 2;
-    // the vectors of this thread's 16 elements: requested before anything waits
-    uint4 psv[2], pln[2], psu[2];
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      if (have_z) psv[hh] = *reinterpret_cast<const uint4*>(sv_prev + e0 + 8 * hh);
-      if (NC > 0) {
-        pln[hh] = *reinterpret_cast<const uint4*>(ln + e0 + 8 * hh);
-        psu[hh] = *reinterpret_cast<const uint4*>(su[grp < NC ? grp : 0] + e0 + 8 * hh);
-      }
-    }
+    const bool have_z = zvec >= 0;
+    uint32_t psv[8];     // fp16 bits
+    u32x4 pln, psu0, psu1;
     if (have_z) {
-      float v[16], tp[16], tr[16];
-      const f16* zs = reinterpret_cast<const f16*>(smem + B::kZs);
-      had::unpack8(*reinterpret_cast<const uint4*>(zs + e0), v);
-      had::unpack8(*reinterpret_cast<const uint4*>(zs + e0 + 8), v + 8);
-      had::unpack8(*reinterpret_cast<const uint4*>(hres + e0), tr);
-      had::unpack8(*reinterpret_cast<const uint4*>(hres + e0 + 8), tr + 8);
-      had::unpack8(psv[0], tp);
-      had::unpack8(psv[1], tp + 8);
-      had::fht16_fixed<12, false>(v, fbuf, 0, tt, grp == 0);
-      f16 o[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[r] = had::out_elem(v[r], 1.f / 64.f, true, tp[r], false, 0.f, true, tr[r]);
-      if (grp == 0) {
-        uint4* dst = reinterpret_cast<uint4*>(hres + e0);
-        dst[0] = *reinterpret_cast<uint4*>(&o[0]);
-        dst[1] = *reinterpret_cast<uint4*>(&o[8]);
+      for (int k = 0; k < 8; ++k) psv[k] = reinterpret_cast<const uint16_t*>(sv_prev)[tid + 512 * k];
+    }
+    if (NC > 0) {
+      pln = *reinterpret_cast<const u32x4*>(ln + 8 * tid);
+      psu0 = *reinterpret_cast<const u32x4*>(su0 + 8 * tid);
+      psu1 = *reinterpret_cast<const u32x4*>(su1 + 8 * tid);
+    }
+    auto u4 = [](const u32x4& v) { return make_uint4(v.x, v.y, v.z, v.w); };
+    if (have_z) {
+      gather(std::integral_constant<int, 1>{}, zvec, tag, code);
+      // The vectors have landed (the gather drained the queue).  Take them over HERE: the compiler counts only its own
+      // loads, so the wait it would place at their first use would also wait for the burst requested below.
+#pragma unroll
+      for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(psv[k]));
+      if (NC > 0) asm volatile("" : "+v"(pln), "+v"(psu0), "+v"(psu1));
+      after_gather();
+      ESTAMP(0);
+      float v[1][8];
+      had::unpack8(*reinterpret_cast<const uint4*>(smem + B::kZs + 16 * tid), v[0]);
+      had8::fht4096<1, true>(v, xbuf, tid);
+      ESTAMP(1);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int idx = tid + 512 * k;
+        hres[idx] = had::out_elem(v[0][k], 1.f / 64.f, true, (float)__builtin_bit_cast(f16, (uint16_t)psv[k]), false, 0.f, true, (float)hres[idx]);
       }
-      __syncthreads();
+      had::wg_barrier<true>();
+      ESTAMP(2);
     }
     if constexpr (NC > 0) {
+      float e[8];
+      had::unpack8(*reinterpret_cast<const uint4*>(hres + 8 * tid), e);
+      const float tot = had8::sumsq4096<true>(e, red, tid);
+      ESTAMP(3);
+      had::mul8(e, u4(pln));
+      float mx0, mx1 = 0.f;
+      if (two) {
+        float v[2][8];
 #pragma unroll
-      for (int r = 0; r < ROUNDS; ++r) {
-        const int c = 2 * r + grp;
-        const bool act = c < NC;
-        uint4 psn[2];      // the next round's SU, requested before this round's transform
-        if (r + 1 < ROUNDS) {
-          const int cn = 2 * (r + 1) + grp;
+        for (int r = 0; r < 8; ++r) v[0][r] = v[1][r] = e[r];
+        had::mul8(v[0], u4(psu0));
+        had::mul8(v[1], u4(psu1));
+        had8::fht4096<2, true>(v, xbuf, tid);
+        ESTAMP(4);
+        mx0 = had::wave_reduce_to_lane63<true>(had8::absmax8(v[0], 1.f));
+        mx1 = had::wave_reduce_to_lane63<true>(had8::absmax8(v[1], 1.f));
+        had::wg_barrier<true>();
+        if (lane == 63) { red[wave] = mx0; red[8 + wave] = mx1; }
+        had::wg_barrier<true>();
+        mx0 = red[0]; mx1 = red[8];
 #pragma unroll
-          for (int hh = 0; hh < 2; ++hh) psn[hh] = *reinterpret_cast<const uint4*>(su[cn < NC ? cn : 0] + e0 + 8 * hh);
-        }
-        float e[16];
-        had::unpack8(*reinterpret_cast<const uint4*>(hres + e0), e);
-        had::unpack8(*reinterpret_cast<const uint4*>(hres + e0 + 8), e + 8);
-        float ss = 0.f;
-        had::sumsq8(e, ss);
-        had::sumsq8(e + 8, ss);
-        had::mul8(e, pln[0]);
-        had::mul8(e + 8, pln[1]);
-        had::mul8(e, psu[0]);
-        had::mul8(e + 8, psu[1]);
-        had::fht16_fixed<12, false>(e, fbuf, 0, tt, act);
-        float tot = ss, mx = had::absmax16(e, 1.f);
-        group_reduce2(tot, mx);
-        const float scale = had::rms_scale(sc[act ? c : 0], tot, HID, a.rms_eps);
-        const int sh = had::shift_for(had::fmul(mx, fabsf(scale)));
-        uint4 dg[3];
-        had::planes16(e, scale, sh, dg);
-        if (act) {
+        for (int i = 1; i < 8; ++i) { mx0 = fmaxf(mx0, red[i]); mx1 = fmaxf(mx1, red[8 + i]); }
+        const float s0 = had::rms_scale(sc0, tot, HID, a.rms_eps), s1 = had::rms_scale(sc1, tot, HID, a.rms_eps);
+        const int sh0 = had::shift_for(had::fmul(mx0, fabsf(s0))), sh1 = had::shift_for(had::fmul(mx1, fabsf(s1)));
+        ESTAMP(5);
+        had8::planes_scatter(v[0], s0, sh0, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
+        had8::planes_scatter(v[1], s1, sh1, reinterpret_cast<uint8_t*>(smem + B::kArea + 3 * HID), tid);
+        if (tid == 0) { shs[0] = sh0; shs[1] = sh1; }
+      } else {
+        float v[1][8];
 #pragma unroll
-          for (int d = 0; d < 3; ++d) *reinterpret_cast<uint4*>(smem + B::kArea + (c * 3 + d) * HID + e0) = dg[d];
-          if (tt == 0) shs[c] = sh;
-        }
-        if (r + 1 < ROUNDS) { psu[0] = psn[0]; psu[1] = psn[1]; }
+        for (int r = 0; r < 8; ++r) v[0][r] = e[r];
+        had::mul8(v[0], u4(psu0));
+        had8::fht4096<1, true>(v, xbuf, tid);
+        mx0 = had8::max4096<true>(had8::absmax8(v[0], 1.f), red, tid);
+        const float s0 = had::rms_scale(sc0, tot, HID, a.rms_eps);
+        const int sh0 = had::shift_for(had::fmul(mx0, fabsf(s0)));
+        had8::planes_scatter(v[0], s0, sh0, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
+        if (tid == 0) shs[0] = sh0;
       }
-      __syncthreads();
+      had::wg_barrier<true>();
+      ESTAMP(6);
     }
+#undef ESTAMP
   };
 
   // ---- one item of a product: slot s, digit planes at xa ------------------------------------------------------------
@@ -358,29 +367,39 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     }
   };
 
+  const f16* sv_d_prev = nullptr;
+  const BlockLayer& Ld = *reinterpret_cast<const BlockLayer*>(smem + B::kDesc);
   for (int l = 0; l < a.n_layers; ++l) {
-    const BlockLayer& Ld = a.layers[l];
+    if (tid < 64) reinterpret_cast<uint32_t*>(smem + B::kDesc)[tid] = reinterpret_cast<const uint32_t*>(a.layers + l)[tid];
+    had::wg_barrier<true>();
     dbg_on = a.dbg != nullptr && l == a.dbg_layer;
     rederive();
     BSTAMP(0);
     // ================= P1: (previous down's output side) + input transforms of q, k, v; their products ===============
-    if (l > 0) {
-      gather(std::integral_constant<int, 1>{}, 5, ebase | hop, 0x4000u);
-      ISSUE(Ld, 0); ISSUE(Ld, 1); ISSUE(Ld, 2);        // burst A: q, k, v of this block (X0-2: gate's slots, consumed)
-    }
-    BSTAMP(1);
-    edge(std::integral_constant<int, 3>{}, l > 0, l > 0 ? a.layers[l - 1].sv[6] : nullptr, Ld.ln[0], Ld.su, Ld.sc);
+    const int c_lo = (3 * w) >> 8, c_hi = (3 * w + 2) >> 8;         // the one or two matrices this workgroup's row blocks are in
+    edge(std::integral_constant<int, 2>{}, l > 0 ? 5 : -1, ebase | hop, 0x4000u, sv_d_prev, Ld.ln[0], Ld.su[c_lo], Ld.su[c_hi],
+         Ld.sc[c_lo], Ld.sc[c_hi], c_hi != c_lo, [&]() {
+      ISSUE(Ld, 0); ISSUE(Ld, 1); ISSUE(Ld, 2);        // burst A: q, k, v row blocks of this block (X0-2: gate's slots, consumed)
+      BSTAMP(1);
+    });
     BSTAMP(2);
     esync::drain();                                    // q, k, v have landed (requested one transform stage ago)
     own_slots();
 #pragma unroll
-    for (int c = 0; c < 3; ++c) run_item(c, xlane + (uint32_t)(c * 3 * HID), c * 16);
-    __syncthreads();
+    for (int i = 0; i < 3; ++i) {
+      const int ci = (3 * w + i) >> 8;
+      run_item(i, xlane + (uint32_t)((ci == c_lo ? 0 : 1) * 3 * HID), i * 16);
+    }
+    had::wg_barrier<true>();
     ++hop;                                             // hand-off: z_q, z_k, z_v
 #pragma unroll
-    for (int c = 0; c < 3; ++c) publish16(c, c * 16, shs[c], ebase | hop);
-    __syncthreads();
+    for (int i = 0; i < 3; ++i) {
+      const int rbq = 3 * w + i, ci = rbq >> 8;
+      publish16(ci, (rbq & 255) * 8, i * 16, shs[ci == c_lo ? 0 : 1], ebase | hop);
+    }
+    had::wg_barrier<true>();
     zero_acc(0, 48);
+    ISSUE(Ld, 3);                                      // burst B: o of this block (X3: up's slot, consumed): 16 KB per CU, lands inside the hand-off's latency
     BSTAMP(3);
 
     // ================= P2: attention ====================================================================================
@@ -388,15 +407,15 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     const bool head_wg = (w & 7) == 0;
     const int hd = w >> 3;
     if (head_wg) {
-      // vectors first, then the gather
-      uint4 psv[2][2];
+      // vectors first, then the gather.  After the transforms thread t holds elements t + 512 k: this head's 128 values
+      // of q, k, v are register hd >> 2 of the threads [128 (hd & 3), +128)
+      const int kreg = hd >> 2, tloc = tid - 128 * (hd & 3);
+      const bool mine = tloc >= 0 && tloc < HD;
+      f16 psv[3];
       float c8[8], s8[8];
       const int d0 = (tid & 15) * 8;
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        psv[0][hh] = *reinterpret_cast<const uint4*>(Ld.sv[grp] + e0 + 8 * hh);        // q (group 0) / k (group 1)
-        psv[1][hh] = *reinterpret_cast<const uint4*>(Ld.sv[2] + e0 + 8 * hh);          // v
-      }
+      for (int c = 0; c < 3; ++c) psv[c] = Ld.sv[c][mine ? HD * hd + tloc : 0];
       {
         const float* cs = a.cos + (size_t)pos * HD;
         const float* sn = a.sin + (size_t)pos * HD;
@@ -404,37 +423,22 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         for (int i = 0; i < 8; ++i) { c8[i] = cs[d0 + i]; s8[i] = sn[d0 + i]; }
       }
       gather(std::integral_constant<int, 3>{}, 0, ebase | hop, 0x5000u);
-      ISSUE(Ld, 3);                                    // burst B: o of this block (X3)
       BSTAMP(4);
       f16* s_qkv = reinterpret_cast<f16*>(smem + B::kQkv);
-      const f16* zs = reinterpret_cast<const f16*>(smem + B::kZs);
-      // both inputs of this thread are read before the first transform (group 1's shuffle buffer lies over z_v)
-      float zin[2][16];
+      {
+        float v[3][8];
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int c = r == 0 ? grp : 2;
-        had::unpack8(*reinterpret_cast<const uint4*>(zs + c * HID + e0), zin[r]);
-        had::unpack8(*reinterpret_cast<const uint4*>(zs + c * HID + e0 + 8), zin[r] + 8);
-      }
-      __syncthreads();
+        for (int c = 0; c < 3; ++c) had::unpack8(*reinterpret_cast<const uint4*>(smem + B::kZs + c * HID * 2 + 16 * tid), v[c]);
+        had8::fht4096<3, true>(v, xbuf, tid);
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int c = r == 0 ? grp : 2;               // round 0: q | k, round 1: v (group 0)
-        const bool act = r == 0 || grp == 0;
-        float tp[16];
-        had::unpack8(psv[r][0], tp);
-        had::unpack8(psv[r][1], tp + 8);
-        had::fht16_fixed<12, false>(zin[r], fbuf, 0, tt, act);
-        if (act && e0 >= hd * HD && e0 < hd * HD + HD) {
-          f16 o[16];
+        for (int c = 0; c < 3; ++c) {
+          float val = v[c][0];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) o[i] = had::out_elem(zin[r][i], 1.f / 64.f, true, tp[i], false, 0.f, false, 0.f);
-          uint4* dst = reinterpret_cast<uint4*>(s_qkv + c * HD + (e0 - hd * HD));
-          dst[0] = *reinterpret_cast<uint4*>(&o[0]);
-          dst[1] = *reinterpret_cast<uint4*>(&o[8]);
+          for (int k = 1; k < 8; ++k) val = kreg == k ? v[c][k] : val;
+          if (mine) s_qkv[c * HD + tloc] = had::out_elem(val, 1.f / 64.f, true, (float)psv[c], false, 0.f, false, 0.f);
         }
       }
-      __syncthreads();
+      had::wg_barrier<true>();
       BSTAMP(5);
       // single-query attention of head hd over positions [0, pos] (decode_glue.hip's arithmetic): 16 lanes per key,
       // 16 key groups with their own online-softmax state, merged through LDS
@@ -520,7 +524,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) s_acc[g * (HD + 4) + d0 + i] = acc8[i];
       }
-      __syncthreads();
+      had::wg_barrier<true>();
       f16* s_a = s_qkv + 3 * HD;
       if (tid < HD) {
         float M = -INFINITY, Lsum = 0.f, o = 0.f;
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         }
         s_a[tid] = pos_ok ? (f16)(o / Lsum) : __builtin_bit_cast(f16, (unsigned short)0x7e00);
       }
-      __syncthreads();
+      had::wg_barrier<true>();
       ++hop;                                           // hand-off: attention output
       if (tid < 64) {
         const uint32_t pr = *reinterpret_cast<const uint32_t*>(s_a + 2 * tid);
@@ -545,50 +549,40 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     rederive();
     {
       // o_proj's input side: x = H (a (.) SU_o) * sc  (no norm), every workgroup
-      uint4 psu[2];
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) psu[hh] = *reinterpret_cast<const uint4*>(Ld.su[3] + e0 + 8 * hh);
+      const u32x4 psu = *reinterpret_cast<const u32x4*>(Ld.su[3] + 8 * tid);
       gather(std::integral_constant<int, 1>{}, 3, ebase | hop, 0x6000u);
-      if (!head_wg) ISSUE(Ld, 3);                      // burst B for the workgroups that skipped the transforms
-      ISSUE(Ld, 4); ISSUE(Ld, 5); ISSUE(Ld, 6);        // and gate's row blocks (X0-2: q, k, v consumed)
       BSTAMP(7);
-      const f16* zs = reinterpret_cast<const f16*>(smem + B::kZs);
-      float e[16];
-      had::unpack8(*reinterpret_cast<const uint4*>(zs + e0), e);
-      had::unpack8(*reinterpret_cast<const uint4*>(zs + e0 + 8), e + 8);
-      had::mul8(e, psu[0]);
-      had::mul8(e + 8, psu[1]);
-      had::fht16_fixed<12, false>(e, fbuf, 0, tt, grp == 0);
-      float dummy = 0.f, mx = had::absmax16(e, Ld.sc[3]);
-      group_reduce2(dummy, mx);
+      float v[1][8];
+      had::unpack8(*reinterpret_cast<const uint4*>(smem + B::kZs + 16 * tid), v[0]);
+      had::mul8(v[0], make_uint4(psu.x, psu.y, psu.z, psu.w));
+      had8::fht4096<1, true>(v, xbuf, tid);
+      const float sco = Ld.sc[3];
+      const float mx = had8::max4096<true>(had8::absmax8(v[0], sco), red, tid);
       const int sh = had::shift_for(mx);
-      uint4 dg[3];
-      had::planes16(e, Ld.sc[3], sh, dg);
-      if (grp == 0) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) *reinterpret_cast<uint4*>(smem + B::kArea + d * HID + e0) = dg[d];
-        if (tt == 0) shs[3] = sh;
-      }
-      __syncthreads();
+      had8::planes_scatter(v[0], sco, sh, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
+      if (tid == 0) shs[3] = sh;
+      had::wg_barrier<true>();
     }
     BSTAMP(8);
     esync::drain();
     own_slots();
     run_item(3, xlane, 48);
-    __syncthreads();
+    ISSUE(Ld, 4); ISSUE(Ld, 5); ISSUE(Ld, 6);          // gate's row blocks (X0-2: q, k, v consumed): they land during the z_o hand-off's latency
+    had::wg_barrier<true>();
     ++hop;                                             // hand-off: z_o
-    publish16(4, 48, shs[3], ebase | hop);
-    __syncthreads();
+    publish16(4, w * 8, 48, shs[3], ebase | hop);
+    had::wg_barrier<true>();
     zero_acc(48, 16);
     BSTAMP(9);
 
     // ================= P3: o's output side + residual, RMSNorm, input transforms of gate / up; their products =========
     rederive();
-    gather(std::integral_constant<int, 1>{}, 4, ebase | hop, 0x7000u);
-    ISSUE(Ld, 7); ISSUE(Ld, 8); ISSUE(Ld, 9);          // burst C: up's row blocks (X3-5) and down (X6-8)
-    ISSUE(Ld, 10); ISSUE(Ld, 11); ISSUE(Ld, 12);
-    BSTAMP(10);
-    edge(std::integral_constant<int, 2>{}, true, Ld.sv[3], Ld.ln[1], Ld.su + 4, Ld.sc + 4);
+    edge(std::integral_constant<int, 2>{}, 4, ebase | hop, 0x7000u, Ld.sv[3], Ld.ln[1], Ld.su[4], Ld.su[5], Ld.sc[4], Ld.sc[5], true,
+         [&]() {
+      ISSUE(Ld, 7); ISSUE(Ld, 8); ISSUE(Ld, 9);        // burst C: up's row blocks (X3-5) and down (X6-8)
+      ISSUE(Ld, 10); ISSUE(Ld, 11); ISSUE(Ld, 12);
+      BSTAMP(10);
+    }, 18);
     BSTAMP(11);
     // row owners: SV_gate / SV_up / SU_down of their row, and everybody's image of the K x K factors, for the MLP edge
     {
@@ -609,7 +603,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       const int m = i / FRB;
       run_item(i, xlane + (uint32_t)(m * 3 * HID), 64 + i * 16);
     }
-    __syncthreads();
+    had::wg_barrier<true>();
     BSTAMP(12);
 
     // ================= P4: the MLP edge (decode_engine.hip) and down's product ==========================================
@@ -622,7 +616,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         const float f = __builtin_fmaf((float)s3[0], 65536.f, __builtin_fmaf((float)s3[1], 256.f, (float)s3[2]));
         zcol[tid] = (float)(f16)(f * unscale_of(shs[m], 2));
       }
-      __syncthreads();
+      had::wg_barrier<true>();
       zero_acc(64, 96);
       ++hop;                                           // hand-off: column -> row owners
       const uint32_t tag1 = ebase | hop;
@@ -735,7 +729,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
             if (esync::spin_step(f.y == tag2, spins0, ctl + 1, 0x3000u + (uint32_t)w)) break;
           }
         }
-        __syncthreads();
+        had::wg_barrier<true>();
         u32x4_t p[NP];
         uint32_t spins = 0;
         for (;;) {
@@ -768,7 +762,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         }
         own_slots();
       }
-      __syncthreads();
+      had::wg_barrier<true>();
       BSTAMP(15);
       typedef float f32x4 __attribute__((ext_vector_type(4)));
       f32x4 acc[2][FRB];
@@ -839,7 +833,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           for (int d = 0; d < 3; ++d) *reinterpret_cast<uint32_t*>(pl + d * B::kPlaneD + off) = 0u;
         }
       }
-      __syncthreads();
+      had::wg_barrier<true>();
       BSTAMP(16);
       const uint32_t xlane_d = (uint32_t)B::kArea + (uint32_t)min(n, 2) * (uint32_t)B::kPlaneD + (uint32_t)q * 64u;
 #pragma unroll
@@ -857,21 +851,18 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           }
         }
       }
-      __syncthreads();
+      had::wg_barrier<true>();
       ++hop;                                           // hand-off: z_d
-      publish16(5, 160, sh_d, ebase | hop);
-      __syncthreads();
+      publish16(5, w * 8, 160, sh_d, ebase | hop);
+      had::wg_barrier<true>();
       zero_acc(160, 16);
       BSTAMP(17);
     }
+    sv_d_prev = Ld.sv[6];
   }
   // ---- the last block's down: output side + residual -> h_out ------------------------------------------------------
   rederive();
-  gather(std::integral_constant<int, 1>{}, 5, ebase | hop, 0x4000u);
-  {
-    const f16* const* none = nullptr;
-    edge(std::integral_constant<int, 0>{}, true, a.layers[a.n_layers - 1].sv[6], nullptr, none, nullptr);
-  }
+  edge(std::integral_constant<int, 0>{}, 5, ebase | hop, 0x4000u, sv_d_prev, nullptr, nullptr, nullptr, 0.f, 0.f, false, [&]() {});
   if (w == 0) {
     *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.h_out) + tid * 16) = *reinterpret_cast<const u32x4*>(smem + B::kH + tid * 16);
     if (tid == 0) esync::st_word(ctl, ebase >> 10);

@@ -31,6 +31,16 @@ __device__ __forceinline__ float silu(float g) {
   return g * __builtin_amdgcn_rcpf(1.f + __expf(-g));
 }
 
+// Workgroup barrier between LDS phases.  RAW = false: __syncthreads() (a workgroup fence: s_waitcnt vmcnt(0) lgkmcnt(0) +
+// s_barrier).  RAW = true: only the LDS counter is drained before the s_barrier -- for kernels that keep vector-memory
+// loads in flight across their LDS phases on purpose (the persistent decode engine's weight requests) and exchange
+// nothing through global memory inside the workgroup at that point.
+template <bool RAW>
+__device__ __forceinline__ void wg_barrier() {
+  if constexpr (RAW) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else __syncthreads();
+}
+
 // LDS index with one pad word per 32 (keeps the strided pass reads off a single bank)
 __device__ __forceinline__ int pad(int i) { return i + (i >> 5); }
 __host__ __device__ constexpr int buf_floats(int elems) { return elems + (elems >> 5) + 4; }
@@ -283,21 +293,21 @@ __device__ __forceinline__ void fht16_lanes(float v[16], int t) {
 // PP (ping-pong): pass P stores to half (P & 1) of a buffer of 2 * buf_floats(E) floats, so that a
 // pass needs ONE barrier (store -> barrier -> load) instead of two; one more barrier at entry
 // protects the buffer from earlier readers.  Same data movement, same results.
-template <int LOGL, int P, bool PP>
+template <int LOGL, int P, bool PP, bool RAW = false>
 __device__ __forceinline__ void fht16_passes(float v[16], float* buf, int stride, int t, bool active) {
   constexpr int NPASS = (LOGL + 3) / 4;
   if constexpr (P == 0 && LOGL > 4) {
     // passes 0 and 1 without LDS (fht16_lanes); longer transforms hand over in natural order -- pass 0's store
     // mapping -- in the half pass 1 would have written
-    if constexpr (NPASS <= 2) __syncthreads();   // callers order their own LDS data (reduction slots, staged rows) across this call
+    if constexpr (NPASS <= 2) wg_barrier<RAW>();   // callers order their own LDS data (reduction slots, staged rows) across this call
     fht16_lanes<LOGL>(v, t);
-    if constexpr (NPASS <= 2) __syncthreads();
+    if constexpr (NPASS <= 2) wg_barrier<RAW>();
     if constexpr (NPASS > 2) {
       float* cur = PP ? buf + stride : buf;
-      __syncthreads();   // the buffer's earlier readers are done
+      wg_barrier<RAW>();   // the buffer's earlier readers are done
       if (active) FhtPass<LOGL, 0>::store(v, cur, t);
-      __syncthreads();
-      fht16_passes<LOGL, 2, PP>(v, buf, stride, t, active);
+      wg_barrier<RAW>();
+      fht16_passes<LOGL, 2, PP, RAW>(v, buf, stride, t, active);
     }
   } else if constexpr (P < NPASS) {
     using Pass = FhtPass<LOGL, P>;
@@ -306,17 +316,17 @@ __device__ __forceinline__ void fht16_passes(float v[16], float* buf, int stride
     if (P > 0 && active) Pass::load(v, prev, t);
     Pass::butterflies(v);
     if (NPASS > 1) {
-      if (!PP || P == 0) __syncthreads();  // !PP: everyone has read its pass-P inputs; PP: entry barrier
+      if (!PP || P == 0) wg_barrier<RAW>();  // !PP: everyone has read its pass-P inputs; PP: entry barrier
       if (active) Pass::store(v, cur, t);
-      __syncthreads();
+      wg_barrier<RAW>();
     }
-    fht16_passes<LOGL, P + 1, PP>(v, buf, stride, t, active);
+    fht16_passes<LOGL, P + 1, PP, RAW>(v, buf, stride, t, active);
   }
 }
 
-template <int LOGL, bool PP>
+template <int LOGL, bool PP, bool RAW = false>
 __device__ __forceinline__ void fht16_fixed(float v[16], float* buf, int stride, int t, bool active) {
-  fht16_passes<LOGL, 0, PP>(v, buf, stride, t, active);
+  fht16_passes<LOGL, 0, PP, RAW>(v, buf, stride, t, active);
   constexpr int NPASS = (LOGL + 3) / 4;
   if (NPASS > 2 && active) {  // back to 16 consecutive elements per thread (up to 2^8 they never left)
     const float* b = buf + (PP ? ((NPASS - 1) & 1) * stride : 0) + (16 * t + ((16 * t) >> 5));

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Phase clocks of one block inside the persistent token launch (csrc/decode_block.hip, BSTAMP), Llama-2-7B shape.
+usage: python tools/block_stamps.py [layers] [dbg_layer] [pos]"""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from quip_for_all_amd import decode as D  # noqa: E402
+
+layers = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+dl = int(sys.argv[2]) if len(sys.argv) > 2 else layers // 2
+pos0 = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+shape = D.LlamaShape(hidden=4096, ffn=11008, layers=layers, heads=32, kv_heads=32, vocab=32000)
+dec = D.LlamaDecoder(shape, "E8P12", max_len=max(256, pos0 + 16), device="cuda:0", seed=0, device_init=True)
+assert dec.block_eng
+dec.reset(7)
+dec.pos.fill_(pos0)
+h = dec.embed[dec.tok].reshape(-1)
+dbg = torch.zeros(256 * 32, dtype=torch.int64, device="cuda:0")
+names = ["(top)", "z_d gathered + burst A", "edge: out(down) + in(q,k,v)", "gemv q,k,v + publish", "head: z_qkv gathered", "head: out(q,k,v)",
+         "attention + publish a", "a gathered", "in(o)", "gemv o + publish", "z_o gathered", "edge: out(o) + in(gate,up)",
+         "gemv gate,up", "kmix + publish (mlp hop 1)", "row owner", "rows gathered", "kmix_in + planes", "gemv down + publish"]
+acc = []
+args = (dec.eng_layers, h, dec.pos, dec.cos, dec.sin, dec.layers[0]["q"].codebook.grid_packed_abs, dec.eng_ws, layers, dec.max_len,
+        shape.rms_eps, 1.0 / math.sqrt(128))
+for it in range(6):
+    dbg.zero_()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    torch.ops.quip_lib.block_engine(*args, dbg, dl)
+    e1.record()
+    torch.cuda.synchronize()
+    if it >= 2:
+        d = dbg.cpu().numpy().reshape(256, 32)[:, :25].astype(np.float64)
+        acc.append((d, e0.elapsed_time(e1) * 1e3))
+print(f"status {dec.engine_status()}; launch of {layers} blocks: {np.median([t for _, t in acc]):.1f} us = {np.median([t for _, t in acc]) / layers:.2f} us per block")
+head = np.arange(256) % 8 == 0
+D_ = np.stack([d for d, _ in acc])          # (runs, 256, 18)
+print("clocks between stamps inside block %d (mean over workgroups | head workgroups | others), s_memtime ticks:" % dl)
+tot = 0
+for i in range(1, 18):
+    prev = i - 1
+    if i in (4, 5, 6):                      # head-only stamps
+        seg = D_[:, head, i] - D_[:, head, prev if i > 4 else 3]
+        print(f"  {i:2d} {names[i]:34s} {'':>9s} {seg.mean():9.0f}")
+        continue
+    if i == 7:                              # from stamp 3 (others) / 6 (heads)
+        so = D_[:, ~head, 7] - D_[:, ~head, 3]
+        sh = D_[:, head, 7] - D_[:, head, 6]
+        print(f"  {i:2d} {names[i]:34s} {'':>9s} {sh.mean():9.0f} {so.mean():9.0f}")
+        continue
+    seg = D_[:, :, i] - D_[:, :, prev]
+    print(f"  {i:2d} {names[i]:34s} {seg.mean():9.0f} {seg[:, head].mean():9.0f} {seg[:, ~head].mean():9.0f}")
+span = D_[:, :, 17] - D_[:, :, 0]
+print(f"  block span (stamp 0 -> 17): {span.mean():.0f} ticks")
+en = ["(after burst C)", "out: fht<1>", "out: h written + barrier", "sumsq", "in: mul + fht<2>", "in: max reduce", "planes + barrier"]
+print("inside the gate / up edge (stamps 18..24):")
+for i in range(1, 7):
+    seg = D_[:, :, 18 + i] - D_[:, :, 18 + i - 1]
+    print(f"  {en[i]:28s} {seg.mean():9.0f}")
+print(f"  (stamp 10 -> 18: {(D_[:, :, 18] - D_[:, :, 10]).mean():.0f}, 24 -> 11: {(D_[:, :, 11] - D_[:, :, 24]).mean():.0f})")
