@@ -10,11 +10,12 @@ layers are E8P12 2-bit QuantLinear (BASELINE.json configs[1]), on N GPUs of one 
 * multi-GPU = independent replicas (the Hadamard transform precludes tensor parallelism, SURVEY
   8e): every rank decodes its own sequence, no data-path collective; value = all ranks' tokens /
   max-over-ranks time; scaling "weak";
-* `roofline`: the dominant kernel is the E8P12 decode GEMV.  Its launches (4 per decoder block:
-  q/k/v group, o, gate/up group, down) are timed live with HIP events on the launch stream
-  (graph over the model's own per-layer weights, so every launch streams different HBM bytes); achieved = algorithmic bytes (Qidxs + x + y) / mean
-  launch duration; peak = 8 TB/s.  `traffic` = measured HBM bytes per launch from the PMC pass
-  committed under profiles/ (null when that file is absent);
+* `roofline`: the dominant kernel.  Llama-2-7B E8P12 decodes a token with ONE persistent launch for all 32 blocks
+  (`decode_block_kernel`, csrc/decode_block.hip): it is timed live with HIP events on the launch stream (graph replay of
+  that launch alone), achieved = the algorithmic bytes of the 224 QuantLinear calls it contains (codes + x + y + SU / SV,
+  SURVEY 8d) / its duration; peak = 8 TB/s.  Models the persistent launch does not take (70B, other codebooks) report
+  the stage-wise step's GEMV launches the same way (4 per block, each on its own layer's weights).  `traffic` = measured
+  HBM bytes per launch from the PMC pass committed under profiles/ (null when that file is absent);
 * `cpu_baseline`: the CPU oracle (a port of the reference semantics: the reference has no CPU
   inference path) timed on this host for one layer of each Llama-7B shape and extrapolated to
   tokens/s.
@@ -110,6 +111,106 @@ def gemv_roofline(dec):
             "mean_launch_us": round(per_launch_s * 1e6, 3)}
 
 
+def engine_roofline(dec):
+    """the persistent token launch (decode_block_kernel) alone, replayed from a hipGraph and timed with HIP events on
+    the launch stream; algorithmic bytes = SURVEY 8d's per-call figure summed over the launch's QuantLinear calls"""
+    import math
+    dev = dec.dev
+    s = dec.s
+    h = dec.embed[:1].reshape(-1).clone()
+    pos = torch.full((1,), 64, dtype=torch.long, device=dev)
+    grid = dec.layers[0]["q"].codebook.grid_packed_abs
+    args = (dec.eng_layers, h, pos, dec.cos, dec.sin, grid, dec.eng_ws, len(dec.layers), dec.max_len, s.rms_eps,
+            1.0 / math.sqrt(s.head_dim))
+    torch.ops.quip_lib.block_engine(*args)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.cuda.graph(graph, stream=side):
+        torch.ops.quip_lib.block_engine(*args)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(8):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        graph.replay()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e-3)
+    t = float(np.median(ts[2:]))
+    algo = 0
+    for layer in dec.layers:
+        for m in layer.values():
+            if hasattr(m, "Qidxs"):
+                algo += m.Qidxs.numel() * m.Qidxs.element_size() + 4 * (m.in_features + m.out_features)
+    achieved = algo / t / 1e9
+    traffic = traffic_src = None
+    pf = os.path.join(REPO, "profiles", "engine_hbm_traffic.json")
+    if os.path.exists(pf):
+        try:
+            j = json.load(open(pf))
+            traffic = j.get("hbm_bytes_per_launch")
+            traffic_src = "profiles/engine_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2, %s)" % j.get("measured_at", "?")
+        except Exception:
+            traffic = None
+    return {"bound": "hbm", "kernel": "decode_block_kernel (one persistent launch per token: all %d blocks)" % len(dec.layers),
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "traffic": traffic, "traffic_source": traffic_src, "launches": 1, "algorithmic_bytes_per_launch": algo,
+            "mean_launch_us": round(t * 1e6, 1), "us_per_block": round(t * 1e6 / len(dec.layers), 2),
+            "engine_status": dec.engine_status()}
+
+
+def gemv_per_shape(shapes, dev, pool_bytes=640 << 20, iters=100):
+    """SURVEY 8d layer micro-bench inside the bench run: the default bs=1 E8P12 GEMV entry point on every (n, k) of
+    `shapes`, weights cycled through a pool larger than the 256 MB Infinity Cache, `iters` launches per graph replay,
+    HIP-event timed; frac = algorithmic bytes (codes + x + y) / time / 8 TB/s"""
+    import quip_for_all_amd as Q
+    from quip_for_all_amd import capi
+    L = capi.lib()
+    grid = Q.codebook.codebook_id["E8P12"](inference=True).to(dev).grid_packed_abs
+    st = lambda: torch.cuda.current_stream().cuda_stream   # noqa: E731
+    out = {}
+    for n, k in shapes:
+        wbytes = n * k // 4
+        npool = max(4, pool_bytes // wbytes + 1)
+        g = torch.Generator(device=dev).manual_seed(0)
+        pool = [torch.randint(-32768, 32767, (n, k // 8), generator=g, dtype=torch.int32, device=dev).to(torch.int16)
+                for _ in range(npool)]
+        x = torch.randn(1, k, device=dev).half()
+        planes = torch.empty(L.quip_e8p_planes_bytes(k), dtype=torch.uint8, device=dev)
+        capi.check(L.quip_e8p_x_to_planes(x.data_ptr(), planes.data_ptr(), k, st()), "planes")
+        y = torch.empty(1, n, dtype=torch.float16, device=dev)
+        ws = torch.zeros(max(L.quip_e8p_gemv_workspace_bytes(n) // 4, 1), dtype=torch.int32, device=dev)
+        call = lambda i: capi.check(L.quip_e8p_gemv_planes_ws(planes.data_ptr(), pool[i % npool].data_ptr(), grid.data_ptr(),   # noqa: E731
+                                                              y.data_ptr(), n, k, ws.data_ptr(), ws.numel() * 4, st()), "gemv")
+        for i in range(3):
+            call(i)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.cuda.graph(gr, stream=side):
+            for i in range(iters):
+                call(i)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(4):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            gr.replay()
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b) * 1e3 / iters)
+        us = sorted(ts)[1]
+        algo = n * k // 4 + 2 * k + 2 * n
+        out["%dx%d" % (n, k)] = {"algorithmic_bytes": algo, "us_per_launch": round(us, 2), "GBps": round(algo / us / 1e3, 1),
+                                 "frac": round(algo / us / 1e3 / HBM_PEAK_GBPS, 4)}
+        del pool, gr
+        torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline(budget_s=25.0):
     """CPU oracle ("port": the reference has no CPU path) on one layer of each 7B shape; tokens/s =
     1 / (32 * (4 t_4096x4096 + 2 t_11008x4096 + t_4096x11008) + lm_head)."""
@@ -199,14 +300,17 @@ def decode_parity_check(dec, n_tokens=8):
     import torch
     with torch.no_grad():
         fused = dec.generate(n_tokens, first_token=7, use_graph=True).cpu().tolist()
-        saved = (dec.fused_prologue, dec.chain)
+        saved = (dec.fused_prologue, dec.chain, getattr(dec, "block_eng", False), getattr(dec, "ffn_eng", False))
         try:
             dec.fused_prologue, dec.chain = False, False      # (the fused transforms / GEMVs are bit identical by design;
+            dec.block_eng = dec.ffn_eng = False               # no persistent launch either: one launch per stage
             plain = dec.generate(n_tokens, first_token=7, use_graph=False).cpu().tolist()   # attention stays as it is)
         finally:
-            dec.fused_prologue, dec.chain = saved
-    return {"tokens": n_tokens, "captured_fused_step_equals_eager_unfused_step": fused == plain,
-            "first_tokens": fused}
+            dec.fused_prologue, dec.chain, dec.block_eng, dec.ffn_eng = saved
+    return {"tokens": n_tokens, "captured_step_equals_eager_unfused_step": fused == plain,
+            "captured_step": "persistent block launch" if saved[2] else ("stage-wise + MLP launch" if saved[3] else "stage-wise"),
+            "engine_status": dec.engine_status() if hasattr(dec, "engine_status") else 0,
+            "first_tokens": fused, "first_tokens_unfused": plain}
 
 
 def time_decoder(D, shape, codebook, steps, warmup, device, **cb_kwargs):
@@ -231,7 +335,13 @@ def time_decoder(D, shape, codebook, steps, warmup, device, **cb_kwargs):
            "warmup": warmup, "algorithmic_bytes_per_token": algo,
            "token_roofline_frac": round(steps / dt / (HBM_PEAK_GBPS * 1e9 / algo), 4)}
     if codebook == "E8P12":
-        out["gemv_roofline"] = gemv_roofline(dec)
+        out["gemv_roofline"] = engine_roofline(dec) if getattr(dec, "block_eng", False) else gemv_roofline(dec)
+    if codebook == "E8P12" and shape.hidden == 8192:
+        # the north star's target shapes, timed here so that the driver's run holds them (SURVEY 8d layer micro-bench)
+        del dec
+        torch.cuda.empty_cache()
+        out["per_shape"] = gemv_per_shape([(28672, 8192), (8192, 28672), (8192, 8192), (1024, 8192)], device)
+        return out
     del dec
     torch.cuda.empty_cache()
     return out
@@ -350,7 +460,7 @@ def main():
                                "frac": round(tok_s / world / (HBM_PEAK_GBPS * 1e9 / algo_bytes), 4)},
         }
         if a.codebook == "E8P12":
-            out["roofline"] = gemv_roofline(dec)
+            out["roofline"] = engine_roofline(dec) if getattr(dec, "block_eng", False) else gemv_roofline(dec)
         try:
             out["parity"] = decode_parity_check(dec)
         except Exception as e:

@@ -36,10 +36,22 @@ with open(f"{R}/gpurun_out/{tag}_bench_fetch_size.txt", "w") as f:
         rows = c.execute(f"select {namecol}, count(*), sum(value), avg(value) from counters_collection where counter_name='FETCH_SIZE' group by {namecol} order by 3 desc").fetchall()
         print("%-100s %8s %16s %16s" % ("kernel", "dispatches", "sum FETCH_SIZE", "mean/dispatch"), file=f)
         gsum = gcnt = 0
+        esum = ecnt = 0
         for name, n, s, avg in rows[:30]:
             print("%-100s %8d %16.1f %16.2f" % (name[:100], n, s, avg), file=f)
             if "e8p_gemv_mfma_kernel" in name or "e8p_gemv_v2_kernel" in name:
                 gsum += s; gcnt += n
+            if "decode_block_kernel" in name:
+                esum += s; ecnt += n
+        if ecnt:
+            raw = esum / ecnt
+            j = {"counter": "FETCH_SIZE", "raw_mean_per_launch": raw, "unit_assumed": "KB", "gfx950_correction": 2.0,
+                 "hbm_bytes_per_launch": raw * 1024 * 2.0, "dispatches": ecnt,
+                 "kernels": "decode_block_kernel dispatches of the run (one per token: all blocks)",
+                 "measured_at": "round 3 (%s), tools/prof_bench.sh %s" % (tag, "$*"),
+                 "source": "rocprofv3 --pmc FETCH_SIZE pass of bench.py, tools/prof_bench.sh"}
+            print("# ENGINE:", json.dumps(j), file=f)
+            json.dump(j, open(f"{R}/gpurun_out/{tag}_engine_hbm_traffic.json", "w"))
         if gcnt:
             raw = gsum / gcnt
             # FETCH_SIZE is reported in KiB-ish units of 64-B requests; gfx950 tallies the 128-B requests of a
