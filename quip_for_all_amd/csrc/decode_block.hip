@@ -68,9 +68,12 @@ constexpr int KPD = 11264, JD = 22;                  // digits of down's input, 
 constexpr int kRowU4 = HID / 64, kRowU4D = NFFN / 64;
 constexpr int NSLOT = 9;                             // X0-2: q k v, then gate's row blocks | X3-5: o, then up's | X6-8: down
 
-// workspace: ctl | z_q z_k z_v | a | z_o | z_d (2048 granules each) | inbox [43][2][256] | rows [256][48]
+// workspace: ctl | z_q z_k z_v | a | z_o | z_d (2048 granules each) | inbox [11 row owners][256 columns][2][4] | rows [256][48]
 constexpr size_t kWsCtl = 0, kWsZ = 64, kWsVec = 2048 * 8;
-constexpr size_t kWsInbox = kWsZ + 6 * kWsVec, kWsRows = kWsInbox + (size_t)FK * 2 * FL * 8;
+// row-owner workgroups of the MLP edge: RPO rows k' each, one per wave on waves 0..RPO-1 (four waves = one per SIMD: the
+// row work is DPP-serial VALU code, two such waves on a SIMD take twice as long)
+constexpr int RPO = 4, NRO = (FK + RPO - 1) / RPO;
+constexpr size_t kWsInbox = kWsZ + 6 * kWsVec, kWsRows = kWsInbox + (size_t)NRO * FL * 2 * RPO * 8;
 constexpr size_t kWsBytes = kWsRows + (size_t)FL * 48 * 8;
 
 template <int REP>
@@ -97,7 +100,8 @@ struct BLds {
   static constexpr int kArea = kBuf0 + kBufBytes;
   static constexpr int kAreaBytes = 50 * 1024;               // >= 36 KB planes, 48 KB MLP rows, 35.1 KB down planes
   static constexpr int kBuf1 = kArea + 3 * 3 * HID - kBufBytes;   // tail of the planes area (dead before any plane is written there)
-  static constexpr int kZs = kArea;                          // gathered vector(s), fp16
+  static constexpr int kStage = kArea + 24 * 1024;            // MLP row owners: their eight rows, transposed, on the way out (8 KB)
+  static constexpr int kStash = kArea + 36 * 1024;            // MLP row owners: SV_gate / SV_up / SU_down of their eight rows (12 KB)
   static constexpr int kPlaneD = (KPD / 256) * 272;
   static constexpr int kBytes = kArea + kAreaBytes;
 };
@@ -224,14 +228,17 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 
   // ---- all-gather of one or more 4096-vectors (2048 granules each, {2 x fp16, tag}) into LDS as fp16 -------------------
   // NV vectors starting at zbufs[first]; every thread sweeps 2 NV 16-byte pieces; returns with the data in smem + kZs
-  auto gather = [&](auto nv_tag, int first, uint32_t tag, uint32_t code) {
+  auto gather = [&](auto nv_tag, int first, uint32_t tag, uint32_t code, float (&out)[decltype(nv_tag)::value][8]) {
     constexpr int NV = decltype(nv_tag)::value;
     u32x4_t p[2 * NV];
     uint32_t spins = 0;
-    const uint64_t* src = zbufs + (size_t)first * 2048;
+    const uint64_t* src = zbufs + (size_t)first * 2048 + 4 * tid;      // this thread's 4 granules of vector `first`
     for (;;) {
 #pragma unroll
-      for (int j = 0; j < 2 * NV; ++j) esync::ld16(p[j], src + 2 * (tid + kThreads * j));
+      for (int c = 0; c < NV; ++c) {
+        esync::ld16(p[2 * c], src + c * 2048);
+        esync::ld16(p[2 * c + 1], src + c * 2048 + 2);
+      }
       esync::drain();
       bool ok = true;
 #pragma unroll
@@ -241,12 +248,11 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       }
       if (esync::spin_step(ok, spins, ctl + 1, code + (uint32_t)w)) break;
     }
-    uint32_t* zs = reinterpret_cast<uint32_t*>(smem + B::kZs);
+    // straight into the transform's input registers: no staging, no barrier (every thread waited for its own elements)
 #pragma unroll
-    for (int j = 0; j < 2 * NV; ++j)
-      *reinterpret_cast<uint2*>(zs + 2 * (tid + kThreads * j)) = make_uint2(p[j].x, p[j].z);
+    for (int c = 0; c < NV; ++c)
+      had::unpack8(make_uint4(p[2 * c].x, p[2 * c].z, p[2 * c + 1].x, p[2 * c + 1].z), out[c]);
     own_slots();
-    had::wg_barrier<true>();
   };
   // this workgroup's 16 values of a product (accumulator rows [row0, row0 + 16), block exponent sh) -> 8 granules
   auto publish16 = [&](int vec, int gr0, int row0, int sh, uint32_t tag) {      // gr0: first granule of the block in its vector
@@ -287,7 +293,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     }
     auto u4 = [](const u32x4& v) { return make_uint4(v.x, v.y, v.z, v.w); };
     if (have_z) {
-      gather(std::integral_constant<int, 1>{}, zvec, tag, code);
+      float v[1][8];
+      gather(std::integral_constant<int, 1>{}, zvec, tag, code, v);
       // The vectors have landed (the gather drained the queue).  Take them over HERE: the compiler counts only its own
       // loads, so the wait it would place at their first use would also wait for the burst requested below.
 #pragma unroll
@@ -295,8 +302,6 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       if (NC > 0) asm volatile("" : "+v"(pln), "+v"(psu0), "+v"(psu1));
       after_gather();
       ESTAMP(0);
-      float v[1][8];
-      had::unpack8(*reinterpret_cast<const uint4*>(smem + B::kZs + 16 * tid), v[0]);
       had8::fht4096<1, true>(v, xbuf, tid);
       ESTAMP(1);
 #pragma unroll
@@ -369,19 +374,18 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 
   const f16* sv_d_prev = nullptr;
   const BlockLayer& Ld = *reinterpret_cast<const BlockLayer*>(smem + B::kDesc);
+  if (tid < 64) reinterpret_cast<uint32_t*>(smem + B::kDesc)[tid] = reinterpret_cast<const uint32_t*>(a.layers)[tid];
+  had::wg_barrier<true>();
   for (int l = 0; l < a.n_layers; ++l) {
-    if (tid < 64) reinterpret_cast<uint32_t*>(smem + B::kDesc)[tid] = reinterpret_cast<const uint32_t*>(a.layers + l)[tid];
-    had::wg_barrier<true>();
     dbg_on = a.dbg != nullptr && l == a.dbg_layer;
     rederive();
     BSTAMP(0);
     // ================= P1: (previous down's output side) + input transforms of q, k, v; their products ===============
     const int c_lo = (3 * w) >> 8, c_hi = (3 * w + 2) >> 8;         // the one or two matrices this workgroup's row blocks are in
-    edge(std::integral_constant<int, 2>{}, l > 0 ? 5 : -1, ebase | hop, 0x4000u, sv_d_prev, Ld.ln[0], Ld.su[c_lo], Ld.su[c_hi],
-         Ld.sc[c_lo], Ld.sc[c_hi], c_hi != c_lo, [&]() {
-      ISSUE(Ld, 0); ISSUE(Ld, 1); ISSUE(Ld, 2);        // burst A: q, k, v row blocks of this block (X0-2: gate's slots, consumed)
-      BSTAMP(1);
-    });
+    // (the output side of the previous block's down_proj + residual ran at the bottom of the previous iteration: no
+    //  weight request may be in flight across the loop edge, where the compiler is free to copy registers)
+    edge(std::integral_constant<int, 2>{}, -1, 0u, 0u, nullptr, Ld.ln[0], Ld.su[c_lo], Ld.su[c_hi], Ld.sc[c_lo], Ld.sc[c_hi],
+         c_hi != c_lo, [&]() {});
     BSTAMP(2);
     esync::drain();                                    // q, k, v have landed (requested one transform stage ago)
     own_slots();
@@ -422,13 +426,11 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) { c8[i] = cs[d0 + i]; s8[i] = sn[d0 + i]; }
       }
-      gather(std::integral_constant<int, 3>{}, 0, ebase | hop, 0x5000u);
+      float v[3][8];
+      gather(std::integral_constant<int, 3>{}, 0, ebase | hop, 0x5000u, v);
       BSTAMP(4);
       f16* s_qkv = reinterpret_cast<f16*>(smem + B::kQkv);
       {
-        float v[3][8];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) had::unpack8(*reinterpret_cast<const uint4*>(smem + B::kZs + c * HID * 2 + 16 * tid), v[c]);
         had8::fht4096<3, true>(v, xbuf, tid);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -550,10 +552,10 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     {
       // o_proj's input side: x = H (a (.) SU_o) * sc  (no norm), every workgroup
       const u32x4 psu = *reinterpret_cast<const u32x4*>(Ld.su[3] + 8 * tid);
-      gather(std::integral_constant<int, 1>{}, 3, ebase | hop, 0x6000u);
-      BSTAMP(7);
+      ISSUE(Ld, 4); ISSUE(Ld, 5); ISSUE(Ld, 6);        // gate's row blocks (X0-2: q, k, v consumed), at the start of the wait
       float v[1][8];
-      had::unpack8(*reinterpret_cast<const uint4*>(smem + B::kZs + 16 * tid), v[0]);
+      gather(std::integral_constant<int, 1>{}, 3, ebase | hop, 0x6000u, v);
+      BSTAMP(7);
       had::mul8(v[0], make_uint4(psu.x, psu.y, psu.z, psu.w));
       had8::fht4096<1, true>(v, xbuf, tid);
       const float sco = Ld.sc[3];
@@ -567,30 +569,30 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     esync::drain();
     own_slots();
     run_item(3, xlane, 48);
-    ISSUE(Ld, 4); ISSUE(Ld, 5); ISSUE(Ld, 6);          // gate's row blocks (X0-2: q, k, v consumed): they land during the z_o hand-off's latency
     had::wg_barrier<true>();
     ++hop;                                             // hand-off: z_o
     publish16(4, w * 8, 48, shs[3], ebase | hop);
     had::wg_barrier<true>();
     zero_acc(48, 16);
+    ISSUE(Ld, 7); ISSUE(Ld, 8); ISSUE(Ld, 9);          // up's row blocks (X3-5: o consumed), at the start of the wait for z_o
     BSTAMP(9);
 
     // ================= P3: o's output side + residual, RMSNorm, input transforms of gate / up; their products =========
     rederive();
     edge(std::integral_constant<int, 2>{}, 4, ebase | hop, 0x7000u, Ld.sv[3], Ld.ln[1], Ld.su[4], Ld.su[5], Ld.sc[4], Ld.sc[5], true,
-         [&]() {
-      ISSUE(Ld, 7); ISSUE(Ld, 8); ISSUE(Ld, 9);        // burst C: up's row blocks (X3-5) and down (X6-8)
-      ISSUE(Ld, 10); ISSUE(Ld, 11); ISSUE(Ld, 12);
-      BSTAMP(10);
-    }, 18);
+         [&]() { BSTAMP(10); }, 18);
     BSTAMP(11);
-    // row owners: SV_gate / SV_up / SU_down of their row, and everybody's image of the K x K factors, for the MLP edge
+    // row owners (w < NRO: rows k' = RPO w .. RPO w + RPO - 1, one per wave): SV_gate / SV_up / SU_down of their rows into the free
+    // tail of the area; everybody: the image of the K x K factors, for the MLP edge
     {
-      constexpr int VPIECES = 3 * FL / 8;
-      if (w < FK && tid < VPIECES) {
-        const int vsel = tid / (FL / 8), piece = tid - vsel * (FL / 8);
-        const f16* vsrc = (vsel == 0 ? Ld.sv[4] : (vsel == 1 ? Ld.sv[5] : Ld.su[6])) + (size_t)w * FL + piece * 8;
-        *reinterpret_cast<uint4*>(smem + B::kVec + tid * 16) = *reinterpret_cast<const uint4*>(vsrc);
+      if (w < NRO) {
+        for (int p = tid; p < RPO * 3 * (FL / 8); p += kThreads) {
+          const int row = p / (3 * (FL / 8)), rem = p - row * (3 * (FL / 8));
+          const int vsel = rem / (FL / 8), piece = rem - vsel * (FL / 8);
+          const int kr = RPO * w + row < FK ? RPO * w + row : FK - 1;
+          const f16* vsrc = (vsel == 0 ? Ld.sv[4] : (vsel == 1 ? Ld.sv[5] : Ld.su[6])) + (size_t)kr * FL + piece * 8;
+          *reinterpret_cast<uint4*>(smem + B::kStash + ((row * 3 + vsel) * FL + piece * 8) * 2) = *reinterpret_cast<const uint4*>(vsrc);
+        }
       }
       constexpr int HPIECES = B::kHadElems / 8;
       for (int i = tid; i < HPIECES; i += kThreads)
@@ -634,37 +636,62 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         }
         t += __shfl_xor(t, 1, 64);
         t += __shfl_xor(t, 2, 64);
-        if (live && part == 0) esync::st_granule(inbox + ((size_t)(kq * 2 + m) * FL + w), as_u32(t), tag1);
+        // row k' goes to row owner k' / RPO.  This workgroup's 2 RPO granules per owner are a cache line of its own, written
+        // as 16-byte stores of the rows (k', k' + 1), k' even (the odd row's value comes over from the next quad)
+        const float tn = __shfl_down(t, 4, 64);
+        if (live && part == 0 && (kq & 1) == 0) {
+          uint64_t* dst = inbox + (((size_t)(kq / RPO) * FL + w) * (2 * RPO) + m * RPO + (kq % RPO));
+          if (kq + 1 < FK) esync::st_granule2(dst, as_u32(t), as_u32(tn), tag1);
+          else esync::st_granule(dst, as_u32(t), tag1);
+        }
       }
       ++hop;                                           // hand-off: rows -> everybody
       const uint32_t tag2 = ebase | hop;
       BSTAMP(13);
-      if (w < FK && wave == 0) {
+      if (w < NRO) {
+        const int kr = RPO * w + wave;                   // this wave's row of the (43, 256) view (waves 0..RPO-1)
+        const bool have_row = wave < RPO && kr < FK;
         const int m = (lane >> 4) & 1, t = lane & 15;
-        const bool active = lane < 32;
-        const uint64_t* src = inbox + ((size_t)(w * 2 + m) * FL + t * 16);
-        u32x4_t g[8];
-        uint32_t spins = 0;
-        for (;;) {
+        // the owner's inbox = 256 columns x (2 matrices x RPO rows) granules, swept by all 512 threads (coalesced 16-byte
+        // pieces); piece p = column p / RPO, matrix (p / (RPO / 2)) & 1, rows 2 (p % (RPO / 2)) and + 1
+        {
+          constexpr int NPC = FL * RPO / kThreads;       // pieces per thread
+          u32x4_t pc[NPC];
+          uint32_t spins = 0;
+          for (;;) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) esync::ld16(g[j], src + 2 * j);
-          esync::drain();
-          bool ok = true;
+            for (int jj = 0; jj < NPC; ++jj) esync::ld16(pc[jj], inbox + ((size_t)w * FL * 2 * RPO + 2 * (tid + kThreads * jj)));
+            esync::drain();
+            bool ok = true;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            esync::own(g[j]);
-            ok = ok && g[j].y == tag1 && g[j].w == tag1;
+            for (int jj = 0; jj < NPC; ++jj) {
+              esync::own(pc[jj]);
+              const int kl = 2 * ((tid + kThreads * jj) % (RPO / 2));
+              ok = ok && (RPO * w + kl >= FK || pc[jj].y == tag1) && (RPO * w + kl + 1 >= FK || pc[jj].w == tag1);
+            }
+            if (esync::spin_step(ok, spins, ctl + 1, 0x1000u + (uint32_t)w)) break;
           }
-          if (esync::spin_step(ok || !active, spins, ctl + 1, 0x1000u + (uint32_t)w)) break;
+          if (dbg_on && tid == 0) a.dbg[w * 32 + 25] = __builtin_amdgcn_s_memtime();
+          uint32_t* rowbuf = reinterpret_cast<uint32_t*>(smem + B::kArea);        // [RPO rows][2 matrices][256 columns]
+#pragma unroll
+          for (int jj = 0; jj < NPC; ++jj) {
+            const int pi = tid + kThreads * jj, col = pi / RPO, mm = (pi / (RPO / 2)) & 1, kl = 2 * (pi % (RPO / 2));
+            rowbuf[(kl * 2 + mm) * FL + col] = pc[jj].x;
+            rowbuf[((kl + 1) * 2 + mm) * FL + col] = pc[jj].z;
+          }
+          had::wg_barrier<true>();
         }
         float v[16];
+        {
+          const float* rb = reinterpret_cast<const float*>(smem + B::kArea) + ((have_row ? wave : 0) * 2 + m) * FL + t * 16;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          v[2 * j] = as_f32(g[j].x);
-          v[2 * j + 1] = as_f32(g[j].z);
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const float4 f4 = *reinterpret_cast<const float4*>(rb + 4 * r4);
+            v[4 * r4] = f4.x; v[4 * r4 + 1] = f4.y; v[4 * r4 + 2] = f4.z; v[4 * r4 + 3] = f4.w;
+          }
         }
         had::fht16_lanes<FLOGL>(v, t);
-        const f16* vecs = reinterpret_cast<const f16*>(smem + B::kVec);
+        const f16* vecs = reinterpret_cast<const f16*>(smem + B::kStash) + (have_row ? wave : 0) * 3 * FL;
         const f16* sv = vecs + m * FL + t * 16;
         float o[16];
         {
@@ -687,19 +714,32 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           }
         }
         had::fht16_lanes<FLOGL>(e, t);
-        if (lane < 16) {
+        // the wave's row, as fp16 hi + lo of the prescaled values, next to the owner's other rows in LDS ([j][RPO]) ...
+        uint32_t* stage = reinterpret_cast<uint32_t*>(smem + B::kStage);
+        if (lane < 16 && wave < RPO) {
           constexpr float kPre = 1.f / 16.f;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float vv = e[r] * kPre;
             const f16 hi = (f16)vv;
             const f16 lo = (f16)(vv - (float)hi);
-            const uint32_t pair = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
-            esync::st_granule(frow + ((size_t)(16 * t + r) * B::KP16 + w), pair, tag2);
+            stage[(16 * t + r) * RPO + wave] = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
           }
         }
+        had::wg_barrier<true>();
+        // ... and out: column j's RPO rows = granules [j * 48 + RPO w, +RPO) as 16-byte stores
+        if (tid < FL * RPO / 4) {
+          static_assert(RPO == 4, "one thread per column");
+          const int j = tid;
+          const u32x4 d = *reinterpret_cast<const u32x4*>(stage + j * RPO);
+          uint64_t* dst = frow + ((size_t)j * B::KP16 + RPO * w);
+          esync::st_granule2(dst, d.x, d.y, tag2);
+          esync::st_granule2(dst + 2, d.z, d.w, tag2);
+        }
+        had::wg_barrier<true>();                         // the staging area is free again (the gather below zeroes over it)
       }
       BSTAMP(14);
+      ISSUE(Ld, 10); ISSUE(Ld, 11); ISSUE(Ld, 12);     // down (X6-8), at the start of the wait for the rows
       // B fragments of the K-mix (had_d^T in LDS)
       typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
       f16x4 bfr[3][FRB];
@@ -730,6 +770,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           }
         }
         had::wg_barrier<true>();
+        BSTAMP(26);
         u32x4_t p[NP];
         uint32_t spins = 0;
         for (;;) {
@@ -752,6 +793,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           }
           if (esync::spin_step(ok, spins, ctl + 1, 0x2000u + (uint32_t)w)) break;
         }
+        BSTAMP(27);
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
           const int i = tid + kThreads * j;
@@ -859,10 +901,18 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       BSTAMP(17);
     }
     sv_d_prev = Ld.sv[6];
+    if (l + 1 < a.n_layers) {
+      had::wg_barrier<true>();                         // everybody has read this block's descriptor for the last time
+      if (tid < 64) reinterpret_cast<uint32_t*>(smem + B::kDesc)[tid] = reinterpret_cast<const uint32_t*>(a.layers + l + 1)[tid];
+      had::wg_barrier<true>();
+      ISSUE(Ld, 0); ISSUE(Ld, 1); ISSUE(Ld, 2);        // q, k, v row blocks of the NEXT block (X0-2: gate consumed), at the start of the wait for z_d
+    }
+    // output side of this block's down_proj + residual -> h (the gather drains the requests above)
+    rederive();
+    edge(std::integral_constant<int, 0>{}, 5, ebase | hop, 0x4000u, sv_d_prev, nullptr, nullptr, nullptr, 0.f, 0.f, false,
+         [&]() { BSTAMP(1); });
   }
-  // ---- the last block's down: output side + residual -> h_out ------------------------------------------------------
-  rederive();
-  edge(std::integral_constant<int, 0>{}, 5, ebase | hop, 0x4000u, sv_d_prev, nullptr, nullptr, nullptr, 0.f, 0.f, false, [&]() {});
+  // ---- h_out -----------------------------------------------------------------------------------------------------------
   if (w == 0) {
     *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.h_out) + tid * 16) = *reinterpret_cast<const u32x4*>(smem + B::kH + tid * 16);
     if (tid == 0) esync::st_word(ctl, ebase >> 10);

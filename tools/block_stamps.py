@@ -35,7 +35,7 @@ for it in range(6):
     e1.record()
     torch.cuda.synchronize()
     if it >= 2:
-        d = dbg.cpu().numpy().reshape(256, 32)[:, :25].astype(np.float64)
+        d = dbg.cpu().numpy().reshape(256, 32)[:, :28].astype(np.float64)
         acc.append((d, e0.elapsed_time(e1) * 1e3))
 print(f"status {dec.engine_status()}; launch of {layers} blocks: {np.median([t for _, t in acc]):.1f} us = {np.median([t for _, t in acc]) / layers:.2f} us per block")
 head = np.arange(256) % 8 == 0
@@ -63,3 +63,7 @@ for i in range(1, 7):
     seg = D_[:, :, 18 + i] - D_[:, :, 18 + i - 1]
     print(f"  {en[i]:28s} {seg.mean():9.0f}")
 print(f"  (stamp 10 -> 18: {(D_[:, :, 18] - D_[:, :, 10]).mean():.0f}, 24 -> 11: {(D_[:, :, 11] - D_[:, :, 24]).mean():.0f})")
+ro = np.arange(256) < 11
+print("inside the MLP edge: row owners: publish(13) -> inbox complete %.0f, -> rows published(14) %.0f; everyone: 14 -> poll done(26) %.0f (row owners %.0f), sweep(27) %.0f, staging + barrier(15) %.0f" % (
+    (D_[:, ro, 25] - D_[:, ro, 13]).mean(), (D_[:, ro, 14] - D_[:, ro, 25]).mean(), (D_[:, :, 26] - D_[:, :, 14]).mean(),
+    (D_[:, ro, 26] - D_[:, ro, 14]).mean(), (D_[:, :, 27] - D_[:, :, 26]).mean(), (D_[:, :, 15] - D_[:, :, 27]).mean()))
