@@ -101,6 +101,23 @@ for _name, _schema in _SCHEMAS.items():
         pass  # already defined (e.g. the reference's register_lib was imported first)
 
 
+# QUIP_POISON_OUTPUTS=1 (debug): every output tensor an op allocates is filled with a pattern (fp16 / fp32 NaN, 0xA5 bytes)
+# before the launch instead of being left as _empty() memory, so a kernel that does not write all of its output,
+# or that reads its output buffer, shows up as NaN / garbage instead of depending on what the allocator recycled.
+import os as _os
+_POISON = _os.environ.get("QUIP_POISON_OUTPUTS", "0") != "0"
+
+
+def _empty(*shape, **kw):
+    t = torch.empty(*shape, **kw)
+    if _POISON and not torch.cuda.is_current_stream_capturing():
+        if t.dtype.is_floating_point:
+            t.fill_(float("nan"))
+        else:
+            t.view(torch.uint8).fill_(0xA5)
+    return t
+
+
 def _stream(t: Tensor):
     return torch.cuda.current_stream(t.device).cuda_stream
 
@@ -169,7 +186,7 @@ def _had_transform_cuda(x, out_features, n, K, had, transpose, pre, pre2, post, 
         _need(t is None or (t.dtype == torch.float16 and t.is_contiguous() and t.device == x.device),
               "had_transform: vectors must be contiguous float16 on x's device")
     _chk_lens("had_transform", xc.shape[1], out_features, n, K, had, pre, pre2, post, bias)
-    y = torch.empty((xc.shape[0], out_features), dtype=torch.float16, device=x.device)
+    y = _empty((xc.shape[0], out_features), dtype=torch.float16, device=x.device)
     with torch.cuda.device(x.device):
         capi.check(capi.lib().quip_had_transform_f16(
             xc.data_ptr(), y.data_ptr(), xc.shape[0], xc.shape[1], out_features, n, K, _ptr(had),
@@ -186,7 +203,7 @@ def _had_transform_planes_cuda(x, n, K, had, transpose, pre, scale):
               "had_transform_planes: vectors must be contiguous float16 on x's device")
     _chk_lens("had_transform_planes", xc.shape[1], n, n, K, had, pre)
     L = capi.lib()
-    planes = torch.empty(L.quip_e8p_planes_bytes(n), dtype=torch.uint8, device=x.device)
+    planes = _empty(L.quip_e8p_planes_bytes(n), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
         capi.check(L.quip_had_transform_planes(xc.data_ptr(), planes.data_ptr(), xc.shape[1], n, K, _ptr(had),
                                                int(bool(transpose)), _ptr(pre), float(scale), _stream(x)),
@@ -210,7 +227,7 @@ def _had_transform_fused_cuda(x, out_features, n, K, had, transpose, pre, pre2, 
     _need(gate is None or gate.shape == xc.shape, "gate must have x's shape")
     _need(residual is None or tuple(residual.shape) == (xc.shape[0], out_features), "residual shape")
     _chk_lens("had_transform_fused", xc.shape[1], out_features, n, K, had, pre, pre2, post, bias, rms_weight)
-    y = torch.empty((xc.shape[0], out_features), dtype=torch.float16, device=x.device)
+    y = _empty((xc.shape[0], out_features), dtype=torch.float16, device=x.device)
     f = _fusion(residual, rms_weight, rms_eps, gate, x)
     import ctypes
     with torch.cuda.device(x.device):
@@ -233,7 +250,7 @@ def _had_transform_planes_fused_cuda(x, n, K, had, transpose, pre, scale, rms_we
     _need(gate is None or gate.shape == xc.shape, "gate must have x's shape")
     _chk_lens("had_transform_planes_fused", xc.shape[1], n, n, K, had, pre, rms_weight=rms_weight)
     L = capi.lib()
-    planes = torch.empty(L.quip_e8p_planes_bytes(n), dtype=torch.uint8, device=x.device)
+    planes = _empty(L.quip_e8p_planes_bytes(n), dtype=torch.uint8, device=x.device)
     f = _fusion(None, rms_weight, rms_eps, gate, x)
     import ctypes
     with torch.cuda.device(x.device):
@@ -259,7 +276,7 @@ def _d4_gemv_planes_cuda(planes, Qidxs, grid):
     _need(Qidxs.dtype == torch.uint8 and Qidxs.is_contiguous(), "Qidxs must be contiguous uint8 (n, k/4)")
     _need(planes.dtype == torch.uint8 and planes.is_contiguous() and planes.device == Qidxs.device, "planes: uint8")
     n, k = Qidxs.shape[0], Qidxs.shape[1] * 4
-    y = torch.empty((1, n), dtype=torch.float16, device=Qidxs.device)
+    y = _empty((1, n), dtype=torch.float16, device=Qidxs.device)
     with torch.cuda.device(Qidxs.device):
         capi.check(capi.lib().quip_d4_gemv_planes(planes.data_ptr(), Qidxs.data_ptr(), _d4_grid(grid).data_ptr(),
                                                   y.data_ptr(), n, k, _stream(Qidxs)), "quip_d4_gemv_planes")
@@ -280,7 +297,7 @@ def _e8prvq3_gemv_planes_group_cuda(planes, Qidxs, grid, e81b_i8):
     _need(e81b_i8.dtype == torch.int8 and tuple(e81b_i8.shape) == (256, 8) and e81b_i8.is_contiguous()
           and e81b_i8.device == dev, "e81b_i8 must be the contiguous int8 (256, 8) table")
     g = _grid_i64(grid, planes[0])
-    outs = [torch.empty((1, q.shape[0]), dtype=torch.float16, device=dev) for q in Qidxs]
+    outs = [_empty((1, q.shape[0]), dtype=torch.float16, device=dev) for q in Qidxs]
     vp = ctypes.c_void_p * count
     ns = (ctypes.c_int32 * count)(*[q.shape[0] for q in Qidxs])
     ws = _gemv_workspace(dev, sum(q.shape[0] for q in Qidxs))
@@ -302,7 +319,7 @@ def _d4_gemv_planes_group_cuda(planes, Qidxs, grid):
         _need(q.dtype == torch.uint8 and q.is_contiguous() and q.shape[1] * 4 == k and q.device == dev,
               "Qidxs must be contiguous uint8 (n, k/4) with a common k")
         _need(pl.dtype == torch.uint8 and pl.is_contiguous() and pl.device == dev, "planes must be uint8")
-    outs = [torch.empty((1, q.shape[0]), dtype=torch.float16, device=dev) for q in Qidxs]
+    outs = [_empty((1, q.shape[0]), dtype=torch.float16, device=dev) for q in Qidxs]
     vp = ctypes.c_void_p * count
     ns = (ctypes.c_int32 * count)(*[q.shape[0] for q in Qidxs])
     with torch.cuda.device(dev):
@@ -319,7 +336,7 @@ def _had_transform_planes_rows_cuda(x, n, K, had, transpose, pre, scale, rms_wei
     _chk_lens("had_transform_planes_rows", xc.shape[1], n, n, K, had, pre, rms_weight=rms_weight)
     L = capi.lib()
     rows = xc.shape[0]
-    out = torch.empty((rows, _planes_numel(n, resid_scale)), dtype=torch.uint8, device=x.device)
+    out = _empty((rows, _planes_numel(n, resid_scale)), dtype=torch.uint8, device=x.device)
     pr = capi.HadProblem(xc.data_ptr(), out.data_ptr(), _vec_ok(had, x.device), _vec_ok(pre, x.device), None, None,
                          None, None, _vec_ok(rms_weight, x.device), _ptr(gate), xc.shape[1], n, float(scale),
                          float(rms_eps), None, None, None, None, 1.0, *_layout(resid_scale))
@@ -345,7 +362,7 @@ def _e8p_quantize_cuda(X, grid):
           "e8p_quantize: X must be contiguous float32 (N, 8)")
     g = _grid_i64(grid, X)
     vals = torch.empty_like(X)
-    idx = torch.empty(X.shape[0], dtype=torch.int64, device=X.device)
+    idx = _empty(X.shape[0], dtype=torch.int64, device=X.device)
     with torch.cuda.device(X.device):
         capi.check(capi.lib().quip_e8p_quantize_f32(X.data_ptr(), X.shape[0], g.data_ptr(), vals.data_ptr(),
                                                     idx.data_ptr(), _stream(X)), "quip_e8p_quantize_f32")
@@ -362,7 +379,7 @@ def _e8p_gemv_planes_rows_cuda(planes, Qidxs, grid):
     rows = planes.shape[0]
     per = L.quip_e8p_gemv_max_rows(n, k)
     g = _grid_i64(grid, Qidxs)
-    out = torch.empty((rows, n), dtype=torch.float16, device=Qidxs.device)
+    out = _empty((rows, n), dtype=torch.float16, device=Qidxs.device)
     if per < 1:
         # rows longer than rows mode holds in LDS (k > 28672: E8P12RVQ4B's 2k-wide virtual rows at 70B): one bs=1
         # launch per row through the dispatcher (the K-splitting kernel) -- the same exact integer sums
@@ -405,7 +422,7 @@ def _gemv_planes_rows_mode_cuda(planes, Qidxs, grid, grid2, mode):
         # virtual rows longer than rows mode holds in LDS (70B down_proj): one bs=1 launch per row (K-splitting kernel)
         return torch.cat([_e8prvq3_gemv_planes_group_cuda([planes[r]], [Qidxs], grid, grid2)[0] for r in range(rows)])
     _need(per >= 1, "shape not supported by the matrix-core GEMV")
-    out = torch.empty((rows, n), dtype=torch.float16, device=Qidxs.device)
+    out = _empty((rows, n), dtype=torch.float16, device=Qidxs.device)
     with torch.cuda.device(Qidxs.device):
         for r0 in range(0, rows, per):
             m = min(per, rows - r0)
@@ -422,7 +439,7 @@ def _e8p_mm_planes_rows_cuda(planes, Qidxs, grid):
     _need(Qidxs.dtype == torch.int16 and Qidxs.is_contiguous(), "Qidxs must be contiguous int16 (n, k/8)")
     n, k = Qidxs.shape[0], Qidxs.shape[1] * 8
     dev = Qidxs.device
-    out = torch.empty((count, n), dtype=torch.float16, device=dev)
+    out = _empty((count, n), dtype=torch.float16, device=dev)
     vp = ctypes.c_void_p * count
     ns = (ctypes.c_int32 * count)(*([n] * count))
     g = _grid_i64(grid, Qidxs)
@@ -444,7 +461,7 @@ def _had_transform_planes_group_cuda(x, n, K, had, transpose, pre, scale, rms_we
         _chk_lens("had_transform_planes_group", xc.shape[1], n, n, K, had[i], pre[i], rms_weight=rms_weight)
     L = capi.lib()
     nbytes = L.quip_e8p_planes_bytes(2 * n if resid_scale != 0.0 else n)
-    outs = [torch.empty(nbytes, dtype=torch.uint8, device=x.device) for _ in range(count)]
+    outs = [_empty(nbytes, dtype=torch.uint8, device=x.device) for _ in range(count)]
     arr = (capi.HadProblem * count)()
     per_row = xc.shape[0] == count and count > 1
     gptr = _vec_ok(gate, x.device)
@@ -470,8 +487,8 @@ def _had_chain_planes_group_cuda(z, z_post, z_residual, z_scale, n, pre, scale, 
         _chk_lens("had_chain_planes_group", n, n, n, 1, None, pre[i], post=z_post, rms_weight=rms_weight)
     L = capi.lib()
     nbytes = L.quip_e8p_planes_bytes(2 * n if resid_scale != 0.0 else n)
-    outs = [torch.empty(nbytes, dtype=torch.uint8, device=z.device) for _ in range(count)]
-    h = torch.empty((1, n), dtype=torch.float16, device=z.device)
+    outs = [_empty(nbytes, dtype=torch.uint8, device=z.device) for _ in range(count)]
+    h = _empty((1, n), dtype=torch.float16, device=z.device)
     arr = (capi.HadProblem * count)()
     for i in range(count):
         arr[i] = capi.HadProblem(None, outs[i].data_ptr(), None, _vec_ok(pre[i], z.device), None, None, None, None,
@@ -496,7 +513,7 @@ def _had_transform_group_cuda(x, out_features, n, K, had, transpose, pre2, post,
     _need(ns is None or (len(ns) == count and K == 1 and rms_weight is None),
           "ns: one width per problem, K == 1, no rms_weight")
     dev = xs[0].device
-    outs = [torch.empty((rows, int(o)), dtype=torch.float16, device=dev) for o in out_features]
+    outs = [_empty((rows, int(o)), dtype=torch.float16, device=dev) for o in out_features]
     arr = (capi.HadProblem * count)()
     for i in range(count):
         _need(residual[i] is None or tuple(residual[i].shape) == tuple(outs[i].shape), "residual shape")
@@ -542,7 +559,7 @@ def _e8p_gemv_planes_group_cuda(planes, Qidxs, grid):
         _need(q.dtype == torch.int16 and q.is_contiguous() and q.shape[1] * 8 == k and q.device == dev,
               "Qidxs must be contiguous int16 (n, k/8) with a common k")
         _need(pl.dtype == torch.uint8 and pl.is_contiguous() and pl.device == dev, "planes must be uint8")
-    outs = [torch.empty((1, q.shape[0]), dtype=torch.float16, device=dev) for q in Qidxs]
+    outs = [_empty((1, q.shape[0]), dtype=torch.float16, device=dev) for q in Qidxs]
     vp = ctypes.c_void_p * count
     ns = (ctypes.c_int32 * count)(*[q.shape[0] for q in Qidxs])
     g = _grid_i64(grid, planes[0])
@@ -571,8 +588,8 @@ def _e8p_gemv_fused_cuda(x, z, post, residual, rms_weight, rms_eps, z_scale, pre
         _need(t is None or (t.numel() == k and t.dtype == torch.float16 and t.is_contiguous() and t.device == dev),
               "vectors must be contiguous fp16 of k elements")
     _need(z is None or post is not None, "post (the producer's SV) is required with z")
-    outs = [torch.empty((1, q.shape[0]), dtype=torch.float16, device=dev) for q in Qidxs]
-    h_out = torch.empty((1, k), dtype=torch.float16, device=dev) if z is not None else None
+    outs = [_empty((1, q.shape[0]), dtype=torch.float16, device=dev) for q in Qidxs]
+    h_out = _empty((1, k), dtype=torch.float16, device=dev) if z is not None else None
     fin = capi.GemvFusedIn()
     fin.x, fin.z, fin.post_scale, fin.residual = _ptr(x), _ptr(z), _ptr(post), _ptr(residual)
     fin.h_out, fin.rms_weight = _ptr(h_out), _ptr(rms_weight)
@@ -625,7 +642,7 @@ def _ffn_engine_cuda(planes_gate, planes_up, q_gate, q_up, q_down, had3, sv_gate
     _need(workspace.dtype == torch.uint8 and workspace.device == dev
           and workspace.numel() >= capi.lib().quip_ffn_engine_workspace_bytes(n_ffn, K), "workspace too small")
     g = _grid_i64(grid, planes_gate)
-    out = torch.empty((1, hidden), dtype=torch.float16, device=dev)
+    out = _empty((1, hidden), dtype=torch.float16, device=dev)
     a = capi.FfnEngineArgs(q_gate.data_ptr(), q_up.data_ptr(), q_down.data_ptr(), planes_gate.data_ptr(),
                            planes_up.data_ptr(), had3.data_ptr(), sv_gate.data_ptr(), sv_up.data_ptr(),
                            su_down.data_ptr(), out.data_ptr(), g.data_ptr(), workspace.data_ptr(), _ptr(dbg),
@@ -724,7 +741,7 @@ def _rope_attn_decode_z_cuda(zs, posts, scales, cos, sin, pos, kcache, vcache, w
           and tuple(cos.shape) == (max_len, hd) and tuple(sin.shape) == (max_len, hd), "cos / sin: float32 (max_len, hd)")
     _need(pos.dtype == torch.int64 and pos.numel() == 1 and pos.is_cuda, "pos must be an int64 device scalar")
     _need(tuple(vcache.shape) == tuple(kcache.shape), "cache shapes differ")
-    out = torch.empty((heads, hd), dtype=torch.float16, device=kcache.device)
+    out = _empty((heads, hd), dtype=torch.float16, device=kcache.device)
     if workspace is not None:
         _need(workspace.dtype == torch.uint8 and workspace.is_contiguous() and workspace.device == kcache.device
               and workspace.numel() >= capi.lib().quip_rope_attn_workspace_bytes(heads, hd),
@@ -753,7 +770,7 @@ def _e8p_mm_batched_cuda(x, Qidxs, grid):
     _need(Qc.shape[1] * 8 == k, f"e8p_mm_batched: x has {k} columns but Qidxs {tuple(Qidxs.shape)} encodes {Qc.shape[1] * 8}")
     _need(Qc.device == x.device, "Qidxs and x must be on the same device")
     _need(e8p_mm_batched_supported(m, n, k), f"e8p_mm_batched: shape ({m}, {n}, {k}) needs k % 64 == 0 and n % 2 == 0")
-    y = torch.empty((m, n), dtype=torch.float16, device=x.device)
+    y = _empty((m, n), dtype=torch.float16, device=x.device)
     if m == 0:
         return y
     with torch.cuda.device(x.device):
@@ -775,7 +792,7 @@ def _e8p_mm_skinny_cuda(x, Qidxs, grid):
     _need(Qc.shape[1] * 8 == k, f"e8p_mm_skinny: x has {k} columns but Qidxs {tuple(Qidxs.shape)} encodes {Qc.shape[1] * 8}")
     _need(Qc.device == x.device, "Qidxs and x must be on the same device")
     _need(e8p_mm_skinny_supported(m, n, k), f"e8p_mm_skinny: shape ({m}, {n}, {k}) needs k % 128 == 0, n % 2 == 0")
-    y = torch.empty((m, n), dtype=torch.float16, device=x.device)
+    y = _empty((m, n), dtype=torch.float16, device=x.device)
     with torch.cuda.device(x.device):
         capi.check(capi.lib().quip_e8p_mm_skinny(xc.data_ptr(), Qc.data_ptr(), g.data_ptr(), y.data_ptr(), m, n, k,
                                                  _stream(x)), "quip_e8p_mm_skinny")
@@ -788,7 +805,7 @@ def _e8p_gemv_planes_cuda(planes, Qidxs, grid):
     n, k = Qc.shape[0], Qc.shape[1] * 8
     L = capi.lib()
     _need(planes.dtype == torch.uint8 and planes.numel() >= L.quip_e8p_planes_bytes(k), "planes buffer too small")
-    y = torch.empty((1, n), dtype=torch.float16, device=Qidxs.device)
+    y = _empty((1, n), dtype=torch.float16, device=Qidxs.device)
     ws = _gemv_workspace(Qidxs.device, n)
     with torch.cuda.device(Qidxs.device):
         capi.check(L.quip_e8p_gemv_planes_ws(planes.data_ptr(), Qc.data_ptr(), g.data_ptr(), y.data_ptr(), n, k,
@@ -804,7 +821,7 @@ def _mm(fn_name, x, Q, qdtype, k_per_col_num, k_per_col_den, extra):
     _need(Qc.shape[1] * k_per_col_num == k * k_per_col_den,
           f"{fn_name}: x has {k} columns but Qidxs {tuple(Q.shape)} encodes {Qc.shape[1] * k_per_col_num // k_per_col_den}")
     _need(Qc.device == x.device, "Qidxs and x must be on the same device")
-    y = torch.empty((xc.shape[0], Qc.shape[0]), dtype=x.dtype, device=x.device)
+    y = _empty((xc.shape[0], Qc.shape[0]), dtype=x.dtype, device=x.device)
     if y.numel() == 0:
         return y
     with torch.cuda.device(x.device):
@@ -827,12 +844,12 @@ def _e8p_mm_cuda(x, Qidxs, grid):
     m, k, n = xc.shape[0], xc.shape[1], Qc.shape[0]
     _need(Qc.shape[1] * 8 == k, f"e8p_mm: x has {k} columns but Qidxs {tuple(Qidxs.shape)} encodes {Qc.shape[1] * 8}")
     _need(Qc.device == x.device, "Qidxs and x must be on the same device")
-    y = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    y = _empty((m, n), dtype=x.dtype, device=x.device)
     if y.numel() == 0:
         return y
     L = capi.lib()
     ws_bytes = L.quip_e8p_mm_workspace_bytes(m, n, k)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
+    ws = _empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
     with torch.cuda.device(x.device):
         capi.check(L.quip_e8p_mm_origorder_ws(xc.data_ptr(), Qc.data_ptr(), g.data_ptr(), y.data_ptr(), m, n, k,
                                               _ptr(ws), ws_bytes, _stream(x)), "quip_e8p_mm_origorder_ws")
@@ -872,7 +889,7 @@ def _hi_mm_cuda(x, Qidxs):
 # ---- decompress ops --------------------------------------------------------------------
 def _dec(fn_name, Q, qdtype, k, extra):
     Qc = _chk_q(Q, qdtype)
-    w = torch.empty((Qc.shape[0], k), dtype=torch.float16, device=Q.device)
+    w = _empty((Qc.shape[0], k), dtype=torch.float16, device=Q.device)
     with torch.cuda.device(Q.device):
         fn = getattr(capi.lib(), fn_name)
         capi.check(fn(Qc.data_ptr(), *extra(), w.data_ptr(), Qc.shape[0], k, _stream(Q)), fn_name)
