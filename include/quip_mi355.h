@@ -384,6 +384,11 @@ int quip_rope_attn_decode_z_f16(const void* const* z, const void* const* post, c
                                 int32_t heads, int32_t kv_heads, int32_t head_dim, int32_t max_len, float scale,
                                 void* workspace, quip_stream_t stream);
 
+/* Which kernel a bs=1 E8P12 GEMV launch of `count` matrices (ns[i] rows, common k) is dispatched to by default, without
+ * launching anything: 1 = e8p_gemv_mfma_kernel, 2 = e8p_gemv_v2_kernel (needs the workspace of the *_ws entry points when
+ * it splits K), negative = QUIP_ERR_*.  Lets a host-side test pin the regime table of the shapes it cares about. */
+int quip_e8p_gemv_kernel_choice(const int32_t* ns, int32_t count, int32_t k);
+
 /* ---- persistent decode engine, stage 1: the MLP half of a decoder block in ONE launch -------------------------
  * z_down = raw product of down_proj on  SU_d (.) silu(g) (.) u,  g / u = the finished outputs of gate_proj / up_proj
  * computed from the digit planes of their transformed input (quip_had_transform_planes_group): what

@@ -46,6 +46,7 @@ SIGNATURES = {
     "quip_block_engine_workspace_bytes": [],
     "quip_block_engine_layer_bytes": [],
     "quip_block_engine": [_P, _P],
+    "quip_e8p_gemv_kernel_choice": [_P, _I32, _I32],
     "quip_ffn_engine_supported": [_I32, _I32, _I32],
     "quip_ffn_engine_workspace_bytes": [_I32, _I32],
     "quip_ffn_engine": [_P, _P],

@@ -83,6 +83,17 @@ class E8P12_codebook(_Codebook):
     # rounding), no dense W in memory.  QUIP_BATCHED_MM=0 selects the reference-shaped path (A/B, odd shapes).
     fused_batched = os.environ.get("QUIP_BATCHED_MM", "1") != "0"
 
+    def batched_regime(self, m, n, k):
+        """the path forward() takes for an (m, k) fp16 batch against (n, k / 8) codes, as a name: mm (below the
+        threshold) | skinny_chunks | fused_gemm | decompress_gemm"""
+        if m < self.mm_threshold:
+            return "mm"
+        if self.fused_batched and n % 2 == 0 and k % 64 == 0:
+            if m * n <= self.skinny_chunks_max_mn and self.skinny_supported(m, n, k):
+                return "skinny_chunks"
+            return "fused_gemm"
+        return "decompress_gemm"
+
     def forward(self, input, Qidxs):
         if input.size(0) < self.mm_threshold:
             return self.mm(input, Qidxs)

@@ -214,17 +214,43 @@ static int gemv_v2_mode() {
   return mode;
 }
 
-static int e8p_gemv_dispatch(const void* const* planes, const void* const* qidxs, const void* grid, void* const* ys,
-                             const int* ns, int count, int k, void* ws, size_t ws_bytes, hipStream_t stream) {
-  size_t bytes = 0, need = 0;
-  for (int i = 0; i < count; ++i) {
-    bytes += (size_t)ns[i] * (size_t)k / 4;
-    need += e8p_gemv_v2_workspace_words(ns[i]) * 4;
-  }
-  if (ws && ws_bytes < need) ws = nullptr;
+// which kernel a bs=1 E8P12 GEMV launch of `count` matrices takes first: the K-splitting kernel (e8p_gemv_v2.hip) when
+// the first one (e8p_gemv_mfma.hip) does not take the shape, or for long rows (k >= 8192) from 16 MB of codes, or from
+// 20 MB; QUIP_GEMV_V2 = 0 / 1 forces either
+static bool gemv_prefers_v2(const int* ns, int count, int k, bool* v1_ok_out) {
+  size_t bytes = 0;
+  for (int i = 0; i < count; ++i) bytes += (size_t)ns[i] * (size_t)k / 4;
   const bool v1_ok = e8p_gemv_mfma_group_supported(ns, count, k);
   const int mode = gemv_v2_mode();
-  bool v2 = mode == 1 || !v1_ok || (mode != 0 && ((k >= 8192 && bytes >= ((size_t)16 << 20)) || bytes >= ((size_t)20 << 20)));
+  if (v1_ok_out) *v1_ok_out = v1_ok;
+  return mode == 1 || !v1_ok || (mode != 0 && ((k >= 8192 && bytes >= ((size_t)16 << 20)) || bytes >= ((size_t)20 << 20)));
+}
+
+int quip_e8p_gemv_kernel_choice(const int32_t* ns, int32_t count, int32_t k) {
+  if (!ns) return QUIP_ERR_NULL_POINTER;
+  if (count < 1 || count > QUIP_MAX_GROUP || k < 1 || k % 8 != 0) return QUIP_ERR_BAD_SHAPE;
+  int n32[QUIP_MAX_GROUP];
+  for (int i = 0; i < count; ++i) {
+    if (ns[i] < 1) return QUIP_ERR_BAD_SHAPE;
+    n32[i] = ns[i];
+  }
+  bool v1_ok = false;
+  const bool v2 = gemv_prefers_v2(n32, count, k, &v1_ok);
+  if (v2) {
+    for (int i = 0; i < count; ++i)
+      if (!e8p_gemv_v2_supported(n32[i], k)) return v1_ok ? 1 : QUIP_ERR_UNSUPPORTED;
+    return 2;
+  }
+  return 1;
+}
+
+static int e8p_gemv_dispatch(const void* const* planes, const void* const* qidxs, const void* grid, void* const* ys,
+                             const int* ns, int count, int k, void* ws, size_t ws_bytes, hipStream_t stream) {
+  size_t need = 0;
+  for (int i = 0; i < count; ++i) need += e8p_gemv_v2_workspace_words(ns[i]) * 4;
+  if (ws && ws_bytes < need) ws = nullptr;
+  bool v1_ok = false;
+  const bool v2 = gemv_prefers_v2(ns, count, k, &v1_ok);
   if (v2) {
     const int rc = e8p_gemv_v2_group_launch(planes, qidxs, grid, ys, ws, ns, count, k, GemvTune{}, stream);
     if (rc == QUIP_OK || !v1_ok || (rc != QUIP_ERR_NULL_POINTER && rc != QUIP_ERR_UNSUPPORTED)) return rc;

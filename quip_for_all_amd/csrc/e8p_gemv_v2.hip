@@ -103,7 +103,9 @@ struct V2Args {
   const uint4* W[kMaxG];          // (N, K / 8) int16 codes
   const uint8_t* planes[kMaxG];   // [3][kp_src] digit bytes + int32 shift word at 3 * kp_src
   f16* y[kMaxG];
-  int* ws[kMaxG];                 // ksplit > 1: zeroed int32 [N][4] accumulators followed by [row blocks] arrival counters
+  int* ws[kMaxG];                 // ksplit > 1: zeroed int32 [N][4] accumulators of every problem, back to back
+  int* cnt;                       // ... followed by the [row blocks] arrival counters of the launch (after ALL accumulators:
+                                  // a launch whose first problem is small has more row blocks than that problem has words)
   int N[kMaxG];
   int rpb[kMaxG];                 // rows per workgroup (multiple of 4)
   const uint64_t* grid;           // grid_packed_abs
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's atomics have been performed
     __syncthreads();                                    // ... and everybody's
-    int* cnt = a.ws[0] + (size_t)a.N[0] * 4 + rb;
+    int* cnt = a.cnt + rb;
     int* flag = accs;                                   // LDS word, free after the barrier
     if (tid == 0) *flag = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
@@ -584,11 +586,13 @@ int v2_group_launch(const void* const* planes, const void* const* qidxs, const v
     a.rpb[p] = rpb[pp];
     a.ws[p] = ws ? reinterpret_cast<int*>(ws) + ws_off : nullptr;
     if (p < G) {
-      ws_off += e8p_gemv_v2_workspace_words(ns[p]);
+      ws_off += (size_t)ns[p] * 4;                 // accumulators back to back; the counters follow the last one
       quads += rpb[p] >> 2;
       rows += rpb[p];
     }
   }
+  // row blocks <= max_p ceil(n_p / 4) <= the counter words e8p_gemv_v2_workspace_words() reserves in total
+  a.cnt = ws ? reinterpret_cast<int*>(ws) + ws_off : nullptr;
   a.grid = reinterpret_cast<const uint64_t*>(grid);
   a.grid2 = reinterpret_cast<const uint64_t*>(tune.grid2);
   a.K = k;

@@ -210,7 +210,7 @@ class LlamaDecoder:
         from .register_lib import rope_attn_decode_z_supported
         self.attn_z = (self.fused_prologue and self.fused_attention and os.environ.get("QUIP_ATTN_Z", "1") != "0"
                        and rope_attn_decode_z_supported(s.heads, s.kv_heads, s.head_dim)
-                       and all(l.K_right == 1 and not l.per_channel and l.bias is None
+                       and all(l.K_right == 1 and not l.per_channel and l.bias is None and l.SV is not None
                                and l.q_out_features == l.out_features == s.hidden for l in qkv0))
 
     def _init_block_engine(self):
@@ -388,6 +388,8 @@ class LlamaDecoder:
         self.pos.add_(1)
         return logits
 
+    prefill_graph_cache_size = 8      # captured prompt lengths kept (each graph owns a memory pool)
+
     @torch.no_grad()
     def prefill_graph(self, tokens):
         """prefill() replayed from a hipGraph captured per prompt LENGTH (first call of a length captures: a serving
@@ -396,6 +398,8 @@ class LlamaDecoder:
         tokens = torch.as_tensor(tokens, dtype=torch.long, device=self.dev).reshape(-1)
         P = tokens.numel()
         cache = self.__dict__.setdefault("_prefill_graphs", {})
+        if P not in cache and len(cache) >= self.prefill_graph_cache_size:
+            cache.pop(next(iter(cache)))              # oldest captured length out (a graph keeps its own memory pool)
         if P not in cache:
             static_tok = tokens.clone()
             side = torch.cuda.Stream()

@@ -90,6 +90,24 @@ class QuantLinear(nn.Module):
             self._rpp = r
         return r
 
+    def regime(self, M):
+        """which product path a forward of M activation rows takes (the dispatch of forward_fused, as a name):
+        reference_ops | gemv_planes (M = 1, digit planes + matrix-core GEMV) | rows_exact (2 .. one rows-mode pass:
+        bit identical to bs = 1) | skinny_fp16 (single-pass fp16 MFMA skinny kernel) | codebook (the codebook's own
+        product: generic mm below its threshold, batched path beyond -- see codebook.batched_regime)"""
+        cb = self.codebook
+        if self.reference_ops:
+            return "reference_ops"
+        planes_ok = hasattr(cb, "mm_planes") and cb.planes_supported(self.q_out_features, self.q_in_features)
+        if M == 1 and planes_ok:
+            return "gemv_planes"
+        if (2 <= M <= self.skinny_max_rows and not self.skinny_exact and hasattr(cb, "mm_skinny")
+                and cb.skinny_supported(M, self.q_out_features, self.q_in_features) and M > self._rows_per_pass()):
+            return "skinny_fp16"
+        if 2 <= M <= self.skinny_max_rows and hasattr(cb, "mm_planes_rows") and planes_ok:
+            return "rows_exact"
+        return "codebook"
+
     def _had(self, name):
         h = getattr(self, name)
         if h is not None and (h.dtype != torch.float16 or not h.is_contiguous()):
@@ -126,14 +144,14 @@ class QuantLinear(nn.Module):
             x = x.to(torch.float16)
         L_in = self.q_in_features // self.K_left
         cb = self.codebook
-        if self.reference_ops:
+        regime = self.regime(x.shape[0])
+        if regime == "reference_ops":
             xh = torch.ops.quip_lib.had_transform_fused(
                 x, self.q_in_features, self.q_in_features, self.K_left, self._had("had_left"), True,
                 self._vec(self.SU), None, None, None, self.wscale_float / math.sqrt(L_in), None,
                 self._vec(rms_weight), rms_eps, None if gate is None else gate.reshape(x.shape).to(torch.float16))
             z = cb.forward_reference(xh, self.Qidxs)
-        elif x.shape[0] == 1 and hasattr(cb, "mm_planes") and cb.planes_supported(self.q_out_features,
-                                                                                 self.q_in_features):
+        elif regime == "gemv_planes":
             # bs=1 decode: transform straight into the GEMV's int8 digit planes (no fp16 xh)
             planes = torch.ops.quip_lib.had_transform_planes_fused(
                 x, self.q_in_features, self.K_left, self._had("had_left"), True, self._vec(self.SU),
@@ -141,17 +159,14 @@ class QuantLinear(nn.Module):
                 None if gate is None else gate.reshape(x.shape).to(torch.float16),
                 getattr(cb, "planes_resid_scale", 0.0))
             z = cb.mm_planes(planes, self.Qidxs)
-        elif (2 <= x.shape[0] <= self.skinny_max_rows and not self.skinny_exact and hasattr(cb, "mm_skinny")
-              and cb.skinny_supported(x.shape[0], self.q_out_features, self.q_in_features)
-              and x.shape[0] > self._rows_per_pass()):
+        elif regime == "skinny_fp16":
             # more rows than one exact pass carries: single-pass skinny product on fp16 activations
             xh = torch.ops.quip_lib.had_transform_fused(
                 x, self.q_in_features, self.q_in_features, self.K_left, self._had("had_left"), True,
                 self._vec(self.SU), None, None, None, self.wscale_float / math.sqrt(L_in), None,
                 self._vec(rms_weight), rms_eps, None if gate is None else gate.reshape(x.shape).to(torch.float16))
             z = cb.mm_skinny(xh, self.Qidxs)
-        elif (2 <= x.shape[0] <= self.skinny_max_rows and hasattr(cb, "mm_planes_rows")
-              and cb.planes_supported(self.q_out_features, self.q_in_features)):
+        elif regime == "rows_exact":
             # skinny GEMM on the matrix cores (E8P12, E8P12RVQ4B): every row gets its own digit planes (one
             # transform launch); the GEMV's MFMA carries (row, plane) pairs in its 16 A rows, so up to 5 rows
             # share ONE pass over the codes (more rows / longer k: several passes) -- exact integer
@@ -162,7 +177,7 @@ class QuantLinear(nn.Module):
                 None if gate is None else gate.reshape(x.shape).to(torch.float16).contiguous(),
                 getattr(cb, "planes_resid_scale", 0.0))
             z = cb.mm_planes_rows(planes, self.Qidxs)
-        else:
+        else:     # "codebook": the codebook's own product (M < 32: generic mm; beyond: its batched path)
             xh = torch.ops.quip_lib.had_transform_fused(
                 x, self.q_in_features, self.q_in_features, self.K_left, self._had("had_left"), True,
                 self._vec(self.SU), None, None, None, self.wscale_float / math.sqrt(L_in), None,

@@ -299,8 +299,10 @@ def load_quantized_model(save_folder: str, revision: Optional[str] = None,
         # the fake 0-dim `weight` of a QuantLinear; SU / SV of layers packed with merge_su / merge_sv (the reference
         # drops those parameters, qlinear.py:117-131, loads non-strictly and leaves them at their init of ones,
         # which the post-load step then removes); a tied lm_head
+        # Only a merge_suv checkpoint may lack SU / SV: without it a missing SU / SV means a truncated or renamed
+        # checkpoint, and filling it with ones would load a model that silently computes something else.
         stem, _, leaf = k.rpartition(".")
-        if stem + ".Qidxs" in own and leaf in ("weight", "SU", "SV"):
+        if stem + ".Qidxs" in own and (leaf == "weight" or (leaf in ("SU", "SV") and bool(quantizer.merge_suv))):
             return True
         return k == "lm_head.weight" and bool(getattr(config, "tie_word_embeddings", False))
     hard_missing = [k for k in missing if not soft(k) and (k in was_meta or k.rpartition(".")[0] + ".Qidxs" in own)]

@@ -532,19 +532,23 @@ def _had_transform_group_cuda(x, out_features, n, K, had, transpose, pre2, post,
     return outs
 
 
-_GEMV_WS = {}
+_GEMV_WS = {}        # (device type, index, stream handle) -> zeroed int32 workspace
+_GEMV_WS_RETIRED = []   # superseded workspaces: captured hipGraphs may still hold their pointers, so they are never freed
 
 
 def _gemv_workspace(dev, n_total):
-    """zeroed int32 scratch for K-split GEMV launches, one per device, kept for the life of the process (it is
-    captured by hipGraphs); every launch leaves it zeroed, launches on one stream share it"""
+    """zeroed int32 scratch for K-split GEMV launches: ONE PER (device, stream) -- two streams running such launches at
+    the same time must not add into the same accumulators and arrival counters -- kept for the life of the process
+    (captured hipGraphs hold its pointer); every launch leaves it zeroed.  A workspace that has to grow is replaced,
+    never freed: the old one stays alive for the graphs that captured it."""
     need = capi.lib().quip_e8p_gemv_workspace_bytes(int(n_total))
-    key = (dev.type, dev.index)
+    key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)
     ws = _GEMV_WS.get(key)
     if ws is None or ws.numel() * 4 < need:
-        _need(not torch.cuda.is_current_stream_capturing() or ws is None or ws.numel() * 4 >= need,
-              "GEMV workspace would have to grow during graph capture; run one eager step first")
-        ws = torch.zeros(max(need // 4, 1 << 20), dtype=torch.int32, device=dev)
+        if ws is not None:
+            _GEMV_WS_RETIRED.append(ws)
+        with torch.cuda.stream(torch.cuda.current_stream(dev)):
+            ws = torch.zeros(max(need // 4, 1 << 20), dtype=torch.int32, device=dev)
         _GEMV_WS[key] = ws
     return ws
 

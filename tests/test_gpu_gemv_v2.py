@@ -68,7 +68,10 @@ def test_v2_against_oracle_and_first_kernel(Q, variant, n, k):
     assert torch.equal(y.view(torch.int16), y2.view(torch.int16))
 
 
-@pytest.mark.parametrize("ns,k", [((512, 64, 64), 8192), ((1000, 1000), 4096), ((300, 8, 1024), 2048), ((96, 96), 28672)])
+# (16, 20000): a small first problem next to a large one -- more row blocks than the first problem has accumulator
+# words: the arrival counters sit behind ALL accumulators (round 2 put them behind the first problem's)
+@pytest.mark.parametrize("ns,k", [((512, 64, 64), 8192), ((1000, 1000), 4096), ((300, 8, 1024), 2048), ((96, 96), 28672),
+                                  ((16, 20000), 8192), ((8, 8, 12000), 4096)])
 @pytest.mark.parametrize("variant", [(0, 0, 0, 0, 0, 0), (16, 2, 0, 0, 0, 0), (32, 2, 0, 2, 0, 0)])
 def test_v2_group_equals_single_launches(Q, ns, k, variant):
     from quip_for_all_amd import capi
@@ -127,10 +130,43 @@ def test_public_entry_dispatches_and_matches(Q):
     y64 = x64 @ W64.T
     assert np.all(np.abs(y.cpu().numpy().astype(np.float64) - y64) <= _mm_tol(x64, W64, y64))
     from quip_for_all_amd import register_lib
-    ws = register_lib._GEMV_WS[("cuda", 0)]
+    ws = register_lib._GEMV_WS[("cuda", 0, torch.cuda.current_stream().cuda_stream)]
     assert int(ws.abs().max()) == 0
     # without a workspace the C entry refuses what needs a K split and no kernel can serve
     y0 = torch.empty_like(y)
     rc = L.quip_e8p_gemv_planes(planes.data_ptr(), Qd.data_ptr(), grid.data_ptr(), y0.data_ptr(), n, k,
                                 torch.cuda.current_stream().cuda_stream)
     assert rc in (-1, -5)
+
+
+def test_two_streams_run_k_split_gemvs_at_the_same_time(Q):
+    """quip_lib::e8p_gemv_planes keeps one K-split workspace per (device, stream): launches issued on two streams at
+    the same time neither share accumulators nor arrival counters (round 2: one per device)"""
+    from quip_for_all_amd import capi, register_lib as R
+    L = capi.lib()
+    grid = _cb(Q, "E8P12").grid_packed_abs
+    n, k = 8192, 28672                       # K-split kernel
+    g = torch.Generator().manual_seed(5)
+    Qs = [torch.randint(-32768, 32768, (n, k // 8), generator=g, dtype=torch.int32).to(torch.int16).to(DEV) for _ in range(2)]
+    planes = []
+    for i in range(2):
+        x = torch.randn(1, k, generator=g).half().to(DEV)
+        pl = torch.empty(L.quip_e8p_planes_bytes(k), dtype=torch.uint8, device=DEV)
+        assert L.quip_e8p_x_to_planes(x.data_ptr(), pl.data_ptr(), k, torch.cuda.current_stream().cuda_stream) == 0
+        planes.append(pl)
+    ref = [torch.ops.quip_lib.e8p_gemv_planes(planes[i], Qs[i], grid).clone() for i in range(2)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[], []]
+    for it in range(30):
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                outs[i].append(torch.ops.quip_lib.e8p_gemv_planes(planes[i], Qs[i], grid))
+    torch.cuda.synchronize()
+    for i in range(2):
+        for y in outs[i]:
+            assert torch.equal(y.view(torch.int16), ref[i].view(torch.int16))
+    keys = [k_ for k_ in R._GEMV_WS if k_[2] in (streams[0].cuda_stream, streams[1].cuda_stream)]
+    assert len(keys) == 2 and R._GEMV_WS[keys[0]].data_ptr() != R._GEMV_WS[keys[1]].data_ptr()
+    for k_ in keys:
+        assert int(R._GEMV_WS[k_].abs().max()) == 0
