@@ -94,6 +94,11 @@ def test_own_save_shards_and_round_trips(tmp_path, safe):
     assert again.lm_head.weight.data_ptr() == again.model.embed_tokens.weight.data_ptr()
 
 
+# fp16 ulps of rms(logits) between our forward and the reference's own (whose CPU fp16 matmuls round differently): twice
+# the maximum observed over the variants on MI355X (profiles/r03_model_ulps.txt)
+_LOGIT_ULPS = 12.0      # observed: 6.0 on both reference-written checkpoints
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", VARIANTS)
 def test_reference_checkpoint_logits(variant):
@@ -109,8 +114,10 @@ def test_reference_checkpoint_logits(variant):
     # a few fp16 ulps of the largest logit per element, and the greedy tokens agree
     scale = float(np.abs(ref).max())
     err = float(np.abs(lg - ref).max())
-    print(f"{variant}: max |logit| {scale:.3f}, max abs err {err:.2e}")
-    assert err <= 2e-2 * scale
+    rms = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
+    ulps = err / 2.0 ** (np.floor(np.log2(rms)) - 10)
+    print(f"{variant}: max |logit| {scale:.3f}, rms {rms:.3f}, max abs err {err:.2e} = {ulps:.1f} fp16 ulps of rms")
+    assert ulps <= _LOGIT_ULPS, ulps
     top_ref, top = ref.argmax(-1), lg.argmax(-1)
     margin = np.sort(ref, -1)[..., -1] - np.sort(ref, -1)[..., -2]
     assert np.all((top == top_ref) | (margin < 4 * err))
