@@ -443,6 +443,9 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     dt = max_over_ranks(dist, dt, f"cuda:{local_rank}")
+    status = dec.engine_status() if hasattr(dec, "engine_status") else 0
+    if status:      # a persistent launch gave up on a hand-off: its tokens are not results, no line
+        raise RuntimeError("rank %d: persistent decode launch gave up (code 0x%x)" % (rank, status))
 
     if rank == 0:
         tok_s = aggregate_tokens_per_s(world, a.steps, dt)
