@@ -286,7 +286,11 @@ def prefill_config5(dec, batch=16, seq=2048):
         ttft = repr(e)
     return {"ttft_ms_one_2048_token_prompt_whole_model": ttft,
             "workload": "Llama-2-7B E8P12, bs=%d x seq=%d prefill: the 7 QuantLinear forwards of one decoder block "
-                        "(Hadamard + fused dequant MFMA GEMM + Hadamard), M=%d rows" % (batch, seq, M),
+                        "(batch Hadamard kernels around %s), M=%d rows" % (
+                            batch, seq, {"decompress_gemm": "decompress + dense fp16 GEMM (hipBLASLt): the default at this M, "
+                                         "faster than the fused kernel here", "fused_gemm": "the fused dequant MFMA GEMM"}.get(
+                                mods[0].codebook.batched_regime(M, mods[0].q_out_features, mods[0].q_in_features), "?"), M),
+            "gemm_path": mods[0].codebook.batched_regime(M, mods[0].q_out_features, mods[0].q_in_features),
             "ms_per_block": round(ms, 3), "tflops": round(flops / ms / 1e9, 1),
             "roofline": {"bound": "mfma", "achieved": round(flops / ms / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": round(flops / ms / 1e9 / 2500.0, 4)},

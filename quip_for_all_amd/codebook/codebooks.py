@@ -78,35 +78,42 @@ class E8P12_codebook(_Codebook):
     def mm(self, input, Qidxs):
         return torch.ops.quip_lib.e8p_mm_origorder(input, Qidxs, self.grid_packed_abs)
 
-    # M >= mm_threshold: fused dequant + MFMA GEMM (csrc/e8p_prefill_gemm.hip) instead of the reference's
-    # decompress + dense GEMM (e8p12.py:152-155) -- same arithmetic (exact fp16 weights, fp32 accumulation, one fp16
-    # rounding), no dense W in memory.  QUIP_BATCHED_MM=0 selects the reference-shaped path (A/B, odd shapes).
-    fused_batched = os.environ.get("QUIP_BATCHED_MM", "1") != "0"
+    # M >= mm_threshold: three paths with the same arithmetic (exact fp16 weights, fp32 accumulation, one fp16 rounding):
+    #   skinny_chunks    the single-pass skinny kernel on chunks of 32 rows, up to a few hundred rows;
+    #   decompress_gemm  the reference's shape (e8p12.py:152-155): dense fp16 W in scratch memory, then the vendor GEMM.
+    #                    Measured on MI355X (tools/prefill_crossover.py, profiles/r03_prefill_crossover.txt) it beats the
+    #                    fused kernel at every M from 256 to 32768 on all three 7B shapes (1.0-2.0 x; 1.34-1.46 x at
+    #                    M = 32768: 1.2-1.6 PFLOP/s), so it is the default;
+    #   fused_gemm       fused dequant + MFMA GEMM (csrc/e8p_prefill_gemm.hip): no 2 n k bytes of scratch, no vendor
+    #                    library in the path, 0.94-1.17 PFLOP/s.  QUIP_BATCHED_MM=fused (or 1) selects it.
+    # QUIP_BATCHED_MM=0: the reference-shaped path for every M >= mm_threshold (no skinny chunks either).
+    batched_mode = {"1": "fused", "0": "reference"}.get(os.environ.get("QUIP_BATCHED_MM", "auto"),
+                                                        os.environ.get("QUIP_BATCHED_MM", "auto"))
 
     def batched_regime(self, m, n, k):
         """the path forward() takes for an (m, k) fp16 batch against (n, k / 8) codes, as a name: mm (below the
         threshold) | skinny_chunks | fused_gemm | decompress_gemm"""
         if m < self.mm_threshold:
             return "mm"
-        if self.fused_batched and n % 2 == 0 and k % 64 == 0:
+        if self.batched_mode != "reference" and n % 2 == 0 and k % 64 == 0:
             if m * n <= self.skinny_chunks_max_mn and self.skinny_supported(m, n, k):
                 return "skinny_chunks"
-            return "fused_gemm"
+            if self.batched_mode == "fused":
+                return "fused_gemm"
         return "decompress_gemm"
 
     def forward(self, input, Qidxs):
         if input.size(0) < self.mm_threshold:
             return self.mm(input, Qidxs)
-        if (self.fused_batched and input.is_cuda and input.dtype == torch.float16 and input.dim() == 2
-                and Qidxs.shape[0] % 2 == 0 and input.shape[1] % 64 == 0):
-            m, n = input.shape[0], Qidxs.shape[0]
+        if input.is_cuda and input.dtype == torch.float16 and input.dim() == 2:
             # up to a few hundred rows the single-pass skinny kernel on chunks of 32 rows (many small workgroups, a
-            # few microseconds each) beats the tile GEMM, whose K loop alone takes 55 (K = 4096, 128-row tiles) to
-            # 125 us (K = 11008) however few tiles there are (tools/midm_bench.py: 4096 x 4096 at M = 64: 10 vs 55 us,
-            # M = 256: 34 vs 56; crossover M n ~ 1.8e6)
-            if m * n <= self.skinny_chunks_max_mn and self.skinny_supported(m, n, input.shape[1]):
+            # few microseconds each) beats both GEMMs (tools/midm_bench.py: 4096 x 4096 at M = 64: 10 us against 37
+            # for decompress + GEMM and 55 for the tile kernel; M = 256: 34 / 40 / 56)
+            regime = self.batched_regime(input.shape[0], Qidxs.shape[0], input.shape[1])
+            if regime == "skinny_chunks":
                 return torch.ops.quip_lib.e8p_mm_skinny(input, Qidxs, self.grid_packed_abs)
-            return torch.ops.quip_lib.e8p_mm_batched(input, Qidxs, self.grid_packed_abs)
+            if regime == "fused_gemm":
+                return torch.ops.quip_lib.e8p_mm_batched(input, Qidxs, self.grid_packed_abs)
         W = self.decompress_weight(Qidxs)
         return input @ W.T
 
@@ -140,7 +147,7 @@ class E8P12_codebook(_Codebook):
         """skinny product: planes (M, planes_bytes) -> (M, n), passes of up to 5 rows over the codes"""
         return torch.ops.quip_lib.e8p_gemv_planes_rows(planes, Qidxs, self.grid_packed_abs)
 
-    skinny_chunks_max_mn = int(os.environ.get("QUIP_SKINNY_MAX_MN", str(1_800_000)))
+    skinny_chunks_max_mn = int(os.environ.get("QUIP_SKINNY_MAX_MN", str(1_200_000)))
 
     @staticmethod
     def skinny_supported(m, q_out, q_in):

@@ -103,7 +103,8 @@ struct BLds {
   static constexpr int kStage = kArea + 24 * 1024;            // MLP row owners: their eight rows, transposed, on the way out (8 KB)
   static constexpr int kStash = kArea + 36 * 1024;            // MLP row owners: SV_gate / SV_up / SU_down of their eight rows (12 KB)
   static constexpr int kPlaneD = (KPD / 256) * 272;
-  static constexpr int kBytes = kArea + kAreaBytes;
+  static constexpr int kCs = kArea + kAreaBytes;             // float [2][128]: the rotary row of this token (cos | sin), the same for every block
+  static constexpr int kBytes = kCs + 2 * HD * 4;
 };
 static_assert(BLds<16>::kBytes <= 160 * 1024, "LDS budget");
 
@@ -192,10 +193,15 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     }                                                                                                                  \
   } while (0)
   // after a drain: every slot is a plain register again
-  auto own_slots = [&]() {
+  // (`mask`: the slots that can be in flight at that point.  The others are dead there, and saying so frees their
+  //  registers for the phase: the attention prologue keeps 8 of the 72 slot registers)
+  auto own_slots = [&](auto mask) {
+    constexpr unsigned M = decltype(mask)::value;
 #pragma unroll
-    for (int s = 0; s < NSLOT; ++s) { esync::own(qa[s]); esync::own(qb[s]); }
+    for (int s = 0; s < NSLOT; ++s)
+      if ((M >> s) & 1u) { esync::own(qa[s]); esync::own(qb[s]); }
   };
+#define SLOTS(m) std::integral_constant<unsigned, (m)>{}
 
   // ---- prologue ---------------------------------------------------------------------------------------------------
   u32x2 tsrc;
@@ -219,6 +225,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   const long long pos64 = *a.pos;
   const bool pos_ok = pos64 >= 0 && pos64 < (long long)a.max_len;
   const int pos = pos_ok ? (int)pos64 : 0;
+  if (tid < 2 * HD)
+    reinterpret_cast<float*>(smem + B::kCs)[tid] = (tid < HD ? a.cos : a.sin - HD)[(size_t)pos * HD + tid];
   had::wg_barrier<true>();
   uint32_t hop = 0;                                 // hand-offs so far in this launch (tag = ebase | hop)
 
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 
   // ---- all-gather of one or more 4096-vectors (2048 granules each, {2 x fp16, tag}) into LDS as fp16 -------------------
   // NV vectors starting at zbufs[first]; every thread sweeps 2 NV 16-byte pieces; returns with the data in smem + kZs
-  auto gather = [&](auto nv_tag, int first, uint32_t tag, uint32_t code, float (&out)[decltype(nv_tag)::value][8]) {
+  auto gather = [&](auto nv_tag, auto slots, int first, uint32_t tag, uint32_t code, float (&out)[decltype(nv_tag)::value][8]) {
     constexpr int NV = decltype(nv_tag)::value;
     u32x4_t p[2 * NV];
     uint32_t spins = 0;
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 #pragma unroll
     for (int c = 0; c < NV; ++c)
       had::unpack8(make_uint4(p[2 * c].x, p[2 * c].z, p[2 * c + 1].x, p[2 * c + 1].z), out[c]);
-    own_slots();
+    own_slots(slots);
   };
   // this workgroup's 16 values of a product (accumulator rows [row0, row0 + 16), block exponent sh) -> 8 granules
   auto publish16 = [&](int vec, int gr0, int row0, int sh, uint32_t tag) {      // gr0: first granule of the block in its vector
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   // Transforms: fht_wg512.hip.h (all 512 threads, 8 elements each: input element 8 tid + r, output element tid + 512 k).
   // The vectors of this thread's elements are requested before the gather waits; after_gather() runs right after it.
   float* xbuf = reinterpret_cast<float*>(smem + B::kBuf0);
-  auto edge = [&](auto nc_tag, int zvec, uint32_t tag, uint32_t code, const f16* sv_prev, const f16* ln, const f16* su0,
+  auto edge = [&](auto nc_tag, auto slots, int zvec, uint32_t tag, uint32_t code, const f16* sv_prev, const f16* ln, const f16* su0,
                   const f16* su1, float sc0, float sc1, bool two, auto after_gather, int sb = -1) {
 #define ESTAMP(i) do { if (sb >= 0) BSTAMP(sb + (i)); } while (0)
     constexpr int NC = decltype(nc_tag)::value;
@@ -294,7 +302,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     auto u4 = [](const u32x4& v) { return make_uint4(v.x, v.y, v.z, v.w); };
     if (have_z) {
       float v[1][8];
-      gather(std::integral_constant<int, 1>{}, zvec, tag, code, v);
+      gather(std::integral_constant<int, 1>{}, slots, zvec, tag, code, v);
       // The vectors have landed (the gather drained the queue).  Take them over HERE: the compiler counts only its own
       // loads, so the wait it would place at their first use would also wait for the burst requested below.
 #pragma unroll
@@ -372,6 +380,22 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     }
   };
 
+  // the same item in two halves: the table lookups while a hand-off is awaited (the codes are there long before the digits),
+  // the eight MFMAs once the digit planes exist
+  auto decode_item = [&](int s, i32x4 (&Bf)[8]) {
+    ItemAddr ad;
+    item_addresses<REP>(qa[s], qb[s], lane_c, lane_c2, ad, 0u);
+    item_decode(ad, Bf);
+  };
+  auto add_rows = [&](const i32x4& r, int accrow) {
+    if (q == 0) {
+      int* dst = accs + (accrow + n) * 4;
+      __hip_atomic_fetch_add(dst + 0, r.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(dst + 1, r.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(dst + 2, r.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  };
+
   const f16* sv_d_prev = nullptr;
   const BlockLayer& Ld = *reinterpret_cast<const BlockLayer*>(smem + B::kDesc);
   if (tid < 64) reinterpret_cast<uint32_t*>(smem + B::kDesc)[tid] = reinterpret_cast<const uint32_t*>(a.layers)[tid];
@@ -384,11 +408,11 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     const int c_lo = (3 * w) >> 8, c_hi = (3 * w + 2) >> 8;         // the one or two matrices this workgroup's row blocks are in
     // (the output side of the previous block's down_proj + residual ran at the bottom of the previous iteration: no
     //  weight request may be in flight across the loop edge, where the compiler is free to copy registers)
-    edge(std::integral_constant<int, 2>{}, -1, 0u, 0u, nullptr, Ld.ln[0], Ld.su[c_lo], Ld.su[c_hi], Ld.sc[c_lo], Ld.sc[c_hi],
+    edge(std::integral_constant<int, 2>{}, SLOTS(0x007u), -1, 0u, 0u, nullptr, Ld.ln[0], Ld.su[c_lo], Ld.su[c_hi], Ld.sc[c_lo], Ld.sc[c_hi],
          c_hi != c_lo, [&]() {});
     BSTAMP(2);
     esync::drain();                                    // q, k, v have landed (requested one transform stage ago)
-    own_slots();
+    own_slots(SLOTS(0x007u));
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int ci = (3 * w + i) >> 8;
@@ -420,14 +444,29 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       const int d0 = (tid & 15) * 8;
 #pragma unroll
       for (int c = 0; c < 3; ++c) psv[c] = Ld.sv[c][mine ? HD * hd + tloc : 0];
-      {
-        const float* cs = a.cos + (size_t)pos * HD;
-        const float* sn = a.sin + (size_t)pos * HD;
+      // the cached rows of this head depend on nothing: the first two rounds (2 x 64 positions) are requested HERE / right after the gather and land
+      // while the hand-off is awaited / under the transforms (they come from HBM -- a token's weight stream has flushed every cache since they were
+      // written: 2 us per dependent round otherwise); later rounds are requested two rounds ahead of their use
+      constexpr int LPK = HD / 8, NG = 256 / LPK, U = 4;
+      const int g = (tid & 255) / LPK;
+      const f16* kc = Ld.kcache + (size_t)hd * a.max_len * HD;
+      const f16* vc = Ld.vcache + (size_t)hd * a.max_len * HD;
+      uint4 kr0[U], vr0[U], kr1[U], vr1[U];
+      auto load_round = [&](uint4 (&kr)[U], uint4 (&vr)[U], int t0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { c8[i] = cs[d0 + i]; s8[i] = sn[d0 + i]; }
+        for (int u = 0; u < U; ++u) {
+          const int t = t0 + u * NG;
+          const int tc = t < pos ? t : 0;
+          kr[u] = *reinterpret_cast<const uint4*>(kc + (size_t)tc * HD + d0);
+          vr[u] = *reinterpret_cast<const uint4*>(vc + (size_t)tc * HD + d0);
+        }
+      };
+      if (tid < 256) {
+        load_round(kr0, vr0, g);
+        if (NG * U < pos) load_round(kr1, vr1, g + NG * U);
       }
       float v[3][8];
-      gather(std::integral_constant<int, 3>{}, 0, ebase | hop, 0x5000u, v);
+      gather(std::integral_constant<int, 3>{}, SLOTS(0x008u), 0, ebase | hop, 0x5000u, v);
       BSTAMP(4);
       f16* s_qkv = reinterpret_cast<f16*>(smem + B::kQkv);
       {
@@ -444,12 +483,10 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       BSTAMP(5);
       // single-query attention of head hd over positions [0, pos] (decode_glue.hip's arithmetic): 16 lanes per key,
       // 16 key groups with their own online-softmax state, merged through LDS
-      constexpr int LPK = HD / 8, NG = 256 / LPK, U = 4;
       float* s_m = reinterpret_cast<float*>(smem + B::kArea);
       float* s_l = s_m + NG;
       float* s_acc = s_l + NG;                         // [NG][HD + 4]
       if (tid < 256) {
-        const int g = tid / LPK;
         auto unpack8h = [](const uint4& u, float o[8]) {
           const uint32_t ww[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
@@ -468,6 +505,11 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) o[i] = (float)(f16)had::fadd(had::fmul(x[i], c8[i]), had::fmul(sgn * y[i], s8[i]));
         };
+        {
+          const float* cs = reinterpret_cast<const float*>(smem + B::kCs);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { c8[i] = cs[d0 + i]; s8[i] = cs[HD + d0 + i]; }
+        }
         float q8[8], kn[8], vn[8];
         rope8(s_qkv, q8);
         rope8(s_qkv + HD, kn);
@@ -475,28 +517,19 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         unpack8h(vraw, vn);
 #pragma unroll
         for (int i = 0; i < 8; ++i) q8[i] *= a.attn_scale;
-        f16* kc = Ld.kcache + (size_t)hd * a.max_len * HD;
-        f16* vc = Ld.vcache + (size_t)hd * a.max_len * HD;
         if (g == 0 && pos_ok) {                        // append the new row (StaticCache.update)
           uint4 kr;
           kr.x = pack_f16(kn[0], kn[1]); kr.y = pack_f16(kn[2], kn[3]);
           kr.z = pack_f16(kn[4], kn[5]); kr.w = pack_f16(kn[6], kn[7]);
-          *reinterpret_cast<uint4*>(kc + (size_t)pos * HD + d0) = kr;
-          *reinterpret_cast<uint4*>(vc + (size_t)pos * HD + d0) = vraw;
+          *const_cast<uint4*>(reinterpret_cast<const uint4*>(kc + (size_t)pos * HD + d0)) = kr;
+          *const_cast<uint4*>(reinterpret_cast<const uint4*>(vc + (size_t)pos * HD + d0)) = vraw;
         }
         float m = -INFINITY, lsum = 0.f, acc8[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc8[i] = 0.f;
         const int t_hi = pos + 1;
-        for (int t0 = g; t0 < t_hi; t0 += NG * U) {
-          uint4 kr[U], vr[U];
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int t = t0 + u * NG;
-            const int tc = t < pos ? t : 0;
-            kr[u] = *reinterpret_cast<const uint4*>(kc + (size_t)tc * HD + d0);
-            vr[u] = *reinterpret_cast<const uint4*>(vc + (size_t)tc * HD + d0);
-          }
+        // one round: positions t0 + u NG of this key group, rows in (kr, vr)
+        auto round = [&](const uint4 (&kr)[U], const uint4 (&vr)[U], int t0) {
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             const int t = t0 + u * NG;
@@ -520,6 +553,15 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
               for (int i = 0; i < 8; ++i) acc8[i] = acc8[i] * cc + pp * v8[i];
               m = mn;
             }
+          }
+        };
+        // (uniform trip count: the lanes of a wave differ in g < NG only, and every round is entered for t0 - g < t_hi)
+        for (int tb = 0; tb < t_hi; tb += 2 * NG * U) {
+          round(kr0, vr0, tb + g);
+          if (tb + 2 * NG * U < t_hi) load_round(kr0, vr0, tb + g + 2 * NG * U);
+          if (tb + NG * U < t_hi) {
+            round(kr1, vr1, tb + g + NG * U);
+            if (tb + 3 * NG * U < t_hi) load_round(kr1, vr1, tb + g + 3 * NG * U);
           }
         }
         if ((tid & (LPK - 1)) == 0) { s_m[g] = m; s_l[g] = lsum; }
@@ -549,12 +591,17 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     }
     BSTAMP(6);
     rederive();
+    i32x4 Bo[8];
     {
+      // o's codes were requested a hand-off ago: their table lookups run HERE, inside the wait for the attention output
+      esync::drain();
+      own_slots(SLOTS(0x008u));
+      decode_item(3, Bo);
       // o_proj's input side: x = H (a (.) SU_o) * sc  (no norm), every workgroup
       const u32x4 psu = *reinterpret_cast<const u32x4*>(Ld.su[3] + 8 * tid);
       ISSUE(Ld, 4); ISSUE(Ld, 5); ISSUE(Ld, 6);        // gate's row blocks (X0-2: q, k, v consumed), at the start of the wait
       float v[1][8];
-      gather(std::integral_constant<int, 1>{}, 3, ebase | hop, 0x6000u, v);
+      gather(std::integral_constant<int, 1>{}, SLOTS(0x007u), 3, ebase | hop, 0x6000u, v);
       BSTAMP(7);
       had::mul8(v[0], make_uint4(psu.x, psu.y, psu.z, psu.w));
       had8::fht4096<1, true>(v, xbuf, tid);
@@ -566,9 +613,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       had::wg_barrier<true>();
     }
     BSTAMP(8);
-    esync::drain();
-    own_slots();
-    run_item(3, xlane, 48);
+    add_rows(item_multiply(Bo, xlane), 48);
     had::wg_barrier<true>();
     ++hop;                                             // hand-off: z_o
     publish16(4, w * 8, 48, shs[3], ebase | hop);
@@ -579,7 +624,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 
     // ================= P3: o's output side + residual, RMSNorm, input transforms of gate / up; their products =========
     rederive();
-    edge(std::integral_constant<int, 2>{}, 4, ebase | hop, 0x7000u, Ld.sv[3], Ld.ln[1], Ld.su[4], Ld.su[5], Ld.sc[4], Ld.sc[5], true,
+    edge(std::integral_constant<int, 2>{}, SLOTS(0x03fu), 4, ebase | hop, 0x7000u, Ld.sv[3], Ld.ln[1], Ld.su[4], Ld.su[5], Ld.sc[4], Ld.sc[5], true,
          [&]() { BSTAMP(10); }, 18);
     BSTAMP(11);
     // row owners (w < NRO: rows k' = RPO w .. RPO w + RPO - 1, one per wave): SV_gate / SV_up / SU_down of their rows into the free
@@ -599,12 +644,11 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         *reinterpret_cast<uint4*>(smem + B::kHad + i * 16) = reinterpret_cast<const uint4*>(Ld.had3)[i];
     }
     esync::drain();
-    own_slots();
+    own_slots(SLOTS(0x03fu));
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int m = i / FRB;
-      run_item(i, xlane + (uint32_t)(m * 3 * HID), 64 + i * 16);
-    }
+    for (int i = 0; i < FRB; ++i) run_item(i, xlane, 64 + i * 16);
+#pragma unroll
+    for (int i = FRB; i < 2 * FRB; ++i) run_item(i, xlane + (uint32_t)(3 * HID), 64 + i * 16);
     had::wg_barrier<true>();
     BSTAMP(12);
 
@@ -647,11 +691,13 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       }
       ++hop;                                           // hand-off: rows -> everybody
       const uint32_t tag2 = ebase | hop;
+      ISSUE(Ld, 10); ISSUE(Ld, 11); ISSUE(Ld, 12);     // down (X6-8), behind the inbox stores: a row owner's first poll queues
+                                                       // behind them, and the inbox takes longer than that to fill
       BSTAMP(13);
       if (w < NRO) {
         const int kr = RPO * w + wave;                   // this wave's row of the (43, 256) view (waves 0..RPO-1)
         const bool have_row = wave < RPO && kr < FK;
-        const int m = (lane >> 4) & 1, t = lane & 15;
+        const int m = lane >> 5, t = lane & 31;
         // the owner's inbox = 256 columns x (2 matrices x RPO rows) granules, swept by all 512 threads (coalesced 16-byte
         // pieces); piece p = column p / RPO, matrix (p / (RPO / 2)) & 1, rows 2 (p % (RPO / 2)) and + 1
         {
@@ -681,49 +727,49 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           }
           had::wg_barrier<true>();
         }
-        float v[16];
+        // a row on the whole wave: lanes 0..31 its gate half, 32..63 its up half, 8 consecutive elements each (index bits
+        // 0..2 in registers, 3..7 = lane bits 0..4; ascending bit order: the same additions as fht16_lanes, fht_wg512.hip.h)
+        float v[8];
         {
-          const float* rb = reinterpret_cast<const float*>(smem + B::kArea) + ((have_row ? wave : 0) * 2 + m) * FL + t * 16;
-#pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) {
-            const float4 f4 = *reinterpret_cast<const float4*>(rb + 4 * r4);
-            v[4 * r4] = f4.x; v[4 * r4 + 1] = f4.y; v[4 * r4 + 2] = f4.z; v[4 * r4 + 3] = f4.w;
-          }
+          const float* rb = reinterpret_cast<const float*>(smem + B::kArea) + ((have_row ? wave : 0) * 2 + m) * FL + t * 8;
+          const float4 f0 = *reinterpret_cast<const float4*>(rb), f1 = *reinterpret_cast<const float4*>(rb + 4);
+          v[0] = f0.x; v[1] = f0.y; v[2] = f0.z; v[3] = f0.w; v[4] = f1.x; v[5] = f1.y; v[6] = f1.z; v[7] = f1.w;
         }
-        had::fht16_lanes<FLOGL>(v, t);
+        auto fht256 = [&](float (&x)[8]) {
+          had8::reg_stage<1>(x); had8::reg_stage<2>(x); had8::reg_stage<4>(x);
+          had8::lane_stage<0>(x, lane); had8::lane_stage<1>(x, lane); had8::lane_stage<2>(x, lane);
+          had8::lane_stage<3>(x, lane); had8::lane_stage<4>(x, lane);
+        };
+        fht256(v);
         const f16* vecs = reinterpret_cast<const f16*>(smem + B::kStash) + (have_row ? wave : 0) * 3 * FL;
-        const f16* sv = vecs + m * FL + t * 16;
-        float o[16];
+        float o[8];
         {
-          float svf[16];
-          had::unpack8(*reinterpret_cast<const uint4*>(sv), svf);
-          had::unpack8(*reinterpret_cast<const uint4*>(sv + 8), svf + 8);
+          float svf[8];
+          had::unpack8(*reinterpret_cast<const uint4*>(vecs + m * FL + t * 8), svf);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) o[r] = (float)had::out_elem(v[r], 1.f / 16.f, true, svf[r], false, 0.f, false, 0.f);
+          for (int r = 0; r < 8; ++r) o[r] = (float)had::out_elem(v[r], 1.f / 16.f, true, svf[r], false, 0.f, false, 0.f);
         }
-        float e[16];
+        float e[8];
         {
-          float suf[16];
-          const f16* su = vecs + 2 * FL + t * 16;
-          had::unpack8(*reinterpret_cast<const uint4*>(su), suf);
-          had::unpack8(*reinterpret_cast<const uint4*>(su + 8), suf + 8);
+          float suf[8];
+          had::unpack8(*reinterpret_cast<const uint4*>(vecs + 2 * FL + t * 8), suf);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float u = __shfl(o[r], (lane + 16) & 63, 64);
+          for (int r = 0; r < 8; ++r) {
+            const float u = had8::lane_partner<5>(o[r], lane);          // the up half's value (lane + 32)
             e[r] = had::fmul(had::fmul(u, had::silu(o[r])), suf[r]);
           }
         }
-        had::fht16_lanes<FLOGL>(e, t);
+        fht256(e);
         // the wave's row, as fp16 hi + lo of the prescaled values, next to the owner's other rows in LDS ([j][RPO]) ...
         uint32_t* stage = reinterpret_cast<uint32_t*>(smem + B::kStage);
-        if (lane < 16 && wave < RPO) {
+        if (lane < 32 && wave < RPO) {
           constexpr float kPre = 1.f / 16.f;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
+          for (int r = 0; r < 8; ++r) {
             const float vv = e[r] * kPre;
             const f16 hi = (f16)vv;
             const f16 lo = (f16)(vv - (float)hi);
-            stage[(16 * t + r) * RPO + wave] = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
+            stage[(8 * t + r) * RPO + wave] = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
           }
         }
         had::wg_barrier<true>();
@@ -739,7 +785,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         had::wg_barrier<true>();                         // the staging area is free again (the gather below zeroes over it)
       }
       BSTAMP(14);
-      ISSUE(Ld, 10); ISSUE(Ld, 11); ISSUE(Ld, 12);     // down (X6-8), at the start of the wait for the rows
+      // down's lookups inside the wait for the rows
       // B fragments of the K-mix (had_d^T in LDS)
       typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
       f16x4 bfr[3][FRB];
@@ -802,7 +848,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
             *reinterpret_cast<uint2*>(ft + col * B::KP16 + 2 * kp) = make_uint2(p[j].x, (2 * kp + 1 < FK) ? p[j].z : 0u);
           }
         }
-        own_slots();
+        own_slots(SLOTS(0x1c0u));
       }
       had::wg_barrier<true>();
       BSTAMP(15);
@@ -884,13 +930,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         if (sl < JD) {
           ItemAddr ad;
           item_addresses<REP>(qa[6 + i], qb[6 + i], lane_c, lane_c2, ad, 0u);
-          const i32x4 d4 = item_mfma<272>(ad, xlane_d + (uint32_t)(sl * 544));
-          if (q == 0) {
-            int* dst = accs + (160 + n) * 4;
-            __hip_atomic_fetch_add(dst + 0, d4.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(dst + 1, d4.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(dst + 2, d4.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
+          add_rows(item_mfma<272>(ad, xlane_d + (uint32_t)(sl * 544)), 160);
         }
       }
       had::wg_barrier<true>();
@@ -909,7 +949,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     }
     // output side of this block's down_proj + residual -> h (the gather drains the requests above)
     rederive();
-    edge(std::integral_constant<int, 0>{}, 5, ebase | hop, 0x4000u, sv_d_prev, nullptr, nullptr, nullptr, 0.f, 0.f, false,
+    edge(std::integral_constant<int, 0>{}, SLOTS(0x007u), 5, ebase | hop, 0x4000u, sv_d_prev, nullptr, nullptr, nullptr, 0.f, 0.f, false,
          [&]() { BSTAMP(1); });
   }
   // ---- h_out -----------------------------------------------------------------------------------------------------------
@@ -919,6 +959,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   }
 #undef BSTAMP
 #undef ISSUE
+#undef SLOTS
 }
 
 }  // namespace

@@ -295,5 +295,28 @@ __device__ __forceinline__ i32x4 item_mfma(const ItemAddr& ad, uint32_t xaddr) {
   return acc;
 }
 
+// The two halves of item_mfma() as separate calls, for callers that have the codes long before the digit planes (the
+// persistent decode engine decodes while it waits for a hand-off): item_decode() turns the 32 addresses into the eight B
+// fragments (all the table lookups), item_multiply() reads the eight A fragments and runs the MFMAs.  Same operations, same
+// integer sums as item_mfma().
+__device__ __forceinline__ void item_decode(const ItemAddr& ad, i32x4 (&B)[8]) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const uint2 t1l = lds_read8(ad.a1l[t]), t2l = lds_read8(ad.a2l[t]);
+    const uint2 t1h = lds_read8(ad.a1h[t]), t2h = lds_read8(ad.a2h[t]);
+    B[t] = i32x4{(int)(t1l.x ^ t2l.x), (int)(t1l.y ^ t2l.y), (int)(t1h.x ^ t2h.x), (int)(t1h.y ^ t2h.y)};
+  }
+}
+template <int HALF = 256>
+__device__ __forceinline__ i32x4 item_multiply(const i32x4 (&B)[8], uint32_t xaddr) {
+  i32x4 A[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) A[t] = lds_read16i(xaddr + (t < 4 ? 16 * t : HALF + 16 * (t - 4)));
+  i32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t], B[t], acc, 0, 0, 0);
+  return acc;
+}
+
 }  // namespace
 }  // namespace quip

@@ -48,10 +48,13 @@ constexpr int kBM = 256, kBN = 256, kBK = 64;
 constexpr int kRep = 8;
 constexpr int kT1 = 0;
 constexpr int kT2 = 256 * kRep * 8;          // 16 KiB
-constexpr int kA = 2 * kT2;                  // 32 KiB; behind it the X tiles of 32 KiB
-constexpr int kTileBytes = kBM * kBK * 2;
+constexpr int kA = 2 * kT2;                  // 32 KiB; behind it the X tiles (128 bytes per row)
+#ifndef QUIP_PREFILL_INTERLEAVE
+#define QUIP_PREFILL_INTERLEAVE 1
+#endif
+constexpr bool kInterleave = QUIP_PREFILL_INTERLEAVE != 0;
 constexpr int kStages = 4;                   // X tiles in LDS: one multiplied, one landed, two in flight
-constexpr int kLds = kA + kStages * kTileBytes;   // 160 KiB
+constexpr int lds_bytes(int bm) { return kA + kStages * bm * kBK * 2; }   // 160 KiB at 256 rows
 
 // sign table image (same statement as the GEMV's: 4w = T1[abs] ^ T2[sign] byte-wise, origin_order.cu:211-253)
 struct PT2Image {
@@ -92,17 +95,24 @@ __device__ __forceinline__ void bytes_to_f16x4(uint32_t u4, uint32_t& lo, uint32
   hi = as_u32(as_f16x2(b) + m288);
 }
 
-// NB = row blocks of 32 per wave: 8 (256-row tiles) or 4 (128-row tiles, for launches whose 256-row tiles would not
-// fill the GPU: a few thousand rows against 4096 columns)
-template <int NB>
-__global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __restrict__ X,
-                                                                  const uint16_t* __restrict__ Wc,
-                                                                  const uint64_t* __restrict__ grid,
-                                                                  f16* __restrict__ Y, int M, int N, int K, int MT,
-                                                                  int NT) {
+// Wave layout: WM x WN waves; a wave owns NB row blocks x NC column blocks of 32 (tile = 32 NB WM rows x 32 NC WN = 256
+// columns).  <8, 1, 1, 8>: every code decoded once per workgroup, every A fragment read from LDS by all eight waves
+// (one ds_read_b128 per MFMA: the LDS pipe is as busy as the matrix cores); <4, 2, 2, 4>: an A fragment feeds two
+// MFMAs (half the LDS traffic), a code is decoded by the two waves that share its columns; <8, 2, 1, 4>: four waves,
+// both.  128-row tiles (<4, 1, 1, 8>, <2, 2, 2, 4>) for launches whose 256-row tiles would not fill the GPU.
+template <int NB, int NC, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void e8p_prefill_gemm_kernel(const f16* __restrict__ X,
+                                                                        const uint16_t* __restrict__ Wc,
+                                                                        const uint64_t* __restrict__ grid,
+                                                                        f16* __restrict__ Y, int M, int N, int K, int MT,
+                                                                        int NT) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(32 * NC * WN == kBN, "256 columns per tile");
+  constexpr int NW = WM * WN, BM = 32 * NB * WM;
+  constexpr int kTileBytes = BM * kBK * 2;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave - wm * WN;
   int mt, nt;
   if (MT >= 8) {
     const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
@@ -113,17 +123,16 @@ __global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __r
     mt = (int)blockIdx.x % MT;
     nt = (int)blockIdx.x / MT;
   }
-  constexpr int BM = 32 * NB;
   const int m0 = mt * BM, n0 = nt * kBN;
   const int KT = K / kBK;
 
-  // ---- X tile loader (global_load_lds): instruction i of this wave fills LDS slots [(8 i + wave) * 64, +64) of the
+  // ---- X tile loader (global_load_lds): instruction i of this wave fills LDS slots [(NW i + wave) * 64, +64) of the
   // tile; slot s = (row s >> 3, stored chunk s & 7) holds source chunk (s & 7) ^ ((row >> 1) & 7) of that row
-  constexpr int XL = NB / 2;            // loader instructions per wave and tile (8 rows x 128 bytes each)
+  constexpr int XL = BM / 8 / NW;       // loader instructions per wave and tile (8 rows x 128 bytes each)
   const f16* xsrc[XL];
 #pragma unroll
   for (int i = 0; i < XL; ++i) {
-    const int row = (8 * i + wave) * 8 + (lane >> 3);
+    const int row = (NW * i + wave) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
     const int gr = min(m0 + row, M - 1);
     xsrc[i] = X + (size_t)gr * K + c * 8;
@@ -133,42 +142,56 @@ __global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __r
     for (int i = 0; i < XL; ++i)
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(xsrc[i] + (size_t)t * kBK),
-          (__attribute__((address_space(3))) void*)(smem + kA + buf * kTileBytes + (8 * i + wave) * 1024), 16, 0, 0);
+          (__attribute__((address_space(3))) void*)(smem + kA + buf * kTileBytes + (NW * i + wave) * 1024), 16, 0, 0);
   };
-  // ---- codes: lane (n = lane & 31, kb = lane >> 5) holds the 4 codes k = 64 t + 32 kb + 8 j .. (j = 0..3) of column
-  // n0 + 32 wave + n
-  const int ncol = n0 + 32 * wave + (lane & 31);
+  // ---- codes: lane (n = lane & 31, kb = lane >> 5) holds the 4 codes k = 64 t + 32 kb + 8 j .. (j = 0..3) of columns
+  // n0 + 32 (NC wn + c) + n, c < NC
+  int ncol[NC];
+  const uint16_t* wsrc[NC];
   const int kb = lane >> 5;
-  const uint16_t* wsrc = Wc + (size_t)min(ncol, N - 1) * (K >> 3) + kb * 4;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    ncol[c] = n0 + 32 * (NC * wn + c) + (lane & 31);
+    wsrc[c] = Wc + (size_t)min(ncol[c], N - 1) * (K >> 3) + kb * 4;
+  }
   // (asm: beside LDS-DMA loads in flight hipcc waits vmcnt(0) for any ordinary register load, which would drain the
   //  prefetch queue every tile; all VMEM traffic of the K loop is counted by hand instead)
-  auto load_codes = [&](pu32x2& dst, int t) {
-    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(wsrc + (size_t)t * (kBK / 8)) : "memory");
+  auto load_codes = [&](pu32x2 (&dst)[NC], int t) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst[c]) : "v"(wsrc[c] + (size_t)t * (kBK / 8)) : "memory");
   };
 
-  // tiles 0, 1 and 2 are requested here, tile t + 3 in the middle of tile t.  Per tile and wave: one code load + four
-  // LDS-DMA instructions = 5 VMEM operations.
+  // tiles 0, 1 and 2 are requested here, tile t + 3 in the middle of tile t.  Per tile and wave: NC code loads + XL
+  // LDS-DMA instructions.
   // cq[]: registers the code loads write (in flight); cv[]: the codes of the current / next tile, taken over by an
   // asm that waits and then moves them (a register in flight is never a tied operand: the compiler may copy a tied
   // operand ahead of the asm, i.e. ahead of the wait -- see e8p_skinny_gemm.hip)
-  pu32x2 cq[kStages], cv[2];
+  pu32x2 cq[kStages][NC], cv[2][NC];
   load_codes(cq[0], 0);
   issue_x(0, 0);
   load_codes(cq[1], min(1, KT - 1));      // (past the end: tile KT - 1 again -- the queue depth stays constant, so
   issue_x(min(1, KT - 1), 1);             //  every wait below is the same counted wait, with no branch around it)
   load_codes(cq[2], min(2, KT - 1));
   issue_x(min(2, KT - 1), 2);
-  auto take = [](pu32x2& dst, const pu32x2& src, auto nw) {
-    asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
-                 : "=&v"(dst.x), "=&v"(dst.y)
-                 : "v"(src.x), "v"(src.y), "n"(decltype(nw)::value)
-                 : "memory");
+  auto take = [](pu32x2 (&dst)[NC], const pu32x2 (&src)[NC], auto nw) {
+    if constexpr (NC == 1)
+      asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
+                   : "=&v"(dst[0].x), "=&v"(dst[0].y)
+                   : "v"(src[0].x), "v"(src[0].y), "n"(decltype(nw)::value)
+                   : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%8)\n\tv_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                   : "=&v"(dst[0].x), "=&v"(dst[0].y), "=&v"(dst[1].x), "=&v"(dst[1].y)
+                   : "v"(src[0].x), "v"(src[0].y), "v"(src[1].x), "v"(src[1].y), "n"(decltype(nw)::value)
+                   : "memory");
   };
 
   // ---- tables: T1' = (4a | 1) ^ 0x80.. (the ^0x80 turns 4w into the unsigned byte 4w + 128 the fp16 conversion
   // wants), T2 = sign masks; kRep copies each, copy (lane + c) & (kRep - 1) at step c
-  {
-    const int e = wave * 32 + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 8 / NW; ++r) {
+    const int e = (wave + NW * r) * 32 + (lane & 31);
     const bool second = (lane & 32) != 0;
     const uint2 raw = second ? kPT2Img.v[e] : reinterpret_cast<const uint2*>(grid)[e];
     const uint32_t t1x = (__builtin_amdgcn_perm(0u, raw.x, 0x03010200u) | 0x01010101u) ^ 0x80808080u;
@@ -187,13 +210,15 @@ __global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __r
   const int m = lane & 31;
   uint32_t aoff[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) aoff[j] = (uint32_t)(m * 128 + (((kb * 4 + j) ^ ((m >> 1) & 7)) << 4));
+  for (int j = 0; j < 4; ++j) aoff[j] = (uint32_t)(wm * NB * 4096 + m * 128 + (((kb * 4 + j) ^ ((m >> 1) & 7)) << 4));
 
-  f32x16 acc[NB];
+  f32x16 acc[NC][NB];
 #pragma unroll
-  for (int b = 0; b < NB; ++b)
+  for (int c = 0; c < NC; ++c)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][b][r] = 0.f;
 
   // ---- the K loop.  k steps of 16 (8 MFMAs per wave each) flow across the 64-wide tiles without a bubble: during
   // step g the two table lookups and the eight A fragments of step g + 1 are requested (asm LDS reads, pinned by
@@ -202,23 +227,29 @@ __global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __r
   // decoded under the other four.  The only workgroup synchronisation is in the MIDDLE of a tile: "tile t + 1 has
   // landed" (vmcnt(0) + barrier), which also says that everybody is done with tile t - 1, whose buffer the loads
   // of tile t + 2 then take.  So step 3 of tile t can already request step 0 of tile t + 1.
-  pu32x2 tl[2][2];      // [parity of the step][T1 / T2 entry]
+  pu32x2 tl[2][NC][2];  // [parity of the step][column block][T1 / T2 entry]
   pu32x4 Af[2][NB];
-  auto request = [&](uint32_t d, bool hi, uint32_t aj, pu32x2 (&tt)[2], pu32x4 (&A8)[NB]) {
-    uint32_t a1, a2;
-    if (hi) {
-      a1 = ((d >> 18) & 0x3fc0u) | lane_c1;      // entry row = 8 copies x 8 bytes
-      a2 = ((d >> 10) & 0x3fc0u) | lane_c2;
-    } else {
-      a1 = ((d >> 2) & 0x3fc0u) | lane_c1;
-      a2 = ((d << 6) & 0x3fc0u) | lane_c2;
+  auto request = [&](const pu32x2 (&cvt)[NC], int jj, uint32_t aj, pu32x2 (&tt)[NC][2], pu32x4 (&A8)[NB]) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const uint32_t d = jj < 2 ? cvt[c].x : cvt[c].y;
+      uint32_t a1, a2;
+      if (jj & 1) {
+        a1 = ((d >> 18) & 0x3fc0u) | lane_c1;      // entry row = 8 copies x 8 bytes
+        a2 = ((d >> 10) & 0x3fc0u) | lane_c2;
+      } else {
+        a1 = ((d >> 2) & 0x3fc0u) | lane_c1;
+        a2 = ((d << 6) & 0x3fc0u) | lane_c2;
+      }
+      asm volatile("ds_read_b64 %0, %1" : "=v"(tt[c][0]) : "v"(a1));
+      asm volatile("ds_read_b64 %0, %1" : "=v"(tt[c][1]) : "v"(a2));
     }
-    asm volatile("ds_read_b64 %0, %1" : "=v"(tt[0]) : "v"(a1));
-    asm volatile("ds_read_b64 %0, %1" : "=v"(tt[1]) : "v"(a2));
     asm volatile("ds_read_b128 %0, %1" : "=v"(A8[0]) : "v"(aj));
     asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(A8[1]) : "v"(aj));
-    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(A8[2]) : "v"(aj));
-    asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(A8[3]) : "v"(aj));
+    if constexpr (NB >= 4) {
+      asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(A8[2]) : "v"(aj));
+      asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(A8[3]) : "v"(aj));
+    }
     if constexpr (NB == 8) {
       asm volatile("ds_read_b128 %0, %1 offset:16384" : "=v"(A8[4]) : "v"(aj));
       asm volatile("ds_read_b128 %0, %1 offset:20480" : "=v"(A8[5]) : "v"(aj));
@@ -231,8 +262,17 @@ __global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __r
     if constexpr (NB == 8)
       asm volatile("s_waitcnt lgkmcnt(0)"
                    : "+v"(A8[0]), "+v"(A8[1]), "+v"(A8[2]), "+v"(A8[3]), "+v"(A8[4]), "+v"(A8[5]), "+v"(A8[6]), "+v"(A8[7]));
-    else
+    else if constexpr (NB == 4)
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A8[0]), "+v"(A8[1]), "+v"(A8[2]), "+v"(A8[3]));
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A8[0]), "+v"(A8[1]));
+  };
+  // the lookups of a request have landed (the NB fragment reads behind them may still be in flight)
+  auto looked_up = [&](pu32x2 (&tt)[NC][2]) {
+    if constexpr (NC == 1)
+      asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(tt[0][0]), "+v"(tt[0][1]) : "n"(NB));
+    else
+      asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(tt[0][0]), "+v"(tt[0][1]), "+v"(tt[1][0]), "+v"(tt[1][1]) : "n"(NB));
   };
   auto frag_b = [&](const pu32x2 (&tt)[2]) -> f16x8v {
     uint32_t w0, w1, w2, w3;
@@ -243,10 +283,12 @@ __global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __r
   // tiles 0 and 1 (and the tables) are in LDS; first step's operands
   take(cv[0], cq[0], std::integral_constant<int, 0>{});   // (everything requested so far has landed)
   __syncthreads();
-  request(cv[0].x, false, (uint32_t)kA + aoff[0], tl[0], Af[0]);
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tl[0][0]), "+v"(tl[0][1]));
+  request(cv[0], 0, (uint32_t)kA + aoff[0], tl[0], Af[0]);
+  looked_up(tl[0]);
   landed(Af[0]);
-  f16x8v B = frag_b(tl[0]);
+  f16x8v B[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) B[c] = frag_b(tl[0][c]);
 
   // one tile: `st` = t % 4 (its buffer / code register), compile-time through the 4x unrolled loop
   auto tile = [&](int t, auto stc) {
@@ -255,31 +297,47 @@ __global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __r
     const uint32_t abase = (uint32_t)(kA + st * kTileBytes);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int c = j & 1, nx = c ^ 1;
+      const int c2 = j & 1, nx = c2 ^ 1;
       // operands of the next step: step j + 1 of this tile, or step 0 of the next one
       if (j < 3)
-        request(j + 1 < 2 ? cv[cur].x : cv[cur].y, ((j + 1) & 1) != 0, abase + aoff[j + 1], tl[nx], Af[nx]);
+        request(cv[cur], j + 1, abase + aoff[j + 1], tl[nx], Af[nx]);
       else
-        request(cv[nxt].x, false, (uint32_t)(kA + st1 * kTileBytes) + aoff[0], tl[nx], Af[nx]);
+        request(cv[nxt], 0, (uint32_t)(kA + st1 * kTileBytes) + aoff[0], tl[nx], Af[nx]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int b = 0; b < NB / 2; ++b)
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, Af[c][b]), B, acc[b], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+          acc[c][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, Af[c2][b]), B[c], acc[c][b], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(tl[nx][0]), "+v"(tl[nx][1]) : "n"(NB));   // the two oldest of 2 + NB
-      const f16x8v Bn = frag_b(tl[nx]);
-      __builtin_amdgcn_sched_barrier(0);
+      looked_up(tl[nx]);   // the 2 NC oldest of 2 NC + NB
+      f16x8v Bn[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) Bn[c] = frag_b(tl[nx][c]);
+      if constexpr (!kInterleave) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int b = NB / 2; b < NB; ++b)
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, Af[c][b]), B, acc[b], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+          acc[c][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, Af[c2][b]), B[c], acc[c][b], 0, 0, 0);
+      if constexpr (kInterleave) {
+        // the next fragments' conversion (12 VALU instructions per code) between this half's MFMAs: one MFMA, then what
+        // fits under its 32 cycles
+#pragma unroll
+        for (int i = 0; i < NB / 2 * NC; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, (12 * NC + NB / 2 * NC - 1) / (NB / 2 * NC), 0);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
       landed(Af[nx]);
-      B = Bn;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) B[c] = Bn[c];
       if (j == 1) {
         // middle of the tile: tile t + 1 (requested in the middle of tile t - 2: two tile times ago) has landed
-        // everywhere -- the 5 operations of tile t + 2 may still be in flight; tile t - 1 is dead, its buffer takes
+        // everywhere -- the operations of tile t + 2 may still be in flight; tile t - 1 is dead, its buffer takes
         // tile t + 3 (past the end: tile KT - 1 again, harmless, keeps the code uniform)
-        take(cv[nxt], cq[st1], std::integral_constant<int, 1 + XL>{});
+        take(cv[nxt], cq[st1], std::integral_constant<int, NC + XL>{});
         __builtin_amdgcn_s_barrier();
         load_codes(cq[st3], min(t + 3, KT - 1));
         issue_x(min(t + 3, KT - 1), st3);
@@ -298,20 +356,23 @@ __global__ __launch_bounds__(512, 2) void e8p_prefill_gemm_kernel(const f16* __r
   // the even register's row, odd lanes the odd register's
   const bool odd = (lane & 1) != 0;
 #pragma unroll
-  for (int b = 0; b < NB; ++b) {
+  for (int c = 0; c < NC; ++c) {
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      const float mine = odd ? acc[b][r + 1] : acc[b][r];
-      const float give = odd ? acc[b][r] : acc[b][r + 1];
-      const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, true));
-      const int rr = odd ? r + 1 : r;
-      const int row = m0 + 32 * b + (rr & 3) + 8 * (rr >> 2) + 4 * kb;
-      const int col = ncol & ~1;
-      const uint32_t pk = odd ? pack_f16(got, mine) : pack_f16(mine, got);
-      if (row < M && col + 1 < N) {
-        *reinterpret_cast<uint32_t*>(Y + (size_t)row * N + col) = pk;
-      } else if (row < M && col < N) {
-        Y[(size_t)row * N + col] = odd ? (f16)got : (f16)mine;
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float mine = odd ? acc[c][b][r + 1] : acc[c][b][r];
+        const float give = odd ? acc[c][b][r] : acc[c][b][r + 1];
+        const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, true));
+        const int rr = odd ? r + 1 : r;
+        const int row = m0 + 32 * (NB * wm + b) + (rr & 3) + 8 * (rr >> 2) + 4 * kb;
+        const int col = ncol[c] & ~1;
+        const uint32_t pk = odd ? pack_f16(got, mine) : pack_f16(mine, got);
+        if (row < M && col + 1 < N) {
+          *reinterpret_cast<uint32_t*>(Y + (size_t)row * N + col) = pk;
+        } else if (row < M && col < N) {
+          Y[(size_t)row * N + col] = odd ? (f16)got : (f16)mine;
+        }
       }
     }
   }
@@ -330,20 +391,25 @@ int e8p_prefill_gemm_launch(const void* x, const void* qidxs, const void* grid, 
   // 128-row tiles while 256-row tiles would leave CUs without a workgroup (the K loop of a workgroup takes the same
   // time whatever the tile height: a second half-filled round costs less than idle CUs)
   static const int force = getenv("QUIP_PREFILL_TILE") ? atoi(getenv("QUIP_PREFILL_TILE")) : 0;   // 128 / 256: experiments
+  // wave layout (see the kernel): 0 = eight waves of 256 x 32, 1 = 2 x 4 waves of 128 x 64, 2 = four waves of 256 x 64
+  static const int layout = getenv("QUIP_PREFILL_LAYOUT") ? atoi(getenv("QUIP_PREFILL_LAYOUT")) : 0;   // measured: 0 is the fastest
   const bool half = force ? force == 128 : (m + kBM - 1) / kBM * NT < device_cu_count();
   const int bm = half ? kBM / 2 : kBM;
   const int MT = (int)((m + bm - 1) / bm);
   const int64_t blocks = MT >= 8 ? (int64_t)((MT + 7) / 8) * NT * 8 : (int64_t)MT * NT;
   if (blocks > 0x7fffffff) return QUIP_ERR_UNSUPPORTED;
-  auto go = [&](auto kern, DynLdsCache& configured) -> int {
-    if (ensure_dyn_lds(configured, reinterpret_cast<const void*>(kern), kLds) != QUIP_OK) return QUIP_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), kLds, stream, reinterpret_cast<const f16*>(x),
+  auto go = [&](auto kern, DynLdsCache& configured, int threads) -> int {
+    const int lds = lds_bytes(bm);
+    if (ensure_dyn_lds(configured, reinterpret_cast<const void*>(kern), lds) != QUIP_OK) return QUIP_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads), lds, stream, reinterpret_cast<const f16*>(x),
                        reinterpret_cast<const uint16_t*>(qidxs), reinterpret_cast<const uint64_t*>(grid),
                        reinterpret_cast<f16*>(y), (int)m, n, k, MT, NT);
     return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
   };
-  static DynLdsCache c8, c4;   // per device
-  return half ? go(e8p_prefill_gemm_kernel<4>, c4) : go(e8p_prefill_gemm_kernel<8>, c8);
+  static DynLdsCache c[6];   // per device
+  if (layout == 2) return half ? go(e8p_prefill_gemm_kernel<4, 2, 1, 4>, c[0], 256) : go(e8p_prefill_gemm_kernel<8, 2, 1, 4>, c[1], 256);
+  if (layout == 1) return half ? go(e8p_prefill_gemm_kernel<2, 2, 2, 4>, c[2], 512) : go(e8p_prefill_gemm_kernel<4, 2, 2, 4>, c[3], 512);
+  return half ? go(e8p_prefill_gemm_kernel<4, 1, 1, 8>, c[4], 512) : go(e8p_prefill_gemm_kernel<8, 1, 1, 8>, c[5], 512);
 }
 
 }  // namespace quip

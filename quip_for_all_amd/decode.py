@@ -420,7 +420,7 @@ class LlamaDecoder:
 
     def prefill(self, tokens):
         """Batched prompt pass (the reference demo's prefill, example_generate.py:36-47): all `tokens` (1-D ids) go
-        through every block at once -- QuantLinear on (P, hidden) rows (M >= 32: the fused dequant MFMA GEMM, fewer
+        through every block at once -- QuantLinear on (P, hidden) rows (M >= 32: skinny chunks or decompress + dense GEMM, fewer
         rows: the skinny paths), rotary embedding for positions 0..P-1, causal attention, K / V written to rows 0..P-1
         of the static cache -- and the position counter is left at P.  Returns the logits of the last token (1, vocab)."""
         s = self.s

@@ -44,7 +44,9 @@ def test_e8p12_regimes_by_row_count(fin, fout):
         assert layer.regime(m) == want, (m, layer.regime(m))
     for m in (32, 64, 256, 2048, 32768):
         assert layer.regime(m) == "codebook"
-        want = "skinny_chunks" if m * fout <= 1_800_000 else "fused_gemm"
+        # beyond the skinny regime the default is the reference's shape, decompress + vendor GEMM: faster than the fused
+        # kernel at every M on this part (profiles/r03_prefill_crossover.txt); QUIP_BATCHED_MM=fused selects the latter
+        want = "skinny_chunks" if m * fout <= 1_200_000 else "decompress_gemm"
         assert cb.batched_regime(m, fout, fin) == want, (m, cb.batched_regime(m, fout, fin))
 
 
