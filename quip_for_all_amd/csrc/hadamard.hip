@@ -568,7 +568,8 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2) void had_tall_batch
   const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
   const int ksteps = (K + 3) >> 2;
   const int BR = (K + 3) & ~3;                     // buffer rows: inputs k < K, outputs kp < BR (kp >= K are zero)
-  // H as the MFMA's A operand, A[row kq][k] at hs[k * KP + kq] (fp16 as stored), zero outside (K, K).  RT row tiles of
+  // H as the MFMA's A operand, A[row kq][k] at hs[kq * KP + k] (fp16 as stored; a lane's four k of a step are one 8-byte
+  // read), zero outside (K, K).  RT row tiles of
   // 16: 3 (K <= 48) or 11 (K <= 176: 11008 = 172 x 64 with the table factors of get_hadK(use_rand=False); 62 KB of H
   // next to the 45 KB row: one workgroup per CU)
   constexpr int KP = RT * 16;
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2) void had_tall_batch
   float* const gbuf = buf + half * RowF;
   f16* hs = reinterpret_cast<f16*>(buf + G * RowF);
   for (int i = threadIdx.x; i < KP * KP; i += G * nt) {
-    const int k = i / KP, kq = i - k * KP;
+    const int kq = i / KP, k = i - kq * KP;
     hs[i] = (kq < K && k < K) ? (a.transpose ? a.had[k * K + kq] : a.had[kq * K + k]) : (f16)0.f;
   }
   const int j0 = (tid * 16) & (L - 1);
@@ -703,38 +704,73 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2) void had_tall_batch
     //     k step one A read per row tile feeds all of them, and the 3 x tiles MFMAs of a step (>= 96 cycles of
     //     matrix-core time) cover the LDS latency of the next step's operands.
     if (valid) {
+      // v_mfma_f32_16x16x16_f16, k steps of 16: A = four consecutive k of a row of H (fp16 as stored), B = four rows of
+      // the staged columns as fp16.  Output side: the staged values ARE fp16 numbers (raw products, times 0 / 1), one MFMA
+      // per step; input side (x * pre, silu(gate) * x: fp32): hi + lo = the value to 22 bits, two MFMAs.  Products of two
+      // fp16 numbers are exact in the fp32 accumulator either way.  (The fp32 MFMA this replaces, 16x16x4, ran at the
+      // vector rate: 132 instructions of 32 cycles per row and wave at K = 43, against 36 / 72 of 16 here.  Results differ
+      // from the single-row kernel's fp32 K-mix in the order of the additions: tests/test_gpu_ops.py states the bound.)
+      typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
       f32x4 acc[tpw][RT];
 #pragma unroll
       for (int t = 0; t < tpw; ++t)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // operands of step ks + 1 are requested before the MFMAs of step ks (the loop is not unrolled by the compiler:
-      // left alone every step waits for its own LDS reads)
-      f16 ah[RT];
-      float bv[tpw];
-      auto operands = [&](int ks, f16 (&ah_)[RT], float (&bv_)[tpw]) {
-        const int k = min(4 * ks + lq, K - 1);
+      constexpr int ksteps16 = RT;                           // KP / 16
+      f16x4v ah[RT];
+      float bv[tpw][4];
+      auto operands = [&](int ks, f16x4v (&ah_)[RT], float (&bv_)[tpw][4]) {
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) ah_[rt] = hs[(4 * ks + lq) * KP + rt * 16 + lr];
+        for (int rt = 0; rt < RT; ++rt)
+          ah_[rt] = *reinterpret_cast<const f16x4v*>(hs + (rt * 16 + lr) * KP + 16 * ks + 4 * lq);
 #pragma unroll
-        for (int t = 0; t < tpw; ++t) bv_[t] = mixcol[k * RS + 66 * t];
+        for (int i = 0; i < 4; ++i) {
+          const int k = min(16 * ks + 4 * lq + i, K - 1);   // (rows past K: any finite value, their column of H is zero)
+#pragma unroll
+          for (int t = 0; t < tpw; ++t) bv_[t][i] = mixcol[k * RS + 66 * t];
+        }
       };
-      operands(0, ah, bv);
+      auto step = [&](const f16x4v (&ah_)[RT], const float (&bv_)[tpw][4]) {
+#pragma unroll
+        for (int t = 0; t < tpw; ++t) {
+          const auto h01 = __builtin_amdgcn_cvt_pkrtz(bv_[t][0], bv_[t][1]), h23 = __builtin_amdgcn_cvt_pkrtz(bv_[t][2], bv_[t][3]);
+          const f16x4v bh = __builtin_bit_cast(f16x4v, uint2{__builtin_bit_cast(uint32_t, h01), __builtin_bit_cast(uint32_t, h23)});
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah_[rt], bh, acc[t][rt], 0, 0, 0);
+          if (SIDE == 0) {
+            const auto l01 = __builtin_amdgcn_cvt_pkrtz(bv_[t][0] - (float)h01[0], bv_[t][1] - (float)h01[1]);
+            const auto l23 = __builtin_amdgcn_cvt_pkrtz(bv_[t][2] - (float)h23[0], bv_[t][3] - (float)h23[1]);
+            const f16x4v bl = __builtin_bit_cast(f16x4v, uint2{__builtin_bit_cast(uint32_t, l01), __builtin_bit_cast(uint32_t, l23)});
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah_[rt], bl, acc[t][rt], 0, 0, 0);
+          }
+        }
+      };
+      if constexpr (RT <= 3) {
+        // three steps, straight line: the scheduler overlaps a step's reads with the previous step's MFMAs, and the other
+        // workgroup of the CU covers the rest (operands a step ahead do not fit the registers at L = 256)
+#pragma unroll
+        for (int ks = 0; ks < ksteps16; ++ks) {
+          operands(ks, ah, bv);
+          step(ah, bv);
+        }
+      } else {
+        operands(0, ah, bv);
 #pragma unroll 1
-      for (int ks = 0; ks < ksteps; ++ks) {
-        f16 an[RT];
-        float bn[tpw];
-        operands(min(ks + 1, ksteps - 1), an, bn);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int ks = 0; ks < ksteps16; ++ks) {
+          f16x4v an[RT];
+          float bn[tpw][4];
+          operands(min(ks + 1, ksteps16 - 1), an, bn);
+          __builtin_amdgcn_sched_barrier(0);
+          step(ah, bv);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < tpw; ++t)
+          for (int rt = 0; rt < RT; ++rt) ah[rt] = an[rt];
 #pragma unroll
-          for (int rt = 0; rt < RT; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)ah[rt], bv[t], acc[t][rt], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int t = 0; t < tpw; ++t)
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) ah[rt] = an[rt];
-#pragma unroll
-        for (int t = 0; t < tpw; ++t) bv[t] = bn[t];
+            for (int i = 0; i < 4; ++i) bv[t][i] = bn[t][i];
+        }
       }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {

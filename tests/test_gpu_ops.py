@@ -431,12 +431,26 @@ def test_tall_hadamard_batches_with_table_factors(n, rows, side):
     test_tall_hadamard_batches_equal_single_rows(n, rows, side, use_rand=False)
 
 
+def _same_or_close(batch_row, single_row, what):
+    """the batch kernels that run the same operations as the single-row launch give the same bits; had_tall_batch_kernel
+    runs its K-mix on the fp16 matrix cores (hi + lo split, exact products, fp32 accumulation in another order than the
+    single-row kernel's fp32 MFMA): every element within one fp16 ulp of max(|y|, rms(y)), at most a few per cent differ"""
+    if torch.equal(batch_row, single_row):
+        return
+    a, b = batch_row.float(), single_row.float()
+    scale = torch.maximum(b.abs(), b.pow(2).mean().sqrt().expand_as(b))
+    ulp = torch.exp2(torch.floor(torch.log2(scale)) - 10)
+    assert torch.all((a - b).abs() <= ulp), (what, float(((a - b).abs() / ulp).max()))
+    assert float((a != b).float().mean()) < 0.06, (what, float((a != b).float().mean()))
+
+
 @pytest.mark.parametrize("n,rows", [(11008, 70), (2752, 33), (5504, 64), (11008, 600), (688 * 4, 40)])
 @pytest.mark.parametrize("side", ["in", "out", "both"])
 def test_tall_hadamard_batches_equal_single_rows(n, rows, side, use_rand=True):
-    """prefill batches of the tall transform (one workgroup per row, K-mix in place: had_tall_batch_kernel) give
-    bit for bit what the latency-shaped launch gives row by row; input side with gate / pre-scale, output side with
-    post-scale / bias / residual and a ragged out_features"""
+    """prefill batches of the tall transform (one workgroup per row, K-mix in place on the fp16 matrix cores:
+    had_tall_batch_kernel) against the latency-shaped launch row by row (_same_or_close), and a row's result does not
+    depend on the batch it is in; input side with gate / pre-scale, output side with post-scale / bias / residual and a
+    ragged out_features"""
     from quip_for_all_amd.quant import get_hadK
     torch.manual_seed(n + rows)
     had, K, qn = get_hadK(n, use_rand)
@@ -445,12 +459,15 @@ def test_tall_hadamard_batches_equal_single_rows(n, rows, side, use_rand=True):
     op = torch.ops.quip_lib
     x = torch.randn(rows, n, device=DEV).half()
     v1 = torch.randn(n, device=DEV).half()
+    sub = slice(min(rows // 4, rows - 32), min(rows // 4, rows - 32) + 32)      # 32 rows: still the batch kernel
     if side == "in":
         g = torch.randn(rows, n, device=DEV).half()
         full = op.had_transform_fused(x, n, n, K, hd, True, v1, None, None, None, 0.37, None, None, 1e-5, g)
         for r in (0, 1, rows // 2, rows - 1):
             one = op.had_transform_fused(x[r:r + 1], n, n, K, hd, True, v1, None, None, None, 0.37, None, None, 1e-5, g[r:r + 1])
-            assert torch.equal(full[r:r + 1], one), r
+            _same_or_close(full[r:r + 1], one, r)
+        part = op.had_transform_fused(x[sub].contiguous(), n, n, K, hd, True, v1, None, None, None, 0.37, None, None, 1e-5, g[sub].contiguous())
+        assert torch.equal(part, full[sub]), "a row's result does not depend on the batch it is in"
     elif side == "both":
         # vectors of both sides in one launch: not the batch kernel's case (it keeps one side's vectors in registers),
         # the launch takes the row-parallel kernel -- same bits
@@ -467,7 +484,9 @@ def test_tall_hadamard_batches_equal_single_rows(n, rows, side, use_rand=True):
         full = op.had_transform_fused(x, out_f, n, K, hd, False, None, None, post, bias, 0.11, res, None, 1e-5, None)
         for r in (0, 1, rows // 2, rows - 1):
             one = op.had_transform_fused(x[r:r + 1], out_f, n, K, hd, False, None, None, post, bias, 0.11, res[r:r + 1], None, 1e-5, None)
-            assert torch.equal(full[r:r + 1], one), r
+            _same_or_close(full[r:r + 1], one, r)
+        part = op.had_transform_fused(x[sub].contiguous(), out_f, n, K, hd, False, None, None, post, bias, 0.11, res[sub].contiguous(), None, 1e-5, None)
+        assert torch.equal(part, full[sub]), "a row's result does not depend on the batch it is in"
         assert full.shape == (rows, out_f)
 
 
