@@ -86,6 +86,17 @@ int quip_e8p_mm_origorder(const void* x, const void* qidxs /* int16 (n, k/8) */,
  * QUIP_ERR_UNSUPPORTED. */
 int quip_e8p_mm_skinny(const void* x, const void* qidxs /* int16 (n, k/8) */, const void* grid_packed_abs, void* y,
                        int32_t m, int32_t n, int32_t k, quip_stream_t stream);
+/* The same for E8P12RVQ4B (replaces the 1 < M < 32 use of tinygemm_m16n8k16_chunk_kernel<.., BLayout_E8RVQ4, ..>,
+ * origin_order.cu:337-385, 388-555; e8p12_rvq4.py:47-63): qidxs int32 (n, k/8), code = main << 16 | residual, weight =
+ * fma(resid_scale, w_residual, w_main) rounded once to fp16 -- exactly the dense W of quip_decompress_e8prvq4_origorder
+ * -- fp16 activations, fp32 accumulation.  Same shape rules. */
+int quip_e8prvq4_mm_skinny(const void* x, const void* qidxs /* int32 (n, k/8) */, const void* grid_packed_abs,
+                           float resid_scale, void* y, int32_t m, int32_t n, int32_t k, quip_stream_t stream);
+/* ... for D4 (BLayout_D4; d4.py:134-151): qidxs uint8 (n, k/4), grid_f16 = the fp16 (256, 4) table as the reference holds it;
+ * and for HI (BLayout_HI; hi.py:52-66): qidxs int32 (n, k/8), eight nibbles per code, w = nibble - 7.5. */
+int quip_d4_mm_skinny(const void* x, const void* qidxs, const void* grid_f16, void* y, int32_t m, int32_t n, int32_t k,
+                      quip_stream_t stream);
+int quip_hi_mm_skinny(const void* x, const void* qidxs, void* y, int32_t m, int32_t n, int32_t k, quip_stream_t stream);
 /* Batched E8P12 product for M >= 32 (prompt prefill): fused dequant + MFMA GEMM, y (m, n) = x (m, k) @ W^T with
  * W = decode(qidxs), fp16 in / fp32 accumulation / fp16 out -- the arithmetic of the reference's M >= 32 path
  * (e8p12.py:152-155: decompress_e8p_origorder + `x @ W.T`; origin_order.cu:837-885) without ever materialising W.

@@ -42,9 +42,40 @@ class _Codebook(nn.Module):
         W = self.decompress_weight(Qidxs)
         return input @ W.T
 
+    def batched_regime(self, m, n, k):
+        """the path forward() takes, as a name (tests/test_dispatch_table.py): mm | skinny_chunks | fused_gemm | decompress_gemm"""
+        return "mm" if m < self.mm_threshold else "decompress_gemm"
+
     def forward_reference(self, input, Qidxs):
         """the reference's own op sequence, whatever faster path exists: `*_mm_origorder` below the threshold,
         decompress + dense GEMM from it on (codebook/e8p12.py:139-156 and its siblings)"""
+        return _Codebook.forward(self, input, Qidxs)
+
+
+class _SkinnyMixin:
+    """2 <= M < 32 beyond one exact rows-mode pass, and M >= mm_threshold up to a few hundred rows: the single-pass fp16
+    skinny kernel in the codebook's mode (csrc/e8p_skinny_gemm.hip) -- the reference's arithmetic for this regime
+    (origin_order.cu:388-555 with the codebook's BLayout: exact fp16 weights, fp32 accumulation), i.e. x . W of the dense W
+    that decompress_weight() writes.  Subclasses give mm_skinny() and the m * n up to which chunks of 32 rows beat
+    decompress + dense GEMM."""
+    skinny_chunks_max_mn = int(os.environ.get("QUIP_SKINNY_MAX_MN", str(1_200_000)))
+
+    @staticmethod
+    def skinny_supported(m, q_out, q_in):
+        return 1 <= m and q_out >= 2 and q_out % 2 == 0 and q_in >= 128 and q_in % 128 == 0
+
+    def batched_regime(self, m, n, k):
+        if m < self.mm_threshold:
+            return "mm"
+        if (E8P12_codebook.batched_mode != "reference" and m * n <= self.skinny_chunks_max_mn
+                and self.skinny_supported(m, n, k)):
+            return "skinny_chunks"
+        return "decompress_gemm"
+
+    def forward(self, input, Qidxs):
+        if (input.size(0) >= self.mm_threshold and input.is_cuda and input.dtype == torch.float16 and input.dim() == 2
+                and self.batched_regime(input.shape[0], Qidxs.shape[0], input.shape[1]) == "skinny_chunks"):
+            return self.mm_skinny(input, Qidxs)
         return _Codebook.forward(self, input, Qidxs)
 
 
@@ -160,7 +191,7 @@ class E8P12_codebook(_Codebook):
         return torch.ops.quip_lib.e8p_mm_skinny(xh, Qidxs, self.grid_packed_abs)
 
 
-class E8P12RVQ4B_codebook(_Codebook):
+class E8P12RVQ4B_codebook(_SkinnyMixin, _Codebook):
     def __init__(self, inference=False, opt_resid_scale=None, **kwargs):
         super().__init__()
         self.id = "E8P12RVQ4B"
@@ -220,6 +251,11 @@ class E8P12RVQ4B_codebook(_Codebook):
 
     def mm_planes_rows(self, planes, Qidxs):
         return torch.ops.quip_lib.e8p_gemv_planes_rows(planes, Qidxs.view(torch.int16), self.grid_packed_abs)
+
+    skinny_chunks_max_mn = _SkinnyMixin.skinny_chunks_max_mn // 2     # (twice the code bytes per weight)
+
+    def mm_skinny(self, xh, Qidxs):
+        return torch.ops.quip_lib.e8prvq4_mm_skinny(xh, Qidxs, self.grid_packed_abs, self.opt_resid_scale)
 
 
 class E8P12RVQ3B_codebook(_Codebook):
@@ -296,7 +332,7 @@ class E8P12RVQ3B_codebook(_Codebook):
             input, Qidxs, self.grid_packed_abs, self.e81b_grid_packed, self.opt_resid_scale)
 
 
-class D4_codebook(_Codebook):
+class D4_codebook(_SkinnyMixin, _Codebook):
     mm_threshold = 24  # d4.py:134
 
     def __init__(self, inference=False, **kwargs):
@@ -342,8 +378,11 @@ class D4_codebook(_Codebook):
     def mm_planes_rows(self, planes, Qidxs):
         return torch.ops.quip_lib.gemv_planes_rows_mode(planes, Qidxs, self.grid, None, 64)
 
+    def mm_skinny(self, xh, Qidxs):
+        return torch.ops.quip_lib.d4_mm_skinny(xh, Qidxs, self.grid)
 
-class HI4B1C_codebook(_Codebook):
+
+class HI4B1C_codebook(_SkinnyMixin, _Codebook):
     def __init__(self, inference=False, **kwargs):
         super().__init__()
         self.id = "HI"
@@ -404,6 +443,11 @@ class HI4B1C_codebook(_Codebook):
         for i, col in enumerate(tables.HI_NIBBLE_COLS):
             out = out + (idxs[:, col::8] << (4 * i))
         return out
+
+    skinny_chunks_max_mn = _SkinnyMixin.skinny_chunks_max_mn // 2     # (twice the code bytes per weight)
+
+    def mm_skinny(self, xh, Qidxs):
+        return torch.ops.quip_lib.hi_mm_skinny(xh, Qidxs)
 
     def decompress_weight(self, Qidxs):
         return torch.ops.quip_lib.decompress_hi_origorder(Qidxs)

@@ -531,6 +531,34 @@ int quip_e8p_mm_skinny(const void* x, const void* qidxs, const void* grid, void*
   return e8p_skinny_gemm_launch(x, qidxs, grid, y, m, n, k, (hipStream_t)stream);
 }
 
+int quip_e8prvq4_mm_skinny(const void* x, const void* qidxs, const void* grid, float resid_scale, void* y, int32_t m,
+                           int32_t n, int32_t k, quip_stream_t stream) {
+  if (!x || !qidxs || !grid || !y) return QUIP_ERR_NULL_POINTER;
+  if (m < 0 || n < 1 || k < 8) return QUIP_ERR_BAD_SHAPE;
+  if (m == 0) return QUIP_OK;
+  if (!aligned16(x) || !aligned16(qidxs) || (reinterpret_cast<uintptr_t>(y) & 3u) || (reinterpret_cast<uintptr_t>(grid) & 7u))
+    return QUIP_ERR_MISALIGNED;
+  return e8prvq4_skinny_gemm_launch(x, qidxs, grid, resid_scale, y, m, n, k, (hipStream_t)stream);
+}
+
+int quip_d4_mm_skinny(const void* x, const void* qidxs, const void* grid_f16, void* y, int32_t m, int32_t n, int32_t k,
+                      quip_stream_t stream) {
+  if (!x || !qidxs || !grid_f16 || !y) return QUIP_ERR_NULL_POINTER;
+  if (m < 0 || n < 1 || k < 8) return QUIP_ERR_BAD_SHAPE;
+  if (m == 0) return QUIP_OK;
+  if (!aligned16(x) || !aligned16(qidxs) || (reinterpret_cast<uintptr_t>(y) & 3u) || (reinterpret_cast<uintptr_t>(grid_f16) & 7u))
+    return QUIP_ERR_MISALIGNED;
+  return d4_skinny_gemm_launch(x, qidxs, grid_f16, y, m, n, k, (hipStream_t)stream);
+}
+
+int quip_hi_mm_skinny(const void* x, const void* qidxs, void* y, int32_t m, int32_t n, int32_t k, quip_stream_t stream) {
+  if (!x || !qidxs || !y) return QUIP_ERR_NULL_POINTER;
+  if (m < 0 || n < 1 || k < 8) return QUIP_ERR_BAD_SHAPE;
+  if (m == 0) return QUIP_OK;
+  if (!aligned16(x) || !aligned16(qidxs) || (reinterpret_cast<uintptr_t>(y) & 3u)) return QUIP_ERR_MISALIGNED;
+  return hi_skinny_gemm_launch(x, qidxs, y, m, n, k, (hipStream_t)stream);
+}
+
 int quip_e8p_mm_batched(const void* x, const void* qidxs, const void* grid, void* y, int64_t m, int32_t n, int32_t k,
                         quip_stream_t stream) {
   if (!x || !qidxs || !grid || !y) return QUIP_ERR_NULL_POINTER;

@@ -36,6 +36,15 @@
 // the counts constant.  The K slices are added in a fixed order through LDS (every wave reduces a share of the
 // tile), so the result does not depend on scheduling.
 // Bound: LDS / L2 issue (codes N K / 4 bytes once from HBM; activations M K 2 bytes per 32 columns from L2).
+//
+// MODE 1 = E8P12RVQ4B (e8p12_rvq4.py:37-45; origin_order.cu:337-385): a code is 32 bits, main << 16 | residual, both E8P12
+// codes; the weight is fma(s, w_resid, w_main) in packed fp16 -- ONE fp16 rounding per weight, exactly what
+// decompress_e8prvq4_origorder writes (quip_device.hip.h: rvq_combine), so the product is x . W of the reference's dense W.
+// Per lane and unit two 16-byte loads (eight 4-byte codes), four table lookups and four v_pk_fma_f16 per MFMA.
+// MODE 2 = D4 (d4.py:26-96; origin_order.cu BLayout_D4): two one-byte codes per 8 weights -- the data movement of MODE 0 --
+// and the table holds the fp16 entries themselves: a B fragment is two 8-byte lookups, no arithmetic.
+// MODE 3 = HI (hi.py:41-50; origin_order.cu:1028-1051): eight nibbles per 8 weights -- the data movement of MODE 1 --,
+// w = nibble - 7.5 through the 0x4c00 | n << 6 = 16 + n identity and one packed subtraction; no table.
 #include "quip_device.hip.h"
 #include "quip_internal.h"
 #include <type_traits>
@@ -93,11 +102,12 @@ __device__ __forceinline__ void s_bytes_to_f16x4(uint32_t u4, uint32_t& lo, uint
 constexpr int kSDepth = 3;   // granules in flight per wave
 
 // CB column blocks of 32 per workgroup, 16 / CB slices of K (16 waves); MP = activation rows staged (16 or 32)
-template <int CB, int MP>
+template <int CB, int MP, int MODE = 0>
 __global__ __launch_bounds__(1024) void e8p_skinny_gemm_kernel(const f16* __restrict__ X,
                                                                const uint16_t* __restrict__ Wc,
                                                                const uint64_t* __restrict__ grid,
-                                                               f16* __restrict__ Y, int M, int N, int K) {
+                                                               f16* __restrict__ Y, int M, int N, int K, float resid_scale) {
+  constexpr int NCL = (MODE == 1 || MODE == 3) ? 2 : 1;     // 16-byte code loads per lane and unit
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // more than 32 rows: grid.y walks over chunks of 32 rows (each workgroup streams its columns' codes again; the
   // chunks of one column block run side by side and share them in L2)
@@ -119,10 +129,13 @@ __global__ __launch_bounds__(1024) void e8p_skinny_gemm_kernel(const f16* __rest
   const int ulast = max(un - 1, 0), qlast = max(4 * un - 1, 0);
 
   // (a wave without units -- K < 2048 -- still issues the loads of the prologue: inside its row)
-  const uint4* wsrc =
-      reinterpret_cast<const uint4*>(Wc + (size_t)min(ncol, N - 1) * (K >> 3)) + 2 * min(u0, units - 1) + kb;
-  auto load_codes = [&](su32x4& dst, int u) {
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(wsrc + 2 * u) : "memory");
+  // a unit's 16 codes of a column: 32 bytes (MODE 0), 64 bytes (MODE 1); lane kb takes the half with blocks 8 kb .. 8 kb + 7
+  const uint4* wsrc = reinterpret_cast<const uint4*>(Wc + (size_t)min(ncol, N - 1) * (K >> 3) * NCL) +
+                      2 * NCL * min(u0, units - 1) + kb * NCL;
+  auto load_codes = [&](su32x4 (&dst)[NCL], int u) {
+#pragma unroll
+    for (int c = 0; c < NCL; ++c)
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[c]) : "v"(wsrc + 2 * NCL * u + c) : "memory");
   };
   // granule loader: instruction h fills LDS slots [64 h, 64 h + 64) of the granule; slot s = (row s >> 2, stored
   // piece s & 3) holds source piece (s & 3) ^ ((row >> 1) & 3) of that row's 64 bytes
@@ -149,32 +162,34 @@ __global__ __launch_bounds__(1024) void e8p_skinny_gemm_kernel(const f16* __rest
   const int e = (wave & 7) * 32 + (lane & 31);
   su32x2 rawv;
   {
-    const uint2* tsrc = second ? &kST2Img.v[e] : reinterpret_cast<const uint2*>(grid) + e;
+    const uint2* tsrc = (second || MODE == 3) ? &kST2Img.v[e] : reinterpret_cast<const uint2*>(grid) + e;   // (HI: no table, `grid` is not read)
     asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rawv) : "v"(tsrc) : "memory");
   }
   // A register that a load is still going to write must never be a TIED asm operand ("+v") or cross a loop edge:
   // for either the compiler may emit a copy of it -- before the wait.  Loaded values are taken over by an asm that
   // waits and then moves them into fresh registers; only those are used afterwards.  (tools/check_inflight.py walks
   // the ISA for exactly this; tests/test_build_invariants.py runs it.)
-  su32x4 f0, f1, c2;
+  su32x4 f0[NCL], f1[NCL], c2[NCL];
   load_codes(f0, 0);
   load_codes(f1, min(1, ulast));
-  auto take = [](su32x4& dst, const su32x4& src, auto nw) {
-    asm volatile("s_waitcnt vmcnt(%8)\n\tv_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
-                 : "=&v"(dst.x), "=&v"(dst.y), "=&v"(dst.z), "=&v"(dst.w)
-                 : "v"(src.x), "v"(src.y), "v"(src.z), "v"(src.w), "n"(decltype(nw)::value)
-                 : "memory");
+  auto take = [](su32x4 (&dst)[NCL], const su32x4 (&src)[NCL], auto nw) {
+#pragma unroll
+    for (int c = 0; c < NCL; ++c)
+      asm volatile("s_waitcnt vmcnt(%8)\n\tv_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                   : "=&v"(dst[c].x), "=&v"(dst[c].y), "=&v"(dst[c].z), "=&v"(dst[c].w)
+                   : "v"(src[c].x), "v"(src[c].y), "v"(src[c].z), "v"(src[c].w), "n"(decltype(nw)::value)
+                   : "memory");
   };
   // tables: T1' = (4a | 1) ^ 0x80.., T2 = sign masks; 16 copies each (waves 0..7)
   uint2 raw;
-  asm volatile("s_waitcnt vmcnt(2)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
+  asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
                : "=&v"(raw.x), "=&v"(raw.y)
-               : "v"(rawv.x), "v"(rawv.y)
+               : "v"(rawv.x), "v"(rawv.y), "n"(2 * NCL)
                : "memory");
   if (wave < 8) {
     const uint32_t t1x = (__builtin_amdgcn_perm(0u, raw.x, 0x03010200u) | 0x01010101u) ^ 0x80808080u;
     const uint32_t t1y = (__builtin_amdgcn_perm(0u, raw.y, 0x03010200u) | 0x01010101u) ^ 0x80808080u;
-    const su32x2 val = {second ? raw.x : t1x, second ? raw.y : t1y};
+    const su32x2 val = {(second || MODE == 2) ? raw.x : t1x, (second || MODE == 2) ? raw.y : t1y};   // (D4: the fp16 entries as they are)
     const uint32_t rowbase = (second ? (uint32_t)kST2 : (uint32_t)kST1) + (uint32_t)e * (kSRep * 8);
 #pragma unroll
     for (int c = 0; c < kSRep; ++c) {
@@ -189,7 +204,7 @@ __global__ __launch_bounds__(1024) void e8p_skinny_gemm_kernel(const f16* __rest
   __builtin_amdgcn_sched_barrier(0);
   using std::integral_constant;
   // the codes of units 0 and 1 have arrived (the granules were requested after them); tables written
-  su32x4 c0, c1;
+  su32x4 c0[NCL], c1[NCL];
   take(c0, f0, integral_constant<int, kSDepth * L>{});
   take(c1, f1, integral_constant<int, kSDepth * L>{});
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -233,34 +248,142 @@ __global__ __launch_bounds__(1024) void e8p_skinny_gemm_kernel(const f16* __rest
                                                  __builtin_bit_cast(sf16x8, su32x4{w0, w1, w2, w3}), acc, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   };
+  // MODE 1: two 32-bit codes (main << 16 | residual) of this lane's two MFMAs
+  const f16 rs16 = (f16)resid_scale;
+  const f16x2 rs2 = {rs16, rs16};
+  auto granule_rvq = [&](uint32_t dA, uint32_t dB, uint32_t boff, auto nw) {
+    constexpr int NW = decltype(nw)::value;
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NW) : "memory");
+    su32x4 A0, A1;
+    su32x2 t[8];
+    auto addr = [&](uint32_t d, uint32_t (&a)[4]) {
+      a[0] = ((d >> 17) & 0x7f80u) | lane_c1;     // main (high half): abs index, sign byte
+      a[1] = ((d >> 9) & 0x7f80u) | lane_c2;
+      a[2] = ((d >> 1) & 0x7f80u) | lane_c1;      // residual (low half)
+      a[3] = ((d << 7) & 0x7f80u) | lane_c2;
+    };
+    uint32_t aa[4], ab[4];
+    addr(dA, aa);
+    addr(dB, ab);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("ds_read_b64 %0, %1" : "=v"(t[i]) : "v"(aa[i]));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(A0) : "v"(rd0 + boff));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("ds_read_b64 %0, %1" : "=v"(t[4 + i]) : "v"(ab[i]));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(A1) : "v"(rd1 + boff));
+    auto weights = [&](const su32x2& m1, const su32x2& m2, const su32x2& r1, const su32x2& r2) -> su32x4 {
+      uint32_t m[4], r[4], w[4];
+      s_bytes_to_f16x4(m1.x ^ m2.x, m[0], m[1]);
+      s_bytes_to_f16x4(m1.y ^ m2.y, m[2], m[3]);
+      s_bytes_to_f16x4(r1.x ^ r2.x, r[0], r[1]);
+      s_bytes_to_f16x4(r1.y ^ r2.y, r[2], r[3]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w[i] = as_u32(__builtin_elementwise_fma(rs2, as_f16x2(r[i]), as_f16x2(m[i])));
+      return su32x4{w[0], w[1], w[2], w[3]};
+    };
+    asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(A0));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sf16x8, A0),
+                                                 __builtin_bit_cast(sf16x8, weights(t[0], t[1], t[2], t[3])), acc, 0, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]), "+v"(A1));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sf16x8, A1),
+                                                 __builtin_bit_cast(sf16x8, weights(t[4], t[5], t[6], t[7])), acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // MODE 2: dword d = the four D4 code bytes of this lane's two MFMAs (two per MFMA: weights 0..3, 4..7 of the block)
+  auto granule_d4 = [&](uint32_t d, uint32_t boff, auto nw) {
+    constexpr int NW = decltype(nw)::value;
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NW) : "memory");
+    su32x4 A0, A1;
+    su32x2 t[4];
+    const uint32_t a0 = ((d << 7) & 0x7f80u) | lane_c1, a1 = ((d >> 1) & 0x7f80u) | lane_c1;
+    const uint32_t a2 = ((d >> 9) & 0x7f80u) | lane_c1, a3 = ((d >> 17) & 0x7f80u) | lane_c1;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(t[0]) : "v"(a0));
+    asm volatile("ds_read_b64 %0, %1" : "=v"(t[1]) : "v"(a1));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(A0) : "v"(rd0 + boff));
+    asm volatile("ds_read_b64 %0, %1" : "=v"(t[2]) : "v"(a2));
+    asm volatile("ds_read_b64 %0, %1" : "=v"(t[3]) : "v"(a3));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(A1) : "v"(rd1 + boff));
+    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(t[0]), "+v"(t[1]), "+v"(A0));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sf16x8, A0),
+                                                 __builtin_bit_cast(sf16x8, su32x4{t[0].x, t[0].y, t[1].x, t[1].y}), acc, 0, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[2]), "+v"(t[3]), "+v"(A1));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sf16x8, A1),
+                                                 __builtin_bit_cast(sf16x8, su32x4{t[2].x, t[2].y, t[3].x, t[3].y}), acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // MODE 3: two 32-bit HI codes; nibble i of a code is column [0,2,4,6,1,3,5,7][i] of its 8-group, i.e. the fp16 pair d of
+  // the fragment is (nibble d, nibble d + 4) (quip_device.hip.h: hi_decode_f16)
+  auto granule_hi = [&](uint32_t dA, uint32_t dB, uint32_t boff, auto nw) {
+    constexpr int NW = decltype(nw)::value;
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NW) : "memory");
+    su32x4 A0, A1;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(A0) : "v"(rd0 + boff));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(A1) : "v"(rd1 + boff));
+    auto weights = [&](uint32_t c) -> su32x4 {
+      // 0x4c00 | n << 6 is the fp16 number 16 + n (the mantissa bit of weight 1.0 at exponent 4); 23.5 is a fp16 number too,
+      // so the subtraction is exact (1024 + n would not do: 1031.5 is not representable)
+      const f16x2 off = {(f16)-23.5f, (f16)-23.5f};
+      const uint32_t sh[4] = {c << 6, c << 2, c >> 2, c >> 6};
+      uint32_t w[4];
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd) w[dd] = as_u32(as_f16x2((sh[dd] & 0x03c003c0u) | 0x4c004c00u) + off);
+      return su32x4{w[0], w[1], w[2], w[3]};
+    };
+    const su32x4 B0 = weights(dA), B1 = weights(dB);
+    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(A0));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sf16x8, A0), __builtin_bit_cast(sf16x8, B0), acc, 0, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A1));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sf16x8, A1), __builtin_bit_cast(sf16x8, B1), acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
   int rb = 0;                                   // ring buffer of the current granule
   auto next_rb = [&]() { rb = rb == kSDepth - 1 ? 0 : rb + 1; };
   for (int u = 0; u < un; ++u) {
-    // the kb halves trade code pairs: afterwards c0.x / .z / .y / .w serve granules 0 / 1 / 2 / 3
+    // the kb halves trade code pairs: afterwards c0.x / .z / .y / .w serve granules 0 / 1 / 2 / 3 (MODE 1: the dword
+    // pairs (c0[0].x, .y) / (c0[1].x, .y) / (c0[0].z, .w) / (c0[1].z, .w))
     // (builtin, not asm: v_permlane32_swap has wait-state requirements against neighbouring VALU instructions that
     //  only the compiler's hazard recogniser keeps track of)
-    const auto s01 = __builtin_amdgcn_permlane32_swap(c0.x, c0.y, false, false);
-    const auto s23 = __builtin_amdgcn_permlane32_swap(c0.z, c0.w, false, false);
-    c0 = su32x4{s01[0], s01[1], s23[0], s23[1]};
-    granule(c0.x, (uint32_t)(rb * kGran), integral_constant<int, 2 * L>{});
+    uint32_t gA[4], gB[4];      // per granule: the code dword(s) of this lane
+    if constexpr (MODE == 0 || MODE == 2) {
+      const auto s01 = __builtin_amdgcn_permlane32_swap(c0[0].x, c0[0].y, false, false);
+      const auto s23 = __builtin_amdgcn_permlane32_swap(c0[0].z, c0[0].w, false, false);
+      gA[0] = s01[0]; gA[2] = s01[1]; gA[1] = s23[0]; gA[3] = s23[1];
+      gB[0] = gB[1] = gB[2] = gB[3] = 0u;
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const auto sx = __builtin_amdgcn_permlane32_swap(c0[h].x, c0[h].z, false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap(c0[h].y, c0[h].w, false, false);
+        gA[h] = sx[0]; gB[h] = sy[0];           // granule h: blocks 4 h + 2 kb, + 1
+        gA[2 + h] = sx[1]; gB[2 + h] = sy[1];   // granule 2 + h
+      }
+    }
+    auto gran = [&](int i, auto nw) {
+      if constexpr (MODE == 0) granule(gA[i], (uint32_t)(rb * kGran), nw);
+      else if constexpr (MODE == 1) granule_rvq(gA[i], gB[i], (uint32_t)(rb * kGran), nw);
+      else if constexpr (MODE == 2) granule_d4(gA[i], (uint32_t)(rb * kGran), nw);
+      else granule_hi(gA[i], gB[i], (uint32_t)(rb * kGran), nw);
+    };
+    gran(0, integral_constant<int, 2 * L>{});
     load_codes(c2, min(u + 2, ulast));
     issue_x(min(4 * u + 3, qlast), rb);
     __builtin_amdgcn_sched_barrier(0);
     next_rb();
-    granule(c0.z, (uint32_t)(rb * kGran), integral_constant<int, 2 * L + 1>{});
+    gran(1, integral_constant<int, 2 * L + NCL>{});
     issue_x(min(4 * u + 4, qlast), rb);
     __builtin_amdgcn_sched_barrier(0);
     next_rb();
-    granule(c0.y, (uint32_t)(rb * kGran), integral_constant<int, 2 * L + 1>{});
+    gran(2, integral_constant<int, 2 * L + NCL>{});
     issue_x(min(4 * u + 5, qlast), rb);
     __builtin_amdgcn_sched_barrier(0);
     next_rb();
-    granule(c0.w, (uint32_t)(rb * kGran), integral_constant<int, 2 * L>{});
+    gran(3, integral_constant<int, 2 * L>{});
     issue_x(min(4 * u + 6, qlast), rb);
     __builtin_amdgcn_sched_barrier(0);
     next_rb();
     // the codes of unit u + 2 were requested before granule 4u + 3, which has just been waited for
-    c0 = c1;
+#pragma unroll
+    for (int c = 0; c < NCL; ++c) c0[c] = c1[c];
     take(c1, c2, integral_constant<int, kSDepth * L>{});
   }
   // the trailing filler granules must have landed before the ring is reused for the reduction
@@ -294,8 +417,10 @@ bool e8p_skinny_gemm_supported(int m, int n, int k) {
   return m >= 1 && m <= 32 * 65535 && n >= 2 && n % 2 == 0 && k >= 128 && k % 128 == 0;
 }
 
-int e8p_skinny_gemm_launch(const void* x, const void* qidxs, const void* grid, void* y, int m, int n, int k,
-                           hipStream_t stream) {
+// mode 0: E8P12 (16-bit codes), 1: E8P12RVQ4B (32-bit codes, resid_scale = the fp16 residual scale), 2: D4 (grid = the fp16
+// (256, 4) table), 3: HI (no table)
+static int skinny_launch_mode(int mode, const void* x, const void* qidxs, const void* grid, float resid_scale, void* y, int m,
+                              int n, int k, hipStream_t stream) {
   if (!e8p_skinny_gemm_supported(m, n, k)) return QUIP_ERR_UNSUPPORTED;
   // few columns: one column block of 32 per workgroup and 16 slices of K (more workgroups, shorter chains per wave);
   // many columns: two column blocks x 8 slices
@@ -303,16 +428,46 @@ int e8p_skinny_gemm_launch(const void* x, const void* qidxs, const void* grid, v
   //  how many rows the launch has)
   const bool one = (n + 63) / 64 < 2 * device_cu_count() / 3;
   auto go = [&](auto kern, int cols, int slot) -> int {
-    static DynLdsCache configured[4];   // per instantiation, per device
+    static DynLdsCache configured[16];   // per instantiation, per device
     if (ensure_dyn_lds(configured[slot], reinterpret_cast<const void*>(kern), kSLds) != QUIP_OK) return QUIP_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3((n + cols - 1) / cols, (m + 31) / 32), dim3(1024), kSLds, stream,
                        reinterpret_cast<const f16*>(x),
                        reinterpret_cast<const uint16_t*>(qidxs), reinterpret_cast<const uint64_t*>(grid),
-                       reinterpret_cast<f16*>(y), m, n, k);
+                       reinterpret_cast<f16*>(y), m, n, k, resid_scale);
     return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
   };
+  if (mode == 1) {
+    if (m <= 16) return one ? go(e8p_skinny_gemm_kernel<1, 16, 1>, 32, 4) : go(e8p_skinny_gemm_kernel<2, 16, 1>, 64, 5);
+    return one ? go(e8p_skinny_gemm_kernel<1, 32, 1>, 32, 6) : go(e8p_skinny_gemm_kernel<2, 32, 1>, 64, 7);
+  }
+  if (mode == 2) {
+    if (m <= 16) return one ? go(e8p_skinny_gemm_kernel<1, 16, 2>, 32, 8) : go(e8p_skinny_gemm_kernel<2, 16, 2>, 64, 9);
+    return one ? go(e8p_skinny_gemm_kernel<1, 32, 2>, 32, 10) : go(e8p_skinny_gemm_kernel<2, 32, 2>, 64, 11);
+  }
+  if (mode == 3) {
+    if (m <= 16) return one ? go(e8p_skinny_gemm_kernel<1, 16, 3>, 32, 12) : go(e8p_skinny_gemm_kernel<2, 16, 3>, 64, 13);
+    return one ? go(e8p_skinny_gemm_kernel<1, 32, 3>, 32, 14) : go(e8p_skinny_gemm_kernel<2, 32, 3>, 64, 15);
+  }
   if (m <= 16) return one ? go(e8p_skinny_gemm_kernel<1, 16>, 32, 0) : go(e8p_skinny_gemm_kernel<2, 16>, 64, 1);
   return one ? go(e8p_skinny_gemm_kernel<1, 32>, 32, 2) : go(e8p_skinny_gemm_kernel<2, 32>, 64, 3);
+}
+
+int e8p_skinny_gemm_launch(const void* x, const void* qidxs, const void* grid, void* y, int m, int n, int k,
+                           hipStream_t stream) {
+  return skinny_launch_mode(0, x, qidxs, grid, 0.f, y, m, n, k, stream);
+}
+
+int e8prvq4_skinny_gemm_launch(const void* x, const void* qidxs, const void* grid, float resid_scale, void* y, int m, int n,
+                               int k, hipStream_t stream) {
+  return skinny_launch_mode(1, x, qidxs, grid, resid_scale, y, m, n, k, stream);
+}
+
+int d4_skinny_gemm_launch(const void* x, const void* qidxs, const void* grid_f16, void* y, int m, int n, int k, hipStream_t stream) {
+  return skinny_launch_mode(2, x, qidxs, grid_f16, 0.f, y, m, n, k, stream);
+}
+
+int hi_skinny_gemm_launch(const void* x, const void* qidxs, void* y, int m, int n, int k, hipStream_t stream) {
+  return skinny_launch_mode(3, x, qidxs, nullptr, 0.f, y, m, n, k, stream);
 }
 
 }  // namespace quip

@@ -135,6 +135,12 @@ int e8p_prefill_gemm_launch(const void* x, const void* qidxs, const void* grid, 
 bool e8p_skinny_gemm_supported(int m, int n, int k);
 int e8p_skinny_gemm_launch(const void* x, const void* qidxs, const void* grid, void* y, int m, int n, int k,
                            hipStream_t stream);
+// the same for E8P12RVQ4B: 32-bit codes (main << 16 | residual), weight = fma(resid_scale, w_resid, w_main) in fp16
+int e8prvq4_skinny_gemm_launch(const void* x, const void* qidxs, const void* grid, float resid_scale, void* y, int m, int n,
+                               int k, hipStream_t stream);
+// D4: one-byte codes (n, k/4), grid = the fp16 (256, 4) table; HI: 32-bit codes of eight nibbles (n, k/8)
+int d4_skinny_gemm_launch(const void* x, const void* qidxs, const void* grid_f16, void* y, int m, int n, int k, hipStream_t stream);
+int hi_skinny_gemm_launch(const void* x, const void* qidxs, void* y, int m, int n, int k, hipStream_t stream);
 // bf16 / fp32 (and plain fp16) Walsh-Hadamard transform of the last dimension (hadamard_generic.hip)
 int hadamard_generic_launch(const void* x, void* y, int64_t rows, int n, float scale, int dtype, hipStream_t stream);
 int had_transform_launch(const void* x, void* y, int64_t rows, int in_features, int out_features,

@@ -98,7 +98,10 @@ class QuantLinear(nn.Module):
         cb = self.codebook
         if self.reference_ops:
             return "reference_ops"
-        planes_ok = hasattr(cb, "mm_planes") and cb.planes_supported(self.q_out_features, self.q_in_features)
+        L_in = self.q_in_features // self.K_left
+        # (the transform that writes digit planes is the register-blocked one: L >= 256, or K > 1 and L >= 64 -- hadamard.hip)
+        planes_ok = (hasattr(cb, "mm_planes") and cb.planes_supported(self.q_out_features, self.q_in_features)
+                     and (L_in >= 256 or (self.K_left > 1 and L_in >= 64)))
         if M == 1 and planes_ok:
             return "gemv_planes"
         if (2 <= M <= self.skinny_max_rows and not self.skinny_exact and hasattr(cb, "mm_skinny")

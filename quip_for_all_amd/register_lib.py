@@ -52,6 +52,10 @@ _SCHEMAS = {
     "e8p_mm_batched": "(Tensor x, Tensor Qidxs, Tensor grid) -> Tensor",
     # 2 <= M <= 32 rows in one pass over the codes, fp16 MFMA (csrc/e8p_skinny_gemm.hip)
     "e8p_mm_skinny": "(Tensor x, Tensor Qidxs, Tensor grid) -> Tensor",
+    # the same for E8P12RVQ4B: int32 codes (main << 16 | residual), weights = fp16 fma(scale, residual, main)
+    "e8prvq4_mm_skinny": "(Tensor x, Tensor Qidxs, Tensor grid, float scale) -> Tensor",
+    "d4_mm_skinny": "(Tensor x, Tensor Qidxs, Tensor grid) -> Tensor",      # uint8 codes (n, k/4), the fp16 (256, 4) table
+    "hi_mm_skinny": "(Tensor x, Tensor Qidxs) -> Tensor",                   # int32 codes (n, k/8), eight nibbles each
     # E8P12RVQ3B on the matrix-core GEMV: Qidxs = the checkpoint's 3-byte codes (int32 (n, 3k/32)), e81b_i8 = int8 (256, 8)
     "e8prvq3_gemv_planes_group": "(Tensor[] planes, Tensor[] Qidxs, Tensor grid, Tensor e81b_i8) -> Tensor[]",
     "d4_gemv_planes": "(Tensor planes, Tensor Qidxs, Tensor grid) -> Tensor",
@@ -803,6 +807,43 @@ def _e8p_mm_skinny_cuda(x, Qidxs, grid):
     return y
 
 
+def _e8prvq4_mm_skinny_cuda(x, Qidxs, grid, scale):
+    g = _grid_i64(grid, x)
+    xc = _chk_x(x)
+    Qc = _chk_q(Qidxs, torch.int32)
+    m, k, n = xc.shape[0], xc.shape[1], Qc.shape[0]
+    _need(Qc.shape[1] * 8 == k, f"e8prvq4_mm_skinny: x has {k} columns but Qidxs {tuple(Qidxs.shape)} encodes {Qc.shape[1] * 8}")
+    _need(Qc.device == x.device, "Qidxs and x must be on the same device")
+    _need(e8p_mm_skinny_supported(m, n, k), f"e8prvq4_mm_skinny: shape ({m}, {n}, {k}) needs k % 128 == 0, n % 2 == 0")
+    y = _empty((m, n), dtype=torch.float16, device=x.device)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().quip_e8prvq4_mm_skinny(xc.data_ptr(), Qc.data_ptr(), g.data_ptr(), float(scale), y.data_ptr(),
+                                                     m, n, k, _stream(x)), "quip_e8prvq4_mm_skinny")
+    return y
+
+
+def _skinny_generic(fn, what, x, Qidxs, qdtype, per_code, extra):
+    xc = _chk_x(x)
+    Qc = _chk_q(Qidxs, qdtype)
+    m, k, n = xc.shape[0], xc.shape[1], Qc.shape[0]
+    _need(Qc.shape[1] * per_code == k, f"{what}: x has {k} columns but Qidxs {tuple(Qidxs.shape)} encodes {Qc.shape[1] * per_code}")
+    _need(Qc.device == x.device, "Qidxs and x must be on the same device")
+    _need(e8p_mm_skinny_supported(m, n, k), f"{what}: shape ({m}, {n}, {k}) needs k % 128 == 0, n % 2 == 0")
+    y = _empty((m, n), dtype=torch.float16, device=x.device)
+    with torch.cuda.device(x.device):
+        capi.check(getattr(capi.lib(), fn)(xc.data_ptr(), Qc.data_ptr(), *extra(), y.data_ptr(), m, n, k, _stream(x)), fn)
+    return y
+
+
+def _d4_mm_skinny_cuda(x, Qidxs, grid):
+    g = _d4_grid_f16(grid)
+    return _skinny_generic("quip_d4_mm_skinny", "d4_mm_skinny", x, Qidxs, torch.uint8, 4, lambda: (g.data_ptr(),))
+
+
+def _hi_mm_skinny_cuda(x, Qidxs):
+    return _skinny_generic("quip_hi_mm_skinny", "hi_mm_skinny", x, Qidxs, torch.int32, 8, lambda: ())
+
+
 def _e8p_gemv_planes_cuda(planes, Qidxs, grid):
     g = _grid_i64(grid, Qidxs)
     Qc = _chk_q(Qidxs, torch.int16)
@@ -946,6 +987,9 @@ _IMPLS = {
     "e8p_gemv_planes_group": _e8p_gemv_planes_group_cuda,
     "e8p_mm_batched": _e8p_mm_batched_cuda,
     "e8p_mm_skinny": _e8p_mm_skinny_cuda,
+    "e8prvq4_mm_skinny": _e8prvq4_mm_skinny_cuda,
+    "d4_mm_skinny": _d4_mm_skinny_cuda,
+    "hi_mm_skinny": _hi_mm_skinny_cuda,
     "e8p_mm_planes_rows": _e8p_mm_planes_rows_cuda,
     "had_transform_planes_rows": _had_transform_planes_rows_cuda,
     "e8p_gemv_planes_rows": _e8p_gemv_planes_rows_cuda,
@@ -1039,6 +1083,9 @@ _reg_fake("rope_attn_decode", lambda q, k, v, cos, sin, pos, kcache, vcache, wor
 _reg_fake("rope_attn_decode_z", lambda zs, posts, scales, cos, sin, pos, kcache, vcache, workspace=None:
           kcache.new_empty((zs[0].numel() // kcache.shape[2], kcache.shape[2])))
 _reg_fake("e8p_mm_skinny", lambda x, Q, g: x.new_empty((x.shape[0], Q.shape[0]), dtype=torch.float16))
+_reg_fake("e8prvq4_mm_skinny", lambda x, Q, g, s: x.new_empty((x.shape[0], Q.shape[0]), dtype=torch.float16))
+_reg_fake("d4_mm_skinny", lambda x, Q, g: x.new_empty((x.shape[0], Q.shape[0]), dtype=torch.float16))
+_reg_fake("hi_mm_skinny", lambda x, Q: x.new_empty((x.shape[0], Q.shape[0]), dtype=torch.float16))
 _reg_fake("e8p_mm_batched", lambda x, Q, g: x.new_empty((x.shape[0], Q.shape[0]), dtype=torch.float16))
 _reg_fake("e8p_gemv_planes", lambda planes, Q, g: Q.new_empty((1, Q.shape[0]), dtype=torch.float16))
 for _n in ("e8p_mm_origorder", "e8prvq3_mm_origorder", "e8prvq4_mm_origorder", "d4_mm_origorder",

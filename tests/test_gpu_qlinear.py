@@ -304,12 +304,12 @@ def test_skinny_rows_on_matrix_core_path(fin, fout, M, cbid="E8P12"):
     What = O.qlinear_dense_weight(P)
     ref = O.qlinear_forward(P, x.astype(np.float64), "exact", What)
     assert np.all(np.abs(y.cpu().numpy().astype(np.float64) - ref) <= O.ulp_bound(P, x.astype(np.float64), What))
-    # default dispatch: as long as one exact pass carries the rows nothing changes; beyond that E8P12 takes the
+    # default dispatch: as long as one exact pass carries the rows nothing changes; beyond that E8P12 / E8P12RVQ4B take the
     # single-pass fp16 skinny kernel -- inside the same stated bound, but not bit identical to bs=1 any more
     layer.skinny_exact = False
     with torch.no_grad():
         yd = layer(xd)
-    if M <= layer._rows_per_pass() or cbid != "E8P12":
+    if layer.regime(M) == "rows_exact":
         assert torch.equal(yd, y)
     else:
         assert np.all(np.abs(yd.cpu().numpy().astype(np.float64) - ref) <= O.ulp_bound(P, x.astype(np.float64), What))
@@ -352,6 +352,96 @@ def test_single_pass_skinny_kernel(fin, fout, M):
         ref = O.qlinear_forward(P, x64m, "exact", What)
         assert np.all(np.abs(y.cpu().numpy().astype(np.float64) - ref) <= O.ulp_bound(P, x64m, What))
 
+
+
+@pytest.mark.parametrize("fin,fout,M", [(4096, 4096, 6), (4096, 4096, 16), (4096, 4096, 31), (4096, 11008, 17), (11008, 4096, 9),
+                                        (256, 688, 12), (4096, 4096, 100), (1024, 512, 40), (128, 64, 2)])
+def test_single_pass_skinny_kernel_rvq4(fin, fout, M):
+    """E8P12RVQ4B through the fp16-MFMA skinny kernel's RVQ4 mode (csrc/e8p_skinny_gemm.hip; the 1 < M < 32 use of the
+    reference's tinygemm kernel with BLayout_E8RVQ4, origin_order.cu:337-385): weights = the dense W the reference's
+    decompress writes (bit for bit: checked through the op), product against float64 of the same fp16 operands, the module
+    inside the stated ulp bound, rows independent of their batch"""
+    P = O.make_layer("E8P12RVQ4B", fin, fout, seed=fin + fout + 1)
+    layer = _layer(P)
+    cb = layer.codebook
+    rng = np.random.default_rng(M + fout)
+    k, n = layer.q_in_features, layer.q_out_features
+    if not cb.skinny_supported(M, n, k):
+        pytest.skip("k % 128 != 0: rows mode / generic path")
+    xh = torch.from_numpy(rng.standard_normal((M, k)).astype(np.float16)).to(DEV)
+    z = torch.ops.quip_lib.e8prvq4_mm_skinny(xh, layer.Qidxs, cb.grid_packed_abs, cb.opt_resid_scale)
+    Wd = cb.decompress_weight(layer.Qidxs)
+    Wq = O.decompress_e8prvq4(P.Qidxs, cb.opt_resid_scale).astype(np.float64)
+    assert np.array_equal(Wd.cpu().numpy().astype(np.float64), Wq)
+    x64 = xh.cpu().numpy().astype(np.float64)
+    z64 = x64 @ Wq.T
+    tol = 2.0 ** -10 * np.abs(z64) + 2.0 ** -21 * (np.abs(x64) @ np.abs(Wq).T) + 1e-7
+    assert np.all(np.abs(z.cpu().numpy().astype(np.float64) - z64) <= tol)
+    # an identity row picks single weights out: the kernel's weights ARE the dense W's
+    e = torch.zeros(min(M, 8), k, dtype=torch.float16, device=DEV)
+    cols = [0, 1, 7, 8, k // 2 + 3, k - 9, k - 8, k - 1][:e.shape[0]]
+    for i, c in enumerate(cols):
+        e[i, c] = 1.0
+    ze = torch.ops.quip_lib.e8prvq4_mm_skinny(e, layer.Qidxs, cb.grid_packed_abs, cb.opt_resid_scale)
+    assert torch.equal(ze, Wd[:, cols].T.contiguous())
+    if M >= 5:
+        z2 = torch.ops.quip_lib.e8prvq4_mm_skinny(xh[3:3 + 2].contiguous(), layer.Qidxs, cb.grid_packed_abs, cb.opt_resid_scale)
+        assert torch.equal(z[3:5], z2), "a row's result does not depend on the other rows"
+    if M > 40:   # ... nor on the chunk it falls into
+        z3 = torch.ops.quip_lib.e8prvq4_mm_skinny(xh[M - 7:].contiguous(), layer.Qidxs, cb.grid_packed_abs, cb.opt_resid_scale)
+        assert torch.equal(z[M - 7:], z3)
+    x = torch.from_numpy(rng.standard_normal((M, fin)).astype(np.float16)).to(DEV)
+    with torch.no_grad():
+        y = layer(x)
+    if 5 < M < 32:
+        assert layer.regime(M) == "skinny_fp16"
+    What = O.qlinear_dense_weight(P)
+    x64m = x.cpu().numpy().astype(np.float64)
+    ref = O.qlinear_forward(P, x64m, "exact", What)
+    assert np.all(np.abs(y.cpu().numpy().astype(np.float64) - ref) <= O.ulp_bound(P, x64m, What))
+
+
+@pytest.mark.parametrize("cbid", ["D4", "HI"])
+@pytest.mark.parametrize("fin,fout,M", [(4096, 4096, 6), (4096, 4096, 31), (4096, 11008, 17), (11008, 4096, 9), (256, 688, 12),
+                                        (4096, 4096, 100), (1024, 512, 40)])
+def test_single_pass_skinny_kernel_d4_hi(cbid, fin, fout, M):
+    """D4 and HI through the skinny kernel's table / nibble modes: the weights are the dense W of the reference's decompress
+    bit for bit (identity rows), the product agrees with float64 of the same fp16 operands, the module sits inside the stated
+    bound, rows do not depend on their batch"""
+    P = O.make_layer(cbid, fin, fout, seed=fin + fout + 2)
+    layer = _layer(P)
+    cb = layer.codebook
+    rng = np.random.default_rng(M + fout)
+    k, n = layer.q_in_features, layer.q_out_features
+    if not cb.skinny_supported(M, n, k):
+        pytest.skip("k % 128 != 0: rows mode / generic path")
+    xh = torch.from_numpy(rng.standard_normal((M, k)).astype(np.float16)).to(DEV)
+    z = cb.mm_skinny(xh, layer.Qidxs)
+    Wd = cb.decompress_weight(layer.Qidxs)
+    Wq = O.decompress(cbid, P.Qidxs).astype(np.float64)
+    assert np.array_equal(Wd.cpu().numpy().astype(np.float64), Wq)
+    x64 = xh.cpu().numpy().astype(np.float64)
+    z64 = x64 @ Wq.T
+    tol = 2.0 ** -10 * np.abs(z64) + 2.0 ** -21 * (np.abs(x64) @ np.abs(Wq).T) + 1e-7
+    assert np.all(np.abs(z.cpu().numpy().astype(np.float64) - z64) <= tol)
+    e = torch.zeros(8, k, dtype=torch.float16, device=DEV)
+    cols = [0, 1, 3, 4, 7, k // 2 + 5, k - 8, k - 1]
+    for i, c in enumerate(cols):
+        e[i, c] = 1.0
+    assert torch.equal(cb.mm_skinny(e, layer.Qidxs), Wd[:, cols].T.contiguous())
+    z2 = cb.mm_skinny(xh[3:3 + 2].contiguous(), layer.Qidxs)
+    assert torch.equal(z[3:5], z2), "a row's result does not depend on the other rows"
+    if M > 40:
+        assert torch.equal(z[M - 7:], cb.mm_skinny(xh[M - 7:].contiguous(), layer.Qidxs))
+    x = torch.from_numpy(rng.standard_normal((M, fin)).astype(np.float16)).to(DEV)
+    with torch.no_grad():
+        y = layer(x)
+    if 5 < M < (24 if cbid == "D4" else 32):
+        assert layer.regime(M) == "skinny_fp16"
+    What = O.qlinear_dense_weight(P)
+    x64m = x.cpu().numpy().astype(np.float64)
+    ref = O.qlinear_forward(P, x64m, "exact", What)
+    assert np.all(np.abs(y.cpu().numpy().astype(np.float64) - ref) <= O.ulp_bound(P, x64m, What))
 
 
 @pytest.mark.parametrize("fin,fout,M", [(4096, 4096, 2), (4096, 4096, 7), (256, 688, 3), (4096, 11008, 4)])
