@@ -68,13 +68,18 @@ constexpr int KPD = 11264, JD = 22;                  // digits of down's input, 
 constexpr int kRowU4 = HID / 64, kRowU4D = NFFN / 64;
 constexpr int NSLOT = 9;                             // X0-2: q k v, then gate's row blocks | X3-5: o, then up's | X6-8: down
 
-// workspace: ctl | z_q z_k z_v | a | z_o | z_d (2048 granules each) | inbox [11 row owners][256 columns][2][4] | rows [256][48]
+// workspace: ctl | z_q z_k z_v | a | z_o | z_d (2048 granules each) | inbox [11 row owners][256 columns][2][4] | rows [256][48] |
+// attention partials [32 heads][8][132]
 constexpr size_t kWsCtl = 0, kWsZ = 64, kWsVec = 2048 * 8;
 // row-owner workgroups of the MLP edge: RPO rows k' each, one per wave on waves 0..RPO-1 (four waves = one per SIMD: the
 // row work is DPP-serial VALU code, two such waves on a SIMD take twice as long)
 constexpr int RPO = 4, NRO = (FK + RPO - 1) / RPO;
 constexpr size_t kWsInbox = kWsZ + 6 * kWsVec, kWsRows = kWsInbox + (size_t)NRO * FL * 2 * RPO * 8;
-constexpr size_t kWsBytes = kWsRows + (size_t)FL * 48 * 8;
+// long contexts: the eight workgroups of a head each take every eighth position; their partial softmax states (128 sums +
+// maximum + denominator, padded to 132 granules) meet at the head's first workgroup
+constexpr int kParts = 8, kPartGran = 132, kSplitPos = 128;      // (measured: 1.83 ms per token at 200 positions on one workgroup per head, 1.74 at 256 split)
+constexpr size_t kWsPart = kWsRows + (size_t)FL * 48 * 8;
+constexpr size_t kWsBytes = kWsPart + (size_t)NH * kParts * kPartGran * 8;
 
 template <int REP>
 struct BLds {
@@ -123,6 +128,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   uint64_t* zbufs = reinterpret_cast<uint64_t*>(a.ws + kWsZ);       // [6][2048]: q k v a o d
   uint64_t* inbox = reinterpret_cast<uint64_t*>(a.ws + kWsInbox);
   uint64_t* frow = reinterpret_cast<uint64_t*>(a.ws + kWsRows);
+  uint64_t* pbuf = reinterpret_cast<uint64_t*>(a.ws + kWsPart);
   int dbg_on = 0;
 #define BSTAMP(i) do { if (dbg_on && tid == 0) a.dbg[w * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
@@ -432,9 +438,15 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 
     // ================= P2: attention ====================================================================================
     rederive();
-    const bool head_wg = (w & 7) == 0;
+    // Short contexts: the workgroup that owns the first rows of a head (w % 8 == 0) runs its attention alone, the other seven
+    // wait for the result.  From kSplitPos positions on all eight take part: workgroup `part` every eighth position, and
+    // their partial states (maximum, denominator, 128 unnormalised sums) meet at the first one through one more hand-off
+    // (2 us, against 21 ns per position and block on one workgroup: 43 us per block at 2048 positions).
+    const bool split = pos >= kSplitPos;
+    const int part = w & 7, nparts = split ? kParts : 1;
+    const bool head_wg = part == 0;
     const int hd = w >> 3;
-    if (head_wg) {
+    if (head_wg || split) {
       // vectors first, then the gather.  After the transforms thread t holds elements t + 512 k: this head's 128 values
       // of q, k, v are register hd >> 2 of the threads [128 (hd & 3), +128)
       const int kreg = hd >> 2, tloc = tid - 128 * (hd & 3);
@@ -452,10 +464,11 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       const f16* kc = Ld.kcache + (size_t)hd * a.max_len * HD;
       const f16* vc = Ld.vcache + (size_t)hd * a.max_len * HD;
       uint4 kr0[U], vr0[U], kr1[U], vr1[U];
-      auto load_round = [&](uint4 (&kr)[U], uint4 (&vr)[U], int t0) {
+      // local index i of this workgroup <-> position part + nparts i; a round = local indices i0 + u NG, u < U
+      auto load_round = [&](uint4 (&kr)[U], uint4 (&vr)[U], int i0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const int t = t0 + u * NG;
+          const int t = part + nparts * (i0 + u * NG);
           const int tc = t < pos ? t : 0;
           kr[u] = *reinterpret_cast<const uint4*>(kc + (size_t)tc * HD + d0);
           vr[u] = *reinterpret_cast<const uint4*>(vc + (size_t)tc * HD + d0);
@@ -463,7 +476,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       };
       if (tid < 256) {
         load_round(kr0, vr0, g);
-        if (NG * U < pos) load_round(kr1, vr1, g + NG * U);
+        if (part + nparts * NG * U < pos) load_round(kr1, vr1, g + NG * U);
       }
       float v[3][8];
       gather(std::integral_constant<int, 3>{}, SLOTS(0x008u), 0, ebase | hop, 0x5000u, v);
@@ -517,7 +530,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         unpack8h(vraw, vn);
 #pragma unroll
         for (int i = 0; i < 8; ++i) q8[i] *= a.attn_scale;
-        if (g == 0 && pos_ok) {                        // append the new row (StaticCache.update)
+        if (g == 0 && pos_ok && part == (split ? (pos & (kParts - 1)) : 0)) {   // append the new row (StaticCache.update): once
           uint4 kr;
           kr.x = pack_f16(kn[0], kn[1]); kr.y = pack_f16(kn[2], kn[3]);
           kr.z = pack_f16(kn[4], kn[5]); kr.w = pack_f16(kn[6], kn[7]);
@@ -529,10 +542,10 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         for (int i = 0; i < 8; ++i) acc8[i] = 0.f;
         const int t_hi = pos + 1;
         // one round: positions t0 + u NG of this key group, rows in (kr, vr)
-        auto round = [&](const uint4 (&kr)[U], const uint4 (&vr)[U], int t0) {
+        auto round = [&](const uint4 (&kr)[U], const uint4 (&vr)[U], int i0) {
 #pragma unroll
           for (int u = 0; u < U; ++u) {
-            const int t = t0 + u * NG;
+            const int t = part + nparts * (i0 + u * NG);
             float k8[8], v8[8];
             unpack8h(kr[u], k8);
             unpack8h(vr[u], v8);
@@ -555,13 +568,14 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
             }
           }
         };
-        // (uniform trip count: the lanes of a wave differ in g < NG only, and every round is entered for t0 - g < t_hi)
-        for (int tb = 0; tb < t_hi; tb += 2 * NG * U) {
-          round(kr0, vr0, tb + g);
-          if (tb + 2 * NG * U < t_hi) load_round(kr0, vr0, tb + g + 2 * NG * U);
-          if (tb + NG * U < t_hi) {
-            round(kr1, vr1, tb + g + NG * U);
-            if (tb + 3 * NG * U < t_hi) load_round(kr1, vr1, tb + g + 3 * NG * U);
+        // (uniform trip count: the lanes of a wave differ in g < NG only)
+        const int n_loc = t_hi > part ? (t_hi - part + nparts - 1) / nparts : 0;     // local indices of this workgroup
+        for (int ib = 0; ib < n_loc; ib += 2 * NG * U) {
+          round(kr0, vr0, ib + g);
+          if (ib + 2 * NG * U < n_loc) load_round(kr0, vr0, ib + g + 2 * NG * U);
+          if (ib + NG * U < n_loc) {
+            round(kr1, vr1, ib + g + NG * U);
+            if (ib + 3 * NG * U < n_loc) load_round(kr1, vr1, ib + g + 3 * NG * U);
           }
         }
         if ((tid & (LPK - 1)) == 0) { s_m[g] = m; s_l[g] = lsum; }
@@ -570,24 +584,76 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       }
       had::wg_barrier<true>();
       f16* s_a = s_qkv + 3 * HD;
+      float pM = -INFINITY, pL = 0.f, pO = 0.f;        // this workgroup's state for dimension tid: maximum, denominator, sum
       if (tid < HD) {
-        float M = -INFINITY, Lsum = 0.f, o = 0.f;
-        for (int g = 0; g < NG; ++g) M = fmaxf(M, s_m[g]);
-        for (int g = 0; g < NG; ++g) {
-          const float ww = s_m[g] == -INFINITY ? 0.f : __expf(s_m[g] - M);
-          Lsum = __builtin_fmaf(s_l[g], ww, Lsum);
-          o = __builtin_fmaf(s_acc[g * (HD + 4) + tid], ww, o);
+        for (int g2 = 0; g2 < NG; ++g2) pM = fmaxf(pM, s_m[g2]);
+        for (int g2 = 0; g2 < NG; ++g2) {
+          const float ww = s_m[g2] == -INFINITY ? 0.f : __expf(s_m[g2] - pM);
+          pL = __builtin_fmaf(s_l[g2], ww, pL);
+          pO = __builtin_fmaf(s_acc[g2 * (HD + 4) + tid], ww, pO);
         }
-        s_a[tid] = pos_ok ? (f16)(o / Lsum) : __builtin_bit_cast(f16, (unsigned short)0x7e00);
+      }
+      if (split) {
+        // hand-off: the partial states of the head's eight workgroups -> its first one
+        ++hop;
+        const uint32_t tagp = ebase | hop;
+        uint64_t* mine_p = pbuf + ((size_t)hd * kParts + part) * kPartGran;
+        if (tid < HD) esync::st_granule(mine_p + tid, as_u32(pO), tagp);
+        if (tid == 0) { esync::st_granule(mine_p + HD, as_u32(pM), tagp); esync::st_granule(mine_p + HD + 1, as_u32(pL), tagp); }
+        if (head_wg) {
+          constexpr int PIECES = kParts * kPartGran / 2;        // 16-byte pieces of the head's partials (the padding is never written)
+          float* s_p = reinterpret_cast<float*>(smem + B::kArea);                  // [parts][132]
+          const uint64_t* srcp = pbuf + (size_t)hd * kParts * kPartGran;
+          u32x4_t pp[2];
+          uint32_t spins = 0;
+          for (;;) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int i = tid + kThreads * j;
+              esync::ld16(pp[j], srcp + 2 * (i < PIECES ? i : 0));
+            }
+            esync::drain();
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              esync::own(pp[j]);
+              const int i = tid + kThreads * j;
+              const int gi = 2 * (i < PIECES ? i : 0), within = gi % kPartGran;
+              ok = ok && (within >= HD + 2 || (pp[j].y == tagp && (within + 1 >= HD + 2 || pp[j].w == tagp)));
+            }
+            if (esync::spin_step(ok, spins, ctl + 1, 0x8000u + (uint32_t)w)) break;
+          }
+          had::wg_barrier<true>();                       // s_m / s_l / s_acc have been read by everybody
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int i = tid + kThreads * j;
+            if (i < PIECES) *reinterpret_cast<uint2*>(s_p + 2 * i) = make_uint2(pp[j].x, pp[j].z);
+          }
+          own_slots(SLOTS(0x008u));
+          had::wg_barrier<true>();
+          if (tid < HD) {
+            float M = -INFINITY, Lsum = 0.f, o = 0.f;
+            for (int q2 = 0; q2 < kParts; ++q2) M = fmaxf(M, s_p[q2 * kPartGran + HD]);
+            for (int q2 = 0; q2 < kParts; ++q2) {
+              const float mq = s_p[q2 * kPartGran + HD];
+              const float ww = mq == -INFINITY ? 0.f : __expf(mq - M);
+              Lsum = __builtin_fmaf(s_p[q2 * kPartGran + HD + 1], ww, Lsum);
+              o = __builtin_fmaf(s_p[q2 * kPartGran + tid], ww, o);
+            }
+            s_a[tid] = pos_ok ? (f16)(o / Lsum) : __builtin_bit_cast(f16, (unsigned short)0x7e00);
+          }
+        }
+      } else if (tid < HD) {
+        s_a[tid] = pos_ok ? (f16)(pO / pL) : __builtin_bit_cast(f16, (unsigned short)0x7e00);
       }
       had::wg_barrier<true>();
       ++hop;                                           // hand-off: attention output
-      if (tid < 64) {
+      if (head_wg && tid < 64) {
         const uint32_t pr = *reinterpret_cast<const uint32_t*>(s_a + 2 * tid);
         esync::st_granule(zbufs + (size_t)3 * 2048 + hd * 64 + tid, pr, ebase | hop);
       }
     } else {
-      ++hop;
+      ++hop;                                           // (short context: the seven other workgroups of a head wait for the result)
     }
     BSTAMP(6);
     rederive();
@@ -973,7 +1039,7 @@ bool block_engine_supported(int hidden, int heads, int kv_heads, int head_dim, i
 }
 
 int block_engine_launch(const BlockEngineArgs& in, hipStream_t stream) {
-  if (in.n_layers < 1 || in.n_layers > 160) return QUIP_ERR_BAD_SHAPE;     // 6 hand-offs per block, 10-bit counter
+  if (in.n_layers < 1 || in.n_layers > 146) return QUIP_ERR_BAD_SHAPE;     // up to 7 hand-offs per block, 10-bit counter
   BlockArgs a;
   a.layers = reinterpret_cast<const BlockLayer*>(in.layers);
   a.h_in = reinterpret_cast<const f16*>(in.h_in);
