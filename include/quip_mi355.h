@@ -448,7 +448,8 @@ int quip_ffn_engine(const quip_ffn_engine_args* args, quip_stream_t stream);
  *   uint64 had3   the K x K factors packed as for quip_ffn_engine
  *   uint64 kcache, vcache   fp16 [heads, max_len, 128], row *pos is written
  *   float  sc[7]  wscale_float / sqrt(L_in) (L_in = 4096; down: 256), then 5 floats of padding
- * workspace: quip_block_engine_workspace_bytes() bytes, zeroed once at allocation. */
+ * workspace: quip_block_engine_workspace_bytes() bytes, zeroed once at allocation.  1 <= n_layers <= 146 per launch (longer
+ * models: several launches).  From 128 positions on the eight workgroups of a head share its attention. */
 typedef struct quip_block_engine_args {
   const void* layers;
   const void* h_in;          /* fp16 [4096]: embedding row of the token */
