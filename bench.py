@@ -351,6 +351,34 @@ def time_decoder(D, shape, codebook, steps, warmup, device, **cb_kwargs):
     return out
 
 
+def long_context_decode(D, device, positions=(2048, 4000), steps=16):
+    """the headline model's decode step at long contexts (same captured step, position counter moved: the cache rows hold
+    whatever earlier tokens left there -- attention time does not depend on the values)"""
+    import torch
+    dec = D.LlamaDecoder(D.LLAMA2_7B, "E8P12", max_len=max(positions) + steps + 8, device=device, seed=0, device_init=True)
+    dec.capture()
+    out = {}
+    with torch.no_grad():
+        for p in positions:
+            dec.reset(first_token=1)
+            dec.pos.fill_(p)
+            for _ in range(3):
+                dec.graph.replay()
+            dec.pos.fill_(p)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                dec.graph.replay()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out["position_%d" % p] = {"tokens_per_s": round(steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4)}
+    out["engine_status"] = dec.engine_status() if hasattr(dec, "engine_status") else 0
+    out["step"] = "persistent block launch" if getattr(dec, "block_eng", False) else "stage-wise"
+    del dec
+    torch.cuda.empty_cache()
+    return out
+
+
 def max_over_ranks(dist, dt, device):
     """the job's step time is the slowest replica's"""
     if dist is None:
@@ -489,6 +517,10 @@ def main():
                     extras[key] = time_decoder(D, shp, cbk, st, 8, f"cuda:{local_rank}", **kw)
                 except Exception as e:
                     extras[key] = {"error": repr(e)}
+            try:
+                extras["llama2_7b_e8p12_long_context"] = long_context_decode(D, f"cuda:{local_rank}")
+            except Exception as e:
+                extras["llama2_7b_e8p12_long_context"] = {"error": repr(e)}
             out["extras"] = extras
         if not a.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only (bench contract)
             try:

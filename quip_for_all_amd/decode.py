@@ -259,6 +259,12 @@ class LlamaDecoder:
                 return ffn_engine_status(ws)
         return 0
 
+    def engine_reset(self):
+        """after a launch that gave up: workspaces back to their allocation state (generation 0, no granules, no code)"""
+        for ws in (getattr(self, "eng_ws", None), getattr(self, "ffn_ws", None)):
+            if ws is not None:
+                ws.zero_()
+
     # ---- model bytes the decode step has to stream (roofline denominator, SURVEY 8d) -----------
     def algorithmic_bytes_per_token(self):
         b = 0
@@ -497,4 +503,13 @@ class LlamaDecoder:
                 self.tok.copy_(prompt[t + 1:t + 2].view_as(self.tok))
             else:
                 out[t - n_prompt] = self.tok.reshape(-1)[0]
+        # a persistent launch whose workgroups were not all resident (something else on the device) gives up on a hand-off
+        # instead of hanging and leaves a code: its tokens are not results
+        if getattr(self, "block_eng", False) or getattr(self, "ffn_eng", False):
+            st = self.engine_status()
+            if st:
+                self.engine_reset()
+                raise RuntimeError("persistent decode launch gave up on a hand-off (code 0x%x): the device was shared with "
+                                   "other work during generation; QUIP_BLOCK_ENGINE=0 QUIP_FFN_ENGINE=0 selects the "
+                                   "stage-wise step" % st)
         return out
