@@ -92,6 +92,10 @@ int quip_e8p_mm_skinny(const void* x, const void* qidxs /* int16 (n, k/8) */, co
  * -- fp16 activations, fp32 accumulation.  Same shape rules. */
 int quip_e8prvq4_mm_skinny(const void* x, const void* qidxs /* int32 (n, k/8) */, const void* grid_packed_abs,
                            float resid_scale, void* y, int32_t m, int32_t n, int32_t k, quip_stream_t stream);
+/* ... for E8P12RVQ3B (BLayout_E8RVQ3, origin_order.cu:287-335; e8p12_rvq3.py:109-129): qidxs = the checkpoint's packed 3-byte
+ * codes (n, 3 k / 8 bytes; k % 32 == 0), e81b_packed = the uint32 [256] residual table as the reference passes it. */
+int quip_e8prvq3_mm_skinny(const void* x, const void* qidxs, const void* grid_packed_abs, const void* e81b_packed,
+                           float resid_scale, void* y, int32_t m, int32_t n, int32_t k, quip_stream_t stream);
 /* ... for D4 (BLayout_D4; d4.py:134-151): qidxs uint8 (n, k/4), grid_f16 = the fp16 (256, 4) table as the reference holds it;
  * and for HI (BLayout_HI; hi.py:52-66): qidxs int32 (n, k/8), eight nibbles per code, w = nibble - 7.5. */
 int quip_d4_mm_skinny(const void* x, const void* qidxs, const void* grid_f16, void* y, int32_t m, int32_t n, int32_t k,

@@ -258,7 +258,7 @@ class E8P12RVQ4B_codebook(_SkinnyMixin, _Codebook):
         return torch.ops.quip_lib.e8prvq4_mm_skinny(xh, Qidxs, self.grid_packed_abs, self.opt_resid_scale)
 
 
-class E8P12RVQ3B_codebook(_Codebook):
+class E8P12RVQ3B_codebook(_SkinnyMixin, _Codebook):
     def __init__(self, inference=False, opt_resid_scale=None, **kwargs):
         super().__init__()
         self.id = "E8P12RVQ3B"
@@ -317,6 +317,11 @@ class E8P12RVQ3B_codebook(_Codebook):
     def mm_planes_rows(self, planes, Qidxs):
         return torch.ops.quip_lib.gemv_planes_rows_mode(planes, Qidxs, self.grid_packed_abs,
                                                         self._e81b_i8(Qidxs.device), 40)
+
+    skinny_chunks_max_mn = _SkinnyMixin.skinny_chunks_max_mn * 2 // 3     # (1.5 x the code bytes per weight)
+
+    def mm_skinny(self, xh, Qidxs):
+        return torch.ops.quip_lib.e8prvq3_mm_skinny(xh, Qidxs, self.grid_packed_abs, self.e81b_grid_packed, self.opt_resid_scale)
 
     def maybe_pack_idxs(self, idxs):
         """keep the low 3 bytes of every int32 index (e8p12_rvq3.py:102-107)"""

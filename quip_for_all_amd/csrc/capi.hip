@@ -541,6 +541,17 @@ int quip_e8prvq4_mm_skinny(const void* x, const void* qidxs, const void* grid, f
   return e8prvq4_skinny_gemm_launch(x, qidxs, grid, resid_scale, y, m, n, k, (hipStream_t)stream);
 }
 
+int quip_e8prvq3_mm_skinny(const void* x, const void* qidxs, const void* grid, const void* e81b_packed, float resid_scale,
+                           void* y, int32_t m, int32_t n, int32_t k, quip_stream_t stream) {
+  if (!x || !qidxs || !grid || !e81b_packed || !y) return QUIP_ERR_NULL_POINTER;
+  if (m < 0 || n < 1 || k < 8) return QUIP_ERR_BAD_SHAPE;
+  if (m == 0) return QUIP_OK;
+  if (!aligned16(x) || (reinterpret_cast<uintptr_t>(qidxs) & 3u) || (reinterpret_cast<uintptr_t>(y) & 3u) ||
+      (reinterpret_cast<uintptr_t>(grid) & 7u) || (reinterpret_cast<uintptr_t>(e81b_packed) & 7u))
+    return QUIP_ERR_MISALIGNED;
+  return e8prvq3_skinny_gemm_launch(x, qidxs, grid, e81b_packed, resid_scale, y, m, n, k, (hipStream_t)stream);
+}
+
 int quip_d4_mm_skinny(const void* x, const void* qidxs, const void* grid_f16, void* y, int32_t m, int32_t n, int32_t k,
                       quip_stream_t stream) {
   if (!x || !qidxs || !grid_f16 || !y) return QUIP_ERR_NULL_POINTER;

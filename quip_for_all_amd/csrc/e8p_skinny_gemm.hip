@@ -41,6 +41,11 @@
 // codes; the weight is fma(s, w_resid, w_main) in packed fp16 -- ONE fp16 rounding per weight, exactly what
 // decompress_e8prvq4_origorder writes (quip_device.hip.h: rvq_combine), so the product is x . W of the reference's dense W.
 // Per lane and unit two 16-byte loads (eight 4-byte codes), four table lookups and four v_pk_fma_f16 per MFMA.
+// MODE 4 = E8P12RVQ3B (e8p12_rvq3.py:81-129; origin_order.cu:287-335): 3-byte codes [residual index, E8P code]; two 12-byte
+// loads per lane and unit, a shift and two v_perm_b32 turn them into the dwords (main << 16 | residual << 8) of MODE 1's
+// data movement; the residual is one 4-byte lookup (eight int4 = 2 x value, the reference's packed E81B table) turned into
+// fp16 by 0x4c00 | (n ^ 8) << 6 = 16 + (n ^ 8) and one exact fma (x 0.5, - 12), then fma(s, w_resid, w_main) as in MODE 1.
+// (Table space: the sign table keeps 8 copies instead of 16, the 16 KB hold 16 copies of the residual table.)
 // MODE 2 = D4 (d4.py:26-96; origin_order.cu BLayout_D4): two one-byte codes per 8 weights -- the data movement of MODE 0 --
 // and the table holds the fp16 entries themselves: a B fragment is two 8-byte lookups, no arithmetic.
 // MODE 3 = HI (hi.py:41-50; origin_order.cu:1028-1051): eight nibbles per 8 weights -- the data movement of MODE 1 --,
@@ -57,6 +62,7 @@ typedef _Float16 sf16x8 __attribute__((ext_vector_type(8)));
 typedef float sf32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t su32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t su32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t su32x3 __attribute__((ext_vector_type(3)));
 
 constexpr int kSRep = 16;
 constexpr int kST1 = 0;
@@ -106,8 +112,12 @@ template <int CB, int MP, int MODE = 0>
 __global__ __launch_bounds__(1024) void e8p_skinny_gemm_kernel(const f16* __restrict__ X,
                                                                const uint16_t* __restrict__ Wc,
                                                                const uint64_t* __restrict__ grid,
-                                                               f16* __restrict__ Y, int M, int N, int K, float resid_scale) {
-  constexpr int NCL = (MODE == 1 || MODE == 3) ? 2 : 1;     // 16-byte code loads per lane and unit
+                                                               f16* __restrict__ Y, int M, int N, int K, float resid_scale,
+                                                               const uint32_t* __restrict__ grid2) {
+  constexpr int NCL = (MODE == 1 || MODE == 3 || MODE == 4) ? 2 : 1;     // code loads per lane and unit (16 bytes; MODE 4: 12)
+  constexpr int kRep2 = MODE == 4 ? 8 : kSRep;                           // copies of the sign table
+  constexpr int kST3 = kST2 + 256 * 8 * 8;                               // MODE 4: the residual table (256 x 4 bytes x 16 copies)
+  using CodeT = std::conditional_t<MODE == 4, su32x3, su32x4>;           // what one code load writes
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // more than 32 rows: grid.y walks over chunks of 32 rows (each workgroup streams its columns' codes again; the
   // chunks of one column block run side by side and share them in L2)
@@ -130,12 +140,18 @@ __global__ __launch_bounds__(1024) void e8p_skinny_gemm_kernel(const f16* __rest
 
   // (a wave without units -- K < 2048 -- still issues the loads of the prologue: inside its row)
   // a unit's 16 codes of a column: 32 bytes (MODE 0), 64 bytes (MODE 1); lane kb takes the half with blocks 8 kb .. 8 kb + 7
-  const uint4* wsrc = reinterpret_cast<const uint4*>(Wc + (size_t)min(ncol, N - 1) * (K >> 3) * NCL) +
-                      2 * NCL * min(u0, units - 1) + kb * NCL;
-  auto load_codes = [&](su32x4 (&dst)[NCL], int u) {
+  // (MODE 4: a unit's 16 codes are 48 bytes; lane kb takes bytes [24 kb, 24 kb + 24) as two 12-byte loads)
+  const char* wsrc_b = reinterpret_cast<const char*>(Wc) +
+                       (MODE == 4 ? (size_t)min(ncol, N - 1) * (size_t)(K >> 3) * 3 + (size_t)48 * min(u0, units - 1) + 24 * kb
+                                  : ((size_t)min(ncol, N - 1) * (K >> 3) * 2 * NCL + (size_t)32 * NCL * min(u0, units - 1) + 16 * NCL * kb));
+  auto load_codes = [&](CodeT (&dst)[NCL], int u) {
 #pragma unroll
-    for (int c = 0; c < NCL; ++c)
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[c]) : "v"(wsrc + 2 * NCL * u + c) : "memory");
+    for (int c = 0; c < NCL; ++c) {
+      if constexpr (MODE == 4)
+        asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(dst[c]) : "v"(wsrc_b + 48 * u + 12 * c) : "memory");
+      else
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[c]) : "v"(wsrc_b + 32 * NCL * u + 16 * c) : "memory");
+    }
   };
   // granule loader: instruction h fills LDS slots [64 h, 64 h + 64) of the granule; slot s = (row s >> 2, stored
   // piece s & 3) holds source piece (s & 3) ^ ((row >> 1) & 3) of that row's 64 bytes
@@ -163,22 +179,30 @@ __global__ __launch_bounds__(1024) void e8p_skinny_gemm_kernel(const f16* __rest
   su32x2 rawv;
   {
     const uint2* tsrc = (second || MODE == 3) ? &kST2Img.v[e] : reinterpret_cast<const uint2*>(grid) + e;   // (HI: no table, `grid` is not read)
+    if (MODE == 4 && wave >= 8) tsrc = reinterpret_cast<const uint2*>(grid2 + (e & ~1));            // residual table: entries e & ~1, e | 1
     asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rawv) : "v"(tsrc) : "memory");
   }
   // A register that a load is still going to write must never be a TIED asm operand ("+v") or cross a loop edge:
   // for either the compiler may emit a copy of it -- before the wait.  Loaded values are taken over by an asm that
   // waits and then moves them into fresh registers; only those are used afterwards.  (tools/check_inflight.py walks
   // the ISA for exactly this; tests/test_build_invariants.py runs it.)
-  su32x4 f0[NCL], f1[NCL], c2[NCL];
+  CodeT f0[NCL], f1[NCL], c2[NCL];
   load_codes(f0, 0);
   load_codes(f1, min(1, ulast));
-  auto take = [](su32x4 (&dst)[NCL], const su32x4 (&src)[NCL], auto nw) {
+  auto take = [](CodeT (&dst)[NCL], const CodeT (&src)[NCL], auto nw) {
 #pragma unroll
-    for (int c = 0; c < NCL; ++c)
-      asm volatile("s_waitcnt vmcnt(%8)\n\tv_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
-                   : "=&v"(dst[c].x), "=&v"(dst[c].y), "=&v"(dst[c].z), "=&v"(dst[c].w)
-                   : "v"(src[c].x), "v"(src[c].y), "v"(src[c].z), "v"(src[c].w), "n"(decltype(nw)::value)
-                   : "memory");
+    for (int c = 0; c < NCL; ++c) {
+      if constexpr (MODE == 4)
+        asm volatile("s_waitcnt vmcnt(%6)\n\tv_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5"
+                     : "=&v"(dst[c].x), "=&v"(dst[c].y), "=&v"(dst[c].z)
+                     : "v"(src[c].x), "v"(src[c].y), "v"(src[c].z), "n"(decltype(nw)::value)
+                     : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%8)\n\tv_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                     : "=&v"(dst[c].x), "=&v"(dst[c].y), "=&v"(dst[c].z), "=&v"(dst[c].w)
+                     : "v"(src[c].x), "v"(src[c].y), "v"(src[c].z), "v"(src[c].w), "n"(decltype(nw)::value)
+                     : "memory");
+    }
   };
   // tables: T1' = (4a | 1) ^ 0x80.., T2 = sign masks; 16 copies each (waves 0..7)
   uint2 raw;
@@ -190,12 +214,20 @@ __global__ __launch_bounds__(1024) void e8p_skinny_gemm_kernel(const f16* __rest
     const uint32_t t1x = (__builtin_amdgcn_perm(0u, raw.x, 0x03010200u) | 0x01010101u) ^ 0x80808080u;
     const uint32_t t1y = (__builtin_amdgcn_perm(0u, raw.y, 0x03010200u) | 0x01010101u) ^ 0x80808080u;
     const su32x2 val = {(second || MODE == 2) ? raw.x : t1x, (second || MODE == 2) ? raw.y : t1y};   // (D4: the fp16 entries as they are)
-    const uint32_t rowbase = (second ? (uint32_t)kST2 : (uint32_t)kST1) + (uint32_t)e * (kSRep * 8);
+    const uint32_t rowbase = (second ? (uint32_t)kST2 + (uint32_t)e * (kRep2 * 8) : (uint32_t)kST1 + (uint32_t)e * (kSRep * 8));
 #pragma unroll
     for (int c = 0; c < kSRep; ++c) {
-      const uint32_t copy = (uint32_t)(lane + c) & (kSRep - 1);
-      *reinterpret_cast<__attribute__((address_space(3))) su32x2*>((uintptr_t)(rowbase + copy * 8)) = val;
+      const uint32_t copy = (uint32_t)(lane + c) & (uint32_t)((second ? kRep2 : kSRep) - 1);
+      if (!second || c < kRep2)
+        *reinterpret_cast<__attribute__((address_space(3))) su32x2*>((uintptr_t)(rowbase + copy * 8)) = val;
     }
+  } else if (MODE == 4 && !second) {
+    // waves 8..15, lanes 0..31: residual entry e = 32 (wave & 7) + lane, 16 copies of 4 bytes
+    const uint32_t val = (e & 1) ? raw.y : raw.x;
+    const uint32_t rowbase = (uint32_t)kST3 + (uint32_t)e * (kSRep * 4);
+#pragma unroll
+    for (int c = 0; c < kSRep; ++c)
+      *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>((uintptr_t)(rowbase + (((uint32_t)(lane + c) & (kSRep - 1)) << 2))) = val;
   }
   __builtin_amdgcn_sched_barrier(0);
   // (a wave without units requests its three granules like the others: clamped addresses, never read)
@@ -204,14 +236,15 @@ __global__ __launch_bounds__(1024) void e8p_skinny_gemm_kernel(const f16* __rest
   __builtin_amdgcn_sched_barrier(0);
   using std::integral_constant;
   // the codes of units 0 and 1 have arrived (the granules were requested after them); tables written
-  su32x4 c0[NCL], c1[NCL];
+  CodeT c0[NCL], c1[NCL];
   take(c0, f0, integral_constant<int, kSDepth * L>{});
   take(c1, f1, integral_constant<int, kSDepth * L>{});
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   const uint32_t lane_c1 = (uint32_t)(lane & 15) << 3;
-  const uint32_t lane_c2 = lane_c1 | (uint32_t)kST2;
+  const uint32_t lane_c2 = (MODE == 4 ? (uint32_t)(lane & 7) << 3 : lane_c1) | (uint32_t)kST2;
+  const uint32_t lane_c3 = ((uint32_t)(lane & 15) << 2) | (uint32_t)kST3;
   // A fragment of MFMA t of a granule: row lane & 31, piece 2 kb + t
   const int arow = n & (MP - 1);
   const uint32_t rd0 = ring + (uint32_t)(arow * 64 + (((2 * kb + 0) ^ ((arow >> 1) & 3)) << 4));
@@ -289,6 +322,51 @@ __global__ __launch_bounds__(1024) void e8p_skinny_gemm_kernel(const f16* __rest
                                                  __builtin_bit_cast(sf16x8, weights(t[4], t[5], t[6], t[7])), acc, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   };
+  // MODE 4: dwords (main << 16 | residual index << 8) of this lane's two MFMAs
+  auto granule_rvq3 = [&](uint32_t dA, uint32_t dB, uint32_t boff, auto nw) {
+    constexpr int NW = decltype(nw)::value;
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NW) : "memory");
+    su32x4 A0, A1;
+    su32x2 t[4];
+    uint32_t r[2];
+    auto addr = [&](uint32_t d, uint32_t (&a)[3]) {
+      a[0] = ((d >> 17) & 0x7f80u) | lane_c1;     // main: abs index (16 copies x 8 bytes), sign byte (8 copies)
+      a[1] = ((d >> 10) & 0x3fc0u) | lane_c2;
+      a[2] = ((d >> 2) & 0x3fc0u) | lane_c3;      // residual index (16 copies x 4 bytes)
+    };
+    uint32_t aa[3], ab[3];
+    addr(dA, aa);
+    addr(dB, ab);
+    asm volatile("ds_read_b64 %0, %1" : "=v"(t[0]) : "v"(aa[0]));
+    asm volatile("ds_read_b64 %0, %1" : "=v"(t[1]) : "v"(aa[1]));
+    asm volatile("ds_read_b32 %0, %1" : "=v"(r[0]) : "v"(aa[2]));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(A0) : "v"(rd0 + boff));
+    asm volatile("ds_read_b64 %0, %1" : "=v"(t[2]) : "v"(ab[0]));
+    asm volatile("ds_read_b64 %0, %1" : "=v"(t[3]) : "v"(ab[1]));
+    asm volatile("ds_read_b32 %0, %1" : "=v"(r[1]) : "v"(ab[2]));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(A1) : "v"(rd1 + boff));
+    auto weights = [&](const su32x2& m1, const su32x2& m2, uint32_t c) -> su32x4 {
+      uint32_t m[4], w[4];
+      s_bytes_to_f16x4(m1.x ^ m2.x, m[0], m[1]);
+      s_bytes_to_f16x4(m1.y ^ m2.y, m[2], m[3]);
+      const f16x2 half2 = {(f16)0.5f, (f16)0.5f}, m12 = {(f16)-12.f, (f16)-12.f};
+      const uint32_t sh[4] = {c << 6, c << 2, c >> 2, c >> 6};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // nibble n = int4 of 2 x value: 0x4c00 | (n ^ 8) << 6 is 16 + (n ^ 8); x 0.5 - 12 = 0.5 ((n ^ 8) - 8), exact
+        const f16x2 res = __builtin_elementwise_fma(as_f16x2((sh[i] & 0x03c003c0u) ^ 0x4e004e00u), half2, m12);
+        w[i] = as_u32(__builtin_elementwise_fma(rs2, res, as_f16x2(m[i])));
+      }
+      return su32x4{w[0], w[1], w[2], w[3]};
+    };
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(t[0]), "+v"(t[1]), "+v"(r[0]), "+v"(A0));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sf16x8, A0),
+                                                 __builtin_bit_cast(sf16x8, weights(t[0], t[1], r[0])), acc, 0, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[2]), "+v"(t[3]), "+v"(r[1]), "+v"(A1));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sf16x8, A1),
+                                                 __builtin_bit_cast(sf16x8, weights(t[2], t[3], r[1])), acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
   // MODE 2: dword d = the four D4 code bytes of this lane's two MFMAs (two per MFMA: weights 0..3, 4..7 of the block)
   auto granule_d4 = [&](uint32_t d, uint32_t boff, auto nw) {
     constexpr int NW = decltype(nw)::value;
@@ -350,10 +428,21 @@ __global__ __launch_bounds__(1024) void e8p_skinny_gemm_kernel(const f16* __rest
       gA[0] = s01[0]; gA[2] = s01[1]; gA[1] = s23[0]; gA[3] = s23[1];
       gB[0] = gB[1] = gB[2] = gB[3] = 0u;
     } else {
+      su32x4 cd[2];
+      if constexpr (MODE == 4) {
+        // 12 landed bytes = four 3-byte codes [residual, e8p lo, e8p hi] -> dwords (main << 16 | residual << 8)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          cd[h] = su32x4{c0[h].x << 8, __builtin_amdgcn_perm(c0[h].y, c0[h].x, 0x0504030cu),
+                         __builtin_amdgcn_perm(c0[h].z, c0[h].y, 0x0403020cu), c0[h].z & 0xffffff00u};
+      } else {
+        cd[0] = su32x4{c0[0].x, c0[0].y, c0[0].z, c0[0][3]};
+        cd[1] = su32x4{c0[1].x, c0[1].y, c0[1].z, c0[1][3]};
+      }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const auto sx = __builtin_amdgcn_permlane32_swap(c0[h].x, c0[h].z, false, false);
-        const auto sy = __builtin_amdgcn_permlane32_swap(c0[h].y, c0[h].w, false, false);
+        const auto sx = __builtin_amdgcn_permlane32_swap(cd[h].x, cd[h].z, false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap(cd[h].y, cd[h].w, false, false);
         gA[h] = sx[0]; gB[h] = sy[0];           // granule h: blocks 4 h + 2 kb, + 1
         gA[2 + h] = sx[1]; gB[2 + h] = sy[1];   // granule 2 + h
       }
@@ -362,6 +451,7 @@ __global__ __launch_bounds__(1024) void e8p_skinny_gemm_kernel(const f16* __rest
       if constexpr (MODE == 0) granule(gA[i], (uint32_t)(rb * kGran), nw);
       else if constexpr (MODE == 1) granule_rvq(gA[i], gB[i], (uint32_t)(rb * kGran), nw);
       else if constexpr (MODE == 2) granule_d4(gA[i], (uint32_t)(rb * kGran), nw);
+      else if constexpr (MODE == 4) granule_rvq3(gA[i], gB[i], (uint32_t)(rb * kGran), nw);
       else granule_hi(gA[i], gB[i], (uint32_t)(rb * kGran), nw);
     };
     gran(0, integral_constant<int, 2 * L>{});
@@ -420,7 +510,7 @@ bool e8p_skinny_gemm_supported(int m, int n, int k) {
 // mode 0: E8P12 (16-bit codes), 1: E8P12RVQ4B (32-bit codes, resid_scale = the fp16 residual scale), 2: D4 (grid = the fp16
 // (256, 4) table), 3: HI (no table)
 static int skinny_launch_mode(int mode, const void* x, const void* qidxs, const void* grid, float resid_scale, void* y, int m,
-                              int n, int k, hipStream_t stream) {
+                              int n, int k, hipStream_t stream, const void* grid2 = nullptr) {
   if (!e8p_skinny_gemm_supported(m, n, k)) return QUIP_ERR_UNSUPPORTED;
   // few columns: one column block of 32 per workgroup and 16 slices of K (more workgroups, shorter chains per wave);
   // many columns: two column blocks x 8 slices
@@ -428,12 +518,12 @@ static int skinny_launch_mode(int mode, const void* x, const void* qidxs, const 
   //  how many rows the launch has)
   const bool one = (n + 63) / 64 < 2 * device_cu_count() / 3;
   auto go = [&](auto kern, int cols, int slot) -> int {
-    static DynLdsCache configured[16];   // per instantiation, per device
+    static DynLdsCache configured[20];   // per instantiation, per device
     if (ensure_dyn_lds(configured[slot], reinterpret_cast<const void*>(kern), kSLds) != QUIP_OK) return QUIP_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3((n + cols - 1) / cols, (m + 31) / 32), dim3(1024), kSLds, stream,
                        reinterpret_cast<const f16*>(x),
                        reinterpret_cast<const uint16_t*>(qidxs), reinterpret_cast<const uint64_t*>(grid),
-                       reinterpret_cast<f16*>(y), m, n, k, resid_scale);
+                       reinterpret_cast<f16*>(y), m, n, k, resid_scale, reinterpret_cast<const uint32_t*>(grid2));
     return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
   };
   if (mode == 1) {
@@ -443,6 +533,10 @@ static int skinny_launch_mode(int mode, const void* x, const void* qidxs, const 
   if (mode == 2) {
     if (m <= 16) return one ? go(e8p_skinny_gemm_kernel<1, 16, 2>, 32, 8) : go(e8p_skinny_gemm_kernel<2, 16, 2>, 64, 9);
     return one ? go(e8p_skinny_gemm_kernel<1, 32, 2>, 32, 10) : go(e8p_skinny_gemm_kernel<2, 32, 2>, 64, 11);
+  }
+  if (mode == 4) {
+    if (m <= 16) return one ? go(e8p_skinny_gemm_kernel<1, 16, 4>, 32, 16) : go(e8p_skinny_gemm_kernel<2, 16, 4>, 64, 17);
+    return one ? go(e8p_skinny_gemm_kernel<1, 32, 4>, 32, 18) : go(e8p_skinny_gemm_kernel<2, 32, 4>, 64, 19);
   }
   if (mode == 3) {
     if (m <= 16) return one ? go(e8p_skinny_gemm_kernel<1, 16, 3>, 32, 12) : go(e8p_skinny_gemm_kernel<2, 16, 3>, 64, 13);
@@ -460,6 +554,12 @@ int e8p_skinny_gemm_launch(const void* x, const void* qidxs, const void* grid, v
 int e8prvq4_skinny_gemm_launch(const void* x, const void* qidxs, const void* grid, float resid_scale, void* y, int m, int n,
                                int k, hipStream_t stream) {
   return skinny_launch_mode(1, x, qidxs, grid, resid_scale, y, m, n, k, stream);
+}
+
+int e8prvq3_skinny_gemm_launch(const void* x, const void* qidxs, const void* grid, const void* e81b_packed, float resid_scale,
+                               void* y, int m, int n, int k, hipStream_t stream) {
+  if (k % 32 != 0) return QUIP_ERR_UNSUPPORTED;
+  return skinny_launch_mode(4, x, qidxs, grid, resid_scale, y, m, n, k, stream, e81b_packed);
 }
 
 int d4_skinny_gemm_launch(const void* x, const void* qidxs, const void* grid_f16, void* y, int m, int n, int k, hipStream_t stream) {

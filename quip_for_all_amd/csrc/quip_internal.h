@@ -138,6 +138,9 @@ int e8p_skinny_gemm_launch(const void* x, const void* qidxs, const void* grid, v
 // the same for E8P12RVQ4B: 32-bit codes (main << 16 | residual), weight = fma(resid_scale, w_resid, w_main) in fp16
 int e8prvq4_skinny_gemm_launch(const void* x, const void* qidxs, const void* grid, float resid_scale, void* y, int m, int n,
                                int k, hipStream_t stream);
+// E8P12RVQ3B: 3-byte codes (n, 3 k / 8 bytes), e81b_packed = uint32 [256] (eight int4 = 2 x value per entry)
+int e8prvq3_skinny_gemm_launch(const void* x, const void* qidxs, const void* grid, const void* e81b_packed, float resid_scale,
+                               void* y, int m, int n, int k, hipStream_t stream);
 // D4: one-byte codes (n, k/4), grid = the fp16 (256, 4) table; HI: 32-bit codes of eight nibbles (n, k/8)
 int d4_skinny_gemm_launch(const void* x, const void* qidxs, const void* grid_f16, void* y, int m, int n, int k, hipStream_t stream);
 int hi_skinny_gemm_launch(const void* x, const void* qidxs, void* y, int m, int n, int k, hipStream_t stream);

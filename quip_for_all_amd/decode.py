@@ -127,7 +127,11 @@ class LlamaDecoder:
             raise NotImplementedError(f"partial rotary embeddings (factor {prf}) are not supported")
         if getattr(cfg, "sliding_window", None) and getattr(cfg, "use_sliding_window", True) and \
                 any(t != "full_attention" for t in (getattr(cfg, "layer_types", None) or ["sliding_attention"])):
-            raise NotImplementedError("sliding-window attention is not supported")
+            # a window that is never shorter than the context is full attention (Mistral-7B: 4096); beyond it the cache would
+            # have to be read as a ring, which the attention kernels do not do
+            if max_len > int(cfg.sliding_window):
+                raise NotImplementedError(f"sliding-window attention (window {cfg.sliding_window}) with max_len {max_len} > window "
+                                          "is not supported: use max_len <= the window")
         # rotary frequencies and attention scaling as the model computes them (llama3 / linear / yarn scaling change
         # inv_freq at every position; taking only rope_theta from the config would silently give other logits)
         self._inv_freq, self._att_scale = None, 1.0

@@ -54,6 +54,7 @@ _SCHEMAS = {
     "e8p_mm_skinny": "(Tensor x, Tensor Qidxs, Tensor grid) -> Tensor",
     # the same for E8P12RVQ4B: int32 codes (main << 16 | residual), weights = fp16 fma(scale, residual, main)
     "e8prvq4_mm_skinny": "(Tensor x, Tensor Qidxs, Tensor grid, float scale) -> Tensor",
+    "e8prvq3_mm_skinny": "(Tensor x, Tensor Qidxs, Tensor grid, Tensor grid2, float scale) -> Tensor",   # packed 3-byte codes
     "d4_mm_skinny": "(Tensor x, Tensor Qidxs, Tensor grid) -> Tensor",      # uint8 codes (n, k/4), the fp16 (256, 4) table
     "hi_mm_skinny": "(Tensor x, Tensor Qidxs) -> Tensor",                   # int32 codes (n, k/8), eight nibbles each
     # E8P12RVQ3B on the matrix-core GEMV: Qidxs = the checkpoint's 3-byte codes (int32 (n, 3k/32)), e81b_i8 = int8 (256, 8)
@@ -835,6 +836,23 @@ def _skinny_generic(fn, what, x, Qidxs, qdtype, per_code, extra):
     return y
 
 
+def _e8prvq3_mm_skinny_cuda(x, Qidxs, grid, grid2, scale):
+    g = _grid_i64(grid, x)
+    _need(grid2.dtype == torch.int32 and grid2.numel() == 256, "e81b_grid_packed must be int32[256]")
+    g2 = grid2.contiguous()
+    xc = _chk_x(x)
+    Qc = _chk_q(Qidxs, torch.int32)
+    m, k, n = xc.shape[0], xc.shape[1], Qc.shape[0]
+    _need(Qc.shape[1] * 32 == 3 * k, f"e8prvq3_mm_skinny: x has {k} columns but Qidxs {tuple(Qidxs.shape)} encodes {Qc.shape[1] * 32 // 3}")
+    _need(Qc.device == x.device and g2.device == x.device, "Qidxs, grid2 and x must be on the same device")
+    _need(e8p_mm_skinny_supported(m, n, k), f"e8prvq3_mm_skinny: shape ({m}, {n}, {k}) needs k % 128 == 0, n % 2 == 0")
+    y = _empty((m, n), dtype=torch.float16, device=x.device)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().quip_e8prvq3_mm_skinny(xc.data_ptr(), Qc.data_ptr(), g.data_ptr(), g2.data_ptr(), float(scale),
+                                                     y.data_ptr(), m, n, k, _stream(x)), "quip_e8prvq3_mm_skinny")
+    return y
+
+
 def _d4_mm_skinny_cuda(x, Qidxs, grid):
     g = _d4_grid_f16(grid)
     return _skinny_generic("quip_d4_mm_skinny", "d4_mm_skinny", x, Qidxs, torch.uint8, 4, lambda: (g.data_ptr(),))
@@ -988,6 +1006,7 @@ _IMPLS = {
     "e8p_mm_batched": _e8p_mm_batched_cuda,
     "e8p_mm_skinny": _e8p_mm_skinny_cuda,
     "e8prvq4_mm_skinny": _e8prvq4_mm_skinny_cuda,
+    "e8prvq3_mm_skinny": _e8prvq3_mm_skinny_cuda,
     "d4_mm_skinny": _d4_mm_skinny_cuda,
     "hi_mm_skinny": _hi_mm_skinny_cuda,
     "e8p_mm_planes_rows": _e8p_mm_planes_rows_cuda,
@@ -1084,6 +1103,7 @@ _reg_fake("rope_attn_decode_z", lambda zs, posts, scales, cos, sin, pos, kcache,
           kcache.new_empty((zs[0].numel() // kcache.shape[2], kcache.shape[2])))
 _reg_fake("e8p_mm_skinny", lambda x, Q, g: x.new_empty((x.shape[0], Q.shape[0]), dtype=torch.float16))
 _reg_fake("e8prvq4_mm_skinny", lambda x, Q, g, s: x.new_empty((x.shape[0], Q.shape[0]), dtype=torch.float16))
+_reg_fake("e8prvq3_mm_skinny", lambda x, Q, g, g2, s: x.new_empty((x.shape[0], Q.shape[0]), dtype=torch.float16))
 _reg_fake("d4_mm_skinny", lambda x, Q, g: x.new_empty((x.shape[0], Q.shape[0]), dtype=torch.float16))
 _reg_fake("hi_mm_skinny", lambda x, Q: x.new_empty((x.shape[0], Q.shape[0]), dtype=torch.float16))
 _reg_fake("e8p_mm_batched", lambda x, Q, g: x.new_empty((x.shape[0], Q.shape[0]), dtype=torch.float16))

@@ -78,12 +78,12 @@ def test_other_codebooks_regimes(cb_name):
     assert layer.regime(1) == "gemv_planes"
     for m in (2, 5, 16, 31):
         # E8P12RVQ4B beyond one exact pass: the single-pass fp16 skinny kernel in its RVQ4 mode (round 3)
-        # beyond one exact pass: the single-pass fp16 skinny kernel in the codebook's mode (round 3; E8P12RVQ3B: not yet)
-        want = "skinny_fp16" if cb_name != "E8P12RVQ3B" and m > 5 else "rows_exact"
+        # beyond one exact pass: the single-pass fp16 skinny kernel in the codebook's mode (round 3)
+        want = "skinny_fp16" if m > 5 else "rows_exact"
         assert layer.regime(m) == want, (m, layer.regime(m))
     for m in (32, 2048):
         assert layer.regime(m) == "codebook"
-    assert layer.codebook.batched_regime(32, 4096, 4096) == ("decompress_gemm" if cb_name == "E8P12RVQ3B" else "skinny_chunks")
+    assert layer.codebook.batched_regime(32, 4096, 4096) == "skinny_chunks"
     assert layer.codebook.batched_regime(2048, 4096, 4096) == "decompress_gemm"
 
 

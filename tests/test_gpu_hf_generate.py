@@ -141,3 +141,7 @@ def test_fast_decoder_takes_the_models_rotary_embedding(tmp_path):
     q.config.sliding_window, q.config.layer_types = 16, ["sliding_attention"] * q.config.num_hidden_layers
     with pytest.raises(NotImplementedError):
         LlamaDecoder.from_hf(q, max_len=48)
+    # ... but a window that is never shorter than the context is full attention (Mistral-7B's 4096): accepted, same tokens
+    q.config.sliding_window = 48
+    dec2 = LlamaDecoder.from_hf(q, max_len=48)
+    assert torch.equal(dec2.generate(10, prompt=prompt), toks)

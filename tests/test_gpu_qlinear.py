@@ -401,11 +401,11 @@ def test_single_pass_skinny_kernel_rvq4(fin, fout, M):
     assert np.all(np.abs(y.cpu().numpy().astype(np.float64) - ref) <= O.ulp_bound(P, x64m, What))
 
 
-@pytest.mark.parametrize("cbid", ["D4", "HI"])
+@pytest.mark.parametrize("cbid", ["D4", "HI", "E8P12RVQ3B"])
 @pytest.mark.parametrize("fin,fout,M", [(4096, 4096, 6), (4096, 4096, 31), (4096, 11008, 17), (11008, 4096, 9), (256, 688, 12),
                                         (4096, 4096, 100), (1024, 512, 40)])
 def test_single_pass_skinny_kernel_d4_hi(cbid, fin, fout, M):
-    """D4 and HI through the skinny kernel's table / nibble modes: the weights are the dense W of the reference's decompress
+    """D4, HI and E8P12RVQ3B through the skinny kernel's table / nibble / 3-byte modes: the weights are the dense W of the reference's decompress
     bit for bit (identity rows), the product agrees with float64 of the same fp16 operands, the module sits inside the stated
     bound, rows do not depend on their batch"""
     P = O.make_layer(cbid, fin, fout, seed=fin + fout + 2)
@@ -418,7 +418,7 @@ def test_single_pass_skinny_kernel_d4_hi(cbid, fin, fout, M):
     xh = torch.from_numpy(rng.standard_normal((M, k)).astype(np.float16)).to(DEV)
     z = cb.mm_skinny(xh, layer.Qidxs)
     Wd = cb.decompress_weight(layer.Qidxs)
-    Wq = O.decompress(cbid, P.Qidxs).astype(np.float64)
+    Wq = O.decompress(cbid, P.Qidxs, getattr(cb, "opt_resid_scale", 0.0)).astype(np.float64)
     assert np.array_equal(Wd.cpu().numpy().astype(np.float64), Wq)
     x64 = xh.cpu().numpy().astype(np.float64)
     z64 = x64 @ Wq.T
