@@ -119,9 +119,8 @@ def engine_roofline(dec):
     s = dec.s
     h = dec.embed[:1].reshape(-1).clone()
     pos = torch.full((1,), 64, dtype=torch.long, device=dev)
-    grid = dec.layers[0]["q"].codebook.grid_packed_abs
-    args = (dec.eng_layers, h, pos, dec.cos, dec.sin, grid, dec.eng_ws, len(dec.layers), dec.max_len, s.rms_eps,
-            1.0 / math.sqrt(s.head_dim))
+    args = (dec.eng_layers, h, pos, dec.cos, dec.sin, dec.eng_grid, dec.eng_ws, len(dec.layers), dec.max_len, s.rms_eps,
+            1.0 / math.sqrt(s.head_dim), None, -1, dec.eng_codebook)
     torch.ops.quip_lib.block_engine(*args)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()

@@ -111,7 +111,7 @@ struct BLds {
   static constexpr int kCs = kArea + kAreaBytes;             // float [2][128]: the rotary row of this token (cos | sin), the same for every block
   static constexpr int kBytes = kCs + 2 * HD * 4;
 };
-static_assert(BLds<16>::kBytes <= 160 * 1024, "LDS budget");
+static_assert(BLds<16>::kBytes <= 160 * 1024 && BLds<64>::kBytes <= 160 * 1024, "LDS budget");
 
 template <int REP>
 __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
@@ -165,8 +165,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         vo_d2b = (uint32_t)(((w * RPW + n) * kRowU4D + off) * 16);
       }
     }
-    lane_c = (Lds<REP>::kRep1 == 32) ? ((((uint32_t)lane & 31u) << 3) | 0x00010000u)
-                                     : ((((uint32_t)lane & 15u) << 3) | (uint32_t)Lds<REP>::kT1);
+    lane_c = Lds<REP>::kD4 ? ((uint32_t)lane << 2)
+             : (Lds<REP>::kRep1 == 32) ? ((((uint32_t)lane & 31u) << 3) | 0x00010000u)
+                                       : ((((uint32_t)lane & 15u) << 3) | (uint32_t)Lds<REP>::kT1);
     lane_c2 = (((uint32_t)lane & 15u) << 3) | (uint32_t)Lds<REP>::kT2;
     xlane = (uint32_t)BLds<REP>::kArea + (uint32_t)min(n, 2) * (uint32_t)HID + (uint32_t)q * 64u + (uint32_t)wave * 512u;
   };
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 
   // ---- prologue ---------------------------------------------------------------------------------------------------
   u32x2 tsrc;
-  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(tsrc) : "v"(table_source_ptr(a.grid, lane, wave)) : "memory");
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(tsrc) : "v"(T::kD4 ? table_source_ptr_d4(a.grid, lane, wave) : table_source_ptr(a.grid, lane, wave)) : "memory");
   uint32_t gen;
   esync::ld4(gen, ctl);
   u32x4 hpiece;
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   auto publish16 = [&](int vec, int gr0, int row0, int sh, uint32_t tag) {      // gr0: first granule of the block in its vector
     if (tid < 8) {
       const int* s3 = accs + (row0 + 2 * tid) * 4;
-      const float us = unscale_of(sh, 2);
+      const float us = unscale_of(sh, T::kD4 ? 1 : 2);      // table entries are 4 w (E8P12) / 2 w (D4)
       const float f0 = __builtin_fmaf((float)s3[0], 65536.f, __builtin_fmaf((float)s3[1], 256.f, (float)s3[2]));
       const float f1 = __builtin_fmaf((float)s3[4], 65536.f, __builtin_fmaf((float)s3[5], 256.f, (float)s3[6]));
       esync::st_granule(zbufs + (size_t)vec * 2048 + gr0 + tid, pack_f16(f0 * us, f1 * us), tag);
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   auto run_item = [&](int s, uint32_t xa, int accrow) {
     ItemAddr ad;
     item_addresses<REP>(qa[s], qb[s], lane_c, lane_c2, ad, 0u);
-    const i32x4 r = item_mfma(ad, xa);
+    const i32x4 r = T::kD4 ? item_mfma_d4(ad, xa) : item_mfma(ad, xa);
     if (q == 0) {
       int* dst = accs + (accrow + n) * 4;
       __hip_atomic_fetch_add(dst + 0, r.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   auto decode_item = [&](int s, i32x4 (&Bf)[8]) {
     ItemAddr ad;
     item_addresses<REP>(qa[s], qb[s], lane_c, lane_c2, ad, 0u);
-    item_decode(ad, Bf);
+    if constexpr (T::kD4) item_decode_d4(ad, Bf); else item_decode(ad, Bf);
   };
   auto add_rows = [&](const i32x4& r, int accrow) {
     if (q == 0) {
@@ -726,7 +727,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         const int m = tid / 48;
         const int* s3 = accs + (64 + tid) * 4;
         const float f = __builtin_fmaf((float)s3[0], 65536.f, __builtin_fmaf((float)s3[1], 256.f, (float)s3[2]));
-        zcol[tid] = (float)(f16)(f * unscale_of(shs[m], 2));
+        zcol[tid] = (float)(f16)(f * unscale_of(shs[m], T::kD4 ? 1 : 2));
       }
       had::wg_barrier<true>();
       zero_acc(64, 96);
@@ -996,7 +997,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         if (sl < JD) {
           ItemAddr ad;
           item_addresses<REP>(qa[6 + i], qb[6 + i], lane_c, lane_c2, ad, 0u);
-          add_rows(item_mfma<272>(ad, xlane_d + (uint32_t)(sl * 544)), 160);
+          add_rows(T::kD4 ? item_mfma_d4<272>(ad, xlane_d + (uint32_t)(sl * 544)) : item_mfma<272>(ad, xlane_d + (uint32_t)(sl * 544)), 160);
         }
       }
       had::wg_barrier<true>();
@@ -1051,12 +1052,16 @@ int block_engine_launch(const BlockEngineArgs& in, hipStream_t stream) {
   a.dbg = reinterpret_cast<uint64_t*>(in.dbg);
   a.n_layers = in.n_layers; a.max_len = in.max_len; a.dbg_layer = in.dbg_layer;
   a.rms_eps = in.rms_eps; a.attn_scale = in.attn_scale;
-  auto kern = decode_block_kernel<16>;
-  const int lds = BLds<16>::kBytes;
-  static DynLdsCache configured;
-  if (ensure_dyn_lds(configured, reinterpret_cast<const void*>(kern), lds) != QUIP_OK) return QUIP_ERR_LAUNCH;
-  hipLaunchKernelGGL(kern, dim3(NWG), dim3(kThreads), lds, stream, a);
-  return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+  // codebook 0: E8P12 (16 copies of both tables), 1: D4 (one table of 256 x 4 bytes, a private copy per lane)
+  auto go = [&](auto kern, int lds, DynLdsCache& configured) -> int {
+    if (ensure_dyn_lds(configured, reinterpret_cast<const void*>(kern), lds) != QUIP_OK) return QUIP_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(NWG), dim3(kThreads), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+  };
+  static DynLdsCache c16, c64;
+  if (in.codebook == 1) return go(decode_block_kernel<64>, BLds<64>::kBytes, c64);
+  if (in.codebook != 0) return QUIP_ERR_UNSUPPORTED;
+  return go(decode_block_kernel<16>, BLds<16>::kBytes, c16);
 }
 
 }  // namespace quip

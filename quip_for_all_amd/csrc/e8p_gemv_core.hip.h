@@ -252,13 +252,14 @@ __device__ __forceinline__ uint32_t lds_read4(uint32_t addr) {
 }
 
 // D4: the B fragment of a step is four 4-byte table entries, no sign fix-up
+template <int HALF = 256>
 __device__ __forceinline__ i32x4 item_mfma_d4(const ItemAddr& ad, uint32_t xaddr) {
   constexpr int PIPE = QUIP_GEMV_PIPE;
   i32x4 B[8], A[8];
   auto issue = [&](int t) {
     B[t] = i32x4{(int)lds_read4(ad.a1l[t]), (int)lds_read4(ad.a2l[t]), (int)lds_read4(ad.a1h[t]),
                  (int)lds_read4(ad.a2h[t])};
-    A[t] = lds_read16i(xaddr + (t < 4 ? 16 * t : 256 + 16 * (t - 4)));
+    A[t] = lds_read16i(xaddr + (t < 4 ? 16 * t : HALF + 16 * (t - 4)));
   };
 #pragma unroll
   for (int t = 0; t < PIPE; ++t) issue(t);
@@ -306,6 +307,11 @@ __device__ __forceinline__ void item_decode(const ItemAddr& ad, i32x4 (&B)[8]) {
     const uint2 t1h = lds_read8(ad.a1h[t]), t2h = lds_read8(ad.a2h[t]);
     B[t] = i32x4{(int)(t1l.x ^ t2l.x), (int)(t1l.y ^ t2l.y), (int)(t1h.x ^ t2h.x), (int)(t1h.y ^ t2h.y)};
   }
+}
+__device__ __forceinline__ void item_decode_d4(const ItemAddr& ad, i32x4 (&B)[8]) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+    B[t] = i32x4{(int)lds_read4(ad.a1l[t]), (int)lds_read4(ad.a2l[t]), (int)lds_read4(ad.a1h[t]), (int)lds_read4(ad.a2h[t])};
 }
 template <int HALF = 256>
 __device__ __forceinline__ i32x4 item_multiply(const i32x4 (&B)[8], uint32_t xaddr) {

@@ -206,8 +206,11 @@ class LlamaDecoder:
             from .register_lib import ffn_engine_workspace
             self.ffn_ws = ffn_engine_workspace(s.ffn, L0["gate"].K_right, self.dev)
         # all blocks of a token as ONE persistent launch (csrc/decode_block.hip); QUIP_BLOCK_ENGINE=0 keeps the stage-wise step
+        # (E8P12, and D4 through the same kernel's one-table mode)
         self.block_eng = False
-        if self.ffn_eng and os.environ.get("QUIP_BLOCK_ENGINE", "1") != "0":
+        d4 = all(getattr(m.codebook, "id", None) == "D4" for m in L0.values() if isinstance(m, QuantLinear))
+        if ((self.ffn_eng or (d4 and self.fused_prologue and self.chain and os.environ.get("QUIP_FFN_ENGINE", "1") != "0"))
+                and os.environ.get("QUIP_BLOCK_ENGINE", "1") != "0"):
             self._init_block_engine()
         # q / k / v output transforms inside the attention launch (multi-head attention, power-of-two hidden <= 4096,
         # plain SV output side)
@@ -226,8 +229,12 @@ class LlamaDecoder:
         L0 = self.layers[0]
         names = ("q", "k", "v", "o", "gate", "up", "down")
 
+        cbid = getattr(L0["q"].codebook, "id", None)
+        if cbid not in ("E8P12", "D4"):
+            return
+
         def plain(m, n_in, n_out):
-            return (getattr(m.codebook, "id", None) == "E8P12" and not m.per_channel and m.bias is None and not m.training
+            return (getattr(m.codebook, "id", None) == cbid and not m.per_channel and m.bias is None and not m.training
                     and m.SU is not None and m.SV is not None and m.in_features == m.q_in_features == n_in
                     and m.out_features == m.q_out_features == n_out)
         ok = block_engine_supported(s.hidden, s.heads, s.kv_heads, s.head_dim, s.ffn, L0["gate"].K_right)
@@ -253,6 +260,8 @@ class LlamaDecoder:
         self._eng_keep = keep
         self.eng_layers = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).to(self.dev)
         self.eng_ws = block_engine_workspace(self.dev)
+        self.eng_codebook = 1 if cbid == "D4" else 0
+        self.eng_grid = L0["q"].codebook.grid if cbid == "D4" else L0["q"].codebook.grid_packed_abs
         self.block_eng = True
 
     def engine_status(self):
@@ -308,8 +317,8 @@ class LlamaDecoder:
             mask = (self.arange[None, None, None, :] <= self.pos)      # (1,1,1,max_len) keys <= current
         if getattr(self, "block_eng", False):
             h = torch.ops.quip_lib.block_engine(self.eng_layers, h.reshape(-1), self.pos, self.cos, self.sin,
-                                                self.layers[0]["q"].codebook.grid_packed_abs, self.eng_ws,
-                                                len(self.layers), self.max_len, s.rms_eps, 1.0 / math.sqrt(s.head_dim))
+                                                self.eng_grid, self.eng_ws, len(self.layers), self.max_len, s.rms_eps,
+                                                1.0 / math.sqrt(s.head_dim), None, -1, self.eng_codebook)
             return self._head(h.reshape(1, -1))
         if self.fused_prologue:
             return self._step_fused(h, cos, sin, mask)

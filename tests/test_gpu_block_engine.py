@@ -13,14 +13,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _decoder(layers, block_engine, ffn_engine=True, max_len=48, seed=3):
+def _decoder(layers, block_engine, ffn_engine=True, max_len=48, seed=3, codebook="E8P12"):
     from quip_for_all_amd import decode as D
     shape = D.LlamaShape(hidden=4096, ffn=11008, layers=layers, heads=32, kv_heads=32, vocab=2048)
     old = {k: os.environ.get(k) for k in ("QUIP_BLOCK_ENGINE", "QUIP_FFN_ENGINE")}
     os.environ["QUIP_BLOCK_ENGINE"] = "1" if block_engine else "0"
     os.environ["QUIP_FFN_ENGINE"] = "1" if ffn_engine else "0"
     try:
-        dec = D.LlamaDecoder(shape, "E8P12", max_len=max_len, device=DEV, seed=seed, device_init=True)
+        dec = D.LlamaDecoder(shape, codebook, max_len=max_len, device=DEV, seed=seed, device_init=True)
     finally:
         for k, v in old.items():
             if v is None:
@@ -120,3 +120,27 @@ def test_block_engine_long_context_split_attention(pos0):
                 assert d <= 2.0 ** -6 * cb_[1, :, p].float().abs().max().item(), d
             with torch.no_grad():
                 a.tok.copy_(b.tok)                        # keep the two on the same token whatever a near tie decides
+
+
+def test_block_engine_d4_matches_stagewise():
+    """the D4 codebook through the same persistent launch (one table of 256 x 4 bytes, a private copy per lane): against the
+    plain stage-wise step of the same model -- logits to the MLP edge's rounding, the same greedy tokens"""
+    a = _decoder(2, True, max_len=40, codebook="D4")
+    c = _decoder(2, False, ffn_engine=False, max_len=40, codebook="D4")
+    _same_weights(c, a)
+    assert a.block_eng and a.eng_codebook == 1 and not c.block_eng and not c.ffn_eng
+    for dec in (a, c):
+        dec.reset(first_token=5)
+    with torch.no_grad():
+        for t in range(4):
+            la = a.step().float().clone()
+            lc = c.step().float().clone()
+            assert a.engine_status() == 0
+            assert (la - lc).abs().max().item() <= 2.0 ** -8 * lc.abs().max().item(), (t, (la - lc).abs().max().item())
+            a.tok.copy_(c.tok)
+    ta = a.generate(24, first_token=5, use_graph=True).cpu().numpy()
+    tc = c.generate(24, first_token=5, use_graph=True).cpu().numpy()
+    assert a.engine_status() == 0
+    same = int((ta == tc).sum())
+    print(f"D4: greedy tokens equal: {same} / {len(ta)}")
+    assert same >= len(ta) - 2          # (a near tie may go the other way: the MLP edge rounds its block exponent differently)

@@ -25,7 +25,7 @@ names = ["(top)", "z_d gathered + burst A", "edge: out(down) + in(q,k,v)", "gemv
          "attention + publish a", "a gathered", "in(o)", "gemv o + publish", "z_o gathered", "edge: out(o) + in(gate,up)",
          "gemv gate,up", "kmix + publish (mlp hop 1)", "row owner", "rows gathered", "kmix_in + planes", "gemv down + publish"]
 acc = []
-args = (dec.eng_layers, h, dec.pos, dec.cos, dec.sin, dec.layers[0]["q"].codebook.grid_packed_abs, dec.eng_ws, layers, dec.max_len,
+args = (dec.eng_layers, h, dec.pos, dec.cos, dec.sin, dec.eng_grid, dec.eng_ws, layers, dec.max_len,
         shape.rms_eps, 1.0 / math.sqrt(128))
 for it in range(6):
     dbg.zero_()
