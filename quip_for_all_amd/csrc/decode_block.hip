@@ -387,6 +387,26 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     }
   };
 
+  // three items of one K slice (the row blocks of a matrix share the slice's A fragments; xa differs between items only where
+  // a workgroup's row blocks straddle two matrices: re-read then -- a uniform branch)
+  auto run_items3 = [&](int s0, uint32_t xa0, uint32_t xa1, uint32_t xa2, int accrow0) {
+    i32x4 A[8];
+    item_fragments(xa0, A);
+    const uint32_t xas[3] = {xa0, xa1, xa2};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (i > 0 && xas[i] != xas[i - 1]) item_fragments(xas[i], A);
+      ItemAddr ad;
+      item_addresses<REP>(qa[s0 + i], qb[s0 + i], lane_c, lane_c2, ad, 0u);
+      const i32x4 r = item_mfma_shared<T::kD4>(ad, A);
+      if (q == 0) {
+        int* dst = accs + (accrow0 + 16 * i + n) * 4;
+        __hip_atomic_fetch_add(dst + 0, r.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(dst + 1, r.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(dst + 2, r.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  };
   // the same item in two halves: the table lookups while a hand-off is awaited (the codes are there long before the digits),
   // the eight MFMAs once the digit planes exist
   auto decode_item = [&](int s, i32x4 (&Bf)[8]) {
@@ -420,10 +440,11 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     BSTAMP(2);
     esync::drain();                                    // q, k, v have landed (requested one transform stage ago)
     own_slots(SLOTS(0x007u));
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int ci = (3 * w + i) >> 8;
-      run_item(i, xlane + (uint32_t)((ci == c_lo ? 0 : 1) * 3 * HID), i * 16);
+    {
+      const uint32_t x0 = xlane + (uint32_t)((((3 * w) >> 8) == c_lo ? 0 : 1) * 3 * HID);
+      const uint32_t x1 = xlane + (uint32_t)((((3 * w + 1) >> 8) == c_lo ? 0 : 1) * 3 * HID);
+      const uint32_t x2 = xlane + (uint32_t)((((3 * w + 2) >> 8) == c_lo ? 0 : 1) * 3 * HID);
+      run_items3(0, x0, x1, x2, 0);
     }
     had::wg_barrier<true>();
     ++hop;                                             // hand-off: z_q, z_k, z_v
@@ -712,10 +733,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     }
     esync::drain();
     own_slots(SLOTS(0x03fu));
-#pragma unroll
-    for (int i = 0; i < FRB; ++i) run_item(i, xlane, 64 + i * 16);
-#pragma unroll
-    for (int i = FRB; i < 2 * FRB; ++i) run_item(i, xlane + (uint32_t)(3 * HID), 64 + i * 16);
+    static_assert(FRB == 3, "three row blocks per matrix");
+    run_items3(0, xlane, xlane, xlane, 64);
+    run_items3(FRB, xlane + (uint32_t)(3 * HID), xlane + (uint32_t)(3 * HID), xlane + (uint32_t)(3 * HID), 64 + 16 * FRB);
     had::wg_barrier<true>();
     BSTAMP(12);
 

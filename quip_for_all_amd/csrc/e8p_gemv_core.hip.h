@@ -324,5 +324,47 @@ __device__ __forceinline__ i32x4 item_multiply(const i32x4 (&B)[8], uint32_t xad
   return acc;
 }
 
+// Items of one K slice that multiply the same digit planes (the row blocks of a matrix) share their A fragments: read once
+// (item_fragments), then item_mfma_shared() per item -- the lookups of item_mfma() without its eight 16-byte plane reads.
+template <int HALF = 256>
+__device__ __forceinline__ void item_fragments(uint32_t xaddr, i32x4 (&A)[8]) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) A[t] = lds_read16i(xaddr + (t < 4 ? 16 * t : HALF + 16 * (t - 4)));
+}
+template <bool D4>
+__device__ __forceinline__ i32x4 item_mfma_shared(const ItemAddr& ad, const i32x4 (&A)[8]) {
+  constexpr int PIPE = QUIP_GEMV_PIPE;
+  i32x4 acc = {0, 0, 0, 0};
+  if constexpr (D4) {
+    i32x4 B[8];
+    auto issue = [&](int t) {
+      B[t] = i32x4{(int)lds_read4(ad.a1l[t]), (int)lds_read4(ad.a2l[t]), (int)lds_read4(ad.a1h[t]), (int)lds_read4(ad.a2h[t])};
+    };
+#pragma unroll
+    for (int t = 0; t < PIPE; ++t) issue(t);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (t + PIPE < 8) issue(t + PIPE);
+      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t], B[t], acc, 0, 0, 0);
+    }
+  } else {
+    uint2 o[8][4];
+    auto issue = [&](int t) {
+      o[t][0] = lds_read8(ad.a1l[t]); o[t][1] = lds_read8(ad.a2l[t]);
+      o[t][2] = lds_read8(ad.a1h[t]); o[t][3] = lds_read8(ad.a2h[t]);
+    };
+#pragma unroll
+    for (int t = 0; t < PIPE; ++t) issue(t);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (t + PIPE < 8) issue(t + PIPE);
+      const i32x4 B = {(int)(o[t][0].x ^ o[t][1].x), (int)(o[t][0].y ^ o[t][1].y), (int)(o[t][2].x ^ o[t][3].x),
+                       (int)(o[t][2].y ^ o[t][3].y)};
+      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t], B, acc, 0, 0, 0);
+    }
+  }
+  return acc;
+}
+
 }  // namespace
 }  // namespace quip
