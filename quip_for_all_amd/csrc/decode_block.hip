@@ -87,31 +87,34 @@ struct BLds {
   static constexpr int KKP = (FK * FK + 7) & ~7, KP16 = 48;
   static constexpr int kAcc = T::kAcc;                       // int32 [176][4]: q k v (48) | o (16) | gate up (96) | down (16)
   static constexpr int kAccRows = 176;
-  static constexpr int kHad = kAcc + kAccRows * 16;          // fp16 had3 image
-  static constexpr int kHadElems = 2 * KKP + KP16 * KP16;
-  static constexpr int kZcol = kHad + kHadElems * 2;         // float [2][48]: z of this column (MLP)
+  static constexpr int kZcol = kAcc + kAccRows * 16;         // float [2][48]: z of this column (MLP)
   static constexpr int kRed = kZcol + 2 * 48 * 4;            // float [64] reduction scratch, int [8] shift words
   static constexpr int kDesc = kRed + 256 + 32;              // the current block's descriptor (256 bytes): pointers are read
                                                              // from here, not from memory (a vector load of a pointer ahead of
                                                              // every request would wait for the requests before it)
-  static constexpr int kVec = kDesc + 256;                   // row owner: SV_gate, SV_up, SU_down rows (fp16 [3][256])
-  static constexpr int kH = kVec + 3 * FL * 2;               // fp16 [4096]: residual stream
+  static constexpr int kH = kDesc + 256;                     // fp16 [4096]: residual stream
   static constexpr int kQkv = kH + HID * 2;                  // fp16 [3][128]: this head's q, k, v; [128] attention output
-  static constexpr int kR = kQkv + 4 * HD * 2;               // region R
-  // region R: [buf0: FHT shuffle buffer of group 0][area: digit planes (3 x 3 x 4096) | group 1's buffer | gathered vector |
-  //            MLP rows | down's planes | attention partials]
-  static constexpr int kBuf0 = kR;
+  static constexpr int kCs = kQkv + 4 * HD * 2;              // float [2][128]: the rotary row of this token (cos | sin), the same for every block
+  // ONE transient area for everything that lives between two products (E8P12: T1 x 32 + T2 x 16 = 96 KB of tables leave 50.3 KB).
+  // In time: the transforms' exchange buffers (16.5 KB per transform from the base: 1, 2 or -- attention -- 3) -> digit planes
+  // of the consumers (12 / 24 KB from the base, written after the transforms' last reads) | attention partials; for the MLP:
+  // planes [0, 24 K) + the K x K factor image [24 K, 36 K) + the row owners' vectors [36 K, 48 K) -> row owners: inbox rows
+  // [0, 8 K), rows on the way out [8 K, 16 K) -> the gathered rows [0, 48 K) (the factor image is in registers by then) ->
+  // down's planes [0, 35.1 K).
+  static constexpr int kArea = kCs + 2 * HD * 4;
   static constexpr int kBufBytes = ((had::buf_floats(HID) * 4) + 15) & ~15;
-  static constexpr int kArea = kBuf0 + kBufBytes;
-  static constexpr int kAreaBytes = 50 * 1024;               // >= 36 KB planes, 48 KB MLP rows, 35.1 KB down planes
-  static constexpr int kBuf1 = kArea + 3 * 3 * HID - kBufBytes;   // tail of the planes area (dead before any plane is written there)
-  static constexpr int kStage = kArea + 24 * 1024;            // MLP row owners: their eight rows, transposed, on the way out (8 KB)
-  static constexpr int kStash = kArea + 36 * 1024;            // MLP row owners: SV_gate / SV_up / SU_down of their eight rows (12 KB)
+  static constexpr int kAreaBytes = (160 * 1024 - kArea) & ~15;
+  static constexpr int kBuf0 = kArea;
+  static constexpr int kHadElems = 2 * KKP + KP16 * KP16;
+  static constexpr int kStage = kArea + 8 * 1024;            // MLP row owners: their four rows, transposed, on the way out (4 KB)
+  static constexpr int kHad = kArea + 24 * 1024;             // fp16 image of the three K x K factors (12 KB)
+  static constexpr int kStash = kArea + 36 * 1024;           // MLP row owners: SV_gate / SV_up / SU_down of their rows (6 KB)
   static constexpr int kPlaneD = (KPD / 256) * 272;
-  static constexpr int kCs = kArea + kAreaBytes;             // float [2][128]: the rotary row of this token (cos | sin), the same for every block
-  static constexpr int kBytes = kCs + 2 * HD * 4;
+  static constexpr int kBytes = kArea + kAreaBytes;
+  static_assert(kAreaBytes >= 3 * kBufBytes && kAreaBytes >= FL * KP16 * 4 && kAreaBytes >= 3 * kPlaneD && kHadElems * 2 <= 12 * 1024,
+                "transient area");
 };
-static_assert(BLds<16>::kBytes <= 160 * 1024 && BLds<64>::kBytes <= 160 * 1024, "LDS budget");
+static_assert(BLds<24>::kBytes <= 160 * 1024 && BLds<16>::kBytes <= 160 * 1024 && BLds<64>::kBytes <= 160 * 1024, "LDS budget");
 
 template <int REP>
 __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
@@ -884,6 +887,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           for (int ct = 0; ct < FRB; ++ct)
             bfr[s][ct] = *reinterpret_cast<const f16x4*>(hdT + (16 * ct + n) * B::KP16 + 16 * s + 4 * q);
       }
+      had::wg_barrier<true>();                         // (the factor image sits where the rows are about to land)
       // gather the rows
       {
         constexpr int KPAIRS = (FK + 1) / 2, PIECES = FL * KPAIRS, NP = (PIECES + kThreads - 1) / kThreads;
@@ -1072,7 +1076,7 @@ int block_engine_launch(const BlockEngineArgs& in, hipStream_t stream) {
   a.dbg = reinterpret_cast<uint64_t*>(in.dbg);
   a.n_layers = in.n_layers; a.max_len = in.max_len; a.dbg_layer = in.dbg_layer;
   a.rms_eps = in.rms_eps; a.attn_scale = in.attn_scale;
-  // codebook 0: E8P12 (16 copies of both tables), 1: D4 (one table of 256 x 4 bytes, a private copy per lane)
+  // codebook 0: E8P12 (32 copies of the abs table, 16 of the sign table), 1: D4 (one table of 256 x 4 bytes, a private copy per lane)
   auto go = [&](auto kern, int lds, DynLdsCache& configured) -> int {
     if (ensure_dyn_lds(configured, reinterpret_cast<const void*>(kern), lds) != QUIP_OK) return QUIP_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(NWG), dim3(kThreads), lds, stream, a);
@@ -1081,7 +1085,10 @@ int block_engine_launch(const BlockEngineArgs& in, hipStream_t stream) {
   static DynLdsCache c16, c64;
   if (in.codebook == 1) return go(decode_block_kernel<64>, BLds<64>::kBytes, c64);
   if (in.codebook != 0) return QUIP_ERR_UNSUPPORTED;
-  return go(decode_block_kernel<16>, BLds<16>::kBytes, c16);
+  static const bool rep16 = getenv("QUIP_ENG_REP") && atoi(getenv("QUIP_ENG_REP")) == 16;     // A/B: two-way conflicts on both tables
+  static DynLdsCache c24;
+  if (rep16) return go(decode_block_kernel<16>, BLds<16>::kBytes, c16);
+  return go(decode_block_kernel<24>, BLds<24>::kBytes, c24);
 }
 
 }  // namespace quip
