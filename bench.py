@@ -120,7 +120,7 @@ def engine_roofline(dec):
     h = dec.embed[:1].reshape(-1).clone()
     pos = torch.full((1,), 64, dtype=torch.long, device=dev)
     args = (dec.eng_layers, h, pos, dec.cos, dec.sin, dec.eng_grid, dec.eng_ws, len(dec.layers), dec.max_len, s.rms_eps,
-            1.0 / math.sqrt(s.head_dim), None, -1, dec.eng_codebook)
+            1.0 / math.sqrt(s.head_dim), None, -1, dec.eng_codebook, dec.eng_resid_scale)
     torch.ops.quip_lib.block_engine(*args)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()

@@ -466,7 +466,9 @@ typedef struct quip_block_engine_args {
   void* dbg;                 /* NULL, or 32 uint64 clock stamps per workgroup of block dbg_layer */
   int32_t n_layers, max_len, dbg_layer;
   float rms_eps, attn_scale;
-  int32_t codebook;          /* 0: E8P12; 1: D4 (uint8 codes, grid_packed_abs = the fp16 (256, 4) table, d4.py:26-96) */
+  int32_t codebook;          /* 0: E8P12; 1: D4 (uint8 codes, grid_packed_abs = the fp16 (256, 4) table, d4.py:26-96);
+                              * 2: E8P12RVQ4B (int32 codes, e8p12_rvq4.py:37-45) */
+  float resid_scale;         /* codebook 2: the residual scale rounded to fp16 (origin_order.cu:337-385), else ignored */
 } quip_block_engine_args;
 int quip_block_engine_supported(int32_t hidden, int32_t heads, int32_t kv_heads, int32_t head_dim, int32_t n_ffn, int32_t K);
 size_t quip_block_engine_workspace_bytes(void);

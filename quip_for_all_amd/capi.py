@@ -113,7 +113,7 @@ class BlockEngineArgs(_c.Structure):
     """mirror of quip_block_engine_args (include/quip_mi355.h)"""
     _fields_ = [("layers", _P), ("h_in", _P), ("h_out", _P), ("pos", _P), ("cos", _P), ("sin", _P),
                 ("grid_packed_abs", _P), ("workspace", _P), ("dbg", _P), ("n_layers", _I32), ("max_len", _I32),
-                ("dbg_layer", _I32), ("rms_eps", _F), ("attn_scale", _F), ("codebook", _I32)]
+                ("dbg_layer", _I32), ("rms_eps", _F), ("attn_scale", _F), ("codebook", _I32), ("resid_scale", _F)]
 
 
 class HadFusion(_c.Structure):

@@ -449,7 +449,7 @@ int quip_block_engine(const quip_block_engine_args* in, quip_stream_t stream) {
   a.layers = in->layers; a.h_in = in->h_in; a.h_out = in->h_out; a.pos = in->pos; a.cos = in->cos; a.sin = in->sin;
   a.grid = in->grid_packed_abs; a.workspace = in->workspace; a.dbg = in->dbg;
   a.n_layers = in->n_layers; a.max_len = in->max_len; a.dbg_layer = in->dbg_layer;
-  a.rms_eps = in->rms_eps; a.attn_scale = in->attn_scale; a.codebook = in->codebook;
+  a.rms_eps = in->rms_eps; a.attn_scale = in->attn_scale; a.codebook = in->codebook; a.resid_scale = in->resid_scale;
   return block_engine_launch(a, (hipStream_t)stream);
 }
 

@@ -59,6 +59,7 @@ struct BlockArgs {
   uint64_t* dbg;           // optional: 32 clock stamps per workgroup of block `dbg_layer`
   int n_layers, max_len, dbg_layer;
   float rms_eps, attn_scale;
+  float resid_scale;       // E8P12RVQ4B: the fp16 residual scale (as float)
 };
 
 constexpr int kWaves = 8, kThreads = 512;
@@ -81,9 +82,13 @@ constexpr int kParts = 8, kPartGran = 132, kSplitPos = 128;      // (measured: 1
 constexpr size_t kWsPart = kWsRows + (size_t)FL * 48 * 8;
 constexpr size_t kWsBytes = kWsPart + (size_t)NH * kParts * kPartGran * 8;
 
-template <int REP>
+template <int REP, bool RVQ = false>
 struct BLds {
   using T = Lds<REP>;
+  // RVQ (E8P12RVQ4B): read as 16-bit E8P codes a row has twice as many (virtual) weights, 8-groups alternating residual / main,
+  // and multiplies x' = [s x_g | x_g]_g: twice the digits per vector, twice the items per product (hadamard.hip, rvq_scale)
+  static constexpr int VM = RVQ ? 2 : 1, KV = VM * HID;
+  static constexpr int KPDV = RVQ ? 22528 : KPD, JDV = RVQ ? 43 : JD;   // digits of down's input (virtual, padded), its slices
   static constexpr int KKP = (FK * FK + 7) & ~7, KP16 = 48;
   static constexpr int kAcc = T::kAcc;                       // int32 [176][4]: q k v (48) | o (16) | gate up (96) | down (16)
   static constexpr int kAccRows = 176;
@@ -107,19 +112,23 @@ struct BLds {
   static constexpr int kBuf0 = kArea;
   static constexpr int kHadElems = 2 * KKP + KP16 * KP16;
   static constexpr int kStage = kArea + 8 * 1024;            // MLP row owners: their four rows, transposed, on the way out (4 KB)
-  static constexpr int kHad = kArea + 24 * 1024;             // fp16 image of the three K x K factors (12 KB)
-  static constexpr int kStash = kArea + 36 * 1024;           // MLP row owners: SV_gate / SV_up / SU_down of their rows (6 KB)
-  static constexpr int kPlaneD = (KPD / 256) * 272;
+  static constexpr int kHad = kArea + 2 * 3 * KV;            // fp16 image of the three K x K factors (12 KB), behind the planes of gate / up
+  static constexpr int kStash = kHad + 12 * 1024;            // MLP row owners: SV_gate / SV_up / SU_down of their rows (6 KB)
+  static constexpr int kPlaneD = (KPDV / 256) * 272;
   static constexpr int kBytes = kArea + kAreaBytes;
-  static_assert(kAreaBytes >= 3 * kBufBytes && kAreaBytes >= FL * KP16 * 4 && kAreaBytes >= 3 * kPlaneD && kHadElems * 2 <= 12 * 1024,
+  static_assert(kAreaBytes >= 3 * kBufBytes && kAreaBytes >= FL * KP16 * 4 && kAreaBytes >= 3 * kPlaneD && kHadElems * 2 <= 12 * 1024 &&
+                kStash + 6 * 1024 <= kArea + kAreaBytes,
                 "transient area");
 };
-static_assert(BLds<24>::kBytes <= 160 * 1024 && BLds<16>::kBytes <= 160 * 1024 && BLds<64>::kBytes <= 160 * 1024, "LDS budget");
+static_assert(BLds<24>::kBytes <= 160 * 1024 && BLds<16>::kBytes <= 160 * 1024 && BLds<64>::kBytes <= 160 * 1024 &&
+              BLds<16, true>::kBytes <= 160 * 1024, "LDS budget");
 
-template <int REP>
+template <int REP, bool RVQ = false>
 __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using B = BLds<REP>;
+  using B = BLds<REP, RVQ>;
+  constexpr int VM = B::VM, KV = B::KV;
+  constexpr int kRowU4V = VM * kRowU4, kRowU4DV = VM * kRowU4D;     // 16-byte pieces of a weight row (hidden- / ffn-wide input)
   using T = Lds<REP>;
   // Everything derived from the thread index is RE-derived from an opaque copy at the top of every stage (rederive()):
   // left to itself the compiler hoists ~70 lane-dependent addresses out of the block loop and spills them.
@@ -142,20 +151,20 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   // [16 w, +16) (slice = wave); 4..9 = gate / up row block (kind - 4) % 3 of matrix (kind - 4) / 3 (rows k * 256 + w);
   // 10..12 = down, slice (kind - 10) * 8 + wave.  A load = scalar base of the matrix + a 32-bit byte offset of this
   // lane (+ 64 for the second half of the item).
-  uint32_t vo_row, vo_q[3], vo_gu[FRB], vo_d[3], vo_d2b;
+  uint32_t vo_row, vo_q[3], vo_gu[FRB], vo_d[3], vo_d2b, vo_dr[3];
   uint32_t lane_c, lane_c2, xlane;
   auto rederive = [&]() {
     int t = threadIdx.x;
     asm volatile("" : "+v"(t));
     tid = t; lane = t & 63; n = lane & 15; q = lane >> 4;
-    vo_row = (uint32_t)(((w * RPW + n) * kRowU4 + wave * 8 + q) * 16);
+    vo_row = (uint32_t)(((w * RPW + n) * kRowU4V + wave * 8 + q) * 16);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) vo_q[i] = (uint32_t)(((((3 * w + i) & 255) * 16 + n) * kRowU4 + wave * 8 + q) * 16);
+    for (int i = 0; i < 3; ++i) vo_q[i] = (uint32_t)(((((3 * w + i) & 255) * 16 + n) * kRowU4V + wave * 8 + q) * 16);
 #pragma unroll
     for (int rb = 0; rb < FRB; ++rb) {
       int kr = rb * 16 + n;
       kr = kr < FK ? kr : FK - 1;
-      vo_gu[rb] = (uint32_t)(((kr * FL + w) * kRowU4 + wave * 8 + q) * 16);
+      vo_gu[rb] = (uint32_t)(((kr * FL + w) * kRowU4V + wave * 8 + q) * 16);
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -168,11 +177,15 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         vo_d2b = (uint32_t)(((w * RPW + n) * kRowU4D + off) * 16);
       }
     }
+    // RVQ: down's 43 virtual slices: slice wave + 8 i, i < 6, at vo_dr[i >> 2] + (i & 3) KB (the sixth exists for waves 0..2)
+    vo_dr[0] = (uint32_t)(((w * RPW + n) * kRowU4DV + wave * 8 + q) * 16);
+    vo_dr[1] = vo_dr[0] + 4096u;
+    vo_dr[2] = vo_dr[1] + (wave < 3 ? 1024u : 0u);
     lane_c = Lds<REP>::kD4 ? ((uint32_t)lane << 2)
              : (Lds<REP>::kRep1 == 32) ? ((((uint32_t)lane & 31u) << 3) | 0x00010000u)
                                        : ((((uint32_t)lane & 15u) << 3) | (uint32_t)Lds<REP>::kT1);
     lane_c2 = (((uint32_t)lane & 15u) << 3) | (uint32_t)Lds<REP>::kT2;
-    xlane = (uint32_t)BLds<REP>::kArea + (uint32_t)min(n, 2) * (uint32_t)HID + (uint32_t)q * 64u + (uint32_t)wave * 512u;
+    xlane = (uint32_t)B::kArea + (uint32_t)min(n, 2) * (uint32_t)KV + (uint32_t)q * 64u + (uint32_t)wave * 512u;
   };
   rederive();
   // a pointer the descriptor holds, as a scalar register pair (the same value in every lane)
@@ -202,6 +215,35 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(qb[8]) : "v"(vo_d2b), "s"(bd_) : "memory");              \
     }                                                                                                                  \
   } while (0)
+  // RVQ: the same with a compile-time byte offset (the second virtual slice of a row block is 1 KB further in the row)
+  auto ld_item_o = [&](auto off_c, u32x4& da, u32x4& db, const uint4* base0, uint32_t vo) {
+    constexpr int OFF = decltype(off_c)::value;
+    const uint4* base = uni(base0);
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(da) : "v"(vo), "s"(base), "n"(OFF) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(db) : "v"(vo), "s"(base), "n"(OFF + 64) : "memory");
+  };
+#define OFFC(n) std::integral_constant<int, (n)>{}
+  // RVQ slot plan (8 of the 9 slots): items (row block rb, virtual half h: slice wave + 8 h) of q k v / gate -> slot 3 h + rb;
+  // o -> 6 + h; up: half 0 -> 6 + rb (requested while gate is still in flight), half 1 -> rb (requested when gate's half 0
+  // has been multiplied); down: slice wave + 8 i -> slot i
+#define ISSUE_RVQ_QKV(Ld) do {                                                                          \
+    ld_item_o(OFFC(0), qa[0], qb[0], Ld.W[(3 * w) >> 8], vo_q[0]);    ld_item_o(OFFC(1024), qa[3], qb[3], Ld.W[(3 * w) >> 8], vo_q[0]);     \
+    ld_item_o(OFFC(0), qa[1], qb[1], Ld.W[(3 * w + 1) >> 8], vo_q[1]); ld_item_o(OFFC(1024), qa[4], qb[4], Ld.W[(3 * w + 1) >> 8], vo_q[1]); \
+    ld_item_o(OFFC(0), qa[2], qb[2], Ld.W[(3 * w + 2) >> 8], vo_q[2]); ld_item_o(OFFC(1024), qa[5], qb[5], Ld.W[(3 * w + 2) >> 8], vo_q[2]); \
+  } while (0)
+#define ISSUE_RVQ_O(Ld) do { ld_item_o(OFFC(0), qa[6], qb[6], Ld.W[3], vo_row); ld_item_o(OFFC(1024), qa[7], qb[7], Ld.W[3], vo_row); } while (0)
+#define ISSUE_RVQ_GATE(Ld) do {                                                                         \
+    ld_item_o(OFFC(0), qa[0], qb[0], Ld.W[4], vo_gu[0]); ld_item_o(OFFC(0), qa[1], qb[1], Ld.W[4], vo_gu[1]); ld_item_o(OFFC(0), qa[2], qb[2], Ld.W[4], vo_gu[2]); \
+    ld_item_o(OFFC(1024), qa[3], qb[3], Ld.W[4], vo_gu[0]); ld_item_o(OFFC(1024), qa[4], qb[4], Ld.W[4], vo_gu[1]); ld_item_o(OFFC(1024), qa[5], qb[5], Ld.W[4], vo_gu[2]); \
+  } while (0)
+#define ISSUE_RVQ_UP_A(Ld) do { ld_item_o(OFFC(0), qa[6], qb[6], Ld.W[5], vo_gu[0]); ld_item_o(OFFC(0), qa[7], qb[7], Ld.W[5], vo_gu[1]); ld_item_o(OFFC(0), qa[8], qb[8], Ld.W[5], vo_gu[2]); } while (0)
+#define ISSUE_RVQ_UP_B(Ld) do { ld_item_o(OFFC(1024), qa[0], qb[0], Ld.W[5], vo_gu[0]); ld_item_o(OFFC(1024), qa[1], qb[1], Ld.W[5], vo_gu[1]); ld_item_o(OFFC(1024), qa[2], qb[2], Ld.W[5], vo_gu[2]); } while (0)
+#define ISSUE_RVQ_DOWN(Ld) do {                                                                         \
+    ld_item_o(OFFC(0), qa[0], qb[0], Ld.W[6], vo_dr[0]); ld_item_o(OFFC(1024), qa[1], qb[1], Ld.W[6], vo_dr[0]); \
+    ld_item_o(OFFC(2048), qa[2], qb[2], Ld.W[6], vo_dr[0]); ld_item_o(OFFC(3072), qa[3], qb[3], Ld.W[6], vo_dr[0]); \
+    ld_item_o(OFFC(0), qa[4], qb[4], Ld.W[6], vo_dr[1]);                                                        \
+    ld_item_o(OFFC(0), qa[5], qb[5], Ld.W[6], vo_dr[2]);      /* (waves 3..7: slice wave + 32 again, not multiplied) */ \
+  } while (0)
   // after a drain: every slot is a plain register again
   // (`mask`: the slots that can be in flight at that point.  The others are dead there, and saying so frees their
   //  registers for the phase: the attention prologue keeps 8 of the 72 slot registers)
@@ -212,6 +254,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       if ((M >> s) & 1u) { esync::own(qa[s]); esync::own(qb[s]); }
   };
 #define SLOTS(m) std::integral_constant<unsigned, (m)>{}
+  // slots of the items of a product (see ISSUE / ISSUE_RVQ_*)
+  constexpr unsigned M_QKV = RVQ ? 0x03fu : 0x007u, M_O = RVQ ? 0x0c0u : 0x008u, M_GATE = RVQ ? 0x03fu : 0x007u;
+  constexpr unsigned M_UP = RVQ ? 0x1c0u : 0x038u /* RVQ: up's first half */, M_DOWN = RVQ ? 0x03fu : 0x1c0u;
 
   // ---- prologue ---------------------------------------------------------------------------------------------------
   u32x2 tsrc;
@@ -222,15 +267,16 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   asm_load16(hpiece, reinterpret_cast<const uint4*>(a.h_in) + tid);
   {
     const BlockLayer& L0 = a.layers[0];
-    ISSUE(L0, 0); ISSUE(L0, 1); ISSUE(L0, 2);
+    if constexpr (RVQ) ISSUE_RVQ_QKV(L0); else { ISSUE(L0, 0); ISSUE(L0, 1); ISSUE(L0, 2); }
   }
+  constexpr int NQ = RVQ ? 12 : 6;                   // loads of the first q, k, v items in flight across the prologue
   int* accs = reinterpret_cast<int*>(smem + B::kAcc);
   for (int i = tid; i < B::kAccRows * 4; i += kThreads) accs[i] = 0;
-  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(tsrc) : "n"(2 + 6) : "memory");
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(tsrc) : "n"(2 + NQ) : "memory");
   fill_tables_from_lane<REP>(smem, tsrc, lane, wave);
-  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(gen) : "n"(1 + 6) : "memory");
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(gen) : "n"(1 + NQ) : "memory");
   const uint32_t ebase = ((uint32_t)__builtin_amdgcn_readfirstlane((int)gen) + 1u) << 10;
-  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(hpiece) : "n"(6) : "memory");
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(hpiece) : "n"(NQ) : "memory");
   *reinterpret_cast<u32x4*>(smem + B::kH + tid * 16) = hpiece;
   const long long pos64 = *a.pos;
   const bool pos_ok = pos64 >= 0 && pos64 < (long long)a.max_len;
@@ -354,10 +400,16 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 #pragma unroll
         for (int i = 1; i < 8; ++i) { mx0 = fmaxf(mx0, red[i]); mx1 = fmaxf(mx1, red[8 + i]); }
         const float s0 = had::rms_scale(sc0, tot, HID, a.rms_eps), s1 = had::rms_scale(sc1, tot, HID, a.rms_eps);
-        const int sh0 = had::shift_for(had::fmul(mx0, fabsf(s0))), sh1 = had::shift_for(had::fmul(mx1, fabsf(s1)));
+        const float rvf = RVQ ? fmaxf(1.f, fabsf(a.resid_scale)) : 1.f;       // (hadamard.hip: bound * max(1, |rs|))
+        const int sh0 = had::shift_for(had::fmul(mx0, fabsf(s0)) * rvf), sh1 = had::shift_for(had::fmul(mx1, fabsf(s1)) * rvf);
         ESTAMP(5);
-        had8::planes_scatter(v[0], s0, sh0, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
-        had8::planes_scatter(v[1], s1, sh1, reinterpret_cast<uint8_t*>(smem + B::kArea + 3 * HID), tid);
+        if constexpr (RVQ) {
+          had8::planes_scatter_rvq(v[0], s0, a.resid_scale, sh0, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
+          had8::planes_scatter_rvq(v[1], s1, a.resid_scale, sh1, reinterpret_cast<uint8_t*>(smem + B::kArea + 3 * KV), tid);
+        } else {
+          had8::planes_scatter(v[0], s0, sh0, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
+          had8::planes_scatter(v[1], s1, sh1, reinterpret_cast<uint8_t*>(smem + B::kArea + 3 * HID), tid);
+        }
         if (tid == 0) { shs[0] = sh0; shs[1] = sh1; }
       } else {
         float v[1][8];
@@ -367,8 +419,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         had8::fht4096<1, true>(v, xbuf, tid);
         mx0 = had8::max4096<true>(had8::absmax8(v[0], 1.f), red, tid);
         const float s0 = had::rms_scale(sc0, tot, HID, a.rms_eps);
-        const int sh0 = had::shift_for(had::fmul(mx0, fabsf(s0)));
-        had8::planes_scatter(v[0], s0, sh0, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
+        const int sh0 = had::shift_for(had::fmul(mx0, fabsf(s0)) * (RVQ ? fmaxf(1.f, fabsf(a.resid_scale)) : 1.f));
+        if constexpr (RVQ) had8::planes_scatter_rvq(v[0], s0, a.resid_scale, sh0, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
+        else had8::planes_scatter(v[0], s0, sh0, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
         if (tid == 0) shs[0] = sh0;
       }
       had::wg_barrier<true>();
@@ -438,16 +491,17 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     const int c_lo = (3 * w) >> 8, c_hi = (3 * w + 2) >> 8;         // the one or two matrices this workgroup's row blocks are in
     // (the output side of the previous block's down_proj + residual ran at the bottom of the previous iteration: no
     //  weight request may be in flight across the loop edge, where the compiler is free to copy registers)
-    edge(std::integral_constant<int, 2>{}, SLOTS(0x007u), -1, 0u, 0u, nullptr, Ld.ln[0], Ld.su[c_lo], Ld.su[c_hi], Ld.sc[c_lo], Ld.sc[c_hi],
+    edge(std::integral_constant<int, 2>{}, SLOTS(M_QKV), -1, 0u, 0u, nullptr, Ld.ln[0], Ld.su[c_lo], Ld.su[c_hi], Ld.sc[c_lo], Ld.sc[c_hi],
          c_hi != c_lo, [&]() {});
     BSTAMP(2);
     esync::drain();                                    // q, k, v have landed (requested one transform stage ago)
-    own_slots(SLOTS(0x007u));
+    own_slots(SLOTS(M_QKV));
     {
-      const uint32_t x0 = xlane + (uint32_t)((((3 * w) >> 8) == c_lo ? 0 : 1) * 3 * HID);
-      const uint32_t x1 = xlane + (uint32_t)((((3 * w + 1) >> 8) == c_lo ? 0 : 1) * 3 * HID);
-      const uint32_t x2 = xlane + (uint32_t)((((3 * w + 2) >> 8) == c_lo ? 0 : 1) * 3 * HID);
+      const uint32_t x0 = xlane + (uint32_t)((((3 * w) >> 8) == c_lo ? 0 : 1) * 3 * KV);
+      const uint32_t x1 = xlane + (uint32_t)((((3 * w + 1) >> 8) == c_lo ? 0 : 1) * 3 * KV);
+      const uint32_t x2 = xlane + (uint32_t)((((3 * w + 2) >> 8) == c_lo ? 0 : 1) * 3 * KV);
       run_items3(0, x0, x1, x2, 0);
+      if constexpr (RVQ) run_items3(3, x0 + 4096u, x1 + 4096u, x2 + 4096u, 0);      // the second virtual slice: wave + 8
     }
     had::wg_barrier<true>();
     ++hop;                                             // hand-off: z_q, z_k, z_v
@@ -458,7 +512,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     }
     had::wg_barrier<true>();
     zero_acc(0, 48);
-    ISSUE(Ld, 3);                                      // burst B: o of this block (X3: up's slot, consumed): 16 KB per CU, lands inside the hand-off's latency
+    if constexpr (RVQ) ISSUE_RVQ_O(Ld); else ISSUE(Ld, 3);   // burst B: o of this block: lands inside the hand-off's latency
     BSTAMP(3);
 
     // ================= P2: attention ====================================================================================
@@ -504,7 +558,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         if (part + nparts * NG * U < pos) load_round(kr1, vr1, g + NG * U);
       }
       float v[3][8];
-      gather(std::integral_constant<int, 3>{}, SLOTS(0x008u), 0, ebase | hop, 0x5000u, v);
+      gather(std::integral_constant<int, 3>{}, SLOTS(M_O), 0, ebase | hop, 0x5000u, v);
       BSTAMP(4);
       f16* s_qkv = reinterpret_cast<f16*>(smem + B::kQkv);
       {
@@ -654,7 +708,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
             const int i = tid + kThreads * j;
             if (i < PIECES) *reinterpret_cast<uint2*>(s_p + 2 * i) = make_uint2(pp[j].x, pp[j].z);
           }
-          own_slots(SLOTS(0x008u));
+          own_slots(SLOTS(M_O));
           had::wg_barrier<true>();
           if (tid < HD) {
             float M = -INFINITY, Lsum = 0.f, o = 0.f;
@@ -685,37 +739,46 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     i32x4 Bo[8];
     {
       // o's codes were requested a hand-off ago: their table lookups run HERE, inside the wait for the attention output
+      // (RVQ: two items -- their fragments would be 64 registers: decoded with the product instead)
       esync::drain();
-      own_slots(SLOTS(0x008u));
-      decode_item(3, Bo);
+      own_slots(SLOTS(M_O));
+      if constexpr (!RVQ) decode_item(3, Bo);
       // o_proj's input side: x = H (a (.) SU_o) * sc  (no norm), every workgroup
       const u32x4 psu = *reinterpret_cast<const u32x4*>(Ld.su[3] + 8 * tid);
-      ISSUE(Ld, 4); ISSUE(Ld, 5); ISSUE(Ld, 6);        // gate's row blocks (X0-2: q, k, v consumed), at the start of the wait
+      // gate's row blocks (the slots of q, k, v: consumed), at the start of the wait
+      if constexpr (RVQ) ISSUE_RVQ_GATE(Ld); else { ISSUE(Ld, 4); ISSUE(Ld, 5); ISSUE(Ld, 6); }
       float v[1][8];
-      gather(std::integral_constant<int, 1>{}, SLOTS(0x007u), 3, ebase | hop, 0x6000u, v);
+      gather(std::integral_constant<int, 1>{}, SLOTS(M_GATE | (RVQ ? M_O : 0u)), 3, ebase | hop, 0x6000u, v);
       BSTAMP(7);
       had::mul8(v[0], make_uint4(psu.x, psu.y, psu.z, psu.w));
       had8::fht4096<1, true>(v, xbuf, tid);
       const float sco = Ld.sc[3];
       const float mx = had8::max4096<true>(had8::absmax8(v[0], sco), red, tid);
-      const int sh = had::shift_for(mx);
-      had8::planes_scatter(v[0], sco, sh, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
+      const int sh = had::shift_for(mx * (RVQ ? fmaxf(1.f, fabsf(a.resid_scale)) : 1.f));
+      if constexpr (RVQ) had8::planes_scatter_rvq(v[0], sco, a.resid_scale, sh, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
+      else had8::planes_scatter(v[0], sco, sh, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
       if (tid == 0) shs[3] = sh;
       had::wg_barrier<true>();
     }
     BSTAMP(8);
-    add_rows(item_multiply(Bo, xlane), 48);
+    if constexpr (RVQ) {
+      run_item(6, xlane, 48);
+      run_item(7, xlane + 4096u, 48);
+    } else {
+      add_rows(item_multiply(Bo, xlane), 48);
+    }
     had::wg_barrier<true>();
     ++hop;                                             // hand-off: z_o
     publish16(4, w * 8, 48, shs[3], ebase | hop);
     had::wg_barrier<true>();
     zero_acc(48, 16);
-    ISSUE(Ld, 7); ISSUE(Ld, 8); ISSUE(Ld, 9);          // up's row blocks (X3-5: o consumed), at the start of the wait for z_o
+    // up's row blocks (RVQ: their first virtual slice), at the start of the wait for z_o
+    if constexpr (RVQ) ISSUE_RVQ_UP_A(Ld); else { ISSUE(Ld, 7); ISSUE(Ld, 8); ISSUE(Ld, 9); }
     BSTAMP(9);
 
     // ================= P3: o's output side + residual, RMSNorm, input transforms of gate / up; their products =========
     rederive();
-    edge(std::integral_constant<int, 2>{}, SLOTS(0x03fu), 4, ebase | hop, 0x7000u, Ld.sv[3], Ld.ln[1], Ld.su[4], Ld.su[5], Ld.sc[4], Ld.sc[5], true,
+    edge(std::integral_constant<int, 2>{}, SLOTS(M_GATE | M_UP), 4, ebase | hop, 0x7000u, Ld.sv[3], Ld.ln[1], Ld.su[4], Ld.su[5], Ld.sc[4], Ld.sc[5], true,
          [&]() { BSTAMP(10); }, 18);
     BSTAMP(11);
     // row owners (w < NRO: rows k' = RPO w .. RPO w + RPO - 1, one per wave): SV_gate / SV_up / SU_down of their rows into the free
@@ -735,10 +798,21 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         *reinterpret_cast<uint4*>(smem + B::kHad + i * 16) = reinterpret_cast<const uint4*>(Ld.had3)[i];
     }
     esync::drain();
-    own_slots(SLOTS(0x03fu));
+    own_slots(SLOTS(M_GATE | M_UP));
     static_assert(FRB == 3, "three row blocks per matrix");
-    run_items3(0, xlane, xlane, xlane, 64);
-    run_items3(FRB, xlane + (uint32_t)(3 * HID), xlane + (uint32_t)(3 * HID), xlane + (uint32_t)(3 * HID), 64 + 16 * FRB);
+    if constexpr (RVQ) {
+      const uint32_t xu = xlane + (uint32_t)(3 * KV);
+      run_items3(0, xlane, xlane, xlane, 64);                                     // gate, slice wave
+      ISSUE_RVQ_UP_B(Ld);                                                           // up's second half into the slots just freed:
+      run_items3(3, xlane + 4096u, xlane + 4096u, xlane + 4096u, 64);             // six items of time to land
+      run_items3(6, xu, xu, xu, 64 + 16 * FRB);                                     // up, slice wave
+      esync::drain();
+      own_slots(SLOTS(0x007u));
+      run_items3(0, xu + 4096u, xu + 4096u, xu + 4096u, 64 + 16 * FRB);           // up, slice wave + 8
+    } else {
+      run_items3(0, xlane, xlane, xlane, 64);
+      run_items3(FRB, xlane + (uint32_t)(3 * HID), xlane + (uint32_t)(3 * HID), xlane + (uint32_t)(3 * HID), 64 + 16 * FRB);
+    }
     had::wg_barrier<true>();
     BSTAMP(12);
 
@@ -781,8 +855,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       }
       ++hop;                                           // hand-off: rows -> everybody
       const uint32_t tag2 = ebase | hop;
-      ISSUE(Ld, 10); ISSUE(Ld, 11); ISSUE(Ld, 12);     // down (X6-8), behind the inbox stores: a row owner's first poll queues
-                                                       // behind them, and the inbox takes longer than that to fill
+      // down, behind the inbox stores: a row owner's first poll queues behind them, and the inbox takes longer than that to fill
+      if constexpr (RVQ) ISSUE_RVQ_DOWN(Ld); else { ISSUE(Ld, 10); ISSUE(Ld, 11); ISSUE(Ld, 12); }
       BSTAMP(13);
       if (w < NRO) {
         const int kr = RPO * w + wave;                   // this wave's row of the (43, 256) view (waves 0..RPO-1)
@@ -875,7 +949,6 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         had::wg_barrier<true>();                         // the staging area is free again (the gather below zeroes over it)
       }
       BSTAMP(14);
-      // down's lookups inside the wait for the rows
       // B fragments of the K-mix (had_d^T in LDS)
       typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
       f16x4 bfr[3][FRB];
@@ -939,7 +1012,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
             *reinterpret_cast<uint2*>(ft + col * B::KP16 + 2 * kp) = make_uint2(p[j].x, (2 * kp + 1 < FK) ? p[j].z : 0u);
           }
         }
-        own_slots(SLOTS(0x1c0u));
+        own_slots(SLOTS(M_DOWN));
       }
       had::wg_barrier<true>();
       BSTAMP(15);
@@ -980,10 +1053,11 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
             mx = fmaxf(mx, mm == mm ? mm : __builtin_inff());
           }
       const float bound = had::block_reduce(mx, true, red, tid, kThreads);
-      const int sh_d = had::shift_for(bound);
+      const int sh_d = had::shift_for(bound * (RVQ ? fmaxf(1.f, fabsf(a.resid_scale)) : 1.f));
       {
         uint8_t* pl = reinterpret_cast<uint8_t*>(smem + B::kArea);
         const float s2 = had::fmul(in_scale, as_f32((uint32_t)(sh_d + 127) << 23));
+        const float s2r = had::fmul(had::fmul(in_scale, a.resid_scale), as_f32((uint32_t)(sh_d + 127) << 23));   // RVQ: the residual side
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
           const int tile = wave + jt * kWaves;
@@ -999,14 +1073,33 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
             }
             if (kc < FK) {
               const int kk = kc * FL + 16 * tile + 4 * q;
-              const int off = (kk >> 8) * 272 + (kk & 255);
-              *reinterpret_cast<uint32_t*>(pl + off) = had::low_bytes4(H[0], H[1], H[2], H[3]);
-              *reinterpret_cast<uint32_t*>(pl + B::kPlaneD + off) = had::low_bytes4(X1[0], X1[1], X1[2], X1[3]);
-              *reinterpret_cast<uint32_t*>(pl + 2 * B::kPlaneD + off) = had::low_bytes4(X[0], X[1], X[2], X[3]);
+              if constexpr (RVQ) {
+                // four elements of one 8-group: residual-side digits at 2 (kk & ~7) + (kk & 7), main-side 8 further
+                int Y[4], Y1[4], G[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  Y[i] = (int)__builtin_rintf(had::fmul(acc[jt][ct][i], s2r));
+                  Y1[i] = (Y[i] + 128) >> 8;
+                  G[i] = (Y1[i] + 128) >> 8;
+                }
+                const int vv = 2 * (kk & ~7) + (kk & 7);
+                const int offr = (vv >> 8) * 272 + (vv & 255), offm = ((vv + 8) >> 8) * 272 + ((vv + 8) & 255);
+                *reinterpret_cast<uint32_t*>(pl + offr) = had::low_bytes4(G[0], G[1], G[2], G[3]);
+                *reinterpret_cast<uint32_t*>(pl + B::kPlaneD + offr) = had::low_bytes4(Y1[0], Y1[1], Y1[2], Y1[3]);
+                *reinterpret_cast<uint32_t*>(pl + 2 * B::kPlaneD + offr) = had::low_bytes4(Y[0], Y[1], Y[2], Y[3]);
+                *reinterpret_cast<uint32_t*>(pl + offm) = had::low_bytes4(H[0], H[1], H[2], H[3]);
+                *reinterpret_cast<uint32_t*>(pl + B::kPlaneD + offm) = had::low_bytes4(X1[0], X1[1], X1[2], X1[3]);
+                *reinterpret_cast<uint32_t*>(pl + 2 * B::kPlaneD + offm) = had::low_bytes4(X[0], X[1], X[2], X[3]);
+              } else {
+                const int off = (kk >> 8) * 272 + (kk & 255);
+                *reinterpret_cast<uint32_t*>(pl + off) = had::low_bytes4(H[0], H[1], H[2], H[3]);
+                *reinterpret_cast<uint32_t*>(pl + B::kPlaneD + off) = had::low_bytes4(X1[0], X1[1], X1[2], X1[3]);
+                *reinterpret_cast<uint32_t*>(pl + 2 * B::kPlaneD + off) = had::low_bytes4(X[0], X[1], X[2], X[3]);
+              }
             }
           }
         }
-        for (int i = NFFN + 4 * tid; i < KPD; i += 4 * kThreads) {
+        for (int i = VM * NFFN + 4 * tid; i < B::KPDV; i += 4 * kThreads) {
           const int off = (i >> 8) * 272 + (i & 255);
 #pragma unroll
           for (int d = 0; d < 3; ++d) *reinterpret_cast<uint32_t*>(pl + d * B::kPlaneD + off) = 0u;
@@ -1015,13 +1108,25 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       had::wg_barrier<true>();
       BSTAMP(16);
       const uint32_t xlane_d = (uint32_t)B::kArea + (uint32_t)min(n, 2) * (uint32_t)B::kPlaneD + (uint32_t)q * 64u;
+      if constexpr (RVQ) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int sl = i * kWaves + wave;
-        if (sl < JD) {
-          ItemAddr ad;
-          item_addresses<REP>(qa[6 + i], qb[6 + i], lane_c, lane_c2, ad, 0u);
-          add_rows(T::kD4 ? item_mfma_d4<272>(ad, xlane_d + (uint32_t)(sl * 544)) : item_mfma<272>(ad, xlane_d + (uint32_t)(sl * 544)), 160);
+        for (int i = 0; i < 6; ++i) {
+          const int sl = i * kWaves + wave;
+          if (sl < B::JDV) {
+            ItemAddr ad;
+            item_addresses<REP>(qa[i], qb[i], lane_c, lane_c2, ad, 0u);
+            add_rows(item_mfma<272>(ad, xlane_d + (uint32_t)(sl * 544)), 160);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int sl = i * kWaves + wave;
+          if (sl < JD) {
+            ItemAddr ad;
+            item_addresses<REP>(qa[6 + i], qb[6 + i], lane_c, lane_c2, ad, 0u);
+            add_rows(T::kD4 ? item_mfma_d4<272>(ad, xlane_d + (uint32_t)(sl * 544)) : item_mfma<272>(ad, xlane_d + (uint32_t)(sl * 544)), 160);
+          }
         }
       }
       had::wg_barrier<true>();
@@ -1036,11 +1141,12 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       had::wg_barrier<true>();                         // everybody has read this block's descriptor for the last time
       if (tid < 64) reinterpret_cast<uint32_t*>(smem + B::kDesc)[tid] = reinterpret_cast<const uint32_t*>(a.layers + l + 1)[tid];
       had::wg_barrier<true>();
-      ISSUE(Ld, 0); ISSUE(Ld, 1); ISSUE(Ld, 2);        // q, k, v row blocks of the NEXT block (X0-2: gate consumed), at the start of the wait for z_d
+      // q, k, v row blocks of the NEXT block, at the start of the wait for z_d
+      if constexpr (RVQ) ISSUE_RVQ_QKV(Ld); else { ISSUE(Ld, 0); ISSUE(Ld, 1); ISSUE(Ld, 2); }
     }
     // output side of this block's down_proj + residual -> h (the gather drains the requests above)
     rederive();
-    edge(std::integral_constant<int, 0>{}, SLOTS(0x007u), 5, ebase | hop, 0x4000u, sv_d_prev, nullptr, nullptr, nullptr, 0.f, 0.f, false,
+    edge(std::integral_constant<int, 0>{}, SLOTS(M_QKV), 5, ebase | hop, 0x4000u, sv_d_prev, nullptr, nullptr, nullptr, 0.f, 0.f, false,
          [&]() { BSTAMP(1); });
   }
   // ---- h_out -----------------------------------------------------------------------------------------------------------
@@ -1051,6 +1157,13 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 #undef BSTAMP
 #undef ISSUE
 #undef SLOTS
+#undef OFFC
+#undef ISSUE_RVQ_QKV
+#undef ISSUE_RVQ_O
+#undef ISSUE_RVQ_GATE
+#undef ISSUE_RVQ_UP_A
+#undef ISSUE_RVQ_UP_B
+#undef ISSUE_RVQ_DOWN
 }
 
 }  // namespace
@@ -1075,7 +1188,7 @@ int block_engine_launch(const BlockEngineArgs& in, hipStream_t stream) {
   a.ws = reinterpret_cast<char*>(in.workspace);
   a.dbg = reinterpret_cast<uint64_t*>(in.dbg);
   a.n_layers = in.n_layers; a.max_len = in.max_len; a.dbg_layer = in.dbg_layer;
-  a.rms_eps = in.rms_eps; a.attn_scale = in.attn_scale;
+  a.rms_eps = in.rms_eps; a.attn_scale = in.attn_scale; a.resid_scale = 0.f;
   // codebook 0: E8P12 (32 copies of the abs table, 16 of the sign table), 1: D4 (one table of 256 x 4 bytes, a private copy per lane)
   auto go = [&](auto kern, int lds, DynLdsCache& configured) -> int {
     if (ensure_dyn_lds(configured, reinterpret_cast<const void*>(kern), lds) != QUIP_OK) return QUIP_ERR_LAUNCH;
@@ -1083,6 +1196,8 @@ int block_engine_launch(const BlockEngineArgs& in, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
   };
   static DynLdsCache c16, c64;
+  static DynLdsCache crvq;
+  if (in.codebook == 2) { a.resid_scale = in.resid_scale; return go(decode_block_kernel<16, true>, BLds<16, true>::kBytes, crvq); }
   if (in.codebook == 1) return go(decode_block_kernel<64>, BLds<64>::kBytes, c64);
   if (in.codebook != 0) return QUIP_ERR_UNSUPPORTED;
   static const bool rep16 = getenv("QUIP_ENG_REP") && atoi(getenv("QUIP_ENG_REP")) == 16;     // A/B: two-way conflicts on both tables

@@ -168,5 +168,24 @@ __device__ __forceinline__ void planes_scatter(const float v[8], float scale, in
   }
 }
 
+// E8P12RVQ4B: the digits of x' = [s x_g | x_g]_g (hadamard.hip, rvq_scale): element e's residual-side digits at 2 (e & ~7) +
+// (e & 7), its main-side digits 8 further; plane d at planes + d * 2 * kN; planes16's arithmetic with scale * rs / scale
+__device__ __forceinline__ void planes_scatter_rvq(const float v[8], float scale, float rs, int sh, uint8_t* planes, int tid) {
+#pragma clang fp contract(off)
+  const float p2 = as_f32((uint32_t)(sh + 127) << 23);
+  const float s2m = had::fmul(scale, p2), s2r = had::fmul(had::fmul(scale, rs), p2);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int e = tid + 512 * k;
+    uint8_t* p = planes + 2 * (e & ~7) + (e & 7);
+    const int Xm = (int)__builtin_rintf(v[k] * s2m), Xr = (int)__builtin_rintf(v[k] * s2r);
+    const int X1m = (Xm + 128) >> 8, X1r = (Xr + 128) >> 8;
+    const int Hm = (X1m + 128) >> 8, Hr = (X1r + 128) >> 8;
+    p[0] = (uint8_t)Hr;  p[8] = (uint8_t)Hm;
+    p[2 * kN] = (uint8_t)X1r;  p[2 * kN + 8] = (uint8_t)X1m;
+    p[4 * kN] = (uint8_t)Xr;  p[4 * kN + 8] = (uint8_t)Xm;
+  }
+}
+
 }  // namespace had8
 }  // namespace quip

@@ -91,7 +91,7 @@ _SCHEMAS = {
     # `layers` = the packed descriptors (decode.py builds them; they point at the KV caches, which the launch appends to)
     "block_engine": "(Tensor layers, Tensor h_in, Tensor pos, Tensor cos, Tensor sin, Tensor grid, Tensor(a!) workspace, "
                     "int n_layers, int max_len, float rms_eps, float attn_scale, Tensor? dbg=None, int dbg_layer=-1, "
-                    "int codebook=0) -> Tensor",
+                    "int codebook=0, float resid_scale=0.0) -> Tensor",
     # decode-step glue between q/k/v_proj and o_proj: rope + KV-cache append + single-query attention
     "rope_attn_decode": "(Tensor q, Tensor k, Tensor v, Tensor cos, Tensor sin, Tensor pos, Tensor(a!) kcache, "
                         "Tensor(b!) vcache, Tensor(c!)? workspace) -> Tensor",
@@ -672,7 +672,7 @@ def block_engine_workspace(device):
 
 
 def _block_engine_cuda(layers, h_in, pos, cos, sin, grid, workspace, n_layers, max_len, rms_eps, attn_scale, dbg=None,
-                       dbg_layer=-1, codebook=0):
+                       dbg_layer=-1, codebook=0, resid_scale=0.0):
     dev = h_in.device
     lb = capi.lib().quip_block_engine_layer_bytes()
     _need(layers.dtype == torch.uint8 and layers.is_contiguous() and layers.numel() >= n_layers * lb and layers.device == dev,
@@ -692,7 +692,7 @@ def _block_engine_cuda(layers, h_in, pos, cos, sin, grid, workspace, n_layers, m
     out = torch.empty_like(h_in)
     a = capi.BlockEngineArgs(layers.data_ptr(), h_in.data_ptr(), out.data_ptr(), pos.data_ptr(), cos.data_ptr(),
                              sin.data_ptr(), g.data_ptr(), workspace.data_ptr(), _ptr(dbg), int(n_layers), int(max_len),
-                             int(dbg_layer), float(rms_eps), float(attn_scale), int(codebook))
+                             int(dbg_layer), float(rms_eps), float(attn_scale), int(codebook), float(resid_scale))
     import ctypes
     with torch.cuda.device(dev):
         capi.check(capi.lib().quip_block_engine(ctypes.byref(a), _stream(h_in)), "quip_block_engine")
@@ -1102,7 +1102,7 @@ _reg_fake("e8p_gemv_fused", lambda x, z, post, residual, rms_weight, rms_eps, z_
 _reg_fake("ffn_engine", lambda planes_gate, planes_up, q_gate, q_up, q_down, had3, sv_gate, sv_up, su_down, grid, workspace,
           out_scale, in_scale, K, dbg=None: q_down.new_empty((1, q_down.shape[0]), dtype=torch.float16))
 _reg_fake("block_engine", lambda layers, h_in, pos, cos, sin, grid, workspace, n_layers, max_len, rms_eps, attn_scale,
-          dbg=None, dbg_layer=-1, codebook=0: torch.empty_like(h_in))
+          dbg=None, dbg_layer=-1, codebook=0, resid_scale=0.0: torch.empty_like(h_in))
 _reg_fake("rope_attn_decode", lambda q, k, v, cos, sin, pos, kcache, vcache, workspace=None: torch.empty_like(q))
 _reg_fake("rope_attn_decode_z", lambda zs, posts, scales, cos, sin, pos, kcache, vcache, workspace=None:
           kcache.new_empty((zs[0].numel() // kcache.shape[2], kcache.shape[2])))

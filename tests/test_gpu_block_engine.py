@@ -122,13 +122,15 @@ def test_block_engine_long_context_split_attention(pos0):
                 a.tok.copy_(b.tok)                        # keep the two on the same token whatever a near tie decides
 
 
-def test_block_engine_d4_matches_stagewise():
-    """the D4 codebook through the same persistent launch (one table of 256 x 4 bytes, a private copy per lane): against the
-    plain stage-wise step of the same model -- logits to the MLP edge's rounding, the same greedy tokens"""
-    a = _decoder(2, True, max_len=40, codebook="D4")
-    c = _decoder(2, False, ffn_engine=False, max_len=40, codebook="D4")
+@pytest.mark.parametrize("codebook,code", [("D4", 1), ("E8P12RVQ4B", 2)])
+def test_block_engine_d4_matches_stagewise(codebook, code):
+    """the D4 codebook (one table of 256 x 4 bytes, a private copy per lane) and E8P12RVQ4B (virtual rows of twice the
+    width against x' = [s x_g | x_g]: twice the digits and items) through the same persistent launch: against the plain
+    stage-wise step of the same model -- logits to the MLP edge's rounding, the same greedy tokens"""
+    a = _decoder(2, True, max_len=40, codebook=codebook)
+    c = _decoder(2, False, ffn_engine=False, max_len=40, codebook=codebook)
     _same_weights(c, a)
-    assert a.block_eng and a.eng_codebook == 1 and not c.block_eng and not c.ffn_eng
+    assert a.block_eng and a.eng_codebook == code and not c.block_eng and not c.ffn_eng
     for dec in (a, c):
         dec.reset(first_token=5)
     with torch.no_grad():
@@ -142,5 +144,5 @@ def test_block_engine_d4_matches_stagewise():
     tc = c.generate(24, first_token=5, use_graph=True).cpu().numpy()
     assert a.engine_status() == 0
     same = int((ta == tc).sum())
-    print(f"D4: greedy tokens equal: {same} / {len(ta)}")
+    print(f"{codebook}: greedy tokens equal: {same} / {len(ta)}")
     assert same >= len(ta) - 2          # (a near tie may go the other way: the MLP edge rounds its block exponent differently)
