@@ -90,7 +90,7 @@ def test_full_size_block_against_float64_model(codebook):
     shape = D.LlamaShape(hidden=4096, ffn=11008, layers=1, heads=32, kv_heads=32, vocab=1024)
     np.random.seed(7)
     dec = D.LlamaDecoder(shape, codebook, max_len=16, device="cuda:0", seed=5, device_init=True)
-    assert dec.block_eng == (codebook == "E8P12")
+    assert dec.block_eng                               # E8P12 and E8P12RVQ4B both take the persistent launch
     toks = dec.generate(3, first_token=9, use_graph=True).cpu().numpy()
     got = dec.step_logits.float().cpu().numpy()[0].astype(np.float64)
     assert dec.engine_status() == 0
