@@ -327,11 +327,18 @@ def time_decoder(D, shape, codebook, steps, warmup, device, **cb_kwargs):
         for _ in range(warmup):
             dec.graph.replay()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            dec.graph.replay()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        # four quarters, the median quarter x 4: one stall of the box (seen once: 45 ms inside 64 steps) does not become the
+        # figure of an extra (the headline is timed as the contract says: K steps, one clock)
+        q = max(1, steps // 4)
+        dts = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            for _ in range(q):
+                dec.graph.replay()
+            torch.cuda.synchronize()
+            dts.append(time.perf_counter() - t0)
+        steps = 4 * q
+        dt = 4 * sorted(dts)[1]
     algo = dec.algorithmic_bytes_per_token()
     out = {"codebook": codebook, "layers": shape.layers, "hidden": shape.hidden, "ffn": shape.ffn,
            "tokens_per_s": round(steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
