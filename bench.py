@@ -323,6 +323,8 @@ def time_decoder(D, shape, codebook, steps, warmup, device, **cb_kwargs):
                          device_init=shape.hidden >= 8192, **cb_kwargs)
     dec.capture()
     dec.reset(first_token=1)
+    import gc
+    gc.collect()            # (cyclic garbage of an earlier decoder freed INSIDE a timed region is a device-wide stall)
     with torch.no_grad():
         for _ in range(warmup):
             dec.graph.replay()
@@ -470,6 +472,9 @@ def main():
         torch.cuda.synchronize()
 
     dec.reset(first_token=1 + rank)
+    import gc
+    gc.collect()
+    gc.disable()            # no collector pause (and no freeing of device memory) inside the timed region
     with torch.no_grad():
         for _ in range(a.warmup):
             dec.graph.replay()
@@ -480,6 +485,7 @@ def main():
             dec.graph.replay()
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     dt = max_over_ranks(dist, dt, f"cuda:{local_rank}")
     status = dec.engine_status() if hasattr(dec, "engine_status") else 0
     if status:      # a persistent launch gave up on a hand-off: its tokens are not results, no line
