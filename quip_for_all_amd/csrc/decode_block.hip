@@ -14,7 +14,10 @@
 //     every workgroup repeats the small transforms between two products on its own copy (RMSNorm, SU / SV, 4096-point
 //     Walsh-Hadamard: the functions of had_device.hip.h, same operations in the same order as the stand-alone
 //     kernels, so the same bits); the 11008-wide MLP edge is the distributed two-hop computation of decode_engine.hip;
-//   * attention runs on the workgroup that owns the first 16 rows of its head (the other seven wait for the result).
+//   * attention runs on the workgroup that owns the first 16 rows of its head (the other seven wait for the result); from 128
+//     positions on all eight take every eighth position each and merge their partial softmax states through one more hand-off.
+// Codebooks: E8P12 (32 copies of the abs table, 16 of the sign table), D4 (the one-table mode of e8p_gemv_core.hip.h) and
+// E8P12RVQ4B (virtual rows of twice the width against x' = [s x_g | x_g]: twice the digits and items, eight of the nine slots).
 // Row ownership: q / k / v / o / down rows [16 w, 16 w + 16); gate / up rows k * 256 + w, k = 0..42 (column w of the
 // (43, 256) view, decode_engine.hip).
 //
