@@ -83,7 +83,9 @@ constexpr size_t kWsInbox = kWsZ + 6 * kWsVec, kWsRows = kWsInbox + (size_t)NRO 
 // maximum + denominator, padded to 132 granules) meet at the head's first workgroup
 constexpr int kParts = 8, kPartGran = 132, kSplitPos = 128;      // (measured: 1.83 ms per token at 200 positions on one workgroup per head, 1.74 at 256 split)
 constexpr size_t kWsPart = kWsRows + (size_t)FL * 48 * 8;
-constexpr size_t kWsBytes = kWsPart + (size_t)NH * kParts * kPartGran * 8;
+// short contexts: the head's second / third workgroup transform k / v of the new position and hand its 128 values over
+constexpr size_t kWsKvNew = kWsPart + (size_t)NH * kParts * kPartGran * 8;
+constexpr size_t kWsBytes = kWsKvNew + (size_t)NH * HD * 8;
 
 template <int REP, bool RVQ = false>
 struct BLds {
@@ -144,6 +146,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   uint64_t* inbox = reinterpret_cast<uint64_t*>(a.ws + kWsInbox);
   uint64_t* frow = reinterpret_cast<uint64_t*>(a.ws + kWsRows);
   uint64_t* pbuf = reinterpret_cast<uint64_t*>(a.ws + kWsPart);
+  uint64_t* kvnew = reinterpret_cast<uint64_t*>(a.ws + kWsKvNew);
   int dbg_on = 0;
 #define BSTAMP(i) do { if (dbg_on && tid == 0) a.dbg[w * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
@@ -528,7 +531,11 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     const int part = w & 7, nparts = split ? kParts : 1;
     const bool head_wg = part == 0;
     const int hd = w >> 3;
-    if (head_wg || split) {
+    // short contexts: the head's first workgroup transforms q only and starts on the cached rows; its second / third one
+    // transform k / v, write the new cache row and hand the head's 128 values over (one 4096-point transform each instead
+    // of three in a row on the critical path; the new position is the last one of its key group either way)
+    const bool kv_wg = !split && (part == 1 || part == 2);
+    if (head_wg || split || kv_wg) {
       // vectors first, then the gather.  After the transforms thread t holds elements t + 512 k: this head's 128 values
       // of q, k, v are register hd >> 2 of the threads [128 (hd & 3), +128)
       const int kreg = hd >> 2, tloc = tid - 128 * (hd & 3);
@@ -556,15 +563,15 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           vr[u] = *reinterpret_cast<const uint4*>(vc + (size_t)tc * HD + d0);
         }
       };
-      if (tid < 256) {
+      if (tid < 256 && !kv_wg) {
         load_round(kr0, vr0, g);
         if (part + nparts * NG * U < pos) load_round(kr1, vr1, g + NG * U);
       }
-      float v[3][8];
-      gather(std::integral_constant<int, 3>{}, SLOTS(M_O), 0, ebase | hop, 0x5000u, v);
-      BSTAMP(4);
       f16* s_qkv = reinterpret_cast<f16*>(smem + B::kQkv);
-      {
+      if (split) {
+        float v[3][8];
+        gather(std::integral_constant<int, 3>{}, SLOTS(M_O), 0, ebase | hop, 0x5000u, v);
+        BSTAMP(4);
         had8::fht4096<3, true>(v, xbuf, tid);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -573,56 +580,109 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           for (int k = 1; k < 8; ++k) val = kreg == k ? v[c][k] : val;
           if (mine) s_qkv[c * HD + tloc] = had::out_elem(val, 1.f / 64.f, true, (float)psv[c], false, 0.f, false, 0.f);
         }
+      } else {
+        float v[1][8];                                 // workgroup `part` of the head: vector q / k / v
+        gather(std::integral_constant<int, 1>{}, SLOTS(M_O), part, ebase | hop, 0x5000u, v);
+        BSTAMP(4);
+        had8::fht4096<1, true>(v, xbuf, tid);
+        float val = v[0][0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) val = kreg == k ? v[0][k] : val;
+        const f16 svp = part == 0 ? psv[0] : (part == 1 ? psv[1] : psv[2]);
+        if (mine) s_qkv[part * HD + tloc] = had::out_elem(val, 1.f / 64.f, true, (float)svp, false, 0.f, false, 0.f);
       }
+      // (both branches have drained the queue in their gather; said once more for tools/check_inflight.py, which follows the
+      //  control flow graph without knowing that the two conditional regions the compiler makes of this if / else are
+      //  complementary)
+      esync::drain();
+      own_slots(SLOTS(M_O));
       had::wg_barrier<true>();
       BSTAMP(5);
+      ++hop;                                           // hand-off inside the head's group: k / v of the new position | partial states
+      const uint32_t tagg = ebase | hop;
+      auto unpack8h = [](const uint4& u, float o[8]) {
+        const uint32_t ww[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f16x2 hh = as_f16x2(ww[i]);
+          o[2 * i] = (float)hh.x;
+          o[2 * i + 1] = (float)hh.y;
+        }
+      };
+      auto rope8 = [&](const f16* vec, float o[8]) {
+        float x[8], y[8];
+        unpack8h(*reinterpret_cast<const uint4*>(vec + d0), x);
+        const int dp = d0 < HD / 2 ? d0 + HD / 2 : d0 - HD / 2;
+        unpack8h(*reinterpret_cast<const uint4*>(vec + dp), y);
+        const float sgn = d0 < HD / 2 ? -1.f : 1.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (float)(f16)had::fadd(had::fmul(x[i], c8[i]), had::fmul(sgn * y[i], s8[i]));
+      };
+      {
+        const float* cs = reinterpret_cast<const float*>(smem + B::kCs);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { c8[i] = cs[d0 + i]; s8[i] = cs[HD + d0 + i]; }
+      }
+      if (kv_wg && tid < LPK) {
+        // this head's k (rotated) or v of the new position: the cache row (StaticCache.update) and 64 granules for the head
+        uint4 row;
+        if (part == 1) {
+          float kn[8];
+          rope8(s_qkv + HD, kn);
+          row.x = pack_f16(kn[0], kn[1]); row.y = pack_f16(kn[2], kn[3]);
+          row.z = pack_f16(kn[4], kn[5]); row.w = pack_f16(kn[6], kn[7]);
+        } else {
+          row = *reinterpret_cast<const uint4*>(s_qkv + 2 * HD + d0);
+        }
+        if (pos_ok) *const_cast<uint4*>(reinterpret_cast<const uint4*>((part == 1 ? kc : vc) + (size_t)pos * HD + d0)) = row;
+        uint64_t* dst = kvnew + (size_t)hd * HD + (part == 1 ? 0 : HD / 2) + 4 * tid;
+        esync::st_granule2(dst, row.x, row.y, tagg);
+        esync::st_granule2(dst + 2, row.z, row.w, tagg);
+      }
+      if (!kv_wg) {
       // single-query attention of head hd over positions [0, pos] (decode_glue.hip's arithmetic): 16 lanes per key,
       // 16 key groups with their own online-softmax state, merged through LDS
       float* s_m = reinterpret_cast<float*>(smem + B::kArea);
       float* s_l = s_m + NG;
       float* s_acc = s_l + NG;                         // [NG][HD + 4]
-      if (tid < 256) {
-        auto unpack8h = [](const uint4& u, float o[8]) {
-          const uint32_t ww[4] = {u.x, u.y, u.z, u.w};
+      float q8[8], kn[8], vn[8];
+      float m = -INFINITY, lsum = 0.f, acc8[8];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const f16x2 hh = as_f16x2(ww[i]);
-            o[2 * i] = (float)hh.x;
-            o[2 * i + 1] = (float)hh.y;
-          }
-        };
-        auto rope8 = [&](const f16* vec, float o[8]) {
-          float x[8], y[8];
-          unpack8h(*reinterpret_cast<const uint4*>(vec + d0), x);
-          const int dp = d0 < HD / 2 ? d0 + HD / 2 : d0 - HD / 2;
-          unpack8h(*reinterpret_cast<const uint4*>(vec + dp), y);
-          const float sgn = d0 < HD / 2 ? -1.f : 1.f;
+      for (int i = 0; i < 8; ++i) { acc8[i] = 0.f; kn[i] = 0.f; vn[i] = 0.f; }
+      // one key: score against q (16 lanes), online-softmax update of this group's state
+      auto one_key = [&](const float (&k8)[8], const float (&v8)[8], bool live) {
+        float sc = 0.f;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] = (float)(f16)had::fadd(had::fmul(x[i], c8[i]), had::fmul(sgn * y[i], s8[i]));
-        };
-        {
-          const float* cs = reinterpret_cast<const float*>(smem + B::kCs);
+        for (int i = 0; i < 8; ++i) sc = __builtin_fmaf(q8[i], k8[i], sc);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) { c8[i] = cs[d0 + i]; s8[i] = cs[HD + d0 + i]; }
+        for (int o = 1; o < LPK; o <<= 1) sc += __shfl_xor(sc, o, 64);
+        if (live) {
+          const float mn = fmaxf(m, sc);
+          const float cc = __expf(m - mn), pp = __expf(sc - mn);
+          lsum = lsum * cc + pp;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc8[i] = acc8[i] * cc + pp * v8[i];
+          m = mn;
         }
-        float q8[8], kn[8], vn[8];
+      };
+      if (tid < 256) {
         rope8(s_qkv, q8);
-        rope8(s_qkv + HD, kn);
-        const uint4 vraw = *reinterpret_cast<const uint4*>(s_qkv + 2 * HD + d0);
-        unpack8h(vraw, vn);
 #pragma unroll
         for (int i = 0; i < 8; ++i) q8[i] *= a.attn_scale;
-        if (g == 0 && pos_ok && part == (split ? (pos & (kParts - 1)) : 0)) {   // append the new row (StaticCache.update): once
-          uint4 kr;
-          kr.x = pack_f16(kn[0], kn[1]); kr.y = pack_f16(kn[2], kn[3]);
-          kr.z = pack_f16(kn[4], kn[5]); kr.w = pack_f16(kn[6], kn[7]);
-          *const_cast<uint4*>(reinterpret_cast<const uint4*>(kc + (size_t)pos * HD + d0)) = kr;
-          *const_cast<uint4*>(reinterpret_cast<const uint4*>(vc + (size_t)pos * HD + d0)) = vraw;
+        if (split) {
+          rope8(s_qkv + HD, kn);
+          const uint4 vraw = *reinterpret_cast<const uint4*>(s_qkv + 2 * HD + d0);
+          unpack8h(vraw, vn);
+          if (g == 0 && pos_ok && part == (pos & (kParts - 1))) {   // append the new row (StaticCache.update): once
+            uint4 kr;
+            kr.x = pack_f16(kn[0], kn[1]); kr.y = pack_f16(kn[2], kn[3]);
+            kr.z = pack_f16(kn[4], kn[5]); kr.w = pack_f16(kn[6], kn[7]);
+            *const_cast<uint4*>(reinterpret_cast<const uint4*>(kc + (size_t)pos * HD + d0)) = kr;
+            *const_cast<uint4*>(reinterpret_cast<const uint4*>(vc + (size_t)pos * HD + d0)) = vraw;
+          }
         }
-        float m = -INFINITY, lsum = 0.f, acc8[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc8[i] = 0.f;
-        const int t_hi = pos + 1;
+        // (short contexts: the cached positions here, the new one -- the last of its key group -- after the hand-off below)
+        const int t_hi = split ? pos + 1 : pos;
         // one round: positions t0 + u NG of this key group, rows in (kr, vr)
         auto round = [&](const uint4 (&kr)[U], const uint4 (&vr)[U], int i0) {
 #pragma unroll
@@ -635,19 +695,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 #pragma unroll
               for (int i = 0; i < 8; ++i) { k8[i] = kn[i]; v8[i] = vn[i]; }
             }
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) s = __builtin_fmaf(q8[i], k8[i], s);
-#pragma unroll
-            for (int o = 1; o < LPK; o <<= 1) s += __shfl_xor(s, o, 64);
-            if (t < t_hi) {
-              const float mn = fmaxf(m, s);
-              const float cc = __expf(m - mn), pp = __expf(s - mn);
-              lsum = lsum * cc + pp;
-#pragma unroll
-              for (int i = 0; i < 8; ++i) acc8[i] = acc8[i] * cc + pp * v8[i];
-              m = mn;
-            }
+            one_key(k8, v8, t < t_hi);
           }
         };
         // (uniform trip count: the lanes of a wave differ in g < NG only)
@@ -660,6 +708,29 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
             if (ib + 3 * NG * U < n_loc) load_round(kr1, vr1, ib + g + 3 * NG * U);
           }
         }
+      }
+      if (!split) {
+        // k / v of the new position from the head's second / third workgroup: 128 granules = 64 16-byte pieces
+        if (tid < 64) {
+          u32x4_t kv;
+          uint32_t spins = 0;
+          for (;;) {
+            esync::ld16(kv, kvnew + (size_t)hd * HD + 2 * tid);
+            esync::drain();
+            esync::own(kv);
+            if (esync::spin_step(kv.y == tagg && kv.w == tagg, spins, ctl + 1, 0x9000u + (uint32_t)w)) break;
+          }
+          *reinterpret_cast<uint2*>(s_qkv + HD + 4 * tid) = make_uint2(kv.x, kv.z);      // k [0, 128) | v [128, 256)
+        }
+        own_slots(SLOTS(M_O));
+        had::wg_barrier<true>();
+        if (tid < 256 && g == (pos & (NG - 1))) {
+          unpack8h(*reinterpret_cast<const uint4*>(s_qkv + HD + d0), kn);          // (already rotated and rounded)
+          unpack8h(*reinterpret_cast<const uint4*>(s_qkv + 2 * HD + d0), vn);
+          one_key(kn, vn, true);
+        }
+      }
+      if (tid < 256) {
         if ((tid & (LPK - 1)) == 0) { s_m[g] = m; s_l[g] = lsum; }
 #pragma unroll
         for (int i = 0; i < 8; ++i) s_acc[g * (HD + 4) + d0 + i] = acc8[i];
@@ -677,8 +748,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       }
       if (split) {
         // hand-off: the partial states of the head's eight workgroups -> its first one
-        ++hop;
-        const uint32_t tagp = ebase | hop;
+        const uint32_t tagp = tagg;
         uint64_t* mine_p = pbuf + ((size_t)hd * kParts + part) * kPartGran;
         if (tid < HD) esync::st_granule(mine_p + tid, as_u32(pO), tagp);
         if (tid == 0) { esync::st_granule(mine_p + HD, as_u32(pM), tagp); esync::st_granule(mine_p + HD + 1, as_u32(pL), tagp); }
@@ -729,13 +799,14 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         s_a[tid] = pos_ok ? (f16)(pO / pL) : __builtin_bit_cast(f16, (unsigned short)0x7e00);
       }
       had::wg_barrier<true>();
-      ++hop;                                           // hand-off: attention output
       if (head_wg && tid < 64) {
         const uint32_t pr = *reinterpret_cast<const uint32_t*>(s_a + 2 * tid);
-        esync::st_granule(zbufs + (size_t)3 * 2048 + hd * 64 + tid, pr, ebase | hop);
+        esync::st_granule(zbufs + (size_t)3 * 2048 + hd * 64 + tid, pr, ebase | (hop + 1u));
       }
+      }  // !kv_wg
+      ++hop;                                           // hand-off: attention output
     } else {
-      ++hop;                                           // (short context: the seven other workgroups of a head wait for the result)
+      hop += 2;                                        // (short context: five workgroups of a head wait for the result)
     }
     BSTAMP(6);
     rederive();
