@@ -534,7 +534,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     // short contexts: the head's first workgroup transforms q only and starts on the cached rows; its second / third one
     // transform k / v, write the new cache row and hand the head's 128 values over (one 4096-point transform each instead
     // of three in a row on the critical path; the new position is the last one of its key group either way)
-    const bool kv_wg = !split && (part == 1 || part == 2);
+    constexpr bool kOffload = !RVQ;                    // (RVQ: the extra addresses do not fit its registers)
+    const bool kv_wg = kOffload && !split && (part == 1 || part == 2);
+    const bool all3 = split || !kOffload;              // this workgroup transforms q, k and v itself
     if (head_wg || split || kv_wg) {
       // vectors first, then the gather.  After the transforms thread t holds elements t + 512 k: this head's 128 values
       // of q, k, v are register hd >> 2 of the threads [128 (hd & 3), +128)
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         if (part + nparts * NG * U < pos) load_round(kr1, vr1, g + NG * U);
       }
       f16* s_qkv = reinterpret_cast<f16*>(smem + B::kQkv);
-      if (split) {
+      if (all3) {
         float v[3][8];
         gather(std::integral_constant<int, 3>{}, SLOTS(M_O), 0, ebase | hop, 0x5000u, v);
         BSTAMP(4);
@@ -669,11 +671,11 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         rope8(s_qkv, q8);
 #pragma unroll
         for (int i = 0; i < 8; ++i) q8[i] *= a.attn_scale;
-        if (split) {
+        if (all3) {
           rope8(s_qkv + HD, kn);
           const uint4 vraw = *reinterpret_cast<const uint4*>(s_qkv + 2 * HD + d0);
           unpack8h(vraw, vn);
-          if (g == 0 && pos_ok && part == (pos & (kParts - 1))) {   // append the new row (StaticCache.update): once
+          if (g == 0 && pos_ok && part == (split ? (pos & (kParts - 1)) : 0)) {   // append the new row (StaticCache.update): once
             uint4 kr;
             kr.x = pack_f16(kn[0], kn[1]); kr.y = pack_f16(kn[2], kn[3]);
             kr.z = pack_f16(kn[4], kn[5]); kr.w = pack_f16(kn[6], kn[7]);
@@ -682,7 +684,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           }
         }
         // (short contexts: the cached positions here, the new one -- the last of its key group -- after the hand-off below)
-        const int t_hi = split ? pos + 1 : pos;
+        const int t_hi = all3 ? pos + 1 : pos;
         // one round: positions t0 + u NG of this key group, rows in (kr, vr)
         auto round = [&](const uint4 (&kr)[U], const uint4 (&vr)[U], int i0) {
 #pragma unroll
@@ -709,7 +711,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           }
         }
       }
-      if (!split) {
+      if (!all3) {
         // k / v of the new position from the head's second / third workgroup: 128 granules = 64 16-byte pieces
         if (tid < 64) {
           u32x4_t kv;
