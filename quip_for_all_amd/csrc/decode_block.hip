@@ -935,9 +935,6 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       if constexpr (RVQ) ISSUE_RVQ_DOWN(Ld); else { ISSUE(Ld, 10); ISSUE(Ld, 11); ISSUE(Ld, 12); }
       BSTAMP(13);
       if (w < NRO) {
-        const int kr = RPO * w + wave;                   // this wave's row of the (43, 256) view (waves 0..RPO-1)
-        const bool have_row = wave < RPO && kr < FK;
-        const int m = lane >> 5, t = lane & 31;
         // the owner's inbox = 256 columns x (2 matrices x RPO rows) granules, swept by all 512 threads (coalesced 16-byte
         // pieces); piece p = column p / RPO, matrix (p / (RPO / 2)) & 1, rows 2 (p % (RPO / 2)) and + 1
         {
@@ -967,49 +964,62 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           }
           had::wg_barrier<true>();
         }
-        // a row on the whole wave: lanes 0..31 its gate half, 32..63 its up half, 8 consecutive elements each (index bits
-        // 0..2 in registers, 3..7 = lane bits 0..4; ascending bit order: the same additions as fht16_lanes, fht_wg512.hip.h)
-        float v[8];
-        {
-          const float* rb = reinterpret_cast<const float*>(smem + B::kArea) + ((have_row ? wave : 0) * 2 + m) * FL + t * 8;
-          const float4 f0 = *reinterpret_cast<const float4*>(rb), f1 = *reinterpret_cast<const float4*>(rb + 4);
-          v[0] = f0.x; v[1] = f0.y; v[2] = f0.z; v[3] = f0.w; v[4] = f1.x; v[5] = f1.y; v[6] = f1.z; v[7] = f1.w;
-        }
-        auto fht256 = [&](float (&x)[8]) {
-          had8::reg_stage<1>(x); had8::reg_stage<2>(x); had8::reg_stage<4>(x);
-          had8::lane_stage<0>(x, lane); had8::lane_stage<1>(x, lane); had8::lane_stage<2>(x, lane);
-          had8::lane_stage<3>(x, lane); had8::lane_stage<4>(x, lane);
+        // a row on a PAIR of waves: wave rw its gate half, wave 4 + rw its up half, 4 consecutive elements per lane (index bits
+        // 0..1 in registers, 2..7 = lane bits 0..5; ascending bit order: the same additions as fht16_lanes, fht_wg512.hip.h);
+        // the up half crosses to the gate wave through LDS
+        const int rw = wave & (RPO - 1), mh = wave >> 2;
+        const bool row_ok = RPO * w + rw < FK;
+        auto fht256 = [&](float (&x)[4]) {
+#pragma clang fp contract(off)
+          const float a0 = x[0] + x[1], a1 = x[0] - x[1], a2 = x[2] + x[3], a3 = x[2] - x[3];
+          x[0] = a0 + a2; x[2] = a0 - a2; x[1] = a1 + a3; x[3] = a1 - a3;
+          auto lst = [&](auto sc) {
+            constexpr int S = decltype(sc)::value;
+            const float sg = ((lane >> S) & 1) ? -1.f : 1.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = __builtin_fmaf(x[r], sg, had8::lane_partner<S>(x[r], lane));
+          };
+          lst(std::integral_constant<int, 0>{}); lst(std::integral_constant<int, 1>{}); lst(std::integral_constant<int, 2>{});
+          lst(std::integral_constant<int, 3>{}); lst(std::integral_constant<int, 4>{}); lst(std::integral_constant<int, 5>{});
         };
+        float v[4];
+        {
+          const float4 f0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(smem + B::kArea) +
+                                                            ((row_ok ? rw : 0) * 2 + mh) * FL + lane * 4);
+          v[0] = f0.x; v[1] = f0.y; v[2] = f0.z; v[3] = f0.w;
+        }
         fht256(v);
-        const f16* vecs = reinterpret_cast<const f16*>(smem + B::kStash) + (have_row ? wave : 0) * 3 * FL;
-        float o[8];
+        const f16* vecs = reinterpret_cast<const f16*>(smem + B::kStash) + (row_ok ? rw : 0) * 3 * FL;
+        float o[4];
         {
-          float svf[8];
-          had::unpack8(*reinterpret_cast<const uint4*>(vecs + m * FL + t * 8), svf);
+          const uint2 svp = *reinterpret_cast<const uint2*>(vecs + mh * FL + lane * 4);
+          const f16x2 s01 = as_f16x2(svp.x), s23 = as_f16x2(svp.y);
+          const float svf[4] = {(float)s01.x, (float)s01.y, (float)s23.x, (float)s23.y};
 #pragma unroll
-          for (int r = 0; r < 8; ++r) o[r] = (float)had::out_elem(v[r], 1.f / 16.f, true, svf[r], false, 0.f, false, 0.f);
+          for (int r = 0; r < 4; ++r) o[r] = (float)had::out_elem(v[r], 1.f / 16.f, true, svf[r], false, 0.f, false, 0.f);
         }
-        float e[8];
-        {
-          float suf[8];
-          had::unpack8(*reinterpret_cast<const uint4*>(vecs + 2 * FL + t * 8), suf);
-#pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            const float u = had8::lane_partner<5>(o[r], lane);          // the up half's value (lane + 32)
-            e[r] = had::fmul(had::fmul(u, had::silu(o[r])), suf[r]);
-          }
-        }
-        fht256(e);
-        // the wave's row, as fp16 hi + lo of the prescaled values, next to the owner's other rows in LDS ([j][RPO]) ...
+        float* xch = reinterpret_cast<float*>(smem + B::kStage + RPO * FL * 4);     // [RPO][256]: the up halves
+        if (mh == 1) *reinterpret_cast<float4*>(xch + rw * FL + lane * 4) = float4{o[0], o[1], o[2], o[3]};
+        had::wg_barrier<true>();
         uint32_t* stage = reinterpret_cast<uint32_t*>(smem + B::kStage);
-        if (lane < 32 && wave < RPO) {
+        if (mh == 0) {
+          const float4 u4 = *reinterpret_cast<const float4*>(xch + rw * FL + lane * 4);
+          const float u[4] = {u4.x, u4.y, u4.z, u4.w};
+          const uint2 sup = *reinterpret_cast<const uint2*>(vecs + 2 * FL + lane * 4);
+          const f16x2 s01 = as_f16x2(sup.x), s23 = as_f16x2(sup.y);
+          const float suf[4] = {(float)s01.x, (float)s01.y, (float)s23.x, (float)s23.y};
+          float e[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) e[r] = had::fmul(had::fmul(u[r], had::silu(o[r])), suf[r]);
+          fht256(e);
+          // the row, as fp16 hi + lo of the prescaled values, next to the owner's other rows in LDS ([j][RPO]) ...
           constexpr float kPre = 1.f / 16.f;
 #pragma unroll
-          for (int r = 0; r < 8; ++r) {
+          for (int r = 0; r < 4; ++r) {
             const float vv = e[r] * kPre;
             const f16 hi = (f16)vv;
             const f16 lo = (f16)(vv - (float)hi);
-            stage[(8 * t + r) * RPO + wave] = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
+            stage[(4 * lane + r) * RPO + rw] = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
           }
         }
         had::wg_barrier<true>();
