@@ -81,6 +81,10 @@ constexpr int RPO = 4, NRO = (FK + RPO - 1) / RPO;
 constexpr size_t kWsInbox = kWsZ + 6 * kWsVec, kWsRows = kWsInbox + (size_t)NRO * FL * 2 * RPO * 8;
 // long contexts: the eight workgroups of a head each take every eighth position; their partial softmax states (128 sums +
 // maximum + denominator, padded to 132 granules) meet at the head's first workgroup
+// rows hand-off: wave 0 polls the last column before everybody sweeps the 90 KB.  Without it (every workgroup sweeping
+// until its pieces are all there) the hand-off takes 29.5K clocks instead of 21.4K: 256 x 90 KB of polls per retry crowd out
+// the owners' stores
+constexpr bool kCheapPoll = true;
 constexpr int kParts = 8, kPartGran = 132, kSplitPos = 128;      // (measured: 1.83 ms per token at 200 positions on one workgroup per head, 1.74 at 256 split)
 constexpr size_t kWsPart = kWsRows + (size_t)FL * 48 * 8;
 // short contexts: the head's second / third workgroup transform k / v of the new position and hand its 128 values over
@@ -1054,7 +1058,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         for (int j = tid; j < FL; j += kThreads)
 #pragma unroll
           for (int k = 2 * KPAIRS; k < B::KP16; ++k) ft[j * B::KP16 + k] = 0u;
-        if (wave == 0) {
+        if (kCheapPoll && wave == 0) {
           uint32_t spins0 = 0;
           const uint64_t* last = frow + ((size_t)(FL - 1) * B::KP16 + (lane < FK ? lane : 0));
           for (;;) {
