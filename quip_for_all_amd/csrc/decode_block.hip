@@ -246,6 +246,13 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     ld_item_o(OFFC(0), qa[0], qb[0], Ld.W[4], vo_gu[0]); ld_item_o(OFFC(0), qa[1], qb[1], Ld.W[4], vo_gu[1]); ld_item_o(OFFC(0), qa[2], qb[2], Ld.W[4], vo_gu[2]); \
     ld_item_o(OFFC(1024), qa[3], qb[3], Ld.W[4], vo_gu[0]); ld_item_o(OFFC(1024), qa[4], qb[4], Ld.W[4], vo_gu[1]); ld_item_o(OFFC(1024), qa[5], qb[5], Ld.W[4], vo_gu[2]); \
   } while (0)
+// the same bursts a third at a time (the CU's address unit takes ~25 clocks per 1 KB request: 48 requests in a row stall
+// the issuing waves for ~1.2K clocks, 16 at a time between other work do not)
+#define ISSUE_RVQ_GATE_G(Ld, i) do { ld_item_o(OFFC(0), qa[i], qb[i], Ld.W[4], vo_gu[i]); ld_item_o(OFFC(1024), qa[3 + (i)], qb[3 + (i)], Ld.W[4], vo_gu[i]); } while (0)
+#define ISSUE_RVQ_DOWN_G0(Ld) do { ld_item_o(OFFC(0), qa[0], qb[0], Ld.W[6], vo_dr[0]); ld_item_o(OFFC(1024), qa[1], qb[1], Ld.W[6], vo_dr[0]); } while (0)
+#define ISSUE_RVQ_DOWN_G1(Ld) do { ld_item_o(OFFC(2048), qa[2], qb[2], Ld.W[6], vo_dr[0]); ld_item_o(OFFC(3072), qa[3], qb[3], Ld.W[6], vo_dr[0]); } while (0)
+#define ISSUE_RVQ_DOWN_G2(Ld) do { ld_item_o(OFFC(0), qa[4], qb[4], Ld.W[6], vo_dr[1]); ld_item_o(OFFC(0), qa[5], qb[5], Ld.W[6], vo_dr[2]); } while (0)
+#define ISSUE_RVQ_UP_A_G(Ld, i) do { ld_item_o(OFFC(0), qa[6 + (i)], qb[6 + (i)], Ld.W[5], vo_gu[i]); } while (0)
 #define ISSUE_RVQ_UP_A(Ld) do { ld_item_o(OFFC(0), qa[6], qb[6], Ld.W[5], vo_gu[0]); ld_item_o(OFFC(0), qa[7], qb[7], Ld.W[5], vo_gu[1]); ld_item_o(OFFC(0), qa[8], qb[8], Ld.W[5], vo_gu[2]); } while (0)
 #define ISSUE_RVQ_UP_B(Ld) do { ld_item_o(OFFC(1024), qa[0], qb[0], Ld.W[5], vo_gu[0]); ld_item_o(OFFC(1024), qa[1], qb[1], Ld.W[5], vo_gu[1]); ld_item_o(OFFC(1024), qa[2], qb[2], Ld.W[5], vo_gu[2]); } while (0)
 #define ISSUE_RVQ_DOWN(Ld) do {                                                                         \
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   // The vectors of this thread's elements are requested before the gather waits; after_gather() runs right after it.
   float* xbuf = reinterpret_cast<float*>(smem + B::kBuf0);
   auto edge = [&](auto nc_tag, auto slots, int zvec, uint32_t tag, uint32_t code, const f16* sv_prev, const f16* ln, const f16* su0,
-                  const f16* su1, float sc0, float sc1, bool two, auto after_gather, int sb = -1) {
+                  const f16* su1, float sc0, float sc1, bool two, auto after_gather, auto drip1, auto drip2, int sb = -1) {
 #define ESTAMP(i) do { if (sb >= 0) BSTAMP(sb + (i)); } while (0)
     constexpr int NC = decltype(nc_tag)::value;
     const bool have_z = zvec >= 0;
@@ -385,6 +392,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       }
       had::wg_barrier<true>();
       ESTAMP(2);
+      drip1();
     }
     if constexpr (NC > 0) {
       float e[8];
@@ -401,6 +409,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         had::mul8(v[1], u4(psu1));
         had8::fht4096<2, true>(v, xbuf, tid);
         ESTAMP(4);
+        drip2();
         mx0 = had::wave_reduce_to_lane63<true>(had8::absmax8(v[0], 1.f));
         mx1 = had::wave_reduce_to_lane63<true>(had8::absmax8(v[1], 1.f));
         had::wg_barrier<true>();
@@ -502,7 +511,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     // (the output side of the previous block's down_proj + residual ran at the bottom of the previous iteration: no
     //  weight request may be in flight across the loop edge, where the compiler is free to copy registers)
     edge(std::integral_constant<int, 2>{}, SLOTS(M_QKV), -1, 0u, 0u, nullptr, Ld.ln[0], Ld.su[c_lo], Ld.su[c_hi], Ld.sc[c_lo], Ld.sc[c_hi],
-         c_hi != c_lo, [&]() {});
+         c_hi != c_lo, [&]() {}, [&]() {}, [&]() {});
     BSTAMP(2);
     esync::drain();                                    // q, k, v have landed (requested one transform stage ago)
     own_slots(SLOTS(M_QKV));
@@ -522,7 +531,11 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     }
     had::wg_barrier<true>();
     zero_acc(0, 48);
-    if constexpr (RVQ) ISSUE_RVQ_O(Ld); else ISSUE(Ld, 3);   // burst B: o of this block: lands inside the hand-off's latency
+    // o of this block, behind the publication.  (A burst in front of a gather makes the gather's first check wait for the
+    // burst -- vmcnt retires in order: ~2.3 us of HBM latency against the ~1.7 us a hand-off takes -- and a burst anywhere
+    // else stalls the issuing waves for ~1.2K clocks, the CU's address unit taking ~25 clocks per 1 KB request.  Measured per
+    // burst: gate, up and down are cheaper behind their hand-off; o, which only the head's workgroups would gain from, here.)
+    if constexpr (RVQ) ISSUE_RVQ_O(Ld); else ISSUE(Ld, 3);
     BSTAMP(3);
 
     // ================= P2: attention ====================================================================================
@@ -825,15 +838,18 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       if constexpr (!RVQ) decode_item(3, Bo);
       // o_proj's input side: x = H (a (.) SU_o) * sc  (no norm), every workgroup
       const u32x4 psu = *reinterpret_cast<const u32x4*>(Ld.su[3] + 8 * tid);
-      // gate's row blocks (the slots of q, k, v: consumed), at the start of the wait
-      if constexpr (RVQ) ISSUE_RVQ_GATE(Ld); else { ISSUE(Ld, 4); ISSUE(Ld, 5); ISSUE(Ld, 6); }
       float v[1][8];
-      gather(std::integral_constant<int, 1>{}, SLOTS(M_GATE | (RVQ ? M_O : 0u)), 3, ebase | hop, 0x6000u, v);
+      gather(std::integral_constant<int, 1>{}, SLOTS(RVQ ? M_O : 0u), 3, ebase | hop, 0x6000u, v);
+      // gate's row blocks (the slots of q, k, v: consumed) once the hand-off is through, one at a time between the stages
+      // of o's input side: they have o's product, a hand-off and an edge to land
+      if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 0); else ISSUE(Ld, 4);
       BSTAMP(7);
       had::mul8(v[0], make_uint4(psu.x, psu.y, psu.z, psu.w));
       had8::fht4096<1, true>(v, xbuf, tid);
+      if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 1); else ISSUE(Ld, 5);
       const float sco = Ld.sc[3];
       const float mx = had8::max4096<true>(had8::absmax8(v[0], sco), red, tid);
+      if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 2); else ISSUE(Ld, 6);
       const int sh = had::shift_for(mx * (RVQ ? fmaxf(1.f, fabsf(a.resid_scale)) : 1.f));
       if constexpr (RVQ) had8::planes_scatter_rvq(v[0], sco, a.resid_scale, sh, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
       else had8::planes_scatter(v[0], sco, sh, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
@@ -852,14 +868,15 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     publish16(4, w * 8, 48, shs[3], ebase | hop);
     had::wg_barrier<true>();
     zero_acc(48, 16);
-    // up's row blocks (RVQ: their first virtual slice), at the start of the wait for z_o
-    if constexpr (RVQ) ISSUE_RVQ_UP_A(Ld); else { ISSUE(Ld, 7); ISSUE(Ld, 8); ISSUE(Ld, 9); }
     BSTAMP(9);
 
     // ================= P3: o's output side + residual, RMSNorm, input transforms of gate / up; their products =========
     rederive();
-    edge(std::integral_constant<int, 2>{}, SLOTS(M_GATE | M_UP), 4, ebase | hop, 0x7000u, Ld.sv[3], Ld.ln[1], Ld.su[4], Ld.su[5], Ld.sc[4], Ld.sc[5], true,
-         [&]() { BSTAMP(10); }, 18);
+    edge(std::integral_constant<int, 2>{}, SLOTS(M_GATE), 4, ebase | hop, 0x7000u, Ld.sv[3], Ld.ln[1], Ld.su[4], Ld.su[5], Ld.sc[4], Ld.sc[5], true,
+         // up's row blocks (RVQ: their first virtual slice) behind the hand-off, one at a time between the edge's stages
+         [&]() { BSTAMP(10); if constexpr (RVQ) ISSUE_RVQ_UP_A_G(Ld, 0); else ISSUE(Ld, 7); },
+         [&]() { if constexpr (RVQ) ISSUE_RVQ_UP_A_G(Ld, 1); else ISSUE(Ld, 8); },
+         [&]() { if constexpr (RVQ) ISSUE_RVQ_UP_A_G(Ld, 2); else ISSUE(Ld, 9); }, 18);
     BSTAMP(11);
     // row owners (w < NRO: rows k' = RPO w .. RPO w + RPO - 1, one per wave): SV_gate / SV_up / SU_down of their rows into the free
     // tail of the area; everybody: the image of the K x K factors, for the MLP edge
@@ -935,8 +952,6 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       }
       ++hop;                                           // hand-off: rows -> everybody
       const uint32_t tag2 = ebase | hop;
-      // down, behind the inbox stores: a row owner's first poll queues behind them, and the inbox takes longer than that to fill
-      if constexpr (RVQ) ISSUE_RVQ_DOWN(Ld); else { ISSUE(Ld, 10); ISSUE(Ld, 11); ISSUE(Ld, 12); }
       BSTAMP(13);
       if (w < NRO) {
         // the owner's inbox = 256 columns x (2 matrices x RPO rows) granules, swept by all 512 threads (coalesced 16-byte
@@ -1094,6 +1109,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           if (esync::spin_step(ok, spins, ctl + 1, 0x2000u + (uint32_t)w)) break;
         }
         BSTAMP(27);
+        // down, once the rows are here, a third at a time: staging, K-mix and planes are its time to land
+        if constexpr (RVQ) ISSUE_RVQ_DOWN_G0(Ld); else ISSUE(Ld, 10);
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
           const int i = tid + kThreads * j;
@@ -1102,9 +1119,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
             *reinterpret_cast<uint2*>(ft + col * B::KP16 + 2 * kp) = make_uint2(p[j].x, (2 * kp + 1 < FK) ? p[j].z : 0u);
           }
         }
-        own_slots(SLOTS(M_DOWN));
       }
       had::wg_barrier<true>();
+      if constexpr (RVQ) ISSUE_RVQ_DOWN_G1(Ld); else ISSUE(Ld, 11);
       BSTAMP(15);
       typedef float f32x4 __attribute__((ext_vector_type(4)));
       f32x4 acc[2][FRB];
@@ -1131,6 +1148,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           }
         }
       }
+      if constexpr (RVQ) ISSUE_RVQ_DOWN_G2(Ld); else ISSUE(Ld, 12);
       const float in_scale = Ld.sc[6] * 16.f;
       float mx = 0.f;
 #pragma unroll
@@ -1197,6 +1215,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       }
       had::wg_barrier<true>();
       BSTAMP(16);
+      esync::drain();                                  // down's codes (requested behind the rows' sweep)
+      own_slots(SLOTS(M_DOWN));
       const uint32_t xlane_d = (uint32_t)B::kArea + (uint32_t)min(n, 2) * (uint32_t)B::kPlaneD + (uint32_t)q * 64u;
       if constexpr (RVQ) {
 #pragma unroll
@@ -1237,7 +1257,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     // output side of this block's down_proj + residual -> h (the gather drains the requests above)
     rederive();
     edge(std::integral_constant<int, 0>{}, SLOTS(M_QKV), 5, ebase | hop, 0x4000u, sv_d_prev, nullptr, nullptr, nullptr, 0.f, 0.f, false,
-         [&]() { BSTAMP(1); });
+         [&]() { BSTAMP(1); }, [&]() {}, [&]() {});
   }
   // ---- h_out -----------------------------------------------------------------------------------------------------------
   if (w == 0) {
@@ -1253,6 +1273,11 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 #undef ISSUE_RVQ_GATE
 #undef ISSUE_RVQ_UP_A
 #undef ISSUE_RVQ_UP_B
+#undef ISSUE_RVQ_GATE_G
+#undef ISSUE_RVQ_DOWN_G0
+#undef ISSUE_RVQ_DOWN_G1
+#undef ISSUE_RVQ_DOWN_G2
+#undef ISSUE_RVQ_UP_A_G
 #undef ISSUE_RVQ_DOWN
 }
 
