@@ -249,6 +249,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 // the same bursts a third at a time (the CU's address unit takes ~25 clocks per 1 KB request: 48 requests in a row stall
 // the issuing waves for ~1.2K clocks, 16 at a time between other work do not)
 #define ISSUE_RVQ_GATE_G(Ld, i) do { ld_item_o(OFFC(0), qa[i], qb[i], Ld.W[4], vo_gu[i]); ld_item_o(OFFC(1024), qa[3 + (i)], qb[3 + (i)], Ld.W[4], vo_gu[i]); } while (0)
+#define ISSUE_RVQ_QKV_G(Ld, i) do { ld_item_o(OFFC(0), qa[i], qb[i], Ld.W[(3 * w + (i)) >> 8], vo_q[i]); ld_item_o(OFFC(1024), qa[3 + (i)], qb[3 + (i)], Ld.W[(3 * w + (i)) >> 8], vo_q[i]); } while (0)
 #define ISSUE_RVQ_DOWN_G0(Ld) do { ld_item_o(OFFC(0), qa[0], qb[0], Ld.W[6], vo_dr[0]); ld_item_o(OFFC(1024), qa[1], qb[1], Ld.W[6], vo_dr[0]); } while (0)
 #define ISSUE_RVQ_DOWN_G1(Ld) do { ld_item_o(OFFC(2048), qa[2], qb[2], Ld.W[6], vo_dr[0]); ld_item_o(OFFC(3072), qa[3], qb[3], Ld.W[6], vo_dr[0]); } while (0)
 #define ISSUE_RVQ_DOWN_G2(Ld) do { ld_item_o(OFFC(0), qa[4], qb[4], Ld.W[6], vo_dr[1]); ld_item_o(OFFC(0), qa[5], qb[5], Ld.W[6], vo_dr[2]); } while (0)
@@ -502,14 +503,13 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   const BlockLayer& Ld = *reinterpret_cast<const BlockLayer*>(smem + B::kDesc);
   if (tid < 64) reinterpret_cast<uint32_t*>(smem + B::kDesc)[tid] = reinterpret_cast<const uint32_t*>(a.layers)[tid];
   had::wg_barrier<true>();
-  for (int l = 0; l < a.n_layers; ++l) {
-    dbg_on = a.dbg != nullptr && l == a.dbg_layer;
+  // ================= P1: input transforms of q, k, v of the block whose descriptor is in LDS; their products; hand-off ========
+  // (called for block 0 here and, for block l + 1, at the bottom of iteration l: the requests of q, k, v go out BEHIND the
+  //  hand-off of z_d and are consumed before the loop's back edge, where no request may be in flight -- the compiler is free to
+  //  copy registers there)
+  auto P1 = [&]() {
     rederive();
-    BSTAMP(0);
-    // ================= P1: (previous down's output side) + input transforms of q, k, v; their products ===============
     const int c_lo = (3 * w) >> 8, c_hi = (3 * w + 2) >> 8;         // the one or two matrices this workgroup's row blocks are in
-    // (the output side of the previous block's down_proj + residual ran at the bottom of the previous iteration: no
-    //  weight request may be in flight across the loop edge, where the compiler is free to copy registers)
     edge(std::integral_constant<int, 2>{}, SLOTS(M_QKV), -1, 0u, 0u, nullptr, Ld.ln[0], Ld.su[c_lo], Ld.su[c_hi], Ld.sc[c_lo], Ld.sc[c_hi],
          c_hi != c_lo, [&]() {}, [&]() {}, [&]() {});
     BSTAMP(2);
@@ -531,12 +531,18 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     }
     had::wg_barrier<true>();
     zero_acc(0, 48);
+    BSTAMP(3);
+  };
+  P1();
+  for (int l = 0; l < a.n_layers; ++l) {
+    dbg_on = a.dbg != nullptr && l == a.dbg_layer;
+    rederive();
+    BSTAMP(0);
     // o of this block, behind the publication.  (A burst in front of a gather makes the gather's first check wait for the
     // burst -- vmcnt retires in order: ~2.3 us of HBM latency against the ~1.7 us a hand-off takes -- and a burst anywhere
     // else stalls the issuing waves for ~1.2K clocks, the CU's address unit taking ~25 clocks per 1 KB request.  Measured per
     // burst: gate, up and down are cheaper behind their hand-off; o, which only the head's workgroups would gain from, here.)
     if constexpr (RVQ) ISSUE_RVQ_O(Ld); else ISSUE(Ld, 3);
-    BSTAMP(3);
 
     // ================= P2: attention ====================================================================================
     rederive();
@@ -1247,17 +1253,25 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       BSTAMP(17);
     }
     sv_d_prev = Ld.sv[6];
-    if (l + 1 < a.n_layers) {
+    const bool more = l + 1 < a.n_layers;
+    if (more) {
       had::wg_barrier<true>();                         // everybody has read this block's descriptor for the last time
       if (tid < 64) reinterpret_cast<uint32_t*>(smem + B::kDesc)[tid] = reinterpret_cast<const uint32_t*>(a.layers + l + 1)[tid];
       had::wg_barrier<true>();
-      // q, k, v row blocks of the NEXT block, at the start of the wait for z_d
-      if constexpr (RVQ) ISSUE_RVQ_QKV(Ld); else { ISSUE(Ld, 0); ISSUE(Ld, 1); ISSUE(Ld, 2); }
     }
-    // output side of this block's down_proj + residual -> h (the gather drains the requests above)
+    // output side of this block's down_proj + residual -> h; the q, k, v row blocks of the NEXT block go out behind the
+    // hand-off, a third at a time
     rederive();
-    edge(std::integral_constant<int, 0>{}, SLOTS(M_QKV), 5, ebase | hop, 0x4000u, sv_d_prev, nullptr, nullptr, nullptr, 0.f, 0.f, false,
-         [&]() { BSTAMP(1); }, [&]() {}, [&]() {});
+    edge(std::integral_constant<int, 0>{}, SLOTS(0u), 5, ebase | hop, 0x4000u, sv_d_prev, nullptr, nullptr, nullptr, 0.f, 0.f, false,
+         [&]() { BSTAMP(1); if constexpr (RVQ) ISSUE_RVQ_QKV_G(Ld, 0); else ISSUE(Ld, 0); },
+         [&]() { if constexpr (RVQ) ISSUE_RVQ_QKV_G(Ld, 1); else ISSUE(Ld, 1); }, [&]() {});
+    // (requested unconditionally -- behind the last block: its own q, k, v rows once more, never multiplied -- so that no
+    //  request depends on a branch: the compiler makes several conditional regions of one `if`, and a register a load is
+    //  still going to write must not meet a copy at their joins)
+    if constexpr (RVQ) ISSUE_RVQ_QKV_G(Ld, 2); else ISSUE(Ld, 2);
+    if (more) P1();
+    esync::drain();
+    own_slots(SLOTS(M_QKV));
   }
   // ---- h_out -----------------------------------------------------------------------------------------------------------
   if (w == 0) {
@@ -1275,6 +1289,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 #undef ISSUE_RVQ_UP_B
 #undef ISSUE_RVQ_GATE_G
 #undef ISSUE_RVQ_DOWN_G0
+#undef ISSUE_RVQ_QKV_G
 #undef ISSUE_RVQ_DOWN_G1
 #undef ISSUE_RVQ_DOWN_G2
 #undef ISSUE_RVQ_UP_A_G

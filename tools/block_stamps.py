@@ -21,7 +21,7 @@ dec.reset(7)
 dec.pos.fill_(pos0)
 h = dec.embed[dec.tok].reshape(-1)
 dbg = torch.zeros(256 * 32, dtype=torch.int64, device="cuda:0")
-names = ["(top)", "z_d gathered + burst A", "edge: out(down) + in(q,k,v)", "gemv q,k,v + publish", "head: z_qkv gathered", "head: out(q,k,v)",
+names = ["(top)", "z_d gathered", "edge: out(down) + next block's in(q,k,v)", "next block's gemv q,k,v + publish", "head: z_qkv gathered", "head: out(q,k,v)",
          "attention + publish a", "a gathered", "in(o)", "gemv o + publish", "z_o gathered", "edge: out(o) + in(gate,up)",
          "gemv gate,up", "kmix + publish (mlp hop 1)", "row owner", "rows gathered", "kmix_in + planes", "gemv down + publish"]
 acc = []
@@ -41,22 +41,27 @@ print(f"status {dec.engine_status()}; launch of {layers} blocks: {np.median([t f
 head = np.arange(256) % 8 == 0
 D_ = np.stack([d for d, _ in acc])          # (runs, 256, 18)
 print("clocks between stamps inside block %d (mean over workgroups | head workgroups | others), s_memtime ticks:" % dl)
-tot = 0
-for i in range(1, 18):
-    prev = i - 1
+# iteration dl of the rotated loop: stamp 0 right behind the publication of ITS z_q, z_k, z_v, 4 .. 17, then 1 (z_d gathered),
+# 2 and 3 (the in-edge, products and publication of q, k, v of block dl + 1)
+order = [4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 1, 2, 3]
+prev_of = {4: 0, 7: 0, 1: 17}
+last = 0
+for i in order:
+    prev = prev_of.get(i, last)
+    last = i
     if i in (4, 5, 6):                      # head-only stamps
-        seg = D_[:, head, i] - D_[:, head, prev if i > 4 else 3]
+        seg = D_[:, head, i] - D_[:, head, prev]
         print(f"  {i:2d} {names[i]:34s} {'':>9s} {seg.mean():9.0f}")
         continue
-    if i == 7:                              # from stamp 3 (others) / 6 (heads)
-        so = D_[:, ~head, 7] - D_[:, ~head, 3]
+    if i == 7:                              # from stamp 0 (others) / 6 (heads)
+        so = D_[:, ~head, 7] - D_[:, ~head, 0]
         sh = D_[:, head, 7] - D_[:, head, 6]
         print(f"  {i:2d} {names[i]:34s} {'':>9s} {sh.mean():9.0f} {so.mean():9.0f}")
         continue
     seg = D_[:, :, i] - D_[:, :, prev]
     print(f"  {i:2d} {names[i]:34s} {seg.mean():9.0f} {seg[:, head].mean():9.0f} {seg[:, ~head].mean():9.0f}")
-span = D_[:, :, 17] - D_[:, :, 0]
-print(f"  block span (stamp 0 -> 17): {span.mean():.0f} ticks")
+span = D_[:, :, 3] - D_[:, :, 0]
+print(f"  block span (stamp 0 -> 3 of the next block): {span.mean():.0f} ticks")
 en = ["(after burst C)", "out: fht<1>", "out: h written + barrier", "sumsq", "in: mul + fht<2>", "in: max reduce", "planes + barrier"]
 print("inside the gate / up edge (stamps 18..24):")
 for i in range(1, 7):
