@@ -467,7 +467,9 @@ typedef struct quip_block_engine_args {
   int32_t n_layers, max_len, dbg_layer;
   float rms_eps, attn_scale;
   int32_t codebook;          /* 0: E8P12; 1: D4 (uint8 codes, grid_packed_abs = the fp16 (256, 4) table, d4.py:26-96);
-                              * 2: E8P12RVQ4B (int32 codes, e8p12_rvq4.py:37-45) */
+                              * 2: E8P12RVQ4B (int32 codes, e8p12_rvq4.py:37-45); 3: HI (int32 codes = 8 nibbles,
+                              * hi.py:41-63; grid_packed_abs = the fp16 (256, 4) table [lo - 7.5, hi - 7.5, 0, 0] of a
+                              * code BYTE: the row reads as a D4 row of twice the width) */
   float resid_scale;         /* codebook 2: the residual scale rounded to fp16 (origin_order.cu:337-385), else ignored */
 } quip_block_engine_args;
 int quip_block_engine_supported(int32_t hidden, int32_t heads, int32_t kv_heads, int32_t head_dim, int32_t n_ffn, int32_t K);

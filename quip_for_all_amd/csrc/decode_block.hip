@@ -130,10 +130,14 @@ struct BLds {
                 "transient area");
 };
 static_assert(BLds<24>::kBytes <= 160 * 1024 && BLds<16>::kBytes <= 160 * 1024 && BLds<64>::kBytes <= 160 * 1024 &&
-              BLds<16, true>::kBytes <= 160 * 1024, "LDS budget");
+              BLds<16, true>::kBytes <= 160 * 1024 && BLds<64, true>::kBytes <= 160 * 1024, "LDS budget");
 
-template <int REP, bool RVQ = false>
+// RVQ: rows of twice the (virtual) width.  HI (with RVQ and the D4 table mode): the HI codebook -- a code byte holds two
+// nibbles and reads as a D4 code of the virtual row with the table entry [lo - 7.5, hi - 7.5, 0, 0], against
+// x' = [x0 x2 0 0 | x4 x6 0 0 | x1 x3 0 0 | x5 x7 0 0]_g (hadamard.hip, HI layout)
+template <int REP, bool RVQ = false, bool HI = false>
 __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
+  static_assert(!HI || (RVQ && Lds<REP>::kD4), "HI = virtual rows of twice the width on the D4 table mode");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using B = BLds<REP, RVQ>;
   constexpr int VM = B::VM, KV = B::KV;
@@ -420,10 +424,13 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 #pragma unroll
         for (int i = 1; i < 8; ++i) { mx0 = fmaxf(mx0, red[i]); mx1 = fmaxf(mx1, red[8 + i]); }
         const float s0 = had::rms_scale(sc0, tot, HID, a.rms_eps), s1 = had::rms_scale(sc1, tot, HID, a.rms_eps);
-        const float rvf = RVQ ? fmaxf(1.f, fabsf(a.resid_scale)) : 1.f;       // (hadamard.hip: bound * max(1, |rs|))
+        const float rvf = (RVQ && !HI) ? fmaxf(1.f, fabsf(a.resid_scale)) : 1.f;       // (hadamard.hip: bound * max(1, |rs|))
         const int sh0 = had::shift_for(had::fmul(mx0, fabsf(s0)) * rvf), sh1 = had::shift_for(had::fmul(mx1, fabsf(s1)) * rvf);
         ESTAMP(5);
-        if constexpr (RVQ) {
+        if constexpr (HI) {
+          had8::planes_scatter_hi(v[0], s0, sh0, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
+          had8::planes_scatter_hi(v[1], s1, sh1, reinterpret_cast<uint8_t*>(smem + B::kArea + 3 * KV), tid);
+        } else if constexpr (RVQ) {
           had8::planes_scatter_rvq(v[0], s0, a.resid_scale, sh0, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
           had8::planes_scatter_rvq(v[1], s1, a.resid_scale, sh1, reinterpret_cast<uint8_t*>(smem + B::kArea + 3 * KV), tid);
         } else {
@@ -439,8 +446,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         had8::fht4096<1, true>(v, xbuf, tid);
         mx0 = had8::max4096<true>(had8::absmax8(v[0], 1.f), red, tid);
         const float s0 = had::rms_scale(sc0, tot, HID, a.rms_eps);
-        const int sh0 = had::shift_for(had::fmul(mx0, fabsf(s0)) * (RVQ ? fmaxf(1.f, fabsf(a.resid_scale)) : 1.f));
-        if constexpr (RVQ) had8::planes_scatter_rvq(v[0], s0, a.resid_scale, sh0, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
+        const int sh0 = had::shift_for(had::fmul(mx0, fabsf(s0)) * ((RVQ && !HI) ? fmaxf(1.f, fabsf(a.resid_scale)) : 1.f));
+        if constexpr (HI) had8::planes_scatter_hi(v[0], s0, sh0, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
+        else if constexpr (RVQ) had8::planes_scatter_rvq(v[0], s0, a.resid_scale, sh0, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
         else had8::planes_scatter(v[0], s0, sh0, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
         if (tid == 0) shs[0] = sh0;
       }
@@ -856,8 +864,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       const float sco = Ld.sc[3];
       const float mx = had8::max4096<true>(had8::absmax8(v[0], sco), red, tid);
       if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 2); else ISSUE(Ld, 6);
-      const int sh = had::shift_for(mx * (RVQ ? fmaxf(1.f, fabsf(a.resid_scale)) : 1.f));
-      if constexpr (RVQ) had8::planes_scatter_rvq(v[0], sco, a.resid_scale, sh, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
+      const int sh = had::shift_for(mx * ((RVQ && !HI) ? fmaxf(1.f, fabsf(a.resid_scale)) : 1.f));
+      if constexpr (HI) had8::planes_scatter_hi(v[0], sco, sh, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
+      else if constexpr (RVQ) had8::planes_scatter_rvq(v[0], sco, a.resid_scale, sh, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
       else had8::planes_scatter(v[0], sco, sh, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
       if (tid == 0) shs[3] = sh;
       had::wg_barrier<true>();
@@ -1167,7 +1176,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
             mx = fmaxf(mx, mm == mm ? mm : __builtin_inff());
           }
       const float bound = had::block_reduce(mx, true, red, tid, kThreads);
-      const int sh_d = had::shift_for(bound * (RVQ ? fmaxf(1.f, fabsf(a.resid_scale)) : 1.f));
+      const int sh_d = had::shift_for(bound * ((RVQ && !HI) ? fmaxf(1.f, fabsf(a.resid_scale)) : 1.f));
       {
         uint8_t* pl = reinterpret_cast<uint8_t*>(smem + B::kArea);
         const float s2 = had::fmul(in_scale, as_f32((uint32_t)(sh_d + 127) << 23));
@@ -1187,7 +1196,18 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
             }
             if (kc < FK) {
               const int kk = kc * FL + 16 * tile + 4 * q;
-              if constexpr (RVQ) {
+              if constexpr (HI) {
+                // four elements i0 .. i0 + 3 (i0 = 0 | 4) of one 8-group: virtual positions i0 + [0 1 . .] hold elements i0, i0 + 2,
+                // positions 8 + i0 + [0 1 . .] elements i0 + 1, i0 + 3; the other two of each word are zero digits
+                const int vv = 2 * (kk & ~7) + (kk & 4);
+                const int offa = (vv >> 8) * 272 + (vv & 255), offb = offa + 8;
+                *reinterpret_cast<uint32_t*>(pl + offa) = had::low_bytes4(H[0], H[2], 0, 0);
+                *reinterpret_cast<uint32_t*>(pl + B::kPlaneD + offa) = had::low_bytes4(X1[0], X1[2], 0, 0);
+                *reinterpret_cast<uint32_t*>(pl + 2 * B::kPlaneD + offa) = had::low_bytes4(X[0], X[2], 0, 0);
+                *reinterpret_cast<uint32_t*>(pl + offb) = had::low_bytes4(H[1], H[3], 0, 0);
+                *reinterpret_cast<uint32_t*>(pl + B::kPlaneD + offb) = had::low_bytes4(X1[1], X1[3], 0, 0);
+                *reinterpret_cast<uint32_t*>(pl + 2 * B::kPlaneD + offb) = had::low_bytes4(X[1], X[3], 0, 0);
+              } else if constexpr (RVQ) {
                 // four elements of one 8-group: residual-side digits at 2 (kk & ~7) + (kk & 7), main-side 8 further
                 int Y[4], Y1[4], G[4];
 #pragma unroll
@@ -1231,7 +1251,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           if (sl < B::JDV) {
             ItemAddr ad;
             item_addresses<REP>(qa[i], qb[i], lane_c, lane_c2, ad, 0u);
-            add_rows(item_mfma<272>(ad, xlane_d + (uint32_t)(sl * 544)), 160);
+            add_rows(T::kD4 ? item_mfma_d4<272>(ad, xlane_d + (uint32_t)(sl * 544)) : item_mfma<272>(ad, xlane_d + (uint32_t)(sl * 544)), 160);
           }
         }
       } else {
@@ -1326,7 +1346,8 @@ int block_engine_launch(const BlockEngineArgs& in, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
   };
   static DynLdsCache c16, c64;
-  static DynLdsCache crvq;
+  static DynLdsCache crvq, chi;
+  if (in.codebook == 3) return go(decode_block_kernel<64, true, true>, BLds<64, true>::kBytes, chi);
   if (in.codebook == 2) { a.resid_scale = in.resid_scale; return go(decode_block_kernel<16, true>, BLds<16, true>::kBytes, crvq); }
   if (in.codebook == 1) return go(decode_block_kernel<64>, BLds<64>::kBytes, c64);
   if (in.codebook != 0) return QUIP_ERR_UNSUPPORTED;

@@ -187,5 +187,24 @@ __device__ __forceinline__ void planes_scatter_rvq(const float v[8], float scale
   }
 }
 
+// HI: the digits of x' = [x0 x2 0 0 | x4 x6 0 0 | x1 x3 0 0 | x5 x7 0 0]_g (hadamard.hip, HI layout): element i of an
+// 8-group at virtual position 8 (i & 1) + 4 (i >> 2) + ((i >> 1) & 1) of its 16-group, a zero digit two positions further;
+// plane d at planes + d * 2 * kN; planes16's arithmetic
+__device__ __forceinline__ void planes_scatter_hi(const float v[8], float scale, int sh, uint8_t* planes, int tid) {
+#pragma clang fp contract(off)
+  const float s2 = had::fmul(scale, as_f32((uint32_t)(sh + 127) << 23));
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int e = tid + 512 * k, i = e & 7;
+    uint8_t* p = planes + 2 * (e & ~7) + (((i & 1) << 3) | ((i >> 2) << 2) | ((i >> 1) & 1));
+    const int X = (int)__builtin_rintf(v[k] * s2);
+    const int X1 = (X + 128) >> 8;
+    const int H = (X1 + 128) >> 8;
+    p[0] = (uint8_t)H;  p[2] = 0;
+    p[2 * kN] = (uint8_t)X1;  p[2 * kN + 2] = 0;
+    p[4 * kN] = (uint8_t)X;  p[4 * kN + 2] = 0;
+  }
+}
+
 }  // namespace had8
 }  // namespace quip

@@ -196,7 +196,7 @@ struct BlockEngineArgs {
   void* dbg = nullptr;
   int n_layers = 0, max_len = 0, dbg_layer = -1;
   float rms_eps = 1e-5f, attn_scale = 1.f;
-  int codebook = 0;                  // 0: E8P12 (grid = grid_packed_abs), 1: D4 (grid = the fp16 (256, 4) table), 2: E8P12RVQ4B
+  int codebook = 0;                  // 0: E8P12 (grid = grid_packed_abs), 1: D4 (grid = the fp16 (256, 4) table), 2: E8P12RVQ4B, 3: HI (grid = the byte table)
   float resid_scale = 0.f;           // codebook 2: the fp16 residual scale
 };
 bool block_engine_supported(int hidden, int heads, int kv_heads, int head_dim, int n_ffn, int K);

@@ -206,9 +206,9 @@ class LlamaDecoder:
             from .register_lib import ffn_engine_workspace
             self.ffn_ws = ffn_engine_workspace(s.ffn, L0["gate"].K_right, self.dev)
         # all blocks of a token as ONE persistent launch (csrc/decode_block.hip); QUIP_BLOCK_ENGINE=0 keeps the stage-wise step
-        # (E8P12, and D4 through the same kernel's one-table mode)
+        # (E8P12; D4 through the same kernel's one-table mode; E8P12RVQ4B and HI as rows of twice the virtual width)
         self.block_eng = False
-        d4 = all(getattr(m.codebook, "id", None) in ("D4", "E8P12RVQ4B") for m in L0.values() if isinstance(m, QuantLinear))
+        d4 = all(getattr(m.codebook, "id", None) in ("D4", "E8P12RVQ4B", "HI") for m in L0.values() if isinstance(m, QuantLinear))
         if ((self.ffn_eng or (d4 and self.fused_prologue and self.chain and os.environ.get("QUIP_FFN_ENGINE", "1") != "0"))
                 and os.environ.get("QUIP_BLOCK_ENGINE", "1") != "0"):
             self._init_block_engine()
@@ -230,7 +230,7 @@ class LlamaDecoder:
         names = ("q", "k", "v", "o", "gate", "up", "down")
 
         cbid = getattr(L0["q"].codebook, "id", None)
-        if cbid not in ("E8P12", "D4", "E8P12RVQ4B"):
+        if cbid not in ("E8P12", "D4", "E8P12RVQ4B", "HI"):
             return
 
         def plain(m, n_in, n_out):
@@ -260,8 +260,9 @@ class LlamaDecoder:
         self._eng_keep = keep
         self.eng_layers = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).to(self.dev)
         self.eng_ws = block_engine_workspace(self.dev)
-        self.eng_codebook = {"E8P12": 0, "D4": 1, "E8P12RVQ4B": 2}[cbid]
-        self.eng_grid = L0["q"].codebook.grid if cbid == "D4" else L0["q"].codebook.grid_packed_abs
+        self.eng_codebook = {"E8P12": 0, "D4": 1, "E8P12RVQ4B": 2, "HI": 3}[cbid]
+        cb0 = L0["q"].codebook
+        self.eng_grid = cb0.grid if cbid == "D4" else (cb0._virtual_grid(self.dev) if cbid == "HI" else cb0.grid_packed_abs)
         self.eng_resid_scale = float(getattr(L0["q"].codebook, "planes_resid_scale", 0.0)) if cbid == "E8P12RVQ4B" else 0.0
         self.block_eng = True
 

@@ -684,9 +684,9 @@ def _block_engine_cuda(layers, h_in, pos, cos, sin, grid, workspace, n_layers, m
               "cos / sin: fp32 [max_len, 128]")
     _need(workspace.dtype == torch.uint8 and workspace.device == dev
           and workspace.numel() >= capi.lib().quip_block_engine_workspace_bytes(), "workspace too small")
-    if codebook == 1:      # D4: the fp16 (256, 4) table -- 2 KB like grid_packed_abs
+    if codebook in (1, 3):      # D4 / HI: the fp16 (256, 4) table (HI: of a code byte) -- 2 KB like grid_packed_abs
         g = _d4_grid_f16(grid)
-        _need(g.device == dev and g.numel() == 1024, "D4 grid: fp16 (256, 4) on the device")
+        _need(g.device == dev and g.numel() == 1024, "D4 / HI grid: fp16 (256, 4) on the device")
     else:
         g = _grid_i64(grid, h_in)
     out = torch.empty_like(h_in)

@@ -125,9 +125,9 @@ def test_block_engine_kernels_use_no_scratch_and_touch_no_register_in_flight():
     r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", "-", src,
                         "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, check=True)
     scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
-    assert len(scratch) == 4 and not any(scratch), scratch
+    assert len(scratch) == 5 and not any(scratch), scratch
     kernels = [(n, l) for n, l in check_inflight.kernels_of(r.stdout) if "decode_block_kernel" in n]
-    assert len(kernels) == 4
+    assert len(kernels) == 5
     for name, lines in kernels:
         assert check_inflight.check_kernel(lines) == [], name
 

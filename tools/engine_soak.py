@@ -9,7 +9,7 @@ from quip_for_all_amd import decode as D  # noqa
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 bad = 0
-for cb in ("E8P12", "D4", "E8P12RVQ4B"):
+for cb in ("E8P12", "D4", "E8P12RVQ4B", "HI"):
     dec = D.LlamaDecoder(D.LLAMA2_7B, cb, max_len=n + 8, device="cuda:0", seed=0, device_init=True)
     assert dec.block_eng
     runs = [dec.generate(n, first_token=11, use_graph=True).cpu() for _ in range(reps)]
