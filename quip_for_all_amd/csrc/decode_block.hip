@@ -692,9 +692,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         if (live) {
           const float mn = fmaxf(m, sc);
           const float cc = __expf(m - mn), pp = __expf(sc - mn);
-          lsum = lsum * cc + pp;
+          lsum = __builtin_fmaf(lsum, cc, pp);          // (decode_glue.hip's arithmetic, spelled out there and here)
 #pragma unroll
-          for (int i = 0; i < 8; ++i) acc8[i] = acc8[i] * cc + pp * v8[i];
+          for (int i = 0; i < 8; ++i) acc8[i] = __builtin_fmaf(acc8[i], cc, had::fmul(pp, v8[i]));
           m = mn;
         }
       };

@@ -28,8 +28,9 @@ namespace {
 struct AttnZ {
   const f16* z[3];      // raw GEMV outputs of q / k / v_proj, [n] each
   const f16* post[3];   // SV of the three modules, [n]
-  float scale[3];       // 1 / sqrt(n)
-  int n, logL;          // common width (heads * HD == kv_heads * HD == n), a power of two <= 4096
+  float scale[3];       // 1 / sqrt(width)
+  int n, logL;          // multi-head attention: common width (heads * HD == kv_heads * HD == n), a power of two <= 4096
+                        // grouped queries (LQ / LKV instantiations): the width of q; k and v are 2^LKV wide
 };
 
 struct AttnArgs {
@@ -78,8 +79,14 @@ __device__ __forceinline__ void rope8(const f16* vec, const float c8[8], const f
   for (int i = 0; i < 8; ++i) o[i] = (float)(f16)had::fadd(had::fmul(a[i], c8[i]), had::fmul(sgn * b[i], s8[i]));
 }
 
-template <int HD, bool ZIN>
-__global__ __launch_bounds__(ZIN ? 768 : 256) void rope_attn_decode_kernel(AttnArgs a, AttnZ zz) {
+// barriers inside fht16_fixed<LOGL, false> (had_device.hip.h): two around the lane stages, two per pass through LDS
+__host__ __device__ constexpr int fht16_barriers(int logl) { return logl <= 8 ? 2 : 2 + 2 * ((logl + 3) / 4 - 2); }
+
+// ZIN with LQ == 0: q, k, v of one common width on 3 x 256 threads (run-time length).  LQ > 0 (grouped queries): q of
+// width 2^LQ on the first 2^LQ / 16 threads, k and v of width 2^LKV on the next 2 x 2^LKV / 16 (whole waves each).
+template <int HD, bool ZIN, int LQ = 0, int LKV = 0>
+__global__ __launch_bounds__(!ZIN ? 256 : (LQ == 0 ? 768 : (1 << LQ) / 16 + 2 * ((1 << LKV) / 16)))
+void rope_attn_decode_kernel(AttnArgs a, AttnZ zz) {
   constexpr int LPK = HD / 8;        // lanes per key
   constexpr int NG = 256 / LPK;      // key groups per workgroup
   constexpr int U = 4;               // keys in flight per group
@@ -89,8 +96,12 @@ __global__ __launch_bounds__(ZIN ? 768 : 256) void rope_attn_decode_kernel(AttnA
   const int gl = tid % LPK, grp = tid / LPK, d0 = gl * 8;
   const int group = a.heads / a.kv_heads, kvh = h / group;
   // ZIN: the transform inputs do not depend on the position: requested before it is read
-  const int g3 = tid >> 8, tt = tid & 255, e0 = tt * 16;
-  const bool zact = ZIN && e0 < zz.n;
+  constexpr bool GQ = LQ > 0;
+  constexpr int TQ = GQ ? (1 << LQ) / 16 : 256, TKV = GQ ? (1 << LKV) / 16 : 256;
+  static_assert(!GQ || (TQ >= 256 && TKV % 64 == 0), "the attention runs on the first 256 threads; k / v on whole waves");
+  const int g3 = GQ ? (tid < TQ ? 0 : (tid < TQ + TKV ? 1 : 2)) : tid >> 8;
+  const int tt = GQ ? tid - (g3 == 0 ? 0 : (g3 == 1 ? TQ : TQ + TKV)) : tid & 255, e0 = tt * 16;
+  const bool zact = ZIN && (GQ || e0 < zz.n);
   uint4 zraw[2] = {}, praw[2] = {};
   if constexpr (ZIN) {
     if (zact) {
@@ -138,7 +149,19 @@ __global__ __launch_bounds__(ZIN ? 768 : 256) void rope_attn_decode_kernel(AttnA
     had::unpack8(zraw[1], v + 8);
     had::unpack8(praw[0], tp);
     had::unpack8(praw[1], tp + 8);
-    had::fht16(v, zbuf + g3 * had::buf_floats(zz.n), tt, zz.logL, act, 0);
+    if constexpr (GQ) {
+      // different lengths side by side: the shorter transform passes the barriers the longer one still has to meet
+      float* zb = zbuf + (g3 == 0 ? 0 : had::buf_floats(1 << LQ) + (g3 - 1) * had::buf_floats(1 << LKV));
+      if (g3 == 0) {
+        had::fht16_fixed<LQ, false>(v, zb, 0, tt, true);
+      } else {
+        had::fht16_fixed<LKV, false>(v, zb, 0, tt, true);
+#pragma unroll
+        for (int i = 0; i < fht16_barriers(LQ) - fht16_barriers(LKV); ++i) __syncthreads();
+      }
+    } else {
+      had::fht16(v, zbuf + g3 * had::buf_floats(zz.n), tt, zz.logL, act, 0);
+    }
     const int base = (g3 == 0 ? h : kvh) * HD;
     if (act && e0 >= base && e0 < base + HD) {
       f16 o[16];
@@ -201,9 +224,11 @@ __global__ __launch_bounds__(ZIN ? 768 : 256) void rope_attn_decode_kernel(AttnA
       if (t < t_hi) {
         const float mn = fmaxf(m, s);
         const float c = __expf(m - mn), p = __expf(s - mn);
-        l = l * c + p;
+        // (spelled out: left to the compiler, the instantiations of this kernel contract a * c + p * v differently -- one
+        //  element in 8192 moved by an ulp between the grouped-query prologue and the plain kernel)
+        l = __builtin_fmaf(l, c, p);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = acc[i] * c + p * v8[i];
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_fmaf(acc[i], c, had::fmul(p, v8[i]));
         m = mn;
       }
     }
@@ -282,7 +307,16 @@ static int rope_attn_launch_common(AttnArgs a, const AttnZ* zz, int head_dim, in
                                              (size_t)heads * kSplits * (head_dim + 4) * sizeof(float));
   }
   const dim3 grid(heads, split ? kSplits : 1);
-  if (zz) {
+  if (zz && a.heads != a.kv_heads) {
+    const int nq = a.heads * head_dim, nkv = a.kv_heads * head_dim;
+    const size_t lds = ((size_t)had::buf_floats(nq) + 2 * (size_t)had::buf_floats(nkv)) * sizeof(float);
+    if (head_dim == 128 && nq == 8192 && nkv == 1024)
+      hipLaunchKernelGGL((rope_attn_decode_kernel<128, true, 13, 10>), grid, dim3(512 + 128), lds, stream, a, *zz);
+    else if (head_dim == 128 && nq == 4096 && nkv == 1024)
+      hipLaunchKernelGGL((rope_attn_decode_kernel<128, true, 12, 10>), grid, dim3(256 + 128), lds, stream, a, *zz);
+    else
+      return QUIP_ERR_UNSUPPORTED;
+  } else if (zz) {
     const size_t lds = 3 * (size_t)had::buf_floats(zz->n) * sizeof(float);
     if (head_dim == 128)
       hipLaunchKernelGGL((rope_attn_decode_kernel<128, true>), grid, dim3(768), lds, stream, a, *zz);
@@ -314,8 +348,9 @@ int rope_attn_decode_launch(const void* q, const void* k, const void* v, const f
 
 bool rope_attn_decode_z_supported(int heads, int kv_heads, int head_dim) {
   const int n = heads * head_dim;
-  return heads >= 1 && heads == kv_heads && (head_dim == 64 || head_dim == 128) && n >= 256 && n <= 4096 &&
-         (n & (n - 1)) == 0;
+  // grouped queries: Llama-2-70B / Llama-3-70B (64 heads, 8 KV heads) and Llama-3-8B / Mistral-7B (32 / 8)
+  if (heads != kv_heads) return head_dim == 128 && kv_heads == 8 && (heads == 64 || heads == 32);
+  return heads >= 1 && (head_dim == 64 || head_dim == 128) && n >= 256 && n <= 4096 && (n & (n - 1)) == 0;
 }
 
 int rope_attn_decode_z_launch(const void* const* z, const void* const* post, const float* scales, const float* cos,

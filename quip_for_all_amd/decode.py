@@ -212,13 +212,14 @@ class LlamaDecoder:
         if ((self.ffn_eng or (d4 and self.fused_prologue and self.chain and os.environ.get("QUIP_FFN_ENGINE", "1") != "0"))
                 and os.environ.get("QUIP_BLOCK_ENGINE", "1") != "0"):
             self._init_block_engine()
-        # q / k / v output transforms inside the attention launch (multi-head attention, power-of-two hidden <= 4096,
-        # plain SV output side)
+        # q / k / v output transforms inside the attention launch (multi-head attention with a power-of-two hidden <= 4096,
+        # or 64 / 32 heads on 8 KV heads -- Llama-2-70B, Llama-3, Mistral-7B; plain SV output side)
         from .register_lib import rope_attn_decode_z_supported
         self.attn_z = (self.fused_prologue and self.fused_attention and os.environ.get("QUIP_ATTN_Z", "1") != "0"
                        and rope_attn_decode_z_supported(s.heads, s.kv_heads, s.head_dim)
                        and all(l.K_right == 1 and not l.per_channel and l.bias is None and l.SV is not None
-                               and l.q_out_features == l.out_features == s.hidden for l in qkv0))
+                               and l.q_out_features == l.out_features == (s.heads if i == 0 else s.kv_heads) * s.head_dim
+                               for i, l in enumerate(qkv0)))
 
     def _init_block_engine(self):
         """descriptors + workspace of the persistent block launch, when every block qualifies"""

@@ -744,13 +744,14 @@ def _rope_attn_decode_z_cuda(zs, posts, scales, cos, sin, pos, kcache, vcache, w
     kvh, max_len, hd = kcache.shape
     n = zs[0].numel()
     heads = n // hd
-    for t in list(zs) + list(posts):
-        _need(t.dtype == torch.float16 and t.is_contiguous() and t.is_cuda and t.numel() == n,
-              "rope_attn_decode_z: fp16 contiguous CUDA vectors of one common length")
+    for i, t in enumerate(list(zs) + list(posts)):
+        _need(t.dtype == torch.float16 and t.is_contiguous() and t.is_cuda and t.numel() == (n if i % 3 == 0 else kvh * hd),
+              "rope_attn_decode_z: fp16 contiguous CUDA vectors, heads * head_dim (q) / kv_heads * head_dim (k, v) long")
     for t in (kcache, vcache):
         _need(t.dtype == torch.float16 and t.is_contiguous() and t.is_cuda, "rope_attn_decode_z: fp16 caches")
     _need(heads * hd == n and rope_attn_decode_z_supported(heads, kvh, hd),
-          "rope_attn_decode_z: needs heads == kv_heads and heads * head_dim a power of two in 256..4096")
+          "rope_attn_decode_z: needs heads == kv_heads and heads * head_dim a power of two in 256..4096, or 64 / 32 heads "
+          "of 128 on 8 KV heads")
     _need(cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous()
           and tuple(cos.shape) == (max_len, hd) and tuple(sin.shape) == (max_len, hd), "cos / sin: float32 (max_len, hd)")
     _need(pos.dtype == torch.int64 and pos.numel() == 1 and pos.is_cuda, "pos must be an int64 device scalar")

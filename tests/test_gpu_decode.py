@@ -329,30 +329,33 @@ def test_batched_prompt_prefill_matches_token_by_token(shape_name, plen):
                 assert float(lg.max() - lg[tok]) <= 0.03 * (float(lg.abs().max()) + 1.0), (t, tok)
 
 
-@pytest.mark.parametrize("heads,hd,pos,max_len", [(32, 128, 0, 64), (32, 128, 37, 64), (32, 128, 300, 512), (8, 128, 5, 32),
-                                                 (16, 64, 11, 32), (4, 64, 3, 16)])
-def test_rope_attn_decode_z_equals_transform_then_attention(heads, hd, pos, max_len):
+@pytest.mark.parametrize("heads,kvh,hd,pos,max_len", [(32, 32, 128, 0, 64), (32, 32, 128, 37, 64), (32, 32, 128, 300, 512),
+                                                     (8, 8, 128, 5, 32), (16, 16, 64, 11, 32), (4, 4, 64, 3, 16),
+                                                     (64, 8, 128, 0, 64), (64, 8, 128, 37, 64), (64, 8, 128, 300, 512),
+                                                     (32, 8, 128, 5, 32), (32, 8, 128, 301, 512)])
+def test_rope_attn_decode_z_equals_transform_then_attention(heads, kvh, hd, pos, max_len):
     """the attention launch that runs the q / k / v output transforms in its prologue (quip_rope_attn_decode_z_f16)
     against the two launches it replaces: same output, same cache rows, bit for bit -- short contexts and the
-    split mode (pos >= 256)"""
+    split mode (pos >= 256); multi-head attention and grouped queries (Llama-2-70B: 64 heads on 8 KV heads -- an
+    8192-point transform next to two 1024-point ones in one workgroup)"""
     import quip_for_all_amd  # noqa: F401
     from quip_for_all_amd.register_lib import rope_attn_workspace, rope_attn_decode_z_supported
-    assert rope_attn_decode_z_supported(heads, heads, hd)
-    n = heads * hd
+    assert rope_attn_decode_z_supported(heads, kvh, hd)
+    ns = [heads * hd, kvh * hd, kvh * hd]
     g = torch.Generator().manual_seed(heads * 1000 + pos)
-    zs = [(torch.randn(1, n, generator=g) * 3).half().to(DEV) for _ in range(3)]
+    zs = [(torch.randn(1, n, generator=g) * 3).half().to(DEV) for n in ns]
     svs = [(torch.randint(0, 2, (n,), generator=g).float() * 2 - 1).mul(torch.rand(n, generator=g) + 0.5).half().to(DEV)
-           for _ in range(3)]
-    scales = [1.0 / np.sqrt(n)] * 3
+           for n in ns]
+    scales = [1.0 / np.sqrt(n) for n in ns]
     ang = torch.arange(max_len, dtype=torch.float32)[:, None] * (1.0 / (10000 ** (torch.arange(0, hd, 2).float() / hd)))[None]
     cos = torch.cat([ang.cos(), ang.cos()], -1).to(DEV).contiguous()
     sin = torch.cat([ang.sin(), ang.sin()], -1).to(DEV).contiguous()
-    kc0 = torch.randn(heads, max_len, hd, generator=g).half().to(DEV)
-    vc0 = torch.randn(heads, max_len, hd, generator=g).half().to(DEV)
+    kc0 = torch.randn(kvh, max_len, hd, generator=g).half().to(DEV)
+    vc0 = torch.randn(kvh, max_len, hd, generator=g).half().to(DEV)
     p = torch.tensor([pos], dtype=torch.long, device=DEV)
-    outs = torch.ops.quip_lib.had_transform_group(zs, [n] * 3, n, 1, [None] * 3, False, [None] * 3, svs, [None] * 3,
-                                                  scales, [None] * 3, [None] * 3, None, 1e-5, None)
-    q, k, v = [o.view(heads, hd) for o in outs]
+    outs = [torch.ops.quip_lib.had_transform_group([z], [n], n, 1, [None], False, [None], [sv], [None], [sc], [None], [None],
+                                                   None, 1e-5, None)[0] for z, n, sv, sc in zip(zs, ns, svs, scales)]
+    q, k, v = outs[0].view(heads, hd), outs[1].view(kvh, hd), outs[2].view(kvh, hd)
     kc1, vc1, kc2, vc2 = kc0.clone(), vc0.clone(), kc0.clone(), vc0.clone()
     ws1, ws2 = rope_attn_workspace(heads, hd, DEV), rope_attn_workspace(heads, hd, DEV)
     ref = torch.ops.quip_lib.rope_attn_decode(q, k, v, cos, sin, p, kc1, vc1, ws1)
@@ -365,13 +368,14 @@ def test_rope_attn_decode_z_equals_transform_then_attention(heads, hd, pos, max_
     assert torch.equal(got2, ref)
 
 
-def test_decoder_step_with_transforms_in_the_attention_launch():
-    """a multi-head model (heads == kv_heads, hidden a power of two) takes the 9-launch block; tokens and logits
-    equal the 10-launch block's"""
+@pytest.mark.parametrize("hidden,ffn,heads,kv_heads", [(1024, 2816, 8, 8), (4096, 2816, 32, 8), (8192, 3584, 64, 8)])
+def test_decoder_step_with_transforms_in_the_attention_launch(hidden, ffn, heads, kv_heads):
+    """a multi-head model (heads == kv_heads, hidden a power of two), or one with 32 / 64 heads on 8 KV heads (Llama-3-8B /
+    Mistral-7B / Llama-2-70B attention shapes), takes the 9-launch block; tokens and logits equal the 10-launch block's"""
     from quip_for_all_amd import decode as D
-    shape = D.LlamaShape(hidden=1024, ffn=2816, layers=2, heads=8, kv_heads=8, vocab=1024)
+    shape = D.LlamaShape(hidden=hidden, ffn=ffn, layers=2, heads=heads, kv_heads=kv_heads, vocab=1024)
     dec = D.LlamaDecoder(shape, "E8P12", max_len=32, device="cuda:0", seed=5)
-    assert dec.attn_z and dec.fused_prologue
+    assert dec.attn_z and dec.fused_prologue and not getattr(dec, "block_eng", False)
     t9 = dec.generate(10, first_token=3, use_graph=False)
     dec.reset(3)
     with torch.no_grad():
