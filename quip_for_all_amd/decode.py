@@ -238,7 +238,8 @@ class LlamaDecoder:
             return (getattr(m.codebook, "id", None) == cbid and not m.per_channel and m.bias is None and not m.training
                     and m.SU is not None and m.SV is not None and m.in_features == m.q_in_features == n_in
                     and m.out_features == m.q_out_features == n_out)
-        ok = block_engine_supported(s.hidden, s.heads, s.kv_heads, s.head_dim, s.ffn, L0["gate"].K_right)
+        ok = (block_engine_supported(s.hidden, s.heads, s.kv_heads, s.head_dim, s.ffn, L0["gate"].K_right)
+              and len(self.layers) <= 146)      # (the launch's hand-off counter: 7 per block in 10 bits)
         for L in self.layers:
             ok = ok and all(plain(L[k], s.hidden, s.hidden) and L[k].K_left == 1 and L[k].K_right == 1 for k in "qkvo")
             ok = ok and all(plain(L[k], s.hidden, s.ffn) and L[k].K_left == 1 for k in ("gate", "up"))
