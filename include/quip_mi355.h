@@ -108,6 +108,20 @@ int quip_hi_mm_skinny(const void* x, const void* qidxs, void* y, int32_t m, int3
  * quip_decompress_e8p_origorder + a dense GEMM). */
 int quip_e8p_mm_batched(const void* x, const void* qidxs /* int16 (n, k/8) */, const void* grid_packed_abs,
                         void* y, int64_t m, int32_t n, int32_t k, quip_stream_t stream);
+/* The same fused tile kernel with the other codebooks' decode -- what the reference serves at M >= 32 with
+ * decompress_* + `x @ W.T` (e8p12_rvq4.py:50-67, e8p12_rvq3.py:109-129, d4.py:128-139, hi.py:52-63), computed on the
+ * exact fp16 weights those decompress ops write (E8P12RVQ4B / 3B: fma(resid_scale, w_residual, w_main), one fp16 rounding
+ * per weight, origin_order.cu:330-331,378-380), without materialising W.  Code layouts and tables as for the *_mm_skinny
+ * entry points above; same shape rules as quip_e8p_mm_batched. */
+int quip_e8prvq4_mm_batched(const void* x, const void* qidxs /* int32 (n, k/8) */, const void* grid_packed_abs,
+                            float resid_scale, void* y, int64_t m, int32_t n, int32_t k, quip_stream_t stream);
+int quip_e8prvq3_mm_batched(const void* x, const void* qidxs /* 3 k / 8 bytes per row */, const void* grid_packed_abs,
+                            const void* e81b_packed, float resid_scale, void* y, int64_t m, int32_t n, int32_t k,
+                            quip_stream_t stream);
+int quip_d4_mm_batched(const void* x, const void* qidxs /* uint8 (n, k/4) */, const void* grid_f16, void* y, int64_t m,
+                       int32_t n, int32_t k, quip_stream_t stream);
+int quip_hi_mm_batched(const void* x, const void* qidxs /* int32 (n, k/8) */, void* y, int64_t m, int32_t n, int32_t k,
+                       quip_stream_t stream);
 /* Workspace variant of the E8P12 product.  For 1 <= m < 32 (the range the codebook module sends to this
  * op, e8p12.py:147-150) the fast path first rewrites every row of x as block fixed point int8 digit planes
  * (one small launch, one workgroup per row) and then runs the integer-domain matrix-core GEMV -- m == 1:

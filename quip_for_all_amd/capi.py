@@ -52,6 +52,10 @@ SIGNATURES = {
     "quip_ffn_engine": [_P, _P],
     "quip_e8p_mm_origorder": [_P, _P, _P, _P, _I32, _I32, _I32, _P],
     "quip_e8p_mm_batched": [_P, _P, _P, _P, _I64, _I32, _I32, _P],
+    "quip_e8prvq4_mm_batched": [_P, _P, _P, _F, _P, _I64, _I32, _I32, _P],
+    "quip_e8prvq3_mm_batched": [_P, _P, _P, _P, _F, _P, _I64, _I32, _I32, _P],
+    "quip_d4_mm_batched": [_P, _P, _P, _P, _I64, _I32, _I32, _P],
+    "quip_hi_mm_batched": [_P, _P, _P, _I64, _I32, _I32, _P],
     "quip_e8p_mm_skinny": [_P, _P, _P, _P, _I32, _I32, _I32, _P],
     "quip_e8prvq4_mm_skinny": [_P, _P, _P, _F, _P, _I32, _I32, _I32, _P],
     "quip_e8prvq3_mm_skinny": [_P, _P, _P, _P, _F, _P, _I32, _I32, _I32, _P],

@@ -57,7 +57,10 @@ class _SkinnyMixin:
     skinny kernel in the codebook's mode (csrc/e8p_skinny_gemm.hip) -- the reference's arithmetic for this regime
     (origin_order.cu:388-555 with the codebook's BLayout: exact fp16 weights, fp32 accumulation), i.e. x . W of the dense W
     that decompress_weight() writes.  Subclasses give mm_skinny() and the m * n up to which chunks of 32 rows beat
-    decompress + dense GEMM."""
+    decompress + dense GEMM.  Beyond that, QUIP_BATCHED_MM=fused selects the fused dequant + MFMA tile kernel in the
+    codebook's mode (csrc/e8p_prefill_gemm.hip, mm_batched()): the same product of the same dense W without the
+    2 n k bytes of scratch and without the vendor GEMM; the default stays decompress + dense GEMM, the reference's shape
+    (e8p12_rvq4.py:50-67, e8p12_rvq3.py:109-129, d4.py:128-139, hi.py:52-63), measured faster."""
     skinny_chunks_max_mn = int(os.environ.get("QUIP_SKINNY_MAX_MN", str(1_200_000)))
 
     @staticmethod
@@ -70,12 +73,17 @@ class _SkinnyMixin:
         if (E8P12_codebook.batched_mode != "reference" and m * n <= self.skinny_chunks_max_mn
                 and self.skinny_supported(m, n, k)):
             return "skinny_chunks"
+        if E8P12_codebook.batched_mode == "fused" and n % 2 == 0 and k % 64 == 0:
+            return "fused_gemm"
         return "decompress_gemm"
 
     def forward(self, input, Qidxs):
-        if (input.size(0) >= self.mm_threshold and input.is_cuda and input.dtype == torch.float16 and input.dim() == 2
-                and self.batched_regime(input.shape[0], Qidxs.shape[0], input.shape[1]) == "skinny_chunks"):
-            return self.mm_skinny(input, Qidxs)
+        if input.size(0) >= self.mm_threshold and input.is_cuda and input.dtype == torch.float16 and input.dim() == 2:
+            regime = self.batched_regime(input.shape[0], Qidxs.shape[0], input.shape[1])
+            if regime == "skinny_chunks":
+                return self.mm_skinny(input, Qidxs)
+            if regime == "fused_gemm":
+                return self.mm_batched(input, Qidxs)
         return _Codebook.forward(self, input, Qidxs)
 
 
@@ -257,6 +265,9 @@ class E8P12RVQ4B_codebook(_SkinnyMixin, _Codebook):
     def mm_skinny(self, xh, Qidxs):
         return torch.ops.quip_lib.e8prvq4_mm_skinny(xh, Qidxs, self.grid_packed_abs, self.opt_resid_scale)
 
+    def mm_batched(self, xh, Qidxs):
+        return torch.ops.quip_lib.e8prvq4_mm_batched(xh, Qidxs, self.grid_packed_abs, self.opt_resid_scale)
+
 
 class E8P12RVQ3B_codebook(_SkinnyMixin, _Codebook):
     def __init__(self, inference=False, opt_resid_scale=None, **kwargs):
@@ -323,6 +334,9 @@ class E8P12RVQ3B_codebook(_SkinnyMixin, _Codebook):
     def mm_skinny(self, xh, Qidxs):
         return torch.ops.quip_lib.e8prvq3_mm_skinny(xh, Qidxs, self.grid_packed_abs, self.e81b_grid_packed, self.opt_resid_scale)
 
+    def mm_batched(self, xh, Qidxs):
+        return torch.ops.quip_lib.e8prvq3_mm_batched(xh, Qidxs, self.grid_packed_abs, self.e81b_grid_packed, self.opt_resid_scale)
+
     def maybe_pack_idxs(self, idxs):
         """keep the low 3 bytes of every int32 index (e8p12_rvq3.py:102-107)"""
         b = idxs.contiguous().view(torch.int8).view(idxs.shape[0], idxs.shape[1], -1)
@@ -385,6 +399,9 @@ class D4_codebook(_SkinnyMixin, _Codebook):
 
     def mm_skinny(self, xh, Qidxs):
         return torch.ops.quip_lib.d4_mm_skinny(xh, Qidxs, self.grid)
+
+    def mm_batched(self, xh, Qidxs):
+        return torch.ops.quip_lib.d4_mm_batched(xh, Qidxs, self.grid)
 
 
 class HI4B1C_codebook(_SkinnyMixin, _Codebook):
@@ -453,6 +470,9 @@ class HI4B1C_codebook(_SkinnyMixin, _Codebook):
 
     def mm_skinny(self, xh, Qidxs):
         return torch.ops.quip_lib.hi_mm_skinny(xh, Qidxs)
+
+    def mm_batched(self, xh, Qidxs):
+        return torch.ops.quip_lib.hi_mm_batched(xh, Qidxs)
 
     def decompress_weight(self, Qidxs):
         return torch.ops.quip_lib.decompress_hi_origorder(Qidxs)

@@ -579,6 +579,47 @@ int quip_e8p_mm_batched(const void* x, const void* qidxs, const void* grid, void
   return e8p_prefill_gemm_launch(x, qidxs, grid, y, m, n, k, (hipStream_t)stream);
 }
 
+// the other codebooks on the fused tile kernel (e8p_prefill_gemm.hip, MODE 1..4)
+static int batched_args_ok(const void* x, const void* qidxs, const void* y, int64_t m, int32_t n, int32_t k) {
+  if (!x || !qidxs || !y) return QUIP_ERR_NULL_POINTER;
+  if (m < 0 || n < 1 || k < 8) return QUIP_ERR_BAD_SHAPE;
+  if (!aligned16(x) || !aligned16(qidxs) || !aligned16(y)) return QUIP_ERR_MISALIGNED;
+  return QUIP_OK;
+}
+
+int quip_e8prvq4_mm_batched(const void* x, const void* qidxs, const void* grid, float resid_scale, void* y, int64_t m,
+                            int32_t n, int32_t k, quip_stream_t stream) {
+  if (!grid) return QUIP_ERR_NULL_POINTER;
+  if (const int st = batched_args_ok(x, qidxs, y, m, n, k)) return st;
+  if (reinterpret_cast<uintptr_t>(grid) & 7u) return QUIP_ERR_MISALIGNED;
+  if (m == 0) return QUIP_OK;
+  return e8prvq4_prefill_gemm_launch(x, qidxs, grid, resid_scale, y, m, n, k, (hipStream_t)stream);
+}
+
+int quip_e8prvq3_mm_batched(const void* x, const void* qidxs, const void* grid, const void* e81b_packed, float resid_scale,
+                            void* y, int64_t m, int32_t n, int32_t k, quip_stream_t stream) {
+  if (!grid || !e81b_packed) return QUIP_ERR_NULL_POINTER;
+  if (const int st = batched_args_ok(x, qidxs, y, m, n, k)) return st;
+  if ((reinterpret_cast<uintptr_t>(grid) & 7u) || (reinterpret_cast<uintptr_t>(e81b_packed) & 3u)) return QUIP_ERR_MISALIGNED;
+  if (m == 0) return QUIP_OK;
+  return e8prvq3_prefill_gemm_launch(x, qidxs, grid, e81b_packed, resid_scale, y, m, n, k, (hipStream_t)stream);
+}
+
+int quip_d4_mm_batched(const void* x, const void* qidxs, const void* grid_f16, void* y, int64_t m, int32_t n, int32_t k,
+                       quip_stream_t stream) {
+  if (!grid_f16) return QUIP_ERR_NULL_POINTER;
+  if (const int st = batched_args_ok(x, qidxs, y, m, n, k)) return st;
+  if (reinterpret_cast<uintptr_t>(grid_f16) & 7u) return QUIP_ERR_MISALIGNED;
+  if (m == 0) return QUIP_OK;
+  return d4_prefill_gemm_launch(x, qidxs, grid_f16, y, m, n, k, (hipStream_t)stream);
+}
+
+int quip_hi_mm_batched(const void* x, const void* qidxs, void* y, int64_t m, int32_t n, int32_t k, quip_stream_t stream) {
+  if (const int st = batched_args_ok(x, qidxs, y, m, n, k)) return st;
+  if (m == 0) return QUIP_OK;
+  return hi_prefill_gemm_launch(x, qidxs, y, m, n, k, (hipStream_t)stream);
+}
+
 int quip_e8p_mm_origorder_ws(const void* x, const void* qidxs, const void* grid, void* y, int32_t m,
                              int32_t n, int32_t k, void* workspace, size_t workspace_bytes,
                              quip_stream_t stream) {

@@ -29,6 +29,18 @@
 // (one multiplied, one landed, two in flight: counted vmcnt + raw s_barrier).  Measured: three tiles with 16 table
 // copies (tile t + 1 awaited one tile time after its request) and this layout (two tile times) run at the same
 // rate, i.e. the K loop does not wait on memory; halving the A-fragment LDS reads (experiment) changed 2-3 %.
+//
+// The other codebooks on the same tile machinery (template parameter MODE; the decode of a B fragment is the only
+// thing that differs -- the role of the reference's BLayout_* classes, origin_order.cu:143-385, whose M >= 32 use is
+// decompress_* + `x @ W.T`: e8p12_rvq4.py:50-67, e8p12_rvq3.py:109-129, d4.py:128-139, hi.py:52-63):
+//   MODE 1 = E8P12RVQ4B: 32-bit codes main << 16 | residual, four lookups, w = fma(s, w_residual, w_main) in packed
+//            fp16 -- one rounding per weight, the dense W of decompress_e8prvq4_origorder (origin_order.cu:337-385);
+//   MODE 4 = E8P12RVQ3B: the checkpoint's 3-byte codes (12 bytes per lane and tile), main through T1 / T2, the
+//            residual through a third table (the packed E81B entries, 8 copies of 4 bytes) as in e8p_skinny_gemm.hip;
+//   MODE 2 = D4: two code bytes per B fragment, the table holds the fp16 entries themselves (two 8-byte lookups, no
+//            arithmetic);
+//   MODE 3 = HI: eight nibbles per B fragment, w = nibble - 7.5 (0x4c00 | n << 6 = 16 + n, one packed add), no table.
+// These run the eight-wave layout only (every code decoded once per workgroup).
 #include <cstdlib>
 #include <type_traits>
 
@@ -42,6 +54,7 @@ namespace {
 typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t pu32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t pu32x3 __attribute__((ext_vector_type(3)));
 typedef uint32_t pu32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBM = 256, kBN = 256, kBK = 64;
@@ -54,7 +67,13 @@ constexpr int kA = 2 * kT2;                  // 32 KiB; behind it the X tiles (1
 #endif
 constexpr bool kInterleave = QUIP_PREFILL_INTERLEAVE != 0;
 constexpr int kStages = 4;                   // X tiles in LDS: one multiplied, one landed, two in flight
-constexpr int lds_bytes(int bm) { return kA + kStages * bm * kBK * 2; }   // 160 KiB at 256 rows
+constexpr int kRep3 = 8;                     // MODE 4: copies of the residual table (4-byte entries) behind T2
+constexpr int kT3Bytes = 256 * kRep3 * 4;    // 8 KiB
+constexpr int lds_bytes(int bm, int mode = 0) { return kA + (mode == 4 ? kT3Bytes : 0) + kStages * bm * kBK * 2; }   // 160 KiB at 256 rows
+// bytes of codes per 8 weights / dwords a lane loads per tile and column block (32 k) / table lookups per B fragment
+constexpr int mode_code_bytes(int mode) { return mode == 1 || mode == 3 ? 4 : mode == 4 ? 3 : 2; }
+constexpr int mode_lookups(int mode) { return mode == 1 ? 4 : mode == 4 ? 3 : mode == 3 ? 0 : 2; }
+constexpr int mode_convert_valu(int mode) { return mode == 1 ? 30 : mode == 4 ? 28 : mode == 3 ? 12 : mode == 2 ? 0 : 12; }
 
 // sign table image (same statement as the GEMV's: 4w = T1[abs] ^ T2[sign] byte-wise, origin_order.cu:211-253)
 struct PT2Image {
@@ -100,16 +119,24 @@ __device__ __forceinline__ void bytes_to_f16x4(uint32_t u4, uint32_t& lo, uint32
 // (one ds_read_b128 per MFMA: the LDS pipe is as busy as the matrix cores); <4, 2, 2, 4>: an A fragment feeds two
 // MFMAs (half the LDS traffic), a code is decoded by the two waves that share its columns; <8, 2, 1, 4>: four waves,
 // both.  128-row tiles (<4, 1, 1, 8>, <2, 2, 2, 4>) for launches whose 256-row tiles would not fill the GPU.
-template <int NB, int NC, int WM, int WN>
+template <int NB, int NC, int WM, int WN, int MODE = 0>
 __global__ __launch_bounds__(64 * WM * WN) void e8p_prefill_gemm_kernel(const f16* __restrict__ X,
-                                                                        const uint16_t* __restrict__ Wc,
+                                                                        const uint8_t* __restrict__ Wc,
                                                                         const uint64_t* __restrict__ grid,
                                                                         f16* __restrict__ Y, int M, int N, int K, int MT,
-                                                                        int NT) {
+                                                                        int NT, float resid_scale,
+                                                                        const uint32_t* __restrict__ grid2) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   static_assert(32 * NC * WN == kBN, "256 columns per tile");
+  static_assert(MODE == 0 || NC == 1, "the other codebooks: one column block per wave");
   constexpr int NW = WM * WN, BM = 32 * NB * WM;
   constexpr int kTileBytes = BM * kBK * 2;
+  constexpr int CB = mode_code_bytes(MODE);     // code bytes per 8 weights
+  constexpr int CW = CB == 3 ? 3 : CB;          // dwords per lane, tile and column block (4 fragments of 8 weights)
+  constexpr int NL = mode_lookups(MODE);
+  constexpr int kT3 = kA;                       // MODE 4: the residual table, the X tiles behind it
+  constexpr int kX = kA + (MODE == 4 ? kT3Bytes : 0);
+  using CodeT = std::conditional_t<CW == 2, pu32x2, std::conditional_t<CW == 3, pu32x3, pu32x4>>;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave - wm * WN;
@@ -142,24 +169,31 @@ __global__ __launch_bounds__(64 * WM * WN) void e8p_prefill_gemm_kernel(const f1
     for (int i = 0; i < XL; ++i)
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(xsrc[i] + (size_t)t * kBK),
-          (__attribute__((address_space(3))) void*)(smem + kA + buf * kTileBytes + (NW * i + wave) * 1024), 16, 0, 0);
+          (__attribute__((address_space(3))) void*)(smem + kX + buf * kTileBytes + (NW * i + wave) * 1024), 16, 0, 0);
   };
   // ---- codes: lane (n = lane & 31, kb = lane >> 5) holds the 4 codes k = 64 t + 32 kb + 8 j .. (j = 0..3) of columns
   // n0 + 32 (NC wn + c) + n, c < NC
   int ncol[NC];
-  const uint16_t* wsrc[NC];
+  const uint8_t* wsrc[NC];
   const int kb = lane >> 5;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     ncol[c] = n0 + 32 * (NC * wn + c) + (lane & 31);
-    wsrc[c] = Wc + (size_t)min(ncol[c], N - 1) * (K >> 3) + kb * 4;
+    wsrc[c] = Wc + ((size_t)min(ncol[c], N - 1) * (K >> 3) + kb * 4) * CB;
   }
   // (asm: beside LDS-DMA loads in flight hipcc waits vmcnt(0) for any ordinary register load, which would drain the
   //  prefetch queue every tile; all VMEM traffic of the K loop is counted by hand instead)
-  auto load_codes = [&](pu32x2 (&dst)[NC], int t) {
+  auto load_codes = [&](CodeT (&dst)[NC], int t) {
 #pragma unroll
-    for (int c = 0; c < NC; ++c)
-      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst[c]) : "v"(wsrc[c] + (size_t)t * (kBK / 8)) : "memory");
+    for (int c = 0; c < NC; ++c) {
+      const uint8_t* src = wsrc[c] + (size_t)t * (kBK / 8 * CB);
+      if constexpr (CW == 2)
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst[c]) : "v"(src) : "memory");
+      else if constexpr (CW == 3)
+        asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(dst[c]) : "v"(src) : "memory");
+      else
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[c]) : "v"(src) : "memory");
+    }
   };
 
   // tiles 0, 1 and 2 are requested here, tile t + 3 in the middle of tile t.  Per tile and wave: NC code loads + XL
@@ -167,15 +201,25 @@ __global__ __launch_bounds__(64 * WM * WN) void e8p_prefill_gemm_kernel(const f1
   // cq[]: registers the code loads write (in flight); cv[]: the codes of the current / next tile, taken over by an
   // asm that waits and then moves them (a register in flight is never a tied operand: the compiler may copy a tied
   // operand ahead of the asm, i.e. ahead of the wait -- see e8p_skinny_gemm.hip)
-  pu32x2 cq[kStages][NC], cv[2][NC];
+  CodeT cq[kStages][NC], cv[2][NC];
   load_codes(cq[0], 0);
   issue_x(0, 0);
   load_codes(cq[1], min(1, KT - 1));      // (past the end: tile KT - 1 again -- the queue depth stays constant, so
   issue_x(min(1, KT - 1), 1);             //  every wait below is the same counted wait, with no branch around it)
   load_codes(cq[2], min(2, KT - 1));
   issue_x(min(2, KT - 1), 2);
-  auto take = [](pu32x2 (&dst)[NC], const pu32x2 (&src)[NC], auto nw) {
-    if constexpr (NC == 1)
+  auto take = [](CodeT (&dst)[NC], const CodeT (&src)[NC], auto nw) {
+    if constexpr (CW == 3)
+      asm volatile("s_waitcnt vmcnt(%6)\n\tv_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5"
+                   : "=&v"(dst[0].x), "=&v"(dst[0].y), "=&v"(dst[0].z)
+                   : "v"(src[0].x), "v"(src[0].y), "v"(src[0].z), "n"(decltype(nw)::value)
+                   : "memory");
+    else if constexpr (CW == 4)
+      asm volatile("s_waitcnt vmcnt(%8)\n\tv_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                   : "=&v"(dst[0].x), "=&v"(dst[0].y), "=&v"(dst[0].z), "=&v"(dst[0].w)
+                   : "v"(src[0].x), "v"(src[0].y), "v"(src[0].z), "v"(src[0].w), "n"(decltype(nw)::value)
+                   : "memory");
+    else if constexpr (NC == 1)
       asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
                    : "=&v"(dst[0].x), "=&v"(dst[0].y)
                    : "v"(src[0].x), "v"(src[0].y), "n"(decltype(nw)::value)
@@ -193,10 +237,12 @@ __global__ __launch_bounds__(64 * WM * WN) void e8p_prefill_gemm_kernel(const f1
   for (int r = 0; r < 8 / NW; ++r) {
     const int e = (wave + NW * r) * 32 + (lane & 31);
     const bool second = (lane & 32) != 0;
-    const uint2 raw = second ? kPT2Img.v[e] : reinterpret_cast<const uint2*>(grid)[e];
+    if constexpr (MODE == 3) break;   // HI: no table
+    // (D4: both regions hold the fp16 entries as they are -- the fragment's first code byte looks up T1, its second T2)
+    const uint2 raw = (second && MODE != 2) ? kPT2Img.v[e] : reinterpret_cast<const uint2*>(grid)[e];
     const uint32_t t1x = (__builtin_amdgcn_perm(0u, raw.x, 0x03010200u) | 0x01010101u) ^ 0x80808080u;
     const uint32_t t1y = (__builtin_amdgcn_perm(0u, raw.y, 0x03010200u) | 0x01010101u) ^ 0x80808080u;
-    const pu32x2 val = {second ? raw.x : t1x, second ? raw.y : t1y};
+    const pu32x2 val = {(second || MODE == 2) ? raw.x : t1x, (second || MODE == 2) ? raw.y : t1y};
     const uint32_t rowbase = (second ? (uint32_t)kT2 : (uint32_t)kT1) + (uint32_t)e * (kRep * 8);
 #pragma unroll
     for (int c = 0; c < kRep; ++c) {
@@ -204,8 +250,21 @@ __global__ __launch_bounds__(64 * WM * WN) void e8p_prefill_gemm_kernel(const f1
       *reinterpret_cast<__attribute__((address_space(3))) pu32x2*>((uintptr_t)(rowbase + copy * 8)) = val;
     }
   }
+  if constexpr (MODE == 4) {
+    // residual table: entry e of the packed E81B table (eight int4 = 2 x value), kRep3 copies of 4 bytes
+    if (tid < 256) {
+      const uint32_t val = grid2[tid];
+#pragma unroll
+      for (int c = 0; c < kRep3; ++c)
+        *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(
+            (uintptr_t)((uint32_t)kT3 + (uint32_t)tid * (kRep3 * 4) + (((uint32_t)(lane + c) & (kRep3 - 1)) << 2))) = val;
+    }
+  }
   const uint32_t lane_c1 = (uint32_t)(lane & (kRep - 1)) << 3;
   const uint32_t lane_c2 = lane_c1 | (uint32_t)kT2;
+  const uint32_t lane_c3 = ((uint32_t)(lane & (kRep3 - 1)) << 2) | (uint32_t)kT3;
+  const f16 rs16 = (f16)resid_scale;
+  const f16x2 rs2 = {rs16, rs16};
   // A fragment address of this lane for k step j (without tile base / row block): row m = lane & 31
   const int m = lane & 31;
   uint32_t aoff[4];
@@ -227,22 +286,66 @@ __global__ __launch_bounds__(64 * WM * WN) void e8p_prefill_gemm_kernel(const f1
   // decoded under the other four.  The only workgroup synchronisation is in the MIDDLE of a tile: "tile t + 1 has
   // landed" (vmcnt(0) + barrier), which also says that everybody is done with tile t - 1, whose buffer the loads
   // of tile t + 2 then take.  So step 3 of tile t can already request step 0 of tile t + 1.
-  pu32x2 tl[2][NC][2];  // [parity of the step][column block][T1 / T2 entry]
+  constexpr int NT_ = NL > 2 ? NL : 2;
+  pu32x2 tl[2][NC][NT_];  // [parity of the step][column block][table entries: T1 / T2 (main), T1 / T2 or T3 (residual); HI: .x = the code]
   pu32x4 Af[2][NB];
-  auto request = [&](const pu32x2 (&cvt)[NC], int jj, uint32_t aj, pu32x2 (&tt)[NC][2], pu32x4 (&A8)[NB]) {
+  // the 32 code bits (MODE 0 / 2: the 16) of fragment jj of a lane's tile piece
+  auto code_dword = [](const CodeT& cd, int jj) -> uint32_t {
+    if constexpr (MODE == 0 || MODE == 2) {
+      return jj < 2 ? cd.x : cd.y;
+    } else if constexpr (MODE == 4) {
+      // 12 landed bytes = four 3-byte codes [residual index, e8p lo, e8p hi] -> main << 16 | residual << 8
+      return jj == 0   ? cd.x << 8
+             : jj == 1 ? __builtin_amdgcn_perm(cd.y, cd.x, 0x0504030cu)
+             : jj == 2 ? __builtin_amdgcn_perm(cd.z, cd.y, 0x0403020cu)
+                       : cd.z & 0xffffff00u;
+    } else {
+      return jj == 0 ? cd.x : jj == 1 ? cd.y : jj == 2 ? cd.z : cd.w;
+    }
+  };
+  auto request = [&](const CodeT (&cvt)[NC], int jj, uint32_t aj, pu32x2 (&tt)[NC][NT_], pu32x4 (&A8)[NB]) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      const uint32_t d = jj < 2 ? cvt[c].x : cvt[c].y;
-      uint32_t a1, a2;
-      if (jj & 1) {
-        a1 = ((d >> 18) & 0x3fc0u) | lane_c1;      // entry row = 8 copies x 8 bytes
-        a2 = ((d >> 10) & 0x3fc0u) | lane_c2;
+      const uint32_t d = code_dword(cvt[c], jj);
+      if constexpr (MODE == 0) {
+        uint32_t a1, a2;
+        if (jj & 1) {
+          a1 = ((d >> 18) & 0x3fc0u) | lane_c1;      // entry row = 8 copies x 8 bytes
+          a2 = ((d >> 10) & 0x3fc0u) | lane_c2;
+        } else {
+          a1 = ((d >> 2) & 0x3fc0u) | lane_c1;
+          a2 = ((d << 6) & 0x3fc0u) | lane_c2;
+        }
+        asm volatile("ds_read_b64 %0, %1" : "=v"(tt[c][0]) : "v"(a1));
+        asm volatile("ds_read_b64 %0, %1" : "=v"(tt[c][1]) : "v"(a2));
+      } else if constexpr (MODE == 2) {
+        // D4: the fragment's first code byte (weights 0..3) / second (weights 4..7)
+        uint32_t a1, a2;
+        if (jj & 1) {
+          a1 = ((d >> 10) & 0x3fc0u) | lane_c1;
+          a2 = ((d >> 18) & 0x3fc0u) | lane_c2;
+        } else {
+          a1 = ((d << 6) & 0x3fc0u) | lane_c1;
+          a2 = ((d >> 2) & 0x3fc0u) | lane_c2;
+        }
+        asm volatile("ds_read_b64 %0, %1" : "=v"(tt[c][0]) : "v"(a1));
+        asm volatile("ds_read_b64 %0, %1" : "=v"(tt[c][1]) : "v"(a2));
+      } else if constexpr (MODE == 3) {
+        tt[c][0].x = d;
       } else {
-        a1 = ((d >> 2) & 0x3fc0u) | lane_c1;
-        a2 = ((d << 6) & 0x3fc0u) | lane_c2;
+        // main code in the high half: abs index (bits 24..31) through T1, sign byte (16..23) through T2
+        const uint32_t a1 = ((d >> 18) & 0x3fc0u) | lane_c1, a2 = ((d >> 10) & 0x3fc0u) | lane_c2;
+        asm volatile("ds_read_b64 %0, %1" : "=v"(tt[c][0]) : "v"(a1));
+        asm volatile("ds_read_b64 %0, %1" : "=v"(tt[c][1]) : "v"(a2));
+        if constexpr (MODE == 1) {
+          const uint32_t b1 = ((d >> 2) & 0x3fc0u) | lane_c1, b2 = ((d << 6) & 0x3fc0u) | lane_c2;
+          asm volatile("ds_read_b64 %0, %1" : "=v"(tt[c][2]) : "v"(b1));
+          asm volatile("ds_read_b64 %0, %1" : "=v"(tt[c][3]) : "v"(b2));
+        } else {
+          const uint32_t b1 = ((d >> 3) & 0x1fe0u) | lane_c3;      // residual index (bits 8..15): 8 copies x 4 bytes
+          asm volatile("ds_read_b32 %0, %1" : "=v"(tt[c][2].x) : "v"(b1));
+        }
       }
-      asm volatile("ds_read_b64 %0, %1" : "=v"(tt[c][0]) : "v"(a1));
-      asm volatile("ds_read_b64 %0, %1" : "=v"(tt[c][1]) : "v"(a2));
     }
     asm volatile("ds_read_b128 %0, %1" : "=v"(A8[0]) : "v"(aj));
     asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(A8[1]) : "v"(aj));
@@ -268,22 +371,59 @@ __global__ __launch_bounds__(64 * WM * WN) void e8p_prefill_gemm_kernel(const f1
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A8[0]), "+v"(A8[1]));
   };
   // the lookups of a request have landed (the NB fragment reads behind them may still be in flight)
-  auto looked_up = [&](pu32x2 (&tt)[NC][2]) {
-    if constexpr (NC == 1)
+  auto looked_up = [&](pu32x2 (&tt)[NC][NT_]) {
+    if constexpr (MODE == 3)
+      ;
+    else if constexpr (MODE == 1)
+      asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(tt[0][0]), "+v"(tt[0][1]), "+v"(tt[0][2]), "+v"(tt[0][3]) : "n"(NB));
+    else if constexpr (MODE == 4)
+      asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(tt[0][0]), "+v"(tt[0][1]), "+v"(tt[0][2].x) : "n"(NB));
+    else if constexpr (NC == 1)
       asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(tt[0][0]), "+v"(tt[0][1]) : "n"(NB));
     else
       asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(tt[0][0]), "+v"(tt[0][1]), "+v"(tt[1][0]), "+v"(tt[1][1]) : "n"(NB));
   };
-  auto frag_b = [&](const pu32x2 (&tt)[2]) -> f16x8v {
-    uint32_t w0, w1, w2, w3;
-    bytes_to_f16x4(tt[0].x ^ tt[1].x, w0, w1);
-    bytes_to_f16x4(tt[0].y ^ tt[1].y, w2, w3);
-    return __builtin_bit_cast(f16x8v, pu32x4{w0, w1, w2, w3});
+  auto frag_b = [&](const pu32x2 (&tt)[NT_]) -> f16x8v {
+    if constexpr (MODE == 2) {
+      return __builtin_bit_cast(f16x8v, pu32x4{tt[0].x, tt[0].y, tt[1].x, tt[1].y});
+    } else if constexpr (MODE == 3) {
+      // nibble i of the code is column [0, 2, 4, 6, 1, 3, 5, 7][i] of its 8-group: the fragment's fp16 pair d is
+      // (nibble d, nibble d + 4); 0x4c00 | n << 6 is the fp16 number 16 + n, 23.5 is one too: the subtraction is exact
+      const uint32_t c = tt[0].x;
+      const f16x2 off = {(f16)-23.5f, (f16)-23.5f};
+      const uint32_t sh[4] = {c << 6, c << 2, c >> 2, c >> 6};
+      uint32_t w[4];
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd) w[dd] = as_u32(as_f16x2((sh[dd] & 0x03c003c0u) | 0x4c004c00u) + off);
+      return __builtin_bit_cast(f16x8v, pu32x4{w[0], w[1], w[2], w[3]});
+    } else {
+      uint32_t m[4];
+      bytes_to_f16x4(tt[0].x ^ tt[1].x, m[0], m[1]);
+      bytes_to_f16x4(tt[0].y ^ tt[1].y, m[2], m[3]);
+      if constexpr (MODE == 1) {
+        uint32_t r[4];
+        bytes_to_f16x4(tt[2].x ^ tt[3].x, r[0], r[1]);
+        bytes_to_f16x4(tt[2].y ^ tt[3].y, r[2], r[3]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m[i] = as_u32(__builtin_elementwise_fma(rs2, as_f16x2(r[i]), as_f16x2(m[i])));
+      } else if constexpr (MODE == 4) {
+        // residual nibble n = int4 of 2 x value: 0x4c00 | (n ^ 8) << 6 is 16 + (n ^ 8); x 0.5 - 12 = 0.5 ((n ^ 8) - 8), exact
+        const uint32_t c = tt[2].x;
+        const f16x2 half2 = {(f16)0.5f, (f16)0.5f}, m12 = {(f16)-12.f, (f16)-12.f};
+        const uint32_t sh[4] = {c << 6, c << 2, c >> 2, c >> 6};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f16x2 res = __builtin_elementwise_fma(as_f16x2((sh[i] & 0x03c003c0u) ^ 0x4e004e00u), half2, m12);
+          m[i] = as_u32(__builtin_elementwise_fma(rs2, res, as_f16x2(m[i])));
+        }
+      }
+      return __builtin_bit_cast(f16x8v, pu32x4{m[0], m[1], m[2], m[3]});
+    }
   };
   // tiles 0 and 1 (and the tables) are in LDS; first step's operands
   take(cv[0], cq[0], std::integral_constant<int, 0>{});   // (everything requested so far has landed)
   __syncthreads();
-  request(cv[0], 0, (uint32_t)kA + aoff[0], tl[0], Af[0]);
+  request(cv[0], 0, (uint32_t)kX + aoff[0], tl[0], Af[0]);
   looked_up(tl[0]);
   landed(Af[0]);
   f16x8v B[NC];
@@ -294,7 +434,7 @@ __global__ __launch_bounds__(64 * WM * WN) void e8p_prefill_gemm_kernel(const f1
   auto tile = [&](int t, auto stc) {
     constexpr int st = decltype(stc)::value;
     constexpr int st1 = (st + 1) % kStages, st3 = (st + 3) % kStages, cur = st & 1, nxt = cur ^ 1;
-    const uint32_t abase = (uint32_t)(kA + st * kTileBytes);
+    const uint32_t abase = (uint32_t)(kX + st * kTileBytes);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c2 = j & 1, nx = c2 ^ 1;
@@ -302,7 +442,7 @@ __global__ __launch_bounds__(64 * WM * WN) void e8p_prefill_gemm_kernel(const f1
       if (j < 3)
         request(cv[cur], j + 1, abase + aoff[j + 1], tl[nx], Af[nx]);
       else
-        request(cv[nxt], 0, (uint32_t)(kA + st1 * kTileBytes) + aoff[0], tl[nx], Af[nx]);
+        request(cv[nxt], 0, (uint32_t)(kX + st1 * kTileBytes) + aoff[0], tl[nx], Af[nx]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int b = 0; b < NB / 2; ++b)
@@ -326,7 +466,7 @@ __global__ __launch_bounds__(64 * WM * WN) void e8p_prefill_gemm_kernel(const f1
 #pragma unroll
         for (int i = 0; i < NB / 2 * NC; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, (12 * NC + NB / 2 * NC - 1) / (NB / 2 * NC), 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, (mode_convert_valu(MODE) * NC + NB / 2 * NC - 1) / (NB / 2 * NC) + (MODE == 2), 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -384,8 +524,10 @@ bool e8p_prefill_gemm_supported(int64_t m, int n, int k) {
   return m >= 1 && n >= 2 && n % 2 == 0 && k >= kBK && k % kBK == 0 && m < ((int64_t)1 << 31);
 }
 
-int e8p_prefill_gemm_launch(const void* x, const void* qidxs, const void* grid, void* y, int64_t m, int n, int k,
-                            hipStream_t stream) {
+// mode 0: E8P12 (int16 codes (n, k/8)), 1: E8P12RVQ4B (int32 codes, resid_scale), 2: D4 (uint8 codes (n, k/4), grid = the fp16
+// (256, 4) table), 3: HI (int32 codes, no table), 4: E8P12RVQ3B (packed 3-byte codes, grid2 = the packed E81B table)
+static int prefill_launch_mode(int mode, const void* x, const void* qidxs, const void* grid, const void* grid2, float resid_scale,
+                               void* y, int64_t m, int n, int k, hipStream_t stream) {
   if (!e8p_prefill_gemm_supported(m, n, k)) return QUIP_ERR_UNSUPPORTED;
   const int NT = (n + kBN - 1) / kBN;
   // 128-row tiles while 256-row tiles would leave CUs without a workgroup (the K loop of a workgroup takes the same
@@ -393,23 +535,53 @@ int e8p_prefill_gemm_launch(const void* x, const void* qidxs, const void* grid, 
   static const int force = getenv("QUIP_PREFILL_TILE") ? atoi(getenv("QUIP_PREFILL_TILE")) : 0;   // 128 / 256: experiments
   // wave layout (see the kernel): 0 = eight waves of 256 x 32, 1 = 2 x 4 waves of 128 x 64, 2 = four waves of 256 x 64
   static const int layout = getenv("QUIP_PREFILL_LAYOUT") ? atoi(getenv("QUIP_PREFILL_LAYOUT")) : 0;   // measured: 0 is the fastest
-  const bool half = force ? force == 128 : (m + kBM - 1) / kBM * NT < device_cu_count();
+  // (E8P12RVQ3B: a third table; E8P12RVQ4B: four table entries per fragment in flight, the 256-row tile's 128
+  //  accumulator registers would leave it 9 registers short -- 128-row tiles always)
+  const bool half = (mode == 4 || mode == 1) ? true : force ? force == 128 : (m + kBM - 1) / kBM * NT < device_cu_count();
   const int bm = half ? kBM / 2 : kBM;
   const int MT = (int)((m + bm - 1) / bm);
   const int64_t blocks = MT >= 8 ? (int64_t)((MT + 7) / 8) * NT * 8 : (int64_t)MT * NT;
   if (blocks > 0x7fffffff) return QUIP_ERR_UNSUPPORTED;
   auto go = [&](auto kern, DynLdsCache& configured, int threads) -> int {
-    const int lds = lds_bytes(bm);
+    const int lds = lds_bytes(bm, mode);
     if (ensure_dyn_lds(configured, reinterpret_cast<const void*>(kern), lds) != QUIP_OK) return QUIP_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads), lds, stream, reinterpret_cast<const f16*>(x),
-                       reinterpret_cast<const uint16_t*>(qidxs), reinterpret_cast<const uint64_t*>(grid),
-                       reinterpret_cast<f16*>(y), (int)m, n, k, MT, NT);
+                       reinterpret_cast<const uint8_t*>(qidxs), reinterpret_cast<const uint64_t*>(grid),
+                       reinterpret_cast<f16*>(y), (int)m, n, k, MT, NT, resid_scale, reinterpret_cast<const uint32_t*>(grid2));
     return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
   };
-  static DynLdsCache c[6];   // per device
+  static DynLdsCache c[13];   // per instantiation, per device
+  if (mode == 1) return go(e8p_prefill_gemm_kernel<4, 1, 1, 8, 1>, c[6], 512);
+  if (mode == 2) return half ? go(e8p_prefill_gemm_kernel<4, 1, 1, 8, 2>, c[8], 512) : go(e8p_prefill_gemm_kernel<8, 1, 1, 8, 2>, c[9], 512);
+  if (mode == 3) return half ? go(e8p_prefill_gemm_kernel<4, 1, 1, 8, 3>, c[10], 512) : go(e8p_prefill_gemm_kernel<8, 1, 1, 8, 3>, c[11], 512);
+  if (mode == 4) return go(e8p_prefill_gemm_kernel<4, 1, 1, 8, 4>, c[12], 512);
   if (layout == 2) return half ? go(e8p_prefill_gemm_kernel<4, 2, 1, 4>, c[0], 256) : go(e8p_prefill_gemm_kernel<8, 2, 1, 4>, c[1], 256);
   if (layout == 1) return half ? go(e8p_prefill_gemm_kernel<2, 2, 2, 4>, c[2], 512) : go(e8p_prefill_gemm_kernel<4, 2, 2, 4>, c[3], 512);
   return half ? go(e8p_prefill_gemm_kernel<4, 1, 1, 8>, c[4], 512) : go(e8p_prefill_gemm_kernel<8, 1, 1, 8>, c[5], 512);
+}
+
+int e8p_prefill_gemm_launch(const void* x, const void* qidxs, const void* grid, void* y, int64_t m, int n, int k,
+                            hipStream_t stream) {
+  return prefill_launch_mode(0, x, qidxs, grid, nullptr, 0.f, y, m, n, k, stream);
+}
+
+int e8prvq4_prefill_gemm_launch(const void* x, const void* qidxs, const void* grid, float resid_scale, void* y, int64_t m, int n,
+                                int k, hipStream_t stream) {
+  return prefill_launch_mode(1, x, qidxs, grid, nullptr, resid_scale, y, m, n, k, stream);
+}
+
+int e8prvq3_prefill_gemm_launch(const void* x, const void* qidxs, const void* grid, const void* e81b_packed, float resid_scale,
+                                void* y, int64_t m, int n, int k, hipStream_t stream) {
+  return prefill_launch_mode(4, x, qidxs, grid, e81b_packed, resid_scale, y, m, n, k, stream);
+}
+
+int d4_prefill_gemm_launch(const void* x, const void* qidxs, const void* grid_f16, void* y, int64_t m, int n, int k,
+                           hipStream_t stream) {
+  return prefill_launch_mode(2, x, qidxs, grid_f16, nullptr, 0.f, y, m, n, k, stream);
+}
+
+int hi_prefill_gemm_launch(const void* x, const void* qidxs, void* y, int64_t m, int n, int k, hipStream_t stream) {
+  return prefill_launch_mode(3, x, qidxs, nullptr, nullptr, 0.f, y, m, n, k, stream);
 }
 
 }  // namespace quip

@@ -131,6 +131,14 @@ int e8p_gemv_mfma_fused_launch(const GemvFusedIn& in, const void* const* qidxs, 
 bool e8p_prefill_gemm_supported(int64_t m, int n, int k);
 int e8p_prefill_gemm_launch(const void* x, const void* qidxs, const void* grid, void* y, int64_t m, int n, int k,
                             hipStream_t stream);
+// the same tile kernel with the other codebooks' B-fragment decode (argument meaning as the skinny launchers below)
+int e8prvq4_prefill_gemm_launch(const void* x, const void* qidxs, const void* grid, float resid_scale, void* y, int64_t m, int n,
+                                int k, hipStream_t stream);
+int e8prvq3_prefill_gemm_launch(const void* x, const void* qidxs, const void* grid, const void* e81b_packed, float resid_scale,
+                                void* y, int64_t m, int n, int k, hipStream_t stream);
+int d4_prefill_gemm_launch(const void* x, const void* qidxs, const void* grid_f16, void* y, int64_t m, int n, int k,
+                           hipStream_t stream);
+int hi_prefill_gemm_launch(const void* x, const void* qidxs, void* y, int64_t m, int n, int k, hipStream_t stream);
 // single-pass skinny E8P12 product, 1 <= m <= 32 rows, fp16 MFMA (e8p_skinny_gemm.hip)
 bool e8p_skinny_gemm_supported(int m, int n, int k);
 int e8p_skinny_gemm_launch(const void* x, const void* qidxs, const void* grid, void* y, int m, int n, int k,

@@ -50,6 +50,11 @@ _SCHEMAS = {
                           "Tensor(a!) kcache, Tensor(b!) vcache, Tensor? workspace=None) -> Tensor",
     # M >= 32 (prefill): fused dequant + MFMA GEMM, x (M, k) fp16 -> (M, n) fp16; no dense W (csrc/e8p_prefill_gemm.hip)
     "e8p_mm_batched": "(Tensor x, Tensor Qidxs, Tensor grid) -> Tensor",
+    # ... with the other codebooks' decode (argument meaning as the *_mm_skinny ops below)
+    "e8prvq4_mm_batched": "(Tensor x, Tensor Qidxs, Tensor grid, float scale) -> Tensor",
+    "e8prvq3_mm_batched": "(Tensor x, Tensor Qidxs, Tensor grid, Tensor grid2, float scale) -> Tensor",
+    "d4_mm_batched": "(Tensor x, Tensor Qidxs, Tensor grid) -> Tensor",
+    "hi_mm_batched": "(Tensor x, Tensor Qidxs) -> Tensor",
     # 2 <= M <= 32 rows in one pass over the codes, fp16 MFMA (csrc/e8p_skinny_gemm.hip)
     "e8p_mm_skinny": "(Tensor x, Tensor Qidxs, Tensor grid) -> Tensor",
     # the same for E8P12RVQ4B: int32 codes (main << 16 | residual), weights = fp16 fma(scale, residual, main)
@@ -859,6 +864,46 @@ def _e8prvq3_mm_skinny_cuda(x, Qidxs, grid, grid2, scale):
     return y
 
 
+def _batched_generic(fn, what, x, Qidxs, qdtype, k_of_cols, extra):
+    """the fused tile kernel in another codebook's mode: x (M, k) fp16, any M >= 0"""
+    xc = _chk_x(x)
+    Qc = _chk_q(Qidxs, qdtype)
+    m, k, n = xc.shape[0], xc.shape[1], Qc.shape[0]
+    _need(k_of_cols(Qc.shape[1]) == k, f"{what}: x has {k} columns but Qidxs {tuple(Qidxs.shape)} encodes {k_of_cols(Qc.shape[1])}")
+    _need(Qc.device == x.device, "Qidxs and x must be on the same device")
+    _need(e8p_mm_batched_supported(max(m, 1), n, k), f"{what}: shape ({m}, {n}, {k}) needs k % 64 == 0 and n % 2 == 0")
+    y = _empty((m, n), dtype=torch.float16, device=x.device)
+    if m == 0:
+        return y
+    with torch.cuda.device(x.device):
+        capi.check(getattr(capi.lib(), fn)(xc.data_ptr(), Qc.data_ptr(), *extra(), y.data_ptr(), m, n, k, _stream(x)), fn)
+    return y
+
+
+def _e8prvq4_mm_batched_cuda(x, Qidxs, grid, scale):
+    g = _grid_i64(grid, x)
+    return _batched_generic("quip_e8prvq4_mm_batched", "e8prvq4_mm_batched", x, Qidxs, torch.int32, lambda c: c * 8,
+                            lambda: (g.data_ptr(), float(scale)))
+
+
+def _e8prvq3_mm_batched_cuda(x, Qidxs, grid, grid2, scale):
+    g = _grid_i64(grid, x)
+    _need(grid2.dtype == torch.int32 and grid2.numel() == 256, "e81b_grid_packed must be int32[256]")
+    g2 = grid2.contiguous()
+    _need(g2.device == x.device, "grid2 and x must be on the same device")
+    return _batched_generic("quip_e8prvq3_mm_batched", "e8prvq3_mm_batched", x, Qidxs, torch.int32, lambda c: c * 32 // 3,
+                            lambda: (g.data_ptr(), g2.data_ptr(), float(scale)))
+
+
+def _d4_mm_batched_cuda(x, Qidxs, grid):
+    g = _d4_grid_f16(grid)
+    return _batched_generic("quip_d4_mm_batched", "d4_mm_batched", x, Qidxs, torch.uint8, lambda c: c * 4, lambda: (g.data_ptr(),))
+
+
+def _hi_mm_batched_cuda(x, Qidxs):
+    return _batched_generic("quip_hi_mm_batched", "hi_mm_batched", x, Qidxs, torch.int32, lambda c: c * 8, lambda: ())
+
+
 def _d4_mm_skinny_cuda(x, Qidxs, grid):
     g = _d4_grid_f16(grid)
     return _skinny_generic("quip_d4_mm_skinny", "d4_mm_skinny", x, Qidxs, torch.uint8, 4, lambda: (g.data_ptr(),))
@@ -1010,6 +1055,10 @@ _IMPLS = {
     "had_transform_group": _had_transform_group_cuda,
     "e8p_gemv_planes_group": _e8p_gemv_planes_group_cuda,
     "e8p_mm_batched": _e8p_mm_batched_cuda,
+    "e8prvq4_mm_batched": _e8prvq4_mm_batched_cuda,
+    "e8prvq3_mm_batched": _e8prvq3_mm_batched_cuda,
+    "d4_mm_batched": _d4_mm_batched_cuda,
+    "hi_mm_batched": _hi_mm_batched_cuda,
     "e8p_mm_skinny": _e8p_mm_skinny_cuda,
     "e8prvq4_mm_skinny": _e8prvq4_mm_skinny_cuda,
     "e8prvq3_mm_skinny": _e8prvq3_mm_skinny_cuda,
@@ -1113,6 +1162,10 @@ _reg_fake("e8prvq3_mm_skinny", lambda x, Q, g, g2, s: x.new_empty((x.shape[0], Q
 _reg_fake("d4_mm_skinny", lambda x, Q, g: x.new_empty((x.shape[0], Q.shape[0]), dtype=torch.float16))
 _reg_fake("hi_mm_skinny", lambda x, Q: x.new_empty((x.shape[0], Q.shape[0]), dtype=torch.float16))
 _reg_fake("e8p_mm_batched", lambda x, Q, g: x.new_empty((x.shape[0], Q.shape[0]), dtype=torch.float16))
+_reg_fake("e8prvq4_mm_batched", lambda x, Q, g, s: x.new_empty((x.shape[0], Q.shape[0]), dtype=torch.float16))
+_reg_fake("e8prvq3_mm_batched", lambda x, Q, g, g2, s: x.new_empty((x.shape[0], Q.shape[0]), dtype=torch.float16))
+_reg_fake("d4_mm_batched", lambda x, Q, g: x.new_empty((x.shape[0], Q.shape[0]), dtype=torch.float16))
+_reg_fake("hi_mm_batched", lambda x, Q: x.new_empty((x.shape[0], Q.shape[0]), dtype=torch.float16))
 _reg_fake("e8p_gemv_planes", lambda planes, Q, g: Q.new_empty((1, Q.shape[0]), dtype=torch.float16))
 for _n in ("e8p_mm_origorder", "e8prvq3_mm_origorder", "e8prvq4_mm_origorder", "d4_mm_origorder",
            "hi_mm_origorder"):

@@ -116,3 +116,67 @@ def test_config5_full_size(Q, fin, fout, mode):
         assert np.all(err40 <= O.ulp_bound(P, xs40))
     finally:
         cbt.batched_mode = saved
+
+
+@pytest.mark.parametrize("cbid", ["E8P12RVQ4B", "E8P12RVQ3B", "D4", "HI"])
+@pytest.mark.parametrize("m,n,k", [(1, 64, 64), (40, 256, 256), (257, 30, 128), (300, 290, 704), (700, 512, 4096),
+                                   (255, 96, 11008), (2048, 1024, 1024)])
+def test_batched_product_other_codebooks(Q, cbid, m, n, k):
+    """the fused tile kernel in the other codebooks' modes (csrc/e8p_prefill_gemm.hip MODE 1..4; the M >= 32 role of
+    decompress_* + `x @ W.T`, e8p12_rvq4.py:50-67, e8p12_rvq3.py:109-129, d4.py:128-139, hi.py:52-63): the weights are the
+    dense W of the reference's decompress op bit for bit (identity rows: every output is one weight, exactly), the
+    product agrees with float64 of the same fp16 operands, a row's result does not depend on its batch"""
+    from quip_for_all_amd.qlinear import QuantLinear
+    P = O.make_layer(cbid, k, n, seed=m + n + k)
+    layer = QuantLinear.from_params(P).to(DEV).eval()
+    cb, Qd = layer.codebook, layer.Qidxs
+    k, n = layer.q_in_features, layer.q_out_features
+    if k % 64 or n % 2:
+        pytest.skip("k % 64 != 0: decompress + dense GEMM")
+    rng = np.random.default_rng(m * 7 + n)
+    x = torch.from_numpy(rng.standard_normal((m, k)).astype(np.float16)).to(DEV)
+    y = cb.mm_batched(x, Qd)
+    assert y.shape == (m, n) and y.dtype == torch.float16
+    Wd = cb.decompress_weight(Qd)
+    W64 = Wd.cpu().numpy().astype(np.float64)
+    assert np.array_equal(W64, O.decompress(cbid, P.Qidxs, getattr(cb, "opt_resid_scale", 0.0)).astype(np.float64))
+    x64 = x.cpu().numpy().astype(np.float64)
+    y64 = x64 @ W64.T
+    err = np.abs(y.cpu().numpy().astype(np.float64) - y64)
+    assert np.all(err <= _tol(x64, W64, y64)), (err.max(), np.unravel_index(err.argmax(), err.shape))
+    cols = sorted({0, 1, 3, 4, 7, 8, 31, 32, 33, k // 2 + 5, k - 8, k - 1})
+    e = torch.zeros(len(cols), k, dtype=torch.float16, device=DEV)
+    for i, c in enumerate(cols):
+        e[i, c] = 1.0
+    assert torch.equal(cb.mm_batched(e, Qd), Wd[:, cols].T.contiguous()), "every weight exactly as decompress writes it"
+    if m > 40:
+        assert torch.equal(y[m - 33:], cb.mm_batched(x[m - 33:].contiguous(), Qd)), "rows do not depend on their batch"
+
+
+@pytest.mark.parametrize("cbid", ["E8P12RVQ4B", "E8P12RVQ3B", "D4", "HI"])
+def test_module_forward_fused_mode_other_codebooks(Q, cbid):
+    """QuantLinear.forward of the other codebooks beyond the skinny regime: decompress + dense GEMM by default, the fused
+    kernel under QUIP_BATCHED_MM=fused; both inside the module's stated bound against the float64 oracle"""
+    from quip_for_all_amd.qlinear import QuantLinear
+    from quip_for_all_amd.codebook.codebooks import E8P12_codebook
+    fin, fout, M = 1024, 2048, 1500
+    P = O.make_layer(cbid, fin, fout, seed=23)
+    layer = QuantLinear.from_params(P).to(DEV).eval()
+    g = torch.Generator(device=DEV).manual_seed(4)
+    x = torch.randn(M, fin, generator=g, device=DEV, dtype=torch.float16)
+    rows = [0, 1, 31, 32, 255, 256, 1000, M - 1]
+    xs = x[rows].cpu().numpy()
+    yo = O.qlinear_forward(P, xs, mode="exact")
+    bound = O.ulp_bound(P, xs)
+    saved = E8P12_codebook.batched_mode
+    try:
+        for mode in ("auto", "fused"):
+            E8P12_codebook.batched_mode = mode
+            assert layer.codebook.batched_regime(M, layer.q_out_features, layer.q_in_features) == \
+                ("fused_gemm" if mode == "fused" else "decompress_gemm")
+            with torch.no_grad():
+                y = layer(x)
+            err = np.abs(y[rows].cpu().numpy().astype(np.float64) - yo)
+            assert np.all(err <= bound), (cbid, mode, float((err / bound).max()))
+    finally:
+        E8P12_codebook.batched_mode = saved
