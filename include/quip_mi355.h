@@ -401,6 +401,14 @@ int quip_rope_attn_decode_f16(const void* q, const void* k, const void* v, const
                               const float* sin, const int64_t* pos, void* kcache, void* vcache,
                               void* out, int32_t heads, int32_t kv_heads, int32_t head_dim,
                               int32_t max_len, float scale, void* workspace, quip_stream_t stream);
+/* ... with sliding-window attention (HF `config.sliding_window`, e.g. Mistral-7B): the softmax runs over the last
+ * `window` positions (pos - window, pos] only; the cache stays linear (row t = position t).  window == 0: all of [0, pos]
+ * (quip_rope_attn_decode_f16 is this call with window 0). */
+int quip_rope_attn_decode_window_f16(const void* q, const void* k, const void* v, const float* cos,
+                                     const float* sin, const int64_t* pos, void* kcache, void* vcache,
+                                     void* out, int32_t heads, int32_t kv_heads, int32_t head_dim,
+                                     int32_t max_len, float scale, int32_t window, void* workspace,
+                                     quip_stream_t stream);
 
 /* The same launch on the RAW GEMV outputs of q / k / v_proj: their output-side transforms (SV (.) H z * scales[i],
  * qlinear.py:106-114 with K = 1, no bias) run in the launch's prologue -- same bits as quip_had_transform_f16 followed
@@ -412,6 +420,10 @@ int quip_rope_attn_decode_z_f16(const void* const* z, const void* const* post, c
                                 const float* sin, const int64_t* pos, void* kcache, void* vcache, void* out,
                                 int32_t heads, int32_t kv_heads, int32_t head_dim, int32_t max_len, float scale,
                                 void* workspace, quip_stream_t stream);
+int quip_rope_attn_decode_z_window_f16(const void* const* z, const void* const* post, const float* scales,
+                                       const float* cos, const float* sin, const int64_t* pos, void* kcache, void* vcache,
+                                       void* out, int32_t heads, int32_t kv_heads, int32_t head_dim, int32_t max_len,
+                                       float scale, int32_t window, void* workspace, quip_stream_t stream);
 
 /* Which kernel a bs=1 E8P12 GEMV launch of `count` matrices (ns[i] rows, common k) is dispatched to by default, without
  * launching anything: 1 = e8p_gemv_mfma_kernel, 2 = e8p_gemv_v2_kernel (needs the workspace of the *_ws entry points when

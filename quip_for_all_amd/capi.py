@@ -40,6 +40,8 @@ SIGNATURES = {
     "quip_rope_attn_workspace_bytes": [_I32, _I32],
     "quip_argmax_step_f16": [_P, _I32, _P, _P, _P],
     "quip_rope_attn_decode_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _P, _P],
+    "quip_rope_attn_decode_window_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _I32, _P, _P],
+    "quip_rope_attn_decode_z_window_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _I32, _P, _P],
     "quip_rope_attn_decode_z_supported": [_I32, _I32, _I32],
     "quip_rope_attn_decode_z_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _P, _P],
     "quip_block_engine_supported": [_I32, _I32, _I32, _I32, _I32, _I32],

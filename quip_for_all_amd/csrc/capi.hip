@@ -461,12 +461,22 @@ int quip_rope_attn_decode_f16(const void* q, const void* k, const void* v, const
                               const float* sin, const int64_t* pos, void* kcache, void* vcache,
                               void* out, int32_t heads, int32_t kv_heads, int32_t head_dim,
                               int32_t max_len, float scale, void* workspace, quip_stream_t stream) {
+  return quip_rope_attn_decode_window_f16(q, k, v, cos, sin, pos, kcache, vcache, out, heads, kv_heads, head_dim, max_len,
+                                          scale, 0, workspace, stream);
+}
+
+int quip_rope_attn_decode_window_f16(const void* q, const void* k, const void* v, const float* cos,
+                                     const float* sin, const int64_t* pos, void* kcache, void* vcache,
+                                     void* out, int32_t heads, int32_t kv_heads, int32_t head_dim,
+                                     int32_t max_len, float scale, int32_t window, void* workspace,
+                                     quip_stream_t stream) {
   if (!q || !k || !v || !cos || !sin || !pos || !kcache || !vcache || !out) return QUIP_ERR_NULL_POINTER;
   if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(kcache) || !aligned16(vcache))
     return QUIP_ERR_MISALIGNED;
   if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return QUIP_ERR_MISALIGNED;
+  if (window < 0) return QUIP_ERR_BAD_SHAPE;
   return rope_attn_decode_launch(q, k, v, cos, sin, pos, kcache, vcache, out, heads, kv_heads, head_dim,
-                                 max_len, scale, (hipStream_t)stream, workspace);
+                                 max_len, scale, (hipStream_t)stream, workspace, window);
 }
 
 int quip_rope_attn_decode_z_supported(int32_t heads, int32_t kv_heads, int32_t head_dim) {
@@ -477,6 +487,14 @@ int quip_rope_attn_decode_z_f16(const void* const* z, const void* const* post, c
                                 const float* sin, const int64_t* pos, void* kcache, void* vcache, void* out,
                                 int32_t heads, int32_t kv_heads, int32_t head_dim, int32_t max_len, float scale,
                                 void* workspace, quip_stream_t stream) {
+  return quip_rope_attn_decode_z_window_f16(z, post, scales, cos, sin, pos, kcache, vcache, out, heads, kv_heads, head_dim,
+                                            max_len, scale, 0, workspace, stream);
+}
+
+int quip_rope_attn_decode_z_window_f16(const void* const* z, const void* const* post, const float* scales,
+                                       const float* cos, const float* sin, const int64_t* pos, void* kcache, void* vcache,
+                                       void* out, int32_t heads, int32_t kv_heads, int32_t head_dim, int32_t max_len,
+                                       float scale, int32_t window, void* workspace, quip_stream_t stream) {
   if (!z || !post || !scales || !cos || !sin || !pos || !kcache || !vcache || !out) return QUIP_ERR_NULL_POINTER;
   for (int i = 0; i < 3; ++i) {
     if (!z[i] || !post[i]) return QUIP_ERR_NULL_POINTER;
@@ -484,8 +502,9 @@ int quip_rope_attn_decode_z_f16(const void* const* z, const void* const* post, c
   }
   if (!aligned16(kcache) || !aligned16(vcache)) return QUIP_ERR_MISALIGNED;
   if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return QUIP_ERR_MISALIGNED;
+  if (window < 0) return QUIP_ERR_BAD_SHAPE;
   return rope_attn_decode_z_launch(z, post, scales, cos, sin, pos, kcache, vcache, out, heads, kv_heads, head_dim,
-                                   max_len, scale, (hipStream_t)stream, workspace);
+                                   max_len, scale, (hipStream_t)stream, workspace, window);
 }
 
 int quip_e8p_mm_origorder(const void* x, const void* qidxs, const void* grid, void* y, int32_t m,

@@ -47,6 +47,7 @@ struct AttnArgs {
   float scale;
   float* ws;           // split mode: partial (acc[HD], m, l) per (head, split); null: one workgroup per head
   unsigned* counters;  // split mode: arrivals per head (zero between launches)
+  int window;          // sliding-window attention (Mistral: config.sliding_window): positions (pos - window, pos]; <= 0: [0, pos]
 };
 
 constexpr int kSplits = 8;  // workgroups per head for long contexts (grid.y)
@@ -125,9 +126,11 @@ void rope_attn_decode_kernel(AttnArgs a, AttnZ zz) {
   const bool split = a.ws != nullptr && pos >= kSplitFromPos;
   const int sidx = blockIdx.y;
   if (!split && sidx > 0) return;
-  const int chunk = split ? (pos + kSplits) / kSplits : pos + 1;      // ceil((pos + 1) / kSplits)
-  const int t_lo = split ? sidx * chunk : 0;
-  const int t_hi = split ? min(pos + 1, t_lo + chunk) : pos + 1;       // exclusive
+  // sliding window: the walk starts at `first` instead of 0 (the cache stays linear: rows [0, pos] all exist)
+  const int first = a.window > 0 ? max(0, pos + 1 - a.window) : 0;
+  const int chunk = split ? (pos - first + kSplits) / kSplits : pos + 1 - first;      // ceil((pos + 1 - first) / kSplits)
+  const int t_lo = first + (split ? sidx * chunk : 0);
+  const int t_hi = split ? min(pos + 1, t_lo + chunk) : pos + 1;       // exclusive (a split past the end walks nothing: m = -inf)
   const float* cs = a.cos + (size_t)pos * HD;
   const float* sn = a.sin + (size_t)pos * HD;
 
@@ -338,11 +341,11 @@ static int rope_attn_launch_common(AttnArgs a, const AttnZ* zz, int head_dim, in
 
 int rope_attn_decode_launch(const void* q, const void* k, const void* v, const float* cos, const float* sin,
                             const int64_t* pos, void* kcache, void* vcache, void* out, int heads, int kv_heads,
-                            int head_dim, int max_len, float scale, hipStream_t stream, void* workspace) {
+                            int head_dim, int max_len, float scale, hipStream_t stream, void* workspace, int window) {
   if (heads < 1 || kv_heads < 1 || heads % kv_heads != 0 || max_len < 1) return QUIP_ERR_BAD_SHAPE;
   AttnArgs a{reinterpret_cast<const f16*>(q), reinterpret_cast<const f16*>(k), reinterpret_cast<const f16*>(v),
              cos, sin, pos, reinterpret_cast<f16*>(kcache), reinterpret_cast<f16*>(vcache),
-             reinterpret_cast<f16*>(out), heads, kv_heads, max_len, scale, nullptr, nullptr};
+             reinterpret_cast<f16*>(out), heads, kv_heads, max_len, scale, nullptr, nullptr, window};
   return rope_attn_launch_common(a, nullptr, head_dim, max_len, stream, workspace);
 }
 
@@ -356,12 +359,12 @@ bool rope_attn_decode_z_supported(int heads, int kv_heads, int head_dim) {
 int rope_attn_decode_z_launch(const void* const* z, const void* const* post, const float* scales, const float* cos,
                               const float* sin, const int64_t* pos, void* kcache, void* vcache, void* out, int heads,
                               int kv_heads, int head_dim, int max_len, float scale, hipStream_t stream,
-                              void* workspace) {
+                              void* workspace, int window) {
   if (heads < 1 || kv_heads < 1 || max_len < 1) return QUIP_ERR_BAD_SHAPE;
   if (!rope_attn_decode_z_supported(heads, kv_heads, head_dim)) return QUIP_ERR_UNSUPPORTED;
   AttnArgs a{nullptr, nullptr, nullptr, cos, sin, pos, reinterpret_cast<f16*>(kcache),
              reinterpret_cast<f16*>(vcache), reinterpret_cast<f16*>(out), heads, kv_heads, max_len, scale, nullptr,
-             nullptr};
+             nullptr, window};
   AttnZ zz{};
   const int n = heads * head_dim;
   for (int i = 0; i < 3; ++i) {

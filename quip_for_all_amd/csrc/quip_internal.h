@@ -160,13 +160,14 @@ int had_transform_launch(const void* x, void* y, int64_t rows, int in_features, 
                          hipStream_t stream, const HadFusion* fuse = nullptr);
 int rope_attn_decode_launch(const void* q, const void* k, const void* v, const float* cos, const float* sin,
                             const int64_t* pos, void* kcache, void* vcache, void* out, int heads, int kv_heads,
-                            int head_dim, int max_len, float scale, hipStream_t stream, void* workspace = nullptr);
+                            int head_dim, int max_len, float scale, hipStream_t stream, void* workspace = nullptr,
+                            int window = 0);
 size_t rope_attn_workspace_bytes(int heads, int head_dim);
 bool rope_attn_decode_z_supported(int heads, int kv_heads, int head_dim);
 int rope_attn_decode_z_launch(const void* const* z, const void* const* post, const float* scales, const float* cos,
                               const float* sin, const int64_t* pos, void* kcache, void* vcache, void* out, int heads,
                               int kv_heads, int head_dim, int max_len, float scale, hipStream_t stream,
-                              void* workspace);
+                              void* workspace, int window = 0);
 int argmax_step_launch(const void* logits, int n, void* tok, void* pos, hipStream_t stream);
 // persistent decode engine, stage 1 (decode_engine.hip): GEMV[gate, up] -> output transforms -> SiLU product ->
 // input transform of down -> GEMV[down] of one decoder block in one launch

@@ -80,8 +80,9 @@ class LlamaDecoder:
     """Random-init Llama with QuantLinear projections, static KV cache, bs=1."""
 
     def __init__(self, shape: LlamaShape = LLAMA2_7B, codebook="E8P12", max_len=256, device="cuda", seed=0,
-                 device_init=False, **cb_kwargs):
+                 device_init=False, window=0, **cb_kwargs):
         self.s, self.dev, self.max_len = shape, torch.device(device), max_len
+        self.window = int(window) if 0 < int(window) < max_len else 0     # sliding-window attention (HF config.sliding_window)
         g = torch.Generator().manual_seed(seed)
         gq = torch.Generator(device=self.dev).manual_seed(seed) if device_init else g
         s = shape
@@ -125,13 +126,18 @@ class LlamaDecoder:
         prf = getattr(cfg, "partial_rotary_factor", prf)
         if prf not in (None, 1, 1.0):
             raise NotImplementedError(f"partial rotary embeddings (factor {prf}) are not supported")
-        if getattr(cfg, "sliding_window", None) and getattr(cfg, "use_sliding_window", True) and \
-                any(t != "full_attention" for t in (getattr(cfg, "layer_types", None) or ["sliding_attention"])):
-            # a window that is never shorter than the context is full attention (Mistral-7B: 4096); beyond it the cache would
-            # have to be read as a ring, which the attention kernels do not do
-            if max_len > int(cfg.sliding_window):
-                raise NotImplementedError(f"sliding-window attention (window {cfg.sliding_window}) with max_len {max_len} > window "
-                                          "is not supported: use max_len <= the window")
+        self.window = 0
+        # (HF's Llama modelling code never reads `sliding_window`: on such a config the attribute changes nothing there,
+        #  so it changes nothing here)
+        if (getattr(cfg, "sliding_window", None) and getattr(cfg, "use_sliding_window", True)
+                and getattr(cfg, "model_type", "") != "llama"):
+            types = getattr(cfg, "layer_types", None) or ["sliding_attention"]
+            if any(t not in ("full_attention", "sliding_attention") for t in types) or len(set(types)) > 1:
+                raise NotImplementedError(f"layer_types {sorted(set(types))}: per-layer attention patterns are not supported")
+            # a window that is never shorter than the context is full attention (Mistral-7B: 4096 on a 4096 cache); a
+            # shorter one bounds the attention walk from below -- the cache stays linear (row t = position t)
+            if types[0] == "sliding_attention" and max_len > int(cfg.sliding_window):
+                self.window = int(cfg.sliding_window)
         # rotary frequencies and attention scaling as the model computes them (llama3 / linear / yarn scaling change
         # inv_freq at every position; taking only rope_theta from the config would silently give other logits)
         self._inv_freq, self._att_scale = None, 1.0
@@ -183,6 +189,7 @@ class LlamaDecoder:
         self.graph = None
         self.sampling = None
         self.fused_attention = s.head_dim in (64, 128)
+        self.window = int(getattr(self, "window", 0) or 0)    # sliding-window attention: keys (pos - window, pos]; 0 = all
         from .register_lib import rope_attn_workspace
         self.attn_ws = rope_attn_workspace(s.heads, s.head_dim, self.dev) if self.fused_attention else None
         L0 = self.layers[0]
@@ -210,7 +217,7 @@ class LlamaDecoder:
         self.block_eng = False
         d4 = all(getattr(m.codebook, "id", None) in ("D4", "E8P12RVQ4B", "HI") for m in L0.values() if isinstance(m, QuantLinear))
         if ((self.ffn_eng or (d4 and self.fused_prologue and self.chain and os.environ.get("QUIP_FFN_ENGINE", "1") != "0"))
-                and os.environ.get("QUIP_BLOCK_ENGINE", "1") != "0"):
+                and os.environ.get("QUIP_BLOCK_ENGINE", "1") != "0" and not self.window):   # (its attention walks [0, pos])
             self._init_block_engine()
         # q / k / v output transforms inside the attention launch (multi-head attention with a power-of-two hidden <= 4096,
         # or 64 / 32 heads on 8 KV heads -- Llama-2-70B, Llama-3, Mistral-7B; plain SV output side)
@@ -302,7 +309,7 @@ class LlamaDecoder:
             # rope + cache append + attention over [0, pos]: one launch
             return torch.ops.quip_lib.rope_attn_decode(
                 q.view(s.heads, s.head_dim), k.view(s.kv_heads, s.head_dim), v.view(s.kv_heads, s.head_dim),
-                self.cos, self.sin, self.pos, self.kcache[i], self.vcache[i], self.attn_ws)
+                self.cos, self.sin, self.pos, self.kcache[i], self.vcache[i], self.attn_ws, self.window)
         q = self._rope(q.view(1, s.heads, 1, s.head_dim), cos, sin)
         k = self._rope(k.view(1, s.kv_heads, 1, s.head_dim), cos, sin)
         self.kcache[i].index_copy_(1, self.pos, k[0])
@@ -319,6 +326,8 @@ class LlamaDecoder:
         if not self.fused_attention:
             cos, sin = self.cos[self.pos], self.sin[self.pos]          # (1, head_dim)
             mask = (self.arange[None, None, None, :] <= self.pos)      # (1,1,1,max_len) keys <= current
+            if self.window:
+                mask = mask & (self.arange[None, None, None, :] > self.pos - self.window)
         if getattr(self, "block_eng", False):
             h = torch.ops.quip_lib.block_engine(self.eng_layers, h.reshape(-1), self.pos, self.cos, self.sin,
                                                 self.eng_grid, self.eng_ws, len(self.layers), self.max_len, s.rms_eps,
@@ -355,7 +364,7 @@ class LlamaDecoder:
                 # the K = 1 output transforms of q / k / v in the attention launch's prologue: 9 launches per block
                 a = torch.ops.quip_lib.rope_attn_decode_z(
                     list(zs), [l._vec(l.SV) for l in qkv], [1.0 / math.sqrt(l.q_out_features) for l in qkv],
-                    self.cos, self.sin, self.pos, self.kcache[i], self.vcache[i], self.attn_ws)
+                    self.cos, self.sin, self.pos, self.kcache[i], self.vcache[i], self.attn_ws, self.window)
             else:
                 q, k, v = out_transform_group(qkv, zs)
                 a = self._attention(i, q, k, v, cos, sin, mask)
@@ -459,8 +468,13 @@ class LlamaDecoder:
             v = v.view(P, s.kv_heads, s.head_dim).transpose(0, 1)
             self.kcache[i][:, :P].copy_(k)
             self.vcache[i][:, :P].copy_(v)
-            a = F.scaled_dot_product_attention(q[None], k[None], v[None], is_causal=True,
-                                               enable_gqa=(s.kv_heads != s.heads))[0]         # (heads, P, hd)
+            if self.window and P > self.window:     # causal band: key t for query p iff p - window < t <= p
+                band = (self.arange[:P, None] >= self.arange[None, :P]) & (self.arange[:P, None] - self.arange[None, :P] < self.window)
+                a = F.scaled_dot_product_attention(q[None], k[None], v[None], attn_mask=band,
+                                                   enable_gqa=(s.kv_heads != s.heads))[0]
+            else:
+                a = F.scaled_dot_product_attention(q[None], k[None], v[None], is_causal=True,
+                                                   enable_gqa=(s.kv_heads != s.heads))[0]     # (heads, P, hd)
             h = L["o"].forward_fused(a.transpose(0, 1).reshape(P, s.hidden), residual=h)
             g, u = forward_group([L["gate"], L["up"]], h, rms_weight=L["ln2"], rms_eps=s.rms_eps)
             h = L["down"].forward_fused(u, gate=g, residual=h)

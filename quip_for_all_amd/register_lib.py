@@ -47,7 +47,7 @@ _SCHEMAS = {
     # rope + KV append + attention on the RAW GEMV outputs of q / k / v_proj (their K = 1 output transforms in the
     # launch's prologue): zs / posts = [q, k, v], scales = 1 / sqrt(n)
     "rope_attn_decode_z": "(Tensor[] zs, Tensor[] posts, float[] scales, Tensor cos, Tensor sin, Tensor pos, "
-                          "Tensor(a!) kcache, Tensor(b!) vcache, Tensor? workspace=None) -> Tensor",
+                          "Tensor(a!) kcache, Tensor(b!) vcache, Tensor? workspace=None, int window=0) -> Tensor",
     # M >= 32 (prefill): fused dequant + MFMA GEMM, x (M, k) fp16 -> (M, n) fp16; no dense W (csrc/e8p_prefill_gemm.hip)
     "e8p_mm_batched": "(Tensor x, Tensor Qidxs, Tensor grid) -> Tensor",
     # ... with the other codebooks' decode (argument meaning as the *_mm_skinny ops below)
@@ -99,7 +99,7 @@ _SCHEMAS = {
                     "int codebook=0, float resid_scale=0.0) -> Tensor",
     # decode-step glue between q/k/v_proj and o_proj: rope + KV-cache append + single-query attention
     "rope_attn_decode": "(Tensor q, Tensor k, Tensor v, Tensor cos, Tensor sin, Tensor pos, Tensor(a!) kcache, "
-                        "Tensor(b!) vcache, Tensor(c!)? workspace) -> Tensor",
+                        "Tensor(b!) vcache, Tensor(c!)? workspace, int window=0) -> Tensor",   # window > 0: the last `window` positions only
     # greedy tail of the decode step: tok <- argmax(logits) (first maximum), pos += 1
     "argmax_step": "(Tensor logits, Tensor(a!) tok, Tensor(b!) pos) -> ()",
     "had_transform_planes_fused": "(Tensor x, int n, int K, Tensor? had, bool transpose, Tensor? pre, float scale, "
@@ -709,7 +709,7 @@ def rope_attn_workspace(heads, head_dim, device):
     return torch.zeros(capi.lib().quip_rope_attn_workspace_bytes(heads, head_dim), dtype=torch.uint8, device=device)
 
 
-def _rope_attn_decode_cuda(q, k, v, cos, sin, pos, kcache, vcache, workspace=None):
+def _rope_attn_decode_cuda(q, k, v, cos, sin, pos, kcache, vcache, workspace=None, window=0):
     """q (heads, hd), k / v (kv_heads, hd) fp16; cos / sin (max_len, hd) fp32; pos int64 device scalar;
     kcache / vcache (kv_heads, max_len, hd) fp16 (row pos is written) -> (heads, hd) fp16"""
     import math
@@ -729,10 +729,10 @@ def _rope_attn_decode_cuda(q, k, v, cos, sin, pos, kcache, vcache, workspace=Non
               and workspace.numel() >= capi.lib().quip_rope_attn_workspace_bytes(heads, hd),
               "workspace: use rope_attn_workspace(heads, head_dim, device)")
     with torch.cuda.device(q.device):
-        capi.check(capi.lib().quip_rope_attn_decode_f16(
+        capi.check(capi.lib().quip_rope_attn_decode_window_f16(
             q.data_ptr(), k.data_ptr(), v.data_ptr(), cos.data_ptr(), sin.data_ptr(), pos.data_ptr(),
             kcache.data_ptr(), vcache.data_ptr(), out.data_ptr(), heads, kvh, hd, max_len, 1.0 / math.sqrt(hd),
-            _ptr(workspace), _stream(q)), "quip_rope_attn_decode_f16")
+            int(window), _ptr(workspace), _stream(q)), "quip_rope_attn_decode_window_f16")
     return out
 
 
@@ -740,7 +740,7 @@ def rope_attn_decode_z_supported(heads, kv_heads, head_dim):
     return bool(capi.lib().quip_rope_attn_decode_z_supported(heads, kv_heads, head_dim))
 
 
-def _rope_attn_decode_z_cuda(zs, posts, scales, cos, sin, pos, kcache, vcache, workspace=None):
+def _rope_attn_decode_z_cuda(zs, posts, scales, cos, sin, pos, kcache, vcache, workspace=None, window=0):
     """zs / posts: the raw GEMV outputs (1, n) or (n,) and SV vectors (n,) of q / k / v_proj, fp16; the rest as
     rope_attn_decode -> (heads, hd) fp16"""
     import ctypes
@@ -770,10 +770,10 @@ def _rope_attn_decode_z_cuda(zs, posts, scales, cos, sin, pos, kcache, vcache, w
     pp = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in posts])
     sc = (ctypes.c_float * 3)(*[float(x) for x in scales])
     with torch.cuda.device(kcache.device):
-        capi.check(capi.lib().quip_rope_attn_decode_z_f16(
+        capi.check(capi.lib().quip_rope_attn_decode_z_window_f16(
             zp, pp, sc, cos.data_ptr(), sin.data_ptr(), pos.data_ptr(), kcache.data_ptr(), vcache.data_ptr(),
-            out.data_ptr(), heads, kvh, hd, max_len, 1.0 / math.sqrt(hd), _ptr(workspace), _stream(kcache)),
-            "quip_rope_attn_decode_z_f16")
+            out.data_ptr(), heads, kvh, hd, max_len, 1.0 / math.sqrt(hd), int(window), _ptr(workspace), _stream(kcache)),
+            "quip_rope_attn_decode_z_window_f16")
     return out
 
 
@@ -1153,8 +1153,8 @@ _reg_fake("ffn_engine", lambda planes_gate, planes_up, q_gate, q_up, q_down, had
           out_scale, in_scale, K, dbg=None: q_down.new_empty((1, q_down.shape[0]), dtype=torch.float16))
 _reg_fake("block_engine", lambda layers, h_in, pos, cos, sin, grid, workspace, n_layers, max_len, rms_eps, attn_scale,
           dbg=None, dbg_layer=-1, codebook=0, resid_scale=0.0: torch.empty_like(h_in))
-_reg_fake("rope_attn_decode", lambda q, k, v, cos, sin, pos, kcache, vcache, workspace=None: torch.empty_like(q))
-_reg_fake("rope_attn_decode_z", lambda zs, posts, scales, cos, sin, pos, kcache, vcache, workspace=None:
+_reg_fake("rope_attn_decode", lambda q, k, v, cos, sin, pos, kcache, vcache, workspace=None, window=0: torch.empty_like(q))
+_reg_fake("rope_attn_decode_z", lambda zs, posts, scales, cos, sin, pos, kcache, vcache, workspace=None, window=0:
           kcache.new_empty((zs[0].numel() // kcache.shape[2], kcache.shape[2])))
 _reg_fake("e8p_mm_skinny", lambda x, Q, g: x.new_empty((x.shape[0], Q.shape[0]), dtype=torch.float16))
 _reg_fake("e8prvq4_mm_skinny", lambda x, Q, g, s: x.new_empty((x.shape[0], Q.shape[0]), dtype=torch.float16))

@@ -52,7 +52,8 @@ def _ref_logits(dec, tokens):
             v = lin("v", x).reshape(s.kv_heads, s.head_dim)
             ks[i].append(k)
             vs[i].append(v)
-            K, V = np.stack(ks[i], 1), np.stack(vs[i], 1)          # (kv, T, d)
+            lo = max(0, p + 1 - dec.window) if getattr(dec, "window", 0) else 0     # sliding window: keys (p - window, p]
+            K, V = np.stack(ks[i][lo:], 1), np.stack(vs[i][lo:], 1)          # (kv, T, d)
             rep = s.heads // s.kv_heads
             out = np.empty((s.heads, s.head_dim))
             for hh in range(s.heads):
@@ -256,6 +257,81 @@ def test_llama3_8b_shaped_decoder_graph_equals_eager():
     dec.graph = None
     c = dec.generate(6, first_token=11, use_graph=False)
     assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("heads,kv_heads,hd,pos,window", [(32, 32, 128, 37, 8), (8, 2, 128, 200, 64), (4, 4, 64, 130, 131),
+                                                          (4, 4, 64, 130, 500), (32, 8, 128, 1000, 300), (8, 8, 64, 2047, 1),
+                                                          (16, 2, 128, 4100, 4096), (8, 8, 128, 300, 5)])
+def test_rope_attn_decode_sliding_window(heads, kv_heads, hd, pos, window):
+    """sliding-window attention (HF config.sliding_window; Mistral): the softmax runs over keys (pos - window, pos] of the
+    linear cache; with and without the split-mode workspace; a window that covers the context is the plain launch bit for bit"""
+    import quip_for_all_amd  # noqa: F401
+    from quip_for_all_amd.register_lib import rope_attn_workspace
+    dev = "cuda"
+    g = torch.Generator().manual_seed(pos + heads + window)
+    max_len = pos + 9
+    q = torch.randn(heads, hd, generator=g).half().to(dev)
+    k = torch.randn(kv_heads, hd, generator=g).half().to(dev)
+    v = torch.randn(kv_heads, hd, generator=g).half().to(dev)
+    kc = torch.randn(kv_heads, max_len, hd, generator=g).half().to(dev)
+    vc = torch.randn(kv_heads, max_len, hd, generator=g).half().to(dev)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    ang = torch.arange(max_len, dtype=torch.float32)[:, None] * inv[None, :]
+    cos = torch.cat([ang.cos(), ang.cos()], -1).to(dev)
+    sin = torch.cat([ang.sin(), ang.sin()], -1).to(dev)
+    p = torch.tensor([pos], device=dev)
+    kc2, vc2 = kc.clone(), vc.clone()
+    out = torch.ops.quip_lib.rope_attn_decode(q, k, v, cos, sin, p, kc2, vc2, None, window)
+    ws = rope_attn_workspace(heads, hd, dev)
+    for _ in range(2):
+        kc3, vc3 = kc.clone(), vc.clone()
+        out_s = torch.ops.quip_lib.rope_attn_decode(q, k, v, cos, sin, p, kc3, vc3, ws, window)
+        assert torch.equal(kc3, kc2) and torch.equal(vc3, vc2)
+        assert (out_s.float() - out.float()).abs().max().item() <= 2e-3 * max(1.0, out.float().abs().max().item())
+    if window > pos:
+        kc4, vc4 = kc.clone(), vc.clone()
+        assert torch.equal(out, torch.ops.quip_lib.rope_attn_decode(q, k, v, cos, sin, p, kc4, vc4, None))
+    lo = max(0, pos + 1 - window)
+    rep = heads // kv_heads
+    K = kc2[:, lo:pos + 1].double().repeat_interleave(rep, 0)
+    V = vc2[:, lo:pos + 1].double().repeat_interleave(rep, 0)
+    d = hd // 2
+    qr = (q.float() * cos[pos] + torch.cat([-q[..., d:], q[..., :d]], -1).float() * sin[pos]).half()
+    s = torch.einsum("hd,htd->ht", qr.double(), K) / hd ** 0.5
+    ref = torch.einsum("ht,htd->hd", torch.softmax(s, -1), V)
+    err = (out.double() - ref).abs().max().item()
+    assert err <= 2e-3 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("shape_name,window,plen", [("TINY", 4, 0), ("TINY", 5, 9), ("SMALL", 7, 12)])
+def test_decoder_with_sliding_window_against_float64_model(shape_name, window, plen):
+    """LlamaDecoder(window=W): captured step (and the batched prompt pass) against the float64 model whose attention sees
+    the last W positions only; the window changes the logits (a decoder without one differs)"""
+    from quip_for_all_amd import decode as D
+    shape = getattr(D, shape_name)
+    dec = D.LlamaDecoder(shape, "E8P12", max_len=32, device="cuda", seed=5, window=window)
+    assert dec.window == window and not dec.block_eng
+    n_new = 6
+    if plen:
+        prompt = [3, 9, 1, 14, 7, 2, 30, 11, 5, 8, 21, 13][:plen]
+        toks = dec.generate(n_new, prompt=prompt, use_graph=True)
+        seq = list(prompt) + [int(t) for t in toks]
+    else:
+        toks = dec.generate(n_new, first_token=3, use_graph=True)
+        seq = [3] + [int(t) for t in toks]
+    eager = dec.generate(n_new, prompt=seq[:plen] if plen else None, first_token=3, use_graph=False)
+    assert [int(t) for t in eager] == [int(t) for t in toks]
+    # teacher-forced: the logits of the float64 windowed model at the last consumed position pick the same token
+    # (up to fp16 noise at near ties)
+    hist = seq[:-1]
+    ref = _ref_logits(dec, hist)
+    nxt = seq[-1]
+    assert ref.max() - ref[nxt] <= 0.03 * (np.abs(ref).max() + 1.0)
+    dec.window = 0            # the float64 model of the same weights without the window
+    ref_f = _ref_logits(dec, hist)
+    dec.window = window
+    ref_w = ref
+    assert np.abs(ref_w - ref_f).max() > 1e-3, "the window must matter at this length"
 
 
 @pytest.mark.parametrize("bad_pos", [-1, 64, 10 ** 12])

@@ -138,10 +138,37 @@ def test_fast_decoder_takes_the_models_rotary_embedding(tmp_path):
         margin = (row.max() - row[int(toks[t])]).item()
         assert margin <= 0.03 * (row.abs().max().item() + 1.0), (t, margin)
     # unsupported options raise instead of decoding something else
-    q.config.sliding_window, q.config.layer_types = 16, ["sliding_attention"] * q.config.num_hidden_layers
+    q.config.sliding_window, q.config.layer_types = 16, ["sliding_attention", "chunked_attention"]
+    q.config.model_type = "somethingelse"
     with pytest.raises(NotImplementedError):
         LlamaDecoder.from_hf(q, max_len=48)
-    # ... but a window that is never shorter than the context is full attention (Mistral-7B's 4096): accepted, same tokens
-    q.config.sliding_window = 48
+    # ... a window that is never shorter than the context is full attention (Mistral-7B's 4096): same tokens
+    q.config.sliding_window, q.config.layer_types = 48, ["sliding_attention"] * q.config.num_hidden_layers
     dec2 = LlamaDecoder.from_hf(q, max_len=48)
-    assert torch.equal(dec2.generate(10, prompt=prompt), toks)
+    assert dec2.window == 0 and torch.equal(dec2.generate(10, prompt=prompt), toks)
+
+
+@pytest.mark.parametrize("window,plen", [(6, 20), (5, 3), (16, 40)])
+def test_fast_decoder_sliding_window_follows_hf_mistral(tmp_path, window, plen):
+    """A Mistral-architecture checkpoint whose sliding window is shorter than the context: LlamaDecoder.from_hf bounds the
+    attention walk (rope_attn_decode's window, the band mask of the batched prompt pass) and follows the stock HF forward
+    of the same model -- which masks keys at distance >= window -- token by token (teacher forced, fp16 noise margin)"""
+    from transformers import AutoModelForCausalLM, MistralConfig
+    from quip_for_all_amd.quantizer import QuipQuantizer, load_quantized_model
+    from quip_for_all_amd.decode import LlamaDecoder
+    cfg = MistralConfig(hidden_size=256, intermediate_size=688, num_hidden_layers=2, num_attention_heads=4,
+                        num_key_value_heads=2, vocab_size=320, max_position_embeddings=64, tie_word_embeddings=False,
+                        sliding_window=window)
+    torch.manual_seed(3)
+    model = AutoModelForCausalLM.from_config(cfg, dtype=torch.float16)
+    qz = QuipQuantizer(codebook="E8P12", inference=True, ft_epochs=0)
+    qz.convert_model(model)
+    _fill_random(model, seed=13)
+    qz.save(model, str(tmp_path))
+    q = load_quantized_model(str(tmp_path), device_map={"": "cuda:0"})
+    dec = LlamaDecoder.from_hf(q, max_len=64)
+    assert dec.window == window and not dec.block_eng
+    prompt = torch.randint(0, 320, (plen,), generator=torch.Generator().manual_seed(plen)).cuda()
+    _check_prompt(q, dec, prompt)
+    toks = dec.generate(8, prompt=prompt)
+    assert torch.equal(toks, dec.generate(8, prompt=prompt, use_graph=False))
