@@ -332,6 +332,14 @@ int quip_d4_gemv_planes(const void* planes, const void* qidxs, const void* grid_
 int quip_d4_gemv_planes_group(const void* const* planes, const void* const* qidxs, const void* grid_f16,
                               void* const* ys, const int32_t* ns, int32_t count, int32_t k,
                               quip_stream_t stream);
+/* ... with the zeroed workspace of quip_e8p_gemv_workspace_bytes(sum of ns): rows longer than 28672 (HI's virtual rows at the
+ * Llama-2-70B down_proj width, 2 k = 57344) go to the K-splitting kernel in its D4 table mode; grid_f16 64-byte aligned there. */
+/* (the K-splitting kernel's D4 table mode on any shape it takes, k % 128 == 0: for A/B tests against the first kernel) */
+int quip_d4_gemv_planes_v2(const void* planes, const void* qidxs, const void* grid_f16, void* y, int32_t n, int32_t k,
+                           void* workspace, size_t workspace_bytes, quip_stream_t stream);
+int quip_d4_gemv_planes_group_ws(const void* const* planes, const void* const* qidxs, const void* grid_f16,
+                                 void* const* ys, const int32_t* ns, int32_t count, int32_t k, void* workspace,
+                                 size_t workspace_bytes, quip_stream_t stream);
 
 /* E8P12RVQ3B (3-byte codes: resid8 | e8p16 << 8, e8p12_rvq3.py:81-107) on the matrix-core GEMV.  qidxs is the
  * checkpoint's own packed tensor (n rows of 3 k / 8 bytes, the int32 (n, 3 k / 32) Qidxs of the reference; rows need

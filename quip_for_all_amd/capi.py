@@ -36,6 +36,8 @@ SIGNATURES = {
     "quip_e8prvq3_gemv_planes_group_ws": [_P, _P, _P, _P, _P, _P, _I32, _I32, _P, _c.c_size_t, _P],
     "quip_d4_gemv_planes": [_P, _P, _P, _P, _I32, _I32, _P],
     "quip_d4_gemv_planes_group": [_P, _P, _P, _P, _P, _I32, _I32, _P],
+    "quip_d4_gemv_planes_v2": [_P, _P, _P, _P, _I32, _I32, _P, _c.c_size_t, _P],
+    "quip_d4_gemv_planes_group_ws": [_P, _P, _P, _P, _P, _I32, _I32, _P, _c.c_size_t, _P],
     "quip_e8p_gemv_fused": [_P, _P, _P, _P, _P, _I32, _I32, _P],
     "quip_rope_attn_workspace_bytes": [_I32, _I32],
     "quip_argmax_step_f16": [_P, _I32, _P, _P, _P],

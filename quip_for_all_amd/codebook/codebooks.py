@@ -435,7 +435,9 @@ class HI4B1C_codebook(_SkinnyMixin, _Codebook):
 
     @staticmethod
     def planes_supported(q_out, q_in):
-        return (2 * q_in) % 128 == 0 and 128 <= 2 * q_in <= 28672 and q_out >= 1
+        # virtual rows longer than 28672 (70B down_proj: 2 k = 57344) go to the K-splitting kernel's D4 table mode
+        # (csrc/e8p_gemv_v2.hip) through the op's dispatcher
+        return (2 * q_in) % 128 == 0 and 128 <= 2 * q_in <= 57344 and q_out >= 1
 
     @staticmethod
     def planes_group_supported(q_outs, q_in):

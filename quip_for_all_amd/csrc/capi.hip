@@ -341,32 +341,58 @@ int quip_e8prvq3_gemv_planes_group_ws(const void* const* planes, const void* con
                               stream);
 }
 
-int quip_d4_gemv_planes(const void* planes, const void* qidxs, const void* grid_f16, void* y, int32_t n,
-                        int32_t k, quip_stream_t stream) {
-  if (!planes || !qidxs || !grid_f16 || !y) return QUIP_ERR_NULL_POINTER;
-  if (n < 1 || k < 1 || k % 8 != 0) return QUIP_ERR_BAD_SHAPE;
-  if (!aligned16(planes) || !aligned16(qidxs)) return QUIP_ERR_MISALIGNED;
-  GemvTune t;
-  t.rep = 64;   // D4 mode of the matrix-core GEMV
-  return e8p_gemv_mfma_launch(planes, qidxs, grid_f16, y, n, k, t, (hipStream_t)stream);
-}
-
-int quip_d4_gemv_planes_group(const void* const* planes, const void* const* qidxs, const void* grid_f16,
-                              void* const* ys, const int32_t* ns, int32_t count, int32_t k,
-                              quip_stream_t stream) {
+// D4 table mode of the matrix-core GEMVs: the first kernel wherever it takes the shape (k <= 28672), else the
+// K-splitting kernel in its D4 table mode (HI's virtual rows at the 70B down_proj width: 2 k = 57344)
+static int d4_group_common(const void* const* planes, const void* const* qidxs, const void* grid_f16,
+                           void* const* ys, const int32_t* ns, int32_t count, int32_t k, void* ws, size_t ws_bytes,
+                           quip_stream_t stream) {
   if (!planes || !qidxs || !grid_f16 || !ys || !ns) return QUIP_ERR_NULL_POINTER;
   if (count < 1 || count > QUIP_MAX_GROUP) return QUIP_ERR_BAD_SHAPE;
   int n32[QUIP_MAX_GROUP];
+  size_t need = 0;
   for (int i = 0; i < count; ++i) {
     if (!planes[i] || !qidxs[i] || !ys[i]) return QUIP_ERR_NULL_POINTER;
     if (!aligned16(planes[i]) || !aligned16(qidxs[i])) return QUIP_ERR_MISALIGNED;
     if (ns[i] < 1) return QUIP_ERR_BAD_SHAPE;
     n32[i] = ns[i];
+    need += e8p_gemv_v2_workspace_words(ns[i]) * 4;
   }
   if (k < 1 || k % 8 != 0) return QUIP_ERR_BAD_SHAPE;
+  if (ws && !aligned16(ws)) return QUIP_ERR_MISALIGNED;
+  if (ws && ws_bytes < need) ws = nullptr;
   GemvTune t;
   t.rep = 64;
-  return e8p_gemv_mfma_group_launch(planes, qidxs, grid_f16, ys, n32, count, k, t, (hipStream_t)stream);
+  const int rc = e8p_gemv_mfma_group_launch(planes, qidxs, grid_f16, ys, n32, count, k, t, (hipStream_t)stream);
+  if (rc != QUIP_ERR_UNSUPPORTED) return rc;
+  return e8p_gemv_v2_group_launch(planes, qidxs, grid_f16, ys, ws, n32, count, k, t, (hipStream_t)stream);
+}
+
+int quip_d4_gemv_planes(const void* planes, const void* qidxs, const void* grid_f16, void* y, int32_t n,
+                        int32_t k, quip_stream_t stream) {
+  return d4_group_common(&planes, &qidxs, grid_f16, &y, &n, 1, k, nullptr, 0, stream);
+}
+
+int quip_d4_gemv_planes_group(const void* const* planes, const void* const* qidxs, const void* grid_f16,
+                              void* const* ys, const int32_t* ns, int32_t count, int32_t k,
+                              quip_stream_t stream) {
+  return d4_group_common(planes, qidxs, grid_f16, ys, ns, count, k, nullptr, 0, stream);
+}
+
+int quip_d4_gemv_planes_v2(const void* planes, const void* qidxs, const void* grid_f16, void* y, int32_t n, int32_t k,
+                           void* workspace, size_t workspace_bytes, quip_stream_t stream) {
+  if (!planes || !qidxs || !grid_f16 || !y) return QUIP_ERR_NULL_POINTER;
+  if (n < 1 || k < 1 || k % 8 != 0) return QUIP_ERR_BAD_SHAPE;
+  if (!aligned16(planes) || !aligned16(qidxs) || (workspace && !aligned16(workspace))) return QUIP_ERR_MISALIGNED;
+  if (workspace && workspace_bytes < e8p_gemv_v2_workspace_words(n) * 4) workspace = nullptr;
+  GemvTune t;
+  t.rep = 64;
+  return e8p_gemv_v2_launch(planes, qidxs, grid_f16, y, workspace, n, k, t, (hipStream_t)stream);
+}
+
+int quip_d4_gemv_planes_group_ws(const void* const* planes, const void* const* qidxs, const void* grid_f16,
+                                 void* const* ys, const int32_t* ns, int32_t count, int32_t k, void* workspace,
+                                 size_t workspace_bytes, quip_stream_t stream) {
+  return d4_group_common(planes, qidxs, grid_f16, ys, ns, count, k, workspace, workspace_bytes, stream);
 }
 
 int quip_e8p_gemv_fused(const quip_gemv_fused_in* in, const void* const* qidxs,

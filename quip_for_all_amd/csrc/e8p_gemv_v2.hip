@@ -116,6 +116,9 @@ struct V2Args {
   int spw;                        // segments per workgroup (K split)
   int ksplit;
   int runlen;                     // segments per run
+  int d4;                         // D4 table mode (also HI through its virtual layout): `grid` = the fp16 (256, 4) table; a
+                                  // 16-bit "code" is two D4 code bytes -- T2[low byte] = (4w of weights 0..3, 0),
+                                  // T1[high byte] = (0, 4w of weights 4..7), so T1 ^ T2 is the 8-group as for E8P12
   uint64_t* dbg;
 };
 
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
   {
     const int e = (wave & 7) * 32 + (lane & 31);
     const uint2* t1 = reinterpret_cast<const uint2*>(a.grid) + e;
-    const uint2* t2 = &kV2T2Img.v[e];
+    const uint2* t2 = a.d4 ? t1 : &kV2T2Img.v[e];
     asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(tsrc) : "v"((lane & 32) ? t2 : t1) : "memory");
   }
   u32x2 tsrc3 = {0u, 0u};   // RVQ3: this lane's E81B entry (requested right behind tsrc: any later wait covers both)
@@ -312,7 +315,14 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
     const bool second = (lane & 32) != 0;
     const uint32_t t1x = __builtin_amdgcn_perm(0u, tsrc.x, 0x03010200u) | 0x01010101u;
     const uint32_t t1y = __builtin_amdgcn_perm(0u, tsrc.y, 0x03010200u) | 0x01010101u;
-    const u32x2 val = {second ? tsrc.x : t1x, second ? tsrc.y : t1y};
+    u32x2 val = {second ? tsrc.x : t1x, second ? tsrc.y : t1y};
+    if (a.d4) {
+      // four fp16 half-integers -> int8 4w (|w| <= 7.5: exact), in the half of the 8-byte entry its code byte stands for
+      const f16x2 lo = as_f16x2(tsrc.x), hi = as_f16x2(tsrc.y);
+      const uint32_t pk = ((uint32_t)(int)(4.f * (float)lo.x) & 0xffu) | (((uint32_t)(int)(4.f * (float)lo.y) & 0xffu) << 8) |
+                          (((uint32_t)(int)(4.f * (float)hi.x) & 0xffu) << 16) | (((uint32_t)(int)(4.f * (float)hi.y) & 0xffu) << 24);
+      val = second ? u32x2{pk, 0u} : u32x2{0u, pk};
+    }
     const uint32_t row = (uint32_t)(wave * 32 + (lane & 31));
     const uint32_t rowbase = second ? (uint32_t)L::kT2 + row * (REP2 * 8) : row * (REP1 * 8);
     const uint32_t mask = second ? (uint32_t)(REP2 - 1) : (uint32_t)(REP1 - 1);
@@ -561,8 +571,8 @@ int v2_group_launch(const void* const* planes, const void* const* qidxs, const v
     if (G != 1 || !tune.grid2) return QUIP_ERR_UNSUPPORTED;
     for (int ks = 1; ks <= segs; ++ks)
       if (consider(40, ks)) break;
-  } else if (tune.rep || tune.waves_g) {
-    const int rp = tune.rep ? tune.rep : 32;
+  } else if ((tune.rep && tune.rep != 64) || tune.waves_g) {
+    const int rp = tune.rep && tune.rep != 64 ? tune.rep : 32;
     for (int ks = tune.waves_g > 0 ? tune.waves_g : 1; ks <= segs; ++ks)
       if (consider(rp, ks)) break;
   } else {
@@ -599,6 +609,7 @@ int v2_group_launch(const void* const* planes, const void* const* qidxs, const v
   a.kp_src = (k + 511) & ~511;
   a.segs = segs; a.spw = spw; a.ksplit = ksplit;
   a.dbg = reinterpret_cast<uint64_t*>(tune.dbg);
+  a.d4 = tune.rep == 64 ? 1 : 0;      // (the first kernel's mode number for its D4 table)
   // 16 waves for long streams; 12 when a workgroup has few units (8192^2: 64 units, 7.2 vs 7.9 us with 16)
   int waves = tune.max_waves > 0 ? tune.max_waves : (quads * spw >= 128 ? 16 : 12);
   if (waves < 8) waves = 8;     // the table build uses waves 0..7

@@ -284,14 +284,7 @@ def _d4_grid(grid):
 
 
 def _d4_gemv_planes_cuda(planes, Qidxs, grid):
-    _need(Qidxs.dtype == torch.uint8 and Qidxs.is_contiguous(), "Qidxs must be contiguous uint8 (n, k/4)")
-    _need(planes.dtype == torch.uint8 and planes.is_contiguous() and planes.device == Qidxs.device, "planes: uint8")
-    n, k = Qidxs.shape[0], Qidxs.shape[1] * 4
-    y = _empty((1, n), dtype=torch.float16, device=Qidxs.device)
-    with torch.cuda.device(Qidxs.device):
-        capi.check(capi.lib().quip_d4_gemv_planes(planes.data_ptr(), Qidxs.data_ptr(), _d4_grid(grid).data_ptr(),
-                                                  y.data_ptr(), n, k, _stream(Qidxs)), "quip_d4_gemv_planes")
-    return y
+    return _d4_gemv_planes_group_cuda([planes], [Qidxs], grid)[0]
 
 
 def _e8prvq3_gemv_planes_group_cuda(planes, Qidxs, grid, e81b_i8):
@@ -333,10 +326,12 @@ def _d4_gemv_planes_group_cuda(planes, Qidxs, grid):
     outs = [_empty((1, q.shape[0]), dtype=torch.float16, device=dev) for q in Qidxs]
     vp = ctypes.c_void_p * count
     ns = (ctypes.c_int32 * count)(*[q.shape[0] for q in Qidxs])
+    ws = _gemv_workspace(dev, sum(q.shape[0] for q in Qidxs))    # (rows beyond 28672: the K-splitting kernel's partial sums)
     with torch.cuda.device(dev):
-        capi.check(capi.lib().quip_d4_gemv_planes_group(
+        capi.check(capi.lib().quip_d4_gemv_planes_group_ws(
             vp(*[p.data_ptr() for p in planes]), vp(*[q.data_ptr() for q in Qidxs]), _d4_grid(grid).data_ptr(),
-            vp(*[o.data_ptr() for o in outs]), ns, count, k, _stream(planes[0])), "quip_d4_gemv_planes_group")
+            vp(*[o.data_ptr() for o in outs]), ns, count, k, ws.data_ptr(), ws.numel() * 4, _stream(planes[0])),
+            "quip_d4_gemv_planes_group_ws")
     return outs
 
 
@@ -432,6 +427,8 @@ def _gemv_planes_rows_mode_cuda(planes, Qidxs, grid, grid2, mode):
     if per < 1 and mode == 40:
         # virtual rows longer than rows mode holds in LDS (70B down_proj): one bs=1 launch per row (K-splitting kernel)
         return torch.cat([_e8prvq3_gemv_planes_group_cuda([planes[r]], [Qidxs], grid, grid2)[0] for r in range(rows)])
+    if per < 1 and mode == 64:      # ... the same for the D4 table mode (HI's virtual rows)
+        return torch.cat([_d4_gemv_planes_group_cuda([planes[r]], [Qidxs], grid)[0] for r in range(rows)])
     _need(per >= 1, "shape not supported by the matrix-core GEMV")
     out = _empty((rows, n), dtype=torch.float16, device=Qidxs.device)
     with torch.cuda.device(Qidxs.device):

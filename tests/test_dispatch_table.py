@@ -85,6 +85,18 @@ def test_other_codebooks_regimes(cb_name):
         assert layer.regime(m) == "codebook"
     assert layer.codebook.batched_regime(32, 4096, 4096) == "skinny_chunks"
     assert layer.codebook.batched_regime(2048, 4096, 4096) == "decompress_gemm"
+    # QUIP_BATCHED_MM=fused: the fused dequant + MFMA tile kernel in the codebook's mode beyond the skinny regime
+    from quip_for_all_amd.codebook.codebooks import E8P12_codebook
+    saved = E8P12_codebook.batched_mode
+    try:
+        E8P12_codebook.batched_mode = "fused"
+        assert layer.codebook.batched_regime(2048, 4096, 4096) == "fused_gemm"
+        assert layer.codebook.batched_regime(32, 4096, 4096) == "skinny_chunks"
+    finally:
+        E8P12_codebook.batched_mode = saved
+    # Llama-2-70B down_proj width: every codebook's bs = 1 product stays on the matrix-core GEMV (the RVQ codebooks' and
+    # HI's 2k = 57344-wide virtual rows through the K-splitting kernel)
+    assert layer.codebook.planes_supported(8192, 28672)
 
 
 def test_persistent_launch_shapes():

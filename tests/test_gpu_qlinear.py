@@ -149,6 +149,58 @@ def test_rvq_rows_longer_than_28672_on_matrix_core_path(cbid, fin, fout, M):
     assert np.all(np.abs(y.cpu().numpy().astype(np.float64) - ref) <= O.ulp_bound(P, x64, What))
 
 
+@pytest.mark.parametrize("fin,fout,M", [(28672, 512, 1), (28672, 8192, 1), (16384, 256, 1), (14336, 1000, 1), (28672, 512, 3)])
+def test_hi_rows_longer_than_28672_on_matrix_core_path(fin, fout, M):
+    """HI at Llama-2-70B's down_proj width: the 2k = 57344-wide virtual D4 row is beyond the first GEMV kernel and is
+    taken by the K-splitting kernel's D4 table mode (csrc/e8p_gemv_v2.hip: T2[low code byte] = (4w, 0), T1[high code byte]
+    = (0, 4w)) -- module forward against the oracle, rows bit identical to bs=1, and (where both kernels take the shape)
+    bit identical to the first kernel"""
+    P = O.make_layer("HI", fin, fout, seed=fin + fout)
+    layer = _layer(P)
+    assert layer.codebook.planes_supported(layer.q_out_features, layer.q_in_features)
+    assert layer.regime(1) == "gemv_planes"
+    x = np.random.default_rng(M).standard_normal((M, fin)).astype(np.float16)
+    xd = torch.from_numpy(x).to(DEV)
+    with torch.no_grad():
+        y = layer(xd)
+        for r in range(M):
+            assert torch.equal(y[r:r + 1], layer(xd[r:r + 1]))
+    What = O.qlinear_dense_weight(P)
+    x64 = x.astype(np.float64)
+    ref = O.qlinear_forward(P, x64, "exact", What)
+    assert np.all(np.abs(y.cpu().numpy().astype(np.float64) - ref) <= O.ulp_bound(P, x64, What))
+
+
+@pytest.mark.parametrize("cbid,n,k", [("D4", 512, 4096), ("D4", 4096, 11008), ("D4", 100, 28672), ("HI", 512, 4096), ("HI", 300, 11008)])
+def test_v2_d4_table_mode_equals_first_kernel(cbid, n, k):
+    """the K-splitting kernel's D4 table mode against the first kernel's on shapes both take: exact integer sums, one
+    rounding -- bit identical"""
+    import ctypes
+    import math
+    from quip_for_all_amd import capi
+    from quip_for_all_amd.register_lib import _gemv_workspace, _stream
+    P = O.make_layer(cbid, k, n, seed=n + k)
+    layer = _layer(P)
+    cb = layer.codebook
+    xd = torch.from_numpy(np.random.default_rng(n).standard_normal((1, k)).astype(np.float16)).to(DEV)
+    L_in = layer.q_in_features // layer.K_left
+    with torch.no_grad():
+        planes = torch.ops.quip_lib.had_transform_planes_fused(
+            xd, layer.q_in_features, layer.K_left, layer._had("had_left"), True, layer._vec(layer.SU),
+            layer.wscale_float / math.sqrt(L_in), None, 1e-5, None, getattr(cb, "planes_resid_scale", 0.0))
+        y1 = cb.mm_planes(planes, layer.Qidxs)
+    q8 = layer.Qidxs.view(torch.uint8)
+    grid = cb.grid if cbid == "D4" else cb._virtual_grid(q8.device)
+    kv = q8.shape[1] * 4
+    y2 = torch.empty_like(y1)
+    ws = _gemv_workspace(q8.device, n)
+    # (the K-splitting kernel directly: QUIP_GEMV_V2 does not reach the D4 entry points)
+    rc = capi.lib().quip_d4_gemv_planes_v2(planes.data_ptr(), q8.data_ptr(), grid.data_ptr(), y2.data_ptr(), n, kv,
+                                           ws.data_ptr(), ws.numel() * 4, _stream(q8))
+    assert rc == 0, rc
+    assert torch.equal(y1, y2)
+
+
 @pytest.mark.parametrize("cbid,fin,fout", [("E8P12", 4096, 4096), ("E8P12", 1408, 512), ("D4", 1024, 1024),
                                            ("E8P12", 4096, 11008), ("E8P12", 11008, 4096),
                                            ("E8P12RVQ4B", 4096, 11008), ("E8P12RVQ4B", 11008, 4096),
