@@ -172,3 +172,34 @@ def test_fast_decoder_sliding_window_follows_hf_mistral(tmp_path, window, plen):
     _check_prompt(q, dec, prompt)
     toks = dec.generate(8, prompt=prompt)
     assert torch.equal(toks, dec.generate(8, prompt=prompt, use_graph=False))
+
+
+def test_fast_decoder_qwen2_architecture_with_qkv_bias(tmp_path):
+    """A Qwen2-architecture checkpoint (Llama-shaped blocks, bias on q / k / v_proj, `sliding_window` present but unused):
+    LlamaDecoder.from_hf follows the stock HF forward of the same model, prompt pass and captured steps"""
+    from transformers import AutoModelForCausalLM, Qwen2Config
+    from quip_for_all_amd.quantizer import QuipQuantizer, load_quantized_model
+    from quip_for_all_amd.decode import LlamaDecoder
+    cfg = Qwen2Config(hidden_size=256, intermediate_size=688, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, vocab_size=320, max_position_embeddings=64, tie_word_embeddings=False)
+    torch.manual_seed(4)
+    model = AutoModelForCausalLM.from_config(cfg, dtype=torch.float16)
+    assert model.model.layers[0].self_attn.q_proj.bias is not None
+    qz = QuipQuantizer(codebook="E8P12", inference=True, ft_epochs=0)
+    qz.convert_model(model)          # (module replacement only: the biases of a checkpoint arrive with its state dict)
+    _fill_random(model, seed=17)
+    with torch.no_grad():
+        for blk in model.model.layers:
+            for m in (blk.self_attn.q_proj, blk.self_attn.k_proj, blk.self_attn.v_proj):
+                assert m.bias is not None, "QuantLinear keeps the bias of the layer it replaces (quantizer.py:147-160)"
+                m.bias.copy_(0.5 * torch.randn(m.bias.shape).to(m.bias.dtype))
+    qz.save(model, str(tmp_path))
+    q = load_quantized_model(str(tmp_path), device_map={"": "cuda:0"})
+    assert q.model.layers[0].self_attn.q_proj.bias is not None and float(q.model.layers[0].self_attn.q_proj.bias.abs().max()) > 0
+    dec = LlamaDecoder.from_hf(q, max_len=64)
+    assert dec.window == 0
+    for prompt in (torch.tensor([5, 17, 3, 99, 42], device="cuda:0"),
+                   torch.randint(0, 320, (40,), generator=torch.Generator().manual_seed(6)).cuda()):
+        _check_prompt(q, dec, prompt)
+    toks = dec.generate(8, prompt=prompt)
+    assert torch.equal(toks, dec.generate(8, prompt=prompt, use_graph=False))
