@@ -113,6 +113,25 @@ def test_skinny_kernel_touches_no_register_in_flight():
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_prefill_tile_kernels_of_every_codebook_use_no_scratch():
+    """e8p_prefill_gemm.hip: the eight-wave layout (the one the launcher selects) in all five codebook modes keeps its 64 / 128
+    accumulator registers, the code registers in flight and the table entries in VGPRs -- a spill would put scratch
+    (VMEM) operations into a K loop whose vmcnt queue is counted by hand.  (tools/check_inflight.py is not run on this
+    file: its `if (t + i < KT) tile(..)` loop has control-flow paths from a skipped tile back to the loop head that
+    never execute -- t + i >= KT ends the loop -- and the checker follows every path.)"""
+    src = os.path.join(REPO, "quip_for_all_amd", "csrc", "e8p_prefill_gemm.hip")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", os.devnull, src,
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, check=True)
+    names = re.findall(r"Function Name: (\S+)", r.stderr)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+    assert len(names) == len(scratch)
+    eight_wave = {n: sc for n, sc in zip(names, scratch) if "e8p_prefill_gemm_kernel" in n and "ELi1ELi1ELi8ELi" in n}
+    # <4 | 8 row blocks> x E8P12, D4, HI; 128-row tiles only for the two RVQ codebooks
+    assert len(eight_wave) == 8, sorted(eight_wave)
+    assert not any(eight_wave.values()), eight_wave
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_block_engine_kernels_use_no_scratch_and_touch_no_register_in_flight():
     """decode_block.hip keeps weight requests in flight in asm-written registers across whole phases of the persistent
     launch, and sits within a few registers of the 256 a 512-thread workgroup can have: a spill costs 10-30 us per block
