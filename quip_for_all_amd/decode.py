@@ -105,14 +105,35 @@ class LlamaDecoder:
                 gate=ql(s.hidden, s.ffn), up=ql(s.hidden, s.ffn), down=ql(s.ffn, s.hidden)))
         self._init_runtime()
 
+    # architectures whose decoder block is Llama's: RMSNorm (weight only) -> q / k / v (+ bias) -> rotary -> softmax attention
+    # -> o -> residual -> RMSNorm -> SiLU-gated MLP -> residual, embeddings and residuals unscaled
+    LLAMA_LIKE = ("llama", "mistral", "qwen2")
+
     @classmethod
-    def from_hf(cls, model, max_len=256, device=None):
+    def from_hf(cls, model, max_len=256, device=None, assume_llama_like=False):
         """Fast bs=1 decoder around a Llama-architecture HF model whose linear layers are QuantLinear
         (what `load_quantized_model` returns): shares the modules / weights, adds the static KV cache and
-        the captured step.  Needs `model.model.{embed_tokens, layers, norm}` and `model.lm_head`."""
+        the captured step.  Needs `model.model.{embed_tokens, layers, norm}` and `model.lm_head`.
+        Architectures outside LLAMA_LIKE are refused (Gemma scales embeddings and norms, StableLM uses LayerNorm, ...:
+        the module names match, the arithmetic does not) unless `assume_llama_like` vouches for them; such checkpoints run
+        through `load_quantized_model` + the stock HF `generate`."""
         cfg = model.config
         dev = torch.device(device) if device is not None else next(model.parameters()).device
         self = cls.__new__(cls)
+        mt = getattr(cfg, "model_type", "")
+        if mt not in cls.LLAMA_LIKE and not assume_llama_like:
+            raise NotImplementedError(f"model_type {mt!r}: only {cls.LLAMA_LIKE} are known to have Llama's decoder block "
+                                      "(pass assume_llama_like=True if this one does)")
+        if getattr(cfg, "hidden_act", "silu") != "silu":
+            raise NotImplementedError(f"hidden_act {cfg.hidden_act!r}: the MLP here is SiLU-gated")
+        # the normalisation must be y = x / sqrt(mean(x^2) + eps) * weight: checked on numbers, not on a class name
+        n0 = model.model.layers[0].input_layernorm
+        with torch.no_grad():
+            xt = torch.linspace(-2.0, 3.0, cfg.hidden_size, dtype=torch.float32, device=n0.weight.device)[None]
+            want = xt / torch.sqrt((xt * xt).mean() + cfg.rms_norm_eps) * n0.weight.float()
+            got = n0(xt.to(n0.weight.dtype)).float()
+        if getattr(n0, "bias", None) is not None or not torch.allclose(got, want, rtol=2e-2, atol=2e-2):
+            raise NotImplementedError(f"{type(n0).__name__} is not RMSNorm(x) * weight with eps = rms_norm_eps")
         heads = cfg.num_attention_heads
         rope = getattr(cfg, "rope_theta", None)
         rp = getattr(cfg, "rope_parameters", None) or getattr(cfg, "rope_scaling", None) or {}

@@ -139,10 +139,14 @@ def test_fast_decoder_takes_the_models_rotary_embedding(tmp_path):
         assert margin <= 0.03 * (row.abs().max().item() + 1.0), (t, margin)
     # unsupported options raise instead of decoding something else
     q.config.sliding_window, q.config.layer_types = 16, ["sliding_attention", "chunked_attention"]
-    q.config.model_type = "somethingelse"
+    q.config.model_type = "mistral"
+    with pytest.raises(NotImplementedError):
+        LlamaDecoder.from_hf(q, max_len=48)
+    q.config.model_type = "somethingelse"      # an architecture nobody vouches for
     with pytest.raises(NotImplementedError):
         LlamaDecoder.from_hf(q, max_len=48)
     # ... a window that is never shorter than the context is full attention (Mistral-7B's 4096): same tokens
+    q.config.model_type = "mistral"
     q.config.sliding_window, q.config.layer_types = 48, ["sliding_attention"] * q.config.num_hidden_layers
     dec2 = LlamaDecoder.from_hf(q, max_len=48)
     assert dec2.window == 0 and torch.equal(dec2.generate(10, prompt=prompt), toks)
@@ -203,3 +207,42 @@ def test_fast_decoder_qwen2_architecture_with_qkv_bias(tmp_path):
         _check_prompt(q, dec, prompt)
     toks = dec.generate(8, prompt=prompt)
     assert torch.equal(toks, dec.generate(8, prompt=prompt, use_graph=False))
+
+
+def test_fast_decoder_refuses_blocks_that_are_not_llamas(tmp_path):
+    """module names alone do not make a Llama block: a Gemma-architecture model (scaled embeddings, (1 + w) norms, GELU gate)
+    has the same q / k / v / o / gate / up / down modules and must be refused, not decoded with Llama's arithmetic; a
+    Llama config with biases everywhere (attention_bias, mlp_bias) is served and follows the HF forward"""
+    from transformers import AutoModelForCausalLM, GemmaConfig, LlamaConfig
+    from quip_for_all_amd.quantizer import QuipQuantizer
+    from quip_for_all_amd.decode import LlamaDecoder
+    from quip_for_all_amd.qlinear import QuantLinear
+    cfg = GemmaConfig(hidden_size=256, intermediate_size=688, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, head_dim=64, vocab_size=320, max_position_embeddings=64)
+    model = AutoModelForCausalLM.from_config(cfg, dtype=torch.float16)
+    QuipQuantizer(codebook="E8P12", inference=True, ft_epochs=0).convert_model(model)
+    _fill_random(model, seed=1)
+    model = model.to("cuda:0")
+    with pytest.raises(NotImplementedError):
+        LlamaDecoder.from_hf(model, max_len=32)
+    with pytest.raises(NotImplementedError):     # vouched for, but the norm check still sees (1 + w) / the GELU gate
+        LlamaDecoder.from_hf(model, max_len=32, assume_llama_like=True)
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=688, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                      vocab_size=320, max_position_embeddings=64, tie_word_embeddings=False, attention_bias=True, mlp_bias=True)
+    torch.manual_seed(8)
+    model = AutoModelForCausalLM.from_config(cfg, dtype=torch.float16)
+    QuipQuantizer(codebook="E8P12", inference=True, ft_epochs=0).convert_model(model)
+    _fill_random(model, seed=2)
+    nb = 0
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, QuantLinear):
+                assert m.bias is not None
+                m.bias.copy_(0.3 * torch.randn(m.bias.shape).to(m.bias.dtype))
+                nb += 1
+    assert nb == 14
+    model = model.to("cuda:0").eval()
+    dec = LlamaDecoder.from_hf(model, max_len=64)
+    for prompt in (torch.tensor([5, 17, 3, 99, 42], device="cuda:0"),
+                   torch.randint(0, 320, (40,), generator=torch.Generator().manual_seed(7)).cuda()):
+        _check_prompt(model, dec, prompt)
