@@ -62,6 +62,20 @@ def test_argument_validation_without_gpu(libpath):
     assert L.quip_hadamard_f16(p16, p16, 1, 24, 1.0, None) == -2                      # not a power of two
     assert L.quip_decompress_hi_origorder(p16, p16, 0, 8, None) == 0                  # empty: ok, no launch
     assert L.quip_hi_mm_origorder(p16, p16, p16, 0, 8, 8, None) == 0                  # m == 0: ok
+    # round 3 entry points: the fused tile kernel's codebook modes, the attention launch's window, the D4 table GEMV
+    assert L.quip_e8prvq4_mm_batched(None, p16, p16, 0.3, p16, 40, 64, 64, None) == -1
+    assert L.quip_e8prvq4_mm_batched(p16, p16, None, 0.3, p16, 40, 64, 64, None) == -1
+    assert L.quip_e8prvq3_mm_batched(p16, p16, p16, None, 0.3, p16, 40, 64, 64, None) == -1
+    assert L.quip_d4_mm_batched(p16, p16, p16, p16 + 2, 40, 64, 64, None) == -3          # misaligned y
+    assert L.quip_hi_mm_batched(p16, p16, p16, -1, 64, 64, None) == -2                   # negative m
+    assert L.quip_hi_mm_batched(p16, p16, p16, 0, 64, 64, None) == 0                     # empty: ok, no launch
+    assert L.quip_rope_attn_decode_window_f16(None, p16, p16, p16, p16, p16, p16, p16, p16, 4, 4, 64, 32, 0.125, 8, None, None) == -1
+    assert L.quip_rope_attn_decode_window_f16(p16, p16, p16, p16, p16, p16, p16, p16, p16, 4, 4, 64, 32, 0.125, -1, None, None) == -2
+    vp = (ctypes.c_void_p * 1)(p16)
+    n1 = (ctypes.c_int32 * 1)(8)
+    assert L.quip_d4_gemv_planes_group_ws(vp, vp, None, vp, n1, 1, 128, None, 0, None) == -1
+    assert L.quip_d4_gemv_planes_group_ws(vp, vp, p16, vp, n1, 1, 12, None, 0, None) == -2      # k % 8
+    assert L.quip_d4_gemv_planes_v2(p16, p16, p16, None, 8, 128, None, 0, None) == -1
 
 
 def test_ops_registered_and_fail_loudly_on_cpu(libpath):
