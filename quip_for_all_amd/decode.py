@@ -40,6 +40,7 @@ class LlamaShape:
 
 LLAMA2_7B = LlamaShape()
 LLAMA2_70B = LlamaShape(hidden=8192, ffn=28672, layers=80, heads=64, kv_heads=8)
+LLAMA3_8B = LlamaShape(hidden=4096, ffn=14336, layers=32, heads=32, kv_heads=8, vocab=128256)   # also Mistral-7B's block (vocab 32000)
 SMALL = LlamaShape(hidden=1024, ffn=2816, layers=2, heads=8, kv_heads=4, vocab=1024)   # takes the fused-prologue path
 TINY = LlamaShape(hidden=256, ffn=688, layers=2, heads=4, kv_heads=2, vocab=512)
 
