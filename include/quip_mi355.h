@@ -405,12 +405,6 @@ size_t quip_rope_attn_workspace_bytes(int32_t heads, int32_t head_dim);
 /* Greedy tail of the decode step: tok[0] = first index of the largest of the n fp16 logits (torch.argmax's tie
  * rule), pos[0] += 1 (both int64 on the device) -- one launch instead of reduce + copy + add. */
 int quip_argmax_step_f16(const void* logits, int32_t n, void* tok, void* pos, quip_stream_t stream);
-/* Read-ahead of a code matrix (n_rows rows of row_bytes bytes, row_bytes % 16 == 0) into the memory-side cache, to be launched
- * on a second stream while the transforms between two GEMVs run: of every block of rows_per_block rows the first touch_rows are
- * read (rows_per_block == touch_rows == n_rows: the whole matrix).  Reads only; `sink` (optional, 4 bytes) exists so that the
- * loads cannot be optimised away.  Not a quip_cuda entry point: the reference's launches are serialised by the tracing compiler. */
-int quip_prefetch_codes(const void* qidxs, int64_t row_bytes, int32_t n_rows, int32_t rows_per_block, int32_t touch_rows,
-                        void* sink, quip_stream_t stream);
 int quip_rope_attn_decode_f16(const void* q, const void* k, const void* v, const float* cos,
                               const float* sin, const int64_t* pos, void* kcache, void* vcache,
                               void* out, int32_t heads, int32_t kv_heads, int32_t head_dim,

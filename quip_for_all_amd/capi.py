@@ -40,7 +40,6 @@ SIGNATURES = {
     "quip_d4_gemv_planes_group_ws": [_P, _P, _P, _P, _P, _I32, _I32, _P, _c.c_size_t, _P],
     "quip_e8p_gemv_fused": [_P, _P, _P, _P, _P, _I32, _I32, _P],
     "quip_rope_attn_workspace_bytes": [_I32, _I32],
-    "quip_prefetch_codes": [_P, _I64, _I32, _I32, _I32, _P, _P],
     "quip_argmax_step_f16": [_P, _I32, _P, _P, _P],
     "quip_rope_attn_decode_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _P, _P],
     "quip_rope_attn_decode_window_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _I32, _P, _P],

@@ -428,13 +428,6 @@ int quip_argmax_step_f16(const void* logits, int32_t n, void* tok, void* pos, qu
   return argmax_step_launch(logits, n, tok, pos, (hipStream_t)stream);
 }
 
-int quip_prefetch_codes(const void* qidxs, int64_t row_bytes, int32_t n_rows, int32_t rows_per_block, int32_t touch_rows,
-                        void* sink, quip_stream_t stream) {
-  if (!qidxs) return QUIP_ERR_NULL_POINTER;
-  if (!aligned16(qidxs) || (sink && (reinterpret_cast<uintptr_t>(sink) & 3))) return QUIP_ERR_MISALIGNED;
-  return prefetch_rows_launch(qidxs, row_bytes, n_rows, rows_per_block, touch_rows, sink, (hipStream_t)stream);
-}
-
 int quip_ffn_engine_supported(int32_t hidden, int32_t n_ffn, int32_t K) {
   return ffn_engine_supported(hidden, n_ffn, K) ? 1 : 0;
 }

@@ -421,44 +421,6 @@ __global__ __launch_bounds__(1024) void argmax_step_kernel(const f16* __restrict
 }
 }  // namespace
 
-// Read-ahead of a code matrix into the memory-side cache (256 MB Infinity Cache) while the chip is busy with the transforms
-// between two GEMVs: the codes depend on nothing, the GEMV that streams them a few microseconds later finds them there
-// (tools/l3_prefetch_probe.py: 28672 x 8192 from HBM 15.0 us, behind such a read 12.4).  Runs on a second stream beside the
-// transform launches; touches rows [b * rows_per_block, + touch_rows) of every block b of rows_per_block rows -- the stripes
-// the GEMV's workgroups start with when the window is too short for the whole matrix.  Reads only.
-__global__ __launch_bounds__(256) void prefetch_rows_kernel(const uint4* __restrict__ base, long long row_u4, int n_rows,
-                                                            int rows_per_block, int touch_rows, unsigned* sink) {
-  const int nblocks = (n_rows + rows_per_block - 1) / rows_per_block;
-  uint32_t acc = 0;
-  for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
-    const int r0 = b * rows_per_block;
-    const long long cnt = (long long)min(touch_rows, n_rows - r0) * row_u4;
-    const uint4* p = base + (long long)r0 * row_u4;
-    for (long long i = threadIdx.x; i < cnt; i += 256) {
-      const uint4 v = p[i];
-      acc |= v.x ^ v.y ^ v.z ^ v.w;
-    }
-  }
-  if (acc == 0x9e3779b9u && sink) *sink = acc;   // (keeps the loads; a value the XOR of code words practically never takes)
-}
-
-int prefetch_rows_launch(const void* base, long long row_bytes, int n_rows, int rows_per_block, int touch_rows, void* sink,
-                         hipStream_t stream) {
-  if (n_rows < 1 || rows_per_block < 1 || touch_rows < 1 || row_bytes < 16 || row_bytes % 16 != 0) return QUIP_ERR_BAD_SHAPE;
-  if (touch_rows > rows_per_block) touch_rows = rows_per_block;
-  const int nblocks = (n_rows + rows_per_block - 1) / rows_per_block;
-  // few large blocks (a whole matrix as one block): split it so that every CU reads
-  if (nblocks < 256 && touch_rows == rows_per_block) {
-    const int per = (n_rows + 1023) / 1024;
-    rows_per_block = touch_rows = per < 1 ? 1 : per;
-  }
-  const int nb2 = (n_rows + rows_per_block - 1) / rows_per_block;
-  hipLaunchKernelGGL(prefetch_rows_kernel, dim3(nb2 < 1024 ? nb2 : 1024), dim3(256), 0, stream,
-                     reinterpret_cast<const uint4*>(base), row_bytes / 16, n_rows, rows_per_block, touch_rows,
-                     reinterpret_cast<unsigned*>(sink));
-  return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
-}
-
 int argmax_step_launch(const void* logits, int n, void* tok, void* pos, hipStream_t stream) {
   if (n < 1) return QUIP_ERR_BAD_SHAPE;
   hipLaunchKernelGGL(argmax_step_kernel, dim3(1), dim3(1024), 0, stream, reinterpret_cast<const f16*>(logits), n,

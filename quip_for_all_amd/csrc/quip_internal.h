@@ -169,8 +169,6 @@ int rope_attn_decode_z_launch(const void* const* z, const void* const* post, con
                               int kv_heads, int head_dim, int max_len, float scale, hipStream_t stream,
                               void* workspace, int window = 0);
 int argmax_step_launch(const void* logits, int n, void* tok, void* pos, hipStream_t stream);
-int prefetch_rows_launch(const void* base, long long row_bytes, int n_rows, int rows_per_block, int touch_rows, void* sink,
-                         hipStream_t stream);
 // persistent decode engine, stage 1 (decode_engine.hip): GEMV[gate, up] -> output transforms -> SiLU product ->
 // input transform of down -> GEMV[down] of one decoder block in one launch
 struct FfnEngineArgs {

@@ -212,11 +212,6 @@ class LlamaDecoder:
         self.sampling = None
         self.fused_attention = s.head_dim in (64, 128)
         self.window = int(getattr(self, "window", 0) or 0)    # sliding-window attention: keys (pos - window, pos]; 0 = all
-        import os as _os
-        # read-ahead of the next GEMV's codes on a second stream (stage-wise step only; QUIP_READ_AHEAD=0/1, _ROWS = stripe)
-        self.read_ahead = _os.environ.get("QUIP_READ_AHEAD", "0") == "1"
-        self.read_ahead_rows = int(_os.environ.get("QUIP_READ_AHEAD_ROWS", "48"))
-        self._ra_stream, self._ra_pending = None, False
         from .register_lib import rope_attn_workspace
         self.attn_ws = rope_attn_workspace(s.heads, s.head_dim, self.dev) if self.fused_attention else None
         L0 = self.layers[0]
@@ -373,36 +368,12 @@ class LlamaDecoder:
             h = L["down"].forward_fused(u, gate=g, residual=h)
         return self._head(h)
 
-    def _read_ahead(self, mods, stripe=False):
-        """codes of the NEXT GEMV's matrices into the memory-side cache, on a second stream, while the launches between this
-        point (a GEMV has just been issued) and that GEMV run: the codes depend on nothing (csrc/decode_glue.hip:
-        prefetch_rows_kernel).  stripe: the window is shorter than the matrices -- of every 1/256th of the rows (a GEMV
-        workgroup's share) only the first `read_ahead_rows`.  The side stream joins at the end of the step."""
-        if not self.read_ahead:
-            return
-        from . import capi
-        if self._ra_stream is None:
-            self._ra_stream = torch.cuda.Stream(self.dev)
-        side = self._ra_stream
-        side.wait_stream(torch.cuda.current_stream(self.dev))
-        Lc = capi.lib()
-        with torch.cuda.stream(side):
-            for m in mods:
-                q = m.Qidxs
-                n, row_bytes = q.shape[0], q.shape[1] * q.element_size()
-                rpb = ((n + 255) // 256 + 3) // 4 * 4 if stripe else n
-                touch = min(self.read_ahead_rows, rpb) if stripe else n
-                capi.check(Lc.quip_prefetch_codes(q.data_ptr(), row_bytes, n, rpb, touch, None, side.cuda_stream),
-                           "quip_prefetch_codes")
-        self._ra_pending = True
-
     def _step_fused(self, h, cos, sin, mask):
         """8 launches per block: the GEMV launches of q/k/v, o and gate/up compute their own input
         transform (RMSNorm, SU, Hadamard) and the output transform + residual of the module before
         them (down of the previous block, o) in their prologue."""
         s = self.s
         zd = prev_down = None
-        self._ra_pending = False
         for i, L in enumerate(self.layers):
             qkv = [L["q"], L["k"], L["v"]]
             if zd is None and self.qkv_fused:
@@ -411,7 +382,6 @@ class LlamaDecoder:
                 zs = gemv_group_unfused(qkv, h, rms_weight=L["ln1"], rms_eps=s.rms_eps)
             else:   # finishes the previous block: h += down(...)
                 h, zs = self._zx(qkv, prev_down, zd, h, L["ln1"])
-            self._read_ahead([L["o"]])
             if self.attn_z:
                 # the K = 1 output transforms of q / k / v in the attention launch's prologue: 9 launches per block
                 a = torch.ops.quip_lib.rope_attn_decode_z(
@@ -424,24 +394,16 @@ class LlamaDecoder:
                 _, (zo,) = gemv_fused([L["o"]], x=a.reshape(1, s.hidden))
             else:
                 zo = gemv_unfused(L["o"], a.reshape(1, s.hidden))
-            if not self.ffn_eng:
-                self._read_ahead([L["gate"], L["up"]], stripe=True)
             if self.ffn_eng:
                 h, planes = chain_planes([L["gate"], L["up"]], L["o"], zo, residual=h, rms_weight=L["ln2"],
                                          rms_eps=s.rms_eps)
                 zd = ffn_engine(L["gate"], L["up"], L["down"], planes, self.ffn_ws)
             else:
                 h, zgu = self._zx([L["gate"], L["up"]], L["o"], zo, h, L["ln2"])
-                self._read_ahead([L["down"]])
                 g, u = out_transform_group([L["gate"], L["up"]], zgu)
                 zd = gemv_unfused(L["down"], u, gate=g)
             prev_down = L["down"]
-            if i + 1 < len(self.layers):
-                nx = self.layers[i + 1]
-                self._read_ahead([nx["q"], nx["k"], nx["v"]])
         (h,) = out_transform_group([prev_down], [zd], residual=[h])
-        if self._ra_pending:
-            torch.cuda.current_stream(self.dev).wait_stream(self._ra_stream)
         return self._head(h)
 
     def _zx(self, layers, prev, z, residual, ln):

@@ -22,5 +22,4 @@ for rep in range(3):
         dec.graph.replay()
     torch.cuda.synchronize()
     best = min(best, (time.perf_counter() - t0) / steps)
-print("read_ahead", dec.read_ahead, dec.read_ahead_rows, "tokens", dec.generate(8, first_token=3).tolist())
 print(f"70B E8P12: {1 / best:.2f} tok/s, {best * 1e3:.3f} ms per token, {best * 1e6 / 80:.1f} us per block (incl. head)")
