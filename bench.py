@@ -90,8 +90,10 @@ def gemv_roofline(dec):
     # measured HBM bytes per GEMV launch: the committed PMC pass of THIS workload (tools/prof_bench.sh),
     # one file per model; null when there is none for the model being run
     traffic = traffic_src = None
-    name = "gemv_hbm_traffic.json" if dec.s.hidden == 4096 and dec.s.layers == 32 else \
-        f"gemv_hbm_traffic_h{dec.s.hidden}_l{dec.s.layers}.json"
+    llama2 = dec.s.ffn in (11008, 28672)     # (the committed passes are of the Llama-2 shapes: another ffn / KV width is another workload)
+    name = "gemv_hbm_traffic.json" if dec.s.hidden == 4096 and dec.s.layers == 32 and llama2 else \
+        f"gemv_hbm_traffic_h{dec.s.hidden}_l{dec.s.layers}.json" if llama2 else \
+        f"gemv_hbm_traffic_h{dec.s.hidden}_f{dec.s.ffn}_l{dec.s.layers}.json"
     pf = os.path.join(REPO, "profiles", name)
     if os.path.exists(pf):
         try:
