@@ -505,11 +505,25 @@ typedef struct quip_block_engine_args {
                               * hi.py:41-63; grid_packed_abs = the fp16 (256, 4) table [lo - 7.5, hi - 7.5, 0, 0] of a
                               * code BYTE: the row reads as a D4 row of twice the width) */
   float resid_scale;         /* codebook 2: the residual scale rounded to fp16 (origin_order.cu:337-385), else ignored */
+  int32_t shape;             /* 0: hidden 4096, 32 heads, n_ffn 43 x 256 (Llama-2-7B); 1: hidden 8192, 64 heads on 8 KV heads,
+                              * n_ffn 7 x 4096 (Llama-2-70B; E8P12 only) -- see quip_block_engine_gqa_* below */
 } quip_block_engine_args;
 int quip_block_engine_supported(int32_t hidden, int32_t heads, int32_t kv_heads, int32_t head_dim, int32_t n_ffn, int32_t K);
 size_t quip_block_engine_workspace_bytes(void);
 size_t quip_block_engine_layer_bytes(void);
 int quip_block_engine(const quip_block_engine_args* args, quip_stream_t stream);
+/* shape 1 (grouped-query attention, hidden 8192; csrc/decode_block_gqa.hip): the same call with args->shape = 1, h_in / h_out
+ * fp16 [8192], kcache / vcache fp16 [kv_heads, max_len, 128], its own workspace size, and descriptors of the same 256-byte
+ * layout whose static vectors are stored the way the launch reads them:
+ *   ln[0], ln[1], su of q, k, v, gate, up and sv of o, down:  PERMUTED  p[16 t + k] = v[t + 512 k]  (t < 512, k < 16: the
+ *     strided layout a 512-thread transform of 8192 points leaves its values in);  su of o, down and sv of q, k, v, gate, up: as stored;
+ *   had3 -> float [3][7][8]: rows of gate.had_right, up.had_right and of down.had_left TRANSPOSED (7 x 7, padded to 8);
+ *   sc[i] = wscale_float / sqrt(8192) (down: / 64).
+ * One weight stream per wave runs through the whole launch (a ring of nine 2 KB requests always ahead of the products);
+ * 7 workgroups own the 4096-point chunks of the MLP edge; from 128 positions on the four workgroups of a head share its
+ * attention.  Same liveness rules as shape 0 (256 resident workgroups, bounded waits, workspace word 1). */
+int quip_block_engine_gqa_supported(int32_t hidden, int32_t heads, int32_t kv_heads, int32_t head_dim, int32_t n_ffn, int32_t K);
+size_t quip_block_engine_gqa_workspace_bytes(void);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,8 @@ SIGNATURES = {
     "quip_block_engine_workspace_bytes": [],
     "quip_block_engine_layer_bytes": [],
     "quip_block_engine": [_P, _P],
+    "quip_block_engine_gqa_supported": [_I32, _I32, _I32, _I32, _I32, _I32],
+    "quip_block_engine_gqa_workspace_bytes": [],
     "quip_e8p_gemv_kernel_choice": [_P, _I32, _I32],
     "quip_ffn_engine_supported": [_I32, _I32, _I32],
     "quip_ffn_engine_workspace_bytes": [_I32, _I32],
@@ -121,7 +123,8 @@ class BlockEngineArgs(_c.Structure):
     """mirror of quip_block_engine_args (include/quip_mi355.h)"""
     _fields_ = [("layers", _P), ("h_in", _P), ("h_out", _P), ("pos", _P), ("cos", _P), ("sin", _P),
                 ("grid_packed_abs", _P), ("workspace", _P), ("dbg", _P), ("n_layers", _I32), ("max_len", _I32),
-                ("dbg_layer", _I32), ("rms_eps", _F), ("attn_scale", _F), ("codebook", _I32), ("resid_scale", _F)]
+                ("dbg_layer", _I32), ("rms_eps", _F), ("attn_scale", _F), ("codebook", _I32), ("resid_scale", _F),
+                ("shape", _I32)]
 
 
 class HadFusion(_c.Structure):

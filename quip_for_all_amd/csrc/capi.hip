@@ -476,8 +476,15 @@ int quip_block_engine(const quip_block_engine_args* in, quip_stream_t stream) {
   a.grid = in->grid_packed_abs; a.workspace = in->workspace; a.dbg = in->dbg;
   a.n_layers = in->n_layers; a.max_len = in->max_len; a.dbg_layer = in->dbg_layer;
   a.rms_eps = in->rms_eps; a.attn_scale = in->attn_scale; a.codebook = in->codebook; a.resid_scale = in->resid_scale;
+  if (in->shape == 1) return block_engine_gqa_launch(a, (hipStream_t)stream);
+  if (in->shape != 0) return QUIP_ERR_UNSUPPORTED;
   return block_engine_launch(a, (hipStream_t)stream);
 }
+
+int quip_block_engine_gqa_supported(int32_t hidden, int32_t heads, int32_t kv_heads, int32_t head_dim, int32_t n_ffn, int32_t K) {
+  return block_engine_gqa_supported(hidden, heads, kv_heads, head_dim, n_ffn, K) ? 1 : 0;
+}
+size_t quip_block_engine_gqa_workspace_bytes(void) { return block_engine_gqa_workspace_bytes(); }
 
 size_t quip_rope_attn_workspace_bytes(int32_t heads, int32_t head_dim) {
   return heads > 0 && head_dim > 0 ? rope_attn_workspace_bytes(heads, head_dim) : 0;

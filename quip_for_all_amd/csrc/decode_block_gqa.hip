@@ -1,0 +1,1082 @@
+// Persistent decode engine for gfx950, stage 2 for the grouped-query 8192-wide shape (Llama-2-70B: hidden 8192, 64 heads of
+// 128 on 8 KV heads, n_ffn = 7 x 4096): all decoder blocks of a token (bs = 1) in ONE launch.  Same contract as
+// decode_block.hip (the HF LlamaDecoderLayer of the reference's metric driver, example_generate.py:28-33, every projection a
+// QuantLinear, qlinear.py:87-115; reference kernel for the products: origin_order.cu:388-555 at m = 1), a different
+// machine inside, because a block of this shape streams 214 MB of codes (836 KB per CU) instead of 51 MB:
+//
+//   * ONE weight stream per wave for the whole launch: the 54 items (16 rows x 512 k = 2 KB of codes) a wave multiplies per
+//     block form a fixed sequence -- o (4), gate / up (28), down (14), 2 fillers, the NEXT block's q (4) and k | v (2) --
+//     that runs through a ring of 9 register slots.  Consuming item s requests item s + 9 into the same slot, so 9 items
+//     (18 KB per wave, 147 KB per CU) are always requested ahead, across products, hand-offs and blocks, and "slot s has
+//     landed" is the constant `s_waitcnt vmcnt(16)`.  The queue is empty after every hand-off's gather (its polls drain
+//     it), in particular at the block loop's back edge, where the compiler is free to copy registers.
+//   * Row ownership: q / o / down rows [32 w, +32) (two row blocks); k | v: row block w >> 1 of the stacked [k; v] rows
+//     on the odd workgroups; gate / up rows k * 4096 + 16 w + i, k < 7 (seven row blocks: COLUMNS [16 w, +16) of the
+//     (7, 4096) view, so the 7 x 7 mix of the output transform is local to the workgroup).
+//   * 8192-point transforms on 512 threads x 16 elements with one LDS exchange, in two directions (fht_wg512x.hip.h):
+//     gather (natural order) -> fwd -> residual / RMSNorm / SU in the strided layout (the static vectors are stored
+//     pre-permuted by the host) -> rev -> digit planes as 16-byte pieces.
+//   * The MLP edge (28672 = 7 x 4096): column-local 7 x 7 mix of z_gate / z_up -> hand-off to 7 chunk owners, which run
+//     the 4096-point transforms of their chunk of gate and up, SV, SiLU product, SU and down's 4096-point transform ->
+//     hand-off of the 7 x 4096 rows to everybody, where the 7 x 7 mix of down's input side and the digit planes happen
+//     on the fly (block exponent from the owners' maxima: a bound, known before the rows are swept).
+//   * Grouped-query attention: head h on workgroup 4 h (the owner of its first rows); from 128 positions on the four
+//     workgroups of a head take every fourth position each and merge their softmax states through one more hand-off.
+//
+// Hand-off protocol, liveness, error word: engine_sync.hip.h / decode_block.hip.  E8P12 (16 copies of both tables: 64 KB
+// of tables + 84 KB of planes of down's input fill the LDS).
+#include "e8p_gemv_core.hip.h"
+#include "engine_sync.hip.h"
+#include "fht_wg512x.hip.h"
+#include <utility>
+
+namespace quip {
+
+namespace {
+
+using esync::u32x2_t;
+using esync::u32x4_t;
+
+// one decoder block as the kernel reads it (256 bytes; same field order as decode_block.hip's descriptor)
+struct GLayer {
+  const uint4* W[7];       // Qidxs of q, k, v, o, gate, up, down
+  const f16* ln[2];        // RMSNorm weights, PERMUTED: p[16 t + k] = w[t + 512 k]
+  const f16* su[7];        // SU: q, k, v, gate, up permuted; o, down natural
+  const f16* sv[7];        // SV: o, down permuted; q, k, v, gate, up natural
+  const float* mix;        // fp32 [3][7][8]: gate.had_right, up.had_right (rows), down.had_left TRANSPOSED (rows)
+  f16* kcache;             // [kv_heads, max_len, 128]
+  f16* vcache;
+  float sc[7];             // wscale_float / sqrt(L_in): L_in = 8192 (q k v o gate up), 4096 (down)
+  float pad_[5];
+};
+static_assert(sizeof(GLayer) == 256, "layer descriptor layout");
+
+struct GArgs {
+  const GLayer* layers;
+  const f16* h_in;         // [8192] natural order
+  f16* h_out;
+  const int64_t* pos;
+  const float* cos;        // [max_len, 128]
+  const float* sin;
+  const uint64_t* grid;
+  char* ws;
+  uint64_t* dbg;
+  int n_layers, max_len, dbg_layer;
+  float rms_eps, attn_scale;
+};
+
+constexpr int kWaves = 8, kThreads = 512, NWG = 256, HD = 128;
+constexpr int HID = 8192, NH = 64, NKV = 8, GQ = NH / NKV;
+constexpr int FK = 7, FL = 4096, NFFN = FK * FL;
+constexpr int EPT = HID / kThreads;                 // 16 elements per thread
+constexpr int kRowH = HID / 4, kRowF = NFFN / 4;    // bytes of a weight row (hidden- / ffn-wide input)
+constexpr int NS = 9, NSEQ = 54;                    // ring slots, items per wave and block
+// item sequence of an iteration: [0, 4) o | [4, 32) gate / up | [32, 46) down | 46, 47 fillers | [48, 52) q | 52, 53 k | v
+constexpr int SQ_O = 0, SQ_GU = 4, SQ_D = 32, SQ_F = 46, SQ_Q = 48, SQ_KV = 52;
+static_assert(NSEQ % NS == 0, "the ring position of an item is the same in every block");
+constexpr float kOutScaleH = 0.011048543456039806f;  // 1 / sqrt(8192)
+constexpr int kParts = 4, kPartGran = 132, kSplitPos = 128;
+
+// workspace (bytes)
+constexpr size_t kWsCtl = 0;
+constexpr size_t kWsZq = 64, kWsZk = kWsZq + (HID / 2) * 8, kWsZv = kWsZk + (NKV * HD / 2) * 8;
+constexpr size_t kWsA = kWsZv + (NKV * HD / 2) * 8, kWsZo = kWsA + (HID / 2) * 8, kWsZd = kWsZo + (HID / 2) * 8;
+constexpr size_t kWsInbox = kWsZd + (HID / 2) * 8;                    // [FK][2][FL] granules (fp32 payload)
+constexpr size_t kWsRows = kWsInbox + (size_t)FK * 2 * FL * 8;        // [FK][FL] granules (fp16 hi | lo << 16)
+constexpr size_t kWsRowMax = kWsRows + (size_t)FK * FL * 8;           // [8] granules
+constexpr size_t kWsPart = kWsRowMax + 64;                            // [NH][kParts][132]
+constexpr size_t kWsBytes = kWsPart + (size_t)NH * kParts * kPartGran * 8;
+
+struct GLds {
+  using T = Lds<16>;
+  static constexpr int kAcc = T::kAcc;                       // int32 [336][4]: q 0 | kv 32 | o 48 | gate, up 80 | down 304
+  static constexpr int kAccRows = 336;
+  static constexpr int AQ = 0, AKV = 32, AO = 48, AGU = 80, AD = 304;
+  static constexpr int kZcol = kAcc + kAccRows * 16;         // float [224]
+  static constexpr int kRed = kZcol + 224 * 4;               // float [64], int [8]
+  static constexpr int kDesc = kRed + 256 + 32;              // two descriptors
+  static constexpr int kQkv = kDesc + 512;                   // fp16 [4][128]: q, k, v of this head; attention output
+  static constexpr int kCs = kQkv + 4 * HD * 2;              // float [2][128]
+  static constexpr int kMix = kCs + 2 * HD * 4;              // float [3][7][8]
+  static constexpr int kArea = kMix + 3 * 7 * 8 * 4;
+  static constexpr int kAreaBytes = (160 * 1024 - kArea) & ~15;
+  static constexpr int PSH = HID + 16, PSD = NFFN + 16;      // plane strides (16 bytes off a multiple of 256: the three planes of an A fragment on different banks)
+  static constexpr int kBufBytes = hadw::Geo<13>::kBufFloats * 4;
+  static constexpr int kBytes = kArea + kAreaBytes;
+  static_assert(kAreaBytes >= 3 * PSD && kAreaBytes >= 2 * kBufBytes && kAreaBytes >= 2 * 3 * PSH, "transient area");
+  static_assert(kArea % 16 == 0, "alignment");
+};
+static_assert(GLds::kBytes <= 160 * 1024, "LDS budget");
+
+template <int I> using IC = std::integral_constant<int, I>;
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(IC<Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+__global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using B = GLds;
+  using T = Lds<16>;
+  int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w = blockIdx.x;
+  int n = lane & 15, q = lane >> 4;
+  uint32_t* ctl = reinterpret_cast<uint32_t*>(a.ws + kWsCtl);
+  uint64_t* zq = reinterpret_cast<uint64_t*>(a.ws + kWsZq);
+  uint64_t* zk = reinterpret_cast<uint64_t*>(a.ws + kWsZk);
+  uint64_t* zv = reinterpret_cast<uint64_t*>(a.ws + kWsZv);
+  uint64_t* za = reinterpret_cast<uint64_t*>(a.ws + kWsA);
+  uint64_t* zo = reinterpret_cast<uint64_t*>(a.ws + kWsZo);
+  uint64_t* zd = reinterpret_cast<uint64_t*>(a.ws + kWsZd);
+  uint64_t* inbox = reinterpret_cast<uint64_t*>(a.ws + kWsInbox);
+  uint64_t* frow = reinterpret_cast<uint64_t*>(a.ws + kWsRows);
+  uint64_t* rowmax = reinterpret_cast<uint64_t*>(a.ws + kWsRowMax);
+  uint64_t* pbuf = reinterpret_cast<uint64_t*>(a.ws + kWsPart);
+  int dbg_on = 0;
+#define BSTAMP(i) do { if (dbg_on && tid == 0) a.dbg[w * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+
+  // this workgroup's k | v row block (odd workgroups): block kvb of the stacked [k; v] row blocks
+  const bool has_kv = (w & 1) != 0;
+  const int kvb = w >> 1, kvm = kvb >> 6;                  // kvm: 0 = k, 1 = v
+
+  // ---- the weight ring ----------------------------------------------------------------------------------------------
+  u32x4 qa[NS], qb[NS];
+  uint32_t vo_h, vo_kv, vo_gu, vo_d, vo_hot;
+  uint32_t lane_c, lane_c2;
+  auto rederive = [&]() __attribute__((always_inline)) {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    tid = t; lane = t & 63; n = lane & 15; q = lane >> 4;
+    vo_h = (uint32_t)((32 * w + n) * kRowH + (wave * 8 + q) * 16);
+    vo_kv = has_kv ? (uint32_t)((16 * (kvb & 63) + n) * kRowH + (wave * 8 + q) * 16) : (uint32_t)((lane & 31) * 16);
+    vo_gu = (uint32_t)((16 * w + n) * kRowH + (wave * 8 + q) * 16);
+    vo_d = (uint32_t)((32 * w + n) * kRowF + (wave * 8 + q) * 16);
+    vo_hot = (uint32_t)((lane & 31) * 16);     // (the hot 2 KB: offsets < 496 + 1024 + 80)
+    lane_c = (((uint32_t)lane & 15u) << 3) | (uint32_t)T::kT1;
+    lane_c2 = (((uint32_t)lane & 15u) << 3) | (uint32_t)T::kT2;
+  };
+  rederive();
+  // uniform matrix bases of the stream: this block's o, gate, up, down; the next block's q, k | v, o; a hot 2 KB
+  const uint4 *pw_o, *pw_g, *pw_u, *pw_d, *pw_q, *pw_kv, *pw_o2, *pw_hot;
+  auto uni = [](const void* p) -> const uint4* {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return reinterpret_cast<const uint4*>(((uint64_t)hi << 32) | lo);
+  };
+  pw_hot = uni(a.grid);
+  // request item T of the sequence (T >= NSEQ: item T - NSEQ of the next iteration) into ring slot T % NS
+  auto issue = [&](auto t_c) __attribute__((always_inline)) {
+    constexpr int TT = decltype(t_c)::value, t = TT % NSEQ, slot = TT % NS;
+    constexpr bool wrap = TT >= NSEQ;
+    const uint4* base;
+    uint32_t vo;
+    constexpr int u_gu = t - SQ_GU, u_d = t - SQ_D, u_q = t - SQ_Q;
+    constexpr int off = t < SQ_GU ? (t & 1) * 16 * kRowH
+                        : t < SQ_D ? (u_gu % 7) * FL * kRowH
+                        : t < SQ_F ? (u_d & 1) * 16 * kRowF + ((u_d >> 1) >= 4 ? 4096 : 0)
+                        : t < SQ_Q ? 0
+                        : t < SQ_KV ? (u_q & 1) * 16 * kRowH : 0;
+    constexpr int imm = t < SQ_GU ? (t >> 1) * 1024
+                        : t < SQ_D ? ((u_gu / 7) >> 1) * 1024
+                        : t < SQ_F ? ((u_d >> 1) & 3) * 1024
+                        : t < SQ_Q ? 0
+                        : t < SQ_KV ? (u_q >> 1) * 1024 : (t - SQ_KV) * 1024;
+    // (a wrapped request comes from the tail of an iteration: items 0..2 -- requested by down's last item and the fillers --
+    //  belong to the NEXT block, items 3..8 -- requested by q and k | v at the top of the iteration -- to this one)
+    if constexpr (t < SQ_GU) { base = (wrap && t < 3) ? pw_o2 : pw_o; vo = vo_h; }
+    else if constexpr (t < SQ_D) { base = ((u_gu / 7) & 1) ? pw_u : pw_g; vo = vo_gu; }
+    else if constexpr (t < SQ_F) { base = pw_d; vo = vo_d; }
+    else if constexpr (t < SQ_Q) { base = pw_hot; vo = vo_hot; }
+    else if constexpr (t < SQ_KV) { base = pw_q; vo = vo_h; }
+    else { base = pw_kv; vo = vo_kv; }
+    static_assert(!wrap || t < SQ_GU + 7, "a wrapped request stays inside o / gate");
+    const uint4* bo = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + off);
+    // s_nop: a scalar base fresh from v_readfirstlane / v_readlane needs 5 wait states before a VMEM instruction reads it,
+    // and the compiler pads nothing inside an asm statement
+    u32x4& da = qa[slot];                              // (named here: an asm operand alone does not capture in a generic lambda)
+    u32x4& db = qb[slot];
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(da) : "v"(vo), "s"(bo), "n"(imm) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(db) : "v"(vo), "s"(bo), "n"(imm + 64) : "memory");
+  };
+  // after a drain every slot is a plain register again
+  auto own_ring = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { esync::own(qa[s]); esync::own(qb[s]); }
+  };
+  int* accs = reinterpret_cast<int*>(smem + B::kAcc);
+  auto add_rows = [&](const i32x4& r, int accrow) __attribute__((always_inline)) {
+    if (q == 0) {
+      int* dst = accs + (accrow + n) * 4;
+      __hip_atomic_fetch_add(dst + 0, r.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(dst + 1, r.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(dst + 2, r.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  };
+  // item S of the sequence: wait for its slot, turn the codes into table addresses, refill the slot with item S + NS,
+  // multiply (A: the digit fragments of the item's K slice, shared by the items of a group); live = false: a filler
+  auto consume = [&](auto s_c, const i32x4 (&A)[8], i32x4& acc, bool live) {
+    constexpr int S = decltype(s_c)::value, slot = S % NS;
+    u32x4& da = qa[slot];
+    u32x4& db = qb[slot];
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(da), "+v"(db) : "n"(2 * (NS - 1)) : "memory");
+    ItemAddr ad;
+    if (live) {
+      item_addresses<16>(da, db, lane_c, lane_c2, ad, 0u);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) asm volatile("" : "+v"(ad.a1l[t]), "+v"(ad.a2l[t]), "+v"(ad.a1h[t]), "+v"(ad.a2h[t]));
+    }
+    issue(IC<S + NS>{});
+    if (live) {
+      constexpr int PIPE = QUIP_GEMV_PIPE;
+      uint2 o[8][4];
+      auto lk = [&](int t) {
+        o[t][0] = lds_read8(ad.a1l[t]); o[t][1] = lds_read8(ad.a2l[t]);
+        o[t][2] = lds_read8(ad.a1h[t]); o[t][3] = lds_read8(ad.a2h[t]);
+      };
+#pragma unroll
+      for (int t = 0; t < PIPE; ++t) lk(t);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        if (t + PIPE < 8) lk(t + PIPE);
+        const i32x4 Bf = {(int)(o[t][0].x ^ o[t][1].x), (int)(o[t][0].y ^ o[t][1].y), (int)(o[t][2].x ^ o[t][3].x),
+                          (int)(o[t][2].y ^ o[t][3].y)};
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t], Bf, acc, 0, 0, 0);
+      }
+    }
+  };
+  // CNT consecutive items that multiply the same K slice (A fragments at xa) into accumulator rows accrow0 + 16 c
+  auto group = [&](auto s0_c, auto cnt_c, uint32_t xa, int accrow0) __attribute__((always_inline)) {
+    constexpr int S0 = decltype(s0_c)::value, CNT = decltype(cnt_c)::value;
+    i32x4 A[8];
+    item_fragments(xa, A);
+    static_for<CNT>([&](auto c) {
+      constexpr int C = decltype(c)::value;
+      i32x4 acc = {0, 0, 0, 0};
+      consume(IC<S0 + C>{}, A, acc, true);
+      add_rows(acc, accrow0 + 16 * C);
+    });
+  };
+
+  // ---- prologue -----------------------------------------------------------------------------------------------------
+  GLayer* desc = reinterpret_cast<GLayer*>(smem + B::kDesc);
+  u32x2 tsrc;
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(tsrc) : "v"(table_source_ptr(a.grid, lane, wave)) : "memory");
+  uint32_t gen;
+  esync::ld4(gen, ctl);
+  asm volatile("s_waitcnt vmcnt(1)" : "+v"(tsrc) : : "memory");
+  fill_tables_from_lane<16>(smem, tsrc, lane, wave);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(gen) : : "memory");
+  const uint32_t ebase = ((uint32_t)__builtin_amdgcn_readfirstlane((int)gen) + 1u) << 10;
+  for (int i = tid; i < B::kAccRows * 4; i += kThreads) accs[i] = 0;
+  if (tid < 64) reinterpret_cast<uint32_t*>(desc)[tid] = reinterpret_cast<const uint32_t*>(a.layers)[tid];
+  const long long pos64 = *a.pos;
+  const bool pos_ok = pos64 >= 0 && pos64 < (long long)a.max_len;
+  const int pos = pos_ok ? (int)pos64 : 0;
+  if (tid < 2 * HD)
+    reinterpret_cast<float*>(smem + B::kCs)[tid] = (tid < HD ? a.cos : a.sin - HD)[(size_t)pos * HD + tid];
+  // the residual stream, strided layout: this thread's h[t + 512 k], k < 16, as 8 fp16 pairs (registers for the whole launch:
+  // the LDS holds tables and planes)
+  uint32_t hreg[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const f16 lo = a.h_in[tid + 512 * (2 * j)], hi = a.h_in[tid + 512 * (2 * j + 1)];
+    hreg[j] = (uint32_t)__builtin_bit_cast(uint16_t, lo) | ((uint32_t)__builtin_bit_cast(uint16_t, hi) << 16);
+  }
+  had::wg_barrier<false>();                          // (a full fence: nothing counted is in flight yet)
+  uint32_t hop = 0;
+
+  float* red = reinterpret_cast<float*>(smem + B::kRed);
+  int* shs = reinterpret_cast<int*>(smem + B::kRed + 256);
+  float* xbuf = reinterpret_cast<float*>(smem + B::kArea);
+
+  // bases of the stream for the block whose descriptor sits in slot `cur` (o, gate, up, down) and the one in slot `nxt`
+  auto set_bases = [&](const GLayer& C, const GLayer& N) __attribute__((always_inline)) {
+    pw_o = uni(C.W[3]); pw_g = uni(C.W[4]); pw_u = uni(C.W[5]); pw_d = uni(C.W[6]);
+    pw_q = uni(N.W[0]); pw_kv = has_kv ? uni(N.W[1 + kvm]) : pw_hot; pw_o2 = uni(N.W[3]);
+  };
+  set_bases(desc[0], desc[0]);
+  // the ring's first nine items: q and k | v of block 0, its first three o items
+  issue(IC<SQ_Q>{}); issue(IC<SQ_Q + 1>{}); issue(IC<SQ_Q + 2>{}); issue(IC<SQ_Q + 3>{});
+  issue(IC<SQ_KV>{}); issue(IC<SQ_KV + 1>{});
+  issue(IC<NSEQ>{}); issue(IC<NSEQ + 1>{}); issue(IC<NSEQ + 2>{});
+
+  // ---- all-gather of an 8192-vector (4096 granules {2 x fp16, tag}): thread t takes elements [16 t, +16) ----------------
+  auto gather16 = [&](const uint64_t* vec, uint32_t tag, uint32_t code, float (&out)[16]) {
+    u32x4_t p[4];
+    uint32_t spins = 0;
+    const uint64_t* src = vec + 8 * tid;
+    for (;;) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) esync::ld16(p[j], src + 2 * j);
+      esync::drain();
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        esync::own(p[j]);
+        ok = ok && p[j].y == tag && p[j].w == tag;
+      }
+      if (esync::spin_step(ok, spins, ctl + 1, code + (uint32_t)w)) break;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f16x2 h0 = as_f16x2(p[j].x), h1 = as_f16x2(p[j].z);
+      out[4 * j] = (float)h0.x; out[4 * j + 1] = (float)h0.y; out[4 * j + 2] = (float)h1.x; out[4 * j + 3] = (float)h1.y;
+    }
+    own_ring();
+  };
+  // 16 fp16 of a permuted / natural vector at p + 16 t -> floats
+  auto load16 = [&](const f16* p, u32x4 (&v)[2]) {
+    v[0] = *reinterpret_cast<const u32x4*>(p + 16 * tid);
+    v[1] = *reinterpret_cast<const u32x4*>(p + 16 * tid + 8);
+  };
+  auto unpack16 = [](const u32x4 (&v)[2], float (&o)[16]) {
+    had::unpack8(make_uint4(v[0].x, v[0].y, v[0].z, v[0].w), o);
+    had::unpack8(make_uint4(v[1].x, v[1].y, v[1].z, v[1].w), o + 8);
+  };
+  // rows [row0, row0 + 2 cnt) of the accumulators (block exponent sh) -> cnt granules starting at gran
+  auto publish = [&](uint64_t* vec, int gran, int row0, int cnt, int sh, uint32_t tag) __attribute__((always_inline)) {
+    if (tid < cnt) {
+      const int* s3 = accs + (row0 + 2 * tid) * 4;
+      const float us = unscale_of(sh, 2);
+      const float f0 = __builtin_fmaf((float)s3[0], 65536.f, __builtin_fmaf((float)s3[1], 256.f, (float)s3[2]));
+      const float f1 = __builtin_fmaf((float)s3[4], 65536.f, __builtin_fmaf((float)s3[5], 256.f, (float)s3[6]));
+      esync::st_granule(vec + gran + tid, pack_f16(f0 * us, f1 * us), tag);
+    }
+  };
+  auto zero_acc = [&](int row0, int rows) __attribute__((always_inline)) {
+    for (int i = tid; i < rows * 4; i += kThreads) accs[row0 * 4 + i] = 0;
+  };
+  // digit planes of a transformed vector held in natural order (16 consecutive values per thread): three 16-byte pieces
+  auto planes_nat = [&](const float (&v)[16], float scale, int sh, uint32_t base) {
+    uint4 out[3];
+    had::planes16(v, scale, sh, out);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) *reinterpret_cast<uint4*>(smem + base + d * B::PSH + 16 * tid) = out[d];
+  };
+  // the same from the strided layout (values X[t + 512 k]): bytes
+  auto planes_str = [&](const float (&v)[16], float scale, int sh, uint32_t base) {
+#pragma clang fp contract(off)
+    const float s2 = had::fmul(scale, as_f32((uint32_t)(sh + 127) << 23));
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int X = (int)__builtin_rintf(v[k] * s2);
+      const int X1 = (X + 128) >> 8;
+      const int H = (X1 + 128) >> 8;
+      uint8_t* p = reinterpret_cast<uint8_t*>(smem + base) + tid + 512 * k;
+      p[0] = (uint8_t)H;
+      p[B::PSH] = (uint8_t)X1;
+      p[2 * B::PSH] = (uint8_t)X;
+    }
+  };
+  auto wg_max = [&](float mx) __attribute__((always_inline)) {
+    mx = had::wave_reduce_to_lane63<true>(mx);
+    had::wg_barrier<true>();
+    if (lane == 63) red[16 + wave] = mx;
+    had::wg_barrier<true>();
+    float r = red[16];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) r = fmaxf(r, red[16 + i]);
+    return r;
+  };
+
+  // ---- an 8192-wide edge: output side of the producer (+ residual) and the input transforms of up to two consumers ------
+  //   zvec: gather z (hand-off `tag`), h += SV_prev (.) H z / sqrt(8192)                  [qlinear.py:106-114 of the producer]
+  //   NC consumers (0 | 2; `two` false: only consumer 0): planes_i = digits( sc_i rms(h) H (h (.) ln (.) su_i) )
+  //   [RMSNorm + qlinear.py:90-100]; planes of consumer i at area + i * 3 * PSH, block exponent in shs[sh0 + i]
+  // sv_prev, ln, su0, su1: permuted vectors.
+  auto edge = [&](auto nc_tag, const uint64_t* zvec, uint32_t tag, uint32_t code, const f16* sv_prev, const f16* ln, const f16* su0,
+                  const f16* su1, float sc0, float sc1, bool two, int sh0, int sb) __attribute__((always_inline)) {
+#define ESTAMP(i) do { if (sb >= 0) BSTAMP(sb + (i)); } while (0)
+    constexpr int NC = decltype(nc_tag)::value;
+    u32x4 psv[2], pln[2], ps0[2], ps1[2];
+    if (zvec) load16(sv_prev, psv);
+    if (NC > 0) {
+      load16(ln, pln);
+      load16(su0, ps0);
+      load16(two ? su1 : su0, ps1);
+    }
+    if (zvec) {
+      float v[1][16];
+      gather16(zvec, tag, code, v[0]);
+      asm volatile("" : "+v"(psv[0]), "+v"(psv[1]));
+      if (NC > 0) asm volatile("" : "+v"(pln[0]), "+v"(pln[1]), "+v"(ps0[0]), "+v"(ps0[1]), "+v"(ps1[0]), "+v"(ps1[1]));
+      ESTAMP(0);
+      hadw::fwd<13, 1, true>(v, xbuf, tid);
+      ESTAMP(1);
+      float svf[16];
+      unpack16(psv, svf);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const f16x2 hh = as_f16x2(hreg[j]);
+        const f16 n0 = had::out_elem(v[0][2 * j], kOutScaleH, true, svf[2 * j], false, 0.f, true, (float)hh.x);
+        const f16 n1 = had::out_elem(v[0][2 * j + 1], kOutScaleH, true, svf[2 * j + 1], false, 0.f, true, (float)hh.y);
+        hreg[j] = (uint32_t)__builtin_bit_cast(uint16_t, n0) | ((uint32_t)__builtin_bit_cast(uint16_t, n1) << 16);
+      }
+    }
+    if constexpr (NC > 0) {
+      float e[16];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const f16x2 hh = as_f16x2(hreg[j]);
+        e[2 * j] = (float)hh.x;
+        e[2 * j + 1] = (float)hh.y;
+      }
+      const float tot = hadw::sumsq<16, true>(e, red, tid);
+      ESTAMP(2);
+      {
+        float lnf[16];
+        unpack16(pln, lnf);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) e[k] = had::fmul(e[k], lnf[k]);
+      }
+      if (two) {
+        float v[2][16], s0f[16], s1f[16];
+        unpack16(ps0, s0f);
+        unpack16(ps1, s1f);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { v[0][k] = had::fmul(e[k], s0f[k]); v[1][k] = had::fmul(e[k], s1f[k]); }
+        hadw::rev<13, 2, true>(v, xbuf, tid);
+        ESTAMP(3);
+        float mx0 = had::wave_reduce_to_lane63<true>(hadw::absmax<16>(v[0], 1.f));
+        float mx1 = had::wave_reduce_to_lane63<true>(hadw::absmax<16>(v[1], 1.f));
+        had::wg_barrier<true>();
+        if (lane == 63) { red[16 + wave] = mx0; red[24 + wave] = mx1; }
+        had::wg_barrier<true>();
+        mx0 = red[16]; mx1 = red[24];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) { mx0 = fmaxf(mx0, red[16 + i]); mx1 = fmaxf(mx1, red[24 + i]); }
+        const float s0 = had::rms_scale(sc0, tot, HID, a.rms_eps), s1 = had::rms_scale(sc1, tot, HID, a.rms_eps);
+        const int h0 = had::shift_for(had::fmul(mx0, fabsf(s0))), h1 = had::shift_for(had::fmul(mx1, fabsf(s1)));
+        planes_nat(v[0], s0, h0, (uint32_t)B::kArea);
+        planes_nat(v[1], s1, h1, (uint32_t)(B::kArea + 3 * B::PSH));
+        if (tid == 0) { shs[sh0] = h0; shs[sh0 + 1] = h1; }
+      } else {
+        float v[1][16], s0f[16];
+        unpack16(ps0, s0f);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[0][k] = had::fmul(e[k], s0f[k]);
+        hadw::rev<13, 1, true>(v, xbuf, tid);
+        ESTAMP(3);
+        const float mx0 = wg_max(hadw::absmax<16>(v[0], 1.f));
+        const float s0 = had::rms_scale(sc0, tot, HID, a.rms_eps);
+        const int h0 = had::shift_for(had::fmul(mx0, fabsf(s0)));
+        planes_nat(v[0], s0, h0, (uint32_t)B::kArea);
+        if (tid == 0) shs[sh0] = h0;
+      }
+      had::wg_barrier<true>();
+      ESTAMP(4);
+    }
+#undef ESTAMP
+  };
+  // A fragment address of this lane for K slice (wave + 8 i) of the planes at `base` (plane stride ps)
+  auto xaddr = [&](uint32_t base, int ps, int i) -> uint32_t __attribute__((always_inline)) {
+    return base + (uint32_t)min(n, 2) * (uint32_t)ps + (uint32_t)q * 64u + (uint32_t)(wave + 8 * i) * 512u;
+  };
+
+  had::wg_barrier<true>();
+  const f16* sv_prev = nullptr;                      // SV of the previous block's down_proj (permuted)
+  for (int l = 0; l < a.n_layers; ++l) {
+    dbg_on = a.dbg != nullptr && l == a.dbg_layer;
+    rederive();
+    BSTAMP(0);
+    const GLayer& Ld = desc[l & 1];
+    const GLayer& Ln = desc[(l + 1) & 1];
+    {
+      // the next block's descriptor (the last block: its own once more -- requests beyond the end re-read its rows)
+      const int ln_ = l + 1 < a.n_layers ? l + 1 : l;
+      if (tid < 64) reinterpret_cast<uint32_t*>(&desc[(l + 1) & 1])[tid] = reinterpret_cast<const uint32_t*>(a.layers + ln_)[tid];
+      if (tid >= 64 && tid < 64 + 3 * 7 * 8) reinterpret_cast<float*>(smem + B::kMix)[tid - 64] = Ld.mix[tid - 64];
+      had::wg_barrier<false>();
+      set_bases(Ld, Ln);
+    }
+    // ================= P1: output side of the previous block's down_proj + residual (block 0: h = the embedding row), RMSNorm,
+    // input transforms of q and k | v; their products; hand-off ==============================================================
+    edge(IC<2>{}, l > 0 ? zd : nullptr, ebase | hop, 0x4000u, sv_prev, Ld.ln[0], Ld.su[0], Ld.su[1 + kvm], Ld.sc[0], Ld.sc[1 + kvm], has_kv, 0, 18);
+    BSTAMP(2);
+    rederive();
+    {
+      const uint32_t p0 = (uint32_t)B::kArea, p1 = (uint32_t)(B::kArea + 3 * B::PSH);
+      group(IC<SQ_Q>{}, IC<2>{}, xaddr(p0, B::PSH, 0), B::AQ);
+      group(IC<SQ_Q + 2>{}, IC<2>{}, xaddr(p0, B::PSH, 1), B::AQ);
+      i32x4 A[8];
+      i32x4 acc = {0, 0, 0, 0};
+      item_fragments(xaddr(p1, B::PSH, 0), A);
+      consume(IC<SQ_KV>{}, A, acc, has_kv);
+      if (has_kv) item_fragments(xaddr(p1, B::PSH, 1), A);
+      consume(IC<SQ_KV + 1>{}, A, acc, has_kv);
+      if (has_kv) add_rows(acc, B::AKV);
+    }
+    had::wg_barrier<true>();
+    ++hop;                                             // hand-off: z_q, z_k, z_v
+    publish(zq, 16 * w, B::AQ, 16, shs[0], ebase | hop);
+    if (has_kv) publish(kvm ? zv : zk, 8 * (kvb & 63), B::AKV, 8, shs[1], ebase | hop);
+    had::wg_barrier<true>();
+    zero_acc(B::AQ, 48);
+    BSTAMP(3);
+
+    // ================= P2: attention =====================================================================================
+    // head hd on workgroup 4 hd; from kSplitPos positions on the head's four workgroups take every fourth position each
+    const bool split = pos >= kSplitPos;
+    const int part = w & 3, nparts = split ? kParts : 1;
+    const bool head_wg = part == 0;
+    const int hd = w >> 2, kvh = hd / GQ;
+    if (head_wg || split) {
+      const int kreg = hd >> 2, tloc = tid - 128 * (hd & 3);
+      const bool mine = tloc >= 0 && tloc < HD;
+      const f16 psvq = Ld.sv[0][mine ? HD * hd + tloc : 0];
+      // wave 0 / 1: the k / v vector (1024 values, 16 per lane), SV of this KV head's values
+      const bool kvw = wave < 2;
+      const f16* svkv = Ld.sv[1 + (wave & 1)];
+      u32x4 psvkv[2];
+      psvkv[0] = *reinterpret_cast<const u32x4*>(svkv + 16 * lane);
+      psvkv[1] = *reinterpret_cast<const u32x4*>(svkv + 16 * lane + 8);
+      float c8[8], s8[8];
+      const int d0 = (tid & 15) * 8;
+      constexpr int LPK = HD / 8, NG = 256 / LPK, U = 2;
+      const int g = (tid & 255) / LPK;
+      const f16* kc = Ld.kcache + (size_t)kvh * a.max_len * HD;
+      const f16* vc = Ld.vcache + (size_t)kvh * a.max_len * HD;
+      uint4 kr0[U], vr0[U], kr1[U], vr1[U];
+      auto load_round = [&](uint4 (&kr)[U], uint4 (&vr)[U], int i0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int t = part + nparts * (i0 + u * NG);
+          const int tc = t < pos ? t : 0;
+          kr[u] = *reinterpret_cast<const uint4*>(kc + (size_t)tc * HD + d0);
+          vr[u] = *reinterpret_cast<const uint4*>(vc + (size_t)tc * HD + d0);
+        }
+      };
+      if (tid < 256) {
+        load_round(kr0, vr0, g);
+        if (part + nparts * NG * U < pos) load_round(kr1, vr1, g + NG * U);
+      }
+      f16* s_qkv = reinterpret_cast<f16*>(smem + B::kQkv);
+      {
+        // gather z_q (everybody) and z_k / z_v (waves 0 / 1)
+        u32x4_t p[4], pk[4];
+        uint32_t spins = 0;
+        const uint64_t* src = zq + 8 * tid;
+        const uint64_t* srck = ((wave & 1) ? zv : zk) + 8 * lane;
+        const uint32_t tag = ebase | hop;
+        for (;;) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) esync::ld16(p[j], src + 2 * j);
+          if (kvw) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) esync::ld16(pk[j], srck + 2 * j);
+          }
+          esync::drain();
+          bool ok = true;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            esync::own(p[j]);
+            ok = ok && p[j].y == tag && p[j].w == tag;
+          }
+          if (kvw) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              esync::own(pk[j]);
+              ok = ok && pk[j].y == tag && pk[j].w == tag;
+            }
+          }
+          if (esync::spin_step(ok, spins, ctl + 1, 0x5000u + (uint32_t)w)) break;
+        }
+        own_ring();
+        BSTAMP(4);
+        float v[1][16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f16x2 h0 = as_f16x2(p[j].x), h1 = as_f16x2(p[j].z);
+          v[0][4 * j] = (float)h0.x; v[0][4 * j + 1] = (float)h0.y; v[0][4 * j + 2] = (float)h1.x; v[0][4 * j + 3] = (float)h1.y;
+        }
+        hadw::fwd<13, 1, true>(v, xbuf, tid);
+        {
+          float val = v[0][0];
+#pragma unroll
+          for (int k = 1; k < 16; ++k) val = kreg == k ? v[0][k] : val;
+          if (mine) s_qkv[tloc] = had::out_elem(val, kOutScaleH, true, (float)psvq, false, 0.f, false, 0.f);
+        }
+        if (kvw) {
+          float kv[16], svf[16];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f16x2 h0 = as_f16x2(pk[j].x), h1 = as_f16x2(pk[j].z);
+            kv[4 * j] = (float)h0.x; kv[4 * j + 1] = (float)h0.y; kv[4 * j + 2] = (float)h1.x; kv[4 * j + 3] = (float)h1.y;
+          }
+          hadw::wave_fht1024(kv, lane);
+          unpack16(psvkv, svf);
+          // this KV head's 128 values: lanes [8 kvh, +8), all 16 registers
+          if ((lane >> 3) == kvh) {
+            f16* dst = s_qkv + HD * (1 + (wave & 1)) + 16 * (lane & 7);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[r] = had::out_elem(kv[r], 1.f / 32.f, true, svf[r], false, 0.f, false, 0.f);
+          }
+        }
+      }
+      had::wg_barrier<true>();
+      BSTAMP(5);
+      ++hop;                                           // hand-off inside the head's group: partial states
+      const uint32_t tagg = ebase | hop;
+      auto unpack8h = [](const uint4& u, float o[8]) {
+        const uint32_t ww[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f16x2 hh = as_f16x2(ww[i]);
+          o[2 * i] = (float)hh.x;
+          o[2 * i + 1] = (float)hh.y;
+        }
+      };
+      auto rope8 = [&](const f16* vec, float o[8]) {
+        float x[8], y[8];
+        unpack8h(*reinterpret_cast<const uint4*>(vec + d0), x);
+        const int dp = d0 < HD / 2 ? d0 + HD / 2 : d0 - HD / 2;
+        unpack8h(*reinterpret_cast<const uint4*>(vec + dp), y);
+        const float sgn = d0 < HD / 2 ? -1.f : 1.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (float)(f16)had::fadd(had::fmul(x[i], c8[i]), had::fmul(sgn * y[i], s8[i]));
+      };
+      {
+        const float* cs = reinterpret_cast<const float*>(smem + B::kCs);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { c8[i] = cs[d0 + i]; s8[i] = cs[HD + d0 + i]; }
+      }
+      // single-query attention of head hd over positions [0, pos] (decode_glue.hip's arithmetic): 16 lanes per key,
+      // 16 key groups with their own online-softmax state, merged through LDS
+      float* s_m = reinterpret_cast<float*>(smem + B::kArea);
+      float* s_l = s_m + NG;
+      float* s_acc = s_l + NG;                         // [NG][HD + 4]
+      float q8[8], kn[8], vn[8];
+      float m = -INFINITY, lsum = 0.f, acc8[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { acc8[i] = 0.f; kn[i] = 0.f; vn[i] = 0.f; }
+      auto one_key = [&](const float (&k8)[8], const float (&v8)[8], bool live) {
+        float sc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sc = __builtin_fmaf(q8[i], k8[i], sc);
+#pragma unroll
+        for (int o = 1; o < LPK; o <<= 1) sc += __shfl_xor(sc, o, 64);
+        if (live) {
+          const float mn = fmaxf(m, sc);
+          const float cc = __expf(m - mn), pp = __expf(sc - mn);
+          lsum = __builtin_fmaf(lsum, cc, pp);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc8[i] = __builtin_fmaf(acc8[i], cc, had::fmul(pp, v8[i]));
+          m = mn;
+        }
+      };
+      if (tid < 256) {
+        rope8(s_qkv, q8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q8[i] *= a.attn_scale;
+        rope8(s_qkv + HD, kn);
+        const uint4 vraw = *reinterpret_cast<const uint4*>(s_qkv + 2 * HD + d0);
+        unpack8h(vraw, vn);
+        // append the new row (StaticCache.update): once per KV head -- the first of its query heads, the workgroup whose turn the position is
+        if (g == 0 && pos_ok && (hd % GQ) == 0 && part == (split ? (pos & (kParts - 1)) : 0)) {
+          uint4 kr;
+          kr.x = pack_f16(kn[0], kn[1]); kr.y = pack_f16(kn[2], kn[3]);
+          kr.z = pack_f16(kn[4], kn[5]); kr.w = pack_f16(kn[6], kn[7]);
+          *const_cast<uint4*>(reinterpret_cast<const uint4*>(kc + (size_t)pos * HD + d0)) = kr;
+          *const_cast<uint4*>(reinterpret_cast<const uint4*>(vc + (size_t)pos * HD + d0)) = vraw;
+        }
+        const int t_hi = pos + 1;
+        auto round = [&](const uint4 (&kr)[U], const uint4 (&vr)[U], int i0) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int t = part + nparts * (i0 + u * NG);
+            float k8[8], v8[8];
+            unpack8h(kr[u], k8);
+            unpack8h(vr[u], v8);
+            if (t == pos) {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) { k8[i] = kn[i]; v8[i] = vn[i]; }
+            }
+            one_key(k8, v8, t < t_hi);
+          }
+        };
+        const int n_loc = t_hi > part ? (t_hi - part + nparts - 1) / nparts : 0;
+        for (int ib = 0; ib < n_loc; ib += 2 * NG * U) {
+          round(kr0, vr0, ib + g);
+          if (ib + 2 * NG * U < n_loc) load_round(kr0, vr0, ib + g + 2 * NG * U);
+          if (ib + NG * U < n_loc) {
+            round(kr1, vr1, ib + g + NG * U);
+            if (ib + 3 * NG * U < n_loc) load_round(kr1, vr1, ib + g + 3 * NG * U);
+          }
+        }
+        if ((tid & (LPK - 1)) == 0) { s_m[g] = m; s_l[g] = lsum; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s_acc[g * (HD + 4) + d0 + i] = acc8[i];
+      }
+      had::wg_barrier<false>();                        // (full fence: the cache rows' loads are the compiler's own)
+      own_ring();
+      f16* s_a = s_qkv + 3 * HD;
+      float pM = -INFINITY, pL = 0.f, pO = 0.f;
+      if (tid < HD) {
+        for (int g2 = 0; g2 < NG; ++g2) pM = fmaxf(pM, s_m[g2]);
+        for (int g2 = 0; g2 < NG; ++g2) {
+          const float ww = s_m[g2] == -INFINITY ? 0.f : __expf(s_m[g2] - pM);
+          pL = __builtin_fmaf(s_l[g2], ww, pL);
+          pO = __builtin_fmaf(s_acc[g2 * (HD + 4) + tid], ww, pO);
+        }
+      }
+      if (split) {
+        uint64_t* mine_p = pbuf + ((size_t)hd * kParts + part) * kPartGran;
+        if (tid < HD) esync::st_granule(mine_p + tid, as_u32(pO), tagg);
+        if (tid == 0) { esync::st_granule(mine_p + HD, as_u32(pM), tagg); esync::st_granule(mine_p + HD + 1, as_u32(pL), tagg); }
+        if (head_wg) {
+          constexpr int PIECES = kParts * kPartGran / 2;
+          float* s_p = reinterpret_cast<float*>(smem + B::kArea);
+          const uint64_t* srcp = pbuf + (size_t)hd * kParts * kPartGran;
+          u32x4_t pp;
+          uint32_t spins = 0;
+          const int i = tid < PIECES ? tid : 0;
+          const int within = (2 * i) % kPartGran;
+          for (;;) {
+            esync::ld16(pp, srcp + 2 * i);
+            esync::drain();
+            esync::own(pp);
+            const bool ok = within >= HD + 2 || (pp.y == tagg && (within + 1 >= HD + 2 || pp.w == tagg));
+            if (esync::spin_step(ok, spins, ctl + 1, 0x8000u + (uint32_t)w)) break;
+          }
+          had::wg_barrier<true>();                     // s_m / s_l / s_acc have been read by everybody
+          if (tid < PIECES) *reinterpret_cast<uint2*>(s_p + 2 * tid) = make_uint2(pp.x, pp.z);
+          own_ring();
+          had::wg_barrier<true>();
+          if (tid < HD) {
+            float M = -INFINITY, Lsum = 0.f, o = 0.f;
+            for (int q2 = 0; q2 < kParts; ++q2) M = fmaxf(M, s_p[q2 * kPartGran + HD]);
+            for (int q2 = 0; q2 < kParts; ++q2) {
+              const float mq = s_p[q2 * kPartGran + HD];
+              const float ww = mq == -INFINITY ? 0.f : __expf(mq - M);
+              Lsum = __builtin_fmaf(s_p[q2 * kPartGran + HD + 1], ww, Lsum);
+              o = __builtin_fmaf(s_p[q2 * kPartGran + tid], ww, o);
+            }
+            s_a[tid] = pos_ok ? (f16)(o / Lsum) : __builtin_bit_cast(f16, (unsigned short)0x7e00);
+          }
+        }
+      } else if (tid < HD) {
+        s_a[tid] = pos_ok ? (f16)(pO / pL) : __builtin_bit_cast(f16, (unsigned short)0x7e00);
+      }
+      had::wg_barrier<true>();
+      if (head_wg && tid < 64) {
+        const uint32_t pr = *reinterpret_cast<const uint32_t*>(s_a + 2 * tid);
+        esync::st_granule(za + hd * 64 + tid, pr, ebase | (hop + 1u));
+      }
+      ++hop;                                           // hand-off: attention output
+    } else {
+      hop += 2;
+    }
+    BSTAMP(6);
+
+    // ================= o: input side (no norm), product, hand-off =========================================================
+    rederive();
+    {
+      u32x4 psu[2];
+      load16(Ld.su[3], psu);                           // natural order
+      float v[1][16], suf[16];
+      gather16(za, ebase | hop, 0x6000u, v[0]);
+      asm volatile("" : "+v"(psu[0]), "+v"(psu[1]));
+      BSTAMP(7);
+      unpack16(psu, suf);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[0][k] = had::fmul(v[0][k], suf[k]);
+      hadw::fwd<13, 1, true>(v, xbuf, tid);
+      const float sco = Ld.sc[3];
+      const float mx = wg_max(hadw::absmax<16>(v[0], sco));
+      const int sh = had::shift_for(mx);
+      planes_str(v[0], sco, sh, (uint32_t)B::kArea);
+      if (tid == 0) shs[2] = sh;
+      had::wg_barrier<true>();
+    }
+    BSTAMP(8);
+    rederive();
+    group(IC<SQ_O>{}, IC<2>{}, xaddr((uint32_t)B::kArea, B::PSH, 0), B::AO);
+    group(IC<SQ_O + 2>{}, IC<2>{}, xaddr((uint32_t)B::kArea, B::PSH, 1), B::AO);
+    had::wg_barrier<true>();
+    ++hop;                                             // hand-off: z_o
+    publish(zo, 16 * w, B::AO, 16, shs[2], ebase | hop);
+    had::wg_barrier<true>();
+    zero_acc(B::AO, 32);
+    BSTAMP(9);
+
+    // ================= o's output side + residual, RMSNorm, input transforms of gate / up; their products ===================
+    rederive();
+    edge(IC<2>{}, zo, ebase | hop, 0x7000u, Ld.sv[3], Ld.ln[1], Ld.su[4], Ld.su[5], Ld.sc[4], Ld.sc[5], true, 3, 20);
+    BSTAMP(10);
+    rederive();
+    {
+      const uint32_t pg = (uint32_t)B::kArea, pu = (uint32_t)(B::kArea + 3 * B::PSH);
+      group(IC<SQ_GU>{}, IC<7>{}, xaddr(pg, B::PSH, 0), B::AGU);
+      group(IC<SQ_GU + 7>{}, IC<7>{}, xaddr(pu, B::PSH, 0), B::AGU + 112);
+      group(IC<SQ_GU + 14>{}, IC<7>{}, xaddr(pg, B::PSH, 1), B::AGU);
+      group(IC<SQ_GU + 21>{}, IC<7>{}, xaddr(pu, B::PSH, 1), B::AGU + 112);
+    }
+    had::wg_barrier<true>();
+    BSTAMP(11);
+
+    // ================= the MLP edge =========================================================================================
+    rederive();
+    float* zcol = reinterpret_cast<float*>(smem + B::kZcol);
+    const float* mixf = reinterpret_cast<const float*>(smem + B::kMix);
+    if (tid < 224) {
+      const int* s3 = accs + (B::AGU + tid) * 4;
+      const float f = __builtin_fmaf((float)s3[0], 65536.f, __builtin_fmaf((float)s3[1], 256.f, (float)s3[2]));
+      zcol[tid] = (float)(f16)(f * unscale_of(shs[3 + tid / 112], 2));
+    }
+    had::wg_barrier<true>();
+    zero_acc(B::AGU, 224);
+    ++hop;                                             // hand-off: columns -> chunk owners
+    const uint32_t tag1 = ebase | hop;
+    if (tid < 224) {
+      // output (matrix mm, chunk k', column i): t = sum_k had[k'][k] z[k][i]
+      const int mm = tid / 112, rem = tid - 112 * mm, kq = rem >> 4, i = rem & 15;
+      const float* hs = mixf + (mm * 7 + kq) * 8;
+      const float* zz = zcol + mm * 112 + i;
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < FK; ++k) t = __builtin_fmaf(hs[k], zz[16 * k], t);
+      const float tn = __shfl_down(t, 1, 64);
+      if ((i & 1) == 0)
+        esync::st_granule2(inbox + ((size_t)(kq * 2 + mm) * FL + 16 * w + i), as_u32(t), as_u32(tn), tag1);
+    }
+    ++hop;                                             // hand-off: rows -> everybody
+    const uint32_t tag2 = ebase | hop;
+    BSTAMP(12);
+    if (w < FK) {
+      // chunk owner w: 4096 values of gate and of up (fp32 payloads) -> transforms, SV, SiLU product, SU, down's transform
+      const f16* svg = Ld.sv[4] + (size_t)w * FL;
+      const f16* svu = Ld.sv[5] + (size_t)w * FL;
+      const f16* sud = Ld.su[6] + (size_t)w * FL;
+      uint16_t psg[8], psu_[8], psd[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        psg[j] = reinterpret_cast<const uint16_t*>(svg)[tid + 512 * j];
+        psu_[j] = reinterpret_cast<const uint16_t*>(svu)[tid + 512 * j];
+        psd[j] = reinterpret_cast<const uint16_t*>(sud)[tid + 512 * j];
+      }
+      float v[2][8];
+      {
+        u32x4_t pc[8];
+        uint32_t spins = 0;
+        const uint64_t* src = inbox + (size_t)(w * 2) * FL + 8 * tid;
+        for (;;) {
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) esync::ld16(pc[jj], src + (jj >> 2) * FL + 2 * (jj & 3));
+          esync::drain();
+          bool ok = true;
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) {
+            esync::own(pc[jj]);
+            ok = ok && pc[jj].y == tag1 && pc[jj].w == tag1;
+          }
+          if (esync::spin_step(ok, spins, ctl + 1, 0x1000u + (uint32_t)w)) break;
+        }
+        own_ring();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(psg[j]), "+v"(psu_[j]), "+v"(psd[j]));
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          v[jj >> 2][2 * (jj & 3)] = as_f32(pc[jj].x);
+          v[jj >> 2][2 * (jj & 3) + 1] = as_f32(pc[jj].z);
+        }
+      }
+      BSTAMP(25);
+      had8::fht4096<2, true>(v, xbuf, tid);
+      float e[1][8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float og = (float)had::out_elem(v[0][j], 1.f / 64.f, true, (float)__builtin_bit_cast(f16, psg[j]), false, 0.f, false, 0.f);
+        const float ou = (float)had::out_elem(v[1][j], 1.f / 64.f, true, (float)__builtin_bit_cast(f16, psu_[j]), false, 0.f, false, 0.f);
+        e[0][j] = had::fmul(had::fmul(ou, had::silu(og)), (float)__builtin_bit_cast(f16, psd[j]));
+      }
+      hadw::rev<12, 1, true>(e, xbuf, tid);
+      constexpr float kPre = 1.f / 64.f;
+      float mxr = 0.f;
+      uint32_t pk[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float vv = e[0][r] * kPre;
+        const float av = fabsf(vv);
+        mxr = fmaxf(mxr, av == av ? av : __builtin_inff());
+        const f16 hi = (f16)vv;
+        const f16 lo = (f16)(vv - (float)hi);
+        pk[r] = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
+      }
+      uint64_t* dst = frow + (size_t)w * FL + 8 * tid;
+#pragma unroll
+      for (int r = 0; r < 8; r += 2) esync::st_granule2(dst + r, pk[r], pk[r + 1], tag2);
+      mxr = wg_max(mxr);
+      if (tid == 0) esync::st_granule(rowmax + w, as_u32(mxr), tag2);
+      had::wg_barrier<true>();
+    }
+    BSTAMP(13);
+    // everybody: the owners' maxima -> block exponent of down's input; then the rows, mixed and turned into digits on the fly
+    const float in_scale = Ld.sc[6] * 64.f;
+    if (wave == 0) {
+      uint32_t spins0 = 0;
+      u32x2_t f;
+      for (;;) {
+        esync::ld8(f, rowmax + (lane < FK ? lane : 0));
+        esync::drain();
+        esync::own(f);
+        if (esync::spin_step(f.y == tag2, spins0, ctl + 1, 0x3000u + (uint32_t)w)) break;
+      }
+      if (lane < FK) red[32 + lane] = as_f32(f.x);
+    }
+    had::wg_barrier<false>();
+    own_ring();
+    int sh_d;
+    {
+      float bound = 0.f;
+#pragma unroll
+      for (int kp = 0; kp < FK; ++kp) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < FK; ++k) s = __builtin_fmaf(fabsf(mixf[(14 + kp) * 8 + k]), red[32 + k], s);
+        bound = fmaxf(bound, s == s ? s : __builtin_inff());
+      }
+      sh_d = had::shift_for(had::fmul(bound, fabsf(in_scale)));
+    }
+    BSTAMP(14);
+    {
+      const float s2 = had::fmul(in_scale, as_f32((uint32_t)(sh_d + 127) << 23));
+      uint8_t* pl = reinterpret_cast<uint8_t*>(smem + B::kArea);
+#pragma unroll 1
+      for (int c = 0; c < 2; ++c) {
+        // columns [4 (t + 512 c), +4) of the seven rows: two 16-byte pieces each
+        u32x4_t p[FK][2];
+        uint32_t spins = 0;
+        const int col = 4 * (tid + 512 * c);
+        for (;;) {
+#pragma unroll
+          for (int k = 0; k < FK; ++k) {
+            esync::ld16(p[k][0], frow + (size_t)k * FL + col);
+            esync::ld16(p[k][1], frow + (size_t)k * FL + col + 2);
+          }
+          esync::drain();
+          bool ok = true;
+#pragma unroll
+          for (int k = 0; k < FK; ++k) {
+            esync::own(p[k][0]);
+            esync::own(p[k][1]);
+            ok = ok && p[k][0].y == tag2 && p[k][0].w == tag2 && p[k][1].y == tag2 && p[k][1].w == tag2;
+          }
+          if (esync::spin_step(ok, spins, ctl + 1, 0x2000u + (uint32_t)w)) break;
+        }
+        own_ring();
+        float e[FK][4];
+#pragma unroll
+        for (int k = 0; k < FK; ++k) {
+          const uint32_t ww[4] = {p[k][0].x, p[k][0].z, p[k][1].x, p[k][1].z};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f16x2 hl = as_f16x2(ww[j]);
+            e[k][j] = (float)hl.x + (float)hl.y;
+          }
+        }
+#pragma unroll
+        for (int kp = 0; kp < FK; ++kp) {
+          // row kp of down.had_left^T: uniform, from LDS (broadcast reads) into scalar registers for this row only
+          float rt[FK];
+#pragma unroll
+          for (int k = 0; k < FK; ++k) rt[k] = as_f32((uint32_t)__builtin_amdgcn_readfirstlane((int)as_u32(mixf[(14 + kp) * 8 + k])));
+          int X[4], X1[4], H[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float x = 0.f;
+#pragma unroll
+            for (int k = 0; k < FK; ++k) x = __builtin_fmaf(rt[k], e[k][j], x);
+            X[j] = (int)__builtin_rintf(had::fmul(x, s2));
+            X1[j] = (X[j] + 128) >> 8;
+            H[j] = (X1[j] + 128) >> 8;
+          }
+          const int off = kp * FL + col;
+          *reinterpret_cast<uint32_t*>(pl + off) = had::low_bytes4(H[0], H[1], H[2], H[3]);
+          *reinterpret_cast<uint32_t*>(pl + B::PSD + off) = had::low_bytes4(X1[0], X1[1], X1[2], X1[3]);
+          *reinterpret_cast<uint32_t*>(pl + 2 * B::PSD + off) = had::low_bytes4(X[0], X[1], X[2], X[3]);
+        }
+      }
+    }
+    had::wg_barrier<true>();
+    BSTAMP(15);
+    // ================= down's product ====================================================================================
+    rederive();
+    {
+      i32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+      static_for<7>([&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+        i32x4 A[8];
+        item_fragments(xaddr((uint32_t)B::kArea, B::PSD, I), A);
+        consume(IC<SQ_D + 2 * I>{}, A, acc0, true);
+        consume(IC<SQ_D + 2 * I + 1>{}, A, acc1, true);
+      });
+      add_rows(acc0, B::AD);
+      add_rows(acc1, B::AD + 16);
+      i32x4 A0[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) A0[t] = i32x4{0, 0, 0, 0};
+      i32x4 accf = {0, 0, 0, 0};
+      consume(IC<SQ_F>{}, A0, accf, false);            // the two fillers keep the ring's period at 54
+      consume(IC<SQ_F + 1>{}, A0, accf, false);
+    }
+    had::wg_barrier<true>();
+    ++hop;                                             // hand-off: z_d
+    publish(zd, 16 * w, B::AD, 16, sh_d, ebase | hop);
+    had::wg_barrier<true>();
+    zero_acc(B::AD, 32);
+    BSTAMP(16);
+
+    sv_prev = Ld.sv[6];
+    // the loop's back edge: nothing in flight (the requests of the last items would be waited for by the next gather anyway)
+    esync::drain();
+    own_ring();
+    BSTAMP(17);
+  }
+  // output side of the last block's down_proj + residual -> h
+  rederive();
+  edge(IC<0>{}, zd, ebase | hop, 0x4000u, sv_prev, nullptr, nullptr, nullptr, 0.f, 0.f, false, 0, -1);
+  // ---- h_out (natural order) -------------------------------------------------------------------------------------------------
+  if (w == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      reinterpret_cast<uint16_t*>(a.h_out)[tid + 512 * (2 * j)] = (uint16_t)(hreg[j] & 0xffffu);
+      reinterpret_cast<uint16_t*>(a.h_out)[tid + 512 * (2 * j + 1)] = (uint16_t)(hreg[j] >> 16);
+    }
+    if (tid == 0) esync::st_word(ctl, ebase >> 10);
+  }
+#undef BSTAMP
+}
+
+}  // namespace
+
+size_t block_engine_gqa_workspace_bytes() { return kWsBytes; }
+size_t block_engine_gqa_layer_bytes() { return sizeof(GLayer); }
+
+bool block_engine_gqa_supported(int hidden, int heads, int kv_heads, int head_dim, int n_ffn, int K) {
+  return hidden == HID && heads == NH && kv_heads == NKV && head_dim == HD && n_ffn == NFFN && K == FK && device_cu_count() >= NWG;
+}
+
+int block_engine_gqa_launch(const BlockEngineArgs& in, hipStream_t stream) {
+  if (in.n_layers < 1 || in.n_layers > 146) return QUIP_ERR_BAD_SHAPE;     // 7 hand-offs per block, 10-bit counter
+  if (in.codebook != 0) return QUIP_ERR_UNSUPPORTED;
+  if (device_cu_count() < NWG) return QUIP_ERR_UNSUPPORTED;
+  GArgs a;
+  a.layers = reinterpret_cast<const GLayer*>(in.layers);
+  a.h_in = reinterpret_cast<const f16*>(in.h_in);
+  a.h_out = reinterpret_cast<f16*>(in.h_out);
+  a.pos = reinterpret_cast<const int64_t*>(in.pos);
+  a.cos = in.cos; a.sin = in.sin;
+  a.grid = reinterpret_cast<const uint64_t*>(in.grid);
+  a.ws = reinterpret_cast<char*>(in.workspace);
+  a.dbg = reinterpret_cast<uint64_t*>(in.dbg);
+  a.n_layers = in.n_layers; a.max_len = in.max_len; a.dbg_layer = in.dbg_layer;
+  a.rms_eps = in.rms_eps; a.attn_scale = in.attn_scale;
+  static DynLdsCache cache;
+  if (ensure_dyn_lds(cache, reinterpret_cast<const void*>(decode_block_gqa_kernel), GLds::kBytes) != QUIP_OK) return QUIP_ERR_LAUNCH;
+  hipLaunchKernelGGL(decode_block_gqa_kernel, dim3(NWG), dim3(kThreads), GLds::kBytes, stream, a);
+  return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+}
+
+}  // namespace quip

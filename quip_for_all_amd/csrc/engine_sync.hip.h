@@ -65,7 +65,8 @@ __device__ __forceinline__ bool spin_step(bool done, uint32_t& spins, uint32_t* 
     own(e);
     if (__builtin_amdgcn_readfirstlane(e) != 0u) return true;
     if (spins >= kSpinLimit) {
-      if ((threadIdx.x & 63) == 0) st_word(err, code);
+      // (lane id from the exec mask, not from threadIdx: nothing to keep live across a whole persistent launch)
+      if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) st_word(err, code);
       return true;
     }
   }

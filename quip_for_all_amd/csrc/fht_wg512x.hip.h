@@ -1,0 +1,156 @@
+// Walsh-Hadamard transforms of 4096 (8 elements per thread) or 8192 (16 per thread) points across a 512-thread workgroup
+// with ONE LDS exchange, in both directions, for the persistent decode engine of the grouped-query / 8192-wide shapes
+// (decode_block_gqa.hip).  Generalises fht_wg512.hip.h (4096 points, natural -> strided only):
+//
+//   fwd: thread t holds x[EPT t + r]  ->  thread t holds X[t + 512 k]     (index bits in ascending order: the additions of
+//        had_device.hip.h's transforms, so the same bits as the stand-alone kernels)
+//   rev: thread t holds x[t + 512 k]  ->  thread t holds X[EPT t + r]     (bits 9.. first, then 0..8: same transform,
+//        another order of the additions)
+//
+// The pair lets an edge of the decoder block run  gather (natural) -> fwd -> element-wise in the strided layout
+// (residual, RMSNorm, SU: the static vectors are stored pre-permuted by the host) -> rev -> digit planes as 16-byte
+// pieces, without a layout change through LDS in between.  wave_fht1024: 1024 points inside one wave, no LDS at all.
+#pragma once
+#include "fht_wg512.hip.h"
+
+namespace quip {
+namespace hadw {
+
+template <int N, int STRIDE>
+__device__ __forceinline__ void reg_stage(float (&v)[N]) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int r = 0; r < N; ++r) {
+    if (!(r & STRIDE)) {
+      const float x0 = v[r], x1 = v[r | STRIDE];
+      v[r] = x0 + x1;
+      v[r | STRIDE] = x0 - x1;
+    }
+  }
+}
+template <int N, int FROM>
+__device__ __forceinline__ void reg_stages(float (&v)[N]) {      // strides FROM, 2 FROM, .. < N
+  if constexpr (FROM < N) {
+    reg_stage<N, FROM>(v);
+    reg_stages<N, 2 * FROM>(v);
+  }
+}
+template <int N, int S>
+__device__ __forceinline__ void lane_stage(float (&v)[N], int lane) {
+#pragma clang fp contract(off)
+  const float sg = ((lane >> S) & 1) ? -1.f : 1.f;     // bit clear: own + partner; bit set: partner - own
+#pragma unroll
+  for (int r = 0; r < N; ++r) v[r] = __builtin_fmaf(v[r], sg, had8::lane_partner<S>(v[r], lane));
+}
+template <int N, int S, int END>
+__device__ __forceinline__ void lane_stages(float (&v)[N], int lane) {     // lane bits S .. END - 1
+  if constexpr (S < END) {
+    lane_stage<N, S>(v, lane);
+    lane_stages<N, S + 1, END>(v, lane);
+  }
+}
+
+template <int LOGN>
+struct Geo {
+  static constexpr int N = 1 << LOGN, EPT = N / 512, RB = LOGN - 9;
+  static constexpr int kBufFloats = N + (N >> 5) + 4;
+  static_assert(EPT == 8 || EPT == 16, "4096 or 8192 points");
+  // natural element EPT t + r  ->  padded index (one word per 32)
+  __device__ static __forceinline__ int nat(int t) { return EPT * t + ((EPT * t) >> 5); }
+  // strided element t + 512 k  ->  t + (t >> 5) + 528 k
+  __device__ static __forceinline__ int str(int t) { return t + (t >> 5); }
+};
+
+// natural -> strided (ascending index bits)
+template <int LOGN, int NT, bool RAW>
+__device__ __forceinline__ void fwd(float (&v)[NT][Geo<LOGN>::EPT], float* xbuf, int tid) {
+  using G = Geo<LOGN>;
+  constexpr int E = G::EPT;
+  const int lane = tid & 63;
+#pragma unroll
+  for (int i = 0; i < NT; ++i) reg_stages<E, 1>(v[i]);
+#pragma unroll
+  for (int i = 0; i < NT; ++i) lane_stages<E, 0, 6>(v[i], lane);          // index bits RB .. RB + 5
+  had::wg_barrier<RAW>();
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    float* b = xbuf + i * G::kBufFloats + G::nat(tid);
+#pragma unroll
+    for (int r = 0; r < E; ++r) b[r] = v[i][r];
+  }
+  had::wg_barrier<RAW>();
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const float* b = xbuf + i * G::kBufFloats + G::str(tid);
+#pragma unroll
+    for (int k = 0; k < E; ++k) v[i][k] = b[528 * k];
+    // pending index bits RB + 6 .. LOGN - 1 = bits (RB - 3) .. of k
+    reg_stages<E, (1 << (G::RB - 3))>(v[i]);
+  }
+}
+
+// strided -> natural
+template <int LOGN, int NT, bool RAW>
+__device__ __forceinline__ void rev(float (&v)[NT][Geo<LOGN>::EPT], float* xbuf, int tid) {
+  using G = Geo<LOGN>;
+  constexpr int E = G::EPT;
+  const int lane = tid & 63;
+#pragma unroll
+  for (int i = 0; i < NT; ++i) reg_stages<E, 1>(v[i]);                      // index bits 9 .. LOGN - 1 (all bits of k)
+  had::wg_barrier<RAW>();
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    float* b = xbuf + i * G::kBufFloats + G::str(tid);
+#pragma unroll
+    for (int k = 0; k < E; ++k) b[528 * k] = v[i][k];
+  }
+  had::wg_barrier<RAW>();
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const float* b = xbuf + i * G::kBufFloats + G::nat(tid);
+#pragma unroll
+    for (int r = 0; r < E; ++r) v[i][r] = b[r];
+    reg_stages<E, 1>(v[i]);                                                // index bits 0 .. RB - 1
+  }
+#pragma unroll
+  for (int i = 0; i < NT; ++i) lane_stages<E, 0, 9 - G::RB>(v[i], lane);    // index bits RB .. 8
+}
+
+// 1024 points inside ONE wave: lane l holds x[16 l + r] before and X[16 l + r] after; no LDS, no barrier
+__device__ __forceinline__ void wave_fht1024(float (&v)[16], int lane) {
+  reg_stages<16, 1>(v);
+  lane_stages<16, 0, 6>(v, lane);
+}
+
+// sum of squares / maximum over the workgroup, a fixed order (every workgroup of a launch computes the same value from the
+// same data): the thread's chain, the wave's DPP tree, the eight waves in order.  red: 8 floats per call site.
+template <int N, bool RAW>
+__device__ __forceinline__ float sumsq(const float (&e)[N], float* red, int tid) {
+#pragma clang fp contract(off)
+  const int lane = tid & 63, wave = tid >> 6;
+  float ss = 0.f;
+#pragma unroll
+  for (int r = 0; r < N; ++r) ss = __builtin_fmaf(e[r], e[r], ss);
+  ss = had::wave_reduce_to_lane63<false>(ss);
+  had::wg_barrier<RAW>();
+  if (lane == 63) red[wave] = ss;
+  had::wg_barrier<RAW>();
+  float r = red[0];
+#pragma unroll
+  for (int w = 1; w < 8; ++w) r = had::fadd(r, red[w]);
+  return r;
+}
+template <int N>
+__device__ __forceinline__ float absmax(const float (&v)[N], float scale) {
+#pragma clang fp contract(off)
+  float mx = 0.f;
+#pragma unroll
+  for (int r = 0; r < N; ++r) {
+    const float a = fabsf(v[r] * scale);
+    mx = fmaxf(mx, a == a ? a : __builtin_inff());
+  }
+  return mx;
+}
+
+}  // namespace hadw
+}  // namespace quip

@@ -212,6 +212,12 @@ bool block_engine_supported(int hidden, int heads, int kv_heads, int head_dim, i
 size_t block_engine_workspace_bytes();
 size_t block_engine_layer_bytes();
 int block_engine_launch(const BlockEngineArgs& in, hipStream_t stream);
+// the same for the grouped-query 8192-wide shape (decode_block_gqa.hip: Llama-2-70B; E8P12): its own descriptor vectors
+// (permuted, see include/quip_mi355.h) and workspace
+bool block_engine_gqa_supported(int hidden, int heads, int kv_heads, int head_dim, int n_ffn, int K);
+size_t block_engine_gqa_workspace_bytes();
+size_t block_engine_gqa_layer_bytes();
+int block_engine_gqa_launch(const BlockEngineArgs& in, hipStream_t stream);
 int had_transform_planes_launch(const void* x, void* planes, int in_features, int n, int K,
                                 const void* had, int transpose, const void* pre, float scale,
                                 hipStream_t stream, const HadFusion* fuse = nullptr);

@@ -238,7 +238,8 @@ class LlamaDecoder:
         # (E8P12; D4 through the same kernel's one-table mode; E8P12RVQ4B and HI as rows of twice the virtual width)
         self.block_eng = False
         d4 = all(getattr(m.codebook, "id", None) in ("D4", "E8P12RVQ4B", "HI") for m in L0.values() if isinstance(m, QuantLinear))
-        if ((self.ffn_eng or (d4 and self.fused_prologue and self.chain and os.environ.get("QUIP_FFN_ENGINE", "1") != "0"))
+        gqa_shape = self.fused_prologue and self.chain and s.kv_heads != s.heads and s.hidden == 8192   # (csrc/decode_block_gqa.hip)
+        if ((self.ffn_eng or gqa_shape or (d4 and self.fused_prologue and self.chain and os.environ.get("QUIP_FFN_ENGINE", "1") != "0"))
                 and os.environ.get("QUIP_BLOCK_ENGINE", "1") != "0" and not self.window):   # (its attention walks [0, pos])
             self._init_block_engine()
         # q / k / v output transforms inside the attention launch (multi-head attention with a power-of-two hidden <= 4096,
@@ -267,10 +268,14 @@ class LlamaDecoder:
             return (getattr(m.codebook, "id", None) == cbid and not m.per_channel and m.bias is None and not m.training
                     and m.SU is not None and m.SV is not None and m.in_features == m.q_in_features == n_in
                     and m.out_features == m.q_out_features == n_out)
-        ok = (block_engine_supported(s.hidden, s.heads, s.kv_heads, s.head_dim, s.ffn, L0["gate"].K_right)
+        from .register_lib import block_engine_gqa_supported
+        gqa = block_engine_gqa_supported(s.hidden, s.heads, s.kv_heads, s.head_dim, s.ffn, L0["gate"].K_right) and cbid == "E8P12"
+        ok = ((gqa or block_engine_supported(s.hidden, s.heads, s.kv_heads, s.head_dim, s.ffn, L0["gate"].K_right))
               and len(self.layers) <= 146)      # (the launch's hand-off counter: 7 per block in 10 bits)
+        kvw = s.kv_heads * s.head_dim
         for L in self.layers:
-            ok = ok and all(plain(L[k], s.hidden, s.hidden) and L[k].K_left == 1 and L[k].K_right == 1 for k in "qkvo")
+            ok = ok and all(plain(L[k], s.hidden, s.hidden) and L[k].K_left == 1 and L[k].K_right == 1 for k in "qo")
+            ok = ok and all(plain(L[k], s.hidden, kvw) and L[k].K_left == 1 and L[k].K_right == 1 for k in "kv")
             ok = ok and all(plain(L[k], s.hidden, s.ffn) and L[k].K_left == 1 for k in ("gate", "up"))
             ok = ok and plain(L["down"], s.ffn, s.hidden) and L["down"].K_right == 1
         if not ok:
@@ -279,9 +284,23 @@ class LlamaDecoder:
         for i, L in enumerate(self.layers):
             mods = [L[k] for k in names]
             vec = lambda t: t.detach().to(torch.float16).contiguous()     # noqa: E731
-            su, sv = [vec(m.SU) for m in mods], [vec(m.SV) for m in mods]
-            ln = [vec(L["ln1"]), vec(L["ln2"])]
-            had3 = _engine_had3(L["gate"], L["up"], L["down"])
+            # shape 1 reads the vectors it multiplies in the strided layout of its 512-thread transforms pre-permuted:
+            # p[16 t + k] = v[t + 512 k]
+            perm = lambda t: vec(t).reshape(16, 512).t().contiguous().reshape(-1)     # noqa: E731
+            if gqa:
+                su = [perm(m.SU) if k in ("q", "k", "v", "gate", "up") else vec(m.SU) for k, m in zip(names, mods)]
+                sv = [perm(m.SV) if k in ("o", "down") else vec(m.SV) for k, m in zip(names, mods)]
+                ln = [perm(L["ln1"]), perm(L["ln2"])]
+                K = L["gate"].K_right
+                mix = torch.zeros(3, K, 8, dtype=torch.float32, device=self.dev)
+                mix[0, :, :K] = L["gate"].had_right.detach().float()
+                mix[1, :, :K] = L["up"].had_right.detach().float()
+                mix[2, :, :K] = L["down"].had_left.detach().float().t()
+                had3 = mix.contiguous()
+            else:
+                su, sv = [vec(m.SU) for m in mods], [vec(m.SV) for m in mods]
+                ln = [vec(L["ln1"]), vec(L["ln2"])]
+                had3 = _engine_had3(L["gate"], L["up"], L["down"])
             keep += su + sv + ln + [had3]
             ptrs = ([m.Qidxs.data_ptr() for m in mods] + [t.data_ptr() for t in ln] + [t.data_ptr() for t in su]
                     + [t.data_ptr() for t in sv] + [had3.data_ptr(), self.kcache[i].data_ptr(), self.vcache[i].data_ptr()])
@@ -290,7 +309,8 @@ class LlamaDecoder:
             rec[i, 26:].view(np.float32)[:7] = np.array(sc, dtype=np.float32)
         self._eng_keep = keep
         self.eng_layers = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).to(self.dev)
-        self.eng_ws = block_engine_workspace(self.dev)
+        self.eng_shape = 1 if gqa else 0
+        self.eng_ws = block_engine_workspace(self.dev, self.eng_shape)
         self.eng_codebook = {"E8P12": 0, "D4": 1, "E8P12RVQ4B": 2, "HI": 3}[cbid]
         cb0 = L0["q"].codebook
         self.eng_grid = cb0.grid if cbid == "D4" else (cb0._virtual_grid(self.dev) if cbid == "HI" else cb0.grid_packed_abs)
@@ -353,7 +373,8 @@ class LlamaDecoder:
         if getattr(self, "block_eng", False):
             h = torch.ops.quip_lib.block_engine(self.eng_layers, h.reshape(-1), self.pos, self.cos, self.sin,
                                                 self.eng_grid, self.eng_ws, len(self.layers), self.max_len, s.rms_eps,
-                                                1.0 / math.sqrt(s.head_dim), None, -1, self.eng_codebook, self.eng_resid_scale)
+                                                1.0 / math.sqrt(s.head_dim), None, -1, self.eng_codebook, self.eng_resid_scale,
+                                                getattr(self, "eng_shape", 0))
             return self._head(h.reshape(1, -1))
         if self.fused_prologue:
             return self._step_fused(h, cos, sin, mask)

@@ -96,7 +96,7 @@ _SCHEMAS = {
     # `layers` = the packed descriptors (decode.py builds them; they point at the KV caches, which the launch appends to)
     "block_engine": "(Tensor layers, Tensor h_in, Tensor pos, Tensor cos, Tensor sin, Tensor grid, Tensor(a!) workspace, "
                     "int n_layers, int max_len, float rms_eps, float attn_scale, Tensor? dbg=None, int dbg_layer=-1, "
-                    "int codebook=0, float resid_scale=0.0) -> Tensor",
+                    "int codebook=0, float resid_scale=0.0, int shape=0) -> Tensor",
     # decode-step glue between q/k/v_proj and o_proj: rope + KV-cache append + single-query attention
     "rope_attn_decode": "(Tensor q, Tensor k, Tensor v, Tensor cos, Tensor sin, Tensor pos, Tensor(a!) kcache, "
                         "Tensor(b!) vcache, Tensor(c!)? workspace, int window=0) -> Tensor",   # window > 0: the last `window` positions only
@@ -669,23 +669,30 @@ def block_engine_supported(hidden, heads, kv_heads, head_dim, n_ffn, K):
     return bool(capi.lib().quip_block_engine_supported(int(hidden), int(heads), int(kv_heads), int(head_dim), int(n_ffn), int(K)))
 
 
-def block_engine_workspace(device):
-    return torch.zeros(capi.lib().quip_block_engine_workspace_bytes(), dtype=torch.uint8, device=device)
+def block_engine_workspace(device, shape=0):
+    n = capi.lib().quip_block_engine_gqa_workspace_bytes() if shape == 1 else capi.lib().quip_block_engine_workspace_bytes()
+    return torch.zeros(n, dtype=torch.uint8, device=device)
+
+
+def block_engine_gqa_supported(hidden, heads, kv_heads, head_dim, n_ffn, K):
+    return bool(capi.lib().quip_block_engine_gqa_supported(int(hidden), int(heads), int(kv_heads), int(head_dim), int(n_ffn), int(K)))
 
 
 def _block_engine_cuda(layers, h_in, pos, cos, sin, grid, workspace, n_layers, max_len, rms_eps, attn_scale, dbg=None,
-                       dbg_layer=-1, codebook=0, resid_scale=0.0):
+                       dbg_layer=-1, codebook=0, resid_scale=0.0, shape=0):
     dev = h_in.device
     lb = capi.lib().quip_block_engine_layer_bytes()
     _need(layers.dtype == torch.uint8 and layers.is_contiguous() and layers.numel() >= n_layers * lb and layers.device == dev,
           "layers must be the packed descriptors (uint8, n_layers x 256 bytes) on the device")
-    _need(h_in.dtype == torch.float16 and h_in.is_contiguous() and h_in.numel() == 4096, "h_in: fp16 [4096]")
+    _need(shape in (0, 1), "shape: 0 (hidden 4096, multi-head) or 1 (hidden 8192, grouped-query)")
+    hid = 8192 if shape == 1 else 4096
+    _need(h_in.dtype == torch.float16 and h_in.is_contiguous() and h_in.numel() == hid, f"h_in: fp16 [{hid}]")
     _need(pos.dtype == torch.int64 and pos.numel() == 1 and pos.device == dev, "pos: int64 device scalar")
     for t in (cos, sin):
         _need(t.dtype == torch.float32 and t.is_contiguous() and t.shape == (max_len, 128) and t.device == dev,
               "cos / sin: fp32 [max_len, 128]")
-    _need(workspace.dtype == torch.uint8 and workspace.device == dev
-          and workspace.numel() >= capi.lib().quip_block_engine_workspace_bytes(), "workspace too small")
+    need_ws = capi.lib().quip_block_engine_gqa_workspace_bytes() if shape == 1 else capi.lib().quip_block_engine_workspace_bytes()
+    _need(workspace.dtype == torch.uint8 and workspace.device == dev and workspace.numel() >= need_ws, "workspace too small")
     if codebook in (1, 3):      # D4 / HI: the fp16 (256, 4) table (HI: of a code byte) -- 2 KB like grid_packed_abs
         g = _d4_grid_f16(grid)
         _need(g.device == dev and g.numel() == 1024, "D4 / HI grid: fp16 (256, 4) on the device")
@@ -694,7 +701,7 @@ def _block_engine_cuda(layers, h_in, pos, cos, sin, grid, workspace, n_layers, m
     out = torch.empty_like(h_in)
     a = capi.BlockEngineArgs(layers.data_ptr(), h_in.data_ptr(), out.data_ptr(), pos.data_ptr(), cos.data_ptr(),
                              sin.data_ptr(), g.data_ptr(), workspace.data_ptr(), _ptr(dbg), int(n_layers), int(max_len),
-                             int(dbg_layer), float(rms_eps), float(attn_scale), int(codebook), float(resid_scale))
+                             int(dbg_layer), float(rms_eps), float(attn_scale), int(codebook), float(resid_scale), int(shape))
     import ctypes
     with torch.cuda.device(dev):
         capi.check(capi.lib().quip_block_engine(ctypes.byref(a), _stream(h_in)), "quip_block_engine")
@@ -1149,7 +1156,7 @@ _reg_fake("e8p_gemv_fused", lambda x, z, post, residual, rms_weight, rms_eps, z_
 _reg_fake("ffn_engine", lambda planes_gate, planes_up, q_gate, q_up, q_down, had3, sv_gate, sv_up, su_down, grid, workspace,
           out_scale, in_scale, K, dbg=None: q_down.new_empty((1, q_down.shape[0]), dtype=torch.float16))
 _reg_fake("block_engine", lambda layers, h_in, pos, cos, sin, grid, workspace, n_layers, max_len, rms_eps, attn_scale,
-          dbg=None, dbg_layer=-1, codebook=0, resid_scale=0.0: torch.empty_like(h_in))
+          dbg=None, dbg_layer=-1, codebook=0, resid_scale=0.0, shape=0: torch.empty_like(h_in))
 _reg_fake("rope_attn_decode", lambda q, k, v, cos, sin, pos, kcache, vcache, workspace=None, window=0: torch.empty_like(q))
 _reg_fake("rope_attn_decode_z", lambda zs, posts, scales, cos, sin, pos, kcache, vcache, workspace=None, window=0:
           kcache.new_empty((zs[0].numel() // kcache.shape[2], kcache.shape[2])))
