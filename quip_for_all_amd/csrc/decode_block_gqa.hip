@@ -82,7 +82,7 @@ constexpr size_t kWsCtl = 0;
 constexpr size_t kWsZq = 64, kWsZk = kWsZq + (HID / 2) * 8, kWsZv = kWsZk + (NKV * HD / 2) * 8;
 constexpr size_t kWsA = kWsZv + (NKV * HD / 2) * 8, kWsZo = kWsA + (HID / 2) * 8, kWsZd = kWsZo + (HID / 2) * 8;
 constexpr size_t kWsInbox = kWsZd + (HID / 2) * 8;                    // [FK][2][FL] granules (fp32 payload)
-constexpr size_t kWsRows = kWsInbox + (size_t)FK * 2 * FL * 8;        // [FK][FL] granules (fp16 hi | lo << 16)
+constexpr size_t kWsRows = kWsInbox + (size_t)FK * 2 * FL * 8;        // [FK][FL] granules (fp32 payload)
 constexpr size_t kWsRowMax = kWsRows + (size_t)FK * FL * 8;           // [8] granules
 constexpr size_t kWsPart = kWsRowMax + 64;                            // [NH][kParts][132]
 constexpr size_t kWsBytes = kWsPart + (size_t)NH * kParts * kPartGran * 8;
@@ -500,6 +500,10 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
       const uint32_t p0 = (uint32_t)B::kArea, p1 = (uint32_t)(B::kArea + 3 * B::PSH);
       group(IC<SQ_Q>{}, IC<2>{}, xaddr(p0, B::PSH, 0), B::AQ);
       group(IC<SQ_Q + 2>{}, IC<2>{}, xaddr(p0, B::PSH, 1), B::AQ);
+      had::wg_barrier<true>();
+      ++hop;                                           // hand-off: z_q, then z_k / z_v (the same index: they are different vectors)
+      // z_q goes out before the k | v items are multiplied: the heads transform q while the odd workgroups finish theirs
+      publish(zq, 16 * w, B::AQ, 16, shs[0], ebase | hop);
       i32x4 A[8];
       i32x4 acc = {0, 0, 0, 0};
       item_fragments(xaddr(p1, B::PSH, 0), A);
@@ -509,8 +513,6 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
       if (has_kv) add_rows(acc, B::AKV);
     }
     had::wg_barrier<true>();
-    ++hop;                                             // hand-off: z_q, z_k, z_v
-    publish(zq, 16 * w, B::AQ, 16, shs[0], ebase | hop);
     if (has_kv) publish(kvm ? zv : zk, 8 * (kvb & 63), B::AKV, 8, shs[1], ebase | hop);
     had::wg_barrier<true>();
     zero_acc(B::AQ, 48);
@@ -554,43 +556,10 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
       }
       f16* s_qkv = reinterpret_cast<f16*>(smem + B::kQkv);
       {
-        // gather z_q (everybody) and z_k / z_v (waves 0 / 1)
-        u32x4_t p[4], pk[4];
-        uint32_t spins = 0;
-        const uint64_t* src = zq + 8 * tid;
-        const uint64_t* srck = ((wave & 1) ? zv : zk) + 8 * lane;
-        const uint32_t tag = ebase | hop;
-        for (;;) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) esync::ld16(p[j], src + 2 * j);
-          if (kvw) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) esync::ld16(pk[j], srck + 2 * j);
-          }
-          esync::drain();
-          bool ok = true;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            esync::own(p[j]);
-            ok = ok && p[j].y == tag && p[j].w == tag;
-          }
-          if (kvw) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              esync::own(pk[j]);
-              ok = ok && pk[j].y == tag && pk[j].w == tag;
-            }
-          }
-          if (esync::spin_step(ok, spins, ctl + 1, 0x5000u + (uint32_t)w)) break;
-        }
-        own_ring();
-        BSTAMP(4);
+        // gather z_q, transform it; z_k / z_v (waves 0 / 1) come a little later (published behind the k | v products)
         float v[1][16];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const f16x2 h0 = as_f16x2(p[j].x), h1 = as_f16x2(p[j].z);
-          v[0][4 * j] = (float)h0.x; v[0][4 * j + 1] = (float)h0.y; v[0][4 * j + 2] = (float)h1.x; v[0][4 * j + 3] = (float)h1.y;
-        }
+        gather16(zq, ebase | hop, 0x5000u, v[0]);
+        BSTAMP(4);
         hadw::fwd<13, 1, true>(v, xbuf, tid);
         {
           float val = v[0][0];
@@ -598,6 +567,25 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
           for (int k = 1; k < 16; ++k) val = kreg == k ? v[0][k] : val;
           if (mine) s_qkv[tloc] = had::out_elem(val, kOutScaleH, true, (float)psvq, false, 0.f, false, 0.f);
         }
+        u32x4_t pk[4];
+        if (kvw) {
+          uint32_t spins = 0;
+          const uint64_t* srck = ((wave & 1) ? zv : zk) + 8 * lane;
+          const uint32_t tag = ebase | hop;
+          for (;;) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) esync::ld16(pk[j], srck + 2 * j);
+            esync::drain();
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              esync::own(pk[j]);
+              ok = ok && pk[j].y == tag && pk[j].w == tag;
+            }
+            if (esync::spin_step(ok, spins, ctl + 1, 0x9000u + (uint32_t)w)) break;
+          }
+        }
+        own_ring();
         if (kvw) {
           float kv[16], svf[16];
 #pragma unroll
@@ -803,7 +791,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
 
     // ================= o's output side + residual, RMSNorm, input transforms of gate / up; their products ===================
     rederive();
-    edge(IC<2>{}, zo, ebase | hop, 0x7000u, Ld.sv[3], Ld.ln[1], Ld.su[4], Ld.su[5], Ld.sc[4], Ld.sc[5], true, 3, 20);
+    edge(IC<2>{}, zo, ebase | hop, 0x7000u, Ld.sv[3], Ld.ln[1], Ld.su[4], Ld.su[5], Ld.sc[4], Ld.sc[5], true, 3, 23);
     BSTAMP(10);
     rederive();
     {
@@ -882,8 +870,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
           v[jj >> 2][2 * (jj & 3) + 1] = as_f32(pc[jj].z);
         }
       }
-      BSTAMP(25);
+      BSTAMP(28);
       had8::fht4096<2, true>(v, xbuf, tid);
+      BSTAMP(29);
       float e[1][8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -891,7 +880,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
         const float ou = (float)had::out_elem(v[1][j], 1.f / 64.f, true, (float)__builtin_bit_cast(f16, psu_[j]), false, 0.f, false, 0.f);
         e[0][j] = had::fmul(had::fmul(ou, had::silu(og)), (float)__builtin_bit_cast(f16, psd[j]));
       }
+      BSTAMP(30);
       hadw::rev<12, 1, true>(e, xbuf, tid);
+      BSTAMP(31);
       constexpr float kPre = 1.f / 64.f;
       float mxr = 0.f;
       uint32_t pk[8];
@@ -900,9 +891,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
         const float vv = e[0][r] * kPre;
         const float av = fabsf(vv);
         mxr = fmaxf(mxr, av == av ? av : __builtin_inff());
-        const f16 hi = (f16)vv;
-        const f16 lo = (f16)(vv - (float)hi);
-        pk[r] = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
+        pk[r] = as_u32(vv);
       }
       uint64_t* dst = frow + (size_t)w * FL + 8 * tid;
 #pragma unroll
@@ -969,26 +958,22 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
         float e[FK][4];
 #pragma unroll
         for (int k = 0; k < FK; ++k) {
-          const uint32_t ww[4] = {p[k][0].x, p[k][0].z, p[k][1].x, p[k][1].z};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const f16x2 hl = as_f16x2(ww[j]);
-            e[k][j] = (float)hl.x + (float)hl.y;
-          }
+          e[k][0] = as_f32(p[k][0].x); e[k][1] = as_f32(p[k][0].z); e[k][2] = as_f32(p[k][1].x); e[k][3] = as_f32(p[k][1].z);
         }
 #pragma unroll
         for (int kp = 0; kp < FK; ++kp) {
           // row kp of down.had_left^T: uniform, from LDS (broadcast reads) into scalar registers for this row only
           float rt[FK];
 #pragma unroll
-          for (int k = 0; k < FK; ++k) rt[k] = as_f32((uint32_t)__builtin_amdgcn_readfirstlane((int)as_u32(mixf[(14 + kp) * 8 + k])));
+          for (int k = 0; k < FK; ++k)      // (the scale 2^sh * wscale rides in the coefficients)
+            rt[k] = as_f32((uint32_t)__builtin_amdgcn_readfirstlane((int)as_u32(had::fmul(mixf[(14 + kp) * 8 + k], s2))));
           int X[4], X1[4], H[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float x = 0.f;
 #pragma unroll
             for (int k = 0; k < FK; ++k) x = __builtin_fmaf(rt[k], e[k][j], x);
-            X[j] = (int)__builtin_rintf(had::fmul(x, s2));
+            X[j] = (int)__builtin_rintf(x);
             X1[j] = (X[j] + 128) >> 8;
             H[j] = (X1[j] + 128) >> 8;
           }

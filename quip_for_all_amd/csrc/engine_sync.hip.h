@@ -28,10 +28,12 @@ __device__ __forceinline__ void st_granule(void* p, uint32_t value, uint32_t tag
 }
 __device__ __forceinline__ void st_granule2(void* p, uint32_t v0, uint32_t v1, uint32_t tag) {   // two granules, 16 B
   const u32x4_t v = {v0, tag, v1, tag};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+  // (s_nop 1: a VMEM store of more than 8 bytes reads its data registers over two more cycles, and the compiler pads no
+  //  hazard for an instruction inside an asm statement: the VALU instruction behind it could overwrite them)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void st_payload16(void* p, const u32x4_t& v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void st_word(void* p, uint32_t v) {
   asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");

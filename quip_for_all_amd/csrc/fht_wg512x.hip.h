@@ -16,15 +16,32 @@
 namespace quip {
 namespace hadw {
 
+// two butterflies per instruction (v_pk_add_f32 on the register pairs (v[2 i], v[2 i + 1])): the IEEE additions of the
+// one-at-a-time form (had_device.hip.h, FhtPass::butterflies), half the issue slots -- the transforms are VALU bound
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int N, int STRIDE>
 __device__ __forceinline__ void reg_stage(float (&v)[N]) {
 #pragma clang fp contract(off)
+  if constexpr (STRIDE == 1) {
 #pragma unroll
-  for (int r = 0; r < N; ++r) {
-    if (!(r & STRIDE)) {
-      const float x0 = v[r], x1 = v[r | STRIDE];
-      v[r] = x0 + x1;
-      v[r | STRIDE] = x0 - x1;
+    for (int r = 0; r < N; r += 2) {      // partners inside a pair: (a + b, a - b)
+      const f32x2 a = {v[r], v[r]}, b = {v[r + 1], -v[r + 1]};
+      const f32x2 c = a + b;
+      v[r] = c.x;
+      v[r + 1] = c.y;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < N; r += 2) {
+      if (!(r & STRIDE)) {
+        const int q = r | STRIDE;
+        const f32x2 x0 = {v[r], v[r + 1]}, x1 = {v[q], v[q + 1]};
+        const f32x2 p = x0 + x1, m = x0 - x1;
+        v[r] = p.x;
+        v[r + 1] = p.y;
+        v[q] = m.x;
+        v[q + 1] = m.y;
+      }
     }
   }
 }
@@ -39,8 +56,14 @@ template <int N, int S>
 __device__ __forceinline__ void lane_stage(float (&v)[N], int lane) {
 #pragma clang fp contract(off)
   const float sg = ((lane >> S) & 1) ? -1.f : 1.f;     // bit clear: own + partner; bit set: partner - own
+  const f32x2 sg2 = {sg, sg};
 #pragma unroll
-  for (int r = 0; r < N; ++r) v[r] = __builtin_fmaf(v[r], sg, had8::lane_partner<S>(v[r], lane));
+  for (int r = 0; r < N; r += 2) {
+    const f32x2 own = {v[r], v[r + 1]}, par = {had8::lane_partner<S>(v[r], lane), had8::lane_partner<S>(v[r + 1], lane)};
+    const f32x2 w = __builtin_elementwise_fma(own, sg2, par);
+    v[r] = w.x;
+    v[r + 1] = w.y;
+  }
 }
 template <int N, int S, int END>
 __device__ __forceinline__ void lane_stages(float (&v)[N], int lane) {     // lane bits S .. END - 1
