@@ -82,7 +82,7 @@ constexpr size_t kWsCtl = 0;
 constexpr size_t kWsZq = 64, kWsZk = kWsZq + (HID / 2) * 8, kWsZv = kWsZk + (NKV * HD / 2) * 8;
 constexpr size_t kWsA = kWsZv + (NKV * HD / 2) * 8, kWsZo = kWsA + (HID / 2) * 8, kWsZd = kWsZo + (HID / 2) * 8;
 constexpr size_t kWsInbox = kWsZd + (HID / 2) * 8;                    // [FK][2][FL] granules (fp32 payload)
-constexpr size_t kWsRows = kWsInbox + (size_t)FK * 2 * FL * 8;        // [FK][FL] granules (fp32 payload)
+constexpr size_t kWsRows = kWsInbox + (size_t)FK * 2 * FL * 8;        // [FK][FL / 2] granules (two 24-bit values each)
 constexpr size_t kWsRowMax = kWsRows + (size_t)FK * FL * 8;           // [8] granules
 constexpr size_t kWsPart = kWsRowMax + 64;                            // [NH][kParts][132]
 constexpr size_t kWsBytes = kWsPart + (size_t)NH * kParts * kPartGran * 8;
@@ -883,20 +883,33 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
       BSTAMP(30);
       hadw::rev<12, 1, true>(e, xbuf, tid);
       BSTAMP(31);
+      // the chunk goes out as 24-bit fixed point against its own maximum, TWO values per granule {a | b << 24, b >> 8 | tag16 << 16}
+      // (half the bytes of the sweep every workgroup makes; 2^-23 of the maximum: finer than the digits made of it).  The tag's
+      // low 16 bits suffice here: every granule of the rows is rewritten in every block, so a stale one carries the tag of the
+      // block before, which differs in the hand-off index.
       constexpr float kPre = 1.f / 64.f;
       float mxr = 0.f;
-      uint32_t pk[8];
+      float vv[8];
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        const float vv = e[0][r] * kPre;
-        const float av = fabsf(vv);
+        vv[r] = e[0][r] * kPre;
+        const float av = fabsf(vv[r]);
         mxr = fmaxf(mxr, av == av ? av : __builtin_inff());
-        pk[r] = as_u32(vv);
       }
-      uint64_t* dst = frow + (size_t)w * FL + 8 * tid;
-#pragma unroll
-      for (int r = 0; r < 8; r += 2) esync::st_granule2(dst + r, pk[r], pk[r + 1], tag2);
       mxr = wg_max(mxr);
+      const float inv = (mxr > 0.f && mxr < __builtin_inff()) ? 8388607.f / mxr : 0.f;
+      uint32_t pk[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r)       // (clamped: maximum * fl(8388607 / maximum) may round to 2^23, which would wrap to -2^23)
+        pk[r] = (uint32_t)min(max((int)__builtin_rintf(vv[r] * inv), -8388607), 8388607);
+      const uint32_t t16 = (tag2 & 0xffffu) << 16;
+      uint64_t* dst = frow + (size_t)w * (FL / 2) + 4 * tid;
+#pragma unroll
+      for (int r = 0; r < 8; r += 4) {
+        const u32x4_t piece = {(pk[r] & 0xffffffu) | (pk[r + 1] << 24), ((pk[r + 1] >> 8) & 0xffffu) | t16,
+                               (pk[r + 2] & 0xffffffu) | (pk[r + 3] << 24), ((pk[r + 3] >> 8) & 0xffffu) | t16};
+        esync::st_payload16(dst + r / 2, piece);
+      }
       if (tid == 0) esync::st_granule(rowmax + w, as_u32(mxr), tag2);
       had::wg_barrier<true>();
     }
@@ -912,7 +925,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
         esync::own(f);
         if (esync::spin_step(f.y == tag2, spins0, ctl + 1, 0x3000u + (uint32_t)w)) break;
       }
-      if (lane < FK) red[32 + lane] = as_f32(f.x);
+      if (lane < FK) { red[32 + lane] = as_f32(f.x); red[40 + lane] = as_f32(f.x) * (1.f / 8388607.f); }
     }
     had::wg_barrier<false>();
     own_ring();
@@ -932,41 +945,50 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     {
       const float s2 = had::fmul(in_scale, as_f32((uint32_t)(sh_d + 127) << 23));
       uint8_t* pl = reinterpret_cast<uint8_t*>(smem + B::kArea);
-#pragma unroll 1
-      for (int c = 0; c < 2; ++c) {
-        // columns [4 (t + 512 c), +4) of the seven rows: two 16-byte pieces each
-        u32x4_t p[FK][2];
-        uint32_t spins = 0;
-        const int col = 4 * (tid + 512 * c);
-        for (;;) {
+      const uint32_t t16 = tag2 & 0xffffu;
+      // columns [4 (t + 512 c), +4) of the seven rows = one 16-byte piece (two granules) per row; chunk 1 is in flight while
+      // chunk 0 is mixed
+      u32x4_t p0[FK], p1[FK];
+      auto request = [&](u32x4_t (&p)[FK], int c) __attribute__((always_inline)) {
 #pragma unroll
-          for (int k = 0; k < FK; ++k) {
-            esync::ld16(p[k][0], frow + (size_t)k * FL + col);
-            esync::ld16(p[k][1], frow + (size_t)k * FL + col + 2);
-          }
-          esync::drain();
-          bool ok = true;
+        for (int k = 0; k < FK; ++k) esync::ld16(p[k], frow + (size_t)k * (FL / 2) + 2 * (tid + 512 * c));
+      };
+      auto landed = [&](u32x4_t (&p)[FK]) __attribute__((always_inline)) -> bool {          // after a drain
+        bool ok = true;
 #pragma unroll
-          for (int k = 0; k < FK; ++k) {
-            esync::own(p[k][0]);
-            esync::own(p[k][1]);
-            ok = ok && p[k][0].y == tag2 && p[k][0].w == tag2 && p[k][1].y == tag2 && p[k][1].w == tag2;
-          }
-          if (esync::spin_step(ok, spins, ctl + 1, 0x2000u + (uint32_t)w)) break;
+        for (int k = 0; k < FK; ++k) {
+          esync::own(p[k]);
+          ok = ok && (p[k].y >> 16) == t16 && (p[k].w >> 16) == t16;
         }
-        own_ring();
+        return ok;
+      };
+      auto poll = [&](u32x4_t (&p)[FK], int c) __attribute__((always_inline)) {            // request, wait, check -- until every tag is there
+        uint32_t spins = 0;
+        for (;;) {
+          request(p, c);
+          esync::drain();
+          if (esync::spin_step(landed(p), spins, ctl + 1, 0x2000u + (uint32_t)w)) break;
+        }
+      };
+      auto mix = [&](const u32x4_t (&p)[FK], int c) __attribute__((always_inline)) {
         float e[FK][4];
 #pragma unroll
         for (int k = 0; k < FK; ++k) {
-          e[k][0] = as_f32(p[k][0].x); e[k][1] = as_f32(p[k][0].z); e[k][2] = as_f32(p[k][1].x); e[k][3] = as_f32(p[k][1].z);
+          e[k][0] = (float)((int)(p[k].x << 8) >> 8);
+          e[k][1] = (float)((int)(__builtin_amdgcn_alignbit(p[k].y, p[k].x, 24) << 8) >> 8);
+          e[k][2] = (float)((int)(p[k].z << 8) >> 8);
+          e[k][3] = (float)((int)(__builtin_amdgcn_alignbit(p[k].w, p[k].z, 24) << 8) >> 8);
         }
+        const int col = 4 * (tid + 512 * c);
 #pragma unroll
         for (int kp = 0; kp < FK; ++kp) {
-          // row kp of down.had_left^T: uniform, from LDS (broadcast reads) into scalar registers for this row only
+          // row kp of down.had_left^T times (2^sh wscale) times the chunk's step M_k / (2^23 - 1): uniform, from LDS into scalar
+          // registers for this row only
           float rt[FK];
 #pragma unroll
-          for (int k = 0; k < FK; ++k)      // (the scale 2^sh * wscale rides in the coefficients)
-            rt[k] = as_f32((uint32_t)__builtin_amdgcn_readfirstlane((int)as_u32(had::fmul(mixf[(14 + kp) * 8 + k], s2))));
+          for (int k = 0; k < FK; ++k)
+            rt[k] = as_f32((uint32_t)__builtin_amdgcn_readfirstlane(
+                (int)as_u32(had::fmul(had::fmul(mixf[(14 + kp) * 8 + k], s2), red[40 + k]))));
           int X[4], X1[4], H[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -982,7 +1004,14 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
           *reinterpret_cast<uint32_t*>(pl + B::PSD + off) = had::low_bytes4(X1[0], X1[1], X1[2], X1[3]);
           *reinterpret_cast<uint32_t*>(pl + 2 * B::PSD + off) = had::low_bytes4(X[0], X[1], X[2], X[3]);
         }
-      }
+      };
+      poll(p0, 0);
+      own_ring();
+      request(p1, 1);                                  // (no request may cross a loop's back edge: the first try of chunk 1 is straight-line code)
+      mix(p0, 0);
+      esync::drain();
+      if (!__all(landed(p1))) poll(p1, 1);
+      mix(p1, 1);
     }
     had::wg_barrier<true>();
     BSTAMP(15);
