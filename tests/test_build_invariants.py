@@ -151,6 +151,30 @@ def test_block_engine_kernels_use_no_scratch_and_touch_no_register_in_flight():
         assert check_inflight.check_kernel(lines) == [], name
 
 
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_gqa_block_engine_kernel_uses_no_scratch_and_touches_no_register_in_flight():
+    """decode_block_gqa.hip keeps a ring of nine weight requests per wave in flight through the whole launch and waits with
+    the constant `s_waitcnt vmcnt(16)`: no scratch (a spill is a VMEM operation the count does not know), no instruction on a
+    register a counted load is still going to write (tools/check_inflight.py follows every path with the in-order queue and
+    retires entries at each counted wait), and every ring request is the asm `global_load_dwordx4 ... nt` pair"""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import check_inflight
+    src = os.path.join(REPO, "quip_for_all_amd", "csrc", "decode_block_gqa.hip")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", "-", src,
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, check=True)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+    assert len(scratch) == 1 and scratch[0] == 0, scratch
+    kernels = [(n, l) for n, l in check_inflight.kernels_of(r.stdout) if "decode_block_gqa_kernel" in n]
+    assert len(kernels) == 1
+    name, lines = kernels[0]
+    assert check_inflight.check_kernel(lines) == [], name
+    waits = [l for l in lines if l.startswith("s_waitcnt") and "vmcnt(16)" in l]
+    assert len(waits) >= 54, len(waits)          # one per item of the sequence (the block loop's body is one iteration)
+    nt = [l for l in lines if "global_load_dwordx4" in l and " nt" in l]
+    assert len(nt) >= 2 * (54 + 9) and len(nt) % 2 == 0
+
+
 def test_inflight_checker_flags_a_copy_before_the_wait():
     """the checker itself, on a hand-written listing: a tied-operand copy ahead of the wait is reported, the same
     sequence with the wait first is clean, and a conditional skip of the wait is followed"""

@@ -1,0 +1,134 @@
+"""Persistent decode engine for the grouped-query 8192-wide shape (csrc/decode_block_gqa.hip: Llama-2-70B -- hidden 8192,
+64 heads of 128 on 8 KV heads, n_ffn = 7 x 4096): all decoder blocks of a token in one launch, against the stage-wise step
+of the same model and against the float64 model.  The launch runs its 8192-point input transforms in another order of the
+additions than the stand-alone kernels (strided -> natural, fht_wg512x.hip.h), mixes the 7 x 7 factors of the MLP in fp32 and
+takes the block exponent of down's input from a bound: the two paths agree to a few fp16 ulps of rms(logits), not bit for bit
+(the bounds below are twice the largest values observed on MI355X)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _decoder(layers, block_engine, max_len=48, seed=3, vocab=2048):
+    from quip_for_all_amd import decode as D
+    shape = D.LlamaShape(hidden=8192, ffn=28672, layers=layers, heads=64, kv_heads=8, vocab=vocab)
+    old = os.environ.get("QUIP_BLOCK_ENGINE")
+    os.environ["QUIP_BLOCK_ENGINE"] = "1" if block_engine else "0"
+    try:
+        dec = D.LlamaDecoder(shape, "E8P12", max_len=max_len, device=DEV, seed=seed, device_init=True)
+    finally:
+        if old is None:
+            os.environ.pop("QUIP_BLOCK_ENGINE", None)
+        else:
+            os.environ["QUIP_BLOCK_ENGINE"] = old
+    return dec
+
+
+def _same_weights(dst, src):
+    """the 7 x 7 factors are drawn from scipy's global generator (get_hadK, quant.py:26-39): copy them over"""
+    with torch.no_grad():
+        for Ld, Ls in zip(dst.layers, src.layers):
+            for k in ("gate", "up", "down"):
+                for name in ("had_left", "had_right"):
+                    if getattr(Ls[k], name) is not None:
+                        getattr(Ld[k], name).copy_(getattr(Ls[k], name))
+    if getattr(dst, "block_eng", False):
+        dst._init_block_engine()
+
+
+def _ulps(la, lb):
+    rms = lb.pow(2).mean().sqrt().item()
+    return (la - lb).abs().max().item() / 2.0 ** (np.floor(np.log2(rms)) - 10)
+
+
+@pytest.mark.parametrize("layers", [1, 3])
+def test_gqa_block_engine_matches_stagewise_step(layers):
+    a = _decoder(layers, True)
+    b = _decoder(layers, False)
+    _same_weights(a, b)
+    assert a.block_eng and a.eng_shape == 1 and not b.block_eng
+    for dec in (a, b):
+        dec.reset(first_token=7)
+    worst = 0.0
+    with torch.no_grad():
+        for t in range(6):
+            la = a.step().float().clone()
+            lb = b.step().float().clone()
+            assert a.engine_status() == 0
+            assert torch.isfinite(la).all()
+            worst = max(worst, _ulps(la, lb))
+            # (a near tie of the top two logits may go either way: keep the two decoders on the same token)
+            a.tok.copy_(b.tok)
+    print(f"{layers} block(s): max |logit difference| over 6 tokens = {worst:.2f} fp16 ulps of rms(logits)")
+    assert worst <= 20.0, worst                      # observed: 8 (1 block), 10 (3 blocks)
+    for ca, cb_ in ((a.kcache, b.kcache), (a.vcache, b.vcache)):
+        d = (ca[:, :, :6].float() - cb_[:, :, :6].float()).abs().max().item()
+        assert d <= 2.0 ** -6 * cb_[:, :, :6].float().abs().max().item(), d
+
+
+@pytest.mark.parametrize("pos0", [126, 127, 128, 300, 1021])
+def test_gqa_block_engine_long_context_split_attention(pos0):
+    """from 128 positions on the four workgroups of a head share its attention (every fourth position each, partial softmax
+    states merged at the head's first workgroup through one more hand-off); positions on both sides of the threshold"""
+    a = _decoder(2, True, max_len=1100)
+    b = _decoder(2, False, max_len=1100)
+    _same_weights(a, b)
+    g = torch.Generator(device=DEV).manual_seed(pos0)
+    for dec in (a, b):
+        dec.reset(first_token=7)
+    with torch.no_grad():
+        kc = (torch.randn(a.kcache[..., :pos0, :].shape, generator=g, device=DEV) * 0.5).half()
+        vc = (torch.randn(a.vcache[..., :pos0, :].shape, generator=g, device=DEV) * 0.5).half()
+        for dec in (a, b):
+            dec.kcache[..., :pos0, :].copy_(kc)
+            dec.vcache[..., :pos0, :].copy_(vc)
+            dec.pos.fill_(pos0)
+        for t in range(3):
+            la = a.step().float().clone()
+            lb = b.step().float().clone()
+            assert a.engine_status() == 0
+            p = pos0 + t
+            err = _ulps(la, lb)
+            print(f"position {p}: max |logit difference| = {err:.2f} fp16 ulps of rms(logits)")
+            assert err <= 20.0, (p, err)                 # observed: 8
+            for ca, cb_ in ((a.kcache, b.kcache), (a.vcache, b.vcache)):      # the new rows: written once, by one workgroup
+                d = (ca[:, :, p].float() - cb_[:, :, p].float()).abs().max().item()
+                assert d <= 2.0 ** -6 * cb_[:, :, p].float().abs().max().item(), d
+            a.tok.copy_(b.tok)
+    # nothing beyond the rows of the three new positions was written
+    assert torch.equal(a.kcache[..., :pos0, :], kc) and torch.equal(a.vcache[..., pos0 + 3:, :], b.vcache[..., pos0 + 3:, :])
+
+
+def test_gqa_block_engine_captured_generation_matches_stagewise_tokens():
+    a = _decoder(2, True, max_len=40)
+    b = _decoder(2, False, max_len=40)
+    _same_weights(a, b)
+    ta = a.generate(24, first_token=5, use_graph=True).cpu().numpy()
+    tb = b.generate(24, first_token=5, use_graph=True).cpu().numpy()
+    assert a.engine_status() == 0
+    same = int((ta == tb).sum())
+    print(f"greedy tokens equal: {same} / {len(ta)}")
+    first = int(np.argmax(ta != tb)) if same < len(ta) else len(ta)
+    assert first >= 8, (ta, tb)              # (a near tie may go the other way later on and the sequences part there)
+
+
+def test_full_size_70b_block_against_float64_model():
+    """ONE Llama-2-70B-shaped decoder block (hidden 8192, 64 / 8 heads, n_ffn 28672; random init, reduced vocabulary) for 3
+    decode steps through the captured step on the persistent launch, against the float64 model whose projections go through
+    the CPU oracle (qlinear.py:87-115, example_generate.py:28-33)"""
+    from tests.test_gpu_decode import _ref_logits, _ulps_of_rms
+    np.random.seed(7)
+    dec = _decoder(1, True, max_len=16, seed=5, vocab=1024)
+    assert dec.block_eng and dec.eng_shape == 1
+    toks = dec.generate(3, first_token=9, use_graph=True).cpu().numpy()
+    got = dec.step_logits.float().cpu().numpy()[0].astype(np.float64)
+    assert dec.engine_status() == 0
+    ref = _ref_logits(dec, [9, int(toks[0]), int(toks[1])])
+    u = _ulps_of_rms(got, ref)
+    print(f"70B-shaped block (E8P12), logits of step 3 vs float64: max {u:.2f} fp16 ulps of rms(logits) = {np.sqrt(np.mean(ref * ref)):.3f}")
+    assert u <= 6.0, u                        # observed: 2.58

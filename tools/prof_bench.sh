@@ -41,13 +41,13 @@ with open(f"{R}/gpurun_out/{tag}_bench_fetch_size.txt", "w") as f:
             print("%-100s %8d %16.1f %16.2f" % (name[:100], n, s, avg), file=f)
             if "e8p_gemv_mfma_kernel" in name or "e8p_gemv_v2_kernel" in name:
                 gsum += s; gcnt += n
-            if "decode_block_kernel" in name:
+            if "decode_block_kernel" in name or "decode_block_gqa_kernel" in name:
                 esum += s; ecnt += n
         if ecnt:
             raw = esum / ecnt
             j = {"counter": "FETCH_SIZE", "raw_mean_per_launch": raw, "unit_assumed": "KB", "gfx950_correction": 2.0,
                  "hbm_bytes_per_launch": raw * 1024 * 2.0, "dispatches": ecnt,
-                 "kernels": "decode_block_kernel dispatches of the run (one per token: all blocks)",
+                 "kernels": "decode_block[_gqa]_kernel dispatches of the run (one per token: all blocks)",
                  "measured_at": "round 4 (%s), tools/prof_bench.sh %s" % (tag, "$*"),
                  "source": "rocprofv3 --pmc FETCH_SIZE pass of bench.py, tools/prof_bench.sh"}
             print("# ENGINE:", json.dumps(j), file=f)
