@@ -108,6 +108,19 @@ struct GLds {
 };
 static_assert(GLds::kBytes <= 160 * 1024, "LDS budget");
 
+// The three balanced digits of X (had::digits_of) as bytes, without the shifts: l = byte 0 of X, m = byte 0 of (X + 128) >> 8 =
+// byte 1 of X + 0x80, h = byte 0 of (((X + 128) >> 8) + 128) >> 8 = byte 2 of X + 0x8080.  Byte B of four values -> one word.
+template <int BYTE>
+__device__ __forceinline__ uint32_t bytes4(int a, int b, int c, int d) {
+  constexpr uint32_t lo = 0x0c0c0400u + BYTE * 0x0101u, hi = 0x04000c0cu + BYTE * 0x01010000u;
+  return __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, lo) | __builtin_amdgcn_perm((uint32_t)d, (uint32_t)c, hi);
+}
+__device__ __forceinline__ void digit_words(const int (&X)[4], uint32_t& h, uint32_t& m, uint32_t& l) {
+  l = bytes4<0>(X[0], X[1], X[2], X[3]);
+  m = bytes4<1>(X[0] + 0x80, X[1] + 0x80, X[2] + 0x80, X[3] + 0x80);
+  h = bytes4<2>(X[0] + 0x8080, X[1] + 0x8080, X[2] + 0x8080, X[3] + 0x8080);
+}
+
 template <int I> using IC = std::integral_constant<int, I>;
 template <class F, int... Is>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(IC<Is>{}), ...); }
@@ -349,11 +362,20 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     for (int i = tid; i < rows * 4; i += kThreads) accs[row0 * 4 + i] = 0;
   };
   // digit planes of a transformed vector held in natural order (16 consecutive values per thread): three 16-byte pieces
-  auto planes_nat = [&](const float (&v)[16], float scale, int sh, uint32_t base) {
-    uint4 out[3];
-    had::planes16(v, scale, sh, out);
+  auto planes_nat = [&](const float (&v)[16], float scale, int sh, uint32_t base) __attribute__((always_inline)) {
+#pragma clang fp contract(off)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const float s2 = had::fmul(scale, as_f32((uint32_t)(sh + 127) << 23));
+    uint32_t dg[3][4];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) *reinterpret_cast<uint4*>(smem + base + d * B::PSH + 16 * tid) = out[d];
+    for (int g = 0; g < 4; ++g) {
+      const f32x2 p01 = f32x2{v[4 * g], v[4 * g + 1]} * f32x2{s2, s2}, p23 = f32x2{v[4 * g + 2], v[4 * g + 3]} * f32x2{s2, s2};
+      const int X[4] = {(int)__builtin_rintf(p01.x), (int)__builtin_rintf(p01.y), (int)__builtin_rintf(p23.x), (int)__builtin_rintf(p23.y)};
+      digit_words(X, dg[0][g], dg[1][g], dg[2][g]);
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+      *reinterpret_cast<uint4*>(smem + base + d * B::PSH + 16 * tid) = make_uint4(dg[d][0], dg[d][1], dg[d][2], dg[d][3]);
   };
   // the same from the strided layout (values X[t + 512 k]): bytes
   auto planes_str = [&](const float (&v)[16], float scale, int sh, uint32_t base) {
@@ -362,11 +384,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int X = (int)__builtin_rintf(v[k] * s2);
-      const int X1 = (X + 128) >> 8;
-      const int H = (X1 + 128) >> 8;
       uint8_t* p = reinterpret_cast<uint8_t*>(smem + base) + tid + 512 * k;
-      p[0] = (uint8_t)H;
-      p[B::PSH] = (uint8_t)X1;
+      p[0] = (uint8_t)((X + 0x8080) >> 16);
+      p[B::PSH] = (uint8_t)((X + 0x80) >> 8);
       p[2 * B::PSH] = (uint8_t)X;
     }
   };
@@ -423,7 +443,14 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
         e[2 * j] = (float)hh.x;
         e[2 * j + 1] = (float)hh.y;
       }
-      const float tot = hadw::sumsq<16, true>(e, red, tid);
+      // (the sum of squares is needed for the scale only: it is reduced together with the maxima behind the transform)
+      float ssw = 0.f;
+      {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ssw = __builtin_fmaf(e[r], e[r], ssw);
+        ssw = had::wave_reduce_to_lane63<false>(ssw);
+      }
       ESTAMP(2);
       {
         float lnf[16];
@@ -431,6 +458,12 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) e[k] = had::fmul(e[k], lnf[k]);
       }
+      auto total = [&]() __attribute__((always_inline)) {          // after the barrier pair: the eight waves' sums in order
+        float r = red[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) r = had::fadd(r, red[i]);
+        return r;
+      };
       if (two) {
         float v[2][16], s0f[16], s1f[16];
         unpack16(ps0, s0f);
@@ -442,8 +475,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
         float mx0 = had::wave_reduce_to_lane63<true>(hadw::absmax<16>(v[0], 1.f));
         float mx1 = had::wave_reduce_to_lane63<true>(hadw::absmax<16>(v[1], 1.f));
         had::wg_barrier<true>();
-        if (lane == 63) { red[16 + wave] = mx0; red[24 + wave] = mx1; }
+        if (lane == 63) { red[wave] = ssw; red[16 + wave] = mx0; red[24 + wave] = mx1; }
         had::wg_barrier<true>();
+        const float tot = total();
         mx0 = red[16]; mx1 = red[24];
 #pragma unroll
         for (int i = 1; i < 8; ++i) { mx0 = fmaxf(mx0, red[16 + i]); mx1 = fmaxf(mx1, red[24 + i]); }
@@ -459,7 +493,14 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
         for (int k = 0; k < 16; ++k) v[0][k] = had::fmul(e[k], s0f[k]);
         hadw::rev<13, 1, true>(v, xbuf, tid);
         ESTAMP(3);
-        const float mx0 = wg_max(hadw::absmax<16>(v[0], 1.f));
+        float mx0 = had::wave_reduce_to_lane63<true>(hadw::absmax<16>(v[0], 1.f));
+        had::wg_barrier<true>();
+        if (lane == 63) { red[wave] = ssw; red[16 + wave] = mx0; }
+        had::wg_barrier<true>();
+        const float tot = total();
+        mx0 = red[16];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) mx0 = fmaxf(mx0, red[16 + i]);
         const float s0 = had::rms_scale(sc0, tot, HID, a.rms_eps);
         const int h0 = had::shift_for(had::fmul(mx0, fabsf(s0)));
         planes_nat(v[0], s0, h0, (uint32_t)B::kArea);
@@ -525,9 +566,6 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     const bool head_wg = part == 0;
     const int hd = w >> 2, kvh = hd / GQ;
     if (head_wg || split) {
-      const int kreg = hd >> 2, tloc = tid - 128 * (hd & 3);
-      const bool mine = tloc >= 0 && tloc < HD;
-      const f16 psvq = Ld.sv[0][mine ? HD * hd + tloc : 0];
       // wave 0 / 1: the k / v vector (1024 values, 16 per lane), SV of this KV head's values
       const bool kvw = wave < 2;
       const f16* svkv = Ld.sv[1 + (wave & 1)];
@@ -560,12 +598,35 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
         float v[1][16];
         gather16(zq, ebase | hop, 0x5000u, v[0]);
         BSTAMP(4);
-        hadw::fwd<13, 1, true>(v, xbuf, tid);
+        // Only this head's 128 values of H_8192 z are needed: H_8192 = H_64 (x) H_128, so u[j2] = sum_j1 H_64[hd][j1] z[128 j1 + j2]
+        // (signed sums of the 64 segments), then a 128-point transform of u in one wave -- instead of the whole 8192-point
+        // transform in every head's workgroup.  Thread t holds z[16 t + r]: j1 = t >> 3, j2 = 16 (t & 7) + r.
         {
-          float val = v[0][0];
+          const float sgn = (__builtin_popcount((uint32_t)hd & (uint32_t)(tid >> 3)) & 1) ? -1.f : 1.f;
+          float u[16];
 #pragma unroll
-          for (int k = 1; k < 16; ++k) val = kreg == k ? v[0][k] : val;
-          if (mine) s_qkv[tloc] = had::out_elem(val, kOutScaleH, true, (float)psvq, false, 0.f, false, 0.f);
+          for (int r = 0; r < 16; ++r) u[r] = had::fadd(v[0][r] * sgn, had::lane_xor<3>(v[0][r] * sgn));      // lane bit 3 = j1 bit 0
+          had::wg_barrier<true>();
+          if ((lane & 8) == 0) {
+            float* dstp = xbuf + ((wave * 4 + (lane >> 4)) * 128 + (lane & 7) * 16);
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) *reinterpret_cast<float4*>(dstp + r) = float4{u[r], u[r + 1], u[r + 2], u[r + 3]};
+          }
+          had::wg_barrier<true>();
+          if (wave == 0) {
+            float y[2] = {0.f, 0.f};
+#pragma unroll
+            for (int gg = 0; gg < 32; ++gg) {
+              const float2 pr = *reinterpret_cast<const float2*>(xbuf + gg * 128 + 2 * lane);
+              y[0] = had::fadd(y[0], pr.x);
+              y[1] = had::fadd(y[1], pr.y);
+            }
+            hadw::reg_stage<2, 1>(y);
+            hadw::lane_stages<2, 0, 6>(y, lane);
+            const f16x2 svq = as_f16x2(*reinterpret_cast<const uint32_t*>(Ld.sv[0] + HD * hd + 2 * lane));
+            s_qkv[2 * lane] = had::out_elem(y[0], kOutScaleH, true, (float)svq.x, false, 0.f, false, 0.f);
+            s_qkv[2 * lane + 1] = had::out_elem(y[1], kOutScaleH, true, (float)svq.y, false, 0.f, false, 0.f);
+          }
         }
         u32x4_t pk[4];
         if (kvw) {
@@ -989,20 +1050,20 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
           for (int k = 0; k < FK; ++k)
             rt[k] = as_f32((uint32_t)__builtin_amdgcn_readfirstlane(
                 (int)as_u32(had::fmul(had::fmul(mixf[(14 + kp) * 8 + k], s2), red[40 + k]))));
-          int X[4], X1[4], H[4];
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          f32x2 x01 = {0.f, 0.f}, x23 = {0.f, 0.f};
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float x = 0.f;
-#pragma unroll
-            for (int k = 0; k < FK; ++k) x = __builtin_fmaf(rt[k], e[k][j], x);
-            X[j] = (int)__builtin_rintf(x);
-            X1[j] = (X[j] + 128) >> 8;
-            H[j] = (X1[j] + 128) >> 8;
+          for (int k = 0; k < FK; ++k) {
+            x01 = __builtin_elementwise_fma(f32x2{rt[k], rt[k]}, f32x2{e[k][0], e[k][1]}, x01);
+            x23 = __builtin_elementwise_fma(f32x2{rt[k], rt[k]}, f32x2{e[k][2], e[k][3]}, x23);
           }
+          const int X[4] = {(int)__builtin_rintf(x01.x), (int)__builtin_rintf(x01.y), (int)__builtin_rintf(x23.x), (int)__builtin_rintf(x23.y)};
+          uint32_t dh, dm, dl;
+          digit_words(X, dh, dm, dl);
           const int off = kp * FL + col;
-          *reinterpret_cast<uint32_t*>(pl + off) = had::low_bytes4(H[0], H[1], H[2], H[3]);
-          *reinterpret_cast<uint32_t*>(pl + B::PSD + off) = had::low_bytes4(X1[0], X1[1], X1[2], X1[3]);
-          *reinterpret_cast<uint32_t*>(pl + 2 * B::PSD + off) = had::low_bytes4(X[0], X[1], X[2], X[3]);
+          *reinterpret_cast<uint32_t*>(pl + off) = dh;
+          *reinterpret_cast<uint32_t*>(pl + B::PSD + off) = dm;
+          *reinterpret_cast<uint32_t*>(pl + 2 * B::PSD + off) = dl;
         }
       };
       poll(p0, 0);
