@@ -10,8 +10,8 @@
 //     (18 KB per wave, 147 KB per CU) are always requested ahead, across products, hand-offs and blocks, and "slot s has
 //     landed" is the constant `s_waitcnt vmcnt(16)`.  The queue is empty after every hand-off's gather (its polls drain
 //     it), in particular at the block loop's back edge, where the compiler is free to copy registers.
-//   * Row ownership: q / o / down rows [32 w, +32) (two row blocks); k | v: row block w >> 1 of the stacked [k; v] rows
-//     on the odd workgroups; gate / up rows k * 4096 + 16 w + i, k < 7 (seven row blocks: COLUMNS [16 w, +16) of the
+//   * Row ownership: o / down rows [32 w, +32) (two row blocks); k | v: row block w >> 1 of the stacked [k; v] rows on the odd
+//     workgroups; q: rows [64 p, +64) per PAIR of workgroups, three row blocks on the even one, one on the odd one; gate / up rows k * 4096 + 16 w + i, k < 7 (seven row blocks: COLUMNS [16 w, +16) of the
 //     (7, 4096) view, so the 7 x 7 mix of the output transform is local to the workgroup).
 //   * 8192-point transforms on 512 threads x 16 elements with one LDS exchange, in two directions (fht_wg512x.hip.h):
 //     gather (natural order) -> fwd -> residual / RMSNorm / SU in the strided layout (the static vectors are stored
@@ -71,8 +71,10 @@ constexpr int FK = 7, FL = 4096, NFFN = FK * FL;
 constexpr int EPT = HID / kThreads;                 // 16 elements per thread
 constexpr int kRowH = HID / 4, kRowF = NFFN / 4;    // bytes of a weight row (hidden- / ffn-wide input)
 constexpr int NS = 9, NSEQ = 54;                    // ring slots, items per wave and block
-// item sequence of an iteration: [0, 4) o | [4, 32) gate / up | [32, 46) down | 46, 47 fillers | [48, 52) q | 52, 53 k | v
-constexpr int SQ_O = 0, SQ_GU = 4, SQ_D = 32, SQ_F = 46, SQ_Q = 48, SQ_KV = 52;
+// item sequence of an iteration: [0, 4) o | [4, 32) gate / up | [32, 46) down | 46, 47 fillers | [48, 54) k | v and q
+constexpr int SQ_O = 0, SQ_GU = 4, SQ_D = 32, SQ_F = 46, SQ_A = 48, SQ_B = 50;
+// [48, 50): slot A = the k | v row block (odd workgroups) or a third q row block (even ones), slices i = 0, 1;
+// [50, 54): slot B = q row blocks 0 / 1 x slices 0, 1 (odd workgroups: their one q row block; row block 1 is a filler)
 static_assert(NSEQ % NS == 0, "the ring position of an item is the same in every block");
 constexpr float kOutScaleH = 0.011048543456039806f;  // 1 / sqrt(8192)
 constexpr int kParts = 4, kPartGran = 132, kSplitPos = 128;
@@ -155,14 +157,18 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
 
   // ---- the weight ring ----------------------------------------------------------------------------------------------
   u32x4 qa[NS], qb[NS];
-  uint32_t vo_h, vo_kv, vo_gu, vo_d, vo_hot;
+  uint32_t vo_h, vo_qa, vo_qb, vo_qb1, vo_gu, vo_d, vo_hot;
   uint32_t lane_c, lane_c2;
   auto rederive = [&]() __attribute__((always_inline)) {
     int t = threadIdx.x;
     asm volatile("" : "+v"(t));
     tid = t; lane = t & 63; n = lane & 15; q = lane >> 4;
     vo_h = (uint32_t)((32 * w + n) * kRowH + (wave * 8 + q) * 16);
-    vo_kv = has_kv ? (uint32_t)((16 * (kvb & 63) + n) * kRowH + (wave * 8 + q) * 16) : (uint32_t)((lane & 31) * 16);
+    // q rows: the pair of workgroups (2 p, 2 p + 1) owns rows [64 p, +64): three row blocks on the even one (it has no k | v
+    // rows), one on the odd one -- the odd workgroups' extra transform and k | v items no longer make them the last to publish
+    vo_qb = (uint32_t)((64 * (w >> 1) + (has_kv ? 48 : 0) + n) * kRowH + (wave * 8 + q) * 16);
+    vo_qa = has_kv ? (uint32_t)((16 * (kvb & 63) + n) * kRowH + (wave * 8 + q) * 16) : vo_qb + (uint32_t)(32 * kRowH);
+    vo_qb1 = has_kv ? (uint32_t)((lane & 31) * 16) : vo_qb + (uint32_t)(16 * kRowH);
     vo_gu = (uint32_t)((16 * w + n) * kRowH + (wave * 8 + q) * 16);
     vo_d = (uint32_t)((32 * w + n) * kRowF + (wave * 8 + q) * 16);
     vo_hot = (uint32_t)((lane & 31) * 16);     // (the hot 2 KB: offsets < 496 + 1024 + 80)
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
   };
   rederive();
   // uniform matrix bases of the stream: this block's o, gate, up, down; the next block's q, k | v, o; a hot 2 KB
-  const uint4 *pw_o, *pw_g, *pw_u, *pw_d, *pw_q, *pw_kv, *pw_o2, *pw_hot;
+  const uint4 *pw_o, *pw_g, *pw_u, *pw_d, *pw_q, *pw_qa, *pw_qb1, *pw_o2, *pw_hot;
   auto uni = [](const void* p) -> const uint4* {
     const uint64_t v = reinterpret_cast<uint64_t>(p);
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
@@ -185,25 +191,25 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     constexpr bool wrap = TT >= NSEQ;
     const uint4* base;
     uint32_t vo;
-    constexpr int u_gu = t - SQ_GU, u_d = t - SQ_D, u_q = t - SQ_Q;
+    constexpr int u_gu = t - SQ_GU, u_d = t - SQ_D, u_q = t - SQ_B;
     constexpr int off = t < SQ_GU ? (t & 1) * 16 * kRowH
                         : t < SQ_D ? (u_gu % 7) * FL * kRowH
                         : t < SQ_F ? (u_d & 1) * 16 * kRowF + ((u_d >> 1) >= 4 ? 4096 : 0)
-                        : t < SQ_Q ? 0
-                        : t < SQ_KV ? (u_q & 1) * 16 * kRowH : 0;
+                        : 0;
     constexpr int imm = t < SQ_GU ? (t >> 1) * 1024
                         : t < SQ_D ? ((u_gu / 7) >> 1) * 1024
                         : t < SQ_F ? ((u_d >> 1) & 3) * 1024
-                        : t < SQ_Q ? 0
-                        : t < SQ_KV ? (u_q >> 1) * 1024 : (t - SQ_KV) * 1024;
+                        : t < SQ_A ? 0
+                        : t < SQ_B ? (t - SQ_A) * 1024 : (u_q >> 1) * 1024;
     // (a wrapped request comes from the tail of an iteration: items 0..2 -- requested by down's last item and the fillers --
     //  belong to the NEXT block, items 3..8 -- requested by q and k | v at the top of the iteration -- to this one)
     if constexpr (t < SQ_GU) { base = (wrap && t < 3) ? pw_o2 : pw_o; vo = vo_h; }
     else if constexpr (t < SQ_D) { base = ((u_gu / 7) & 1) ? pw_u : pw_g; vo = vo_gu; }
     else if constexpr (t < SQ_F) { base = pw_d; vo = vo_d; }
-    else if constexpr (t < SQ_Q) { base = pw_hot; vo = vo_hot; }
-    else if constexpr (t < SQ_KV) { base = pw_q; vo = vo_h; }
-    else { base = pw_kv; vo = vo_kv; }
+    else if constexpr (t < SQ_A) { base = pw_hot; vo = vo_hot; }
+    else if constexpr (t < SQ_B) { base = pw_qa; vo = vo_qa; }
+    else if constexpr ((u_q & 1) == 0) { base = pw_q; vo = vo_qb; }
+    else { base = pw_qb1; vo = vo_qb1; }
     static_assert(!wrap || t < SQ_GU + 7, "a wrapped request stays inside o / gate");
     const uint4* bo = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + off);
     // s_nop: a scalar base fresh from v_readfirstlane / v_readlane needs 5 wait states before a VMEM instruction reads it,
@@ -307,12 +313,12 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
   // bases of the stream for the block whose descriptor sits in slot `cur` (o, gate, up, down) and the one in slot `nxt`
   auto set_bases = [&](const GLayer& C, const GLayer& N) __attribute__((always_inline)) {
     pw_o = uni(C.W[3]); pw_g = uni(C.W[4]); pw_u = uni(C.W[5]); pw_d = uni(C.W[6]);
-    pw_q = uni(N.W[0]); pw_kv = has_kv ? uni(N.W[1 + kvm]) : pw_hot; pw_o2 = uni(N.W[3]);
+    pw_q = uni(N.W[0]); pw_qa = has_kv ? uni(N.W[1 + kvm]) : pw_q; pw_qb1 = has_kv ? pw_hot : pw_q; pw_o2 = uni(N.W[3]);
   };
   set_bases(desc[0], desc[0]);
   // the ring's first nine items: q and k | v of block 0, its first three o items
-  issue(IC<SQ_Q>{}); issue(IC<SQ_Q + 1>{}); issue(IC<SQ_Q + 2>{}); issue(IC<SQ_Q + 3>{});
-  issue(IC<SQ_KV>{}); issue(IC<SQ_KV + 1>{});
+  issue(IC<SQ_A>{}); issue(IC<SQ_A + 1>{});
+  issue(IC<SQ_B>{}); issue(IC<SQ_B + 1>{}); issue(IC<SQ_B + 2>{}); issue(IC<SQ_B + 3>{});
   issue(IC<NSEQ>{}); issue(IC<NSEQ + 1>{}); issue(IC<NSEQ + 2>{});
 
   // ---- all-gather of an 8192-vector (4096 granules {2 x fp16, tag}): thread t takes elements [16 t, +16) ----------------
@@ -539,22 +545,34 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     rederive();
     {
       const uint32_t p0 = (uint32_t)B::kArea, p1 = (uint32_t)(B::kArea + 3 * B::PSH);
-      group(IC<SQ_Q>{}, IC<2>{}, xaddr(p0, B::PSH, 0), B::AQ);
-      group(IC<SQ_Q + 2>{}, IC<2>{}, xaddr(p0, B::PSH, 1), B::AQ);
-      had::wg_barrier<true>();
-      ++hop;                                           // hand-off: z_q, then z_k / z_v (the same index: they are different vectors)
-      // z_q goes out before the k | v items are multiplied: the heads transform q while the odd workgroups finish theirs
-      publish(zq, 16 * w, B::AQ, 16, shs[0], ebase | hop);
+      // slot A first: the k | v items (odd workgroups), so that z_k / z_v are on their way while q is multiplied
+      const uint32_t pa = has_kv ? p1 : p0;
       i32x4 A[8];
-      i32x4 acc = {0, 0, 0, 0};
-      item_fragments(xaddr(p1, B::PSH, 0), A);
-      consume(IC<SQ_KV>{}, A, acc, has_kv);
-      if (has_kv) item_fragments(xaddr(p1, B::PSH, 1), A);
-      consume(IC<SQ_KV + 1>{}, A, acc, has_kv);
-      if (has_kv) add_rows(acc, B::AKV);
+      {
+        i32x4 acc = {0, 0, 0, 0};
+        item_fragments(xaddr(pa, B::PSH, 0), A);
+        consume(IC<SQ_A>{}, A, acc, true);
+        item_fragments(xaddr(pa, B::PSH, 1), A);
+        consume(IC<SQ_A + 1>{}, A, acc, true);
+        add_rows(acc, B::AKV);
+      }
+      had::wg_barrier<true>();
+      ++hop;                                           // hand-off: z_k / z_v, then z_q (the same index: they are different vectors)
+      if (has_kv) publish(kvm ? zv : zk, 8 * (kvb & 63), B::AKV, 8, shs[1], ebase | hop);
+      static_for<2>([&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+        i32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+        item_fragments(xaddr(p0, B::PSH, I), A);
+        consume(IC<SQ_B + 2 * I>{}, A, acc0, true);
+        consume(IC<SQ_B + 2 * I + 1>{}, A, acc1, !has_kv);
+        add_rows(acc0, B::AQ);
+        if (!has_kv) add_rows(acc1, B::AQ + 16);
+      });
     }
     had::wg_barrier<true>();
-    if (has_kv) publish(kvm ? zv : zk, 8 * (kvb & 63), B::AKV, 8, shs[1], ebase | hop);
+    // rows [64 p, +48) (even workgroup: accumulator rows 0 .. 47) | [64 p + 48, +16) (odd one: rows 0 .. 15)
+    if (has_kv) publish(zq, 32 * (w >> 1) + 24, B::AQ, 8, shs[0], ebase | hop);
+    else publish(zq, 32 * (w >> 1), B::AQ, 24, shs[0], ebase | hop);
     had::wg_barrier<true>();
     zero_acc(B::AQ, 48);
     BSTAMP(3);
@@ -594,13 +612,50 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
       }
       f16* s_qkv = reinterpret_cast<f16*>(smem + B::kQkv);
       {
-        // gather z_q, transform it; z_k / z_v (waves 0 / 1) come a little later (published behind the k | v products)
+        // gather z_q (everybody) and z_k / z_v (waves 0 / 1: they went out first, ahead of the q items) in one poll
         float v[1][16];
-        gather16(zq, ebase | hop, 0x5000u, v[0]);
+        u32x4_t pk[4];
+        {
+          u32x4_t p[4];
+          uint32_t spins = 0;
+          const uint64_t* src = zq + 8 * tid;
+          const uint64_t* srck = ((wave & 1) ? zv : zk) + 8 * lane;
+          const uint32_t tag = ebase | hop;
+          for (;;) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) esync::ld16(p[j], src + 2 * j);
+            if (kvw) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) esync::ld16(pk[j], srck + 2 * j);
+            }
+            esync::drain();
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              esync::own(p[j]);
+              ok = ok && p[j].y == tag && p[j].w == tag;
+            }
+            if (kvw) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                esync::own(pk[j]);
+                ok = ok && pk[j].y == tag && pk[j].w == tag;
+              }
+            }
+            if (esync::spin_step(ok, spins, ctl + 1, 0x5000u + (uint32_t)w)) break;
+          }
+          own_ring();
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f16x2 h0 = as_f16x2(p[j].x), h1 = as_f16x2(p[j].z);
+            v[0][4 * j] = (float)h0.x; v[0][4 * j + 1] = (float)h0.y; v[0][4 * j + 2] = (float)h1.x; v[0][4 * j + 3] = (float)h1.y;
+          }
+        }
         BSTAMP(4);
         // Only this head's 128 values of H_8192 z are needed: H_8192 = H_64 (x) H_128, so u[j2] = sum_j1 H_64[hd][j1] z[128 j1 + j2]
-        // (signed sums of the 64 segments), then a 128-point transform of u in one wave -- instead of the whole 8192-point
-        // transform in every head's workgroup.  Thread t holds z[16 t + r]: j1 = t >> 3, j2 = 16 (t & 7) + r.
+        // (signed sums of the 64 segments), then a 128-point transform of u in one wave (wave 2; waves 0 / 1 transform k / v
+        // meanwhile) -- instead of the whole 8192-point transform in every head's workgroup.
+        // Thread t holds z[16 t + r]: j1 = t >> 3, j2 = 16 (t & 7) + r.
         {
           const float sgn = (__builtin_popcount((uint32_t)hd & (uint32_t)(tid >> 3)) & 1) ? -1.f : 1.f;
           float u[16];
@@ -612,41 +667,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r += 4) *reinterpret_cast<float4*>(dstp + r) = float4{u[r], u[r + 1], u[r + 2], u[r + 3]};
           }
-          had::wg_barrier<true>();
-          if (wave == 0) {
-            float y[2] = {0.f, 0.f};
-#pragma unroll
-            for (int gg = 0; gg < 32; ++gg) {
-              const float2 pr = *reinterpret_cast<const float2*>(xbuf + gg * 128 + 2 * lane);
-              y[0] = had::fadd(y[0], pr.x);
-              y[1] = had::fadd(y[1], pr.y);
-            }
-            hadw::reg_stage<2, 1>(y);
-            hadw::lane_stages<2, 0, 6>(y, lane);
-            const f16x2 svq = as_f16x2(*reinterpret_cast<const uint32_t*>(Ld.sv[0] + HD * hd + 2 * lane));
-            s_qkv[2 * lane] = had::out_elem(y[0], kOutScaleH, true, (float)svq.x, false, 0.f, false, 0.f);
-            s_qkv[2 * lane + 1] = had::out_elem(y[1], kOutScaleH, true, (float)svq.y, false, 0.f, false, 0.f);
-          }
         }
-        u32x4_t pk[4];
-        if (kvw) {
-          uint32_t spins = 0;
-          const uint64_t* srck = ((wave & 1) ? zv : zk) + 8 * lane;
-          const uint32_t tag = ebase | hop;
-          for (;;) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) esync::ld16(pk[j], srck + 2 * j);
-            esync::drain();
-            bool ok = true;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              esync::own(pk[j]);
-              ok = ok && pk[j].y == tag && pk[j].w == tag;
-            }
-            if (esync::spin_step(ok, spins, ctl + 1, 0x9000u + (uint32_t)w)) break;
-          }
-        }
-        own_ring();
         if (kvw) {
           float kv[16], svf[16];
 #pragma unroll
@@ -662,6 +683,21 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) dst[r] = had::out_elem(kv[r], 1.f / 32.f, true, svf[r], false, 0.f, false, 0.f);
           }
+        }
+        had::wg_barrier<true>();
+        if (wave == 2) {
+          float y[2] = {0.f, 0.f};
+#pragma unroll
+          for (int gg = 0; gg < 32; ++gg) {
+            const float2 pr = *reinterpret_cast<const float2*>(xbuf + gg * 128 + 2 * lane);
+            y[0] = had::fadd(y[0], pr.x);
+            y[1] = had::fadd(y[1], pr.y);
+          }
+          hadw::reg_stage<2, 1>(y);
+          hadw::lane_stages<2, 0, 6>(y, lane);
+          const f16x2 svq = as_f16x2(*reinterpret_cast<const uint32_t*>(Ld.sv[0] + HD * hd + 2 * lane));
+          s_qkv[2 * lane] = had::out_elem(y[0], kOutScaleH, true, (float)svq.x, false, 0.f, false, 0.f);
+          s_qkv[2 * lane + 1] = had::out_elem(y[1], kOutScaleH, true, (float)svq.y, false, 0.f, false, 0.f);
         }
       }
       had::wg_barrier<true>();
