@@ -479,7 +479,11 @@ int quip_ffn_engine(const quip_ffn_engine_args* args, quip_stream_t stream);
  * of the stage-wise step.  Shape: hidden 4096, 32 heads of 128 (multi-head), n_ffn = 43 x 256 (Llama-2-7B);
  * quip_block_engine_supported says so.  256 workgroups exchange data through `workspace` and must all be resident:
  * nothing else may occupy the device while the launch runs; launches sharing a workspace must be stream ordered.
- * Every wait is bounded; a launch that gives up leaves a non-zero code in workspace word 1.
+ * Every wait is bounded; a launch that gives up leaves a non-zero code in workspace word 1, answers all-NaN in h_out, and workspace
+ * word 2 keeps (*pos + 1) of the first such launch (a host can replay from there on another path after zeroing the workspace).
+ * Code 0xE000 in word 1 = the launch counter is about to wrap (after 2^22 launches on one workspace): zero the workspace.
+ * The launch is refused (QUIP_ERR_UNSUPPORTED) when the device cannot hold all 256 workgroups at once (fewer CUs, e.g. a CPX
+ * partition; occupancy query).
  * layers: n_layers descriptors of quip_block_engine_layer_bytes() = 256 bytes each, in device memory:
  *   uint64 W[7]   Qidxs of q, k, v, o, gate, up, down        uint64 ln[2]  input / post-attention RMSNorm weights (fp16)
  *   uint64 su[7]  SU of the same seven modules (fp16)          uint64 sv[7]  SV (fp16)
@@ -522,6 +526,10 @@ int quip_block_engine(const quip_block_engine_args* args, quip_stream_t stream);
  * One weight stream per wave runs through the whole launch (a ring of nine 2 KB requests always ahead of the products);
  * 7 workgroups own the 4096-point chunks of the MLP edge; from 128 positions on the four workgroups of a head share its
  * attention.  Same liveness rules as shape 0 (256 resident workgroups, bounded waits, workspace word 1). */
+/* Test helper (not part of the replaced interface): nwg single-wave workgroups that each hold lds_bytes of LDS -- above 80 KB a
+ * whole CU, as far as the persistent launches are concerned -- for `ticks` shader clocks, on `stream`.  The tests use it to
+ * share the device with a persistent launch and check that the launch gives up cleanly instead of hanging. */
+int quip_debug_occupy(int32_t nwg, int32_t lds_bytes, int64_t ticks, void* sink, quip_stream_t stream);
 int quip_block_engine_gqa_supported(int32_t hidden, int32_t heads, int32_t kv_heads, int32_t head_dim, int32_t n_ffn, int32_t K);
 size_t quip_block_engine_gqa_workspace_bytes(void);
 

@@ -20,6 +20,29 @@ int device_cu_count() {
   return cached[dev];
 }
 
+int device_cu_count_strict() {
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 0;
+  return v;
+}
+
+bool persistent_grid_fits(ResidencyCache& cache, const void* kernel, int threads, int lds, int nwg) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  const bool slot = dev >= 0 && dev < 16;
+  if (slot && cache.ok[dev] != 0) return cache.ok[dev] > 0;
+  bool fits = false;
+  const int cus = device_cu_count_strict();
+  int per_cu = 0;
+  // (one workgroup per CU is the design -- the LDS footprint admits no second one --, so a device with fewer CUs than
+  //  workgroups, e.g. a CPX partition or a CU-masked queue, cannot hold the grid whatever the occupancy query says)
+  if (cus >= nwg && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, (size_t)lds) == hipSuccess)
+    fits = (long long)per_cu * cus >= nwg;
+  if (slot) cache.ok[dev] = fits ? 1 : -1;
+  return fits;
+}
+
 int ensure_dyn_lds(DynLdsCache& cache, const void* kernel, int lds) {
   if (lds <= 48 * 1024) return QUIP_OK;
   int dev = 0;
@@ -64,6 +87,28 @@ const char* quip_strerror(int code) {
 }
 
 int quip_device_cu_count(void) { return device_cu_count(); }
+
+namespace {
+// test helper: `nwg` workgroups that hold `lds` bytes of LDS each (i.e. a CU each above 80 KB) for `ticks` shader clocks
+__global__ void occupy_kernel(long long ticks, unsigned* sink) {
+  extern __shared__ char smem_occ[];
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  unsigned acc = 0;
+  while ((long long)(__builtin_amdgcn_s_memtime() - t0) < ticks) {
+    __builtin_amdgcn_s_sleep(32);
+    acc += (unsigned)smem_occ[threadIdx.x];
+  }
+  if (acc == 0x12345678u) *sink = acc;
+}
+}  // namespace
+
+int quip_debug_occupy(int32_t nwg, int32_t lds_bytes, int64_t ticks, void* sink, quip_stream_t stream) {
+  if (nwg < 1 || nwg > 4096 || lds_bytes < 0 || lds_bytes > 160 * 1024 || ticks < 0 || !sink) return QUIP_ERR_BAD_SHAPE;
+  static quip::DynLdsCache configured;
+  if (quip::ensure_dyn_lds(configured, reinterpret_cast<const void*>(occupy_kernel), lds_bytes) != QUIP_OK) return QUIP_ERR_LAUNCH;
+  hipLaunchKernelGGL(occupy_kernel, dim3(nwg), dim3(64), lds_bytes, (hipStream_t)stream, (long long)ticks, reinterpret_cast<unsigned*>(sink));
+  return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+}
 
 int quip_hadamard_f16(const void* x, void* y, int64_t rows, int32_t n, float scale,
                       quip_stream_t stream) {

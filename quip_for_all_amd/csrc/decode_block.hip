@@ -1295,8 +1295,24 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   }
   // ---- h_out -----------------------------------------------------------------------------------------------------------
   if (w == 0) {
-    *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.h_out) + tid * 16) = *reinterpret_cast<const u32x4*>(smem + B::kH + tid * 16);
-    if (tid == 0) esync::st_word(ctl, ebase >> 10);
+    // A launch in which a wait gave up (ctl[1] != 0) has no result: h_out is all NaN then -- whoever consumes it sees that
+    // without reading the workspace -- and ctl[2] keeps position + 1 of the FIRST such launch (the host replays from there)
+    uint32_t e, fp;
+    esync::ld4(e, ctl + 1);
+    esync::ld4(fp, ctl + 2);
+    esync::drain();
+    esync::own(e);
+    esync::own(fp);
+    const bool failed = __builtin_amdgcn_readfirstlane((int)e) != 0;
+    const u32x4 nan4 = {0x7e007e00u, 0x7e007e00u, 0x7e007e00u, 0x7e007e00u};
+    *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.h_out) + tid * 16) =
+        failed ? nan4 : *reinterpret_cast<const u32x4*>(smem + B::kH + tid * 16);
+    if (tid == 0) {
+      if (failed && fp == 0u) esync::st_word(ctl + 2, (uint32_t)pos + 1u);
+      esync::st_word(ctl, ebase >> 10);
+      // the tag's generation field has 22 bits: ask for a fresh workspace before it wraps (the next launch answers NaN at once)
+      if (!failed && (ebase >> 10) >= (1u << 22) - 2u) esync::st_word(ctl + 1, 0xE000u);
+    }
   }
 #undef BSTAMP
 #undef ISSUE
@@ -1323,7 +1339,7 @@ size_t block_engine_layer_bytes() { return sizeof(BlockLayer); }
 
 bool block_engine_supported(int hidden, int heads, int kv_heads, int head_dim, int n_ffn, int K) {
   return hidden == HID && heads == NH && kv_heads == NH && head_dim == HD && n_ffn == NFFN && K == FK &&
-         device_cu_count() >= NWG;
+         device_cu_count_strict() >= NWG;
 }
 
 int block_engine_launch(const BlockEngineArgs& in, hipStream_t stream) {
@@ -1340,21 +1356,23 @@ int block_engine_launch(const BlockEngineArgs& in, hipStream_t stream) {
   a.n_layers = in.n_layers; a.max_len = in.max_len; a.dbg_layer = in.dbg_layer;
   a.rms_eps = in.rms_eps; a.attn_scale = in.attn_scale; a.resid_scale = 0.f;
   // codebook 0: E8P12 (32 copies of the abs table, 16 of the sign table), 1: D4 (one table of 256 x 4 bytes, a private copy per lane)
-  auto go = [&](auto kern, int lds, DynLdsCache& configured) -> int {
+  auto go = [&](auto kern, int lds, DynLdsCache& configured, ResidencyCache& resident) -> int {
     if (ensure_dyn_lds(configured, reinterpret_cast<const void*>(kern), lds) != QUIP_OK) return QUIP_ERR_LAUNCH;
+    if (!persistent_grid_fits(resident, reinterpret_cast<const void*>(kern), kThreads, lds, NWG)) return QUIP_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(kern, dim3(NWG), dim3(kThreads), lds, stream, a);
     return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
   };
   static DynLdsCache c16, c64;
   static DynLdsCache crvq, chi;
-  if (in.codebook == 3) return go(decode_block_kernel<64, true, true>, BLds<64, true>::kBytes, chi);
-  if (in.codebook == 2) { a.resid_scale = in.resid_scale; return go(decode_block_kernel<16, true>, BLds<16, true>::kBytes, crvq); }
-  if (in.codebook == 1) return go(decode_block_kernel<64>, BLds<64>::kBytes, c64);
+  static ResidencyCache r16, r24, r64, rrvq, rhi;
+  if (in.codebook == 3) return go(decode_block_kernel<64, true, true>, BLds<64, true>::kBytes, chi, rhi);
+  if (in.codebook == 2) { a.resid_scale = in.resid_scale; return go(decode_block_kernel<16, true>, BLds<16, true>::kBytes, crvq, rrvq); }
+  if (in.codebook == 1) return go(decode_block_kernel<64>, BLds<64>::kBytes, c64, r64);
   if (in.codebook != 0) return QUIP_ERR_UNSUPPORTED;
   static const bool rep16 = getenv("QUIP_ENG_REP") && atoi(getenv("QUIP_ENG_REP")) == 16;     // A/B: two-way conflicts on both tables
   static DynLdsCache c24;
-  if (rep16) return go(decode_block_kernel<16>, BLds<16>::kBytes, c16);
-  return go(decode_block_kernel<24>, BLds<24>::kBytes, c24);
+  if (rep16) return go(decode_block_kernel<16>, BLds<16>::kBytes, c16, r16);
+  return go(decode_block_kernel<24>, BLds<24>::kBytes, c24, r24);
 }
 
 }  // namespace quip

@@ -1150,12 +1150,26 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
   edge(IC<0>{}, zd, ebase | hop, 0x4000u, sv_prev, nullptr, nullptr, nullptr, 0.f, 0.f, false, 0, -1);
   // ---- h_out (natural order) -------------------------------------------------------------------------------------------------
   if (w == 0) {
+    // A launch in which a wait gave up (ctl[1] != 0) has no result: h_out is all NaN then, and ctl[2] keeps position + 1 of
+    // the FIRST such launch (decode_block.hip)
+    uint32_t e, fp;
+    esync::ld4(e, ctl + 1);
+    esync::ld4(fp, ctl + 2);
+    esync::drain();
+    esync::own(e);
+    esync::own(fp);
+    const bool failed = __builtin_amdgcn_readfirstlane((int)e) != 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      reinterpret_cast<uint16_t*>(a.h_out)[tid + 512 * (2 * j)] = (uint16_t)(hreg[j] & 0xffffu);
-      reinterpret_cast<uint16_t*>(a.h_out)[tid + 512 * (2 * j + 1)] = (uint16_t)(hreg[j] >> 16);
+      reinterpret_cast<uint16_t*>(a.h_out)[tid + 512 * (2 * j)] = failed ? (uint16_t)0x7e00 : (uint16_t)(hreg[j] & 0xffffu);
+      reinterpret_cast<uint16_t*>(a.h_out)[tid + 512 * (2 * j + 1)] = failed ? (uint16_t)0x7e00 : (uint16_t)(hreg[j] >> 16);
     }
-    if (tid == 0) esync::st_word(ctl, ebase >> 10);
+    if (tid == 0) {
+      if (failed && fp == 0u) esync::st_word(ctl + 2, (uint32_t)pos + 1u);
+      esync::st_word(ctl, ebase >> 10);
+      // the tag's generation field has 22 bits: ask for a fresh workspace before it wraps (the next launch answers NaN at once)
+      if (!failed && (ebase >> 10) >= (1u << 22) - 2u) esync::st_word(ctl + 1, 0xE000u);
+    }
   }
 #undef BSTAMP
 }
@@ -1166,13 +1180,12 @@ size_t block_engine_gqa_workspace_bytes() { return kWsBytes; }
 size_t block_engine_gqa_layer_bytes() { return sizeof(GLayer); }
 
 bool block_engine_gqa_supported(int hidden, int heads, int kv_heads, int head_dim, int n_ffn, int K) {
-  return hidden == HID && heads == NH && kv_heads == NKV && head_dim == HD && n_ffn == NFFN && K == FK && device_cu_count() >= NWG;
+  return hidden == HID && heads == NH && kv_heads == NKV && head_dim == HD && n_ffn == NFFN && K == FK && device_cu_count_strict() >= NWG;
 }
 
 int block_engine_gqa_launch(const BlockEngineArgs& in, hipStream_t stream) {
   if (in.n_layers < 1 || in.n_layers > 146) return QUIP_ERR_BAD_SHAPE;     // 7 hand-offs per block, 10-bit counter
   if (in.codebook != 0) return QUIP_ERR_UNSUPPORTED;
-  if (device_cu_count() < NWG) return QUIP_ERR_UNSUPPORTED;
   GArgs a;
   a.layers = reinterpret_cast<const GLayer*>(in.layers);
   a.h_in = reinterpret_cast<const f16*>(in.h_in);
@@ -1186,6 +1199,9 @@ int block_engine_gqa_launch(const BlockEngineArgs& in, hipStream_t stream) {
   a.rms_eps = in.rms_eps; a.attn_scale = in.attn_scale;
   static DynLdsCache cache;
   if (ensure_dyn_lds(cache, reinterpret_cast<const void*>(decode_block_gqa_kernel), GLds::kBytes) != QUIP_OK) return QUIP_ERR_LAUNCH;
+  static ResidencyCache resident;
+  if (!persistent_grid_fits(resident, reinterpret_cast<const void*>(decode_block_gqa_kernel), kThreads, GLds::kBytes, NWG))
+    return QUIP_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(decode_block_gqa_kernel, dim3(NWG), dim3(kThreads), GLds::kBytes, stream, a);
   return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
 }

@@ -576,6 +576,8 @@ int launch_ffn(const FfnArgs& a, hipStream_t stream) {
   if (lds > 160 * 1024) return QUIP_ERR_UNSUPPORTED;
   static DynLdsCache configured;
   if (ensure_dyn_lds(configured, reinterpret_cast<const void*>(kern), lds) != QUIP_OK) return QUIP_ERR_LAUNCH;
+  static ResidencyCache resident;
+  if (!persistent_grid_fits(resident, reinterpret_cast<const void*>(kern), kEngThreads, lds, E::L)) return QUIP_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(kern, dim3(E::L), dim3(kEngThreads), lds, stream, a);
   return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
 }
@@ -608,7 +610,7 @@ size_t ffn_engine_workspace_bytes(int n_ffn, int K) {
 bool ffn_engine_supported(int hidden, int n_ffn, int K) {
   FfnShape s;
   if (!ffn_shape_of(hidden, n_ffn, K, s)) return false;
-  if (n_ffn / K > device_cu_count()) return false;       // every workgroup has to be resident
+  if (n_ffn / K > device_cu_count_strict()) return false;       // every workgroup has to be resident
   return (s.K == 43 && s.logL == 8 && s.ngu <= 6 && s.nd <= 3) || (s.K == 11 && s.logL == 8 && s.ngu <= 1 && s.nd <= 1) ||
          (s.K == 43 && s.logL == 7 && s.ngu <= 3 && s.nd <= 2);
 }

@@ -415,7 +415,9 @@ __global__ __launch_bounds__(1024) void argmax_step_kernel(const f16* __restrict
   if (tid == 0) {
     for (int w = 1; w < 16; ++w)
       if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
-    tok[0] = bi;
+    // (all-NaN / all -inf logits -- e.g. the answer of a persistent launch that gave up -- leave no index: token 0, a
+    //  valid row of the embedding table, instead of INT_MAX into the next step's lookup)
+    tok[0] = bi < n ? bi : 0;
     pos[0] += 1;
   }
 }

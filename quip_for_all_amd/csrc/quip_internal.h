@@ -8,6 +8,12 @@
 namespace quip {
 
 int device_cu_count();
+// Persistent launches (decode_engine.hip, decode_block*.hip) spin across workgroups: every one of the `nwg` workgroups has to be
+// resident at once.  True when the current device has at least nwg CUs (no fall-back value: a failed query says no) and the
+// occupancy query admits the grid for this kernel / block size / dynamic LDS.  Cached per kernel and device by the caller.
+struct ResidencyCache { signed char ok[16] = {}; };      // 0 unknown, 1 fits, -1 does not
+bool persistent_grid_fits(ResidencyCache& cache, const void* kernel, int threads, int lds, int nwg);
+int device_cu_count_strict();                            // 0 when the query fails
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: one static DynLdsCache per kernel
 // instantiation (at its launch site) remembers the largest size configured on each device of the process, so a

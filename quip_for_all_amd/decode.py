@@ -269,6 +269,28 @@ class LlamaDecoder:
                     and m.SU is not None and m.SV is not None and m.in_features == m.q_in_features == n_in
                     and m.out_features == m.q_out_features == n_out)
         from .register_lib import block_engine_gqa_supported
+        with torch.cuda.device(self.dev):           # (the support queries ask the CURRENT device for its CU count)
+            return self._init_block_engine_on_device(L0, names, cbid, plain, block_engine_supported, block_engine_gqa_supported,
+                                                     block_engine_workspace, _engine_had3)
+
+    def _engine_signature(self):
+        """(data_ptr, version) of every tensor the engine descriptors were built from: a load_state_dict / .to() / in-place
+        edit of a module after the descriptors were baked shows up here (reset() rebuilds them then)"""
+        sig = []
+        for L in self.layers:
+            for k in ("q", "k", "v", "o", "gate", "up", "down"):
+                m = L[k]
+                for t in (m.Qidxs, m.SU, m.SV, m.had_left, m.had_right):
+                    if t is not None:
+                        sig.append((t.data_ptr(), t._version))
+                sig.append(float(m.wscale_float))
+            sig += [(L["ln1"].data_ptr(), L["ln1"]._version), (L["ln2"].data_ptr(), L["ln2"]._version)]
+        return tuple(sig)
+
+    def _init_block_engine_on_device(self, L0, names, cbid, plain, block_engine_supported, block_engine_gqa_supported,
+                                     block_engine_workspace, _engine_had3):
+        import numpy as np
+        s = self.s
         gqa = block_engine_gqa_supported(s.hidden, s.heads, s.kv_heads, s.head_dim, s.ffn, L0["gate"].K_right) and cbid == "E8P12"
         ok = ((gqa or block_engine_supported(s.hidden, s.heads, s.kv_heads, s.head_dim, s.ffn, L0["gate"].K_right))
               and len(self.layers) <= 146)      # (the launch's hand-off counter: 7 per block in 10 bits)
@@ -315,6 +337,7 @@ class LlamaDecoder:
         cb0 = L0["q"].codebook
         self.eng_grid = cb0.grid if cbid == "D4" else (cb0._virtual_grid(self.dev) if cbid == "HI" else cb0.grid_packed_abs)
         self.eng_resid_scale = float(getattr(L0["q"].codebook, "planes_resid_scale", 0.0)) if cbid == "E8P12RVQ4B" else 0.0
+        self._eng_sig = self._engine_signature()
         self.block_eng = True
 
     def engine_status(self):
@@ -324,6 +347,14 @@ class LlamaDecoder:
             if ws is not None and ffn_engine_status(ws) != 0:
                 return ffn_engine_status(ws)
         return 0
+
+    def engine_fail_position(self):
+        """position of the first token a persistent block launch did not compute (workspace word 2 - 1), or None"""
+        ws = getattr(self, "eng_ws", None)
+        if ws is None:
+            return None
+        v = int(ws[8:12].view(torch.int32).item())
+        return v - 1 if v > 0 else None
 
     def engine_reset(self):
         """after a launch that gave up: workspaces back to their allocation state (generation 0, no granules, no code)"""
@@ -525,6 +556,14 @@ class LlamaDecoder:
         return F.rms_norm(h[-1:], (s.hidden,), self.final_norm, s.rms_eps) @ self.lm_head.T
 
     def reset(self, first_token=1):
+        if getattr(self, "block_eng", False) and getattr(self, "_eng_sig", None) != self._engine_signature():
+            # a module's tensors were replaced or edited since the descriptors were baked: rebuild them (and the captured step)
+            for L in self.layers:
+                if hasattr(L["down"], "_eng_had3"):
+                    del L["down"]._eng_had3
+            self.block_eng = False
+            self._init_block_engine()
+            self.graph = None
         self.tok.fill_(first_token)
         self.pos.zero_()
 
@@ -568,22 +607,46 @@ class LlamaDecoder:
             (self.prefill_graph if prefill_graph else self.prefill)(prompt[:-1])   # graph: captured per prompt length
             self.tok.copy_(prompt[-1:].view_as(self.tok))
             n_prompt = 0
-        for t in range(n_prompt + n_tokens):
-            if use_graph:
-                self.graph.replay()
-            else:
-                self.step_logits = self.step()
-            if t < n_prompt:
-                self.tok.copy_(prompt[t + 1:t + 2].view_as(self.tok))
-            else:
-                out[t - n_prompt] = self.tok.reshape(-1)[0]
-        # a persistent launch whose workgroups were not all resident (something else on the device) gives up on a hand-off
-        # instead of hanging and leaves a code: its tokens are not results
-        if getattr(self, "block_eng", False) or getattr(self, "ffn_eng", False):
+        pos0 = prompt.numel() - 1 if (batched_prefill and prompt is not None and prompt.numel() > 1) else 0
+
+        def run(t_from):
+            for t in range(t_from, n_prompt + n_tokens):
+                if use_graph:
+                    self.graph.replay()
+                else:
+                    self.step_logits = self.step()
+                if t < n_prompt:
+                    self.tok.copy_(prompt[t + 1:t + 2].view_as(self.tok))
+                else:
+                    out[t - n_prompt] = self.tok.reshape(-1)[0]
+        run(0)
+        # A persistent launch whose workgroups were not all resident (something else on the device) gives up on a hand-off
+        # instead of hanging, leaves a code, answers NaN, and remembers the position of the first token it did not compute:
+        # that token and everything behind it is decoded again -- on the stage-wise step, unless the code only says that the
+        # workspace wants zeroing (0xE000: its launch counter is about to wrap).  Cache rows of earlier positions are results.
+        for _ in range(3):
+            if not (getattr(self, "block_eng", False) or getattr(self, "ffn_eng", False)):
+                break
             st = self.engine_status()
-            if st:
-                self.engine_reset()
-                raise RuntimeError("persistent decode launch gave up on a hand-off (code 0x%x): the device was shared with "
-                                   "other work during generation; QUIP_BLOCK_ENGINE=0 QUIP_FFN_ENGINE=0 selects the "
-                                   "stage-wise step" % st)
+            if not st:
+                break
+            fail = self.engine_fail_position()
+            self.engine_reset()
+            if st != 0xE000:
+                import warnings
+                warnings.warn("persistent decode launch gave up on a hand-off (code 0x%x): the device was shared with other "
+                              "work; this decoder continues on the stage-wise step" % st)
+                self.block_eng = self.ffn_eng = False
+                self.graph = None
+            t_from = 0 if fail is None else max(0, fail - pos0)
+            if use_graph and self.graph is None:
+                self.capture()
+            self.pos.fill_(pos0 + t_from)
+            if t_from == 0:
+                self.tok.fill_(first_token if not (batched_prefill and prompt is not None and prompt.numel() > 1) else int(prompt[-1]))
+            elif t_from <= n_prompt:
+                self.tok.copy_(prompt[t_from:t_from + 1].view_as(self.tok))
+            else:
+                self.tok.copy_(out[t_from - 1 - n_prompt].view_as(self.tok))
+            run(t_from)
         return out

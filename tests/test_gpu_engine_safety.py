@@ -1,0 +1,104 @@
+"""The persistent launches spin across workgroups and need every workgroup resident.  What happens when that does not hold:
+the launch is refused up front where it can be known (CU count, occupancy query: csrc/capi.hip persistent_grid_fits), and a
+launch that finds the device shared at run time gives up on a bounded wait, answers NaN, remembers the position -- and
+`LlamaDecoder.generate` decodes that token and the ones behind it again on the stage-wise step instead of raising."""
+import ctypes
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _decoder(block_engine, ffn_engine, layers=2, max_len=40, seed=3):
+    from quip_for_all_amd import decode as D
+    shape = D.LlamaShape(hidden=4096, ffn=11008, layers=layers, heads=32, kv_heads=32, vocab=2048)
+    old = {k: os.environ.get(k) for k in ("QUIP_BLOCK_ENGINE", "QUIP_FFN_ENGINE")}
+    os.environ["QUIP_BLOCK_ENGINE"] = "1" if block_engine else "0"
+    os.environ["QUIP_FFN_ENGINE"] = "1" if ffn_engine else "0"
+    try:
+        return D.LlamaDecoder(shape, "E8P12", max_len=max_len, device=DEV, seed=seed, device_init=True)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _same_weights(dst, src):
+    with torch.no_grad():
+        for Ld, Ls in zip(dst.layers, src.layers):
+            for k in ("gate", "up", "down"):
+                for name in ("had_left", "had_right"):
+                    if getattr(Ls[k], name) is not None:
+                        getattr(Ld[k], name).copy_(getattr(Ls[k], name))
+
+
+def test_generate_falls_back_to_the_stagewise_step_when_the_device_is_shared():
+    """32 CUs held by another stream's kernel for longer than a hand-off waits: the persistent launch cannot have its 256
+    workgroups resident, gives up (no hang), and generate() returns the tokens of the stage-wise step"""
+    from quip_for_all_amd import capi
+    plain = _decoder(False, False)
+    dec = _decoder(True, True)
+    _same_weights(dec, plain)
+    assert dec.block_eng and not plain.block_eng and not plain.ffn_eng
+    expected = plain.generate(12, first_token=5, use_graph=True).cpu().numpy()
+    dec.capture()                                     # (descriptors rebuilt by reset(): the factors were edited)
+    assert dec.block_eng and dec.engine_status() == 0
+    sink = torch.zeros(4, dtype=torch.int32, device=DEV)
+    side = torch.cuda.Stream()
+    # ~8 s of shader clocks at 2.1 GHz: longer than the ~2-4 s after which a wait gives up
+    capi.check(capi.lib().quip_debug_occupy(32, 100 * 1024, ctypes.c_int64(17_000_000_000), sink.data_ptr(), side.cuda_stream),
+               "quip_debug_occupy")
+    with warnings.catch_warnings(record=True) as wr:
+        warnings.simplefilter("always")
+        got = dec.generate(12, first_token=5, use_graph=True).cpu().numpy()
+    torch.cuda.synchronize()
+    assert any("gave up" in str(w.message) for w in wr), [str(w.message) for w in wr]
+    assert not dec.block_eng and not dec.ffn_eng and dec.engine_status() == 0
+    np.testing.assert_array_equal(got, expected)
+    # and the decoder keeps working (stage-wise) afterwards
+    again = dec.generate(12, first_token=5, use_graph=True).cpu().numpy()
+    np.testing.assert_array_equal(again, expected)
+
+
+def test_a_failed_launch_answers_nan_and_remembers_the_position():
+    from quip_for_all_amd import capi
+    dec = _decoder(True, True, layers=1)
+    dec.reset(first_token=3)
+    dec.pos.fill_(5)
+    sink = torch.zeros(4, dtype=torch.int32, device=DEV)
+    side = torch.cuda.Stream()
+    capi.check(capi.lib().quip_debug_occupy(16, 100 * 1024, ctypes.c_int64(17_000_000_000), sink.data_ptr(), side.cuda_stream),
+               "quip_debug_occupy")
+    with torch.no_grad():
+        logits = dec.step()
+    torch.cuda.synchronize()
+    assert dec.engine_status() != 0
+    assert dec.engine_fail_position() == 5
+    assert torch.isnan(logits).all()
+    dec.engine_reset()
+    assert dec.engine_status() == 0 and dec.engine_fail_position() is None
+
+
+def test_launch_counter_wrap_asks_for_a_fresh_workspace_and_generation_continues():
+    """the hand-off tag carries 22 bits of launch counter: two launches before the wrap the launch leaves code 0xE000, the
+    next one answers NaN at once, and generate() zeroes the workspace and decodes on -- still on the persistent launch"""
+    ref = _decoder(True, True)
+    dec = _decoder(True, True)
+    _same_weights(dec, ref)
+    expected = ref.generate(10, first_token=5, use_graph=True).cpu().numpy()
+    dec.capture()
+    dec.eng_ws[:4].view(torch.int32).fill_((1 << 22) - 6)         # the generation word: a few launches before the wrap
+    with warnings.catch_warnings(record=True) as wr:
+        warnings.simplefilter("always")
+        got = dec.generate(10, first_token=5, use_graph=True).cpu().numpy()
+    assert not wr, [str(w.message) for w in wr]
+    assert dec.block_eng and dec.engine_status() == 0
+    assert int(dec.eng_ws[:4].view(torch.int32).item()) < 64      # a fresh workspace
+    np.testing.assert_array_equal(got, expected)
