@@ -368,6 +368,81 @@ def time_decoder(D, shape, codebook, steps, warmup, device, **cb_kwargs):
     return out
 
 
+def hf_static_cache_extra(D, device, new_tokens=128, cache_len=2048):
+    """the reference's own harness shape on the headline model (example_generate.py:62-70, 103-110): random-init HF Llama-2-7B
+    -> QuipQuantizer.convert_model (every block projection a QuantLinear, E8P12) -> StaticCache(2048) -> greedy `new_tokens`
+    tokens, timed around the decode loop as the reference does: (i) eager, (ii) the single-token step captured in a hipGraph
+    (the reference: torch.compile(mode="reduce-overhead", fullgraph=True)); beside them LlamaDecoder.from_hf on the SAME
+    module objects with a 2048-slot cache.  The reference's published 138-184 tok/s (RTX 4090) is figure (ii)'s counterpart."""
+    import torch
+    from transformers import AutoModelForCausalLM, LlamaConfig
+    from quip_for_all_amd.quantizer import QuipQuantizer
+    from quip_for_all_amd.qlinear import QuantLinear
+    from quip_for_all_amd.hf_static import HFStaticDecoder
+    cfg = LlamaConfig(hidden_size=4096, intermediate_size=11008, num_hidden_layers=32, num_attention_heads=32,
+                      num_key_value_heads=32, vocab_size=32000, max_position_embeddings=4096, rms_norm_eps=1e-5)
+    with torch.device("meta"):
+        model = AutoModelForCausalLM.from_config(cfg, dtype=torch.float16)
+    qz = QuipQuantizer(codebook="E8P12", inference=True, ft_epochs=0)
+    qz.convert_model(model)
+    model.to_empty(device=device)
+    g = torch.Generator(device=device).manual_seed(0)
+    with torch.no_grad():
+        for name, prm in list(model.named_parameters()) + list(model.named_buffers()):
+            if prm.is_floating_point() and "inv_freq" not in name:
+                prm.copy_((torch.randn(prm.shape, generator=g, device=device, dtype=torch.float32) * 0.02).to(prm.dtype))
+        for m in model.modules():
+            if isinstance(m, QuantLinear):
+                m.Qidxs.copy_(torch.randint(-32768, 32768, m.Qidxs.shape, generator=g, device=device, dtype=torch.int32).to(m.Qidxs.dtype))
+                m.SU.copy_((torch.randint(0, 2, m.SU.shape, generator=g, device=device) * 2 - 1).half())
+                m.SV.copy_((torch.randint(0, 2, m.SV.shape, generator=g, device=device) * 2 - 1).half())
+                m.Wscale.fill_(1.0 / 64.0)
+                for nm in ("had_left", "had_right"):
+                    h = getattr(m, nm)
+                    if h is not None:
+                        h.copy_(torch.linalg.qr(torch.randn(h.shape, generator=g, device=device))[0].half())
+            if m.__class__.__name__.endswith("RMSNorm"):
+                m.weight.fill_(1.0)
+        # buffers computed in __init__ (the rotary frequencies) were built on the meta device: build them again
+        rot = model.model.rotary_emb
+        model.model.rotary_emb = type(rot)(config=cfg, device=device)
+        for m in model.modules():
+            if isinstance(m, QuantLinear):
+                m.wscale_float = float(m.Wscale.mean().item())          # load_quantized_model's post-load step (quantizer.py:835-844)
+    model.eval()
+    ids = torch.randint(1, 32000, (1, 16), generator=torch.Generator().manual_seed(1)).to(device)
+    out = {"model": "random-init Llama-2-7B shape, E8P12, HF LlamaForCausalLM + StaticCache(%d)" % cache_len,
+           "prompt_tokens": 16, "new_tokens": new_tokens, "timing": "decode loop of new_tokens - 1 single-token steps, synchronised at both ends"}
+    toks = {}
+    for mode in ("eager", "graph"):
+        dec = HFStaticDecoder(model, max_cache_len=cache_len)
+        dec.generate(ids, 8, mode)                      # warm-up (and capture)
+        ts = []
+        for _ in range(3):
+            t, dt = dec.generate(ids, new_tokens, mode)
+            ts.append((new_tokens - 1) / dt)
+        toks[mode] = t
+        out["hf_%s_tokens_per_s" % mode] = round(float(np.median(ts)), 2)
+        out["hf_%s_runs" % mode] = [round(x, 2) for x in ts]
+        del dec
+    out["hf_graph_equals_eager"] = bool(torch.equal(toks["eager"], toks["graph"]))
+    fast = D.LlamaDecoder.from_hf(model, max_len=cache_len)
+    fast.generate(8, prompt=ids[0])
+    ts = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ft = fast.generate(new_tokens, prompt=ids[0])
+        torch.cuda.synchronize()
+        ts.append(new_tokens / (time.perf_counter() - t0))
+    out["llamadecoder_from_hf_tokens_per_s"] = round(float(np.median(ts)), 2)
+    out["llamadecoder_from_hf_runs"] = [round(x, 2) for x in ts]
+    out["llamadecoder_step"] = "persistent block launch" if getattr(fast, "block_eng", False) else "stage-wise"
+    n_same = int((ft[:new_tokens].cpu() == toks["graph"].cpu()).sum())
+    out["llamadecoder_tokens_equal_to_hf"] = "%d / %d" % (n_same, new_tokens)
+    return out
+
+
 def long_context_decode(D, device, positions=(2048, 4000), steps=16):
     """the headline model's decode step at long contexts (same captured step, position counter moved: the cache rows hold
     whatever earlier tokens left there -- attention time does not depend on the values)"""
@@ -545,6 +620,13 @@ def main():
                 extras["llama2_7b_e8p12_long_context"] = long_context_decode(D, f"cuda:{local_rank}")
             except Exception as e:
                 extras["llama2_7b_e8p12_long_context"] = {"error": repr(e)}
+            try:
+                extras["hf_generate_static_cache"] = hf_static_cache_extra(D, f"cuda:{local_rank}")
+            except Exception as e:
+                extras["hf_generate_static_cache"] = {"error": repr(e)[:400]}
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
             out["extras"] = extras
         if not a.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only (bench contract)
             try:

@@ -246,3 +246,30 @@ def test_fast_decoder_refuses_blocks_that_are_not_llamas(tmp_path):
     for prompt in (torch.tensor([5, 17, 3, 99, 42], device="cuda:0"),
                    torch.randint(0, 320, (40,), generator=torch.Generator().manual_seed(7)).cuda()):
         _check_prompt(model, dec, prompt)
+
+
+def test_hf_static_cache_step_captured_in_a_graph_equals_eager():
+    """the reference's harness shape (example_generate.py:28-33, 62-70): the stock HF forward on a StaticCache, one token
+    per call -- eager, and with the single-token step captured in a hipGraph (what mode="reduce-overhead" buys the
+    reference); both decode the same greedy tokens, which are the stock `generate` loop's"""
+    from transformers import AutoModelForCausalLM
+    from quip_for_all_amd.quantizer import QuipQuantizer
+    from quip_for_all_amd.hf_static import HFStaticDecoder
+    torch.manual_seed(0)
+    model = AutoModelForCausalLM.from_config(_tiny_config(), dtype=torch.float16)
+    qz = QuipQuantizer(codebook="E8P12", inference=True, ft_epochs=0)
+    qz.convert_model(model)
+    _fill_random(model, seed=3)
+    model = model.to("cuda:0").eval()
+    model.generation_config.eos_token_id = None
+    ids = torch.tensor([[1, 17, 42, 99, 7, 250]], device="cuda:0")
+    eager, _ = HFStaticDecoder(model, max_cache_len=64).generate(ids, 16, "eager")
+    dec = HFStaticDecoder(model, max_cache_len=64)
+    graph, _ = dec.generate(ids, 16, "graph")
+    assert dec.graph is not None
+    assert torch.equal(eager, graph), (eager, graph)
+    again, _ = dec.generate(ids, 16, "graph")           # the captured step replays from a reset cache
+    assert torch.equal(again, graph)
+    ref = model.generate(ids, max_new_tokens=16, do_sample=False)[0, ids.shape[1]:]
+    n = min(len(ref), 16)
+    assert n >= 8 and torch.equal(ref[:n], graph[:n]), (ref, graph)

@@ -1,0 +1,5 @@
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench
+from quip_for_all_amd import decode as D
+print(json.dumps(bench.hf_static_cache_extra(D, "cuda:0"), indent=1))
