@@ -515,6 +515,10 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
       had::wg_barrier<true>();
       ESTAMP(4);
     }
+    // (opaque from here on: otherwise the fp32 images of h made above are kept alive until the next edge's update -- 16 registers
+    //  through the attention and o phases)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(hreg[j]));
 #undef ESTAMP
   };
   // A fragment address of this lane for K slice (wave + 8 i) of the planes at `base` (plane stride ps)
@@ -968,7 +972,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
         }
       }
       BSTAMP(28);
-      had8::fht4096<2, true>(v, xbuf, tid);
+      hadw::fwd<12, 2, true>(v, xbuf, tid);
       BSTAMP(29);
       float e[1][8];
 #pragma unroll

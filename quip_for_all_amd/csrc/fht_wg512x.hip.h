@@ -52,17 +52,43 @@ __device__ __forceinline__ void reg_stages(float (&v)[N]) {      // strides FROM
     reg_stages<N, 2 * FROM>(v);
   }
 }
+#ifndef QUIP_FHT_SWAP_STAGES
+#define QUIP_FHT_SWAP_STAGES 1
+#endif
+#ifndef QUIP_FHT_SWAP_FROM
+#define QUIP_FHT_SWAP_FROM 5      // measured: the half swap (bit 5) beats ds_bpermute, the row swap (bit 4) loses to ds_swizzle
+#endif
 template <int N, int S>
 __device__ __forceinline__ void lane_stage(float (&v)[N], int lane) {
 #pragma clang fp contract(off)
-  const float sg = ((lane >> S) & 1) ? -1.f : 1.f;     // bit clear: own + partner; bit set: partner - own
-  const f32x2 sg2 = {sg, sg};
+  if constexpr (QUIP_FHT_SWAP_STAGES && S >= QUIP_FHT_SWAP_FROM && N % 2 == 0) {
+    // lane bits 4 / 5 (partners 16 / 32 lanes away) on gfx950's row / half swaps instead of the LDS crossbar (ds_swizzle,
+    // ds_bpermute): for a PAIR of registers (x, y)
+    //   swap(x, y)        -> x' = x's even rows | y's even rows interleaved, y' = the odd rows (S = 4); lower | upper halves (S = 5)
+    //   s = x' + y', d = x' - y'
+    //   swap(s, d)        -> x'' = (x_lo + x_hi | x_lo - x_hi), y'' = the same of y
+    // i.e. own + partner where the bit is clear, partner - own where it is set: the same two IEEE operations as the fma form
 #pragma unroll
-  for (int r = 0; r < N; r += 2) {
-    const f32x2 own = {v[r], v[r + 1]}, par = {had8::lane_partner<S>(v[r], lane), had8::lane_partner<S>(v[r + 1], lane)};
-    const f32x2 w = __builtin_elementwise_fma(own, sg2, par);
-    v[r] = w.x;
-    v[r + 1] = w.y;
+    for (int r = 0; r < N; r += 2) {
+      const unsigned a = __builtin_bit_cast(unsigned, v[r]), b = __builtin_bit_cast(unsigned, v[r + 1]);
+      const auto t = S == 4 ? __builtin_amdgcn_permlane16_swap(a, b, false, false) : __builtin_amdgcn_permlane32_swap(a, b, false, false);
+      const float x1 = __builtin_bit_cast(float, (unsigned)t[0]), y1 = __builtin_bit_cast(float, (unsigned)t[1]);
+      const float sm = x1 + y1, df = x1 - y1;
+      const auto u = S == 4 ? __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, sm), __builtin_bit_cast(unsigned, df), false, false)
+                            : __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, sm), __builtin_bit_cast(unsigned, df), false, false);
+      v[r] = __builtin_bit_cast(float, (unsigned)u[0]);
+      v[r + 1] = __builtin_bit_cast(float, (unsigned)u[1]);
+    }
+  } else {
+    const float sg = ((lane >> S) & 1) ? -1.f : 1.f;     // bit clear: own + partner; bit set: partner - own
+    const f32x2 sg2 = {sg, sg};
+#pragma unroll
+    for (int r = 0; r < N; r += 2) {
+      const f32x2 own = {v[r], v[r + 1]}, par = {had8::lane_partner<S>(v[r], lane), had8::lane_partner<S>(v[r + 1], lane)};
+      const f32x2 w = __builtin_elementwise_fma(own, sg2, par);
+      v[r] = w.x;
+      v[r + 1] = w.y;
+    }
   }
 }
 template <int N, int S, int END>
