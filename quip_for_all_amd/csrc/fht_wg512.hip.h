@@ -43,12 +43,32 @@ __device__ __forceinline__ float lane_partner(float v, int lane) {
   else
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, v)));
 }
+#ifndef QUIP_FHT8_HALF_SWAP
+#define QUIP_FHT8_HALF_SWAP 1
+#endif
 template <int S>
 __device__ __forceinline__ void lane_stage(float v[8], int lane) {
 #pragma clang fp contract(off)
-  const float sg = ((lane >> S) & 1) ? -1.f : 1.f;     // bit clear: x0 + x1 = own + partner; bit set: x0 - x1 = partner - own
+  if constexpr (S == 5 && QUIP_FHT8_HALF_SWAP) {
+    // lane bit 5 (the partner is 32 lanes away) on gfx950's half swap instead of ds_bpermute (round 4, measured on the
+    // 8192-point transforms: -0.5K of 5K clocks): for a PAIR of registers (x, y)
+    //   swap(x, y) -> x' = (x lower half | y lower half), y' = (x upper half | y upper half);  s = x' + y', d = x' - y';
+    //   swap(s, d) -> (x_lo + x_hi | x_lo - x_hi), the same of y
+    // -- own + partner where the bit is clear, partner - own where it is set: the values of the fma form, bit for bit
 #pragma unroll
-  for (int r = 0; r < 8; ++r) v[r] = __builtin_fmaf(v[r], sg, lane_partner<S>(v[r], lane));
+    for (int r = 0; r < 8; r += 2) {
+      const auto t = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v[r]), __builtin_bit_cast(unsigned, v[r + 1]), false, false);
+      const float x1 = __builtin_bit_cast(float, (unsigned)t[0]), y1 = __builtin_bit_cast(float, (unsigned)t[1]);
+      const float sm = x1 + y1, df = x1 - y1;
+      const auto u = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, sm), __builtin_bit_cast(unsigned, df), false, false);
+      v[r] = __builtin_bit_cast(float, (unsigned)u[0]);
+      v[r + 1] = __builtin_bit_cast(float, (unsigned)u[1]);
+    }
+  } else {
+    const float sg = ((lane >> S) & 1) ? -1.f : 1.f;     // bit clear: x0 + x1 = own + partner; bit set: x0 - x1 = partner - own
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = __builtin_fmaf(v[r], sg, lane_partner<S>(v[r], lane));
+  }
 }
 
 // RAW: barriers that do not wait for vector-memory loads in flight (had::wg_barrier)

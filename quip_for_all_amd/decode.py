@@ -153,7 +153,14 @@ class LlamaDecoder:
         #  so it changes nothing here)
         if (getattr(cfg, "sliding_window", None) and getattr(cfg, "use_sliding_window", True)
                 and getattr(cfg, "model_type", "") != "llama"):
-            types = getattr(cfg, "layer_types", None) or ["sliding_attention"]
+            types = getattr(cfg, "layer_types", None)
+            if not types:
+                # older Qwen2-style configs have no layer_types: HF applies the window to layers >= max_window_layers only
+                # (modeling_qwen2.py), so the per-layer pattern follows from that field
+                mwl = getattr(cfg, "max_window_layers", None)
+                nl = cfg.num_hidden_layers
+                types = ["sliding_attention"] if mwl is None else \
+                    ["full_attention" if i < int(mwl) else "sliding_attention" for i in range(nl)]
             if any(t not in ("full_attention", "sliding_attention") for t in types) or len(set(types)) > 1:
                 raise NotImplementedError(f"layer_types {sorted(set(types))}: per-layer attention patterns are not supported")
             # a window that is never shorter than the context is full attention (Mistral-7B: 4096 on a 4096 cache); a

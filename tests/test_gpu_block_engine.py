@@ -19,6 +19,7 @@ def _decoder(layers, block_engine, ffn_engine=True, max_len=48, seed=3, codebook
     old = {k: os.environ.get(k) for k in ("QUIP_BLOCK_ENGINE", "QUIP_FFN_ENGINE")}
     os.environ["QUIP_BLOCK_ENGINE"] = "1" if block_engine else "0"
     os.environ["QUIP_FFN_ENGINE"] = "1" if ffn_engine else "0"
+    np.random.seed(1234 + seed)       # (the K x K factors come from scipy's / numpy's global generator: the same model in every run)
     try:
         dec = D.LlamaDecoder(shape, codebook, max_len=max_len, device=DEV, seed=seed, device_init=True)
     finally:

@@ -19,6 +19,7 @@ def _decoder(layers, block_engine, max_len=48, seed=3, vocab=2048):
     shape = D.LlamaShape(hidden=8192, ffn=28672, layers=layers, heads=64, kv_heads=8, vocab=vocab)
     old = os.environ.get("QUIP_BLOCK_ENGINE")
     os.environ["QUIP_BLOCK_ENGINE"] = "1" if block_engine else "0"
+    np.random.seed(1234 + seed)       # (the K x K factors come from scipy's / numpy's global generator: the same model in every run)
     try:
         dec = D.LlamaDecoder(shape, "E8P12", max_len=max_len, device=DEV, seed=seed, device_init=True)
     finally:

@@ -20,6 +20,7 @@ def _decoder(block_engine, ffn_engine, layers=2, max_len=40, seed=3):
     old = {k: os.environ.get(k) for k in ("QUIP_BLOCK_ENGINE", "QUIP_FFN_ENGINE")}
     os.environ["QUIP_BLOCK_ENGINE"] = "1" if block_engine else "0"
     os.environ["QUIP_FFN_ENGINE"] = "1" if ffn_engine else "0"
+    np.random.seed(1234 + seed)
     try:
         return D.LlamaDecoder(shape, "E8P12", max_len=max_len, device=DEV, seed=seed, device_init=True)
     finally:
