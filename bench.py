@@ -167,6 +167,55 @@ def engine_roofline(dec):
             "engine_status": dec.engine_status()}
 
 
+def gqa_phase_rates(dec):
+    """The E8P12 products at the 70B layer shapes as they run INSIDE the persistent launch (decode_block_gqa_kernel): clock
+    stamps (s_memtime, workgroup mean) around the product phases of one block in the middle of the model, converted to time
+    with the same launch's own clocks-per-microsecond (block span in clocks / HIP-event time per block).  A phase = the 8
+    waves of every workgroup multiplying their items of the matrices named, weights streamed through the launch-long ring
+    (nine 2 KB requests ahead per wave), accumulation and -- where it is part of the phase -- the 16-granule publication;
+    bytes = the matrices' code bytes.  `GBps` = code bytes MULTIPLIED per second inside the phase: the rate of the
+    decode GEMV at these shapes with its prologue (tables, planes) and tail amortised over the launch.  It is not the HBM
+    rate of the phase: the ring had requested the first nine items of every wave before the phase began, so only
+    (items - 9) / items of the bytes had to LAND inside it -- `GBps_landed_at_least` is that lower bound on the HBM side."""
+    import math
+    s = dec.s
+    L = len(dec.layers)
+    dl = L // 2
+    h = dec.embed[:1].reshape(-1).clone()
+    pos = torch.full((1,), 40, dtype=torch.long, device=dec.dev)
+    dbg = torch.zeros(256 * 32, dtype=torch.int64, device=dec.dev)
+    args = (dec.eng_layers, h, pos, dec.cos, dec.sin, dec.eng_grid, dec.eng_ws, L, dec.max_len, s.rms_eps,
+            1.0 / math.sqrt(s.head_dim), dbg, dl, 0, 0.0, 1)
+    runs = []
+    for it in range(6):
+        dbg.zero_()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        torch.ops.quip_lib.block_engine(*args)
+        b.record()
+        torch.cuda.synchronize()
+        if it >= 2:
+            runs.append((dbg.cpu().numpy().reshape(256, 32).astype(np.float64), a.elapsed_time(b) * 1e3 / L))
+    hid, ffn, kvw = s.hidden, s.ffn, s.kv_heads * s.head_dim
+    # (stamp before, stamp after, code bytes, items per wave)
+    phases = {"gate_up (2 x %dx%d)" % (ffn, hid): (27, 11, 2 * ffn * hid // 4, 28),
+              "down (%dx%d) + publish" % (hid, ffn): (15, 16, hid * ffn // 4, 14),
+              "o (%dx%d) + publish" % (hid, hid): (8, 9, hid * hid // 4, 4),
+              "q, k, v (%dx%d + 2 x %dx%d) + publish" % (hid, hid, kvw, hid): (22, 3, (hid + 2 * kvw) * hid // 4, 6)}
+    out = {}
+    tpu = float(np.median([(d[:, 17] - d[:, 0]).mean() / us for d, us in runs]))        # clocks per microsecond (block span / block time)
+    for name, (s0, s1, nbytes, items) in phases.items():
+        ticks = float(np.median([(d[:, s1] - d[:, s0]).mean() for d, _ in runs]))
+        us = ticks / tpu
+        out[name] = {"code_bytes": nbytes, "clocks": round(ticks), "us": round(us, 2), "GBps": round(nbytes / us / 1e3, 1),
+                     "frac_of_8TBps": round(nbytes / us / 1e3 / HBM_PEAK_GBPS, 4), "items_per_wave": items,
+                     "GBps_landed_at_least": round(nbytes * max(items - 9, 0) / items / us / 1e3, 1)}
+    out["clocks_per_us"] = round(tpu, 1)
+    out["block"] = dl
+    out["engine_status"] = dec.engine_status()
+    return out
+
+
 def gemv_per_shape(shapes, dev, pool_bytes=640 << 20, iters=100):
     """SURVEY 8d layer micro-bench inside the bench run: the default bs=1 E8P12 GEMV entry point on every (n, k) of
     `shapes`, weights cycled through a pool larger than the 256 MB Infinity Cache, `iters` launches per graph replay,
@@ -358,6 +407,11 @@ def time_decoder(D, shape, codebook, steps, warmup, device, **cb_kwargs):
     if codebook == "E8P12":
         out["gemv_roofline"] = engine_roofline(dec) if getattr(dec, "block_eng", False) else gemv_roofline(dec)
     if codebook == "E8P12" and shape.hidden == 8192:
+        if getattr(dec, "block_eng", False) and getattr(dec, "eng_shape", 0) == 1:
+            try:
+                out["gemv_phases_in_launch"] = gqa_phase_rates(dec)
+            except Exception as e:
+                out["gemv_phases_in_launch"] = {"error": repr(e)[:300]}
         # the north star's target shapes, timed here so that the driver's run holds them (SURVEY 8d layer micro-bench)
         del dec
         torch.cuda.empty_cache()
