@@ -507,10 +507,13 @@ typedef struct quip_block_engine_args {
   int32_t codebook;          /* 0: E8P12; 1: D4 (uint8 codes, grid_packed_abs = the fp16 (256, 4) table, d4.py:26-96);
                               * 2: E8P12RVQ4B (int32 codes, e8p12_rvq4.py:37-45); 3: HI (int32 codes = 8 nibbles,
                               * hi.py:41-63; grid_packed_abs = the fp16 (256, 4) table [lo - 7.5, hi - 7.5, 0, 0] of a
-                              * code BYTE: the row reads as a D4 row of twice the width) */
-  float resid_scale;         /* codebook 2: the residual scale rounded to fp16 (origin_order.cu:337-385), else ignored */
+                              * code BYTE: the row reads as a D4 row of twice the width); 4: E8P12RVQ3B (the checkpoint's
+                              * 3-byte codes, int32 (n, 3 k / 32), e8p12_rvq3.py:81-107; grid2 = the E81B table) */
+  float resid_scale;         /* codebooks 2, 4: the residual scale rounded to fp16 (origin_order.cu:337-385), else ignored */
   int32_t shape;             /* 0: hidden 4096, 32 heads, n_ffn 43 x 256 (Llama-2-7B); 1: hidden 8192, 64 heads on 8 KV heads,
                               * n_ffn 7 x 4096 (Llama-2-70B; E8P12 only) -- see quip_block_engine_gqa_* below */
+  const void* grid2;         /* codebook 4: the E81B residual table as int8 (256, 8) = 4 r (as for quip_e8prvq3_gemv_planes_group),
+                              * 8-byte aligned; else ignored */
 } quip_block_engine_args;
 int quip_block_engine_supported(int32_t hidden, int32_t heads, int32_t kv_heads, int32_t head_dim, int32_t n_ffn, int32_t K);
 size_t quip_block_engine_workspace_bytes(void);

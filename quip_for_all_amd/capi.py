@@ -125,7 +125,7 @@ class BlockEngineArgs(_c.Structure):
     _fields_ = [("layers", _P), ("h_in", _P), ("h_out", _P), ("pos", _P), ("cos", _P), ("sin", _P),
                 ("grid_packed_abs", _P), ("workspace", _P), ("dbg", _P), ("n_layers", _I32), ("max_len", _I32),
                 ("dbg_layer", _I32), ("rms_eps", _F), ("attn_scale", _F), ("codebook", _I32), ("resid_scale", _F),
-                ("shape", _I32)]
+                ("shape", _I32), ("grid2", _P)]
 
 
 class HadFusion(_c.Structure):

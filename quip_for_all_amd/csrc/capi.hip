@@ -521,6 +521,9 @@ int quip_block_engine(const quip_block_engine_args* in, quip_stream_t stream) {
   a.grid = in->grid_packed_abs; a.workspace = in->workspace; a.dbg = in->dbg;
   a.n_layers = in->n_layers; a.max_len = in->max_len; a.dbg_layer = in->dbg_layer;
   a.rms_eps = in->rms_eps; a.attn_scale = in->attn_scale; a.codebook = in->codebook; a.resid_scale = in->resid_scale;
+  a.grid2 = in->grid2;
+  if (in->codebook == 4 && (!in->grid2 || (reinterpret_cast<uintptr_t>(in->grid2) & 7u) != 0))
+    return in->grid2 ? QUIP_ERR_MISALIGNED : QUIP_ERR_NULL_POINTER;
   if (in->shape == 1) return block_engine_gqa_launch(a, (hipStream_t)stream);
   if (in->shape != 0) return QUIP_ERR_UNSUPPORTED;
   return block_engine_launch(a, (hipStream_t)stream);

@@ -62,7 +62,8 @@ struct BlockArgs {
   uint64_t* dbg;           // optional: 32 clock stamps per workgroup of block `dbg_layer`
   int n_layers, max_len, dbg_layer;
   float rms_eps, attn_scale;
-  float resid_scale;       // E8P12RVQ4B: the fp16 residual scale (as float)
+  float resid_scale;       // E8P12RVQ4B / RVQ3B: the fp16 residual scale (as float)
+  const void* grid2;       // E8P12RVQ3B: the E81B residual table, 256 x 8 int8 (4 r); else unused
 };
 
 constexpr int kWaves = 8, kThreads = 512;
@@ -130,14 +131,23 @@ struct BLds {
                 "transient area");
 };
 static_assert(BLds<24>::kBytes <= 160 * 1024 && BLds<16>::kBytes <= 160 * 1024 && BLds<64>::kBytes <= 160 * 1024 &&
-              BLds<16, true>::kBytes <= 160 * 1024 && BLds<64, true>::kBytes <= 160 * 1024, "LDS budget");
+              BLds<16, true>::kBytes <= 160 * 1024 && BLds<64, true>::kBytes <= 160 * 1024 && BLds<12, true>::kBytes <= 160 * 1024,
+              "LDS budget");
 
 // RVQ: rows of twice the (virtual) width.  HI (with RVQ and the D4 table mode): the HI codebook -- a code byte holds two
 // nibbles and reads as a D4 code of the virtual row with the table entry [lo - 7.5, hi - 7.5, 0, 0], against
 // x' = [x0 x2 0 0 | x4 x6 0 0 | x1 x3 0 0 | x5 x7 0 0]_g (hadamard.hip, HI layout)
+// E8P12RVQ3B (RVQ on the third-table mode REP = 12): the checkpoint's 3-byte codes [resid8, e8p_lo, e8p_hi] behind a zero byte
+// are the dwords (main16 << 16 | resid8 << 8) of an RVQ4-style virtual row whose low codes index the E81B table
+// (e8p_gemv_core.hip.h, rvq3_dwords).  Same items, digits and slots as E8P12RVQ4B; a lane's half item is 12 bytes (four codes)
+// instead of 16, so every byte offset of the weight stream is 3/4 of RVQ4B's (rows of 3 k / 8 bytes).
 template <int REP, bool RVQ = false, bool HI = false>
 __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   static_assert(!HI || (RVQ && Lds<REP>::kD4), "HI = virtual rows of twice the width on the D4 table mode");
+  constexpr bool R3 = Lds<REP>::kRvq3;
+  static_assert(!R3 || (RVQ && !HI), "RVQ3B: the virtual rows of RVQ");
+  using slot_t = std::conditional_t<R3, u32x3, u32x4>;
+  constexpr uint32_t PB = R3 ? 12u : 16u;              // bytes of a lane's piece of the weight stream
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using B = BLds<REP, RVQ>;
   constexpr int VM = B::VM, KV = B::KV;
@@ -159,26 +169,26 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 #define BSTAMP(i) do { if (dbg_on && tid == 0) a.dbg[w * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
   // ---- weight slots ---------------------------------------------------------------------------------------------
-  u32x4 qa[NSLOT], qb[NSLOT];
+  slot_t qa[NSLOT], qb[NSLOT];
   // item kinds: 0..2 = row blocks 3 w + kind of the stacked [q; k; v] rows (256 row blocks of 16 rows per matrix: a
   // workgroup's three blocks touch at most two of the matrices, so ONE round of input transforms serves it), 3 = o rows
   // [16 w, +16) (slice = wave); 4..9 = gate / up row block (kind - 4) % 3 of matrix (kind - 4) / 3 (rows k * 256 + w);
   // 10..12 = down, slice (kind - 10) * 8 + wave.  A load = scalar base of the matrix + a 32-bit byte offset of this
   // lane (+ 64 for the second half of the item).
   uint32_t vo_row, vo_q[3], vo_gu[FRB], vo_d[3], vo_d2b, vo_dr[3];
-  uint32_t lane_c, lane_c2, xlane;
+  uint32_t lane_c, lane_c2, lane_c3 = 0u, xlane;
   auto rederive = [&]() {
     int t = threadIdx.x;
     asm volatile("" : "+v"(t));
     tid = t; lane = t & 63; n = lane & 15; q = lane >> 4;
-    vo_row = (uint32_t)(((w * RPW + n) * kRowU4V + wave * 8 + q) * 16);
+    vo_row = (uint32_t)((w * RPW + n) * kRowU4V + wave * 8 + q) * PB;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) vo_q[i] = (uint32_t)(((((3 * w + i) & 255) * 16 + n) * kRowU4V + wave * 8 + q) * 16);
+    for (int i = 0; i < 3; ++i) vo_q[i] = (uint32_t)((((3 * w + i) & 255) * 16 + n) * kRowU4V + wave * 8 + q) * PB;
 #pragma unroll
     for (int rb = 0; rb < FRB; ++rb) {
       int kr = rb * 16 + n;
       kr = kr < FK ? kr : FK - 1;
-      vo_gu[rb] = (uint32_t)(((kr * FL + w) * kRowU4V + wave * 8 + q) * 16);
+      vo_gu[rb] = (uint32_t)((kr * FL + w) * kRowU4V + wave * 8 + q) * PB;
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -192,13 +202,14 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       }
     }
     // RVQ: down's 43 virtual slices: slice wave + 8 i, i < 6, at vo_dr[i >> 2] + (i & 3) KB (the sixth exists for waves 0..2)
-    vo_dr[0] = (uint32_t)(((w * RPW + n) * kRowU4DV + wave * 8 + q) * 16);
-    vo_dr[1] = vo_dr[0] + 4096u;
-    vo_dr[2] = vo_dr[1] + (wave < 3 ? 1024u : 0u);
+    vo_dr[0] = (uint32_t)((w * RPW + n) * kRowU4DV + wave * 8 + q) * PB;
+    vo_dr[1] = vo_dr[0] + 256u * PB;
+    vo_dr[2] = vo_dr[1] + (wave < 3 ? 64u * PB : 0u);
     lane_c = Lds<REP>::kD4 ? ((uint32_t)lane << 2)
              : (Lds<REP>::kRep1 == 32) ? ((((uint32_t)lane & 31u) << 3) | 0x00010000u)
                                        : ((((uint32_t)lane & 15u) << 3) | (uint32_t)Lds<REP>::kT1);
     lane_c2 = (((uint32_t)lane & 15u) << 3) | (uint32_t)Lds<REP>::kT2;
+    if constexpr (R3) lane_c3 = (((uint32_t)lane & (uint32_t)(Lds<REP>::kRep3 - 1)) << 3) | (uint32_t)Lds<REP>::kT3;
     xlane = (uint32_t)B::kArea + (uint32_t)min(n, 2) * (uint32_t)KV + (uint32_t)q * 64u + (uint32_t)wave * 512u;
   };
   rederive();
@@ -209,7 +220,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
     return reinterpret_cast<const uint4*>(((uint64_t)hi << 32) | lo);
   };
-  auto ld_item = [&](u32x4& da, u32x4& db, const uint4* base0, uint32_t vo) {
+  auto ld_item = [&](slot_t& da, slot_t& db, const uint4* base0, uint32_t vo) {
     const uint4* base = uni(base0);
     // s_nop: the base was just written by v_readfirstlane (VALU write of an SGPR -> VMEM read needs 5 wait states, and
     // the compiler pads no hazard for an instruction inside an asm statement)
@@ -230,11 +241,16 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     }                                                                                                                  \
   } while (0)
   // RVQ: the same with a compile-time byte offset (the second virtual slice of a row block is 1 KB further in the row)
-  auto ld_item_o = [&](auto off_c, u32x4& da, u32x4& db, const uint4* base0, uint32_t vo) {
-    constexpr int OFF = decltype(off_c)::value;
+  auto ld_item_o = [&](auto off_c, slot_t& da, slot_t& db, const uint4* base0, uint32_t vo) {
+    constexpr int OFF = decltype(off_c)::value / 16 * (int)PB;      // (written in RVQ4B's bytes)
     const uint4* base = uni(base0);
-    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(da) : "v"(vo), "s"(base), "n"(OFF) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(db) : "v"(vo), "s"(base), "n"(OFF + 64) : "memory");
+    if constexpr (R3) {
+      asm volatile("s_nop 4\n\tglobal_load_dwordx3 %0, %1, %2 offset:%3 nt" : "=v"(da) : "v"(vo), "s"(base), "n"(OFF) : "memory");
+      asm volatile("global_load_dwordx3 %0, %1, %2 offset:%3 nt" : "=v"(db) : "v"(vo), "s"(base), "n"(OFF + 48) : "memory");
+    } else {
+      asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(da) : "v"(vo), "s"(base), "n"(OFF) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(db) : "v"(vo), "s"(base), "n"(OFF + 64) : "memory");
+    }
   };
 #define OFFC(n) std::integral_constant<int, (n)>{}
   // RVQ slot plan (8 of the 9 slots): items (row block rb, virtual half h: slice wave + 8 h) of q k v / gate -> slot 3 h + rb;
@@ -283,6 +299,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   // ---- prologue ---------------------------------------------------------------------------------------------------
   u32x2 tsrc;
   asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(tsrc) : "v"(T::kD4 ? table_source_ptr_d4(a.grid, lane, wave) : table_source_ptr(a.grid, lane, wave)) : "memory");
+  u32x2 tsrc3 = {0u, 0u};                            // RVQ3B: this lane's E81B entry (row 32 wave + (lane & 31) of T3)
+  if constexpr (R3)
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(tsrc3) : "v"(reinterpret_cast<const uint2*>(a.grid2) + (wave * 32 + (lane & 31))) : "memory");
   uint32_t gen;
   esync::ld4(gen, ctl);
   u32x4 hpiece;
@@ -294,8 +313,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   constexpr int NQ = RVQ ? 12 : 6;                   // loads of the first q, k, v items in flight across the prologue
   int* accs = reinterpret_cast<int*>(smem + B::kAcc);
   for (int i = tid; i < B::kAccRows * 4; i += kThreads) accs[i] = 0;
-  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(tsrc) : "n"(2 + NQ) : "memory");
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(tsrc), "+v"(tsrc3) : "n"(2 + NQ) : "memory");
   fill_tables_from_lane<REP>(smem, tsrc, lane, wave);
+  fill_t3_from_lane<REP>(smem, tsrc3, lane, wave);
   asm volatile("s_waitcnt vmcnt(%1)" : "+v"(gen) : "n"(1 + NQ) : "memory");
   const uint32_t ebase = ((uint32_t)__builtin_amdgcn_readfirstlane((int)gen) + 1u) << 10;
   asm volatile("s_waitcnt vmcnt(%1)" : "+v"(hpiece) : "n"(NQ) : "memory");
@@ -461,7 +481,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   // ---- one item of a product: slot s, digit planes at xa ------------------------------------------------------------
   auto run_item = [&](int s, uint32_t xa, int accrow) {
     ItemAddr ad;
-    item_addresses<REP>(qa[s], qb[s], lane_c, lane_c2, ad, 0u);
+    item_addresses<REP>(qa[s], qb[s], lane_c, lane_c2, ad, lane_c3);
     const i32x4 r = T::kD4 ? item_mfma_d4(ad, xa) : item_mfma(ad, xa);
     if (q == 0) {
       int* dst = accs + (accrow + n) * 4;
@@ -481,7 +501,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     for (int i = 0; i < 3; ++i) {
       if (i > 0 && xas[i] != xas[i - 1]) item_fragments(xas[i], A);
       ItemAddr ad;
-      item_addresses<REP>(qa[s0 + i], qb[s0 + i], lane_c, lane_c2, ad, 0u);
+      item_addresses<REP>(qa[s0 + i], qb[s0 + i], lane_c, lane_c2, ad, lane_c3);
       const i32x4 r = item_mfma_shared<T::kD4>(ad, A);
       if (q == 0) {
         int* dst = accs + (accrow0 + 16 * i + n) * 4;
@@ -495,7 +515,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   // the eight MFMAs once the digit planes exist
   auto decode_item = [&](int s, i32x4 (&Bf)[8]) {
     ItemAddr ad;
-    item_addresses<REP>(qa[s], qb[s], lane_c, lane_c2, ad, 0u);
+    item_addresses<REP>(qa[s], qb[s], lane_c, lane_c2, ad, lane_c3);
     if constexpr (T::kD4) item_decode_d4(ad, Bf); else item_decode(ad, Bf);
   };
   auto add_rows = [&](const i32x4& r, int accrow) {
@@ -1250,7 +1270,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           const int sl = i * kWaves + wave;
           if (sl < B::JDV) {
             ItemAddr ad;
-            item_addresses<REP>(qa[i], qb[i], lane_c, lane_c2, ad, 0u);
+            item_addresses<REP>(qa[i], qb[i], lane_c, lane_c2, ad, lane_c3);
             add_rows(T::kD4 ? item_mfma_d4<272>(ad, xlane_d + (uint32_t)(sl * 544)) : item_mfma<272>(ad, xlane_d + (uint32_t)(sl * 544)), 160);
           }
         }
@@ -1260,7 +1280,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           const int sl = i * kWaves + wave;
           if (sl < JD) {
             ItemAddr ad;
-            item_addresses<REP>(qa[6 + i], qb[6 + i], lane_c, lane_c2, ad, 0u);
+            item_addresses<REP>(qa[6 + i], qb[6 + i], lane_c, lane_c2, ad, lane_c3);
             add_rows(T::kD4 ? item_mfma_d4<272>(ad, xlane_d + (uint32_t)(sl * 544)) : item_mfma<272>(ad, xlane_d + (uint32_t)(sl * 544)), 160);
           }
         }
@@ -1355,6 +1375,7 @@ int block_engine_launch(const BlockEngineArgs& in, hipStream_t stream) {
   a.dbg = reinterpret_cast<uint64_t*>(in.dbg);
   a.n_layers = in.n_layers; a.max_len = in.max_len; a.dbg_layer = in.dbg_layer;
   a.rms_eps = in.rms_eps; a.attn_scale = in.attn_scale; a.resid_scale = 0.f;
+  a.grid2 = in.grid2;
   // codebook 0: E8P12 (32 copies of the abs table, 16 of the sign table), 1: D4 (one table of 256 x 4 bytes, a private copy per lane)
   auto go = [&](auto kern, int lds, DynLdsCache& configured, ResidencyCache& resident) -> int {
     if (ensure_dyn_lds(configured, reinterpret_cast<const void*>(kern), lds) != QUIP_OK) return QUIP_ERR_LAUNCH;
@@ -1363,8 +1384,13 @@ int block_engine_launch(const BlockEngineArgs& in, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
   };
   static DynLdsCache c16, c64;
-  static DynLdsCache crvq, chi;
-  static ResidencyCache r16, r24, r64, rrvq, rhi;
+  static DynLdsCache crvq, chi, crvq3;
+  static ResidencyCache r16, r24, r64, rrvq, rhi, rrvq3;
+  if (in.codebook == 4) {
+    if (!in.grid2) return QUIP_ERR_NULL_POINTER;
+    a.resid_scale = in.resid_scale;
+    return go(decode_block_kernel<12, true>, BLds<12, true>::kBytes, crvq3, rrvq3);
+  }
   if (in.codebook == 3) return go(decode_block_kernel<64, true, true>, BLds<64, true>::kBytes, chi, rhi);
   if (in.codebook == 2) { a.resid_scale = in.resid_scale; return go(decode_block_kernel<16, true>, BLds<16, true>::kBytes, crvq, rrvq); }
   if (in.codebook == 1) return go(decode_block_kernel<64>, BLds<64>::kBytes, c64, r64);

@@ -38,10 +38,12 @@ struct Lds {
   //           E81B residual table (4r as int8; 16 / 8 copies), looked up by the LOW code of every dword; the
   //           weight stream is the checkpoint's own 3-byte codes (12-byte loads, 3 k / 8 bytes per row)
   static constexpr bool kD4 = REP == 64;
-  static constexpr bool kRvq3 = REP == 40 || REP == 20;
-  static constexpr int kRep1 = kD4 ? 64 : ((REP == 16 || REP == 20) ? 16 : 32);
+  // REP = 12: E8P12RVQ3B inside the persistent block launch -- 16 / 16 copies and FOUR of T3 (72 KB of tables: the virtual
+  //           rows' digit planes need the rest)
+  static constexpr bool kRvq3 = REP == 40 || REP == 20 || REP == 12;
+  static constexpr int kRep1 = kD4 ? 64 : ((REP == 16 || REP == 20 || REP == 12) ? 16 : 32);
   static constexpr int kRep2 = REP == 32 ? 32 : 16;
-  static constexpr int kRep3 = REP == 40 ? 16 : (REP == 20 ? 8 : 0);
+  static constexpr int kRep3 = REP == 40 ? 16 : (REP == 20 ? 8 : (REP == 12 ? 4 : 0));
   static constexpr int kRow1 = kRep1 * (kD4 ? 4 : 8);   // bytes per T1 entry row
   static constexpr int kRow2 = kD4 ? 0 : kRep2 * 8;     // bytes per T2 entry row
   static constexpr int kRow3 = kRep3 * 8;               // bytes per T3 entry row
@@ -211,7 +213,9 @@ __device__ __forceinline__ void item_addresses(const u32x4& q0, const u32x4& q1,
     if constexpr (Lds<REP>::kRvq3) {
       // RVQ3: the low code of the dword is (residual index << 8 | 0) and reads T3 (E81B); its sign byte is 0
       // and T2[0] == 0, so the generic "T1 ^ T2" below leaves the T3 entry unchanged
-      ad.a1l[t] = Lds<REP>::kRep3 == 16 ? (((d[t] >> 1) & 0x7f80u) | lane_c3) : (((d[t] >> 2) & 0x3fc0u) | lane_c3);
+      ad.a1l[t] = Lds<REP>::kRep3 == 16  ? (((d[t] >> 1) & 0x7f80u) | lane_c3)
+                  : Lds<REP>::kRep3 == 8 ? (((d[t] >> 2) & 0x3fc0u) | lane_c3)
+                                         : (((d[t] >> 3) & 0x1fe0u) | lane_c3);
     }
     if constexpr (REP == 32) {
       // T2 base 0x10000 comes from byte 2 of lane_c

@@ -211,8 +211,9 @@ struct BlockEngineArgs {
   void* dbg = nullptr;
   int n_layers = 0, max_len = 0, dbg_layer = -1;
   float rms_eps = 1e-5f, attn_scale = 1.f;
-  int codebook = 0;                  // 0: E8P12 (grid = grid_packed_abs), 1: D4 (grid = the fp16 (256, 4) table), 2: E8P12RVQ4B, 3: HI (grid = the byte table)
-  float resid_scale = 0.f;           // codebook 2: the fp16 residual scale
+  int codebook = 0;                  // 0: E8P12 (grid = grid_packed_abs), 1: D4 (grid = the fp16 (256, 4) table), 2: E8P12RVQ4B, 3: HI (grid = the byte table), 4: E8P12RVQ3B
+  float resid_scale = 0.f;           // codebooks 2, 4: the fp16 residual scale
+  const void* grid2 = nullptr;       // codebook 4 (E8P12RVQ3B): int8 (256, 8) E81B table
 };
 bool block_engine_supported(int hidden, int heads, int kv_heads, int head_dim, int n_ffn, int K);
 size_t block_engine_workspace_bytes();

@@ -242,9 +242,9 @@ class LlamaDecoder:
             from .register_lib import ffn_engine_workspace
             self.ffn_ws = ffn_engine_workspace(s.ffn, L0["gate"].K_right, self.dev)
         # all blocks of a token as ONE persistent launch (csrc/decode_block.hip); QUIP_BLOCK_ENGINE=0 keeps the stage-wise step
-        # (E8P12; D4 through the same kernel's one-table mode; E8P12RVQ4B and HI as rows of twice the virtual width)
+        # (E8P12; D4 through the same kernel's one-table mode; E8P12RVQ4B, E8P12RVQ3B and HI as rows of twice the virtual width)
         self.block_eng = False
-        d4 = all(getattr(m.codebook, "id", None) in ("D4", "E8P12RVQ4B", "HI") for m in L0.values() if isinstance(m, QuantLinear))
+        d4 = all(getattr(m.codebook, "id", None) in ("D4", "E8P12RVQ4B", "HI", "E8P12RVQ3B") for m in L0.values() if isinstance(m, QuantLinear))
         gqa_shape = self.fused_prologue and self.chain and s.kv_heads != s.heads and s.hidden == 8192   # (csrc/decode_block_gqa.hip)
         if ((self.ffn_eng or gqa_shape or (d4 and self.fused_prologue and self.chain and os.environ.get("QUIP_FFN_ENGINE", "1") != "0"))
                 and os.environ.get("QUIP_BLOCK_ENGINE", "1") != "0" and not self.window):   # (its attention walks [0, pos])
@@ -268,7 +268,7 @@ class LlamaDecoder:
         names = ("q", "k", "v", "o", "gate", "up", "down")
 
         cbid = getattr(L0["q"].codebook, "id", None)
-        if cbid not in ("E8P12", "D4", "E8P12RVQ4B", "HI"):
+        if cbid not in ("E8P12", "D4", "E8P12RVQ4B", "HI", "E8P12RVQ3B"):
             return
 
         def plain(m, n_in, n_out):
@@ -340,10 +340,12 @@ class LlamaDecoder:
         self.eng_layers = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).to(self.dev)
         self.eng_shape = 1 if gqa else 0
         self.eng_ws = block_engine_workspace(self.dev, self.eng_shape)
-        self.eng_codebook = {"E8P12": 0, "D4": 1, "E8P12RVQ4B": 2, "HI": 3}[cbid]
+        self.eng_codebook = {"E8P12": 0, "D4": 1, "E8P12RVQ4B": 2, "HI": 3, "E8P12RVQ3B": 4}[cbid]
         cb0 = L0["q"].codebook
         self.eng_grid = cb0.grid if cbid == "D4" else (cb0._virtual_grid(self.dev) if cbid == "HI" else cb0.grid_packed_abs)
-        self.eng_resid_scale = float(getattr(L0["q"].codebook, "planes_resid_scale", 0.0)) if cbid == "E8P12RVQ4B" else 0.0
+        self.eng_resid_scale = (float(getattr(L0["q"].codebook, "planes_resid_scale", 0.0))
+                                if cbid in ("E8P12RVQ4B", "E8P12RVQ3B") else 0.0)
+        self.eng_grid2 = cb0._e81b_i8(self.dev) if cbid == "E8P12RVQ3B" else None      # int8 (256, 8): 4 x the E81B entries
         self._eng_sig = self._engine_signature()
         self.block_eng = True
 
@@ -412,7 +414,7 @@ class LlamaDecoder:
             h = torch.ops.quip_lib.block_engine(self.eng_layers, h.reshape(-1), self.pos, self.cos, self.sin,
                                                 self.eng_grid, self.eng_ws, len(self.layers), self.max_len, s.rms_eps,
                                                 1.0 / math.sqrt(s.head_dim), None, -1, self.eng_codebook, self.eng_resid_scale,
-                                                getattr(self, "eng_shape", 0))
+                                                getattr(self, "eng_shape", 0), getattr(self, "eng_grid2", None))
             return self._head(h.reshape(1, -1))
         if self.fused_prologue:
             return self._step_fused(h, cos, sin, mask)

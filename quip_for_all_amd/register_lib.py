@@ -96,7 +96,7 @@ _SCHEMAS = {
     # `layers` = the packed descriptors (decode.py builds them; they point at the KV caches, which the launch appends to)
     "block_engine": "(Tensor layers, Tensor h_in, Tensor pos, Tensor cos, Tensor sin, Tensor grid, Tensor(a!) workspace, "
                     "int n_layers, int max_len, float rms_eps, float attn_scale, Tensor? dbg=None, int dbg_layer=-1, "
-                    "int codebook=0, float resid_scale=0.0, int shape=0) -> Tensor",
+                    "int codebook=0, float resid_scale=0.0, int shape=0, Tensor? grid2=None) -> Tensor",
     # decode-step glue between q/k/v_proj and o_proj: rope + KV-cache append + single-query attention
     "rope_attn_decode": "(Tensor q, Tensor k, Tensor v, Tensor cos, Tensor sin, Tensor pos, Tensor(a!) kcache, "
                         "Tensor(b!) vcache, Tensor(c!)? workspace, int window=0) -> Tensor",   # window > 0: the last `window` positions only
@@ -679,7 +679,7 @@ def block_engine_gqa_supported(hidden, heads, kv_heads, head_dim, n_ffn, K):
 
 
 def _block_engine_cuda(layers, h_in, pos, cos, sin, grid, workspace, n_layers, max_len, rms_eps, attn_scale, dbg=None,
-                       dbg_layer=-1, codebook=0, resid_scale=0.0, shape=0):
+                       dbg_layer=-1, codebook=0, resid_scale=0.0, shape=0, grid2=None):
     dev = h_in.device
     lb = capi.lib().quip_block_engine_layer_bytes()
     _need(layers.dtype == torch.uint8 and layers.is_contiguous() and layers.numel() >= n_layers * lb and layers.device == dev,
@@ -698,10 +698,14 @@ def _block_engine_cuda(layers, h_in, pos, cos, sin, grid, workspace, n_layers, m
         _need(g.device == dev and g.numel() == 1024, "D4 / HI grid: fp16 (256, 4) on the device")
     else:
         g = _grid_i64(grid, h_in)
+    if codebook == 4:           # E8P12RVQ3B: the E81B table as int8 (256, 8) = 4 r
+        _need(grid2 is not None and grid2.dtype == torch.int8 and grid2.is_contiguous() and grid2.numel() == 2048 and grid2.device == dev,
+              "grid2: the E81B table as int8 (256, 8) on the device")
     out = torch.empty_like(h_in)
     a = capi.BlockEngineArgs(layers.data_ptr(), h_in.data_ptr(), out.data_ptr(), pos.data_ptr(), cos.data_ptr(),
                              sin.data_ptr(), g.data_ptr(), workspace.data_ptr(), _ptr(dbg), int(n_layers), int(max_len),
-                             int(dbg_layer), float(rms_eps), float(attn_scale), int(codebook), float(resid_scale), int(shape))
+                             int(dbg_layer), float(rms_eps), float(attn_scale), int(codebook), float(resid_scale), int(shape),
+                             _ptr(grid2) if codebook == 4 else None)
     import ctypes
     with torch.cuda.device(dev):
         capi.check(capi.lib().quip_block_engine(ctypes.byref(a), _stream(h_in)), "quip_block_engine")
@@ -1156,7 +1160,7 @@ _reg_fake("e8p_gemv_fused", lambda x, z, post, residual, rms_weight, rms_eps, z_
 _reg_fake("ffn_engine", lambda planes_gate, planes_up, q_gate, q_up, q_down, had3, sv_gate, sv_up, su_down, grid, workspace,
           out_scale, in_scale, K, dbg=None: q_down.new_empty((1, q_down.shape[0]), dtype=torch.float16))
 _reg_fake("block_engine", lambda layers, h_in, pos, cos, sin, grid, workspace, n_layers, max_len, rms_eps, attn_scale,
-          dbg=None, dbg_layer=-1, codebook=0, resid_scale=0.0, shape=0: torch.empty_like(h_in))
+          dbg=None, dbg_layer=-1, codebook=0, resid_scale=0.0, shape=0, grid2=None: torch.empty_like(h_in))
 _reg_fake("rope_attn_decode", lambda q, k, v, cos, sin, pos, kcache, vcache, workspace=None, window=0: torch.empty_like(q))
 _reg_fake("rope_attn_decode_z", lambda zs, posts, scales, cos, sin, pos, kcache, vcache, workspace=None, window=0:
           kcache.new_empty((zs[0].numel() // kcache.shape[2], kcache.shape[2])))

@@ -123,10 +123,11 @@ def test_block_engine_long_context_split_attention(pos0):
                 a.tok.copy_(b.tok)                        # keep the two on the same token whatever a near tie decides
 
 
-@pytest.mark.parametrize("codebook,code", [("D4", 1), ("E8P12RVQ4B", 2), ("HI", 3)])
+@pytest.mark.parametrize("codebook,code", [("D4", 1), ("E8P12RVQ4B", 2), ("HI", 3), ("E8P12RVQ3B", 4)])
 def test_block_engine_d4_matches_stagewise(codebook, code):
     """the D4 codebook (one table of 256 x 4 bytes, a private copy per lane) and E8P12RVQ4B (virtual rows of twice the
     width against x' = [s x_g | x_g]: twice the digits and items) and HI (a code byte as a D4 code of a row of twice the width)
+    and E8P12RVQ3B (the 3-byte codes as RVQ4-style virtual rows whose low codes read the E81B table)
     through the same persistent launch: against the plain
     stage-wise step of the same model -- logits to the MLP edge's rounding, the same greedy tokens"""
     a = _decoder(2, True, max_len=40, codebook=codebook)
