@@ -671,6 +671,7 @@ def main():
             extras = {}
             for key, (shp, cbk, st, kw) in {"llama2_70b_e8p12": (D.LLAMA2_70B, "E8P12", 32, {}),
                                             "llama2_7b_e8p12rvq4b": (D.LLAMA2_7B, "E8P12RVQ4B", 64, {}),
+                                            "llama2_7b_e8p12rvq3b": (D.LLAMA2_7B, "E8P12RVQ3B", 64, {}),
                                             "llama2_7b_d4": (D.LLAMA2_7B, "D4", 64, {}),
                                             "llama2_7b_hi": (D.LLAMA2_7B, "HI", 64, {}),
                                             # a grouped-query block outside the persistent launch's shape (stage-wise step)
