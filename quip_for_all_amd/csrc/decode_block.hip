@@ -482,7 +482,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   auto run_item = [&](int s, uint32_t xa, int accrow) {
     ItemAddr ad;
     item_addresses<REP>(qa[s], qb[s], lane_c, lane_c2, ad, lane_c3);
-    const i32x4 r = T::kD4 ? item_mfma_d4(ad, xa) : item_mfma(ad, xa);
+    const i32x4 r = T::kD4 ? item_mfma_d4(ad, xa) : item_mfma<256, R3>(ad, xa);
     if (q == 0) {
       int* dst = accs + (accrow + n) * 4;
       __hip_atomic_fetch_add(dst + 0, r.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       if (i > 0 && xas[i] != xas[i - 1]) item_fragments(xas[i], A);
       ItemAddr ad;
       item_addresses<REP>(qa[s0 + i], qb[s0 + i], lane_c, lane_c2, ad, lane_c3);
-      const i32x4 r = item_mfma_shared<T::kD4>(ad, A);
+      const i32x4 r = item_mfma_shared<T::kD4, R3>(ad, A);
       if (q == 0) {
         int* dst = accs + (accrow0 + 16 * i + n) * 4;
         __hip_atomic_fetch_add(dst + 0, r.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   auto decode_item = [&](int s, i32x4 (&Bf)[8]) {
     ItemAddr ad;
     item_addresses<REP>(qa[s], qb[s], lane_c, lane_c2, ad, lane_c3);
-    if constexpr (T::kD4) item_decode_d4(ad, Bf); else item_decode(ad, Bf);
+    if constexpr (T::kD4) item_decode_d4(ad, Bf); else item_decode<R3>(ad, Bf);
   };
   auto add_rows = [&](const i32x4& r, int accrow) {
     if (q == 0) {
@@ -1271,7 +1271,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           if (sl < B::JDV) {
             ItemAddr ad;
             item_addresses<REP>(qa[i], qb[i], lane_c, lane_c2, ad, lane_c3);
-            add_rows(T::kD4 ? item_mfma_d4<272>(ad, xlane_d + (uint32_t)(sl * 544)) : item_mfma<272>(ad, xlane_d + (uint32_t)(sl * 544)), 160);
+            add_rows(T::kD4 ? item_mfma_d4<272>(ad, xlane_d + (uint32_t)(sl * 544)) : item_mfma<272, R3>(ad, xlane_d + (uint32_t)(sl * 544)), 160);
           }
         }
       } else {
@@ -1281,7 +1281,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           if (sl < JD) {
             ItemAddr ad;
             item_addresses<REP>(qa[6 + i], qb[6 + i], lane_c, lane_c2, ad, lane_c3);
-            add_rows(T::kD4 ? item_mfma_d4<272>(ad, xlane_d + (uint32_t)(sl * 544)) : item_mfma<272>(ad, xlane_d + (uint32_t)(sl * 544)), 160);
+            add_rows(T::kD4 ? item_mfma_d4<272>(ad, xlane_d + (uint32_t)(sl * 544)) : item_mfma<272, R3>(ad, xlane_d + (uint32_t)(sl * 544)), 160);
           }
         }
       }

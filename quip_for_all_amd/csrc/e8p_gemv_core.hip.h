@@ -278,12 +278,14 @@ __device__ __forceinline__ i32x4 item_mfma_d4(const ItemAddr& ad, uint32_t xaddr
 
 // HALF: bytes between the digits of k and k + 256 of a plane (256 in the plain [3][Kp] image; the engine pads
 // every 256 digits by 16 bytes)
-template <int HALF = 256>
+// R3 (E8P12RVQ3B, callers that opt in): the low code of a dword is a residual index whose sign byte is 0 and T2[0] == 0 --
+// its sign look-up is skipped (a quarter of the item's LDS reads), same integers
+template <int HALF = 256, bool R3 = false>
 __device__ __forceinline__ i32x4 item_mfma(const ItemAddr& ad, uint32_t xaddr) {
   constexpr int PIPE = QUIP_GEMV_PIPE;
   StepOperands op[8];
   auto issue = [&](int t) {
-    op[t].t1l = lds_read8(ad.a1l[t]); op[t].t2l = lds_read8(ad.a2l[t]);
+    op[t].t1l = lds_read8(ad.a1l[t]); op[t].t2l = R3 ? make_uint2(0u, 0u) : lds_read8(ad.a2l[t]);
     op[t].t1h = lds_read8(ad.a1h[t]); op[t].t2h = lds_read8(ad.a2h[t]);
     op[t].A = lds_read16i(xaddr + (kR8 ? 64 * (t >> 2) + 16 * (t & 3) : (t < 4 ? 16 * t : HALF + 16 * (t - 4))));
   };
@@ -304,10 +306,11 @@ __device__ __forceinline__ i32x4 item_mfma(const ItemAddr& ad, uint32_t xaddr) {
 // persistent decode engine decodes while it waits for a hand-off): item_decode() turns the 32 addresses into the eight B
 // fragments (all the table lookups), item_multiply() reads the eight A fragments and runs the MFMAs.  Same operations, same
 // integer sums as item_mfma().
+template <bool R3 = false>
 __device__ __forceinline__ void item_decode(const ItemAddr& ad, i32x4 (&B)[8]) {
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    const uint2 t1l = lds_read8(ad.a1l[t]), t2l = lds_read8(ad.a2l[t]);
+    const uint2 t1l = lds_read8(ad.a1l[t]), t2l = R3 ? make_uint2(0u, 0u) : lds_read8(ad.a2l[t]);
     const uint2 t1h = lds_read8(ad.a1h[t]), t2h = lds_read8(ad.a2h[t]);
     B[t] = i32x4{(int)(t1l.x ^ t2l.x), (int)(t1l.y ^ t2l.y), (int)(t1h.x ^ t2h.x), (int)(t1h.y ^ t2h.y)};
   }
@@ -335,7 +338,7 @@ __device__ __forceinline__ void item_fragments(uint32_t xaddr, i32x4 (&A)[8]) {
 #pragma unroll
   for (int t = 0; t < 8; ++t) A[t] = lds_read16i(xaddr + (t < 4 ? 16 * t : HALF + 16 * (t - 4)));
 }
-template <bool D4>
+template <bool D4, bool R3 = false>
 __device__ __forceinline__ i32x4 item_mfma_shared(const ItemAddr& ad, const i32x4 (&A)[8]) {
   constexpr int PIPE = QUIP_GEMV_PIPE;
   i32x4 acc = {0, 0, 0, 0};
@@ -354,7 +357,7 @@ __device__ __forceinline__ i32x4 item_mfma_shared(const ItemAddr& ad, const i32x
   } else {
     uint2 o[8][4];
     auto issue = [&](int t) {
-      o[t][0] = lds_read8(ad.a1l[t]); o[t][1] = lds_read8(ad.a2l[t]);
+      o[t][0] = lds_read8(ad.a1l[t]); o[t][1] = R3 ? make_uint2(0u, 0u) : lds_read8(ad.a2l[t]);
       o[t][2] = lds_read8(ad.a1h[t]); o[t][3] = lds_read8(ad.a2h[t]);
     };
 #pragma unroll
