@@ -414,7 +414,8 @@ class LlamaDecoder:
             h = torch.ops.quip_lib.block_engine(self.eng_layers, h.reshape(-1), self.pos, self.cos, self.sin,
                                                 self.eng_grid, self.eng_ws, len(self.layers), self.max_len, s.rms_eps,
                                                 1.0 / math.sqrt(s.head_dim), None, -1, self.eng_codebook, self.eng_resid_scale,
-                                                getattr(self, "eng_shape", 0), getattr(self, "eng_grid2", None))
+                                                getattr(self, "eng_shape", 0), getattr(self, "eng_grid2", None),
+                                                self.kcache, self.vcache)
             return self._head(h.reshape(1, -1))
         if self.fused_prologue:
             return self._step_fused(h, cos, sin, mask)

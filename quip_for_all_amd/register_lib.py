@@ -96,7 +96,10 @@ _SCHEMAS = {
     # `layers` = the packed descriptors (decode.py builds them; they point at the KV caches, which the launch appends to)
     "block_engine": "(Tensor layers, Tensor h_in, Tensor pos, Tensor cos, Tensor sin, Tensor grid, Tensor(a!) workspace, "
                     "int n_layers, int max_len, float rms_eps, float attn_scale, Tensor? dbg=None, int dbg_layer=-1, "
-                    "int codebook=0, float resid_scale=0.0, int shape=0, Tensor? grid2=None) -> Tensor",
+                    "int codebook=0, float resid_scale=0.0, int shape=0, Tensor? grid2=None, "
+                    # the KV caches the descriptors point into: row *pos of every block is written (declared here so that the
+                    # mutation is visible to PyTorch; the kernel reaches them through the descriptors)
+                    "Tensor(b!)? kcache=None, Tensor(c!)? vcache=None) -> Tensor",
     # decode-step glue between q/k/v_proj and o_proj: rope + KV-cache append + single-query attention
     "rope_attn_decode": "(Tensor q, Tensor k, Tensor v, Tensor cos, Tensor sin, Tensor pos, Tensor(a!) kcache, "
                         "Tensor(b!) vcache, Tensor(c!)? workspace, int window=0) -> Tensor",   # window > 0: the last `window` positions only
@@ -679,7 +682,7 @@ def block_engine_gqa_supported(hidden, heads, kv_heads, head_dim, n_ffn, K):
 
 
 def _block_engine_cuda(layers, h_in, pos, cos, sin, grid, workspace, n_layers, max_len, rms_eps, attn_scale, dbg=None,
-                       dbg_layer=-1, codebook=0, resid_scale=0.0, shape=0, grid2=None):
+                       dbg_layer=-1, codebook=0, resid_scale=0.0, shape=0, grid2=None, kcache=None, vcache=None):
     dev = h_in.device
     lb = capi.lib().quip_block_engine_layer_bytes()
     _need(layers.dtype == torch.uint8 and layers.is_contiguous() and layers.numel() >= n_layers * lb and layers.device == dev,
@@ -1160,7 +1163,7 @@ _reg_fake("e8p_gemv_fused", lambda x, z, post, residual, rms_weight, rms_eps, z_
 _reg_fake("ffn_engine", lambda planes_gate, planes_up, q_gate, q_up, q_down, had3, sv_gate, sv_up, su_down, grid, workspace,
           out_scale, in_scale, K, dbg=None: q_down.new_empty((1, q_down.shape[0]), dtype=torch.float16))
 _reg_fake("block_engine", lambda layers, h_in, pos, cos, sin, grid, workspace, n_layers, max_len, rms_eps, attn_scale,
-          dbg=None, dbg_layer=-1, codebook=0, resid_scale=0.0, shape=0, grid2=None: torch.empty_like(h_in))
+          dbg=None, dbg_layer=-1, codebook=0, resid_scale=0.0, shape=0, grid2=None, kcache=None, vcache=None: torch.empty_like(h_in))
 _reg_fake("rope_attn_decode", lambda q, k, v, cos, sin, pos, kcache, vcache, workspace=None, window=0: torch.empty_like(q))
 _reg_fake("rope_attn_decode_z", lambda zs, posts, scales, cos, sin, pos, kcache, vcache, workspace=None, window=0:
           kcache.new_empty((zs[0].numel() // kcache.shape[2], kcache.shape[2])))
