@@ -497,6 +497,40 @@ def hf_static_cache_extra(D, device, new_tokens=128, cache_len=2048):
         out["hf_%s_runs" % mode] = [round(x, 2) for x in ts]
         del dec
     out["hf_graph_equals_eager"] = bool(torch.equal(toks["eager"], toks["graph"]))
+    # the SAME harness on the SAME model object with hf_fast.enable_fast_decode (what load_quantized_model switches on):
+    # single-token calls on the StaticCache run LlamaDecoder.step() on the cache's own tensors
+    try:
+        from quip_for_all_amd.hf_fast import enable_fast_decode, disable_fast_decode
+        enable_fast_decode(model)
+        for mode in ("eager", "graph"):
+            dec = HFStaticDecoder(model, max_cache_len=cache_len)
+            dec.generate(ids, 8, mode)
+            ts = []
+            for _ in range(3):
+                t, dt = dec.generate(ids, new_tokens, mode)
+                ts.append((new_tokens - 1) / dt)
+            out["hf_fast_decode_%s_tokens_per_s" % mode] = round(float(np.median(ts)), 2)
+            out["hf_fast_decode_%s_runs" % mode] = [round(x, 2) for x in ts]
+            out["hf_fast_decode_%s_tokens_equal_to_stock" % mode] = "%d / %d" % (int((t == toks["eager"]).sum()), new_tokens)
+            del dec
+        fd = model._quip_fast_decode
+        out["hf_fast_decode_step"] = ("persistent block launch" if getattr(fd.dec, "block_eng", False) else "stage-wise") \
+            if fd.dec is not None else "refused: %s" % fd.disabled
+        # HF's own loop: model.generate(cache_implementation="static"), greedy, timed whole (prompt pass included)
+        model.generation_config.eos_token_id = None
+        model.generation_config.pad_token_id = 0
+        model.generate(ids, max_new_tokens=8, do_sample=False, cache_implementation="static")
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            model.generate(ids, max_new_tokens=new_tokens, do_sample=False, cache_implementation="static")
+            torch.cuda.synchronize()
+            ts.append(new_tokens / (time.perf_counter() - t0))
+        out["hf_generate_api_fast_decode_tokens_per_s"] = round(float(np.median(ts)), 2)
+        disable_fast_decode(model)
+    except Exception as e:
+        out["hf_fast_decode_error"] = repr(e)[:300]
     fast = D.LlamaDecoder.from_hf(model, max_len=cache_len)
     fast.generate(8, prompt=ids[0])
     ts = []

@@ -111,10 +111,12 @@ class LlamaDecoder:
     LLAMA_LIKE = ("llama", "mistral", "qwen2")
 
     @classmethod
-    def from_hf(cls, model, max_len=256, device=None, assume_llama_like=False):
+    def from_hf(cls, model, max_len=256, device=None, assume_llama_like=False, kv_cache=None):
         """Fast bs=1 decoder around a Llama-architecture HF model whose linear layers are QuantLinear
         (what `load_quantized_model` returns): shares the modules / weights, adds the static KV cache and
         the captured step.  Needs `model.model.{embed_tokens, layers, norm}` and `model.lm_head`.
+        `kv_cache` = (keys, values): per-layer fp16 tensors (kv_heads, max_len, head_dim) to use as the static cache instead of
+        allocating one (hf_fast.py binds the tensors of a transformers StaticCache this way; bind_kv() swaps them later).
         Architectures outside LLAMA_LIKE are refused (Gemma scales embeddings and norms, StableLM uses LayerNorm, ...:
         the module names match, the arithmetic does not) unless `assume_llama_like` vouches for them; such checkpoints run
         through `load_quantized_model` + the stock HF `generate`."""
@@ -183,6 +185,7 @@ class LlamaDecoder:
                             heads=heads, kv_heads=getattr(cfg, "num_key_value_heads", heads) or heads,
                             vocab=cfg.vocab_size, rms_eps=cfg.rms_norm_eps, rope_theta=float(rope))
         self.dev, self.max_len = dev, max_len
+        self._external_kv = kv_cache
         h16 = lambda t: t.detach().to(device=dev, dtype=torch.float16).contiguous()  # noqa: E731
         self.embed = h16(model.model.embed_tokens.weight)
         self.lm_head = h16(model.lm_head.weight)
@@ -202,8 +205,12 @@ class LlamaDecoder:
 
     def _init_runtime(self):
         s, max_len = self.s, self.max_len
-        self.kcache = torch.zeros(s.layers, s.kv_heads, max_len, s.head_dim, dtype=torch.float16, device=self.dev)
-        self.vcache = torch.zeros_like(self.kcache)
+        ext = getattr(self, "_external_kv", None)
+        if ext is not None:
+            self.kcache, self.vcache = self._check_kv(*ext)
+        else:
+            self.kcache = torch.zeros(s.layers, s.kv_heads, max_len, s.head_dim, dtype=torch.float16, device=self.dev)
+            self.vcache = torch.zeros_like(self.kcache)
         inv = getattr(self, "_inv_freq", None)
         if inv is None:
             inv = 1.0 / (s.rope_theta ** (torch.arange(0, s.head_dim, 2, dtype=torch.float32) / s.head_dim))
@@ -365,6 +372,29 @@ class LlamaDecoder:
         v = int(ws[8:12].view(torch.int32).item())
         return v - 1 if v > 0 else None
 
+    def _check_kv(self, keys, values):
+        s = self.s
+        keys, values = list(keys), list(values)
+        if len(keys) != s.layers or len(values) != s.layers:
+            raise ValueError(f"kv_cache: {s.layers} key and value tensors expected")
+        for t in keys + values:
+            if (tuple(t.shape) != (s.kv_heads, self.max_len, s.head_dim) or t.dtype != torch.float16 or not t.is_contiguous()
+                    or t.device != self.dev):
+                raise ValueError(f"kv_cache tensors: contiguous fp16 ({s.kv_heads}, {self.max_len}, {s.head_dim}) on {self.dev}")
+        return keys, values
+
+    def bind_kv(self, keys, values):
+        """use other cache tensors (same shapes) from now on: the stage-wise step reads self.kcache[i] at every call; the
+        block launch's descriptors hold the row pointers (words 24, 25 of a 256-byte descriptor) and are patched in place;
+        a captured step is dropped (its launches hold the old pointers)"""
+        self.kcache, self.vcache = self._check_kv(keys, values)
+        if getattr(self, "block_eng", False):
+            import numpy as np
+            ptr = np.array([[k.data_ptr(), v.data_ptr()] for k, v in zip(self.kcache, self.vcache)], dtype=np.uint64)
+            rec = self.eng_layers.view(torch.int64).view(len(self.layers), 32)
+            rec[:, 24:26] = torch.from_numpy(ptr.view(np.int64)).to(self.dev)
+        self.graph = None
+
     def engine_reset(self):
         """after a launch that gave up: workspaces back to their allocation state (generation 0, no granules, no code)"""
         for ws in (getattr(self, "eng_ws", None), getattr(self, "ffn_ws", None)):
@@ -415,7 +445,7 @@ class LlamaDecoder:
                                                 self.eng_grid, self.eng_ws, len(self.layers), self.max_len, s.rms_eps,
                                                 1.0 / math.sqrt(s.head_dim), None, -1, self.eng_codebook, self.eng_resid_scale,
                                                 getattr(self, "eng_shape", 0), getattr(self, "eng_grid2", None),
-                                                self.kcache, self.vcache)
+                                                *((self.kcache, self.vcache) if torch.is_tensor(self.kcache) else (None, None)))
             return self._head(h.reshape(1, -1))
         if self.fused_prologue:
             return self._step_fused(h, cos, sin, mask)

@@ -258,11 +258,16 @@ def finalize_quant_layers(model: nn.Module, merge_suv: bool = False):
 def load_quantized_model(save_folder: str, revision: Optional[str] = None,
                          torch_dtype: Optional[Union[str, torch.dtype]] = torch.float16,
                          trust_remote_code: bool = True, use_safetensors: bool = False,
-                         device_map: Optional[Union[str, Dict]] = None, _require_gpu: bool = True):
+                         device_map: Optional[Union[str, Dict]] = None, _require_gpu: bool = True,
+                         fast_decode: Optional[bool] = None):
     """Load a QuIP-for-all checkpoint directory into a HF causal LM whose linear layers are
     QuantLinear (quantizer.py:779-848).  Like the reference: needs a GPU (raises otherwise),
     default device_map leaves the weights on the CPU ({"": "cpu"}), the model comes back in eval
-    mode with `is_quantized = True`.  device_map may also be a device string or {"": device}."""
+    mode with `is_quantized = True`.  device_map may also be a device string or {"": device}.
+    fast_decode (not in the reference; default on, QUIP_FAST_DECODE=0 or fast_decode=False switches it off): single-token
+    forward calls on an initialised transformers StaticCache -- the reference's decode loop, example_generate.py:28-33, and
+    `generate(cache_implementation="static")` -- run the fused decoder on the same modules and cache tensors (hf_fast.py);
+    every other call is the stock forward."""
     if _require_gpu and not torch.cuda.is_available():
         raise RuntimeError("No GPU found. A GPU is needed to run quantized model.")          # quantizer.py:799-801
     if not os.path.isdir(save_folder):
@@ -330,6 +335,11 @@ def load_quantized_model(save_folder: str, revision: Optional[str] = None,
         model = model.to(dev)
     model.is_quantized = True
     model.eval()
+    if fast_decode is None:
+        fast_decode = os.environ.get("QUIP_FAST_DECODE", "1") != "0"
+    if fast_decode:
+        from .hf_fast import enable_fast_decode
+        enable_fast_decode(model)
     return model
 
 

@@ -273,3 +273,59 @@ def test_hf_static_cache_step_captured_in_a_graph_equals_eager():
     ref = model.generate(ids, max_new_tokens=16, do_sample=False)[0, ids.shape[1]:]
     n = min(len(ref), 16)
     assert n >= 8 and torch.equal(ref[:n], graph[:n]), (ref, graph)
+
+
+def test_fast_decode_wrapper_routes_static_cache_steps_through_the_decoder():
+    """hf_fast.enable_fast_decode: single-token calls on an initialised StaticCache run LlamaDecoder.step() on the cache
+    object's own tensors; the prompt and everything else stays on the stock forward.  Same greedy tokens as the stock
+    harness (a near tie may flip one: logits are compared too), cache rows and lengths as StaticLayer.update leaves them,
+    and `model.generate(cache_implementation="static")` goes through the wrapper as well."""
+    from transformers import AutoModelForCausalLM
+    from quip_for_all_amd.quantizer import QuipQuantizer
+    from quip_for_all_amd.hf_static import HFStaticDecoder
+    from quip_for_all_amd.hf_fast import enable_fast_decode, disable_fast_decode
+    torch.manual_seed(0)
+    model = AutoModelForCausalLM.from_config(_tiny_config(), dtype=torch.float16)
+    qz = QuipQuantizer(codebook="E8P12", inference=True, ft_epochs=0)
+    qz.convert_model(model)
+    _fill_random(model, seed=3)
+    model = model.to("cuda:0").eval()
+    model.generation_config.eos_token_id = None
+    ids = torch.tensor([[1, 17, 42, 99, 7, 250]], device="cuda:0")
+    stock = HFStaticDecoder(model, max_cache_len=64)
+    want, _ = stock.generate(ids, 16, "eager")
+    enable_fast_decode(model)
+    fd = model._quip_fast_decode
+    fast = HFStaticDecoder(model, max_cache_len=64)
+    got, _ = fast.generate(ids, 16, "eager")
+    assert fd.disabled is None and fd.fast_steps == 15, (fd.disabled, fd.fast_steps)
+    assert int((got == want).sum()) >= 14, (got, want)
+    # cache bookkeeping and rows: as the stock path leaves them
+    n = ids.shape[1] + 15
+    for Ls, Lf in zip(stock.cache.layers, fast.cache.layers):
+        assert int(Lf.cumulative_length) == n == int(Ls.cumulative_length)
+    if torch.equal(got, want):
+        for Ls, Lf in zip(stock.cache.layers, fast.cache.layers):
+            dk = (Lf.keys[:, :, :n].float() - Ls.keys[:, :, :n].float()).abs().max().item()
+            dv = (Lf.values[:, :, :n].float() - Ls.values[:, :, :n].float()).abs().max().item()
+            assert dk <= 2.0 ** -5 * Ls.keys.float().abs().max().item() and dv <= 2.0 ** -5 * Ls.values.float().abs().max().item(), (dk, dv)
+    # one step's logits against the stock forward on the same cache state
+    a, b = HFStaticDecoder(model, max_cache_len=64), HFStaticDecoder(model, max_cache_len=64)
+    a.prefill(ids)
+    disable_fast_decode(model)
+    b.prefill(ids)
+    lb = b._forward(b.tok, b.pos).float()
+    enable_fast_decode(model)
+    la = a._forward(a.tok, a.pos).float()
+    assert (la - lb).abs().max().item() <= 2.0 ** -6 * lb.abs().max().item(), (la - lb).abs().max().item()
+    # the captured step (the reference's reduce-overhead counterpart) on the wrapper, and a second cache object (re-bound)
+    g = HFStaticDecoder(model, max_cache_len=64)
+    gt, _ = g.generate(ids, 16, "graph")
+    assert int((gt == want).sum()) >= 14, (gt, want)
+    # HF's own generate with a static cache
+    steps0 = model._quip_fast_decode.fast_steps
+    ref = model.generate(ids, max_new_tokens=12, do_sample=False, cache_implementation="static")[0, ids.shape[1]:]
+    assert model._quip_fast_decode.fast_steps > steps0
+    assert int((ref[:12] == want[:12]).sum()) >= 10, (ref, want)
+    disable_fast_decode(model)
+    assert model.forward.__self__ is model
