@@ -528,7 +528,22 @@ def hf_static_cache_extra(D, device, new_tokens=128, cache_len=2048):
             torch.cuda.synchronize()
             ts.append(new_tokens / (time.perf_counter() - t0))
         out["hf_generate_api_fast_decode_tokens_per_s"] = round(float(np.median(ts)), 2)
+        # ... and with generate()'s default DynamicCache (the wrapper decodes on its own static buffers and hands views back)
+        model.generate(ids, max_new_tokens=8, do_sample=False)
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            model.generate(ids, max_new_tokens=new_tokens, do_sample=False)
+            torch.cuda.synchronize()
+            ts.append(new_tokens / (time.perf_counter() - t0))
+        out["hf_generate_api_default_cache_fast_decode_tokens_per_s"] = round(float(np.median(ts)), 2)
         disable_fast_decode(model)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.generate(ids, max_new_tokens=new_tokens, do_sample=False)
+        torch.cuda.synchronize()
+        out["hf_generate_api_default_cache_stock_tokens_per_s"] = round(new_tokens / (time.perf_counter() - t0), 2)
     except Exception as e:
         out["hf_fast_decode_error"] = repr(e)[:300]
     fast = D.LlamaDecoder.from_hf(model, max_len=cache_len)

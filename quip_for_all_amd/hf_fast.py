@@ -9,6 +9,13 @@ asked for -- runs `LlamaDecoder.step()` on the SAME modules and on the cache obj
 the fused stage-wise step elsewhere.  Every other call (the prompt, batches, dynamic caches, `output_attentions`,
 `inputs_embeds`, training) goes to the original forward untouched, so the model stays a drop-in HF model.
 
+The default cache of `model.generate()` (`DynamicCache`: key / value tensors that grow by concatenation) is served too: the
+wrapper keeps ONE static buffer per layer (`max_position_embeddings` rows, at most QUIP_FAST_DECODE_MAX_LEN = 8192), copies
+the prompt's rows into it at the first decode step and from then on hands the cache object VIEWS of the buffer
+(`layer.keys = buffer[:, :, :n + 1]`), so the object keeps answering `get_seq_length()` and can go back to the stock
+forward at any time (which concatenates into fresh tensors; the next fast step imports them again).  A second cache
+object taking over the buffer first gets the previous owner's views cloned, so no two caches ever alias.
+
 Not checked (it would cost a device synchronisation per token): that `position_ids` equals the cache length and that
 `attention_mask` has no holes -- true for an unpadded single sequence, which is what batch 1 generation passes.
 Logits are those of `LlamaDecoder` (same arithmetic as the stage-wise ops, tests/test_gpu_hf_generate.py pins them against
@@ -21,21 +28,38 @@ class _FastDecode:
         self.model = model
         self.orig_forward = model.forward
         self.assume_llama_like = assume_llama_like
-        self.dec = None
-        self.bound = None            # the key / value data pointers the decoder currently uses
+        self.dec = None              # decoder on a StaticCache's tensors
+        self.bound = None            # the key / value data pointers that decoder currently uses
+        self.dyn = None              # decoder on this wrapper's own buffers (DynamicCache calls)
+        self.dyn_owner = None        # weakref of the cache object whose layers are views of the buffers
+        self.dyn_len = 0
         self.disabled = None         # the reason LlamaDecoder refused this model, once known
         self.fast_steps = 0
 
     # -- eligibility: shapes and types only, nothing that reads device memory
     def _static_layers(self, cache):
+        """("static" | "dynamic", layers) of a cache this wrapper serves, else None"""
         layers = getattr(cache, "layers", None)
         if not layers or len(layers) != self.model.config.num_hidden_layers:
             return None
+        kind = type(layers[0]).__name__
+        if kind not in ("StaticLayer", "DynamicLayer"):
+            return None
         for L in layers:
-            if (type(L).__name__ != "StaticLayer" or not getattr(L, "is_initialized", False) or L.keys.shape[0] != 1
+            if (type(L).__name__ != kind or not getattr(L, "is_initialized", False) or L.keys.dim() != 4 or L.keys.shape[0] != 1
                     or L.keys.dtype != torch.float16 or not L.keys.is_cuda):
                 return None
-        return layers
+        if kind == "DynamicLayer":
+            n = layers[0].keys.shape[-2]
+            if n < 1 or n + 1 > self._dyn_capacity() or any(L.keys.shape[-2] != n for L in layers):
+                return None
+            return "dynamic", layers
+        return "static", layers
+
+    def _dyn_capacity(self):
+        import os
+        cap = int(os.environ.get("QUIP_FAST_DECODE_MAX_LEN", "8192"))
+        return min(cap, int(getattr(self.model.config, "max_position_embeddings", cap) or cap))
 
     def _eligible(self, input_ids, past_key_values, inputs_embeds, labels, kw):
         if self.disabled is not None or input_ids is None or inputs_embeds is not None or labels is not None:
@@ -65,8 +89,48 @@ class _FastDecode:
             self.bound = sig
         return self.dec
 
+    def _dynamic_step(self, input_ids, cache, layers):
+        import weakref
+        from .decode import LlamaDecoder
+        n = layers[0].keys.shape[-2]
+        dev = layers[0].keys.device
+        if self.dyn is None or self.dyn.dev != dev:
+            try:
+                self.dyn = LlamaDecoder.from_hf(self.model, max_len=self._dyn_capacity(), assume_llama_like=self.assume_llama_like)
+            except (NotImplementedError, TypeError, ValueError) as e:
+                self.disabled = repr(e)
+                return None
+            self.dyn_owner = None
+        dec = self.dyn
+        owner = self.dyn_owner() if self.dyn_owner is not None else None
+        owned = (owner is cache and n <= self.dyn_len and layers[0].keys.data_ptr() == dec.kcache[0].data_ptr()
+                 and layers[-1].values.data_ptr() == dec.vcache[-1].data_ptr())
+        with torch.no_grad():
+            if not owned:
+                if owner is not None and owner is not cache:
+                    # the previous owner keeps its contents: its views of the buffers become tensors of its own
+                    for L in getattr(owner, "layers", []):
+                        if getattr(L, "is_initialized", False) and torch.is_tensor(L.keys):
+                            L.keys, L.values = L.keys.clone(), L.values.clone()
+                for i, L in enumerate(layers):
+                    dec.kcache[i][:, :n].copy_(L.keys[0])
+                    dec.vcache[i][:, :n].copy_(L.values[0])
+                self.dyn_owner = weakref.ref(cache)
+            dec.tok.copy_(input_ids.reshape(1))
+            dec.pos.fill_(n)
+            logits = dec.step()
+            for i, L in enumerate(layers):              # DynamicLayer.update()'s result: tensors one row longer
+                L.keys = dec.kcache[i][None, :, :n + 1]
+                L.values = dec.vcache[i][None, :, :n + 1]
+        self.dyn_len = n + 1
+        self.fast_steps += 1
+        return logits.reshape(1, 1, -1)
+
     @torch.compiler.disable      # (an opaque eager call inside a torch.compile'd generate loop: the decoder owns its launches)
-    def _fast_step(self, input_ids, layers):
+    def _fast_step(self, input_ids, cache, kind_layers):
+        kind, layers = kind_layers
+        if kind == "dynamic":
+            return self._dynamic_step(input_ids, cache, layers)
         dec = self._decoder(layers)
         if dec is None:
             return None
@@ -82,7 +146,7 @@ class _FastDecode:
     def __call__(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
                  labels=None, use_cache=None, logits_to_keep=0, **kw):
         layers = self._eligible(input_ids, past_key_values, inputs_embeds, labels, kw)
-        logits = self._fast_step(input_ids, layers) if layers is not None else None
+        logits = self._fast_step(input_ids, past_key_values, layers) if layers is not None else None
         if logits is None:
             return self.orig_forward(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,
                                      past_key_values=past_key_values, inputs_embeds=inputs_embeds, labels=labels,

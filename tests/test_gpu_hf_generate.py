@@ -329,3 +329,55 @@ def test_fast_decode_wrapper_routes_static_cache_steps_through_the_decoder():
     assert int((ref[:12] == want[:12]).sum()) >= 10, (ref, want)
     disable_fast_decode(model)
     assert model.forward.__self__ is model
+
+
+def test_fast_decode_wrapper_serves_the_default_dynamic_cache():
+    """model.generate() with its default DynamicCache: after the stock prompt pass the wrapper imports the rows into its own
+    static buffers, decodes on them and hands the cache object views one row longer per step; tokens as the stock loop's,
+    the cache object keeps answering get_seq_length(), can go back to the stock forward, and two cache objects never alias"""
+    from transformers import AutoModelForCausalLM, DynamicCache
+    from quip_for_all_amd.quantizer import QuipQuantizer
+    from quip_for_all_amd.hf_fast import enable_fast_decode, disable_fast_decode
+    torch.manual_seed(0)
+    model = AutoModelForCausalLM.from_config(_tiny_config(), dtype=torch.float16)
+    qz = QuipQuantizer(codebook="E8P12", inference=True, ft_epochs=0)
+    qz.convert_model(model)
+    _fill_random(model, seed=3)
+    model = model.to("cuda:0").eval()
+    model.generation_config.eos_token_id = None
+    model.generation_config.pad_token_id = 0
+    ids = torch.tensor([[1, 17, 42, 99, 7, 250]], device="cuda:0")
+    want = model.generate(ids, max_new_tokens=16, do_sample=False)[0, ids.shape[1]:]
+    enable_fast_decode(model)
+    fd = model._quip_fast_decode
+    got = model.generate(ids, max_new_tokens=16, do_sample=False)[0, ids.shape[1]:]
+    assert fd.disabled is None and fd.fast_steps == 15, (fd.disabled, fd.fast_steps)
+    assert int((got == want).sum()) >= 14, (got, want)
+
+    # by hand: two cache objects interleaved, one of them sent back to the stock forward in between
+    def prompt(cache, p):
+        with torch.no_grad():
+            return model(p, past_key_values=cache, use_cache=True).logits[:, -1].argmax(-1, keepdim=True)
+
+    def step(cache, tok):
+        with torch.no_grad():
+            return model(tok, past_key_values=cache, use_cache=True).logits[:, -1].argmax(-1, keepdim=True)
+    ids2 = torch.tensor([[3, 9, 200, 41]], device="cuda:0")
+    ca, cb = DynamicCache(config=model.config), DynamicCache(config=model.config)
+    ta, tb = prompt(ca, ids), prompt(cb, ids2)
+    seq_a, seq_b = [int(ta)], [int(tb)]
+    for i in range(6):
+        ta = step(ca, ta); seq_a.append(int(ta))          # noqa: E702
+        tb = step(cb, tb); seq_b.append(int(tb))          # noqa: E702
+        assert ca.get_seq_length() == ids.shape[1] + i + 1 and cb.get_seq_length() == ids2.shape[1] + i + 1
+    steps_before = fd.fast_steps
+    disable_fast_decode(model)
+    ta = step(ca, ta); seq_a.append(int(ta))              # noqa: E702  (stock forward on a cache whose layers were views)
+    enable_fast_decode(model)
+    fd = model._quip_fast_decode
+    ta = step(ca, ta); seq_a.append(int(ta))              # noqa: E702
+    assert fd.fast_steps == 1 and steps_before == 15 + 12
+    disable_fast_decode(model)
+    ra = model.generate(ids, max_new_tokens=9, do_sample=False)[0, ids.shape[1]:].tolist()
+    rb = model.generate(ids2, max_new_tokens=7, do_sample=False)[0, ids2.shape[1]:].tolist()
+    assert sum(x == y for x, y in zip(seq_a, ra)) >= 8 and sum(x == y for x, y in zip(seq_b, rb)) >= 6, (seq_a, ra, seq_b, rb)
