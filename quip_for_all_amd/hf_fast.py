@@ -89,6 +89,26 @@ class _FastDecode:
             self.bound = sig
         return self.dec
 
+    def _step_checked(self, dec, set_inputs):
+        """one decoder step; when the call is not being captured into a graph, the persistent launch's status word is read
+        back (one small synchronising copy per token -- HF's generate loop synchronises per token anyway) and a launch that
+        gave up on a hand-off (a shared device: NaN logits, decode.py) is answered by the same step on the stage-wise path"""
+        set_inputs()
+        logits = dec.step()
+        if (getattr(dec, "block_eng", False) or getattr(dec, "ffn_eng", False)) and not torch.cuda.is_current_stream_capturing():
+            st = dec.engine_status()
+            if st:
+                dec.engine_reset()
+                if st != 0xE000:        # (0xE000: the workspace's launch counter was about to wrap -- zeroed, same path again)
+                    import warnings
+                    warnings.warn("persistent decode launch gave up on a hand-off (code 0x%x): the device was shared with "
+                                  "other work; fast decode continues on the stage-wise step" % st)
+                    dec.block_eng = dec.ffn_eng = False
+                    dec.graph = None
+                set_inputs()
+                logits = dec.step()
+        return logits
+
     def _dynamic_step(self, input_ids, cache, layers):
         import weakref
         from .decode import LlamaDecoder
@@ -116,9 +136,10 @@ class _FastDecode:
                     dec.kcache[i][:, :n].copy_(L.keys[0])
                     dec.vcache[i][:, :n].copy_(L.values[0])
                 self.dyn_owner = weakref.ref(cache)
-            dec.tok.copy_(input_ids.reshape(1))
-            dec.pos.fill_(n)
-            logits = dec.step()
+            def set_inputs():
+                dec.tok.copy_(input_ids.reshape(1))
+                dec.pos.fill_(n)
+            logits = self._step_checked(dec, set_inputs)
             for i, L in enumerate(layers):              # DynamicLayer.update()'s result: tensors one row longer
                 L.keys = dec.kcache[i][None, :, :n + 1]
                 L.values = dec.vcache[i][None, :, :n + 1]
@@ -136,9 +157,11 @@ class _FastDecode:
             return None
         with torch.no_grad():
             lens = [L.cumulative_length for L in layers]
-            dec.tok.copy_(input_ids.reshape(1))
-            dec.pos.copy_(lens[0].reshape(1))
-            logits = dec.step()                          # (1, vocab) fp16; row pos of every layer's cache written
+
+            def set_inputs():
+                dec.tok.copy_(input_ids.reshape(1))
+                dec.pos.copy_(lens[0].reshape(1))
+            logits = self._step_checked(dec, set_inputs)   # (1, vocab) fp16; row pos of every layer's cache written
             torch._foreach_add_(lens, 1)                 # StaticLayer.update()'s bookkeeping
         self.fast_steps += 1
         return logits.reshape(1, 1, -1)

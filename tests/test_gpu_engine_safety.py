@@ -103,3 +103,48 @@ def test_launch_counter_wrap_asks_for_a_fresh_workspace_and_generation_continues
     assert dec.block_eng and dec.engine_status() == 0
     assert int(dec.eng_ws[:4].view(torch.int32).item()) < 64      # a fresh workspace
     np.testing.assert_array_equal(got, expected)
+
+
+def test_hf_fast_decode_wrapper_redoes_a_step_the_shared_device_spoiled():
+    """hf_fast (what load_quantized_model installs): a 7B-shaped HF model decoding on a StaticCache through the persistent
+    launch while another stream holds 32 CUs -- the step whose launch gave up is answered by the stage-wise step (a warning,
+    no NaN logits, no hang), the tokens are those of the unshared run, and the wrapper stays on the stage-wise step"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from transformers import AutoModelForCausalLM, LlamaConfig
+    from tests.test_quantizer_host import _fill_random
+    from quip_for_all_amd import capi
+    from quip_for_all_amd.quantizer import QuipQuantizer
+    from quip_for_all_amd.hf_static import HFStaticDecoder
+    from quip_for_all_amd.hf_fast import enable_fast_decode
+    cfg = LlamaConfig(hidden_size=4096, intermediate_size=11008, num_hidden_layers=2, num_attention_heads=32,
+                      num_key_value_heads=32, vocab_size=2048, max_position_embeddings=64, tie_word_embeddings=False)
+    torch.manual_seed(0)
+    model = AutoModelForCausalLM.from_config(cfg, dtype=torch.float16)
+    QuipQuantizer(codebook="E8P12", inference=True, ft_epochs=0).convert_model(model)
+    _fill_random(model, seed=5)
+    model = model.to(DEV).eval()
+    enable_fast_decode(model)
+    fd = model._quip_fast_decode
+    ids = torch.tensor([[1, 17, 42, 99, 7, 250]], device=DEV)
+    expected, _ = HFStaticDecoder(model, max_cache_len=64).generate(ids, 10, "eager")
+    assert fd.dec is not None and fd.dec.block_eng and fd.fast_steps == 9
+    sink = torch.zeros(4, dtype=torch.int32, device=DEV)
+    side = torch.cuda.Stream()
+    h = HFStaticDecoder(model, max_cache_len=64)
+    got = [int(h.prefill(ids))]                        # (the stock prompt pass allocates: it would wait for the other stream's kernel)
+    torch.cuda.synchronize()
+    capi.check(capi.lib().quip_debug_occupy(32, 100 * 1024, ctypes.c_int64(17_000_000_000), sink.data_ptr(), side.cuda_stream),
+               "quip_debug_occupy")
+    with warnings.catch_warnings(record=True) as wr:
+        warnings.simplefilter("always")
+        for _ in range(9):
+            nxt = h.decode_one_token(h.tok, h.pos)
+            h.tok.copy_(nxt)
+            h.pos += 1
+            got.append(int(nxt))
+    torch.cuda.synchronize()
+    assert any("gave up" in str(w.message) for w in wr), [str(w.message) for w in wr]
+    assert not fd.dec.block_eng and fd.dec.engine_status() == 0
+    got = torch.tensor(got, device=DEV)
+    assert int((got == expected).sum()) >= 9, (got, expected)      # (stage-wise vs launch: a near tie may flip one)
