@@ -381,3 +381,66 @@ def test_fast_decode_wrapper_serves_the_default_dynamic_cache():
     ra = model.generate(ids, max_new_tokens=9, do_sample=False)[0, ids.shape[1]:].tolist()
     rb = model.generate(ids2, max_new_tokens=7, do_sample=False)[0, ids2.shape[1]:].tolist()
     assert sum(x == y for x, y in zip(seq_a, ra)) >= 8 and sum(x == y for x, y in zip(seq_b, rb)) >= 6, (seq_a, ra, seq_b, rb)
+
+
+def _random_quantized_hf_llama(cfg, device="cuda:0", seed=0):
+    """an HF Llama of any size without its dense weights ever existing: parameters on the meta device -> convert_model ->
+    to_empty on the GPU -> random codes / signs / scales / norms, rotary buffers rebuilt (what bench.py does for the 7B shape)"""
+    from transformers import AutoModelForCausalLM
+    from quip_for_all_amd.quantizer import QuipQuantizer
+    from quip_for_all_amd.qlinear import QuantLinear
+    with torch.device("meta"):
+        model = AutoModelForCausalLM.from_config(cfg, dtype=torch.float16)
+    QuipQuantizer(codebook="E8P12", inference=True, ft_epochs=0).convert_model(model)
+    model.to_empty(device=device)
+    g = torch.Generator(device=device).manual_seed(seed)
+    with torch.no_grad():
+        for name, prm in list(model.named_parameters()) + list(model.named_buffers()):
+            if prm.is_floating_point() and "inv_freq" not in name:
+                prm.copy_((torch.randn(prm.shape, generator=g, device=device, dtype=torch.float32) * 0.02).to(prm.dtype))
+        for m in model.modules():
+            if isinstance(m, QuantLinear):
+                m.Qidxs.copy_(torch.randint(-32768, 32768, m.Qidxs.shape, generator=g, device=device, dtype=torch.int32).to(m.Qidxs.dtype))
+                m.SU.copy_((torch.randint(0, 2, m.SU.shape, generator=g, device=device) * 2 - 1).half())
+                m.SV.copy_((torch.randint(0, 2, m.SV.shape, generator=g, device=device) * 2 - 1).half())
+                m.Wscale.fill_(1.0 / 64.0)
+                for nm in ("had_left", "had_right"):
+                    h = getattr(m, nm)
+                    if h is not None:
+                        h.copy_(torch.linalg.qr(torch.randn(h.shape, generator=g, device=device))[0].half())
+            if m.__class__.__name__.endswith("RMSNorm"):
+                m.weight.fill_(1.0)
+        rot = model.model.rotary_emb
+        model.model.rotary_emb = type(rot)(config=cfg, device=device)
+        for m in model.modules():
+            if isinstance(m, QuantLinear):
+                m.wscale_float = float(m.Wscale.mean().item())
+    return model.eval()
+
+
+def test_fast_decode_wrapper_on_a_70b_shaped_hf_model_runs_the_grouped_query_launch():
+    """two blocks of the Llama-2-70B shape (hidden 8192, 64 heads on 8 KV heads, n_ffn 28672) as an HF model: the wrapper's
+    decoder takes the grouped-query persistent launch (shape 1) on the StaticCache's (1, 8, len, 128) tensors; logits of a
+    step within 2^-6 of the stock forward's maximum, greedy tokens equal up to a near tie"""
+    from transformers import LlamaConfig
+    from quip_for_all_amd.hf_static import HFStaticDecoder
+    from quip_for_all_amd.hf_fast import enable_fast_decode, disable_fast_decode
+    cfg = LlamaConfig(hidden_size=8192, intermediate_size=28672, num_hidden_layers=2, num_attention_heads=64,
+                      num_key_value_heads=8, vocab_size=2048, max_position_embeddings=64, rms_norm_eps=1e-5,
+                      tie_word_embeddings=False)
+    model = _random_quantized_hf_llama(cfg)
+    ids = torch.tensor([[1, 17, 42, 99, 7, 250]], device="cuda:0")
+    want, _ = HFStaticDecoder(model, max_cache_len=64).generate(ids, 12, "eager")
+    b = HFStaticDecoder(model, max_cache_len=64)
+    b.prefill(ids)
+    lb = b._forward(b.tok, b.pos).float()
+    enable_fast_decode(model)
+    fd = model._quip_fast_decode
+    got, _ = HFStaticDecoder(model, max_cache_len=64).generate(ids, 12, "eager")
+    assert fd.disabled is None and fd.dec.block_eng and fd.dec.eng_shape == 1 and fd.dec.engine_status() == 0
+    assert int((got == want).sum()) >= 10, (got, want)
+    a = HFStaticDecoder(model, max_cache_len=64)
+    a.prefill(ids)
+    la = a._forward(a.tok, a.pos).float()
+    assert (la - lb).abs().max().item() <= 2.0 ** -6 * lb.abs().max().item(), (la - lb).abs().max().item()
+    disable_fast_decode(model)
