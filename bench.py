@@ -456,7 +456,13 @@ def hf_static_cache_extra(D, device, new_tokens=128, cache_len=2048):
         model = AutoModelForCausalLM.from_config(cfg, dtype=torch.float16)
     qz = QuipQuantizer(codebook="E8P12", inference=True, ft_epochs=0)
     qz.convert_model(model)
+    # (to_empty replaces EVERY tensor by uninitialised memory, also the real ones convert_model made -- the codebooks' tables)
+    real = {n: t.detach().clone() for n, t in list(model.named_parameters()) + list(model.named_buffers()) if not t.is_meta}
     model.to_empty(device=device)
+    with torch.no_grad():
+        live = dict(list(model.named_parameters()) + list(model.named_buffers()))
+        for n, t in real.items():
+            live[n].copy_(t)
     g = torch.Generator(device=device).manual_seed(0)
     with torch.no_grad():
         for name, prm in list(model.named_parameters()) + list(model.named_buffers()):

@@ -740,20 +740,22 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
       float m = -INFINITY, lsum = 0.f, acc8[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) { acc8[i] = 0.f; kn[i] = 0.f; vn[i] = 0.f; }
-      auto one_key = [&](const float (&k8)[8], const float (&v8)[8], bool live) {
+      // one key: score against q (16 lanes: the group's sum on DPP moves, had::sum16_xor), online-softmax update of this
+      // group's state.  A round scores all of its keys first (independent chains), then updates the state in key order:
+      // the same operations on the same operands as key after key.
+      auto score = [&](const float (&k8)[8]) -> float {
         float sc = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) sc = __builtin_fmaf(q8[i], k8[i], sc);
+        return had::sum16_xor(sc);
+      };
+      auto update = [&](float sc, const float (&v8)[8]) {
+        const float mn = fmaxf(m, sc);
+        const float cc = __expf(m - mn), pp = __expf(sc - mn);
+        lsum = __builtin_fmaf(lsum, cc, pp);
 #pragma unroll
-        for (int o = 1; o < LPK; o <<= 1) sc += __shfl_xor(sc, o, 64);
-        if (live) {
-          const float mn = fmaxf(m, sc);
-          const float cc = __expf(m - mn), pp = __expf(sc - mn);
-          lsum = __builtin_fmaf(lsum, cc, pp);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) acc8[i] = __builtin_fmaf(acc8[i], cc, had::fmul(pp, v8[i]));
-          m = mn;
-        }
+        for (int i = 0; i < 8; ++i) acc8[i] = __builtin_fmaf(acc8[i], cc, had::fmul(pp, v8[i]));
+        m = mn;
       };
       if (tid < 256) {
         rope8(s_qkv, q8);
@@ -772,18 +774,21 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
         }
         const int t_hi = pos + 1;
         auto round = [&](const uint4 (&kr)[U], const uint4 (&vr)[U], int i0) {
+          float k8[U][8], v8[U][8], sc[U];
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             const int t = part + nparts * (i0 + u * NG);
-            float k8[8], v8[8];
-            unpack8h(kr[u], k8);
-            unpack8h(vr[u], v8);
+            unpack8h(kr[u], k8[u]);
+            unpack8h(vr[u], v8[u]);
             if (t == pos) {
 #pragma unroll
-              for (int i = 0; i < 8; ++i) { k8[i] = kn[i]; v8[i] = vn[i]; }
+              for (int i = 0; i < 8; ++i) { k8[u][i] = kn[i]; v8[u][i] = vn[i]; }
             }
-            one_key(k8, v8, t < t_hi);
+            sc[u] = score(k8[u]);
           }
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (part + nparts * (i0 + u * NG) < t_hi) update(sc[u], v8[u]);
         };
         const int n_loc = t_hi > part ? (t_hi - part + nparts - 1) / nparts : 0;
         for (int ib = 0; ib < n_loc; ib += 2 * NG * U) {

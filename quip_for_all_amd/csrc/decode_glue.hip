@@ -209,21 +209,28 @@ void rope_attn_decode_kernel(AttnArgs a, AttnZ zz) {
       kr[u] = *reinterpret_cast<const uint4*>(kc + (size_t)tc * HD + d0);
       vr[u] = *reinterpret_cast<const uint4*>(vc + (size_t)tc * HD + d0);
     }
+    // the round's scores first (independent chains; the 16-lane sums on DPP moves, had::sum16_xor: the additions of
+    // `s += __shfl_xor(s, o)`, o = 1, 2, 4, 8), then the online-softmax updates in key order
+    float k8a[U][8], v8a[U][8], sa[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int t = t0 + u * NG;
-      float k8[8], v8[8];
-      unpack8h(kr[u], k8);
-      unpack8h(vr[u], v8);
+      unpack8h(kr[u], k8a[u]);
+      unpack8h(vr[u], v8a[u]);
       if (t == pos) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { k8[i] = kn[i]; v8[i] = vn[i]; }
+        for (int i = 0; i < 8; ++i) { k8a[u][i] = kn[i]; v8a[u][i] = vn[i]; }
       }
       float s = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) s = __builtin_fmaf(q8[i], k8[i], s);
+      for (int i = 0; i < 8; ++i) s = __builtin_fmaf(q8[i], k8a[u][i], s);
+      sa[u] = had::sum16_xor<LPK>(s);
+    }
 #pragma unroll
-      for (int o = 1; o < LPK; o <<= 1) s += __shfl_xor(s, o, 64);
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 + u * NG;
+      const float s = sa[u];
+      const float (&v8)[8] = v8a[u];
       if (t < t_hi) {
         const float mn = fmaxf(m, s);
         const float c = __expf(m - mn), p = __expf(s - mn);

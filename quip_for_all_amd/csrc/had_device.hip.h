@@ -266,6 +266,24 @@ __device__ __forceinline__ float lane_xor(float v) {
   else if constexpr (S == 2) return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(i, 0x101F));              // bit mode: xor 4
   else return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(i, 0x128, 0xf, 0xf, true));                        // row_ror:8
 }
+// xor 4 without the LDS crossbar: row_half_mirror (lane ^ 7 within 8) then quad_perm [3, 2, 1, 0] (lane ^ 3)
+__device__ __forceinline__ float lane_xor4_dpp(float v) {
+  const int a = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true);
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(a, 0x1B, 0xf, 0xf, true));
+}
+// s + s(lane ^ 1), then ^ 2, ^ 4, ^ 8: the sum over an aligned group of 16 lanes in every lane of the group -- the additions
+// of `for (o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o)`, operand for operand, on DPP moves instead of four dependent
+// ds_bpermute round trips (the attention loops' critical path: ~100 clocks each)
+template <int N = 16>
+__device__ __forceinline__ float sum16_xor(float s) {      // N = 16 or 8 lanes per group
+#pragma clang fp contract(off)
+  static_assert(N == 16 || N == 8, "groups of 8 or 16 lanes");
+  s = s + lane_xor<0>(s);
+  s = s + lane_xor<1>(s);
+  s = s + lane_xor4_dpp(s);
+  if constexpr (N == 16) s = s + lane_xor<3>(s);
+  return s;
+}
 template <int S>
 __device__ __forceinline__ void lane_stage(float v[16], int t) {
 #pragma clang fp contract(off)
