@@ -585,7 +585,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     // short contexts: the head's first workgroup transforms q only and starts on the cached rows; its second / third one
     // transform k / v, write the new cache row and hand the head's 128 values over (one 4096-point transform each instead
     // of three in a row on the critical path; the new position is the last one of its key group either way)
-    constexpr bool kOffload = !RVQ || HI;              // (E8P12RVQ4B: the extra addresses do not fit its registers)
+    constexpr bool kOffload = !RVQ || HI || R3;        // (E8P12RVQ4B: the extra addresses do not fit its registers; RVQ3B's 12-byte slots leave room)
     const bool kv_wg = kOffload && !split && (part == 1 || part == 2);
     const bool all3 = split || !kOffload;              // this workgroup transforms q, k and v itself
     if (head_wg || split || kv_wg) {
