@@ -491,9 +491,15 @@ def hf_static_cache_extra(D, device, new_tokens=128, cache_len=2048):
     out = {"model": "random-init Llama-2-7B shape, E8P12, HF LlamaForCausalLM + StaticCache(%d)" % cache_len,
            "prompt_tokens": 16, "new_tokens": new_tokens, "timing": "decode loop of new_tokens - 1 single-token steps, synchronised at both ends"}
     toks = {}
-    for mode in ("eager", "graph"):
+    for mode in ("eager", "graph", "compile"):           # compile: the reference's torch.compile(mode="reduce-overhead", fullgraph=True)
         dec = HFStaticDecoder(model, max_cache_len=cache_len)
-        dec.generate(ids, 8, mode)                      # warm-up (and capture)
+        try:
+            dec.generate(ids, 8, mode)                  # warm-up (and capture / compilation)
+            if mode == "compile":
+                dec.generate(ids, 8, mode)
+        except Exception as e:
+            out["hf_%s_error" % mode] = repr(e)[:300]
+            continue
         ts = []
         for _ in range(3):
             t, dt = dec.generate(ids, new_tokens, mode)
@@ -503,6 +509,8 @@ def hf_static_cache_extra(D, device, new_tokens=128, cache_len=2048):
         out["hf_%s_runs" % mode] = [round(x, 2) for x in ts]
         del dec
     out["hf_graph_equals_eager"] = bool(torch.equal(toks["eager"], toks["graph"]))
+    if "compile" in toks:
+        out["hf_compile_equals_eager"] = bool(torch.equal(toks["eager"], toks["compile"]))
     # the SAME harness on the SAME model object with hf_fast.enable_fast_decode (what load_quantized_model switches on):
     # single-token calls on the StaticCache run LlamaDecoder.step() on the cache's own tensors
     try:

@@ -16,8 +16,9 @@ the prompt's rows into it at the first decode step and from then on hands the ca
 forward at any time (which concatenates into fresh tensors; the next fast step imports them again).  A second cache
 object taking over the buffer first gets the previous owner's views cloned, so no two caches ever alias.
 
-Not checked (it would cost a device synchronisation per token): that `position_ids` equals the cache length and that
-`attention_mask` has no holes -- true for an unpadded single sequence, which is what batch 1 generation passes.
+That `position_ids` equals the cache length and that `attention_mask` has no holes (an unpadded single sequence: what
+batch 1 generation passes) is checked when the wrapper takes a cache object over -- one device synchronisation per
+generation, not per token; a padded sequence stays on the stock forward.
 Logits are those of `LlamaDecoder` (same arithmetic as the stage-wise ops, tests/test_gpu_hf_generate.py pins them against
 the stock forward); the cache rows are bit-compatible (rotated keys, fp16), so fast and stock steps may be mixed freely."""
 import torch
@@ -89,6 +90,18 @@ class _FastDecode:
             self.bound = sig
         return self.dec
 
+    @staticmethod
+    def _unpadded(attention_mask, position_ids, n):
+        """one token at cache length n of a single sequence without padding?  (reads device memory: called once per cache take-over)"""
+        if torch.cuda.is_current_stream_capturing():
+            return True
+        n = int(n)
+        if attention_mask is not None and attention_mask.dim() == 2 and not bool((attention_mask[:, :n + 1] != 0).all()):
+            return False
+        if position_ids is not None and position_ids.numel() >= 1 and int(position_ids.reshape(-1)[-1]) != int(n):
+            return False
+        return True
+
     def _step_checked(self, dec, set_inputs):
         """one decoder step; when the call is not being captured into a graph, the persistent launch's status word is read
         back (one small synchronising copy per token -- HF's generate loop synchronises per token anyway) and a launch that
@@ -109,7 +122,7 @@ class _FastDecode:
                 logits = dec.step()
         return logits
 
-    def _dynamic_step(self, input_ids, cache, layers):
+    def _dynamic_step(self, input_ids, cache, layers, attention_mask=None, position_ids=None):
         import weakref
         from .decode import LlamaDecoder
         n = layers[0].keys.shape[-2]
@@ -125,6 +138,8 @@ class _FastDecode:
         owner = self.dyn_owner() if self.dyn_owner is not None else None
         owned = (owner is cache and n <= self.dyn_len and layers[0].keys.data_ptr() == dec.kcache[0].data_ptr()
                  and layers[-1].values.data_ptr() == dec.vcache[-1].data_ptr())
+        if not owned and not self._unpadded(attention_mask, position_ids, n):
+            return None
         with torch.no_grad():
             if not owned:
                 if owner is not None and owner is not cache:
@@ -148,10 +163,16 @@ class _FastDecode:
         return logits.reshape(1, 1, -1)
 
     @torch.compiler.disable      # (an opaque eager call inside a torch.compile'd generate loop: the decoder owns its launches)
-    def _fast_step(self, input_ids, cache, kind_layers):
+    def _fast_step(self, input_ids, cache, kind_layers, attention_mask=None, position_ids=None):
         kind, layers = kind_layers
         if kind == "dynamic":
-            return self._dynamic_step(input_ids, cache, layers)
+            return self._dynamic_step(input_ids, cache, layers, attention_mask, position_ids)
+        seen = getattr(self, "_static_checked", None)
+        if seen is None or seen() is not cache:                      # a cache object seen for the first time
+            import weakref
+            if not self._unpadded(attention_mask, position_ids, layers[0].cumulative_length):
+                return None
+            self._static_checked = weakref.ref(cache)
         dec = self._decoder(layers)
         if dec is None:
             return None
@@ -169,7 +190,7 @@ class _FastDecode:
     def __call__(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
                  labels=None, use_cache=None, logits_to_keep=0, **kw):
         layers = self._eligible(input_ids, past_key_values, inputs_embeds, labels, kw)
-        logits = self._fast_step(input_ids, past_key_values, layers) if layers is not None else None
+        logits = self._fast_step(input_ids, past_key_values, layers, attention_mask, position_ids) if layers is not None else None
         if logits is None:
             return self.orig_forward(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,
                                      past_key_values=past_key_values, inputs_embeds=inputs_embeds, labels=labels,

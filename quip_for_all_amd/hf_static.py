@@ -2,9 +2,9 @@
 Llama forward on a `StaticCache`, one token per call, greedy -- eager, or with the single-token step captured in a hipGraph
 (what the reference gets from `torch.compile(decode_one_tokens, mode="reduce-overhead", fullgraph=True)` on top of
 `model._setup_cache(StaticCache, 1, max_cache_len=2048)`, example_generate.py:28-33, 62-70; `_setup_cache` is a
-transformers-4.38 API, the cache object is passed explicitly here).  (torch.compile's cudagraph trees refuse the step as it
-stands: the ops' per-stream K-split workspace is allocated on first use, inside the trees' memory pool, and outlives the
-recorded function; capturing the step by hand has no such bookkeeping.)
+transformers-4.38 API, the cache object is passed explicitly here), or compiled exactly like that (mode "compile": the ops
+carry fake implementations, and their process-lifetime K-split workspace is raw device memory so that the cudagraph
+trees' pool never sees it).
 
 This is the drop-in path a user of the reference lands on first: every projection is a `QuantLinear.forward` (bs = 1: one
 transform launch, one GEMV launch, one transform launch), everything else is the framework's.  `LlamaDecoder`
@@ -57,15 +57,22 @@ class HFStaticDecoder:
             self._next = self.decode_one_token(self.tok, self.pos)
         torch.cuda.synchronize()
 
+    def compile(self, fullgraph=True):
+        """the reference's own call: torch.compile(decode_one_tokens, mode="reduce-overhead", fullgraph=True)
+        (example_generate.py:69-70)"""
+        self._compiled = torch.compile(self.decode_one_token, mode="reduce-overhead", fullgraph=fullgraph)
+
     @torch.no_grad()
     def generate(self, prompt_ids, max_new_tokens, mode="eager"):
-        """greedy; mode: "eager" | "graph" (captured step).
+        """greedy; mode: "eager" | "graph" (captured step) | "compile" (torch.compile, mode="reduce-overhead").
         Returns (tokens (max_new_tokens,), seconds spent in the decode loop, synchronised at both ends)"""
         prompt_ids = torch.as_tensor(prompt_ids, dtype=torch.long, device=self.dev).reshape(1, -1)
         assert prompt_ids.shape[1] + max_new_tokens <= self.max_cache_len
         if mode == "graph" and self.graph is None:
             self.prefill(prompt_ids)                   # (the warm-up steps need an initialised cache)
             self.capture()
+        if mode == "compile" and getattr(self, "_compiled", None) is None:
+            self.compile()
         out = torch.empty(max_new_tokens, dtype=torch.long, device=self.dev)
         out[0] = self.prefill(prompt_ids).reshape(-1)[0]
         torch.cuda.synchronize()
@@ -74,6 +81,9 @@ class HFStaticDecoder:
             if mode == "graph":
                 self.graph.replay()
                 nxt = self._next
+            elif mode == "compile":
+                torch.compiler.cudagraph_mark_step_begin()
+                nxt = self._compiled(self.tok.clone(), self.pos.clone()).clone()
             else:
                 nxt = self.decode_one_token(self.tok, self.pos)
             self.tok.copy_(nxt)

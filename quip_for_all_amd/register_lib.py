@@ -547,19 +547,53 @@ _GEMV_WS = {}        # (device type, index, stream handle) -> zeroed int32 works
 _GEMV_WS_RETIRED = []   # superseded workspaces: captured hipGraphs may still hold their pointers, so they are never freed
 
 
+class _RawWorkspace:
+    """device memory from hipMalloc itself, not from torch's caching allocator: a buffer that is created on first use and lives
+    for the whole process must not come out of whatever memory pool is current at that moment -- inside
+    torch.compile(mode="reduce-overhead") (HF's generate with a static cache compiles the forward that way) that is the
+    cudagraph trees' private pool, which refuses live allocations it did not hand out as outputs"""
+    _hip = None
+
+    def __init__(self, nbytes, dev):
+        import ctypes
+        if _RawWorkspace._hip is None:
+            _RawWorkspace._hip = ctypes.CDLL("libamdhip64.so")
+        hip = _RawWorkspace._hip
+        p = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            rc = hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(nbytes))
+            if rc != 0 or not p.value:
+                raise RuntimeError(f"hipMalloc({nbytes}) failed: {rc}")
+            rc = hip.hipMemset(p, 0, ctypes.c_size_t(nbytes))
+            if rc != 0:
+                raise RuntimeError(f"hipMemset failed: {rc}")
+        self.ptr, self.nbytes = int(p.value), int(nbytes)
+
+    def data_ptr(self):
+        return self.ptr
+
+    def numel(self):                 # int32 words, like the tensor this replaces
+        return self.nbytes // 4
+
+
 def _gemv_workspace(dev, n_total):
     """zeroed int32 scratch for K-split GEMV launches: ONE PER (device, stream) -- two streams running such launches at
     the same time must not add into the same accumulators and arrival counters -- kept for the life of the process
     (captured hipGraphs hold its pointer); every launch leaves it zeroed.  A workspace that has to grow is replaced,
-    never freed: the old one stays alive for the graphs that captured it."""
+    never freed: the old one stays alive for the graphs that captured it.  Raw device memory (_RawWorkspace) unless a stream
+    capture is under way (hipMalloc is not allowed there: torch's allocator, which knows the capture's pool, serves it)."""
     need = capi.lib().quip_e8p_gemv_workspace_bytes(int(n_total))
     key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)
     ws = _GEMV_WS.get(key)
     if ws is None or ws.numel() * 4 < need:
         if ws is not None:
             _GEMV_WS_RETIRED.append(ws)
-        with torch.cuda.stream(torch.cuda.current_stream(dev)):
-            ws = torch.zeros(max(need // 4, 1 << 20), dtype=torch.int32, device=dev)
+        nbytes = max(need, 4 << 20)
+        if torch.cuda.is_current_stream_capturing():
+            with torch.cuda.stream(torch.cuda.current_stream(dev)):
+                ws = torch.zeros(nbytes // 4, dtype=torch.int32, device=dev)
+        else:
+            ws = _RawWorkspace(nbytes, dev)
         _GEMV_WS[key] = ws
     return ws
 

@@ -273,6 +273,15 @@ def test_hf_static_cache_step_captured_in_a_graph_equals_eager():
     ref = model.generate(ids, max_new_tokens=16, do_sample=False)[0, ids.shape[1]:]
     n = min(len(ref), 16)
     assert n >= 8 and torch.equal(ref[:n], graph[:n]), (ref, graph)
+    # the reference's own call on the step: torch.compile(mode="reduce-overhead", fullgraph=True) (example_generate.py:69-70)
+    comp = HFStaticDecoder(model, max_cache_len=64)
+    comp.compile(fullgraph=True)
+    ct, _ = comp.generate(ids, 16, "compile")
+    ct, _ = comp.generate(ids, 16, "compile")
+    assert torch.equal(ct, eager), (ct, eager)
+    # ... and HF's generate with a static cache, which compiles the forward the same way, on the stock modules
+    st = model.generate(ids, max_new_tokens=16, do_sample=False, cache_implementation="static")[0, ids.shape[1]:]
+    assert torch.equal(st[:n], ref[:n]), (st, ref)
 
 
 def test_fast_decode_wrapper_routes_static_cache_steps_through_the_decoder():
@@ -460,4 +469,32 @@ def test_fast_decode_wrapper_on_a_70b_shaped_hf_model_runs_the_grouped_query_lau
         assert int(La.cumulative_length) == n == int(Lb.cumulative_length)
         dk = (La.keys[:, :, :n].float() - Lb.keys[:, :, :n].float()).abs().max().item()
         assert dk <= 2.0 ** -5 * Lb.keys.float().abs().max().item(), dk
+    disable_fast_decode(model)
+
+
+def test_fast_decode_wrapper_leaves_a_padded_sequence_to_the_stock_forward():
+    """a left-padded single sequence (attention_mask with a hole, position_ids behind the cache length): the wrapper checks
+    once when it takes a cache object over and stays out; the tokens are the stock forward's"""
+    from transformers import AutoModelForCausalLM
+    from quip_for_all_amd.quantizer import QuipQuantizer
+    from quip_for_all_amd.hf_fast import enable_fast_decode, disable_fast_decode
+    torch.manual_seed(0)
+    model = AutoModelForCausalLM.from_config(_tiny_config(), dtype=torch.float16)
+    QuipQuantizer(codebook="E8P12", inference=True, ft_epochs=0).convert_model(model)
+    _fill_random(model, seed=3)
+    model = model.to("cuda:0").eval()
+    model.generation_config.eos_token_id = None
+    model.generation_config.pad_token_id = 0
+    ids = torch.tensor([[0, 0, 17, 42, 99, 7]], device="cuda:0")
+    mask = torch.tensor([[0, 0, 1, 1, 1, 1]], device="cuda:0")
+    want = model.generate(ids, attention_mask=mask, max_new_tokens=8, do_sample=False)[0, ids.shape[1]:]
+    enable_fast_decode(model)
+    fd = model._quip_fast_decode
+    got = model.generate(ids, attention_mask=mask, max_new_tokens=8, do_sample=False)[0, ids.shape[1]:]
+    assert fd.fast_steps == 0 and torch.equal(got, want), (fd.fast_steps, got, want)
+    got2 = model.generate(ids, attention_mask=mask, max_new_tokens=8, do_sample=False, cache_implementation="static")[0, ids.shape[1]:]
+    assert fd.fast_steps == 0 and int((got2 == want).sum()) >= 7, (fd.fast_steps, got2, want)
+    # ... and an unpadded one still goes through
+    model.generate(ids[:, 2:], max_new_tokens=4, do_sample=False)
+    assert fd.fast_steps == 3
     disable_fast_decode(model)
