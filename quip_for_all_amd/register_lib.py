@@ -575,6 +575,19 @@ class _RawWorkspace:
     def numel(self):                 # int32 words, like the tensor this replaces
         return self.nbytes // 4
 
+    def read(self):
+        """the contents as an int32 CPU tensor (tests: a launch leaves its workspace zeroed); synchronises the device"""
+        import ctypes
+        out = torch.empty(self.nbytes // 4, dtype=torch.int32)
+        torch.cuda.synchronize()
+        rc = _RawWorkspace._hip.hipMemcpy(ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(self.ptr), ctypes.c_size_t(self.nbytes), 2)
+        if rc != 0:
+            raise RuntimeError(f"hipMemcpy failed: {rc}")
+        return out
+
+    def abs(self):                   # (the tensor methods the tests use on a workspace)
+        return self.read().abs()
+
 
 def _gemv_workspace(dev, n_total):
     """zeroed int32 scratch for K-split GEMV launches: ONE PER (device, stream) -- two streams running such launches at
