@@ -516,9 +516,11 @@ def hf_static_cache_extra(D, device, new_tokens=128, cache_len=2048):
     try:
         from quip_for_all_amd.hf_fast import enable_fast_decode, disable_fast_decode
         enable_fast_decode(model)
-        for mode in ("eager", "graph"):
+        for mode in ("eager", "graph", "compile"):
             dec = HFStaticDecoder(model, max_cache_len=cache_len)
             dec.generate(ids, 8, mode)
+            if mode == "compile":                      # (the step through quip_lib::hf_decode_step: fullgraph=True holds)
+                dec.generate(ids, 8, mode)
             ts = []
             for _ in range(3):
                 t, dt = dec.generate(ids, new_tokens, mode)
@@ -541,7 +543,8 @@ def hf_static_cache_extra(D, device, new_tokens=128, cache_len=2048):
             model.generate(ids, max_new_tokens=new_tokens, do_sample=False, cache_implementation="static")
             torch.cuda.synchronize()
             ts.append(new_tokens / (time.perf_counter() - t0))
-        out["hf_generate_api_fast_decode_tokens_per_s"] = round(float(np.median(ts)), 2)
+        # (HF compiles the forward there and passes an attention mask: the wrapper leaves such traced calls to the stock forward)
+        out["hf_generate_api_static_cache_tokens_per_s"] = round(float(np.median(ts)), 2)
         # ... and with generate()'s default DynamicCache (the wrapper decodes on its own static buffers and hands views back)
         model.generate(ids, max_new_tokens=8, do_sample=False)
         ts = []

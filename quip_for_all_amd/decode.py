@@ -354,6 +354,7 @@ class LlamaDecoder:
                                 if cbid in ("E8P12RVQ4B", "E8P12RVQ3B") else 0.0)
         self.eng_grid2 = cb0._e81b_i8(self.dev) if cbid == "E8P12RVQ3B" else None      # int8 (256, 8): 4 x the E81B entries
         self._eng_sig = self._engine_signature()
+        self._kv_ptr_host = torch.empty(len(self.layers), 2, dtype=torch.int64).pin_memory()      # (bind_kv's staging buffer)
         self.block_eng = True
 
     def engine_status(self):
@@ -389,10 +390,15 @@ class LlamaDecoder:
         a captured step is dropped (its launches hold the old pointers)"""
         self.kcache, self.vcache = self._check_kv(keys, values)
         if getattr(self, "block_eng", False):
-            import numpy as np
-            ptr = np.array([[k.data_ptr(), v.data_ptr()] for k, v in zip(self.kcache, self.vcache)], dtype=np.uint64)
+            # through a pinned staging buffer that lives as long as the decoder: the copy is legal inside a stream capture
+            # (a re-recording torch.compile graph meets a new cache object there) and replays read the same host memory
+            host = getattr(self, "_kv_ptr_host", None)
+            if host is None:
+                host = self._kv_ptr_host = torch.empty(len(self.layers), 2, dtype=torch.int64).pin_memory()
+            for i, (k, v) in enumerate(zip(self.kcache, self.vcache)):
+                host[i, 0], host[i, 1] = k.data_ptr(), v.data_ptr()
             rec = self.eng_layers.view(torch.int64).view(len(self.layers), 32)
-            rec[:, 24:26] = torch.from_numpy(ptr.view(np.int64)).to(self.dev)
+            rec[:, 24:26].copy_(host, non_blocking=True)
         self.graph = None
 
     def engine_reset(self):

@@ -23,6 +23,60 @@ Logits are those of `LlamaDecoder` (same arithmetic as the stage-wise ops, tests
 the stock forward); the cache rows are bit-compatible (rotated keys, fp16), so fast and stock steps may be mixed freely."""
 import torch
 
+from . import register_lib as _R
+
+# The static-cache step as ONE operator, so that a caller's torch.compile(..., fullgraph=True) -- the reference's own decode
+# loop compiles its step that way (example_generate.py:69-70), HF's static-cache generate compiles the forward -- traces
+# through the wrapper instead of meeting a function it may not inline: input token, the cache object's key / value tensors
+# and lengths (mutated in place, declared so), an integer handle naming the wrapper; the logits (1, 1, vocab) come back.
+_HANDLES = {}
+import os as _os
+_ASSUME_UNPADDED = _os.environ.get("QUIP_FAST_DECODE_ASSUME_UNPADDED", "0") != "0"
+try:
+    _R._lib.define("hf_decode_step(Tensor input_ids, Tensor(a!)[] keys, Tensor(b!)[] values, Tensor(c!)[] lens, int handle) -> Tensor")
+except RuntimeError:
+    pass
+
+
+def _hf_decode_step_cuda(input_ids, keys, values, lens, handle):
+    return _HANDLES[handle]._static_step(input_ids, keys, values, lens)
+
+
+def _hf_decode_step_fake(input_ids, keys, values, lens, handle):
+    return input_ids.new_empty((1, 1, int(_HANDLES[handle].model.config.vocab_size)), dtype=torch.float16)
+
+
+try:
+    _R._lib.impl("hf_decode_step", _hf_decode_step_cuda, "CUDA")
+    _R._reg_fake("hf_decode_step", _hf_decode_step_fake)
+except RuntimeError:
+    pass
+
+
+def _off_thread(fn):
+    """run fn() on a helper thread and hand back its result.  A decoder lives as long as the wrapper; when its first use falls
+    into the warm-up run of torch.compile(mode="reduce-overhead"), the calling thread's allocations are being routed into the
+    cudagraph trees' private pool, which then refuses to record because of live allocations it did not hand out.  That routing
+    is per thread: what another thread allocates comes from the ordinary pool."""
+    import threading
+    box = {}
+    dev = torch.cuda.current_device()
+
+    def run():
+        try:
+            torch.cuda.set_device(dev)
+            with torch.no_grad():
+                box["v"] = fn()
+            torch.cuda.synchronize(dev)
+        except BaseException as e:      # noqa: BLE001 (re-raised on the caller's thread)
+            box["e"] = e
+    t = threading.Thread(target=run)
+    t.start()
+    t.join()
+    if "e" in box:
+        raise box["e"]
+    return box["v"]
+
 
 class _FastDecode:
     def __init__(self, model, assume_llama_like=False):
@@ -36,6 +90,31 @@ class _FastDecode:
         self.dyn_len = 0
         self.disabled = None         # the reason LlamaDecoder refused this model, once known
         self.fast_steps = 0
+        self.handle = len(_HANDLES) + 1
+        _HANDLES[self.handle] = self
+        self._precheck()
+
+    def _precheck(self):
+        """the refusals of LlamaDecoder.from_hf that can be known without building a decoder, known NOW: inside a
+        torch.compile trace the wrapper must decide between the operator and the stock forward without running anything"""
+        from .decode import LlamaDecoder
+        from .qlinear import QuantLinear
+        cfg = self.model.config
+        try:
+            if getattr(cfg, "model_type", "") not in LlamaDecoder.LLAMA_LIKE and not self.assume_llama_like:
+                raise NotImplementedError(f"model_type {getattr(cfg, 'model_type', '')!r}")
+            if getattr(cfg, "hidden_act", "silu") != "silu":
+                raise NotImplementedError(f"hidden_act {cfg.hidden_act!r}")
+            rp = getattr(cfg, "rope_parameters", None) or getattr(cfg, "rope_scaling", None) or {}
+            if isinstance(rp, dict) and rp.get("rope_type", "default") in ("dynamic", "longrope"):
+                raise NotImplementedError(f"rope_type {rp.get('rope_type')!r}")
+            for blk in self.model.model.layers:
+                a, m = blk.self_attn, blk.mlp
+                for mod in (a.q_proj, a.k_proj, a.v_proj, a.o_proj, m.gate_proj, m.up_proj, m.down_proj):
+                    if not isinstance(mod, QuantLinear):
+                        raise TypeError(f"{type(mod).__name__} where a QuantLinear is expected")
+        except (NotImplementedError, TypeError, AttributeError) as e:
+            self.disabled = repr(e)
 
     # -- eligibility: shapes and types only, nothing that reads device memory
     def _static_layers(self, cache):
@@ -71,16 +150,17 @@ class _FastDecode:
             return None
         return self._static_layers(past_key_values) if past_key_values is not None else None
 
-    def _decoder(self, layers):
+    def _decoder(self, keys4, values4):
         from .decode import LlamaDecoder
-        keys = [L.keys[0] for L in layers]
-        values = [L.values[0] for L in layers]
+        keys = [k[0] for k in keys4]
+        values = [v[0] for v in values4]
         sig = tuple(t.data_ptr() for t in keys + values)
-        max_len = layers[0].max_cache_len
+        max_len = keys[0].shape[-2]
         if self.dec is None or self.dec.max_len != max_len or self.dec.dev != keys[0].device:
             try:
-                self.dec = LlamaDecoder.from_hf(self.model, max_len=max_len, assume_llama_like=self.assume_llama_like,
-                                                kv_cache=(keys, values))
+                self.dec = _off_thread(lambda: LlamaDecoder.from_hf(self.model, max_len=max_len,
+                                                                    assume_llama_like=self.assume_llama_like,
+                                                                    kv_cache=(keys, values)))
             except (NotImplementedError, TypeError, ValueError) as e:
                 self.disabled = repr(e)
                 return None
@@ -129,7 +209,8 @@ class _FastDecode:
         dev = layers[0].keys.device
         if self.dyn is None or self.dyn.dev != dev:
             try:
-                self.dyn = LlamaDecoder.from_hf(self.model, max_len=self._dyn_capacity(), assume_llama_like=self.assume_llama_like)
+                self.dyn = _off_thread(lambda: LlamaDecoder.from_hf(self.model, max_len=self._dyn_capacity(),
+                                                                    assume_llama_like=self.assume_llama_like))
             except (NotImplementedError, TypeError, ValueError) as e:
                 self.disabled = repr(e)
                 return None
@@ -173,24 +254,41 @@ class _FastDecode:
             if not self._unpadded(attention_mask, position_ids, layers[0].cumulative_length):
                 return None
             self._static_checked = weakref.ref(cache)
-        dec = self._decoder(layers)
-        if dec is None:
+        if self._decoder([L.keys for L in layers], [L.values for L in layers]) is None:
             return None
-        with torch.no_grad():
-            lens = [L.cumulative_length for L in layers]
+        return self._static_step(input_ids, [L.keys for L in layers], [L.values for L in layers],
+                                 [L.cumulative_length for L in layers])
 
+    def _static_step(self, input_ids, keys4, values4, lens):
+        """the body of quip_lib::hf_decode_step: one token on the cache tensors, lengths advanced (StaticLayer.update's bookkeeping)"""
+        dec = self._decoder(keys4, values4)
+        if dec is None:
+            raise RuntimeError("fast decode is not available for this model: " + str(self.disabled))
+        with torch.no_grad():
             def set_inputs():
                 dec.tok.copy_(input_ids.reshape(1))
                 dec.pos.copy_(lens[0].reshape(1))
             logits = self._step_checked(dec, set_inputs)   # (1, vocab) fp16; row pos of every layer's cache written
-            torch._foreach_add_(lens, 1)                 # StaticLayer.update()'s bookkeeping
+            torch._foreach_add_(list(lens), 1)
         self.fast_steps += 1
         return logits.reshape(1, 1, -1)
 
     def __call__(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
                  labels=None, use_cache=None, logits_to_keep=0, **kw):
         layers = self._eligible(input_ids, past_key_values, inputs_embeds, labels, kw)
-        logits = self._fast_step(input_ids, past_key_values, layers, attention_mask, position_ids) if layers is not None else None
+        if layers is not None and torch.compiler.is_compiling():
+            # inside somebody's torch.compile: static caches go through the operator (traceable; padding is not checked
+            # there -- it would be a graph break); anything else is the stock forward, which compiles as it always did
+            kind, ls = layers
+            # (a mask's VALUES cannot be looked at in a trace: a call that passes one -- HF's generate does -- stays on the stock
+            #  forward unless QUIP_FAST_DECODE_ASSUME_UNPADDED=1 vouches for unpadded sequences; the reference's loop passes none)
+            if kind == "static" and self.disabled is None and (attention_mask is None or _ASSUME_UNPADDED):
+                logits = torch.ops.quip_lib.hf_decode_step(input_ids, [L.keys for L in ls], [L.values for L in ls],
+                                                           [L.cumulative_length for L in ls], self.handle)
+            else:
+                logits = None
+        else:
+            logits = self._fast_step(input_ids, past_key_values, layers, attention_mask, position_ids) if layers is not None else None
         if logits is None:
             return self.orig_forward(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,
                                      past_key_values=past_key_values, inputs_embeds=inputs_embeds, labels=labels,

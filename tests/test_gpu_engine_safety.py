@@ -52,7 +52,7 @@ def test_generate_falls_back_to_the_stagewise_step_when_the_device_is_shared():
     dec.capture()                                     # (descriptors rebuilt by reset(): the factors were edited)
     assert dec.block_eng and dec.engine_status() == 0
     sink = torch.zeros(4, dtype=torch.int32, device=DEV)
-    side = torch.cuda.Stream()
+    side = torch.cuda.Stream(priority=-1)      # (its own hardware queue: streams of equal priority may share one, which would serialise the two kernels)
     # ~8 s of shader clocks at 2.1 GHz: longer than the ~2-4 s after which a wait gives up
     capi.check(capi.lib().quip_debug_occupy(32, 100 * 1024, ctypes.c_int64(17_000_000_000), sink.data_ptr(), side.cuda_stream),
                "quip_debug_occupy")
@@ -74,7 +74,7 @@ def test_a_failed_launch_answers_nan_and_remembers_the_position():
     dec.reset(first_token=3)
     dec.pos.fill_(5)
     sink = torch.zeros(4, dtype=torch.int32, device=DEV)
-    side = torch.cuda.Stream()
+    side = torch.cuda.Stream(priority=-1)      # (its own hardware queue: streams of equal priority may share one, which would serialise the two kernels)
     capi.check(capi.lib().quip_debug_occupy(16, 100 * 1024, ctypes.c_int64(17_000_000_000), sink.data_ptr(), side.cuda_stream),
                "quip_debug_occupy")
     with torch.no_grad():
