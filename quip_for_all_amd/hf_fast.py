@@ -53,6 +53,22 @@ except RuntimeError:
     pass
 
 
+def _mask_has_holes(mask, n_total):
+    """does an attention mask hide any of the first n_total positions from the LAST query row?  2-D (1, len) masks of ones /
+    zeros, or the 4-D (1, 1, q, kv) masks HF prepares for static caches (bool: True = attend; float: 0 = attend).
+    Reads device memory."""
+    if mask is None or not torch.is_tensor(mask):
+        return False
+    n_total = int(n_total)
+    if mask.dim() == 2:
+        return not bool((mask[:, :n_total] != 0).all())
+    if mask.dim() == 4:
+        row = mask[0, 0, -1, :n_total]
+        ok = row if row.dtype == torch.bool else (row == 0)
+        return not bool(ok.all())
+    return True                         # (a layout this wrapper does not know: not vouched for)
+
+
 def _off_thread(fn):
     """run fn() on a helper thread and hand back its result.  A decoder lives as long as the wrapper; when its first use falls
     into the warm-up run of torch.compile(mode="reduce-overhead"), the calling thread's allocations are being routed into the
@@ -176,7 +192,7 @@ class _FastDecode:
         if torch.cuda.is_current_stream_capturing():
             return True
         n = int(n)
-        if attention_mask is not None and attention_mask.dim() == 2 and not bool((attention_mask[:, :n + 1] != 0).all()):
+        if _mask_has_holes(attention_mask, n + 1):
             return False
         if position_ids is not None and position_ids.numel() >= 1 and int(position_ids.reshape(-1)[-1]) != int(n):
             return False
@@ -280,14 +296,25 @@ class _FastDecode:
             # inside somebody's torch.compile: static caches go through the operator (traceable; padding is not checked
             # there -- it would be a graph break); anything else is the stock forward, which compiles as it always did
             kind, ls = layers
-            # (a mask's VALUES cannot be looked at in a trace: a call that passes one -- HF's generate does -- stays on the stock
-            #  forward unless QUIP_FAST_DECODE_ASSUME_UNPADDED=1 vouches for unpadded sequences; the reference's loop passes none)
-            if kind == "static" and self.disabled is None and (attention_mask is None or _ASSUME_UNPADDED):
+            # (a mask's VALUES cannot be looked at in a trace.  The prompt pass -- eager, HF never compiles it -- has looked and
+            #  left its finding on the cache object (_quip_padded, below): a plain attribute, so the trace is guarded on it and a
+            #  later generation with the other finding gets its own graph.  No finding = stock forward, unless
+            #  QUIP_FAST_DECODE_ASSUME_UNPADDED=1 vouches for unpadded sequences; the reference's loop passes no mask at all.)
+            if kind == "static" and self.disabled is None and (
+                    attention_mask is None or _ASSUME_UNPADDED or getattr(past_key_values, "_quip_padded", True) is False):
                 logits = torch.ops.quip_lib.hf_decode_step(input_ids, [L.keys for L in ls], [L.values for L in ls],
                                                            [L.cumulative_length for L in ls], self.handle)
             else:
                 logits = None
         else:
+            if (layers is None and past_key_values is not None and input_ids is not None and input_ids.dim() == 2
+                    and input_ids.shape[0] == 1 and input_ids.shape[1] > 1 and not torch.compiler.is_compiling()):
+                # a prompt pass of a single sequence: does its mask have holes?  (one synchronisation per generation)
+                try:
+                    seen = past_key_values.get_seq_length()
+                    past_key_values._quip_padded = _mask_has_holes(attention_mask, int(seen) + input_ids.shape[1])
+                except Exception:       # noqa: BLE001 (an object that takes no attributes / an unknown cache: no finding)
+                    pass
             logits = self._fast_step(input_ids, past_key_values, layers, attention_mask, position_ids) if layers is not None else None
         if logits is None:
             return self.orig_forward(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,

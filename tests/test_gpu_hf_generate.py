@@ -341,10 +341,10 @@ def test_fast_decode_wrapper_routes_static_cache_steps_through_the_decoder():
     ct, _ = c.generate(ids, 16, "compile")
     assert model._quip_fast_decode.fast_steps > steps_c and int((ct == want).sum()) >= 14, (ct, want)
     # HF's own generate with a static cache compiles the forward and passes an attention mask, whose values a trace cannot
-    # look at: those calls stay on the (compiled) stock forward
+    # look at: the (eager) prompt pass has, and left its finding on the cache object -- unpadded here, so the operator runs
     steps0 = model._quip_fast_decode.fast_steps
     ref = model.generate(ids, max_new_tokens=12, do_sample=False, cache_implementation="static")[0, ids.shape[1]:]
-    assert model._quip_fast_decode.fast_steps == steps0
+    assert model._quip_fast_decode.fast_steps > steps0
     assert int((ref[:12] == want[:12]).sum()) >= 10, (ref, want)
     disable_fast_decode(model)
     assert model.forward.__self__ is model
@@ -504,6 +504,18 @@ def test_fast_decode_wrapper_leaves_a_padded_sequence_to_the_stock_forward():
     assert fd.fast_steps == 0 and torch.equal(got, want), (fd.fast_steps, got, want)
     got2 = model.generate(ids, attention_mask=mask, max_new_tokens=8, do_sample=False, cache_implementation="static")[0, ids.shape[1]:]
     assert fd.fast_steps == 0 and int((got2 == want).sum()) >= 7, (fd.fast_steps, got2, want)
+    # the same (reused) static cache object, now with an unpadded prompt: its own graph, through the operator -- and padded again
+    u_want = None
+    for rounds in range(2):
+        steps0 = fd.fast_steps
+        u = model.generate(ids[:, 2:], max_new_tokens=8, do_sample=False, cache_implementation="static")[0, 4:]
+        u_want = u if u_want is None else u_want
+        assert fd.fast_steps > steps0 or rounds == 1, (rounds, fd.fast_steps, steps0)     # (a replayed graph runs no Python)
+        assert torch.equal(u, u_want)
+        steps0 = fd.fast_steps
+        got3 = model.generate(ids, attention_mask=mask, max_new_tokens=8, do_sample=False, cache_implementation="static")[0, ids.shape[1]:]
+        assert fd.fast_steps == steps0 and torch.equal(got3, got2), (got3, got2)
+    fd.fast_steps = 0
     # ... and an unpadded one still goes through
     model.generate(ids[:, 2:], max_new_tokens=4, do_sample=False)
     assert fd.fast_steps == 3
