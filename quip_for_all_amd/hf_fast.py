@@ -38,12 +38,19 @@ except RuntimeError:
     pass
 
 
+def _wrapper_of(handle):
+    fd = _HANDLES.get(handle, lambda: None)()       # (weak references: a wrapper goes away with its model)
+    if fd is None:
+        raise RuntimeError("quip_lib::hf_decode_step: the model this compiled graph was traced for no longer exists")
+    return fd
+
+
 def _hf_decode_step_cuda(input_ids, keys, values, lens, handle):
-    return _HANDLES[handle]._static_step(input_ids, keys, values, lens)
+    return _wrapper_of(handle)._static_step(input_ids, keys, values, lens)
 
 
 def _hf_decode_step_fake(input_ids, keys, values, lens, handle):
-    return input_ids.new_empty((1, 1, int(_HANDLES[handle].model.config.vocab_size)), dtype=torch.float16)
+    return input_ids.new_empty((1, 1, int(_wrapper_of(handle).model.config.vocab_size)), dtype=torch.float16)
 
 
 try:
@@ -106,8 +113,10 @@ class _FastDecode:
         self.dyn_len = 0
         self.disabled = None         # the reason LlamaDecoder refused this model, once known
         self.fast_steps = 0
-        self.handle = len(_HANDLES) + 1
-        _HANDLES[self.handle] = self
+        import weakref
+        _FastDecode._next_handle = getattr(_FastDecode, "_next_handle", 0) + 1
+        self.handle = _FastDecode._next_handle
+        _HANDLES[self.handle] = weakref.ref(self, lambda _r, h=self.handle: _HANDLES.pop(h, None))
         self._precheck()
 
     def _precheck(self):
