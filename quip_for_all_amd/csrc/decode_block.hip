@@ -1115,7 +1115,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           for (int k = 2 * KPAIRS; k < B::KP16; ++k) ft[j * B::KP16 + k] = 0u;
         if (kCheapPoll && wave == 0) {
           uint32_t spins0 = 0;
-          const uint64_t* last = frow + ((size_t)(FL - 1) * B::KP16 + (lane < FK ? lane : 0));
+          const uint64_t* last = frow + ((size_t)(FL - 1 - (w & 7)) * B::KP16 + (lane < FK ? lane : 0));      // (eight of the last columns: 32 workgroups per polled line instead of 256 -- 256 pollers of ONE line delay the owners' stores to it: 1410 -> 1380 us per 32-block launch)
           for (;;) {
             u32x2_t f;
             esync::ld8(f, last);

@@ -85,8 +85,8 @@ constexpr size_t kWsZq = 64, kWsZk = kWsZq + (HID / 2) * 8, kWsZv = kWsZk + (NKV
 constexpr size_t kWsA = kWsZv + (NKV * HD / 2) * 8, kWsZo = kWsA + (HID / 2) * 8, kWsZd = kWsZo + (HID / 2) * 8;
 constexpr size_t kWsInbox = kWsZd + (HID / 2) * 8;                    // [FK][2][FL] granules (fp32 payload)
 constexpr size_t kWsRows = kWsInbox + (size_t)FK * 2 * FL * 8;        // [FK][FL / 2] granules (two 24-bit values each)
-constexpr size_t kWsRowMax = kWsRows + (size_t)FK * FL * 8;           // [8] granules
-constexpr size_t kWsPart = kWsRowMax + 64;                            // [NH][kParts][132]
+constexpr size_t kWsRowMax = kWsRows + (size_t)FK * FL * 8;           // [8 copies][16] granules: a 128-byte line per copy, workgroup w polls copy w & 7
+constexpr size_t kWsPart = kWsRowMax + 8 * 128;                       // [NH][kParts][132]
 constexpr size_t kWsBytes = kWsPart + (size_t)NH * kParts * kPartGran * 8;
 
 struct GLds {
@@ -326,16 +326,22 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     u32x4_t p[4];
     uint32_t spins = 0;
     const uint64_t* src = vec + 8 * tid;
-    for (;;) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) esync::ld16(p[j], src + 2 * j);
+    for (int j = 0; j < 4; ++j) p[j] = u32x4_t{0u, 0u, 0u, 0u};
+    bool ok = false;
+    for (;;) {
+      if (!ok) {                                       // (a lane whose pieces are all there sits the retries out)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) esync::ld16_keep(p[j], src + 2 * j);
+      }
       esync::drain();
-      bool ok = true;
+      bool now = true;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         esync::own(p[j]);
-        ok = ok && p[j].y == tag && p[j].w == tag;
+        now = now && p[j].y == tag && p[j].w == tag;
       }
+      ok = now;
       if (esync::spin_step(ok, spins, ctl + 1, code + (uint32_t)w)) break;
     }
 #pragma unroll
@@ -1016,7 +1022,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
                                (pk[r + 2] & 0xffffffu) | (pk[r + 3] << 24), ((pk[r + 3] >> 8) & 0xffffu) | t16};
         esync::st_payload16(dst + r / 2, piece);
       }
-      if (tid == 0) esync::st_granule(rowmax + w, as_u32(mxr), tag2);
+      // (eight copies in eight lines: 256 workgroups polling ONE line delay the owners' stores to it)
+      if (tid < 8) esync::st_granule(rowmax + 16 * tid + w, as_u32(mxr), tag2);
       had::wg_barrier<true>();
     }
     BSTAMP(13);
@@ -1026,7 +1033,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
       uint32_t spins0 = 0;
       u32x2_t f;
       for (;;) {
-        esync::ld8(f, rowmax + (lane < FK ? lane : 0));
+        esync::ld8(f, rowmax + 16 * (w & 7) + (lane < FK ? lane : 0));
         esync::drain();
         esync::own(f);
         if (esync::spin_step(f.y == tag2, spins0, ctl + 1, 0x3000u + (uint32_t)w)) break;

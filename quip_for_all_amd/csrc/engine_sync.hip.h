@@ -44,6 +44,11 @@ __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: 
 __device__ __forceinline__ void ld16(u32x4_t& dst, const void* p) {
   asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory");
 }
+// the same into a register that keeps its value in the lanes that do not execute the load (a poll loop's lanes whose
+// pieces have arrived sit out the retries: 256 workgroups re-reading a whole vector per retry delay the stores they wait for)
+__device__ __forceinline__ void ld16_keep(u32x4_t& dst, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+v"(dst) : "v"(p) : "memory");
+}
 __device__ __forceinline__ void ld8(u32x2_t& dst, const void* p) {
   asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory");
 }
