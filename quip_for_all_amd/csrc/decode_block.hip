@@ -878,6 +878,19 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       // o_proj's input side: x = H (a (.) SU_o) * sc  (no norm), every workgroup
       const u32x4 psu = *reinterpret_cast<const u32x4*>(Ld.su[3] + 8 * tid);
       float v[1][8];
+      {
+        // the attention output is ~8 us away for the workgroups that do not compute it: they wait for it on ONE granule (of a
+        // head of their own choice per wave) instead of re-reading the whole 16 KB vector per retry next to the heads' stores
+        uint32_t sp = 0;
+        u32x2_t f;
+        const uint64_t* g1 = zbufs + (size_t)3 * 2048 + (size_t)((8 * w + wave) & (NH - 1)) * 64;
+        for (;;) {
+          esync::ld8(f, g1);
+          esync::drain();
+          esync::own(f);
+          if (esync::spin_step(f.y == (ebase | hop), sp, ctl + 1, 0x6100u + (uint32_t)w)) break;
+        }
+      }
       gather(std::integral_constant<int, 1>{}, SLOTS(RVQ ? M_O : 0u), 3, ebase | hop, 0x6000u, v);
       // gate's row blocks (the slots of q, k, v: consumed) once the hand-off is through, one at a time between the stages
       // of o's input side: they have o's product, a hand-off and an edge to land

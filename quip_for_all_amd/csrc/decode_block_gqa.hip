@@ -351,6 +351,18 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     }
     own_ring();
   };
+  // a long wait is spent on ONE granule per wave (a line of its own choice), not on re-reading a whole vector per retry next to
+  // the stores that are awaited; the gather behind it re-checks every piece
+  auto prepoll = [&](const uint64_t* g1, uint32_t tag, uint32_t code) {
+    uint32_t sp = 0;
+    u32x2_t f;
+    for (;;) {
+      esync::ld8(f, g1);
+      esync::drain();
+      esync::own(f);
+      if (esync::spin_step(f.y == tag, sp, ctl + 1, code + (uint32_t)w)) break;
+    }
+  };
   // 16 fp16 of a permuted / natural vector at p + 16 t -> floats
   auto load16 = [&](const f16* p, u32x4 (&v)[2]) {
     v[0] = *reinterpret_cast<const u32x4*>(p + 16 * tid);
@@ -876,6 +888,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
       u32x4 psu[2];
       load16(Ld.su[3], psu);                           // natural order
       float v[1][16], suf[16];
+      prepoll(za + (size_t)((8 * w + wave) & (NH - 1)) * 64, ebase | hop, 0x6100u);      // (the attention output is ~10 us away)
       gather16(za, ebase | hop, 0x6000u, v[0]);
       asm volatile("" : "+v"(psu[0]), "+v"(psu[1]));
       BSTAMP(7);
