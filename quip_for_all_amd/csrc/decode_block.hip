@@ -76,9 +76,9 @@ constexpr int NSLOT = 9;                             // X0-2: q k v, then gate's
 // workspace: ctl | z_q z_k z_v | a | z_o | z_d (2048 granules each) | inbox [11 row owners][256 columns][2][4] | rows [256][48] |
 // attention partials [32 heads][8][132]
 constexpr size_t kWsCtl = 0, kWsZ = 64, kWsVec = 2048 * 8;
-// row-owner workgroups of the MLP edge: RPO rows k' each, one per wave on waves 0..RPO-1 (four waves = one per SIMD: the
+// row-owner workgroups of the MLP edge: RPO rows k' each, a PAIR of waves per row (gate half, up half) on waves 0..2 RPO-1 (RPO = 2: four waves = one per SIMD, 22 owners; with RPO = 4 the eight waves shared SIMDs: 1390 -> 1354 us per 32-block launch, same box: the
 // row work is DPP-serial VALU code, two such waves on a SIMD take twice as long)
-constexpr int RPO = 4, NRO = (FK + RPO - 1) / RPO;
+constexpr int RPO = 2, NRO = (FK + RPO - 1) / RPO;
 constexpr size_t kWsInbox = kWsZ + 6 * kWsVec, kWsRows = kWsInbox + (size_t)NRO * FL * 2 * RPO * 8;
 // long contexts: the eight workgroups of a head each take every eighth position; their partial softmax states (128 sums +
 // maximum + denominator, padded to 132 granules) meet at the head's first workgroup
@@ -1039,7 +1039,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         // a row on a PAIR of waves: wave rw its gate half, wave 4 + rw its up half, 4 consecutive elements per lane (index bits
         // 0..1 in registers, 2..7 = lane bits 0..5; ascending bit order: the same additions as fht16_lanes, fht_wg512.hip.h);
         // the up half crosses to the gate wave through LDS
-        const int rw = wave & (RPO - 1), mh = wave >> 2;
+        const int rw = wave & (RPO - 1), mh = (wave / RPO) & 1;
+        const bool act = wave < 2 * RPO;                 // (RPO = 2: waves 0..3, one per SIMD)
         const bool row_ok = RPO * w + rw < FK;
         auto fht256 = [&](float (&x)[4]) {
 #pragma clang fp contract(off)
@@ -1054,16 +1055,16 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           lst(std::integral_constant<int, 0>{}); lst(std::integral_constant<int, 1>{}); lst(std::integral_constant<int, 2>{});
           lst(std::integral_constant<int, 3>{}); lst(std::integral_constant<int, 4>{}); lst(std::integral_constant<int, 5>{});
         };
-        float v[4];
-        {
-          const float4 f0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(smem + B::kArea) +
-                                                            ((row_ok ? rw : 0) * 2 + mh) * FL + lane * 4);
-          v[0] = f0.x; v[1] = f0.y; v[2] = f0.z; v[3] = f0.w;
-        }
-        fht256(v);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
         const f16* vecs = reinterpret_cast<const f16*>(smem + B::kStash) + (row_ok ? rw : 0) * 3 * FL;
-        float o[4];
-        {
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        if (act) {
+          {
+            const float4 f0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(smem + B::kArea) +
+                                                              ((row_ok ? rw : 0) * 2 + mh) * FL + lane * 4);
+            v[0] = f0.x; v[1] = f0.y; v[2] = f0.z; v[3] = f0.w;
+          }
+          fht256(v);
           const uint2 svp = *reinterpret_cast<const uint2*>(vecs + mh * FL + lane * 4);
           const f16x2 s01 = as_f16x2(svp.x), s23 = as_f16x2(svp.y);
           const float svf[4] = {(float)s01.x, (float)s01.y, (float)s23.x, (float)s23.y};
@@ -1071,10 +1072,10 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           for (int r = 0; r < 4; ++r) o[r] = (float)had::out_elem(v[r], 1.f / 16.f, true, svf[r], false, 0.f, false, 0.f);
         }
         float* xch = reinterpret_cast<float*>(smem + B::kStage + RPO * FL * 4);     // [RPO][256]: the up halves
-        if (mh == 1) *reinterpret_cast<float4*>(xch + rw * FL + lane * 4) = float4{o[0], o[1], o[2], o[3]};
+        if (act && mh == 1) *reinterpret_cast<float4*>(xch + rw * FL + lane * 4) = float4{o[0], o[1], o[2], o[3]};
         had::wg_barrier<true>();
         uint32_t* stage = reinterpret_cast<uint32_t*>(smem + B::kStage);
-        if (mh == 0) {
+        if (act && mh == 0) {
           const float4 u4 = *reinterpret_cast<const float4*>(xch + rw * FL + lane * 4);
           const float u[4] = {u4.x, u4.y, u4.z, u4.w};
           const uint2 sup = *reinterpret_cast<const uint2*>(vecs + 2 * FL + lane * 4);
@@ -1096,13 +1097,12 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         }
         had::wg_barrier<true>();
         // ... and out: column j's RPO rows = granules [j * 48 + RPO w, +RPO) as 16-byte stores
-        if (tid < FL * RPO / 4) {
-          static_assert(RPO == 4, "one thread per column");
+        if (tid < FL) {
+          static_assert(RPO == 2, "one thread per column, one 16-byte store");
           const int j = tid;
-          const u32x4 d = *reinterpret_cast<const u32x4*>(stage + j * RPO);
+          const uint2 d = *reinterpret_cast<const uint2*>(stage + j * RPO);
           uint64_t* dst = frow + ((size_t)j * B::KP16 + RPO * w);
           esync::st_granule2(dst, d.x, d.y, tag2);
-          esync::st_granule2(dst + 2, d.z, d.w, tag2);
         }
         had::wg_barrier<true>();                         // the staging area is free again (the gather below zeroes over it)
       }
