@@ -32,6 +32,7 @@ from . import register_lib as _R
 _HANDLES = {}
 import os as _os
 _ASSUME_UNPADDED = _os.environ.get("QUIP_FAST_DECODE_ASSUME_UNPADDED", "0") != "0"
+_PREFILL = _os.environ.get("QUIP_FAST_DECODE_PREFILL", "1") != "0"
 try:
     _R._lib.define("hf_decode_step(Tensor input_ids, Tensor(a!)[] keys, Tensor(b!)[] values, Tensor(c!)[] lens, int handle) -> Tensor")
 except RuntimeError:
@@ -113,6 +114,7 @@ class _FastDecode:
         self.dyn_len = 0
         self.disabled = None         # the reason LlamaDecoder refused this model, once known
         self.fast_steps = 0
+        self.fast_prefills = 0
         import weakref
         _FastDecode._next_handle = getattr(_FastDecode, "_next_handle", 0) + 1
         self.handle = _FastDecode._next_handle
@@ -207,6 +209,14 @@ class _FastDecode:
             return False
         return True
 
+    @staticmethod
+    def _positions_from_zero(position_ids, P):
+        if position_ids is None:
+            return True
+        if position_ids.numel() != P:
+            return False
+        return bool((position_ids.reshape(-1) == torch.arange(P, device=position_ids.device)).all())
+
     def _step_checked(self, dec, set_inputs):
         """one decoder step; when the call is not being captured into a graph, the persistent launch's status word is read
         back (one small synchronising copy per token -- HF's generate loop synchronises per token anyway) and a launch that
@@ -227,11 +237,8 @@ class _FastDecode:
                 logits = dec.step()
         return logits
 
-    def _dynamic_step(self, input_ids, cache, layers, attention_mask=None, position_ids=None):
-        import weakref
+    def _dynamic_decoder(self, dev):
         from .decode import LlamaDecoder
-        n = layers[0].keys.shape[-2]
-        dev = layers[0].keys.device
         if self.dyn is None or self.dyn.dev != dev:
             try:
                 self.dyn = _off_thread(lambda: LlamaDecoder.from_hf(self.model, max_len=self._dyn_capacity(),
@@ -240,7 +247,59 @@ class _FastDecode:
                 self.disabled = repr(e)
                 return None
             self.dyn_owner = None
-        dec = self.dyn
+        return self.dyn
+
+    def _release_owner(self, cache):
+        """a cache object other than `cache` that holds views of the buffers keeps its contents: the views become its own tensors"""
+        owner = self.dyn_owner() if self.dyn_owner is not None else None
+        if owner is not None and owner is not cache:
+            for L in getattr(owner, "layers", []):
+                if getattr(L, "is_initialized", False) and torch.is_tensor(L.keys) and L.keys.numel():
+                    L.keys, L.values = L.keys.clone(), L.values.clone()
+
+    @torch.compiler.disable
+    def _dynamic_prefill(self, input_ids, cache, attention_mask, kw):
+        """the prompt pass of a single unpadded sequence on an EMPTY DynamicCache (what generate() starts with), last-token
+        logits only (logits_to_keep = 1): LlamaDecoder.prefill on the wrapper's buffers -- one batched pass, grouped launches --
+        and the cache object gets views of the first P rows.  Anything else: None (the stock forward runs)."""
+        import weakref
+        if self.disabled is not None or type(cache).__name__ != "DynamicCache":
+            return None
+        layers = getattr(cache, "layers", None)
+        if not layers or len(layers) != self.model.config.num_hidden_layers:
+            return None
+        if any(type(L).__name__ != "DynamicLayer" or getattr(L, "is_initialized", False) for L in layers):
+            return None
+        P = input_ids.shape[1]
+        if P + 1 > self._dyn_capacity() or _mask_has_holes(attention_mask, P):
+            return None
+        dec = self._dynamic_decoder(input_ids.device)
+        if dec is None or dec.window:
+            return None
+        with torch.no_grad():
+            self._release_owner(cache)
+            logits = dec.prefill(input_ids.reshape(-1))
+            for i, L in enumerate(layers):
+                L.lazy_initialization(dec.kcache[i][None, :, :0], dec.vcache[i][None, :, :0])
+                L.keys = dec.kcache[i][None, :, :P]
+                L.values = dec.vcache[i][None, :, :P]
+        self.dyn_owner = weakref.ref(cache)
+        self.dyn_len = P
+        try:
+            cache._quip_padded = False
+        except Exception:       # noqa: BLE001
+            pass
+        self.fast_prefills += 1
+        return logits.reshape(1, 1, -1)
+
+    def _dynamic_step(self, input_ids, cache, layers, attention_mask=None, position_ids=None):
+        import weakref
+        from .decode import LlamaDecoder
+        n = layers[0].keys.shape[-2]
+        dev = layers[0].keys.device
+        dec = self._dynamic_decoder(dev)
+        if dec is None:
+            return None
         owner = self.dyn_owner() if self.dyn_owner is not None else None
         owned = (owner is cache and n <= self.dyn_len and layers[0].keys.data_ptr() == dec.kcache[0].data_ptr()
                  and layers[-1].values.data_ptr() == dec.vcache[-1].data_ptr())
@@ -248,11 +307,7 @@ class _FastDecode:
             return None
         with torch.no_grad():
             if not owned:
-                if owner is not None and owner is not cache:
-                    # the previous owner keeps its contents: its views of the buffers become tensors of its own
-                    for L in getattr(owner, "layers", []):
-                        if getattr(L, "is_initialized", False) and torch.is_tensor(L.keys):
-                            L.keys, L.values = L.keys.clone(), L.values.clone()
+                self._release_owner(cache)
                 for i, L in enumerate(layers):
                     dec.kcache[i][:, :n].copy_(L.keys[0])
                     dec.vcache[i][:, :n].copy_(L.values[0])
@@ -325,6 +380,12 @@ class _FastDecode:
                 except Exception:       # noqa: BLE001 (an object that takes no attributes / an unknown cache: no finding)
                     pass
             logits = self._fast_step(input_ids, past_key_values, layers, attention_mask, position_ids) if layers is not None else None
+            if (logits is None and layers is None and _PREFILL and past_key_values is not None and input_ids is not None
+                    and input_ids.dim() == 2 and input_ids.shape[0] == 1 and input_ids.shape[1] > 1 and input_ids.is_cuda
+                    and inputs_embeds is None and labels is None and isinstance(logits_to_keep, int) and logits_to_keep == 1
+                    and not self.model.training and not kw.get("output_attentions") and not kw.get("output_hidden_states")
+                    and not torch.compiler.is_compiling() and self._positions_from_zero(position_ids, input_ids.shape[1])):
+                logits = self._dynamic_prefill(input_ids, past_key_values, attention_mask, kw)
         if logits is None:
             return self.orig_forward(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,
                                      past_key_values=past_key_values, inputs_embeds=inputs_embeds, labels=labels,

@@ -370,8 +370,17 @@ def test_fast_decode_wrapper_serves_the_default_dynamic_cache():
     enable_fast_decode(model)
     fd = model._quip_fast_decode
     got = model.generate(ids, max_new_tokens=16, do_sample=False)[0, ids.shape[1]:]
-    assert fd.disabled is None and fd.fast_steps == 15, (fd.disabled, fd.fast_steps)
+    assert fd.disabled is None and fd.fast_steps == 15 and fd.fast_prefills == 1, (fd.disabled, fd.fast_steps, fd.fast_prefills)
     assert int((got == want).sum()) >= 14, (got, want)
+    # the prompt pass alone: last-token logits of the decoder's batched prefill against the stock forward's
+    from transformers import DynamicCache as _DC
+    with torch.no_grad():
+        lf = model(ids, past_key_values=_DC(config=model.config), use_cache=True, logits_to_keep=1).logits.float()
+        model.forward = fd.orig_forward
+        ls = model(ids, past_key_values=_DC(config=model.config), use_cache=True, logits_to_keep=1).logits.float()
+        model.forward = fd
+    assert fd.fast_prefills == 2 and lf.shape == ls.shape == (1, 1, model.config.vocab_size)
+    assert (lf - ls).abs().max().item() <= 2.0 ** -6 * ls.abs().max().item(), (lf - ls).abs().max().item()
 
     # by hand: two cache objects interleaved, one of them sent back to the stock forward in between
     def prompt(cache, p):
