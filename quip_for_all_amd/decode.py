@@ -655,9 +655,11 @@ class LlamaDecoder:
             n_prompt = 0
         pos0 = prompt.numel() - 1 if (batched_prefill and prompt is not None and prompt.numel() > 1) else 0
 
+        replay = [bool(use_graph)]
+
         def run(t_from):
             for t in range(t_from, n_prompt + n_tokens):
-                if use_graph:
+                if replay[0]:
                     self.graph.replay()
                 else:
                     self.step_logits = self.step()
@@ -686,7 +688,10 @@ class LlamaDecoder:
                 self.graph = None
             t_from = 0 if fail is None else max(0, fail - pos0)
             if use_graph and self.graph is None:
-                self.capture()
+                # The rest of THIS call runs eagerly: capture() warms up with two steps at positions 0 and 1, which would
+                # overwrite cache rows 0 and 1 of every layer -- rows the resumed decode still attends to.  The next
+                # generate() call captures the stage-wise step (its reset + prompt pass rewrite those rows anyway).
+                replay[0] = False
             self.pos.fill_(pos0 + t_from)
             if t_from == 0:
                 self.tok.fill_(first_token if not (batched_prefill and prompt is not None and prompt.numel() > 1) else int(prompt[-1]))

@@ -133,3 +133,21 @@ def test_full_size_70b_block_against_float64_model():
     u = _ulps_of_rms(got, ref)
     print(f"70B-shaped block (E8P12), logits of step 3 vs float64: max {u:.2f} fp16 ulps of rms(logits) = {np.sqrt(np.mean(ref * ref)):.3f}")
     assert u <= 6.0, u                        # observed: 2.58
+
+
+def test_four_full_size_70b_blocks_against_float64_model():
+    """FOUR Llama-2-70B-shaped blocks for 3 decode steps on the persistent launch against the layer-major
+    float64 model (one block's 6.8 GB of float64 weights at a time).  Bound: deep_bound_ulps(4) = 4 sqrt(4) + 2 = 10 fp16
+    ulps of rms(logits) -- the per-block error (one block: 2.58) growing in quadrature."""
+    from tests.test_gpu_decode import _ref_logits_deep, _ulps_of_rms, deep_bound_ulps
+    np.random.seed(19)
+    dec = _decoder(4, True, max_len=16, seed=8, vocab=1024)
+    assert dec.block_eng and dec.eng_shape == 1
+    toks = dec.generate(3, first_token=9, use_graph=True).cpu().numpy()
+    got = dec.step_logits.float().cpu().numpy()[0].astype(np.float64)
+    assert dec.engine_status() == 0
+    ref = _ref_logits_deep(dec, [9, int(toks[0]), int(toks[1])])
+    u = _ulps_of_rms(got, ref)
+    print(f"4 x 70B-shaped blocks (E8P12), logits of step 3 vs float64: max {u:.2f} fp16 ulps of rms(logits) = "
+          f"{np.sqrt(np.mean(ref * ref)):.3f} (bound {deep_bound_ulps(4):.1f})")
+    assert u <= deep_bound_ulps(4), u

@@ -68,6 +68,50 @@ def test_generate_falls_back_to_the_stagewise_step_when_the_device_is_shared():
     np.testing.assert_array_equal(again, expected)
 
 
+def test_a_launch_that_fails_mid_generation_behind_a_prompt_keeps_the_prompt_rows():
+    """the retry after a persistent launch gave up must not warm a new capture up on the LIVE cache (capture() runs
+    two steps at positions 0 and 1).  A failure is injected behind a batched prompt pass (engine words written by hand after
+    the decode loop): the resumed decode runs eagerly from the failed position, cache rows of the prompt stay what the prompt
+    pass wrote, and the tokens in front of the failed position are kept."""
+    plain = _decoder(False, False)
+    dec = _decoder(True, True)
+    _same_weights(dec, plain)
+    prompt = torch.tensor([5, 9, 2, 7, 11], device=DEV)
+    n = 8
+    expected = plain.generate(n, prompt=prompt, use_graph=True).cpu().numpy()
+    rows_ref = [k[:, :4].clone() for k in plain.kcache]
+    clean = dec.generate(n, prompt=prompt, use_graph=True).cpu().numpy()
+    fail_at = (prompt.numel() - 1) + 3                           # absolute position of the fourth generated token
+    state = {"armed": True}
+    real_status, real_fail = dec.engine_status, dec.engine_fail_position
+
+    def status():
+        if state["armed"]:
+            return 0x2001
+        return real_status()
+
+    def fail_position():
+        if state["armed"]:
+            state["armed"] = False
+            return fail_at
+        return real_fail()
+
+    dec.engine_status, dec.engine_fail_position = status, fail_position
+    with warnings.catch_warnings(record=True) as wr:
+        warnings.simplefilter("always")
+        got = dec.generate(n, prompt=prompt, use_graph=True).cpu().numpy()
+    del dec.engine_status, dec.engine_fail_position
+    assert any("gave up" in str(w.message) for w in wr)
+    assert not dec.block_eng and dec.graph is None               # the next call captures the stage-wise step
+    for k_ref, k in zip(rows_ref, dec.kcache):
+        assert torch.equal(k[:, :4], k_ref), "prompt rows of the cache were overwritten by the retry"
+    np.testing.assert_array_equal(got[:3], clean[:3])            # tokens in front of the failed position are kept
+    if np.array_equal(clean, expected):                          # (the two paths agree on this model: then so does the mix)
+        np.testing.assert_array_equal(got, expected)
+    again = dec.generate(n, prompt=prompt, use_graph=True).cpu().numpy()
+    np.testing.assert_array_equal(again, expected)
+
+
 def test_a_failed_launch_answers_nan_and_remembers_the_position():
     from quip_for_all_amd import capi
     dec = _decoder(True, True, layers=1)
