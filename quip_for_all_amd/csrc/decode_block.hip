@@ -27,7 +27,17 @@
 // every wait is bounded and a launch that gives up leaves a code in ctl[1] (engine_sync.hip.h).
 #include "e8p_gemv_core.hip.h"
 #include "engine_sync.hip.h"
-#include "fht_wg512.hip.h"
+#include "fht_wg512x.hip.h"
+
+#ifndef QUIP_INO_EXACT
+#define QUIP_INO_EXACT 0
+#endif
+#ifndef QUIP_PREDECODE_DOWN
+#define QUIP_PREDECODE_DOWN 1      // items of down decoded inside the wait for the MLP rows (2: the register allocator spills)
+#endif
+#ifndef QUIP_PREDECODE_GATE
+#define QUIP_PREDECODE_GATE 1      // items of gate / up decoded inside the wait for z_o (2: spills)
+#endif
 
 namespace quip {
 
@@ -152,19 +162,24 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   using B = BLds<REP, RVQ>;
   constexpr int VM = B::VM, KV = B::KV;
   constexpr int kRowU4V = VM * kRowU4, kRowU4DV = VM * kRowU4D;     // 16-byte pieces of a weight row (hidden- / ffn-wide input)
+  // gate / up (round 5): workgroup w multiplies ONE of the two matrices -- mgu = w >> 7: 0 gate, 1 up -- for TWO columns of
+  // the (43, 256) view of its output, 2 (w & 127) and + 1 (rows k * 256 + column: the second column is the next weight row,
+  // kRowB bytes on, in the units ld_item_o() takes), so that it needs ONE input transform on the edge in front of them instead of two
+  constexpr int kRowB = kRowU4V * 16;
   using T = Lds<REP>;
   // Everything derived from the thread index is RE-derived from an opaque copy at the top of every stage (rederive()):
   // left to itself the compiler hoists ~70 lane-dependent addresses out of the block loop and spills them.
   int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int w = blockIdx.x;
+  const int mgu = w >> 7;
   int n = lane & 15, q = lane >> 4;
   uint32_t* ctl = reinterpret_cast<uint32_t*>(a.ws + kWsCtl);
   uint64_t* zbufs = reinterpret_cast<uint64_t*>(a.ws + kWsZ);       // [6][2048]: q k v a o d
   uint64_t* inbox = reinterpret_cast<uint64_t*>(a.ws + kWsInbox);
   uint64_t* frow = reinterpret_cast<uint64_t*>(a.ws + kWsRows);
   uint64_t* pbuf = reinterpret_cast<uint64_t*>(a.ws + kWsPart);
-  uint64_t* kvnew = reinterpret_cast<uint64_t*>(a.ws + kWsKvNew);
+  // (kWsKvNew: the k / v hand-off inside a head's group of rounds 3-4; unused since the heads transform q, k, v themselves)
   int dbg_on = 0;
 #define BSTAMP(i) do { if (dbg_on && tid == 0) a.dbg[w * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
@@ -188,7 +203,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     for (int rb = 0; rb < FRB; ++rb) {
       int kr = rb * 16 + n;
       kr = kr < FK ? kr : FK - 1;
-      vo_gu[rb] = (uint32_t)((kr * FL + w) * kRowU4V + wave * 8 + q) * PB;
+      vo_gu[rb] = (uint32_t)((kr * FL + 2 * (w & 127)) * kRowU4V + wave * 8 + q) * PB;
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -232,7 +247,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 #define ISSUE(Ld, kind) do {                                                                                          \
     if ((kind) < 3) ld_item(qa[SLOT_OF(kind)], qb[SLOT_OF(kind)], Ld.W[(3 * w + ((kind) < 3 ? (kind) : 0)) >> 8], vo_q[(kind) < 3 ? (kind) : 0]); \
     else if ((kind) == 3) ld_item(qa[3], qb[3], Ld.W[3], vo_row);                                                      \
-    else if ((kind) < 10) ld_item(qa[SLOT_OF(kind)], qb[SLOT_OF(kind)], Ld.W[4 + ((kind) - 4) / FRB], vo_gu[((kind) - 4) % FRB]); \
+    else if ((kind) < 7) ld_item(qa[SLOT_OF(kind)], qb[SLOT_OF(kind)], Ld.W[4 + mgu], vo_gu[((kind) - 4) % FRB]); \
+    else if ((kind) < 10) ld_item_o(OFFC(kRowB), qa[SLOT_OF(kind)], qb[SLOT_OF(kind)], Ld.W[4 + mgu], vo_gu[((kind) - 4) % FRB]); \
     else if ((kind) < 12) ld_item(qa[SLOT_OF(kind)], qb[SLOT_OF(kind)], Ld.W[6], vo_d[(kind) >= 10 ? ((kind) - 10) % 3 : 0]);     \
     else {                                                                                                             \
       const uint4* bd_ = uni(Ld.W[6]);                                                                                 \
@@ -263,19 +279,19 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   } while (0)
 #define ISSUE_RVQ_O(Ld) do { ld_item_o(OFFC(0), qa[6], qb[6], Ld.W[3], vo_row); ld_item_o(OFFC(1024), qa[7], qb[7], Ld.W[3], vo_row); } while (0)
 #define ISSUE_RVQ_GATE(Ld) do {                                                                         \
-    ld_item_o(OFFC(0), qa[0], qb[0], Ld.W[4], vo_gu[0]); ld_item_o(OFFC(0), qa[1], qb[1], Ld.W[4], vo_gu[1]); ld_item_o(OFFC(0), qa[2], qb[2], Ld.W[4], vo_gu[2]); \
-    ld_item_o(OFFC(1024), qa[3], qb[3], Ld.W[4], vo_gu[0]); ld_item_o(OFFC(1024), qa[4], qb[4], Ld.W[4], vo_gu[1]); ld_item_o(OFFC(1024), qa[5], qb[5], Ld.W[4], vo_gu[2]); \
+    ld_item_o(OFFC(0), qa[0], qb[0], Ld.W[4 + mgu], vo_gu[0]); ld_item_o(OFFC(0), qa[1], qb[1], Ld.W[4 + mgu], vo_gu[1]); ld_item_o(OFFC(0), qa[2], qb[2], Ld.W[4 + mgu], vo_gu[2]); \
+    ld_item_o(OFFC(1024), qa[3], qb[3], Ld.W[4 + mgu], vo_gu[0]); ld_item_o(OFFC(1024), qa[4], qb[4], Ld.W[4 + mgu], vo_gu[1]); ld_item_o(OFFC(1024), qa[5], qb[5], Ld.W[4 + mgu], vo_gu[2]); \
   } while (0)
 // the same bursts a third at a time (the CU's address unit takes ~25 clocks per 1 KB request: 48 requests in a row stall
 // the issuing waves for ~1.2K clocks, 16 at a time between other work do not)
-#define ISSUE_RVQ_GATE_G(Ld, i) do { ld_item_o(OFFC(0), qa[i], qb[i], Ld.W[4], vo_gu[i]); ld_item_o(OFFC(1024), qa[3 + (i)], qb[3 + (i)], Ld.W[4], vo_gu[i]); } while (0)
+#define ISSUE_RVQ_GATE_G(Ld, i) do { ld_item_o(OFFC(0), qa[i], qb[i], Ld.W[4 + mgu], vo_gu[i]); ld_item_o(OFFC(1024), qa[3 + (i)], qb[3 + (i)], Ld.W[4 + mgu], vo_gu[i]); } while (0)
 #define ISSUE_RVQ_QKV_G(Ld, i) do { ld_item_o(OFFC(0), qa[i], qb[i], Ld.W[(3 * w + (i)) >> 8], vo_q[i]); ld_item_o(OFFC(1024), qa[3 + (i)], qb[3 + (i)], Ld.W[(3 * w + (i)) >> 8], vo_q[i]); } while (0)
 #define ISSUE_RVQ_DOWN_G0(Ld) do { ld_item_o(OFFC(0), qa[0], qb[0], Ld.W[6], vo_dr[0]); ld_item_o(OFFC(1024), qa[1], qb[1], Ld.W[6], vo_dr[0]); } while (0)
 #define ISSUE_RVQ_DOWN_G1(Ld) do { ld_item_o(OFFC(2048), qa[2], qb[2], Ld.W[6], vo_dr[0]); ld_item_o(OFFC(3072), qa[3], qb[3], Ld.W[6], vo_dr[0]); } while (0)
 #define ISSUE_RVQ_DOWN_G2(Ld) do { ld_item_o(OFFC(0), qa[4], qb[4], Ld.W[6], vo_dr[1]); ld_item_o(OFFC(0), qa[5], qb[5], Ld.W[6], vo_dr[2]); } while (0)
-#define ISSUE_RVQ_UP_A_G(Ld, i) do { ld_item_o(OFFC(0), qa[6 + (i)], qb[6 + (i)], Ld.W[5], vo_gu[i]); } while (0)
-#define ISSUE_RVQ_UP_A(Ld) do { ld_item_o(OFFC(0), qa[6], qb[6], Ld.W[5], vo_gu[0]); ld_item_o(OFFC(0), qa[7], qb[7], Ld.W[5], vo_gu[1]); ld_item_o(OFFC(0), qa[8], qb[8], Ld.W[5], vo_gu[2]); } while (0)
-#define ISSUE_RVQ_UP_B(Ld) do { ld_item_o(OFFC(1024), qa[0], qb[0], Ld.W[5], vo_gu[0]); ld_item_o(OFFC(1024), qa[1], qb[1], Ld.W[5], vo_gu[1]); ld_item_o(OFFC(1024), qa[2], qb[2], Ld.W[5], vo_gu[2]); } while (0)
+#define ISSUE_RVQ_UP_A_G(Ld, i) do { ld_item_o(OFFC(kRowB), qa[6 + (i)], qb[6 + (i)], Ld.W[4 + mgu], vo_gu[i]); } while (0)
+#define ISSUE_RVQ_UP_A(Ld) do { ld_item_o(OFFC(kRowB), qa[6], qb[6], Ld.W[4 + mgu], vo_gu[0]); ld_item_o(OFFC(kRowB), qa[7], qb[7], Ld.W[4 + mgu], vo_gu[1]); ld_item_o(OFFC(kRowB), qa[8], qb[8], Ld.W[4 + mgu], vo_gu[2]); } while (0)
+#define ISSUE_RVQ_UP_B(Ld) do { ld_item_o(OFFC(kRowB + 1024), qa[0], qb[0], Ld.W[4 + mgu], vo_gu[0]); ld_item_o(OFFC(kRowB + 1024), qa[1], qb[1], Ld.W[4 + mgu], vo_gu[1]); ld_item_o(OFFC(kRowB + 1024), qa[2], qb[2], Ld.W[4 + mgu], vo_gu[2]); } while (0)
 #define ISSUE_RVQ_DOWN(Ld) do {                                                                         \
     ld_item_o(OFFC(0), qa[0], qb[0], Ld.W[6], vo_dr[0]); ld_item_o(OFFC(1024), qa[1], qb[1], Ld.W[6], vo_dr[0]); \
     ld_item_o(OFFC(2048), qa[2], qb[2], Ld.W[6], vo_dr[0]); ld_item_o(OFFC(3072), qa[3], qb[3], Ld.W[6], vo_dr[0]); \
@@ -304,8 +320,13 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(tsrc3) : "v"(reinterpret_cast<const uint2*>(a.grid2) + (wave * 32 + (lane & 31))) : "memory");
   uint32_t gen;
   esync::ld4(gen, ctl);
-  u32x4 hpiece;
-  asm_load16(hpiece, reinterpret_cast<const uint4*>(a.h_in) + tid);
+  // the residual stream lives in registers for the whole launch, in the strided layout of the 512-thread transforms: this
+  // thread's h[tid + 512 k], k < 8, as four fp16 pairs (k = 2 j | 2 j + 1)
+  uint32_t hreg[4];
+  uint32_t hraw[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    asm volatile("global_load_ushort %0, %1, off" : "=v"(hraw[k]) : "v"(reinterpret_cast<const uint16_t*>(a.h_in) + tid + 512 * k) : "memory");
   {
     const BlockLayer& L0 = a.layers[0];
     if constexpr (RVQ) ISSUE_RVQ_QKV(L0); else { ISSUE(L0, 0); ISSUE(L0, 1); ISSUE(L0, 2); }
@@ -313,13 +334,15 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   constexpr int NQ = RVQ ? 12 : 6;                   // loads of the first q, k, v items in flight across the prologue
   int* accs = reinterpret_cast<int*>(smem + B::kAcc);
   for (int i = tid; i < B::kAccRows * 4; i += kThreads) accs[i] = 0;
-  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(tsrc), "+v"(tsrc3) : "n"(2 + NQ) : "memory");
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(tsrc), "+v"(tsrc3) : "n"(9 + NQ) : "memory");
   fill_tables_from_lane<REP>(smem, tsrc, lane, wave);
   fill_t3_from_lane<REP>(smem, tsrc3, lane, wave);
-  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(gen) : "n"(1 + NQ) : "memory");
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(gen) : "n"(8 + NQ) : "memory");
   const uint32_t ebase = ((uint32_t)__builtin_amdgcn_readfirstlane((int)gen) + 1u) << 10;
-  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(hpiece) : "n"(NQ) : "memory");
-  *reinterpret_cast<u32x4*>(smem + B::kH + tid * 16) = hpiece;
+  asm volatile("s_waitcnt vmcnt(%8)" : "+v"(hraw[0]), "+v"(hraw[1]), "+v"(hraw[2]), "+v"(hraw[3]), "+v"(hraw[4]), "+v"(hraw[5]),
+               "+v"(hraw[6]), "+v"(hraw[7]) : "n"(NQ) : "memory");
+#pragma unroll
+  for (int j = 0; j < 4; ++j) hreg[j] = (hraw[2 * j] & 0xffffu) | (hraw[2 * j + 1] << 16);
   const long long pos64 = *a.pos;
   const bool pos_ok = pos64 >= 0 && pos64 < (long long)a.max_len;
   const int pos = pos_ok ? (int)pos64 : 0;
@@ -330,7 +353,6 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 
   float* red = reinterpret_cast<float*>(smem + B::kRed);
   int* shs = reinterpret_cast<int*>(smem + B::kRed + 256);
-  f16* hres = reinterpret_cast<f16*>(smem + B::kH);
 
   // ---- all-gather of one or more 4096-vectors (2048 granules each, {2 x fp16, tag}) into LDS as fp16 -------------------
   // NV vectors starting at zbufs[first]; every thread sweeps 2 NV 16-byte pieces; returns with the data in smem + kZs
@@ -375,106 +397,185 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   };
 
   // ---- output side of the producer (+ residual) and the input transforms of up to two consumers --------------------------
-  //   zvec >= 0: gather z (hand-off `tag`), then h += SV_prev (.) H z / 64                [qlinear.py:106-114 of the producer]
+  //   HAVE_Z: gather z (hand-off `tag`), then h += SV_prev (.) H z / 64                    [qlinear.py:106-114 of the producer]
   //   NC consumers i (NC = 0 | 2; `two` false: only consumer 0): planes_i = digits( sc_i * rms(h) * H (h (.) ln (.) su_i) )
-  //   [RMSNorm + qlinear.py:90-100]; planes of consumer i at area + i * 3 * 4096, block exponent in shs[i]
-  // Transforms: fht_wg512.hip.h (all 512 threads, 8 elements each: input element 8 tid + r, output element tid + 512 k).
-  // The vectors of this thread's elements are requested before the gather waits; after_gather() runs right after it.
+  //   [RMSNorm + qlinear.py:90-100]; planes of consumer i at area + i * 3 * KV, block exponent in shs[i]
+  // Round 5: the edge in the shape of the 8192-wide launch (decode_block_gqa.hip, fht_wg512x.hip.h) --
+  //   gather (natural order) -> fwd -> strided layout: residual (registers), sum of squares, ln, SU -> rev -> natural order:
+  //   digit planes as 8 / 16-byte pieces.  No layout change through LDS between the two transforms, the residual stream never
+  //   leaves its registers, and the three reductions of the old edge (sum of squares, two maxima: three barrier pairs) ride
+  //   on rev's own barriers: the block exponent comes from the NORM bound |H x|_inf <= sqrt(4096) |x|_2 (hadamard.hip's
+  //   bound for the same planes; up to 4 of the 22 bits of X idle, 2^-18 of the maximum per digit: far below the fp16 output)
+  //   whose sum is known BEFORE the transform.  10 barriers -> 6; 10.6K -> ~6K clocks per edge (profiles/r05_block_stamps.txt).
+  // sv_prev, ln, su0, su1: vectors PERMUTED by the host to the strided layout, p[8 t + k] = v[t + 512 k].
+  // `rev` adds in another order than the stand-alone kernels: the launch is no longer bit identical to the stage-wise step
+  // (tests/test_gpu_block_engine.py states the bound, tests/test_gpu_decode.py the distance to the float64 model).
   float* xbuf = reinterpret_cast<float*>(smem + B::kBuf0);
-  auto edge = [&](auto nc_tag, auto slots, int zvec, uint32_t tag, uint32_t code, const f16* sv_prev, const f16* ln, const f16* su0,
-                  const f16* su1, float sc0, float sc1, bool two, auto after_gather, auto drip1, auto drip2, int sb = -1) {
-#define ESTAMP(i) do { if (sb >= 0) BSTAMP(sb + (i)); } while (0)
-    constexpr int NC = decltype(nc_tag)::value;
-    const bool have_z = zvec >= 0;
-    uint32_t psv[8];     // fp16 bits
-    u32x4 pln, psu0, psu1;
-    if (have_z) {
+  auto planes_nat = [&](const float (&v)[8], float scale, int sh, uint32_t base) {
+#pragma clang fp contract(off)
+    const float p2 = as_f32((uint32_t)(sh + 127) << 23);
+    const float s2 = had::fmul(scale, p2);
+    int X[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) psv[k] = reinterpret_cast<const uint16_t*>(sv_prev)[tid + 512 * k];
+    for (int r = 0; r < 8; ++r) X[r] = (int)__builtin_rintf(v[r] * s2);
+    const int Xa[4] = {X[0], X[1], X[2], X[3]}, Xb[4] = {X[4], X[5], X[6], X[7]};
+    if constexpr (HI) {
+      // [x0 x2 0 0 | x4 x6 0 0 | x1 x3 0 0 | x5 x7 0 0] (planes_scatter_hi's positions), plane stride 2 * 4096
+      const int E0[4] = {X[0], X[2], 0, 0}, E1[4] = {X[4], X[6], 0, 0}, E2[4] = {X[1], X[3], 0, 0}, E3[4] = {X[5], X[7], 0, 0};
+      uint32_t dg[3][4];
+      hadw::digit_words(E0, dg[0][0], dg[1][0], dg[2][0]);
+      hadw::digit_words(E1, dg[0][1], dg[1][1], dg[2][1]);
+      hadw::digit_words(E2, dg[0][2], dg[1][2], dg[2][2]);
+      hadw::digit_words(E3, dg[0][3], dg[1][3], dg[2][3]);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        // (the zero digits: byte 1 of 0x80 and byte 2 of 0x8080 are 0 -- nothing to mask)
+        *reinterpret_cast<uint4*>(smem + base + d * 2 * HID + 16 * tid) = make_uint4(dg[d][0], dg[d][1], dg[d][2], dg[d][3]);
+      }
+    } else if constexpr (RVQ) {
+      // x' = [s x_g | x_g]: the 8-group's residual-side digits, then its main-side digits (planes_scatter_rvq's positions)
+      const float s2r = had::fmul(had::fmul(scale, a.resid_scale), p2);
+      int Y[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) Y[r] = (int)__builtin_rintf(v[r] * s2r);
+      const int Ya[4] = {Y[0], Y[1], Y[2], Y[3]}, Yb[4] = {Y[4], Y[5], Y[6], Y[7]};
+      uint32_t dg[3][4];
+      hadw::digit_words(Ya, dg[0][0], dg[1][0], dg[2][0]);
+      hadw::digit_words(Yb, dg[0][1], dg[1][1], dg[2][1]);
+      hadw::digit_words(Xa, dg[0][2], dg[1][2], dg[2][2]);
+      hadw::digit_words(Xb, dg[0][3], dg[1][3], dg[2][3]);
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        *reinterpret_cast<uint4*>(smem + base + d * 2 * HID + 16 * tid) = make_uint4(dg[d][0], dg[d][1], dg[d][2], dg[d][3]);
+    } else {
+      uint32_t dg[3][2];
+      hadw::digit_words(Xa, dg[0][0], dg[1][0], dg[2][0]);
+      hadw::digit_words(Xb, dg[0][1], dg[1][1], dg[2][1]);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) *reinterpret_cast<uint2*>(smem + base + d * HID + 8 * tid) = make_uint2(dg[d][0], dg[d][1]);
     }
-    if (NC > 0) {
+  };
+  // block exponent of planes made of H x * scale, from the sum of squares of x (4096 values): |H x|_inf <= 64 |x|_2
+  auto norm_shift = [&](float sumsq_x, float scale) -> int {
+    const float bound = sqrtf(sumsq_x) * 64.f * fabsf(scale) * 1.0625f;
+    return had::shift_for(bound * ((RVQ && !HI) ? fmaxf(1.f, fabsf(a.resid_scale)) : 1.f));
+  };
+  auto red_sum8 = [&](int at) -> float {               // the eight waves' partial sums in order
+    float r = red[at];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) r = had::fadd(r, red[at + i]);
+    return r;
+  };
+  auto edge = [&](auto z_tag, auto nc_tag, auto slots, int zvec, uint32_t tag, uint32_t code, const f16* sv_prev, const f16* ln,
+                  const f16* su0, const f16* su1, float sc0, float sc1, bool two, auto after_gather, auto drip1, auto drip2, int sb = -1) {
+    // stamps of the edge's stages: 18..22 (sb = 18: the gate / up edge) or 23, 24, 28, 29, 30 (sb = 23: the q / k / v edge)
+#define ESTAMP(i) do { if (sb >= 0) BSTAMP(sb + (i) + ((sb == 23 && (i) >= 2) ? 3 : 0)); } while (0)
+    constexpr int NC = decltype(nc_tag)::value;
+    constexpr bool HAVE_Z = decltype(z_tag)::value;
+    u32x4 psv, pln, psu0, psu1;
+    if constexpr (HAVE_Z) psv = *reinterpret_cast<const u32x4*>(sv_prev + 8 * tid);
+    if constexpr (NC > 0) {
       pln = *reinterpret_cast<const u32x4*>(ln + 8 * tid);
       psu0 = *reinterpret_cast<const u32x4*>(su0 + 8 * tid);
       psu1 = *reinterpret_cast<const u32x4*>(su1 + 8 * tid);
     }
     auto u4 = [](const u32x4& v) { return make_uint4(v.x, v.y, v.z, v.w); };
-    if (have_z) {
+    if constexpr (HAVE_Z) {
       float v[1][8];
       gather(std::integral_constant<int, 1>{}, slots, zvec, tag, code, v);
       // The vectors have landed (the gather drained the queue).  Take them over HERE: the compiler counts only its own
       // loads, so the wait it would place at their first use would also wait for the burst requested below.
-#pragma unroll
-      for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(psv[k]));
-      if (NC > 0) asm volatile("" : "+v"(pln), "+v"(psu0), "+v"(psu1));
+      asm volatile("" : "+v"(psv));
+      if constexpr (NC > 0) asm volatile("" : "+v"(pln), "+v"(psu0), "+v"(psu1));
       after_gather();
       ESTAMP(0);
-      had8::fht4096<1, true>(v, xbuf, tid);
+      hadw::fwd<12, 1, true>(v, xbuf, tid);
       ESTAMP(1);
+      float svf[8];
+      had::unpack8(u4(psv), svf);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int idx = tid + 512 * k;
-        hres[idx] = had::out_elem(v[0][k], 1.f / 64.f, true, (float)__builtin_bit_cast(f16, (uint16_t)psv[k]), false, 0.f, true, (float)hres[idx]);
+      for (int j = 0; j < 4; ++j) {
+        const f16x2 hh = as_f16x2(hreg[j]);
+        const f16 n0 = had::out_elem(v[0][2 * j], 1.f / 64.f, true, svf[2 * j], false, 0.f, true, (float)hh.x);
+        const f16 n1 = had::out_elem(v[0][2 * j + 1], 1.f / 64.f, true, svf[2 * j + 1], false, 0.f, true, (float)hh.y);
+        hreg[j] = (uint32_t)__builtin_bit_cast(uint16_t, n0) | ((uint32_t)__builtin_bit_cast(uint16_t, n1) << 16);
       }
-      had::wg_barrier<true>();
-      ESTAMP(2);
       drip1();
     }
     if constexpr (NC > 0) {
       float e[8];
-      had::unpack8(*reinterpret_cast<const uint4*>(hres + 8 * tid), e);
-      const float tot = had8::sumsq4096<true>(e, red, tid);
-      ESTAMP(3);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f16x2 hh = as_f16x2(hreg[j]);
+        e[2 * j] = (float)hh.x;
+        e[2 * j + 1] = (float)hh.y;
+      }
+      // the sum of squares of h (the RMSNorm statistic) and of each consumer's input (its planes' bound): per-wave partial
+      // sums into LDS HERE, totals read behind rev's barriers -- no barrier of their own
+      float ssw = 0.f;
+      {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ssw = __builtin_fmaf(e[r], e[r], ssw);
+      }
       had::mul8(e, u4(pln));
-      float mx0, mx1 = 0.f;
+      const int lane_ = tid & 63;
       if (two) {
         float v[2][8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[0][r] = v[1][r] = e[r];
         had::mul8(v[0], u4(psu0));
         had::mul8(v[1], u4(psu1));
-        had8::fht4096<2, true>(v, xbuf, tid);
-        ESTAMP(4);
-        drip2();
-        mx0 = had::wave_reduce_to_lane63<true>(had8::absmax8(v[0], 1.f));
-        mx1 = had::wave_reduce_to_lane63<true>(had8::absmax8(v[1], 1.f));
-        had::wg_barrier<true>();
-        if (lane == 63) { red[wave] = mx0; red[8 + wave] = mx1; }
-        had::wg_barrier<true>();
-        mx0 = red[0]; mx1 = red[8];
+        float n0 = 0.f, n1 = 0.f;
+        {
+#pragma clang fp contract(off)
 #pragma unroll
-        for (int i = 1; i < 8; ++i) { mx0 = fmaxf(mx0, red[i]); mx1 = fmaxf(mx1, red[8 + i]); }
-        const float s0 = had::rms_scale(sc0, tot, HID, a.rms_eps), s1 = had::rms_scale(sc1, tot, HID, a.rms_eps);
-        const float rvf = (RVQ && !HI) ? fmaxf(1.f, fabsf(a.resid_scale)) : 1.f;       // (hadamard.hip: bound * max(1, |rs|))
-        const int sh0 = had::shift_for(had::fmul(mx0, fabsf(s0)) * rvf), sh1 = had::shift_for(had::fmul(mx1, fabsf(s1)) * rvf);
-        ESTAMP(5);
-        if constexpr (HI) {
-          had8::planes_scatter_hi(v[0], s0, sh0, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
-          had8::planes_scatter_hi(v[1], s1, sh1, reinterpret_cast<uint8_t*>(smem + B::kArea + 3 * KV), tid);
-        } else if constexpr (RVQ) {
-          had8::planes_scatter_rvq(v[0], s0, a.resid_scale, sh0, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
-          had8::planes_scatter_rvq(v[1], s1, a.resid_scale, sh1, reinterpret_cast<uint8_t*>(smem + B::kArea + 3 * KV), tid);
-        } else {
-          had8::planes_scatter(v[0], s0, sh0, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
-          had8::planes_scatter(v[1], s1, sh1, reinterpret_cast<uint8_t*>(smem + B::kArea + 3 * HID), tid);
+          for (int r = 0; r < 8; ++r) { n0 = __builtin_fmaf(v[0][r], v[0][r], n0); n1 = __builtin_fmaf(v[1][r], v[1][r], n1); }
         }
+        ssw = had::wave_reduce_to_lane63<false>(ssw);
+        n0 = had::wave_reduce_to_lane63<false>(n0);
+        n1 = had::wave_reduce_to_lane63<false>(n1);
+        if (lane_ == 63) { red[wave] = ssw; red[8 + wave] = n0; red[16 + wave] = n1; }
+        ESTAMP(2);
+        hadw::rev<12, 2, true, true>(v, xbuf, tid);
+        ESTAMP(3);
+        drip2();
+        const float tot = red_sum8(0);
+        const float s0 = had::rms_scale(sc0, tot, HID, a.rms_eps), s1 = had::rms_scale(sc1, tot, HID, a.rms_eps);
+        const int sh0 = norm_shift(red_sum8(8), s0), sh1 = norm_shift(red_sum8(16), s1);
+        planes_nat(v[0], s0, sh0, (uint32_t)B::kArea);
+        planes_nat(v[1], s1, sh1, (uint32_t)(B::kArea + 3 * KV));
         if (tid == 0) { shs[0] = sh0; shs[1] = sh1; }
       } else {
         float v[1][8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[0][r] = e[r];
         had::mul8(v[0], u4(psu0));
-        had8::fht4096<1, true>(v, xbuf, tid);
-        mx0 = had8::max4096<true>(had8::absmax8(v[0], 1.f), red, tid);
+        float n0 = 0.f;
+        {
+#pragma clang fp contract(off)
+#pragma unroll
+          for (int r = 0; r < 8; ++r) n0 = __builtin_fmaf(v[0][r], v[0][r], n0);
+        }
+        ssw = had::wave_reduce_to_lane63<false>(ssw);
+        n0 = had::wave_reduce_to_lane63<false>(n0);
+        if (lane_ == 63) { red[wave] = ssw; red[8 + wave] = n0; }
+        ESTAMP(2);
+        hadw::rev<12, 1, true, true>(v, xbuf, tid);
+        ESTAMP(3);
+        drip2();
+        const float tot = red_sum8(0);
         const float s0 = had::rms_scale(sc0, tot, HID, a.rms_eps);
-        const int sh0 = had::shift_for(had::fmul(mx0, fabsf(s0)) * ((RVQ && !HI) ? fmaxf(1.f, fabsf(a.resid_scale)) : 1.f));
-        if constexpr (HI) had8::planes_scatter_hi(v[0], s0, sh0, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
-        else if constexpr (RVQ) had8::planes_scatter_rvq(v[0], s0, a.resid_scale, sh0, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
-        else had8::planes_scatter(v[0], s0, sh0, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
+        const int sh0 = norm_shift(red_sum8(8), s0);
+        planes_nat(v[0], s0, sh0, (uint32_t)B::kArea);
         if (tid == 0) shs[0] = sh0;
       }
       had::wg_barrier<true>();
-      ESTAMP(6);
+      ESTAMP(4);
     }
+    // (opaque from here on: otherwise the fp32 images of h made above stay alive until the next edge's update)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(hreg[j]));
 #undef ESTAMP
   };
 
@@ -511,6 +612,30 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       }
     }
   };
+  // three items of one K slice whose first NPRE were decoded earlier (pre: their eight B fragments each)
+  constexpr int NPRE = QUIP_PREDECODE_GATE > 0 ? QUIP_PREDECODE_GATE : 1;
+  auto run_items3_pre = [&](const i32x4 (&pre)[NPRE][8], int s0, uint32_t xa, int accrow0) {
+    i32x4 A[8];
+    item_fragments(xa, A);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      i32x4 r = {0, 0, 0, 0};
+      if (i < NPRE) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) r = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t], pre[i < NPRE ? i : 0][t], r, 0, 0, 0);
+      } else {
+        ItemAddr ad;
+        item_addresses<REP>(qa[s0 + i], qb[s0 + i], lane_c, lane_c2, ad, lane_c3);
+        r = item_mfma_shared<T::kD4, R3>(ad, A);
+      }
+      if (q == 0) {
+        int* dst = accs + (accrow0 + 16 * i + n) * 4;
+        __hip_atomic_fetch_add(dst + 0, r.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(dst + 1, r.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(dst + 2, r.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  };
   // the same item in two halves: the table lookups while a hand-off is awaited (the codes are there long before the digits),
   // the eight MFMAs once the digit planes exist
   auto decode_item = [&](int s, i32x4 (&Bf)[8]) {
@@ -531,17 +656,14 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   const BlockLayer& Ld = *reinterpret_cast<const BlockLayer*>(smem + B::kDesc);
   if (tid < 64) reinterpret_cast<uint32_t*>(smem + B::kDesc)[tid] = reinterpret_cast<const uint32_t*>(a.layers)[tid];
   had::wg_barrier<true>();
-  // ================= P1: input transforms of q, k, v of the block whose descriptor is in LDS; their products; hand-off ========
+  // ================= P1: [output side of the previous block's down_proj + residual,] RMSNorm, input transforms of q, k, v of
+  // the block whose descriptor is in LDS; their products; hand-off ========================================================
   // (called for block 0 here and, for block l + 1, at the bottom of iteration l: the requests of q, k, v go out BEHIND the
   //  hand-off of z_d and are consumed before the loop's back edge, where no request may be in flight -- the compiler is free to
   //  copy registers there)
-  auto P1 = [&]() {
-    rederive();
-    const int c_lo = (3 * w) >> 8, c_hi = (3 * w + 2) >> 8;         // the one or two matrices this workgroup's row blocks are in
-    edge(std::integral_constant<int, 2>{}, SLOTS(M_QKV), -1, 0u, 0u, nullptr, Ld.ln[0], Ld.su[c_lo], Ld.su[c_hi], Ld.sc[c_lo], Ld.sc[c_hi],
-         c_hi != c_lo, [&]() {}, [&]() {}, [&]() {});
-    BSTAMP(2);
-    esync::drain();                                    // q, k, v have landed (requested one transform stage ago)
+  auto P1_products = [&]() {
+    const int c_lo = (3 * w) >> 8;                   // the first of the one or two matrices this workgroup's row blocks are in
+    esync::drain();                                    // q, k, v have landed (requested behind the z_d hand-off)
     own_slots(SLOTS(M_QKV));
     {
       const uint32_t x0 = xlane + (uint32_t)((((3 * w) >> 8) == c_lo ? 0 : 1) * 3 * KV);
@@ -561,7 +683,13 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     zero_acc(0, 48);
     BSTAMP(3);
   };
-  P1();
+  {
+    rederive();
+    const int c_lo = (3 * w) >> 8, c_hi = (3 * w + 2) >> 8;
+    edge(std::false_type{}, std::integral_constant<int, 2>{}, SLOTS(M_QKV), -1, 0u, 0u, nullptr, Ld.ln[0], Ld.su[c_lo], Ld.su[c_hi],
+         Ld.sc[c_lo], Ld.sc[c_hi], c_hi != c_lo, [&]() {}, [&]() {}, [&]() {});
+    P1_products();
+  }
   for (int l = 0; l < a.n_layers; ++l) {
     dbg_on = a.dbg != nullptr && l == a.dbg_layer;
     rederive();
@@ -582,26 +710,15 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     const int part = w & 7, nparts = split ? kParts : 1;
     const bool head_wg = part == 0;
     const int hd = w >> 3;
-    // short contexts: the head's first workgroup transforms q only and starts on the cached rows; its second / third one
-    // transform k / v, write the new cache row and hand the head's 128 values over (one 4096-point transform each instead
-    // of three in a row on the critical path; the new position is the last one of its key group either way)
-    constexpr bool kOffload = !RVQ || HI || R3;        // (E8P12RVQ4B: the extra addresses do not fit its registers; RVQ3B's 12-byte slots leave room)
-    const bool kv_wg = kOffload && !split && (part == 1 || part == 2);
-    const bool all3 = split || !kOffload;              // this workgroup transforms q, k and v itself
-    if (head_wg || split || kv_wg) {
-      // vectors first, then the gather.  After the transforms thread t holds elements t + 512 k: this head's 128 values
-      // of q, k, v are register hd >> 2 of the threads [128 (hd & 3), +128)
-      const int kreg = hd >> 2, tloc = tid - 128 * (hd & 3);
-      const bool mine = tloc >= 0 && tloc < HD;
-      f16 psv[3];
+    if (head_wg || split) {
       float c8[8], s8[8];
       const int d0 = (tid & 15) * 8;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) psv[c] = Ld.sv[c][mine ? HD * hd + tloc : 0];
       // the cached rows of this head depend on nothing: the first two rounds (2 x 64 positions) are requested HERE / right after the gather and land
       // while the hand-off is awaited / under the transforms (they come from HBM -- a token's weight stream has flushed every cache since they were
       // written: 2 us per dependent round otherwise); later rounds are requested two rounds ahead of their use
-      constexpr int LPK = HD / 8, NG = 256 / LPK, U = 4;
+      // (U: cached rows per key group and round; E8P12RVQ4B, at 256 registers, prefetches half as many -- the keys are
+      //  visited in the same order either way)
+      constexpr int LPK = HD / 8, NG = 256 / LPK, U = (RVQ && !HI && !R3) ? 2 : 4;
       const int g = (tid & 255) / LPK;
       const f16* kc = Ld.kcache + (size_t)hd * a.max_len * HD;
       const f16* vc = Ld.vcache + (size_t)hd * a.max_len * HD;
@@ -616,42 +733,71 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           vr[u] = *reinterpret_cast<const uint4*>(vc + (size_t)tc * HD + d0);
         }
       };
-      if (tid < 256 && !kv_wg) {
+      if (tid < 256) {
         load_round(kr0, vr0, g);
         if (part + nparts * NG * U < pos) load_round(kr1, vr1, g + NG * U);
       }
       f16* s_qkv = reinterpret_cast<f16*>(smem + B::kQkv);
-      if (all3) {
+      {
+        // Round 5: only this head's 128 values of H_4096 z are needed, for z = z_q, z_k, z_v.  H_4096 = H_32 (x) H_128 with the
+        // index split 128 j1 + j2, so they are H_128 u with u[j2] = sum_j1 H_32[hd][j1] z[128 j1 + j2]: signed sums of the 32
+        // segments, then a 128-point transform in ONE wave per vector -- instead of a 4096-point transform of q here and of k, v
+        // on two more workgroups with one more hand-off inside the head's group (rounds 3-4: 1.8K clocks + that hop).
+        // Thread t holds z[8 t + r]: j1 = t >> 4 = (lane >> 4) + 4 wave, j2 = 8 (t & 15) + r.
         float v[3][8];
         gather(std::integral_constant<int, 3>{}, SLOTS(M_O), 0, ebase | hop, 0x5000u, v);
         BSTAMP(4);
-        had8::fht4096<3, true>(v, xbuf, tid);
+        // H_32[hd][j1] = (-1)^popcount(hd & j1): lane bit 5 <-> hd bit 1, lane bit 4 <-> hd bit 0 (folded into the two swap
+        // steps), the wave <-> hd bits 2..4 (folded into the sum over the waves' partial results)
+        const float sg1 = (hd & 2) ? -1.f : 1.f, sg0 = (hd & 1) ? -1.f : 1.f;
+        float P[12], Q[6];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          float val = v[c][0];
-#pragma unroll
-          for (int k = 1; k < 8; ++k) val = kreg == k ? v[c][k] : val;
-          if (mine) s_qkv[c * HD + tloc] = had::out_elem(val, 1.f / 64.f, true, (float)psv[c], false, 0.f, false, 0.f);
+        for (int pi = 0; pi < 12; ++pi) {
+          // lanes l and l ^ 32 of the values 2 pi and 2 pi + 1: lower half <- value 2 pi, upper half <- value 2 pi + 1
+          const int va = 2 * pi, vb = 2 * pi + 1;
+          const auto t = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v[va >> 3][va & 7]),
+                                                         __builtin_bit_cast(unsigned, v[vb >> 3][vb & 7]), false, false);
+          P[pi] = __builtin_fmaf(__builtin_bit_cast(float, (unsigned)t[1]), sg1, __builtin_bit_cast(float, (unsigned)t[0]));
         }
-      } else {
-        float v[1][8];                                 // workgroup `part` of the head: vector q / k / v
-        gather(std::integral_constant<int, 1>{}, SLOTS(M_O), part, ebase | hop, 0x5000u, v);
-        BSTAMP(4);
-        had8::fht4096<1, true>(v, xbuf, tid);
-        float val = v[0][0];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) val = kreg == k ? v[0][k] : val;
-        const f16 svp = part == 0 ? psv[0] : (part == 1 ? psv[1] : psv[2]);
-        if (mine) s_qkv[part * HD + tloc] = had::out_elem(val, 1.f / 64.f, true, (float)svp, false, 0.f, false, 0.f);
+        for (int si = 0; si < 6; ++si) {
+          // rows (16 lanes) r and r ^ 1: row 0 <- value 4 si, row 1 <- value 4 si + 2, row 2 <- 4 si + 1, row 3 <- 4 si + 3
+          const auto t = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, P[2 * si]), __builtin_bit_cast(unsigned, P[2 * si + 1]), false, false);
+          Q[si] = __builtin_fmaf(__builtin_bit_cast(float, (unsigned)t[1]), sg0, __builtin_bit_cast(float, (unsigned)t[0]));
+        }
+        // this wave's partial sums: [vector][wave][128]
+        {
+          const int row = lane >> 4, cc = lane & 15;
+          const int vsel = ((row & 1) << 1) | (row >> 1);                  // {0, 2, 1, 3}[row]
+#pragma unroll
+          for (int si = 0; si < 6; ++si) {
+            const int vi = 4 * si + vsel;                                   // value index: vector vi >> 3, register vi & 7
+            xbuf[((vi >> 3) * 8 + wave) * HD + 8 * cc + (vi & 7)] = Q[si];
+          }
+        }
+        had::wg_barrier<true>();
+        if (wave < 3) {
+          float y[2] = {0.f, 0.f};
+#pragma unroll
+          for (int gg = 0; gg < 8; ++gg) {
+            const float sw = (__builtin_popcount((uint32_t)(hd >> 2) & (uint32_t)gg) & 1) ? -1.f : 1.f;
+            const float2 pr = *reinterpret_cast<const float2*>(xbuf + (wave * 8 + gg) * HD + 2 * lane);
+            y[0] = __builtin_fmaf(pr.x, sw, y[0]);
+            y[1] = __builtin_fmaf(pr.y, sw, y[1]);
+          }
+          hadw::reg_stage<2, 1>(y);
+          hadw::lane_stages<2, 0, 6>(y, lane);
+          const f16x2 svp = as_f16x2(*reinterpret_cast<const uint32_t*>(Ld.sv[wave] + HD * hd + 2 * lane));
+          s_qkv[wave * HD + 2 * lane] = had::out_elem(y[0], 1.f / 64.f, true, (float)svp.x, false, 0.f, false, 0.f);
+          s_qkv[wave * HD + 2 * lane + 1] = had::out_elem(y[1], 1.f / 64.f, true, (float)svp.y, false, 0.f, false, 0.f);
+        }
       }
-      // (both branches have drained the queue in their gather; said once more for tools/check_inflight.py, which follows the
-      //  control flow graph without knowing that the two conditional regions the compiler makes of this if / else are
-      //  complementary)
+      // (the gather has drained the queue; said once more for tools/check_inflight.py)
       esync::drain();
       own_slots(SLOTS(M_O));
       had::wg_barrier<true>();
       BSTAMP(5);
-      ++hop;                                           // hand-off inside the head's group: k / v of the new position | partial states
+      ++hop;                                           // hand-off inside the head's group (long contexts): partial states
       const uint32_t tagg = ebase | hop;
       auto unpack8h = [](const uint4& u, float o[8]) {
         const uint32_t ww[4] = {u.x, u.y, u.z, u.w};
@@ -676,23 +822,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) { c8[i] = cs[d0 + i]; s8[i] = cs[HD + d0 + i]; }
       }
-      if (kv_wg && tid < LPK) {
-        // this head's k (rotated) or v of the new position: the cache row (StaticCache.update) and 64 granules for the head
-        uint4 row;
-        if (part == 1) {
-          float kn[8];
-          rope8(s_qkv + HD, kn);
-          row.x = pack_f16(kn[0], kn[1]); row.y = pack_f16(kn[2], kn[3]);
-          row.z = pack_f16(kn[4], kn[5]); row.w = pack_f16(kn[6], kn[7]);
-        } else {
-          row = *reinterpret_cast<const uint4*>(s_qkv + 2 * HD + d0);
-        }
-        if (pos_ok) *const_cast<uint4*>(reinterpret_cast<const uint4*>((part == 1 ? kc : vc) + (size_t)pos * HD + d0)) = row;
-        uint64_t* dst = kvnew + (size_t)hd * HD + (part == 1 ? 0 : HD / 2) + 4 * tid;
-        esync::st_granule2(dst, row.x, row.y, tagg);
-        esync::st_granule2(dst + 2, row.z, row.w, tagg);
-      }
-      if (!kv_wg) {
+      {
       // single-query attention of head hd over positions [0, pos] (decode_glue.hip's arithmetic): 16 lanes per key,
       // 16 key groups with their own online-softmax state, merged through LDS
       float* s_m = reinterpret_cast<float*>(smem + B::kArea);
@@ -724,7 +854,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         rope8(s_qkv, q8);
 #pragma unroll
         for (int i = 0; i < 8; ++i) q8[i] *= a.attn_scale;
-        if (all3) {
+        {
           rope8(s_qkv + HD, kn);
           const uint4 vraw = *reinterpret_cast<const uint4*>(s_qkv + 2 * HD + d0);
           unpack8h(vraw, vn);
@@ -736,8 +866,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
             *const_cast<uint4*>(reinterpret_cast<const uint4*>(vc + (size_t)pos * HD + d0)) = vraw;
           }
         }
-        // (short contexts: the cached positions here, the new one -- the last of its key group -- after the hand-off below)
-        const int t_hi = all3 ? pos + 1 : pos;
+        const int t_hi = pos + 1;
         // one round: positions t0 + u NG of this key group, rows in (kr, vr)
         auto round = [&](const uint4 (&kr)[U], const uint4 (&vr)[U], int i0) {
           float k8[U][8], v8[U][8], sc[U];
@@ -765,27 +894,6 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
             round(kr1, vr1, ib + g + NG * U);
             if (ib + 3 * NG * U < n_loc) load_round(kr1, vr1, ib + g + 3 * NG * U);
           }
-        }
-      }
-      if (!all3) {
-        // k / v of the new position from the head's second / third workgroup: 128 granules = 64 16-byte pieces
-        if (tid < 64) {
-          u32x4_t kv;
-          uint32_t spins = 0;
-          for (;;) {
-            esync::ld16(kv, kvnew + (size_t)hd * HD + 2 * tid);
-            esync::drain();
-            esync::own(kv);
-            if (esync::spin_step(kv.y == tagg && kv.w == tagg, spins, ctl + 1, 0x9000u + (uint32_t)w)) break;
-          }
-          *reinterpret_cast<uint2*>(s_qkv + HD + 4 * tid) = make_uint2(kv.x, kv.z);      // k [0, 128) | v [128, 256)
-        }
-        own_slots(SLOTS(M_O));
-        had::wg_barrier<true>();
-        if (tid < 256 && g == (pos & (NG - 1))) {
-          unpack8h(*reinterpret_cast<const uint4*>(s_qkv + HD + d0), kn);          // (already rotated and rounded)
-          unpack8h(*reinterpret_cast<const uint4*>(s_qkv + 2 * HD + d0), vn);
-          update(score(kn), vn);
         }
       }
       if (tid < 256) {
@@ -861,7 +969,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         const uint32_t pr = *reinterpret_cast<const uint32_t*>(s_a + 2 * tid);
         esync::st_granule(zbufs + (size_t)3 * 2048 + hd * 64 + tid, pr, ebase | (hop + 1u));
       }
-      }  // !kv_wg
+      }
       ++hop;                                           // hand-off: attention output
     } else {
       hop += 2;                                        // (short context: five workgroups of a head wait for the result)
@@ -876,7 +984,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       own_slots(SLOTS(M_O));
       if constexpr (!RVQ) decode_item(3, Bo);
       // o_proj's input side: x = H (a (.) SU_o) * sc  (no norm), every workgroup
-      const u32x4 psu = *reinterpret_cast<const u32x4*>(Ld.su[3] + 8 * tid);
+      u32x4 psu = *reinterpret_cast<const u32x4*>(Ld.su[3] + 8 * tid);
       float v[1][8];
       {
         // the attention output is ~8 us away for the workgroups that do not compute it: they wait for it on ONE granule (of a
@@ -892,10 +1000,14 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         }
       }
       gather(std::integral_constant<int, 1>{}, SLOTS(RVQ ? M_O : 0u), 3, ebase | hop, 0x6000u, v);
+      // (SU_o has landed -- the gather drained the queue: taken over HERE, or the compiler's wait for it, placed at its first
+      //  use, also waits for the request just below: a memory latency on the critical path)
+      asm volatile("" : "+v"(psu));
       // gate's row blocks (the slots of q, k, v: consumed) once the hand-off is through, one at a time between the stages
       // of o's input side: they have o's product, a hand-off and an edge to land
       if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 0); else ISSUE(Ld, 4);
       BSTAMP(7);
+#if QUIP_INO_EXACT      /* A/B (tools/dbg): rounds 3-4's o input side -- the exact maximum behind the transform */
       had::mul8(v[0], make_uint4(psu.x, psu.y, psu.z, psu.w));
       had8::fht4096<1, true>(v, xbuf, tid);
       if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 1); else ISSUE(Ld, 5);
@@ -903,6 +1015,25 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       const float mx = had8::max4096<true>(had8::absmax8(v[0], sco), red, tid);
       if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 2); else ISSUE(Ld, 6);
       const int sh = had::shift_for(mx * ((RVQ && !HI) ? fmaxf(1.f, fabsf(a.resid_scale)) : 1.f));
+#else
+      had::mul8(v[0], make_uint4(psu.x, psu.y, psu.z, psu.w));
+      {
+        // the planes' block exponent from the norm bound (see edge()): the sum of squares of the transform's INPUT, per-wave
+        // partial sums into LDS here, read behind the transform's barriers
+#pragma clang fp contract(off)
+        float n0 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) n0 = __builtin_fmaf(v[0][r], v[0][r], n0);
+        n0 = had::wave_reduce_to_lane63<false>(n0);
+        if ((tid & 63) == 63) red[wave] = n0;
+      }
+      had8::fht4096<1, true>(v, xbuf, tid);
+      if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 1); else ISSUE(Ld, 5);
+      const float sco = Ld.sc[3];
+      had::wg_barrier<true>();                         // the transform's last reads of the exchange buffer: the planes land on it
+      const int sh = norm_shift(red_sum8(0), sco);
+      if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 2); else ISSUE(Ld, 6);
+#endif
       if constexpr (HI) had8::planes_scatter_hi(v[0], sco, sh, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
       else if constexpr (RVQ) had8::planes_scatter_rvq(v[0], sco, a.resid_scale, sh, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
       else had8::planes_scatter(v[0], sco, sh, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
@@ -925,7 +1056,18 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 
     // ================= P3: o's output side + residual, RMSNorm, input transforms of gate / up; their products =========
     rederive();
-    edge(std::integral_constant<int, 2>{}, SLOTS(M_GATE), 4, ebase | hop, 0x7000u, Ld.sv[3], Ld.ln[1], Ld.su[4], Ld.su[5], Ld.sc[4], Ld.sc[5], true,
+#if QUIP_PREDECODE_GATE
+    // the first gate / up item's table look-ups inside the wait for z_o (its codes were requested under o's input side)
+    i32x4 Bg[QUIP_PREDECODE_GATE][8];
+    if constexpr (!RVQ) {
+      esync::drain();
+      own_slots(SLOTS(M_GATE));
+#pragma unroll
+      for (int i = 0; i < QUIP_PREDECODE_GATE; ++i) decode_item(i, Bg[i]);
+    }
+#endif
+    // (ONE consumer per workgroup: its half of the machine multiplies gate, the other half up)
+    edge(std::true_type{}, std::integral_constant<int, 2>{}, SLOTS(M_GATE), 4, ebase | hop, 0x7000u, Ld.sv[3], Ld.ln[1], Ld.su[4 + mgu], Ld.su[4 + mgu], Ld.sc[4 + mgu], Ld.sc[4 + mgu], false,
          // up's row blocks (RVQ: their first virtual slice) behind the hand-off, one at a time between the edge's stages
          [&]() { BSTAMP(10); if constexpr (RVQ) ISSUE_RVQ_UP_A_G(Ld, 0); else ISSUE(Ld, 7); },
          [&]() { if constexpr (RVQ) ISSUE_RVQ_UP_A_G(Ld, 1); else ISSUE(Ld, 8); },
@@ -951,8 +1093,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     own_slots(SLOTS(M_GATE | M_UP));
     static_assert(FRB == 3, "three row blocks per matrix");
     if constexpr (RVQ) {
-      const uint32_t xu = xlane + (uint32_t)(3 * KV);
-      run_items3(0, xlane, xlane, xlane, 64);                                     // gate, slice wave
+      const uint32_t xu = xlane;                                                  // (the second column: the same planes)
+      run_items3(0, xlane, xlane, xlane, 64);                                     // first column, slice wave
       ISSUE_RVQ_UP_B(Ld);                                                           // up's second half into the slots just freed:
       run_items3(3, xlane + 4096u, xlane + 4096u, xlane + 4096u, 64);             // six items of time to land
       run_items3(6, xu, xu, xu, 64 + 16 * FRB);                                     // up, slice wave
@@ -960,8 +1102,17 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       own_slots(SLOTS(0x007u));
       run_items3(0, xu + 4096u, xu + 4096u, xu + 4096u, 64 + 16 * FRB);           // up, slice wave + 8
     } else {
-      run_items3(0, xlane, xlane, xlane, 64);
-      run_items3(FRB, xlane + (uint32_t)(3 * HID), xlane + (uint32_t)(3 * HID), xlane + (uint32_t)(3 * HID), 64 + 16 * FRB);
+      // down's items: its slots have been free since the previous block.  Requested HERE they land under these products, far
+      // from any poll (a burst in front of a poll delays its first check by a memory latency: in front of the row owners'
+      // rows poll it made them 2.9K clocks late for down's product, profiles/r05_block_stamps.txt).  Rounds 3-4 requested
+      // them behind the rows' sweep, a third at a time: the last third was still on its way when the planes were done.
+      ISSUE(Ld, 10); ISSUE(Ld, 11); ISSUE(Ld, 12);
+#if QUIP_PREDECODE_GATE
+      run_items3_pre(Bg, 0, xlane, 64);
+#else
+      run_items3(0, xlane, xlane, xlane, 64);                                     // first column's three row blocks
+#endif
+      run_items3(FRB, xlane, xlane, xlane, 64 + 16 * FRB);                         // second column's
     }
     had::wg_barrier<true>();
     BSTAMP(12);
@@ -974,7 +1125,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         const int m = tid / 48;
         const int* s3 = accs + (64 + tid) * 4;
         const float f = __builtin_fmaf((float)s3[0], 65536.f, __builtin_fmaf((float)s3[1], 256.f, (float)s3[2]));
-        zcol[tid] = (float)(f16)(f * unscale_of(shs[m], T::kD4 ? 1 : 2));
+        zcol[tid] = (float)(f16)(f * unscale_of(shs[0], T::kD4 ? 1 : 2));      // [column 2 (w & 127) + m][k]: one matrix, one exponent
       }
       had::wg_barrier<true>();
       zero_acc(64, 96);
@@ -984,7 +1135,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         const int o = tid >> 2, part = tid & 3;
         const int m = o >> 6, kq = o & 63;
         const bool live = kq < FK;
-        const f16* hs = reinterpret_cast<const f16*>(smem + B::kHad) + m * B::KKP + (live ? kq : 0) * FK;
+        // (m: which of this workgroup's two columns; the factor is its matrix's: mgu)
+        const f16* hs = reinterpret_cast<const f16*>(smem + B::kHad) + mgu * B::KKP + (live ? kq : 0) * FK;
         const float* zz = zcol + m * 48;
         float t = 0.f;
 #pragma unroll
@@ -998,7 +1150,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         // as 16-byte stores of the rows (k', k' + 1), k' even (the odd row's value comes over from the next quad)
         const float tn = __shfl_down(t, 4, 64);
         if (live && part == 0 && (kq & 1) == 0) {
-          uint64_t* dst = inbox + (((size_t)(kq / RPO) * FL + w) * (2 * RPO) + m * RPO + (kq % RPO));
+          uint64_t* dst = inbox + (((size_t)(kq / RPO) * FL + (2 * (w & 127) + m)) * (2 * RPO) + mgu * RPO + (kq % RPO));
           if (kq + 1 < FK) esync::st_granule2(dst, as_u32(t), as_u32(tn), tag1);
           else esync::st_granule(dst, as_u32(t), tag1);
         }
@@ -1085,50 +1237,48 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) e[r] = had::fmul(had::fmul(u[r], had::silu(o[r])), suf[r]);
           fht256(e);
-          // the row, as fp16 hi + lo of the prescaled values, next to the owner's other rows in LDS ([j][RPO]) ...
+          // the row, ROUNDED TO fp16 (round 5; the reference materialises fp16 here too: the transform's output feeds
+          // `hadK @ x` as an fp16 tensor, quant.py:72-88), prescaled, next to the owner's other row in LDS ([j][RPO] fp16).
+          // Rounds 3-4 sent fp16 hi + lo (22 bits): twice the bytes on the hand-off every workgroup sweeps.
           constexpr float kPre = 1.f / 16.f;
+          uint16_t* stage16 = reinterpret_cast<uint16_t*>(stage);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float vv = e[r] * kPre;
-            const f16 hi = (f16)vv;
-            const f16 lo = (f16)(vv - (float)hi);
-            stage[(4 * lane + r) * RPO + rw] = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
-          }
+          for (int r = 0; r < 4; ++r)
+            stage16[(4 * lane + r) * RPO + rw] = __builtin_bit_cast(uint16_t, (f16)(e[r] * kPre));
         }
         had::wg_barrier<true>();
-        // ... and out: column j's RPO rows = granules [j * 48 + RPO w, +RPO) as 16-byte stores
-        if (tid < FL) {
-          static_assert(RPO == 2, "one thread per column, one 16-byte store");
-          const int j = tid;
-          const uint2 d = *reinterpret_cast<const uint2*>(stage + j * RPO);
-          uint64_t* dst = frow + ((size_t)j * B::KP16 + RPO * w);
-          esync::st_granule2(dst, d.x, d.y, tag2);
+        // ... and out: granule (owner w, column j) = {rows 2 w | 2 w + 1 of column j, tag}: [owner][256], two columns per store
+        if (tid < FL / 2) {
+          static_assert(RPO == 2, "one fp16 pair per column and owner");
+          const uint2 d = *reinterpret_cast<const uint2*>(stage + 2 * tid);
+          esync::st_granule2(frow + ((size_t)w * FL + 2 * tid), d.x, d.y, tag2);
         }
         had::wg_barrier<true>();                         // the staging area is free again (the gather below zeroes over it)
       }
       BSTAMP(14);
-      // B fragments of the K-mix (had_d^T in LDS)
       typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-      f16x4 bfr[3][FRB];
-      {
-        const f16* hdT = reinterpret_cast<const f16*>(smem + B::kHad) + 2 * B::KKP;
+#if QUIP_PREDECODE_DOWN
+      // down's table look-ups inside the wait for the rows (its codes landed under the gate / up products): the product behind
+      // the planes is then eight MFMAs per item.  (Round 3 tried this next to gate's items and spilled; this phase holds little else.)
+      i32x4 Bd[QUIP_PREDECODE_DOWN][8];                                 // (the macro: how many of the three items)
+      if constexpr (!RVQ) {
+        esync::drain();
+        own_slots(SLOTS(M_DOWN));
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
-#pragma unroll
-          for (int ct = 0; ct < FRB; ++ct)
-            bfr[s][ct] = *reinterpret_cast<const f16x4*>(hdT + (16 * ct + n) * B::KP16 + 16 * s + 4 * q);
+        for (int i = 0; i < QUIP_PREDECODE_DOWN; ++i) decode_item(6 + i, Bd[i]);          // (slice 16 + wave >= 22: decoded, never multiplied)
       }
-      had::wg_barrier<true>();                         // (the factor image sits where the rows are about to land)
-      // gather the rows
+#endif
+      // gather the rows: granule (owner o, column j) = {fp16 rows 2 o | 2 o + 1 of column j, tag}; a 16-byte piece = two columns
       {
-        constexpr int KPAIRS = (FK + 1) / 2, PIECES = FL * KPAIRS, NP = (PIECES + kThreads - 1) / kThreads;
+        constexpr int PIECES = NRO * (FL / 2), NP = (PIECES + kThreads - 1) / kThreads;
+        // LDS image [KP16 / 2 row pairs][256 columns] of fp16 pairs (rows 2 o, 2 o + 1): the sweep's pieces (one owner, two
+        // columns) land as 8-byte stores on consecutive addresses (a [column][pair] image put 32 lanes on two banks)
         uint32_t* ft = reinterpret_cast<uint32_t*>(smem + B::kArea);
-        for (int j = tid; j < FL; j += kThreads)
-#pragma unroll
-          for (int k = 2 * KPAIRS; k < B::KP16; ++k) ft[j * B::KP16 + k] = 0u;
+        for (int j = tid; j < (B::KP16 / 2 - NRO) * FL; j += kThreads) ft[NRO * FL + j] = 0u;
         if (kCheapPoll && wave == 0) {
           uint32_t spins0 = 0;
-          const uint64_t* last = frow + ((size_t)(FL - 1 - (w & 7)) * B::KP16 + (lane < FK ? lane : 0));      // (eight of the last columns: 32 workgroups per polled line instead of 256 -- 256 pollers of ONE line delay the owners' stores to it: 1410 -> 1380 us per 32-block launch)
+          // (eight of the last columns: 32 workgroups per polled line instead of 256 -- 256 pollers of ONE line delay the owners' stores to it)
+          const uint64_t* last = frow + ((size_t)(lane < NRO ? lane : 0) * FL + (FL - 1 - (w & 7)));
           for (;;) {
             u32x2_t f;
             esync::ld8(f, last);
@@ -1145,37 +1295,43 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 #pragma unroll
           for (int j = 0; j < NP; ++j) {
             const int i = tid + kThreads * j;
-            const int ic = i < PIECES ? i : 0;
-            const int col = ic / KPAIRS, kp = ic - col * KPAIRS;
-            esync::ld16(p[j], frow + ((size_t)col * B::KP16 + 2 * kp));
+            esync::ld16(p[j], frow + 2 * (size_t)(i < PIECES ? i : 0));
           }
           esync::drain();
           bool ok = true;
 #pragma unroll
           for (int j = 0; j < NP; ++j) {
             esync::own(p[j]);
-            const int i = tid + kThreads * j;
-            const int ic = i < PIECES ? i : 0;
-            const int kp = ic % KPAIRS;
-            ok = ok && p[j].y == tag2 && (2 * kp + 1 >= FK || p[j].w == tag2);
+            ok = ok && p[j].y == tag2 && p[j].w == tag2;
           }
           if (esync::spin_step(ok, spins, ctl + 1, 0x2000u + (uint32_t)w)) break;
         }
+        if constexpr (!RVQ) own_slots(SLOTS(M_DOWN));
         BSTAMP(27);
-        // down, once the rows are here, a third at a time: staging, K-mix and planes are its time to land
-        if constexpr (RVQ) ISSUE_RVQ_DOWN_G0(Ld); else ISSUE(Ld, 10);
+        if constexpr (RVQ) ISSUE_RVQ_DOWN_G0(Ld);
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
           const int i = tid + kThreads * j;
           if (i < PIECES) {
-            const int col = i / KPAIRS, kp = i - col * KPAIRS;
-            *reinterpret_cast<uint2*>(ft + col * B::KP16 + 2 * kp) = make_uint2(p[j].x, (2 * kp + 1 < FK) ? p[j].z : 0u);
+            const int o = i / (FL / 2), cp = i - o * (FL / 2);
+            const uint32_t msk = (2 * o + 1 < FK) ? 0xffffffffu : 0x0000ffffu;       // (row 43 does not exist)
+            *reinterpret_cast<uint2*>(ft + o * FL + 2 * cp) = make_uint2(p[j].x & msk, p[j].z & msk);
           }
         }
       }
       had::wg_barrier<true>();
-      if constexpr (RVQ) ISSUE_RVQ_DOWN_G1(Ld); else ISSUE(Ld, 11);
+      if constexpr (RVQ) ISSUE_RVQ_DOWN_G1(Ld);
       BSTAMP(15);
+      // B fragments of the K-mix (had_d^T in LDS; the fp16 rows take [0, 24 K) of the area, the factor image behind them stays)
+      f16x4 bfr[3][FRB];
+      {
+        const f16* hdT = reinterpret_cast<const f16*>(smem + B::kHad) + 2 * B::KKP;
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+          for (int ct = 0; ct < FRB; ++ct)
+            bfr[s][ct] = *reinterpret_cast<const f16x4*>(hdT + (16 * ct + n) * B::KP16 + 16 * s + 4 * q);
+      }
       typedef float f32x4 __attribute__((ext_vector_type(4)));
       f32x4 acc[2][FRB];
 #pragma unroll
@@ -1189,19 +1345,16 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 #pragma unroll
           for (int jt = 0; jt < 2; ++jt) {
             const int tile = wave + jt * kWaves;
-            const u32x4 d = *reinterpret_cast<const u32x4*>(ft + (16 * tile + n) * B::KP16 + 16 * s + 4 * q);
-            const uint2 h2 = make_uint2(__builtin_amdgcn_perm(d.y, d.x, 0x05040100u), __builtin_amdgcn_perm(d.w, d.z, 0x05040100u));
-            const uint2 l2 = make_uint2(__builtin_amdgcn_perm(d.y, d.x, 0x07060302u), __builtin_amdgcn_perm(d.w, d.z, 0x07060302u));
-            const f16x4 ah = __builtin_bit_cast(f16x4, h2), al = __builtin_bit_cast(f16x4, l2);
+            // A[column 16 tile + n][rows 16 s + 4 q .. + 3] = the row pairs 8 s + 2 q and + 1 of that column
+            const uint2 apr = make_uint2(ft[(8 * s + 2 * q) * FL + 16 * tile + n], ft[(8 * s + 2 * q + 1) * FL + 16 * tile + n]);
+            const f16x4 ah = __builtin_bit_cast(f16x4, apr);
 #pragma unroll
-            for (int ct = 0; ct < FRB; ++ct) {
-              acc[jt][ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bfr[s][ct], acc[jt][ct], 0, 0, 0);
+            for (int ct = 0; ct < FRB; ++ct)
               acc[jt][ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bfr[s][ct], acc[jt][ct], 0, 0, 0);
-            }
           }
         }
       }
-      if constexpr (RVQ) ISSUE_RVQ_DOWN_G2(Ld); else ISSUE(Ld, 12);
+      if constexpr (RVQ) ISSUE_RVQ_DOWN_G2(Ld);
       const float in_scale = Ld.sc[6] * 16.f;
       float mx = 0.f;
 #pragma unroll
@@ -1297,6 +1450,12 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         for (int i = 0; i < 3; ++i) {
           const int sl = i * kWaves + wave;
           if (sl < JD) {
+#if QUIP_PREDECODE_DOWN
+            if (i < QUIP_PREDECODE_DOWN) {
+              add_rows(item_multiply<272>(Bd[i < QUIP_PREDECODE_DOWN ? i : 0], xlane_d + (uint32_t)(sl * 544)), 160);
+              continue;
+            }
+#endif
             ItemAddr ad;
             item_addresses<REP>(qa[6 + i], qb[6 + i], lane_c, lane_c2, ad, lane_c3);
             add_rows(T::kD4 ? item_mfma_d4<272>(ad, xlane_d + (uint32_t)(sl * 544)) : item_mfma<272, R3>(ad, xlane_d + (uint32_t)(sl * 544)), 160);
@@ -1317,17 +1476,21 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       if (tid < 64) reinterpret_cast<uint32_t*>(smem + B::kDesc)[tid] = reinterpret_cast<const uint32_t*>(a.layers + l + 1)[tid];
       had::wg_barrier<true>();
     }
-    // output side of this block's down_proj + residual -> h; the q, k, v row blocks of the NEXT block go out behind the
-    // hand-off, a third at a time
+    // output side of this block's down_proj + residual -> h, RMSNorm and the input transforms of the NEXT block's q, k, v in ONE
+    // edge; their row blocks go out behind the hand-off.
+    // (requested unconditionally -- behind the last block: its own q, k, v rows once more, never multiplied, and the input
+    //  side of its own q, k, v once more, never used -- so that no request depends on a branch: the compiler makes several
+    //  conditional regions of one `if`, and a register a load is still going to write must not meet a copy at their joins)
     rederive();
-    edge(std::integral_constant<int, 0>{}, SLOTS(0u), 5, ebase | hop, 0x4000u, sv_d_prev, nullptr, nullptr, nullptr, 0.f, 0.f, false,
-         [&]() { BSTAMP(1); if constexpr (RVQ) ISSUE_RVQ_QKV_G(Ld, 0); else ISSUE(Ld, 0); },
-         [&]() { if constexpr (RVQ) ISSUE_RVQ_QKV_G(Ld, 1); else ISSUE(Ld, 1); }, [&]() {});
-    // (requested unconditionally -- behind the last block: its own q, k, v rows once more, never multiplied -- so that no
-    //  request depends on a branch: the compiler makes several conditional regions of one `if`, and a register a load is
-    //  still going to write must not meet a copy at their joins)
-    if constexpr (RVQ) ISSUE_RVQ_QKV_G(Ld, 2); else ISSUE(Ld, 2);
-    if (more) P1();
+    {
+      const int c_lo = (3 * w) >> 8, c_hi = (3 * w + 2) >> 8;
+      edge(std::true_type{}, std::integral_constant<int, 2>{}, SLOTS(0u), 5, ebase | hop, 0x4000u, sv_d_prev, Ld.ln[0], Ld.su[c_lo], Ld.su[c_hi],
+           Ld.sc[c_lo], Ld.sc[c_hi], c_hi != c_lo,
+           [&]() { BSTAMP(1); if constexpr (RVQ) { ISSUE_RVQ_QKV_G(Ld, 0); ISSUE_RVQ_QKV_G(Ld, 1); } else { ISSUE(Ld, 0); ISSUE(Ld, 1); } },
+           [&]() { if constexpr (RVQ) ISSUE_RVQ_QKV_G(Ld, 2); else ISSUE(Ld, 2); }, [&]() {}, 23);
+      BSTAMP(2);
+    }
+    if (more) P1_products();
     esync::drain();
     own_slots(SLOTS(M_QKV));
   }
@@ -1342,9 +1505,11 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     esync::own(e);
     esync::own(fp);
     const bool failed = __builtin_amdgcn_readfirstlane((int)e) != 0;
-    const u32x4 nan4 = {0x7e007e00u, 0x7e007e00u, 0x7e007e00u, 0x7e007e00u};
-    *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.h_out) + tid * 16) =
-        failed ? nan4 : *reinterpret_cast<const u32x4*>(smem + B::kH + tid * 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      reinterpret_cast<uint16_t*>(a.h_out)[tid + 512 * (2 * j)] = failed ? (uint16_t)0x7e00 : (uint16_t)(hreg[j] & 0xffffu);
+      reinterpret_cast<uint16_t*>(a.h_out)[tid + 512 * (2 * j + 1)] = failed ? (uint16_t)0x7e00 : (uint16_t)(hreg[j] >> 16);
+    }
     if (tid == 0) {
       if (failed && fp == 0u) esync::st_word(ctl + 2, (uint32_t)pos + 1u);
       esync::st_word(ctl, ebase >> 10);

@@ -110,18 +110,8 @@ struct GLds {
 };
 static_assert(GLds::kBytes <= 160 * 1024, "LDS budget");
 
-// The three balanced digits of X (had::digits_of) as bytes, without the shifts: l = byte 0 of X, m = byte 0 of (X + 128) >> 8 =
-// byte 1 of X + 0x80, h = byte 0 of (((X + 128) >> 8) + 128) >> 8 = byte 2 of X + 0x8080.  Byte B of four values -> one word.
-template <int BYTE>
-__device__ __forceinline__ uint32_t bytes4(int a, int b, int c, int d) {
-  constexpr uint32_t lo = 0x0c0c0400u + BYTE * 0x0101u, hi = 0x04000c0cu + BYTE * 0x01010000u;
-  return __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, lo) | __builtin_amdgcn_perm((uint32_t)d, (uint32_t)c, hi);
-}
-__device__ __forceinline__ void digit_words(const int (&X)[4], uint32_t& h, uint32_t& m, uint32_t& l) {
-  l = bytes4<0>(X[0], X[1], X[2], X[3]);
-  m = bytes4<1>(X[0] + 0x80, X[1] + 0x80, X[2] + 0x80, X[3] + 0x80);
-  h = bytes4<2>(X[0] + 0x8080, X[1] + 0x8080, X[2] + 0x8080, X[3] + 0x8080);
-}
+using hadw::bytes4;
+using hadw::digit_words;
 
 template <int I> using IC = std::integral_constant<int, I>;
 template <class F, int... Is>

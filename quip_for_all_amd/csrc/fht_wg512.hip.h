@@ -66,8 +66,11 @@ __device__ __forceinline__ void lane_stage(float v[8], int lane) {
     }
   } else {
     const float sg = ((lane >> S) & 1) ? -1.f : 1.f;     // bit clear: x0 + x1 = own + partner; bit set: x0 - x1 = partner - own
+    float par[8];                                        // (the partners in a batch: one wait for the crossbar, fht_wg512x.hip.h)
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = __builtin_fmaf(v[r], sg, lane_partner<S>(v[r], lane));
+    for (int r = 0; r < 8; ++r) par[r] = lane_partner<S>(v[r], lane);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = __builtin_fmaf(v[r], sg, par[r]);
   }
 }
 

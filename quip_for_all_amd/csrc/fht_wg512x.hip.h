@@ -82,10 +82,16 @@ __device__ __forceinline__ void lane_stage(float (&v)[N], int lane) {
   } else {
     const float sg = ((lane >> S) & 1) ? -1.f : 1.f;     // bit clear: own + partner; bit set: partner - own
     const f32x2 sg2 = {sg, sg};
+    // all the partners first, then the arithmetic: lane bits 2 and 4 go through the LDS crossbar (ds_swizzle), and written
+    // pair by pair the compiler waits for every pair of swizzles on its own (lgkmcnt(0) four to eight times per stage, ~60
+    // clocks each: profiles/r05_block_stamps.txt) -- in a batch they are one wait
+    float par[N];
+#pragma unroll
+    for (int r = 0; r < N; ++r) par[r] = had8::lane_partner<S>(v[r], lane);
 #pragma unroll
     for (int r = 0; r < N; r += 2) {
-      const f32x2 own = {v[r], v[r + 1]}, par = {had8::lane_partner<S>(v[r], lane), had8::lane_partner<S>(v[r + 1], lane)};
-      const f32x2 w = __builtin_elementwise_fma(own, sg2, par);
+      const f32x2 own = {v[r], v[r + 1]}, pp = {par[r], par[r + 1]};
+      const f32x2 w = __builtin_elementwise_fma(own, sg2, pp);
       v[r] = w.x;
       v[r + 1] = w.y;
     }
@@ -138,8 +144,9 @@ __device__ __forceinline__ void fwd(float (&v)[NT][Geo<LOGN>::EPT], float* xbuf,
   }
 }
 
-// strided -> natural
-template <int LOGN, int NT, bool RAW>
+// strided -> natural.  SYNC_AFTER_READ: one more barrier right behind the LDS reads -- the caller writes over the exchange
+// buffer as soon as rev returns (digit planes), and the barrier's skew hides under the stages that follow it here
+template <int LOGN, int NT, bool RAW, bool SYNC_AFTER_READ = false>
 __device__ __forceinline__ void rev(float (&v)[NT][Geo<LOGN>::EPT], float* xbuf, int tid) {
   using G = Geo<LOGN>;
   constexpr int E = G::EPT;
@@ -159,8 +166,10 @@ __device__ __forceinline__ void rev(float (&v)[NT][Geo<LOGN>::EPT], float* xbuf,
     const float* b = xbuf + i * G::kBufFloats + G::nat(tid);
 #pragma unroll
     for (int r = 0; r < E; ++r) v[i][r] = b[r];
-    reg_stages<E, 1>(v[i]);                                                // index bits 0 .. RB - 1
   }
+  if constexpr (SYNC_AFTER_READ) had::wg_barrier<RAW>();
+#pragma unroll
+  for (int i = 0; i < NT; ++i) reg_stages<E, 1>(v[i]);                      // index bits 0 .. RB - 1
 #pragma unroll
   for (int i = 0; i < NT; ++i) lane_stages<E, 0, 9 - G::RB>(v[i], lane);    // index bits RB .. 8
 }
@@ -169,6 +178,19 @@ __device__ __forceinline__ void rev(float (&v)[NT][Geo<LOGN>::EPT], float* xbuf,
 __device__ __forceinline__ void wave_fht1024(float (&v)[16], int lane) {
   reg_stages<16, 1>(v);
   lane_stages<16, 0, 6>(v, lane);
+}
+
+// The three balanced digits of X (had::digits_of) as bytes, without the shifts: l = byte 0 of X, m = byte 0 of (X + 128) >> 8 =
+// byte 1 of X + 0x80, h = byte 0 of (((X + 128) >> 8) + 128) >> 8 = byte 2 of X + 0x8080.  Byte B of four values -> one word.
+template <int BYTE>
+__device__ __forceinline__ uint32_t bytes4(int a, int b, int c, int d) {
+  constexpr uint32_t lo = 0x0c0c0400u + BYTE * 0x0101u, hi = 0x04000c0cu + BYTE * 0x01010000u;
+  return __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, lo) | __builtin_amdgcn_perm((uint32_t)d, (uint32_t)c, hi);
+}
+__device__ __forceinline__ void digit_words(const int (&X)[4], uint32_t& h, uint32_t& m, uint32_t& l) {
+  l = bytes4<0>(X[0], X[1], X[2], X[3]);
+  m = bytes4<1>(X[0] + 0x80, X[1] + 0x80, X[2] + 0x80, X[3] + 0x80);
+  h = bytes4<2>(X[0] + 0x8080, X[1] + 0x8080, X[2] + 0x8080, X[3] + 0x8080);
 }
 
 // sum of squares / maximum over the workgroup, a fixed order (every workgroup of a launch computes the same value from the

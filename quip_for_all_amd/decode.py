@@ -334,8 +334,12 @@ class LlamaDecoder:
                 mix[2, :, :K] = L["down"].had_left.detach().float().t()
                 had3 = mix.contiguous()
             else:
-                su, sv = [vec(m.SU) for m in mods], [vec(m.SV) for m in mods]
-                ln = [vec(L["ln1"]), vec(L["ln2"])]
+                # shape 0 (round 5): the 4096-wide edges work in the strided layout too (8 elements per thread):
+                # p[8 t + k] = v[t + 512 k] for the vectors they multiply -- ln, SU of q k v gate up, SV of o and down
+                perm8 = lambda t: vec(t).reshape(8, 512).t().contiguous().reshape(-1)     # noqa: E731
+                su = [perm8(m.SU) if k in ("q", "k", "v", "gate", "up") else vec(m.SU) for k, m in zip(names, mods)]
+                sv = [perm8(m.SV) if k in ("o", "down") else vec(m.SV) for k, m in zip(names, mods)]
+                ln = [perm8(L["ln1"]), perm8(L["ln2"])]
                 had3 = _engine_had3(L["gate"], L["up"], L["down"])
             keep += su + sv + ln + [had3]
             ptrs = ([m.Qidxs.data_ptr() for m in mods] + [t.data_ptr() for t in ln] + [t.data_ptr() for t in su]

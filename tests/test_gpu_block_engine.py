@@ -1,8 +1,10 @@
 """Persistent decode engine, stage 2 (csrc/decode_block.hip): all decoder blocks of a token in one launch, against the
-stage-wise step of the same model.  With the MLP half of the stage-wise step on its own persistent launch
-(csrc/decode_engine.hip) both paths execute the same rounded operations in the same order, so hidden states, logits
-and KV caches have to agree bit for bit; against the plain stage-wise step (four launches for the MLP half) the MLP
-edge differs by its block exponent and the order of two commuting factors (tests/test_gpu_engine.py)."""
+stage-wise step of the same model.  Through round 4 the two executed the same rounded operations in the same order and
+agreed bit for bit.  Round 5 restructured the launch's 4096-wide edges (gather -> fwd -> strided layout -> rev -> planes,
+fht_wg512x.hip.h; block exponents from the norm bound instead of the exact maximum): `rev` adds in another order and the
+digits carry up to four bits fewer of the 22, so the launch now sits within a stated number of fp16 ulps of rms(logits) of
+the stage-wise step -- like the 8192-wide launch (tests/test_gpu_block_engine_gqa.py) -- and the distance to the float64
+model is what tests/test_gpu_decode.py bounds (one block, eight blocks)."""
 import os
 
 import numpy as np
@@ -45,22 +47,37 @@ def _same_weights(dst, src):
         dst._init_block_engine()
 
 
+def _ulps(la, lb):
+    """max |la - lb| in fp16 ulps of rms(lb)"""
+    rms = lb.float().pow(2).mean().sqrt().item()
+    return (la.float() - lb.float()).abs().max().item() / 2.0 ** (np.floor(np.log2(rms)) - 10)
+
+
 @pytest.mark.parametrize("layers", [1, 3])
-def test_block_engine_equals_stagewise_step_bit_for_bit(layers):
+def test_block_engine_against_stagewise_step(layers):
+    """teacher forced (both decoders are fed the stage-wise step's tokens): logits within 2 (4 sqrt(layers) + 2) fp16 ulps of
+    rms(logits) of the stage-wise step -- both sit within 4 sqrt(L) + 2 of the float64 model (tests/test_gpu_decode.py:
+    deep_bound_ulps) -- observed 6 / 12 for 1 / 3 blocks; new cache rows within 2^-7 of their maximum"""
     a = _decoder(layers, True)
     b = _decoder(layers, False)
     _same_weights(b, a)
     assert a.block_eng and not b.block_eng and b.ffn_eng
     for dec in (a, b):
         dec.reset(first_token=7)
+    worst = 0.0
     with torch.no_grad():
         for t in range(6):
             la = a.step().clone()
             lb = b.step().clone()
             assert a.engine_status() == 0 and b.engine_status() == 0
-            assert torch.equal(a.tok, b.tok), f"token {t}"
-            assert torch.equal(la, lb), f"logits of token {t}: max diff {(la.float() - lb.float()).abs().max().item()}"
-    assert torch.equal(a.kcache[:, :, :6], b.kcache[:, :, :6]) and torch.equal(a.vcache[:, :, :6], b.vcache[:, :, :6])
+            worst = max(worst, _ulps(la, lb))
+            a.tok.copy_(b.tok)
+    print(f"{layers} block(s): logits within {worst:.2f} fp16 ulps of rms(logits) of the stage-wise step")
+    assert worst <= 2.0 * (4.0 * np.sqrt(layers) + 2.0), worst
+    for ca, cb_ in ((a.kcache, b.kcache), (a.vcache, b.vcache)):
+        ra = torch.stack([c[:, :6] for c in ca]).float() if isinstance(ca, (list, tuple)) else ca[:, :, :6].float()
+        rb = torch.stack([c[:, :6] for c in cb_]).float() if isinstance(cb_, (list, tuple)) else cb_[:, :, :6].float()
+        assert (ra - rb).abs().max().item() <= 2.0 ** -7 * rb.abs().max().item()
 
 
 def test_block_engine_captured_generation_matches_plain_stagewise_tokens():
@@ -77,8 +94,10 @@ def test_block_engine_captured_generation_matches_plain_stagewise_tokens():
     assert a.engine_status() == 0
     same = int((ta == tc).sum())
     print(f"greedy tokens equal: {same} / {len(ta)}; last-step logits max diff {np.abs(la - lc).max():.4f} (|logit| max {np.abs(lc).max():.2f})")
-    assert same == len(ta)
-    assert np.abs(la - lc).max() <= 2.0 ** -8 * np.abs(lc).max()
+    first = int(np.argmax(ta != tc)) if same < len(ta) else len(ta)
+    assert first >= 8, (ta, tc)              # (a near tie may go the other way later on and the sequences part there)
+    if same == len(ta):
+        assert np.abs(la - lc).max() <= 2.0 ** -8 * np.abs(lc).max()
 
 
 @pytest.mark.parametrize("pos0", [126, 127, 128, 300, 1021])
@@ -115,8 +134,9 @@ def test_block_engine_long_context_split_attention(pos0):
             assert err <= 16.0, (p, err)          # (twice the largest observed: 8.0)
             # the new cache rows: written once, by the workgroup whose turn the position is
             # (block 0's rows see identical inputs; block 1's inherit the few-ulp difference of block 0's attention)
-            assert torch.equal(a.kcache[0, :, p], b.kcache[0, :, p]) and torch.equal(a.vcache[0, :, p], b.vcache[0, :, p])
             for ca, cb_ in ((a.kcache, b.kcache), (a.vcache, b.vcache)):
+                d0 = (ca[0, :, p].float() - cb_[0, :, p].float()).abs().max().item()
+                assert d0 <= 2.0 ** -8 * cb_[0, :, p].float().abs().max().item(), d0      # (the planes' rounding only)
                 d = (ca[1, :, p].float() - cb_[1, :, p].float()).abs().max().item()
                 assert d <= 2.0 ** -6 * cb_[1, :, p].float().abs().max().item(), d
             with torch.no_grad():

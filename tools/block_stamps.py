@@ -35,7 +35,7 @@ for it in range(6):
     e1.record()
     torch.cuda.synchronize()
     if it >= 2:
-        d = dbg.cpu().numpy().reshape(256, 32)[:, :28].astype(np.float64)
+        d = dbg.cpu().numpy().reshape(256, 32).astype(np.float64)
         acc.append((d, e0.elapsed_time(e1) * 1e3))
 print(f"status {dec.engine_status()}; launch of {layers} blocks: {np.median([t for _, t in acc]):.1f} us = {np.median([t for _, t in acc]) / layers:.2f} us per block")
 head = np.arange(256) % 8 == 0
@@ -62,13 +62,15 @@ for i in order:
     print(f"  {i:2d} {names[i]:34s} {seg.mean():9.0f} {seg[:, head].mean():9.0f} {seg[:, ~head].mean():9.0f}")
 span = D_[:, :, 3] - D_[:, :, 0]
 print(f"  block span (stamp 0 -> 3 of the next block): {span.mean():.0f} ticks")
-en = ["(after burst C)", "out: fht<1>", "out: h written + barrier", "sumsq", "in: mul + fht<2>", "in: max reduce", "planes + barrier"]
-print("inside the gate / up edge (stamps 18..24):")
-for i in range(1, 7):
-    seg = D_[:, :, 18 + i] - D_[:, :, 18 + i - 1]
-    print(f"  {en[i]:28s} {seg.mean():9.0f}")
-print(f"  (stamp 10 -> 18: {(D_[:, :, 18] - D_[:, :, 10]).mean():.0f}, 24 -> 11: {(D_[:, :, 11] - D_[:, :, 24]).mean():.0f})")
-ro = np.arange(256) < 11
+# round 5: the edges' stages (fwd / rev): gate-up edge stamps 18..22, q-k-v edge stamps 23, 24, 28, 29, 30
+en = ["gathered", "fwd<1>", "h update + sums + ln, su", "rev<NT>", "planes + barrier"]
+for title, st, before, after in (("gate / up edge", [18, 19, 20, 21, 22], 10, 11), ("q / k / v edge", [23, 24, 28, 29, 30], 1, 2)):
+    print(f"inside the {title} (stamps {st}):")
+    for i in range(1, 5):
+        seg = D_[:, :, st[i]] - D_[:, :, st[i - 1]]
+        print(f"  {en[i]:28s} {seg.mean():9.0f}")
+    print(f"  (stamp {before} -> {st[0]}: {(D_[:, :, st[0]] - D_[:, :, before]).mean():.0f}, {st[4]} -> {after}: {(D_[:, :, after] - D_[:, :, st[4]]).mean():.0f})")
+ro = np.arange(256) < 22
 print("inside the MLP edge: row owners: publish(13) -> inbox complete %.0f, -> rows published(14) %.0f; everyone: 14 -> poll done(26) %.0f (row owners %.0f), sweep(27) %.0f, staging + barrier(15) %.0f" % (
     (D_[:, ro, 25] - D_[:, ro, 13]).mean(), (D_[:, ro, 14] - D_[:, ro, 25]).mean(), (D_[:, :, 26] - D_[:, :, 14]).mean(),
     (D_[:, ro, 26] - D_[:, ro, 14]).mean(), (D_[:, :, 27] - D_[:, :, 26]).mean(), (D_[:, :, 15] - D_[:, :, 27]).mean()))

@@ -1,10 +1,11 @@
 #!/bin/bash
-# build_variant.sh <variant.hip> <name>: links tools/dbg/libv_<name>.so = the in-tree library with decode_block.o replaced by
-# the variant source (A/B timing of the block engine through QUIP_LIB_PATH)
+# build a variant of the library with extra flags for ONE source: tools/dbg/build_variant.sh NAME SOURCE.hip "-DFLAG=1 ..."
+# -> tools/dbg/libquip_NAME.so (load it with QUIP_LIB_PATH); the other objects come from quip_for_all_amd/lib/obj
 set -e
 cd "$(dirname "$0")/../.."
-O=quip_for_all_amd/lib/obj
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iquip_for_all_amd/csrc -Iinclude -c "$1" -o /tmp/v_$2.o
-objs=$(ls $O/*.o | grep -v decode_block.o)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/dbg/libv_$2.so $objs /tmp/v_$2.o
-echo built tools/dbg/libv_$2.so
+name=$1; src=$2; flags=$3
+obj=/tmp/variant_${name}.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c quip_for_all_amd/csrc/$src -o $obj
+others=$(ls quip_for_all_amd/lib/obj/*.o | grep -v "/${src%.hip}.o")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/dbg/libquip_${name}.so $obj $others
+echo built tools/dbg/libquip_${name}.so
