@@ -33,10 +33,19 @@
 #define QUIP_INO_EXACT 0
 #endif
 #ifndef QUIP_PREDECODE_DOWN
-#define QUIP_PREDECODE_DOWN 1      // items of down decoded inside the wait for the MLP rows (2: the register allocator spills)
+#define QUIP_PREDECODE_DOWN 2      // items of down decoded inside the wait for the MLP rows (3: the register allocator spills 36 bytes)
+#endif
+#ifndef QUIP_PREDECODE_QKV
+#define QUIP_PREDECODE_QKV 2       // items of the NEXT block's q / k / v decoded inside the wait for z_d (0 | 2)
+#endif
+#ifndef QUIP_QKV_ISSUE_EARLY
+#define QUIP_QKV_ISSUE_EARLY 0     // A/B: the next block's q / k / v requested between the two halves of the gate / up products (1) or behind the rows' sweep (0)
+#endif
+#ifndef QUIP_OWNER_PREDECODE
+#define QUIP_OWNER_PREDECODE 1     // A/B: the MLP row owners decode down's items ahead like everybody (1) or at the product (0)
 #endif
 #ifndef QUIP_PREDECODE_GATE
-#define QUIP_PREDECODE_GATE 1      // items of gate / up decoded inside the wait for z_o (2: spills)
+#define QUIP_PREDECODE_GATE 2      // items of gate / up decoded inside the wait for z_o (3: spills 60 bytes)
 #endif
 
 namespace quip {
@@ -117,7 +126,8 @@ struct BLds {
   static constexpr int kDesc = kRed + 256 + 32;              // the current block's descriptor (256 bytes): pointers are read
                                                              // from here, not from memory (a vector load of a pointer ahead of
                                                              // every request would wait for the requests before it)
-  static constexpr int kH = kDesc + 256;                     // fp16 [4096]: residual stream
+  static constexpr int kH = kDesc + 256;                     // (fp16 [4096]: the residual stream of rounds 3-4; it lives in registers now)
+  static constexpr int kDescN = kH;                          // the next block's descriptor (256 bytes)
   static constexpr int kQkv = kH + HID * 2;                  // fp16 [3][128]: this head's q, k, v; [128] attention output
   static constexpr int kCs = kQkv + 4 * HD * 2;              // float [2][128]: the rotary row of this token (cos | sin), the same for every block
   // ONE transient area for everything that lives between two products (E8P12: T1 x 32 + T2 x 16 = 96 KB of tables leave 50.3 KB).
@@ -415,42 +425,34 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 #pragma clang fp contract(off)
     const float p2 = as_f32((uint32_t)(sh + 127) << 23);
     const float s2 = had::fmul(scale, p2);
-    int X[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) X[r] = (int)__builtin_rintf(v[r] * s2);
-    const int Xa[4] = {X[0], X[1], X[2], X[3]}, Xb[4] = {X[4], X[5], X[6], X[7]};
+    // (digits straight from the fp32 magic number: hadw::digit_words_magic)
+    const float va[4] = {v[0], v[1], v[2], v[3]}, vb[4] = {v[4], v[5], v[6], v[7]};
     if constexpr (HI) {
       // [x0 x2 0 0 | x4 x6 0 0 | x1 x3 0 0 | x5 x7 0 0] (planes_scatter_hi's positions), plane stride 2 * 4096
-      const int E0[4] = {X[0], X[2], 0, 0}, E1[4] = {X[4], X[6], 0, 0}, E2[4] = {X[1], X[3], 0, 0}, E3[4] = {X[5], X[7], 0, 0};
+      const float e0[4] = {v[0], v[2], 0.f, 0.f}, e1[4] = {v[4], v[6], 0.f, 0.f}, e2[4] = {v[1], v[3], 0.f, 0.f}, e3[4] = {v[5], v[7], 0.f, 0.f};
       uint32_t dg[3][4];
-      hadw::digit_words(E0, dg[0][0], dg[1][0], dg[2][0]);
-      hadw::digit_words(E1, dg[0][1], dg[1][1], dg[2][1]);
-      hadw::digit_words(E2, dg[0][2], dg[1][2], dg[2][2]);
-      hadw::digit_words(E3, dg[0][3], dg[1][3], dg[2][3]);
+      hadw::digit_words_magic(e0, s2, dg[0][0], dg[1][0], dg[2][0]);
+      hadw::digit_words_magic(e1, s2, dg[0][1], dg[1][1], dg[2][1]);
+      hadw::digit_words_magic(e2, s2, dg[0][2], dg[1][2], dg[2][2]);
+      hadw::digit_words_magic(e3, s2, dg[0][3], dg[1][3], dg[2][3]);
 #pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        // (the zero digits: byte 1 of 0x80 and byte 2 of 0x8080 are 0 -- nothing to mask)
+      for (int d = 0; d < 3; ++d)      // (a zero value's three digits are zero bytes: nothing to mask)
         *reinterpret_cast<uint4*>(smem + base + d * 2 * HID + 16 * tid) = make_uint4(dg[d][0], dg[d][1], dg[d][2], dg[d][3]);
-      }
     } else if constexpr (RVQ) {
       // x' = [s x_g | x_g]: the 8-group's residual-side digits, then its main-side digits (planes_scatter_rvq's positions)
       const float s2r = had::fmul(had::fmul(scale, a.resid_scale), p2);
-      int Y[8];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) Y[r] = (int)__builtin_rintf(v[r] * s2r);
-      const int Ya[4] = {Y[0], Y[1], Y[2], Y[3]}, Yb[4] = {Y[4], Y[5], Y[6], Y[7]};
       uint32_t dg[3][4];
-      hadw::digit_words(Ya, dg[0][0], dg[1][0], dg[2][0]);
-      hadw::digit_words(Yb, dg[0][1], dg[1][1], dg[2][1]);
-      hadw::digit_words(Xa, dg[0][2], dg[1][2], dg[2][2]);
-      hadw::digit_words(Xb, dg[0][3], dg[1][3], dg[2][3]);
+      hadw::digit_words_magic(va, s2r, dg[0][0], dg[1][0], dg[2][0]);
+      hadw::digit_words_magic(vb, s2r, dg[0][1], dg[1][1], dg[2][1]);
+      hadw::digit_words_magic(va, s2, dg[0][2], dg[1][2], dg[2][2]);
+      hadw::digit_words_magic(vb, s2, dg[0][3], dg[1][3], dg[2][3]);
 #pragma unroll
       for (int d = 0; d < 3; ++d)
         *reinterpret_cast<uint4*>(smem + base + d * 2 * HID + 16 * tid) = make_uint4(dg[d][0], dg[d][1], dg[d][2], dg[d][3]);
     } else {
       uint32_t dg[3][2];
-      hadw::digit_words(Xa, dg[0][0], dg[1][0], dg[2][0]);
-      hadw::digit_words(Xb, dg[0][1], dg[1][1], dg[2][1]);
+      hadw::digit_words_magic(va, s2, dg[0][0], dg[1][0], dg[2][0]);
+      hadw::digit_words_magic(vb, s2, dg[0][1], dg[1][1], dg[2][1]);
 #pragma unroll
       for (int d = 0; d < 3; ++d) *reinterpret_cast<uint2*>(smem + base + d * HID + 8 * tid) = make_uint2(dg[d][0], dg[d][1]);
     }
@@ -612,17 +614,23 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       }
     }
   };
-  // three items of one K slice whose first NPRE were decoded earlier (pre: their eight B fragments each)
-  constexpr int NPRE = QUIP_PREDECODE_GATE > 0 ? QUIP_PREDECODE_GATE : 1;
-  auto run_items3_pre = [&](const i32x4 (&pre)[NPRE][8], int s0, uint32_t xa, int accrow0) {
+  // three items of one K slice whose first NPRE were decoded earlier (pre: their eight B fragments each, as scalars)
+  auto run_items3_pre = [&](auto npre_tag, const uint32_t (&pre)[decltype(npre_tag)::value][32], int s0, uint32_t xa0, uint32_t xa1, uint32_t xa2, int accrow0) {
+    constexpr int NPRE = decltype(npre_tag)::value;
     i32x4 A[8];
-    item_fragments(xa, A);
+    item_fragments(xa0, A);
+    const uint32_t xas[3] = {xa0, xa1, xa2};
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
+      if (i > 0 && xas[i] != xas[i - 1]) item_fragments(xas[i], A);
       i32x4 r = {0, 0, 0, 0};
       if (i < NPRE) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) r = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t], pre[i < NPRE ? i : 0][t], r, 0, 0, 0);
+        for (int t = 0; t < 8; ++t) {
+          const uint32_t* bs = pre[i < NPRE ? i : 0];
+          const i32x4 Bt = {(int)bs[4 * t], (int)bs[4 * t + 1], (int)bs[4 * t + 2], (int)bs[4 * t + 3]};
+          r = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t], Bt, r, 0, 0, 0);
+        }
       } else {
         ItemAddr ad;
         item_addresses<REP>(qa[s0 + i], qb[s0 + i], lane_c, lane_c2, ad, lane_c3);
@@ -654,6 +662,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 
   const f16* sv_d_prev = nullptr;
   const BlockLayer& Ld = *reinterpret_cast<const BlockLayer*>(smem + B::kDesc);
+  const BlockLayer& Ln = *reinterpret_cast<const BlockLayer*>(smem + B::kDescN);
+  constexpr bool kPreQkv = QUIP_PREDECODE_QKV > 0 && !RVQ;
   if (tid < 64) reinterpret_cast<uint32_t*>(smem + B::kDesc)[tid] = reinterpret_cast<const uint32_t*>(a.layers)[tid];
   had::wg_barrier<true>();
   // ================= P1: [output side of the previous block's down_proj + residual,] RMSNorm, input transforms of q, k, v of
@@ -661,23 +671,26 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   // (called for block 0 here and, for block l + 1, at the bottom of iteration l: the requests of q, k, v go out BEHIND the
   //  hand-off of z_d and are consumed before the loop's back edge, where no request may be in flight -- the compiler is free to
   //  copy registers there)
-  auto P1_products = [&]() {
+  constexpr int NPQ = QUIP_PREDECODE_QKV > 0 ? QUIP_PREDECODE_QKV : 1;
+  auto P1_products = [&](auto pre_tag, const uint32_t (&preq)[NPQ][32]) {
     const int c_lo = (3 * w) >> 8;                   // the first of the one or two matrices this workgroup's row blocks are in
-    esync::drain();                                    // q, k, v have landed (requested behind the z_d hand-off)
+    esync::drain();                                    // q, k, v have landed
     own_slots(SLOTS(M_QKV));
     {
       const uint32_t x0 = xlane + (uint32_t)((((3 * w) >> 8) == c_lo ? 0 : 1) * 3 * KV);
       const uint32_t x1 = xlane + (uint32_t)((((3 * w + 1) >> 8) == c_lo ? 0 : 1) * 3 * KV);
       const uint32_t x2 = xlane + (uint32_t)((((3 * w + 2) >> 8) == c_lo ? 0 : 1) * 3 * KV);
-      run_items3(0, x0, x1, x2, 0);
+      if constexpr (decltype(pre_tag)::value) run_items3_pre(std::integral_constant<int, NPQ>{}, preq, 0, x0, x1, x2, 0);
+      else run_items3(0, x0, x1, x2, 0);
       if constexpr (RVQ) run_items3(3, x0 + 4096u, x1 + 4096u, x2 + 4096u, 0);      // the second virtual slice: wave + 8
     }
     had::wg_barrier<true>();
     ++hop;                                             // hand-off: z_q, z_k, z_v
+    const int sh_lo = shs[0], sh_hi = shs[1];          // (both, then a select: a selected ADDRESS was hoisted out of the block loop into a register of its own)
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int rbq = 3 * w + i, ci = rbq >> 8;
-      publish16(ci, (rbq & 255) * 8, i * 16, shs[ci == c_lo ? 0 : 1], ebase | hop);
+      publish16(ci, (rbq & 255) * 8, i * 16, ci == c_lo ? sh_lo : sh_hi, ebase | hop);
     }
     had::wg_barrier<true>();
     zero_acc(0, 48);
@@ -688,12 +701,17 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     const int c_lo = (3 * w) >> 8, c_hi = (3 * w + 2) >> 8;
     edge(std::false_type{}, std::integral_constant<int, 2>{}, SLOTS(M_QKV), -1, 0u, 0u, nullptr, Ld.ln[0], Ld.su[c_lo], Ld.su[c_hi],
          Ld.sc[c_lo], Ld.sc[c_hi], c_hi != c_lo, [&]() {}, [&]() {}, [&]() {});
-    P1_products();
+    uint32_t none[NPQ][32];                          // (block 0: nothing decoded ahead; never read)
+    P1_products(std::false_type{}, none);
   }
   for (int l = 0; l < a.n_layers; ++l) {
     dbg_on = a.dbg != nullptr && l == a.dbg_layer;
     rederive();
     BSTAMP(0);
+    // the NEXT block's descriptor (the last block: its own once more), for the early requests of its q, k, v rows; read long
+    // after the barriers that follow
+    if (tid < 64)
+      reinterpret_cast<uint32_t*>(smem + B::kDescN)[tid] = reinterpret_cast<const uint32_t*>(a.layers + (l + 1 < a.n_layers ? l + 1 : l))[tid];
     // o of this block, behind the publication.  (A burst in front of a gather makes the gather's first check wait for the
     // burst -- vmcnt retires in order: ~2.3 us of HBM latency against the ~1.7 us a hand-off takes -- and a burst anywhere
     // else stalls the issuing waves for ~1.2K clocks, the CU's address unit taking ~25 clocks per 1 KB request.  Measured per
@@ -749,7 +767,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         BSTAMP(4);
         // H_32[hd][j1] = (-1)^popcount(hd & j1): lane bit 5 <-> hd bit 1, lane bit 4 <-> hd bit 0 (folded into the two swap
         // steps), the wave <-> hd bits 2..4 (folded into the sum over the waves' partial results)
-        const float sg1 = (hd & 2) ? -1.f : 1.f, sg0 = (hd & 1) ? -1.f : 1.f;
+        // (scalar registers: as vector constants they were hoisted out of the block loop and held two registers for the whole launch)
+        const float sg1 = as_f32((uint32_t)__builtin_amdgcn_readfirstlane((int)((hd & 2) ? 0xbf800000u : 0x3f800000u)));
+        const float sg0 = as_f32((uint32_t)__builtin_amdgcn_readfirstlane((int)((hd & 1) ? 0xbf800000u : 0x3f800000u)));
         float P[12], Q[6];
 #pragma unroll
         for (int pi = 0; pi < 12; ++pi) {
@@ -780,10 +800,12 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           float y[2] = {0.f, 0.f};
 #pragma unroll
           for (int gg = 0; gg < 8; ++gg) {
-            const float sw = (__builtin_popcount((uint32_t)(hd >> 2) & (uint32_t)gg) & 1) ? -1.f : 1.f;
+            // (the sign as a scalar xor mask: eight +-1.0 constants in vector registers were hoisted out of the block loop and
+            //  lived -- and spilled -- across the whole launch)
+            const uint32_t sm = ((uint32_t)__builtin_popcount((uint32_t)(hd >> 2) & (uint32_t)gg) & 1u) << 31;
             const float2 pr = *reinterpret_cast<const float2*>(xbuf + (wave * 8 + gg) * HD + 2 * lane);
-            y[0] = __builtin_fmaf(pr.x, sw, y[0]);
-            y[1] = __builtin_fmaf(pr.y, sw, y[1]);
+            y[0] = had::fadd(y[0], as_f32(as_u32(pr.x) ^ sm));
+            y[1] = had::fadd(y[1], as_f32(as_u32(pr.y) ^ sm));
           }
           hadw::reg_stage<2, 1>(y);
           hadw::lane_stages<2, 0, 6>(y, lane);
@@ -1058,12 +1080,20 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     rederive();
 #if QUIP_PREDECODE_GATE
     // the first gate / up item's table look-ups inside the wait for z_o (its codes were requested under o's input side)
-    i32x4 Bg[QUIP_PREDECODE_GATE][8];
+    uint32_t Bg[QUIP_PREDECODE_GATE][32];            // (scalar registers while they wait: see down's)
     if constexpr (!RVQ) {
       esync::drain();
       own_slots(SLOTS(M_GATE));
 #pragma unroll
-      for (int i = 0; i < QUIP_PREDECODE_GATE; ++i) decode_item(i, Bg[i]);
+      for (int i = 0; i < QUIP_PREDECODE_GATE; ++i) {
+        i32x4 Bt[8];
+        decode_item(i, Bt);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          Bg[i][4 * t] = (uint32_t)Bt[t].x; Bg[i][4 * t + 1] = (uint32_t)Bt[t].y; Bg[i][4 * t + 2] = (uint32_t)Bt[t].z; Bg[i][4 * t + 3] = (uint32_t)Bt[t].w;
+          asm volatile("" : "+v"(Bg[i][4 * t]), "+v"(Bg[i][4 * t + 1]), "+v"(Bg[i][4 * t + 2]), "+v"(Bg[i][4 * t + 3]));
+        }
+      }
     }
 #endif
     // (ONE consumer per workgroup: its half of the machine multiplies gate, the other half up)
@@ -1108,7 +1138,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       // them behind the rows' sweep, a third at a time: the last third was still on its way when the planes were done.
       ISSUE(Ld, 10); ISSUE(Ld, 11); ISSUE(Ld, 12);
 #if QUIP_PREDECODE_GATE
-      run_items3_pre(Bg, 0, xlane, 64);
+      run_items3_pre(std::integral_constant<int, QUIP_PREDECODE_GATE>{}, Bg, 0, xlane, xlane, xlane, 64);
+      if constexpr (kPreQkv && QUIP_QKV_ISSUE_EARLY) { ISSUE(Ln, 0); ISSUE(Ln, 1); ISSUE(Ln, 2); }
 #else
       run_items3(0, xlane, xlane, xlane, 64);                                     // first column's three row blocks
 #endif
@@ -1158,6 +1189,28 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       ++hop;                                           // hand-off: rows -> everybody
       const uint32_t tag2 = ebase | hop;
       BSTAMP(13);
+#if QUIP_PREDECODE_DOWN
+      // down's table look-ups right behind the publication of the columns, i.e. inside a wait -- the row owners' for their inbox,
+      // everybody else's for the rows (its codes landed under the gate / up products): the product behind the planes is then eight
+      // MFMAs per item.  (Behind the owners' row work instead, the owners were 1K clocks late for down's product.)
+      // (held as scalar registers: a waiting B fragment as a 128-bit tuple needs four consecutive, even-aligned registers,
+      //  and the allocator spills long-lived tuples once the file is fragmented)
+      uint32_t Bd[QUIP_PREDECODE_DOWN][32];                             // (the macro: how many of the three items)
+      if constexpr (!RVQ) {
+        esync::drain();
+        own_slots(SLOTS(M_DOWN));
+#pragma unroll
+        for (int i = 0; i < QUIP_PREDECODE_DOWN; ++i) {                 // (slice 16 + wave >= 22: decoded, never multiplied)
+          i32x4 Bt[8];
+          decode_item(6 + i, Bt);
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            Bd[i][4 * t] = (uint32_t)Bt[t].x; Bd[i][4 * t + 1] = (uint32_t)Bt[t].y; Bd[i][4 * t + 2] = (uint32_t)Bt[t].z; Bd[i][4 * t + 3] = (uint32_t)Bt[t].w;
+            asm volatile("" : "+v"(Bd[i][4 * t]), "+v"(Bd[i][4 * t + 1]), "+v"(Bd[i][4 * t + 2]), "+v"(Bd[i][4 * t + 3]));
+          }
+        }
+      }
+#endif
       if (w < NRO) {
         // the owner's inbox = 256 columns x (2 matrices x RPO rows) granules, swept by all 512 threads (coalesced 16-byte
         // pieces); piece p = column p / RPO, matrix (p / (RPO / 2)) & 1, rows 2 (p % (RPO / 2)) and + 1
@@ -1257,17 +1310,6 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       }
       BSTAMP(14);
       typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-#if QUIP_PREDECODE_DOWN
-      // down's table look-ups inside the wait for the rows (its codes landed under the gate / up products): the product behind
-      // the planes is then eight MFMAs per item.  (Round 3 tried this next to gate's items and spilled; this phase holds little else.)
-      i32x4 Bd[QUIP_PREDECODE_DOWN][8];                                 // (the macro: how many of the three items)
-      if constexpr (!RVQ) {
-        esync::drain();
-        own_slots(SLOTS(M_DOWN));
-#pragma unroll
-        for (int i = 0; i < QUIP_PREDECODE_DOWN; ++i) decode_item(6 + i, Bd[i]);          // (slice 16 + wave >= 22: decoded, never multiplied)
-      }
-#endif
       // gather the rows: granule (owner o, column j) = {fp16 rows 2 o | 2 o + 1 of column j, tag}; a 16-byte piece = two columns
       {
         constexpr int PIECES = NRO * (FL / 2), NP = (PIECES + kThreads - 1) / kThreads;
@@ -1309,29 +1351,32 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         if constexpr (!RVQ) own_slots(SLOTS(M_DOWN));
         BSTAMP(27);
         if constexpr (RVQ) ISSUE_RVQ_DOWN_G0(Ld);
+        // the NEXT block's q, k, v rows (gate's slots: consumed): they land under the K-mix and down's product and are
+        // decoded inside the wait for z_d (rounds 3-4 requested them behind that hand-off)
+        if constexpr (kPreQkv && !QUIP_QKV_ISSUE_EARLY) { ISSUE(Ln, 0); ISSUE(Ln, 1); ISSUE(Ln, 2); }
+        // (the sum of squares of the rows on the way: down's block exponent comes from the norm bound |(H^T (x) I) r|_inf <=
+        //  |r|_2 -- the rows of the orthogonal factor are unit vectors -- known BEFORE the K-mix: no maximum over its results,
+        //  no reduction behind it; 4-5 of the 22 bits idle, as on the 4096-wide edges)
+        float ssr = 0.f;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
           const int i = tid + kThreads * j;
           if (i < PIECES) {
             const int o = i / (FL / 2), cp = i - o * (FL / 2);
             const uint32_t msk = (2 * o + 1 < FK) ? 0xffffffffu : 0x0000ffffu;       // (row 43 does not exist)
-            *reinterpret_cast<uint2*>(ft + o * FL + 2 * cp) = make_uint2(p[j].x & msk, p[j].z & msk);
+            const uint32_t r0 = p[j].x & msk, r1 = p[j].z & msk;
+            *reinterpret_cast<uint2*>(ft + o * FL + 2 * cp) = make_uint2(r0, r1);
+            const f16x2 a0 = as_f16x2(r0), a1 = as_f16x2(r1);
+            ssr = __builtin_fmaf((float)a0.x, (float)a0.x, ssr); ssr = __builtin_fmaf((float)a0.y, (float)a0.y, ssr);
+            ssr = __builtin_fmaf((float)a1.x, (float)a1.x, ssr); ssr = __builtin_fmaf((float)a1.y, (float)a1.y, ssr);
           }
         }
+        ssr = had::wave_reduce_to_lane63<false>(ssr);
+        if (lane == 63) red[wave] = ssr;
       }
       had::wg_barrier<true>();
       if constexpr (RVQ) ISSUE_RVQ_DOWN_G1(Ld);
       BSTAMP(15);
-      // B fragments of the K-mix (had_d^T in LDS; the fp16 rows take [0, 24 K) of the area, the factor image behind them stays)
-      f16x4 bfr[3][FRB];
-      {
-        const f16* hdT = reinterpret_cast<const f16*>(smem + B::kHad) + 2 * B::KKP;
-#pragma unroll
-        for (int s = 0; s < 3; ++s)
-#pragma unroll
-          for (int ct = 0; ct < FRB; ++ct)
-            bfr[s][ct] = *reinterpret_cast<const f16x4*>(hdT + (16 * ct + n) * B::KP16 + 16 * s + 4 * q);
-      }
       typedef float f32x4 __attribute__((ext_vector_type(4)));
       f32x4 acc[2][FRB];
 #pragma unroll
@@ -1340,8 +1385,14 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         for (int ct = 0; ct < FRB; ++ct) acc[jt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
       {
         const uint32_t* ft = reinterpret_cast<const uint32_t*>(smem + B::kArea);
+        // B fragments of the K-mix: had_d^T (the fp16 rows take [0, 24 K) of the area, the factor image behind them stays), a
+        // k step at a time
+        const f16* hdT = reinterpret_cast<const f16*>(smem + B::kHad) + 2 * B::KKP;
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
+          f16x4 bfs[FRB];
+#pragma unroll
+          for (int ct = 0; ct < FRB; ++ct) bfs[ct] = *reinterpret_cast<const f16x4*>(hdT + (16 * ct + n) * B::KP16 + 16 * s + 4 * q);
 #pragma unroll
           for (int jt = 0; jt < 2; ++jt) {
             const int tile = wave + jt * kWaves;
@@ -1350,24 +1401,16 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
             const f16x4 ah = __builtin_bit_cast(f16x4, apr);
 #pragma unroll
             for (int ct = 0; ct < FRB; ++ct)
-              acc[jt][ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bfr[s][ct], acc[jt][ct], 0, 0, 0);
+              acc[jt][ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bfs[ct], acc[jt][ct], 0, 0, 0);
           }
         }
       }
       if constexpr (RVQ) ISSUE_RVQ_DOWN_G2(Ld);
       const float in_scale = Ld.sc[6] * 16.f;
-      float mx = 0.f;
-#pragma unroll
-      for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-        for (int ct = 0; ct < FRB; ++ct)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float mm = fabsf(had::fmul(acc[jt][ct][i], in_scale));
-            mx = fmaxf(mx, mm == mm ? mm : __builtin_inff());
-          }
-      const float bound = had::block_reduce(mx, true, red, tid, kThreads);
+      // (in_scale carries the prescale 1 / 16 of the rows back: the bound is for acc * in_scale, |acc|_inf <= |rows|_2)
+      const float bound = sqrtf(red_sum8(0)) * fabsf(in_scale) * 1.0625f;
       const int sh_d = had::shift_for(bound * ((RVQ && !HI) ? fmaxf(1.f, fabsf(a.resid_scale)) : 1.f));
+      had::wg_barrier<true>();                         // every wave's K-mix has read the rows: the planes land on them
       {
         uint8_t* pl = reinterpret_cast<uint8_t*>(smem + B::kArea);
         const float s2 = had::fmul(in_scale, as_f32((uint32_t)(sh_d + 127) << 23));
@@ -1378,13 +1421,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 #pragma unroll
           for (int ct = 0; ct < FRB; ++ct) {
             const int kc = 16 * ct + n;
-            int X[4], X1[4], H[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              X[i] = (int)__builtin_rintf(had::fmul(acc[jt][ct][i], s2));
-              X1[i] = (X[i] + 128) >> 8;
-              H[i] = (X1[i] + 128) >> 8;
-            }
+            // (digits straight from the fp32 magic number, four values per word: hadw::digit_words_magic)
+            const float av[4] = {acc[jt][ct][0], acc[jt][ct][1], acc[jt][ct][2], acc[jt][ct][3]};
             if (kc < FK) {
               const int kk = kc * FL + 16 * tile + 4 * q;
               if constexpr (HI) {
@@ -1392,34 +1430,36 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
                 // positions 8 + i0 + [0 1 . .] elements i0 + 1, i0 + 3; the other two of each word are zero digits
                 const int vv = 2 * (kk & ~7) + (kk & 4);
                 const int offa = (vv >> 8) * 272 + (vv & 255), offb = offa + 8;
-                *reinterpret_cast<uint32_t*>(pl + offa) = had::low_bytes4(H[0], H[2], 0, 0);
-                *reinterpret_cast<uint32_t*>(pl + B::kPlaneD + offa) = had::low_bytes4(X1[0], X1[2], 0, 0);
-                *reinterpret_cast<uint32_t*>(pl + 2 * B::kPlaneD + offa) = had::low_bytes4(X[0], X[2], 0, 0);
-                *reinterpret_cast<uint32_t*>(pl + offb) = had::low_bytes4(H[1], H[3], 0, 0);
-                *reinterpret_cast<uint32_t*>(pl + B::kPlaneD + offb) = had::low_bytes4(X1[1], X1[3], 0, 0);
-                *reinterpret_cast<uint32_t*>(pl + 2 * B::kPlaneD + offb) = had::low_bytes4(X[1], X[3], 0, 0);
+                const float ea[4] = {av[0], av[2], 0.f, 0.f}, eb[4] = {av[1], av[3], 0.f, 0.f};
+                uint32_t h, m, l;
+                hadw::digit_words_magic(ea, s2, h, m, l);
+                *reinterpret_cast<uint32_t*>(pl + offa) = h;
+                *reinterpret_cast<uint32_t*>(pl + B::kPlaneD + offa) = m;
+                *reinterpret_cast<uint32_t*>(pl + 2 * B::kPlaneD + offa) = l;
+                hadw::digit_words_magic(eb, s2, h, m, l);
+                *reinterpret_cast<uint32_t*>(pl + offb) = h;
+                *reinterpret_cast<uint32_t*>(pl + B::kPlaneD + offb) = m;
+                *reinterpret_cast<uint32_t*>(pl + 2 * B::kPlaneD + offb) = l;
               } else if constexpr (RVQ) {
                 // four elements of one 8-group: residual-side digits at 2 (kk & ~7) + (kk & 7), main-side 8 further
-                int Y[4], Y1[4], G[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                  Y[i] = (int)__builtin_rintf(had::fmul(acc[jt][ct][i], s2r));
-                  Y1[i] = (Y[i] + 128) >> 8;
-                  G[i] = (Y1[i] + 128) >> 8;
-                }
                 const int vv = 2 * (kk & ~7) + (kk & 7);
                 const int offr = (vv >> 8) * 272 + (vv & 255), offm = ((vv + 8) >> 8) * 272 + ((vv + 8) & 255);
-                *reinterpret_cast<uint32_t*>(pl + offr) = had::low_bytes4(G[0], G[1], G[2], G[3]);
-                *reinterpret_cast<uint32_t*>(pl + B::kPlaneD + offr) = had::low_bytes4(Y1[0], Y1[1], Y1[2], Y1[3]);
-                *reinterpret_cast<uint32_t*>(pl + 2 * B::kPlaneD + offr) = had::low_bytes4(Y[0], Y[1], Y[2], Y[3]);
-                *reinterpret_cast<uint32_t*>(pl + offm) = had::low_bytes4(H[0], H[1], H[2], H[3]);
-                *reinterpret_cast<uint32_t*>(pl + B::kPlaneD + offm) = had::low_bytes4(X1[0], X1[1], X1[2], X1[3]);
-                *reinterpret_cast<uint32_t*>(pl + 2 * B::kPlaneD + offm) = had::low_bytes4(X[0], X[1], X[2], X[3]);
+                uint32_t h, m, l;
+                hadw::digit_words_magic(av, s2r, h, m, l);
+                *reinterpret_cast<uint32_t*>(pl + offr) = h;
+                *reinterpret_cast<uint32_t*>(pl + B::kPlaneD + offr) = m;
+                *reinterpret_cast<uint32_t*>(pl + 2 * B::kPlaneD + offr) = l;
+                hadw::digit_words_magic(av, s2, h, m, l);
+                *reinterpret_cast<uint32_t*>(pl + offm) = h;
+                *reinterpret_cast<uint32_t*>(pl + B::kPlaneD + offm) = m;
+                *reinterpret_cast<uint32_t*>(pl + 2 * B::kPlaneD + offm) = l;
               } else {
                 const int off = (kk >> 8) * 272 + (kk & 255);
-                *reinterpret_cast<uint32_t*>(pl + off) = had::low_bytes4(H[0], H[1], H[2], H[3]);
-                *reinterpret_cast<uint32_t*>(pl + B::kPlaneD + off) = had::low_bytes4(X1[0], X1[1], X1[2], X1[3]);
-                *reinterpret_cast<uint32_t*>(pl + 2 * B::kPlaneD + off) = had::low_bytes4(X[0], X[1], X[2], X[3]);
+                uint32_t h, m, l;
+                hadw::digit_words_magic(av, s2, h, m, l);
+                *reinterpret_cast<uint32_t*>(pl + off) = h;
+                *reinterpret_cast<uint32_t*>(pl + B::kPlaneD + off) = m;
+                *reinterpret_cast<uint32_t*>(pl + 2 * B::kPlaneD + off) = l;
               }
             }
           }
@@ -1432,8 +1472,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       }
       had::wg_barrier<true>();
       BSTAMP(16);
-      esync::drain();                                  // down's codes (requested behind the rows' sweep)
-      own_slots(SLOTS(M_DOWN));
+      esync::drain();                                  // down's codes (and, behind them, the next block's q, k, v)
+      own_slots(SLOTS(M_DOWN | (kPreQkv ? M_QKV : 0u)));
       const uint32_t xlane_d = (uint32_t)B::kArea + (uint32_t)min(n, 2) * (uint32_t)B::kPlaneD + (uint32_t)q * 64u;
       if constexpr (RVQ) {
 #pragma unroll
@@ -1452,7 +1492,11 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           if (sl < JD) {
 #if QUIP_PREDECODE_DOWN
             if (i < QUIP_PREDECODE_DOWN) {
-              add_rows(item_multiply<272>(Bd[i < QUIP_PREDECODE_DOWN ? i : 0], xlane_d + (uint32_t)(sl * 544)), 160);
+              const uint32_t* bs = Bd[i < QUIP_PREDECODE_DOWN ? i : 0];
+              i32x4 Bt[8];
+#pragma unroll
+              for (int t = 0; t < 8; ++t) Bt[t] = i32x4{(int)bs[4 * t], (int)bs[4 * t + 1], (int)bs[4 * t + 2], (int)bs[4 * t + 3]};
+              add_rows(item_multiply<272>(Bt, xlane_d + (uint32_t)(sl * 544)), 160);
               continue;
             }
 #endif
@@ -1482,15 +1526,29 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     //  side of its own q, k, v once more, never used -- so that no request depends on a branch: the compiler makes several
     //  conditional regions of one `if`, and a register a load is still going to write must not meet a copy at their joins)
     rederive();
+    uint32_t Bq[NPQ][32];
+    if constexpr (kPreQkv) {
+      // the first items' table look-ups inside the wait for z_d (their codes landed under down's product); held as scalars
+#pragma unroll
+      for (int i = 0; i < NPQ; ++i) {
+        i32x4 Bt[8];
+        decode_item(i, Bt);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          Bq[i][4 * t] = (uint32_t)Bt[t].x; Bq[i][4 * t + 1] = (uint32_t)Bt[t].y; Bq[i][4 * t + 2] = (uint32_t)Bt[t].z; Bq[i][4 * t + 3] = (uint32_t)Bt[t].w;
+          asm volatile("" : "+v"(Bq[i][4 * t]), "+v"(Bq[i][4 * t + 1]), "+v"(Bq[i][4 * t + 2]), "+v"(Bq[i][4 * t + 3]));
+        }
+      }
+    }
     {
       const int c_lo = (3 * w) >> 8, c_hi = (3 * w + 2) >> 8;
       edge(std::true_type{}, std::integral_constant<int, 2>{}, SLOTS(0u), 5, ebase | hop, 0x4000u, sv_d_prev, Ld.ln[0], Ld.su[c_lo], Ld.su[c_hi],
            Ld.sc[c_lo], Ld.sc[c_hi], c_hi != c_lo,
-           [&]() { BSTAMP(1); if constexpr (RVQ) { ISSUE_RVQ_QKV_G(Ld, 0); ISSUE_RVQ_QKV_G(Ld, 1); } else { ISSUE(Ld, 0); ISSUE(Ld, 1); } },
-           [&]() { if constexpr (RVQ) ISSUE_RVQ_QKV_G(Ld, 2); else ISSUE(Ld, 2); }, [&]() {}, 23);
+           [&]() { BSTAMP(1); if constexpr (RVQ) { ISSUE_RVQ_QKV_G(Ld, 0); ISSUE_RVQ_QKV_G(Ld, 1); } else if constexpr (!kPreQkv) { ISSUE(Ld, 0); ISSUE(Ld, 1); } },
+           [&]() { if constexpr (RVQ) ISSUE_RVQ_QKV_G(Ld, 2); else if constexpr (!kPreQkv) ISSUE(Ld, 2); }, [&]() {}, 23);
       BSTAMP(2);
     }
-    if (more) P1_products();
+    if (more) P1_products(std::integral_constant<bool, kPreQkv>{}, Bq);
     esync::drain();
     own_slots(SLOTS(M_QKV));
   }

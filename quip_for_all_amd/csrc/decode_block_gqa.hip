@@ -77,6 +77,7 @@ constexpr int SQ_O = 0, SQ_GU = 4, SQ_D = 32, SQ_F = 46, SQ_A = 48, SQ_B = 50;
 // [50, 54): slot B = q row blocks 0 / 1 x slices 0, 1 (odd workgroups: their one q row block; row block 1 is a filler)
 static_assert(NSEQ % NS == 0, "the ring position of an item is the same in every block");
 constexpr float kOutScaleH = 0.011048543456039806f;  // 1 / sqrt(8192)
+constexpr float kSqrtH = 90.50966799187809f;         // sqrt(8192): |H_8192 x|_inf <= sqrt(8192) |x|_2
 constexpr int kParts = 4, kPartGran = 132, kSplitPos = 128;
 
 // workspace (bytes)
@@ -382,10 +383,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     const float s2 = had::fmul(scale, as_f32((uint32_t)(sh + 127) << 23));
     uint32_t dg[3][4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x2 p01 = f32x2{v[4 * g], v[4 * g + 1]} * f32x2{s2, s2}, p23 = f32x2{v[4 * g + 2], v[4 * g + 3]} * f32x2{s2, s2};
-      const int X[4] = {(int)__builtin_rintf(p01.x), (int)__builtin_rintf(p01.y), (int)__builtin_rintf(p23.x), (int)__builtin_rintf(p23.y)};
-      digit_words(X, dg[0][g], dg[1][g], dg[2][g]);
+    for (int g = 0; g < 4; ++g) {      // (round 5: digits straight from the fp32 magic number, hadw::digit_words_magic)
+      const float vv[4] = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+      hadw::digit_words_magic(vv, s2, dg[0][g], dg[1][g], dg[2][g]);
     }
 #pragma unroll
     for (int d = 0; d < 3; ++d)
@@ -484,19 +484,25 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
         unpack16(ps1, s1f);
 #pragma unroll
         for (int k = 0; k < 16; ++k) { v[0][k] = had::fmul(e[k], s0f[k]); v[1][k] = had::fmul(e[k], s1f[k]); }
-        hadw::rev<13, 2, true>(v, xbuf, tid);
-        ESTAMP(3);
-        float mx0 = had::wave_reduce_to_lane63<true>(hadw::absmax<16>(v[0], 1.f));
-        float mx1 = had::wave_reduce_to_lane63<true>(hadw::absmax<16>(v[1], 1.f));
-        had::wg_barrier<true>();
-        if (lane == 63) { red[wave] = ssw; red[16 + wave] = mx0; red[24 + wave] = mx1; }
-        had::wg_barrier<true>();
-        const float tot = total();
-        mx0 = red[16]; mx1 = red[24];
+        // (round 5: block exponents from the norm bound |H x|_inf <= sqrt(8192) |x|_2 -- decode_block.hip's edge -- whose sums
+        //  are known BEFORE the transform and ride on its barriers: no maxima behind it, one barrier pair less)
+        float n0 = 0.f, n1 = 0.f;
+        {
+#pragma clang fp contract(off)
 #pragma unroll
-        for (int i = 1; i < 8; ++i) { mx0 = fmaxf(mx0, red[16 + i]); mx1 = fmaxf(mx1, red[24 + i]); }
+          for (int r = 0; r < 16; ++r) { n0 = __builtin_fmaf(v[0][r], v[0][r], n0); n1 = __builtin_fmaf(v[1][r], v[1][r], n1); }
+        }
+        n0 = had::wave_reduce_to_lane63<false>(n0);
+        n1 = had::wave_reduce_to_lane63<false>(n1);
+        if (lane == 63) { red[wave] = ssw; red[16 + wave] = n0; red[24 + wave] = n1; }
+        hadw::rev<13, 2, true, true>(v, xbuf, tid);
+        ESTAMP(3);
+        const float tot = total();
+        float q0 = red[16], q1 = red[24];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) { q0 = had::fadd(q0, red[16 + i]); q1 = had::fadd(q1, red[24 + i]); }
         const float s0 = had::rms_scale(sc0, tot, HID, a.rms_eps), s1 = had::rms_scale(sc1, tot, HID, a.rms_eps);
-        const int h0 = had::shift_for(had::fmul(mx0, fabsf(s0))), h1 = had::shift_for(had::fmul(mx1, fabsf(s1)));
+        const int h0 = had::shift_for(sqrtf(q0) * kSqrtH * fabsf(s0) * 1.0625f), h1 = had::shift_for(sqrtf(q1) * kSqrtH * fabsf(s1) * 1.0625f);
         planes_nat(v[0], s0, h0, (uint32_t)B::kArea);
         planes_nat(v[1], s1, h1, (uint32_t)(B::kArea + 3 * B::PSH));
         if (tid == 0) { shs[sh0] = h0; shs[sh0 + 1] = h1; }
@@ -505,18 +511,22 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
         unpack16(ps0, s0f);
 #pragma unroll
         for (int k = 0; k < 16; ++k) v[0][k] = had::fmul(e[k], s0f[k]);
-        hadw::rev<13, 1, true>(v, xbuf, tid);
-        ESTAMP(3);
-        float mx0 = had::wave_reduce_to_lane63<true>(hadw::absmax<16>(v[0], 1.f));
-        had::wg_barrier<true>();
-        if (lane == 63) { red[wave] = ssw; red[16 + wave] = mx0; }
-        had::wg_barrier<true>();
-        const float tot = total();
-        mx0 = red[16];
+        float n0 = 0.f;
+        {
+#pragma clang fp contract(off)
 #pragma unroll
-        for (int i = 1; i < 8; ++i) mx0 = fmaxf(mx0, red[16 + i]);
+          for (int r = 0; r < 16; ++r) n0 = __builtin_fmaf(v[0][r], v[0][r], n0);
+        }
+        n0 = had::wave_reduce_to_lane63<false>(n0);
+        if (lane == 63) { red[wave] = ssw; red[16 + wave] = n0; }
+        hadw::rev<13, 1, true, true>(v, xbuf, tid);
+        ESTAMP(3);
+        const float tot = total();
+        float q0 = red[16];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) q0 = had::fadd(q0, red[16 + i]);
         const float s0 = had::rms_scale(sc0, tot, HID, a.rms_eps);
-        const int h0 = had::shift_for(had::fmul(mx0, fabsf(s0)));
+        const int h0 = had::shift_for(sqrtf(q0) * kSqrtH * fabsf(s0) * 1.0625f);
         planes_nat(v[0], s0, h0, (uint32_t)B::kArea);
         if (tid == 0) shs[sh0] = h0;
       }
@@ -885,10 +895,22 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
       unpack16(psu, suf);
 #pragma unroll
       for (int k = 0; k < 16; ++k) v[0][k] = had::fmul(v[0][k], suf[k]);
+      {
+        // (round 5: the norm bound, as on the other edges -- the sum of squares of the transform's input, read behind its barriers)
+#pragma clang fp contract(off)
+        float n0 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) n0 = __builtin_fmaf(v[0][r], v[0][r], n0);
+        n0 = had::wave_reduce_to_lane63<false>(n0);
+        if (lane == 63) red[wave] = n0;
+      }
       hadw::fwd<13, 1, true>(v, xbuf, tid);
       const float sco = Ld.sc[3];
-      const float mx = wg_max(hadw::absmax<16>(v[0], sco));
-      const int sh = had::shift_for(mx);
+      had::wg_barrier<true>();                         // the transform's last reads of the exchange buffer: the planes land on it
+      float q0 = red[0];
+#pragma unroll
+      for (int i = 1; i < 8; ++i) q0 = had::fadd(q0, red[i]);
+      const int sh = had::shift_for(sqrtf(q0) * kSqrtH * fabsf(sco) * 1.0625f);
       planes_str(v[0], sco, sh, (uint32_t)B::kArea);
       if (tid == 0) shs[2] = sh;
       had::wg_barrier<true>();

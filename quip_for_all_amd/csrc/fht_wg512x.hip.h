@@ -193,6 +193,21 @@ __device__ __forceinline__ void digit_words(const int (&X)[4], uint32_t& h, uint
   h = bytes4<2>(X[0] + 0x8080, X[1] + 0x8080, X[2] + 0x8080, X[3] + 0x8080);
 }
 
+// The same digits straight from fp32: W = bits(fma(v, s, 1.5 * 2^23)) = 0x4B400000 + X with X = rint(v s) (the fma rounds to
+// the integer grid, ties to even, for |v s| < 2^22 -- what rintf + v_cvt_i32_f32 compute in two more instructions per value):
+// byte 0 of W = byte 0 of X, byte 1 of W + 0x80 = byte 1 of X + 0x80, byte 2 of W + 0xC08080 = byte 2 of X + 0x8080
+// (0xC0 takes the 0x40 of the bias out of byte 2, modulo 256).
+constexpr float kMagic = 12582912.f;      // 1.5 * 2^23
+__device__ __forceinline__ void digit_words_magic(const float (&v)[4], float s, uint32_t& h, uint32_t& m, uint32_t& l) {
+#pragma clang fp contract(off)
+  int W[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) W[i] = (int)__builtin_bit_cast(uint32_t, __builtin_fmaf(v[i], s, kMagic));
+  l = bytes4<0>(W[0], W[1], W[2], W[3]);
+  m = bytes4<1>(W[0] + 0x80, W[1] + 0x80, W[2] + 0x80, W[3] + 0x80);
+  h = bytes4<2>(W[0] + 0xC08080, W[1] + 0xC08080, W[2] + 0xC08080, W[3] + 0xC08080);
+}
+
 // sum of squares / maximum over the workgroup, a fixed order (every workgroup of a launch computes the same value from the
 // same data): the thread's chain, the wave's DPP tree, the eight waves in order.  red: 8 floats per call site.
 template <int N, bool RAW>

@@ -118,8 +118,12 @@ def test_every_code_through_every_decode_path(cbid, scale):
 
 def test_block_engine_products_on_a_model_that_holds_every_code():
     """the persistent block launch decodes with the same core (e8p_gemv_core.hip.h) on its own request / slot machinery:
-    a 7B-shaped block whose seven code matrices hold every E8P12 code (a permuted ramp) equals the stage-wise step, whose
-    GEMV the test above pins code by code, bit for bit"""
+    a 7B-shaped block whose seven code matrices hold every E8P12 code (a permuted ramp) against the stage-wise step, whose
+    GEMV the test above pins code by code.  Through round 4 the two agreed bit for bit; since round 5 the launch's edges add in
+    another order and round its planes against the norm bound (decode_block.hip: edge), so the products see inputs that differ
+    in the last of 18-22 bits: logits within 2 (4 sqrt(1) + 2) = 12 fp16 ulps of rms(logits) (tests/test_gpu_block_engine.py),
+    cache rows within 2^-8 of their maximum -- a mis-decoded code (any of the 65 536, 8 weights wrong by >= 1/2) in any of the
+    seven matrices moves the logits by hundreds of ulps."""
     import os
     from quip_for_all_amd import decode as D
     shape = D.LlamaShape(hidden=4096, ffn=11008, layers=1, heads=32, kv_heads=32, vocab=2048)
@@ -154,5 +158,9 @@ def test_block_engine_products_on_a_model_that_holds_every_code():
         for t in range(3):
             la, lb = a.step().clone(), b.step().clone()
             assert a.engine_status() == 0
-            assert torch.equal(la, lb), (t, (la.float() - lb.float()).abs().max().item())
-    assert torch.equal(a.kcache[:, :, :3], b.kcache[:, :, :3]) and torch.equal(a.vcache[:, :, :3], b.vcache[:, :, :3])
+            rms = lb.float().pow(2).mean().sqrt().item()
+            ulps = (la.float() - lb.float()).abs().max().item() / 2.0 ** (np.floor(np.log2(rms)) - 10)
+            assert ulps <= 12.0, (t, ulps)
+            a.tok.copy_(b.tok)
+    for ca, cb in ((a.kcache, b.kcache), (a.vcache, b.vcache)):
+        assert (ca[:, :, :3].float() - cb[:, :, :3].float()).abs().max().item() <= 2.0 ** -8 * cb[:, :, :3].float().abs().max().item()
