@@ -216,6 +216,40 @@ def gqa_phase_rates(dec):
     return out
 
 
+def gqa_stream_rate(dec, launches=8):
+    """HBM-landed rate of the E8P12 decode GEMV at the 70B layer shapes INSIDE the persistent launch, measured:
+    the launch in its measurement mode (decode_block_gqa.hip, dbg_layer = -2) runs the products of all blocks -- the same 54
+    items per wave and block through the same ring, decode and MFMAs: q k v o gate up down of every block -- and leaves out the
+    edges, the attention and the hand-offs, so the weight stream never waits for an input.  Every byte multiplied in the timed
+    region was requested AND landed in it (no pre-filled ring: the first nine items of a wave against 54 x layers): GBps = all
+    code bytes of the model / HIP-event time of the launch.  The rocprofv3 FETCH_SIZE of the same launch is in profiles/
+    (tools/prof_gqa_stream.sh).  The products' results are not used (the digit planes are whatever the LDS holds)."""
+    import math
+    s = dec.s
+    L = len(dec.layers)
+    h = dec.embed[:1].reshape(-1).clone()
+    pos = torch.full((1,), 40, dtype=torch.long, device=dec.dev)
+    args = (dec.eng_layers, h, pos, dec.cos, dec.sin, dec.eng_grid, dec.eng_ws, L, dec.max_len, s.rms_eps,
+            1.0 / math.sqrt(s.head_dim), None, -2, 0, 0.0, 1)
+    ts = []
+    for it in range(launches + 2):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        torch.ops.quip_lib.block_engine(*args)
+        b.record()
+        torch.cuda.synchronize()
+        if it >= 2:
+            ts.append(a.elapsed_time(b) * 1e3)
+    us = float(np.median(ts))
+    code_bytes = sum(L_[k].Qidxs.numel() * L_[k].Qidxs.element_size() for L_ in dec.layers for k in ("q", "k", "v", "o", "gate", "up", "down"))
+    st = dec.engine_status()
+    dec.engine_reset()                  # (the mode publishes nothing: leave the workspace as a fresh one)
+    return {"mode": "products of all %d blocks in one launch, no edges / hand-offs (decode_block_gqa.hip, dbg_layer = -2)" % L,
+            "code_bytes": code_bytes, "us_per_launch": round(us, 1), "us_per_block": round(us / L, 2),
+            "GBps": round(code_bytes / us / 1e3, 1), "frac_of_8TBps": round(code_bytes / us / 1e3 / HBM_PEAK_GBPS, 4),
+            "launch_us_min_max": [round(min(ts), 1), round(max(ts), 1)], "engine_status": st}
+
+
 def gemv_per_shape(shapes, dev, pool_bytes=640 << 20, iters=100):
     """SURVEY 8d layer micro-bench inside the bench run: the default bs=1 E8P12 GEMV entry point on every (n, k) of
     `shapes`, weights cycled through a pool larger than the 256 MB Infinity Cache, `iters` launches per graph replay,
@@ -495,6 +529,10 @@ def time_decoder(D, shape, codebook, steps, warmup, device, **cb_kwargs):
                 out["gemv_phases_in_launch"] = gqa_phase_rates(dec)
             except Exception as e:
                 out["gemv_phases_in_launch"] = {"error": repr(e)[:300]}
+            try:
+                out["gemv_stream_in_launch"] = gqa_stream_rate(dec)
+            except Exception as e:
+                out["gemv_stream_in_launch"] = {"error": repr(e)[:300]}
         # the north star's target shapes, timed here so that the driver's run holds them (SURVEY 8d layer micro-bench)
         del dec
         torch.cuda.empty_cache()

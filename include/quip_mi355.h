@@ -502,6 +502,8 @@ typedef struct quip_block_engine_args {
   const void* grid_packed_abs;
   void* workspace;
   void* dbg;                 /* NULL, or 32 uint64 clock stamps per workgroup of block dbg_layer */
+                             /* (shape 1, dbg_layer == -2: MEASUREMENT MODE -- the products of every block without the edges,
+                                the attention and the hand-offs; h_out holds no result.  bench.py: gemv_stream_in_launch) */
   int32_t n_layers, max_len, dbg_layer;
   float rms_eps, attn_scale;
   int32_t codebook;          /* 0: E8P12; 1: D4 (uint8 codes, grid_packed_abs = the fp16 (256, 4) table, d4.py:26-96);

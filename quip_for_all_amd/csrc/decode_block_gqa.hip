@@ -546,6 +546,12 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
 
   had::wg_barrier<true>();
   const f16* sv_prev = nullptr;                      // SV of the previous block's down_proj (permuted)
+  // MEASUREMENT MODE (dbg_layer == -2, tools/gqa_stream.py, bench.py: gemv_stream_in_launch): the products of every block --
+  // the same 54 items per wave through the same ring, the same decode and MFMAs -- WITHOUT the edges, the attention and the
+  // hand-offs between them, so that the weight stream never waits for an input: what the E8P12 decode GEMV reaches on the 70B
+  // layer shapes when nothing but HBM holds it back (bytes landed per time of a launch that runs only the
+  // product phases; FETCH_SIZE of the same launch in profiles/).  The digit planes are whatever the LDS holds: no result.
+  const bool so = a.dbg_layer == -2;
   for (int l = 0; l < a.n_layers; ++l) {
     dbg_on = a.dbg != nullptr && l == a.dbg_layer;
     rederive();
@@ -562,7 +568,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     }
     // ================= P1: output side of the previous block's down_proj + residual (block 0: h = the embedding row), RMSNorm,
     // input transforms of q and k | v; their products; hand-off ==============================================================
-    edge(IC<2>{}, l > 0 ? zd : nullptr, ebase | hop, 0x4000u, sv_prev, Ld.ln[0], Ld.su[0], Ld.su[1 + kvm], Ld.sc[0], Ld.sc[1 + kvm], has_kv, 0, 18);
+    if (!so) edge(IC<2>{}, l > 0 ? zd : nullptr, ebase | hop, 0x4000u, sv_prev, Ld.ln[0], Ld.su[0], Ld.su[1 + kvm], Ld.sc[0], Ld.sc[1 + kvm], has_kv, 0, 18);
     BSTAMP(2);
     rederive();
     {
@@ -580,7 +586,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
       }
       had::wg_barrier<true>();
       ++hop;                                           // hand-off: z_k / z_v, then z_q (the same index: they are different vectors)
-      if (has_kv) publish(kvm ? zv : zk, 8 * (kvb & 63), B::AKV, 8, shs[1], ebase | hop);
+      if (has_kv && !so) publish(kvm ? zv : zk, 8 * (kvb & 63), B::AKV, 8, shs[1], ebase | hop);
       static_for<2>([&](auto ic) {
         constexpr int I = decltype(ic)::value;
         i32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
@@ -593,8 +599,10 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     }
     had::wg_barrier<true>();
     // rows [64 p, +48) (even workgroup: accumulator rows 0 .. 47) | [64 p + 48, +16) (odd one: rows 0 .. 15)
-    if (has_kv) publish(zq, 32 * (w >> 1) + 24, B::AQ, 8, shs[0], ebase | hop);
-    else publish(zq, 32 * (w >> 1), B::AQ, 24, shs[0], ebase | hop);
+    if (!so) {
+      if (has_kv) publish(zq, 32 * (w >> 1) + 24, B::AQ, 8, shs[0], ebase | hop);
+      else publish(zq, 32 * (w >> 1), B::AQ, 24, shs[0], ebase | hop);
+    }
     had::wg_barrier<true>();
     zero_acc(B::AQ, 48);
     BSTAMP(3);
@@ -605,7 +613,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     const int part = w & 3, nparts = split ? kParts : 1;
     const bool head_wg = part == 0;
     const int hd = w >> 2, kvh = hd / GQ;
-    if (head_wg || split) {
+    if (!so && (head_wg || split)) {
       // wave 0 / 1: the k / v vector (1024 values, 16 per lane), SV of this KV head's values
       const bool kvw = wave < 2;
       const f16* svkv = Ld.sv[1 + (wave & 1)];
@@ -884,7 +892,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
 
     // ================= o: input side (no norm), product, hand-off =========================================================
     rederive();
-    {
+    if (!so) {
       u32x4 psu[2];
       load16(Ld.su[3], psu);                           // natural order
       float v[1][16], suf[16];
@@ -921,14 +929,14 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     group(IC<SQ_O + 2>{}, IC<2>{}, xaddr((uint32_t)B::kArea, B::PSH, 1), B::AO);
     had::wg_barrier<true>();
     ++hop;                                             // hand-off: z_o
-    publish(zo, 16 * w, B::AO, 16, shs[2], ebase | hop);
+    if (!so) publish(zo, 16 * w, B::AO, 16, shs[2], ebase | hop);
     had::wg_barrier<true>();
     zero_acc(B::AO, 32);
     BSTAMP(9);
 
     // ================= o's output side + residual, RMSNorm, input transforms of gate / up; their products ===================
     rederive();
-    edge(IC<2>{}, zo, ebase | hop, 0x7000u, Ld.sv[3], Ld.ln[1], Ld.su[4], Ld.su[5], Ld.sc[4], Ld.sc[5], true, 3, 23);
+    if (!so) edge(IC<2>{}, zo, ebase | hop, 0x7000u, Ld.sv[3], Ld.ln[1], Ld.su[4], Ld.su[5], Ld.sc[4], Ld.sc[5], true, 3, 23);
     BSTAMP(10);
     rederive();
     {
@@ -942,6 +950,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     BSTAMP(11);
 
     // ================= the MLP edge =========================================================================================
+    int sh_d = 0;
+    if (!so) {
     rederive();
     float* zcol = reinterpret_cast<float*>(smem + B::kZcol);
     const float* mixf = reinterpret_cast<const float*>(smem + B::kMix);
@@ -1067,7 +1077,6 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     }
     had::wg_barrier<false>();
     own_ring();
-    int sh_d;
     {
       float bound = 0.f;
 #pragma unroll
@@ -1153,6 +1162,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     }
     had::wg_barrier<true>();
     BSTAMP(15);
+    }
     // ================= down's product ====================================================================================
     rederive();
     {
@@ -1175,7 +1185,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     }
     had::wg_barrier<true>();
     ++hop;                                             // hand-off: z_d
-    publish(zd, 16 * w, B::AD, 16, sh_d, ebase | hop);
+    if (!so) publish(zd, 16 * w, B::AD, 16, sh_d, ebase | hop);
     had::wg_barrier<true>();
     zero_acc(B::AD, 32);
     BSTAMP(16);
@@ -1188,7 +1198,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
   }
   // output side of the last block's down_proj + residual -> h
   rederive();
-  edge(IC<0>{}, zd, ebase | hop, 0x4000u, sv_prev, nullptr, nullptr, nullptr, 0.f, 0.f, false, 0, -1);
+  if (!so) edge(IC<0>{}, zd, ebase | hop, 0x4000u, sv_prev, nullptr, nullptr, nullptr, 0.f, 0.f, false, 0, -1);
   // ---- h_out (natural order) -------------------------------------------------------------------------------------------------
   if (w == 0) {
     // A launch in which a wait gave up (ctl[1] != 0) has no result: h_out is all NaN then, and ctl[2] keeps position + 1 of
