@@ -53,6 +53,8 @@ SIGNATURES = {
     "quip_debug_occupy": [_I32, _I32, _c.c_int64, _P, _P],
     "quip_block_engine_gqa_supported": [_I32, _I32, _I32, _I32, _I32, _I32],
     "quip_block_engine_gqa_workspace_bytes": [],
+    "quip_block_engine_g8_supported": [_I32, _I32, _I32, _I32, _I32, _I32],
+    "quip_block_engine_g8_workspace_bytes": [],
     "quip_e8p_gemv_kernel_choice": [_P, _I32, _I32],
     "quip_ffn_engine_supported": [_I32, _I32, _I32],
     "quip_ffn_engine_workspace_bytes": [_I32, _I32],

@@ -525,6 +525,7 @@ int quip_block_engine(const quip_block_engine_args* in, quip_stream_t stream) {
   if (in->codebook == 4 && (!in->grid2 || (reinterpret_cast<uintptr_t>(in->grid2) & 7u) != 0))
     return in->grid2 ? QUIP_ERR_MISALIGNED : QUIP_ERR_NULL_POINTER;
   if (in->shape == 1) return block_engine_gqa_launch(a, (hipStream_t)stream);
+  if (in->shape == 2) return block_engine_g8_launch(a, (hipStream_t)stream);
   if (in->shape != 0) return QUIP_ERR_UNSUPPORTED;
   return block_engine_launch(a, (hipStream_t)stream);
 }
@@ -533,6 +534,10 @@ int quip_block_engine_gqa_supported(int32_t hidden, int32_t heads, int32_t kv_he
   return block_engine_gqa_supported(hidden, heads, kv_heads, head_dim, n_ffn, K) ? 1 : 0;
 }
 size_t quip_block_engine_gqa_workspace_bytes(void) { return block_engine_gqa_workspace_bytes(); }
+int quip_block_engine_g8_supported(int32_t hidden, int32_t heads, int32_t kv_heads, int32_t head_dim, int32_t n_ffn, int32_t K) {
+  return block_engine_g8_supported(hidden, heads, kv_heads, head_dim, n_ffn, K) ? 1 : 0;
+}
+size_t quip_block_engine_g8_workspace_bytes(void) { return block_engine_g8_workspace_bytes(); }
 
 size_t quip_rope_attn_workspace_bytes(int32_t heads, int32_t head_dim) {
   return heads > 0 && head_dim > 0 ? rope_attn_workspace_bytes(heads, head_dim) : 0;

@@ -87,8 +87,25 @@ struct BlockArgs {
 
 constexpr int kWaves = 8, kThreads = 512;
 constexpr int HID = 4096, NWG = 256, RPW = 16, HD = 128, NH = 32;
-constexpr int FK = 43, FLOGL = 8, FL = 256, NFFN = FK * FL, FRB = 3;
-constexpr int KPD = 11264, JD = 22;                  // digits of down's input, slices
+// Round 5: the SAME kernel for the grouped-query 4096-wide shape of Llama-3-8B / Mistral-7B (32 heads on 8 KV heads, n_ffn =
+// 14336 = 7 x 2048), compiled from this file a second time with QUIP_BLOCK_G8 = 1 (decode_block_g8.hip).  Its MLP is the
+// (43, 256) machinery with K = 56: the reference's transform of a 14336-vector, (R_7 (x) H_2048) / sqrt(2048) on the (7, 2048)
+// view (quant.py:26-39, 72-88), IS ((R_7 (x) H_8) (x) H_256) / (sqrt 8 sqrt 256) on the (56, 256) view -- H_2048 = H_8 (x) H_256
+// in Sylvester order, index k 2048 + j8 256 + j = (8 k + j8) 256 + j -- so the host hands over the 56 x 56 factors
+// R_7 (x) H_8 (entries +-R_7: exact in fp16) and the kernel folds the 1 / sqrt 8 into its scales (kMixScale, sc[6]).
+// G8 differs in: the q / k / v row blocks (384 instead of 768: one or two per workgroup), the KV head of a query head, seven
+// gate / up items and four down items per wave on the nine slots, E8P12 only.
+#ifndef QUIP_BLOCK_G8
+#define QUIP_BLOCK_G8 0
+#endif
+constexpr bool G8 = QUIP_BLOCK_G8 != 0;
+constexpr int NKVH = G8 ? 8 : NH, GQH = NH / NKVH;              // KV heads; query heads per KV head
+constexpr int FK = G8 ? 56 : 43, FLOGL = 8, FL = 256, NFFN = FK * FL, FRB = 3;
+constexpr int NGU = G8 ? 7 : 6;                                 // gate / up items per wave (G8: 2 columns x 56 rows = 7 row blocks)
+constexpr int KPD = G8 ? 14336 : 11264, JD = G8 ? 28 : 22;      // digits of down's input, slices
+constexpr int ND = G8 ? 4 : 3;                                  // down items per wave
+constexpr float kMixScale = G8 ? 0.35355339059327373f : 1.f;    // 1 / sqrt 8 of H_8 inside the 56 x 56 factors
+constexpr int QKB = G8 ? 384 : 768;                             // 16-row blocks of the stacked [q; k; v] rows
 constexpr int kRowU4 = HID / 64, kRowU4D = NFFN / 64;
 constexpr int NSLOT = 9;                             // X0-2: q k v, then gate's row blocks | X3-5: o, then up's | X6-8: down
 
@@ -118,17 +135,18 @@ struct BLds {
   // and multiplies x' = [s x_g | x_g]_g: twice the digits per vector, twice the items per product (hadamard.hip, rvq_scale)
   static constexpr int VM = RVQ ? 2 : 1, KV = VM * HID;
   static constexpr int KPDV = RVQ ? 22528 : KPD, JDV = RVQ ? 43 : JD;   // digits of down's input (virtual, padded), its slices
-  static constexpr int KKP = (FK * FK + 7) & ~7, KP16 = 48;
-  static constexpr int kAcc = T::kAcc;                       // int32 [176][4]: q k v (48) | o (16) | gate up (96) | down (16)
-  static constexpr int kAccRows = 176;
-  static constexpr int kZcol = kAcc + kAccRows * 16;         // float [2][48]: z of this column (MLP)
-  static constexpr int kRed = kZcol + 2 * 48 * 4;            // float [64] reduction scratch, int [8] shift words
+  static constexpr int KKP = (FK * FK + 7) & ~7, KP16 = G8 ? 64 : 48;
+  static constexpr int kAcc = T::kAcc;                       // int32 [176][4]: q k v (48) | o (16) | gate up (96; G8: 112) | down (16)
+  static constexpr int AGU = 64, AD = AGU + 16 * NGU;        // accumulator rows of gate / up and of down
+  static constexpr int kAccRows = AD + 16;
+  static constexpr int kZcol = kAcc + kAccRows * 16;         // float [2][KP16]: z of this workgroup's two columns (MLP)
+  static constexpr int kRed = kZcol + 2 * KP16 * 4;          // float [64] reduction scratch, int [8] shift words
   static constexpr int kDesc = kRed + 256 + 32;              // the current block's descriptor (256 bytes): pointers are read
                                                              // from here, not from memory (a vector load of a pointer ahead of
                                                              // every request would wait for the requests before it)
-  static constexpr int kH = kDesc + 256;                     // (fp16 [4096]: the residual stream of rounds 3-4; it lives in registers now)
-  static constexpr int kDescN = kH;                          // the next block's descriptor (256 bytes)
-  static constexpr int kQkv = kH + HID * 2;                  // fp16 [3][128]: this head's q, k, v; [128] attention output
+  static constexpr int kDescN = kDesc + 256;                 // the next block's descriptor (256 bytes).  (The residual stream
+                                                             // of rounds 3-4, 8 KB here, lives in registers now.)
+  static constexpr int kQkv = kDescN + 256;                  // fp16 [3][128]: this head's q, k, v; [128] attention output
   static constexpr int kCs = kQkv + 4 * HD * 2;              // float [2][128]: the rotary row of this token (cos | sin), the same for every block
   // ONE transient area for everything that lives between two products (E8P12: T1 x 32 + T2 x 16 = 96 KB of tables leave 50.3 KB).
   // In time: the transforms' exchange buffers (16.5 KB per transform from the base: 1, 2 or -- attention -- 3) -> digit planes
@@ -142,17 +160,25 @@ struct BLds {
   static constexpr int kBuf0 = kArea;
   static constexpr int kHadElems = 2 * KKP + KP16 * KP16;
   static constexpr int kStage = kArea + 8 * 1024;            // MLP row owners: their four rows, transposed, on the way out (4 KB)
-  static constexpr int kHad = kArea + 2 * 3 * KV;            // fp16 image of the three K x K factors (12 KB), behind the planes of gate / up
-  static constexpr int kStash = kHad + 12 * 1024;            // MLP row owners: SV_gate / SV_up / SU_down of their rows (6 KB)
+  // fp16 image of the three K x K factors (12 KB; G8: 20.3 KB), behind the planes of gate / up and behind the rows' LDS image
+  // ([KP16 / 2][256] fp16 pairs = 24 KB; G8: 32 KB)
+  static constexpr int kHad = kArea + (G8 ? 32 * 1024 : 2 * 3 * KV);
+  // MLP row owners: SV_gate / SV_up / SU_down of their rows (6 KB): behind the factor image; G8: at 16 K (free while they are alive:
+  // the planes of the ONE consumer end at 12 K, the owners' rows and staging at 12 K)
+  static constexpr int kStash = G8 ? kArea + 16 * 1024 : kHad + 12 * 1024;
   static constexpr int kPlaneD = (KPDV / 256) * 272;
   static constexpr int kBytes = kArea + kAreaBytes;
-  static_assert(kAreaBytes >= 3 * kBufBytes && kAreaBytes >= FL * KP16 * 4 && kAreaBytes >= 3 * kPlaneD && kHadElems * 2 <= 12 * 1024 &&
-                kStash + 6 * 1024 <= kArea + kAreaBytes,
+  static_assert(kAreaBytes >= 3 * kBufBytes && kAreaBytes >= FL * KP16 * 2 && kAreaBytes >= 3 * kPlaneD &&
+                kHad + kHadElems * 2 <= kArea + kAreaBytes && kStash + 6 * 1024 <= (G8 ? kHad : kArea + kAreaBytes),
                 "transient area");
 };
+#if QUIP_BLOCK_G8
+static_assert(BLds<24>::kBytes <= 160 * 1024, "LDS budget");
+#else
 static_assert(BLds<24>::kBytes <= 160 * 1024 && BLds<16>::kBytes <= 160 * 1024 && BLds<64>::kBytes <= 160 * 1024 &&
               BLds<16, true>::kBytes <= 160 * 1024 && BLds<64, true>::kBytes <= 160 * 1024 && BLds<12, true>::kBytes <= 160 * 1024,
               "LDS budget");
+#endif
 
 // RVQ: rows of twice the (virtual) width.  HI (with RVQ and the D4 table mode): the HI codebook -- a code byte holds two
 // nibbles and reads as a D4 code of the virtual row with the table entry [lo - 7.5, hi - 7.5, 0, 0], against
@@ -191,7 +217,10 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   uint64_t* pbuf = reinterpret_cast<uint64_t*>(a.ws + kWsPart);
   // (kWsKvNew: the k / v hand-off inside a head's group of rounds 3-4; unused since the heads transform q, k, v themselves)
   int dbg_on = 0;
-#define BSTAMP(i) do { if (dbg_on && tid == 0) a.dbg[w * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+  // (dbg_layer bit 16: the stamps are s_memrealtime -- 100 MHz, ONE counter for the whole device -- instead of s_memtime, whose
+  //  counters differ between XCDs: which workgroup gets to a stamp last can only be read off the former)
+  const bool dbg_rt = (a.dbg_layer & 0x10000) != 0;
+#define BSTAMP(i) do { if (dbg_on && tid == 0) a.dbg[w * 32 + (i)] = dbg_rt ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
 
   // ---- weight slots ---------------------------------------------------------------------------------------------
   slot_t qa[NSLOT], qb[NSLOT];
@@ -200,13 +229,38 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   // [16 w, +16) (slice = wave); 4..9 = gate / up row block (kind - 4) % 3 of matrix (kind - 4) / 3 (rows k * 256 + w);
   // 10..12 = down, slice (kind - 10) * 8 + wave.  A load = scalar base of the matrix + a 32-bit byte offset of this
   // lane (+ 64 for the second half of the item).
-  uint32_t vo_row, vo_q[3], vo_gu[FRB], vo_d[3], vo_d2b, vo_dr[3];
+  uint32_t vo_row, vo_q[3], vo_gu[G8 ? 7 : FRB], vo_d[G8 ? 4 : 3], vo_d2b, vo_dr[3];
+  // G8: the stacked [q; k; v] rows are 384 blocks of 16 (q 0..255, k 256..319, v 320..383): two on the even workgroups, one on
+  // the odd ones -- blocks qb0 .. qb0 + qcnt - 1; all but workgroup 170 (q 255 | k 0) stay inside one matrix
+  const int qb0 = (3 * w + (w & 1)) >> 1, qcnt = 2 - (w & 1);
+  auto qmat = [](int b) { return b < 256 ? 0 : (b < 320 ? 1 : 2); };
+  auto qblk = [](int b) { return b < 256 ? b : (b < 320 ? b - 256 : b - 320); };
   uint32_t lane_c, lane_c2, lane_c3 = 0u, xlane;
   auto rederive = [&]() {
     int t = threadIdx.x;
     asm volatile("" : "+v"(t));
     tid = t; lane = t & 63; n = lane & 15; q = lane >> 4;
     vo_row = (uint32_t)((w * RPW + n) * kRowU4V + wave * 8 + q) * PB;
+    if constexpr (G8) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {      // (an odd workgroup's second item: its one block once more, never multiplied)
+        const int bq = qb0 + (i < qcnt ? i : 0);
+        vo_q[i] = (uint32_t)((qblk(bq) * 16 + n) * kRowU4V + wave * 8 + q) * PB;
+      }
+      vo_q[2] = vo_q[0];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {      // rows k * 256 + column of this workgroup's two columns, as 112 consecutive (column, k)
+        const int r = 16 * i + n, c = r >= FK ? 1 : 0, k = r - FK * c;
+        vo_gu[i] = (uint32_t)((k * FL + 2 * (w & 127) + c) * kRowU4V + wave * 8 + q) * PB;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {      // down: slice 8 i + wave of the 28 (the fourth item exists on waves 0..3)
+        const int sl0 = i * kWaves + wave;
+        const int sl = sl0 < JD ? sl0 : 0;
+        vo_d[i] = (uint32_t)(((w * RPW + n) * kRowU4D + sl * 8 + q) * 16);
+      }
+      vo_d2b = 0u;
+    } else {
 #pragma unroll
     for (int i = 0; i < 3; ++i) vo_q[i] = (uint32_t)((((3 * w + i) & 255) * 16 + n) * kRowU4V + wave * 8 + q) * PB;
 #pragma unroll
@@ -225,6 +279,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         off = off < kRowU4D ? off : kRowU4D - 1;       // the row's last slice is a half one: its digits beyond are zero
         vo_d2b = (uint32_t)(((w * RPW + n) * kRowU4D + off) * 16);
       }
+    }
     }
     // RVQ: down's 43 virtual slices: slice wave + 8 i, i < 6, at vo_dr[i >> 2] + (i & 3) KB (the sixth exists for waves 0..2)
     vo_dr[0] = (uint32_t)((w * RPW + n) * kRowU4DV + wave * 8 + q) * PB;
@@ -308,6 +363,11 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     ld_item_o(OFFC(0), qa[4], qb[4], Ld.W[6], vo_dr[1]);                                                        \
     ld_item_o(OFFC(0), qa[5], qb[5], Ld.W[6], vo_dr[2]);      /* (waves 3..7: slice wave + 32 again, not multiplied) */ \
   } while (0)
+  // G8 slot plan: the next block's q / k / v items -> X2, X3 | o -> X3 | gate / up items 0..6 -> X0..X6 | down items 0..3 -> X7, X8,
+  // X0, X1 (requested once gate / up's first four items have been multiplied)
+#define ISSUE8_QKV(Ld, i) ld_item(qa[2 + (i)], qb[2 + (i)], Ld.W[qmat(qb0 + ((i) < qcnt ? (i) : 0))], vo_q[i])
+#define ISSUE8_GU(Ld, i) ld_item(qa[i], qb[i], Ld.W[4 + mgu], vo_gu[i])
+#define ISSUE8_DOWN(Ld, i) ld_item(qa[(i) < 2 ? 7 + (i) : (i) - 2], qb[(i) < 2 ? 7 + (i) : (i) - 2], Ld.W[6], vo_d[i])
   // after a drain: every slot is a plain register again
   // (`mask`: the slots that can be in flight at that point.  The others are dead there, and saying so frees their
   //  registers for the phase: the attention prologue keeps 8 of the 72 slot registers)
@@ -319,8 +379,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   };
 #define SLOTS(m) std::integral_constant<unsigned, (m)>{}
   // slots of the items of a product (see ISSUE / ISSUE_RVQ_*)
-  constexpr unsigned M_QKV = RVQ ? 0x03fu : 0x007u, M_O = RVQ ? 0x0c0u : 0x008u, M_GATE = RVQ ? 0x03fu : 0x007u;
-  constexpr unsigned M_UP = RVQ ? 0x1c0u : 0x038u /* RVQ: up's first half */, M_DOWN = RVQ ? 0x03fu : 0x1c0u;
+  constexpr unsigned M_QKV = G8 ? 0x00cu : (RVQ ? 0x03fu : 0x007u), M_O = RVQ ? 0x0c0u : 0x008u, M_GATE = RVQ ? 0x03fu : 0x007u;
+  constexpr unsigned M_UP = G8 ? 0x078u : (RVQ ? 0x1c0u : 0x038u) /* RVQ: up's first half */, M_DOWN = G8 ? 0x183u : (RVQ ? 0x03fu : 0x1c0u);
+  static_assert(!G8 || (!RVQ && !HI && REP == 24), "the grouped-query 4096-wide shape: E8P12 only");
 
   // ---- prologue ---------------------------------------------------------------------------------------------------
   u32x2 tsrc;
@@ -339,9 +400,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     asm volatile("global_load_ushort %0, %1, off" : "=v"(hraw[k]) : "v"(reinterpret_cast<const uint16_t*>(a.h_in) + tid + 512 * k) : "memory");
   {
     const BlockLayer& L0 = a.layers[0];
-    if constexpr (RVQ) ISSUE_RVQ_QKV(L0); else { ISSUE(L0, 0); ISSUE(L0, 1); ISSUE(L0, 2); }
+    if constexpr (RVQ) ISSUE_RVQ_QKV(L0); else if constexpr (G8) { ISSUE8_QKV(L0, 0); ISSUE8_QKV(L0, 1); } else { ISSUE(L0, 0); ISSUE(L0, 1); ISSUE(L0, 2); }
   }
-  constexpr int NQ = RVQ ? 12 : 6;                   // loads of the first q, k, v items in flight across the prologue
+  constexpr int NQ = RVQ ? 12 : (G8 ? 4 : 6);        // loads of the first q, k, v items in flight across the prologue
   int* accs = reinterpret_cast<int*>(smem + B::kAcc);
   for (int i = tid; i < B::kAccRows * 4; i += kThreads) accs[i] = 0;
   asm volatile("s_waitcnt vmcnt(%2)" : "+v"(tsrc), "+v"(tsrc3) : "n"(9 + NQ) : "memory");
@@ -664,6 +725,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   const BlockLayer& Ld = *reinterpret_cast<const BlockLayer*>(smem + B::kDesc);
   const BlockLayer& Ln = *reinterpret_cast<const BlockLayer*>(smem + B::kDescN);
   constexpr bool kPreQkv = QUIP_PREDECODE_QKV > 0 && !RVQ;
+  // slot of down's item i | of the (next block's) q / k / v item i
+  constexpr auto SDf = [](int i) { return G8 ? (i < 2 ? 7 + i : i - 2) : 6 + i; };
+  constexpr auto SQf = [](int i) { return G8 ? 2 + i : i; };
   if (tid < 64) reinterpret_cast<uint32_t*>(smem + B::kDesc)[tid] = reinterpret_cast<const uint32_t*>(a.layers)[tid];
   had::wg_barrier<true>();
   // ================= P1: [output side of the previous block's down_proj + residual,] RMSNorm, input transforms of q, k, v of
@@ -672,10 +736,48 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   //  hand-off of z_d and are consumed before the loop's back edge, where no request may be in flight -- the compiler is free to
   //  copy registers there)
   constexpr int NPQ = QUIP_PREDECODE_QKV > 0 ? QUIP_PREDECODE_QKV : 1;
+  // the first / last of the one or two matrices (q 0, k 1, v 2) this workgroup's q / k / v row blocks are in
+  const int qc_lo = G8 ? qmat(qb0) : ((3 * w) >> 8), qc_hi = G8 ? qmat(qb0 + qcnt - 1) : ((3 * w + 2) >> 8);
+  // one item against the A fragments of its K slice: decoded earlier (pre, as scalars) or from slot `slot_c`
+  auto item_vs = [&](auto slot_c, const uint32_t* pre, const i32x4 (&A)[8]) -> i32x4 {
+    constexpr int S = decltype(slot_c)::value;
+    if (pre) {
+      i32x4 r = {0, 0, 0, 0};
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const i32x4 Bt = {(int)pre[4 * t], (int)pre[4 * t + 1], (int)pre[4 * t + 2], (int)pre[4 * t + 3]};
+        r = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t], Bt, r, 0, 0, 0);
+      }
+      return r;
+    }
+    ItemAddr ad;
+    item_addresses<REP>(qa[S], qb[S], lane_c, lane_c2, ad, lane_c3);
+    return item_mfma_shared<T::kD4, R3>(ad, A);
+  };
   auto P1_products = [&](auto pre_tag, const uint32_t (&preq)[NPQ][32]) {
-    const int c_lo = (3 * w) >> 8;                   // the first of the one or two matrices this workgroup's row blocks are in
+    const int c_lo = qc_lo;
     esync::drain();                                    // q, k, v have landed
     own_slots(SLOTS(M_QKV));
+    if constexpr (G8) {
+      // one or two items (slots X2, X3); the second one's planes are consumer 1's where it lies in the next matrix (workgroup 170)
+      constexpr bool PRE = decltype(pre_tag)::value;
+      i32x4 A[8];
+      item_fragments(xlane, A);
+      add_rows(item_vs(std::integral_constant<int, 2>{}, PRE ? preq[0] : nullptr, A), 0);
+      if (qcnt == 2) {
+        if (qc_hi != qc_lo) item_fragments(xlane + (uint32_t)(3 * KV), A);
+        add_rows(item_vs(std::integral_constant<int, 3>{}, (PRE && NPQ > 1) ? preq[NPQ > 1 ? 1 : 0] : nullptr, A), 16);
+      }
+      had::wg_barrier<true>();
+      ++hop;                                           // hand-off: z_q, z_k, z_v
+      const int sh_lo = shs[0], sh_hi = shs[1];
+      publish16(qc_lo, qblk(qb0) * 8, 0, sh_lo, ebase | hop);
+      if (qcnt == 2) publish16(qc_hi, qblk(qb0 + 1) * 8, 16, qc_hi == qc_lo ? sh_lo : sh_hi, ebase | hop);
+      had::wg_barrier<true>();
+      zero_acc(0, 48);
+      BSTAMP(3);
+      return;
+    }
     {
       const uint32_t x0 = xlane + (uint32_t)((((3 * w) >> 8) == c_lo ? 0 : 1) * 3 * KV);
       const uint32_t x1 = xlane + (uint32_t)((((3 * w + 1) >> 8) == c_lo ? 0 : 1) * 3 * KV);
@@ -698,14 +800,14 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   };
   {
     rederive();
-    const int c_lo = (3 * w) >> 8, c_hi = (3 * w + 2) >> 8;
+    const int c_lo = qc_lo, c_hi = qc_hi;
     edge(std::false_type{}, std::integral_constant<int, 2>{}, SLOTS(M_QKV), -1, 0u, 0u, nullptr, Ld.ln[0], Ld.su[c_lo], Ld.su[c_hi],
          Ld.sc[c_lo], Ld.sc[c_hi], c_hi != c_lo, [&]() {}, [&]() {}, [&]() {});
     uint32_t none[NPQ][32];                          // (block 0: nothing decoded ahead; never read)
     P1_products(std::false_type{}, none);
   }
   for (int l = 0; l < a.n_layers; ++l) {
-    dbg_on = a.dbg != nullptr && l == a.dbg_layer;
+    dbg_on = a.dbg != nullptr && l == (a.dbg_layer & 0xffff);
     rederive();
     BSTAMP(0);
     // the NEXT block's descriptor (the last block: its own once more), for the early requests of its q, k, v rows; read long
@@ -738,8 +840,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       //  visited in the same order either way)
       constexpr int LPK = HD / 8, NG = 256 / LPK, U = (RVQ && !HI && !R3) ? 2 : 4;
       const int g = (tid & 255) / LPK;
-      const f16* kc = Ld.kcache + (size_t)hd * a.max_len * HD;
-      const f16* vc = Ld.vcache + (size_t)hd * a.max_len * HD;
+      const int kvh = hd / GQH;                        // the KV head of this query head (G8: four query heads per KV head)
+      const f16* kc = Ld.kcache + (size_t)kvh * a.max_len * HD;
+      const f16* vc = Ld.vcache + (size_t)kvh * a.max_len * HD;
       uint4 kr0[U], vr0[U], kr1[U], vr1[U];
       // local index i of this workgroup <-> position part + nparts i; a round = local indices i0 + u NG, u < U
       auto load_round = [&](uint4 (&kr)[U], uint4 (&vr)[U], int i0) {
@@ -762,17 +865,40 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         // segments, then a 128-point transform in ONE wave per vector -- instead of a 4096-point transform of q here and of k, v
         // on two more workgroups with one more hand-off inside the head's group (rounds 3-4: 1.8K clocks + that hop).
         // Thread t holds z[8 t + r]: j1 = t >> 4 = (lane >> 4) + 4 wave, j2 = 8 (t & 15) + r.
-        float v[3][8];
-        gather(std::integral_constant<int, 3>{}, SLOTS(M_O), 0, ebase | hop, 0x5000u, v);
+        // G8: z_k, z_v are 1024-vectors (512 granules): thread t takes granule t of each -- z[2 t], z[2 t + 1], segment j1 = t >> 6 =
+        // the wave, so their signed segment sums (H_1024 = H_8 (x) H_128) are the sum over the waves' values alone.
+        constexpr int NVV = G8 ? 1 : 3;                  // 4096-vectors that go through the lane swaps
+        float v[NVV][8];
+        u32x2_t gk = {0u, 0u}, gv = {0u, 0u};
+        if constexpr (G8) {
+          u32x4_t p[2];
+          uint32_t spins = 0;
+          const uint64_t* src = zbufs + 4 * tid;
+          const uint32_t tagq = ebase | hop;
+          for (;;) {
+            esync::ld16(p[0], src);
+            esync::ld16(p[1], src + 2);
+            esync::ld8(gk, zbufs + 2048 + tid);
+            esync::ld8(gv, zbufs + 2 * 2048 + tid);
+            esync::drain();
+            esync::own(p[0]); esync::own(p[1]); esync::own(gk); esync::own(gv);
+            const bool ok = p[0].y == tagq && p[0].w == tagq && p[1].y == tagq && p[1].w == tagq && gk.y == tagq && gv.y == tagq;
+            if (esync::spin_step(ok, spins, ctl + 1, 0x5000u + (uint32_t)w)) break;
+          }
+          had::unpack8(make_uint4(p[0].x, p[0].z, p[1].x, p[1].z), v[0]);
+          own_slots(SLOTS(M_O));
+        } else {
+          gather(std::integral_constant<int, 3>{}, SLOTS(M_O), 0, ebase | hop, 0x5000u, v);
+        }
         BSTAMP(4);
         // H_32[hd][j1] = (-1)^popcount(hd & j1): lane bit 5 <-> hd bit 1, lane bit 4 <-> hd bit 0 (folded into the two swap
         // steps), the wave <-> hd bits 2..4 (folded into the sum over the waves' partial results)
         // (scalar registers: as vector constants they were hoisted out of the block loop and held two registers for the whole launch)
         const float sg1 = as_f32((uint32_t)__builtin_amdgcn_readfirstlane((int)((hd & 2) ? 0xbf800000u : 0x3f800000u)));
         const float sg0 = as_f32((uint32_t)__builtin_amdgcn_readfirstlane((int)((hd & 1) ? 0xbf800000u : 0x3f800000u)));
-        float P[12], Q[6];
+        float P[4 * NVV], Q[2 * NVV];
 #pragma unroll
-        for (int pi = 0; pi < 12; ++pi) {
+        for (int pi = 0; pi < 4 * NVV; ++pi) {
           // lanes l and l ^ 32 of the values 2 pi and 2 pi + 1: lower half <- value 2 pi, upper half <- value 2 pi + 1
           const int va = 2 * pi, vb = 2 * pi + 1;
           const auto t = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v[va >> 3][va & 7]),
@@ -780,7 +906,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           P[pi] = __builtin_fmaf(__builtin_bit_cast(float, (unsigned)t[1]), sg1, __builtin_bit_cast(float, (unsigned)t[0]));
         }
 #pragma unroll
-        for (int si = 0; si < 6; ++si) {
+        for (int si = 0; si < 2 * NVV; ++si) {
           // rows (16 lanes) r and r ^ 1: row 0 <- value 4 si, row 1 <- value 4 si + 2, row 2 <- 4 si + 1, row 3 <- 4 si + 3
           const auto t = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, P[2 * si]), __builtin_bit_cast(unsigned, P[2 * si + 1]), false, false);
           Q[si] = __builtin_fmaf(__builtin_bit_cast(float, (unsigned)t[1]), sg0, __builtin_bit_cast(float, (unsigned)t[0]));
@@ -790,9 +916,14 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           const int row = lane >> 4, cc = lane & 15;
           const int vsel = ((row & 1) << 1) | (row >> 1);                  // {0, 2, 1, 3}[row]
 #pragma unroll
-          for (int si = 0; si < 6; ++si) {
+          for (int si = 0; si < 2 * NVV; ++si) {
             const int vi = 4 * si + vsel;                                   // value index: vector vi >> 3, register vi & 7
             xbuf[((vi >> 3) * 8 + wave) * HD + 8 * cc + (vi & 7)] = Q[si];
+          }
+          if constexpr (G8) {      // k, v: this wave's segment as it is (the signs H_8[kv head][wave] ride on the sum below)
+            const f16x2 hk = as_f16x2(gk.x), hv = as_f16x2(gv.x);
+            *reinterpret_cast<float2*>(xbuf + (1 * 8 + wave) * HD + 2 * lane) = make_float2((float)hk.x, (float)hk.y);
+            *reinterpret_cast<float2*>(xbuf + (2 * 8 + wave) * HD + 2 * lane) = make_float2((float)hv.x, (float)hv.y);
           }
         }
         had::wg_barrier<true>();
@@ -802,6 +933,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           for (int gg = 0; gg < 8; ++gg) {
             // (the sign as a scalar xor mask: eight +-1.0 constants in vector registers were hoisted out of the block loop and
             //  lived -- and spilled -- across the whole launch)
+            // (G8: hd >> 2 is also the KV head, and the waves are z_k's / z_v's eight segments: the same mask for all three)
             const uint32_t sm = ((uint32_t)__builtin_popcount((uint32_t)(hd >> 2) & (uint32_t)gg) & 1u) << 31;
             const float2 pr = *reinterpret_cast<const float2*>(xbuf + (wave * 8 + gg) * HD + 2 * lane);
             y[0] = had::fadd(y[0], as_f32(as_u32(pr.x) ^ sm));
@@ -809,9 +941,10 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           }
           hadw::reg_stage<2, 1>(y);
           hadw::lane_stages<2, 0, 6>(y, lane);
-          const f16x2 svp = as_f16x2(*reinterpret_cast<const uint32_t*>(Ld.sv[wave] + HD * hd + 2 * lane));
-          s_qkv[wave * HD + 2 * lane] = had::out_elem(y[0], 1.f / 64.f, true, (float)svp.x, false, 0.f, false, 0.f);
-          s_qkv[wave * HD + 2 * lane + 1] = had::out_elem(y[1], 1.f / 64.f, true, (float)svp.y, false, 0.f, false, 0.f);
+          const f16x2 svp = as_f16x2(*reinterpret_cast<const uint32_t*>(Ld.sv[wave] + HD * ((G8 && wave > 0) ? kvh : hd) + 2 * lane));
+          const float osc = (G8 && wave > 0) ? 1.f / 32.f : 1.f / 64.f;      // 1 / sqrt(1024) | 1 / sqrt(4096)
+          s_qkv[wave * HD + 2 * lane] = had::out_elem(y[0], osc, true, (float)svp.x, false, 0.f, false, 0.f);
+          s_qkv[wave * HD + 2 * lane + 1] = had::out_elem(y[1], osc, true, (float)svp.y, false, 0.f, false, 0.f);
         }
       }
       // (the gather has drained the queue; said once more for tools/check_inflight.py)
@@ -880,7 +1013,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           rope8(s_qkv + HD, kn);
           const uint4 vraw = *reinterpret_cast<const uint4*>(s_qkv + 2 * HD + d0);
           unpack8h(vraw, vn);
-          if (g == 0 && pos_ok && part == (split ? (pos & (kParts - 1)) : 0)) {   // append the new row (StaticCache.update): once
+          if (g == 0 && pos_ok && (hd % GQH) == 0 && part == (split ? (pos & (kParts - 1)) : 0)) {   // append the new row (StaticCache.update): once per KV head
             uint4 kr;
             kr.x = pack_f16(kn[0], kn[1]); kr.y = pack_f16(kn[2], kn[3]);
             kr.z = pack_f16(kn[4], kn[5]); kr.w = pack_f16(kn[6], kn[7]);
@@ -1027,15 +1160,15 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       asm volatile("" : "+v"(psu));
       // gate's row blocks (the slots of q, k, v: consumed) once the hand-off is through, one at a time between the stages
       // of o's input side: they have o's product, a hand-off and an edge to land
-      if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 0); else ISSUE(Ld, 4);
+      if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 0); else if constexpr (G8) ISSUE8_GU(Ld, 0); else ISSUE(Ld, 4);
       BSTAMP(7);
 #if QUIP_INO_EXACT      /* A/B (tools/dbg): rounds 3-4's o input side -- the exact maximum behind the transform */
       had::mul8(v[0], make_uint4(psu.x, psu.y, psu.z, psu.w));
       had8::fht4096<1, true>(v, xbuf, tid);
-      if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 1); else ISSUE(Ld, 5);
+      if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 1); else if constexpr (G8) ISSUE8_GU(Ld, 1); else ISSUE(Ld, 5);
       const float sco = Ld.sc[3];
       const float mx = had8::max4096<true>(had8::absmax8(v[0], sco), red, tid);
-      if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 2); else ISSUE(Ld, 6);
+      if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 2); else if constexpr (G8) ISSUE8_GU(Ld, 2); else ISSUE(Ld, 6);
       const int sh = had::shift_for(mx * ((RVQ && !HI) ? fmaxf(1.f, fabsf(a.resid_scale)) : 1.f));
 #else
       had::mul8(v[0], make_uint4(psu.x, psu.y, psu.z, psu.w));
@@ -1050,11 +1183,11 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         if ((tid & 63) == 63) red[wave] = n0;
       }
       had8::fht4096<1, true>(v, xbuf, tid);
-      if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 1); else ISSUE(Ld, 5);
+      if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 1); else if constexpr (G8) ISSUE8_GU(Ld, 1); else ISSUE(Ld, 5);
       const float sco = Ld.sc[3];
       had::wg_barrier<true>();                         // the transform's last reads of the exchange buffer: the planes land on it
       const int sh = norm_shift(red_sum8(0), sco);
-      if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 2); else ISSUE(Ld, 6);
+      if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 2); else if constexpr (G8) ISSUE8_GU(Ld, 2); else ISSUE(Ld, 6);
 #endif
       if constexpr (HI) had8::planes_scatter_hi(v[0], sco, sh, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
       else if constexpr (RVQ) had8::planes_scatter_rvq(v[0], sco, a.resid_scale, sh, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
@@ -1099,9 +1232,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     // (ONE consumer per workgroup: its half of the machine multiplies gate, the other half up)
     edge(std::true_type{}, std::integral_constant<int, 2>{}, SLOTS(M_GATE), 4, ebase | hop, 0x7000u, Ld.sv[3], Ld.ln[1], Ld.su[4 + mgu], Ld.su[4 + mgu], Ld.sc[4 + mgu], Ld.sc[4 + mgu], false,
          // up's row blocks (RVQ: their first virtual slice) behind the hand-off, one at a time between the edge's stages
-         [&]() { BSTAMP(10); if constexpr (RVQ) ISSUE_RVQ_UP_A_G(Ld, 0); else ISSUE(Ld, 7); },
-         [&]() { if constexpr (RVQ) ISSUE_RVQ_UP_A_G(Ld, 1); else ISSUE(Ld, 8); },
-         [&]() { if constexpr (RVQ) ISSUE_RVQ_UP_A_G(Ld, 2); else ISSUE(Ld, 9); }, 18);
+         [&]() { BSTAMP(10); if constexpr (RVQ) ISSUE_RVQ_UP_A_G(Ld, 0); else if constexpr (G8) { ISSUE8_GU(Ld, 3); ISSUE8_GU(Ld, 4); } else ISSUE(Ld, 7); },
+         [&]() { if constexpr (RVQ) ISSUE_RVQ_UP_A_G(Ld, 1); else if constexpr (G8) ISSUE8_GU(Ld, 5); else ISSUE(Ld, 8); },
+         [&]() { if constexpr (RVQ) ISSUE_RVQ_UP_A_G(Ld, 2); else if constexpr (G8) ISSUE8_GU(Ld, 6); else ISSUE(Ld, 9); }, 18);
     BSTAMP(11);
     // row owners (w < NRO: rows k' = RPO w .. RPO w + RPO - 1, one per wave): SV_gate / SV_up / SU_down of their rows into the free
     // tail of the area; everybody: the image of the K x K factors, for the MLP edge
@@ -1136,6 +1269,25 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       // from any poll (a burst in front of a poll delays its first check by a memory latency: in front of the row owners'
       // rows poll it made them 2.9K clocks late for down's product, profiles/r05_block_stamps.txt).  Rounds 3-4 requested
       // them behind the rows' sweep, a third at a time: the last third was still on its way when the planes were done.
+      if constexpr (G8) {
+        // seven items (slots X0..X6) against the same planes; down's four (X7, X8, X0, X1) requested behind the fourth
+        i32x4 A[8];
+        item_fragments(xlane, A);
+#if QUIP_PREDECODE_GATE
+#define PRE_G(i) ((i) < QUIP_PREDECODE_GATE ? Bg[(i) < QUIP_PREDECODE_GATE ? (i) : 0] : nullptr)
+#else
+#define PRE_G(i) nullptr
+#endif
+        add_rows(item_vs(std::integral_constant<int, 0>{}, PRE_G(0), A), B::AGU);
+        add_rows(item_vs(std::integral_constant<int, 1>{}, PRE_G(1), A), B::AGU + 16);
+        add_rows(item_vs(std::integral_constant<int, 2>{}, nullptr, A), B::AGU + 32);
+        add_rows(item_vs(std::integral_constant<int, 3>{}, nullptr, A), B::AGU + 48);
+        ISSUE8_DOWN(Ld, 0); ISSUE8_DOWN(Ld, 1); ISSUE8_DOWN(Ld, 2); ISSUE8_DOWN(Ld, 3);
+        add_rows(item_vs(std::integral_constant<int, 4>{}, nullptr, A), B::AGU + 64);
+        add_rows(item_vs(std::integral_constant<int, 5>{}, nullptr, A), B::AGU + 80);
+        add_rows(item_vs(std::integral_constant<int, 6>{}, nullptr, A), B::AGU + 96);
+#undef PRE_G
+      } else {
       ISSUE(Ld, 10); ISSUE(Ld, 11); ISSUE(Ld, 12);
 #if QUIP_PREDECODE_GATE
       run_items3_pre(std::integral_constant<int, QUIP_PREDECODE_GATE>{}, Bg, 0, xlane, xlane, xlane, 64);
@@ -1144,6 +1296,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       run_items3(0, xlane, xlane, xlane, 64);                                     // first column's three row blocks
 #endif
       run_items3(FRB, xlane, xlane, xlane, 64 + 16 * FRB);                         // second column's
+      }
     }
     had::wg_barrier<true>();
     BSTAMP(12);
@@ -1152,14 +1305,15 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     rederive();
     {
       float* zcol = reinterpret_cast<float*>(smem + B::kZcol);
-      if (tid < 96) {
-        const int m = tid / 48;
-        const int* s3 = accs + (64 + tid) * 4;
+      if (tid < 16 * NGU) {
+        // accumulator row -> (column m of this workgroup's two, k): three padded row blocks per column | G8: 112 consecutive (m, k)
+        const int m = G8 ? (tid >= FK ? 1 : 0) : tid / 48, k = G8 ? tid - FK * m : tid - 48 * m;
+        const int* s3 = accs + (B::AGU + tid) * 4;
         const float f = __builtin_fmaf((float)s3[0], 65536.f, __builtin_fmaf((float)s3[1], 256.f, (float)s3[2]));
-        zcol[tid] = (float)(f16)(f * unscale_of(shs[0], T::kD4 ? 1 : 2));      // [column 2 (w & 127) + m][k]: one matrix, one exponent
+        zcol[m * B::KP16 + k] = (float)(f16)(f * unscale_of(shs[0], T::kD4 ? 1 : 2));      // [column 2 (w & 127) + m][k]: one matrix, one exponent
       }
       had::wg_barrier<true>();
-      zero_acc(64, 96);
+      zero_acc(B::AGU, 16 * NGU);
       ++hop;                                           // hand-off: column -> row owners
       const uint32_t tag1 = ebase | hop;
       {
@@ -1168,7 +1322,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         const bool live = kq < FK;
         // (m: which of this workgroup's two columns; the factor is its matrix's: mgu)
         const f16* hs = reinterpret_cast<const f16*>(smem + B::kHad) + mgu * B::KKP + (live ? kq : 0) * FK;
-        const float* zz = zcol + m * 48;
+        const float* zz = zcol + m * B::KP16;
         float t = 0.f;
 #pragma unroll
         for (int k4 = 0; k4 < (FK + 3) / 4; ++k4) {
@@ -1177,6 +1331,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         }
         t += __shfl_xor(t, 1, 64);
         t += __shfl_xor(t, 2, 64);
+        t *= kMixScale;                                  // (G8: the 1 / sqrt 8 of H_8 inside the 56 x 56 factor; else 1)
         // row k' goes to row owner k' / RPO.  This workgroup's 2 RPO granules per owner are a cache line of its own, written
         // as 16-byte stores of the rows (k', k' + 1), k' even (the odd row's value comes over from the next quad)
         const float tn = __shfl_down(t, 4, 64);
@@ -1202,7 +1357,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 #pragma unroll
         for (int i = 0; i < QUIP_PREDECODE_DOWN; ++i) {                 // (slice 16 + wave >= 22: decoded, never multiplied)
           i32x4 Bt[8];
-          decode_item(6 + i, Bt);
+          decode_item(SDf(i), Bt);
 #pragma unroll
           for (int t = 0; t < 8; ++t) {
             Bd[i][4 * t] = (uint32_t)Bt[t].x; Bd[i][4 * t + 1] = (uint32_t)Bt[t].y; Bd[i][4 * t + 2] = (uint32_t)Bt[t].z; Bd[i][4 * t + 3] = (uint32_t)Bt[t].w;
@@ -1353,7 +1508,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         if constexpr (RVQ) ISSUE_RVQ_DOWN_G0(Ld);
         // the NEXT block's q, k, v rows (gate's slots: consumed): they land under the K-mix and down's product and are
         // decoded inside the wait for z_d (rounds 3-4 requested them behind that hand-off)
-        if constexpr (kPreQkv && !QUIP_QKV_ISSUE_EARLY) { ISSUE(Ln, 0); ISSUE(Ln, 1); ISSUE(Ln, 2); }
+        if constexpr (kPreQkv && !QUIP_QKV_ISSUE_EARLY) {
+          if constexpr (G8) { ISSUE8_QKV(Ln, 0); ISSUE8_QKV(Ln, 1); } else { ISSUE(Ln, 0); ISSUE(Ln, 1); ISSUE(Ln, 2); }
+        }
         // (the sum of squares of the rows on the way: down's block exponent comes from the norm bound |(H^T (x) I) r|_inf <=
         //  |r|_2 -- the rows of the orthogonal factor are unit vectors -- known BEFORE the K-mix: no maximum over its results,
         //  no reduction behind it; 4-5 of the 22 bits idle, as on the 4096-wide edges)
@@ -1378,21 +1535,22 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       if constexpr (RVQ) ISSUE_RVQ_DOWN_G1(Ld);
       BSTAMP(15);
       typedef float f32x4 __attribute__((ext_vector_type(4)));
-      f32x4 acc[2][FRB];
+      constexpr int KCT = B::KP16 / 16;                 // 16 x 16 tiles of the K x K factor per side (3; G8: 4)
+      f32x4 acc[2][KCT];
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-        for (int ct = 0; ct < FRB; ++ct) acc[jt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ct = 0; ct < KCT; ++ct) acc[jt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
       {
         const uint32_t* ft = reinterpret_cast<const uint32_t*>(smem + B::kArea);
         // B fragments of the K-mix: had_d^T (the fp16 rows take [0, 24 K) of the area, the factor image behind them stays), a
         // k step at a time
         const f16* hdT = reinterpret_cast<const f16*>(smem + B::kHad) + 2 * B::KKP;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          f16x4 bfs[FRB];
+        for (int s = 0; s < KCT; ++s) {
+          f16x4 bfs[KCT];
 #pragma unroll
-          for (int ct = 0; ct < FRB; ++ct) bfs[ct] = *reinterpret_cast<const f16x4*>(hdT + (16 * ct + n) * B::KP16 + 16 * s + 4 * q);
+          for (int ct = 0; ct < KCT; ++ct) bfs[ct] = *reinterpret_cast<const f16x4*>(hdT + (16 * ct + n) * B::KP16 + 16 * s + 4 * q);
 #pragma unroll
           for (int jt = 0; jt < 2; ++jt) {
             const int tile = wave + jt * kWaves;
@@ -1400,7 +1558,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
             const uint2 apr = make_uint2(ft[(8 * s + 2 * q) * FL + 16 * tile + n], ft[(8 * s + 2 * q + 1) * FL + 16 * tile + n]);
             const f16x4 ah = __builtin_bit_cast(f16x4, apr);
 #pragma unroll
-            for (int ct = 0; ct < FRB; ++ct)
+            for (int ct = 0; ct < KCT; ++ct)
               acc[jt][ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bfs[ct], acc[jt][ct], 0, 0, 0);
           }
         }
@@ -1419,7 +1577,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         for (int jt = 0; jt < 2; ++jt) {
           const int tile = wave + jt * kWaves;
 #pragma unroll
-          for (int ct = 0; ct < FRB; ++ct) {
+          for (int ct = 0; ct < KCT; ++ct) {
             const int kc = 16 * ct + n;
             // (digits straight from the fp32 magic number, four values per word: hadw::digit_words_magic)
             const float av[4] = {acc[jt][ct][0], acc[jt][ct][1], acc[jt][ct][2], acc[jt][ct][3]};
@@ -1482,12 +1640,12 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           if (sl < B::JDV) {
             ItemAddr ad;
             item_addresses<REP>(qa[i], qb[i], lane_c, lane_c2, ad, lane_c3);
-            add_rows(T::kD4 ? item_mfma_d4<272>(ad, xlane_d + (uint32_t)(sl * 544)) : item_mfma<272, R3>(ad, xlane_d + (uint32_t)(sl * 544)), 160);
+            add_rows(T::kD4 ? item_mfma_d4<272>(ad, xlane_d + (uint32_t)(sl * 544)) : item_mfma<272, R3>(ad, xlane_d + (uint32_t)(sl * 544)), B::AD);
           }
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < ND; ++i) {
           const int sl = i * kWaves + wave;
           if (sl < JD) {
 #if QUIP_PREDECODE_DOWN
@@ -1496,21 +1654,21 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
               i32x4 Bt[8];
 #pragma unroll
               for (int t = 0; t < 8; ++t) Bt[t] = i32x4{(int)bs[4 * t], (int)bs[4 * t + 1], (int)bs[4 * t + 2], (int)bs[4 * t + 3]};
-              add_rows(item_multiply<272>(Bt, xlane_d + (uint32_t)(sl * 544)), 160);
+              add_rows(item_multiply<272>(Bt, xlane_d + (uint32_t)(sl * 544)), B::AD);
               continue;
             }
 #endif
             ItemAddr ad;
-            item_addresses<REP>(qa[6 + i], qb[6 + i], lane_c, lane_c2, ad, lane_c3);
-            add_rows(T::kD4 ? item_mfma_d4<272>(ad, xlane_d + (uint32_t)(sl * 544)) : item_mfma<272, R3>(ad, xlane_d + (uint32_t)(sl * 544)), 160);
+            item_addresses<REP>(qa[SDf(i)], qb[SDf(i)], lane_c, lane_c2, ad, lane_c3);
+            add_rows(T::kD4 ? item_mfma_d4<272>(ad, xlane_d + (uint32_t)(sl * 544)) : item_mfma<272, R3>(ad, xlane_d + (uint32_t)(sl * 544)), B::AD);
           }
         }
       }
       had::wg_barrier<true>();
       ++hop;                                           // hand-off: z_d
-      publish16(5, w * 8, 160, sh_d, ebase | hop);
+      publish16(5, w * 8, B::AD, sh_d, ebase | hop);
       had::wg_barrier<true>();
-      zero_acc(160, 16);
+      zero_acc(B::AD, 16);
       BSTAMP(17);
     }
     sv_d_prev = Ld.sv[6];
@@ -1532,7 +1690,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 #pragma unroll
       for (int i = 0; i < NPQ; ++i) {
         i32x4 Bt[8];
-        decode_item(i, Bt);
+        decode_item(SQf(i), Bt);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           Bq[i][4 * t] = (uint32_t)Bt[t].x; Bq[i][4 * t + 1] = (uint32_t)Bt[t].y; Bq[i][4 * t + 2] = (uint32_t)Bt[t].z; Bq[i][4 * t + 3] = (uint32_t)Bt[t].w;
@@ -1541,7 +1699,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       }
     }
     {
-      const int c_lo = (3 * w) >> 8, c_hi = (3 * w + 2) >> 8;
+      const int c_lo = qc_lo, c_hi = qc_hi;
       edge(std::true_type{}, std::integral_constant<int, 2>{}, SLOTS(0u), 5, ebase | hop, 0x4000u, sv_d_prev, Ld.ln[0], Ld.su[c_lo], Ld.su[c_hi],
            Ld.sc[c_lo], Ld.sc[c_hi], c_hi != c_lo,
            [&]() { BSTAMP(1); if constexpr (RVQ) { ISSUE_RVQ_QKV_G(Ld, 0); ISSUE_RVQ_QKV_G(Ld, 1); } else if constexpr (!kPreQkv) { ISSUE(Ld, 0); ISSUE(Ld, 1); } },
@@ -1595,6 +1753,39 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 
 }  // namespace
 
+#if QUIP_BLOCK_G8
+size_t block_engine_g8_workspace_bytes() { return kWsBytes; }
+
+// Llama-3-8B / Mistral-7B: hidden 4096, 32 heads of 128 on 8 KV heads, n_ffn = 14336 with the reference's K = 7 factor (quant.py:26-39)
+bool block_engine_g8_supported(int hidden, int heads, int kv_heads, int head_dim, int n_ffn, int K) {
+  return hidden == HID && heads == NH && kv_heads == NKVH && head_dim == HD && n_ffn == NFFN && K == 7 &&
+         device_cu_count_strict() >= NWG;
+}
+
+int block_engine_g8_launch(const BlockEngineArgs& in, hipStream_t stream) {
+  if (in.n_layers < 1 || in.n_layers > 146) return QUIP_ERR_BAD_SHAPE;     // up to 7 hand-offs per block, 10-bit counter
+  if (in.codebook != 0) return QUIP_ERR_UNSUPPORTED;
+  BlockArgs a;
+  a.layers = reinterpret_cast<const BlockLayer*>(in.layers);
+  a.h_in = reinterpret_cast<const f16*>(in.h_in);
+  a.h_out = reinterpret_cast<f16*>(in.h_out);
+  a.pos = reinterpret_cast<const int64_t*>(in.pos);
+  a.cos = in.cos; a.sin = in.sin;
+  a.grid = reinterpret_cast<const uint64_t*>(in.grid);
+  a.ws = reinterpret_cast<char*>(in.workspace);
+  a.dbg = reinterpret_cast<uint64_t*>(in.dbg);
+  a.n_layers = in.n_layers; a.max_len = in.max_len; a.dbg_layer = in.dbg_layer;
+  a.rms_eps = in.rms_eps; a.attn_scale = in.attn_scale; a.resid_scale = 0.f;
+  a.grid2 = nullptr;
+  static DynLdsCache c24;
+  static ResidencyCache r24;
+  const auto kern = decode_block_kernel<24>;
+  if (ensure_dyn_lds(c24, reinterpret_cast<const void*>(kern), BLds<24>::kBytes) != QUIP_OK) return QUIP_ERR_LAUNCH;
+  if (!persistent_grid_fits(r24, reinterpret_cast<const void*>(kern), kThreads, BLds<24>::kBytes, NWG)) return QUIP_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(kern, dim3(NWG), dim3(kThreads), BLds<24>::kBytes, stream, a);
+  return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+}
+#else
 size_t block_engine_workspace_bytes() { return kWsBytes; }
 size_t block_engine_layer_bytes() { return sizeof(BlockLayer); }
 
@@ -1641,5 +1832,7 @@ int block_engine_launch(const BlockEngineArgs& in, hipStream_t stream) {
   if (rep16) return go(decode_block_kernel<16>, BLds<16>::kBytes, c16, r16);
   return go(decode_block_kernel<24>, BLds<24>::kBytes, c24, r24);
 }
+
+#endif
 
 }  // namespace quip

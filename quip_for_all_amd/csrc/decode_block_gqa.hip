@@ -30,6 +30,15 @@
 #include "fht_wg512x.hip.h"
 #include <utility>
 
+// table copies (e8p_gemv_core.hip.h: Lds<REP>): 16 = 16 / 16 -- what fits beside the 84 KB of down's digit planes.  24 (T1 x 32,
+// T2 x 16) and 32 exist for the MEASUREMENT MODE only (tools/dbg: the planes do not fit then; the mode does not use them)
+#ifndef QUIP_GQA_NODECODE
+#define QUIP_GQA_NODECODE 0
+#endif
+#ifndef QUIP_GQA_REP
+#define QUIP_GQA_REP 16
+#endif
+
 namespace quip {
 
 namespace {
@@ -91,7 +100,7 @@ constexpr size_t kWsPart = kWsRowMax + 8 * 128;                       // [NH][kP
 constexpr size_t kWsBytes = kWsPart + (size_t)NH * kParts * kPartGran * 8;
 
 struct GLds {
-  using T = Lds<16>;
+  using T = Lds<QUIP_GQA_REP>;
   static constexpr int kAcc = T::kAcc;                       // int32 [336][4]: q 0 | kv 32 | o 48 | gate, up 80 | down 304
   static constexpr int kAccRows = 336;
   static constexpr int AQ = 0, AKV = 32, AO = 48, AGU = 80, AD = 304;
@@ -106,7 +115,7 @@ struct GLds {
   static constexpr int PSH = HID + 16, PSD = NFFN + 16;      // plane strides (16 bytes off a multiple of 256: the three planes of an A fragment on different banks)
   static constexpr int kBufBytes = hadw::Geo<13>::kBufFloats * 4;
   static constexpr int kBytes = kArea + kAreaBytes;
-  static_assert(kAreaBytes >= 3 * PSD && kAreaBytes >= 2 * kBufBytes && kAreaBytes >= 2 * 3 * PSH, "transient area");
+  static_assert(QUIP_GQA_REP != 16 || (kAreaBytes >= 3 * PSD && kAreaBytes >= 2 * kBufBytes && kAreaBytes >= 2 * 3 * PSH), "transient area");
   static_assert(kArea % 16 == 0, "alignment");
 };
 static_assert(GLds::kBytes <= 160 * 1024, "LDS budget");
@@ -123,7 +132,7 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make
 __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using B = GLds;
-  using T = Lds<16>;
+  using T = Lds<QUIP_GQA_REP>;
   int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int w = blockIdx.x;
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     vo_gu = (uint32_t)((16 * w + n) * kRowH + (wave * 8 + q) * 16);
     vo_d = (uint32_t)((32 * w + n) * kRowF + (wave * 8 + q) * 16);
     vo_hot = (uint32_t)((lane & 31) * 16);     // (the hot 2 KB: offsets < 496 + 1024 + 80)
-    lane_c = (((uint32_t)lane & 15u) << 3) | (uint32_t)T::kT1;
+    lane_c = (T::kRep1 == 32) ? ((((uint32_t)lane & 31u) << 3) | 0x00010000u) : ((((uint32_t)lane & 15u) << 3) | (uint32_t)T::kT1);
     lane_c2 = (((uint32_t)lane & 15u) << 3) | (uint32_t)T::kT2;
   };
   rederive();
@@ -231,9 +240,17 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     u32x4& da = qa[slot];
     u32x4& db = qb[slot];
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(da), "+v"(db) : "n"(2 * (NS - 1)) : "memory");
+#if QUIP_GQA_NODECODE      /* tools/dbg A/B of the measurement mode: the ring alone -- slots waited for and refilled, the codes folded into the accumulator */
+    {
+      acc.x ^= (int)(da.x ^ da.y ^ da.z ^ da.w);
+      acc.y ^= (int)(db.x ^ db.y ^ db.z ^ db.w);
+      issue(IC<S + NS>{});
+      return;
+    }
+#endif
     ItemAddr ad;
     if (live) {
-      item_addresses<16>(da, db, lane_c, lane_c2, ad, 0u);
+      item_addresses<QUIP_GQA_REP>(da, db, lane_c, lane_c2, ad, 0u);
 #pragma unroll
       for (int t = 0; t < 8; ++t) asm volatile("" : "+v"(ad.a1l[t]), "+v"(ad.a2l[t]), "+v"(ad.a1h[t]), "+v"(ad.a2h[t]));
     }
@@ -276,7 +293,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
   uint32_t gen;
   esync::ld4(gen, ctl);
   asm volatile("s_waitcnt vmcnt(1)" : "+v"(tsrc) : : "memory");
-  fill_tables_from_lane<16>(smem, tsrc, lane, wave);
+  fill_tables_from_lane<QUIP_GQA_REP>(smem, tsrc, lane, wave);
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(gen) : : "memory");
   const uint32_t ebase = ((uint32_t)__builtin_amdgcn_readfirstlane((int)gen) + 1u) << 10;
   for (int i = tid; i < B::kAccRows * 4; i += kThreads) accs[i] = 0;

@@ -225,6 +225,10 @@ bool block_engine_gqa_supported(int hidden, int heads, int kv_heads, int head_di
 size_t block_engine_gqa_workspace_bytes();
 size_t block_engine_gqa_layer_bytes();
 int block_engine_gqa_launch(const BlockEngineArgs& in, hipStream_t stream);
+// the 4096-wide grouped-query shape (Llama-3-8B / Mistral-7B): decode_block.hip compiled with QUIP_BLOCK_G8 (decode_block_g8.hip)
+bool block_engine_g8_supported(int hidden, int heads, int kv_heads, int head_dim, int n_ffn, int K);
+size_t block_engine_g8_workspace_bytes();
+int block_engine_g8_launch(const BlockEngineArgs& in, hipStream_t stream);
 int had_transform_planes_launch(const void* x, void* planes, int in_features, int n, int K,
                                 const void* had, int transpose, const void* pre, float scale,
                                 hipStream_t stream, const HadFusion* fuse = nullptr);

@@ -252,7 +252,7 @@ class LlamaDecoder:
         # (E8P12; D4 through the same kernel's one-table mode; E8P12RVQ4B, E8P12RVQ3B and HI as rows of twice the virtual width)
         self.block_eng = False
         d4 = all(getattr(m.codebook, "id", None) in ("D4", "E8P12RVQ4B", "HI", "E8P12RVQ3B") for m in L0.values() if isinstance(m, QuantLinear))
-        gqa_shape = self.fused_prologue and self.chain and s.kv_heads != s.heads and s.hidden == 8192   # (csrc/decode_block_gqa.hip)
+        gqa_shape = self.fused_prologue and self.chain and s.kv_heads != s.heads and s.hidden in (8192, 4096)   # (csrc/decode_block_gqa.hip; decode_block_g8.hip)
         if ((self.ffn_eng or gqa_shape or (d4 and self.fused_prologue and self.chain and os.environ.get("QUIP_FFN_ENGINE", "1") != "0"))
                 and os.environ.get("QUIP_BLOCK_ENGINE", "1") != "0" and not self.window):   # (its attention walks [0, pos])
             self._init_block_engine()
@@ -306,7 +306,12 @@ class LlamaDecoder:
         import numpy as np
         s = self.s
         gqa = block_engine_gqa_supported(s.hidden, s.heads, s.kv_heads, s.head_dim, s.ffn, L0["gate"].K_right) and cbid == "E8P12"
-        ok = ((gqa or block_engine_supported(s.hidden, s.heads, s.kv_heads, s.head_dim, s.ffn, L0["gate"].K_right))
+        import os
+        from .register_lib import block_engine_g8_supported
+        # shape 2 (round 5): Llama-3-8B / Mistral-7B -- the shape-0 launch compiled for 32 / 8 heads and n_ffn = 14336 = 56 x 256
+        g8 = (not gqa and cbid == "E8P12" and os.environ.get("QUIP_BLOCK_ENGINE_G8", "1") != "0" and not self.window
+              and block_engine_g8_supported(s.hidden, s.heads, s.kv_heads, s.head_dim, s.ffn, L0["gate"].K_right))
+        ok = ((gqa or g8 or block_engine_supported(s.hidden, s.heads, s.kv_heads, s.head_dim, s.ffn, L0["gate"].K_right))
               and len(self.layers) <= 146)      # (the launch's hand-off counter: 7 per block in 10 bits)
         kvw = s.kv_heads * s.head_dim
         for L in self.layers:
@@ -340,7 +345,20 @@ class LlamaDecoder:
                 su = [perm8(m.SU) if k in ("q", "k", "v", "gate", "up") else vec(m.SU) for k, m in zip(names, mods)]
                 sv = [perm8(m.SV) if k in ("o", "down") else vec(m.SV) for k, m in zip(names, mods)]
                 ln = [perm8(L["ln1"]), perm8(L["ln2"])]
-                had3 = _engine_had3(L["gate"], L["up"], L["down"])
+                if g8:
+                    # (R_7 (x) H_2048) / sqrt 2048 on the (7, 2048) view = ((R_7 (x) H_8) (x) H_256) / (sqrt 8 sqrt 256) on the
+                    # (56, 256) view: the launch's K = 56 factors are R_7 (x) H_8 (entries +-R_7: exact in fp16); it folds the
+                    # 1 / sqrt 8 into its scales (decode_block.hip: kMixScale; sc[6] below is wscale / sqrt 2048 already)
+                    h8 = torch.tensor([[1.0 - 2.0 * (bin(i & j).count("1") & 1) for j in range(8)] for i in range(8)], device=self.dev)
+                    k56 = lambda r: torch.kron(r.detach().float(), h8)      # noqa: E731
+                    had3 = torch.zeros(2 * 3136 + 64 * 64, dtype=torch.float16, device=self.dev)
+                    had3[:3136] = k56(L["gate"].had_right).to(torch.float16).reshape(-1)
+                    had3[3136:6272] = k56(L["up"].had_right).to(torch.float16).reshape(-1)
+                    hdT = torch.zeros(64, 64, dtype=torch.float16, device=self.dev)
+                    hdT[:56, :56] = k56(L["down"].had_left).to(torch.float16).T
+                    had3[6272:] = hdT.reshape(-1)
+                else:
+                    had3 = _engine_had3(L["gate"], L["up"], L["down"])
             keep += su + sv + ln + [had3]
             ptrs = ([m.Qidxs.data_ptr() for m in mods] + [t.data_ptr() for t in ln] + [t.data_ptr() for t in su]
                     + [t.data_ptr() for t in sv] + [had3.data_ptr(), self.kcache[i].data_ptr(), self.vcache[i].data_ptr()])
@@ -349,7 +367,7 @@ class LlamaDecoder:
             rec[i, 26:].view(np.float32)[:7] = np.array(sc, dtype=np.float32)
         self._eng_keep = keep
         self.eng_layers = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).to(self.dev)
-        self.eng_shape = 1 if gqa else 0
+        self.eng_shape = 1 if gqa else (2 if g8 else 0)
         self.eng_ws = block_engine_workspace(self.dev, self.eng_shape)
         self.eng_codebook = {"E8P12": 0, "D4": 1, "E8P12RVQ4B": 2, "HI": 3, "E8P12RVQ3B": 4}[cbid]
         cb0 = L0["q"].codebook

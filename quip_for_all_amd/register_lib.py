@@ -719,9 +719,19 @@ def block_engine_supported(hidden, heads, kv_heads, head_dim, n_ffn, K):
     return bool(capi.lib().quip_block_engine_supported(int(hidden), int(heads), int(kv_heads), int(head_dim), int(n_ffn), int(K)))
 
 
+def _block_engine_ws_bytes(shape):
+    L = capi.lib()
+    return (L.quip_block_engine_gqa_workspace_bytes() if shape == 1 else
+            L.quip_block_engine_g8_workspace_bytes() if shape == 2 else L.quip_block_engine_workspace_bytes())
+
+
 def block_engine_workspace(device, shape=0):
-    n = capi.lib().quip_block_engine_gqa_workspace_bytes() if shape == 1 else capi.lib().quip_block_engine_workspace_bytes()
-    return torch.zeros(n, dtype=torch.uint8, device=device)
+    return torch.zeros(_block_engine_ws_bytes(shape), dtype=torch.uint8, device=device)
+
+
+def block_engine_g8_supported(hidden, heads, kv_heads, head_dim, n_ffn, K):
+    """the 4096-wide grouped-query shape of Llama-3-8B / Mistral-7B (32 / 8 heads of 128, n_ffn 14336, K = 7) on the persistent launch"""
+    return bool(capi.lib().quip_block_engine_g8_supported(int(hidden), int(heads), int(kv_heads), int(head_dim), int(n_ffn), int(K)))
 
 
 def block_engine_gqa_supported(hidden, heads, kv_heads, head_dim, n_ffn, K):
@@ -734,14 +744,14 @@ def _block_engine_cuda(layers, h_in, pos, cos, sin, grid, workspace, n_layers, m
     lb = capi.lib().quip_block_engine_layer_bytes()
     _need(layers.dtype == torch.uint8 and layers.is_contiguous() and layers.numel() >= n_layers * lb and layers.device == dev,
           "layers must be the packed descriptors (uint8, n_layers x 256 bytes) on the device")
-    _need(shape in (0, 1), "shape: 0 (hidden 4096, multi-head) or 1 (hidden 8192, grouped-query)")
+    _need(shape in (0, 1, 2), "shape: 0 (hidden 4096, multi-head), 1 (hidden 8192, grouped-query) or 2 (hidden 4096, grouped-query)")
     hid = 8192 if shape == 1 else 4096
     _need(h_in.dtype == torch.float16 and h_in.is_contiguous() and h_in.numel() == hid, f"h_in: fp16 [{hid}]")
     _need(pos.dtype == torch.int64 and pos.numel() == 1 and pos.device == dev, "pos: int64 device scalar")
     for t in (cos, sin):
         _need(t.dtype == torch.float32 and t.is_contiguous() and t.shape == (max_len, 128) and t.device == dev,
               "cos / sin: fp32 [max_len, 128]")
-    need_ws = capi.lib().quip_block_engine_gqa_workspace_bytes() if shape == 1 else capi.lib().quip_block_engine_workspace_bytes()
+    need_ws = _block_engine_ws_bytes(shape)
     _need(workspace.dtype == torch.uint8 and workspace.device == dev and workspace.numel() >= need_ws, "workspace too small")
     if codebook in (1, 3):      # D4 / HI: the fp16 (256, 4) table (HI: of a code byte) -- 2 KB like grid_packed_abs
         g = _d4_grid_f16(grid)

@@ -153,6 +153,24 @@ def test_block_engine_kernels_use_no_scratch_and_touch_no_register_in_flight():
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_g8_block_engine_kernel_uses_no_scratch_and_touches_no_register_in_flight():
+    """decode_block_g8.hip: the same launch compiled for the 4096-wide grouped-query shape (Llama-3-8B / Mistral-7B; seven gate / up
+    items in flight at once): no scratch, no instruction on an in-flight register"""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import check_inflight
+    src = os.path.join(REPO, "quip_for_all_amd", "csrc", "decode_block_g8.hip")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", "-", src,
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, check=True, cwd=os.path.dirname(src))
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+    assert len(scratch) == 1 and not any(scratch), scratch
+    kernels = [(n, l) for n, l in check_inflight.kernels_of(r.stdout) if "decode_block_kernel" in n]
+    assert len(kernels) == 1
+    for name, lines in kernels:
+        assert check_inflight.check_kernel(lines) == [], name
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_gqa_block_engine_kernel_uses_no_scratch_and_touches_no_register_in_flight():
     """decode_block_gqa.hip keeps a ring of nine weight requests per wave in flight through the whole launch and waits with
     the constant `s_waitcnt vmcnt(16)`: no scratch (a spill is a VMEM operation the count does not know), no instruction on a

@@ -169,3 +169,69 @@ def test_block_engine_d4_matches_stagewise(codebook, code):
     same = int((ta == tc).sum())
     print(f"{codebook}: greedy tokens equal: {same} / {len(ta)}")
     assert same >= len(ta) - 2          # (a near tie may go the other way: the MLP edge rounds its block exponent differently)
+
+
+def _decoder_g8(layers, block_engine, max_len=48, seed=3):
+    """Llama-3-8B / Mistral-7B shape: hidden 4096, 32 heads on 8 KV heads, n_ffn 14336 = 7 x 2048"""
+    from quip_for_all_amd import decode as D
+    shape = D.LlamaShape(hidden=4096, ffn=14336, layers=layers, heads=32, kv_heads=8, vocab=2048)
+    old = os.environ.get("QUIP_BLOCK_ENGINE")
+    os.environ["QUIP_BLOCK_ENGINE"] = "1" if block_engine else "0"
+    np.random.seed(4321 + seed)
+    try:
+        return D.LlamaDecoder(shape, "E8P12", max_len=max_len, device=DEV, seed=seed, device_init=True)
+    finally:
+        if old is None:
+            os.environ.pop("QUIP_BLOCK_ENGINE", None)
+        else:
+            os.environ["QUIP_BLOCK_ENGINE"] = old
+
+
+@pytest.mark.parametrize("layers", [1, 3])
+def test_g8_block_engine_against_stagewise_step(layers):
+    """the launch compiled for the grouped-query 4096-wide shape (decode_block_g8.hip: 56 x 256 view of the 14336-wide MLP,
+    one or two q / k / v row blocks per workgroup, four query heads per KV head) against the stage-wise step of the same
+    model, teacher forced: logits within 2 (4 sqrt(layers) + 2) fp16 ulps of rms(logits), cache rows within 2^-7"""
+    a = _decoder_g8(layers, True)
+    b = _decoder_g8(layers, False)
+    _same_weights(b, a)
+    assert a.block_eng and a.eng_shape == 2 and not b.block_eng
+    for dec in (a, b):
+        dec.reset(first_token=7)
+    worst = 0.0
+    with torch.no_grad():
+        for t in range(6):
+            la = a.step().clone()
+            lb = b.step().clone()
+            assert a.engine_status() == 0
+            worst = max(worst, _ulps(la, lb))
+            a.tok.copy_(b.tok)
+    print(f"G8, {layers} block(s): logits within {worst:.2f} fp16 ulps of rms(logits) of the stage-wise step")
+    assert worst <= 2.0 * (4.0 * np.sqrt(layers) + 2.0), worst
+    for ca, cb_ in ((a.kcache, b.kcache), (a.vcache, b.vcache)):
+        assert (ca[:, :, :6].float() - cb_[:, :, :6].float()).abs().max().item() <= 2.0 ** -7 * cb_[:, :, :6].float().abs().max().item()
+
+
+@pytest.mark.parametrize("pos0", [127, 300])
+def test_g8_block_engine_long_context_split_attention(pos0):
+    a = _decoder_g8(2, True, max_len=400)
+    b = _decoder_g8(2, False, max_len=400)
+    _same_weights(b, a)
+    g = torch.Generator(device=DEV).manual_seed(pos0)
+    for dec in (a, b):
+        dec.reset(first_token=7)
+    with torch.no_grad():
+        kc = (torch.randn(a.kcache[..., :pos0, :].shape, generator=g, device=DEV) * 0.5).half()
+        vc = (torch.randn(a.vcache[..., :pos0, :].shape, generator=g, device=DEV) * 0.5).half()
+        for dec in (a, b):
+            dec.kcache[..., :pos0, :].copy_(kc)
+            dec.vcache[..., :pos0, :].copy_(vc)
+            dec.pos.fill_(pos0)
+        for t in range(3):
+            la = a.step().float().clone()
+            lb = b.step().float().clone()
+            assert a.engine_status() == 0
+            err = _ulps(la, lb)
+            print(f"G8 position {pos0 + t}: max |logit difference| = {err:.2f} fp16 ulps of rms(logits)")
+            assert err <= 18.0, (pos0 + t, err)
+            a.tok.copy_(b.tok)

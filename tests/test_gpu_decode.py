@@ -151,6 +151,23 @@ def test_full_size_block_against_float64_model(codebook):
     assert u <= _BLOCK_ULPS[codebook], u
 
 
+def test_full_size_g8_block_against_float64_model():
+    """ONE Llama-3-8B-shaped block (hidden 4096, 32 / 8 heads, n_ffn 14336; random init) for 3 decode steps on the persistent
+    launch compiled for that shape (decode_block_g8.hip) against the float64 model"""
+    from quip_for_all_amd import decode as D
+    shape = D.LlamaShape(hidden=4096, ffn=14336, layers=1, heads=32, kv_heads=8, vocab=1024)
+    np.random.seed(23)
+    dec = D.LlamaDecoder(shape, "E8P12", max_len=16, device="cuda:0", seed=9, device_init=True)
+    assert dec.block_eng and dec.eng_shape == 2
+    toks = dec.generate(3, first_token=9, use_graph=True).cpu().numpy()
+    got = dec.step_logits.float().cpu().numpy()[0].astype(np.float64)
+    assert dec.engine_status() == 0
+    ref = _ref_logits(dec, [9, int(toks[0]), int(toks[1])])
+    u = _ulps_of_rms(got, ref)
+    print(f"8B-shaped block (E8P12, grouped-query launch), logits of step 3 vs float64: max {u:.2f} fp16 ulps of rms(logits) = {np.sqrt(np.mean(ref * ref)):.3f}")
+    assert u <= 8.0, u
+
+
 def test_eight_full_size_blocks_against_float64_model():
     """EIGHT Llama-2-7B-shaped blocks (no test carried the float64 model past 3 blocks) for 3 decode steps
     through the captured step on the persistent launch against the layer-major float64 model.  Bound: deep_bound_ulps(8) =
