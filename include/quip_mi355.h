@@ -539,7 +539,7 @@ int quip_block_engine_gqa_supported(int32_t hidden, int32_t heads, int32_t kv_he
 size_t quip_block_engine_gqa_workspace_bytes(void);
 /* shape 2 (round 5): hidden 4096, 32 heads of 128 on 8 KV heads, n_ffn = 14336 = 7 x 2048 (Llama-3-8B, Mistral-7B; E8P12 only): the
  * shape-0 launch compiled for this shape.  Descriptors as for shape 0, except had3 = the 56 x 56 factors R_7 (x) H_8 of gate.had_right,
- * up.had_right (row major, 3136 fp16 each) and of down.had_left TRANSPOSED (64 x 64, zero padded): see decode_block.hip, QUIP_BLOCK_G8. */
+ * up.had_right (row major, 3136 fp16 each) and of down.had_left TRANSPOSED (64 rows of 72 fp16, zero padded): see decode_block.hip, QUIP_BLOCK_G8. */
 int quip_block_engine_g8_supported(int32_t hidden, int32_t heads, int32_t kv_heads, int32_t head_dim, int32_t n_ffn, int32_t K);
 size_t quip_block_engine_g8_workspace_bytes(void);
 

@@ -136,6 +136,9 @@ struct BLds {
   static constexpr int VM = RVQ ? 2 : 1, KV = VM * HID;
   static constexpr int KPDV = RVQ ? 22528 : KPD, JDV = RVQ ? 43 : JD;   // digits of down's input (virtual, padded), its slices
   static constexpr int KKP = (FK * FK + 7) & ~7, KP16 = G8 ? 64 : 48;
+  // row stride of down's transposed factor in the image: 64 fp16 = 128 bytes put the 16 rows of a B fragment on ONE bank group
+  // (16-way conflicts: 11.6K clocks for the K-mix + planes of the G8 launch instead of ~5K); 72 spreads them
+  static constexpr int KPS = G8 ? 72 : KP16;
   static constexpr int kAcc = T::kAcc;                       // int32 [176][4]: q k v (48) | o (16) | gate up (96; G8: 112) | down (16)
   static constexpr int AGU = 64, AD = AGU + 16 * NGU;        // accumulator rows of gate / up and of down
   static constexpr int kAccRows = AD + 16;
@@ -158,7 +161,7 @@ struct BLds {
   static constexpr int kBufBytes = ((had::buf_floats(HID) * 4) + 15) & ~15;
   static constexpr int kAreaBytes = (160 * 1024 - kArea) & ~15;
   static constexpr int kBuf0 = kArea;
-  static constexpr int kHadElems = 2 * KKP + KP16 * KP16;
+  static constexpr int kHadElems = 2 * KKP + KP16 * KPS;
   static constexpr int kStage = kArea + 8 * 1024;            // MLP row owners: their four rows, transposed, on the way out (4 KB)
   // fp16 image of the three K x K factors (12 KB; G8: 20.3 KB), behind the planes of gate / up and behind the rows' LDS image
   // ([KP16 / 2][256] fp16 pairs = 24 KB; G8: 32 KB)
@@ -1550,7 +1553,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         for (int s = 0; s < KCT; ++s) {
           f16x4 bfs[KCT];
 #pragma unroll
-          for (int ct = 0; ct < KCT; ++ct) bfs[ct] = *reinterpret_cast<const f16x4*>(hdT + (16 * ct + n) * B::KP16 + 16 * s + 4 * q);
+          for (int ct = 0; ct < KCT; ++ct) bfs[ct] = *reinterpret_cast<const f16x4*>(hdT + (16 * ct + n) * B::KPS + 16 * s + 4 * q);
 #pragma unroll
           for (int jt = 0; jt < 2; ++jt) {
             const int tile = wave + jt * kWaves;

@@ -351,10 +351,10 @@ class LlamaDecoder:
                     # 1 / sqrt 8 into its scales (decode_block.hip: kMixScale; sc[6] below is wscale / sqrt 2048 already)
                     h8 = torch.tensor([[1.0 - 2.0 * (bin(i & j).count("1") & 1) for j in range(8)] for i in range(8)], device=self.dev)
                     k56 = lambda r: torch.kron(r.detach().float(), h8)      # noqa: E731
-                    had3 = torch.zeros(2 * 3136 + 64 * 64, dtype=torch.float16, device=self.dev)
+                    had3 = torch.zeros(2 * 3136 + 64 * 72, dtype=torch.float16, device=self.dev)      # (down's: rows of 72: bank spread)
                     had3[:3136] = k56(L["gate"].had_right).to(torch.float16).reshape(-1)
                     had3[3136:6272] = k56(L["up"].had_right).to(torch.float16).reshape(-1)
-                    hdT = torch.zeros(64, 64, dtype=torch.float16, device=self.dev)
+                    hdT = torch.zeros(64, 72, dtype=torch.float16, device=self.dev)
                     hdT[:56, :56] = k56(L["down"].had_left).to(torch.float16).T
                     had3[6272:] = hdT.reshape(-1)
                 else:

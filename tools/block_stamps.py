@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phase clocks of one block inside the persistent token launch (csrc/decode_block.hip, BSTAMP), Llama-2-7B shape.
-usage: python tools/block_stamps.py [layers] [dbg_layer] [pos]"""
+usage: python tools/block_stamps.py [layers] [dbg_layer] [pos] [g8]      (g8: the Llama-3-8B shape, decode_block_g8.hip)"""
 import math
 import os
 import sys
@@ -14,7 +14,9 @@ from quip_for_all_amd import decode as D  # noqa: E402
 layers = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 dl = int(sys.argv[2]) if len(sys.argv) > 2 else layers // 2
 pos0 = int(sys.argv[3]) if len(sys.argv) > 3 else 100
-shape = D.LlamaShape(hidden=4096, ffn=11008, layers=layers, heads=32, kv_heads=32, vocab=32000)
+g8 = len(sys.argv) > 4 and sys.argv[4] == "g8"
+shape = (D.LlamaShape(hidden=4096, ffn=14336, layers=layers, heads=32, kv_heads=8, vocab=32000) if g8 else
+         D.LlamaShape(hidden=4096, ffn=11008, layers=layers, heads=32, kv_heads=32, vocab=32000))
 dec = D.LlamaDecoder(shape, "E8P12", max_len=max(256, pos0 + 16), device="cuda:0", seed=0, device_init=True)
 assert dec.block_eng
 dec.reset(7)
@@ -31,7 +33,7 @@ for it in range(6):
     dbg.zero_()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    torch.ops.quip_lib.block_engine(*args, dbg, dl)
+    torch.ops.quip_lib.block_engine(*args, dbg, dl, 0, 0.0, dec.eng_shape)
     e1.record()
     torch.cuda.synchronize()
     if it >= 2:
@@ -70,7 +72,7 @@ for title, st, before, after in (("gate / up edge", [18, 19, 20, 21, 22], 10, 11
         seg = D_[:, :, st[i]] - D_[:, :, st[i - 1]]
         print(f"  {en[i]:28s} {seg.mean():9.0f}")
     print(f"  (stamp {before} -> {st[0]}: {(D_[:, :, st[0]] - D_[:, :, before]).mean():.0f}, {st[4]} -> {after}: {(D_[:, :, after] - D_[:, :, st[4]]).mean():.0f})")
-ro = np.arange(256) < 22
+ro = np.arange(256) < (28 if g8 else 22)
 print("inside the MLP edge: row owners: publish(13) -> inbox complete %.0f, -> rows published(14) %.0f; everyone: 14 -> poll done(26) %.0f (row owners %.0f), sweep(27) %.0f, staging + barrier(15) %.0f" % (
     (D_[:, ro, 25] - D_[:, ro, 13]).mean(), (D_[:, ro, 14] - D_[:, ro, 25]).mean(), (D_[:, :, 26] - D_[:, :, 14]).mean(),
     (D_[:, ro, 26] - D_[:, ro, 14]).mean(), (D_[:, :, 27] - D_[:, :, 26]).mean(), (D_[:, :, 15] - D_[:, :, 27]).mean()))
