@@ -149,7 +149,8 @@ def engine_roofline(dec):
     traffic = traffic_src = None
     gqa = getattr(dec, "eng_shape", 0) == 1
     # the committed PMC pass of THIS workload: one file per model shape (7B: engine_hbm_traffic.json)
-    fname = "engine_hbm_traffic.json" if (s.hidden == 4096 and len(dec.layers) == 32) else \
+    fname = "engine_hbm_traffic.json" if (s.hidden == 4096 and len(dec.layers) == 32 and s.ffn == 11008) else \
+        "engine_hbm_traffic_h%d_f%d_l%d.json" % (s.hidden, s.ffn, len(dec.layers)) if s.hidden == 4096 else \
         "engine_hbm_traffic_h%d_l%d.json" % (s.hidden, len(dec.layers))
     pf = os.path.join(REPO, "profiles", fname)
     if os.path.exists(pf):
@@ -160,9 +161,13 @@ def engine_roofline(dec):
         except Exception:
             traffic = None
     return {"bound": "hbm", "kernel": "%s (one persistent launch per token: all %d blocks)" % (
-                "decode_block_gqa_kernel" if gqa else "decode_block_kernel", len(dec.layers)),
+                "decode_block_gqa_kernel" if gqa else ("decode_block_kernel (decode_block_g8.hip)" if getattr(dec, "eng_shape", 0) == 2
+                                                       else "decode_block_kernel"), len(dec.layers)),
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-            "traffic": traffic, "traffic_source": traffic_src, "launches": 1, "algorithmic_bytes_per_launch": algo,
+            # (`traffic`: NOT measured beside this timed region -- read from the committed rocprofv3 --pmc pass of the same launch
+            #  on another box, named in traffic_source)
+            "traffic": traffic, "traffic_is_from_file": traffic is not None, "traffic_source": traffic_src, "launches": 1,
+            "algorithmic_bytes_per_launch": algo,
             "mean_launch_us": round(t * 1e6, 1), "us_per_block": round(t * 1e6 / len(dec.layers), 2),
             "engine_status": dec.engine_status()}
 
@@ -882,7 +887,7 @@ def main():
                                             "llama2_7b_e8p12rvq3b": (D.LLAMA2_7B, "E8P12RVQ3B", 64, {}),
                                             "llama2_7b_d4": (D.LLAMA2_7B, "D4", 64, {}),
                                             "llama2_7b_hi": (D.LLAMA2_7B, "HI", 64, {}),
-                                            # a grouped-query block outside the persistent launch's shape (stage-wise step)
+                                            # the grouped-query 4096-wide shape (round 5: the shape-2 persistent launch, decode_block_g8.hip)
                                             "llama3_8b_shape_e8p12": (D.LLAMA3_8B, "E8P12", 64, {})}.items():
                 try:
                     extras[key] = time_decoder(D, shp, cbk, st, 8, f"cuda:{local_rank}", **kw)

@@ -328,20 +328,26 @@ class _FastDecode:
         kind, layers = kind_layers
         if kind == "dynamic":
             return self._dynamic_step(input_ids, cache, layers, attention_mask, position_ids)
+        # every prompt pass through this wrapper leaves its verdict on the cache object (left padding / positions not from
+        # zero): a cache that is reset and used again with a padded prompt goes to the stock forward
+        if getattr(cache, "_quip_padded", None) is True:
+            return None
         seen = getattr(self, "_static_checked", None)
         if seen is None or seen() is not cache:                      # a cache object seen for the first time
             import weakref
             if not self._unpadded(attention_mask, position_ids, layers[0].cumulative_length):
                 return None
             self._static_checked = weakref.ref(cache)
-        if self._decoder([L.keys for L in layers], [L.values for L in layers]) is None:
+        dec = self._decoder([L.keys for L in layers], [L.values for L in layers])
+        if dec is None:
             return None
         return self._static_step(input_ids, [L.keys for L in layers], [L.values for L in layers],
-                                 [L.cumulative_length for L in layers])
+                                 [L.cumulative_length for L in layers], dec)
 
-    def _static_step(self, input_ids, keys4, values4, lens):
+    def _static_step(self, input_ids, keys4, values4, lens, dec=None):
         """the body of quip_lib::hf_decode_step: one token on the cache tensors, lengths advanced (StaticLayer.update's bookkeeping)"""
-        dec = self._decoder(keys4, values4)
+        if dec is None:                                  # (the compiled operator's entry; _fast_step hands its decoder over)
+            dec = self._decoder(keys4, values4)
         if dec is None:
             raise RuntimeError("fast decode is not available for this model: " + str(self.disabled))
         with torch.no_grad():
