@@ -1515,7 +1515,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           if constexpr (G8) { ISSUE8_QKV(Ln, 0); ISSUE8_QKV(Ln, 1); } else { ISSUE(Ln, 0); ISSUE(Ln, 1); ISSUE(Ln, 2); }
         }
         // (the sum of squares of the rows on the way: down's block exponent comes from the norm bound |(H^T (x) I) r|_inf <=
-        //  |r|_2 -- the rows of the orthogonal factor are unit vectors -- known BEFORE the K-mix: no maximum over its results,
+        //  |r|_2 -- the rows of the orthogonal factor are unit vectors (G8: of norm sqrt 8) -- known BEFORE the K-mix: no maximum over its results,
         //  no reduction behind it; 4-5 of the 22 bits idle, as on the 4096-wide edges)
         float ssr = 0.f;
 #pragma unroll
@@ -1569,7 +1569,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       if constexpr (RVQ) ISSUE_RVQ_DOWN_G2(Ld);
       const float in_scale = Ld.sc[6] * 16.f;
       // (in_scale carries the prescale 1 / 16 of the rows back: the bound is for acc * in_scale, |acc|_inf <= |rows|_2)
-      const float bound = sqrtf(red_sum8(0)) * fabsf(in_scale) * 1.0625f;
+      // (G8: the rows of the 56 x 56 factor R_7 (x) H_8 have norm sqrt 8, not 1 -- in_scale carries the 1 / sqrt 8 that undoes it)
+      const float bound = sqrtf(red_sum8(0)) * fabsf(in_scale) * (1.0625f / kMixScale);
       const int sh_d = had::shift_for(bound * ((RVQ && !HI) ? fmaxf(1.f, fabsf(a.resid_scale)) : 1.f));
       had::wg_barrier<true>();                         // every wave's K-mix has read the rows: the planes land on them
       {

@@ -235,3 +235,39 @@ def test_g8_block_engine_long_context_split_attention(pos0):
             print(f"G8 position {pos0 + t}: max |logit difference| = {err:.2f} fp16 ulps of rms(logits)")
             assert err <= 18.0, (pos0 + t, err)
             a.tok.copy_(b.tok)
+
+
+@pytest.mark.parametrize("g8", [False, True])
+def test_norm_bound_planes_take_spiky_activations(g8):
+    """the launches round their digit planes against NORM bounds (|H x|_inf <= sqrt(n) |x|_2; |M r|_inf <= |row|_2 |r|_2) instead
+    of the exact maximum: tight for a one-hot vector, 4-5 bits loose for a flat one.  A one-hot embedding row and RMSNorm
+    weights with a few channels 50 times the rest (the outlier channels of real checkpoints) put both ends through every edge:
+    an exponent that let a digit overflow its 22 bits would show as garbage, too loose a one as lost precision -- logits stay
+    within the usual bound of the stage-wise step (which takes exact maxima)."""
+    mk = _decoder_g8 if g8 else _decoder
+    a = mk(2, True)
+    b = mk(2, False)
+    _same_weights(b, a)
+    with torch.no_grad():
+        for dec in (a, b):
+            dec.embed[7].zero_()
+            dec.embed[7, 123] = 8.0
+            dec.embed[9].mul_(0.02)                       # a tiny row: far below the norm of the others
+            for L in dec.layers:
+                for k in ("ln1", "ln2"):
+                    L[k][torch.tensor([5, 777, 3000], device=DEV)] *= 50.0
+    for dec in (a, b):
+        dec.reset(first_token=7)                          # (rebuilds the launch's descriptors: ln was edited)
+    assert a.block_eng and not b.block_eng
+    worst = 0.0
+    with torch.no_grad():
+        for t, tok in enumerate([7, 9, 7, 11]):
+            a.tok.fill_(tok)
+            b.tok.fill_(tok)
+            la = a.step().clone()
+            lb = b.step().clone()
+            assert a.engine_status() == 0
+            assert torch.isfinite(la).all()
+            worst = max(worst, _ulps(la, lb))
+    print(f"spiky activations ({'G8' if g8 else '7B'} launch): logits within {worst:.2f} fp16 ulps of rms(logits) of the stage-wise step")
+    assert worst <= 2.0 * (4.0 * np.sqrt(2) + 2.0), worst
