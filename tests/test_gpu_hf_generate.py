@@ -491,6 +491,45 @@ def test_fast_decode_wrapper_on_a_70b_shaped_hf_model_runs_the_grouped_query_lau
     disable_fast_decode(model)
 
 
+def test_fast_decode_wrapper_on_a_llama3_8b_shaped_hf_model_runs_the_shape_2_launch():
+    """two blocks of the Llama-3-8B / Mistral-7B shape (hidden 4096, 32 heads on 8 KV heads, n_ffn 14336) as an HF model: the
+    wrapper's decoder takes the persistent launch compiled for that shape (shape 2, decode_block_g8.hip) on the StaticCache's
+    (1, 8, len, 128) tensors; logits of a step within 2^-6 of the stock forward's maximum, greedy tokens equal up to a near tie"""
+    from transformers import LlamaConfig
+    from quip_for_all_amd.hf_static import HFStaticDecoder
+    from quip_for_all_amd.hf_fast import enable_fast_decode, disable_fast_decode
+    cfg = LlamaConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=2, num_attention_heads=32,
+                      num_key_value_heads=8, vocab_size=2048, max_position_embeddings=64, rms_norm_eps=1e-5,
+                      tie_word_embeddings=False)
+    model = _random_quantized_hf_llama(cfg)
+    ids = torch.tensor([[1, 17, 42, 99, 7, 250]], device="cuda:0")
+    enable_fast_decode(model)
+    fd = model._quip_fast_decode
+    a, b = HFStaticDecoder(model, max_cache_len=64), HFStaticDecoder(model, max_cache_len=64)
+    a.prefill(ids)
+    b.prefill(ids)
+    same = 0
+    for t in range(8):                                  # teacher-forced on the stock path's tokens
+        model.forward = fd.orig_forward
+        lb = b._forward(b.tok, b.pos).float()
+        model.forward = fd
+        la = a._forward(a.tok, a.pos).float()
+        assert (la - lb).abs().max().item() <= 2.0 ** -6 * lb.abs().max().item(), (t, (la - lb).abs().max().item())
+        nxt = lb[:, -1].argmax(-1, keepdim=True)
+        same += int(la[:, -1].argmax(-1).item() == nxt.item())
+        for h in (a, b):
+            h.tok.copy_(nxt)
+            h.pos += 1
+    assert fd.disabled is None and fd.fast_steps == 8 and fd.dec.block_eng and fd.dec.eng_shape == 2 and fd.dec.engine_status() == 0
+    assert same >= 7, same
+    n = ids.shape[1] + 8
+    for La, Lb in zip(a.cache.layers, b.cache.layers):
+        assert int(La.cumulative_length) == n == int(Lb.cumulative_length)
+        dk = (La.keys[:, :, :n].float() - Lb.keys[:, :, :n].float()).abs().max().item()
+        assert dk <= 2.0 ** -5 * Lb.keys.float().abs().max().item(), dk
+    disable_fast_decode(model)
+
+
 def test_fast_decode_wrapper_leaves_a_padded_sequence_to_the_stock_forward():
     """a left-padded single sequence (attention_mask with a hole, position_ids behind the cache length): the wrapper checks
     once when it takes a cache object over and stays out; the tokens are the stock forward's"""
