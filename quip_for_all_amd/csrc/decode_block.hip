@@ -44,6 +44,14 @@
 #ifndef QUIP_OWNER_PREDECODE
 #define QUIP_OWNER_PREDECODE 1     // A/B: the MLP row owners decode down's items ahead like everybody (1) or at the product (0)
 #endif
+#ifndef QUIP_POLL2
+#define QUIP_POLL2 0               // A/B: the edges' gathers poll with TWO staggered read sets (1) or one (0).  Measured: two sets make
+                                   // the hand-offs LONGER (z_o 3.6K -> 4.0K clocks, z_d 3.8K -> 4.4K; stagger 5 / 10 / 16 alike) -- the
+                                   // polls' traffic delays the stores they wait for by more than the finer grid gains
+#endif
+#ifndef QUIP_POLL2_STAGGER
+#define QUIP_POLL2_STAGGER 10      // s_sleep units (64 clocks) between the first requests of the two sets
+#endif
 #ifndef QUIP_PREDECODE_GATE
 #define QUIP_PREDECODE_GATE 2      // items of gate / up decoded inside the wait for z_o (3: spills 60 bytes)
 #endif
@@ -456,6 +464,91 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       had::unpack8(make_uint4(p[2 * c].x, p[2 * c].z, p[2 * c + 1].x, p[2 * c + 1].z), out[c]);
     own_slots(slots);
   };
+  // The same with TWO read sets in flight, half a round trip apart.  A hand-off ends when the LAST of 2048 waves has seen its
+  // pieces: with one set a wave notices them up to a full round trip (~0.7 us) after they became visible, with two up to half
+  // of one.  The loop is ONE asm statement on sixteen NAMED registers (v[236:251]): written in C++ the sets are in flight
+  // across the loop's back edge, where the allocator is free to split a live range -- it copied the registers BEFORE the
+  // wait (tools/check_inflight.py).  On success the other set is still in flight: its registers stay bound to `pa`, `pb`
+  // until the caller has said poll2_settle with N = the VMEM requests it has issued since (vmcnt retires in order).
+  auto gather2 = [&](auto slots, int first, uint32_t tag, uint32_t code, float (&out)[1][8], u32x4_t (&pa)[2], u32x4_t (&pb)[2]) {
+    const uint64_t* src = zbufs + (size_t)first * 2048 + 4 * tid;
+    uint32_t o0, o1, o2, o3, st, cnt, rounds = 0;
+    uint64_t tmp;
+#pragma nounroll
+    for (;;) {
+      asm volatile(
+          "global_load_dwordx4 v[236:239], %[src], off sc1\n\t"
+          "global_load_dwordx4 v[240:243], %[src], off offset:16 sc1\n\t"
+          "s_sleep %[stag]\n\t"
+          "global_load_dwordx4 v[244:247], %[src], off sc1\n\t"
+          "global_load_dwordx4 v[248:251], %[src], off offset:16 sc1\n\t"
+          "s_movk_i32 %[cnt], 64\n"
+          ".Lp2_top_%=:\n\t"
+          "s_waitcnt vmcnt(2)\n\t"
+          "v_cmp_eq_u32_e32 vcc, %[tag], v237\n\t"
+          "v_cmp_eq_u32_e64 %[tmp], %[tag], v239\n\t"
+          "s_and_b64 vcc, vcc, %[tmp]\n\t"
+          "v_cmp_eq_u32_e64 %[tmp], %[tag], v241\n\t"
+          "s_and_b64 vcc, vcc, %[tmp]\n\t"
+          "v_cmp_eq_u32_e64 %[tmp], %[tag], v243\n\t"
+          "s_and_b64 vcc, vcc, %[tmp]\n\t"
+          "s_cmp_eq_u64 vcc, exec\n\t"
+          "s_cbranch_scc1 .Lp2_a_%=\n\t"
+          "global_load_dwordx4 v[236:239], %[src], off sc1\n\t"
+          "global_load_dwordx4 v[240:243], %[src], off offset:16 sc1\n\t"
+          "s_waitcnt vmcnt(2)\n\t"
+          "v_cmp_eq_u32_e32 vcc, %[tag], v245\n\t"
+          "v_cmp_eq_u32_e64 %[tmp], %[tag], v247\n\t"
+          "s_and_b64 vcc, vcc, %[tmp]\n\t"
+          "v_cmp_eq_u32_e64 %[tmp], %[tag], v249\n\t"
+          "s_and_b64 vcc, vcc, %[tmp]\n\t"
+          "v_cmp_eq_u32_e64 %[tmp], %[tag], v251\n\t"
+          "s_and_b64 vcc, vcc, %[tmp]\n\t"
+          "s_cmp_eq_u64 vcc, exec\n\t"
+          "s_cbranch_scc1 .Lp2_b_%=\n\t"
+          "global_load_dwordx4 v[244:247], %[src], off sc1\n\t"
+          "global_load_dwordx4 v[248:251], %[src], off offset:16 sc1\n\t"
+          "s_sleep 1\n\t"
+          "s_sub_u32 %[cnt], %[cnt], 1\n\t"
+          "s_cmp_lg_u32 %[cnt], 0\n\t"
+          "s_cbranch_scc1 .Lp2_top_%=\n\t"
+          "s_waitcnt vmcnt(0)\n\t"                    // nothing yet: everything lands, the caller looks at the error word
+          "s_mov_b32 %[st], 0\n\t"
+          "s_branch .Lp2_end_%=\n"
+          ".Lp2_a_%=:\n\t"
+          "v_mov_b32 %[o0], v236\n\t"
+          "v_mov_b32 %[o1], v238\n\t"
+          "v_mov_b32 %[o2], v240\n\t"
+          "v_mov_b32 %[o3], v242\n\t"
+          "s_mov_b32 %[st], 1\n\t"
+          "s_branch .Lp2_end_%=\n"
+          ".Lp2_b_%=:\n\t"
+          "v_mov_b32 %[o0], v244\n\t"
+          "v_mov_b32 %[o1], v246\n\t"
+          "v_mov_b32 %[o2], v248\n\t"
+          "v_mov_b32 %[o3], v250\n\t"
+          "s_mov_b32 %[st], 1\n"
+          ".Lp2_end_%=:"
+          : "={v[236:239]}"(pa[0]), "={v[240:243]}"(pa[1]), "={v[244:247]}"(pb[0]), "={v[248:251]}"(pb[1]), [o0] "=&v"(o0), [o1] "=&v"(o1),
+            [o2] "=&v"(o2), [o3] "=&v"(o3), [st] "=&s"(st), [cnt] "=&s"(cnt), [tmp] "=&s"(tmp)
+          : [src] "v"(src), [tag] "s"(tag), [stag] "n"(QUIP_POLL2_STAGGER)
+          : "vcc", "scc", "memory");
+      if (st != 0u) break;
+      // 128 polls without the pieces: the launch-wide error word, the bound (spin_step's arithmetic)
+      uint32_t e;
+      esync::ld4(e, ctl + 1);
+      esync::drain();
+      esync::own(e);
+      if (__builtin_amdgcn_readfirstlane(e) != 0u) break;
+      rounds += 128u;
+      if (rounds >= esync::kSpinLimit) {
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) esync::st_word(ctl + 1, code + (uint32_t)w);
+        break;
+      }
+    }
+    had::unpack8(make_uint4(o0, o1, o2, o3), out[0]);
+    own_slots(slots);
+  };
   // this workgroup's 16 values of a product (accumulator rows [row0, row0 + 16), block exponent sh) -> 8 granules
   auto publish16 = [&](int vec, int gr0, int row0, int sh, uint32_t tag) {      // gr0: first granule of the block in its vector
     if (tid < 8) {
@@ -533,7 +626,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     return r;
   };
   auto edge = [&](auto z_tag, auto nc_tag, auto slots, int zvec, uint32_t tag, uint32_t code, const f16* sv_prev, const f16* ln,
-                  const f16* su0, const f16* su1, float sc0, float sc1, bool two, auto after_gather, auto drip1, auto drip2, int sb = -1) {
+                  const f16* su0, const f16* su1, float sc0, float sc1, bool two, auto after_gather, auto drip1, auto drip2, int sb, auto ag_tag) {
+    // ag_tag: VMEM requests `after_gather` issues (a hand count: the wait for the gather's second read set is said in them)
     // stamps of the edge's stages: 18..22 (sb = 18: the gate / up edge) or 23, 24, 28, 29, 30 (sb = 23: the q / k / v edge)
 #define ESTAMP(i) do { if (sb >= 0) BSTAMP(sb + (i) + ((sb == 23 && (i) >= 2) ? 3 : 0)); } while (0)
     constexpr int NC = decltype(nc_tag)::value;
@@ -548,7 +642,12 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     auto u4 = [](const u32x4& v) { return make_uint4(v.x, v.y, v.z, v.w); };
     if constexpr (HAVE_Z) {
       float v[1][8];
+#if QUIP_POLL2
+      u32x4_t pa[2], pb[2];
+      gather2(slots, zvec, tag, code, v, pa, pb);
+#else
       gather(std::integral_constant<int, 1>{}, slots, zvec, tag, code, v);
+#endif
       // The vectors have landed (the gather drained the queue).  Take them over HERE: the compiler counts only its own
       // loads, so the wait it would place at their first use would also wait for the burst requested below.
       asm volatile("" : "+v"(psv));
@@ -556,6 +655,12 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       after_gather();
       ESTAMP(0);
       hadw::fwd<12, 1, true>(v, xbuf, tid);
+#if QUIP_POLL2
+      // the read set that was still in flight when the other one succeeded has had the transform's time to land
+      if (dbg_on) esync::drain();                      // (a stamp is a store: one more request than counted)
+      asm volatile("s_waitcnt vmcnt(%0)" : : "n"(decltype(ag_tag)::value), "{v[236:239]}"(pa[0]), "{v[240:243]}"(pa[1]), "{v[244:247]}"(pb[0]),
+                   "{v[248:251]}"(pb[1]) : "memory");
+#endif
       ESTAMP(1);
       float svf[8];
       had::unpack8(u4(psv), svf);
@@ -805,7 +910,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     rederive();
     const int c_lo = qc_lo, c_hi = qc_hi;
     edge(std::false_type{}, std::integral_constant<int, 2>{}, SLOTS(M_QKV), -1, 0u, 0u, nullptr, Ld.ln[0], Ld.su[c_lo], Ld.su[c_hi],
-         Ld.sc[c_lo], Ld.sc[c_hi], c_hi != c_lo, [&]() {}, [&]() {}, [&]() {});
+         Ld.sc[c_lo], Ld.sc[c_hi], c_hi != c_lo, [&]() {}, [&]() {}, [&]() {}, -1, std::integral_constant<int, 0>{});
     uint32_t none[NPQ][32];                          // (block 0: nothing decoded ahead; never read)
     P1_products(std::false_type{}, none);
   }
@@ -1237,7 +1342,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
          // up's row blocks (RVQ: their first virtual slice) behind the hand-off, one at a time between the edge's stages
          [&]() { BSTAMP(10); if constexpr (RVQ) ISSUE_RVQ_UP_A_G(Ld, 0); else if constexpr (G8) { ISSUE8_GU(Ld, 3); ISSUE8_GU(Ld, 4); } else ISSUE(Ld, 7); },
          [&]() { if constexpr (RVQ) ISSUE_RVQ_UP_A_G(Ld, 1); else if constexpr (G8) ISSUE8_GU(Ld, 5); else ISSUE(Ld, 8); },
-         [&]() { if constexpr (RVQ) ISSUE_RVQ_UP_A_G(Ld, 2); else if constexpr (G8) ISSUE8_GU(Ld, 6); else ISSUE(Ld, 9); }, 18);
+         [&]() { if constexpr (RVQ) ISSUE_RVQ_UP_A_G(Ld, 2); else if constexpr (G8) ISSUE8_GU(Ld, 6); else ISSUE(Ld, 9); }, 18,
+         std::integral_constant<int, G8 ? 4 : 2>{});
     BSTAMP(11);
     // row owners (w < NRO: rows k' = RPO w .. RPO w + RPO - 1, one per wave): SV_gate / SV_up / SU_down of their rows into the free
     // tail of the area; everybody: the image of the K x K factors, for the MLP edge
@@ -1707,7 +1813,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       edge(std::true_type{}, std::integral_constant<int, 2>{}, SLOTS(0u), 5, ebase | hop, 0x4000u, sv_d_prev, Ld.ln[0], Ld.su[c_lo], Ld.su[c_hi],
            Ld.sc[c_lo], Ld.sc[c_hi], c_hi != c_lo,
            [&]() { BSTAMP(1); if constexpr (RVQ) { ISSUE_RVQ_QKV_G(Ld, 0); ISSUE_RVQ_QKV_G(Ld, 1); } else if constexpr (!kPreQkv) { ISSUE(Ld, 0); ISSUE(Ld, 1); } },
-           [&]() { if constexpr (RVQ) ISSUE_RVQ_QKV_G(Ld, 2); else if constexpr (!kPreQkv) ISSUE(Ld, 2); }, [&]() {}, 23);
+           [&]() { if constexpr (RVQ) ISSUE_RVQ_QKV_G(Ld, 2); else if constexpr (!kPreQkv) ISSUE(Ld, 2); }, [&]() {}, 23,
+           std::integral_constant<int, RVQ ? 8 : (kPreQkv ? 0 : 4)>{});
       BSTAMP(2);
     }
     if (more) P1_products(std::integral_constant<bool, kPreQkv>{}, Bq);
