@@ -44,6 +44,18 @@
 #ifndef QUIP_OWNER_PREDECODE
 #define QUIP_OWNER_PREDECODE 1     // A/B: the MLP row owners decode down's items ahead like everybody (1) or at the product (0)
 #endif
+#ifndef QUIP_ATT_STAMPS
+#define QUIP_ATT_STAMPS 0          // tools/dbg: the stamps 18..22 inside the attention instead of inside the gate / up edge
+#endif
+#if QUIP_ATT_STAMPS
+#define ASTAMP(i) BSTAMP(18 + (i))
+#else
+#define ASTAMP(i) do { } while (0)
+#endif
+#ifndef QUIP_ATT_THREADS
+#define QUIP_ATT_THREADS 256       // threads of a workgroup that visit cached positions (A/B: 512 -- the rounds are VALU-issue bound, the
+                                   // second wave of a SIMD only makes the first one wait at the barrier: 6.9K -> 7.1K clocks at 100 positions)
+#endif
 #ifndef QUIP_POLL2
 #define QUIP_POLL2 0               // A/B: the edges' gathers poll with TWO staggered read sets (1) or one (0).  Measured: two sets make
                                    // the hand-offs LONGER (z_o 3.6K -> 4.0K clocks, z_d 3.8K -> 4.4K; stagger 5 / 10 / 16 alike) -- the
@@ -629,7 +641,11 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
                   const f16* su0, const f16* su1, float sc0, float sc1, bool two, auto after_gather, auto drip1, auto drip2, int sb, auto ag_tag) {
     // ag_tag: VMEM requests `after_gather` issues (a hand count: the wait for the gather's second read set is said in them)
     // stamps of the edge's stages: 18..22 (sb = 18: the gate / up edge) or 23, 24, 28, 29, 30 (sb = 23: the q / k / v edge)
+#if QUIP_ATT_STAMPS
+#define ESTAMP(i) do { } while (0)
+#else
 #define ESTAMP(i) do { if (sb >= 0) BSTAMP(sb + (i) + ((sb == 23 && (i) >= 2) ? 3 : 0)); } while (0)
+#endif
     constexpr int NC = decltype(nc_tag)::value;
     constexpr bool HAVE_Z = decltype(z_tag)::value;
     u32x4 psv, pln, psu0, psu1;
@@ -946,8 +962,10 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       // written: 2 us per dependent round otherwise); later rounds are requested two rounds ahead of their use
       // (U: cached rows per key group and round; E8P12RVQ4B, at 256 registers, prefetches half as many -- the keys are
       //  visited in the same order either way)
-      constexpr int LPK = HD / 8, NG = 256 / LPK, U = (RVQ && !HI && !R3) ? 2 : 4;
-      const int g = (tid & 255) / LPK;
+      constexpr int ATH = QUIP_ATT_THREADS;
+      constexpr int LPK = HD / 8, NG = ATH / LPK, U = (RVQ && !HI && !R3) ? 2 : 4;
+      constexpr int NST = ATH / 64;                    // online-softmax states that meet in LDS: one per wave
+      const int g = (tid & (ATH - 1)) / LPK;
       const int kvh = hd / GQH;                        // the KV head of this query head (G8: four query heads per KV head)
       const f16* kc = Ld.kcache + (size_t)kvh * a.max_len * HD;
       const f16* vc = Ld.vcache + (size_t)kvh * a.max_len * HD;
@@ -962,7 +980,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           vr[u] = *reinterpret_cast<const uint4*>(vc + (size_t)tc * HD + d0);
         }
       };
-      if (tid < 256) {
+      if (tid < ATH) {
         load_round(kr0, vr0, g);
         if (part + nparts * NG * U < pos) load_round(kr1, vr1, g + NG * U);
       }
@@ -1089,8 +1107,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       // single-query attention of head hd over positions [0, pos] (decode_glue.hip's arithmetic): 16 lanes per key,
       // 16 key groups with their own online-softmax state, merged through LDS
       float* s_m = reinterpret_cast<float*>(smem + B::kArea);
-      float* s_l = s_m + NG;
-      float* s_acc = s_l + NG;                         // [NG][HD + 4]
+      float* s_l = s_m + NST;
+      float* s_acc = s_l + NST;                        // [NST][HD + 4]
       float q8[8], kn[8], vn[8];
       float m = -INFINITY, lsum = 0.f, acc8[8];
 #pragma unroll
@@ -1113,7 +1131,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         for (int i = 0; i < 8; ++i) acc8[i] = __builtin_fmaf(acc8[i], cc, had::fmul(pp, v8[i]));
         m = mn;
       };
-      if (tid < 256) {
+      if (tid < ATH) {
         rope8(s_qkv, q8);
 #pragma unroll
         for (int i = 0; i < 8; ++i) q8[i] *= a.attn_scale;
@@ -1129,27 +1147,24 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
             *const_cast<uint4*>(reinterpret_cast<const uint4*>(vc + (size_t)pos * HD + d0)) = vraw;
           }
         }
-        const int t_hi = pos + 1;
+        ASTAMP(0);
         // one round: positions t0 + u NG of this key group, rows in (kr, vr)
         auto round = [&](const uint4 (&kr)[U], const uint4 (&vr)[U], int i0) {
           float k8[U][8], v8[U][8], sc[U];
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             const int t = part + nparts * (i0 + u * NG);
+            (void)t;
             unpack8h(kr[u], k8[u]);
             unpack8h(vr[u], v8[u]);
-            if (t == pos) {
-#pragma unroll
-              for (int i = 0; i < 8; ++i) { k8[u][i] = kn[i]; v8[u][i] = vn[i]; }
-            }
             sc[u] = score(k8[u]);
           }
 #pragma unroll
           for (int u = 0; u < U; ++u)
-            if (part + nparts * (i0 + u * NG) < t_hi) update(sc[u], v8[u]);
+            if (part + nparts * (i0 + u * NG) < pos) update(sc[u], v8[u]);
         };
         // (uniform trip count: the lanes of a wave differ in g < NG only)
-        const int n_loc = t_hi > part ? (t_hi - part + nparts - 1) / nparts : 0;     // local indices of this workgroup
+        const int n_loc = pos > part ? (pos - part + nparts - 1) / nparts : 0;       // local indices of this workgroup's cached rows
         for (int ib = 0; ib < n_loc; ib += 2 * NG * U) {
           round(kr0, vr0, ib + g);
           if (ib + 2 * NG * U < n_loc) load_round(kr0, vr0, ib + g + 2 * NG * U);
@@ -1158,18 +1173,43 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
             if (ib + 3 * NG * U < n_loc) load_round(kr1, vr1, ib + g + 3 * NG * U);
           }
         }
+        // the new row (position pos, still in registers) is the LAST key of its group: the rounds visit cached rows only -- as
+        // a case inside them it cost sixteen register moves per key
+        if (part == (split ? (pos & (kParts - 1)) : 0) && g == (((pos - part) / nparts) & (NG - 1))) update(score(kn), vn);
       }
-      if (tid < 256) {
-        if ((tid & (LPK - 1)) == 0) { s_m[g] = m; s_l[g] = lsum; }
+      ASTAMP(1);
+      if (tid < ATH) {
+        // The four key groups of a wave (its four rows of 16 lanes) merge in registers first: v_permlane16_swap / 32_swap of a
+        // value with ITSELF hands every lane both partners' copies -- (even row, odd row) / (lower half, upper half) -- so both
+        // sides compute the same merged state and nobody selects.  Eight states meet in LDS instead of sixteen.
+        auto merge2 = [&](auto swap) {
+          const auto tm = swap(as_u32(m)), tl = swap(as_u32(lsum));
+          const float mA = as_f32((uint32_t)tm[0]), mB = as_f32((uint32_t)tm[1]);
+          const float M = fmaxf(mA, mB);
+          const float wA = mA == -INFINITY ? 0.f : __expf(mA - M), wB = mB == -INFINITY ? 0.f : __expf(mB - M);
+          lsum = __builtin_fmaf(as_f32((uint32_t)tl[1]), wB, had::fmul(as_f32((uint32_t)tl[0]), wA));
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s_acc[g * (HD + 4) + d0 + i] = acc8[i];
+          for (int i = 0; i < 8; ++i) {
+            const auto ta = swap(as_u32(acc8[i]));
+            acc8[i] = __builtin_fmaf(as_f32((uint32_t)ta[1]), wB, had::fmul(as_f32((uint32_t)ta[0]), wA));
+          }
+          m = M;
+        };
+        merge2([](uint32_t x) { return __builtin_amdgcn_permlane16_swap(x, x, false, false); });
+        merge2([](uint32_t x) { return __builtin_amdgcn_permlane32_swap(x, x, false, false); });
+        if (lane < LPK) {
+          if (lane == 0) { s_m[wave] = m; s_l[wave] = lsum; }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) s_acc[wave * (HD + 4) + d0 + i] = acc8[i];
+        }
       }
       had::wg_barrier<true>();
+      ASTAMP(2);
       f16* s_a = s_qkv + 3 * HD;
       float pM = -INFINITY, pL = 0.f, pO = 0.f;        // this workgroup's state for dimension tid: maximum, denominator, sum
       if (tid < HD) {
-        for (int g2 = 0; g2 < NG; ++g2) pM = fmaxf(pM, s_m[g2]);
-        for (int g2 = 0; g2 < NG; ++g2) {
+        for (int g2 = 0; g2 < NST; ++g2) pM = fmaxf(pM, s_m[g2]);
+        for (int g2 = 0; g2 < NST; ++g2) {
           const float ww = s_m[g2] == -INFINITY ? 0.f : __expf(s_m[g2] - pM);
           pL = __builtin_fmaf(s_l[g2], ww, pL);
           pO = __builtin_fmaf(s_acc[g2 * (HD + 4) + tid], ww, pO);
@@ -1227,7 +1267,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       } else if (tid < HD) {
         s_a[tid] = pos_ok ? (f16)(pO / pL) : __builtin_bit_cast(f16, (unsigned short)0x7e00);
       }
+      ASTAMP(3);
       had::wg_barrier<true>();
+      ASTAMP(4);
       if (head_wg && tid < 64) {
         const uint32_t pr = *reinterpret_cast<const uint32_t*>(s_a + 2 * tid);
         esync::st_granule(zbufs + (size_t)3 * 2048 + hd * 64 + tid, pr, ebase | (hop + 1u));

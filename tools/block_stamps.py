@@ -76,3 +76,10 @@ ro = np.arange(256) < (28 if g8 else 22)
 print("inside the MLP edge: row owners: publish(13) -> inbox complete %.0f, -> rows published(14) %.0f; everyone: 14 -> poll done(26) %.0f (row owners %.0f), sweep(27) %.0f, staging + barrier(15) %.0f" % (
     (D_[:, ro, 25] - D_[:, ro, 13]).mean(), (D_[:, ro, 14] - D_[:, ro, 25]).mean(), (D_[:, :, 26] - D_[:, :, 14]).mean(),
     (D_[:, ro, 26] - D_[:, ro, 14]).mean(), (D_[:, :, 27] - D_[:, :, 26]).mean(), (D_[:, :, 15] - D_[:, :, 27]).mean()))
+
+if os.environ.get("QUIP_ATT_STAMPS"):      # a library built with -DQUIP_ATT_STAMPS=1: stamps 18..22 sit inside the attention (head workgroups)
+    an = ["5 -> q, k roped, new row appended (18)", "key rounds (19)", "states to LDS + barrier (20)", "merge of the 16 groups (21)", "barrier (22)", "publication (6)"]
+    pts = [5, 18, 19, 20, 21, 22, 6]
+    print("inside the attention (head workgroups):")
+    for i in range(6):
+        print(f"  {an[i]:44s} {(D_[:, head, pts[i + 1]] - D_[:, head, pts[i]]).mean():9.0f}")
