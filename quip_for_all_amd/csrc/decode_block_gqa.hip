@@ -777,8 +777,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
       // single-query attention of head hd over positions [0, pos] (decode_glue.hip's arithmetic): 16 lanes per key,
       // 16 key groups with their own online-softmax state, merged through LDS
       float* s_m = reinterpret_cast<float*>(smem + B::kArea);
-      float* s_l = s_m + NG;
-      float* s_acc = s_l + NG;                         // [NG][HD + 4]
+      constexpr int NST = 4;                           // online-softmax states that meet in LDS: one per wave (waves 0..3)
+      float* s_l = s_m + NST;
+      float* s_acc = s_l + NST;                        // [NST][HD + 4]
       float q8[8], kn[8], vn[8];
       float m = -INFINITY, lsum = 0.f, acc8[8];
 #pragma unroll
@@ -815,25 +816,22 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
           *const_cast<uint4*>(reinterpret_cast<const uint4*>(kc + (size_t)pos * HD + d0)) = kr;
           *const_cast<uint4*>(reinterpret_cast<const uint4*>(vc + (size_t)pos * HD + d0)) = vraw;
         }
-        const int t_hi = pos + 1;
+        // (round 5, as in decode_block.hip: the rounds visit cached rows only -- the new row, still in registers, is the LAST key
+        //  of its group and scored behind them; as a case inside the rounds it cost sixteen register moves per key and kept the
+        //  scores off v_fma_mix)
         auto round = [&](const uint4 (&kr)[U], const uint4 (&vr)[U], int i0) {
           float k8[U][8], v8[U][8], sc[U];
 #pragma unroll
           for (int u = 0; u < U; ++u) {
-            const int t = part + nparts * (i0 + u * NG);
             unpack8h(kr[u], k8[u]);
             unpack8h(vr[u], v8[u]);
-            if (t == pos) {
-#pragma unroll
-              for (int i = 0; i < 8; ++i) { k8[u][i] = kn[i]; v8[u][i] = vn[i]; }
-            }
             sc[u] = score(k8[u]);
           }
 #pragma unroll
           for (int u = 0; u < U; ++u)
-            if (part + nparts * (i0 + u * NG) < t_hi) update(sc[u], v8[u]);
+            if (part + nparts * (i0 + u * NG) < pos) update(sc[u], v8[u]);
         };
-        const int n_loc = t_hi > part ? (t_hi - part + nparts - 1) / nparts : 0;
+        const int n_loc = pos > part ? (pos - part + nparts - 1) / nparts : 0;       // local indices of this workgroup's cached rows
         for (int ib = 0; ib < n_loc; ib += 2 * NG * U) {
           round(kr0, vr0, ib + g);
           if (ib + 2 * NG * U < n_loc) load_round(kr0, vr0, ib + g + 2 * NG * U);
@@ -842,17 +840,37 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
             if (ib + 3 * NG * U < n_loc) load_round(kr1, vr1, ib + g + 3 * NG * U);
           }
         }
-        if ((tid & (LPK - 1)) == 0) { s_m[g] = m; s_l[g] = lsum; }
+        if (part == (split ? (pos & (kParts - 1)) : 0) && g == (((pos - part) / nparts) & (NG - 1))) update(score(kn), vn);
+        // the four key groups of a wave (its rows of 16 lanes) merge in registers: v_permlane16_swap / 32_swap of a value with
+        // ITSELF hands every lane both partners' copies, so both sides compute the same state; four states meet in LDS
+        auto merge2 = [&](auto swap) {
+          const auto tm = swap(as_u32(m)), tl = swap(as_u32(lsum));
+          const float mA = as_f32((uint32_t)tm[0]), mB = as_f32((uint32_t)tm[1]);
+          const float M = fmaxf(mA, mB);
+          const float wA = mA == -INFINITY ? 0.f : __expf(mA - M), wB = mB == -INFINITY ? 0.f : __expf(mB - M);
+          lsum = __builtin_fmaf(as_f32((uint32_t)tl[1]), wB, had::fmul(as_f32((uint32_t)tl[0]), wA));
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s_acc[g * (HD + 4) + d0 + i] = acc8[i];
+          for (int i = 0; i < 8; ++i) {
+            const auto ta = swap(as_u32(acc8[i]));
+            acc8[i] = __builtin_fmaf(as_f32((uint32_t)ta[1]), wB, had::fmul(as_f32((uint32_t)ta[0]), wA));
+          }
+          m = M;
+        };
+        merge2([](uint32_t x) { return __builtin_amdgcn_permlane16_swap(x, x, false, false); });
+        merge2([](uint32_t x) { return __builtin_amdgcn_permlane32_swap(x, x, false, false); });
+        if (lane < LPK) {
+          if (lane == 0) { s_m[wave] = m; s_l[wave] = lsum; }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) s_acc[wave * (HD + 4) + d0 + i] = acc8[i];
+        }
       }
       had::wg_barrier<false>();                        // (full fence: the cache rows' loads are the compiler's own)
       own_ring();
       f16* s_a = s_qkv + 3 * HD;
       float pM = -INFINITY, pL = 0.f, pO = 0.f;
       if (tid < HD) {
-        for (int g2 = 0; g2 < NG; ++g2) pM = fmaxf(pM, s_m[g2]);
-        for (int g2 = 0; g2 < NG; ++g2) {
+        for (int g2 = 0; g2 < NST; ++g2) pM = fmaxf(pM, s_m[g2]);
+        for (int g2 = 0; g2 < NST; ++g2) {
           const float ww = s_m[g2] == -INFINITY ? 0.f : __expf(s_m[g2] - pM);
           pL = __builtin_fmaf(s_l[g2], ww, pL);
           pO = __builtin_fmaf(s_acc[g2 * (HD + 4) + tid], ww, pO);
