@@ -253,9 +253,10 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   // 10..12 = down, slice (kind - 10) * 8 + wave.  A load = scalar base of the matrix + a 32-bit byte offset of this
   // lane (+ 64 for the second half of the item).
   uint32_t vo_row, vo_q[3], vo_gu[G8 ? 7 : FRB], vo_d[G8 ? 4 : 3], vo_d2b, vo_dr[3];
-  // G8: the stacked [q; k; v] rows are 384 blocks of 16 (q 0..255, k 256..319, v 320..383): two on the even workgroups, one on
-  // the odd ones -- blocks qb0 .. qb0 + qcnt - 1; all but workgroup 170 (q 255 | k 0) stay inside one matrix
-  const int qb0 = (3 * w + (w & 1)) >> 1, qcnt = 2 - (w & 1);
+  // G8: the stacked [q; k; v] rows are 384 blocks of 16 (q 0..255, k 256..319, v 320..383): q's two by two on workgroups 0..127,
+  // k's and v's one each on 128..255 -- blocks qb0 .. qb0 + qcnt - 1, always inside ONE matrix (two by two on the even workgroups
+  // and one on the odd ones, workgroup 170 held q 255 | k 0: two input transforms, 1.1 us for which everybody waited)
+  const int qb0 = w < 128 ? 2 * w : 128 + w, qcnt = w < 128 ? 2 : 1;
   auto qmat = [](int b) { return b < 256 ? 0 : (b < 320 ? 1 : 2); };
   auto qblk = [](int b) { return b < 256 ? b : (b < 320 ? b - 256 : b - 320); };
   uint32_t lane_c, lane_c2, lane_c3 = 0u, xlane;
