@@ -537,6 +537,14 @@ int quip_block_engine(const quip_block_engine_args* args, quip_stream_t stream);
 int quip_debug_occupy(int32_t nwg, int32_t lds_bytes, int64_t ticks, void* sink, quip_stream_t stream);
 int quip_block_engine_gqa_supported(int32_t hidden, int32_t heads, int32_t kv_heads, int32_t head_dim, int32_t n_ffn, int32_t K);
 size_t quip_block_engine_gqa_workspace_bytes(void);
+/* shape 1 reads its seven code matrices W[0..6] RE-TILED (round 5), not in the checkpoint's row-major layout: inside every aligned
+ * block of 16 rows the 64-byte pieces of the 16 rows lie side by side, piece after piece --
+ *   tiled[rb][c][q][n] (16 bytes) = bytes [64 c + 16 q, +16) of row 16 rb + n,   rb < rows / 16, c < row_bytes / 64, q < 4, n < 16
+ * -- so that one load instruction of the product (16 rows x 64 bytes of a row-major matrix: origin_order.cu:388-555 walks the rows)
+ * covers 1 KB of consecutive bytes: a pure read stream in the row-major pattern tops at 0.72 of the HBM peak on this part, in full
+ * lines at 0.85-0.88 (tools/ubench/hbm_read.hip).  quip_tile_codes writes that copy (same size; not in place; rows % 16 == 0,
+ * row_bytes % 64 == 0, both pointers 16-byte aligned): once per matrix at model load.  Shapes 0 and 2 read the checkpoint's layout. */
+int quip_tile_codes(const void* qidxs, void* tiled, int64_t rows, int64_t row_bytes, quip_stream_t stream);
 /* shape 2 (round 5): hidden 4096, 32 heads of 128 on 8 KV heads, n_ffn = 14336 = 7 x 2048 (Llama-3-8B, Mistral-7B; E8P12 only): the
  * shape-0 launch compiled for this shape.  Descriptors as for shape 0, except had3 = the 56 x 56 factors R_7 (x) H_8 of gate.had_right,
  * up.had_right (row major, 3136 fp16 each) and of down.had_left TRANSPOSED (64 rows of 72 fp16, zero padded): see decode_block.hip, QUIP_BLOCK_G8. */

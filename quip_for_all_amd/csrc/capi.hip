@@ -530,6 +530,32 @@ int quip_block_engine(const quip_block_engine_args* in, quip_stream_t stream) {
   return block_engine_launch(a, (hipStream_t)stream);
 }
 
+namespace {
+// tiled[rb][c][q][n] = bytes [64 c + 16 q, +16) of row 16 rb + n: one 16-byte piece per thread, destination order
+__global__ void tile_codes_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long long pieces, int row_u4) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pieces) return;
+  const int n = (int)(i & 15), q = (int)((i >> 4) & 3);
+  const long long cc = i >> 6;                         // (row block, 64-byte piece) pairs
+  const int pieces_per_row = row_u4 / 4;
+  const long long rb = cc / pieces_per_row;
+  const int c = (int)(cc - rb * pieces_per_row);
+  dst[i] = src[(rb * 16 + n) * row_u4 + c * 4 + q];
+}
+}  // namespace
+
+int quip_tile_codes(const void* qidxs, void* tiled, int64_t rows, int64_t row_bytes, quip_stream_t stream) {
+  if (!qidxs || !tiled) return QUIP_ERR_NULL_POINTER;
+  if (rows < 0 || row_bytes <= 0 || rows % 16 != 0 || row_bytes % 64 != 0 || row_bytes > (1 << 24)) return QUIP_ERR_BAD_SHAPE;
+  if (rows == 0) return QUIP_OK;
+  if (!aligned16(qidxs) || !aligned16(tiled)) return QUIP_ERR_MISALIGNED;
+  if (qidxs == tiled) return QUIP_ERR_UNSUPPORTED;      // (not in place)
+  const long long pieces = rows * (row_bytes / 16);
+  hipLaunchKernelGGL(tile_codes_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const uint4*>(qidxs), reinterpret_cast<uint4*>(tiled), pieces, (int)(row_bytes / 16));
+  return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+}
+
 int quip_block_engine_gqa_supported(int32_t hidden, int32_t heads, int32_t kv_heads, int32_t head_dim, int32_t n_ffn, int32_t K) {
   return block_engine_gqa_supported(hidden, heads, kv_heads, head_dim, n_ffn, K) ? 1 : 0;
 }

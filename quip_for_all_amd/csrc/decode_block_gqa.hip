@@ -163,14 +163,21 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     int t = threadIdx.x;
     asm volatile("" : "+v"(t));
     tid = t; lane = t & 63; n = lane & 15; q = lane >> 4;
-    vo_h = (uint32_t)((32 * w + n) * kRowH + (wave * 8 + q) * 16);
+    // Round 5: the launch streams a RE-TILED copy of the codes (the host makes it once per model: decode.py, quip_tile_codes):
+    // inside every aligned block of 16 rows the 64-byte pieces of the 16 rows lie side by side, piece after piece --
+    //   tiled[rb][c][q][n] = Qidxs[16 rb + n][64 c + 16 q, +16)      (1 KB per (rb, c): exactly one load instruction)
+    // so a wave's two instructions of an item are 2 KB of CONSECUTIVE bytes at slice * 2 KB instead of 16 rows x 64 bytes each.
+    // tools/ubench/hbm_read.hip: a pure read stream in the old pattern tops at 0.72 (K = 8192) / 0.68 (K = 28672) of 8 TB/s, in
+    // full lines at 0.85-0.88.  Row-block offsets are what they were (a block of 16 rows is 16 x row bytes either way).
+    const uint32_t lt = (uint32_t)(wave * 2048 + lane * 16);
+    vo_h = (uint32_t)(32 * w * kRowH) + lt;
     // q rows: the pair of workgroups (2 p, 2 p + 1) owns rows [64 p, +64): three row blocks on the even one (it has no k | v
     // rows), one on the odd one -- the odd workgroups' extra transform and k | v items no longer make them the last to publish
-    vo_qb = (uint32_t)((64 * (w >> 1) + (has_kv ? 48 : 0) + n) * kRowH + (wave * 8 + q) * 16);
-    vo_qa = has_kv ? (uint32_t)((16 * (kvb & 63) + n) * kRowH + (wave * 8 + q) * 16) : vo_qb + (uint32_t)(32 * kRowH);
+    vo_qb = (uint32_t)((64 * (w >> 1) + (has_kv ? 48 : 0)) * kRowH) + lt;
+    vo_qa = has_kv ? (uint32_t)(16 * (kvb & 63) * kRowH) + lt : vo_qb + (uint32_t)(32 * kRowH);
     vo_qb1 = has_kv ? (uint32_t)((lane & 31) * 16) : vo_qb + (uint32_t)(16 * kRowH);
-    vo_gu = (uint32_t)((16 * w + n) * kRowH + (wave * 8 + q) * 16);
-    vo_d = (uint32_t)((32 * w + n) * kRowF + (wave * 8 + q) * 16);
+    vo_gu = (uint32_t)(16 * w * kRowH) + lt;
+    vo_d = (uint32_t)(32 * w * kRowF) + lt;
     vo_hot = (uint32_t)((lane & 31) * 16);     // (the hot 2 KB: offsets < 496 + 1024 + 80)
     lane_c = (T::kRep1 == 32) ? ((((uint32_t)lane & 31u) << 3) | 0x00010000u) : ((((uint32_t)lane & 15u) << 3) | (uint32_t)T::kT1);
     lane_c2 = (((uint32_t)lane & 15u) << 3) | (uint32_t)T::kT2;
@@ -192,15 +199,14 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     const uint4* base;
     uint32_t vo;
     constexpr int u_gu = t - SQ_GU, u_d = t - SQ_D, u_q = t - SQ_B;
-    constexpr int off = t < SQ_GU ? (t & 1) * 16 * kRowH
-                        : t < SQ_D ? (u_gu % 7) * FL * kRowH
-                        : t < SQ_F ? (u_d & 1) * 16 * kRowF + ((u_d >> 1) >= 4 ? 4096 : 0)
-                        : 0;
-    constexpr int imm = t < SQ_GU ? (t >> 1) * 1024
-                        : t < SQ_D ? ((u_gu / 7) >> 1) * 1024
-                        : t < SQ_F ? ((u_d >> 1) & 3) * 1024
+    // row block (as before) + the 1 KB column span of the old layout = 16 KB of the tiled one (8 waves x 2 KB)
+    constexpr int kSpan = 16 * 1024;
+    constexpr int off = t < SQ_GU ? (t & 1) * 16 * kRowH + (t >> 1) * kSpan
+                        : t < SQ_D ? (u_gu % 7) * FL * kRowH + ((u_gu / 7) >> 1) * kSpan
+                        : t < SQ_F ? (u_d & 1) * 16 * kRowF + (u_d >> 1) * kSpan
                         : t < SQ_A ? 0
-                        : t < SQ_B ? (t - SQ_A) * 1024 : (u_q >> 1) * 1024;
+                        : t < SQ_B ? (t - SQ_A) * kSpan : 0;
+    constexpr int imm = 0;
     // (a wrapped request comes from the tail of an iteration: items 0..2 -- requested by down's last item and the fillers --
     //  belong to the NEXT block, items 3..8 -- requested by q and k | v at the top of the iteration -- to this one)
     if constexpr (t < SQ_GU) { base = (wrap && t < 3) ? pw_o2 : pw_o; vo = vo_h; }
@@ -211,13 +217,15 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     else if constexpr ((u_q & 1) == 0) { base = pw_q; vo = vo_qb; }
     else { base = pw_qb1; vo = vo_qb1; }
     static_assert(!wrap || t < SQ_GU + 7, "a wrapped request stays inside o / gate");
-    const uint4* bo = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + off);
+    // q's items (t >= SQ_B): their span -- not for the odd workgroups' fillers, which read the hot 2 KB
+    const int offq = t >= SQ_B ? (((u_q & 1) != 0 && has_kv) ? 0 : (u_q >> 1) * kSpan) : 0;
+    const uint4* bo = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + off + offq);
     // s_nop: a scalar base fresh from v_readfirstlane / v_readlane needs 5 wait states before a VMEM instruction reads it,
     // and the compiler pads nothing inside an asm statement
     u32x4& da = qa[slot];                              // (named here: an asm operand alone does not capture in a generic lambda)
     u32x4& db = qb[slot];
     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(da) : "v"(vo), "s"(bo), "n"(imm) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(db) : "v"(vo), "s"(bo), "n"(imm + 64) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(db) : "v"(vo), "s"(bo), "n"(imm + 1024) : "memory");
   };
   // after a drain every slot is a plain register again
   auto own_ring = [&]() __attribute__((always_inline)) {

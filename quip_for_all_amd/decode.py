@@ -77,6 +77,24 @@ def random_quant_linear(in_f, out_f, codebook="E8P12", generator=None, device="c
     return layer.to(device).eval()
 
 
+def tile_codes(qidxs):
+    """The persistent 8192-wide launch's layout of a code matrix (include/quip_mi355.h: quip_tile_codes; decode_block_gqa.hip):
+    inside every aligned block of 16 rows the 64-byte pieces of the 16 rows lie side by side, piece after piece --
+    tiled[rb][c][q][n] = bytes [64 c + 16 q, +16) of row 16 rb + n -- so that one load instruction of the product (16 rows x
+    64 bytes in the checkpoint's layout; origin_order.cu:388-555 walks it row-major) covers 1 KB of consecutive bytes.
+    Returns a flat uint8 tensor of the same size on the same device."""
+    from . import capi
+    b = qidxs.detach().contiguous().view(torch.uint8).reshape(qidxs.shape[0], -1)
+    rows, rb = b.shape
+    out = torch.empty(rows * rb, dtype=torch.uint8, device=b.device)
+    if not b.is_cuda:
+        raise capi.QuipNativeError("tile_codes: the codes must be on the GPU (there is no CPU path)")
+    with torch.cuda.device(b.device):
+        capi.check(capi.lib().quip_tile_codes(b.data_ptr(), out.data_ptr(), rows, rb, torch.cuda.current_stream(b.device).cuda_stream),
+                   "quip_tile_codes")
+    return out
+
+
 class LlamaDecoder:
     """Random-init Llama with QuantLinear projections, static KV cache, bs=1."""
 
@@ -360,7 +378,14 @@ class LlamaDecoder:
                 else:
                     had3 = _engine_had3(L["gate"], L["up"], L["down"])
             keep += su + sv + ln + [had3]
-            ptrs = ([m.Qidxs.data_ptr() for m in mods] + [t.data_ptr() for t in ln] + [t.data_ptr() for t in su]
+            if gqa:
+                # shape 1 streams a re-tiled copy of the codes (decode_block_gqa.hip: full-line requests): one more copy of the
+                # weights in HBM, made once per model; the checkpoint's tensors stay what the stage-wise step and prefill read
+                wq = [tile_codes(m.Qidxs) for m in mods]
+                keep += wq
+            else:
+                wq = [m.Qidxs for m in mods]
+            ptrs = ([t.data_ptr() for t in wq] + [t.data_ptr() for t in ln] + [t.data_ptr() for t in su]
                     + [t.data_ptr() for t in sv] + [had3.data_ptr(), self.kcache[i].data_ptr(), self.vcache[i].data_ptr()])
             rec[i, :26] = np.array(ptrs, dtype=np.uint64)
             sc = [m.wscale_float / math.sqrt(m.q_in_features // m.K_left) for m in mods]

@@ -76,6 +76,13 @@ def test_argument_validation_without_gpu(libpath):
     assert L.quip_d4_gemv_planes_group_ws(vp, vp, None, vp, n1, 1, 128, None, 0, None) == -1
     assert L.quip_d4_gemv_planes_group_ws(vp, vp, p16, vp, n1, 1, 12, None, 0, None) == -2      # k % 8
     assert L.quip_d4_gemv_planes_v2(p16, p16, p16, None, 8, 128, None, 0, None) == -1
+    # round 5: the shape-1 launch's re-tiled copy of a code matrix
+    assert L.quip_tile_codes(None, p16, 16, 64, None) == -1
+    assert L.quip_tile_codes(p16, p16 + 1024, 24, 64, None) == -2                        # rows % 16
+    assert L.quip_tile_codes(p16, p16 + 1024, 16, 96, None) == -2                        # row_bytes % 64
+    assert L.quip_tile_codes(p16, p16 + 1026, 16, 64, None) == -3                        # misaligned destination
+    assert L.quip_tile_codes(p16, p16, 16, 64, None) == -5                               # in place
+    assert L.quip_tile_codes(p16, p16 + 1024, 0, 64, None) == 0                          # empty: ok, no launch
 
 
 def test_ops_registered_and_fail_loudly_on_cpu(libpath):

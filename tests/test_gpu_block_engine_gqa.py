@@ -151,3 +151,26 @@ def test_four_full_size_70b_blocks_against_float64_model():
     print(f"4 x 70B-shaped blocks (E8P12), logits of step 3 vs float64: max {u:.2f} fp16 ulps of rms(logits) = "
           f"{np.sqrt(np.mean(ref * ref)):.3f} (bound {deep_bound_ulps(4):.1f})")
     assert u <= deep_bound_ulps(4), u
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,row_bytes", [(16, 64), (48, 2048), (256, 7168), (32, 192)])
+def test_tile_codes_is_the_stated_permutation(rows, row_bytes):
+    """quip_tile_codes (the layout the shape-1 launch streams; include/quip_mi355.h): tiled[rb][c][q][n] = bytes
+    [64 c + 16 q, +16) of row 16 rb + n -- bit exact against the index arithmetic written out"""
+    from quip_for_all_amd import decode as D
+    g = torch.Generator().manual_seed(rows * 7 + row_bytes)
+    src = torch.randint(0, 256, (rows, row_bytes), dtype=torch.uint8, generator=g)
+    got = D.tile_codes(src.view(torch.int16).cuda()).cpu().numpy()
+    ref = np.empty(rows * row_bytes, dtype=np.uint8)
+    a = src.numpy()
+    i = 0
+    for rb in range(rows // 16):
+        for c in range(row_bytes // 64):
+            for q in range(4):
+                for n in range(16):
+                    ref[i:i + 16] = a[16 * rb + n, 64 * c + 16 * q:64 * c + 16 * q + 16]
+                    i += 16
+    assert np.array_equal(got, ref)
+    # and a permutation: every byte of the source exactly once (sorted bytes agree)
+    assert np.array_equal(np.sort(got), np.sort(a.reshape(-1)))
