@@ -11,7 +11,7 @@
 //     landed" is the constant `s_waitcnt vmcnt(16)`.  The queue is empty after every hand-off's gather (its polls drain
 //     it), in particular at the block loop's back edge, where the compiler is free to copy registers.
 //   * Row ownership: o / down rows [32 w, +32) (two row blocks); k | v: row block w >> 1 of the stacked [k; v] rows on the odd
-//     workgroups; q: rows [64 p, +64) per PAIR of workgroups, three row blocks on the even one, one on the odd one; gate / up rows k * 4096 + 16 w + i, k < 7 (seven row blocks: COLUMNS [16 w, +16) of the
+//     workgroups; q: rows [64 p, +64) per PAIR of workgroups, three row blocks on the even one, one on the odd one; gate / up: ONE of the two matrices per workgroup (w >> 7), rows k * 4096 + 32 (w & 127) + i, k < 7, i < 32 (fourteen row blocks: COLUMNS [32 (w & 127), +32) of the
 //     (7, 4096) view, so the 7 x 7 mix of the output transform is local to the workgroup).
 //   * 8192-point transforms on 512 threads x 16 elements with one LDS exchange, in two directions (fht_wg512x.hip.h):
 //     gather (natural order) -> fwd -> residual / RMSNorm / SU in the strided layout (the static vectors are stored
@@ -154,6 +154,10 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
   // this workgroup's k | v row block (odd workgroups): block kvb of the stacked [k; v] row blocks
   const bool has_kv = (w & 1) != 0;
   const int kvb = w >> 1, kvm = kvb >> 6;                  // kvm: 0 = k, 1 = v
+  // gate / up (end of round 5, as decode_block.hip since its restructuring): workgroup w multiplies ONE of the two matrices --
+  // mgu = w >> 7: 0 gate, 1 up -- for TWO groups of 16 columns of the (7, 4096) view, [32 (w & 127), +32), instead of both matrices
+  // for one group: the same 28 items per wave, but ONE input transform and one set of digit planes on the edge in front of them
+  const int mgu = w >> 7;
 
   // ---- the weight ring ----------------------------------------------------------------------------------------------
   u32x4 qa[NS], qb[NS];
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     vo_qb = (uint32_t)((64 * (w >> 1) + (has_kv ? 48 : 0)) * kRowH) + lt;
     vo_qa = has_kv ? (uint32_t)(16 * (kvb & 63) * kRowH) + lt : vo_qb + (uint32_t)(32 * kRowH);
     vo_qb1 = has_kv ? (uint32_t)((lane & 31) * 16) : vo_qb + (uint32_t)(16 * kRowH);
-    vo_gu = (uint32_t)(16 * w * kRowH) + lt;
+    vo_gu = (uint32_t)(32 * (w & 127) * kRowH) + lt;
     vo_d = (uint32_t)(32 * w * kRowF) + lt;
     vo_hot = (uint32_t)((lane & 31) * 16);     // (the hot 2 KB: offsets < 496 + 1024 + 80)
     lane_c = (T::kRep1 == 32) ? ((((uint32_t)lane & 31u) << 3) | 0x00010000u) : ((((uint32_t)lane & 15u) << 3) | (uint32_t)T::kT1);
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
   };
   rederive();
   // uniform matrix bases of the stream: this block's o, gate, up, down; the next block's q, k | v, o; a hot 2 KB
-  const uint4 *pw_o, *pw_g, *pw_u, *pw_d, *pw_q, *pw_qa, *pw_qb1, *pw_o2, *pw_hot;
+  const uint4 *pw_o, *pw_g, *pw_d, *pw_q, *pw_qa, *pw_qb1, *pw_o2, *pw_hot;
   auto uni = [](const void* p) -> const uint4* {
     const uint64_t v = reinterpret_cast<uint64_t>(p);
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     // row block (as before) + the 1 KB column span of the old layout = 16 KB of the tiled one (8 waves x 2 KB)
     constexpr int kSpan = 16 * 1024;
     constexpr int off = t < SQ_GU ? (t & 1) * 16 * kRowH + (t >> 1) * kSpan
-                        : t < SQ_D ? (u_gu % 7) * FL * kRowH + ((u_gu / 7) >> 1) * kSpan
+                        : t < SQ_D ? (u_gu % 7) * FL * kRowH + ((u_gu / 7) & 1) * 16 * kRowH + ((u_gu / 7) >> 1) * kSpan
                         : t < SQ_F ? (u_d & 1) * 16 * kRowF + (u_d >> 1) * kSpan
                         : t < SQ_A ? 0
                         : t < SQ_B ? (t - SQ_A) * kSpan : 0;
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     // (a wrapped request comes from the tail of an iteration: items 0..2 -- requested by down's last item and the fillers --
     //  belong to the NEXT block, items 3..8 -- requested by q and k | v at the top of the iteration -- to this one)
     if constexpr (t < SQ_GU) { base = (wrap && t < 3) ? pw_o2 : pw_o; vo = vo_h; }
-    else if constexpr (t < SQ_D) { base = ((u_gu / 7) & 1) ? pw_u : pw_g; vo = vo_gu; }
+    else if constexpr (t < SQ_D) { base = pw_g; vo = vo_gu; }      // (this workgroup's matrix: gate | up)
     else if constexpr (t < SQ_F) { base = pw_d; vo = vo_d; }
     else if constexpr (t < SQ_A) { base = pw_hot; vo = vo_hot; }
     else if constexpr (t < SQ_B) { base = pw_qa; vo = vo_qa; }
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
 
   // bases of the stream for the block whose descriptor sits in slot `cur` (o, gate, up, down) and the one in slot `nxt`
   auto set_bases = [&](const GLayer& C, const GLayer& N) __attribute__((always_inline)) {
-    pw_o = uni(C.W[3]); pw_g = uni(C.W[4]); pw_u = uni(C.W[5]); pw_d = uni(C.W[6]);
+    pw_o = uni(C.W[3]); pw_g = uni(C.W[4 + mgu]); pw_d = uni(C.W[6]);
     pw_q = uni(N.W[0]); pw_qa = has_kv ? uni(N.W[1 + kvm]) : pw_q; pw_qb1 = has_kv ? pw_hot : pw_q; pw_o2 = uni(N.W[3]);
   };
   set_bases(desc[0], desc[0]);
@@ -979,15 +983,15 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
 
     // ================= o's output side + residual, RMSNorm, input transforms of gate / up; their products ===================
     rederive();
-    if (!so) edge(IC<2>{}, zo, ebase | hop, 0x7000u, Ld.sv[3], Ld.ln[1], Ld.su[4], Ld.su[5], Ld.sc[4], Ld.sc[5], true, 3, 23);
+    if (!so) edge(IC<2>{}, zo, ebase | hop, 0x7000u, Ld.sv[3], Ld.ln[1], Ld.su[4 + mgu], Ld.su[4 + mgu], Ld.sc[4 + mgu], Ld.sc[4 + mgu], false, 3, 23);
     BSTAMP(10);
     rederive();
     {
-      const uint32_t pg = (uint32_t)B::kArea, pu = (uint32_t)(B::kArea + 3 * B::PSH);
-      group(IC<SQ_GU>{}, IC<7>{}, xaddr(pg, B::PSH, 0), B::AGU);
-      group(IC<SQ_GU + 7>{}, IC<7>{}, xaddr(pu, B::PSH, 0), B::AGU + 112);
-      group(IC<SQ_GU + 14>{}, IC<7>{}, xaddr(pg, B::PSH, 1), B::AGU);
-      group(IC<SQ_GU + 21>{}, IC<7>{}, xaddr(pu, B::PSH, 1), B::AGU + 112);
+      // 14 items per K span: chunks k = 0..6 of the first 16 columns (accumulator rows AGU + 16 k + i), then of the second 16
+      // (AGU + 112 + 16 k + i) -- one set of A fragments per span
+      const uint32_t pg = (uint32_t)B::kArea;
+      group(IC<SQ_GU>{}, IC<14>{}, xaddr(pg, B::PSH, 0), B::AGU);
+      group(IC<SQ_GU + 14>{}, IC<14>{}, xaddr(pg, B::PSH, 1), B::AGU);
     }
     had::wg_barrier<true>();
     BSTAMP(11);
@@ -1001,23 +1005,23 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     if (tid < 224) {
       const int* s3 = accs + (B::AGU + tid) * 4;
       const float f = __builtin_fmaf((float)s3[0], 65536.f, __builtin_fmaf((float)s3[1], 256.f, (float)s3[2]));
-      zcol[tid] = (float)(f16)(f * unscale_of(shs[3 + tid / 112], 2));
+      zcol[tid] = (float)(f16)(f * unscale_of(shs[3], 2));      // [column group][k][i]: one matrix, one exponent
     }
     had::wg_barrier<true>();
     zero_acc(B::AGU, 224);
     ++hop;                                             // hand-off: columns -> chunk owners
     const uint32_t tag1 = ebase | hop;
     if (tid < 224) {
-      // output (matrix mm, chunk k', column i): t = sum_k had[k'][k] z[k][i]
-      const int mm = tid / 112, rem = tid - 112 * mm, kq = rem >> 4, i = rem & 15;
-      const float* hs = mixf + (mm * 7 + kq) * 8;
-      const float* zz = zcol + mm * 112 + i;
+      // output (this workgroup's matrix mgu, chunk k', column 32 (w & 127) + 16 cg + i): t = sum_k had[k'][k] z[k][column]
+      const int cg = tid / 112, rem = tid - 112 * cg, kq = rem >> 4, i = rem & 15;
+      const float* hs = mixf + (mgu * 7 + kq) * 8;
+      const float* zz = zcol + cg * 112 + i;
       float t = 0.f;
 #pragma unroll
       for (int k = 0; k < FK; ++k) t = __builtin_fmaf(hs[k], zz[16 * k], t);
       const float tn = __shfl_down(t, 1, 64);
       if ((i & 1) == 0)
-        esync::st_granule2(inbox + ((size_t)(kq * 2 + mm) * FL + 16 * w + i), as_u32(t), as_u32(tn), tag1);
+        esync::st_granule2(inbox + ((size_t)(kq * 2 + mgu) * FL + 32 * (w & 127) + 16 * cg + i), as_u32(t), as_u32(tn), tag1);
     }
     ++hop;                                             // hand-off: rows -> everybody
     const uint32_t tag2 = ebase | hop;
