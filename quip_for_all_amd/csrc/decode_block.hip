@@ -985,6 +985,10 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         load_round(kr0, vr0, g);
         if (part + nparts * NG * U < pos) load_round(kr1, vr1, g + NG * U);
       }
+      // SV of this head's q / k / v values (waves 0..2 finish one vector each below): requested HERE, in front of the hand-off's
+      // wait -- read at its use it was a memory latency on the heads' critical path
+      uint32_t svp_raw = 0u;
+      if (wave < 3) svp_raw = *reinterpret_cast<const uint32_t*>(Ld.sv[wave] + HD * ((G8 && wave > 0) ? kvh : hd) + 2 * lane);
       f16* s_qkv = reinterpret_cast<f16*>(smem + B::kQkv);
       {
         // Round 5: only this head's 128 values of H_4096 z are needed, for z = z_q, z_k, z_v.  H_4096 = H_32 (x) H_128 with the
@@ -1068,7 +1072,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           }
           hadw::reg_stage<2, 1>(y);
           hadw::lane_stages<2, 0, 6>(y, lane);
-          const f16x2 svp = as_f16x2(*reinterpret_cast<const uint32_t*>(Ld.sv[wave] + HD * ((G8 && wave > 0) ? kvh : hd) + 2 * lane));
+          const f16x2 svp = as_f16x2(svp_raw);
           const float osc = (G8 && wave > 0) ? 1.f / 32.f : 1.f / 64.f;      // 1 / sqrt(1024) | 1 / sqrt(4096)
           s_qkv[wave * HD + 2 * lane] = had::out_elem(y[0], osc, true, (float)svp.x, false, 0.f, false, 0.f);
           s_qkv[wave * HD + 2 * lane + 1] = had::out_elem(y[1], osc, true, (float)svp.y, false, 0.f, false, 0.f);

@@ -669,6 +669,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
         load_round(kr0, vr0, g);
         if (part + nparts * NG * U < pos) load_round(kr1, vr1, g + NG * U);
       }
+      // SV of this head's q values (wave 2 finishes them below): requested in front of the hand-off's wait, not at its use
+      uint32_t svq_raw = 0u;
+      if (wave == 2) svq_raw = *reinterpret_cast<const uint32_t*>(Ld.sv[0] + HD * hd + 2 * lane);
       f16* s_qkv = reinterpret_cast<f16*>(smem + B::kQkv);
       {
         // gather z_q (everybody) and z_k / z_v (waves 0 / 1: they went out first, ahead of the q items) in one poll
@@ -727,6 +730,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
             for (int r = 0; r < 16; r += 4) *reinterpret_cast<float4*>(dstp + r) = float4{u[r], u[r + 1], u[r + 2], u[r + 3]};
           }
         }
+        had::wg_barrier<true>();
+        // (k | v on waves 0 / 1 and q on wave 2 -- three SIMDs -- side by side behind ONE barrier: the k / v transform used to sit in
+        //  front of it, with wave 2 waiting)
         if (kvw) {
           float kv[16], svf[16];
 #pragma unroll
@@ -743,7 +749,6 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
             for (int r = 0; r < 16; ++r) dst[r] = had::out_elem(kv[r], 1.f / 32.f, true, svf[r], false, 0.f, false, 0.f);
           }
         }
-        had::wg_barrier<true>();
         if (wave == 2) {
           float y[2] = {0.f, 0.f};
 #pragma unroll
@@ -754,7 +759,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
           }
           hadw::reg_stage<2, 1>(y);
           hadw::lane_stages<2, 0, 6>(y, lane);
-          const f16x2 svq = as_f16x2(*reinterpret_cast<const uint32_t*>(Ld.sv[0] + HD * hd + 2 * lane));
+          const f16x2 svq = as_f16x2(svq_raw);
           s_qkv[2 * lane] = had::out_elem(y[0], kOutScaleH, true, (float)svq.x, false, 0.f, false, 0.f);
           s_qkv[2 * lane + 1] = had::out_elem(y[1], kOutScaleH, true, (float)svq.y, false, 0.f, false, 0.f);
         }
