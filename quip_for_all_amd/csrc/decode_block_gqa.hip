@@ -1143,6 +1143,12 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     BSTAMP(14);
     {
       const float s2 = had::fmul(in_scale, as_f32((uint32_t)(sh_d + 127) << 23));
+      // the 7 x 7 factors of the mix with their scales folded in -- row kp of down.had_left^T times (2^sh wscale) times the
+      // chunk's step M_k / (2^23 - 1) -- once per block into LDS (zcol: free since the columns went out); the sweep reads a row
+      // as two broadcast 16-byte pieces.  (They used to be rebuilt per row and chunk through v_readfirstlane: 3 VALU per factor,
+      // 294 per thread and block, a third of the sweep's arithmetic.)
+      if (tid < FK * 8) zcol[tid] = (tid & 7) < FK ? had::fmul(had::fmul(mixf[(14 + (tid >> 3)) * 8 + (tid & 7)], s2), red[40 + (tid & 7)]) : 0.f;
+      had::wg_barrier<true>();
       uint8_t* pl = reinterpret_cast<uint8_t*>(smem + B::kArea);
       const uint32_t t16 = tag2 & 0xffffu;
       // columns [4 (t + 512 c), +4) of the seven rows = one 16-byte piece (two granules) per row; chunk 1 is in flight while
@@ -1181,13 +1187,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
         const int col = 4 * (tid + 512 * c);
 #pragma unroll
         for (int kp = 0; kp < FK; ++kp) {
-          // row kp of down.had_left^T times (2^sh wscale) times the chunk's step M_k / (2^23 - 1): uniform, from LDS into scalar
-          // registers for this row only
-          float rt[FK];
-#pragma unroll
-          for (int k = 0; k < FK; ++k)
-            rt[k] = as_f32((uint32_t)__builtin_amdgcn_readfirstlane(
-                (int)as_u32(had::fmul(had::fmul(mixf[(14 + kp) * 8 + k], s2), red[40 + k]))));
+          const float4 ra = *reinterpret_cast<const float4*>(zcol + kp * 8), rb = *reinterpret_cast<const float4*>(zcol + kp * 8 + 4);
+          const float rt[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
           typedef float f32x2 __attribute__((ext_vector_type(2)));
           f32x2 x01 = {0.f, 0.f}, x23 = {0.f, 0.f};
 #pragma unroll
