@@ -30,13 +30,33 @@
 #include "fht_wg512x.hip.h"
 #include <utility>
 
-// table copies (e8p_gemv_core.hip.h: Lds<REP>): 16 = 16 / 16 -- what fits beside the 84 KB of down's digit planes.  24 (T1 x 32,
-// T2 x 16) and 32 exist for the MEASUREMENT MODE only (tools/dbg: the planes do not fit then; the mode does not use them)
+// table mode (e8p_gemv_core.hip.h: Lds<REP>): 4 = NIBBLE MODE (round 6, the shipped one): 4-byte entries, 32 conflict-free copies
+// of both tables in 64 KB, half planes, the accumulator rows hold 8 x the digit sums.  16 = 16 / 16 copies of the 8-byte
+// tables (rounds 4-5; kept as the A/B reference: same integers, bit-identical launch).  24 (T1 x 32, T2 x 16) and 32 exist for
+// the MEASUREMENT MODE only (tools/dbg: the planes do not fit then; the mode does not use them)
 #ifndef QUIP_GQA_NODECODE
 #define QUIP_GQA_NODECODE 0
 #endif
 #ifndef QUIP_GQA_REP
-#define QUIP_GQA_REP 16
+#define QUIP_GQA_REP 4
+#endif
+// tools/dbg builds only (tools/gqa_waitstat.py): every wave adds up the clocks it spends in the ring's `s_waitcnt vmcnt` and
+// writes {wait ticks, total ticks, s_memrealtime span} of the launch to dbg[(workgroup * 8 + wave) * 4 ..]
+#ifndef QUIP_GQA_WAITSTAT
+#define QUIP_GQA_WAITSTAT 0
+#endif
+// 1 = the products as a software pipeline over half items (the look-ups of an item's first half issued before the second half of
+// the item in front of it is multiplied).  Measured and NOT shipped (profiles/r06_gqa_stream.txt): 1251 instead of 1270 clocks per
+// item and wave, the same 0.70-0.72 of 8 TB/s in wall time (the launch runs at the clock its power allows: 1.74-1.94 GHz against
+// 1.95-2.06 on the same box), 256 VGPRs instead of 238.
+#ifndef QUIP_GQA_PIPE
+#define QUIP_GQA_PIPE 0
+#endif
+#ifndef QUIP_GQA_ZROWS         /* tools/dbg A/B: 0 = the MFMA's unused A rows read digit plane 2 (as rounds 1-5) instead of zeros */
+#define QUIP_GQA_ZROWS 1
+#endif
+#ifndef QUIP_GQA_ASMADD        /* tools/dbg A/B: 0 = the rows' LDS adds as compiler-generated atomics under `if (q < 2)` */
+#define QUIP_GQA_ASMADD 1
 #endif
 
 namespace quip {
@@ -110,12 +130,18 @@ struct GLds {
   static constexpr int kQkv = kDesc + 512;                   // fp16 [4][128]: q, k, v of this head; attention output
   static constexpr int kCs = kQkv + 4 * HD * 2;              // float [2][128]
   static constexpr int kMix = kCs + 2 * HD * 4;              // float [3][7][8]
-  static constexpr int kArea = kMix + 3 * 7 * 8 * 4;
+  static constexpr int kZero = kMix + 3 * 7 * 8 * 4;         // 160 zero bytes: what the A rows that carry no digit plane read
+  static constexpr int kArea = kZero + 160;
   static constexpr int kAreaBytes = (160 * 1024 - kArea) & ~15;
-  static constexpr int PSH = HID + 16, PSD = NFFN + 16;      // plane strides (16 bytes off a multiple of 256: the three planes of an A fragment on different banks)
+  static constexpr bool kNib = T::kNib;
+  // plane strides.  Byte tables: 16 bytes off a multiple of 256 (the three planes of an A fragment on different banks).  Nibble mode:
+  // a plane = its "lo" half (positions 0..3 of the 8-groups) then, 16 bytes off a multiple of 256 later, its "hi" half; planes 64
+  // bytes off a multiple of 256 apart: the seven distinct 16-byte pieces a ds_read_b128 lane group touches lie on different banks
+  static constexpr int PSH = HID + (kNib ? 64 : 16), PSD = NFFN + (kNib ? 64 : 16);
+  static constexpr int HOH = HID / 2 + 16, HOD = NFFN / 2 + 16;      // nibble mode: offset of a plane's "hi" half
   static constexpr int kBufBytes = hadw::Geo<13>::kBufFloats * 4;
   static constexpr int kBytes = kArea + kAreaBytes;
-  static_assert(QUIP_GQA_REP != 16 || (kAreaBytes >= 3 * PSD && kAreaBytes >= 2 * kBufBytes && kAreaBytes >= 2 * 3 * PSH), "transient area");
+  static_assert((QUIP_GQA_REP != 16 && QUIP_GQA_REP != 4) || (kAreaBytes >= 3 * PSD && kAreaBytes >= 2 * kBufBytes && kAreaBytes >= 2 * 3 * PSH), "transient area");
   static_assert(kArea % 16 == 0, "alignment");
 };
 static_assert(GLds::kBytes <= 160 * 1024, "LDS budget");
@@ -183,8 +209,13 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     vo_gu = (uint32_t)(32 * (w & 127) * kRowH) + lt;
     vo_d = (uint32_t)(32 * w * kRowF) + lt;
     vo_hot = (uint32_t)((lane & 31) * 16);     // (the hot 2 KB: offsets < 496 + 1024 + 80)
-    lane_c = (T::kRep1 == 32) ? ((((uint32_t)lane & 31u) << 3) | 0x00010000u) : ((((uint32_t)lane & 15u) << 3) | (uint32_t)T::kT1);
-    lane_c2 = (((uint32_t)lane & 15u) << 3) | (uint32_t)T::kT2;
+    if constexpr (T::kNib) {
+      lane_c = nib_lane_const(lane);
+      lane_c2 = 0u;
+    } else {
+      lane_c = (T::kRep1 == 32) ? ((((uint32_t)lane & 31u) << 3) | 0x00010000u) : ((((uint32_t)lane & 15u) << 3) | (uint32_t)T::kT1);
+      lane_c2 = (((uint32_t)lane & 15u) << 3) | (uint32_t)T::kT2;
+    }
   };
   rederive();
   // uniform matrix bases of the stream: this block's o, gate, up, down; the next block's q, k | v, o; a hot 2 KB
@@ -237,21 +268,62 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     for (int s = 0; s < NS; ++s) { esync::own(qa[s]); esync::own(qb[s]); }
   };
   int* accs = reinterpret_cast<int*>(smem + B::kAcc);
-  auto add_rows = [&](const i32x4& r, int accrow) __attribute__((always_inline)) {
-    if (q == 0) {
+#if QUIP_GQA_WAITSTAT
+  uint64_t ws_wait = 0;
+  const uint64_t ws_start = __builtin_amdgcn_s_memtime(), ws_rstart = __builtin_amdgcn_s_memrealtime();
+#endif
+  // what an item (or a chain of items over K slices) leaves in registers: byte tables: the three digit sums in r; nibble mode:
+  // r = A x dwords, m = A x low nibbles (e8p_gemv_core.hip.h), to be combined with the digit sums sx of the same K slices
+  struct Acc { i32x4 r, m; };
+  constexpr bool NIB = T::kNib;
+  constexpr int NA = NIB ? 4 : 8;                      // A fragments of a K slice
+  constexpr int kUnsc = NIB ? 5 : 2;                   // the accumulator rows hold 2^kUnsc x sum of digit x w
+  auto add_rows = [&](const Acc& c, const i32x4& sx, int accrow) __attribute__((always_inline)) {
+    if constexpr (NIB) {
+      int v[3];
+      item_rows_nib(c.r, c.m, sx, nib_lane_factors(q), v);
+#if QUIP_GQA_ASMADD
+      lds_add3_low32((uint32_t)B::kAcc + (uint32_t)(accrow + n) * 16u, v);
+#else
+      if (q < 2) {
+        int* dst = accs + (accrow + n) * 4;
+        __hip_atomic_fetch_add(dst + 0, v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(dst + 1, v[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(dst + 2, v[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+#endif
+    } else if (q == 0) {
       int* dst = accs + (accrow + n) * 4;
-      __hip_atomic_fetch_add(dst + 0, r.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_fetch_add(dst + 1, r.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_fetch_add(dst + 2, r.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(dst + 0, c.r.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(dst + 1, c.r.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(dst + 2, c.r.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  };
+  const Acc kAcc0 = {i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}};
+  // the A fragments of a K slice (+ in nibble mode their digit sums, added to sx)
+  auto fragments = [&](uint32_t xa, auto& A, i32x4& sx) __attribute__((always_inline)) {
+    if constexpr (NIB) {
+      item_fragments_nib(xa, A);
+      item_digit_sums_nib(A, sx);
+    } else {
+      item_fragments(xa, A);
     }
   };
   // item S of the sequence: wait for its slot, turn the codes into table addresses, refill the slot with item S + NS,
   // multiply (A: the digit fragments of the item's K slice, shared by the items of a group); live = false: a filler
-  auto consume = [&](auto s_c, const i32x4 (&A)[8], i32x4& acc, bool live) {
+  auto consume = [&](auto s_c, const auto& A, Acc& acc_, bool live) {
+    i32x4& acc = acc_.r;
     constexpr int S = decltype(s_c)::value, slot = S % NS;
     u32x4& da = qa[slot];
     u32x4& db = qb[slot];
+#if QUIP_GQA_WAITSTAT
+    const uint64_t ws_t0 = __builtin_amdgcn_s_memtime();
+#endif
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(da), "+v"(db) : "n"(2 * (NS - 1)) : "memory");
+#if QUIP_GQA_WAITSTAT
+    const uint64_t ws_t1 = __builtin_amdgcn_s_memtime();
+    ws_wait += ws_t1 - ws_t0;
+#endif
 #if QUIP_GQA_NODECODE      /* tools/dbg A/B of the measurement mode: the ring alone -- slots waited for and refilled, the codes folded into the accumulator */
     {
       acc.x ^= (int)(da.x ^ da.y ^ da.z ^ da.w);
@@ -262,12 +334,15 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
 #endif
     ItemAddr ad;
     if (live) {
-      item_addresses<QUIP_GQA_REP>(da, db, lane_c, lane_c2, ad, 0u);
+      if constexpr (NIB) item_addresses_nib(da, db, lane_c, ad);
+      else item_addresses<QUIP_GQA_REP>(da, db, lane_c, lane_c2, ad, 0u);
 #pragma unroll
       for (int t = 0; t < 8; ++t) asm volatile("" : "+v"(ad.a1l[t]), "+v"(ad.a2l[t]), "+v"(ad.a1h[t]), "+v"(ad.a2h[t]));
     }
     issue(IC<S + NS>{});
-    if (live) {
+    if constexpr (NIB) {
+      if (live) item_mfma_nib(ad, A, acc_.r, acc_.m);
+    } else if (live) {
       constexpr int PIPE = QUIP_GEMV_PIPE;
       uint2 o[8][4];
       auto lk = [&](int t) {
@@ -285,30 +360,120 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
       }
     }
   };
-  // CNT consecutive items that multiply the same K slice (A fragments at xa) into accumulator rows accrow0 + 16 c
-  auto group = [&](auto s0_c, auto cnt_c, uint32_t xa, int accrow0) __attribute__((always_inline)) {
+  // ---- nibble mode: a product's items as a software pipeline over HALF items (round 6) -------------------------------------
+  // rocprofv3 on the measurement mode said where an item's ~1400 clocks went: 45 % issuing its ~140 instructions (4 clocks each:
+  // ONE wave issues at most one instruction per 4 clocks, and there are two per SIMD), 23 % issue stalls, 32 % in s_waitcnt --
+  // most of it lgkmcnt: every item began with a burst of look-ups whose first result its first MFMA had to wait for, because no
+  // look-up may move above the asm statements (wait, request) of its own item.  So the look-ups of an item's first half now go out
+  // BEFORE the second half of the item in front of it is multiplied:
+  //     look(S, half 1) | multiply(S, half 0) | wait(S + 1), codes -> addresses, request(S + 1 + NS) | look(S + 1, half 0) |
+  //     multiply(S, half 1) | rows of S -> accumulators
+  // -- a look-up has half an item (~60 instructions) between its issue and its use; LDS results return in order, so consuming the
+  // older half while 16 newer look-ups are in flight is `lgkmcnt(15)`.  Same integers, same order of the MFMAs per accumulator.
+  ItemAddr adn;
+  uint32_t L0[16], L1[16];
+  // wait for item S's slot, its codes -> the 32 look-up addresses (adn), refill the slot with item S + NS
+  auto pre = [&](auto s_c, bool live) __attribute__((always_inline)) {
+    constexpr int S = decltype(s_c)::value, slot = S % NS;
+    u32x4& da = qa[slot];
+    u32x4& db = qb[slot];
+#if QUIP_GQA_WAITSTAT
+    const uint64_t ws_t0 = __builtin_amdgcn_s_memtime();
+#endif
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(da), "+v"(db) : "n"(2 * (NS - 1)) : "memory");
+#if QUIP_GQA_WAITSTAT
+    ws_wait += __builtin_amdgcn_s_memtime() - ws_t0;
+#endif
+    if (live) {
+      item_addresses_nib(da, db, lane_c, adn);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) asm volatile("" : "+v"(adn.a1l[t]), "+v"(adn.a2l[t]), "+v"(adn.a1h[t]), "+v"(adn.a2h[t]));
+    }
+    issue(IC<S + NS>{});
+  };
+  // the 16 look-ups of half H (MFMA steps 2 H, 2 H + 1: dwords 4 H .. 4 H + 3 of the lane's 8) of the item whose addresses adn holds
+  auto look = [&](auto h_c, uint32_t (&L)[16]) __attribute__((always_inline)) {
+    constexpr int H = decltype(h_c)::value;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = 4 * H + u;
+      L[4 * u + 0] = lds_read4(adn.a1l[t]); L[4 * u + 1] = lds_read4(adn.a2l[t]);
+      L[4 * u + 2] = lds_read4(adn.a1h[t]); L[4 * u + 3] = lds_read4(adn.a2h[t]);
+    }
+  };
+  auto mulh = [&](auto h_c, const uint32_t (&L)[16], const i32x4 (&A)[4], Acc& acc) __attribute__((always_inline)) {
+    constexpr int H = decltype(h_c)::value;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const uint32_t* o = L + 8 * s2;
+      const i32x4 Br = {(int)(o[0] ^ o[1]), (int)(o[2] ^ o[3]), (int)(o[4] ^ o[5]), (int)(o[6] ^ o[7])};
+      const i32x4 Bm = {Br.x & 0x0f0f0f0f, Br.y & 0x0f0f0f0f, Br.z & 0x0f0f0f0f, Br.w & 0x0f0f0f0f};
+      acc.r = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[2 * H + s2], Br, acc.r, 0, 0, 0);
+      acc.m = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[2 * H + s2], Bm, acc.m, 0, 0, 0);
+    }
+  };
+  // the first item of a stream: nothing in front of it to hide its first look-ups behind
+  constexpr bool PIPE = NIB && QUIP_GQA_PIPE != 0;
+  auto first = [&](auto s_c, bool live) __attribute__((always_inline)) {
+    if constexpr (PIPE) {
+      pre(s_c, live);
+      if (live) look(IC<0>{}, L0);
+    }
+  };
+  // item S of a stream (its first half's look-ups are in flight: first() or the item in front of it); next_c: another item
+  // follows directly (live_next: and it is not a filler)
+  auto item = [&](auto s_c, auto next_c, const auto& A, Acc& acc, bool live, bool live_next) __attribute__((always_inline)) {
+    constexpr int S = decltype(s_c)::value;
+    constexpr bool NEXT = decltype(next_c)::value;
+    if constexpr (PIPE) {
+      if (live) {
+        look(IC<1>{}, L1);
+        mulh(IC<0>{}, L0, A, acc);
+      }
+      if constexpr (NEXT) {
+        pre(IC<S + 1>{}, live_next);
+        if (live_next) look(IC<0>{}, L0);
+      }
+      if (live) mulh(IC<1>{}, L1, A, acc);
+    } else {
+      consume(s_c, A, acc, live);
+    }
+  };
+  using TrueC = std::integral_constant<bool, true>;
+  using FalseC = std::integral_constant<bool, false>;
+  // CNT consecutive items that multiply the same K slice (A fragments at xa) into accumulator rows accrow0 + 16 c; last_c: the
+  // stream ends behind them
+  auto group = [&](auto s0_c, auto cnt_c, auto last_c, uint32_t xa, int accrow0) __attribute__((always_inline)) {
     constexpr int S0 = decltype(s0_c)::value, CNT = decltype(cnt_c)::value;
-    i32x4 A[8];
-    item_fragments(xa, A);
+    constexpr bool LAST = decltype(last_c)::value;
+    i32x4 A[NA];
+    i32x4 sx = {0, 0, 0, 0};
+    fragments(xa, A, sx);
     static_for<CNT>([&](auto c) {
       constexpr int C = decltype(c)::value;
-      i32x4 acc = {0, 0, 0, 0};
-      consume(IC<S0 + C>{}, A, acc, true);
-      add_rows(acc, accrow0 + 16 * C);
+      Acc acc = kAcc0;
+      item(IC<S0 + C>{}, std::integral_constant<bool, !(LAST && C == CNT - 1)>{}, A, acc, true, true);
+      add_rows(acc, sx, accrow0 + 16 * C);
     });
   };
 
   // ---- prologue -----------------------------------------------------------------------------------------------------
   GLayer* desc = reinterpret_cast<GLayer*>(smem + B::kDesc);
   u32x2 tsrc;
-  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(tsrc) : "v"(table_source_ptr(a.grid, lane, wave)) : "memory");
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(tsrc) : "v"(T::kNib ? table_source_ptr_nib(a.grid, lane, wave) : table_source_ptr(a.grid, lane, wave)) : "memory");
   uint32_t gen;
   esync::ld4(gen, ctl);
   asm volatile("s_waitcnt vmcnt(1)" : "+v"(tsrc) : : "memory");
-  fill_tables_from_lane<QUIP_GQA_REP>(smem, tsrc, lane, wave);
+  if constexpr (T::kNib) fill_tables_nib(tsrc, lane, wave);
+  else fill_tables_from_lane<QUIP_GQA_REP>(smem, tsrc, lane, wave);
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(gen) : : "memory");
   const uint32_t ebase = ((uint32_t)__builtin_amdgcn_readfirstlane((int)gen) + 1u) << 10;
   for (int i = tid; i < B::kAccRows * 4; i += kThreads) accs[i] = 0;
+  if (tid < 40) reinterpret_cast<uint32_t*>(smem + B::kZero)[tid] = 0u;
+  // (measurement mode: no edge ever writes digit planes -- fill the area with digits that look like real ones, so that the
+  //  matrix cores switch as in a real launch: the rate of this mode is a power figure too)
+  if (a.dbg_layer == -2)
+    for (int i = tid; i < B::kAreaBytes / 4; i += kThreads) reinterpret_cast<uint32_t*>(smem + B::kArea)[i] = (uint32_t)(i + 1) * 2654435761u ^ (uint32_t)w * 0x9e3779b9u;
   if (tid < 64) reinterpret_cast<uint32_t*>(desc)[tid] = reinterpret_cast<const uint32_t*>(a.layers)[tid];
   const long long pos64 = *a.pos;
   const bool pos_ok = pos64 >= 0 && pos64 < (long long)a.max_len;
@@ -396,7 +561,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
   auto publish = [&](uint64_t* vec, int gran, int row0, int cnt, int sh, uint32_t tag) __attribute__((always_inline)) {
     if (tid < cnt) {
       const int* s3 = accs + (row0 + 2 * tid) * 4;
-      const float us = unscale_of(sh, 2);
+      const float us = unscale_of(sh, kUnsc);
       const float f0 = __builtin_fmaf((float)s3[0], 65536.f, __builtin_fmaf((float)s3[1], 256.f, (float)s3[2]));
       const float f1 = __builtin_fmaf((float)s3[4], 65536.f, __builtin_fmaf((float)s3[5], 256.f, (float)s3[6]));
       esync::st_granule(vec + gran + tid, pack_f16(f0 * us, f1 * us), tag);
@@ -417,8 +582,14 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
       hadw::digit_words_magic(vv, s2, dg[0][g], dg[1][g], dg[2][g]);
     }
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
-      *reinterpret_cast<uint4*>(smem + base + d * B::PSH + 16 * tid) = make_uint4(dg[d][0], dg[d][1], dg[d][2], dg[d][3]);
+    for (int d = 0; d < 3; ++d) {
+      if constexpr (NIB) {       // dwords 0, 2 (positions 0..3 of the thread's two 8-groups) -> "lo" half, dwords 1, 3 -> "hi" half
+        *reinterpret_cast<uint2*>(smem + base + d * B::PSH + 8 * tid) = make_uint2(dg[d][0], dg[d][2]);
+        *reinterpret_cast<uint2*>(smem + base + d * B::PSH + B::HOH + 8 * tid) = make_uint2(dg[d][1], dg[d][3]);
+      } else {
+        *reinterpret_cast<uint4*>(smem + base + d * B::PSH + 16 * tid) = make_uint4(dg[d][0], dg[d][1], dg[d][2], dg[d][3]);
+      }
+    }
   };
   // the same from the strided layout (values X[t + 512 k]): bytes
   auto planes_str = [&](const float (&v)[16], float scale, int sh, uint32_t base) {
@@ -427,7 +598,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int X = (int)__builtin_rintf(v[k] * s2);
-      uint8_t* p = reinterpret_cast<uint8_t*>(smem + base) + tid + 512 * k;
+      // (nibble mode: digit tid + 512 k of a plane sits at byte nib_byte_of() of its half plane)
+      uint8_t* p = reinterpret_cast<uint8_t*>(smem + base) + (NIB ? nib_half_of(tid) * B::HOH + nib_byte_of(tid) + 256 * k : tid + 512 * k);
       p[0] = (uint8_t)((X + 0x8080) >> 16);
       p[B::PSH] = (uint8_t)((X + 0x80) >> 8);
       p[2 * B::PSH] = (uint8_t)X;
@@ -570,7 +742,15 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
   };
   // A fragment address of this lane for K slice (wave + 8 i) of the planes at `base` (plane stride ps)
   auto xaddr = [&](uint32_t base, int ps, int i) -> uint32_t __attribute__((always_inline)) {
-    return base + (uint32_t)min(n, 2) * (uint32_t)ps + (uint32_t)q * 64u + (uint32_t)(wave + 8 * i) * 512u;
+    if constexpr (NIB) {         // A rows 0..2: "hi" halves of the planes, rows 4..6: "lo" halves
+      const uint32_t half_off = (uint32_t)(ps / 2 - 16);          // = HOH | HOD: (K + 64) / 2 - 16 = K / 2 + 16
+      const uint32_t xa = base + (uint32_t)(n < 4 ? min(n, 2) * ps + (int)half_off : min(n - 4, 2) * ps) + (uint32_t)q * 32u + (uint32_t)(wave + 8 * i) * 256u;
+      // the ten rows that carry nothing read ZEROS (one broadcast address): the launch runs at the clock its power allows, and
+      // ten sixteenths of every MFMA's multipliers switching on a copy of plane 2 is power without a result
+      return (QUIP_GQA_ZROWS && (n == 3 || n >= 7)) ? (uint32_t)B::kZero : xa;
+    } else {
+      return base + (uint32_t)min(n, 2) * (uint32_t)ps + (uint32_t)q * 64u + (uint32_t)(wave + 8 * i) * 512u;
+    }
   };
 
   had::wg_barrier<true>();
@@ -604,26 +784,30 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
       const uint32_t p0 = (uint32_t)B::kArea, p1 = (uint32_t)(B::kArea + 3 * B::PSH);
       // slot A first: the k | v items (odd workgroups), so that z_k / z_v are on their way while q is multiplied
       const uint32_t pa = has_kv ? p1 : p0;
-      i32x4 A[8];
+      i32x4 A[NA];
+      first(IC<SQ_A>{}, true);
       {
-        i32x4 acc = {0, 0, 0, 0};
-        item_fragments(xaddr(pa, B::PSH, 0), A);
-        consume(IC<SQ_A>{}, A, acc, true);
-        item_fragments(xaddr(pa, B::PSH, 1), A);
-        consume(IC<SQ_A + 1>{}, A, acc, true);
-        add_rows(acc, B::AKV);
+        Acc acc = kAcc0;
+        i32x4 sx = {0, 0, 0, 0};
+        fragments(xaddr(pa, B::PSH, 0), A, sx);
+        item(IC<SQ_A>{}, TrueC{}, A, acc, true, true);
+        fragments(xaddr(pa, B::PSH, 1), A, sx);
+        item(IC<SQ_A + 1>{}, FalseC{}, A, acc, true, true);
+        add_rows(acc, sx, B::AKV);
       }
       had::wg_barrier<true>();
       ++hop;                                           // hand-off: z_k / z_v, then z_q (the same index: they are different vectors)
       if (has_kv && !so) publish(kvm ? zv : zk, 8 * (kvb & 63), B::AKV, 8, shs[1], ebase | hop);
+      first(IC<SQ_B>{}, true);
       static_for<2>([&](auto ic) {
         constexpr int I = decltype(ic)::value;
-        i32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-        item_fragments(xaddr(p0, B::PSH, I), A);
-        consume(IC<SQ_B + 2 * I>{}, A, acc0, true);
-        consume(IC<SQ_B + 2 * I + 1>{}, A, acc1, !has_kv);
-        add_rows(acc0, B::AQ);
-        if (!has_kv) add_rows(acc1, B::AQ + 16);
+        Acc acc0 = kAcc0, acc1 = kAcc0;
+        i32x4 sx = {0, 0, 0, 0};
+        fragments(xaddr(p0, B::PSH, I), A, sx);
+        item(IC<SQ_B + 2 * I>{}, TrueC{}, A, acc0, true, !has_kv);
+        item(IC<SQ_B + 2 * I + 1>{}, std::integral_constant<bool, I == 0>{}, A, acc1, !has_kv, true);
+        add_rows(acc0, sx, B::AQ);
+        if (!has_kv) add_rows(acc1, sx, B::AQ + 16);
       });
     }
     had::wg_barrier<true>();
@@ -977,8 +1161,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     }
     BSTAMP(8);
     rederive();
-    group(IC<SQ_O>{}, IC<2>{}, xaddr((uint32_t)B::kArea, B::PSH, 0), B::AO);
-    group(IC<SQ_O + 2>{}, IC<2>{}, xaddr((uint32_t)B::kArea, B::PSH, 1), B::AO);
+    first(IC<SQ_O>{}, true);
+    group(IC<SQ_O>{}, IC<2>{}, FalseC{}, xaddr((uint32_t)B::kArea, B::PSH, 0), B::AO);
+    group(IC<SQ_O + 2>{}, IC<2>{}, TrueC{}, xaddr((uint32_t)B::kArea, B::PSH, 1), B::AO);
     had::wg_barrier<true>();
     ++hop;                                             // hand-off: z_o
     if (!so) publish(zo, 16 * w, B::AO, 16, shs[2], ebase | hop);
@@ -995,8 +1180,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
       // 14 items per K span: chunks k = 0..6 of the first 16 columns (accumulator rows AGU + 16 k + i), then of the second 16
       // (AGU + 112 + 16 k + i) -- one set of A fragments per span
       const uint32_t pg = (uint32_t)B::kArea;
-      group(IC<SQ_GU>{}, IC<14>{}, xaddr(pg, B::PSH, 0), B::AGU);
-      group(IC<SQ_GU + 14>{}, IC<14>{}, xaddr(pg, B::PSH, 1), B::AGU);
+      first(IC<SQ_GU>{}, true);
+      group(IC<SQ_GU>{}, IC<14>{}, FalseC{}, xaddr(pg, B::PSH, 0), B::AGU);
+      group(IC<SQ_GU + 14>{}, IC<14>{}, TrueC{}, xaddr(pg, B::PSH, 1), B::AGU);
     }
     had::wg_barrier<true>();
     BSTAMP(11);
@@ -1010,7 +1196,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     if (tid < 224) {
       const int* s3 = accs + (B::AGU + tid) * 4;
       const float f = __builtin_fmaf((float)s3[0], 65536.f, __builtin_fmaf((float)s3[1], 256.f, (float)s3[2]));
-      zcol[tid] = (float)(f16)(f * unscale_of(shs[3], 2));      // [column group][k][i]: one matrix, one exponent
+      zcol[tid] = (float)(f16)(f * unscale_of(shs[3], kUnsc));      // [column group][k][i]: one matrix, one exponent
     }
     had::wg_barrier<true>();
     zero_acc(B::AGU, 224);
@@ -1199,7 +1385,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
           const int X[4] = {(int)__builtin_rintf(x01.x), (int)__builtin_rintf(x01.y), (int)__builtin_rintf(x23.x), (int)__builtin_rintf(x23.y)};
           uint32_t dh, dm, dl;
           digit_words(X, dh, dm, dl);
-          const int off = kp * FL + col;
+          // (nibble mode: natural dword kp * 1024 + tid + 512 c of a plane = dword (that >> 1) of its "lo" (even) / "hi" (odd) half)
+          const int off = NIB ? (tid & 1) * B::HOD + kp * (FL / 2) + (tid >> 1) * 4 + 1024 * c : kp * FL + col;
           *reinterpret_cast<uint32_t*>(pl + off) = dh;
           *reinterpret_cast<uint32_t*>(pl + B::PSD + off) = dm;
           *reinterpret_cast<uint32_t*>(pl + 2 * B::PSD + off) = dl;
@@ -1219,22 +1406,29 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     // ================= down's product ====================================================================================
     rederive();
     {
-      i32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+      Acc acc0 = kAcc0, acc1 = kAcc0;
+      i32x4 sx = {0, 0, 0, 0};
+      first(IC<SQ_D>{}, true);
       static_for<7>([&](auto ic) {
         constexpr int I = decltype(ic)::value;
-        i32x4 A[8];
-        item_fragments(xaddr((uint32_t)B::kArea, B::PSD, I), A);
-        consume(IC<SQ_D + 2 * I>{}, A, acc0, true);
-        consume(IC<SQ_D + 2 * I + 1>{}, A, acc1, true);
+        i32x4 A[NA];
+        fragments(xaddr((uint32_t)B::kArea, B::PSD, I), A, sx);
+        item(IC<SQ_D + 2 * I>{}, TrueC{}, A, acc0, true, true);
+        item(IC<SQ_D + 2 * I + 1>{}, TrueC{}, A, acc1, true, I < 6);          // (behind the last one: the first filler)
       });
-      add_rows(acc0, B::AD);
-      add_rows(acc1, B::AD + 16);
-      i32x4 A0[8];
+      add_rows(acc0, sx, B::AD);
+      add_rows(acc1, sx, B::AD + 16);
+      i32x4 A0[NA];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) A0[t] = i32x4{0, 0, 0, 0};
-      i32x4 accf = {0, 0, 0, 0};
-      consume(IC<SQ_F>{}, A0, accf, false);            // the two fillers keep the ring's period at 54
-      consume(IC<SQ_F + 1>{}, A0, accf, false);
+      for (int t = 0; t < NA; ++t) A0[t] = i32x4{0, 0, 0, 0};
+      Acc accf = kAcc0;
+      // the two fillers keep the ring's period at 54 (nibble mode: SQ_F was waited for and refilled behind down's last item)
+      if constexpr (PIPE) {
+        pre(IC<SQ_F + 1>{}, false);
+      } else {
+        consume(IC<SQ_F>{}, A0, accf, false);
+        consume(IC<SQ_F + 1>{}, A0, accf, false);
+      }
     }
     had::wg_barrier<true>();
     ++hop;                                             // hand-off: z_d
@@ -1252,6 +1446,12 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
   // output side of the last block's down_proj + residual -> h
   rederive();
   if (!so) edge(IC<0>{}, zd, ebase | hop, 0x4000u, sv_prev, nullptr, nullptr, nullptr, 0.f, 0.f, false, 0, -1);
+#if QUIP_GQA_WAITSTAT
+  if (a.dbg != nullptr && lane == 0) {
+    uint64_t* o = a.dbg + (size_t)(w * 8 + wave) * 4;
+    o[0] = ws_wait; o[1] = __builtin_amdgcn_s_memtime() - ws_start; o[2] = __builtin_amdgcn_s_memrealtime() - ws_rstart; o[3] = 0;
+  }
+#endif
   // ---- h_out (natural order) -------------------------------------------------------------------------------------------------
   if (w == 0) {
     // A launch in which a wait gave up (ctl[1] != 0) has no result: h_out is all NaN then, and ctl[2] keeps position + 1 of

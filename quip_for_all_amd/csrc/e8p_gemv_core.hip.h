@@ -38,6 +38,9 @@ struct Lds {
   //           E81B residual table (4r as int8; 16 / 8 copies), looked up by the LOW code of every dword; the
   //           weight stream is the checkpoint's own 3-byte codes (12-byte loads, 3 k / 8 bytes per row)
   static constexpr bool kD4 = REP == 64;
+  // REP = 4: NIBBLE MODE (see the end of this file) -- both E8P tables as 4-byte entries, 32 copies each, interleaved in
+  //           256-byte rows: 64 KB, every look-up a conflict-free ds_read_b32
+  static constexpr bool kNib = REP == 4;
   // REP = 12: E8P12RVQ3B inside the persistent block launch -- 16 / 16 copies and FOUR of T3 (72 KB of tables: the virtual
   //           rows' digit planes need the rest)
   static constexpr bool kRvq3 = REP == 40 || REP == 20 || REP == 12;
@@ -48,8 +51,8 @@ struct Lds {
   static constexpr int kRow2 = kD4 ? 0 : kRep2 * 8;     // bytes per T2 entry row
   static constexpr int kRow3 = kRep3 * 8;               // bytes per T3 entry row
   static constexpr int kT1 = 0;
-  static constexpr int kT2 = 256 * kRow1;
-  static constexpr int kT3 = kT2 + 256 * kRow2;
+  static constexpr int kT2 = kNib ? 128 : 256 * kRow1;
+  static constexpr int kT3 = kNib ? 256 * 256 : kT2 + 256 * kRow2;
   static constexpr int kAcc = kT3 + 256 * kRow3;     // int32 [kMaxRowsPerBlock][4]
   static constexpr int kX = kAcc + kMaxRowsPerBlock * 16;   // 3 planes x Kp bytes
   static constexpr int kMaxKp = (160 * 1024 - kX) / 3 / 512 * 512;
@@ -372,6 +375,145 @@ __device__ __forceinline__ i32x4 item_mfma_shared(const ItemAddr& ad, const i32x
   }
   return acc;
 }
+
+
+// =====================================================================================================================
+// Nibble mode (round 6).  The byte tables above cost two 8-byte look-ups per code: with 16 copies (the only size that fits
+// beside the 84 KB of down's digit planes) every ds_read_b64 is a two-way bank conflict -- 4 LDS cycles instead of 2
+// (MI355X_MICROARCH.md, LDS: lanes l and l + 16 of a 32-lane group share a bank pair whenever their indices have equal
+// parity) -- and the product of the 70B launch ran at the LDS rate, not at the stream's.  4 w of an E8P12 weight is one of
+// the SIXTEEN odd numbers in [-15, 15] (e8p12.py:82-103: +-{2, 6, 10, 14} + 1 - 2 par), so v = (4 w - 1) / 2 is a 4-bit
+// two's-complement number, and the decode identity holds nibble by nibble:
+//     v = c ^ (neg ? 0xE : 0) ^ (par ? 1 : 0),   c = grid byte / 2 (odd: -c = ~c + 1 = c ^ 0xE, c - 1 = c ^ 1, -c - 1 = c ^ 0xF).
+// A code's eight weights are therefore ONE dword  T1n[abs] ^ T2n[sign]  of two 4-byte look-ups: 32 conflict-free copies of
+// each table (ds_read_b32: two groups of 32 lanes on 32 banks, 2 LDS cycles) in the same 64 KB.  Entry byte b holds position
+// b in its LOW nibble, biased by 8 (unsigned 0..15), and position 4 + b in its HIGH nibble (two's complement), so that the
+// dword read as four int8 is  16 v_hi + lo_u.  No widening: the matrix core takes the bytes as they are, twice --
+//     R1 = mfma(A, raw)               rows "hi" of A:  sum x_hi (16 v_hi + lo_u)
+//     R2 = mfma(A, raw & 0x0f0f0f0f)  rows "hi":       sum x_hi lo_u             rows "lo":  sum x_lo (v_lo + 8)
+// with the digits of positions 4..7 of every 8-group in A rows 0..2 (planes h, m, l) and those of positions 0..3 in rows
+// 4..6.  Per plane  8 sum x 4w = (R1 - R2)[hi] + 16 R2[lo] + 8 SX[hi] - 120 SX[lo],  SX = plain digit sums (one more MFMA
+// per A fragment against a B operand of ones, shared by every item of the K slice).  Same integers as the byte tables: the
+// accumulator rows hold exactly 8 x what they held.  Per item: 32 four-byte look-ups (conflict free) + 4 A fragments instead
+// of 32 eight-byte ones (two-way conflicts) + 8 A fragments; 32 v_perm + 16 v_xor + 16 v_and instead of 64 address
+// operations + 32 v_xor; the same 8 MFMAs (+ 4 per K slice).
+//
+// LDS image of the tables: row idx (256 bytes) = T1n[idx] x 32 copies | T2n[idx] x 32 copies; address of a look-up =
+// idx << 8 | (lane & 31) << 2 (| 128): one v_perm_b32 (lane_c: byte 0 = (lane & 31) << 2, byte 2 = 128 | (lane & 31) << 2).
+// Digit planes for this mode ("half planes"): the natural dwords of a plane de-interleaved -- even dwords (positions 0..3
+// of the 8-groups) and odd dwords (positions 4..7) each contiguous -- so that an A fragment is one 16-byte read.
+struct T2nImage {
+  uint32_t v[256];
+  constexpr T2nImage() : v{} {
+    for (int s = 0; s < 256; ++s) {
+      int par = 0;
+      for (int b = 0; b < 8; ++b) par ^= (s >> b) & 1;
+      const int sv = s ^ par;
+      uint32_t e = 0;
+      for (int p = 0; p < 8; ++p) {
+        const uint32_t nib = (((sv >> (7 - e8p_byte_of_pos(p))) & 1) ? 0xeu : 0u) ^ (uint32_t)par;
+        e |= nib << (8 * (p & 3) + 4 * (p >> 2));
+      }
+      v[s] = e;
+    }
+  }
+};
+__device__ const T2nImage kT2nImg{};
+
+// T1n entry from grid_packed_abs[e] (bytes 4a, byte 7 possibly negative: e8p12.py:63-79)
+__device__ __forceinline__ uint32_t t1n_entry(uint2 packed) {
+  const uint32_t lo = __builtin_amdgcn_perm(0u, packed.x, 0x03010200u), hi = __builtin_amdgcn_perm(0u, packed.y, 0x03010200u);
+  return (((lo >> 1) & 0x0f0f0f0fu) ^ 0x08080808u) | (((hi >> 1) & 0x0f0f0f0fu) << 4);
+}
+constexpr int kNibTableBytes = 256 * 256;
+// wave w < 8 owns table rows [32 w, +32): lanes 0..31 hold grid_packed_abs[32 w + l] (8 bytes, src), lanes 32..63 take
+// the constant sign image; every lane writes its entry 32 times, copy (l + c) & 31 at step c (32 distinct banks per step)
+__device__ __forceinline__ const uint2* table_source_ptr_nib(const uint64_t* grid, int lane, int wave) {
+  return reinterpret_cast<const uint2*>(grid) + ((wave & 7) * 32 + (lane & 31));
+}
+__device__ __forceinline__ void fill_tables_nib(const u32x2& src, int lane, int wave) {
+  const bool second = (lane & 32) != 0;
+  const uint32_t row = (uint32_t)((wave & 7) * 32 + (lane & 31));
+  const uint32_t val = second ? kT2nImg.v[row] : t1n_entry(make_uint2(src.x, src.y));
+  const uint32_t rowbase = row * 256u + (second ? 128u : 0u);
+#pragma unroll
+  for (int c = 0; c < 32; ++c)
+    *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>((uintptr_t)(rowbase + (((uint32_t)(lane + c)) & 31u) * 4u)) = val;
+}
+__device__ __forceinline__ uint32_t nib_lane_const(int lane) {
+  const uint32_t l4 = ((uint32_t)lane & 31u) << 2;
+  return l4 | ((128u | l4) << 16);
+}
+// 16 codes of this lane (dwords d[t] = code 2t | code 2t + 1 << 16; a code = abs << 8 | sign) -> 32 look-up addresses
+__device__ __forceinline__ void item_addresses_nib(const u32x4& q0, const u32x4& q1, uint32_t lane_c, ItemAddr& ad) {
+  const uint32_t d[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    ad.a1l[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c0c0500u);
+    ad.a2l[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c0c0402u);
+    ad.a1h[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c0c0700u);
+    ad.a2h[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c0c0602u);
+  }
+}
+// A fragments of a 512-k slice of half planes: step s covers k = 256 (s >> 1) + 64 q + 32 (s & 1) + [0, 32) of the slice;
+// xaddr = this lane's row (plane / half) + slice * 256 + q * 32
+__device__ __forceinline__ void item_fragments_nib(uint32_t xaddr, i32x4 (&A)[4]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) A[s] = lds_read16i(xaddr + 16 * (s & 1) + 128 * (s >> 1));
+}
+// digit sums of the slice (every column of the result holds them: rows 0..2 the "hi" planes, rows 4..6 the "lo" ones)
+__device__ __forceinline__ void item_digit_sums_nib(const i32x4 (&A)[4], i32x4& sx) {
+  const i32x4 ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) sx = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[s], ones, sx, 0, 0, 0);
+}
+// the item's look-ups and MFMAs: raw += A x dwords, msk += A x (dwords & 0x0f0f0f0f)
+__device__ __forceinline__ void item_mfma_nib(const ItemAddr& ad, const i32x4 (&A)[4], i32x4& raw, i32x4& msk) {
+  uint32_t o[4][8];
+  auto lk = [&](int s) {
+    o[s][0] = lds_read4(ad.a1l[2 * s]); o[s][1] = lds_read4(ad.a2l[2 * s]);
+    o[s][2] = lds_read4(ad.a1h[2 * s]); o[s][3] = lds_read4(ad.a2h[2 * s]);
+    o[s][4] = lds_read4(ad.a1l[2 * s + 1]); o[s][5] = lds_read4(ad.a2l[2 * s + 1]);
+    o[s][6] = lds_read4(ad.a1h[2 * s + 1]); o[s][7] = lds_read4(ad.a2h[2 * s + 1]);
+  };
+  lk(0); lk(1);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (s + 2 < 4) lk(s + 2);
+    const i32x4 Br = {(int)(o[s][0] ^ o[s][1]), (int)(o[s][2] ^ o[s][3]), (int)(o[s][4] ^ o[s][5]), (int)(o[s][6] ^ o[s][7])};
+    const i32x4 Bm = {Br.x & 0x0f0f0f0f, Br.y & 0x0f0f0f0f, Br.z & 0x0f0f0f0f, Br.w & 0x0f0f0f0f};
+    raw = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[s], Br, raw, 0, 0, 0);
+    msk = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[s], Bm, msk, 0, 0, 0);
+  }
+}
+// what the lanes that own accumulator rows add for an item: q == 0 (D rows 0..2) and q == 1 (D rows 4..6) of column n;
+// the sum over the K slices of a row is 8 x (sum of digit x 4w) per plane.  Branch free, per-lane factors:
+//   v = (raw & rmask) + cm msk + cs sx,   (rmask, cm, cs) = (~0, -1, 8) for q == 0, (0, 16, -120) for q == 1
+// (v_mad_i32_i24: |msk| <= 7 slices x 256 bytes x 128 x 15 < 2^23, |sx| smaller still; the compiler's own version of the
+//  two-sided expression was three v_mul_lo_u32 and a nest of exec-mask branches per item)
+struct NibLane { int cm, cs; uint32_t rmask; };
+__device__ __forceinline__ NibLane nib_lane_factors(int q) {
+  return NibLane{q == 0 ? -1 : 16, q == 0 ? 8 : -120, q == 0 ? 0xffffffffu : 0u};
+}
+// (NOT inline asm: raw / msk / sx come straight out of MFMAs, and the wait states between an MFMA and a VALU read of its
+//  result are the COMPILER's to insert -- it does not look inside an asm statement; a hand-written v_mad_i32_i24 here read
+//  accumulators that were still being written)
+__device__ __forceinline__ int mad_i24(int a, int b, int c) { return __mul24(a, b) + c; }
+__device__ __forceinline__ void item_rows_nib(const i32x4& raw, const i32x4& msk, const i32x4& sx, const NibLane& f, int (&v)[3]) {
+  const int r[3] = {raw.x, raw.y, raw.z}, m[3] = {msk.x, msk.y, msk.z}, s[3] = {sx.x, sx.y, sx.z};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) v[d] = mad_i24(m[d], f.cm, mad_i24(s[d], f.cs, (int)((uint32_t)r[d] & f.rmask)));
+}
+// the three atomic adds of an item's rows into the int32 accumulators at LDS byte address `dst` (this lane's row), from
+// the low 32 lanes only (q < 2); the wave's exec mask is all ones before and after
+__device__ __forceinline__ void lds_add3_low32(uint32_t dst, const int (&v)[3]) {
+  // (exec_hi alone: how a 32-bit literal extends into a 64-bit scalar move is not something to depend on)
+  asm volatile("s_mov_b32 exec_hi, 0\n\tds_add_u32 %0, %1\n\tds_add_u32 %0, %2 offset:4\n\tds_add_u32 %0, %3 offset:8\n\ts_mov_b32 exec_hi, -1"
+               : : "v"(dst), "v"(v[0]), "v"(v[1]), "v"(v[2]) : "memory");
+}
+// byte offset of digit k of a plane inside its half plane, and which half (0: positions 0..3, 1: positions 4..7)
+__device__ __forceinline__ constexpr int nib_half_of(int k) { return (k >> 2) & 1; }
+__device__ __forceinline__ constexpr int nib_byte_of(int k) { return ((k >> 3) << 2) | (k & 3); }
 
 }  // namespace
 }  // namespace quip

@@ -1,0 +1,44 @@
+"""A/B of two builds of the library on the 70B-shaped persistent launch: run `python tools/dbg/gqa_ab.py OUT.pt [layers] [tokens]`
+once per build (QUIP_LIB_PATH selects it), then `python tools/dbg/gqa_ab.py --cmp A.pt B.pt`: logits and cache rows must be EQUAL
+bit for bit (the nibble mode of round 6 computes the same integers as the byte tables of rounds 4-5)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+if sys.argv[1] == "--cmp":
+    a, b = torch.load(sys.argv[2]), torch.load(sys.argv[3])
+    ok = True
+    for k in a:
+        same = torch.equal(a[k], b[k])
+        ok = ok and same
+        d = (a[k].float() - b[k].float()).abs().max().item() if a[k].dtype.is_floating_point else -1
+        print(f"{k}: {'EQUAL' if same else 'DIFFERENT'} (max abs diff {d})")
+    print("A/B:", "bit identical" if ok else "NOT identical")
+    sys.exit(0 if ok else 1)
+
+from quip_for_all_amd import decode as D  # noqa: E402
+
+out = sys.argv[1]
+layers = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+tokens = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+shape = D.LlamaShape(hidden=8192, ffn=28672, layers=layers, heads=64, kv_heads=8, vocab=2048)
+import numpy as np  # noqa: E402
+np.random.seed(1234)          # (get_hadK(use_rand=True) draws the 7 x 7 factors from scipy's process-global generator)
+torch.manual_seed(1234)
+dec = D.LlamaDecoder(shape, "E8P12", max_len=64, device="cuda:0", seed=3, device_init=True)
+assert dec.block_eng and dec.eng_shape == 1, (dec.block_eng, getattr(dec, "eng_shape", None))
+dec.reset(first_token=7)
+res = {}
+with torch.no_grad():
+    for t in range(tokens):
+        lg = dec.step().clone()
+        torch.cuda.synchronize()
+        assert dec.engine_status() == 0, hex(dec.engine_status())
+        res[f"logits{t}"] = lg.cpu()
+res["kcache"] = dec.kcache[..., :tokens, :].cpu()
+res["vcache"] = dec.vcache[..., :tokens, :].cpu()
+torch.save(res, out)
+print("saved", out, "finite", all(bool(torch.isfinite(v.float()).all()) for v in res.values()), "lib", os.environ.get("QUIP_LIB_PATH", "default"))
