@@ -64,6 +64,16 @@
 #ifndef QUIP_POLL2_STAGGER
 #define QUIP_POLL2_STAGGER 10      // s_sleep units (64 clocks) between the first requests of the two sets
 #endif
+// nibble mode: a decoded item waits as 16 scalar registers, not 32 -- more of them fit
+#ifndef QUIP_NIB_PREDECODE_QKV
+#define QUIP_NIB_PREDECODE_QKV 3
+#endif
+#ifndef QUIP_NIB_PREDECODE_GATE
+#define QUIP_NIB_PREDECODE_GATE 3
+#endif
+#ifndef QUIP_NIB_PREDECODE_DOWN
+#define QUIP_NIB_PREDECODE_DOWN 3
+#endif
 #ifndef QUIP_PREDECODE_GATE
 #define QUIP_PREDECODE_GATE 2      // items of gate / up decoded inside the wait for z_o (3: spills 60 bytes)
 #endif
@@ -154,6 +164,13 @@ struct BLds {
   // RVQ (E8P12RVQ4B): read as 16-bit E8P codes a row has twice as many (virtual) weights, 8-groups alternating residual / main,
   // and multiplies x' = [s x_g | x_g]_g: twice the digits per vector, twice the items per product (hadamard.hip, rvq_scale)
   static constexpr int VM = RVQ ? 2 : 1, KV = VM * HID;
+  // NIBBLE MODE (REP = 4, round 6; e8p_gemv_core.hip.h): both E8P tables as 4-byte entries, 32 conflict-free copies each, in 64 KB
+  // (the byte tables' 32 / 16 copies: 96 KB); digit planes as HALF planes -- a plane = its "lo" half (positions 0..3 of the
+  // 8-groups), then, 16 bytes off a multiple of 256 later, its "hi" half; planes 64 bytes off a multiple of 256 apart (the pieces
+  // a ds_read_b128 lane group touches on different banks); the accumulator rows hold 8 x the digit sums of the byte tables
+  static constexpr bool kNib = T::kNib;
+  static_assert(!kNib || !RVQ, "nibble mode: E8P12 (the virtual rows of the RVQ codebooks stay on the byte tables)");
+  static constexpr int PSH = kNib ? KV + 64 : KV, HOH = KV / 2 + 16;       // plane stride of a hidden-wide vector; its "hi" half
   static constexpr int KPDV = RVQ ? 22528 : KPD, JDV = RVQ ? 43 : JD;   // digits of down's input (virtual, padded), its slices
   static constexpr int KKP = (FK * FK + 7) & ~7, KP16 = G8 ? 64 : 48;
   // row stride of down's transposed factor in the image: 64 fp16 = 128 bytes put the 16 rows of a B fragment on ONE bank group
@@ -185,20 +202,27 @@ struct BLds {
   static constexpr int kStage = kArea + 8 * 1024;            // MLP row owners: their four rows, transposed, on the way out (4 KB)
   // fp16 image of the three K x K factors (12 KB; G8: 20.3 KB), behind the planes of gate / up and behind the rows' LDS image
   // ([KP16 / 2][256] fp16 pairs = 24 KB; G8: 32 KB)
-  static constexpr int kHad = kArea + (G8 ? 32 * 1024 : 2 * 3 * KV);
+  static constexpr int kHad = kArea + (G8 ? 32 * 1024 : 2 * 3 * PSH);
   // MLP row owners: SV_gate / SV_up / SU_down of their rows (6 KB): behind the factor image; G8: at 16 K (free while they are alive:
   // the planes of the ONE consumer end at 12 K, the owners' rows and staging at 12 K)
   static constexpr int kStash = G8 ? kArea + 16 * 1024 : kHad + 12 * 1024;
-  static constexpr int kPlaneD = (KPDV / 256) * 272;
+  // down's planes.  Byte tables: every 256 digits padded by 16 bytes (the K-mix writes a dword per lane, 256 digits apart).  Nibble
+  // mode: a half plane = (KPDV / 256) blocks of 128 + 16 bytes (the same writers: 144-byte steps land on 16 different banks; without
+  // the pad their dwords, 128 bytes apart, met on two: 6.5K instead of 3.9K clocks for the K-mix + planes), "hi" half at HOD = 16
+  // (mod 256) behind the "lo" half, planes kPlaneD = 64 (mod 256) apart
+  static constexpr int kHalfD = (KPDV / 256) * 144;
+  static constexpr int up256(int x, int r) { return x + ((r - x % 256) + 256) % 256; }
+  static constexpr int HOD = up256(kHalfD, 16);
+  static constexpr int kPlaneD = kNib ? up256(HOD + kHalfD, 64) : (KPDV / 256) * 272;
   static constexpr int kBytes = kArea + kAreaBytes;
   static_assert(kAreaBytes >= 3 * kBufBytes && kAreaBytes >= FL * KP16 * 2 && kAreaBytes >= 3 * kPlaneD &&
                 kHad + kHadElems * 2 <= kArea + kAreaBytes && kStash + 6 * 1024 <= (G8 ? kHad : kArea + kAreaBytes),
                 "transient area");
 };
 #if QUIP_BLOCK_G8
-static_assert(BLds<24>::kBytes <= 160 * 1024, "LDS budget");
+static_assert(BLds<24>::kBytes <= 160 * 1024 && BLds<4>::kBytes <= 160 * 1024, "LDS budget");
 #else
-static_assert(BLds<24>::kBytes <= 160 * 1024 && BLds<16>::kBytes <= 160 * 1024 && BLds<64>::kBytes <= 160 * 1024 &&
+static_assert(BLds<4>::kBytes <= 160 * 1024 && BLds<24>::kBytes <= 160 * 1024 && BLds<16>::kBytes <= 160 * 1024 && BLds<64>::kBytes <= 160 * 1024 &&
               BLds<16, true>::kBytes <= 160 * 1024 && BLds<64, true>::kBytes <= 160 * 1024 && BLds<12, true>::kBytes <= 160 * 1024,
               "LDS budget");
 #endif
@@ -260,6 +284,10 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   auto qmat = [](int b) { return b < 256 ? 0 : (b < 320 ? 1 : 2); };
   auto qblk = [](int b) { return b < 256 ? b : (b < 320 ? b - 256 : b - 320); };
   uint32_t lane_c, lane_c2, lane_c3 = 0u, xlane;
+  constexpr bool NIB = T::kNib;
+  constexpr int kPreW = NIB ? 16 : 32;                  // dwords of a decoded item that waits in registers
+  constexpr int kUnsc = T::kD4 ? 1 : (NIB ? 5 : 2);     // the accumulator rows hold 2^kUnsc x sum of digit x w (table entries 4 w / 2 w; nibble mode 8 x 4 w)
+  NibLane nlf = {0, 0, 0u};                             // nibble mode: this lane's factors of an item's rows (item_rows_nib)
   auto rederive = [&]() {
     int t = threadIdx.x;
     asm volatile("" : "+v"(t));
@@ -309,12 +337,18 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     vo_dr[0] = (uint32_t)((w * RPW + n) * kRowU4DV + wave * 8 + q) * PB;
     vo_dr[1] = vo_dr[0] + 256u * PB;
     vo_dr[2] = vo_dr[1] + (wave < 3 ? 64u * PB : 0u);
-    lane_c = Lds<REP>::kD4 ? ((uint32_t)lane << 2)
+    lane_c = NIB ? nib_lane_const(lane)
+             : Lds<REP>::kD4 ? ((uint32_t)lane << 2)
              : (Lds<REP>::kRep1 == 32) ? ((((uint32_t)lane & 31u) << 3) | 0x00010000u)
                                        : ((((uint32_t)lane & 15u) << 3) | (uint32_t)Lds<REP>::kT1);
     lane_c2 = (((uint32_t)lane & 15u) << 3) | (uint32_t)Lds<REP>::kT2;
     if constexpr (R3) lane_c3 = (((uint32_t)lane & (uint32_t)(Lds<REP>::kRep3 - 1)) << 3) | (uint32_t)Lds<REP>::kT3;
-    xlane = (uint32_t)B::kArea + (uint32_t)min(n, 2) * (uint32_t)KV + (uint32_t)q * 64u + (uint32_t)wave * 512u;
+    if constexpr (NIB) {
+      nlf = nib_lane_factors(q);
+      xlane = (uint32_t)B::kArea + nib_row_offset(n, B::PSH, B::HOH) + (uint32_t)q * 32u + (uint32_t)wave * 256u;
+    } else {
+      xlane = (uint32_t)B::kArea + (uint32_t)min(n, 2) * (uint32_t)KV + (uint32_t)q * 64u + (uint32_t)wave * 512u;
+    }
   };
   rederive();
   // a pointer the descriptor holds, as a scalar register pair (the same value in every lane)
@@ -405,11 +439,11 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   // slots of the items of a product (see ISSUE / ISSUE_RVQ_*)
   constexpr unsigned M_QKV = G8 ? 0x00cu : (RVQ ? 0x03fu : 0x007u), M_O = RVQ ? 0x0c0u : 0x008u, M_GATE = RVQ ? 0x03fu : 0x007u;
   constexpr unsigned M_UP = G8 ? 0x078u : (RVQ ? 0x1c0u : 0x038u) /* RVQ: up's first half */, M_DOWN = G8 ? 0x183u : (RVQ ? 0x03fu : 0x1c0u);
-  static_assert(!G8 || (!RVQ && !HI && REP == 24), "the grouped-query 4096-wide shape: E8P12 only");
+  static_assert(!G8 || (!RVQ && !HI && (REP == 24 || REP == 4)), "the grouped-query 4096-wide shape: E8P12 only");
 
   // ---- prologue ---------------------------------------------------------------------------------------------------
   u32x2 tsrc;
-  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(tsrc) : "v"(T::kD4 ? table_source_ptr_d4(a.grid, lane, wave) : table_source_ptr(a.grid, lane, wave)) : "memory");
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(tsrc) : "v"(NIB ? table_source_ptr_nib(a.grid, lane, wave) : T::kD4 ? table_source_ptr_d4(a.grid, lane, wave) : table_source_ptr(a.grid, lane, wave)) : "memory");
   u32x2 tsrc3 = {0u, 0u};                            // RVQ3B: this lane's E81B entry (row 32 wave + (lane & 31) of T3)
   if constexpr (R3)
     asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(tsrc3) : "v"(reinterpret_cast<const uint2*>(a.grid2) + (wave * 32 + (lane & 31))) : "memory");
@@ -430,7 +464,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   int* accs = reinterpret_cast<int*>(smem + B::kAcc);
   for (int i = tid; i < B::kAccRows * 4; i += kThreads) accs[i] = 0;
   asm volatile("s_waitcnt vmcnt(%2)" : "+v"(tsrc), "+v"(tsrc3) : "n"(9 + NQ) : "memory");
-  fill_tables_from_lane<REP>(smem, tsrc, lane, wave);
+  if constexpr (NIB) fill_tables_nib(tsrc, lane, wave);
+  else fill_tables_from_lane<REP>(smem, tsrc, lane, wave);
   fill_t3_from_lane<REP>(smem, tsrc3, lane, wave);
   asm volatile("s_waitcnt vmcnt(%1)" : "+v"(gen) : "n"(8 + NQ) : "memory");
   const uint32_t ebase = ((uint32_t)__builtin_amdgcn_readfirstlane((int)gen) + 1u) << 10;
@@ -566,7 +601,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   auto publish16 = [&](int vec, int gr0, int row0, int sh, uint32_t tag) {      // gr0: first granule of the block in its vector
     if (tid < 8) {
       const int* s3 = accs + (row0 + 2 * tid) * 4;
-      const float us = unscale_of(sh, T::kD4 ? 1 : 2);      // table entries are 4 w (E8P12) / 2 w (D4)
+      const float us = unscale_of(sh, kUnsc);              // table entries are 4 w (E8P12) / 2 w (D4); nibble mode: 8 x 4 w
       const float f0 = __builtin_fmaf((float)s3[0], 65536.f, __builtin_fmaf((float)s3[1], 256.f, (float)s3[2]));
       const float f1 = __builtin_fmaf((float)s3[4], 65536.f, __builtin_fmaf((float)s3[5], 256.f, (float)s3[6]));
       esync::st_granule(zbufs + (size_t)vec * 2048 + gr0 + tid, pack_f16(f0 * us, f1 * us), tag);
@@ -624,7 +659,14 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       hadw::digit_words_magic(va, s2, dg[0][0], dg[1][0], dg[2][0]);
       hadw::digit_words_magic(vb, s2, dg[0][1], dg[1][1], dg[2][1]);
 #pragma unroll
-      for (int d = 0; d < 3; ++d) *reinterpret_cast<uint2*>(smem + base + d * HID + 8 * tid) = make_uint2(dg[d][0], dg[d][1]);
+      for (int d = 0; d < 3; ++d) {
+        if constexpr (NIB) {       // the thread's 8-group: positions 0..3 -> the "lo" half, 4..7 -> the "hi" half
+          *reinterpret_cast<uint32_t*>(smem + base + d * B::PSH + 4 * tid) = dg[d][0];
+          *reinterpret_cast<uint32_t*>(smem + base + d * B::PSH + B::HOH + 4 * tid) = dg[d][1];
+        } else {
+          *reinterpret_cast<uint2*>(smem + base + d * HID + 8 * tid) = make_uint2(dg[d][0], dg[d][1]);
+        }
+      }
     }
   };
   // block exponent of planes made of H x * scale, from the sum of squares of x (4096 values): |H x|_inf <= 64 |x|_2
@@ -732,7 +774,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         const float s0 = had::rms_scale(sc0, tot, HID, a.rms_eps), s1 = had::rms_scale(sc1, tot, HID, a.rms_eps);
         const int sh0 = norm_shift(red_sum8(8), s0), sh1 = norm_shift(red_sum8(16), s1);
         planes_nat(v[0], s0, sh0, (uint32_t)B::kArea);
-        planes_nat(v[1], s1, sh1, (uint32_t)(B::kArea + 3 * KV));
+        planes_nat(v[1], s1, sh1, (uint32_t)(B::kArea + 3 * B::PSH));
         if (tid == 0) { shs[0] = sh0; shs[1] = sh1; }
       } else {
         float v[1][8];
@@ -768,11 +810,64 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   };
 
   // ---- one item of a product: slot s, digit planes at xa ------------------------------------------------------------
-  auto run_item = [&](int s, uint32_t xa, int accrow) {
+  // the A fragments of a K slice (byte tables: eight; nibble mode: four + their digit sums)
+  struct Frag { i32x4 A[8]; NibFrags N; };
+  auto frags = [&](uint32_t xa, Frag& F) {
+    if constexpr (NIB) nib_fragments(xa, F.N); else item_fragments(xa, F.A);
+  };
+  auto frags_d = [&](uint32_t xa, Frag& F) {            // down's planes (nibble mode: 144-byte blocks, see BLds::kHalfD)
+    if constexpr (NIB) nib_fragments<144>(xa, F.N); else item_fragments(xa, F.A);
+  };
+  // the item in slot registers (da, db) against the fragments F
+  auto mul_slot = [&](const slot_t& da, const slot_t& db, const Frag& F) -> i32x4 {
+    ItemAddr ad;
+    item_addresses<REP>(da, db, lane_c, lane_c2, ad, lane_c3);
+    if constexpr (NIB) return nib_item(ad, F.N, nlf);
+    else return item_mfma_shared<T::kD4, R3>(ad, F.A);
+  };
+  // an item decoded earlier (pre: its B fragments as scalars -- byte tables: 32 dwords; nibble mode: 16) against the fragments F
+  auto mul_pre = [&](const uint32_t* pre, const Frag& F) -> i32x4 {
+    if constexpr (NIB) {
+      return nib_multiply(pre, F.N, nlf);
+    } else {
+      i32x4 r = {0, 0, 0, 0};
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const i32x4 Bt = {(int)pre[4 * t], (int)pre[4 * t + 1], (int)pre[4 * t + 2], (int)pre[4 * t + 3]};
+        r = __builtin_amdgcn_mfma_i32_16x16x64_i8(F.A[t], Bt, r, 0, 0, 0);
+      }
+      return r;
+    }
+  };
+  // the table look-ups of the item in slot s now (inside a hand-off's wait), its MFMAs later: B fragments as scalar registers
+  auto decode_pre = [&](int s, uint32_t (&pre)[kPreW]) {
     ItemAddr ad;
     item_addresses<REP>(qa[s], qb[s], lane_c, lane_c2, ad, lane_c3);
-    const i32x4 r = T::kD4 ? item_mfma_d4(ad, xa) : item_mfma<256, R3>(ad, xa);
-    if (q == 0) {
+    if constexpr (NIB) {
+      uint32_t raw[16];
+      nib_decode(ad, raw);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) { asm volatile("" : "+v"(raw[t])); pre[t] = raw[t]; }
+    } else {
+      i32x4 Bt[8];
+      if constexpr (T::kD4) item_decode_d4(ad, Bt); else item_decode<R3>(ad, Bt);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        pre[4 * t] = (uint32_t)Bt[t].x; pre[4 * t + 1] = (uint32_t)Bt[t].y; pre[4 * t + 2] = (uint32_t)Bt[t].z; pre[4 * t + 3] = (uint32_t)Bt[t].w;
+        asm volatile("" : "+v"(pre[4 * t]), "+v"(pre[4 * t + 1]), "+v"(pre[4 * t + 2]), "+v"(pre[4 * t + 3]));
+      }
+    }
+  };
+  // which lanes own accumulator rows: byte tables q == 0 (D rows 0..2); nibble mode q < 2 (+ D rows 4..6 of the same column)
+  auto owns_rows = [&]() -> bool { return NIB ? q < 2 : q == 0; };
+  auto run_item = [&](int s, uint32_t xa, int accrow) {
+    static_assert(!NIB || true, "");
+    ItemAddr ad;
+    item_addresses<REP>(qa[s], qb[s], lane_c, lane_c2, ad, lane_c3);
+    i32x4 r;
+    if constexpr (NIB) { Frag F; frags(xa, F); r = nib_item(ad, F.N, nlf); }
+    else r = T::kD4 ? item_mfma_d4(ad, xa) : item_mfma<256, R3>(ad, xa);
+    if (owns_rows()) {
       int* dst = accs + (accrow + n) * 4;
       __hip_atomic_fetch_add(dst + 0, r.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       __hip_atomic_fetch_add(dst + 1, r.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -783,16 +878,14 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   // three items of one K slice (the row blocks of a matrix share the slice's A fragments; xa differs between items only where
   // a workgroup's row blocks straddle two matrices: re-read then -- a uniform branch)
   auto run_items3 = [&](int s0, uint32_t xa0, uint32_t xa1, uint32_t xa2, int accrow0) {
-    i32x4 A[8];
-    item_fragments(xa0, A);
+    Frag A;
+    frags(xa0, A);
     const uint32_t xas[3] = {xa0, xa1, xa2};
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      if (i > 0 && xas[i] != xas[i - 1]) item_fragments(xas[i], A);
-      ItemAddr ad;
-      item_addresses<REP>(qa[s0 + i], qb[s0 + i], lane_c, lane_c2, ad, lane_c3);
-      const i32x4 r = item_mfma_shared<T::kD4, R3>(ad, A);
-      if (q == 0) {
+      if (i > 0 && xas[i] != xas[i - 1]) frags(xas[i], A);
+      const i32x4 r = mul_slot(qa[s0 + i], qb[s0 + i], A);
+      if (owns_rows()) {
         int* dst = accs + (accrow0 + 16 * i + n) * 4;
         __hip_atomic_fetch_add(dst + 0, r.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(dst + 1, r.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -801,28 +894,18 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     }
   };
   // three items of one K slice whose first NPRE were decoded earlier (pre: their eight B fragments each, as scalars)
-  auto run_items3_pre = [&](auto npre_tag, const uint32_t (&pre)[decltype(npre_tag)::value][32], int s0, uint32_t xa0, uint32_t xa1, uint32_t xa2, int accrow0) {
+  auto run_items3_pre = [&](auto npre_tag, const uint32_t (&pre)[decltype(npre_tag)::value][kPreW], int s0, uint32_t xa0, uint32_t xa1, uint32_t xa2, int accrow0) {
     constexpr int NPRE = decltype(npre_tag)::value;
-    i32x4 A[8];
-    item_fragments(xa0, A);
+    Frag A;
+    frags(xa0, A);
     const uint32_t xas[3] = {xa0, xa1, xa2};
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      if (i > 0 && xas[i] != xas[i - 1]) item_fragments(xas[i], A);
+      if (i > 0 && xas[i] != xas[i - 1]) frags(xas[i], A);
       i32x4 r = {0, 0, 0, 0};
-      if (i < NPRE) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const uint32_t* bs = pre[i < NPRE ? i : 0];
-          const i32x4 Bt = {(int)bs[4 * t], (int)bs[4 * t + 1], (int)bs[4 * t + 2], (int)bs[4 * t + 3]};
-          r = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t], Bt, r, 0, 0, 0);
-        }
-      } else {
-        ItemAddr ad;
-        item_addresses<REP>(qa[s0 + i], qb[s0 + i], lane_c, lane_c2, ad, lane_c3);
-        r = item_mfma_shared<T::kD4, R3>(ad, A);
-      }
-      if (q == 0) {
+      if (i < NPRE) r = mul_pre(pre[i < NPRE ? i : 0], A);
+      else r = mul_slot(qa[s0 + i], qb[s0 + i], A);
+      if (owns_rows()) {
         int* dst = accs + (accrow0 + 16 * i + n) * 4;
         __hip_atomic_fetch_add(dst + 0, r.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(dst + 1, r.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -832,13 +915,13 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   };
   // the same item in two halves: the table lookups while a hand-off is awaited (the codes are there long before the digits),
   // the eight MFMAs once the digit planes exist
-  auto decode_item = [&](int s, i32x4 (&Bf)[8]) {
+  auto decode_item = [&](int s, i32x4 (&Bf)[8]) {       // (byte tables: o's item waits as eight 128-bit tuples)
     ItemAddr ad;
     item_addresses<REP>(qa[s], qb[s], lane_c, lane_c2, ad, lane_c3);
-    if constexpr (T::kD4) item_decode_d4(ad, Bf); else item_decode<R3>(ad, Bf);
+    if constexpr (T::kD4) item_decode_d4(ad, Bf); else if constexpr (!NIB) item_decode<R3>(ad, Bf);
   };
   auto add_rows = [&](const i32x4& r, int accrow) {
-    if (q == 0) {
+    if (owns_rows()) {
       int* dst = accs + (accrow + n) * 4;
       __hip_atomic_fetch_add(dst + 0, r.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       __hip_atomic_fetch_add(dst + 1, r.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -860,37 +943,28 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   // (called for block 0 here and, for block l + 1, at the bottom of iteration l: the requests of q, k, v go out BEHIND the
   //  hand-off of z_d and are consumed before the loop's back edge, where no request may be in flight -- the compiler is free to
   //  copy registers there)
-  constexpr int NPQ = QUIP_PREDECODE_QKV > 0 ? QUIP_PREDECODE_QKV : 1;
+  constexpr int NPQ = NIB ? (G8 ? 2 : QUIP_NIB_PREDECODE_QKV) : (QUIP_PREDECODE_QKV > 0 ? QUIP_PREDECODE_QKV : 1);
+  constexpr int kPreG = NIB ? (G8 ? 2 : QUIP_NIB_PREDECODE_GATE) : QUIP_PREDECODE_GATE, kPreD = (NIB && !G8) ? QUIP_NIB_PREDECODE_DOWN : QUIP_PREDECODE_DOWN;
   // the first / last of the one or two matrices (q 0, k 1, v 2) this workgroup's q / k / v row blocks are in
   const int qc_lo = G8 ? qmat(qb0) : ((3 * w) >> 8), qc_hi = G8 ? qmat(qb0 + qcnt - 1) : ((3 * w + 2) >> 8);
   // one item against the A fragments of its K slice: decoded earlier (pre, as scalars) or from slot `slot_c`
-  auto item_vs = [&](auto slot_c, const uint32_t* pre, const i32x4 (&A)[8]) -> i32x4 {
+  auto item_vs = [&](auto slot_c, const uint32_t* pre, const Frag& A) -> i32x4 {
     constexpr int S = decltype(slot_c)::value;
-    if (pre) {
-      i32x4 r = {0, 0, 0, 0};
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const i32x4 Bt = {(int)pre[4 * t], (int)pre[4 * t + 1], (int)pre[4 * t + 2], (int)pre[4 * t + 3]};
-        r = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t], Bt, r, 0, 0, 0);
-      }
-      return r;
-    }
-    ItemAddr ad;
-    item_addresses<REP>(qa[S], qb[S], lane_c, lane_c2, ad, lane_c3);
-    return item_mfma_shared<T::kD4, R3>(ad, A);
+    if (pre) return mul_pre(pre, A);
+    return mul_slot(qa[S], qb[S], A);
   };
-  auto P1_products = [&](auto pre_tag, const uint32_t (&preq)[NPQ][32]) {
+  auto P1_products = [&](auto pre_tag, const uint32_t (&preq)[NPQ][kPreW]) {
     const int c_lo = qc_lo;
     esync::drain();                                    // q, k, v have landed
     own_slots(SLOTS(M_QKV));
     if constexpr (G8) {
       // one or two items (slots X2, X3); the second one's planes are consumer 1's where it lies in the next matrix (workgroup 170)
       constexpr bool PRE = decltype(pre_tag)::value;
-      i32x4 A[8];
-      item_fragments(xlane, A);
+      Frag A;
+      frags(xlane, A);
       add_rows(item_vs(std::integral_constant<int, 2>{}, PRE ? preq[0] : nullptr, A), 0);
       if (qcnt == 2) {
-        if (qc_hi != qc_lo) item_fragments(xlane + (uint32_t)(3 * KV), A);
+        if (qc_hi != qc_lo) frags(xlane + (uint32_t)(3 * B::PSH), A);
         add_rows(item_vs(std::integral_constant<int, 3>{}, (PRE && NPQ > 1) ? preq[NPQ > 1 ? 1 : 0] : nullptr, A), 16);
       }
       had::wg_barrier<true>();
@@ -904,9 +978,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       return;
     }
     {
-      const uint32_t x0 = xlane + (uint32_t)((((3 * w) >> 8) == c_lo ? 0 : 1) * 3 * KV);
-      const uint32_t x1 = xlane + (uint32_t)((((3 * w + 1) >> 8) == c_lo ? 0 : 1) * 3 * KV);
-      const uint32_t x2 = xlane + (uint32_t)((((3 * w + 2) >> 8) == c_lo ? 0 : 1) * 3 * KV);
+      const uint32_t x0 = xlane + (uint32_t)((((3 * w) >> 8) == c_lo ? 0 : 1) * 3 * B::PSH);
+      const uint32_t x1 = xlane + (uint32_t)((((3 * w + 1) >> 8) == c_lo ? 0 : 1) * 3 * B::PSH);
+      const uint32_t x2 = xlane + (uint32_t)((((3 * w + 2) >> 8) == c_lo ? 0 : 1) * 3 * B::PSH);
       if constexpr (decltype(pre_tag)::value) run_items3_pre(std::integral_constant<int, NPQ>{}, preq, 0, x0, x1, x2, 0);
       else run_items3(0, x0, x1, x2, 0);
       if constexpr (RVQ) run_items3(3, x0 + 4096u, x1 + 4096u, x2 + 4096u, 0);      // the second virtual slice: wave + 8
@@ -928,7 +1002,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     const int c_lo = qc_lo, c_hi = qc_hi;
     edge(std::false_type{}, std::integral_constant<int, 2>{}, SLOTS(M_QKV), -1, 0u, 0u, nullptr, Ld.ln[0], Ld.su[c_lo], Ld.su[c_hi],
          Ld.sc[c_lo], Ld.sc[c_hi], c_hi != c_lo, [&]() {}, [&]() {}, [&]() {}, -1, std::integral_constant<int, 0>{});
-    uint32_t none[NPQ][32];                          // (block 0: nothing decoded ahead; never read)
+    uint32_t none[NPQ][kPreW];                          // (block 0: nothing decoded ahead; never read)
     P1_products(std::false_type{}, none);
   }
   for (int l = 0; l < a.n_layers; ++l) {
@@ -1287,12 +1361,14 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     BSTAMP(6);
     rederive();
     i32x4 Bo[8];
+    uint32_t Bon[kPreW];                                  // (nibble mode: o's item as 16 scalars)
     {
       // o's codes were requested a hand-off ago: their table lookups run HERE, inside the wait for the attention output
       // (RVQ: two items -- their fragments would be 64 registers: decoded with the product instead)
       esync::drain();
       own_slots(SLOTS(M_O));
-      if constexpr (!RVQ) decode_item(3, Bo);
+      if constexpr (NIB) decode_pre(3, Bon);
+      else if constexpr (!RVQ) decode_item(3, Bo);
       // o_proj's input side: x = H (a (.) SU_o) * sc  (no norm), every workgroup
       u32x4 psu = *reinterpret_cast<const u32x4*>(Ld.su[3] + 8 * tid);
       float v[1][8];
@@ -1346,6 +1422,22 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
 #endif
       if constexpr (HI) had8::planes_scatter_hi(v[0], sco, sh, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
       else if constexpr (RVQ) had8::planes_scatter_rvq(v[0], sco, a.resid_scale, sh, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
+      else if constexpr (NIB) {
+        // planes_scatter's digits (element tid + 512 k of the strided layout) at their half-plane bytes
+#pragma clang fp contract(off)
+        const float s2 = had::fmul(sco, as_f32((uint32_t)(sh + 127) << 23));
+        uint8_t* pb = reinterpret_cast<uint8_t*>(smem + B::kArea) + nib_half_of(tid) * B::HOH + nib_byte_of(tid);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int X = (int)__builtin_rintf(v[0][k] * s2);
+          const int X1 = (X + 128) >> 8;
+          const int H = (X1 + 128) >> 8;
+          uint8_t* p = pb + 256 * k;
+          p[0] = (uint8_t)H;
+          p[B::PSH] = (uint8_t)X1;
+          p[2 * B::PSH] = (uint8_t)X;
+        }
+      }
       else had8::planes_scatter(v[0], sco, sh, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
       if (tid == 0) shs[3] = sh;
       had::wg_barrier<true>();
@@ -1355,7 +1447,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       run_item(6, xlane, 48);
       run_item(7, xlane + 4096u, 48);
     } else {
-      add_rows(item_multiply(Bo, xlane), 48);
+      if constexpr (NIB) { Frag Fo; frags(xlane, Fo); add_rows(mul_pre(Bon, Fo), 48); }
+      else add_rows(item_multiply(Bo, xlane), 48);
     }
     had::wg_barrier<true>();
     ++hop;                                             // hand-off: z_o
@@ -1368,20 +1461,12 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     rederive();
 #if QUIP_PREDECODE_GATE
     // the first gate / up item's table look-ups inside the wait for z_o (its codes were requested under o's input side)
-    uint32_t Bg[QUIP_PREDECODE_GATE][32];            // (scalar registers while they wait: see down's)
+    uint32_t Bg[kPreG][kPreW];                          // (scalar registers while they wait: see down's)
     if constexpr (!RVQ) {
       esync::drain();
       own_slots(SLOTS(M_GATE));
 #pragma unroll
-      for (int i = 0; i < QUIP_PREDECODE_GATE; ++i) {
-        i32x4 Bt[8];
-        decode_item(i, Bt);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          Bg[i][4 * t] = (uint32_t)Bt[t].x; Bg[i][4 * t + 1] = (uint32_t)Bt[t].y; Bg[i][4 * t + 2] = (uint32_t)Bt[t].z; Bg[i][4 * t + 3] = (uint32_t)Bt[t].w;
-          asm volatile("" : "+v"(Bg[i][4 * t]), "+v"(Bg[i][4 * t + 1]), "+v"(Bg[i][4 * t + 2]), "+v"(Bg[i][4 * t + 3]));
-        }
-      }
+      for (int i = 0; i < kPreG; ++i) decode_pre(i, Bg[i]);
     }
 #endif
     // (ONE consumer per workgroup: its half of the machine multiplies gate, the other half up)
@@ -1427,10 +1512,10 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       // them behind the rows' sweep, a third at a time: the last third was still on its way when the planes were done.
       if constexpr (G8) {
         // seven items (slots X0..X6) against the same planes; down's four (X7, X8, X0, X1) requested behind the fourth
-        i32x4 A[8];
-        item_fragments(xlane, A);
+        Frag A;
+        frags(xlane, A);
 #if QUIP_PREDECODE_GATE
-#define PRE_G(i) ((i) < QUIP_PREDECODE_GATE ? Bg[(i) < QUIP_PREDECODE_GATE ? (i) : 0] : nullptr)
+#define PRE_G(i) ((i) < kPreG ? Bg[(i) < kPreG ? (i) : 0] : nullptr)
 #else
 #define PRE_G(i) nullptr
 #endif
@@ -1446,7 +1531,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       } else {
       ISSUE(Ld, 10); ISSUE(Ld, 11); ISSUE(Ld, 12);
 #if QUIP_PREDECODE_GATE
-      run_items3_pre(std::integral_constant<int, QUIP_PREDECODE_GATE>{}, Bg, 0, xlane, xlane, xlane, 64);
+      run_items3_pre(std::integral_constant<int, kPreG>{}, Bg, 0, xlane, xlane, xlane, 64);
       if constexpr (kPreQkv && QUIP_QKV_ISSUE_EARLY) { ISSUE(Ln, 0); ISSUE(Ln, 1); ISSUE(Ln, 2); }
 #else
       run_items3(0, xlane, xlane, xlane, 64);                                     // first column's three row blocks
@@ -1466,7 +1551,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
         const int m = G8 ? (tid >= FK ? 1 : 0) : tid / 48, k = G8 ? tid - FK * m : tid - 48 * m;
         const int* s3 = accs + (B::AGU + tid) * 4;
         const float f = __builtin_fmaf((float)s3[0], 65536.f, __builtin_fmaf((float)s3[1], 256.f, (float)s3[2]));
-        zcol[m * B::KP16 + k] = (float)(f16)(f * unscale_of(shs[0], T::kD4 ? 1 : 2));      // [column 2 (w & 127) + m][k]: one matrix, one exponent
+        zcol[m * B::KP16 + k] = (float)(f16)(f * unscale_of(shs[0], kUnsc));      // [column 2 (w & 127) + m][k]: one matrix, one exponent
       }
       had::wg_barrier<true>();
       zero_acc(B::AGU, 16 * NGU);
@@ -1506,20 +1591,12 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       // MFMAs per item.  (Behind the owners' row work instead, the owners were 1K clocks late for down's product.)
       // (held as scalar registers: a waiting B fragment as a 128-bit tuple needs four consecutive, even-aligned registers,
       //  and the allocator spills long-lived tuples once the file is fragmented)
-      uint32_t Bd[QUIP_PREDECODE_DOWN][32];                             // (the macro: how many of the three items)
+      uint32_t Bd[kPreD][kPreW];                                           // (how many of the three items)
       if constexpr (!RVQ) {
         esync::drain();
         own_slots(SLOTS(M_DOWN));
 #pragma unroll
-        for (int i = 0; i < QUIP_PREDECODE_DOWN; ++i) {                 // (slice 16 + wave >= 22: decoded, never multiplied)
-          i32x4 Bt[8];
-          decode_item(SDf(i), Bt);
-#pragma unroll
-          for (int t = 0; t < 8; ++t) {
-            Bd[i][4 * t] = (uint32_t)Bt[t].x; Bd[i][4 * t + 1] = (uint32_t)Bt[t].y; Bd[i][4 * t + 2] = (uint32_t)Bt[t].z; Bd[i][4 * t + 3] = (uint32_t)Bt[t].w;
-            asm volatile("" : "+v"(Bd[i][4 * t]), "+v"(Bd[i][4 * t + 1]), "+v"(Bd[i][4 * t + 2]), "+v"(Bd[i][4 * t + 3]));
-          }
-        }
+        for (int i = 0; i < kPreD; ++i) decode_pre(SDf(i), Bd[i]);      // (slice 16 + wave >= 22: decoded, never multiplied)
       }
 #endif
       if (w < NRO) {
@@ -1769,7 +1846,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
                 *reinterpret_cast<uint32_t*>(pl + B::kPlaneD + offm) = m;
                 *reinterpret_cast<uint32_t*>(pl + 2 * B::kPlaneD + offm) = l;
               } else {
-                const int off = (kk >> 8) * 272 + (kk & 255);
+                // (nibble mode: natural dword kk / 4 of a plane = dword (that >> 1) of its "lo" (even) / "hi" (odd) half)
+                const int off = NIB ? ((kk >> 2) & 1) * B::HOD + (kk >> 8) * 144 + (((kk & 255) >> 3) << 2) : (kk >> 8) * 272 + (kk & 255);
                 uint32_t h, m, l;
                 hadw::digit_words_magic(av, s2, h, m, l);
                 *reinterpret_cast<uint32_t*>(pl + off) = h;
@@ -1780,7 +1858,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           }
         }
         for (int i = VM * NFFN + 4 * tid; i < B::KPDV; i += 4 * kThreads) {
-          const int off = (i >> 8) * 272 + (i & 255);
+          const int off = NIB ? ((i >> 2) & 1) * B::HOD + (i >> 8) * 144 + (((i & 255) >> 3) << 2) : (i >> 8) * 272 + (i & 255);
 #pragma unroll
           for (int d = 0; d < 3; ++d) *reinterpret_cast<uint32_t*>(pl + d * B::kPlaneD + off) = 0u;
         }
@@ -1789,7 +1867,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       BSTAMP(16);
       esync::drain();                                  // down's codes (and, behind them, the next block's q, k, v)
       own_slots(SLOTS(M_DOWN | (kPreQkv ? M_QKV : 0u)));
-      const uint32_t xlane_d = (uint32_t)B::kArea + (uint32_t)min(n, 2) * (uint32_t)B::kPlaneD + (uint32_t)q * 64u;
+      const uint32_t xlane_d = NIB ? (uint32_t)B::kArea + nib_row_offset(n, B::kPlaneD, B::HOD) + (uint32_t)q * 32u
+                                   : (uint32_t)B::kArea + (uint32_t)min(n, 2) * (uint32_t)B::kPlaneD + (uint32_t)q * 64u;
+      constexpr uint32_t kSliceD = NIB ? 288u : 544u;          // bytes between the A fragments of consecutive K slices of down's planes
       if constexpr (RVQ) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -1806,18 +1886,30 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
           const int sl = i * kWaves + wave;
           if (sl < JD) {
 #if QUIP_PREDECODE_DOWN
-            if (i < QUIP_PREDECODE_DOWN) {
-              const uint32_t* bs = Bd[i < QUIP_PREDECODE_DOWN ? i : 0];
-              i32x4 Bt[8];
+            if (i < kPreD) {
+              const uint32_t* bs = Bd[i < kPreD ? i : 0];
+              if constexpr (NIB) {
+                Frag Fd;
+                frags_d(xlane_d + (uint32_t)sl * kSliceD, Fd);
+                add_rows(mul_pre(bs, Fd), B::AD);
+              } else {
+                i32x4 Bt[8];
 #pragma unroll
-              for (int t = 0; t < 8; ++t) Bt[t] = i32x4{(int)bs[4 * t], (int)bs[4 * t + 1], (int)bs[4 * t + 2], (int)bs[4 * t + 3]};
-              add_rows(item_multiply<272>(Bt, xlane_d + (uint32_t)(sl * 544)), B::AD);
+                for (int t = 0; t < 8; ++t) Bt[t] = i32x4{(int)bs[4 * t], (int)bs[4 * t + 1], (int)bs[4 * t + 2], (int)bs[4 * t + 3]};
+                add_rows(item_multiply<272>(Bt, xlane_d + (uint32_t)(sl * 544)), B::AD);
+              }
               continue;
             }
 #endif
-            ItemAddr ad;
-            item_addresses<REP>(qa[SDf(i)], qb[SDf(i)], lane_c, lane_c2, ad, lane_c3);
-            add_rows(T::kD4 ? item_mfma_d4<272>(ad, xlane_d + (uint32_t)(sl * 544)) : item_mfma<272, R3>(ad, xlane_d + (uint32_t)(sl * 544)), B::AD);
+            if constexpr (NIB) {
+              Frag Fd;
+              frags_d(xlane_d + (uint32_t)sl * kSliceD, Fd);
+              add_rows(mul_slot(qa[SDf(i)], qb[SDf(i)], Fd), B::AD);
+            } else {
+              ItemAddr ad;
+              item_addresses<REP>(qa[SDf(i)], qb[SDf(i)], lane_c, lane_c2, ad, lane_c3);
+              add_rows(T::kD4 ? item_mfma_d4<272>(ad, xlane_d + (uint32_t)(sl * 544)) : item_mfma<272, R3>(ad, xlane_d + (uint32_t)(sl * 544)), B::AD);
+            }
           }
         }
       }
@@ -1841,19 +1933,11 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
     //  side of its own q, k, v once more, never used -- so that no request depends on a branch: the compiler makes several
     //  conditional regions of one `if`, and a register a load is still going to write must not meet a copy at their joins)
     rederive();
-    uint32_t Bq[NPQ][32];
+    uint32_t Bq[NPQ][kPreW];
     if constexpr (kPreQkv) {
       // the first items' table look-ups inside the wait for z_d (their codes landed under down's product); held as scalars
 #pragma unroll
-      for (int i = 0; i < NPQ; ++i) {
-        i32x4 Bt[8];
-        decode_item(SQf(i), Bt);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          Bq[i][4 * t] = (uint32_t)Bt[t].x; Bq[i][4 * t + 1] = (uint32_t)Bt[t].y; Bq[i][4 * t + 2] = (uint32_t)Bt[t].z; Bq[i][4 * t + 3] = (uint32_t)Bt[t].w;
-          asm volatile("" : "+v"(Bq[i][4 * t]), "+v"(Bq[i][4 * t + 1]), "+v"(Bq[i][4 * t + 2]), "+v"(Bq[i][4 * t + 3]));
-        }
-      }
+      for (int i = 0; i < NPQ; ++i) decode_pre(SQf(i), Bq[i]);
     }
     {
       const int c_lo = qc_lo, c_hi = qc_hi;
@@ -1935,13 +2019,18 @@ int block_engine_g8_launch(const BlockEngineArgs& in, hipStream_t stream) {
   a.n_layers = in.n_layers; a.max_len = in.max_len; a.dbg_layer = in.dbg_layer;
   a.rms_eps = in.rms_eps; a.attn_scale = in.attn_scale; a.resid_scale = 0.f;
   a.grid2 = nullptr;
-  static DynLdsCache c24;
-  static ResidencyCache r24;
-  const auto kern = decode_block_kernel<24>;
-  if (ensure_dyn_lds(c24, reinterpret_cast<const void*>(kern), BLds<24>::kBytes) != QUIP_OK) return QUIP_ERR_LAUNCH;
-  if (!persistent_grid_fits(r24, reinterpret_cast<const void*>(kern), kThreads, BLds<24>::kBytes, NWG)) return QUIP_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(kern, dim3(NWG), dim3(kThreads), BLds<24>::kBytes, stream, a);
-  return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+  // QUIP_ENG_REP=24: the byte tables of round 5 (32 / 16 copies) instead of the nibble mode, for A/B
+  static const bool rep24 = getenv("QUIP_ENG_REP") && atoi(getenv("QUIP_ENG_REP")) == 24;
+  auto go = [&](auto kern, int lds, DynLdsCache& configured, ResidencyCache& resident) -> int {
+    if (ensure_dyn_lds(configured, reinterpret_cast<const void*>(kern), lds) != QUIP_OK) return QUIP_ERR_LAUNCH;
+    if (!persistent_grid_fits(resident, reinterpret_cast<const void*>(kern), kThreads, lds, NWG)) return QUIP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(kern, dim3(NWG), dim3(kThreads), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+  };
+  static DynLdsCache c24, c4;
+  static ResidencyCache r24, r4;
+  if (rep24) return go(decode_block_kernel<24>, BLds<24>::kBytes, c24, r24);
+  return go(decode_block_kernel<4>, BLds<4>::kBytes, c4, r4);
 }
 #else
 size_t block_engine_workspace_bytes() { return kWsBytes; }
@@ -1985,10 +2074,13 @@ int block_engine_launch(const BlockEngineArgs& in, hipStream_t stream) {
   if (in.codebook == 2) { a.resid_scale = in.resid_scale; return go(decode_block_kernel<16, true>, BLds<16, true>::kBytes, crvq, rrvq); }
   if (in.codebook == 1) return go(decode_block_kernel<64>, BLds<64>::kBytes, c64, r64);
   if (in.codebook != 0) return QUIP_ERR_UNSUPPORTED;
-  static const bool rep16 = getenv("QUIP_ENG_REP") && atoi(getenv("QUIP_ENG_REP")) == 16;     // A/B: two-way conflicts on both tables
-  static DynLdsCache c24;
-  if (rep16) return go(decode_block_kernel<16>, BLds<16>::kBytes, c16, r16);
-  return go(decode_block_kernel<24>, BLds<24>::kBytes, c24, r24);
+  // A/B: QUIP_ENG_REP=16: byte tables, two-way conflicts on both; 24: byte tables, 32 / 16 copies (round 5); default: nibble mode
+  static const int eng_rep = getenv("QUIP_ENG_REP") ? atoi(getenv("QUIP_ENG_REP")) : 4;
+  static DynLdsCache c24, c4;
+  static ResidencyCache r4;
+  if (eng_rep == 16) return go(decode_block_kernel<16>, BLds<16>::kBytes, c16, r16);
+  if (eng_rep == 24) return go(decode_block_kernel<24>, BLds<24>::kBytes, c24, r24);
+  return go(decode_block_kernel<4>, BLds<4>::kBytes, c4, r4);
 }
 
 #endif

@@ -190,6 +190,17 @@ template <int REP>
 __device__ __forceinline__ void item_addresses(const u32x4& q0, const u32x4& q1, uint32_t lane_c,
                                                uint32_t lane_c2, ItemAddr& ad, uint32_t lane_c3) {
   const uint32_t d[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+  if constexpr (REP == 4) {
+    // nibble mode (the end of this file): lane_c = nib_lane_const(lane)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      ad.a1l[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c0c0500u);
+      ad.a2l[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c0c0402u);
+      ad.a1h[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c0c0700u);
+      ad.a2h[t] = __builtin_amdgcn_perm(d[t], lane_c, 0x0c0c0602u);
+    }
+    return;
+  }
   if constexpr (REP == 64) {
     // D4: dword t = 4 one-byte codes = the 16 weights of MFMA step t; entry address =
     // code << 8 | lane << 2 (lane_c), one v_perm_b32 per code
@@ -457,9 +468,11 @@ __device__ __forceinline__ void item_addresses_nib(const u32x4& q0, const u32x4&
 }
 // A fragments of a 512-k slice of half planes: step s covers k = 256 (s >> 1) + 64 q + 32 (s & 1) + [0, 32) of the slice;
 // xaddr = this lane's row (plane / half) + slice * 256 + q * 32
+// (HB: bytes between the two 128-byte halves of a slice in a half plane: 128, or more where the writer pads)
+template <int HB = 128>
 __device__ __forceinline__ void item_fragments_nib(uint32_t xaddr, i32x4 (&A)[4]) {
 #pragma unroll
-  for (int s = 0; s < 4; ++s) A[s] = lds_read16i(xaddr + 16 * (s & 1) + 128 * (s >> 1));
+  for (int s = 0; s < 4; ++s) A[s] = lds_read16i(xaddr + 16 * (s & 1) + HB * (s >> 1));
 }
 // digit sums of the slice (every column of the result holds them: rows 0..2 the "hi" planes, rows 4..6 the "lo" ones)
 __device__ __forceinline__ void item_digit_sums_nib(const i32x4 (&A)[4], i32x4& sx) {
@@ -511,6 +524,53 @@ __device__ __forceinline__ void lds_add3_low32(uint32_t dst, const int (&v)[3]) 
   asm volatile("s_mov_b32 exec_hi, 0\n\tds_add_u32 %0, %1\n\tds_add_u32 %0, %2 offset:4\n\tds_add_u32 %0, %3 offset:8\n\ts_mov_b32 exec_hi, -1"
                : : "v"(dst), "v"(v[0]), "v"(v[1]), "v"(v[2]) : "memory");
 }
+// ---- the nibble mode behind the byte tables' item interface (decode_block.hip: items that return ONE i32x4) ------------------------
+// fragments of a K slice + their digit sums; an item's result = what this lane adds to its accumulator row (item_rows_nib)
+struct NibFrags { i32x4 A[4]; i32x4 sx; };
+template <int HB = 128>
+__device__ __forceinline__ void nib_fragments(uint32_t xaddr, NibFrags& F) {
+  item_fragments_nib<HB>(xaddr, F.A);
+  F.sx = i32x4{0, 0, 0, 0};
+  item_digit_sums_nib(F.A, F.sx);
+}
+__device__ __forceinline__ i32x4 nib_rows(const i32x4& raw, const i32x4& msk, const i32x4& sx, const NibLane& f) {
+  int v[3];
+  item_rows_nib(raw, msk, sx, f, v);
+  return i32x4{v[0], v[1], v[2], 0};
+}
+__device__ __forceinline__ i32x4 nib_item(const ItemAddr& ad, const NibFrags& F, const NibLane& f) {
+  i32x4 raw = {0, 0, 0, 0}, msk = {0, 0, 0, 0};
+  item_mfma_nib(ad, F.A, raw, msk);
+  return nib_rows(raw, msk, F.sx, f);
+}
+// an item's 32 look-ups now, its MFMAs later (the persistent launches decode inside hand-off waits): 16 dwords, dword 4 s + c =
+// code c of MFMA step s
+__device__ __forceinline__ void nib_decode(const ItemAddr& ad, uint32_t (&raw)[16]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    raw[4 * s + 0] = lds_read4(ad.a1l[2 * s]) ^ lds_read4(ad.a2l[2 * s]);
+    raw[4 * s + 1] = lds_read4(ad.a1h[2 * s]) ^ lds_read4(ad.a2h[2 * s]);
+    raw[4 * s + 2] = lds_read4(ad.a1l[2 * s + 1]) ^ lds_read4(ad.a2l[2 * s + 1]);
+    raw[4 * s + 3] = lds_read4(ad.a1h[2 * s + 1]) ^ lds_read4(ad.a2h[2 * s + 1]);
+  }
+}
+__device__ __forceinline__ i32x4 nib_multiply(const uint32_t* raw, const NibFrags& F, const NibLane& f) {
+  i32x4 r = {0, 0, 0, 0}, m = {0, 0, 0, 0};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const i32x4 Br = {(int)raw[4 * s], (int)raw[4 * s + 1], (int)raw[4 * s + 2], (int)raw[4 * s + 3]};
+    const i32x4 Bm = {Br.x & 0x0f0f0f0f, Br.y & 0x0f0f0f0f, Br.z & 0x0f0f0f0f, Br.w & 0x0f0f0f0f};
+    r = __builtin_amdgcn_mfma_i32_16x16x64_i8(F.A[s], Br, r, 0, 0, 0);
+    m = __builtin_amdgcn_mfma_i32_16x16x64_i8(F.A[s], Bm, m, 0, 0, 0);
+  }
+  return nib_rows(r, m, F.sx, f);
+}
+// this lane's A-fragment row of half planes (plane stride ps, "hi" half at + ho): A rows 0..2 = the planes' "hi" halves, rows
+// 4..6 their "lo" halves, the other rows a copy of a neighbour (their results are never read)
+__device__ __forceinline__ uint32_t nib_row_offset(int n, int ps, int ho) {
+  return (uint32_t)(n < 4 ? min(n, 2) * ps + ho : min(n - 4, 2) * ps);
+}
+
 // byte offset of digit k of a plane inside its half plane, and which half (0: positions 0..3, 1: positions 4..7)
 __device__ __forceinline__ constexpr int nib_half_of(int k) { return (k >> 2) & 1; }
 __device__ __forceinline__ constexpr int nib_byte_of(int k) { return ((k >> 3) << 2) | (k & 3); }
