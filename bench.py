@@ -221,14 +221,18 @@ def gqa_phase_rates(dec):
     return out
 
 
-def gqa_stream_rate(dec, launches=8):
+def gqa_stream_rate(dec, launches=12, warm=12):
     """HBM-landed rate of the E8P12 decode GEMV at the 70B layer shapes INSIDE the persistent launch, measured:
     the launch in its measurement mode (decode_block_gqa.hip, dbg_layer = -2) runs the products of all blocks -- the same 54
     items per wave and block through the same ring, decode and MFMAs: q k v o gate up down of every block -- and leaves out the
     edges, the attention and the hand-offs, so the weight stream never waits for an input.  Every byte multiplied in the timed
     region was requested AND landed in it (no pre-filled ring: the first nine items of a wave against 54 x layers): GBps = all
     code bytes of the model / HIP-event time of the launch.  The rocprofv3 FETCH_SIZE of the same launch is in profiles/
-    (tools/prof_gqa_stream.sh).  The products' results are not used (the digit planes are whatever the LDS holds)."""
+    (tools/prof_gqa_stream.sh).  The products' results are not used (round 6: the launch fills its digit planes with pseudo-random
+    digits in this mode, so that the matrix cores switch as in a real launch -- the rate is a power figure too: the launch runs
+    at the clock its power allows).  `warm` untimed launches first (~40 ms): the clock of an idle device ramps over the first
+    launches of a run (profiles/r06_gqa_stream.txt: 1.55 -> 1.95 GHz over eight), and the figure asked for is the sustained
+    one; every timed launch is listed."""
     import math
     s = dec.s
     L = len(dec.layers)
@@ -237,13 +241,13 @@ def gqa_stream_rate(dec, launches=8):
     args = (dec.eng_layers, h, pos, dec.cos, dec.sin, dec.eng_grid, dec.eng_ws, L, dec.max_len, s.rms_eps,
             1.0 / math.sqrt(s.head_dim), None, -2, 0, 0.0, 1)
     ts = []
-    for it in range(launches + 2):
+    for it in range(launches + warm):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         torch.ops.quip_lib.block_engine(*args)
         b.record()
         torch.cuda.synchronize()
-        if it >= 2:
+        if it >= warm:
             ts.append(a.elapsed_time(b) * 1e3)
     us = float(np.median(ts))
     code_bytes = sum(L_[k].Qidxs.numel() * L_[k].Qidxs.element_size() for L_ in dec.layers for k in ("q", "k", "v", "o", "gate", "up", "down"))
@@ -252,7 +256,8 @@ def gqa_stream_rate(dec, launches=8):
     return {"mode": "products of all %d blocks in one launch, no edges / hand-offs (decode_block_gqa.hip, dbg_layer = -2)" % L,
             "code_bytes": code_bytes, "us_per_launch": round(us, 1), "us_per_block": round(us / L, 2),
             "GBps": round(code_bytes / us / 1e3, 1), "frac_of_8TBps": round(code_bytes / us / 1e3 / HBM_PEAK_GBPS, 4),
-            "launch_us_min_max": [round(min(ts), 1), round(max(ts), 1)], "engine_status": st}
+            "launch_us_min_max": [round(min(ts), 1), round(max(ts), 1)], "launches_us": [round(t, 1) for t in ts],
+            "warm_launches": warm, "engine_status": st}
 
 
 def gemv_per_shape(shapes, dev, pool_bytes=640 << 20, iters=100):
@@ -444,7 +449,7 @@ def decode_parity_check(dec, n_tokens=8):
             outs = []
             for t in range(n_tokens):
                 dec.tok.fill_(forced[t])
-                if use_graph:
+                if use_graph and dec.graph is not None:
                     dec.graph.replay()
                     lg = dec.step_logits
                 else:
@@ -618,8 +623,46 @@ def hf_static_cache_extra(D, device, new_tokens=128, cache_len=2048):
         out["hf_%s_runs" % mode] = [round(x, 2) for x in ts]
         del dec
     out["hf_graph_equals_eager"] = bool(torch.equal(toks["eager"], toks["graph"]))
+
+    def forced_compare(step_a, sync_a, ref, steps=16):
+        """teacher forced on the eager stock path's tokens: `ref` (an HFStaticDecoder on the stock forward,
+        prefilled) and path `step_a(token) -> logits (1, vocab)` see the same token at every step; max |difference| in fp16
+        ulps of rms(logits of the stock path), and how many arg-maxima agree"""
+        worst, same = 0.0, 0
+        with torch.no_grad():
+            for _ in range(steps):
+                lb = ref._forward(ref.tok, ref.pos)[:, -1].float()
+                la = step_a(ref.tok).float().reshape(1, -1)
+                worst = max(worst, _ulps_of_rms((la - lb).abs().max().item(), lb.pow(2).mean().sqrt().item()))
+                nxt = lb.argmax(-1, keepdim=True)
+                same += int(la.argmax(-1).item() == nxt.item())
+                ref.tok.copy_(nxt)
+                ref.pos += 1
+                sync_a(nxt)
+        return {"steps": steps, "max_ulps_of_rms_logits": round(worst, 2), "argmax_equal": same}
     if "compile" in toks:
         out["hf_compile_equals_eager"] = bool(torch.equal(toks["eager"], toks["compile"]))
+        # the free-running sequences of a random-init model part ways at the first near tie (profiles/r05_near_tie_rate.txt); what the
+        # compiled stock step computes, against the eager stock step on the SAME tokens:
+        try:
+            e_, c_ = HFStaticDecoder(model, max_cache_len=cache_len), HFStaticDecoder(model, max_cache_len=cache_len)
+            e_.prefill(ids)
+            c_.prefill(ids)
+            clog = torch.compile(lambda t, p: c_._forward(t, p)[:, -1], mode="reduce-overhead", fullgraph=True)
+
+            def c_step(tok):
+                torch.compiler.cudagraph_mark_step_begin()
+                return clog(tok.clone(), c_.pos.clone()).clone()
+
+            def c_sync(nxt):
+                c_.pos += 1
+            with torch.no_grad():
+                for _ in range(2):                       # (compilation + the cudagraph trees' warm-up on a scratch position)
+                    c_step(c_.tok)
+            out["hf_compile_teacher_forced_vs_eager"] = forced_compare(c_step, c_sync, e_)
+            del e_, c_, clog
+        except Exception as e:
+            out["hf_compile_teacher_forced_vs_eager"] = {"error": repr(e)[:300]}
     # the SAME harness on the SAME model object with hf_fast.enable_fast_decode (what load_quantized_model switches on):
     # single-token calls on the StaticCache run LlamaDecoder.step() on the cache's own tensors
     try:
@@ -708,6 +751,20 @@ def hf_static_cache_extra(D, device, new_tokens=128, cache_len=2048):
     out["llamadecoder_step"] = "persistent block launch" if getattr(fast, "block_eng", False) else "stage-wise"
     n_same = int((ft[:new_tokens].cpu() == toks["graph"].cpu()).sum())
     out["llamadecoder_free_running_tokens_equal_to_hf"] = "%d / %d" % (n_same, new_tokens)
+    # ... and teacher forced: LlamaDecoder.from_hf's step against the eager stock forward on the same tokens
+    try:
+        e_ = HFStaticDecoder(model, max_cache_len=cache_len)
+        e_.prefill(ids)
+        fast.reset(first_token=int(ids[0, 0]))
+        fast.prefill(ids[0])
+
+        def f_step(tok):
+            fast.tok.copy_(tok.view_as(fast.tok))
+            return fast.step()
+        out["llamadecoder_teacher_forced_vs_hf_eager"] = forced_compare(f_step, lambda nxt: None, e_)
+        del e_
+    except Exception as e:
+        out["llamadecoder_teacher_forced_vs_hf_eager"] = {"error": repr(e)[:300]}
     return out
 
 
@@ -869,7 +926,10 @@ def main():
         }
         if a.codebook == "E8P12":
             out["roofline"] = engine_roofline(dec) if getattr(dec, "block_eng", False) else gemv_roofline(dec)
-        out["parity"] = decode_parity_check(dec)
+        try:
+            out["parity"] = decode_parity_check(dec)
+        except Exception as e:      # (a transient failure of the check -- e.g. the launch giving a hand-off up on a shared
+            out["parity"] = {"ok": False, "error": repr(e)[:400]}          # device -- is reported as a failed check, not as a traceback)
         if not out["parity"]["ok"]:      # a fast step whose logits differ from the unfused step's is not a result: no line
             raise RuntimeError("parity check failed: %r" % (out["parity"],))
         if a.model == "7b" and a.codebook == "E8P12" and world == 1 and not a.no_prefill:

@@ -44,7 +44,11 @@ enum {
   QUIP_ERR_BAD_SHAPE = -2,   /* dimension not supported by the packed format   */
   QUIP_ERR_MISALIGNED = -3,  /* pointer not aligned for vector access (16 B)    */
   QUIP_ERR_LAUNCH = -4,      /* HIP launch error; see hipGetLastError           */
-  QUIP_ERR_UNSUPPORTED = -5  /* valid request this build cannot serve           */
+  QUIP_ERR_UNSUPPORTED = -5, /* valid request this build cannot serve           */
+  /* positive: the launch ran, but NOT as the operator the entry point stands for.  quip_block_engine with shape 1 and
+   * dbg_layer == -2 (measurement mode: the products of every block without edges, attention and hand-offs) answers this instead
+   * of QUIP_OK, so that a caller who checks `!= 0` never takes the contents of h_out for a hidden state. */
+  QUIP_NO_RESULT = 1
 };
 
 int quip_abi_version(void);
@@ -503,7 +507,8 @@ typedef struct quip_block_engine_args {
   void* workspace;
   void* dbg;                 /* NULL, or 32 uint64 clock stamps per workgroup of block dbg_layer */
                              /* (shape 1, dbg_layer == -2: MEASUREMENT MODE -- the products of every block without the edges,
-                                the attention and the hand-offs; h_out holds no result.  bench.py: gemv_stream_in_launch) */
+                                the attention and the hand-offs; h_out holds no result and the call returns QUIP_NO_RESULT, not
+                                QUIP_OK.  bench.py: gemv_stream_in_launch) */
   int32_t n_layers, max_len, dbg_layer;
   float rms_eps, attn_scale;
   int32_t codebook;          /* 0: E8P12; 1: D4 (uint8 codes, grid_packed_abs = the fp16 (256, 4) table, d4.py:26-96);

@@ -82,6 +82,7 @@ const char* quip_strerror(int code) {
     case QUIP_ERR_MISALIGNED: return "pointer not 16-byte aligned";
     case QUIP_ERR_LAUNCH: return "HIP kernel launch failed";
     case QUIP_ERR_UNSUPPORTED: return "request not supported by this build";
+    case QUIP_NO_RESULT: return "measurement launch: the outputs hold no result";
     default: return "unknown quip error";
   }
 }
@@ -549,7 +550,12 @@ int quip_tile_codes(const void* qidxs, void* tiled, int64_t rows, int64_t row_by
   if (rows < 0 || row_bytes <= 0 || rows % 16 != 0 || row_bytes % 64 != 0 || row_bytes > (1 << 24)) return QUIP_ERR_BAD_SHAPE;
   if (rows == 0) return QUIP_OK;
   if (!aligned16(qidxs) || !aligned16(tiled)) return QUIP_ERR_MISALIGNED;
-  if (qidxs == tiled) return QUIP_ERR_UNSUPPORTED;      // (not in place)
+  {
+    // not in place, and no partial overlap either: the kernel gathers from the source while it scatters
+    const uintptr_t s0 = reinterpret_cast<uintptr_t>(qidxs), d0 = reinterpret_cast<uintptr_t>(tiled);
+    const uintptr_t bytes = (uintptr_t)rows * (uintptr_t)row_bytes;
+    if (s0 < d0 + bytes && d0 < s0 + bytes) return QUIP_ERR_UNSUPPORTED;
+  }
   const long long pieces = rows * (row_bytes / 16);
   hipLaunchKernelGGL(tile_codes_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const uint4*>(qidxs), reinterpret_cast<uint4*>(tiled), pieces, (int)(row_bytes / 16));

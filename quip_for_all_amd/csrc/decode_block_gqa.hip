@@ -1507,7 +1507,8 @@ int block_engine_gqa_launch(const BlockEngineArgs& in, hipStream_t stream) {
   if (!persistent_grid_fits(resident, reinterpret_cast<const void*>(decode_block_gqa_kernel), kThreads, GLds::kBytes, NWG))
     return QUIP_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(decode_block_gqa_kernel, dim3(NWG), dim3(kThreads), GLds::kBytes, stream, a);
-  return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+  if (hipGetLastError() != hipSuccess) return QUIP_ERR_LAUNCH;
+  return in.dbg_layer == -2 ? QUIP_NO_RESULT : QUIP_OK;      // (measurement mode: h_out holds no hidden state)
 }
 
 }  // namespace quip

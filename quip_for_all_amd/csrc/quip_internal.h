@@ -258,3 +258,6 @@ extern "C" size_t quip_e8p_gemv_v2_workspace_bytes(int32_t n);
 // kernel 2 in quip_e8p_gemv_tuned = streaming-read probe (y is a 4-byte scratch)
 // lane-ordered digit planes for the VALU integer GEMV (kernel 0); planes: 3*k + 16 bytes
 extern "C" int quip_e8p_x_to_planes_laneorder(const void* x, void* planes, int32_t k, quip_stream_t stream);
+// test hook (decode_probe.hip): every E8P12 code through the shared decode core of table mode `mode` (4 nibble | 16 | 24 | 32 byte
+// tables), read back through the matrix core; codes: 64 tiles x 2 KB in item lane order, out: int8 [65536][8] = 4 w
+extern "C" int quip_e8p_decode_probe(const void* grid, const void* codes, void* out, int32_t mode, quip_stream_t stream);

@@ -340,6 +340,10 @@ class LlamaDecoder:
         if not ok:
             return
         keep, rec = [], np.zeros((len(self.layers), 32), dtype=np.uint64)
+        # (a rebuild -- reset() after the modules were edited: the previous descriptors' tensors, for shape 1 a whole tiled copy of
+        #  the codes, go BEFORE the new ones are made, not after: no third copy of the weights in between.  ADVICE r5)
+        self._eng_keep = None
+        self.eng_layers = None
         for i, L in enumerate(self.layers):
             mods = [L[k] for k in names]
             vec = lambda t: t.detach().to(torch.float16).contiguous()     # noqa: E731

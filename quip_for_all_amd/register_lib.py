@@ -768,7 +768,10 @@ def _block_engine_cuda(layers, h_in, pos, cos, sin, grid, workspace, n_layers, m
                              _ptr(grid2) if codebook == 4 else None)
     import ctypes
     with torch.cuda.device(dev):
-        capi.check(capi.lib().quip_block_engine(ctypes.byref(a), _stream(h_in)), "quip_block_engine")
+        rc = capi.lib().quip_block_engine(ctypes.byref(a), _stream(h_in))
+        # (shape 1, dbg_layer == -2: the measurement mode answers QUIP_NO_RESULT = 1 -- the caller asked for exactly that)
+        if not (rc == 1 and shape == 1 and int(dbg_layer) == -2):
+            capi.check(rc, "quip_block_engine")
     return out
 
 

@@ -82,6 +82,8 @@ def test_argument_validation_without_gpu(libpath):
     assert L.quip_tile_codes(p16, p16 + 1024, 16, 96, None) == -2                        # row_bytes % 64
     assert L.quip_tile_codes(p16, p16 + 1026, 16, 64, None) == -3                        # misaligned destination
     assert L.quip_tile_codes(p16, p16, 16, 64, None) == -5                               # in place
+    assert L.quip_tile_codes(p16, p16 + 512, 16, 64, None) == -5                         # partial overlap (16 x 64 = 1024 bytes each)
+    assert L.quip_tile_codes(p16 + 512, p16, 16, 64, None) == -5
     assert L.quip_tile_codes(p16, p16 + 1024, 0, 64, None) == 0                          # empty: ok, no launch
 
 

@@ -240,7 +240,8 @@ def test_g8_block_engine_long_context_split_attention(pos0):
 @pytest.mark.parametrize("g8", [False, True])
 def test_norm_bound_planes_take_spiky_activations(g8):
     """the launches round their digit planes against NORM bounds (|H x|_inf <= sqrt(n) |x|_2; |M r|_inf <= |row|_2 |r|_2) instead
-    of the exact maximum: tight for a one-hot vector, 4-5 bits loose for a flat one.  A one-hot embedding row and RMSNorm
+    of the exact maximum: tight for a flat vector (|H x|_inf = sqrt(n) |x|_2 when every element agrees in sign with a row of H), log2
+    sqrt(n) = 6 bits loose for a one-hot one, typically 4.  A one-hot embedding row and RMSNorm
     weights with a few channels 50 times the rest (the outlier channels of real checkpoints) put both ends through every edge:
     an exponent that let a digit overflow its 22 bits would show as garbage, too loose a one as lost precision -- logits stay
     within the usual bound of the stage-wise step (which takes exact maxima)."""

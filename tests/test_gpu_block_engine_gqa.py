@@ -153,6 +153,57 @@ def test_four_full_size_70b_blocks_against_float64_model():
     assert u <= deep_bound_ulps(4), u
 
 
+def test_twelve_full_size_70b_blocks_against_float64_model():
+    """the quadrature growth behind deep_bound_ulps was measured on 4 of the 80 blocks only.  TWELVE Llama-2-70B-
+    shaped blocks (two decode steps: the second one's attention reads a cached row) on the persistent launch against the layer-
+    major float64 model: 4 sqrt(12) + 2 = 15.9 fp16 ulps of rms(logits)."""
+    from tests.test_gpu_decode import _ref_logits_deep, _ulps_of_rms, deep_bound_ulps
+    np.random.seed(23)
+    dec = _decoder(12, True, max_len=16, seed=9, vocab=1024)
+    assert dec.block_eng and dec.eng_shape == 1
+    toks = dec.generate(2, first_token=9, use_graph=True).cpu().numpy()
+    got = dec.step_logits.float().cpu().numpy()[0].astype(np.float64)
+    assert dec.engine_status() == 0
+    ref = _ref_logits_deep(dec, [9, int(toks[0])])
+    u = _ulps_of_rms(got, ref)
+    print(f"12 x 70B-shaped blocks (E8P12), logits of step 2 vs float64: max {u:.2f} fp16 ulps of rms(logits) = "
+          f"{np.sqrt(np.mean(ref * ref)):.3f} (bound {deep_bound_ulps(12):.1f})")
+    assert u <= deep_bound_ulps(12), u
+
+
+def test_norm_bound_planes_of_the_8192_wide_launch_take_spiky_activations():
+    """the 8192-wide launch rounds its digit planes against norm bounds too (|H x|_inf <= sqrt(8192) |x|_2: up
+    to log2 sqrt(8192) = 6.5 of the 22 bits idle on a one-hot vector, none on a flat one).  A one-hot embedding row, a tiny row and
+    RMSNorm weights with a few channels 50 times the rest put both ends through every edge of the launch: logits finite and within
+    the usual bound of the stage-wise step (which takes exact maxima)."""
+    a = _decoder(2, True)
+    b = _decoder(2, False)
+    _same_weights(a, b)
+    with torch.no_grad():
+        for dec in (a, b):
+            dec.embed[7].zero_()
+            dec.embed[7, 123] = 8.0
+            dec.embed[9].mul_(0.02)
+            for L in dec.layers:
+                for k in ("ln1", "ln2"):
+                    L[k][torch.tensor([5, 777, 3000, 8000], device=DEV)] *= 50.0
+    for dec in (a, b):
+        dec.reset(first_token=7)                          # (rebuilds the launch's descriptors: ln was edited)
+    assert a.block_eng and a.eng_shape == 1 and not b.block_eng
+    worst = 0.0
+    with torch.no_grad():
+        for tok in [7, 9, 7, 11]:
+            a.tok.fill_(tok)
+            b.tok.fill_(tok)
+            la = a.step().float().clone()
+            lb = b.step().float().clone()
+            assert a.engine_status() == 0
+            assert torch.isfinite(la).all()
+            worst = max(worst, _ulps(la, lb))
+    print(f"spiky activations (8192-wide launch): logits within {worst:.2f} fp16 ulps of rms(logits) of the stage-wise step")
+    assert worst <= 2.0 * (4.0 * np.sqrt(2) + 2.0), worst
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("rows,row_bytes", [(16, 64), (48, 2048), (256, 7168), (32, 192)])
 def test_tile_codes_is_the_stated_permutation(rows, row_bytes):

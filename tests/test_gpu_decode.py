@@ -187,6 +187,26 @@ def test_eight_full_size_blocks_against_float64_model():
     assert u <= deep_bound_ulps(8), u
 
 
+def test_all_thirty_two_blocks_of_the_7b_launch_against_float64_model():
+    """the depth the bench runs at.  The FULL Llama-2-7B-shaped stack (32 blocks, E8P12, random init) for two
+    decode steps through the captured persistent launch against the layer-major float64 model (one block's 1.6 GB of float64
+    weights at a time): deep_bound_ulps(32) = 4 sqrt(32) + 2 = 24.6 fp16 ulps of rms(logits) -- the quadrature-growth assumption
+    measured where it is used (bench.py's step-vs-step parity bound is twice this)."""
+    from quip_for_all_amd import decode as D
+    shape = D.LlamaShape(hidden=4096, ffn=11008, layers=32, heads=32, kv_heads=32, vocab=1024)
+    np.random.seed(29)
+    dec = D.LlamaDecoder(shape, "E8P12", max_len=16, device="cuda:0", seed=10, device_init=True)
+    assert dec.block_eng
+    toks = dec.generate(2, first_token=9, use_graph=True).cpu().numpy()
+    got = dec.step_logits.float().cpu().numpy()[0].astype(np.float64)
+    assert dec.engine_status() == 0
+    ref = _ref_logits_deep(dec, [9, int(toks[0])])
+    u = _ulps_of_rms(got, ref)
+    print(f"32 x 7B-shaped blocks (E8P12), logits of step 2 vs float64: max {u:.2f} fp16 ulps of rms(logits) = "
+          f"{np.sqrt(np.mean(ref * ref)):.3f} (bound {deep_bound_ulps(32):.1f})")
+    assert u <= deep_bound_ulps(32), u
+
+
 @pytest.mark.parametrize("codebook", ["E8P12", "E8P12RVQ4B", "D4"])
 def test_tiny_llama_decode(codebook):
     from quip_for_all_amd import decode as D

@@ -13,6 +13,8 @@ so the comparison with the oracle's decoded matrix is BIT FOR BIT (fp16 patterns
 
 The two RVQ codebooks round main + s * resid once to fp16 per weight in the reference (origin_order.cu:330-385); the integer
 paths sum it exactly and round the OUTPUT once, which for a unit vector is the same single rounding."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -114,6 +116,35 @@ def test_every_code_through_every_decode_path(cbid, scale):
     # the codes covered everything there is to cover
     if cbid == "E8P12":
         assert len(np.unique(q.view(np.uint16))) == 65536
+
+
+@pytest.mark.parametrize("mode", [4, 16, 24, 32])
+def test_decode_core_of_every_table_mode_decodes_every_code(mode):
+    """the persistent launches take their LDS tables, look-up addresses and B fragments from the shared decode
+    core (csrc/e8p_gemv_core.hip.h) and are compared with the stage-wise step / the float64 model only to a few fp16 ulps -- one
+    mis-decoded code in 65 536 would not show there.  quip_e8p_decode_probe (csrc/decode_probe.hip) runs that core -- table
+    build, item_addresses<mode>, the fragments fed to v_mfma_i32_16x16x64_i8 -- on every code once and reads the fragments back
+    THROUGH the matrix core (one-hot A rows): bit for bit the oracle's 4 w, in the nibble mode of round 6 (4: what the three
+    launches ship) and the byte-table modes of rounds 1-5 (16 / 16, 32 / 16, 32 / 32 copies)."""
+    from quip_for_all_amd import capi
+    L = capi.lib()
+    ids = np.arange(1 << 16, dtype=np.uint32)
+    code_of = ((ids * 40503 + 12345) & 0xFFFF).astype(np.uint16)          # (a bijection: odd multiplier)
+    assert len(np.unique(code_of)) == 65536
+    # tile t, row n, code j of the row (id = (16 t + n) 64 + j) -> lane order: [t][c][q][n][i], j = 32 c + 8 q + i
+    tiles = code_of.reshape(64, 16, 2, 4, 8).transpose(0, 2, 3, 1, 4).copy()
+    codes = torch.from_numpy(tiles.view(np.int16).reshape(-1)).to(DEV)
+    grid = torch.from_numpy(O.e8p_grid_packed_abs()).to(DEV)
+    out = torch.full((1 << 16, 8), 99, dtype=torch.int8, device=DEV)
+    L.quip_e8p_decode_probe.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int32, ctypes.c_void_p]
+    L.quip_e8p_decode_probe.restype = ctypes.c_int
+    rc = L.quip_e8p_decode_probe(grid.data_ptr(), codes.data_ptr(), out.data_ptr(), mode, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    want = O.e8p_decode_i8(code_of)
+    got = out.cpu().numpy()
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert len(bad) == 0, (mode, len(bad), [(hex(int(code_of[i])), got[i].tolist(), want[i].tolist()) for i in bad[:4]])
 
 
 def test_block_engine_products_on_a_model_that_holds_every_code():
