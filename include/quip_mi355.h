@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QUIP_ABI_VERSION 7
+#define QUIP_ABI_VERSION 8
 
 typedef void* quip_stream_t; /* hipStream_t */
 
@@ -550,6 +550,11 @@ size_t quip_block_engine_gqa_workspace_bytes(void);
  * lines at 0.85-0.88 (tools/ubench/hbm_read.hip).  quip_tile_codes writes that copy (same size; not in place; rows % 16 == 0,
  * row_bytes % 64 == 0, both pointers 16-byte aligned): once per matrix at model load.  Shapes 0 and 2 read the checkpoint's layout. */
 int quip_tile_codes(const void* qidxs, void* tiled, int64_t rows, int64_t row_bytes, quip_stream_t stream);
+/* the inverse (round 6): the checkpoint's row-major matrix back from its tiled copy (same constraints).  A decode-only server keeps
+ * ONE copy of the codes of a shape-1 model -- the tiled one -- and materialises a matrix in the layout the other operators read
+ * (decompress_*_origorder, *_mm_origorder: register_lib.py:8-192 of the reference) into a scratch buffer only where a prompt pass
+ * or the stage-wise fallback needs it (decode.py: LlamaDecoder(single_copy=True)). */
+int quip_untile_codes(const void* tiled, void* qidxs, int64_t rows, int64_t row_bytes, quip_stream_t stream);
 /* shape 2 (round 5): hidden 4096, 32 heads of 128 on 8 KV heads, n_ffn = 14336 = 7 x 2048 (Llama-3-8B, Mistral-7B; E8P12 only): the
  * shape-0 launch compiled for this shape.  Descriptors as for shape 0, except had3 = the 56 x 56 factors R_7 (x) H_8 of gate.had_right,
  * up.had_right (row major, 3136 fp16 each) and of down.had_left TRANSPOSED (64 rows of 72 fp16, zero padded): see decode_block.hip, QUIP_BLOCK_G8. */

@@ -60,6 +60,7 @@ SIGNATURES = {
     "quip_ffn_engine_workspace_bytes": [_I32, _I32],
     "quip_ffn_engine": [_P, _P],
     "quip_tile_codes": [_P, _P, _I64, _I64, _P],
+    "quip_untile_codes": [_P, _P, _I64, _I64, _P],
     "quip_e8p_mm_origorder": [_P, _P, _P, _P, _I32, _I32, _I32, _P],
     "quip_e8p_mm_batched": [_P, _P, _P, _P, _I64, _I32, _I32, _P],
     "quip_e8prvq4_mm_batched": [_P, _P, _P, _F, _P, _I64, _I32, _I32, _P],

@@ -543,6 +543,17 @@ __global__ void tile_codes_kernel(const uint4* __restrict__ src, uint4* __restri
   const int c = (int)(cc - rb * pieces_per_row);
   dst[i] = src[(rb * 16 + n) * row_u4 + c * 4 + q];
 }
+// the inverse: piece i of the tiled copy back to its place in the row-major matrix
+__global__ void untile_codes_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long long pieces, int row_u4) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pieces) return;
+  const int n = (int)(i & 15), q = (int)((i >> 4) & 3);
+  const long long cc = i >> 6;
+  const int pieces_per_row = row_u4 / 4;
+  const long long rb = cc / pieces_per_row;
+  const int c = (int)(cc - rb * pieces_per_row);
+  dst[(rb * 16 + n) * row_u4 + c * 4 + q] = src[i];
+}
 }  // namespace
 
 int quip_tile_codes(const void* qidxs, void* tiled, int64_t rows, int64_t row_bytes, quip_stream_t stream) {
@@ -559,6 +570,22 @@ int quip_tile_codes(const void* qidxs, void* tiled, int64_t rows, int64_t row_by
   const long long pieces = rows * (row_bytes / 16);
   hipLaunchKernelGGL(tile_codes_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const uint4*>(qidxs), reinterpret_cast<uint4*>(tiled), pieces, (int)(row_bytes / 16));
+  return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
+}
+
+int quip_untile_codes(const void* tiled, void* qidxs, int64_t rows, int64_t row_bytes, quip_stream_t stream) {
+  if (!qidxs || !tiled) return QUIP_ERR_NULL_POINTER;
+  if (rows < 0 || row_bytes <= 0 || rows % 16 != 0 || row_bytes % 64 != 0 || row_bytes > (1 << 24)) return QUIP_ERR_BAD_SHAPE;
+  if (rows == 0) return QUIP_OK;
+  if (!aligned16(qidxs) || !aligned16(tiled)) return QUIP_ERR_MISALIGNED;
+  {
+    const uintptr_t s0 = reinterpret_cast<uintptr_t>(tiled), d0 = reinterpret_cast<uintptr_t>(qidxs);
+    const uintptr_t bytes = (uintptr_t)rows * (uintptr_t)row_bytes;
+    if (s0 < d0 + bytes && d0 < s0 + bytes) return QUIP_ERR_UNSUPPORTED;
+  }
+  const long long pieces = rows * (row_bytes / 16);
+  hipLaunchKernelGGL(untile_codes_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const uint4*>(tiled), reinterpret_cast<uint4*>(qidxs), pieces, (int)(row_bytes / 16));
   return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
 }
 

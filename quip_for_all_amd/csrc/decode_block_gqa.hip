@@ -52,6 +52,23 @@
 #ifndef QUIP_GQA_PIPE
 #define QUIP_GQA_PIPE 0
 #endif
+// nibble mode: items whose table look-ups run INSIDE a wait (their codes landed long ago; a decoded item waits as 16 scalar
+// registers) and are multiplied from registers once the digit planes exist: the first ... items of gate / up (wait for z_o), of down
+// (wait for the chunk owners; the owners: for their inbox) and of the next block's q / k | v (wait for z_d), as decode_block.hip
+// does.  Measured (profiles/r06_gqa_predecode.txt, same box, tools/dbg/tok70b.py): 2 / 1 / 1 181.2-181.6, 2 / 2 / 2 180.4-180.7,
+// 3 / 2 / 2 179.7-179.9, none 180.5-180.6 tok/s -- the short hand-offs (z_o, z_d: ~3.5K clocks = the all-gather's own latency)
+// are not idle time for the workgroups that close them: look-ups in front of their poll make the poll late by what they cost
+// (top -> z_d gathered 4.2K -> 5.7K clocks with two items).  Only the LONG wait -- 17K clocks for the chunk owners -- takes them
+// for free: down's first two items (products down 15.2K -> 14.6K clocks).
+#ifndef QUIP_GQA_PRE_GU
+#define QUIP_GQA_PRE_GU 0
+#endif
+#ifndef QUIP_GQA_PRE_D
+#define QUIP_GQA_PRE_D 2
+#endif
+#ifndef QUIP_GQA_PRE_Q
+#define QUIP_GQA_PRE_Q 0
+#endif
 #ifndef QUIP_GQA_ZROWS         /* tools/dbg A/B: 0 = the MFMA's unused A rows read digit plane 2 (as rounds 1-5) instead of zeros */
 #define QUIP_GQA_ZROWS 1
 #endif
@@ -457,6 +474,55 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     });
   };
 
+  // ---- items decoded ahead (nibble mode) ------------------------------------------------------------------------------
+  constexpr bool kPre = NIB && !PIPE && !QUIP_GQA_NODECODE;
+  constexpr int kPreGU = kPre ? QUIP_GQA_PRE_GU : 0, kPreD = kPre ? QUIP_GQA_PRE_D : 0, kPreQ = kPre ? QUIP_GQA_PRE_Q : 0;
+  static_assert(kPreGU <= 14 && kPreD <= 14 && kPreQ <= 2, "items decoded ahead: inside the first group of their product");
+  // item S of the sequence, first half: wait for its slot, codes -> addresses -> the 32 look-ups (16 dwords).  I: how many items
+  // in front of it were decoded ahead in the same wait.  The slot is NOT refilled here: a request in front of a hand-off's poll
+  // delays the poll's first check (first version: z_o gathered 3.6K -> 4.7K clocks, the whole gain); refill() goes out at the top of
+  // the product, behind the gather -- which drained the queue, so the ring's constant wait holds again from there.
+  auto predec = [&](auto s_c, auto i_c, uint32_t (&raw)[16]) __attribute__((always_inline)) {
+    constexpr int S = decltype(s_c)::value, slot = S % NS, I = decltype(i_c)::value;
+    u32x4& da = qa[slot];
+    u32x4& db = qb[slot];
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(da), "+v"(db) : "n"(2 * (NS - 1 - I)) : "memory");
+    ItemAddr ad;
+    item_addresses_nib(da, db, lane_c, ad);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) asm volatile("" : "+v"(ad.a1l[t]), "+v"(ad.a2l[t]), "+v"(ad.a1h[t]), "+v"(ad.a2h[t]));
+    uint32_t r[16];
+    nib_decode(ad, r);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { asm volatile("" : "+v"(r[t])); raw[t] = r[t]; }
+  };
+  auto refill = [&](auto s_c) __attribute__((always_inline)) { issue(IC<decltype(s_c)::value + NS>{}); };
+  // ... second half: its eight MFMAs
+  auto mul_raw = [&](const uint32_t (&raw)[16], const auto& A, Acc& acc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const i32x4 Br = {(int)raw[4 * s4], (int)raw[4 * s4 + 1], (int)raw[4 * s4 + 2], (int)raw[4 * s4 + 3]};
+      const i32x4 Bm = {Br.x & 0x0f0f0f0f, Br.y & 0x0f0f0f0f, Br.z & 0x0f0f0f0f, Br.w & 0x0f0f0f0f};
+      acc.r = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[s4], Br, acc.r, 0, 0, 0);
+      acc.m = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[s4], Bm, acc.m, 0, 0, 0);
+    }
+  };
+  // group() whose first NPRE items were decoded ahead
+  auto group_pre = [&](auto s0_c, auto cnt_c, auto last_c, auto npre_c, const auto& pre, uint32_t xa, int accrow0) __attribute__((always_inline)) {
+    constexpr int S0 = decltype(s0_c)::value, CNT = decltype(cnt_c)::value, NPRE = decltype(npre_c)::value;
+    constexpr bool LAST = decltype(last_c)::value;
+    i32x4 A[NA];
+    i32x4 sx = {0, 0, 0, 0};
+    fragments(xa, A, sx);
+    static_for<CNT>([&](auto c) {
+      constexpr int C = decltype(c)::value;
+      Acc acc = kAcc0;
+      if constexpr (C < NPRE) mul_raw(pre[C < NPRE ? C : 0], A, acc);
+      else item(IC<S0 + C>{}, std::integral_constant<bool, !(LAST && C == CNT - 1)>{}, A, acc, true, true);
+      add_rows(acc, sx, accrow0 + 16 * C);
+    });
+  };
+
   // ---- prologue -----------------------------------------------------------------------------------------------------
   GLayer* desc = reinterpret_cast<GLayer*>(smem + B::kDesc);
   u32x2 tsrc;
@@ -777,6 +843,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     }
     // ================= P1: output side of the previous block's down_proj + residual (block 0: h = the embedding row), RMSNorm,
     // input transforms of q and k | v; their products; hand-off ==============================================================
+    uint32_t Pq[kPreQ > 0 ? kPreQ : 1][16];            // (slot A's items: decoded inside the wait for z_d)
+    static_for<kPreQ>([&](auto ic) { predec(IC<SQ_A + decltype(ic)::value>{}, ic, Pq[decltype(ic)::value]); });
     if (!so) edge(IC<2>{}, l > 0 ? zd : nullptr, ebase | hop, 0x4000u, sv_prev, Ld.ln[0], Ld.su[0], Ld.su[1 + kvm], Ld.sc[0], Ld.sc[1 + kvm], has_kv, 0, 18);
     BSTAMP(2);
     rederive();
@@ -785,14 +853,15 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
       // slot A first: the k | v items (odd workgroups), so that z_k / z_v are on their way while q is multiplied
       const uint32_t pa = has_kv ? p1 : p0;
       i32x4 A[NA];
+      static_for<kPreQ>([&](auto ic) { refill(IC<SQ_A + decltype(ic)::value>{}); });
       first(IC<SQ_A>{}, true);
       {
         Acc acc = kAcc0;
         i32x4 sx = {0, 0, 0, 0};
         fragments(xaddr(pa, B::PSH, 0), A, sx);
-        item(IC<SQ_A>{}, TrueC{}, A, acc, true, true);
+        if constexpr (kPreQ > 0) mul_raw(Pq[0], A, acc); else item(IC<SQ_A>{}, TrueC{}, A, acc, true, true);
         fragments(xaddr(pa, B::PSH, 1), A, sx);
-        item(IC<SQ_A + 1>{}, FalseC{}, A, acc, true, true);
+        if constexpr (kPreQ > 1) mul_raw(Pq[kPreQ > 1 ? 1 : 0], A, acc); else item(IC<SQ_A + 1>{}, FalseC{}, A, acc, true, true);
         add_rows(acc, sx, B::AKV);
       }
       had::wg_barrier<true>();
@@ -1173,6 +1242,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
 
     // ================= o's output side + residual, RMSNorm, input transforms of gate / up; their products ===================
     rederive();
+    uint32_t Pg[kPreGU > 0 ? kPreGU : 1][16];          // (gate / up's first items: decoded inside the wait for z_o)
+    static_for<kPreGU>([&](auto ic) { predec(IC<SQ_GU + decltype(ic)::value>{}, ic, Pg[decltype(ic)::value]); });
     if (!so) edge(IC<2>{}, zo, ebase | hop, 0x7000u, Ld.sv[3], Ld.ln[1], Ld.su[4 + mgu], Ld.su[4 + mgu], Ld.sc[4 + mgu], Ld.sc[4 + mgu], false, 3, 23);
     BSTAMP(10);
     rederive();
@@ -1180,8 +1251,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
       // 14 items per K span: chunks k = 0..6 of the first 16 columns (accumulator rows AGU + 16 k + i), then of the second 16
       // (AGU + 112 + 16 k + i) -- one set of A fragments per span
       const uint32_t pg = (uint32_t)B::kArea;
+      static_for<kPreGU>([&](auto ic) { refill(IC<SQ_GU + decltype(ic)::value>{}); });
       first(IC<SQ_GU>{}, true);
-      group(IC<SQ_GU>{}, IC<14>{}, FalseC{}, xaddr(pg, B::PSH, 0), B::AGU);
+      group_pre(IC<SQ_GU>{}, IC<14>{}, FalseC{}, IC<kPreGU>{}, Pg, xaddr(pg, B::PSH, 0), B::AGU);
       group(IC<SQ_GU + 14>{}, IC<14>{}, TrueC{}, xaddr(pg, B::PSH, 1), B::AGU);
     }
     had::wg_barrier<true>();
@@ -1189,10 +1261,12 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
 
     // ================= the MLP edge =========================================================================================
     int sh_d = 0;
-    if (!so) {
+    uint32_t Pd[kPreD > 0 ? kPreD : 1][16];            // (down's first items: decoded inside the wait for the chunk owners / the owners' inbox)
     rederive();
     float* zcol = reinterpret_cast<float*>(smem + B::kZcol);
     const float* mixf = reinterpret_cast<const float*>(smem + B::kMix);
+    uint32_t tag1 = 0u, tag2 = 0u;
+    if (!so) {
     if (tid < 224) {
       const int* s3 = accs + (B::AGU + tid) * 4;
       const float f = __builtin_fmaf((float)s3[0], 65536.f, __builtin_fmaf((float)s3[1], 256.f, (float)s3[2]));
@@ -1201,7 +1275,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     had::wg_barrier<true>();
     zero_acc(B::AGU, 224);
     ++hop;                                             // hand-off: columns -> chunk owners
-    const uint32_t tag1 = ebase | hop;
+    tag1 = ebase | hop;
     if (tid < 224) {
       // output (this workgroup's matrix mgu, chunk k', column 32 (w & 127) + 16 cg + i): t = sum_k had[k'][k] z[k][column]
       const int cg = tid / 112, rem = tid - 112 * cg, kq = rem >> 4, i = rem & 15;
@@ -1215,8 +1289,12 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
         esync::st_granule2(inbox + ((size_t)(kq * 2 + mgu) * FL + 32 * (w & 127) + 16 * cg + i), as_u32(t), as_u32(tn), tag1);
     }
     ++hop;                                             // hand-off: rows -> everybody
-    const uint32_t tag2 = ebase | hop;
+    tag2 = ebase | hop;
     BSTAMP(12);
+    }
+    // (behind the publication of the columns: everybody waits from here on -- the owners for their inbox)
+    static_for<kPreD>([&](auto ic) { predec(IC<SQ_D + decltype(ic)::value>{}, ic, Pd[decltype(ic)::value]); });
+    if (!so) {
     if (w < FK) {
       // chunk owner w: 4096 values of gate and of up (fp32 payloads) -> transforms, SV, SiLU product, SU, down's transform
       const f16* svg = Ld.sv[4] + (size_t)w * FL;
@@ -1408,13 +1486,16 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
     {
       Acc acc0 = kAcc0, acc1 = kAcc0;
       i32x4 sx = {0, 0, 0, 0};
+      static_for<kPreD>([&](auto ic) { refill(IC<SQ_D + decltype(ic)::value>{}); });
       first(IC<SQ_D>{}, true);
       static_for<7>([&](auto ic) {
         constexpr int I = decltype(ic)::value;
         i32x4 A[NA];
         fragments(xaddr((uint32_t)B::kArea, B::PSD, I), A, sx);
-        item(IC<SQ_D + 2 * I>{}, TrueC{}, A, acc0, true, true);
-        item(IC<SQ_D + 2 * I + 1>{}, TrueC{}, A, acc1, true, I < 6);          // (behind the last one: the first filler)
+        if constexpr (2 * I < kPreD) mul_raw(Pd[2 * I < kPreD ? 2 * I : 0], A, acc0);
+        else item(IC<SQ_D + 2 * I>{}, TrueC{}, A, acc0, true, true);
+        if constexpr (2 * I + 1 < kPreD) mul_raw(Pd[2 * I + 1 < kPreD ? 2 * I + 1 : 0], A, acc1);
+        else item(IC<SQ_D + 2 * I + 1>{}, TrueC{}, A, acc1, true, I < 6);          // (behind the last one: the first filler)
       });
       add_rows(acc0, sx, B::AD);
       add_rows(acc1, sx, B::AD + 16);

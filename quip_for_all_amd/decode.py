@@ -95,11 +95,35 @@ def tile_codes(qidxs):
     return out
 
 
+def untile_codes(tiled, rows, row_bytes, out):
+    """the inverse of tile_codes (quip_untile_codes): `tiled` (flat uint8) -> the row-major matrix, written into `out` (any dtype,
+    rows * row_bytes bytes)"""
+    from . import capi
+    with torch.cuda.device(tiled.device):
+        capi.check(capi.lib().quip_untile_codes(tiled.data_ptr(), out.data_ptr(), rows, row_bytes,
+                                                torch.cuda.current_stream(tiled.device).cuda_stream), "quip_untile_codes")
+    return out
+
+
+def qidxs_nbytes(m):
+    """bytes of a module's code matrix (its row-major tensor, or -- LlamaDecoder(single_copy=True) -- the tiled copy that replaced it)"""
+    return m.Qidxs.numel() * m.Qidxs.element_size() if m.Qidxs is not None else m._qidxs_tiled.numel()
+
+
 class LlamaDecoder:
-    """Random-init Llama with QuantLinear projections, static KV cache, bs=1."""
+    """Random-init Llama with QuantLinear projections, static KV cache, bs=1.
+
+    single_copy (or QUIP_SINGLE_COPY=1; the 8192-wide persistent launch only -- it streams a RE-TILED copy of the codes,
+    tile_codes()): keep ONE copy of the code matrices.  The modules' row-major `Qidxs` are dropped (set to None: every operator that
+    would read them fails loudly, and `state_dict()` no longer holds them -- a decode-only serving mode, not one to save checkpoints
+    from) once the tiled copies exist; the prompt pass and the stage-wise fallback get a matrix back in the checkpoint's layout,
+    one decoder block at a time, in scratch buffers (untile_codes: 2 x 214 MB of traffic per block at HBM speed).  Llama-2-70B
+    E8P12: 17.1 GB of codes resident instead of 34.2 GB."""
 
     def __init__(self, shape: LlamaShape = LLAMA2_7B, codebook="E8P12", max_len=256, device="cuda", seed=0,
-                 device_init=False, window=0, **cb_kwargs):
+                 device_init=False, window=0, single_copy=None, **cb_kwargs):
+        import os
+        self.single_copy = bool(int(os.environ.get("QUIP_SINGLE_COPY", "0"))) if single_copy is None else bool(single_copy)
         self.s, self.dev, self.max_len = shape, torch.device(device), max_len
         self.window = int(window) if 0 < int(window) < max_len else 0     # sliding-window attention (HF config.sliding_window)
         g = torch.Generator().manual_seed(seed)
@@ -312,7 +336,7 @@ class LlamaDecoder:
         for L in self.layers:
             for k in ("q", "k", "v", "o", "gate", "up", "down"):
                 m = L[k]
-                for t in (m.Qidxs, m.SU, m.SV, m.had_left, m.had_right):
+                for t in (m.Qidxs if m.Qidxs is not None else getattr(m, "_qidxs_tiled", None), m.SU, m.SV, m.had_left, m.had_right):
                     if t is not None:
                         sig.append((t.data_ptr(), t._version))
                 sig.append(float(m.wscale_float))
@@ -385,7 +409,17 @@ class LlamaDecoder:
             if gqa:
                 # shape 1 streams a re-tiled copy of the codes (decode_block_gqa.hip: full-line requests): one more copy of the
                 # weights in HBM, made once per model; the checkpoint's tensors stay what the stage-wise step and prefill read
-                wq = [tile_codes(m.Qidxs) for m in mods]
+                wq = []
+                for m in mods:
+                    t = getattr(m, "_qidxs_tiled", None)          # (a rebuild in single-copy mode: the tiled copy is all there is)
+                    if m.Qidxs is not None:
+                        t = tile_codes(m.Qidxs)
+                    if getattr(self, "single_copy", False):
+                        if m.Qidxs is not None:
+                            m._qidxs_meta = (tuple(m.Qidxs.shape), m.Qidxs.dtype)
+                        m._qidxs_tiled = t
+                        m.Qidxs = None
+                    wq.append(t)
                 keep += wq
             else:
                 wq = [m.Qidxs for m in mods]
@@ -458,13 +492,40 @@ class LlamaDecoder:
             if ws is not None:
                 ws.zero_()
 
+    # ---- single-copy mode: a block's matrices in the checkpoint's layout, for the operators that read it ------------------------
+    def _rm_enter(self, L):
+        """the seven modules of block L get their row-major `Qidxs` back (in scratch buffers shared by all blocks, filled by
+        untile_codes on the current stream) until _rm_exit; a no-op unless the modules hold tiled copies only"""
+        if not getattr(self, "single_copy", False):
+            return
+        scr = self.__dict__.setdefault("_rm_scratch", {})
+        for k in ("q", "k", "v", "o", "gate", "up", "down"):
+            m = L[k]
+            if m.Qidxs is None and getattr(m, "_qidxs_tiled", None) is not None:
+                shape, dtype = m._qidxs_meta
+                buf = scr.get(k)
+                if buf is None or tuple(buf.shape) != shape or buf.dtype != dtype:
+                    buf = scr[k] = torch.empty(shape, dtype=dtype, device=self.dev)
+                untile_codes(m._qidxs_tiled, shape[0], buf.numel() * buf.element_size() // shape[0], buf)
+                m.Qidxs = buf
+                m._qidxs_borrowed = True
+
+    def _rm_exit(self, L):
+        if not getattr(self, "single_copy", False):
+            return
+        for k in ("q", "k", "v", "o", "gate", "up", "down"):
+            m = L[k]
+            if getattr(m, "_qidxs_borrowed", False):
+                m.Qidxs = None
+                m._qidxs_borrowed = False
+
     # ---- model bytes the decode step has to stream (roofline denominator, SURVEY 8d) -----------
     def algorithmic_bytes_per_token(self):
         b = 0
         for L in self.layers:
             for k in ("q", "k", "v", "o", "gate", "up", "down"):
                 m = L[k]
-                b += m.Qidxs.numel() * m.Qidxs.element_size() + 2 * (m.in_features + m.out_features)
+                b += qidxs_nbytes(m) + 2 * (m.in_features + m.out_features)
         return b + self.lm_head.numel() * 2
 
     def _rope(self, x, cos, sin):
@@ -507,6 +568,7 @@ class LlamaDecoder:
         if self.fused_prologue:
             return self._step_fused(h, cos, sin, mask)
         for i, L in enumerate(self.layers):
+            self._rm_enter(L)
             # q / k / v (and gate / up below): one launch per stage for the whole group; RMSNorm rides on
             # the input-side Hadamard launch
             q, k, v = forward_group([L["q"], L["k"], L["v"]], h, rms_weight=L["ln1"], rms_eps=s.rms_eps)
@@ -515,6 +577,7 @@ class LlamaDecoder:
             h = L["o"].forward_fused(a.reshape(1, s.hidden), residual=h)
             g, u = forward_group([L["gate"], L["up"]], h, rms_weight=L["ln2"], rms_eps=s.rms_eps)
             h = L["down"].forward_fused(u, gate=g, residual=h)
+            self._rm_exit(L)
         return self._head(h)
 
     def _step_fused(self, h, cos, sin, mask):
@@ -524,6 +587,7 @@ class LlamaDecoder:
         s = self.s
         zd = prev_down = None
         for i, L in enumerate(self.layers):
+            self._rm_enter(L)
             qkv = [L["q"], L["k"], L["v"]]
             if zd is None and self.qkv_fused:
                 _, zs = gemv_fused(qkv, x=h, rms_weight=L["ln1"], rms_eps=s.rms_eps)
@@ -552,6 +616,7 @@ class LlamaDecoder:
                 g, u = out_transform_group([L["gate"], L["up"]], zgu)
                 zd = gemv_unfused(L["down"], u, gate=g)
             prev_down = L["down"]
+            self._rm_exit(L)
         (h,) = out_transform_group([prev_down], [zd], residual=[h])
         return self._head(h)
 
@@ -633,6 +698,7 @@ class LlamaDecoder:
         h = self.embed[tokens]                                          # (P, hidden)
         cos, sin = self.cos[:P], self.sin[:P]                           # (P, head_dim)
         for i, L in enumerate(self.layers):
+            self._rm_enter(L)
             q, k, v = forward_group([L["q"], L["k"], L["v"]], h, rms_weight=L["ln1"], rms_eps=s.rms_eps)
             q = self._rope(q.view(P, s.heads, s.head_dim).transpose(0, 1), cos, sin)          # (heads, P, hd)
             k = self._rope(k.view(P, s.kv_heads, s.head_dim).transpose(0, 1), cos, sin)
@@ -649,6 +715,7 @@ class LlamaDecoder:
             h = L["o"].forward_fused(a.transpose(0, 1).reshape(P, s.hidden), residual=h)
             g, u = forward_group([L["gate"], L["up"]], h, rms_weight=L["ln2"], rms_eps=s.rms_eps)
             h = L["down"].forward_fused(u, gate=g, residual=h)
+            self._rm_exit(L)
         self.pos.fill_(P)
         return F.rms_norm(h[-1:], (s.hidden,), self.final_norm, s.rms_eps) @ self.lm_head.T
 

@@ -191,7 +191,9 @@ def test_gqa_block_engine_kernel_uses_no_scratch_and_touches_no_register_in_flig
     waits = [l for l in lines if l.startswith("s_waitcnt") and "vmcnt(16)" in l]
     # EXACTLY one per item of the sequence (the block loop's body is one iteration): a product that forgets the wait / refill of
     # one of its items (round 6: a filler dropped while the products were re-ordered) shifts every later wait by one slot
-    assert len(waits) == 54, len(waits)
+    # (round 6: down's second item decoded ahead waits with vmcnt(14) -- no refill in front of it, see predec())
+    w14 = [l for l in lines if l.startswith("s_waitcnt") and "vmcnt(14)" in l]
+    assert len(waits) == 53 and len(w14) >= 1, (len(waits), len(w14))
     nt = [l for l in lines if "global_load_dwordx4" in l and " nt" in l]
     assert len(nt) >= 2 * (54 + 9) and len(nt) % 2 == 0
 

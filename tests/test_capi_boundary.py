@@ -85,6 +85,10 @@ def test_argument_validation_without_gpu(libpath):
     assert L.quip_tile_codes(p16, p16 + 512, 16, 64, None) == -5                         # partial overlap (16 x 64 = 1024 bytes each)
     assert L.quip_tile_codes(p16 + 512, p16, 16, 64, None) == -5
     assert L.quip_tile_codes(p16, p16 + 1024, 0, 64, None) == 0                          # empty: ok, no launch
+    assert L.quip_untile_codes(p16, None, 16, 64, None) == -1
+    assert L.quip_untile_codes(p16, p16 + 1024, 24, 64, None) == -2
+    assert L.quip_untile_codes(p16, p16 + 512, 16, 64, None) == -5                       # overlap
+    assert L.quip_untile_codes(p16, p16 + 1024, 0, 64, None) == 0
 
 
 def test_ops_registered_and_fail_loudly_on_cpu(libpath):

@@ -204,6 +204,54 @@ def test_norm_bound_planes_of_the_8192_wide_launch_take_spiky_activations():
     assert worst <= 2.0 * (4.0 * np.sqrt(2) + 2.0), worst
 
 
+def test_single_copy_mode_keeps_one_copy_of_the_codes_and_still_serves_prompts_and_the_fallback():
+    """LlamaDecoder(single_copy=True) drops the modules' row-major code matrices once the tiled copies the launch
+    streams exist.  Same tokens and bit-identical logits as the two-copy decoder on the launch; a batched prompt pass and the
+    stage-wise fallback step (block engine off) get their matrices back through quip_untile_codes and give the two-copy decoder's
+    results bit for bit; a module used outside those paths fails loudly (its Qidxs is None)."""
+    from quip_for_all_amd import decode as D
+    shape = D.LlamaShape(hidden=8192, ffn=28672, layers=2, heads=64, kv_heads=8, vocab=2048)
+    decs = []
+    for single in (False, True):
+        np.random.seed(4321)
+        decs.append(D.LlamaDecoder(shape, "E8P12", max_len=64, device=DEV, seed=11, device_init=True, single_copy=single))
+    two, one = decs
+    assert two.block_eng and one.block_eng and one.eng_shape == 1
+    assert all(L[k].Qidxs is None for L in one.layers for k in ("q", "k", "v", "o", "gate", "up", "down"))
+    assert all(L[k].Qidxs is not None for L in two.layers for k in ("q", "k", "v", "o", "gate", "up", "down"))
+    assert one.algorithmic_bytes_per_token() == two.algorithmic_bytes_per_token()
+    # 1. the tiled copy is the inverse image: untile(tile(Q)) == Q
+    m1, m2 = one.layers[1]["down"], two.layers[1]["down"]
+    back = torch.empty_like(m2.Qidxs)
+    D.untile_codes(m1._qidxs_tiled, m2.Qidxs.shape[0], m2.Qidxs.shape[1] * m2.Qidxs.element_size(), back)
+    assert torch.equal(back, m2.Qidxs)
+    # 2. the launch: same logits
+    for dec in decs:
+        dec.reset(first_token=7)
+    with torch.no_grad():
+        for _ in range(3):
+            la, lb = one.step().clone(), two.step().clone()
+            assert one.engine_status() == 0
+            assert torch.equal(la, lb)
+    # 3. a batched prompt pass (row-major operators on matrices materialised block by block)
+    prompt = torch.tensor([5, 9, 1, 33, 7, 2], device=DEV)
+    with torch.no_grad():
+        pa, pb = one.prefill(prompt).clone(), two.prefill(prompt).clone()
+    assert torch.equal(pa, pb)
+    assert torch.equal(one.kcache[0][:, :6], two.kcache[0][:, :6])
+    assert all(L[k].Qidxs is None for L in one.layers for k in ("q", "k", "v", "o", "gate", "up", "down"))      # (handed back)
+    # 4. the stage-wise fallback step
+    for dec in decs:
+        dec.block_eng = False
+        dec.reset(first_token=7)
+    with torch.no_grad():
+        sa, sb = one.step().clone(), two.step().clone()
+    assert torch.equal(sa, sb)
+    # 5. outside those paths a module has no codes to read: loud failure, no garbage
+    with pytest.raises(Exception):
+        one.layers[0]["q"](torch.zeros(1, 8192, dtype=torch.float16, device=DEV))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("rows,row_bytes", [(16, 64), (48, 2048), (256, 7168), (32, 192)])
 def test_tile_codes_is_the_stated_permutation(rows, row_bytes):
