@@ -69,6 +69,13 @@
 #ifndef QUIP_GQA_PRE_Q
 #define QUIP_GQA_PRE_Q 0
 #endif
+// hop 1 of the MLP edge (columns -> chunk owners): 1 = two values per 8-byte granule as 20-bit mantissas against the pair's larger
+// binary exponent (2^-19 of the larger one: far below the fp16 rounding of the modules' outputs that went into them) + a 16-bit tag;
+// 0 = one fp32 value per granule (rounds 4-5).  An owner's inbox is 64 KB at one value per granule -- ONE sweep of it is ~6K clocks at
+// the ~11 bytes per clock a CU loads (stamps 12 -> 28: 6.1K) -- and 32 KB packed.
+#ifndef QUIP_GQA_INBOX_PACK
+#define QUIP_GQA_INBOX_PACK 1
+#endif
 #ifndef QUIP_GQA_ZROWS         /* tools/dbg A/B: 0 = the MFMA's unused A rows read digit plane 2 (as rounds 1-5) instead of zeros */
 #define QUIP_GQA_ZROWS 1
 #endif
@@ -1285,8 +1292,21 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
 #pragma unroll
       for (int k = 0; k < FK; ++k) t = __builtin_fmaf(hs[k], zz[16 * k], t);
       const float tn = __shfl_down(t, 1, 64);
+#if QUIP_GQA_INBOX_PACK
+      if ((i & 1) == 0) {
+        // {m_a (20) | m_b low 12, m_b high 8 | exponent 8 | tag 16}: m = rint(value 2^(145 - e)), e = the larger biased exponent
+        const uint32_t ea = (as_u32(t) >> 23) & 0xffu, eb = (as_u32(tn) >> 23) & 0xffu;
+        const uint32_t e = max(max(ea, eb), 19u);                              // (255: an inf / NaN in the pair -- the owner reads NaN)
+        const float sc = as_f32((272u - min(e, 254u)) << 23);
+        const int ma = min(max((int)__builtin_rintf(t * sc), -524287), 524287), mb = min(max((int)__builtin_rintf(tn * sc), -524287), 524287);
+        const uint32_t w0 = ((uint32_t)ma & 0xfffffu) | ((uint32_t)mb << 20);
+        const uint32_t w1 = (((uint32_t)mb >> 12) & 0xffu) | (e << 8) | ((tag1 & 0xffffu) << 16);
+        esync::st_granule(inbox + ((size_t)(kq * 2 + mgu) * (FL / 2) + 16 * (w & 127) + 8 * cg + (i >> 1)), w0, w1);
+      }
+#else
       if ((i & 1) == 0)
         esync::st_granule2(inbox + ((size_t)(kq * 2 + mgu) * FL + 32 * (w & 127) + 16 * cg + i), as_u32(t), as_u32(tn), tag1);
+#endif
     }
     ++hop;                                             // hand-off: rows -> everybody
     tag2 = ebase | hop;
@@ -1308,6 +1328,41 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
         psd[j] = reinterpret_cast<const uint16_t*>(sud)[tid + 512 * j];
       }
       float v[2][8];
+#if QUIP_GQA_INBOX_PACK
+      {
+        // this thread's 8 values of each vector = 4 granules = two 16-byte pieces
+        u32x4_t pc[4];
+        uint32_t spins = 0;
+        const uint32_t t16 = tag1 & 0xffffu;
+        const uint64_t* src = inbox + (size_t)(w * 2) * (FL / 2) + 4 * tid;
+        for (;;) {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) esync::ld16(pc[jj], src + (jj >> 1) * (FL / 2) + 2 * (jj & 1));
+          esync::drain();
+          bool ok = true;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            esync::own(pc[jj]);
+            ok = ok && (pc[jj].y >> 16) == t16 && (pc[jj].w >> 16) == t16;
+          }
+          if (esync::spin_step(ok, spins, ctl + 1, 0x1000u + (uint32_t)w)) break;
+        }
+        own_ring();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(psg[j]), "+v"(psu_[j]), "+v"(psd[j]));
+        auto unpack2 = [](uint32_t w0, uint32_t w1, float& a_, float& b_) {
+          const uint32_t e = (w1 >> 8) & 0xffu;
+          const float sc = e == 255u ? as_f32(0x7fc00000u) : as_f32((e - 18u) << 23);      // 2^(e - 145); e >= 19 by construction
+          a_ = (float)((int)(w0 << 12) >> 12) * sc;
+          b_ = (float)((int)(((w0 >> 20) | (w1 << 12)) << 12) >> 12) * sc;
+        };
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          unpack2(pc[jj].x, pc[jj].y, v[jj >> 1][4 * (jj & 1)], v[jj >> 1][4 * (jj & 1) + 1]);
+          unpack2(pc[jj].z, pc[jj].w, v[jj >> 1][4 * (jj & 1) + 2], v[jj >> 1][4 * (jj & 1) + 3]);
+        }
+      }
+#else
       {
         u32x4_t pc[8];
         uint32_t spins = 0;
@@ -1333,6 +1388,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
           v[jj >> 2][2 * (jj & 3) + 1] = as_f32(pc[jj].z);
         }
       }
+#endif
       BSTAMP(28);
       hadw::fwd<12, 2, true>(v, xbuf, tid);
       BSTAMP(29);

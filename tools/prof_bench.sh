@@ -48,7 +48,7 @@ with open(f"{R}/gpurun_out/{tag}_bench_fetch_size.txt", "w") as f:
             j = {"counter": "FETCH_SIZE", "raw_mean_per_launch": raw, "unit_assumed": "KB", "gfx950_correction": 2.0,
                  "hbm_bytes_per_launch": raw * 1024 * 2.0, "dispatches": ecnt,
                  "kernels": "decode_block[_gqa]_kernel dispatches of the run (one per token: all blocks)",
-                 "measured_at": "round 5 (%s), tools/prof_bench.sh %s" % (tag, "$*"),
+                 "measured_at": "round 6 (%s), tools/prof_bench.sh %s" % (tag, "$*"),
                  "source": "rocprofv3 --pmc FETCH_SIZE pass of bench.py, tools/prof_bench.sh"}
             print("# ENGINE:", json.dumps(j), file=f)
             json.dump(j, open(f"{R}/gpurun_out/{tag}_engine_hbm_traffic.json", "w"))
@@ -59,7 +59,7 @@ with open(f"{R}/gpurun_out/{tag}_bench_fetch_size.txt", "w") as f:
             j = {"counter": "FETCH_SIZE", "raw_mean_per_launch": raw, "unit_assumed": "KB", "gfx950_correction": 2.0,
                  "hbm_bytes_per_launch": raw * 1024 * 2.0, "gemv_dispatches": gcnt,
                  "kernels": "e8p_gemv_mfma_kernel + e8p_gemv_v2_kernel dispatches of the run",
-                 "measured_at": "round 5 (%s), tools/prof_bench.sh %s" % (tag, "$*"),
+                 "measured_at": "round 6 (%s), tools/prof_bench.sh %s" % (tag, "$*"),
                  "source": "rocprofv3 --pmc FETCH_SIZE pass of bench.py, tools/prof_bench.sh"}
             print("# GEMV:", json.dumps(j), file=f)
             json.dump(j, open(f"{R}/gpurun_out/{tag}_gemv_hbm_traffic.json", "w"))
