@@ -76,6 +76,14 @@
 #ifndef QUIP_GQA_INBOX_PACK
 #define QUIP_GQA_INBOX_PACK 1
 #endif
+// o_proj's input transform split over its producers (1; 0 = rounds 4-6a: every workgroup transforms all 8192 points of a (.) SU).
+// H_8192 = H_64 (x) H_128 with the head index on top: a head's workgroup multiplies its 128 attention outputs by SU_o and runs their
+// 128-point transform in ONE wave before it publishes them (two fp32 per granule, esync::pack20x2: the same 64 granules per head);
+// everybody then gathers four heads x four columns per thread and finishes with H_64 ACROSS heads -- two register stages and four
+// lane stages, no LDS exchange, no barrier inside -- and writes a dword of digits per head and plane.  in(o): 5.8K -> ... clocks.
+#ifndef QUIP_GQA_OHEAD
+#define QUIP_GQA_OHEAD 1
+#endif
 #ifndef QUIP_GQA_ZROWS         /* tools/dbg A/B: 0 = the MFMA's unused A rows read digit plane 2 (as rounds 1-5) instead of zeros */
 #define QUIP_GQA_ZROWS 1
 #endif
@@ -932,6 +940,10 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
       // SV of this head's q values (wave 2 finishes them below): requested in front of the hand-off's wait, not at its use
       uint32_t svq_raw = 0u;
       if (wave == 2) svq_raw = *reinterpret_cast<const uint32_t*>(Ld.sv[0] + HD * hd + 2 * lane);
+#if QUIP_GQA_OHEAD
+      uint32_t suo_raw = 0u;                           // SU_o of this head's 128 attention outputs (natural order)
+      if (wave == 0) suo_raw = *reinterpret_cast<const uint32_t*>(Ld.su[3] + HD * hd + 2 * lane);
+#endif
       f16* s_qkv = reinterpret_cast<f16*>(smem + B::kQkv);
       {
         // gather z_q (everybody) and z_k / z_v (waves 0 / 1: they went out first, ahead of the q items) in one poll
@@ -1192,10 +1204,23 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
         s_a[tid] = pos_ok ? (f16)(pO / pL) : __builtin_bit_cast(f16, (unsigned short)0x7e00);
       }
       had::wg_barrier<true>();
+#if QUIP_GQA_OHEAD
+      if (head_wg && tid < 64) {
+        // x = a (.) SU_o, its 128-point transform inside this wave (lane l: elements 2 l, 2 l + 1 before and after), two per granule
+        const f16x2 av = as_f16x2(*reinterpret_cast<const uint32_t*>(s_a + 2 * tid)), su2 = as_f16x2(suo_raw);
+        float y[2] = {had::fmul((float)av.x, (float)su2.x), had::fmul((float)av.y, (float)su2.y)};
+        hadw::reg_stage<2, 1>(y);
+        hadw::lane_stages<2, 0, 6>(y, lane);
+        uint32_t w0, w1;
+        esync::pack20x2(y[0], y[1], ebase | (hop + 1u), w0, w1);
+        esync::st_granule(za + hd * 64 + tid, w0, w1);
+      }
+#else
       if (head_wg && tid < 64) {
         const uint32_t pr = *reinterpret_cast<const uint32_t*>(s_a + 2 * tid);
         esync::st_granule(za + hd * 64 + tid, pr, ebase | (hop + 1u));
       }
+#endif
       ++hop;                                           // hand-off: attention output
     } else {
       hop += 2;
@@ -1204,6 +1229,91 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
 
     // ================= o: input side (no norm), product, hand-off =========================================================
     rederive();
+#if QUIP_GQA_OHEAD
+    if (!so) {
+      // thread (wave, lane): columns [4 jq, +4) of heads 4 (lane >> 2) + r, r < 4 -- one 16-byte piece (two granules) per head
+      const int jq = 4 * wave + (lane & 3), hg = lane >> 2;
+      const uint32_t t16 = (ebase | hop) & 0xffffu;
+      {
+        // (the attention output is ~10 us away: the wait is spent on ONE granule per wave, the gather behind it checks every piece)
+        uint32_t sp = 0;
+        u32x2_t f;
+        const uint64_t* g1 = za + (size_t)((8 * w + wave) & (NH - 1)) * 64;
+        for (;;) {
+          esync::ld8(f, g1);
+          esync::drain();
+          esync::own(f);
+          if (esync::spin_step((f.y >> 16) == t16, sp, ctl + 1, 0x6100u + (uint32_t)w)) break;
+        }
+      }
+      u32x4_t p[4];
+      {
+        uint32_t spins = 0;
+        const uint64_t* src = za + (size_t)(4 * hg) * 64 + 2 * jq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] = u32x4_t{0u, 0u, 0u, 0u};
+        bool ok = false;
+        for (;;) {
+          if (!ok) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) esync::ld16_keep(p[r], src + 64 * r);
+          }
+          esync::drain();
+          bool now = true;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            esync::own(p[r]);
+            now = now && (p[r].y >> 16) == t16 && (p[r].w >> 16) == t16;
+          }
+          ok = now;
+          if (esync::spin_step(ok, spins, ctl + 1, 0x6000u + (uint32_t)w)) break;
+        }
+        own_ring();
+      }
+      BSTAMP(7);
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        esync::unpack20x2(p[r].x, p[r].y, v[4 * r], v[4 * r + 1]);
+        esync::unpack20x2(p[r].z, p[r].w, v[4 * r + 2], v[4 * r + 3]);
+      }
+      {
+        // the norm bound: |H_8192 x|_inf <= sqrt(8192) |x|_2, and sum y^2 = 128 sum x^2 (the heads' transforms are orthogonal x sqrt 128)
+#pragma clang fp contract(off)
+        float n0 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) n0 = __builtin_fmaf(v[r], v[r], n0);
+        n0 = had::wave_reduce_to_lane63<false>(n0);
+        if (lane == 63) red[wave] = n0;
+      }
+      hadw::reg_stages<16, 4>(v);                        // head index bits 0, 1 (registers 4 r + e)
+      hadw::lane_stages<16, 2, 6>(v, lane);              // head index bits 2 .. 5 (lane bits 2 .. 5)
+      const float sco = Ld.sc[3];
+      had::wg_barrier<true>();                         // the sums; and the heads' attention scratch in the area has been read
+      float q0 = red[0];
+#pragma unroll
+      for (int i = 1; i < 8; ++i) q0 = had::fadd(q0, red[i]);
+      const int sh = had::shift_for(sqrtf(q0 * (1.f / 128.f)) * kSqrtH * fabsf(sco) * 1.0625f);
+      {
+#pragma clang fp contract(off)
+        const float s2 = had::fmul(sco, as_f32((uint32_t)(sh + 127) << 23));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // X[head 4 hg + r][4 jq .. + 3]: natural dword 32 head + jq of a plane
+          const float vv[4] = {v[4 * r], v[4 * r + 1], v[4 * r + 2], v[4 * r + 3]};
+          uint32_t dh, dm, dl;
+          hadw::digit_words_magic(vv, s2, dh, dm, dl);
+          const int kd = 32 * (4 * hg + r) + jq;
+          const uint32_t off = NIB ? (uint32_t)((kd & 1) * B::HOH + 4 * (kd >> 1)) : (uint32_t)(4 * kd);
+          *reinterpret_cast<uint32_t*>(smem + B::kArea + off) = dh;
+          *reinterpret_cast<uint32_t*>(smem + B::kArea + B::PSH + off) = dm;
+          *reinterpret_cast<uint32_t*>(smem + B::kArea + 2 * B::PSH + off) = dl;
+        }
+      }
+      if (tid == 0) shs[2] = sh;
+      had::wg_barrier<true>();
+    }
+#else
     if (!so) {
       u32x4 psu[2];
       load16(Ld.su[3], psu);                           // natural order
@@ -1235,6 +1345,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
       if (tid == 0) shs[2] = sh;
       had::wg_barrier<true>();
     }
+#endif
     BSTAMP(8);
     rederive();
     first(IC<SQ_O>{}, true);
@@ -1295,12 +1406,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
 #if QUIP_GQA_INBOX_PACK
       if ((i & 1) == 0) {
         // {m_a (20) | m_b low 12, m_b high 8 | exponent 8 | tag 16}: m = rint(value 2^(145 - e)), e = the larger biased exponent
-        const uint32_t ea = (as_u32(t) >> 23) & 0xffu, eb = (as_u32(tn) >> 23) & 0xffu;
-        const uint32_t e = max(max(ea, eb), 19u);                              // (255: an inf / NaN in the pair -- the owner reads NaN)
-        const float sc = as_f32((272u - min(e, 254u)) << 23);
-        const int ma = min(max((int)__builtin_rintf(t * sc), -524287), 524287), mb = min(max((int)__builtin_rintf(tn * sc), -524287), 524287);
-        const uint32_t w0 = ((uint32_t)ma & 0xfffffu) | ((uint32_t)mb << 20);
-        const uint32_t w1 = (((uint32_t)mb >> 12) & 0xffu) | (e << 8) | ((tag1 & 0xffffu) << 16);
+        uint32_t w0, w1;
+        esync::pack20x2(t, tn, tag1, w0, w1);
         esync::st_granule(inbox + ((size_t)(kq * 2 + mgu) * (FL / 2) + 16 * (w & 127) + 8 * cg + (i >> 1)), w0, w1);
       }
 #else
@@ -1350,12 +1457,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
         own_ring();
 #pragma unroll
         for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(psg[j]), "+v"(psu_[j]), "+v"(psd[j]));
-        auto unpack2 = [](uint32_t w0, uint32_t w1, float& a_, float& b_) {
-          const uint32_t e = (w1 >> 8) & 0xffu;
-          const float sc = e == 255u ? as_f32(0x7fc00000u) : as_f32((e - 18u) << 23);      // 2^(e - 145); e >= 19 by construction
-          a_ = (float)((int)(w0 << 12) >> 12) * sc;
-          b_ = (float)((int)(((w0 >> 20) | (w1 << 12)) << 12) >> 12) * sc;
-        };
+        auto unpack2 = [](uint32_t w0, uint32_t w1, float& a_, float& b_) { esync::unpack20x2(w0, w1, a_, b_); };
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           unpack2(pc[jj].x, pc[jj].y, v[jj >> 1][4 * (jj & 1)], v[jj >> 1][4 * (jj & 1) + 1]);

@@ -58,6 +58,28 @@ __device__ __forceinline__ void ld4(uint32_t& dst, const void* p) {
 template <typename T>
 __device__ __forceinline__ void own(T& v) { asm volatile("" : "+v"(v)); }   // after a wait: the value is the register's
 
+// ---- two fp32 values in one granule: 20-bit mantissas against the pair's larger binary exponent, 8-bit exponent, 16-bit tag ------
+// {m_a (20) | m_b low 12, m_b high 8 | e << 8 | tag16 << 16}, m = rint(value 2^(145 - e)): 2^-19 of the larger one of the pair.
+// e = 255: an inf / NaN in the pair (both read back as NaN).  A 16-bit tag suffices where every granule of the vector is
+// rewritten in every block (a stale one carries the tag of the block before, which differs in the hand-off index).
+__device__ __forceinline__ void pack20x2(float a, float b, uint32_t tag, uint32_t& w0, uint32_t& w1) {
+  const uint32_t ea = (__builtin_bit_cast(uint32_t, a) >> 23) & 0xffu, eb = (__builtin_bit_cast(uint32_t, b) >> 23) & 0xffu;
+  uint32_t e = ea > eb ? ea : eb;
+  e = e < 19u ? 19u : e;
+  const float sc = __builtin_bit_cast(float, (272u - (e > 254u ? 254u : e)) << 23);
+  int ma = (int)__builtin_rintf(a * sc), mb = (int)__builtin_rintf(b * sc);
+  ma = ma < -524287 ? -524287 : (ma > 524287 ? 524287 : ma);
+  mb = mb < -524287 ? -524287 : (mb > 524287 ? 524287 : mb);
+  w0 = ((uint32_t)ma & 0xfffffu) | ((uint32_t)mb << 20);
+  w1 = (((uint32_t)mb >> 12) & 0xffu) | (e << 8) | ((tag & 0xffffu) << 16);
+}
+__device__ __forceinline__ void unpack20x2(uint32_t w0, uint32_t w1, float& a, float& b) {
+  const uint32_t e = (w1 >> 8) & 0xffu;
+  const float sc = e == 255u ? __builtin_bit_cast(float, 0x7fc00000u) : __builtin_bit_cast(float, (e - 18u) << 23);      // 2^(e - 145)
+  a = (float)((int)(w0 << 12) >> 12) * sc;
+  b = (float)((int)(((w0 >> 20) | (w1 << 12)) << 12) >> 12) * sc;
+}
+
 // ---- bounded spinning -----------------------------------------------------------------------
 // One step of a spin loop of a whole wave: `done` is this lane's condition.  Returns true when the
 // wave may leave (everything arrived, or the launch is already failing).  err: the launch-wide error
