@@ -74,6 +74,15 @@
 #ifndef QUIP_NIB_PREDECODE_DOWN
 #define QUIP_NIB_PREDECODE_DOWN 3
 #endif
+// o_proj's input transform split over its producers (round 6; 1 | 0 = every workgroup transforms all 4096 points of a (.) SU, rounds
+// 3-5), for the codebooks whose planes are the plain ones (E8P12, D4): H_4096 = H_32 (x) H_128 with the head index on top -- the head's
+// workgroup multiplies its 128 attention outputs by SU_o and runs their 128-point transform in ONE wave before it publishes them (two
+// fp32 per granule, esync::pack20x2: the same 64 granules per head); everybody gathers two heads x four columns per thread and finishes
+// with H_32 ACROSS heads -- one register stage and four lane stages, no LDS exchange -- and writes a dword of digits per head and
+// plane.  (decode_block_gqa.hip: QUIP_GQA_OHEAD.)
+#ifndef QUIP_OHEAD
+#define QUIP_OHEAD 1
+#endif
 #ifndef QUIP_PREDECODE_GATE
 #define QUIP_PREDECODE_GATE 2      // items of gate / up decoded inside the wait for z_o (3: spills 60 bytes)
 #endif
@@ -285,6 +294,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
   auto qblk = [](int b) { return b < 256 ? b : (b < 320 ? b - 256 : b - 320); };
   uint32_t lane_c, lane_c2, lane_c3 = 0u, xlane;
   constexpr bool NIB = T::kNib;
+  constexpr bool kOHead = QUIP_OHEAD != 0 && !RVQ;     // (the RVQ codebooks' and HI's virtual rows scatter their planes differently)
   constexpr int kPreW = NIB ? 16 : 32;                  // dwords of a decoded item that waits in registers
   constexpr int kUnsc = T::kD4 ? 1 : (NIB ? 5 : 2);     // the accumulator rows hold 2^kUnsc x sum of digit x w (table entries 4 w / 2 w; nibble mode 8 x 4 w)
   NibLane nlf = {0, 0, 0u};                             // nibble mode: this lane's factors of an item's rows (item_rows_nib)
@@ -1063,6 +1073,8 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       // wait -- read at its use it was a memory latency on the heads' critical path
       uint32_t svp_raw = 0u;
       if (wave < 3) svp_raw = *reinterpret_cast<const uint32_t*>(Ld.sv[wave] + HD * ((G8 && wave > 0) ? kvh : hd) + 2 * lane);
+      uint32_t suo_raw = 0u;                           // (kOHead: SU_o of this head's 128 attention outputs, natural order)
+      if constexpr (kOHead) { if (wave == 0) suo_raw = *reinterpret_cast<const uint32_t*>(Ld.su[3] + HD * hd + 2 * lane); }
       f16* s_qkv = reinterpret_cast<f16*>(smem + B::kQkv);
       {
         // Round 5: only this head's 128 values of H_4096 z are needed, for z = z_q, z_k, z_v.  H_4096 = H_32 (x) H_128 with the
@@ -1349,7 +1361,18 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       ASTAMP(3);
       had::wg_barrier<true>();
       ASTAMP(4);
-      if (head_wg && tid < 64) {
+      if constexpr (kOHead) {
+        if (head_wg && tid < 64) {
+          // x = a (.) SU_o, its 128-point transform inside this wave (lane l: elements 2 l, 2 l + 1 before and after), two per granule
+          const f16x2 av = as_f16x2(*reinterpret_cast<const uint32_t*>(s_a + 2 * tid)), su2 = as_f16x2(suo_raw);
+          float y[2] = {had::fmul((float)av.x, (float)su2.x), had::fmul((float)av.y, (float)su2.y)};
+          hadw::reg_stage<2, 1>(y);
+          hadw::lane_stages<2, 0, 6>(y, tid);
+          uint32_t w0, w1;
+          esync::pack20x2(y[0], y[1], ebase | (hop + 1u), w0, w1);
+          esync::st_granule(zbufs + (size_t)3 * 2048 + hd * 64 + tid, w0, w1);
+        }
+      } else if (head_wg && tid < 64) {
         const uint32_t pr = *reinterpret_cast<const uint32_t*>(s_a + 2 * tid);
         esync::st_granule(zbufs + (size_t)3 * 2048 + hd * 64 + tid, pr, ebase | (hop + 1u));
       }
@@ -1369,78 +1392,155 @@ __global__ __launch_bounds__(kThreads) void decode_block_kernel(BlockArgs a) {
       own_slots(SLOTS(M_O));
       if constexpr (NIB) decode_pre(3, Bon);
       else if constexpr (!RVQ) decode_item(3, Bo);
-      // o_proj's input side: x = H (a (.) SU_o) * sc  (no norm), every workgroup
-      u32x4 psu = *reinterpret_cast<const u32x4*>(Ld.su[3] + 8 * tid);
-      float v[1][8];
-      {
-        // the attention output is ~8 us away for the workgroups that do not compute it: they wait for it on ONE granule (of a
-        // head of their own choice per wave) instead of re-reading the whole 16 KB vector per retry next to the heads' stores
-        uint32_t sp = 0;
-        u32x2_t f;
-        const uint64_t* g1 = zbufs + (size_t)3 * 2048 + (size_t)((8 * w + wave) & (NH - 1)) * 64;
-        for (;;) {
-          esync::ld8(f, g1);
-          esync::drain();
-          esync::own(f);
-          if (esync::spin_step(f.y == (ebase | hop), sp, ctl + 1, 0x6100u + (uint32_t)w)) break;
+      if constexpr (kOHead) {
+        // o_proj's input side, the heads' half done by the heads: thread (wave, lane) takes columns [4 jq, +4) of heads
+        // 2 (lane >> 2) + r, r < 2 -- one 16-byte piece (two granules) per head -- and finishes H_32 across the head index
+        const int jq = 4 * wave + (lane & 3), hp = lane >> 2;
+        const uint32_t t16 = (ebase | hop) & 0xffffu;
+        {
+          // (the attention output is ~8 us away: the wait is spent on ONE granule per wave, the gather behind it checks every piece)
+          uint32_t sp = 0;
+          u32x2_t f;
+          const uint64_t* g1 = zbufs + (size_t)3 * 2048 + (size_t)((8 * w + wave) & (NH - 1)) * 64;
+          for (;;) {
+            esync::ld8(f, g1);
+            esync::drain();
+            esync::own(f);
+            if (esync::spin_step((f.y >> 16) == t16, sp, ctl + 1, 0x6100u + (uint32_t)w)) break;
+          }
         }
-      }
-      gather(std::integral_constant<int, 1>{}, SLOTS(RVQ ? M_O : 0u), 3, ebase | hop, 0x6000u, v);
-      // (SU_o has landed -- the gather drained the queue: taken over HERE, or the compiler's wait for it, placed at its first
-      //  use, also waits for the request just below: a memory latency on the critical path)
-      asm volatile("" : "+v"(psu));
-      // gate's row blocks (the slots of q, k, v: consumed) once the hand-off is through, one at a time between the stages
-      // of o's input side: they have o's product, a hand-off and an edge to land
-      if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 0); else if constexpr (G8) ISSUE8_GU(Ld, 0); else ISSUE(Ld, 4);
-      BSTAMP(7);
+        u32x4_t p[2];
+        {
+          uint32_t spins = 0;
+          const uint64_t* src = zbufs + (size_t)3 * 2048 + (size_t)(2 * hp) * 64 + 2 * jq;
+          // (plain loads, as gather(): registers kept across the loop's back edge are the allocator's to copy while in flight)
+          for (;;) {
+            esync::ld16(p[0], src);
+            esync::ld16(p[1], src + 64);
+            esync::drain();
+            esync::own(p[0]);
+            esync::own(p[1]);
+            const bool ok = (p[0].y >> 16) == t16 && (p[0].w >> 16) == t16 && (p[1].y >> 16) == t16 && (p[1].w >> 16) == t16;
+            if (esync::spin_step(ok, spins, ctl + 1, 0x6000u + (uint32_t)w)) break;
+          }
+        }
+        if constexpr (G8) ISSUE8_GU(Ld, 0); else ISSUE(Ld, 4);      // gate's row blocks (the slots of q, k, v: consumed)
+        BSTAMP(7);
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          esync::unpack20x2(p[r].x, p[r].y, v[4 * r], v[4 * r + 1]);
+          esync::unpack20x2(p[r].z, p[r].w, v[4 * r + 2], v[4 * r + 3]);
+        }
+        {
+          // the norm bound: |H_4096 x|_inf <= 64 |x|_2, and sum y^2 = 128 sum x^2 (the heads' transforms are orthogonal x sqrt 128)
+#pragma clang fp contract(off)
+          float n0 = 0.f;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) n0 = __builtin_fmaf(v[r], v[r], n0);
+          n0 = had::wave_reduce_to_lane63<false>(n0);
+          if (lane == 63) red[wave] = n0;
+        }
+        hadw::reg_stages<8, 4>(v);                       // head index bit 0 (registers 4 r + e)
+        hadw::lane_stages<8, 2, 6>(v, lane);             // head index bits 1 .. 4 (lane bits 2 .. 5)
+        if constexpr (G8) ISSUE8_GU(Ld, 1); else ISSUE(Ld, 5);
+        const float sco = Ld.sc[3];
+        had::wg_barrier<true>();                         // the sums; and the heads' attention scratch in the area has been read
+        const int sh = norm_shift(red_sum8(0) * (1.f / 128.f), sco);
+        if constexpr (G8) ISSUE8_GU(Ld, 2); else ISSUE(Ld, 6);
+        {
+#pragma clang fp contract(off)
+          const float s2 = had::fmul(sco, as_f32((uint32_t)(sh + 127) << 23));
+          constexpr int kPS = NIB ? B::PSH : 4096;
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            // X[head 2 hp + r][4 jq .. + 3]: natural dword 32 head + jq of a plane
+            const float vv[4] = {v[4 * r], v[4 * r + 1], v[4 * r + 2], v[4 * r + 3]};
+            uint32_t dh, dm, dl;
+            hadw::digit_words_magic(vv, s2, dh, dm, dl);
+            const int kd = 32 * (2 * hp + r) + jq;
+            const uint32_t off = NIB ? (uint32_t)((kd & 1) * B::HOH + 4 * (kd >> 1)) : (uint32_t)(4 * kd);
+            *reinterpret_cast<uint32_t*>(smem + B::kArea + off) = dh;
+            *reinterpret_cast<uint32_t*>(smem + B::kArea + kPS + off) = dm;
+            *reinterpret_cast<uint32_t*>(smem + B::kArea + 2 * kPS + off) = dl;
+          }
+        }
+        if (tid == 0) shs[3] = sh;
+        had::wg_barrier<true>();
+      } else {
+        // o_proj's input side: x = H (a (.) SU_o) * sc  (no norm), every workgroup
+        u32x4 psu = *reinterpret_cast<const u32x4*>(Ld.su[3] + 8 * tid);
+        float v[1][8];
+        {
+          // the attention output is ~8 us away for the workgroups that do not compute it: they wait for it on ONE granule (of a
+          // head of their own choice per wave) instead of re-reading the whole 16 KB vector per retry next to the heads' stores
+          uint32_t sp = 0;
+          u32x2_t f;
+          const uint64_t* g1 = zbufs + (size_t)3 * 2048 + (size_t)((8 * w + wave) & (NH - 1)) * 64;
+          for (;;) {
+            esync::ld8(f, g1);
+            esync::drain();
+            esync::own(f);
+            if (esync::spin_step(f.y == (ebase | hop), sp, ctl + 1, 0x6100u + (uint32_t)w)) break;
+          }
+        }
+        gather(std::integral_constant<int, 1>{}, SLOTS(RVQ ? M_O : 0u), 3, ebase | hop, 0x6000u, v);
+        // (SU_o has landed -- the gather drained the queue: taken over HERE, or the compiler's wait for it, placed at its first
+        //  use, also waits for the request just below: a memory latency on the critical path)
+        asm volatile("" : "+v"(psu));
+        // gate's row blocks (the slots of q, k, v: consumed) once the hand-off is through, one at a time between the stages
+        // of o's input side: they have o's product, a hand-off and an edge to land
+        if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 0); else if constexpr (G8) ISSUE8_GU(Ld, 0); else ISSUE(Ld, 4);
+        BSTAMP(7);
 #if QUIP_INO_EXACT      /* A/B (tools/dbg): rounds 3-4's o input side -- the exact maximum behind the transform */
-      had::mul8(v[0], make_uint4(psu.x, psu.y, psu.z, psu.w));
-      had8::fht4096<1, true>(v, xbuf, tid);
-      if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 1); else if constexpr (G8) ISSUE8_GU(Ld, 1); else ISSUE(Ld, 5);
-      const float sco = Ld.sc[3];
-      const float mx = had8::max4096<true>(had8::absmax8(v[0], sco), red, tid);
-      if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 2); else if constexpr (G8) ISSUE8_GU(Ld, 2); else ISSUE(Ld, 6);
-      const int sh = had::shift_for(mx * ((RVQ && !HI) ? fmaxf(1.f, fabsf(a.resid_scale)) : 1.f));
+        had::mul8(v[0], make_uint4(psu.x, psu.y, psu.z, psu.w));
+        had8::fht4096<1, true>(v, xbuf, tid);
+        if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 1); else if constexpr (G8) ISSUE8_GU(Ld, 1); else ISSUE(Ld, 5);
+        const float sco = Ld.sc[3];
+        const float mx = had8::max4096<true>(had8::absmax8(v[0], sco), red, tid);
+        if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 2); else if constexpr (G8) ISSUE8_GU(Ld, 2); else ISSUE(Ld, 6);
+        const int sh = had::shift_for(mx * ((RVQ && !HI) ? fmaxf(1.f, fabsf(a.resid_scale)) : 1.f));
 #else
-      had::mul8(v[0], make_uint4(psu.x, psu.y, psu.z, psu.w));
-      {
-        // the planes' block exponent from the norm bound (see edge()): the sum of squares of the transform's INPUT, per-wave
-        // partial sums into LDS here, read behind the transform's barriers
+        had::mul8(v[0], make_uint4(psu.x, psu.y, psu.z, psu.w));
+        {
+          // the planes' block exponent from the norm bound (see edge()): the sum of squares of the transform's INPUT, per-wave
+          // partial sums into LDS here, read behind the transform's barriers
 #pragma clang fp contract(off)
-        float n0 = 0.f;
+          float n0 = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) n0 = __builtin_fmaf(v[0][r], v[0][r], n0);
-        n0 = had::wave_reduce_to_lane63<false>(n0);
-        if ((tid & 63) == 63) red[wave] = n0;
-      }
-      had8::fht4096<1, true>(v, xbuf, tid);
-      if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 1); else if constexpr (G8) ISSUE8_GU(Ld, 1); else ISSUE(Ld, 5);
-      const float sco = Ld.sc[3];
-      had::wg_barrier<true>();                         // the transform's last reads of the exchange buffer: the planes land on it
-      const int sh = norm_shift(red_sum8(0), sco);
-      if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 2); else if constexpr (G8) ISSUE8_GU(Ld, 2); else ISSUE(Ld, 6);
-#endif
-      if constexpr (HI) had8::planes_scatter_hi(v[0], sco, sh, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
-      else if constexpr (RVQ) had8::planes_scatter_rvq(v[0], sco, a.resid_scale, sh, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
-      else if constexpr (NIB) {
-        // planes_scatter's digits (element tid + 512 k of the strided layout) at their half-plane bytes
-#pragma clang fp contract(off)
-        const float s2 = had::fmul(sco, as_f32((uint32_t)(sh + 127) << 23));
-        uint8_t* pb = reinterpret_cast<uint8_t*>(smem + B::kArea) + nib_half_of(tid) * B::HOH + nib_byte_of(tid);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int X = (int)__builtin_rintf(v[0][k] * s2);
-          const int X1 = (X + 128) >> 8;
-          const int H = (X1 + 128) >> 8;
-          uint8_t* p = pb + 256 * k;
-          p[0] = (uint8_t)H;
-          p[B::PSH] = (uint8_t)X1;
-          p[2 * B::PSH] = (uint8_t)X;
+          for (int r = 0; r < 8; ++r) n0 = __builtin_fmaf(v[0][r], v[0][r], n0);
+          n0 = had::wave_reduce_to_lane63<false>(n0);
+          if ((tid & 63) == 63) red[wave] = n0;
         }
+        had8::fht4096<1, true>(v, xbuf, tid);
+        if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 1); else if constexpr (G8) ISSUE8_GU(Ld, 1); else ISSUE(Ld, 5);
+        const float sco = Ld.sc[3];
+        had::wg_barrier<true>();                         // the transform's last reads of the exchange buffer: the planes land on it
+        const int sh = norm_shift(red_sum8(0), sco);
+        if constexpr (RVQ) ISSUE_RVQ_GATE_G(Ld, 2); else if constexpr (G8) ISSUE8_GU(Ld, 2); else ISSUE(Ld, 6);
+#endif
+        if constexpr (HI) had8::planes_scatter_hi(v[0], sco, sh, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
+        else if constexpr (RVQ) had8::planes_scatter_rvq(v[0], sco, a.resid_scale, sh, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
+        else if constexpr (NIB) {
+          // planes_scatter's digits (element tid + 512 k of the strided layout) at their half-plane bytes
+#pragma clang fp contract(off)
+          const float s2 = had::fmul(sco, as_f32((uint32_t)(sh + 127) << 23));
+          uint8_t* pb = reinterpret_cast<uint8_t*>(smem + B::kArea) + nib_half_of(tid) * B::HOH + nib_byte_of(tid);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int X = (int)__builtin_rintf(v[0][k] * s2);
+            const int X1 = (X + 128) >> 8;
+            const int H = (X1 + 128) >> 8;
+            uint8_t* p = pb + 256 * k;
+            p[0] = (uint8_t)H;
+            p[B::PSH] = (uint8_t)X1;
+            p[2 * B::PSH] = (uint8_t)X;
+          }
+        }
+        else had8::planes_scatter(v[0], sco, sh, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
+        if (tid == 0) shs[3] = sh;
+        had::wg_barrier<true>();
       }
-      else had8::planes_scatter(v[0], sco, sh, reinterpret_cast<uint8_t*>(smem + B::kArea), tid);
-      if (tid == 0) shs[3] = sh;
-      had::wg_barrier<true>();
     }
     BSTAMP(8);
     if constexpr (RVQ) {

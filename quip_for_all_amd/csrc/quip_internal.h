@@ -56,6 +56,9 @@ bool e8p_gemv_v2_supported(int n, int k);
 size_t e8p_gemv_v2_workspace_words(int n);
 int e8p_gemv_v2_group_launch(const void* const* planes, const void* const* qidxs, const void* grid, void* const* ys,
                              void* ws, const int* ns, int count, int k, const GemvTune& tune, hipStream_t stream);
+// the same kernel in nibble mode (e8p_gemv_v2n.hip; tune.rep == 4): 4-byte table entries, 64 KB of tables whatever K is
+int e8p_gemv_v2n_group_launch(const void* const* planes, const void* const* qidxs, const void* grid, void* const* ys,
+                              void* ws, const int* ns, int count, int k, const GemvTune& tune, hipStream_t stream);
 int e8p_gemv_v2_launch(const void* planes, const void* qidxs, const void* grid, void* y, void* ws, int n, int k,
                        const GemvTune& tune, hipStream_t stream);
 int shape_probe_launch(const void* qidxs, void* out, int n, int k, const GemvTune& tune, hipStream_t stream);

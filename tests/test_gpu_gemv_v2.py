@@ -34,7 +34,9 @@ def _setup(Q, n, k, seed):
 
 # (rep, slots, blocks, ksplit, max_waves, runlen); 0 = automatic
 VARIANTS = [(0, 0, 0, 0, 0, 0), (32, 1, 0, 0, 0, 1), (24, 2, 0, 0, 12, 0), (16, 3, 0, 0, 0, 1), (32, 2, 0, 2, 0, 2),
-            (32, 4, 64, 3, 0, 0), (16, 2, 300, 0, 8, 3)]
+            (32, 4, 64, 3, 0, 0), (16, 2, 300, 0, 8, 3),
+            # rep 4: nibble mode (csrc/e8p_gemv_v2n.hip: row octets, 512-k segments, two accumulators + the K range's constant part)
+            (4, 0, 0, 0, 0, 0), (4, 3, 0, 2, 12, 1), (4, 4, 100, 3, 0, 2), (4, 8, 0, 0, 0, 0), (4, 6, 300, 0, 8, 3)]
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -72,7 +74,7 @@ def test_v2_against_oracle_and_first_kernel(Q, variant, n, k):
 # words: the arrival counters sit behind ALL accumulators (round 2 put them behind the first problem's)
 @pytest.mark.parametrize("ns,k", [((512, 64, 64), 8192), ((1000, 1000), 4096), ((300, 8, 1024), 2048), ((96, 96), 28672),
                                   ((16, 20000), 8192), ((8, 8, 12000), 4096)])
-@pytest.mark.parametrize("variant", [(0, 0, 0, 0, 0, 0), (16, 2, 0, 0, 0, 0), (32, 2, 0, 2, 0, 0)])
+@pytest.mark.parametrize("variant", [(0, 0, 0, 0, 0, 0), (16, 2, 0, 0, 0, 0), (32, 2, 0, 2, 0, 0), (4, 0, 0, 0, 0, 0), (4, 3, 0, 2, 0, 0)])
 def test_v2_group_equals_single_launches(Q, ns, k, variant):
     from quip_for_all_amd import capi
     L = capi.lib()
