@@ -647,18 +647,17 @@ size_t e8p_gemv_v2_workspace_words(int n) { return (size_t)n * 4 + (size_t)((n +
 int e8p_gemv_v2_group_launch(const void* const* planes, const void* const* qidxs, const void* grid, void* const* ys,
                              void* ws, const int* ns, int count, int k, const GemvTune& tune, hipStream_t stream) {
   if (count < 1 || count > kMaxG) return QUIP_ERR_UNSUPPORTED;
-  // nibble mode (e8p_gemv_v2n.hip): asked for, or -- automatic choice -- from 32 MB of codes (measured on 58.7 MB: 28672 x 8192
-  // -5 %, 8192 x 28672 -10 %, where the byte tables fit with 16 copies only; 8192 x 8192 and smaller: no gain); QUIP_GEMV_NIB=0
-  // keeps the byte tables
+  // nibble mode (e8p_gemv_v2n.hip): asked for, or -- automatic choice -- for rows whose digit image leaves the byte tables 16
+  // copies only (k > 10240: two-way conflicts on every look-up; the nibble tables are 64 KB and conflict free whatever k is:
+  // 8192 x 28672 -5..9 % on two boxes, level on a third; at k = 8192 both are conflict free and the two kernels trade places from
+  // box to box: profiles/r06_gemv_v2_nibble.txt); QUIP_GEMV_NIB=0 keeps the byte tables
   {
     static int nib_mode = -1;
     if (nib_mode < 0) {
       const char* e = getenv("QUIP_GEMV_NIB");
       nib_mode = e ? atoi(e) : 1;
     }
-    size_t bytes = 0;
-    for (int i = 0; i < count; ++i) bytes += (size_t)ns[i] * (size_t)k / 4;
-    if (tune.rep == 4 || (tune.rep == 0 && !tune.waves_g && nib_mode != 0 && bytes >= ((size_t)32 << 20))) {
+    if (tune.rep == 4 || (tune.rep == 0 && !tune.waves_g && nib_mode != 0 && k > 10240)) {
       GemvTune t = tune;
       t.rep = 4;
       const int rc = e8p_gemv_v2n_group_launch(planes, qidxs, grid, ys, ws, ns, count, k, t, stream);

@@ -64,6 +64,8 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2n_kernel(V2nArgs a) {
   const int seg0 = ks * a.spw;
   const int S = min(a.segs, seg0 + a.spw) - seg0;     // segments of this workgroup
   const int rpr = (S + a.runlen - 1) / a.runlen;      // runs per row octet
+  // (measured and dropped: the last quarter of every octet as runs a quarter as long, handed out after the long ones -- the
+  //  shorter tail did not pay for the extra flushes: 15.9 against 15.3 us at 28672 x 8192, profiles/r06_gemv_v2_nibble.txt)
   const int row_u4 = a.K >> 6;                        // uint4 per packed row
   int row0[G], rows_here[G], qbase[G + 1], rbase[G];  // first row, rows, first row octet / accumulator row of a problem
   qbase[0] = 0;
@@ -88,13 +90,19 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2n_kernel(V2nArgs a) {
   for (int p = 0; p < G; ++p)
     asm volatile("global_load_dword %0, %1, off" : "=v"(sh[p]) : "v"(a.planes[p] + (size_t)3 * a.kp_src) : "memory");
   u32x2 tsrc;
-  const int te = (wave & 7) * 32 + (lane & 31);       // table row of this lane (waves 0..7 build the tables)
+  // table rows: 16 waves build 16 rows each (lane = 16 g + l: row 16 w + l; g & 1: the sign table; g >> 1: which 16 of the 32
+  // copies), fewer waves 32 rows each in waves 0..7 (lanes 0..31 / 32..63: T1n / T2n, all 32 copies)
+  const bool tw16 = nwaves >= 16;
+  const int te = tw16 ? wave * 16 + (lane & 15) : (wave & 7) * 32 + (lane & 31);
+  const bool tsecond = tw16 ? ((lane >> 4) & 1) != 0 : (lane & 32) != 0;
   {
     const uint2* t1 = reinterpret_cast<const uint2*>(a.grid) + te;
     const uint2* t2 = reinterpret_cast<const uint2*>(&kT2nImg.v[te & ~1]);
-    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(tsrc) : "v"((lane & 32) ? t2 : t1) : "memory");
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(tsrc) : "v"(tsecond ? t2 : t1) : "memory");
   }
-  const uint4* hot = reinterpret_cast<const uint4*>(a.planes[0]) + (tid & 127);   // L2-resident filler for past-the-end slots
+  // filler for the slots that have nothing to fetch (the load counts are compile-time constants): ONE 16-byte address for the
+  // whole wave -- a filler with 64 addresses costs the vector L1 what a real request costs
+  const uint4* hot = reinterpret_cast<const uint4*>(a.planes[0]);
   // digit images, requested BEFORE the weights (e8p_gemv_v2.hip): 16-byte piece i = (problem p, plane d, k16 index g) in
   // source order; every workgroup starts at a different piece so that they do not all queue on the same L2 channels
   constexpr int XR = 6;
@@ -218,15 +226,21 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2n_kernel(V2nArgs a) {
   // (1) accumulators + correction words + run counter, tables
   for (int i = tid; i <= accwords + 4 * G; i += nthreads) accs[i] = 0;
   asm volatile("s_waitcnt vmcnt(%1)" : "+v"(tsrc) : "n"(XR + SLOTS) : "memory");
-  if (wave < 8) {
-    // rows [32 w, +32): lanes 0..31 hold grid_packed_abs[row], lanes 32..63 the sign image's pair of entries; every lane writes
-    // its entry 32 times, copy (l + c) & 31 at step c (32 distinct banks per half wave and step)
-    const bool second = (lane & 32) != 0;
-    const uint32_t val = second ? ((te & 1) ? tsrc.y : tsrc.x) : t1n_entry(make_uint2(tsrc.x, tsrc.y));
-    const uint32_t rowbase = (uint32_t)te * 256u + (second ? 128u : 0u);
+  {
+    // every lane writes its entry 16 / 32 times, copy (l + c) & 31 at step c: the lanes of a step are on distinct banks (rows
+    // are 256 bytes apart -- the same banks --, T1n on banks 0..31, T2n on 32..63, the copy index picks the bank)
+    const uint32_t val = tsecond ? ((te & 1) ? tsrc.y : tsrc.x) : t1n_entry(make_uint2(tsrc.x, tsrc.y));
+    const uint32_t rowbase = (uint32_t)te * 256u + (tsecond ? 128u : 0u);
+    if (tw16) {
+      const uint32_t c0 = (uint32_t)(lane & 15) + (uint32_t)((lane >> 5) << 4);
 #pragma unroll
-    for (int c = 0; c < 32; ++c)
-      *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>((uintptr_t)(rowbase + (((uint32_t)(lane + c)) & 31u) * 4u)) = val;
+      for (int c = 0; c < 16; ++c)
+        *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>((uintptr_t)(rowbase + ((c0 + (uint32_t)c) & 31u) * 4u)) = val;
+    } else if (wave < 8) {
+#pragma unroll
+      for (int c = 0; c < 32; ++c)
+        *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>((uintptr_t)(rowbase + (((uint32_t)(lane + c)) & 31u) * 4u)) = val;
+    }
   }
 #pragma unroll
   for (int p = 0; p < G; ++p) asm volatile("" : "+v"(sh[p]));   // landed before tsrc

@@ -1,10 +1,10 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r18
-bash tools/prof_bench.sh r06 --no-extras --no-prefill > gpurun_out/r18/prof_bench_7b.log 2>&1; tail -3 gpurun_out/r18/prof_bench_7b.log | cut -c1-300
-bash tools/prof_bench.sh r06_70b --model 70b --no-extras --no-prefill > gpurun_out/r18/prof_bench_70b.log 2>&1; tail -3 gpurun_out/r18/prof_bench_70b.log | cut -c1-300
-bash tools/prof_kernel.sh r06_engine decode_block_kernel python $PWD/tools/block_stamps.py 32 16 100 > gpurun_out/r06_engine_pmc.txt 2>&1
-bash tools/prof_kernel.sh r06_gqa_engine decode_block_gqa python $PWD/tools/gqa_stamps.py 80 40 40 > gpurun_out/r06_gqa_engine_pmc.txt 2>&1
-grep -v "^W2026" gpurun_out/r06_gqa_engine_pmc.txt | grep "SQ_WAIT_ANY\|SQ_WAVE_CYCLES\|LDS_BANK\|LDS_IDX\|FETCH\|avg" | head -12
-python tools/gqa_stamps.py 16 8 40 > gpurun_out/r06_gqa_block_stamps.txt 2>&1
-ls gpurun_out | grep r06
+timeout 600 python tools/gemv_v2_bench.py --shapes odd,7b,70b --check-only --variants "4,0,0,0,0,0;4,2,0,2,0,0;4,4,100,3,0,1;4,3,0,0,12,8;516,0,0,0,0,0" 2>&1 | grep -c "bit-identical"
+timeout 600 python tools/gemv_v2_bench.py --shapes odd,7b,70b --check-only --variants "4,0,0,0,0,0;4,2,0,2,0,0;4,4,100,3,0,1;4,3,0,0,12,8;516,0,0,0,0,0" 2>&1 | grep -c "MISMATCH\|rc \|NOT-ZERO"
+V="1796,0,0,0,0,0;4,0,0,0,0,0;260,0,0,0,0,0;516,0,0,0,0,0;1028,0,0,0,0,0;1796,0,0,0,0,0;4,0,0,0,0,0;260,0,0,0,0,0;516,0,0,0,0,0;1028,0,0,0,0,0;32,0,0,0,0,0"
+for i in 1 2; do
+timeout 600 python tools/gemv_v2_bench.py --shapes 70b --variants "$V" 2>&1 | grep -v "amdgpu.ids" 
+done | tee gpurun_out/r18/ab.txt | grep -v "N=  1024" 
+timeout 600 python tools/gemv_v2_bench.py --shapes 70b --variants "1796,0,0,0,0,0;4,0,0,0,0,0" --phases 2>&1 | grep -v "amdgpu.ids" | tee gpurun_out/r18/phases.txt
