@@ -639,18 +639,22 @@ def hf_static_cache_extra(D, device, new_tokens=128, cache_len=2048):
         """teacher forced on the eager stock path's tokens: `ref` (an HFStaticDecoder on the stock forward,
         prefilled) and path `step_a(token) -> logits (1, vocab)` see the same token at every step; max |difference| in fp16
         ulps of rms(logits of the stock path), and how many arg-maxima agree"""
-        worst, same = 0.0, 0
+        worst, same, gap = 0.0, 0, 0.0
         with torch.no_grad():
             for _ in range(steps):
                 lb = ref._forward(ref.tok, ref.pos)[:, -1].float()
                 la = step_a(ref.tok).float().reshape(1, -1)
-                worst = max(worst, _ulps_of_rms((la - lb).abs().max().item(), lb.pow(2).mean().sqrt().item()))
+                rms = lb.pow(2).mean().sqrt().item()
+                worst = max(worst, _ulps_of_rms((la - lb).abs().max().item(), rms))
                 nxt = lb.argmax(-1, keepdim=True)
                 same += int(la.argmax(-1).item() == nxt.item())
+                # where the arg-maxima differ: how far below the stock step's maximum is ITS logit of the token the other path chose
+                gap = max(gap, _ulps_of_rms(float(lb.max() - lb[0, int(la.argmax(-1).item())]), rms))
                 ref.tok.copy_(nxt)
                 ref.pos += 1
                 sync_a(nxt)
-        return {"steps": steps, "max_ulps_of_rms_logits": round(worst, 2), "argmax_equal": same}
+        return {"steps": steps, "max_ulps_of_rms_logits": round(worst, 2), "argmax_equal": same,
+                "stock_logit_of_the_other_choice_below_stock_max_ulps_of_rms": round(gap, 2)}
     if "compile" in toks:
         out["hf_compile_equals_eager"] = bool(torch.equal(toks["eager"], toks["compile"]))
         # the free-running sequences of a random-init model part ways at the first near tie (profiles/r05_near_tie_rate.txt); what the

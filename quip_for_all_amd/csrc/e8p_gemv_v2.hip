@@ -117,6 +117,7 @@ struct V2Args {
   int spw;                        // segments per workgroup (K split)
   int ksplit;
   int runlen;                     // segments per run
+  int rpr_inv;                    // (runs per quad of a full K part) << 24 | 2^20 / that + 1: run / rpr without a division
   int d4;                         // D4 table mode (also HI through its virtual layout): `grid` = the fp16 (256, 4) table; a
                                   // 16-bit "code" is two D4 code bytes -- T2[low byte] = (4w of weights 0..3, 0),
                                   // T1[high byte] = (0, 4w of weights 4..7), so T1 ^ T2 is the 8-group as for E8P12
@@ -129,7 +130,8 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
   using L = V2Lds<REP1, REP2, RVQ3>;
   using Slot = std::conditional_t<RVQ3, u32x3, u32x4>;
   constexpr int kUnit = RVQ3 ? 12 : 16;   // bytes of a lane's piece of the code stream (four dwords' worth of codes)
-#define V2_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+  const int rb = (int)blockIdx.y, ks = (int)blockIdx.x, wg = rb * a.ksplit + ks;      // grid = (K parts, row blocks)
+#define V2_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[wg * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
   V2_STAMP(0);
   const int tid = threadIdx.x;
   const int nthreads = blockDim.x;
@@ -138,7 +140,6 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
   const int nwaves = __builtin_amdgcn_readfirstlane(nthreads >> 6);
   const int n = lane & 15, q = lane >> 4;
   const int r = n & 3, h = n >> 2;
-  const int rb = (int)blockIdx.x / a.ksplit, ks = (int)blockIdx.x - rb * a.ksplit;
   const int seg0 = ks * a.spw;
   const int S = min(a.segs, seg0 + a.spw) - seg0;     // segments of this workgroup
   const int rpr = (S + a.runlen - 1) / a.runlen;      // runs per row quad
@@ -177,48 +178,40 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
                  : "=v"(tsrc3)
                  : "v"(reinterpret_cast<const uint2*>(a.grid2) + ((wave & 7) * 32 + (lane & 31)))
                  : "memory");
-  const uint4* hot = reinterpret_cast<const uint4*>(a.planes[0]) + (tid & 127);   // L2-resident filler for past-the-end slots
+  // filler for the slots that have nothing to fetch (the load counts are compile-time constants): ONE 16-byte address for the
+  // whole wave -- a filler with 64 addresses costs the vector L1 what a real request costs
+  const uint4* hot = reinterpret_cast<const uint4*>(a.planes[0]);
   // digit images, requested BEFORE the weights (loads return in issue order; with the weights first -- HBM requests a
   // few hundred instructions earlier -- every shape measured slower: the digit copy then waits for the first HBM
-  // burst): 16-byte piece i = (problem p, plane d, k16 index g) in source order; every workgroup starts at a
-  // different piece so that they do not all queue on the same L2 channels
-  constexpr int XR = 6;
-  const int gper = S * 64;                  // pieces per plane in this workgroup's K range
-  const int ppp = 3 * gper;                 // pieces per problem
-  const int xpieces = G * ppp;
+  // burst).  A thread takes k16 index g (16 digits) of ALL planes of ALL problems: one index decode for 3 G requests, the
+  // planes' bases are scalars (round 6: a decode per request -- ~40 VALU x 6 -- was 1.7K of the 2.7K clocks between the
+  // kernel's start and its first weight request).  Every workgroup starts at a different index so that they do not all
+  // queue on the same L2 channels; threads without an index re-read piece 0.
+  constexpr int NG = G == 1 ? 2 : 1;        // k16 indices per thread: K parts of up to 32768 k (one problem) / 16384 k
+  constexpr int XR = 3 * G * NG;
+  const int gper = S * 64;                  // k16 indices in this workgroup's K range
   const int src_pieces = a.kp_src >> 4;     // pieces per plane in the source
-  const int rot = (int)(((uint32_t)blockIdx.x * 5u) & 31u) * (xpieces >> 5);   // xpieces is a multiple of 192
+  const int rot = (int)(((uint32_t)wg * 5u) & 31u) * (gper >> 5);
   u32x4 xr[XR];
-  uint32_t xdst[XR];                        // LDS destination; 0xffffffff: none; bit 31: store zeros
+  uint32_t xdst[NG];                        // LDS destination (problem 0, plane 0); 0xffffffff: none; bit 31: store zeros
 #pragma unroll
-  for (int j = 0; j < XR; ++j) {
-    if (j * nthreads >= xpieces) {   // workgroup uniform: nothing left to fetch, keep the load count
-      asm_load16(xr[j], hot);
-      xdst[j] = 0xffffffffu;
-      continue;
-    }
+  for (int j = 0; j < NG; ++j) {
     const int i = tid + j * nthreads;
-    int ic = i + rot;
-    ic = ic >= xpieces ? ic - xpieces : ic;
-    ic = i < xpieces ? ic : 0;
-    int p = 0;
-#pragma unroll
-    for (int g2 = 1; g2 < G; ++g2) p += ic >= g2 * ppp ? 1 : 0;
-    const int jj = ic - p * ppp;
-    const int d = (jj >= gper ? 1 : 0) + (jj >= 2 * gper ? 1 : 0);
-    const int g = jj - d * gper;
-    const int s = g >> 6, c = (g >> 2) & 15, t = g & 3;
+    int g = i + rot;
+    g = g >= gper ? g - gper : g;
+    g = i < gper ? g : 0;
+    const int sgi = g >> 6, c = (g >> 2) & 15, t = g & 3;
     const int sp = seg0 * 64 + g;
     const bool real = sp < src_pieces;      // beyond the source's zero padding: zeros
-    const uint8_t* src = a.planes[0];
+    const uint32_t voff = (uint32_t)(real ? sp : 0) << 4;
 #pragma unroll
-    for (int g2 = 1; g2 < G; ++g2) {
-      src = p == g2 ? a.planes[g2] : src;
-      asm volatile("" : "+v"(src));
+    for (int p = 0; p < G; ++p) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(xr[(j * G + p) * 3 + d]) : "v"(voff), "s"(a.planes[p] + (size_t)d * a.kp_src) : "memory");
     }
-    asm_load16(xr[j], reinterpret_cast<const uint4*>(src + (size_t)d * a.kp_src) + (real ? sp : 0));
-    const uint32_t dst = xbase + (uint32_t)(p * S + s) * kSegBytes + (uint32_t)((((c & 3) * 4 + t) * 12 + 3 * (c >> 2) + d) * 16);
-    xdst[j] = i < xpieces ? (dst | (real ? 0u : 0x80000000u)) : 0xffffffffu;
+    const uint32_t dst = xbase + (uint32_t)sgi * kSegBytes + (uint32_t)((((c & 3) * 4 + t) * 12 + 3 * (c >> 2)) * 16);
+    xdst[j] = i < gper ? (dst | (real ? 0u : 0x80000000u)) : 0xffffffffu;
   }
 
 
@@ -254,7 +247,8 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
     l_run = run;
     const bool ok = run < nruns;
     const int rc = ok ? run : 0;
-    l_gq = __builtin_amdgcn_readfirstlane(rc / rpr);   // (the division runs on the VALU; the quotient is wave uniform)
+    // rc / rpr by the host's reciprocal (rc rpr < 2^20: exact); a short last K part has its own rpr -- the plain division there
+    l_gq = rpr == a.rpr_inv >> 24 ? (int)(((uint32_t)rc * (uint32_t)(a.rpr_inv & 0xffffff)) >> 20) : __builtin_amdgcn_readfirstlane(rc / rpr);
     const int ri = rc - l_gq * rpr;
     l_seg = ri * a.runlen;
     l_left = ok ? min(a.runlen, S - l_seg) : 0;
@@ -355,15 +349,22 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
 
   // (2) digit images into LDS in fragment order: unit ((q * 4 + t) * 12 + 3 h + d) of segment s holds plane d,
   //     k = 1024 s + 64 (4 h + q) + 16 t .. +15
-  asm volatile("s_waitcnt vmcnt(%6)"
-               : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5])
-               : "n"(SLOTS)
-               : "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(SLOTS) : "memory");
 #pragma unroll
-  for (int j = 0; j < XR; ++j) {
+  for (int j = 0; j < XR; ++j) asm volatile("" : "+v"(xr[j]));
+#pragma unroll
+  for (int j = 0; j < NG; ++j) {
     if (xdst[j] != 0xffffffffu) {
-      const u32x4 v = (xdst[j] & 0x80000000u) ? u32x4{0u, 0u, 0u, 0u} : xr[j];
-      *reinterpret_cast<__attribute__((address_space(3))) u32x4*>((uintptr_t)(xdst[j] & 0x7fffffffu)) = v;
+      const bool z = (xdst[j] & 0x80000000u) != 0;
+      const uint32_t at0 = xdst[j] & 0x7fffffffu;
+#pragma unroll
+      for (int p = 0; p < G; ++p) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const u32x4 v = z ? u32x4{0u, 0u, 0u, 0u} : xr[(j * G + p) * 3 + d];
+          *reinterpret_cast<__attribute__((address_space(3))) u32x4*>((uintptr_t)(at0 + (uint32_t)(p * S) * kSegBytes + 16u * d)) = v;
+        }
+      }
     }
   }
   __syncthreads();
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the trailing filler loads
   V2_STAMP(4);
   if (a.dbg && lane == 0)   // slot 7: the last wave to leave the stream
-    atomicMax(reinterpret_cast<unsigned long long*>(a.dbg + blockIdx.x * 8 + 7), (unsigned long long)__builtin_amdgcn_s_memtime());
+    atomicMax(reinterpret_cast<unsigned long long*>(a.dbg + wg * 8 + 7), (unsigned long long)__builtin_amdgcn_s_memtime());
   __syncthreads();
   V2_STAMP(5);
 
@@ -515,11 +516,11 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2_kernel(V2Args a) {
 }
 
 template <int REP1, int REP2, int SLOTS, int G, bool RVQ3 = false>
-int v2_launch(const V2Args& a, int nblocks, int threads, int lds, hipStream_t stream) {
+int v2_launch(const V2Args& a, int nrb, int threads, int lds, hipStream_t stream) {
   auto kern = e8p_gemv_v2_kernel<REP1, REP2, SLOTS, G, RVQ3>;
   static DynLdsCache configured;   // per instantiation, per device
   if (ensure_dyn_lds(configured, reinterpret_cast<const void*>(kern), lds) != QUIP_OK) return QUIP_ERR_LAUNCH;
-  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(threads), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.ksplit, nrb), dim3(threads), lds, stream, a);
   return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
 }
 
@@ -560,7 +561,7 @@ int v2_group_launch(const void* const* planes, const void* const* qidxs, const v
     }
     const int spw_c = (segs + ks - 1) / ks;
     const int room = (V2Lds<16, 16>::kTotal - lds_x(rp) - rows * 16 - 16) / kSegBytes;
-    if (G * spw_c > room || G * 3 * spw_c * 64 > 6 * 1024) return false;
+    if (G * spw_c > room || spw_c * 64 > (G == 1 ? 2 : 1) * 1024) return false;      // (1 or 2 k16 indices per thread)
     const int cost = quads * spw_c;
     if (!ksplit || cost < best) {
       ksplit = ks; nrb = need; spw = spw_c; best = cost; rep = rp;
@@ -615,7 +616,7 @@ int v2_group_launch(const void* const* planes, const void* const* qidxs, const v
   int waves = tune.max_waves > 0 ? tune.max_waves : (quads * spw >= 128 ? 16 : 12);
   if (waves < 8) waves = 8;     // the table build uses waves 0..7
   if (waves > 16) waves = 16;
-  while (waves < 16 && G * 3 * spw * 64 > 6 * waves * 64) ++waves;   // 6 digit pieces per thread
+  while (waves < 16 && spw * 64 > (G == 1 ? 2 : 1) * waves * 64) ++waves;   // k16 indices per thread
   // run length: the longest (fewest LDS flushes, longest contiguous reads) that still leaves about three runs per wave (measured)
   int runlen = tune.digits > 0 ? tune.digits : spw;
   if (tune.digits <= 0)
@@ -623,13 +624,16 @@ int v2_group_launch(const void* const* planes, const void* const* qidxs, const v
   if (runlen > spw) runlen = spw;
   if (runlen < 1) runlen = 1;
   a.runlen = runlen;
+  {
+    const int rpr = (spw + runlen - 1) / runlen;
+    a.rpr_inv = (rpr << 24) | (((1 << 20) / rpr + 1) & 0xffffff);
+  }
   const int threads = waves * 64;
   const int lds = lds_x(rep) + G * spw * kSegBytes + rows * 16 + 16;
-  const int nblocks = nrb * ksplit;
   if constexpr (G == 1)
-    if (rep == 40) return v2_launch<32, 16, 2, 1, true>(a, nblocks, threads, lds, stream);
+    if (rep == 40) return v2_launch<32, 16, 2, 1, true>(a, nrb, threads, lds, stream);
 #define QUIP_V2(R1, R2, RR, S) \
-  if (rep == RR && slots == S) return v2_launch<R1, R2, S, G>(a, nblocks, threads, lds, stream);
+  if (rep == RR && slots == S) return v2_launch<R1, R2, S, G>(a, nrb, threads, lds, stream);
   QUIP_V2(32, 32, 32, 1) QUIP_V2(32, 32, 32, 2) QUIP_V2(32, 32, 32, 3) QUIP_V2(32, 32, 32, 4)
   QUIP_V2(32, 16, 24, 1) QUIP_V2(32, 16, 24, 2) QUIP_V2(32, 16, 24, 3) QUIP_V2(32, 16, 24, 4)
   QUIP_V2(16, 16, 16, 1) QUIP_V2(16, 16, 16, 2) QUIP_V2(16, 16, 16, 3) QUIP_V2(16, 16, 16, 4)
@@ -650,14 +654,16 @@ int e8p_gemv_v2_group_launch(const void* const* planes, const void* const* qidxs
   // nibble mode (e8p_gemv_v2n.hip): asked for, or -- automatic choice -- for rows whose digit image leaves the byte tables 16
   // copies only (k > 10240: two-way conflicts on every look-up; the nibble tables are 64 KB and conflict free whatever k is:
   // 8192 x 28672 -5..9 % on two boxes, level on a third; at k = 8192 both are conflict free and the two kernels trade places from
-  // box to box: profiles/r06_gemv_v2_nibble.txt); QUIP_GEMV_NIB=0 keeps the byte tables
+  // box to box: profiles/r06_gemv_v2_nibble.txt), and for grouped launches (q / k / v of 8192: 11.5-11.9 against 13.3 us and the
+  // first kernel's 12.4; gate / up 24.6 against 27.5-28.2; at k = 4096 the byte tables win: 8.7 against 9.4 us for 2 x 11008);
+  // QUIP_GEMV_NIB=0 keeps the byte tables
   {
     static int nib_mode = -1;
     if (nib_mode < 0) {
       const char* e = getenv("QUIP_GEMV_NIB");
       nib_mode = e ? atoi(e) : 1;
     }
-    if (tune.rep == 4 || (tune.rep == 0 && !tune.waves_g && nib_mode != 0 && k > 10240)) {
+    if (tune.rep == 4 || (tune.rep == 0 && !tune.waves_g && nib_mode != 0 && (k > 10240 || (count >= 2 && k >= 8192)))) {
       GemvTune t = tune;
       t.rep = 4;
       const int rc = e8p_gemv_v2n_group_launch(planes, qidxs, grid, ys, ws, ns, count, k, t, stream);

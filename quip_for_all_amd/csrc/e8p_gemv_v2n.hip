@@ -45,13 +45,16 @@ struct V2nArgs {
   int spw;                         // segments per workgroup (K split)
   int ksplit;
   int runlen;                      // segments per run
+  int rpr_inv;                     // 2^20 / (runs per octet of a full K part) + 1: run / rpr without a division
   uint64_t* dbg;
 };
 
+// grid = (K parts, row blocks)
 template <int SLOTS, int G>
 __global__ __launch_bounds__(1024) void e8p_gemv_v2n_kernel(V2nArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-#define V2_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+  const int rb = (int)blockIdx.y, ks = (int)blockIdx.x, wg = rb * a.ksplit + ks;
+#define V2_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[wg * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
   V2_STAMP(0);
   const int tid = threadIdx.x;
   const int nthreads = blockDim.x;
@@ -60,7 +63,6 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2n_kernel(V2nArgs a) {
   const int nwaves = __builtin_amdgcn_readfirstlane(nthreads >> 6);
   const int n = lane & 15, q = lane >> 4;
   const int r = n & 7, h = n >> 3;
-  const int rb = (int)blockIdx.x / a.ksplit, ks = (int)blockIdx.x - rb * a.ksplit;
   const int seg0 = ks * a.spw;
   const int S = min(a.segs, seg0 + a.spw) - seg0;     // segments of this workgroup
   const int rpr = (S + a.runlen - 1) / a.runlen;      // runs per row octet
@@ -103,46 +105,36 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2n_kernel(V2nArgs a) {
   // filler for the slots that have nothing to fetch (the load counts are compile-time constants): ONE 16-byte address for the
   // whole wave -- a filler with 64 addresses costs the vector L1 what a real request costs
   const uint4* hot = reinterpret_cast<const uint4*>(a.planes[0]);
-  // digit images, requested BEFORE the weights (e8p_gemv_v2.hip): 16-byte piece i = (problem p, plane d, k16 index g) in
-  // source order; every workgroup starts at a different piece so that they do not all queue on the same L2 channels
-  constexpr int XR = 6;
-  const int gper = S * 32;                  // pieces per plane in this workgroup's K range
-  const int ppp = 3 * gper;                 // pieces per problem
-  const int xpieces = G * ppp;
+  // digit images, requested BEFORE the weights (e8p_gemv_v2.hip).  A thread takes k16 index g (16 digits) of ALL planes of ALL
+  // problems: one index decode for 3 G requests, the planes' bases are scalars (round 6: a decode per request -- ~40 VALU x 6 --
+  // was 1.7K of the 2.7K clocks between the kernel's start and its first weight request).  Every workgroup starts at a
+  // different index so that they do not all queue on the same L2 channels; threads without an index re-read piece 0.
+  constexpr int NG = G == 1 ? 2 : 1;        // k16 indices per thread: K parts of up to 32768 k (one problem) / 16384 k
+  constexpr int XR = 3 * G * NG;
+  const int gper = S * 32;                  // k16 indices in this workgroup's K range
   const int src_pieces = a.kp_src >> 4;     // pieces per plane in the source
-  const int rot = (int)(((uint32_t)blockIdx.x * 5u) & 31u) * (xpieces >> 5);   // xpieces is a multiple of 96
+  const int rot = (int)(((uint32_t)wg * 5u) & 31u) * (gper >> 5);
   u32x4 xr[XR];
-  uint32_t xdst[XR];                        // LDS destination of the "hi" unit's 8 bytes; 0xffffffff: none; bit 31: store zeros
+  uint32_t xdst[NG];                        // LDS destination of the "hi" unit's 8 bytes (problem 0, plane 0); 0xffffffff: none; bit 31: zeros
 #pragma unroll
-  for (int j = 0; j < XR; ++j) {
-    if (j * nthreads >= xpieces) {   // workgroup uniform: nothing left to fetch, keep the load count
-      asm_load16(xr[j], hot);
-      xdst[j] = 0xffffffffu;
-      continue;
-    }
+  for (int j = 0; j < NG; ++j) {
     const int i = tid + j * nthreads;
-    int ic = i + rot;
-    ic = ic >= xpieces ? ic - xpieces : ic;
-    ic = i < xpieces ? ic : 0;
-    int p = 0;
-#pragma unroll
-    for (int g2 = 1; g2 < G; ++g2) p += ic >= g2 * ppp ? 1 : 0;
-    const int jj = ic - p * ppp;
-    const int d = (jj >= gper ? 1 : 0) + (jj >= 2 * gper ? 1 : 0);
-    const int g = jj - d * gper;
-    // piece g of the range: segment g >> 5; inside it chunk (g >> 2) & 7 = 4 h' + q', 32-k step t = (g >> 1) & 1, code pair g & 1
-    const int s = g >> 5, hh = (g >> 4) & 1, qq = (g >> 2) & 3, t = (g >> 1) & 1, pr = g & 1;
+    int g = i + rot;
+    g = g >= gper ? g - gper : g;
+    g = i < gper ? g : 0;
+    // index g of the range: segment g >> 5; inside it chunk (g >> 2) & 7 = 4 h' + q', 32-k step t = (g >> 1) & 1, code pair g & 1
+    const int sgi = g >> 5, hh = (g >> 4) & 1, qq = (g >> 2) & 3, t = (g >> 1) & 1, pr = g & 1;
     const int sp = seg0 * 32 + g;
     const bool real = sp < src_pieces;      // beyond the source's zero padding: zeros
-    const uint8_t* src = a.planes[0];
+    const uint32_t voff = (uint32_t)(real ? sp : 0) << 4;
 #pragma unroll
-    for (int g2 = 1; g2 < G; ++g2) {
-      src = p == g2 ? a.planes[g2] : src;
-      asm volatile("" : "+v"(src));
+    for (int p = 0; p < G; ++p) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(xr[(j * G + p) * 3 + d]) : "v"(voff), "s"(a.planes[p] + (size_t)d * a.kp_src) : "memory");
     }
-    asm_load16(xr[j], reinterpret_cast<const uint4*>(src + (size_t)d * a.kp_src) + (real ? sp : 0));
-    const uint32_t dst = xbase + (uint32_t)(p * S + s) * kSegBytesN + (uint32_t)(((qq * 2 + t) * 12 + 6 * hh + d) * 16 + 8 * pr);
-    xdst[j] = i < xpieces ? (dst | (real ? 0u : 0x80000000u)) : 0xffffffffu;
+    const uint32_t dst = xbase + (uint32_t)sgi * kSegBytesN + (uint32_t)(((qq * 2 + t) * 12 + 6 * hh) * 16 + 8 * pr);
+    xdst[j] = i < gper ? (dst | (real ? 0u : 0x80000000u)) : 0xffffffffu;
   }
 
   // run -> (problem, row octet, first segment, length); everything wave uniform
@@ -172,7 +164,8 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2n_kernel(V2nArgs a) {
     l_run = run;
     const bool ok = run < nruns;
     const int rc = ok ? run : 0;
-    l_gq = __builtin_amdgcn_readfirstlane(rc / rpr);
+    // rc / rpr by the host's reciprocal (rc rpr < 2^20: exact); a short last K part has its own rpr -- the plain division there
+    l_gq = rpr == a.rpr_inv >> 24 ? (int)(((uint32_t)rc * (uint32_t)(a.rpr_inv & 0xffffff)) >> 20) : __builtin_amdgcn_readfirstlane(rc / rpr);
     const int ri = rc - l_gq * rpr;
     l_seg = ri * a.runlen;
     l_left = ok ? min(a.runlen, S - l_seg) : 0;
@@ -248,18 +241,25 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2n_kernel(V2nArgs a) {
 
   // (2) digit images into LDS in fragment order: unit ((q * 2 + t) * 12 + 6 h + 3 lo + d) of segment s holds plane d,
   //     positions 4..7 (lo = 0) / 0..3 (lo = 1) of the four 8-groups at k = 512 s + 64 (4 h + q) + 32 t
-  asm volatile("s_waitcnt vmcnt(%6)"
-               : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5])
-               : "n"(SLOTS)
-               : "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(SLOTS) : "memory");
 #pragma unroll
-  for (int j = 0; j < XR; ++j) {
+  for (int j = 0; j < XR; ++j) asm volatile("" : "+v"(xr[j]));
+#pragma unroll
+  for (int j = 0; j < NG; ++j) {
     if (xdst[j] != 0xffffffffu) {
       const bool z = (xdst[j] & 0x80000000u) != 0;
-      const uint32_t at = xdst[j] & 0x7fffffffu;
-      const u32x2 hi = z ? u32x2{0u, 0u} : u32x2{xr[j].y, xr[j].w}, lo = z ? u32x2{0u, 0u} : u32x2{xr[j].x, xr[j].z};
-      *reinterpret_cast<__attribute__((address_space(3))) u32x2*>((uintptr_t)at) = hi;
-      *reinterpret_cast<__attribute__((address_space(3))) u32x2*>((uintptr_t)(at + 48u)) = lo;
+      const uint32_t at0 = xdst[j] & 0x7fffffffu;
+#pragma unroll
+      for (int p = 0; p < G; ++p) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const u32x4 v = xr[(j * G + p) * 3 + d];
+          const uint32_t at = at0 + (uint32_t)(p * S) * kSegBytesN + 16u * d;
+          const u32x2 hi = z ? u32x2{0u, 0u} : u32x2{v.y, v.w}, lo = z ? u32x2{0u, 0u} : u32x2{v.x, v.z};
+          *reinterpret_cast<__attribute__((address_space(3))) u32x2*>((uintptr_t)at) = hi;
+          *reinterpret_cast<__attribute__((address_space(3))) u32x2*>((uintptr_t)(at + 48u)) = lo;
+        }
+      }
     }
   }
   __syncthreads();
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2n_kernel(V2nArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the trailing filler loads
   V2_STAMP(4);
   if (a.dbg && lane == 0)   // slot 7: the last wave to leave the stream
-    atomicMax(reinterpret_cast<unsigned long long*>(a.dbg + blockIdx.x * 8 + 7), (unsigned long long)__builtin_amdgcn_s_memtime());
+    atomicMax(reinterpret_cast<unsigned long long*>(a.dbg + wg * 8 + 7), (unsigned long long)__builtin_amdgcn_s_memtime());
   __syncthreads();
   V2_STAMP(5);
 
@@ -418,11 +418,11 @@ __global__ __launch_bounds__(1024) void e8p_gemv_v2n_kernel(V2nArgs a) {
 }
 
 template <int SLOTS, int G>
-int v2n_launch(const V2nArgs& a, int nblocks, int threads, int lds, hipStream_t stream) {
+int v2n_launch(const V2nArgs& a, int nrb, int threads, int lds, hipStream_t stream) {
   auto kern = e8p_gemv_v2n_kernel<SLOTS, G>;
   static DynLdsCache configured;   // per instantiation, per device
   if (ensure_dyn_lds(configured, reinterpret_cast<const void*>(kern), lds) != QUIP_OK) return QUIP_ERR_LAUNCH;
-  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(threads), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.ksplit, nrb), dim3(threads), lds, stream, a);
   return hipGetLastError() == hipSuccess ? QUIP_OK : QUIP_ERR_LAUNCH;
 }
 
@@ -455,7 +455,7 @@ int v2n_group_launch(const void* const* planes, const void* const* qidxs, const 
     }
     const int spw_c = (segs + ks - 1) / ks;
     const int room = (160 * 1024 - kTablesN - rows * 16 - 16 * kMaxGN - 16) / kSegBytesN;
-    if (G * spw_c > room || G * 3 * spw_c * 32 > 6 * 1024) continue;
+    if (G * spw_c > room || spw_c * 32 > (G == 1 ? 2 : 1) * 1024) continue;      // (1 or 2 k16 indices per thread)
     ksplit = ks; nrb = need; spw = spw_c;
     for (int p = 0; p < G; ++p) rpb[p] = rp_c[p];
   }
@@ -483,7 +483,7 @@ int v2n_group_launch(const void* const* planes, const void* const* qidxs, const 
   int waves = tune.max_waves > 0 ? tune.max_waves : (octets * spw >= 128 ? 16 : 12);
   if (waves < 8) waves = 8;     // the table build uses waves 0..7
   if (waves > 16) waves = 16;
-  while (waves < 16 && G * 3 * spw * 32 > 6 * waves * 64) ++waves;   // 6 digit pieces per thread
+  while (waves < 16 && spw * 32 > (G == 1 ? 2 : 1) * waves * 64) ++waves;   // k16 indices per thread
   // run length: the longest that still leaves about two runs per wave (measured: 28672 x 8192 4 = 8 segments, 8192 x 28672 7-8 > 4 > 2)
   int runlen = tune.digits > 0 ? tune.digits : spw;
   if (tune.digits <= 0)
@@ -491,11 +491,14 @@ int v2n_group_launch(const void* const* planes, const void* const* qidxs, const 
   if (runlen > spw) runlen = spw;
   if (runlen < 1) runlen = 1;
   a.runlen = runlen;
+  {
+    const int rpr = (spw + runlen - 1) / runlen;
+    a.rpr_inv = (rpr << 24) | (((1 << 20) / rpr + 1) & 0xffffff);
+  }
   const int threads = waves * 64;
   const int lds = kTablesN + G * spw * kSegBytesN + rows * 16 + 16 * G + 16;
-  const int nblocks = nrb * ksplit;
-#define QUIP_V2N(S) if (slots == S) return v2n_launch<S, G>(a, nblocks, threads, lds, stream);
-  QUIP_V2N(2) QUIP_V2N(3) QUIP_V2N(4) QUIP_V2N(6) QUIP_V2N(8)
+#define QUIP_V2N(S) if (slots == S) return v2n_launch<S, G>(a, nrb, threads, lds, stream);
+  QUIP_V2N(2) QUIP_V2N(3) QUIP_V2N(4)
 #undef QUIP_V2N
   return QUIP_ERR_UNSUPPORTED;
 }

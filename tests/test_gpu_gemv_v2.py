@@ -36,7 +36,7 @@ def _setup(Q, n, k, seed):
 VARIANTS = [(0, 0, 0, 0, 0, 0), (32, 1, 0, 0, 0, 1), (24, 2, 0, 0, 12, 0), (16, 3, 0, 0, 0, 1), (32, 2, 0, 2, 0, 2),
             (32, 4, 64, 3, 0, 0), (16, 2, 300, 0, 8, 3),
             # rep 4: nibble mode (csrc/e8p_gemv_v2n.hip: row octets, 512-k segments, two accumulators + the K range's constant part)
-            (4, 0, 0, 0, 0, 0), (4, 3, 0, 2, 12, 1), (4, 4, 100, 3, 0, 2), (4, 8, 0, 0, 0, 0), (4, 6, 300, 0, 8, 3)]
+            (4, 0, 0, 0, 0, 0), (4, 3, 0, 2, 12, 1), (4, 4, 100, 3, 0, 2), (4, 4, 0, 0, 0, 0), (4, 3, 300, 0, 8, 3)]
 
 
 @pytest.mark.parametrize("variant", VARIANTS)

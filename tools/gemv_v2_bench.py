@@ -118,7 +118,12 @@ def run(n, k, variants, iters, pool_bytes, check_only=False, phases=False):
                                          flags, dbg.data_ptr(), st())
                 torch.cuda.synchronize()
             d = dbg.cpu().numpy().reshape(-1, 8)
-            d = d[d[:, 0] != 0].astype(np.int64)
+            d2 = d[2048:2048 + 4096 // 2][d[:2048, 0] != 0].astype(np.int64)
+            d = d[:2048][d[:2048, 0] != 0].astype(np.int64)
+            if d2[:, 0].any():
+                print("      kernel start -> arguments in SGPRs %d/%d, -> digit requests issued %d/%d" % (
+                    np.median(d2[:, 0] - d[:, 0]), np.percentile(d2[:, 0] - d[:, 0], 90),
+                    np.median(d2[:, 1] - d[:, 0]), np.percentile(d2[:, 1] - d[:, 0], 90)))
             ph = np.diff(d[:, :7], axis=1)
             t0 = d[:, 0].min()
             print("      " + "  ".join("%s %d/%d" % (nm, np.median(ph[:, i]), np.percentile(ph[:, i], 90))

@@ -39,7 +39,7 @@ with open(f"{R}/gpurun_out/{tag}_bench_fetch_size.txt", "w") as f:
         esum = ecnt = 0
         for name, n, s, avg in rows[:30]:
             print("%-100s %8d %16.1f %16.2f" % (name[:100], n, s, avg), file=f)
-            if "e8p_gemv_mfma_kernel" in name or "e8p_gemv_v2_kernel" in name:
+            if "e8p_gemv_mfma_kernel" in name or "e8p_gemv_v2_kernel" in name or "e8p_gemv_v2n_kernel" in name:
                 gsum += s; gcnt += n
             if "decode_block_kernel" in name or "decode_block_gqa_kernel" in name:
                 esum += s; ecnt += n
