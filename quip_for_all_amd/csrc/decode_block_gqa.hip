@@ -1628,6 +1628,9 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
           *reinterpret_cast<uint32_t*>(pl + 2 * B::PSD + off) = dl;
         }
       };
+      // (measured and dropped, round 6: chunk 0 requested in front of the maxima's barrier -- waves 1..7 waiting on one granule of a
+      //  row meanwhile -- takes 1.5K clocks off this sweep, but its 28 registers are those of down's two pre-decoded items:
+      //  187.6-187.8 against 188.4 tok/s on the same box; and a first try through the caches instead of at device scope: no change)
       poll(p0, 0);
       own_ring();
       request(p1, 1);                                  // (no request may cross a loop's back edge: the first try of chunk 1 is straight-line code)

@@ -42,7 +42,7 @@ kv = np.arange(256) % 2 == 1
 seq = [(0, 18, "top -> z_d gathered (descriptor, bases, hand-off)"), (18, 19, "out(down): fwd 8192"), (19, 20, "h update, sumsq"),
        (20, 21, "in(q [, k|v]): rev 8192"), (21, 22, "max, planes"), (22, 3, "products q, k|v + publish"),
        (3, 4, "head: z_q, z_k, z_v gathered"), (4, 5, "head: out(q) fwd 8192, out(k), out(v) in a wave"), (5, 6, "head: attention + publish a"),
-       (3, 7, "others: wait for a"), (6, 7, "heads: a gathered"), (7, 8, "in(o): fwd 8192, max, planes (bytes)"), (8, 9, "products o + publish"),
+       (3, 7, "others: wait for a"), (6, 7, "heads: a gathered"), (7, 8, "in(o): H_64 over the heads, planes    "), (8, 9, "products o + publish"),
        (9, 23, "z_o gathered"), (23, 24, "out(o): fwd 8192"), (24, 25, "h update, sumsq"), (25, 26, "in(gate | up): rev 8192    "), (26, 27, "planes (one matrix)"),
        (27, 11, "products gate, up (28 items per wave)"), (11, 12, "7 x 7 mix, hop 1 sent"), (12, 28, "owners: inbox complete"),
        (28, 29, "owners: fht 4096 x 2"), (29, 30, "owners: SV, SiLU product, SU"), (30, 31, "owners: rev 4096"), (31, 13, "owners: publish, maximum"), (12, 14, "everybody: owners' maxima known"), (14, 15, "rows swept, mixed, planes of down"),
