@@ -266,10 +266,13 @@ def gqa_stream_rate(dec, launches=12, warm=12):
             "warm_launches": warm, "engine_status": st}
 
 
-def gemv_per_shape(shapes, dev, pool_bytes=640 << 20, iters=100):
+def gemv_per_shape(shapes, dev, pool_bytes=640 << 20, iters=100, warm_ms=40.0):
     """SURVEY 8d layer micro-bench inside the bench run: the default bs=1 E8P12 GEMV entry point on every (n, k) of
     `shapes`, weights cycled through a pool larger than the 256 MB Infinity Cache, `iters` launches per graph replay,
-    HIP-event timed; frac = algorithmic bytes (codes + x + y) / time / 8 TB/s"""
+    HIP-event timed; frac = algorithmic bytes (codes + x + y) / time / 8 TB/s.  The timed replays follow `warm_ms` of untimed ones:
+    an idle device starts at ~1.5 GHz and takes tens of milliseconds of load to reach its sustained clock (the same ramp
+    gqa_stream_rate's warm launches are for: profiles/r06_gqa_stream.txt); the first replay's figure is reported beside the
+    sustained one"""
     import quip_for_all_amd as Q
     from quip_for_all_amd import capi
     L = capi.lib()
@@ -299,18 +302,26 @@ def gemv_per_shape(shapes, dev, pool_bytes=640 << 20, iters=100):
             for i in range(iters):
                 call(i)
         torch.cuda.synchronize()
-        ts = []
-        for _ in range(4):
+        def timed():
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             gr.replay()
             b.record()
             torch.cuda.synchronize()
-            ts.append(a.elapsed_time(b) * 1e3 / iters)
-        us = sorted(ts)[1]
+            return a.elapsed_time(b) * 1e3 / iters
+        cold = timed()                                  # (the first replay: the clock an idle device starts with)
+        t0 = time.perf_counter()
+        warm = 0
+        while (time.perf_counter() - t0) * 1e3 < warm_ms:
+            gr.replay()
+            warm += 1
+        torch.cuda.synchronize()
+        ts = [timed() for _ in range(5)]
+        us = sorted(ts)[2]
         algo = n * k // 4 + 2 * k + 2 * n
         out["%dx%d" % (n, k)] = {"algorithmic_bytes": algo, "us_per_launch": round(us, 2), "GBps": round(algo / us / 1e3, 1),
-                                 "frac": round(algo / us / 1e3 / HBM_PEAK_GBPS, 4)}
+                                 "frac": round(algo / us / 1e3 / HBM_PEAK_GBPS, 4), "us_min_max": [round(min(ts), 2), round(max(ts), 2)],
+                                 "us_first_replay": round(cold, 2), "warm_replays": warm}
         del pool, gr
         torch.cuda.empty_cache()
     return out

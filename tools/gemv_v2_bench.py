@@ -40,6 +40,11 @@ def time_graph(call, iters):
             for i in range(iters):
                 call(i)
     torch.cuda.synchronize()
+    import time as _t
+    t0 = _t.perf_counter()
+    while (_t.perf_counter() - t0) * 1e3 < WARM_MS:      # (an idle device starts at ~1.5 GHz: --warm-ms of load before the timed replays)
+        graph.replay()
+    torch.cuda.synchronize()
     ts = []
     for _ in range(5):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -52,6 +57,7 @@ def time_graph(call, iters):
     return float(np.median(ts[1:]))
 
 
+WARM_MS = 0.0
 PHASES = ["issue loads", "tables", "digits->LDS+bar", "stream (wave 0)", "barrier", "epilogue"]
 
 
@@ -208,7 +214,10 @@ def main():
     ap.add_argument("--phases", action="store_true")
     ap.add_argument("--check-only", action="store_true")
     ap.add_argument("--groups", action="store_true")
+    ap.add_argument("--warm-ms", type=float, default=0.0)
     a = ap.parse_args()
+    global WARM_MS
+    WARM_MS = a.warm_ms
     shapes = []
     for s in a.shapes.split(","):
         shapes += SHAPES.get(s, []) if a.groups else SHAPES[s]
