@@ -91,6 +91,44 @@ def test_gemv_v2_kernels_use_no_scratch_and_only_counted_loads():
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_gemv_v2_nibble_kernels_use_no_scratch_and_only_counted_loads():
+    """e8p_gemv_v2n.hip (round 6: the K-splitting kernel in nibble mode), all nine instantiations (2 / 3 / 4 slots x 1 / 2 / 3
+    problems): no scratch, and every load up to the last weight request is one of the counted asm loads -- G shift words, one
+    table entry pair, 3 G NG digit pieces off scalar plane bases (NG = 2 for one problem, else 1), SLOTS requests + SLOTS reloads."""
+    src = os.path.join(REPO, "quip_for_all_amd", "csrc", "e8p_gemv_v2n.hip")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", "-", src,
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, check=True)
+    name, seen, bad = None, 0, []
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and name and "e8p_gemv_v2n_kernel" in name:
+            seen += 1
+            if int(m.group(1)) != 0:
+                bad.append((name, int(m.group(1))))
+    assert seen == 9, seen
+    assert not bad, bad
+    kernels = re.findall(r"^(_ZN4quip\S*e8p_gemv_v2n_kernel\S*):[^\n]*\n(.*?)\.end_amdhsa_kernel", r.stdout, re.S | re.M)
+    assert len(kernels) == 9
+    for kname, body in kernels:
+        m = re.match(r".*e8p_gemv_v2n_kernelILi(\d+)ELi(\d+)E", kname)
+        slots, g = int(m.group(1)), int(m.group(2))
+        lines = body.splitlines()
+        last_nt = max(i for i, l in enumerate(lines) if "global_load_dwordx4" in l and " nt" in l)
+        loads = [l.strip() for l in lines[:last_nt + 1] if re.search(r"\b(global|buffer|scratch|flat)_load", l)]
+        assert sum("global_load_dword " in l for l in loads) == g, (kname, loads)
+        assert sum("global_load_dwordx2" in l for l in loads) == 1, kname
+        assert sum(" nt" in l for l in loads) == 2 * slots, kname
+        ng = 2 if g == 1 else 1
+        pieces = [l for l in loads if "global_load_dwordx4" in l and " nt" not in l]
+        assert len(pieces) == 3 * g * ng, (kname, len(pieces))
+        assert all(re.search(r", s\[\d+:\d+\]", l) for l in pieces), "digit pieces off scalar plane bases"
+        assert all(l.startswith(("global_load_dword ", "global_load_dwordx2", "global_load_dwordx4")) for l in loads)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_skinny_kernel_touches_no_register_in_flight():
     """e8p_skinny_gemm.hip counts its vector-memory queue by hand around asm loads, so the compiler does not know
     which registers are still going to be written.  A first version tied such registers to the wait ("+v"): in some
