@@ -279,19 +279,32 @@ def gemv_per_shape(shapes, dev, pool_bytes=640 << 20, iters=100, warm_ms=40.0):
     grid = Q.codebook.codebook_id["E8P12"](inference=True).to(dev).grid_packed_abs
     st = lambda: torch.cuda.current_stream().cuda_stream   # noqa: E731
     out = {}
-    for n, k in shapes:
+    import ctypes
+    for shape in shapes:
+        # (n, k): one matrix through quip_e8p_gemv_planes_ws; ((n0, n1, ..), k): the modules that read the same activation (q / k / v,
+        # gate / up) in ONE launch through quip_e8p_gemv_planes_group_ws -- what QuantLinear's grouped forward calls
+        ns, k = (shape[0], shape[1]) if isinstance(shape[0], tuple) else ((shape[0],), shape[1])
+        n = sum(ns)
+        cnt = len(ns)
         wbytes = n * k // 4
         npool = max(4, pool_bytes // wbytes + 1)
         g = torch.Generator(device=dev).manual_seed(0)
-        pool = [torch.randint(-32768, 32767, (n, k // 8), generator=g, dtype=torch.int32, device=dev).to(torch.int16)
+        pool = [[torch.randint(-32768, 32767, (m, k // 8), generator=g, dtype=torch.int32, device=dev).to(torch.int16) for m in ns]
                 for _ in range(npool)]
         x = torch.randn(1, k, device=dev).half()
         planes = torch.empty(L.quip_e8p_planes_bytes(k), dtype=torch.uint8, device=dev)
         capi.check(L.quip_e8p_x_to_planes(x.data_ptr(), planes.data_ptr(), k, st()), "planes")
-        y = torch.empty(1, n, dtype=torch.float16, device=dev)
-        ws = torch.zeros(max(L.quip_e8p_gemv_workspace_bytes(n) // 4, 1), dtype=torch.int32, device=dev)
-        call = lambda i: capi.check(L.quip_e8p_gemv_planes_ws(planes.data_ptr(), pool[i % npool].data_ptr(), grid.data_ptr(),   # noqa: E731
-                                                              y.data_ptr(), n, k, ws.data_ptr(), ws.numel() * 4, st()), "gemv")
+        ys = [torch.empty(1, m, dtype=torch.float16, device=dev) for m in ns]
+        ws = torch.zeros(max(sum(L.quip_e8p_gemv_workspace_bytes(m) for m in ns) // 4, 1), dtype=torch.int32, device=dev)
+        if cnt == 1:
+            call = lambda i: capi.check(L.quip_e8p_gemv_planes_ws(planes.data_ptr(), pool[i % npool][0].data_ptr(), grid.data_ptr(),   # noqa: E731
+                                                                  ys[0].data_ptr(), n, k, ws.data_ptr(), ws.numel() * 4, st()), "gemv")
+        else:
+            vp = ctypes.c_void_p * cnt
+            pl, yp, nsa = vp(*[planes.data_ptr()] * cnt), vp(*[y.data_ptr() for y in ys]), (ctypes.c_int32 * cnt)(*ns)
+            qps = [vp(*[q.data_ptr() for q in qs]) for qs in pool]
+            call = lambda i: capi.check(L.quip_e8p_gemv_planes_group_ws(pl, qps[i % npool], grid.data_ptr(), yp, nsa, cnt, k,   # noqa: E731
+                                                                        ws.data_ptr(), ws.numel() * 4, st()), "gemv group")
         for i in range(3):
             call(i)
         torch.cuda.synchronize()
@@ -319,10 +332,10 @@ def gemv_per_shape(shapes, dev, pool_bytes=640 << 20, iters=100, warm_ms=40.0):
         ts = [timed() for _ in range(5)]
         us = sorted(ts)[2]
         algo = n * k // 4 + 2 * k + 2 * n
-        out["%dx%d" % (n, k)] = {"algorithmic_bytes": algo, "us_per_launch": round(us, 2), "GBps": round(algo / us / 1e3, 1),
+        out[("%dx%d" % (n, k)) if cnt == 1 else ("(%s)x%d, one launch" % (" + ".join(str(m) for m in ns), k))] = {"algorithmic_bytes": algo, "us_per_launch": round(us, 2), "GBps": round(algo / us / 1e3, 1),
                                  "frac": round(algo / us / 1e3 / HBM_PEAK_GBPS, 4), "us_min_max": [round(min(ts), 2), round(max(ts), 2)],
                                  "us_first_replay": round(cold, 2), "warm_replays": warm}
-        del pool, gr
+        del pool, gr, call
         torch.cuda.empty_cache()
     return out
 
@@ -568,7 +581,7 @@ def time_decoder(D, shape, codebook, steps, warmup, device, **cb_kwargs):
         # the north star's target shapes, timed here so that the driver's run holds them (SURVEY 8d layer micro-bench)
         del dec
         torch.cuda.empty_cache()
-        out["per_shape"] = gemv_per_shape([(28672, 8192), (8192, 28672), (8192, 8192), (1024, 8192)], device)
+        out["per_shape"] = gemv_per_shape([(28672, 8192), (8192, 28672), (8192, 8192), (1024, 8192), ((28672, 28672), 8192), ((8192, 1024, 1024), 8192)], device)
         return out
     del dec
     torch.cuda.empty_cache()
