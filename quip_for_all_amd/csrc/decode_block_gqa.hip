@@ -822,7 +822,7 @@ __global__ __launch_bounds__(kThreads) void decode_block_gqa_kernel(GArgs a) {
 #undef ESTAMP
   };
   // A fragment address of this lane for K slice (wave + 8 i) of the planes at `base` (plane stride ps)
-  auto xaddr = [&](uint32_t base, int ps, int i) -> uint32_t __attribute__((always_inline)) {
+  auto xaddr = [&](uint32_t base, int ps, int i) __attribute__((always_inline)) -> uint32_t {
     if constexpr (NIB) {         // A rows 0..2: "hi" halves of the planes, rows 4..6: "lo" halves
       const uint32_t half_off = (uint32_t)(ps / 2 - 16);          // = HOH | HOD: (K + 64) / 2 - 16 = K / 2 + 16
       const uint32_t xa = base + (uint32_t)(n < 4 ? min(n, 2) * ps + (int)half_off : min(n - 4, 2) * ps) + (uint32_t)q * 32u + (uint32_t)(wave + 8 * i) * 256u;
